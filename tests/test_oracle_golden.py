@@ -1,0 +1,106 @@
+"""CPU: the oracle restatement reproduces the real reference's golden vectors
+(tests/golden/*.npz, produced by tests/golden/make_golden.py from the actual
+amoussawi/recoder code) bit-for-bit: collation, per-step loss, parameters and
+Adam state, validation loss, top-k and Recall/NDCG."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import recoder_oracle as orc
+from tests.golden_util import CONFIGS, Golden
+
+
+def make_oracle(g, state):
+  c = g.cfg
+  return orc.OracleRecoder(
+      c["kind"], state, hidden_layers=c.get("hidden_layers"),
+      activation_type=c.get("activation_type"), is_constrained=c.get("is_constrained", False),
+      noise_prob=c.get("noise_prob", 0.0), dropout_prob=c.get("dropout_prob", 0.0),
+      sparse=c.get("sparse", False), loss=c["loss"], loss_params=c["loss_params"],
+      lr=c["lr"], weight_decay=c["weight_decay"])
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_oracle_replays_reference(name):
+  g = Golden(name)
+  o = make_oracle(g, g.state("init"))
+  c = g.cfg
+  for grp in g.groups():
+    users = np.concatenate([g.step(i)["users"] for i in grp])
+    batches = orc.collate(orc.extract_rows(g.csr, users), users, c["batch_size"],
+                          c["negative_sampling"])
+    assert len(batches) == len(grp)
+    for b, i in zip(batches, grp):
+      s = g.step(i)
+      assert np.array_equal(b.indices, s["indices"])
+      assert np.array_equal(b.values, s["values"])
+      assert tuple(b.size) == s["size"]
+      if c["negative_sampling"]:
+        assert np.array_equal(b.items, s["items"])
+      for snap in (1, 2):
+        if i == snap:
+          for k, v in g.state("snap%d" % snap).items():
+            assert torch.equal(o.params[k].detach(), v), (snap, k)
+      o.set_lr(g.lr_at(i))
+      loss = o.train_step(b, None, s["noise_keep"], s["drop_keep"])
+      assert loss == g.losses[i], (i, loss, g.losses[i])
+  for k, v in g.state("final").items():
+    assert torch.equal(o.params[k].detach(), v), k
+  oad = o.adam_state()
+  gad = g.adam("final_adam")
+  assert set(oad) == set(gad)
+  for k, (step, m, v) in oad.items():
+    assert step == gad[k][0]
+    assert np.array_equal(m.numpy(), gad[k][1])
+    assert np.array_equal(v.numpy(), gad[k][2])
+
+
+@pytest.mark.parametrize("name", [n for n, c in CONFIGS.items() if c.get("evaluate")])
+def test_oracle_eval_matches_reference(name):
+  g = Golden(name)
+  o = make_oracle(g, g.state("final"))
+  users = np.arange(g.csr.shape[0])
+  recs = np.concatenate([o.recommend(g.csr[users[off:off + 50]], users[off:off + 50], 20)
+                         for off in range(0, len(users), 50)])
+  assert np.array_equal(recs, g.z["eval/topk"])
+  res = o.evaluate(g.csr, g.csr_te, 20, 50, [("recall", 20), ("recall", 5), ("ndcg", 20)])
+  assert np.isclose(res[("recall", 20)], float(g.z["eval/recall20"]), rtol=1e-12, atol=0)
+  assert np.isclose(res[("recall", 5)], float(g.z["eval/recall5"]), rtol=1e-12, atol=0)
+  assert np.isclose(res[("ndcg", 20)], float(g.z["eval/ndcg20"]), rtol=1e-12, atol=0)
+  out, _ = o.predict(g.csr[users[:8]], users[:8])
+  assert np.array_equal(out.numpy(), g.z["eval/scores8"])
+
+
+# metrics known-answers: plain numbers restated from the reference's
+# tests/test_metrics.py:12-54 (rtol 1e-9)
+@pytest.mark.parametrize("x,y,k,norm,exp", [
+  (np.arange(10), [0, 2, 5, 8, 9], 10, False, 1 / 5 * (1 + 2 / 3 + 3 / 6 + 4 / 9 + 5 / 10)),
+  (np.arange(10), [1, 4, 5, 6, 12], 10, False, 1 / 5 * (1 / 2 + 2 / 5 + 3 / 6 + 4 / 7 + 0)),
+  (np.arange(10), [0, 1, 2, 3, 4], 10, False, 1),
+  (np.arange(10), [0, 2, 5, 8, 9], 3, True, 1 / 3 * (1 + 2 / 3)),
+  (np.arange(10), [1, 4, 5, 6, 12], 3, True, 1 / 3 * (1 / 2)),
+])
+def test_oracle_ap(x, y, k, norm, exp):
+  assert np.isclose(orc.average_precision(x, y, k, norm), exp, rtol=1e-9, atol=0)
+
+
+@pytest.mark.parametrize("x,y,k,norm,exp", [
+  (np.arange(10), [0, 2, 5, 8, 9], 10, False, 1),
+  (np.arange(10), [1, 4, 5, 6, 12], 10, False, 4 / 5),
+  (np.arange(10), [0, 2, 5, 8, 9], 3, False, 2 / 5),
+  (np.arange(10), [1, 4, 5, 6, 12], 3, False, 1 / 5),
+  (np.arange(10), [0, 2, 5, 8, 9], 3, True, 2 / 3),
+  (np.arange(10), [1, 4, 5, 6, 12], 3, True, 1 / 3),
+])
+def test_oracle_recall(x, y, k, norm, exp):
+  assert np.isclose(orc.recall(x, y, k, norm), exp, rtol=1e-9, atol=0)
+
+
+@pytest.mark.parametrize("x,y,k,exp", [
+  (np.arange(10), [0, 2, 5, 8, 9], 10, 0.8296882915641869),
+  (np.arange(10), [1, 4, 5, 6, 12], 10, 0.5790560467042355),
+  (np.arange(10), [0, 2, 5, 8, 9], 3, 0.7039180890341347),
+  (np.arange(10), [1, 4, 5, 6, 12], 3, 0.2960819109658652),
+])
+def test_oracle_ndcg(x, y, k, exp):
+  assert np.isclose(orc.ndcg(x, y, k), exp, rtol=1e-9, atol=0)
