@@ -1,0 +1,221 @@
+/*
+ * recoder_hip.h -- C ABI of librecoder_hip.so (MI355X / gfx950 only).
+ *
+ * The drop-in boundary of the training hot path of amoussawi/recoder
+ * (reference v0.4.0).  The reference has no FFI of its own: every entry point
+ * below replaces a run of eager PyTorch ops at the cited reference file:line.
+ * The binding a maintainer would add on the reference side is the ctypes
+ * loader in recoder_amd/_lib.py.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; rk_last_error() gives a
+ *     thread-local message.
+ *   - every pointer is a DEVICE pointer owned by the caller (tensor.data_ptr())
+ *     unless the name ends in _host; nothing is retained past the call.
+ *   - every launch goes on the caller's hipStream_t (passed as void*); no call
+ *     synchronises the host; no call allocates.
+ *   - "dev count": sizes that only exist on the device (n_b = |sampled item
+ *     set|) are read by the kernels from rk_block_t.counts; grids are sized by
+ *     the host-known capacities and surplus workgroups exit.
+ *   - all matrices are row-major fp32; item/user embedding tables are
+ *     [rows, h] exactly as torch.nn.Embedding.weight stores them.
+ */
+#ifndef RECODER_HIP_H
+#define RECODER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* activation ids (reference nn.py:6-9 `activation(x, act)`) */
+enum { RK_ACT_NONE = 0, RK_ACT_TANH = 1, RK_ACT_SIGMOID = 2, RK_ACT_RELU = 3,
+       RK_ACT_SELU = 4, RK_ACT_ELU = 5 };
+/* loss ids (reference model.py:87-99) */
+enum { RK_LOSS_MSE = 0,      /* recoder/losses.py:43-47  (confidence weighted) */
+       RK_LOSS_BCE = 1,      /* torch BCEWithLogitsLoss, model.py:91 */
+       RK_LOSS_MNLL = 2,     /* recoder/losses.py:68-71 */
+       RK_LOSS_NONE = 3 };   /* store logits only (predict, model.py:487-511) */
+
+/*
+ * One collated sampling group: S user rows restricted to the n_b item columns
+ * that at least one of them touched (reference data.py:203-251 Batch list; all
+ * slices of a group share `items`).  Plain struct of capacities + device
+ * buffers, filled by rk_collate.
+ */
+typedef struct rk_block {
+  int32_t S_cap;      /* max rows of a group */
+  int32_t nnz_cap;    /* max stored interactions of a group */
+  int32_t n_cap;      /* max |item set| = min(n_items, nnz_cap) */
+  int32_t n_items;    /* catalogue size */
+  int32_t ldw_rc;     /* words per row of bits_rc  (>= ceil(n_cap/32)) */
+  int32_t ldw_cr;     /* words per column of bits_cr (>= ceil(S_cap/32)) */
+  int32_t n_chunks;   /* ceil(n_items / RK_SCAN_CHUNK) */
+  int32_t reserved;
+  int32_t *counts;    /* [4] dev: n_b, nnz_b, ld (= round_up(n_b,32)), S */
+  int32_t *indptr;    /* [S_cap+1] block CSR row pointers */
+  int32_t *cols;      /* [nnz_cap] relabelled column (index into items) */
+  float   *vals;      /* [nnz_cap] interaction values */
+  float   *svals;     /* [nnz_cap] normalised * input-dropout-scaled values */
+  int32_t *items;     /* [n_cap] sorted unique item ids (Batch.items) */
+  int32_t *pos;       /* [n_items] item id -> compact column, -1 if absent */
+  int32_t *mark;      /* [n_items] generation stamps */
+  uint32_t *bits_rc;  /* [S_cap][ldw_rc] bit (r,c) set iff (r,c) stored */
+  uint32_t *bits_cr;  /* [n_cap][ldw_cr] transposed bitmap */
+  int32_t *scan_tmp;  /* [n_chunks+1] */
+} rk_block_t;
+
+#define RK_SCAN_CHUNK 2048
+
+int rk_version(void);
+const char *rk_last_error(void);
+/* bytes of split-K workspace rk_decode_bwd_dz needs for (B, h) */
+int64_t rk_dz_workspace_bytes(int32_t B, int32_t h);
+
+/*
+ * rk_collate -- replaces RecommendationDataset.__getitem__/_extract
+ * (data.py:50-83) + BatchCollator.collate (data.py:203-251): row-gather of
+ * `users` from the device-resident CSR, sorted-unique item set
+ * (np.unique(return_inverse)) and relabelled columns.  With
+ * negative_sampling == 0 the item set is the whole catalogue (data.py:224-226).
+ * stamp must differ between consecutive calls on the same blk->mark.
+ * phase: 0 = everything; 1 = row pointers + item marking only; 2 = the rest.
+ * Data-parallel training calls phase 1, all-reduces blk->mark with MAX over
+ * the ranks (RCCL) so that every rank derives the same union item set, then
+ * phase 2.
+ */
+int rk_collate(const int64_t *ds_indptr, const int32_t *ds_indices,
+               const float *ds_data /* NULL => all 1.0 */,
+               const int64_t *users, int32_t S, int32_t negative_sampling,
+               int32_t stamp, int32_t phase, const rk_block_t *blk,
+               void *stream);
+
+/*
+ * rk_ae_encode_fwd -- DynamicAutoencoder.forward first layer (nn.py:235-240):
+ * F.normalize(p=2,dim=1) -> input dropout -> LinearEmbedding(input_based)
+ * (nn.py:269-278) -> activation, as one CSR x embedding SpMM over rows
+ * [row_off, row_off+B) of the block.
+ *   keep : per-nnz uint8 keep flags for the whole block (NULL: drawn from the
+ *          counter RNG (seed, rng_step) when p > 0; all kept when p == 0)
+ *   Z0   : [B, h] activated output
+ */
+int rk_ae_encode_fwd(const rk_block_t *blk, int32_t row_off, int32_t B,
+                     const float *W_en, const float *b_en, int32_t h,
+                     const uint8_t *keep, float p, uint64_t seed,
+                     uint64_t rng_step, const int64_t *users, int32_t act,
+                     float *Z0, void *stream);
+
+/*
+ * rk_ae_encode_bwd -- autograd of the above w.r.t. the gathered encoder rows
+ * (model.py:397): G_en[c,:] (+)= sum_r svals[r,c] * dZ0pre[r,:]  (deterministic
+ * ascending-row order via the transposed bitmap).  accumulate != 0 adds into
+ * G_en (tied weights, nn.py:191-202).
+ */
+int rk_ae_encode_bwd(const rk_block_t *blk, int32_t row_off, int32_t B,
+                     const float *dZ0pre, int32_t h, float *G_en,
+                     int32_t accumulate, void *stream);
+
+/*
+ * rk_decode_loss -- LinearEmbedding(output) (nn.py:271-280) fused with the
+ * loss (losses.py:43-47,68-71 / BCEWithLogits) and its gradient w.r.t. the
+ * logits; the loss is divided by B as model.py:483-484.
+ *   Z [B,h]; target block `tgt` rows [row_off,row_off+B) (training: the input
+ *   block itself, model.py:473-476).
+ *   MSE/BCE : dO[B,ld] <- dLoss/dLogits, loss partials -> loss_part
+ *   MNLL    : dO <- logits (finish with rk_mnll_finish)
+ *   NONE    : out[B, ld_out] <- logits (+bias), ld_out host-given
+ *   loss_part : [rk_loss_partials(B, n_cap)] floats
+ */
+int32_t rk_loss_partials(int32_t B, int32_t n_cap);
+int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
+                   int32_t row_off, const float *W_de, const float *b_de,
+                   int32_t loss_kind, float confidence, float inv_B,
+                   float *dO, int32_t ld_out, float *loss_part, void *stream);
+/* MNLL second pass: row max / logsumexp over the logits in dO, loss, and
+ * dO <- (softmax * sum_t - t) * inv_B  (losses.py:68-71 + autograd). */
+int rk_mnll_finish(float *dO, int32_t B, const rk_block_t *tgt, int32_t row_off,
+                   float inv_B, float *loss_part, void *stream);
+/* sum the (unscaled) loss partials in a fixed order (double) and divide by
+ * denom = rows of the slice in fp32 (model.py:483-484) -> loss[0] */
+int rk_loss_reduce(const float *loss_part, int32_t n, float denom, float *loss,
+                   void *stream);
+
+/*
+ * Decoder backward (autograd of F.linear(z, W_de[T], b_de[T]), nn.py:280):
+ *   rk_decode_bwd_dz : dZ[B,h] = dO[B,n_t] . W_de[T]   (* act'(Zact) if Zact)
+ *   rk_decode_bwd_dw : G_de[n_t,h] = dO^T . Z ;  gb_de[n_t] = colsum(dO)
+ */
+int rk_decode_bwd_dz(const float *dO, int32_t B, int32_t h,
+                     const rk_block_t *tgt, const float *W_de,
+                     const float *Zact /* nullable */, int32_t act,
+                     float *dZ, float *workspace, void *stream);
+int rk_decode_bwd_dw(const float *dO, const float *Z, int32_t B, int32_t h,
+                     const rk_block_t *tgt, float *G_de, float *gb_de,
+                     void *stream);
+
+/*
+ * Hidden nn.Linear stack (nn.py:242-249): Y = act(X W^T + b), and backward.
+ *   rk_linear_fwd : Y[B,N] = act(X[B,K] . W[N,K]^T + b)      (wT: W is [K,N])
+ *   rk_linear_bwd : dYpre = dY * act'(Y) (in place), dX = dYpre . W,
+ *                   dW (+)= dYpre^T . X, db = colsum(dYpre)
+ */
+int rk_linear_fwd(const float *X, const float *W, const float *b, int32_t B,
+                  int32_t N, int32_t K, int32_t w_transposed, int32_t act,
+                  float *Y, void *stream);
+int rk_linear_bwd(float *dY, const float *Y, const float *X, const float *W,
+                  int32_t B, int32_t N, int32_t K, int32_t w_transposed,
+                  int32_t act, float *dX /* nullable */, float *dW,
+                  int32_t dw_accumulate, float *db, void *stream);
+
+/* elementwise helpers */
+int rk_act_grad(float *dY, const float *Y, int64_t n, int32_t act, void *stream);
+int rk_dropout(float *X, const uint8_t *keep, int64_t n, int32_t ncols, float p,
+               uint64_t seed, uint64_t rng_step, void *stream);
+/* out[c] = sum_r X[r,c]; if counts_dev (a block's counts array) is given the
+ * column count and ld are read from it (counts[0], counts[2]) */
+int rk_colsum(const float *X, int32_t rows, int32_t cols, int32_t ld,
+              const int32_t *counts_dev /* nullable */, float *out,
+              void *stream);
+int rk_gather_rows(const float *E, const int64_t *rows, int32_t B, int32_t d,
+                   int32_t act, float *out, void *stream);
+
+/*
+ * Optimisers (exact formulas of torch.optim.Adam `_single_tensor_adam` and
+ * torch.optim.SparseAdam, model.py:135,138,398-402).  `step` is the 1-based
+ * step count after increment.  Hyper-parameters are doubles because torch
+ * evaluates `1 - beta`, the bias corrections and the step size in Python
+ * doubles before the one conversion to fp32.
+ *   rk_adam_table : full sweep of a [n_rows,h] table; row i gets gradient
+ *                   G[pos[i]] if pos[i] >= 0 else 0; L2 weight decay (K14a).
+ *   rk_adam_rows  : SparseAdam on the rows idx[0..n_dev) (K14b); no decay.
+ *   rk_adam_dense : plain dense tensor (biases, hidden layers).
+ */
+int rk_adam_table(float *W, float *m, float *v, int32_t n_rows, int32_t h,
+                  const int32_t *pos, const float *G, double lr, double beta1,
+                  double beta2, double eps, double weight_decay, int32_t step,
+                  void *stream);
+int rk_adam_rows(float *W, float *m, float *v, int32_t h, const int32_t *idx32,
+                 const int64_t *idx64, const int32_t *n_dev, int32_t n_cap,
+                 const float *G, double lr, double beta1, double beta2,
+                 double eps, int32_t step, void *stream);
+int rk_adam_dense(float *p, float *m, float *v, const float *g, int64_t n,
+                  double lr, double beta1, double beta2, double eps,
+                  double weight_decay, int32_t step, void *stream);
+/* user-row position map for MF dense Adam: pos[users[r]] = r (or -1 to clear) */
+int rk_scatter_pos(int32_t *pos, const int64_t *rows, int32_t B, int32_t clear,
+                   void *stream);
+
+/*
+ * rk_topk_masked -- Recoder.recommend (model.py:525-544): scores[B,ld] with the
+ * seen items (bits_rc of the non-sampled block) set to -inf, top-k sorted
+ * descending (ties: lower index first, as torch.topk on CPU).
+ */
+int rk_topk_masked(const float *scores, int32_t B, int32_t n, int32_t ld,
+                   const rk_block_t *seen, int32_t row_off, int32_t k,
+                   int64_t *out_idx, float *out_val, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RECODER_HIP_H */

@@ -1,0 +1,101 @@
+"""ctypes binding of librecoder_hip.so (the C ABI in include/recoder_hip.h).
+
+This is the binding a maintainer of the reference would add:
+plain pointers and sizes, no torch types cross the boundary.  There is NO
+fallback: if the library is missing or a symbol is absent, import of the hot
+path fails loudly.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64,
+                    c_uint64, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librecoder_hip.so")
+
+ACT = {"none": 0, "tanh": 1, "sigmoid": 2, "relu": 3, "selu": 4, "elu": 5}
+LOSS_MSE, LOSS_BCE, LOSS_MNLL, LOSS_NONE = 0, 1, 2, 3
+SCAN_CHUNK = 2048
+
+
+class RkBlock(Structure):
+  """mirror of rk_block_t"""
+  _fields_ = [
+    ("S_cap", c_int32), ("nnz_cap", c_int32), ("n_cap", c_int32), ("n_items", c_int32),
+    ("ldw_rc", c_int32), ("ldw_cr", c_int32), ("n_chunks", c_int32), ("reserved", c_int32),
+    ("counts", c_void_p), ("indptr", c_void_p), ("cols", c_void_p), ("vals", c_void_p),
+    ("svals", c_void_p), ("items", c_void_p), ("pos", c_void_p), ("mark", c_void_p),
+    ("bits_rc", c_void_p), ("bits_cr", c_void_p), ("scan_tmp", c_void_p),
+  ]
+
+
+_P = c_void_p
+_BLK = POINTER(RkBlock)
+
+# name -> (restype, argtypes); every symbol include/recoder_hip.h declares
+SIGNATURES = {
+  "rk_version": (c_int32, []),
+  "rk_last_error": (c_char_p, []),
+  "rk_dz_workspace_bytes": (c_int64, [c_int32, c_int32]),
+  "rk_collate": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _BLK, _P]),
+  "rk_ae_encode_fwd": (c_int32, [_BLK, c_int32, c_int32, _P, _P, c_int32, _P, c_float, c_uint64,
+                                 c_uint64, _P, c_int32, _P, _P]),
+  "rk_ae_encode_bwd": (c_int32, [_BLK, c_int32, c_int32, _P, c_int32, _P, c_int32, _P]),
+  "rk_loss_partials": (c_int32, [c_int32, c_int32]),
+  "rk_decode_loss": (c_int32, [_P, c_int32, c_int32, _BLK, c_int32, _P, _P, c_int32, c_float,
+                               c_float, _P, c_int32, _P, _P]),
+  "rk_mnll_finish": (c_int32, [_P, c_int32, _BLK, c_int32, c_float, _P, _P]),
+  "rk_loss_reduce": (c_int32, [_P, c_int32, c_float, _P, _P]),
+  "rk_decode_bwd_dz": (c_int32, [_P, c_int32, c_int32, _BLK, _P, _P, c_int32, _P, _P, _P]),
+  "rk_decode_bwd_dw": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P]),
+  "rk_linear_fwd": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+  "rk_linear_bwd": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P,
+                              c_int32, _P, _P]),
+  "rk_act_grad": (c_int32, [_P, _P, c_int64, c_int32, _P]),
+  "rk_dropout": (c_int32, [_P, _P, c_int64, c_int32, c_float, c_uint64, c_uint64, _P]),
+  "rk_colsum": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P, _P]),
+  "rk_gather_rows": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P]),
+  "rk_adam_table": (c_int32, [_P, _P, _P, c_int32, c_int32, _P, _P, c_double, c_double, c_double,
+                              c_double, c_double, c_int32, _P]),
+  "rk_adam_rows": (c_int32, [_P, _P, _P, c_int32, _P, _P, _P, c_int32, _P, c_double, c_double,
+                             c_double, c_double, c_int32, _P]),
+  "rk_adam_dense": (c_int32, [_P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double,
+                              c_double, c_int32, _P]),
+  "rk_scatter_pos": (c_int32, [_P, _P, c_int32, c_int32, _P]),
+  "rk_topk_masked": (c_int32, [_P, c_int32, c_int32, c_int32, _BLK, c_int32, c_int32, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class RecoderHipError(RuntimeError):
+  pass
+
+
+def load():
+  """Load the shared library (once) and bind every declared symbol."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise RecoderHipError(
+        "librecoder_hip.so not found at %s -- build it with `python -m recoder_amd.build` "
+        "(there is no CPU fallback for the training path)" % LIB_PATH)
+  lib = ctypes.CDLL(LIB_PATH)
+  for name, (res, args) in SIGNATURES.items():
+    fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
+    fn.restype = res
+    fn.argtypes = args
+  _lib = lib
+  return lib
+
+
+def check(rc, what=""):
+  if rc != 0:
+    msg = load().rk_last_error()
+    raise RecoderHipError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+
+def ptr(t):
+  """device (or host) pointer of a torch tensor / None"""
+  return None if t is None else t.data_ptr()

@@ -1,0 +1,61 @@
+"""Build librecoder_hip.so (hand-written HIP kernels + C ABI) for gfx950.
+
+    python -m recoder_amd.build [--force]
+
+hipcc cross-compiles without a GPU; the built library stays in-tree
+(recoder_amd/csrc/librecoder_hip.so, git-ignored) so that it travels with the
+repository snapshot to the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB = os.path.join(CSRC, "librecoder_hip.so")
+SOURCES = ["capi.hip", "collate.hip", "encoder.hip", "gemm.hip", "optim.hip", "topk.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target, deps):
+  if not os.path.exists(target):
+    return True
+  t = os.path.getmtime(target)
+  return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=True):
+  hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+  headers = [os.path.join(CSRC, "common.h"),
+             os.path.join(os.path.dirname(CSRC), "..", "include", "recoder_hip.h")]
+  objs = []
+  procs = []
+  for src in SOURCES:
+    s = os.path.join(CSRC, src)
+    o = os.path.join(CSRC, src.replace(".hip", ".o"))
+    objs.append(o)
+    if force or _stale(o, [s] + headers):
+      cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+      if verbose:
+        print(" ".join(cmd), flush=True)
+      procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+  failed = False
+  for src, p in procs:
+    out, _ = p.communicate()
+    if out and verbose:
+      sys.stdout.write(out.decode(errors="replace"))
+    if p.returncode != 0:
+      failed = True
+      print("FAILED:", src)
+  if failed:
+    raise RuntimeError("hipcc failed")
+  if force or procs or _stale(LIB, objs):
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+      print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+  return LIB
+
+
+if __name__ == "__main__":
+  build_library(force="--force" in sys.argv)
+  print("built", LIB)

@@ -1,0 +1,101 @@
+// Shared device helpers for librecoder_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/recoder_hip.h"
+
+void rk_set_error(const char *fmt, ...);
+
+#define RK_CHECK_LAUNCH(name)                                              \
+  do {                                                                     \
+    hipError_t e__ = hipGetLastError();                                    \
+    if (e__ != hipSuccess) {                                               \
+      rk_set_error("%s: %s", name, hipGetErrorString(e__));                \
+      return -1;                                                           \
+    }                                                                      \
+  } while (0)
+
+#define RK_REQUIRE(cond, msg)                                              \
+  do {                                                                     \
+    if (!(cond)) {                                                         \
+      rk_set_error("%s: %s", __func__, msg);                               \
+      return -2;                                                           \
+    }                                                                      \
+  } while (0)
+
+static inline int rk_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- activations
+// y = act(x);  derivative expressed through y (what autograd of torch.tanh /
+// sigmoid / relu / selu / elu evaluates to for the saved output).
+__device__ __forceinline__ float rk_act(float x, int act) {
+  switch (act) {
+    case RK_ACT_TANH: return tanhf(x);
+    case RK_ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+    case RK_ACT_RELU: return x > 0.f ? x : 0.f;
+    case RK_ACT_SELU: {
+      const float a = 1.6732632423543772848170429916717f;
+      const float s = 1.0507009873554804934193349852946f;
+      return s * (x > 0.f ? x : a * (expf(x) - 1.0f));
+    }
+    case RK_ACT_ELU: return x > 0.f ? x : (expf(x) - 1.0f);
+    default: return x;
+  }
+}
+
+__device__ __forceinline__ float rk_act_dy(float y, int act) {
+  switch (act) {
+    case RK_ACT_TANH: return 1.0f - y * y;
+    case RK_ACT_SIGMOID: return (1.0f - y) * y;
+    case RK_ACT_RELU: return y > 0.f ? 1.0f : 0.f;
+    case RK_ACT_SELU: {
+      const float a = 1.6732632423543772848170429916717f;
+      const float s = 1.0507009873554804934193349852946f;
+      return y > 0.f ? s : (y + s * a);
+    }
+    case RK_ACT_ELU: return y > 0.f ? 1.0f : (y + 1.0f);
+    default: return 1.0f;
+  }
+}
+
+// ------------------------------------------------------------- counter RNG
+// Stateless keep/drop draw for dropout: a 64-bit mix of (seed, step, a, b).
+// Not the reference's stream (a GPU cannot reproduce torch's CPU Bernoulli
+// stream); parity tests inject masks instead.
+__device__ __forceinline__ uint64_t rk_mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ bool rk_keep_draw(uint64_t seed, uint64_t step, uint64_t a,
+                                             uint64_t b, float p) {
+  uint64_t z = rk_mix64(seed + 0x9e3779b97f4a7c15ULL * (step + 1));
+  z = rk_mix64(z ^ (a * 0xd1342543de82ef95ULL + b + 0x632be59bd9b4e019ULL));
+  // 24 uniform bits -> [0,1)
+  float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+  return u >= p;
+}
+
+// ------------------------------------------------------------ wave helpers
+__device__ __forceinline__ float rk_wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float rk_wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
+  return v;
+}
+
+// binary search of column c in the (ascending) relabelled columns of one row
+__device__ __forceinline__ int rk_find_col(const int32_t *cols, int beg, int end, int c) {
+  int lo = beg, hi = end;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (cols[mid] < c) lo = mid + 1; else hi = mid;
+  }
+  return (lo < end && cols[lo] == c) ? lo : -1;
+}

@@ -1,0 +1,215 @@
+// Encoder side of DynamicAutoencoder: CSR user rows x item-embedding rows.
+//
+// Forward  (reference nn.py:235-240, 269-278, K2..K6 of SURVEY 2.3):
+//   Z0[r,:] = act( sum_j  (v_j / max(||v_r||,1e-12)) * keep_j/(1-p) * W_en[item_j,:] + b_en )
+// The reference densifies the B x n_b block and runs a dense addmm over ~99%
+// zeros; here each workgroup owns one user row, its 4 waves split the row's
+// stored interactions and gather W_en rows with 16-B loads (HBM/L2-bound:
+// nnz_b * h * 4 bytes of gathered rows per step), then combine through LDS.
+//
+// Backward (autograd of the same, model.py:397):
+//   G_en[c,:] = sum_{r in column c} svals[r,c] * dZ0pre[r,:]
+// one wave per sampled item column; rows are visited in ascending order through
+// the transposed bitmap so the fp32 sum is order-deterministic (no atomics).
+#include "common.h"
+
+namespace {
+
+// HV = number of float4 per lane (h <= 256*HV)
+template <int HV>
+__global__ __launch_bounds__(256) void ae_encode_fwd_kernel(
+    rk_block_t b, int row_off, int B, const float *__restrict__ W, const float *__restrict__ bias,
+    int h, const uint8_t *__restrict__ keep, float p, float scale, uint64_t seed,
+    uint64_t rng_step, const int64_t *__restrict__ users, int act, float *__restrict__ Z0) {
+  __shared__ float red[4];
+  __shared__ __attribute__((aligned(16))) float part[3][HV * 256];
+  const int r = blockIdx.x;            // row within the slice
+  if (r >= B) return;
+  const int row = row_off + r;         // row within the block
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int beg = b.indptr[row], end = b.indptr[row + 1];
+  const int n = end - beg;
+
+  // ---- L2 norm of the row (F.normalize: x / max(||x||_2, 1e-12)) ----
+  float ss = 0.f;
+  for (int j = beg + tid; j < end; j += 256) {
+    const float v = b.vals[j];
+    ss += v * v;
+  }
+  ss = rk_wave_sum(ss);
+  if (lane == 0) red[wid] = ss;
+  __syncthreads();
+  const float nrm = fmaxf(sqrtf((red[0] + red[1]) + (red[2] + red[3])), 1e-12f);
+
+  // ---- each wave takes a contiguous quarter of the row's entries ----
+  const int q = (n + 3) >> 2;
+  const int wbeg = beg + wid * q;
+  const int wend = min(end, wbeg + q);
+  const int64_t uid = users ? users[row] : (int64_t)row;
+
+  float4 acc[HV];
+#pragma unroll
+  for (int k = 0; k < HV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (int base = wbeg; base < wend; base += 64) {
+    const int j = base + lane;
+    int item = 0;
+    float s = 0.f;
+    if (j < wend) {
+      const int c = b.cols[j];
+      item = b.items[c];
+      const float xh = b.vals[j] / nrm;
+      bool kp = true;
+      if (p > 0.f) kp = keep ? (keep[j] != 0) : rk_keep_draw(seed, rng_step, (uint64_t)uid, (uint64_t)item, p);
+      s = (p > 0.f) ? (kp ? xh * scale : 0.f) : xh;
+      b.svals[j] = s;
+    }
+    const int cnt = min(64, wend - base);
+    for (int k = 0; k < cnt; ++k) {
+      const int it = __shfl(item, k, 64);
+      const float sv = __shfl(s, k, 64);
+      if (sv != 0.f) {   // wave-uniform: dropped entries contribute exactly 0
+        const float *wrow = W + (int64_t)it * h;
+#pragma unroll
+        for (int v = 0; v < HV; ++v) {
+          const int hh = (v * 64 + lane) * 4;
+          if (hh < h) {
+            const float4 w4 = *reinterpret_cast<const float4 *>(wrow + hh);
+            acc[v].x = fmaf(sv, w4.x, acc[v].x);
+            acc[v].y = fmaf(sv, w4.y, acc[v].y);
+            acc[v].z = fmaf(sv, w4.z, acc[v].z);
+            acc[v].w = fmaf(sv, w4.w, acc[v].w);
+          }
+        }
+      }
+    }
+  }
+  // ---- combine the 4 partial sums in fixed order, bias, activation ----
+  if (wid > 0) {
+#pragma unroll
+    for (int v = 0; v < HV; ++v)
+      *reinterpret_cast<float4 *>(&part[wid - 1][(v * 64 + lane) * 4]) = acc[v];
+  }
+  __syncthreads();
+  if (wid == 0) {
+#pragma unroll
+    for (int v = 0; v < HV; ++v) {
+      const int hh = (v * 64 + lane) * 4;
+      if (hh < h) {
+        float4 a = acc[v];
+        for (int w = 0; w < 3; ++w) {
+          const float4 o = *reinterpret_cast<const float4 *>(&part[w][hh]);
+          a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+        }
+        const float4 bb = *reinterpret_cast<const float4 *>(bias + hh);
+        float4 y;
+        y.x = rk_act(a.x + bb.x, act);
+        y.y = rk_act(a.y + bb.y, act);
+        y.z = rk_act(a.z + bb.z, act);
+        y.w = rk_act(a.w + bb.w, act);
+        *reinterpret_cast<float4 *>(Z0 + (int64_t)r * h + hh) = y;
+      }
+    }
+  }
+}
+
+template <int HV>
+__global__ __launch_bounds__(256) void ae_encode_bwd_kernel(
+    rk_block_t b, int row_off, int B, const float *__restrict__ dZ, int h,
+    float *__restrict__ G, int accumulate) {
+  const int n_b = b.counts[0];
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= n_b) return;
+  const int lane = threadIdx.x & 63;
+  const uint32_t *colbits = b.bits_cr + (int64_t)c * b.ldw_cr;
+  float4 acc[HV];
+#pragma unroll
+  for (int k = 0; k < HV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  const int rend = row_off + B;
+  for (int r0 = row_off & ~63; r0 < rend; r0 += 64) {
+    const int row = r0 + lane;
+    bool on = false;
+    float s = 0.f;
+    if (row >= row_off && row < rend) {
+      on = (colbits[row >> 5] >> (row & 31)) & 1u;
+      if (on) {
+        const int j = rk_find_col(b.cols, b.indptr[row], b.indptr[row + 1], c);
+        s = (j >= 0) ? b.svals[j] : 0.f;
+      }
+    }
+    unsigned long long mask = __ballot(on);
+    while (mask) {
+      const int k = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const float sv = __shfl(s, k, 64);
+      if (sv != 0.f) {
+        const float *drow = dZ + (int64_t)(r0 + k - row_off) * h;
+#pragma unroll
+        for (int v = 0; v < HV; ++v) {
+          const int hh = (v * 64 + lane) * 4;
+          if (hh < h) {
+            const float4 d4 = *reinterpret_cast<const float4 *>(drow + hh);
+            acc[v].x = fmaf(sv, d4.x, acc[v].x);
+            acc[v].y = fmaf(sv, d4.y, acc[v].y);
+            acc[v].z = fmaf(sv, d4.z, acc[v].z);
+            acc[v].w = fmaf(sv, d4.w, acc[v].w);
+          }
+        }
+      }
+    }
+  }
+  float *grow = G + (int64_t)c * h;
+#pragma unroll
+  for (int v = 0; v < HV; ++v) {
+    const int hh = (v * 64 + lane) * 4;
+    if (hh < h) {
+      float4 a = acc[v];
+      if (accumulate) {
+        const float4 o = *reinterpret_cast<const float4 *>(grow + hh);
+        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+      }
+      *reinterpret_cast<float4 *>(grow + hh) = a;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int rk_ae_encode_fwd(const rk_block_t *blk, int32_t row_off, int32_t B,
+                                const float *W_en, const float *b_en, int32_t h,
+                                const uint8_t *keep, float p, uint64_t seed, uint64_t rng_step,
+                                const int64_t *users, int32_t act, float *Z0, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(h > 0 && h % 4 == 0 && h <= 1024, "h must be a multiple of 4, <= 1024");
+  RK_REQUIRE(p >= 0.f && p < 1.f, "noise_prob must be in [0,1)");
+  RK_REQUIRE(row_off >= 0 && B >= 0 && row_off + B <= blk->S_cap, "row slice out of range");
+  if (B == 0) return 0;
+  // ATen dropout: noise = bernoulli(1-p) / (1-p), computed in fp32
+  const float scale = 1.0f / (float)(1.0 - (double)p);
+  const int hv = rk_cdiv(h, 256);
+#define LAUNCH(HV)                                                                         \
+  hipLaunchKernelGGL(ae_encode_fwd_kernel<HV>, dim3(B), dim3(256), 0, stream, *blk, row_off, \
+                     B, W_en, b_en, h, keep, p, scale, seed, rng_step, users, act, Z0)
+  if (hv == 1) LAUNCH(1); else if (hv == 2) LAUNCH(2); else LAUNCH(4);
+#undef LAUNCH
+  RK_CHECK_LAUNCH("ae_encode_fwd");
+  return 0;
+}
+
+extern "C" int rk_ae_encode_bwd(const rk_block_t *blk, int32_t row_off, int32_t B,
+                                const float *dZ0pre, int32_t h, float *G_en,
+                                int32_t accumulate, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(h > 0 && h % 4 == 0 && h <= 1024, "h must be a multiple of 4, <= 1024");
+  RK_REQUIRE(row_off >= 0 && B >= 0 && row_off + B <= blk->S_cap, "row slice out of range");
+  const int grid = rk_cdiv(blk->n_cap, 4);
+  const int hv = rk_cdiv(h, 256);
+#define LAUNCH(HV)                                                                           \
+  hipLaunchKernelGGL(ae_encode_bwd_kernel<HV>, dim3(grid), dim3(256), 0, stream, *blk, row_off, \
+                     B, dZ0pre, h, G_en, accumulate)
+  if (hv == 1) LAUNCH(1); else if (hv == 2) LAUNCH(2); else LAUNCH(4);
+#undef LAUNCH
+  RK_CHECK_LAUNCH("ae_encode_bwd");
+  return 0;
+}

@@ -1,0 +1,279 @@
+// Optimiser + small elementwise kernels (all HBM-bound, 16-B vectorised).
+//
+// Adam     : torch.optim.Adam `_single_tensor_adam` as driven by the reference
+//            (model.py:135,398-399): L2 weight decay folded into the gradient,
+//            lerp first moment, bias-corrected step, eps added after the
+//            bias-corrected sqrt.  rk_adam_table is the "dense gradient"
+//            (sparse=False) form for an embedding table: the reference
+//            materialises a full [n_items,h] gradient that is zero outside the
+//            sampled rows (K13/K14a of SURVEY 2.3); here the sweep reads the
+//            compact gradient rows through pos[] instead.
+// SparseAdam: torch.optim.SparseAdam (`_functional.sparse_adam`) on the touched
+//            rows only (model.py:138,401-402): no weight decay, eps added to
+//            the raw sqrt, bias correction folded into the step size.
+#include "common.h"
+
+namespace {
+
+struct AdamC {
+  float one_m_b1, b2, one_m_b2, eps, wd;
+  float bc2_sqrt;     // sqrt(1 - beta2^t)
+  float neg_step;     // -(lr / (1 - beta1^t))           (Adam)
+  float neg_step_sp;  // -(lr * sqrt(1-beta2^t) / (1-beta1^t))   (SparseAdam)
+};
+
+__device__ __forceinline__ void adam1(float &p, float &m, float &v, float g, const AdamC &c) {
+  if (c.wd != 0.f) g = g + c.wd * p;                 // grad.add(param, alpha=wd)
+  m = fmaf(c.one_m_b1, g - m, m);                    // exp_avg.lerp_(grad, 1-beta1)
+  v = v * c.b2 + (c.one_m_b2 * g) * g;               // mul_(beta2).addcmul_(g, g, 1-beta2)
+  const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
+  p = p + (c.neg_step * m) / denom;                  // addcdiv_(exp_avg, denom, -step_size)
+}
+
+__device__ __forceinline__ void sadam1(float &p, float &m, float &v, float g, const AdamC &c) {
+  const float um = (g - m) * c.one_m_b1;
+  const float uv = (g * g - v) * c.one_m_b2;
+  const float numer = um + m;
+  const float dsq = uv + v;
+  m = m + um;
+  v = v + uv;
+  const float denom = sqrtf(dsq) + c.eps;
+  p = p + (numer / denom) * c.neg_step_sp;
+}
+
+__global__ __launch_bounds__(256) void adam_table_kernel(float *W, float *m, float *v, int n_rows,
+                                                         int h, const int32_t *pos,
+                                                         const float *G, AdamC c) {
+  const int hq = h >> 2;
+  const int64_t tot = (int64_t)n_rows * hq;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    const int row = (int)(i / hq), q = (int)(i % hq);
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pos) {
+      const int pr = pos[row];
+      if (pr >= 0) g = *reinterpret_cast<const float4 *>(G + (int64_t)pr * h + q * 4);
+    } else {
+      g = *reinterpret_cast<const float4 *>(G + (int64_t)row * h + q * 4);
+    }
+    float4 p4 = reinterpret_cast<float4 *>(W)[i];
+    float4 m4 = reinterpret_cast<float4 *>(m)[i];
+    float4 v4 = reinterpret_cast<float4 *>(v)[i];
+    adam1(p4.x, m4.x, v4.x, g.x, c);
+    adam1(p4.y, m4.y, v4.y, g.y, c);
+    adam1(p4.z, m4.z, v4.z, g.z, c);
+    adam1(p4.w, m4.w, v4.w, g.w, c);
+    reinterpret_cast<float4 *>(W)[i] = p4;
+    reinterpret_cast<float4 *>(m)[i] = m4;
+    reinterpret_cast<float4 *>(v)[i] = v4;
+  }
+}
+
+// scalar variant (h == 1 tables such as the decoder bias, or h % 4 != 0)
+__global__ __launch_bounds__(256) void adam_table_scalar_kernel(float *W, float *m, float *v,
+                                                                int n_rows, int h,
+                                                                const int32_t *pos,
+                                                                const float *G, AdamC c) {
+  const int64_t tot = (int64_t)n_rows * h;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    const int row = (int)(i / h), q = (int)(i % h);
+    float g = 0.f;
+    if (pos) {
+      const int pr = pos[row];
+      if (pr >= 0) g = G[(int64_t)pr * h + q];
+    } else {
+      g = G[i];
+    }
+    float p1 = W[i], m1 = m[i], v1 = v[i];
+    adam1(p1, m1, v1, g, c);
+    W[i] = p1; m[i] = m1; v[i] = v1;
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_rows_kernel(float *W, float *m, float *v, int h,
+                                                        const int32_t *idx32, const int64_t *idx64,
+                                                        const int32_t *n_dev, int n_host,
+                                                        const float *G, AdamC c) {
+  const int n = n_dev ? *n_dev : n_host;
+  const int64_t tot = (int64_t)n * h;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / h), q = (int)(i % h);
+    const int64_t row = idx32 ? (int64_t)idx32[r] : idx64[r];
+    const int64_t o = row * h + q;
+    float p1 = W[o], m1 = m[o], v1 = v[o];
+    sadam1(p1, m1, v1, G[i], c);
+    W[o] = p1; m[o] = m1; v[o] = v1;
+  }
+}
+
+__global__ __launch_bounds__(256) void act_grad_kernel(float *dY, const float *Y, int64_t n, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    dY[i] = dY[i] * rk_act_dy(Y[i], act);
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(float *X, const uint8_t *keep, int64_t n,
+                                                      int ncols, float p, float scale,
+                                                      uint64_t seed, uint64_t step) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const bool k = keep ? (keep[i] != 0)
+                        : rk_keep_draw(seed, step, (uint64_t)(i / ncols) + 0x51ed270b1ULL,
+                                       (uint64_t)(i % ncols), p);
+    X[i] = k ? X[i] * scale : X[i] * 0.f;
+  }
+}
+
+// out[c] = sum_r X[r*ld + c]; block = 64 columns x 4 row slices, fixed order
+__global__ __launch_bounds__(256) void colsum_kernel(const float *X, int rows, int cols_host,
+                                                     int ld_host, const int32_t *counts,
+                                                     float *out) {
+  __shared__ float part[4][64];
+  const int cols = counts ? counts[0] : cols_host;
+  const int ld = counts ? counts[2] : ld_host;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int s = threadIdx.x >> 6;
+  const int per = (rows + 3) >> 2;
+  const int r0 = s * per, r1 = min(rows, r0 + per);
+  float acc = 0.f;
+  if (c < cols)
+    for (int r = r0; r < r1; ++r) acc += X[(int64_t)r * ld + c];
+  part[s][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (s == 0 && c < cols)
+    out[c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *E, const int64_t *rows, int B,
+                                                          int d, int act, float *out) {
+  const int64_t tot = (int64_t)B * d;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / d), q = (int)(i % d);
+    out[i] = rk_act(E[rows[r] * d + q], act);
+  }
+}
+
+__global__ __launch_bounds__(256) void scatter_pos_kernel(int32_t *pos, const int64_t *rows, int B,
+                                                          int clear) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < B) pos[rows[i]] = clear ? -1 : i;
+}
+
+AdamC make_consts(double lr, double b1, double b2, double eps, double wd, int step) {
+  AdamC c;
+  c.one_m_b1 = (float)(1.0 - b1);
+  c.b2 = (float)b2;
+  c.one_m_b2 = (float)(1.0 - b2);
+  c.eps = (float)eps;
+  c.wd = (float)wd;
+  const double bc1 = 1.0 - pow(b1, (double)step);
+  const double bc2 = 1.0 - pow(b2, (double)step);
+  c.bc2_sqrt = (float)sqrt(bc2);
+  c.neg_step = (float)(-(lr / bc1));
+  c.neg_step_sp = (float)(-(lr * sqrt(bc2) / bc1));
+  return c;
+}
+
+inline int grid_for(int64_t n) {
+  int64_t g = (n + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int rk_adam_table(float *W, float *m, float *v, int32_t n_rows, int32_t h,
+                             const int32_t *pos, const float *G, double lr, double beta1,
+                             double beta2, double eps, double weight_decay, int32_t step,
+                             void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(step >= 1, "step must be >= 1");
+  if (n_rows == 0) return 0;
+  const AdamC c = make_consts(lr, beta1, beta2, eps, weight_decay, step);
+  if (h % 4 == 0 && (((uintptr_t)W | (uintptr_t)m | (uintptr_t)v | (uintptr_t)G) & 15) == 0) {
+    hipLaunchKernelGGL(adam_table_kernel, dim3(grid_for((int64_t)n_rows * h / 4)), dim3(256), 0,
+                       stream, W, m, v, n_rows, h, pos, G, c);
+  } else {
+    hipLaunchKernelGGL(adam_table_scalar_kernel, dim3(grid_for((int64_t)n_rows * h)), dim3(256), 0,
+                       stream, W, m, v, n_rows, h, pos, G, c);
+  }
+  RK_CHECK_LAUNCH("adam_table");
+  return 0;
+}
+
+extern "C" int rk_adam_rows(float *W, float *m, float *v, int32_t h, const int32_t *idx32,
+                            const int64_t *idx64, const int32_t *n_dev, int32_t n_cap,
+                            const float *G, double lr, double beta1, double beta2, double eps,
+                            int32_t step, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(step >= 1, "step must be >= 1");
+  RK_REQUIRE((idx32 != nullptr) != (idx64 != nullptr), "exactly one index array");
+  if (n_cap == 0) return 0;
+  const AdamC c = make_consts(lr, beta1, beta2, eps, 0.0, step);
+  hipLaunchKernelGGL(adam_rows_kernel, dim3(grid_for((int64_t)n_cap * h)), dim3(256), 0, stream, W,
+                     m, v, h, idx32, idx64, n_dev, n_cap, G, c);
+  RK_CHECK_LAUNCH("adam_rows");
+  return 0;
+}
+
+extern "C" int rk_adam_dense(float *p, float *m, float *v, const float *g, int64_t n, double lr,
+                             double beta1, double beta2, double eps, double weight_decay,
+                             int32_t step, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(step >= 1, "step must be >= 1");
+  RK_REQUIRE(n < (int64_t)1 << 31, "tensor too large for one call");
+  if (n == 0) return 0;
+  const AdamC c = make_consts(lr, beta1, beta2, eps, weight_decay, step);
+  hipLaunchKernelGGL(adam_table_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, m, v,
+                     (int)n, 1, (const int32_t *)nullptr, g, c);
+  RK_CHECK_LAUNCH("adam_dense");
+  return 0;
+}
+
+extern "C" int rk_scatter_pos(int32_t *pos, const int64_t *rows, int32_t B, int32_t clear,
+                              void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(scatter_pos_kernel, dim3(rk_cdiv(B, 256)), dim3(256), 0, stream, pos, rows, B,
+                     clear);
+  RK_CHECK_LAUNCH("scatter_pos");
+  return 0;
+}
+
+extern "C" int rk_act_grad(float *dY, const float *Y, int64_t n, int32_t act, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n == 0 || act == RK_ACT_NONE) return 0;
+  hipLaunchKernelGGL(act_grad_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dY, Y, n, act);
+  RK_CHECK_LAUNCH("act_grad");
+  return 0;
+}
+
+extern "C" int rk_dropout(float *X, const uint8_t *keep, int64_t n, int32_t ncols, float p,
+                          uint64_t seed, uint64_t rng_step, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(p >= 0.f && p < 1.f, "dropout prob must be in [0,1)");
+  if (n == 0 || p == 0.f) return 0;
+  const float scale = 1.0f / (float)(1.0 - (double)p);
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, stream, X, keep, n, ncols, p,
+                     scale, seed, rng_step);
+  RK_CHECK_LAUNCH("dropout");
+  return 0;
+}
+
+extern "C" int rk_colsum(const float *X, int32_t rows, int32_t cols, int32_t ld,
+                         const int32_t *counts_dev, float *out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (cols == 0) return 0;
+  hipLaunchKernelGGL(colsum_kernel, dim3(rk_cdiv(cols, 64)), dim3(256), 0, stream, X, rows, cols, ld,
+                     counts_dev, out);
+  RK_CHECK_LAUNCH("colsum");
+  return 0;
+}
+
+extern "C" int rk_gather_rows(const float *E, const int64_t *rows, int32_t B, int32_t d,
+                              int32_t act, float *out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((int64_t)B * d)), dim3(256), 0, stream, E,
+                     rows, B, d, act, out);
+  RK_CHECK_LAUNCH("gather_rows");
+  return 0;
+}

@@ -1,0 +1,141 @@
+// Masked top-k for Recoder.recommend (reference model.py:525-544):
+//   output[input > 0] = -inf ; torch.topk(output, k, dim=1, sorted=True)
+// One workgroup per user row: 4-pass 8-bit radix select of the k-th largest
+// order-preserving key, ordered collection of the survivors (ties resolved to
+// the lower item id), then a bitonic sort of the <= KMAX winners in LDS.
+// HBM-bound: the score row is read 5 times from L2 (n * 4 B per row).
+#include "common.h"
+
+namespace {
+
+constexpr int KMAX = 1024;
+
+__device__ __forceinline__ uint32_t f2key(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+  uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+__global__ __launch_bounds__(256) void topk_masked_kernel(const float *scores, int n, int ld,
+                                                          rk_block_t seen, int has_seen,
+                                                          int row_off, int k, int64_t *out_idx,
+                                                          float *out_val) {
+  __shared__ uint32_t hist[256];
+  __shared__ unsigned long long cand[KMAX];
+  __shared__ uint32_t s_prefix, s_need, s_cnt, s_tie;
+  __shared__ uint32_t wtot[4];
+  const int r = blockIdx.x, row = row_off + r;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float *srow = scores + (int64_t)r * ld;
+  const uint32_t *bits = has_seen ? seen.bits_rc + (int64_t)row * seen.ldw_rc : nullptr;
+
+  auto key_at = [&](int c) -> uint32_t {
+    float f = srow[c];
+    if (bits && ((bits[c >> 5] >> (c & 31)) & 1u)) f = -INFINITY;
+    return f2key(f);
+  };
+
+  // ---- radix select: find key T of the k-th largest element ----
+  uint32_t prefix = 0, pmask = 0, need = (uint32_t)k;
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    hist[tid] = 0;
+    __syncthreads();
+    for (int c = tid; c < n; c += 256) {
+      const uint32_t key = key_at(c);
+      if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t acc = 0;
+      int d = 255;
+      for (; d > 0; --d) {
+        if (acc + hist[d] >= need) break;
+        acc += hist[d];
+      }
+      s_prefix = prefix | ((uint32_t)d << shift);
+      s_need = need - acc;
+    }
+    __syncthreads();
+    prefix = s_prefix;
+    need = s_need;
+    pmask |= 255u << shift;
+    __syncthreads();
+  }
+  const uint32_t T = prefix;       // k-th largest key; `need` = how many ties of T to take
+  if (tid == 0) { s_cnt = 0; s_tie = 0; }
+  __syncthreads();
+  // ---- collect: key > T (any order), key == T in ascending index order ----
+  for (int base = 0; base < n; base += 256) {
+    const int c = base + tid;
+    uint32_t key = 0;
+    bool gt = false, eq = false;
+    if (c < n) {
+      key = key_at(c);
+      gt = key > T;
+      eq = key == T;
+    }
+    // ordered rank of the ties inside this 256-chunk
+    const unsigned long long bm = __ballot(eq);
+    const uint32_t wrank = __popcll(bm & ((1ull << lane) - 1ull));
+    if (lane == 0) wtot[wid] = __popcll(bm);
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int w = 0; w < wid; ++w) woff += wtot[w];
+    const uint32_t chunk_tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    const uint32_t tie_base = s_tie;
+    bool take = gt;
+    if (eq && (tie_base + woff + wrank) < need) take = true;
+    if (take) {
+      const uint32_t slot = atomicAdd(&s_cnt, 1u);
+      // composite: key descending, then index ascending
+      if (slot < KMAX) cand[slot] = ((unsigned long long)key << 32) | (uint32_t)(~(uint32_t)c);
+    }
+    __syncthreads();
+    if (tid == 0) s_tie = tie_base + chunk_tot;
+    __syncthreads();
+  }
+  const int cnt = (int)min(s_cnt, (uint32_t)KMAX);   // == k
+  // ---- bitonic sort (descending) of cand[0..P) padded with 0 ----
+  int P = 1;
+  while (P < cnt) P <<= 1;
+  for (int i = cnt + tid; i < P; i += 256) cand[i] = 0ull;
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = tid; i < P; i += 256) {
+        const int j = i ^ stride;
+        if (j > i) {
+          const bool desc = ((i & size) == 0);
+          const unsigned long long a = cand[i], b = cand[j];
+          if ((a < b) == desc) { cand[i] = b; cand[j] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < k; i += 256) {
+    const unsigned long long e = cand[i];
+    const uint32_t c = ~(uint32_t)(e & 0xffffffffull);
+    out_idx[(int64_t)r * k + i] = (int64_t)c;
+    if (out_val) out_val[(int64_t)r * k + i] = key2f((uint32_t)(e >> 32));
+  }
+}
+
+}  // namespace
+
+extern "C" int rk_topk_masked(const float *scores, int32_t B, int32_t n, int32_t ld,
+                              const rk_block_t *seen, int32_t row_off, int32_t k,
+                              int64_t *out_idx, float *out_val, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(k >= 1 && k <= KMAX, "k must be in [1, 1024]");
+  RK_REQUIRE(k <= n, "k larger than the number of items");
+  if (B == 0) return 0;
+  rk_block_t dummy = {};
+  hipLaunchKernelGGL(topk_masked_kernel, dim3(B), dim3(256), 0, stream, scores, n, ld,
+                     seen ? *seen : dummy, seen ? 1 : 0, row_off, k, out_idx, out_val);
+  RK_CHECK_LAUNCH("topk_masked");
+  return 0;
+}

@@ -1,0 +1,154 @@
+"""Device-resident data structures of the hot path.
+
+DeviceCSR  -- the user x item interaction matrix in HBM (replaces the scipy
+              matrix held by the reference's RecommendationDataset,
+              data.py:41-48): int64 indptr, int32 indices, fp32 data.
+Block      -- buffers of one collated sampling group (``rk_block_t``): what the
+              reference's BatchCollator.collate (data.py:203-251) returns as a
+              list of ``Batch`` sharing one item set, kept on the device.
+"""
+import ctypes
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import _lib
+from ._lib import RkBlock, SCAN_CHUNK, check, ptr
+
+
+def cdiv(a, b):
+  return (a + b - 1) // b
+
+
+def current_stream():
+  return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+  if not torch.cuda.is_available():
+    raise _lib.RecoderHipError(
+        "recoder_amd needs an AMD MI355X (gfx950) visible to PyTorch-ROCm; "
+        "there is no CPU fallback for the training path")
+  return torch.device("cuda", torch.cuda.current_device())
+
+
+def canonical_csr(m):
+  """Sorted indices, no duplicates, no explicit zeros, fp32 data (a copy).
+
+  The reference drops explicit zeros in ``nonzero()`` (data.py:215) but counts
+  them in ``getnnz()`` (data.py:238) -- a latent mismatch; here they are removed
+  up front, which is what its dense arithmetic sees anyway."""
+  m = sp.csr_matrix(m, copy=True)
+  m.sum_duplicates()
+  m.eliminate_zeros()
+  m.sort_indices()
+  if m.nnz and m.indices.max() >= 2 ** 31:
+    raise ValueError("item ids must fit in int32")
+  return m
+
+
+class DeviceCSR:
+  def __init__(self, matrix, device=None):
+    device = device or require_gpu()
+    m = canonical_csr(matrix)
+    self.shape = m.shape
+    self.nnz = int(m.nnz)
+    self.degrees = np.diff(m.indptr).astype(np.int64)
+    self.device = device
+    self.indptr = torch.from_numpy(m.indptr.astype(np.int64)).to(device)
+    self.indices = torch.from_numpy(m.indices.astype(np.int32)).to(device)
+    data = m.data.astype(np.float32)
+    self.implicit = bool(self.nnz == 0 or np.all(data == 1.0))
+    # implicit-feedback matrices (all values 1.0) elide the value stream
+    self.data = None if self.implicit else torch.from_numpy(data).to(device)
+    if self.nnz == 0:
+      self.indices = torch.zeros(1, dtype=torch.int32, device=device)
+
+  @property
+  def n_items(self):
+    return self.shape[1]
+
+
+class Block:
+  """Capacity-sized device buffers for one sampling group + the ctypes view."""
+
+  def __init__(self, S_cap, nnz_cap, n_items, device=None, negative_sampling=True,
+               need_bits_cr=True):
+    device = device or require_gpu()
+    S_cap = max(1, int(S_cap))
+    nnz_cap = max(1, int(nnz_cap))
+    self.device = device
+    self.S_cap, self.nnz_cap, self.n_items = S_cap, nnz_cap, int(n_items)
+    self.negative_sampling = bool(negative_sampling)
+    self.n_cap = min(self.n_items, nnz_cap) if negative_sampling else self.n_items
+    self.n_cap = max(1, self.n_cap)
+    self.ld_cap = cdiv(self.n_cap, 32) * 32
+    self.ldw_rc = cdiv(self.n_cap, 32)
+    self.ldw_cr = cdiv(S_cap, 32)
+    self.n_chunks = cdiv(self.n_items, SCAN_CHUNK)
+    i32 = dict(dtype=torch.int32, device=device)
+    self.counts = torch.zeros(4, **i32)
+    self.indptr = torch.zeros(S_cap + 1, **i32)
+    self.cols = torch.zeros(nnz_cap, **i32)
+    self.vals = torch.zeros(nnz_cap, dtype=torch.float32, device=device)
+    self.svals = torch.zeros(nnz_cap, dtype=torch.float32, device=device)
+    self.items = torch.zeros(self.n_cap, **i32)
+    self.pos = torch.full((self.n_items,), -1, **i32)
+    self.mark = torch.zeros(self.n_items, **i32)
+    self.bits_rc = torch.zeros(S_cap * self.ldw_rc, **i32)
+    self.bits_cr = torch.zeros((self.n_cap if need_bits_cr else 1) * self.ldw_cr, **i32)
+    self.scan_tmp = torch.zeros(self.n_chunks + 1, **i32)
+    self.stamp = 0
+    self.users = None      # int64 device tensor of the rows of the last collate
+    self.S = 0
+    self.c = RkBlock(
+        S_cap=S_cap, nnz_cap=nnz_cap, n_cap=self.n_cap, n_items=self.n_items,
+        ldw_rc=self.ldw_rc, ldw_cr=self.ldw_cr, n_chunks=self.n_chunks, reserved=0,
+        counts=ptr(self.counts), indptr=ptr(self.indptr), cols=ptr(self.cols),
+        vals=ptr(self.vals), svals=ptr(self.svals), items=ptr(self.items), pos=ptr(self.pos),
+        mark=ptr(self.mark), bits_rc=ptr(self.bits_rc), bits_cr=ptr(self.bits_cr),
+        scan_tmp=ptr(self.scan_tmp))
+    self.ref = ctypes.byref(self.c)
+
+  def collate(self, dcsr, users_dev, negative_sampling=None, phase=0):
+    """users_dev: int64 device tensor of user (row) ids of the group.
+    phase 0: whole collation; 1: rows + marking; 2: the rest (data parallel)."""
+    ns = self.negative_sampling if negative_sampling is None else bool(negative_sampling)
+    S = int(users_dev.numel())
+    assert users_dev.dtype == torch.int64 and users_dev.is_cuda
+    assert dcsr.n_items == self.n_items
+    if phase != 2:
+      self.stamp += 1
+      if self.stamp >= 2 ** 31 - 1:
+        self.mark.zero_()
+        self.stamp = 1
+    self.users, self.S = users_dev, S
+    lib = _lib.load()
+    check(lib.rk_collate(ptr(dcsr.indptr), ptr(dcsr.indices), ptr(dcsr.data), ptr(users_dev), S,
+                         1 if ns else 0, self.stamp, phase, self.ref, current_stream()),
+          "rk_collate")
+    return self
+
+  def set_items(self, items_dev_i32, n, S):
+    """Describe a target item set without interactions (predict path):
+    counts = (n, 0, round_up(n,32), S)."""
+    n = int(n)
+    assert n <= self.n_cap
+    self.items[:n].copy_(items_dev_i32[:n])
+    self.counts.copy_(torch.tensor([n, 0, cdiv(n, 32) * 32, S], dtype=torch.int32), non_blocking=False)
+    self.S = S
+
+  # ---- host views (synchronising; tests / API compatibility only) ----
+  def counts_host(self):
+    c = self.counts.cpu().numpy()
+    return int(c[0]), int(c[1]), int(c[2]), int(c[3])
+
+  def to_host(self):
+    n_b, nnz, ld, S = self.counts_host()
+    return dict(n_b=n_b, nnz=nnz, ld=ld, S=S,
+                indptr=self.indptr[:S + 1].cpu().numpy(),
+                cols=self.cols[:nnz].cpu().numpy(),
+                vals=self.vals[:nnz].cpu().numpy(),
+                items=self.items[:n_b].cpu().numpy().astype(np.int64),
+                pos=self.pos.cpu().numpy())

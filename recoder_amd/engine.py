@@ -1,0 +1,497 @@
+"""Fused training / inference step on the HIP kernels.
+
+``FusedEngine`` sequences the C-ABI calls that replace one iteration of the
+reference's hot loop (model.py:383-404): ``__compute_loss`` (model.py:454-485:
+densify -> model forward -> loss / B), ``loss.backward()`` and the
+``Adam`` / ``SparseAdam`` steps -- without densifying the batch and without a
+host synchronisation.  All arithmetic is in the HIP library; torch is used for
+device memory and streams only.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ACT, LOSS_BCE, LOSS_MNLL, LOSS_MSE, LOSS_NONE, check, ptr
+from .device import Block, cdiv, current_stream, require_gpu
+
+LOSS_IDS = {"mse": LOSS_MSE, "logistic": LOSS_BCE, "logloss": LOSS_MNLL}
+
+
+def _f32(x):
+  return float(np.float32(x))
+
+
+class ParamState:
+  """One trainable tensor + its Adam moments (tensors live in the
+  torch.optim state dict so checkpoints keep the reference layout)."""
+  __slots__ = ("name", "p", "m", "v", "step", "wd", "group", "sparse", "st")
+
+  def __init__(self, name, p, m, v, step, wd, group, sparse, st):
+    self.name, self.p, self.m, self.v = name, p, m, v
+    self.step, self.wd, self.group, self.sparse, self.st = step, wd, group, sparse, st
+
+
+class FusedEngine:
+  """Holds the workspaces for batches of up to ``B_cap`` rows x ``n_cap`` items."""
+
+  def __init__(self, model, kind, loss="mse", loss_params=None, device=None):
+    self.lib = _lib.load()
+    self.device = device or require_gpu()
+    self.model = model
+    self.kind = kind                       # 'ae' | 'mf'
+    if isinstance(loss, str):
+      if loss not in LOSS_IDS:
+        raise ValueError("Unknown loss function {}".format(loss))
+      self.loss_id = LOSS_IDS[loss]
+    else:
+      raise ValueError("the fused engine needs a named loss ('mse', 'logistic', 'logloss')")
+    self.confidence = float((loss_params or {}).get("confidence", 0))
+    self.act = ACT[model.activation_type]
+    self.B_cap = 0
+    self.n_cap = 0
+    self.seed = 0x5eed
+    self.rng_step = 0
+    self.states = {}                       # name -> ParamState
+    self.world_size = 1
+    self.allreduce = None                  # callable(list of tensors) for data parallel
+    if kind == "ae":
+      self.h = list(model.hidden_layers)
+      self.nl = len(self.h) - 1
+      if self.h[0] % 4 != 0:
+        raise ValueError("hidden_layers[0] must be a multiple of 4 (16-byte embedding rows)")
+    else:
+      self.h = [model.embedding_size]
+      self.nl = 0
+      if self.h[0] % 4 != 0:
+        raise ValueError("embedding_size must be a multiple of 4 (16-byte embedding rows)")
+
+  # ------------------------------------------------------------------ setup
+  def ensure_capacity(self, B_cap, n_cap):
+    if B_cap <= self.B_cap and n_cap <= self.n_cap:
+      return
+    B_cap, n_cap = max(B_cap, self.B_cap), max(n_cap, self.n_cap)
+    dev = self.device
+    f = dict(dtype=torch.float32, device=dev)
+    h0 = self.h[0]
+    ld_cap = cdiv(n_cap, 32) * 32
+    self.B_cap, self.n_cap, self.ld_cap = B_cap, n_cap, ld_cap
+    self.dO = torch.empty(B_cap * ld_cap, **f)
+    self.G_de = torch.empty(n_cap * h0, **f)
+    self.G_en = torch.empty(n_cap * h0, **f)
+    self.gb_de = torch.empty(n_cap, **f)
+    self.gb_en = torch.empty(h0, **f)
+    self.ws = torch.empty(self.lib.rk_dz_workspace_bytes(B_cap, h0) // 4, **f)
+    self.n_part = self.lib.rk_loss_partials(B_cap, n_cap)
+    self.loss_part = torch.zeros(self.n_part, **f)
+    self.loss_out = torch.zeros(1, **f)
+    # activations: enc[i] = output of encoder layer i (post activation), i = 0..nl
+    self.enc = [torch.empty(B_cap * self.h[i], **f) for i in range(self.nl + 1)]
+    self.denc = [torch.empty(B_cap * self.h[i], **f) for i in range(self.nl + 1)]
+    hb = self.h[-1]
+    self.bott = torch.empty(B_cap * hb, **f)         # post-dropout bottleneck
+    # dec[i] = output of decoder layer i (i = 0..nl-1); sizes reversed(h)[i+1]
+    rh = list(reversed(self.h))
+    self.dec = [torch.empty(B_cap * rh[i + 1], **f) for i in range(self.nl)]
+    self.ddec = [torch.empty(B_cap * rh[i + 1], **f) for i in range(self.nl)]
+    self.dbott = torch.empty(B_cap * hb, **f)
+    # gradients of the hidden Linear stack
+    if self.kind == "ae":
+      m = self.model
+      self.g_enc_w = [torch.empty_like(l.weight) for l in m.encoding_layers]
+      self.g_enc_b = [torch.empty_like(l.bias) for l in m.encoding_layers]
+      self.g_dec_w = [None if m.is_constrained else torch.empty_like(l.weight)
+                      for l in m.decoding_layers]
+      self.g_dec_b = [torch.empty_like(l.bias) for l in m.decoding_layers]
+    else:
+      self.pos_u = torch.full((self.model.num_users,), -1, dtype=torch.int32, device=dev)
+
+  # ------------------------------------------------------------- optimiser
+  def bind_optimizers(self, optimizer, sparse_optimizer):
+    """Create / adopt the Adam moment tensors inside the torch.optim state
+    (so ``optimizer.state_dict()`` has the reference layout, model.py:210)."""
+    self.states = {}
+    names = {id(p): n for n, p in self.model.named_parameters()}
+    for opt, is_sparse in ((optimizer, False), (sparse_optimizer, True)):
+      if opt is None:
+        continue
+      for group in opt.param_groups:
+        for p in group["params"]:
+          st = opt.state[p]
+          if "exp_avg" not in st:
+            st["step"] = torch.tensor(0.0)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+          else:
+            st["exp_avg"] = st["exp_avg"].to(p.device).contiguous()
+            st["exp_avg_sq"] = st["exp_avg_sq"].to(p.device).contiguous()
+          step = int(st["step"]) if not torch.is_tensor(st["step"]) else int(st["step"].item())
+          self.states[names[id(p)]] = ParamState(
+              names[id(p)], p, st["exp_avg"], st["exp_avg_sq"], step,
+              0.0 if is_sparse else float(group.get("weight_decay", 0.0)), group, is_sparse, st)
+
+  def sync_optimizer_steps(self):
+    """Write the host-side step counters back into the torch.optim state."""
+    for s in self.states.values():
+      s.st["step"] = torch.tensor(float(s.step))
+
+  def _adam_args(self, s):
+    g = s.group
+    b1, b2 = g["betas"]
+    return float(g["lr"]), float(b1), float(b2), float(g["eps"])
+
+  def _adam_table(self, s, pos, G, h, n_rows, stream):
+    s.step += 1
+    lr, b1, b2, eps = self._adam_args(s)
+    check(self.lib.rk_adam_table(ptr(s.p), ptr(s.m), ptr(s.v), n_rows, h, ptr(pos), ptr(G), lr, b1,
+                                 b2, eps, float(s.wd), s.step, stream), "rk_adam_table")
+
+  def _adam_rows(self, s, idx32, idx64, n_dev, n_cap, G, h, stream):
+    s.step += 1
+    lr, b1, b2, eps = self._adam_args(s)
+    check(self.lib.rk_adam_rows(ptr(s.p), ptr(s.m), ptr(s.v), h, ptr(idx32), ptr(idx64), ptr(n_dev),
+                                n_cap, ptr(G), lr, b1, b2, eps, s.step, stream), "rk_adam_rows")
+
+  def _adam_dense(self, s, g, stream):
+    s.step += 1
+    lr, b1, b2, eps = self._adam_args(s)
+    check(self.lib.rk_adam_dense(ptr(s.p), ptr(s.m), ptr(s.v), ptr(g), s.p.numel(), lr, b1, b2,
+                                 eps, float(s.wd), s.step, stream), "rk_adam_dense")
+
+  # --------------------------------------------------------------- forward
+  def _ae_forward(self, blk, row_off, B, keep_noise, keep_drop, train, stream):
+    m, lib = self.model, self.lib
+    p_noise = float(m.noise_prob) if train else 0.0
+    check(lib.rk_ae_encode_fwd(blk.ref, row_off, B, ptr(m.en_embedding_layer.weight),
+                               ptr(m.en_bias), self.h[0], ptr(keep_noise), p_noise, self.seed,
+                               self.rng_step, ptr(blk.users), self.act, ptr(self.enc[0]), stream),
+          "rk_ae_encode_fwd")
+    for i, layer in enumerate(m.encoding_layers):
+      check(lib.rk_linear_fwd(ptr(self.enc[i]), ptr(layer.weight), ptr(layer.bias), B, self.h[i + 1],
+                              self.h[i], 0, self.act, ptr(self.enc[i + 1]), stream), "rk_linear_fwd")
+    z = self.enc[self.nl]
+    self.drop_active = bool(train and m.dropout_prob > 0.0)
+    if self.drop_active:
+      n = B * self.h[-1]
+      self.bott[:n].copy_(z[:n])
+      check(lib.rk_dropout(ptr(self.bott), ptr(keep_drop), n, self.h[-1], float(m.dropout_prob),
+                           self.seed ^ 0xd0d0, self.rng_step, stream), "rk_dropout")
+      z = self.bott
+    self.dec_in = z
+    rh = list(reversed(self.h))
+    for i, layer in enumerate(m.decoding_layers):
+      if m.is_constrained:
+        w, wt = m.encoding_layers[self.nl - 1 - i].weight, 1
+      else:
+        w, wt = layer.weight, 0
+      check(lib.rk_linear_fwd(ptr(z), ptr(w), ptr(layer.bias), B, rh[i + 1], rh[i], wt, self.act,
+                              ptr(self.dec[i]), stream), "rk_linear_fwd")
+      z = self.dec[i]
+    return z
+
+  def _mf_forward(self, users, B, keep_drop, train, stream):
+    m, lib = self.model, self.lib
+    d = self.h[0]
+    check(lib.rk_gather_rows(ptr(m.user_embedding_layer.weight), ptr(users), B, d, self.act,
+                             ptr(self.enc[0]), stream), "rk_gather_rows")
+    z = self.enc[0]
+    self.drop_active = bool(train and m.dropout_prob > 0)
+    if self.drop_active:
+      n = B * d
+      self.bott[:n].copy_(z[:n])
+      check(lib.rk_dropout(ptr(self.bott), ptr(keep_drop), n, d, float(m.dropout_prob),
+                           self.seed ^ 0xd0d0, self.rng_step, stream), "rk_dropout")
+      z = self.bott
+    return z
+
+  def _decoder_params(self):
+    m = self.model
+    if self.kind == "ae":
+      return m.de_embedding_layer.weight, m.de_bias
+    return m.item_embedding_layer.weight, m.bias
+
+  def _loss(self, z, B, tgt, row_off, denom_rows, stream, out=None):
+    """decode + loss; leaves dLoss/dLogits in self.dO. Returns device scalar."""
+    lib = self.lib
+    W, b = self._decoder_params()
+    inv_B = _f32(np.float32(1.0) / np.float32(denom_rows))
+    out = self.loss_out if out is None else out
+    check(lib.rk_decode_loss(ptr(z), B, self.h[0], tgt.ref, row_off, ptr(W), ptr(b), self.loss_id,
+                             self.confidence, inv_B, ptr(self.dO), 0, ptr(self.loss_part), stream),
+          "rk_decode_loss")
+    if self.loss_id == LOSS_MNLL:
+      check(lib.rk_mnll_finish(ptr(self.dO), B, tgt.ref, row_off, inv_B, ptr(self.loss_part),
+                               stream), "rk_mnll_finish")
+      n_part = B
+    else:
+      n_part = cdiv(B, 128) * cdiv(tgt.n_cap, 128)
+    check(lib.rk_loss_reduce(ptr(self.loss_part), n_part, float(denom_rows), ptr(out), stream),
+          "rk_loss_reduce")
+    return out
+
+  # ------------------------------------------------------------------ steps
+  def compute_loss(self, blk, row_off, B, tgt=None, out=None):
+    """Evaluation-mode loss (model.py:439-452 ``_validate`` body)."""
+    self.ensure_capacity(B, max(blk.n_cap, tgt.n_cap if tgt is not None else 0))
+    stream = current_stream()
+    if self.kind == "ae":
+      z = self._ae_forward(blk, row_off, B, None, None, False, stream)
+    else:
+      z = self._mf_forward(blk.users[row_off:row_off + B], B, None, False, stream)
+    return self._loss(z, B, tgt if tgt is not None else blk, row_off, B, stream, out)
+
+  def train_step(self, blk, row_off, B, keep_noise=None, keep_drop=None, out=None,
+                 global_rows=None):
+    """One optimisation step on rows [row_off, row_off+B) of the collated
+    block (model.py:383-404).  ``global_rows`` = rows summed over all ranks
+    (data parallel); the loss/gradients are normalised by it."""
+    self.ensure_capacity(B, blk.n_cap)
+    lib, m = self.lib, self.model
+    stream = current_stream()
+    self.rng_step += 1
+    h0 = self.h[0]
+    rows = B if global_rows is None else global_rows
+    if self.kind == "ae":
+      z = self._ae_forward(blk, row_off, B, keep_noise, keep_drop, True, stream)
+    else:
+      users = blk.users[row_off:row_off + B]
+      z = self._mf_forward(users, B, keep_drop, True, stream)
+    loss = self._loss(z, B, blk, row_off, rows, stream, out)
+
+    # ---- backward through the decoder (nn.py:280) ----
+    W_de, _ = self._decoder_params()
+    simple = (self.kind == "ae" and self.nl == 0 and not self.drop_active)
+    dz = self.denc[0] if simple else self.dbott
+    if self.kind == "ae" and self.nl > 0:
+      dz = self.ddec[self.nl - 1]
+    check(lib.rk_decode_bwd_dz(ptr(self.dO), B, h0, blk.ref, ptr(W_de),
+                               ptr(self.enc[0]) if simple else None, self.act, ptr(dz),
+                               ptr(self.ws), stream), "rk_decode_bwd_dz")
+    check(lib.rk_decode_bwd_dw(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(self.G_de),
+                               ptr(self.gb_de), stream), "rk_decode_bwd_dw")
+
+    if self.kind == "ae":
+      rh = list(reversed(self.h))
+      # decoder Linear stack, last to first
+      for i in range(self.nl - 1, -1, -1):
+        layer = m.decoding_layers[i]
+        x = self.dec[i - 1] if i > 0 else self.dec_in
+        dx = self.ddec[i - 1] if i > 0 else self.dbott
+        if m.is_constrained:
+          j = self.nl - 1 - i
+          w, wt, gw, acc = m.encoding_layers[j].weight, 1, self.g_enc_w[j], 0
+        else:
+          w, wt, gw, acc = layer.weight, 0, self.g_dec_w[i], 0
+        check(lib.rk_linear_bwd(ptr(self.ddec[i]), ptr(self.dec[i]), ptr(x), ptr(w), B, rh[i + 1],
+                                rh[i], wt, self.act, ptr(dx), ptr(gw), acc, ptr(self.g_dec_b[i]),
+                                stream), "rk_linear_bwd")
+      if self.nl > 0 or self.drop_active:
+        # gradient w.r.t. the bottleneck activation: undo dropout, into denc[nl]
+        n = B * self.h[-1]
+        if self.drop_active:
+          check(lib.rk_dropout(ptr(self.dbott), ptr(keep_drop), n, self.h[-1],
+                               float(m.dropout_prob), self.seed ^ 0xd0d0, self.rng_step, stream),
+                "rk_dropout")
+        self.denc[self.nl][:n].copy_(self.dbott[:n])
+      # encoder Linear stack, last to first
+      for i in range(self.nl - 1, -1, -1):
+        layer = m.encoding_layers[i]
+        check(lib.rk_linear_bwd(ptr(self.denc[i + 1]), ptr(self.enc[i + 1]), ptr(self.enc[i]),
+                                ptr(layer.weight), B, self.h[i + 1], self.h[i], 0, self.act,
+                                ptr(self.denc[i]), ptr(self.g_enc_w[i]),
+                                1 if m.is_constrained else 0, ptr(self.g_enc_b[i]), stream),
+              "rk_linear_bwd")
+      if not simple:
+        check(lib.rk_act_grad(ptr(self.denc[0]), ptr(self.enc[0]), B * h0, self.act, stream),
+              "rk_act_grad")
+      check(lib.rk_colsum(ptr(self.denc[0]), B, h0, h0, None, ptr(self.gb_en), stream), "rk_colsum")
+      tied = bool(m.is_constrained)
+      G_en = self.G_de if tied else self.G_en
+      check(lib.rk_ae_encode_bwd(blk.ref, row_off, B, ptr(self.denc[0]), h0, ptr(G_en),
+                                 1 if tied else 0, stream), "rk_ae_encode_bwd")
+    else:
+      # MF: gradient of the gathered user rows = dU * act'(U) (after dropout)
+      n = B * h0
+      if self.drop_active:
+        check(lib.rk_dropout(ptr(self.dbott), ptr(keep_drop), n, h0, float(m.dropout_prob),
+                             self.seed ^ 0xd0d0, self.rng_step, stream), "rk_dropout")
+      check(lib.rk_act_grad(ptr(self.dbott), ptr(self.enc[0]), n, self.act, stream), "rk_act_grad")
+
+    if self.allreduce is not None:
+      self._allreduce_grads(blk, B)
+    self._apply_updates(blk, row_off, B, stream)
+    return loss
+
+  # ------------------------------------------------------- data parallelism
+  def _grad_tensors(self):
+    ts = [self.G_de, self.gb_de, self.loss_out]
+    if self.kind == "ae":
+      m = self.model
+      if not m.is_constrained:
+        ts.append(self.G_en)
+      ts.append(self.gb_en)
+      ts += self.g_enc_w + self.g_enc_b + [g for g in self.g_dec_w if g is not None] + self.g_dec_b
+    return ts
+
+  def _allreduce_grads(self, blk, B):
+    self.allreduce(self._grad_tensors(), blk)
+
+  # ---------------------------------------------------------------- updates
+  def _apply_updates(self, blk, row_off, B, stream):
+    m, S = self.model, self.states
+    h0 = self.h[0]
+    n_items = blk.n_items
+
+    def table(name, G):
+      s = S[name]
+      if s.sparse:
+        self._adam_rows(s, blk.items, None, blk.counts, blk.n_cap, G, h0, stream)
+      else:
+        self._adam_table(s, blk.pos, G, h0, n_items, stream)
+
+    if self.kind == "ae":
+      from .nn import DynamicAutoencoder  # noqa: F401  (names below follow its state dict)
+      en_w = "en_embedding_layer.weight"
+      if m.is_constrained:
+        table(en_w, self.G_de)
+      else:
+        table(en_w, self.G_en)
+        table("de_embedding_layer.weight", self.G_de)
+      self._adam_dense(S["_DynamicAutoencoder__en_linear_embedding_layer.bias"], self.gb_en, stream)
+      for i in range(self.nl):
+        self._adam_dense(S["encoding_layers.%d.weight" % i], self.g_enc_w[i], stream)
+        self._adam_dense(S["encoding_layers.%d.bias" % i], self.g_enc_b[i], stream)
+        if not m.is_constrained:
+          self._adam_dense(S["decoding_layers.%d.weight" % i], self.g_dec_w[i], stream)
+        self._adam_dense(S["decoding_layers.%d.bias" % i], self.g_dec_b[i], stream)
+      # decoder bias: a dense [n_items] gradient (index_select backward), wd = 0
+      self._adam_table(S["_DynamicAutoencoder__de_linear_embedding_layer.bias"], blk.pos,
+                       self.gb_de, 1, n_items, stream)
+    else:
+      lib = self.lib
+      users = blk.users[row_off:row_off + B]
+      su = S["user_embedding_layer.weight"]
+      if su.sparse:
+        self._adam_rows(su, None, users, None, B, self.dbott, h0, stream)
+      else:
+        check(lib.rk_scatter_pos(ptr(self.pos_u), ptr(users), B, 0, stream), "rk_scatter_pos")
+        self._adam_table(su, self.pos_u, self.dbott, h0, m.num_users, stream)
+        check(lib.rk_scatter_pos(ptr(self.pos_u), ptr(users), B, 1, stream), "rk_scatter_pos")
+      table("item_embedding_layer.weight", self.G_de)
+      self._adam_table(S["bias"], blk.pos, self.gb_de, 1, n_items, stream)
+
+  # ------------------------------------------------------------- inference
+  def predict_scores(self, blk, row_off, B, out, ld_out, tgt_items_blk):
+    """Logits for rows of ``blk`` against the item set of ``tgt_items_blk``
+    (model.py:487-511 with input_items=None: the whole catalogue)."""
+    self.ensure_capacity(B, max(blk.n_cap, tgt_items_blk.n_cap))
+    stream = current_stream()
+    if self.kind == "ae":
+      z = self._ae_forward(blk, row_off, B, None, None, False, stream)
+    else:
+      z = self._mf_forward(blk.users[row_off:row_off + B], B, None, False, stream)
+    W, b = self._decoder_params()
+    check(self.lib.rk_decode_loss(ptr(z), B, self.h[0], tgt_items_blk.ref, 0, ptr(W), ptr(b),
+                                  LOSS_NONE, 0.0, 1.0, ptr(out), ld_out, None, stream),
+          "rk_decode_loss")
+    return out
+
+
+# ----------------------------------------------------------------------------
+# dense-input forward of the nn modules (API compatibility: nn.py:228-253,
+# 344-362); builds a block from the dense tensor and runs the same kernels.
+# ----------------------------------------------------------------------------
+class _DenseCSR:
+  def __init__(self, x):
+    B, n = x.shape
+    nzmask = x != 0
+    counts = nzmask.sum(dim=1)
+    self.indptr = torch.zeros(B + 1, dtype=torch.int64, device=x.device)
+    self.indptr[1:] = torch.cumsum(counts, 0)
+    idx = nzmask.nonzero(as_tuple=False)
+    self.indices = idx[:, 1].to(torch.int32).contiguous()
+    self.data = x[nzmask].to(torch.float32).contiguous()
+    self.nnz = int(self.indices.numel())
+    if self.nnz == 0:
+      self.indices = torch.zeros(1, dtype=torch.int32, device=x.device)
+      self.data = torch.zeros(1, dtype=torch.float32, device=x.device)
+    self.shape = (B, n)
+    self.n_items = n
+
+
+def _items_block(items_i32, n, n_items, B, device):
+  blk = Block(B, 1, n_items, device, negative_sampling=False, need_bits_cr=False) \
+      if items_i32 is None else Block(B, max(1, n), max(n_items, n), device, negative_sampling=True,
+                                      need_bits_cr=False)
+  if items_i32 is None:
+    ar = torch.arange(n_items, dtype=torch.int32, device=device)
+    blk.set_items(ar, n_items, B)
+  else:
+    blk.set_items(items_i32, n, B)
+  return blk
+
+
+def _model_engine(model, kind):
+  eng = getattr(model, "_rk_engine", None)
+  if eng is None:
+    eng = FusedEngine(model, kind, "mse", None)
+    object.__setattr__(model, "_rk_engine", eng)
+  return eng
+
+
+@torch.no_grad()
+def ae_dense_forward(model, x, input_items=None, target_items=None):
+  dev = require_gpu()
+  x = x.to(dev, torch.float32).contiguous()
+  B, n_in = x.shape
+  dcsr = _DenseCSR(x)
+  blk = Block(B, max(1, dcsr.nnz), n_in, dev, negative_sampling=False, need_bits_cr=False)
+  users = torch.arange(B, dtype=torch.int64, device=dev)
+  blk.collate(dcsr, users, negative_sampling=False)
+  if input_items is not None:
+    blk.items[:n_in].copy_(input_items.to(dev).to(torch.int32))
+  n_items = model.num_items
+  if target_items is not None:
+    t = target_items.to(dev).to(torch.int32).contiguous()
+    tblk = _items_block(t, int(t.numel()), n_items, B, dev)
+    n_t = int(t.numel())
+  else:
+    tblk = _items_block(None, n_items, n_items, B, dev)
+    n_t = n_items
+  eng = _model_engine(model, "ae")
+  train = model.training
+  eng.ensure_capacity(B, max(blk.n_cap, tblk.n_cap))
+  stream = current_stream()
+  eng.rng_step += 1
+  z = eng._ae_forward(blk, 0, B, None, None, train, stream)
+  W, b = eng._decoder_params()
+  out = torch.empty(B, n_t, dtype=torch.float32, device=dev)
+  check(eng.lib.rk_decode_loss(ptr(z), B, eng.h[0], tblk.ref, 0, ptr(W), ptr(b), LOSS_NONE, 0.0, 1.0,
+                               ptr(out), n_t, None, stream), "rk_decode_loss")
+  return out
+
+
+@torch.no_grad()
+def mf_dense_forward(model, input_users, target_items=None):
+  dev = require_gpu()
+  users = input_users.to(dev).to(torch.int64).contiguous()
+  B = int(users.numel())
+  n_items = model.num_items
+  if target_items is not None:
+    t = target_items.to(dev).to(torch.int32).contiguous()
+    tblk = _items_block(t, int(t.numel()), n_items, B, dev)
+    n_t = int(t.numel())
+  else:
+    tblk = _items_block(None, n_items, n_items, B, dev)
+    n_t = n_items
+  eng = _model_engine(model, "mf")
+  eng.ensure_capacity(B, tblk.n_cap)
+  stream = current_stream()
+  eng.rng_step += 1
+  z = eng._mf_forward(users, B, None, model.training, stream)
+  W, b = eng._decoder_params()
+  out = torch.empty(B, n_t, dtype=torch.float32, device=dev)
+  check(eng.lib.rk_decode_loss(ptr(z), B, eng.h[0], tblk.ref, 0, ptr(W), ptr(b), LOSS_NONE, 0.0, 1.0,
+                               ptr(out), n_t, None, stream), "rk_decode_loss")
+  return out

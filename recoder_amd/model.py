@@ -1,0 +1,492 @@
+"""``Recoder``: the reference's trainer API (recoder/model.py:22-559) on the
+MI355X hot path.
+
+Same constructor, ``train`` signature, public attributes, checkpoint dict and
+error behaviour as the reference; the body of the hot loop
+(model.py:383-404) is ``FusedEngine.train_step`` (HIP kernels) over batches
+collated on the device, with no per-step host synchronisation: the per-step
+losses are left in a device buffer and read once per epoch.
+
+Two hooks exist because a GPU cannot reproduce the reference's CPU RNG streams
+(SURVEY section 7 "RNG parity"):
+  ``user_order_hook(epoch, n_users) -> int64 array | None``  the user order of
+      an epoch (default: the same draw ``RandomSampler`` makes from the global
+      torch RNG, so noise-free runs reproduce the reference's order);
+  ``mask_hook(step, users, nnz) -> (keep_noise | None, keep_drop | None)``
+      explicit dropout keep-masks for a sampling group (default: counter RNG).
+"""
+import logging
+import os
+
+import numpy as np
+import torch
+import torch.optim as optim
+from torch.optim.lr_scheduler import MultiStepLR
+
+from . import __version__
+from .data import (BatchCollator, RecommendationDataLoader, RecommendationDataset,
+                   epoch_user_order)
+from .device import Block, DeviceCSR, require_gpu
+from .engine import FusedEngine
+from .losses import MSELoss, MultinomialNLLLoss
+from .metrics import RecommenderEvaluator
+from .nn import DynamicAutoencoder, FactorizationModel, MatrixFactorization
+from .recommender import InferenceRecommender
+
+log = logging.getLogger("recoder_amd")
+
+
+def _top_sum(degrees, k):
+  d = np.asarray(degrees)
+  if len(d) <= k:
+    return int(d.sum())
+  return int(np.partition(d, len(d) - k)[len(d) - k:].sum())
+
+
+class Recoder(object):
+  """Trains / evaluates a :class:`recoder_amd.nn.FactorizationModel`
+  (arguments as model.py:26-47)."""
+
+  def __init__(self, model: FactorizationModel, num_items=None, num_users=None,
+               optimizer_type="sgd", loss="mse", loss_params=None, use_cuda=False,
+               user_based=True, item_based=True):
+    self.model = model
+    self.num_items = num_items
+    self.num_users = num_users
+    self.optimizer_type = optimizer_type
+    self.loss = loss
+    self.loss_params = loss_params if loss_params else {}
+    self.use_cuda = use_cuda
+    self.user_based = user_based
+    self.item_based = item_based
+    # this build has exactly one device: the MI355X PyTorch-ROCm exposes as
+    # 'cuda'.  use_cuda is kept for signature compatibility.
+    self.device = torch.device("cuda")
+    self.optimizer = None
+    self.sparse_optimizer = None
+    self.current_epoch = 1
+    self.items = None
+    self.users = None
+    self.user_order_hook = None
+    self.mask_hook = None
+    self.last_epoch_losses = None
+    self.loss_history = []      # per-epoch arrays of the per-step training losses
+    self.__model_initialized = False
+    self.__optimizer_state_dict = None
+    self.__sparse_optimizer_state_dict = None
+    self.__engine = None
+    self._dist = None        # (rank, world_size) when data parallel
+
+  # ------------------------------------------------------------------ init
+  def __init_model(self):
+    if self.__model_initialized:
+      return
+    require_gpu()
+    self.model.init_model(self.num_items, self.num_users)
+    self.model = self.model.to(device=self.device)
+    self.__model_initialized = True
+
+  def _fused_kind(self):
+    if isinstance(self.model, DynamicAutoencoder):
+      return "ae"
+    if isinstance(self.model, MatrixFactorization):
+      return "mf"
+    raise NotImplementedError(
+        "only DynamicAutoencoder and MatrixFactorization have HIP kernels; user-defined "
+        "FactorizationModel subclasses are outside this build's hot path")
+
+  def __init_loss_module(self):
+    """model.py:87-99 -- same names, same errors."""
+    if issubclass(self.loss.__class__, torch.nn.Module):
+      if isinstance(self.loss, MSELoss):
+        self._loss_name, self._loss_params = "mse", {"confidence": self.loss.confidence}
+      elif isinstance(self.loss, MultinomialNLLLoss):
+        self._loss_name, self._loss_params = "logloss", {}
+      elif isinstance(self.loss, torch.nn.BCEWithLogitsLoss):
+        self._loss_name, self._loss_params = "logistic", {}
+      else:
+        raise NotImplementedError(
+            "arbitrary loss modules are outside this build's fused hot path; use 'mse', "
+            "'logistic', 'logloss' or recoder_amd.losses.MSELoss / MultinomialNLLLoss")
+    elif self.loss == "logistic":
+      self._loss_name, self._loss_params = "logistic", dict(self.loss_params)
+    elif self.loss == "mse":
+      self._loss_name, self._loss_params = "mse", dict(self.loss_params)
+    elif self.loss == "logloss":
+      self._loss_name, self._loss_params = "logloss", {}
+    elif self.loss is None:
+      raise ValueError("No loss function defined")
+    else:
+      raise ValueError("Unknown loss function {}".format(self.loss))
+    self.loss_module = self.loss
+
+  def __init_optimizer(self, lr, weight_decay):
+    """model.py:101-164: dense / sparse parameter split, one group per tensor,
+    no weight decay on biases."""
+    if self.optimizer is not None:
+      self._engine().sync_optimizer_steps()
+      self.__optimizer_state_dict = self.optimizer.state_dict()
+    if self.sparse_optimizer is not None:
+      self._engine().sync_optimizer_steps()
+      self.__sparse_optimizer_state_dict = self.sparse_optimizer.state_dict()
+
+    sparse_params_names = []
+    sparse_modules = [torch.nn.Embedding, torch.nn.EmbeddingBag]
+    for module_name, module in self.model.named_modules():
+      if type(module) in sparse_modules and module.sparse:
+        sparse_params_names.extend([module_name + "." + n for n, _ in module.named_parameters()])
+
+    params, sparse_params = [], []
+    for param_name, param in self.model.named_parameters():
+      wd = 0 if "bias" in param_name else weight_decay
+      group = {"params": param, "weight_decay": wd}
+      (sparse_params if param_name in sparse_params_names else params).append(group)
+
+    if self.optimizer_type == "adam":
+      if len(params) > 0:
+        self.optimizer = optim.Adam(params, lr=lr)
+      if len(sparse_params) > 0:
+        self.sparse_optimizer = optim.SparseAdam(sparse_params, lr=lr)
+    elif self.optimizer_type in ("adagrad", "sgd", "rmsprop"):
+      if len(sparse_params) > 0:
+        raise ValueError("Sparse gradients optimization not supported with {}"
+                         .format(self.optimizer_type))
+      raise NotImplementedError(
+          "optimizer_type='{}' has no HIP kernel in this build (the hot path is Adam / "
+          "SparseAdam, model.py:135,138)".format(self.optimizer_type))
+    else:
+      raise Exception("Unknown optimizer kind")
+
+    if self.__optimizer_state_dict is not None and self.optimizer is not None:
+      self.optimizer.load_state_dict(self.__optimizer_state_dict)
+      self.__optimizer_state_dict = None
+    if self.__sparse_optimizer_state_dict is not None and self.sparse_optimizer is not None:
+      self.sparse_optimizer.load_state_dict(self.__sparse_optimizer_state_dict)
+      self.__sparse_optimizer_state_dict = None
+    self._engine().bind_optimizers(self.optimizer, self.sparse_optimizer)
+
+  def _engine(self):
+    if self.__engine is None:
+      self.__init_loss_module()
+      self.__engine = FusedEngine(self.model, self._fused_kind(), self._loss_name,
+                                  self._loss_params, self.device)
+    return self.__engine
+
+  # ------------------------------------------------------------ checkpoint
+  def init_from_model_file(self, model_file):
+    """model.py:166-191."""
+    log.info("Loading model from: {}".format(model_file))
+    if not os.path.isfile(model_file):
+      raise Exception("No state file found in {}".format(model_file))
+    st = torch.load(model_file, map_location="cpu", weights_only=False)
+    model_params = st["model_params"]
+    self.current_epoch = st["last_epoch"]
+    self.loss = st.get("loss", self.loss)
+    self.loss_params = st.get("loss_params", self.loss_params)
+    self.optimizer_type = st["optimizer_type"]
+    self.items = st.get("items", None)
+    self.users = st.get("users", None)
+    self.num_items = st.get("num_items", None)
+    self.num_users = st.get("num_users", None)
+    self.__optimizer_state_dict = st["optimizer"]
+    self.__sparse_optimizer_state_dict = st.get("sparse_optimizer", None)
+    self.model.load_model_params(model_params)
+    self.__init_model()
+    self.model.load_state_dict(st["model"])
+
+  def save_state(self, model_checkpoint_prefix):
+    """model.py:193-224 (same dict; like the reference the sparse optimizer's
+    state is not written)."""
+    checkpoint_file = "{}_epoch_{}.model".format(model_checkpoint_prefix, self.current_epoch)
+    log.info("Saving model to {}".format(checkpoint_file))
+    if self.__engine is not None:
+      self.__engine.sync_optimizer_steps()
+    current_state = {
+      "recoder_version": __version__,
+      "model_params": self.model.model_params(),
+      "last_epoch": self.current_epoch,
+      "model": self.model.state_dict(),
+      "optimizer_type": self.optimizer_type,
+      "optimizer": self.optimizer.state_dict(),
+      "items": self.items,
+      "users": self.users,
+      "num_items": self.num_items,
+      "num_users": self.num_users,
+    }
+    if type(self.loss) is str:
+      current_state["loss"] = self.loss
+      current_state["loss_params"] = self.loss_params
+    torch.save(current_state, checkpoint_file)
+    return checkpoint_file
+
+  # --------------------------------------------------------------- training
+  def __init_training(self, train_dataset, lr, weight_decay):
+    """model.py:226-254."""
+    if self.items is None:
+      self.items = train_dataset.items
+    else:
+      self.items = np.unique(np.append(self.items, train_dataset.items))
+    if self.users is None:
+      self.users = train_dataset.users
+    else:
+      self.users = np.unique(np.append(self.users, train_dataset.users))
+
+    if self.item_based and self.num_items is None:
+      self.num_items = int(np.max(self.items)) + 1
+    elif self.item_based:
+      assert self.num_items >= int(np.max(self.items)) + 1, \
+        "The largest item id should be smaller than number of items." \
+        "If your model is not based on items, set item_based to False in Recoder constructor."
+    if self.user_based and self.num_users is None:
+      self.num_users = int(np.max(self.users)) + 1
+    elif self.user_based:
+      assert self.num_users >= int(np.max(self.users)) + 1, \
+        "The largest user id should be smaller than number of users." \
+        "If your model is not based on users, set user_based to False in Recoder constructor."
+
+    self.__init_model()
+    self.__init_loss_module()
+    self.__init_optimizer(lr=lr, weight_decay=weight_decay)
+
+  def train(self, train_dataset, val_dataset=None, lr=0.001, weight_decay=0, num_epochs=1,
+            iters_per_epoch=None, batch_size=64, lr_milestones=None, negative_sampling=False,
+            num_sampling_users=0, num_data_workers=0, model_checkpoint_prefix=None,
+            checkpoint_freq=0, eval_freq=0, eval_num_recommendations=None, eval_num_users=None,
+            metrics=None, eval_batch_size=None):
+    """Trains the model (arguments as model.py:256-289)."""
+    log.info("GPU Mode (MI355X / HIP)")
+    for k, v in self.model.model_params().items():
+      log.info("Model {}: {}".format(k, v))
+    log.info("lr {} wd {} batch {} optimizer {} milestones {} loss {}".format(
+        lr, weight_decay, batch_size, self.optimizer_type, lr_milestones, self.loss))
+
+    if num_sampling_users == 0:
+      num_sampling_users = batch_size
+    if eval_batch_size is None:
+      eval_batch_size = batch_size
+    assert num_sampling_users >= batch_size and num_sampling_users % batch_size == 0, \
+      "number of sampling users should be a multiple of the batch size"
+
+    self.__init_training(train_dataset=train_dataset, lr=lr, weight_decay=weight_decay)
+
+    train_dataloader = RecommendationDataLoader(train_dataset, batch_size=batch_size,
+                                                negative_sampling=negative_sampling,
+                                                num_sampling_users=num_sampling_users,
+                                                num_workers=num_data_workers)
+    if val_dataset is not None:
+      val_dataloader = RecommendationDataLoader(val_dataset, batch_size=batch_size,
+                                                negative_sampling=negative_sampling,
+                                                num_sampling_users=num_sampling_users,
+                                                num_workers=num_data_workers)
+    else:
+      val_dataloader = None
+
+    if lr_milestones is not None:
+      _last_epoch = -1 if self.current_epoch == 1 else (self.current_epoch - 2)
+      if _last_epoch != -1:
+        for g in self.optimizer.param_groups:
+          g.setdefault("initial_lr", lr)
+      lr_scheduler = MultiStepLR(self.optimizer, milestones=lr_milestones, gamma=0.1,
+                                 last_epoch=_last_epoch)
+    else:
+      lr_scheduler = None
+
+    self._train(train_dataloader=train_dataloader, val_dataloader=val_dataloader,
+                num_epochs=num_epochs, current_epoch=self.current_epoch,
+                lr_scheduler=lr_scheduler, batch_size=batch_size,
+                model_checkpoint_prefix=model_checkpoint_prefix,
+                checkpoint_freq=checkpoint_freq, eval_freq=eval_freq, metrics=metrics,
+                eval_num_recommendations=eval_num_recommendations,
+                iters_per_epoch=iters_per_epoch, eval_num_users=eval_num_users,
+                eval_batch_size=eval_batch_size)
+
+  def _make_block(self, dcsr, S, negative_sampling):
+    nnz_cap = max(1, _top_sum(dcsr.degrees, S))
+    return Block(S, nnz_cap, dcsr.n_items, self.device, negative_sampling=negative_sampling)
+
+  def _step_generator(self, dataloader):
+    """Yields (blk, row_off, B, keep_noise, keep_drop) for one pass over the
+    dataset: the device-side equivalent of iterating the reference's
+    RecommendationDataLoader (data.py:138-144)."""
+    ds = dataloader.dataset
+    dcsr = ds.device_csr()
+    B, S = dataloader.batch_size, dataloader.num_sampling_users
+    blk = getattr(self, "_train_blk", None)
+    if blk is None or blk.S_cap < S or blk.n_items != dcsr.n_items or \
+        blk.negative_sampling != dataloader.negative_sampling:
+      blk = self._make_block(dcsr, S, dataloader.negative_sampling)
+      self._train_blk = blk
+    n = len(ds)
+    order = None
+    if self.user_order_hook is not None:
+      order = self.user_order_hook(self.current_epoch, n)
+    if order is None:
+      order = epoch_user_order(n)
+    order_dev = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int64)).to(self.device)
+    for off in range(0, n, S):
+      users = order_dev[off:off + S]
+      blk.collate(dcsr, users)
+      Sg = int(users.numel())
+      keep_noise = keep_drop = None
+      if self.mask_hook is not None:
+        keep_noise, keep_drop = self.mask_hook(self._global_step, order[off:off + S])
+      for r in range(0, Sg, B):
+        rows = min(B, Sg - r)
+        kd = None
+        if keep_drop is not None:
+          kd = keep_drop[r:r + rows].contiguous()
+        yield blk, r, rows, keep_noise, kd
+
+  def _train(self, train_dataloader, val_dataloader, num_epochs, current_epoch, lr_scheduler,
+             batch_size, model_checkpoint_prefix, checkpoint_freq, eval_freq, metrics,
+             eval_num_recommendations, iters_per_epoch, eval_num_users, eval_batch_size):
+    """model.py:349-437."""
+    engine = self._engine()
+    num_batches = len(train_dataloader)
+    iters_processed = 0
+    if iters_per_epoch is None:
+      iters_per_epoch = num_batches
+    self._global_step = getattr(self, "_global_step", 0)
+    loss_buf = torch.zeros(max(1, min(iters_per_epoch, num_batches)), dtype=torch.float32,
+                           device=self.device)
+    iterator = None
+    for epoch in range(current_epoch, num_epochs + 1):
+      self.current_epoch = epoch
+      self.model.train()
+      if lr_scheduler is not None:
+        lr_scheduler.step()     # at epoch start, as model.py:364-366
+      if iters_processed == 0 or iters_processed == num_batches:
+        iters_processed = 0
+        iterator = enumerate(self._step_generator(train_dataloader), 1)
+      iters_to_process = min(iters_per_epoch, num_batches - iters_processed)
+      iters_processed += iters_to_process
+
+      n_done = 0
+      for batch_itr, (blk, row_off, rows, keep_noise, keep_drop) in iterator:
+        engine.train_step(blk, row_off, rows, keep_noise, keep_drop,
+                          out=loss_buf[n_done:n_done + 1])
+        n_done += 1
+        self._global_step += 1
+        if batch_itr % iters_per_epoch == 0:
+          break
+      # one device->host read per epoch instead of loss.item() per step (model.py:404)
+      self.last_epoch_losses = loss_buf[:n_done].cpu().numpy().copy()
+      self.loss_history.append(self.last_epoch_losses)
+      postfix = {"loss": float(self.last_epoch_losses[-1]) if n_done else float("nan")}
+      if eval_freq > 0 and epoch % eval_freq == 0 and val_dataloader is not None:
+        postfix["val_loss"] = self._validate(val_dataloader)
+        if metrics is not None and eval_num_recommendations is not None:
+          results = self._evaluate(val_dataloader.dataset,
+                                   num_recommendations=eval_num_recommendations,
+                                   metrics=metrics, batch_size=eval_batch_size,
+                                   num_users=eval_num_users)
+          for metric in results:
+            postfix[str(metric)] = np.mean(results[metric])
+      log.info("Epoch {}/{} {}".format(epoch, num_epochs, postfix))
+      self.last_epoch_summary = postfix
+      if model_checkpoint_prefix and \
+          ((checkpoint_freq > 0 and epoch % checkpoint_freq == 0) or epoch == num_epochs):
+        self.save_state(model_checkpoint_prefix)
+
+  def _validate(self, val_dataloader):
+    """model.py:439-452: mean over batches of the eval-mode loss; input and
+    target are collated independently (different item sets)."""
+    self.model.eval()
+    engine = self._engine()
+    ds = val_dataloader.dataset
+    dcsr = ds.device_csr()
+    dcsr_t = ds.device_target_csr()
+    B, S = val_dataloader.batch_size, val_dataloader.num_sampling_users
+    ns = val_dataloader.negative_sampling
+    blk = self._make_block(dcsr, S, ns)
+    blk_t = self._make_block(dcsr_t, S, ns) if dcsr_t is not None else None
+    n = len(ds)
+    order = None
+    if self.user_order_hook is not None:
+      order = self.user_order_hook(-1, n)
+    if order is None:
+      order = epoch_user_order(n)
+    order_dev = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int64)).to(self.device)
+    nb = int(np.ceil(n / B)) if n else 1
+    buf = torch.zeros(max(1, nb), dtype=torch.float32, device=self.device)
+    k = 0
+    for off in range(0, n, S):
+      users = order_dev[off:off + S]
+      blk.collate(dcsr, users)
+      if blk_t is not None:
+        blk_t.collate(dcsr_t, users)
+      Sg = int(users.numel())
+      for r in range(0, Sg, B):
+        rows = min(B, Sg - r)
+        engine.compute_loss(blk, r, rows, tgt=blk_t, out=buf[k:k + 1])
+        k += 1
+    total = float(buf[:k].double().sum().item()) if k else 0.0
+    return total / max(1, k)
+
+  # -------------------------------------------------------------- inference
+  def predict(self, users_interactions, return_input=False):
+    """model.py:487-511.  Returns ``(output, input_dense)`` -- like the
+    reference, always a tuple (its ``return output, input if .. else output``
+    precedence quirk); when return_input is False the second element is the
+    output again."""
+    if self.model is None:
+      raise Exception("Model not initialized.")
+    self.model.eval()
+    out, blk, B = self._predict_scores(users_interactions)
+    if return_input:
+      m = users_interactions.interactions_matrix
+      dense = torch.from_numpy(np.asarray(m.todense(), dtype=np.float32)).to(self.device)
+      return out, dense
+    return out, out
+
+  def _predict_scores(self, users_interactions):
+    engine = self._engine()
+    m = users_interactions.interactions_matrix
+    B = m.shape[0]
+    n_items = self.num_items if self.num_items is not None else m.shape[1]
+    dcsr = DeviceCSR(m, self.device)
+    assert dcsr.n_items <= n_items
+    if dcsr.n_items != n_items:
+      dcsr.shape = (B, n_items)
+    blk = Block(B, max(1, dcsr.nnz), n_items, self.device, negative_sampling=False,
+                need_bits_cr=False)
+    rows = torch.arange(B, dtype=torch.int64, device=self.device)
+    blk.collate(dcsr, rows, negative_sampling=False)
+    # MF looks user rows up by their global ids
+    blk.users = torch.as_tensor(np.asarray(users_interactions.users), dtype=torch.int64) \
+        .to(self.device)
+    ld = blk.ld_cap
+    out = torch.empty(B, ld, dtype=torch.float32, device=self.device)
+    engine.predict_scores(blk, 0, B, out, ld, blk)
+    return out[:, :n_items], blk, B
+
+  def _evaluate(self, eval_dataset, num_recommendations, metrics, batch_size=1, num_users=None):
+    """model.py:513-523."""
+    if self.model is None:
+      raise Exception("Model not initialized")
+    self.model.eval()
+    recommender = InferenceRecommender(self, num_recommendations)
+    evaluator = RecommenderEvaluator(recommender, metrics)
+    return evaluator.evaluate(eval_dataset, batch_size=batch_size, num_users=num_users)
+
+  def recommend(self, users_interactions, num_recommendations):
+    """model.py:525-544: scores with the seen items at -inf, top-k sorted."""
+    self.model.eval()
+    out, blk, B = self._predict_scores(users_interactions)
+    n_items = out.shape[1]
+    k = int(num_recommendations)
+    idx = torch.empty(B, k, dtype=torch.int64, device=self.device)
+    from . import _lib
+    from .device import current_stream
+    _lib.check(_lib.load().rk_topk_masked(out.data_ptr(), B, n_items, out.stride(0), blk.ref, 0, k,
+                                          idx.data_ptr(), None, current_stream()),
+               "rk_topk_masked")
+    return idx.cpu().tolist()
+
+  def evaluate(self, eval_dataset, num_recommendations, metrics, batch_size=1, num_users=None):
+    """model.py:546-559."""
+    results = self._evaluate(eval_dataset, num_recommendations, metrics, batch_size=batch_size,
+                             num_users=num_users)
+    for metric in results:
+      log.info("{}: {}".format(metric, np.mean(results[metric])))
+    return results
