@@ -1,0 +1,281 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: training users/sec of the mini-batch
+negative-sampling loop (BASELINE.json metric), one JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2]
+
+A "step" is one pass of the hot path over one batch of B users: on-device
+collation (rk_collate) + encoder SpMM + decoder GEMM with fused loss +
+backward + fused Adam -- everything Recoder._train does per iteration
+(reference model.py:383-404).  The CSR is resident in HBM when the timed region
+starts.  N > 1 is launched by torch.distributed.run, one rank per GPU; users are
+sharded over the ranks (weak scaling: B users per rank per step).
+
+Also reported:
+  roofline     -- the dominant kernel entry (by time per step, chosen from the
+                  warm-up profile), timed with HIP events inside the timed
+                  region, against its algorithmic flops/bytes.
+  cpu_baseline -- oracle/recoder_oracle.py (the pinned CPU restatement of the
+                  reference op sequence, PyTorch-CPU eager) timed on this host's
+                  cores on a bounded sample of the same workload (rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PEAK_MFMA_F32_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
+
+CONFIGS = {
+  # C2 of BASELINE.json: ML-20M autoencoder, hidden [200], MSE, 1 x MI355X
+  "c2": dict(workload="C2 ML-20M-like synthetic CSR 116677x20108 (lognormal degree mean 73, Zipf(1) "
+                      "items, values 1.0, seed 0); DynamicAutoencoder hidden=[200] tanh noise 0.5, "
+                      "MSE, dense Adam lr 1e-3 wd 2e-5, negative sampling",
+             data="ml20m", kind="ae", hidden_layers=[200], activation_type="tanh", noise_prob=0.5,
+             sparse=False, loss="mse", batch_size=500, lr=1e-3, weight_decay=2e-5),
+  "c2s": dict(workload="C2 with sparse=True (SparseAdam on the two tables)",
+              data="ml20m", kind="ae", hidden_layers=[200], activation_type="tanh", noise_prob=0.5,
+              sparse=True, loss="mse", batch_size=500, lr=1e-3, weight_decay=2e-5),
+  "small": dict(workload="smoke-size synthetic 5000x3000", data="small", kind="ae",
+                hidden_layers=[200], activation_type="tanh", noise_prob=0.5, sparse=False,
+                loss="mse", batch_size=500, lr=1e-3, weight_decay=2e-5),
+}
+
+
+def make_csr(cfg):
+  from recoder_amd import synthetic
+  if cfg["data"] == "ml20m":
+    return synthetic.ml20m_like(seed=0)
+  if cfg["data"] == "small":
+    return synthetic.lognormal_zipf(5000, 3000, 40, seed=0)
+  raise ValueError(cfg["data"])
+
+
+def algorithmic_work(entry, B, h0, n_b, nnz, n_items):
+  """(bound, work per launch, unit) of one C-ABI entry."""
+  gemm = 2.0 * B * h0 * n_b
+  if entry in ("rk_decode_loss", "rk_decode_bwd_dz", "rk_decode_bwd_dw"):
+    return "mfma", gemm / 1e12, "TFLOP/s"          # fp32 MFMA contraction
+  if entry == "rk_ae_encode_fwd":
+    return "hbm", (nnz * (h0 * 4 + 12) + B * h0 * 4) / 1e9, "GB/s"
+  if entry == "rk_ae_encode_bwd":
+    return "hbm", (nnz * (h0 * 4 + 8) + n_b * h0 * 4) / 1e9, "GB/s"
+  if entry == "rk_adam_table":
+    # both tables + the bias table call this; dominated by the [n_items,h0] sweeps:
+    # p, m, v read + written (24 B/elem) + gradient rows + pos
+    return "hbm", (n_items * h0 * 24 + n_b * h0 * 4 + n_items * 4) / 1e9, "GB/s"
+  if entry == "rk_adam_rows":
+    return "hbm", (n_b * h0 * 28) / 1e9, "GB/s"
+  return "hbm", 0.0, "GB/s"
+
+
+def cpu_baseline(cfg, csr, steps, warmup=4):
+  """The oracle (CPU restatement of the reference op sequence) on this host."""
+  from oracle import recoder_oracle as orc
+  # eager PyTorch-CPU on B x n_b matrices stops scaling (and oversubscribes) far
+  # below a big host's core count: 256 threads ran 50x slower than 8
+  torch.set_num_threads(min(os.cpu_count(), int(os.environ.get("RK_CPU_THREADS", "16"))))
+  max_seconds = float(os.environ.get("RK_CPU_SECONDS", "20"))
+  B = cfg["batch_size"]
+  torch.manual_seed(0)
+  st = orc.init_ae_state(csr.shape[1], cfg["hidden_layers"])
+  o = orc.OracleRecoder("ae", st, hidden_layers=cfg["hidden_layers"],
+                        activation_type=cfg["activation_type"], noise_prob=cfg["noise_prob"],
+                        sparse=cfg["sparse"], loss=cfg["loss"], lr=cfg["lr"],
+                        weight_decay=cfg["weight_decay"])
+  rng = np.random.RandomState(1)
+  order = rng.permutation(csr.shape[0])
+  t0 = None
+  done = 0
+  for i in range(warmup + steps):
+    if i == warmup:
+      t0 = time.perf_counter()
+    users = order[(i * B) % (len(order) - B):][:B]
+    b = orc.collate(orc.extract_rows(csr, users), users, B, True)[0]   # collation included
+    keep = (rng.random_sample(b.indices.shape[1]) >= cfg["noise_prob"]).astype(np.uint8)
+    o.train_step(b, None, keep, None)
+    if i >= warmup:
+      done += B
+      if time.perf_counter() - t0 > max_seconds:
+        break
+  dt = time.perf_counter() - t0
+  return dict(value=done / dt, unit="users/s", cores=torch.get_num_threads(), kind="port",
+              sample="%d steps of B=%d of the same workload after %d warm-up steps (%.1f s, bounded "
+                     "to ~%.0f s); oracle/recoder_oracle.py = pinned PyTorch-CPU restatement of the "
+                     "reference op sequence incl. collation"
+                     % (done // B, B, warmup, dt, max_seconds))
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=200)
+  ap.add_argument("--warmup", type=int, default=20)
+  ap.add_argument("--config", default="c2")
+  ap.add_argument("--cpu-steps", type=int, default=80)
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  args = ap.parse_args()
+  cfg = CONFIGS[args.config]
+
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  rank = int(os.environ.get("RANK", "0"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+  torch.cuda.set_device(local_rank)
+  device = torch.device("cuda", local_rank)
+  dp = None
+  if world > 1:
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    from recoder_amd.parallel import DataParallel, shard_range
+    dp = DataParallel()
+
+  from recoder_amd.device import Block, DeviceCSR
+  from recoder_amd.engine import FusedEngine
+  from recoder_amd.model import Recoder, _top_sum
+  from recoder_amd.nn import DynamicAutoencoder
+
+  csr_full = make_csr(cfg)
+  if world > 1:
+    lo, hi = shard_range(csr_full.shape[0], rank, world)
+    csr = csr_full[lo:hi]
+  else:
+    csr = csr_full
+  n_users, n_items = csr.shape
+  B = cfg["batch_size"]
+  h0 = cfg["hidden_layers"][0]
+
+  torch.manual_seed(0)       # same initial weights on every rank
+  model = DynamicAutoencoder(hidden_layers=cfg["hidden_layers"], activation_type=cfg["activation_type"],
+                             noise_prob=cfg["noise_prob"], sparse=cfg["sparse"])
+  rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss=cfg["loss"],
+                num_items=n_items, num_users=csr_full.shape[0])
+  from recoder_amd.data import RecommendationDataset
+  ds = RecommendationDataset(csr)
+  rec._Recoder__init_training(ds, cfg["lr"], cfg["weight_decay"])
+  model.train()
+  eng = rec._engine()
+  if dp is not None:
+    dp.attach(eng)
+  dcsr = ds.device_csr()                      # CSR resident in HBM before timing
+  # the union item set over all ranks can exceed one rank's nnz bound
+  blk = Block(B, _top_sum(dcsr.degrees, B), n_items, device, negative_sampling=True,
+              n_cap=_top_sum(dcsr.degrees, B) * world)
+
+  total = args.warmup + args.steps
+  rng = np.random.RandomState(100 + rank)
+  order = np.concatenate([rng.permutation(n_users) for _ in range((total * B) // n_users + 1)])
+  order = order[: total * B].astype(np.int64)
+  order_dev = torch.from_numpy(order).to(device)
+  loss_buf = torch.zeros(total, dtype=torch.float32, device=device)
+  global_rows = B * world
+
+  def step(i):
+    users = order_dev[i * B:(i + 1) * B]
+    if dp is None:
+      blk.collate(dcsr, users)
+    else:
+      dp.collate(blk, dcsr, users)
+    eng.train_step(blk, 0, B, out=loss_buf[i:i + 1],
+                   global_rows=global_rows if dp is not None else None)
+
+  # ---- warm-up (untimed), profiled per C-ABI entry to find the dominant kernel ----
+  step(0)
+  torch.cuda.synchronize()
+  eng.lib.enabled = True
+  for i in range(1, args.warmup):
+    step(i)
+  prof = eng.lib.summary() if args.warmup > 1 else {}
+  eng.lib.reset()
+  dominant = max(prof, key=lambda k: prof[k][0] * prof[k][1]) if prof else "rk_decode_loss"
+  eng.lib.enabled = False
+  only = dominant
+
+  # bracket ONLY the dominant entry with events inside the timed region
+  raw = eng.lib._lib
+  fn = getattr(raw, only)
+  evs = []
+
+  class _One:
+    def __getattr__(self, name):
+      f = getattr(raw, name)
+      if name != only:
+        return f
+
+      def call(*a):
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = f(*a)
+        e.record()
+        evs.append((s, e))
+        return rc
+      return call
+  eng.lib = _One()
+
+  if world > 1:
+    import torch.distributed as dist
+    dist.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  for i in range(args.warmup, total):
+    step(i)
+  torch.cuda.synchronize()
+  if world > 1:
+    dist.barrier()
+  dt = time.perf_counter() - t0
+  if world > 1:
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+  losses = loss_buf.cpu().numpy()
+  assert np.all(np.isfinite(losses)), "non-finite loss"
+  value = args.steps * B * world / dt
+
+  if rank == 0:
+    # per-step n_b / nnz of the timed steps (host recomputation, outside the timing)
+    nbs, nnzs = [], []
+    for i in range(args.warmup, min(total, args.warmup + 50)):
+      rows = csr[order[i * B:(i + 1) * B]]
+      nnzs.append(rows.nnz)
+      nbs.append(len(np.unique(rows.indices)))
+    n_b, nnz = float(np.mean(nbs)), float(np.mean(nnzs))
+    calls_per_step = len(evs) / max(1, args.steps)
+    ms = float(np.mean([s.elapsed_time(e) for s, e in evs])) if evs else float("nan")
+    bound, work, unit = algorithmic_work(only, B, h0, n_b, nnz, n_items)
+    achieved = work / (ms * 1e-3) if ms == ms and ms > 0 else float("nan")
+    peak = PEAK_MFMA_F32_TF if bound == "mfma" else PEAK_HBM_GBS
+    roofline = dict(bound=bound, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
+                    traffic=None, kernel=only, avg_launch_ms=ms, calls_per_step=calls_per_step,
+                    warmup_profile_ms={k: round(v[0] * v[1] / max(1, args.warmup - 1), 4)
+                                       for k, v in sorted(prof.items())})
+    out = {
+      "metric": "train_users_per_sec", "value": value, "unit": "users/s",
+      "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+      "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+      "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+      "config": {"workload": cfg["workload"], "batch_size_per_gpu": B, "global_batch": B * world,
+                 "parallelism": "dp%d" % world, "avg_sampled_items": n_b, "avg_nnz_per_batch": nnz,
+                 "first_loss": float(losses[0]), "last_loss": float(losses[-1])},
+      "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      out["cpu_baseline"] = cpu_baseline(cfg, csr_full, args.cpu_steps)
+    print(json.dumps(out))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

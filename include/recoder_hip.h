@@ -62,7 +62,8 @@ typedef struct rk_block {
   int32_t *pos;       /* [n_items] item id -> compact column, -1 if absent */
   int32_t *mark;      /* [n_items] generation stamps */
   uint32_t *bits_rc;  /* [S_cap][ldw_rc] bit (r,c) set iff (r,c) stored */
-  uint32_t *bits_cr;  /* [n_cap][ldw_cr] transposed bitmap */
+  uint32_t *bits_cr;  /* [n_cap][ldw_cr] transposed bitmap; NULL = not built
+                         (inference-only blocks) */
   int32_t *scan_tmp;  /* [n_chunks+1] */
 } rk_block_t;
 
@@ -137,8 +138,9 @@ int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
 int rk_mnll_finish(float *dO, int32_t B, const rk_block_t *tgt, int32_t row_off,
                    float inv_B, float *loss_part, void *stream);
 /* sum the (unscaled) loss partials in a fixed order (double) and divide by
- * denom = rows of the slice in fp32 (model.py:483-484) -> loss[0] */
-int rk_loss_reduce(const float *loss_part, int32_t n, float denom, float *loss,
+ * denom = rows of the slice in fp32 (model.py:483-484) -> loss[0]; the consumed
+ * partials are reset to 0 (rk_decode_loss requires loss_part zeroed on entry) */
+int rk_loss_reduce(float *loss_part, int32_t n, float denom, float *loss,
                    void *stream);
 
 /*

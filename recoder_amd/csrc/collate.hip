@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void collate_zero_bits_kernel(rk_block_t b) {
   const int wr = (n_b + 31) >> 5;   // words per row in use
   const int wc = (S + 31) >> 5;     // words per column in use
   const int64_t tot_rc = (int64_t)S * wr;
-  const int64_t tot_cr = (int64_t)n_b * wc;
+  const int64_t tot_cr = b.bits_cr ? (int64_t)n_b * wc : 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot_rc; i += stride) {
     const int r = (int)(i / wr), w = (int)(i % wr);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void collate_relabel_kernel(
     b.cols[out0 + k] = c;
     b.vals[out0 + k] = ds_data ? ds_data[beg + k] : 1.0f;
     atomicOr(&b.bits_rc[(int64_t)row * b.ldw_rc + (c >> 5)], 1u << (c & 31));
-    atomicOr(&b.bits_cr[(int64_t)c * b.ldw_cr + (row >> 5)], 1u << (row & 31));
+    if (b.bits_cr) atomicOr(&b.bits_cr[(int64_t)c * b.ldw_cr + (row >> 5)], 1u << (row & 31));
   }
 }
 

@@ -203,6 +203,7 @@ extern "C" int rk_ae_encode_bwd(const rk_block_t *blk, int32_t row_off, int32_t 
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(h > 0 && h % 4 == 0 && h <= 1024, "h must be a multiple of 4, <= 1024");
   RK_REQUIRE(row_off >= 0 && B >= 0 && row_off + B <= blk->S_cap, "row slice out of range");
+  RK_REQUIRE(blk->bits_cr != nullptr, "block was built without the transposed bitmap");
   const int grid = rk_cdiv(blk->n_cap, 4);
   const int hv = rk_cdiv(h, 256);
 #define LAUNCH(HV)                                                                           \

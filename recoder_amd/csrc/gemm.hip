@@ -373,12 +373,19 @@ __global__ __launch_bounds__(256) void mnll_finish_kernel(float *dO, rk_block_t 
   }
 }
 
-__global__ void loss_reduce_kernel(const float *part, int n, float denom, float *loss) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0;
-    for (int i = 0; i < n; ++i) s += (double)part[i];
-    loss[0] = (float)s / denom;
+// one wave: lane-strided double sums + fixed shuffle tree (order-deterministic);
+// re-zeroes the partials so the next rk_decode_loss finds them clean
+__global__ __launch_bounds__(64) void loss_reduce_kernel(float *part, int n, float denom,
+                                                         float *loss) {
+  const int lane = threadIdx.x;
+  double s = 0.0;
+  for (int i = lane; i < n; i += 64) {
+    s += (double)part[i];
+    part[i] = 0.f;
   }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) loss[0] = (float)s / denom;
 }
 
 __global__ __launch_bounds__(256) void fill_kernel(float *p, int64_t n, float v) {
@@ -422,9 +429,8 @@ extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_blo
   p.confidence = confidence; p.inv_B = inv_B; p.loss_part = loss_part;
   const int tiles = p.tiles_m * rk_cdiv(tgt->n_cap, 128);
   if (loss_kind == RK_LOSS_MSE || loss_kind == RK_LOSS_BCE) {
-    // partial sums of surplus tiles must read as 0
-    hipLaunchKernelGGL(fill_kernel, dim3(rk_cdiv(tiles, 256)), dim3(256), 0, stream, loss_part,
-                       (int64_t)tiles, 0.f);
+    // loss_part must be all-zero on entry (surplus tiles never write their slot):
+    // it is allocated zeroed and rk_loss_reduce re-zeroes what it consumed
     p.ld_dev = tgt->counts + 2;
     hipLaunchKernelGGL((gemm_kernel<2, 2, 2, 2, 0, 0, EPI_LOSS>), dim3(tiles, 1), dim3(256), 0,
                        stream, p);
@@ -448,7 +454,7 @@ extern "C" int rk_mnll_finish(float *dO, int32_t B, const rk_block_t *tgt, int32
   return 0;
 }
 
-extern "C" int rk_loss_reduce(const float *loss_part, int32_t n, float denom, float *loss,
+extern "C" int rk_loss_reduce(float *loss_part, int32_t n, float denom, float *loss,
                               void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(64), 0, stream, loss_part, n, denom, loss);

@@ -74,14 +74,15 @@ class Block:
   """Capacity-sized device buffers for one sampling group + the ctypes view."""
 
   def __init__(self, S_cap, nnz_cap, n_items, device=None, negative_sampling=True,
-               need_bits_cr=True):
+               need_bits_cr=True, n_cap=None):
     device = device or require_gpu()
     S_cap = max(1, int(S_cap))
     nnz_cap = max(1, int(nnz_cap))
     self.device = device
     self.S_cap, self.nnz_cap, self.n_items = S_cap, nnz_cap, int(n_items)
     self.negative_sampling = bool(negative_sampling)
-    self.n_cap = min(self.n_items, nnz_cap) if negative_sampling else self.n_items
+    # n_cap override: a data-parallel union item set can exceed one rank's nnz bound
+    self.n_cap = min(self.n_items, n_cap or nnz_cap) if negative_sampling else self.n_items
     self.n_cap = max(1, self.n_cap)
     self.ld_cap = cdiv(self.n_cap, 32) * 32
     self.ldw_rc = cdiv(self.n_cap, 32)
@@ -97,7 +98,8 @@ class Block:
     self.pos = torch.full((self.n_items,), -1, **i32)
     self.mark = torch.zeros(self.n_items, **i32)
     self.bits_rc = torch.zeros(S_cap * self.ldw_rc, **i32)
-    self.bits_cr = torch.zeros((self.n_cap if need_bits_cr else 1) * self.ldw_cr, **i32)
+    # the transposed bitmap is only needed by the encoder backward (training)
+    self.bits_cr = torch.zeros(self.n_cap * self.ldw_cr, **i32) if need_bits_cr else None
     self.scan_tmp = torch.zeros(self.n_chunks + 1, **i32)
     self.stamp = 0
     self.users = None      # int64 device tensor of the rows of the last collate

@@ -33,11 +33,48 @@ class ParamState:
     self.step, self.wd, self.group, self.sparse, self.st = step, wd, group, sparse, st
 
 
+class TimedLib:
+  """Pass-through to the C ABI that can bracket every call with HIP events on
+  the launch stream (bench.py's roofline measurement); disabled by default."""
+
+  def __init__(self, lib):
+    self._lib = lib
+    self.enabled = False
+    self.records = {}       # entry point -> list of (start_event, end_event)
+
+  def __getattr__(self, name):
+    fn = getattr(self._lib, name)
+    if not name.startswith("rk_") or name in ("rk_dz_workspace_bytes", "rk_loss_partials",
+                                              "rk_last_error", "rk_version"):
+      return fn
+
+    def call(*args):
+      if not self.enabled:
+        return fn(*args)
+      s = torch.cuda.Event(enable_timing=True)
+      e = torch.cuda.Event(enable_timing=True)
+      s.record()
+      rc = fn(*args)
+      e.record()
+      self.records.setdefault(name, []).append((s, e))
+      return rc
+    return call
+
+  def summary(self):
+    """{entry point: (calls, mean ms)}; synchronises."""
+    torch.cuda.synchronize()
+    return {k: (len(v), float(np.mean([s.elapsed_time(e) for s, e in v])))
+            for k, v in self.records.items()}
+
+  def reset(self):
+    self.records = {}
+
+
 class FusedEngine:
   """Holds the workspaces for batches of up to ``B_cap`` rows x ``n_cap`` items."""
 
   def __init__(self, model, kind, loss="mse", loss_params=None, device=None):
-    self.lib = _lib.load()
+    self.lib = TimedLib(_lib.load())
     self.device = device or require_gpu()
     self.model = model
     self.kind = kind                       # 'ae' | 'mf'
@@ -258,6 +295,7 @@ class FusedEngine:
       users = blk.users[row_off:row_off + B]
       z = self._mf_forward(users, B, keep_drop, True, stream)
     loss = self._loss(z, B, blk, row_off, rows, stream, out)
+    self._loss_target = loss
 
     # ---- backward through the decoder (nn.py:280) ----
     W_de, _ = self._decoder_params()
@@ -324,18 +362,23 @@ class FusedEngine:
     return loss
 
   # ------------------------------------------------------- data parallelism
-  def _grad_tensors(self):
-    ts = [self.G_de, self.gb_de, self.loss_out]
+  def grad_views(self, n_b):
+    """Views of everything a data-parallel step must SUM over the ranks: the
+    live n_b gradient rows, the gathered-bias gradient, the dense gradients and
+    the (already 1/(N*B)-scaled) loss.  MF user-row gradients are rank-private
+    (each user lives on one rank) and are not reduced."""
+    h0 = self.h[0]
+    ts = [self.G_de[:n_b * h0], self.gb_de[:n_b], self._loss_target]
     if self.kind == "ae":
       m = self.model
       if not m.is_constrained:
-        ts.append(self.G_en)
+        ts.append(self.G_en[:n_b * h0])
       ts.append(self.gb_en)
       ts += self.g_enc_w + self.g_enc_b + [g for g in self.g_dec_w if g is not None] + self.g_dec_b
     return ts
 
   def _allreduce_grads(self, blk, B):
-    self.allreduce(self._grad_tensors(), blk)
+    self.allreduce(self, blk)
 
   # ---------------------------------------------------------------- updates
   def _apply_updates(self, blk, row_off, B, stream):

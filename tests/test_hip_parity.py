@@ -291,8 +291,8 @@ def test_steps_match_oracle(name, c, shape, B, S):
                 loss_params=c["loss_params"])
   ds = RecommendationDataset(csr)
   rng = np.random.RandomState(11)
-  n_steps = 3 * (S // B)
   order = rng.permutation(n_users)[: 3 * S].astype(np.int64)
+  n_steps = sum(int(np.ceil(len(order[o:o + S]) / B)) for o in range(0, len(order), S))
   masks = {}
   h_last = c["hidden_layers"][-1] if c["kind"] == "ae" else c["embedding_size"]
 
