@@ -52,7 +52,8 @@ typedef struct rk_block {
   int32_t ldw_rc;     /* words per row of bits_rc  (>= ceil(n_cap/32)) */
   int32_t ldw_cr;     /* words per column of bits_cr (>= ceil(S_cap/32)) */
   int32_t n_chunks;   /* ceil(n_items / RK_SCAN_CHUNK) */
-  int32_t reserved;
+  int32_t implicit;   /* != 0: every stored value is 1.0 (vals is not read by the
+                         loss / backward kernels) -- implicit-feedback data */
   int32_t *counts;    /* [4] dev: n_b, nnz_b, ld (= round_up(n_b,32)), S */
   int32_t *indptr;    /* [S_cap+1] block CSR row pointers */
   int32_t *cols;      /* [nnz_cap] relabelled column (index into items) */
@@ -65,6 +66,9 @@ typedef struct rk_block {
   uint32_t *bits_cr;  /* [n_cap][ldw_cr] transposed bitmap; NULL = not built
                          (inference-only blocks) */
   int32_t *scan_tmp;  /* [n_chunks+1] */
+  int32_t *pref_rc;   /* [S_cap][ldw_rc] exclusive prefix popcount of bits_rc per row:
+                         entry index of (r,c) = indptr[r] + pref_rc[r][c>>5]
+                         + popc(bits_rc[r][c>>5] & ((1<<(c&31))-1)) */
 } rk_block_t;
 
 #define RK_SCAN_CHUNK 2048
@@ -126,13 +130,19 @@ int rk_ae_encode_bwd(const rk_block_t *blk, int32_t row_off, int32_t B,
  *   MSE/BCE : dO[B,ld] <- dLoss/dLogits, loss partials -> loss_part
  *   MNLL    : dO <- logits (finish with rk_mnll_finish)
  *   NONE    : out[B, ld_out] <- logits (+bias), ld_out host-given
- *   loss_part : [rk_loss_partials(B, n_cap)] floats
+ *   loss_part : [rk_loss_partials(B, n_cap)] floats, all-zero on entry
+ *   gb_part   : nullable [ceil(B/row_tile)][ld] per-row-tile column sums of dO
+ *               (MSE/BCE); colsum over those few rows = gradient of the
+ *               gathered decoder bias (saves a second pass over dO)
  */
 int32_t rk_loss_partials(int32_t B, int32_t n_cap);
+/* rows per decode tile: gb_part holds ceil(B / rk_decode_row_tile()) rows */
+int32_t rk_decode_row_tile(void);
 int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
                    int32_t row_off, const float *W_de, const float *b_de,
                    int32_t loss_kind, float confidence, float inv_B,
-                   float *dO, int32_t ld_out, float *loss_part, void *stream);
+                   float *dO, int32_t ld_out, float *loss_part, float *gb_part,
+                   void *stream);
 /* MNLL second pass: row max / logsumexp over the logits in dO, loss, and
  * dO <- (softmax * sum_t - t) * inv_B  (losses.py:68-71 + autograd). */
 int rk_mnll_finish(float *dO, int32_t B, const rk_block_t *tgt, int32_t row_off,

@@ -22,10 +22,11 @@ class RkBlock(Structure):
   """mirror of rk_block_t"""
   _fields_ = [
     ("S_cap", c_int32), ("nnz_cap", c_int32), ("n_cap", c_int32), ("n_items", c_int32),
-    ("ldw_rc", c_int32), ("ldw_cr", c_int32), ("n_chunks", c_int32), ("reserved", c_int32),
+    ("ldw_rc", c_int32), ("ldw_cr", c_int32), ("n_chunks", c_int32), ("implicit", c_int32),
     ("counts", c_void_p), ("indptr", c_void_p), ("cols", c_void_p), ("vals", c_void_p),
     ("svals", c_void_p), ("items", c_void_p), ("pos", c_void_p), ("mark", c_void_p),
     ("bits_rc", c_void_p), ("bits_cr", c_void_p), ("scan_tmp", c_void_p),
+    ("pref_rc", c_void_p),
   ]
 
 
@@ -42,8 +43,9 @@ SIGNATURES = {
                                  c_uint64, _P, c_int32, _P, _P]),
   "rk_ae_encode_bwd": (c_int32, [_BLK, c_int32, c_int32, _P, c_int32, _P, c_int32, _P]),
   "rk_loss_partials": (c_int32, [c_int32, c_int32]),
+  "rk_decode_row_tile": (c_int32, []),
   "rk_decode_loss": (c_int32, [_P, c_int32, c_int32, _BLK, c_int32, _P, _P, c_int32, c_float,
-                               c_float, _P, c_int32, _P, _P]),
+                               c_float, _P, c_int32, _P, _P, _P]),
   "rk_mnll_finish": (c_int32, [_P, c_int32, _BLK, c_int32, c_float, _P, _P]),
   "rk_loss_reduce": (c_int32, [_P, c_int32, c_float, _P, _P]),
   "rk_decode_bwd_dz": (c_int32, [_P, c_int32, c_int32, _BLK, _P, _P, c_int32, _P, _P, _P]),

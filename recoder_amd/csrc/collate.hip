@@ -185,6 +185,29 @@ __global__ __launch_bounds__(256) void collate_relabel_kernel(
   }
 }
 
+// ---- prefix: per-row exclusive prefix popcount of the (row,col) bitmap ----
+__global__ __launch_bounds__(256) void collate_prefix_kernel(rk_block_t b, int S) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= S) return;
+  const int lane = threadIdx.x & 63;
+  const int wr = (b.counts[0] + 31) >> 5;
+  const uint32_t *bits = b.bits_rc + (int64_t)row * b.ldw_rc;
+  int32_t *pref = b.pref_rc + (int64_t)row * b.ldw_rc;
+  int32_t carry = 0;
+  for (int w0 = 0; w0 < wr; w0 += 64) {
+    const int w = w0 + lane;
+    const int32_t c = (w < wr) ? __popc(bits[w]) : 0;
+    int32_t x = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      int32_t y = __shfl_up(x, off, 64);
+      if (lane >= off) x += y;
+    }
+    if (w < wr) pref[w] = carry + x - c;
+    carry += __shfl(x, 63, 64);
+  }
+}
+
 }  // namespace
 
 extern "C" int rk_collate(const int64_t *ds_indptr, const int32_t *ds_indices,
@@ -229,5 +252,9 @@ extern "C" int rk_collate(const int64_t *ds_indptr, const int32_t *ds_indices,
   hipLaunchKernelGGL(collate_relabel_kernel, dim3(rk_cdiv(S, 4)), dim3(256), 0, stream,
                      ds_indptr, ds_indices, ds_data, users, S, *blk);
   RK_CHECK_LAUNCH("collate_relabel");
+  if (blk->pref_rc) {
+    hipLaunchKernelGGL(collate_prefix_kernel, dim3(rk_cdiv(S, 4)), dim3(256), 0, stream, *blk, S);
+    RK_CHECK_LAUNCH("collate_prefix");
+  }
   return 0;
 }

@@ -90,6 +90,14 @@ __device__ __forceinline__ float rk_wave_max(float v) {
   return v;
 }
 
+// index j into the block's cols/vals/svals of the stored entry (row, c), given
+// the bitmap word that holds its (set) bit: rows are column-sorted, so j is the
+// row start plus the number of set bits before c (prefix popcount, no search)
+__device__ __forceinline__ int rk_entry_index(const rk_block_t &b, int row, int c, uint32_t word) {
+  return b.indptr[row] + b.pref_rc[(int64_t)row * b.ldw_rc + (c >> 5)] +
+         __popc(word & ((1u << (c & 31)) - 1u));
+}
+
 // binary search of column c in the (ascending) relabelled columns of one row
 __device__ __forceinline__ int rk_find_col(const int32_t *cols, int beg, int end, int c) {
   int lo = beg, hi = end;

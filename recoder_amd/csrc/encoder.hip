@@ -65,21 +65,31 @@ __global__ __launch_bounds__(256) void ae_encode_fwd_kernel(
       b.svals[j] = s;
     }
     const int cnt = min(64, wend - base);
-    for (int k = 0; k < cnt; ++k) {
-      const int it = __shfl(item, k, 64);
-      const float sv = __shfl(s, k, 64);
-      if (sv != 0.f) {   // wave-uniform: dropped entries contribute exactly 0
-        const float *wrow = W + (int64_t)it * h;
+    // no branch on dropped entries (s == 0 contributes exactly +0): the row
+    // loads of consecutive entries are independent and stay in flight together
+    // (lanes past the wave's range carry item 0 / s 0, so rounding cnt up to a
+    // multiple of 4 only adds exact zeros)
+    for (int k = 0; k < cnt; k += 4) {
+      int it[4];
+      float sv[4];
 #pragma unroll
-        for (int v = 0; v < HV; ++v) {
-          const int hh = (v * 64 + lane) * 4;
-          if (hh < h) {
-            const float4 w4 = *reinterpret_cast<const float4 *>(wrow + hh);
-            acc[v].x = fmaf(sv, w4.x, acc[v].x);
-            acc[v].y = fmaf(sv, w4.y, acc[v].y);
-            acc[v].z = fmaf(sv, w4.z, acc[v].z);
-            acc[v].w = fmaf(sv, w4.w, acc[v].w);
-          }
+      for (int u = 0; u < 4; ++u) {
+        it[u] = __shfl(item, k + u, 64);
+        sv[u] = __shfl(s, k + u, 64);
+      }
+#pragma unroll
+      for (int v = 0; v < HV; ++v) {
+        const int hh = min((v * 64 + lane) * 4, h - 4);
+        float4 w4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          w4[u] = *reinterpret_cast<const float4 *>(W + (int64_t)it[u] * h + hh);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc[v].x = fmaf(sv[u], w4[u].x, acc[v].x);
+          acc[v].y = fmaf(sv[u], w4[u].y, acc[v].y);
+          acc[v].z = fmaf(sv[u], w4[u].z, acc[v].z);
+          acc[v].w = fmaf(sv[u], w4[u].w, acc[v].w);
         }
       }
     }
@@ -117,59 +127,84 @@ template <int HV>
 __global__ __launch_bounds__(256) void ae_encode_bwd_kernel(
     rk_block_t b, int row_off, int B, const float *__restrict__ dZ, int h,
     float *__restrict__ G, int accumulate) {
+  // one workgroup per sampled item column; its 4 waves take the 64-row groups
+  // round-robin (popular items hold hundreds of entries -- a single wave per
+  // column serialised them into the kernel's tail) and combine in fixed order
+  __shared__ __attribute__((aligned(16))) float part[3][HV * 256];
   const int n_b = b.counts[0];
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int c = blockIdx.x;
   if (c >= n_b) return;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const uint32_t *colbits = b.bits_cr + (int64_t)c * b.ldw_cr;
   float4 acc[HV];
 #pragma unroll
   for (int k = 0; k < HV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   const int rend = row_off + B;
-  for (int r0 = row_off & ~63; r0 < rend; r0 += 64) {
+  for (int r0 = (row_off & ~63) + wid * 64; r0 < rend; r0 += 256) {
     const int row = r0 + lane;
     bool on = false;
     float s = 0.f;
     if (row >= row_off && row < rend) {
       on = (colbits[row >> 5] >> (row & 31)) & 1u;
       if (on) {
-        const int j = rk_find_col(b.cols, b.indptr[row], b.indptr[row + 1], c);
-        s = (j >= 0) ? b.svals[j] : 0.f;
+        const uint32_t word = b.bits_rc[(int64_t)row * b.ldw_rc + (c >> 5)];
+        s = b.svals[rk_entry_index(b, row, c, word)];
       }
     }
     unsigned long long mask = __ballot(on);
+    // ascending-row order, 8 row loads in flight per pass
     while (mask) {
-      const int k = __builtin_ctzll(mask);
-      mask &= mask - 1;
-      const float sv = __shfl(s, k, 64);
-      if (sv != 0.f) {
-        const float *drow = dZ + (int64_t)(r0 + k - row_off) * h;
+      int kk[8];
+      float sv[8];
 #pragma unroll
-        for (int v = 0; v < HV; ++v) {
-          const int hh = (v * 64 + lane) * 4;
-          if (hh < h) {
-            const float4 d4 = *reinterpret_cast<const float4 *>(drow + hh);
-            acc[v].x = fmaf(sv, d4.x, acc[v].x);
-            acc[v].y = fmaf(sv, d4.y, acc[v].y);
-            acc[v].z = fmaf(sv, d4.z, acc[v].z);
-            acc[v].w = fmaf(sv, d4.w, acc[v].w);
-          }
+      for (int u = 0; u < 8; ++u) {
+        const bool have = mask != 0ull;
+        const int k = have ? __builtin_ctzll(mask) : 0;
+        mask = have ? (mask & (mask - 1)) : 0ull;
+        kk[u] = have ? (r0 + k - row_off) : 0;
+        sv[u] = have ? __shfl(s, k, 64) : 0.f;
+      }
+#pragma unroll
+      for (int v = 0; v < HV; ++v) {
+        const int hh = min((v * 64 + lane) * 4, h - 4);
+        float4 d4[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          d4[u] = *reinterpret_cast<const float4 *>(dZ + (int64_t)kk[u] * h + hh);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          acc[v].x = fmaf(sv[u], d4[u].x, acc[v].x);
+          acc[v].y = fmaf(sv[u], d4[u].y, acc[v].y);
+          acc[v].z = fmaf(sv[u], d4[u].z, acc[v].z);
+          acc[v].w = fmaf(sv[u], d4[u].w, acc[v].w);
         }
       }
     }
   }
-  float *grow = G + (int64_t)c * h;
+  if (wid > 0) {
 #pragma unroll
-  for (int v = 0; v < HV; ++v) {
-    const int hh = (v * 64 + lane) * 4;
-    if (hh < h) {
-      float4 a = acc[v];
-      if (accumulate) {
-        const float4 o = *reinterpret_cast<const float4 *>(grow + hh);
-        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+    for (int v = 0; v < HV; ++v)
+      *reinterpret_cast<float4 *>(&part[wid - 1][(v * 64 + lane) * 4]) = acc[v];
+  }
+  __syncthreads();
+  if (wid == 0) {
+    float *grow = G + (int64_t)c * h;
+#pragma unroll
+    for (int v = 0; v < HV; ++v) {
+      const int hh = (v * 64 + lane) * 4;
+      if (hh < h) {
+        float4 a = acc[v];
+        for (int w = 0; w < 3; ++w) {
+          const float4 o = *reinterpret_cast<const float4 *>(&part[w][hh]);
+          a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+        }
+        if (accumulate) {
+          const float4 o = *reinterpret_cast<const float4 *>(grow + hh);
+          a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+        }
+        *reinterpret_cast<float4 *>(grow + hh) = a;
       }
-      *reinterpret_cast<float4 *>(grow + hh) = a;
     }
   }
 }
@@ -203,8 +238,9 @@ extern "C" int rk_ae_encode_bwd(const rk_block_t *blk, int32_t row_off, int32_t 
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(h > 0 && h % 4 == 0 && h <= 1024, "h must be a multiple of 4, <= 1024");
   RK_REQUIRE(row_off >= 0 && B >= 0 && row_off + B <= blk->S_cap, "row slice out of range");
-  RK_REQUIRE(blk->bits_cr != nullptr, "block was built without the transposed bitmap");
-  const int grid = rk_cdiv(blk->n_cap, 4);
+  RK_REQUIRE(blk->bits_cr != nullptr && blk->pref_rc != nullptr,
+             "block was built without the transposed bitmap / prefix index");
+  const int grid = blk->n_cap;
   const int hv = rk_cdiv(h, 256);
 #define LAUNCH(HV)                                                                           \
   hipLaunchKernelGGL(ae_encode_bwd_kernel<HV>, dim3(grid), dim3(256), 0, stream, *blk, row_off, \

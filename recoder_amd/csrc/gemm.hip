@@ -4,18 +4,22 @@
 //   decode + loss : O[B,n_t] = Z[B,h] . W_de[T]^T + b_de[T]   (reference
 //                   nn.py:271-280) with the loss and dLoss/dO fused into the
 //                   epilogue (losses.py:43-47, BCEWithLogits): the logits never
-//                   go to HBM for MSE/BCE, only dO does.
+//                   go to HBM for MSE/BCE, only dO does; the epilogue also
+//                   emits per-row-tile column sums of dO (bias gradient).
 //   bwd dZ        : dZ[B,h]   = dO[B,n_t] . W_de[T]      (split-K over n_t)
 //   bwd dW        : G[n_t,h]  = dO^T . Z
 //   hidden layers : nn.Linear stack fwd/bwd (nn.py:242-249)
 //
 // One templated LDS-tiled kernel: block = 4 waves (WM x WN), each wave owns
 // TM x TN tiles of 32x32, BK = 16.  Operands are staged global -> registers ->
-// LDS (double buffered; next tile's global loads are issued before the MFMAs
-// of the current one).  K-contiguous operands sit in LDS as [row][20] floats
-// (80-B stride = odd multiple of 16 B -> conflict-free ds_read_b128: one read
-// feeds 4 MFMA k-steps because the two lane halves take k = {0..3} / {4..7} of
-// each 8-group); k-major operands sit as [16][tile] and are read with b32.
+// LDS (double buffered; the next tile's global loads are issued before the
+// MFMAs of the current one).  All bounds handling is branch-free (clamped
+// address + select) so the tile's loads issue back to back -- a branchy loader
+// made hipcc wait vmcnt(0) after every load (7% of MFMA peak, profiles/r01_a).
+// K-contiguous operands sit in LDS as [row][20] floats (80-B stride = odd
+// multiple of 16 B -> conflict-free ds_read_b128: one read feeds 4 MFMA k-steps
+// because the two lane halves take k = {0..3} / {4..7} of each 8-group);
+// k-major operands sit as [16][tile] and are read with ds_read_b32.
 #include "common.h"
 
 namespace {
@@ -34,7 +38,6 @@ struct GemmP {
   const int32_t *Mdev, *Ndev, *Kdev;
   int tiles_m;              // host: ceil(Mcap / BM)
   int kchunk;               // K range per blockIdx.y
-  int a_vec, b_vec;         // 16-B loads allowed
   // store epilogue
   float *C;
   int ldc;                  // <=0 : read ld from ld_dev
@@ -49,27 +52,44 @@ struct GemmP {
   int loss_kind;
   float confidence, inv_B;
   float *loss_part;
+  float *gb_part;           // [tiles_m][ld] column sums of dO per row tile (nullable)
 };
 
-__device__ __forceinline__ float4 load4(const float *p, int valid, bool vec) {
-  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (valid >= 4 && vec) {
-    r = *reinterpret_cast<const float4 *>(p);
-  } else if (valid > 0) {
-    r.x = p[0];
-    if (valid > 1) r.y = p[1];
-    if (valid > 2) r.z = p[2];
-    if (valid > 3) r.w = p[3];
+// Branch-free guarded load of 4 consecutive floats; `valid` (<= 0 .. >= 4) of
+// them are logically in range, the rest read as 0.  VEC: one 16-B load (the
+// caller guarantees 16-B alignment and that the 4 floats lie inside the
+// allocation whenever valid > 0).
+template <bool VEC>
+__device__ __forceinline__ float4 ld4(const float *base, int64_t off, int valid) {
+  float4 r;
+  if (VEC) {
+    const float4 v = *reinterpret_cast<const float4 *>(base + (valid > 0 ? off : 0));
+    r.x = valid > 0 ? v.x : 0.f;
+    r.y = valid > 1 ? v.y : 0.f;
+    r.z = valid > 2 ? v.z : 0.f;
+    r.w = valid > 3 ? v.w : 0.f;
+  } else {
+    const float a = base[valid > 0 ? off : 0];
+    const float b = base[valid > 1 ? off + 1 : 0];
+    const float c = base[valid > 2 ? off + 2 : 0];
+    const float d = base[valid > 3 ? off + 3 : 0];
+    r.x = valid > 0 ? a : 0.f;
+    r.y = valid > 1 ? b : 0.f;
+    r.z = valid > 2 ? c : 0.f;
+    r.w = valid > 3 ? d : 0.f;
   }
   return r;
 }
 
-template <int WM, int WN, int TM, int TN, int AMODE, int BMODE, int EPI>
+template <int WM, int WN, int TM, int TN, int AMODE, int BMODE, int EPI, bool VEC, int BK = 16>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   static_assert(WM * WN == 4, "4 waves per block");
-  constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, BK = 16;
-  constexpr int A_SZ = (AMODE == 0) ? BM * 20 : BK * BM;
-  constexpr int B_SZ = (BMODE == 0) ? BN * 20 : BK * BN;
+  static_assert(BK == 16 || BK == 32, "BK");
+  constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+  constexpr int LDK = BK + 4;          // K-contiguous LDS row stride (odd multiple of 16 B)
+  constexpr int QK = BK / 4;           // float4 per K-contiguous row
+  constexpr int A_SZ = (AMODE == 0) ? BM * LDK : BK * BM;
+  constexpr int B_SZ = (BMODE == 0) ? BN * LDK : BK * BN;
   constexpr int A_F4 = BM * BK / 4, B_F4 = BN * BK / 4;      // float4 per tile
   constexpr int A_PT = (A_F4 + 255) / 256, B_PT = (B_F4 + 255) / 256;
   __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
@@ -82,8 +102,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   const int mt = blockIdx.x % p.tiles_m, nt = blockIdx.x / p.tiles_m;
   const int m0 = mt * BM, n0 = nt * BN;
   if (m0 >= M || n0 >= N) return;
-  const int kbeg = blockIdx.y * p.kchunk;
-  const int kend = min(K, kbeg + p.kchunk);
+  // split-K: the chunk follows the device-resident K so that every split is live
+  const int kchunk = (p.kchunk > 0) ? p.kchunk : (((K + (int)gridDim.y - 1) / (int)gridDim.y + 15) & ~15);
+  const int kbeg = blockIdx.y * kchunk;
+  const int kend = min(K, kbeg + kchunk);
   if (kbeg >= kend) return;
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -98,45 +120,81 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // ---- loop-invariant per-thread addressing of the staged tiles ----
+  int64_t a_off[A_PT], b_off[B_PT];   // element offset at k-tile 0 (w/o the per-tile k term)
+  int a_lim[A_PT], b_lim[B_PT];       // AMODE/BMODE 0: row valid ? 1 : 0 ; mode 1: valid count along the row
+  int a_k[A_PT], b_k[B_PT];           // k index of the element inside the tile
+#pragma unroll
+  for (int i = 0; i < A_PT; ++i) {
+    const int idx = tid + i * 256;
+    if (AMODE == 0) {
+      const int row = idx / QK, q = idx % QK;
+      const int m = m0 + row;
+      a_k[i] = q * 4;
+      a_lim[i] = (idx < A_F4 && m < M) ? 1 : 0;
+      a_off[i] = (int64_t)min(m, M - 1) * lda + q * 4;
+    } else {
+      const int k = idx / (BM / 4), m4 = idx % (BM / 4);
+      const int m = m0 + m4 * 4;
+      a_k[i] = k;
+      a_lim[i] = (idx < A_F4) ? (M - m) : 0;
+      a_off[i] = (int64_t)k * lda + m;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < B_PT; ++i) {
+    const int idx = tid + i * 256;
+    if (BMODE == 0) {
+      const int row = idx / QK, q = idx % QK;
+      const int n = n0 + row;
+      const int nc = min(n, N - 1);
+      const int64_t src = p.bidx ? (int64_t)p.bidx[nc] : (int64_t)nc;   // gather index: once
+      b_k[i] = q * 4;
+      b_lim[i] = (idx < B_F4 && n < N) ? 1 : 0;
+      b_off[i] = src * ldb + q * 4;
+    } else {
+      const int k = idx / (BN / 4), n4 = idx % (BN / 4);
+      const int n = n0 + n4 * 4;
+      b_k[i] = k;
+      b_lim[i] = (idx < B_F4) ? (N - n) : 0;
+      b_off[i] = n;
+    }
+  }
+
   float4 ra[A_PT], rb[B_PT];
+  const bool gather_k = (BMODE == 1) && (p.bidx != nullptr);
 
   auto gload = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
-      const int idx = tid + i * 256;
-      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < A_F4) {
-        if (AMODE == 0) {
-          const int row = idx >> 2, q = idx & 3;
-          const int m = m0 + row, k = k0 + q * 4;
-          if (m < M) ra[i] = load4(p.A + (int64_t)m * lda + k, kend - k, p.a_vec);
-        } else {
-          const int k = idx / (BM / 4), m4 = idx % (BM / 4);
-          const int kk = k0 + k, m = m0 + m4 * 4;
-          if (kk < kend) ra[i] = load4(p.A + (int64_t)kk * lda + m, M - m, p.a_vec);
-        }
+      if (AMODE == 0) {
+        const int k = k0 + a_k[i];
+        ra[i] = ld4<VEC>(p.A, a_off[i] + k0, a_lim[i] ? (kend - k) : 0);
+      } else {
+        const int kk = k0 + a_k[i];
+        ra[i] = ld4<VEC>(p.A, a_off[i] + (int64_t)k0 * lda, kk < kend ? a_lim[i] : 0);
       }
     }
+    if (BMODE == 0) {
 #pragma unroll
-    for (int i = 0; i < B_PT; ++i) {
-      const int idx = tid + i * 256;
-      rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < B_F4) {
-        if (BMODE == 0) {
-          const int row = idx >> 2, q = idx & 3;
-          const int n = n0 + row, k = k0 + q * 4;
-          if (n < N) {
-            const int64_t src = p.bidx ? (int64_t)p.bidx[n] : (int64_t)n;
-            rb[i] = load4(p.Bm + src * ldb + k, kend - k, p.b_vec);
-          }
-        } else {
-          const int k = idx / (BN / 4), n4 = idx % (BN / 4);
-          const int kk = k0 + k, n = n0 + n4 * 4;
-          if (kk < kend) {
-            const int64_t src = p.bidx ? (int64_t)p.bidx[kk] : (int64_t)kk;
-            rb[i] = load4(p.Bm + src * ldb + n, N - n, p.b_vec);
-          }
-        }
+      for (int i = 0; i < B_PT; ++i) {
+        const int k = k0 + b_k[i];
+        rb[i] = ld4<VEC>(p.Bm, b_off[i] + k0, b_lim[i] ? (kend - k) : 0);
+      }
+    } else {
+      // k-major B with an optional row gather: fetch every gather index first
+      // (independent loads), then every row segment
+      int src[B_PT];
+#pragma unroll
+      for (int i = 0; i < B_PT; ++i) src[i] = min(k0 + b_k[i], kend - 1);
+      if (gather_k) {
+#pragma unroll
+        for (int i = 0; i < B_PT; ++i) src[i] = p.bidx[src[i]];
+      }
+#pragma unroll
+      for (int i = 0; i < B_PT; ++i) {
+        const int kk = k0 + b_k[i];
+        rb[i] = ld4<VEC>(p.Bm, (int64_t)src[i] * ldb + b_off[i], kk < kend ? b_lim[i] : 0);
       }
     }
   };
@@ -148,8 +206,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       const int idx = tid + i * 256;
       if (idx < A_F4) {
         if (AMODE == 0) {
-          const int row = idx >> 2, q = idx & 3;
-          *reinterpret_cast<float4 *>(As + row * 20 + q * 4) = ra[i];
+          const int row = idx / QK, q = idx % QK;
+          *reinterpret_cast<float4 *>(As + row * LDK + q * 4) = ra[i];
         } else {
           const int k = idx / (BM / 4), m4 = idx % (BM / 4);
           *reinterpret_cast<float4 *>(As + k * BM + m4 * 4) = ra[i];
@@ -161,8 +219,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       const int idx = tid + i * 256;
       if (idx < B_F4) {
         if (BMODE == 0) {
-          const int row = idx >> 2, q = idx & 3;
-          *reinterpret_cast<float4 *>(Bs + row * 20 + q * 4) = rb[i];
+          const int row = idx / QK, q = idx % QK;
+          *reinterpret_cast<float4 *>(Bs + row * LDK + q * 4) = rb[i];
         } else {
           const int k = idx / (BN / 4), n4 = idx % (BN / 4);
           *reinterpret_cast<float4 *>(Bs + k * BN + n4 * 4) = rb[i];
@@ -181,13 +239,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     const float *As = smem + cur * (A_SZ + B_SZ);
     const float *Bs = As + A_SZ;
 #pragma unroll
-    for (int kg = 0; kg < 2; ++kg) {
+    for (int kg = 0; kg < BK / 8; ++kg) {
       float af[TM][4], bf[TN][4];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int row = (wm * TM + i) * 32 + l31;
         if (AMODE == 0) {
-          const float4 v = *reinterpret_cast<const float4 *>(As + row * 20 + kg * 8 + lh * 4);
+          const float4 v = *reinterpret_cast<const float4 *>(As + row * LDK + kg * 8 + lh * 4);
           af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
         } else {
 #pragma unroll
@@ -198,7 +256,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       for (int j = 0; j < TN; ++j) {
         const int col = (wn * TN + j) * 32 + l31;
         if (BMODE == 0) {
-          const float4 v = *reinterpret_cast<const float4 *>(Bs + col * 20 + kg * 8 + lh * 4);
+          const float4 v = *reinterpret_cast<const float4 *>(Bs + col * LDK + kg * 8 + lh * 4);
           bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
         } else {
 #pragma unroll
@@ -225,8 +283,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn * TN + j) * 32 + l31;
+        const int nc = min(n, N - 1);
         float bv = 0.f;
-        if (p.bias && n < N) bv = p.bias[p.bias_gather ? (p.bidx ? p.bidx[n] : n) : n];
+        if (p.bias) bv = p.bias[p.bias_gather ? (p.bidx ? p.bidx[nc] : nc) : nc];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -252,68 +311,101 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
           if (m < M && n < N) ws[(int64_t)m * p.N + n] = acc[i][j][r];
         }
       }
-  } else {  // EPI_LOSS : bias + loss + dLoss/dLogits
-    __shared__ float lred[4];
+  } else {  // EPI_LOSS : bias + loss + dLoss/dLogits (+ column sums of dO)
+    float *lred = smem;                 // reuse the staging LDS (all waves are past the k-loop)
+    float *cpart = smem + 8;            // [WM][BN] column partial sums
     const int ldc = *p.ld_dev;
     const rk_block_t &b = p.blk;
+    const bool implicit = b.implicit != 0;
     float lsum = 0.f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j) {
+      const int nb = n0 + (wn * TN + j) * 32;   // multiple of 32
+      const int n = nb + l31;
+      const int nc = min(n, N - 1);
+      const float bv = p.bias[p.bidx ? p.bidx[nc] : nc];
+      float csum = 0.f;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int nb = n0 + (wn * TN + j) * 32;   // multiple of 32
-        const int n = nb + l31;
-        float bv = 0.f;
-        if (n < N) bv = p.bias[p.bidx ? p.bidx[n] : n];
+      for (int i = 0; i < TM; ++i) {
+        // the 16 bitmap words of this 32x32 tile: independent loads, issued together
+        uint32_t w[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m < M && n < N) {
-            const int row = p.row_off + m;
-            const float o = acc[i][j][r] + bv;
-            float t = 0.f;
-            const uint32_t word = b.bits_rc[(int64_t)row * b.ldw_rc + (nb >> 5)];
-            if ((word >> l31) & 1u) {
-              const int jj = rk_find_col(b.cols, b.indptr[row], b.indptr[row + 1], n);
-              if (jj >= 0) t = b.vals[jj];
-            }
-            float l, g;
-            if (p.loss_kind == RK_LOSS_MSE) {
-              const float w = (t > 0.f) ? (1.0f + p.confidence) : 1.0f;
-              const float d = o - t;
-              l = w * (d * d);
-              g = (2.0f * d) * (w * p.inv_B);
-            } else {  // BCE with logits: (1-t)*o - logsigmoid(o)
-              const float ls = fminf(o, 0.f) - log1pf(expf(-fabsf(o)));
-              l = (1.0f - t) * o - ls;
-              const float sg = 1.0f / (1.0f + expf(-o));
-              g = (sg - t) * p.inv_B;
-            }
+          const int row = p.row_off + min(m, M - 1);
+          w[r] = b.bits_rc[(int64_t)row * b.ldw_rc + min(nb >> 5, b.ldw_rc - 1)];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const bool ok = (m < M) && (n < N);
+          const float o = acc[i][j][r] + bv;
+          float t = 0.f;
+          if (ok && ((w[r] >> l31) & 1u)) {
+            t = 1.0f;
+            if (!implicit) t = b.vals[rk_entry_index(b, p.row_off + m, n, w[r])];
+          }
+          float l, g;
+          if (p.loss_kind == RK_LOSS_MSE) {
+            const float wgt = (t > 0.f) ? (1.0f + p.confidence) : 1.0f;
+            const float d = o - t;
+            l = wgt * (d * d);
+            g = (2.0f * d) * (wgt * p.inv_B);
+          } else {  // BCE with logits: (1-t)*o - logsigmoid(o)
+            const float ls = fminf(o, 0.f) - log1pf(expf(-fabsf(o)));
+            l = (1.0f - t) * o - ls;
+            const float sg = 1.0f / (1.0f + expf(-o));
+            g = (sg - t) * p.inv_B;
+          }
+          if (ok) {
             lsum += l;
+            csum += g;
             p.C[(int64_t)m * ldc + n] = g;
           }
         }
       }
+      // column sum over this wave's rows: the two lane halves hold different rows
+      csum += __shfl_xor(csum, 32, 64);
+      if (lh == 0) cpart[wm * BN + (wn * TN + j) * 32 + l31] = csum;
+    }
     lsum = rk_wave_sum(lsum);
     if (lane == 0) lred[wid] = lsum;
     __syncthreads();
     if (tid == 0) p.loss_part[blockIdx.x] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
+    if (p.gb_part && tid < BN) {
+      const int n = n0 + tid;
+      if (n < N) {
+        float s = cpart[tid];
+#pragma unroll
+        for (int w2 = 1; w2 < WM; ++w2) s += cpart[w2 * BN + tid];
+        p.gb_part[(int64_t)mt * ldc + n] = s;
+      }
+    }
   }
 }
 
 // ws[split][M][N] -> out[M][N] (fixed split order), optional * act'(Zact)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(
-    const float *__restrict__ ws, int M, int N, const int32_t *__restrict__ Kdev, int kchunk,
+    const float *__restrict__ ws, int M, int N, const int32_t *__restrict__ Kdev, int unused,
     int max_splits, const float *__restrict__ Zact, int act, float *__restrict__ out) {
   const int K = *Kdev;
+  const int kchunk = ((K + max_splits - 1) / max_splits + 15) & ~15;   // as the GEMM derives it
   int ns = (K + kchunk - 1) / kchunk;
   if (ns > max_splits) ns = max_splits;
-  const int64_t tot = (int64_t)M * N;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
-    float s = 0.f;
-    for (int z = 0; z < ns; ++z) s += ws[(int64_t)z * tot + i];
-    if (Zact) s *= rk_act_dy(Zact[i], act);
-    out[i] = s;
+  const int64_t tot4 = ((int64_t)M * N) >> 2;      // M*N is a multiple of 4 (N = h)
+  const float4 *ws4 = reinterpret_cast<const float4 *>(ws);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot4; i += (int64_t)gridDim.x * 256) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < ns; ++z) {
+      const float4 v = ws4[(int64_t)z * tot4 + i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (Zact) {
+      const float4 y = reinterpret_cast<const float4 *>(Zact)[i];
+      s.x *= rk_act_dy(y.x, act); s.y *= rk_act_dy(y.y, act);
+      s.z *= rk_act_dy(y.z, act); s.w *= rk_act_dy(y.w, act);
+    }
+    reinterpret_cast<float4 *>(out)[i] = s;
   }
 }
 
@@ -325,6 +417,7 @@ __global__ __launch_bounds__(256) void mnll_finish_kernel(float *dO, rk_block_t 
   const int r = blockIdx.x, row = row_off + r;
   const int n = b.counts[0], ld = b.counts[2];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const bool implicit = b.implicit != 0;
   float *orow = dO + (int64_t)r * ld;
   float mx = -INFINITY;
   for (int c = tid; c < n; c += 256) mx = fmaxf(mx, orow[c]);
@@ -344,16 +437,16 @@ __global__ __launch_bounds__(256) void mnll_finish_kernel(float *dO, rk_block_t 
   const int beg = b.indptr[row], end = b.indptr[row + 1];
   float lp = 0.f, sg = 0.f;
   for (int j = beg + tid; j < end; j += 256) {
-    const float t = b.vals[j];
+    const float t = implicit ? 1.0f : b.vals[j];
     const float lsm = (orow[b.cols[j]] - mx) - lsum;
     lp += -t * lsm;
     sg += -t * inv_B;
   }
   lp = rk_wave_sum(lp);
   sg = rk_wave_sum(sg);
-  if (lane == 0) { red[wid] = lp; }
+  if (lane == 0) red[wid] = lp;
   __syncthreads();
-  if (tid == 0) { loss_part[r] = (red[0] + red[1]) + (red[2] + red[3]); }
+  if (tid == 0) loss_part[r] = (red[0] + red[1]) + (red[2] + red[3]);
   __syncthreads();
   if (lane == 0) red[wid] = sg;
   __syncthreads();
@@ -366,8 +459,8 @@ __global__ __launch_bounds__(256) void mnll_finish_kernel(float *dO, rk_block_t 
     float g = 0.f;
     const uint32_t word = b.bits_rc[(int64_t)row * b.ldw_rc + (c >> 5)];
     if ((word >> (c & 31)) & 1u) {
-      const int jj = rk_find_col(b.cols, beg, end, c);
-      if (jj >= 0) g = -b.vals[jj] * inv_B;
+      const float t = implicit ? 1.0f : b.vals[rk_entry_index(b, row, c, word)];
+      g = -t * inv_B;
     }
     orow[c] = g - e * sum_g;
   }
@@ -388,14 +481,10 @@ __global__ __launch_bounds__(64) void loss_reduce_kernel(float *part, int n, flo
   if (lane == 0) loss[0] = (float)s / denom;
 }
 
-__global__ __launch_bounds__(256) void fill_kernel(float *p, int64_t n, float v) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    p[i] = v;
-}
-
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 constexpr int DZ_SPLITS = 64;
+constexpr int DEC_BM = 64;          // rows per decode tile (rk_loss_partials, gb_part rows)
 
 }  // namespace
 
@@ -403,17 +492,20 @@ extern "C" int64_t rk_dz_workspace_bytes(int32_t B, int32_t h) {
   return (int64_t)DZ_SPLITS * B * h * sizeof(float);
 }
 
+extern "C" int32_t rk_decode_row_tile(void) { return DEC_BM; }
+
 extern "C" int32_t rk_loss_partials(int32_t B, int32_t n_cap) {
-  const int tiles = rk_cdiv(B, 128) * rk_cdiv(n_cap, 128);
+  const int tiles = rk_cdiv(B, DEC_BM) * rk_cdiv(n_cap, 128);
   return tiles > B ? tiles : B;
 }
 
 extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
                               int32_t row_off, const float *W_de, const float *b_de,
                               int32_t loss_kind, float confidence, float inv_B, float *dO,
-                              int32_t ld_out, float *loss_part, void *stream_) {
+                              int32_t ld_out, float *loss_part, float *gb_part, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(h % 4 == 0, "h must be a multiple of 4");
+  RK_REQUIRE(aligned16(Z) && aligned16(W_de), "Z and W_de must be 16-byte aligned");
   RK_REQUIRE(row_off >= 0 && row_off + B <= tgt->S_cap, "row slice out of range");
   if (B == 0) return 0;
   GemmP p = {};
@@ -421,24 +513,26 @@ extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_blo
   p.Bm = W_de; p.ldb = h; p.bidx = tgt->items;
   p.M = B; p.N = tgt->n_cap; p.K = h;
   p.Ndev = tgt->counts;          // n_t
-  p.tiles_m = rk_cdiv(B, 128);
+  p.tiles_m = rk_cdiv(B, DEC_BM);
   p.kchunk = h;
-  p.a_vec = aligned16(Z); p.b_vec = aligned16(W_de);
   p.C = dO; p.bias = b_de; p.bias_gather = 1; p.act = RK_ACT_NONE;
   p.blk = *tgt; p.row_off = row_off; p.loss_kind = loss_kind;
-  p.confidence = confidence; p.inv_B = inv_B; p.loss_part = loss_part;
+  p.confidence = confidence; p.inv_B = inv_B; p.loss_part = loss_part; p.gb_part = gb_part;
   const int tiles = p.tiles_m * rk_cdiv(tgt->n_cap, 128);
+  // 64x128 tiles, BK = 32: ~2x the workgroups of a 128x128 tiling (two resident
+  // per CU hide the staging latency) and 2x the MFMA work per staged tile
   if (loss_kind == RK_LOSS_MSE || loss_kind == RK_LOSS_BCE) {
     // loss_part must be all-zero on entry (surplus tiles never write their slot):
     // it is allocated zeroed and rk_loss_reduce re-zeroes what it consumed
+    RK_REQUIRE(tgt->implicit || tgt->pref_rc != nullptr, "explicit values need pref_rc");
     p.ld_dev = tgt->counts + 2;
-    hipLaunchKernelGGL((gemm_kernel<2, 2, 2, 2, 0, 0, EPI_LOSS>), dim3(tiles, 1), dim3(256), 0,
-                       stream, p);
+    hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 2, 0, 0, EPI_LOSS, true, 32>), dim3(tiles, 1), dim3(256),
+                       0, stream, p);
   } else {
     if (loss_kind == RK_LOSS_MNLL) { p.ldc = 0; p.ld_dev = tgt->counts + 2; }
-    else { RK_REQUIRE(ld_out >= tgt->n_cap || ld_out > 0, "ld_out"); p.ldc = ld_out; }
-    hipLaunchKernelGGL((gemm_kernel<2, 2, 2, 2, 0, 0, EPI_STORE>), dim3(tiles, 1), dim3(256), 0,
-                       stream, p);
+    else { RK_REQUIRE(ld_out > 0, "ld_out"); p.ldc = ld_out; }
+    hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 2, 0, 0, EPI_STORE, true, 32>), dim3(tiles, 1), dim3(256),
+                       0, stream, p);
   }
   RK_CHECK_LAUNCH("decode_loss");
   return 0;
@@ -448,6 +542,7 @@ extern "C" int rk_mnll_finish(float *dO, int32_t B, const rk_block_t *tgt, int32
                               float inv_B, float *loss_part, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B == 0) return 0;
+  RK_REQUIRE(tgt->implicit || tgt->pref_rc != nullptr, "explicit values need pref_rc");
   hipLaunchKernelGGL(mnll_finish_kernel, dim3(B), dim3(256), 0, stream, dO, *tgt, row_off, inv_B,
                      loss_part);
   RK_CHECK_LAUNCH("mnll_finish");
@@ -468,28 +563,28 @@ extern "C" int rk_decode_bwd_dz(const float *dO, int32_t B, int32_t h, const rk_
                                 float *workspace, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(h % 4 == 0, "h must be a multiple of 4");
+  RK_REQUIRE(aligned16(dO) && aligned16(W_de) && aligned16(workspace) && aligned16(dZ),
+             "operands must be 16-byte aligned");
   if (B == 0) return 0;
   GemmP p = {};
   p.A = dO; p.lda_dev = tgt->counts + 2;
   p.Bm = W_de; p.ldb = h; p.bidx = tgt->items;
   p.M = B; p.N = h; p.K = tgt->n_cap; p.Kdev = tgt->counts;
-  p.a_vec = aligned16(dO); p.b_vec = aligned16(W_de);
   p.C = workspace;
-  int kchunk = rk_cdiv(rk_cdiv(tgt->n_cap, DZ_SPLITS), 16) * 16;
-  if (kchunk < 16) kchunk = 16;
-  p.kchunk = kchunk;
-  const int splits = rk_cdiv(tgt->n_cap, kchunk);
+  p.kchunk = 0;                       // derived in-kernel from the device-resident n_t
+  const int splits = DZ_SPLITS;
+  const int kchunk = 0;
   // wave tile 32 x (32*TN): pick TN by h
   const int tn = h <= 64 ? 2 : (h <= 128 ? 4 : (h <= 224 ? 7 : 8));
   p.tiles_m = rk_cdiv(B, 128);
   const int tiles = p.tiles_m * rk_cdiv(h, 32 * tn);
-#define LAUNCH(TN)                                                                         \
-  hipLaunchKernelGGL((gemm_kernel<4, 1, 1, TN, 0, 1, EPI_SPLITK>), dim3(tiles, splits),    \
+#define LAUNCH(TN)                                                                              \
+  hipLaunchKernelGGL((gemm_kernel<4, 1, 1, TN, 0, 1, EPI_SPLITK, true>), dim3(tiles, splits),   \
                      dim3(256), 0, stream, p)
   if (tn == 2) LAUNCH(2); else if (tn == 4) LAUNCH(4); else if (tn == 7) LAUNCH(7); else LAUNCH(8);
 #undef LAUNCH
   RK_CHECK_LAUNCH("decode_bwd_dz");
-  int grid = rk_cdiv((int64_t)B * h, 256);
+  int grid = rk_cdiv((int64_t)B * h / 4, 256);
   if (grid > 1024) grid = 1024;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, workspace, B, h,
                      tgt->counts, kchunk, splits, Zact, act, dZ);
@@ -497,34 +592,43 @@ extern "C" int rk_decode_bwd_dz(const float *dO, int32_t B, int32_t h, const rk_
   return 0;
 }
 
-// G_de[n_t,h] = dO^T . Z   (M = n_t, N = h, K = B); gb_de = colsum(dO)
+// G_de[n_t,h] = dO^T . Z   (M = n_t, N = h, K = B); gb_de = colsum(dO) if asked
 extern "C" int rk_decode_bwd_dw(const float *dO, const float *Z, int32_t B, int32_t h,
                                 const rk_block_t *tgt, float *G_de, float *gb_de,
                                 void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(h % 4 == 0, "h must be a multiple of 4");
+  RK_REQUIRE(aligned16(dO) && aligned16(Z) && aligned16(G_de), "operands must be 16-byte aligned");
   if (B == 0) return 0;
   GemmP p = {};
   p.A = dO; p.lda_dev = tgt->counts + 2;
   p.Bm = Z; p.ldb = h;
   p.M = tgt->n_cap; p.Mdev = tgt->counts; p.N = h; p.K = B;
-  p.a_vec = aligned16(dO); p.b_vec = aligned16(Z);
   p.kchunk = B;
   p.C = G_de; p.ldc = h; p.act = RK_ACT_NONE;
   p.tiles_m = rk_cdiv(tgt->n_cap, 32);
-  if (h <= 128) {
+  {
+    // 32 x 128 tiles, BK = 32 (two workgroups per CU at h = 200)
     const int tiles = p.tiles_m * rk_cdiv(h, 128);
-    hipLaunchKernelGGL((gemm_kernel<1, 4, 1, 1, 1, 1, EPI_STORE>), dim3(tiles, 1), dim3(256), 0,
-                       stream, p);
-  } else {
-    const int tiles = p.tiles_m * rk_cdiv(h, 256);
-    hipLaunchKernelGGL((gemm_kernel<1, 4, 1, 2, 1, 1, EPI_STORE>), dim3(tiles, 1), dim3(256), 0,
-                       stream, p);
+    hipLaunchKernelGGL((gemm_kernel<1, 4, 1, 1, 1, 1, EPI_STORE, true, 32>), dim3(tiles, 1),
+                       dim3(256), 0, stream, p);
   }
   RK_CHECK_LAUNCH("decode_bwd_dw");
   if (gb_de) return rk_colsum(dO, B, tgt->n_cap, 0, tgt->counts, gb_de, stream_);
   return 0;
 }
+
+namespace {
+template <int AMODE, int BMODE>
+void launch_small(const GemmP &p, int tiles, bool vec, hipStream_t stream) {
+  if (vec)
+    hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 1, AMODE, BMODE, EPI_STORE, true>), dim3(tiles, 1),
+                       dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 1, AMODE, BMODE, EPI_STORE, false>), dim3(tiles, 1),
+                       dim3(256), 0, stream, p);
+}
+}  // namespace
 
 // Y[B,N] = act(X[B,K] . W^T + b);  W is [N,K] (nn.Linear) or [K,N] if w_transposed
 extern "C" int rk_linear_fwd(const float *X, const float *W, const float *b, int32_t B,
@@ -536,17 +640,12 @@ extern "C" int rk_linear_fwd(const float *X, const float *W, const float *b, int
   p.A = X; p.lda = K;
   p.Bm = W; p.ldb = w_transposed ? N : K;
   p.M = B; p.N = N; p.K = K; p.kchunk = K;
-  p.a_vec = aligned16(X) && (K % 4 == 0);
-  p.b_vec = aligned16(W) && (p.ldb % 4 == 0);
+  const bool vec = aligned16(X) && aligned16(W) && (K % 4 == 0) && (p.ldb % 4 == 0);
   p.C = Y; p.ldc = N; p.bias = b; p.act = act;
   p.tiles_m = rk_cdiv(B, 64);
   const int tiles = p.tiles_m * rk_cdiv(N, 64);
-  if (!w_transposed)
-    hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 1, 0, 0, EPI_STORE>), dim3(tiles, 1), dim3(256), 0,
-                       stream, p);
-  else
-    hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 1, 0, 1, EPI_STORE>), dim3(tiles, 1), dim3(256), 0,
-                       stream, p);
+  if (!w_transposed) launch_small<0, 0>(p, tiles, vec, stream);
+  else launch_small<0, 1>(p, tiles, vec, stream);
   RK_CHECK_LAUNCH("linear_fwd");
   return 0;
 }
@@ -565,17 +664,12 @@ extern "C" int rk_linear_bwd(float *dY, const float *Y, const float *X, const fl
     p.A = dY; p.lda = N;
     p.Bm = W; p.ldb = ldw;
     p.M = B; p.N = K; p.K = N; p.kchunk = N;
-    p.a_vec = aligned16(dY) && (N % 4 == 0);
-    p.b_vec = aligned16(W) && (ldw % 4 == 0);
+    const bool vec = aligned16(dY) && aligned16(W) && (N % 4 == 0) && (ldw % 4 == 0);
     p.C = dX; p.ldc = K; p.act = RK_ACT_NONE;
     p.tiles_m = rk_cdiv(B, 64);
     const int tiles = p.tiles_m * rk_cdiv(K, 64);
-    if (!w_transposed)   // W[N,K]: row = reduction index -> k-major
-      hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 1, 0, 1, EPI_STORE>), dim3(tiles, 1), dim3(256), 0,
-                         stream, p);
-    else                 // Wst[K,N]: row = output index, reduction contiguous
-      hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 1, 0, 0, EPI_STORE>), dim3(tiles, 1), dim3(256), 0,
-                         stream, p);
+    if (!w_transposed) launch_small<0, 1>(p, tiles, vec, stream);   // W[N,K]: k-major
+    else launch_small<0, 0>(p, tiles, vec, stream);                 // Wst[K,N]: reduction contiguous
     RK_CHECK_LAUNCH("linear_bwd_dx");
   }
   if (dW) {
@@ -586,12 +680,10 @@ extern "C" int rk_linear_bwd(float *dY, const float *Y, const float *X, const fl
     } else {              // dWst[K,N] = X^T . dY
       p.A = X; p.lda = K; p.Bm = dY; p.ldb = N; p.M = K; p.N = N; p.ldc = N;
     }
-    p.a_vec = aligned16(p.A) && (p.lda % 4 == 0);
-    p.b_vec = aligned16(p.Bm) && (p.ldb % 4 == 0);
+    const bool vec = aligned16(p.A) && aligned16(p.Bm) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
     p.tiles_m = rk_cdiv(p.M, 64);
     const int tiles = p.tiles_m * rk_cdiv(p.N, 64);
-    hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 1, 1, 1, EPI_STORE>), dim3(tiles, 1), dim3(256), 0,
-                       stream, p);
+    launch_small<1, 1>(p, tiles, vec, stream);
     RK_CHECK_LAUNCH("linear_bwd_dw");
   }
   return 0;

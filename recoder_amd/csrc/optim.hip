@@ -121,24 +121,39 @@ __global__ __launch_bounds__(256) void dropout_kernel(float *X, const uint8_t *k
   }
 }
 
-// out[c] = sum_r X[r*ld + c]; block = 64 columns x 4 row slices, fixed order
-__global__ __launch_bounds__(256) void colsum_kernel(const float *X, int rows, int cols_host,
-                                                     int ld_host, const int32_t *counts,
-                                                     float *out) {
-  __shared__ float part[4][64];
+// out[c] = sum_r X[r*ld + c]; block = 64 columns x 16 row slices (1024 threads),
+// 4 independent accumulators per thread, everything combined in a fixed order
+__global__ __launch_bounds__(1024) void colsum_kernel(const float *X, int rows, int cols_host,
+                                                      int ld_host, const int32_t *counts,
+                                                      float *out) {
+  __shared__ float part[16][64];
   const int cols = counts ? counts[0] : cols_host;
   const int ld = counts ? counts[2] : ld_host;
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int lc = threadIdx.x & 63;
+  const int c = blockIdx.x * 64 + lc;
   const int s = threadIdx.x >> 6;
-  const int per = (rows + 3) >> 2;
+  const int per = (rows + 15) >> 4;
   const int r0 = s * per, r1 = min(rows, r0 + per);
-  float acc = 0.f;
-  if (c < cols)
-    for (int r = r0; r < r1; ++r) acc += X[(int64_t)r * ld + c];
-  part[s][threadIdx.x & 63] = acc;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < cols) {
+    const float *x = X + c;
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {
+      a0 += x[(int64_t)r * ld];
+      a1 += x[(int64_t)(r + 1) * ld];
+      a2 += x[(int64_t)(r + 2) * ld];
+      a3 += x[(int64_t)(r + 3) * ld];
+    }
+    for (; r < r1; ++r) a0 += x[(int64_t)r * ld];
+  }
+  part[s][lc] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (s == 0 && c < cols)
-    out[c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+  if (s == 0 && c < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += part[k][lc];
+    out[c] = t;
+  }
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float *E, const int64_t *rows, int B,
@@ -262,7 +277,7 @@ extern "C" int rk_colsum(const float *X, int32_t rows, int32_t cols, int32_t ld,
                          const int32_t *counts_dev, float *out, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (cols == 0) return 0;
-  hipLaunchKernelGGL(colsum_kernel, dim3(rk_cdiv(cols, 64)), dim3(256), 0, stream, X, rows, cols, ld,
+  hipLaunchKernelGGL(colsum_kernel, dim3(rk_cdiv(cols, 64)), dim3(1024), 0, stream, X, rows, cols, ld,
                      counts_dev, out);
   RK_CHECK_LAUNCH("colsum");
   return 0;

@@ -101,16 +101,17 @@ class Block:
     # the transposed bitmap is only needed by the encoder backward (training)
     self.bits_cr = torch.zeros(self.n_cap * self.ldw_cr, **i32) if need_bits_cr else None
     self.scan_tmp = torch.zeros(self.n_chunks + 1, **i32)
+    self.pref_rc = torch.zeros(S_cap * self.ldw_rc, **i32)
     self.stamp = 0
     self.users = None      # int64 device tensor of the rows of the last collate
     self.S = 0
     self.c = RkBlock(
         S_cap=S_cap, nnz_cap=nnz_cap, n_cap=self.n_cap, n_items=self.n_items,
-        ldw_rc=self.ldw_rc, ldw_cr=self.ldw_cr, n_chunks=self.n_chunks, reserved=0,
+        ldw_rc=self.ldw_rc, ldw_cr=self.ldw_cr, n_chunks=self.n_chunks, implicit=0,
         counts=ptr(self.counts), indptr=ptr(self.indptr), cols=ptr(self.cols),
         vals=ptr(self.vals), svals=ptr(self.svals), items=ptr(self.items), pos=ptr(self.pos),
         mark=ptr(self.mark), bits_rc=ptr(self.bits_rc), bits_cr=ptr(self.bits_cr),
-        scan_tmp=ptr(self.scan_tmp))
+        scan_tmp=ptr(self.scan_tmp), pref_rc=ptr(self.pref_rc))
     self.ref = ctypes.byref(self.c)
 
   def collate(self, dcsr, users_dev, negative_sampling=None, phase=0):
@@ -126,6 +127,7 @@ class Block:
         self.mark.zero_()
         self.stamp = 1
     self.users, self.S = users_dev, S
+    self.c.implicit = 1 if dcsr.data is None else 0
     lib = _lib.load()
     check(lib.rk_collate(ptr(dcsr.indptr), ptr(dcsr.indices), ptr(dcsr.data), ptr(users_dev), S,
                          1 if ns else 0, self.stamp, phase, self.ref, current_stream()),

@@ -44,7 +44,7 @@ class TimedLib:
 
   def __getattr__(self, name):
     fn = getattr(self._lib, name)
-    if not name.startswith("rk_") or name in ("rk_dz_workspace_bytes", "rk_loss_partials",
+    if not name.startswith("rk_") or name in ("rk_dz_workspace_bytes", "rk_loss_partials", "rk_decode_row_tile",
                                               "rk_last_error", "rk_version"):
       return fn
 
@@ -118,6 +118,8 @@ class FusedEngine:
     self.G_de = torch.empty(n_cap * h0, **f)
     self.G_en = torch.empty(n_cap * h0, **f)
     self.gb_de = torch.empty(n_cap, **f)
+    self.row_tile = self.lib.rk_decode_row_tile()
+    self.gb_part = torch.empty(cdiv(B_cap, self.row_tile) * ld_cap, **f)   # per-row-tile colsums of dO
     self.gb_en = torch.empty(h0, **f)
     self.ws = torch.empty(self.lib.rk_dz_workspace_bytes(B_cap, h0) // 4, **f)
     self.n_part = self.lib.rk_loss_partials(B_cap, n_cap)
@@ -255,14 +257,14 @@ class FusedEngine:
     inv_B = _f32(np.float32(1.0) / np.float32(denom_rows))
     out = self.loss_out if out is None else out
     check(lib.rk_decode_loss(ptr(z), B, self.h[0], tgt.ref, row_off, ptr(W), ptr(b), self.loss_id,
-                             self.confidence, inv_B, ptr(self.dO), 0, ptr(self.loss_part), stream),
-          "rk_decode_loss")
+                             self.confidence, inv_B, ptr(self.dO), 0, ptr(self.loss_part),
+                             ptr(self.gb_part), stream), "rk_decode_loss")
     if self.loss_id == LOSS_MNLL:
       check(lib.rk_mnll_finish(ptr(self.dO), B, tgt.ref, row_off, inv_B, ptr(self.loss_part),
                                stream), "rk_mnll_finish")
       n_part = B
     else:
-      n_part = cdiv(B, 128) * cdiv(tgt.n_cap, 128)
+      n_part = cdiv(B, self.row_tile) * cdiv(tgt.n_cap, 128)
     check(lib.rk_loss_reduce(ptr(self.loss_part), n_part, float(denom_rows), ptr(out), stream),
           "rk_loss_reduce")
     return out
@@ -306,8 +308,16 @@ class FusedEngine:
     check(lib.rk_decode_bwd_dz(ptr(self.dO), B, h0, blk.ref, ptr(W_de),
                                ptr(self.enc[0]) if simple else None, self.act, ptr(dz),
                                ptr(self.ws), stream), "rk_decode_bwd_dz")
-    check(lib.rk_decode_bwd_dw(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(self.G_de),
-                               ptr(self.gb_de), stream), "rk_decode_bwd_dw")
+    if self.loss_id == LOSS_MNLL:
+      # dO was produced by rk_mnll_finish: column sums need a pass over dO
+      check(lib.rk_decode_bwd_dw(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(self.G_de),
+                                 ptr(self.gb_de), stream), "rk_decode_bwd_dw")
+    else:
+      # the loss epilogue already reduced dO per 128-row tile: sum those few rows
+      check(lib.rk_colsum(ptr(self.gb_part), cdiv(B, self.row_tile), blk.n_cap, 0, ptr(blk.counts),
+                          ptr(self.gb_de), stream), "rk_colsum")
+      check(lib.rk_decode_bwd_dw(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(self.G_de), None,
+                                 stream), "rk_decode_bwd_dw")
 
     if self.kind == "ae":
       rh = list(reversed(self.h))
@@ -436,7 +446,7 @@ class FusedEngine:
       z = self._mf_forward(blk.users[row_off:row_off + B], B, None, False, stream)
     W, b = self._decoder_params()
     check(self.lib.rk_decode_loss(ptr(z), B, self.h[0], tgt_items_blk.ref, 0, ptr(W), ptr(b),
-                                  LOSS_NONE, 0.0, 1.0, ptr(out), ld_out, None, stream),
+                                  LOSS_NONE, 0.0, 1.0, ptr(out), ld_out, None, None, stream),
           "rk_decode_loss")
     return out
 
@@ -511,7 +521,7 @@ def ae_dense_forward(model, x, input_items=None, target_items=None):
   W, b = eng._decoder_params()
   out = torch.empty(B, n_t, dtype=torch.float32, device=dev)
   check(eng.lib.rk_decode_loss(ptr(z), B, eng.h[0], tblk.ref, 0, ptr(W), ptr(b), LOSS_NONE, 0.0, 1.0,
-                               ptr(out), n_t, None, stream), "rk_decode_loss")
+                               ptr(out), n_t, None, None, stream), "rk_decode_loss")
   return out
 
 
@@ -536,5 +546,5 @@ def mf_dense_forward(model, input_users, target_items=None):
   W, b = eng._decoder_params()
   out = torch.empty(B, n_t, dtype=torch.float32, device=dev)
   check(eng.lib.rk_decode_loss(ptr(z), B, eng.h[0], tblk.ref, 0, ptr(W), ptr(b), LOSS_NONE, 0.0, 1.0,
-                               ptr(out), n_t, None, stream), "rk_decode_loss")
+                               ptr(out), n_t, None, None, stream), "rk_decode_loss")
   return out
