@@ -230,6 +230,7 @@ def main():
   t0 = time.perf_counter()
   for i in range(args.warmup, total):
     step(i)
+  t_enqueue = time.perf_counter() - t0      # host time to enqueue the timed steps
   torch.cuda.synchronize()
   if world > 1:
     dist.barrier()
@@ -267,7 +268,8 @@ def main():
       "vs_baseline": None, "dtype": "f32", "data": "synthetic",
       "config": {"workload": cfg["workload"], "batch_size_per_gpu": B, "global_batch": B * world,
                  "parallelism": "dp%d" % world, "avg_sampled_items": n_b, "avg_nnz_per_batch": nnz,
-                 "first_loss": float(losses[0]), "last_loss": float(losses[-1])},
+                 "first_loss": float(losses[0]), "last_loss": float(losses[-1]),
+                 "host_enqueue_ms_per_step": t_enqueue / args.steps * 1e3},
       "roofline": roofline,
     }
     if world == 1 and not args.no_cpu_baseline:

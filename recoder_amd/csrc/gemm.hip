@@ -22,11 +22,18 @@
 // k-major operands sit as [16][tile] and are read with ds_read_b32.
 #include "common.h"
 
+#ifdef RK_PROBE
+__device__ unsigned long long rk_dbg[256];
+#define RK_T(slot) do { if (blockIdx.x == 8 && blockIdx.y == 0 && threadIdx.x == 0) rk_dbg[slot] = __builtin_readcyclecounter(); } while (0)
+#else
+#define RK_T(slot) do {} while (0)
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_STORE = 0, EPI_LOSS = 1, EPI_SPLITK = 2 };
+enum { EPI_STORE = 0, EPI_LOSS_MSE = 1, EPI_SPLITK = 2, EPI_LOSS_BCE = 3 };
 
 struct GemmP {
   const float *A;
@@ -36,7 +43,8 @@ struct GemmP {
   const int32_t *lda_dev, *ldb_dev;   // leading dimension read from the device when non-null
   int M, N, K;              // host sizes (capacities when *_dev given)
   const int32_t *Mdev, *Ndev, *Kdev;
-  int tiles_m;              // host: ceil(Mcap / BM)
+  int tiles_m;              // host: ceil(Mcap / BM) (grid sizing only)
+  int n_fastest;            // tile order inside a split: nt fastest (else mt fastest)
   int kchunk;               // K range per blockIdx.y
   // store epilogue
   float *C;
@@ -55,29 +63,33 @@ struct GemmP {
   float *gb_part;           // [tiles_m][ld] column sums of dO per row tile (nullable)
 };
 
-// Branch-free guarded load of 4 consecutive floats; `valid` (<= 0 .. >= 4) of
-// them are logically in range, the rest read as 0.  VEC: one 16-B load (the
-// caller guarantees 16-B alignment and that the 4 floats lie inside the
+// Branch-free guarded staging of 4 consecutive floats, split in two so that the
+// global load can stay in flight across the MFMA block:
+//   ld4_raw  : the load alone, from a clamped (always readable) address
+//   mask4    : zero the elements that are logically out of range -- applied
+//              when the registers are written to LDS, one phase later.
+// `valid` (<= 0 .. >= 4) = how many of the 4 floats are in range.  VEC: one
+// 16-B load (caller guarantees alignment and that the 4 floats lie inside the
 // allocation whenever valid > 0).
 template <bool VEC>
-__device__ __forceinline__ float4 ld4(const float *base, int64_t off, int valid) {
+__device__ __forceinline__ float4 ld4_raw(const float *base, int64_t off, int valid) {
   float4 r;
   if (VEC) {
-    const float4 v = *reinterpret_cast<const float4 *>(base + (valid > 0 ? off : 0));
-    r.x = valid > 0 ? v.x : 0.f;
-    r.y = valid > 1 ? v.y : 0.f;
-    r.z = valid > 2 ? v.z : 0.f;
-    r.w = valid > 3 ? v.w : 0.f;
+    r = *reinterpret_cast<const float4 *>(base + (valid > 0 ? off : 0));
   } else {
-    const float a = base[valid > 0 ? off : 0];
-    const float b = base[valid > 1 ? off + 1 : 0];
-    const float c = base[valid > 2 ? off + 2 : 0];
-    const float d = base[valid > 3 ? off + 3 : 0];
-    r.x = valid > 0 ? a : 0.f;
-    r.y = valid > 1 ? b : 0.f;
-    r.z = valid > 2 ? c : 0.f;
-    r.w = valid > 3 ? d : 0.f;
+    r.x = base[valid > 0 ? off : 0];
+    r.y = base[valid > 1 ? off + 1 : 0];
+    r.z = base[valid > 2 ? off + 2 : 0];
+    r.w = base[valid > 3 ? off + 3 : 0];
   }
+  return r;
+}
+__device__ __forceinline__ float4 mask4(float4 v, int valid) {
+  float4 r;
+  r.x = valid > 0 ? v.x : 0.f;
+  r.y = valid > 1 ? v.y : 0.f;
+  r.z = valid > 2 ? v.z : 0.f;
+  r.w = valid > 3 ? v.w : 0.f;
   return r;
 }
 
@@ -92,19 +104,37 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   constexpr int B_SZ = (BMODE == 0) ? BN * LDK : BK * BN;
   constexpr int A_F4 = BM * BK / 4, B_F4 = BN * BK / 4;      // float4 per tile
   constexpr int A_PT = (A_F4 + 255) / 256, B_PT = (B_F4 + 255) / 256;
-  __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
+  // staging double buffer; the epilogue reuses it (4 per-wave 32x36 transpose areas +
+  // the loss partials), so it is at least that large
+  constexpr int STAGE_F = 2 * (A_SZ + B_SZ);
+  constexpr int EPI_F = 4 * 32 * 36 + 8 + WM * BN;
+  __shared__ __attribute__((aligned(16))) float smem[STAGE_F > EPI_F ? STAGE_F : EPI_F];
 
   const int M = p.Mdev ? *p.Mdev : p.M;
   const int N = p.Ndev ? *p.Ndev : p.N;
   const int K = p.Kdev ? *p.Kdev : p.K;
   const int lda = p.lda_dev ? *p.lda_dev : p.lda;
   const int ldb = p.ldb_dev ? *p.ldb_dev : p.ldb;
-  const int mt = blockIdx.x % p.tiles_m, nt = blockIdx.x / p.tiles_m;
+  // XCD-aware tile mapping.  Workgroup L runs on XCD L % 8 (each XCD has its own
+  // L2), so XCD x gets the contiguous chunk [x*chunk, (x+1)*chunk) of the LIVE
+  // tile list -- tiles that share an operand panel (same nt for gathered W rows,
+  // same mt for a dO column panel, same split) then hit the same L2.  The live
+  // tile count comes from the device-resident M/N, the grid from capacities.
+  const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+  const int nsplit = (int)gridDim.y;
+  const int per_split = tm * tn;
+  const int total = per_split * nsplit;
+  const int L = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+  const int chunk = (total + 7) >> 3;
+  const int t = (L & 7) * chunk + (L >> 3);
+  if ((L >> 3) >= chunk || t >= total) return;
+  const int split = t / per_split, rt = t % per_split;
+  const int mt = p.n_fastest ? rt / tn : rt % tm;
+  const int nt = p.n_fastest ? rt % tn : rt / tm;
   const int m0 = mt * BM, n0 = nt * BN;
-  if (m0 >= M || n0 >= N) return;
   // split-K: the chunk follows the device-resident K so that every split is live
-  const int kchunk = (p.kchunk > 0) ? p.kchunk : (((K + (int)gridDim.y - 1) / (int)gridDim.y + 15) & ~15);
-  const int kbeg = blockIdx.y * kchunk;
+  const int kchunk = (p.kchunk > 0) ? p.kchunk : (((K + nsplit - 1) / nsplit + 15) & ~15);
+  const int kbeg = split * kchunk;
   const int kend = min(K, kbeg + kchunk);
   if (kbeg >= kend) return;
 
@@ -121,122 +151,136 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // ---- loop-invariant per-thread addressing of the staged tiles ----
-  int64_t a_off[A_PT], b_off[B_PT];   // element offset at k-tile 0 (w/o the per-tile k term)
-  int a_lim[A_PT], b_lim[B_PT];       // AMODE/BMODE 0: row valid ? 1 : 0 ; mode 1: valid count along the row
+  // Rows / columns outside the problem are CLAMPED to a readable address instead
+  // of masked: the garbage they bring only reaches output rows/columns that the
+  // epilogue never stores.  Only the K direction needs real zeros, and only in
+  // the last (partial) K-tile -- interior tiles take the lean path below: one
+  // pointer per staged float4, no selects.
+  const float *a_ptr[A_PT], *b_ptr[B_PT];
   int a_k[A_PT], b_k[B_PT];           // k index of the element inside the tile
+  int b_n[B_PT];                      // BMODE 1: column offset (row pointer varies with the gather)
 #pragma unroll
   for (int i = 0; i < A_PT; ++i) {
-    const int idx = tid + i * 256;
+    const int idx = min(tid + i * 256, A_F4 - 1);
     if (AMODE == 0) {
       const int row = idx / QK, q = idx % QK;
-      const int m = m0 + row;
       a_k[i] = q * 4;
-      a_lim[i] = (idx < A_F4 && m < M) ? 1 : 0;
-      a_off[i] = (int64_t)min(m, M - 1) * lda + q * 4;
+      a_ptr[i] = p.A + (int64_t)min(m0 + row, M - 1) * lda + q * 4 + kbeg;
     } else {
       const int k = idx / (BM / 4), m4 = idx % (BM / 4);
       const int m = m0 + m4 * 4;
       a_k[i] = k;
-      a_lim[i] = (idx < A_F4) ? (M - m) : 0;
-      a_off[i] = (int64_t)k * lda + m;
+      a_ptr[i] = p.A + (int64_t)(kbeg + k) * lda + ((m + 3 < lda) ? m : 0);
     }
   }
 #pragma unroll
   for (int i = 0; i < B_PT; ++i) {
-    const int idx = tid + i * 256;
+    const int idx = min(tid + i * 256, B_F4 - 1);
     if (BMODE == 0) {
       const int row = idx / QK, q = idx % QK;
-      const int n = n0 + row;
-      const int nc = min(n, N - 1);
+      const int nc = min(n0 + row, N - 1);
       const int64_t src = p.bidx ? (int64_t)p.bidx[nc] : (int64_t)nc;   // gather index: once
       b_k[i] = q * 4;
-      b_lim[i] = (idx < B_F4 && n < N) ? 1 : 0;
-      b_off[i] = src * ldb + q * 4;
+      b_n[i] = 0;
+      b_ptr[i] = p.Bm + src * ldb + q * 4 + kbeg;
     } else {
       const int k = idx / (BN / 4), n4 = idx % (BN / 4);
       const int n = n0 + n4 * 4;
       b_k[i] = k;
-      b_lim[i] = (idx < B_F4) ? (N - n) : 0;
-      b_off[i] = n;
+      b_n[i] = (n + 3 < ldb) ? n : 0;
+      b_ptr[i] = p.Bm + b_n[i];          // + row * ldb per tile
     }
   }
 
-  float4 ra[A_PT], rb[B_PT];
+  float4 ra0[A_PT], rb0[B_PT], ra1[A_PT], rb1[B_PT];   // two staged tiles in flight
   const bool gather_k = (BMODE == 1) && (p.bidx != nullptr);
 
-  auto gload = [&](int k0) {
+  // kt = tile index inside this block's K range; tiles with (kt+1)*BK <= klen are
+  // interior.  The tail tile clamps k to the last valid index (readable) and is
+  // masked to zero when written to LDS.
+  const int klen = kend - kbeg;
+  // 4 consecutive floats along K starting at (tile-relative) k: interior tiles
+  // read them as they are; the tail tile clamps k to the last readable group
+  auto load_kcontig = [&](const float *ptr_k0, int k, bool tail) -> float4 {
+    // ptr_k0 points at tile-relative k = 0 of this thread's row
+    const int kk = tail ? min(k, (klen - 1) & ~3) : k;
+    const float *q = ptr_k0 + kk;
+    if (VEC) return *reinterpret_cast<const float4 *>(q);
+    const int last = klen - 1 - kk;          // >= 0
+    return make_float4(q[0], q[last > 0 ? 1 : 0], q[last > 1 ? 2 : 0], q[last > 2 ? 3 : 0]);
+  };
+  auto load4 = [&](const float *q) -> float4 {
+    if (VEC) return *reinterpret_cast<const float4 *>(q);
+    return make_float4(q[0], q[1], q[2], q[3]);
+  };
+  auto gload = [&](float4 (&ra)[A_PT], float4 (&rb)[B_PT], int kt) {
+    const int kb = kt * BK;
+    const bool tail = (kb + BK > klen);
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
       if (AMODE == 0) {
-        const int k = k0 + a_k[i];
-        ra[i] = ld4<VEC>(p.A, a_off[i] + k0, a_lim[i] ? (kend - k) : 0);
+        ra[i] = load_kcontig(a_ptr[i] - a_k[i], kb + a_k[i], tail);
       } else {
-        const int kk = k0 + a_k[i];
-        ra[i] = ld4<VEC>(p.A, a_off[i] + (int64_t)k0 * lda, kk < kend ? a_lim[i] : 0);
+        const int row = tail ? min(kb + a_k[i], klen - 1) : kb + a_k[i];
+        ra[i] = load4(a_ptr[i] + (int64_t)(row - a_k[i]) * lda);
       }
     }
     if (BMODE == 0) {
 #pragma unroll
-      for (int i = 0; i < B_PT; ++i) {
-        const int k = k0 + b_k[i];
-        rb[i] = ld4<VEC>(p.Bm, b_off[i] + k0, b_lim[i] ? (kend - k) : 0);
-      }
+      for (int i = 0; i < B_PT; ++i) rb[i] = load_kcontig(b_ptr[i] - b_k[i], kb + b_k[i], tail);
     } else {
       // k-major B with an optional row gather: fetch every gather index first
       // (independent loads), then every row segment
       int src[B_PT];
 #pragma unroll
-      for (int i = 0; i < B_PT; ++i) src[i] = min(k0 + b_k[i], kend - 1);
+      for (int i = 0; i < B_PT; ++i) src[i] = kbeg + (tail ? min(kb + b_k[i], klen - 1) : kb + b_k[i]);
       if (gather_k) {
 #pragma unroll
         for (int i = 0; i < B_PT; ++i) src[i] = p.bidx[src[i]];
       }
 #pragma unroll
-      for (int i = 0; i < B_PT; ++i) {
-        const int kk = k0 + b_k[i];
-        rb[i] = ld4<VEC>(p.Bm, (int64_t)src[i] * ldb + b_off[i], kk < kend ? b_lim[i] : 0);
-      }
+      for (int i = 0; i < B_PT; ++i) rb[i] = load4(b_ptr[i] + (int64_t)src[i] * ldb);
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, const float4 (&ra)[A_PT], const float4 (&rb)[B_PT], int kt) {
+    const int kb = kt * BK;
+    const bool tail = (kb + BK > klen);
     float *As = smem + buf * (A_SZ + B_SZ);
     float *Bs = As + A_SZ;
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
       const int idx = tid + i * 256;
-      if (idx < A_F4) {
+      if ((A_F4 % 256 == 0) || idx < A_F4) {
+        float4 v = ra[i];
+        if (tail) v = mask4(v, (AMODE == 0) ? (klen - kb - a_k[i]) : ((kb + a_k[i] < klen) ? 4 : 0));
         if (AMODE == 0) {
           const int row = idx / QK, q = idx % QK;
-          *reinterpret_cast<float4 *>(As + row * LDK + q * 4) = ra[i];
+          *reinterpret_cast<float4 *>(As + row * LDK + q * 4) = v;
         } else {
           const int k = idx / (BM / 4), m4 = idx % (BM / 4);
-          *reinterpret_cast<float4 *>(As + k * BM + m4 * 4) = ra[i];
+          *reinterpret_cast<float4 *>(As + k * BM + m4 * 4) = v;
         }
       }
     }
 #pragma unroll
     for (int i = 0; i < B_PT; ++i) {
       const int idx = tid + i * 256;
-      if (idx < B_F4) {
+      if ((B_F4 % 256 == 0) || idx < B_F4) {
+        float4 v = rb[i];
+        if (tail) v = mask4(v, (BMODE == 0) ? (klen - kb - b_k[i]) : ((kb + b_k[i] < klen) ? 4 : 0));
         if (BMODE == 0) {
           const int row = idx / QK, q = idx % QK;
-          *reinterpret_cast<float4 *>(Bs + row * LDK + q * 4) = rb[i];
+          *reinterpret_cast<float4 *>(Bs + row * LDK + q * 4) = v;
         } else {
           const int k = idx / (BN / 4), n4 = idx % (BN / 4);
-          *reinterpret_cast<float4 *>(Bs + k * BN + n4 * 4) = rb[i];
+          *reinterpret_cast<float4 *>(Bs + k * BN + n4 * 4) = v;
         }
       }
     }
   };
 
-  const int nk = (kend - kbeg + BK - 1) / BK;
-  gload(kbeg);
-  sstore(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);
-    const float *As = smem + cur * (A_SZ + B_SZ);
+  auto compute = [&](int buf) {
+    const float *As = smem + buf * (A_SZ + B_SZ);
     const float *Bs = As + A_SZ;
 #pragma unroll
     for (int kg = 0; kg < BK / 8; ++kg) {
@@ -271,121 +315,236 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nk) sstore(cur ^ 1);
-    __syncthreads();
-  }
+  };
 
+  // Pipeline: tile kt is computed from LDS buffer kt&1 while the global loads of
+  // tiles kt+1 (already issued, landing in one register set) and kt+2 (issued
+  // now into the other set) are in flight; hipcc's counted vmcnt only waits for
+  // the older set when it is written to LDS.
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  // Loss epilogue operands (gathered bias, bitmap words) are fetched NOW so that
+  // their two dependent round trips overlap the k-loop instead of the epilogue.
+  constexpr bool LOSS = (EPI == EPI_LOSS_MSE || EPI == EPI_LOSS_BCE);
+  float pre_bv[LOSS ? TN : 1][4];
+  uint32_t pre_w[LOSS ? TM : 1][LOSS ? TN : 1][4];
+  if (LOSS) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nb = n0 + (wn * TN + j) * 32;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int nc = min(nb + (lane & 7) * 4 + e, N - 1);
+        pre_bv[j][e] = p.bias[p.bidx ? p.bidx[nc] : nc];
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int m = m0 + (wm * TM + i) * 32 + (lane >> 3) + 8 * it;
+          const int row = p.row_off + min(m, M - 1);
+          pre_w[i][j][it] = p.blk.bits_rc[(int64_t)row * p.blk.ldw_rc + min(nb >> 5, p.blk.ldw_rc - 1)];
+        }
+    }
+  }
+  RK_T(0);
+  gload(ra0, rb0, 0);
+  gload(ra1, rb1, min(1, nk - 1));
+  sstore(0, ra0, rb0, 0);
+  __syncthreads();
+  RK_T(1);
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt == 2) RK_T(2);
+    // prefetch UNCONDITIONALLY (past the end: re-read the last tile, never stored):
+    // a branch around the loads makes hipcc merge the vmcnt state pessimistically
+    // and wait for the loads just issued before every LDS store
+    gload(ra0, rb0, min(kt + 2, nk - 1));
+    if (kt == 2) RK_T(3);
+    compute(0);
+    if (kt == 2) RK_T(4);
+    if (kt + 1 < nk) sstore(1, ra1, rb1, kt + 1);
+    if (kt == 2) RK_T(5);
+    __syncthreads();
+    if (kt == 2) RK_T(6);
+    if (kt + 1 >= nk) break;
+    gload(ra1, rb1, min(kt + 3, nk - 1));
+    compute(1);
+    if (kt + 2 < nk) sstore(0, ra0, rb0, kt + 2);
+    __syncthreads();
+    if (kt == 2) RK_T(7);
+  }
   // ------------------------------------------------------------- epilogues
+  // Every 32x32 accumulator tile goes through a per-wave LDS transpose: the MFMA
+  // layout gives a lane 16 rows of ONE column (16 scalar stores, 16 bitmap words);
+  // read back row-major a lane owns 4 x (one row, 4 consecutive columns), so the
+  // epilogue issues 4x fewer, 16-byte-wide global stores / loads per tile.
+  RK_T(8);
+  constexpr int TLD = 36;                                   // 32 + 4 floats: 16-B aligned rows
+  float *wlds = smem + wid * (32 * TLD);                    // private to this wave
+  const int rr0 = lane >> 3, c4 = lane & 7;                 // row-major role of the lane
+  auto transpose_tile = [&](const f32x16 &a, float4 (&v)[4]) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wlds[((r & 3) + 8 * (r >> 2) + 4 * lh) * TLD + l31] = a[r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      v[it] = *reinterpret_cast<const float4 *>(wlds + (rr0 + 8 * it) * TLD + c4 * 4);
+    __builtin_amdgcn_wave_barrier();
+  };
+
   if (EPI == EPI_STORE) {
     const int ldc = p.ldc > 0 ? p.ldc : *p.ld_dev;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + l31;
-        const int nc = min(n, N - 1);
-        float bv = 0.f;
-        if (p.bias) bv = p.bias[p.bias_gather ? (p.bidx ? p.bidx[nc] : nc) : nc];
+        float4 v[4];
+        transpose_tile(acc[i][j], v);
+        const int n = n0 + (wn * TN + j) * 32 + c4 * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          for (int e = 0; e < 4; ++e) {
+            const int nc = min(n + e, N - 1);
+            bv[e] = p.bias[p.bias_gather ? (p.bidx ? p.bidx[nc] : nc) : nc];
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int m = m0 + (wm * TM + i) * 32 + rr0 + 8 * it;
           if (m < M && n < N) {
-            float v = acc[i][j][r] + bv;
-            v = rk_act(v, p.act);
+            float o[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = rk_act(o[e] + bv[e], p.act);
             float *dst = p.C + (int64_t)m * ldc + n;
-            if (p.accumulate) v += *dst;
-            *dst = v;
+            if (VEC && n + 3 < N) {
+              float4 w4 = make_float4(o[0], o[1], o[2], o[3]);
+              if (p.accumulate) {
+                const float4 old = *reinterpret_cast<const float4 *>(dst);
+                w4.x += old.x; w4.y += old.y; w4.z += old.z; w4.w += old.w;
+              }
+              *reinterpret_cast<float4 *>(dst) = w4;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n + e < N) dst[e] = p.accumulate ? (o[e] + dst[e]) : o[e];
+            }
           }
         }
       }
   } else if (EPI == EPI_SPLITK) {
-    float *ws = p.C + (int64_t)blockIdx.y * p.M * p.N;   // [split][Mcap][Ncap]
+    float *ws = p.C + (int64_t)split * p.M * p.N;   // [split][Mcap][Ncap]
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int n = n0 + (wn * TN + j) * 32 + l31;
+        float4 v[4];
+        transpose_tile(acc[i][j], v);
+        const int n = n0 + (wn * TN + j) * 32 + c4 * 4;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m < M && n < N) ws[(int64_t)m * p.N + n] = acc[i][j][r];
+        for (int it = 0; it < 4; ++it) {
+          const int m = m0 + (wm * TM + i) * 32 + rr0 + 8 * it;
+          if (m < M && n < N) {
+            float *dst = ws + (int64_t)m * p.N + n;
+            if (VEC && n + 3 < N) {
+              *reinterpret_cast<float4 *>(dst) = v[it];
+            } else {
+              const float o[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n + e < N) dst[e] = o[e];
+            }
+          }
         }
       }
-  } else {  // EPI_LOSS : bias + loss + dLoss/dLogits (+ column sums of dO)
-    float *lred = smem;                 // reuse the staging LDS (all waves are past the k-loop)
-    float *cpart = smem + 8;            // [WM][BN] column partial sums
+  } else {  // EPI_LOSS_* : bias + loss + dLoss/dLogits (+ column sums of dO); the loss kind is a
+            // compile-time choice (a runtime select made hipcc emit the exp/log code of
+            // BCE for every element of an MSE run: ~7.8k instructions per wave)
+    float *lred = smem + 4 * (32 * TLD);          // after the 4 per-wave transpose areas
+    float *cpart = lred + 8;                      // [WM][BN] column partial sums
     const int ldc = *p.ld_dev;
     const rk_block_t &b = p.blk;
     const bool implicit = b.implicit != 0;
     float lsum = 0.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int nb = n0 + (wn * TN + j) * 32;   // multiple of 32
-      const int n = nb + l31;
-      const int nc = min(n, N - 1);
-      const float bv = p.bias[p.bidx ? p.bidx[nc] : nc];
-      float csum = 0.f;
+      const int nb = n0 + (wn * TN + j) * 32;   // multiple of 32: one bitmap word per row
+      const int n = nb + c4 * 4;
+      float bv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[e] = pre_bv[LOSS ? j : 0][e];
+      float cs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        // the 16 bitmap words of this 32x32 tile: independent loads, issued together
-        uint32_t w[16];
+        float4 v[4];
+        transpose_tile(acc[i][j], v);
+        uint32_t w[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const int row = p.row_off + min(m, M - 1);
-          w[r] = b.bits_rc[(int64_t)row * b.ldw_rc + min(nb >> 5, b.ldw_rc - 1)];
-        }
+        for (int it = 0; it < 4; ++it) w[it] = pre_w[LOSS ? i : 0][LOSS ? j : 0][it];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const bool ok = (m < M) && (n < N);
-          const float o = acc[i][j][r] + bv;
-          float t = 0.f;
-          if (ok && ((w[r] >> l31) & 1u)) {
-            t = 1.0f;
-            if (!implicit) t = b.vals[rk_entry_index(b, p.row_off + m, n, w[r])];
+        for (int it = 0; it < 4; ++it) {
+          const int m = m0 + (wm * TM + i) * 32 + rr0 + 8 * it;
+          const float ov[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+          float g[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = (m < M) && (n + e < N);
+            const float o = ov[e] + bv[e];
+            float t = 0.f;
+            if (ok && ((w[it] >> (c4 * 4 + e)) & 1u)) {
+              t = 1.0f;
+              if (!implicit) t = b.vals[rk_entry_index(b, p.row_off + m, n + e, w[it])];
+            }
+            float l;
+            if (EPI == EPI_LOSS_MSE) {
+              const float wgt = (t > 0.f) ? (1.0f + p.confidence) : 1.0f;
+              const float d = o - t;
+              l = wgt * (d * d);
+              g[e] = (2.0f * d) * (wgt * p.inv_B);
+            } else {  // BCE with logits: (1-t)*o - logsigmoid(o)
+              const float ls = fminf(o, 0.f) - log1pf(expf(-fabsf(o)));
+              l = (1.0f - t) * o - ls;
+              const float sg = 1.0f / (1.0f + expf(-o));
+              g[e] = (sg - t) * p.inv_B;
+            }
+            if (ok) { lsum += l; cs[e] += g[e]; }
           }
-          float l, g;
-          if (p.loss_kind == RK_LOSS_MSE) {
-            const float wgt = (t > 0.f) ? (1.0f + p.confidence) : 1.0f;
-            const float d = o - t;
-            l = wgt * (d * d);
-            g = (2.0f * d) * (wgt * p.inv_B);
-          } else {  // BCE with logits: (1-t)*o - logsigmoid(o)
-            const float ls = fminf(o, 0.f) - log1pf(expf(-fabsf(o)));
-            l = (1.0f - t) * o - ls;
-            const float sg = 1.0f / (1.0f + expf(-o));
-            g = (sg - t) * p.inv_B;
-          }
-          if (ok) {
-            lsum += l;
-            csum += g;
-            p.C[(int64_t)m * ldc + n] = g;
-          }
+          // columns in [N, ld) are padding of the dO row: storing them is harmless
+          if (m < M && n < N)
+            *reinterpret_cast<float4 *>(p.C + (int64_t)m * ldc + n) = make_float4(g[0], g[1], g[2], g[3]);
         }
       }
-      // column sum over this wave's rows: the two lane halves hold different rows
-      csum += __shfl_xor(csum, 32, 64);
-      if (lh == 0) cpart[wm * BN + (wn * TN + j) * 32 + l31] = csum;
+      // column sums over this wave's rows: lanes with equal c4 hold different rows
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        cs[e] += __shfl_xor(cs[e], 8, 64);
+        cs[e] += __shfl_xor(cs[e], 16, 64);
+        cs[e] += __shfl_xor(cs[e], 32, 64);
+      }
+      if (rr0 == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cpart[wm * BN + (wn * TN + j) * 32 + c4 * 4 + e] = cs[e];
+      }
     }
     lsum = rk_wave_sum(lsum);
     if (lane == 0) lred[wid] = lsum;
     __syncthreads();
-    if (tid == 0) p.loss_part[blockIdx.x] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
+    if (tid == 0) p.loss_part[rt] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
     if (p.gb_part && tid < BN) {
       const int n = n0 + tid;
       if (n < N) {
-        float s = cpart[tid];
+        float s2 = cpart[tid];
 #pragma unroll
-        for (int w2 = 1; w2 < WM; ++w2) s += cpart[w2 * BN + tid];
-        p.gb_part[(int64_t)mt * ldc + n] = s;
+        for (int w2 = 1; w2 < WM; ++w2) s2 += cpart[w2 * BN + tid];
+        p.gb_part[(int64_t)mt * ldc + n] = s2;
       }
     }
   }
+  RK_T(9);
 }
 
 // ws[split][M][N] -> out[M][N] (fixed split order), optional * act'(Zact)
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(
+__global__ __launch_bounds__(64) void splitk_reduce_kernel(
     const float *__restrict__ ws, int M, int N, const int32_t *__restrict__ Kdev, int unused,
     int max_splits, const float *__restrict__ Zact, int act, float *__restrict__ out) {
   const int K = *Kdev;
@@ -394,9 +553,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(
   if (ns > max_splits) ns = max_splits;
   const int64_t tot4 = ((int64_t)M * N) >> 2;      // M*N is a multiple of 4 (N = h)
   const float4 *ws4 = reinterpret_cast<const float4 *>(ws);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot4; i += (int64_t)gridDim.x * 256) {
+  for (int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x; i < tot4; i += (int64_t)gridDim.x * 64) {
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int z = 0; z < ns; ++z) {
+    int z = 0;
+    for (; z + 8 <= ns; z += 8) {          // 8 loads in flight, summed in split order
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = ws4[(int64_t)(z + u) * tot4 + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; z < ns; ++z) {
       const float4 v = ws4[(int64_t)z * tot4 + i];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
@@ -518,7 +685,7 @@ extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_blo
   p.C = dO; p.bias = b_de; p.bias_gather = 1; p.act = RK_ACT_NONE;
   p.blk = *tgt; p.row_off = row_off; p.loss_kind = loss_kind;
   p.confidence = confidence; p.inv_B = inv_B; p.loss_part = loss_part; p.gb_part = gb_part;
-  const int tiles = p.tiles_m * rk_cdiv(tgt->n_cap, 128);
+  const int tiles = rk_cdiv(p.tiles_m * rk_cdiv(tgt->n_cap, 128), 8) * 8;
   // 64x128 tiles, BK = 32: ~2x the workgroups of a 128x128 tiling (two resident
   // per CU hide the staging latency) and 2x the MFMA work per staged tile
   if (loss_kind == RK_LOSS_MSE || loss_kind == RK_LOSS_BCE) {
@@ -526,8 +693,12 @@ extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_blo
     // it is allocated zeroed and rk_loss_reduce re-zeroes what it consumed
     RK_REQUIRE(tgt->implicit || tgt->pref_rc != nullptr, "explicit values need pref_rc");
     p.ld_dev = tgt->counts + 2;
-    hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 2, 0, 0, EPI_LOSS, true, 32>), dim3(tiles, 1), dim3(256),
-                       0, stream, p);
+    if (loss_kind == RK_LOSS_MSE)
+      hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 2, 0, 0, EPI_LOSS_MSE, true, 32>), dim3(tiles, 1),
+                         dim3(256), 0, stream, p);
+    else
+      hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 2, 0, 0, EPI_LOSS_BCE, true, 32>), dim3(tiles, 1),
+                         dim3(256), 0, stream, p);
   } else {
     if (loss_kind == RK_LOSS_MNLL) { p.ldc = 0; p.ld_dev = tgt->counts + 2; }
     else { RK_REQUIRE(ld_out > 0, "ld_out"); p.ldc = ld_out; }
@@ -577,16 +748,16 @@ extern "C" int rk_decode_bwd_dz(const float *dO, int32_t B, int32_t h, const rk_
   // wave tile 32 x (32*TN): pick TN by h
   const int tn = h <= 64 ? 2 : (h <= 128 ? 4 : (h <= 224 ? 7 : 8));
   p.tiles_m = rk_cdiv(B, 128);
-  const int tiles = p.tiles_m * rk_cdiv(h, 32 * tn);
+  const int tiles = p.tiles_m * rk_cdiv(h, 32 * tn);   // x 64 splits: a multiple of 8
 #define LAUNCH(TN)                                                                              \
   hipLaunchKernelGGL((gemm_kernel<4, 1, 1, TN, 0, 1, EPI_SPLITK, true>), dim3(tiles, splits),   \
                      dim3(256), 0, stream, p)
   if (tn == 2) LAUNCH(2); else if (tn == 4) LAUNCH(4); else if (tn == 7) LAUNCH(7); else LAUNCH(8);
 #undef LAUNCH
   RK_CHECK_LAUNCH("decode_bwd_dz");
-  int grid = rk_cdiv((int64_t)B * h / 4, 256);
-  if (grid > 1024) grid = 1024;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, workspace, B, h,
+  int grid = rk_cdiv((int64_t)B * h / 4, 64);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(64), 0, stream, workspace, B, h,
                      tgt->counts, kchunk, splits, Zact, act, dZ);
   RK_CHECK_LAUNCH("splitk_reduce");
   return 0;
@@ -609,7 +780,8 @@ extern "C" int rk_decode_bwd_dw(const float *dO, const float *Z, int32_t B, int3
   p.tiles_m = rk_cdiv(tgt->n_cap, 32);
   {
     // 32 x 128 tiles, BK = 32 (two workgroups per CU at h = 200)
-    const int tiles = p.tiles_m * rk_cdiv(h, 128);
+    p.n_fastest = 1;   // the h/128 column tiles of one dO panel stay on one XCD
+    const int tiles = rk_cdiv(p.tiles_m * rk_cdiv(h, 128), 8) * 8;
     hipLaunchKernelGGL((gemm_kernel<1, 4, 1, 1, 1, 1, EPI_STORE, true, 32>), dim3(tiles, 1),
                        dim3(256), 0, stream, p);
   }
@@ -643,7 +815,7 @@ extern "C" int rk_linear_fwd(const float *X, const float *W, const float *b, int
   const bool vec = aligned16(X) && aligned16(W) && (K % 4 == 0) && (p.ldb % 4 == 0);
   p.C = Y; p.ldc = N; p.bias = b; p.act = act;
   p.tiles_m = rk_cdiv(B, 64);
-  const int tiles = p.tiles_m * rk_cdiv(N, 64);
+  const int tiles = rk_cdiv(p.tiles_m * rk_cdiv(N, 64), 8) * 8;
   if (!w_transposed) launch_small<0, 0>(p, tiles, vec, stream);
   else launch_small<0, 1>(p, tiles, vec, stream);
   RK_CHECK_LAUNCH("linear_fwd");
@@ -667,7 +839,7 @@ extern "C" int rk_linear_bwd(float *dY, const float *Y, const float *X, const fl
     const bool vec = aligned16(dY) && aligned16(W) && (N % 4 == 0) && (ldw % 4 == 0);
     p.C = dX; p.ldc = K; p.act = RK_ACT_NONE;
     p.tiles_m = rk_cdiv(B, 64);
-    const int tiles = p.tiles_m * rk_cdiv(K, 64);
+    const int tiles = rk_cdiv(p.tiles_m * rk_cdiv(K, 64), 8) * 8;
     if (!w_transposed) launch_small<0, 1>(p, tiles, vec, stream);   // W[N,K]: k-major
     else launch_small<0, 0>(p, tiles, vec, stream);                 // Wst[K,N]: reduction contiguous
     RK_CHECK_LAUNCH("linear_bwd_dx");
@@ -682,7 +854,7 @@ extern "C" int rk_linear_bwd(float *dY, const float *Y, const float *X, const fl
     }
     const bool vec = aligned16(p.A) && aligned16(p.Bm) && (p.lda % 4 == 0) && (p.ldb % 4 == 0);
     p.tiles_m = rk_cdiv(p.M, 64);
-    const int tiles = p.tiles_m * rk_cdiv(p.N, 64);
+    const int tiles = rk_cdiv(p.tiles_m * rk_cdiv(p.N, 64), 8) * 8;
     launch_small<1, 1>(p, tiles, vec, stream);
     RK_CHECK_LAUNCH("linear_bwd_dw");
   }
