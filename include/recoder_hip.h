@@ -219,6 +219,49 @@ int rk_scatter_pos(int32_t *pos, const int64_t *rows, int32_t B, int32_t clear,
                    void *stream);
 
 /*
+ * rk_ae_train_step -- one call = one optimisation step of Recoder._train's hot
+ * loop (model.py:383-404) for DynamicAutoencoder(hidden_layers=[h]) without
+ * bottleneck dropout: zero_grad / __compute_loss (model.py:454-485) / backward /
+ * optimizer.step + sparse_optimizer.step, sequenced on two HIP streams (the dW
+ * chain and the decoder-side Adam overlap the dZ chain).  It launches exactly
+ * the entry points above; it exists so that the host pays one FFI call per
+ * step instead of ~35.
+ */
+enum { RK_PAR_W_EN = 0, RK_PAR_B_EN = 1, RK_PAR_W_DE = 2, RK_PAR_B_DE = 3, RK_PAR_COUNT = 4 };
+enum { RK_ENTRY_NONE = 0, RK_ENTRY_ENCODE_FWD = 1, RK_ENTRY_DECODE_LOSS = 2,
+       RK_ENTRY_DECODE_BWD_DZ = 3, RK_ENTRY_DECODE_BWD_DW = 4, RK_ENTRY_ENCODE_BWD = 5,
+       RK_ENTRY_ADAM_TABLE = 6 };
+
+typedef struct rk_adam_param {
+  float *p, *m, *v;          /* parameter and its Adam moments */
+  double lr, beta1, beta2, eps, weight_decay;
+  int32_t step;              /* 1-based step of THIS update */
+  int32_t sparse;            /* tables only: SparseAdam on the touched rows */
+} rk_adam_param_t;
+
+typedef struct rk_ae_step {
+  const rk_block_t *blk;
+  int32_t row_off, B, h, act, loss_kind, tied;
+  float confidence, inv_B, denom, noise_p;
+  uint64_t seed, rng_step;
+  const uint8_t *keep;       /* nullable per-nnz keep flags (parity tests) */
+  const int64_t *users;      /* global user ids of the block rows (RNG key) */
+  rk_adam_param_t par[RK_PAR_COUNT];
+  /* workspaces (sizes as FusedEngine.ensure_capacity allocates them) */
+  float *Z0, *dZ0, *dO, *G_de, *G_en, *gb_de, *gb_part, *gb_en, *ws, *loss_part, *loss_out;
+  void *stream_main, *stream_aux;                  /* hipStream_t */
+  void *ev_loss, *ev_dz, *ev_dw, *ev_aux_done;     /* hipEvent_t (rk_event_create) */
+  int32_t time_entry;        /* RK_ENTRY_*: bracket that entry with the two events below */
+  int32_t reserved;
+  void *time_ev0, *time_ev1;
+} rk_ae_step_t;
+
+void *rk_event_create(void);
+void rk_event_destroy(void *event);
+float rk_event_elapsed_ms(void *ev0, void *ev1);   /* synchronises on ev1 */
+int rk_ae_train_step(const rk_ae_step_t *step);
+
+/*
  * rk_topk_masked -- Recoder.recommend (model.py:525-544): scores[B,ld] with the
  * seen items (bits_rc of the non-sampled block) set to -inf, top-k sorted
  * descending (ties: lower index first, as torch.topk on CPU).

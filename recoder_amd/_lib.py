@@ -7,6 +7,12 @@ path fails loudly.
 """
 import ctypes
 import os
+
+# PyTorch-ROCm must load its HIP runtime BEFORE this library is dlopen'ed: both link
+# libamdhip64 and the process must end up with ONE runtime instance (otherwise our
+# launches see "no ROCm-capable device" on streams torch created).
+import torch  # noqa: F401  (side effect: loads the HIP runtime torch will use)
+
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64,
                     c_uint64, c_void_p)
 
@@ -27,6 +33,38 @@ class RkBlock(Structure):
     ("svals", c_void_p), ("items", c_void_p), ("pos", c_void_p), ("mark", c_void_p),
     ("bits_rc", c_void_p), ("bits_cr", c_void_p), ("scan_tmp", c_void_p),
     ("pref_rc", c_void_p),
+  ]
+
+
+class RkAdamParam(Structure):
+  """mirror of rk_adam_param_t"""
+  _fields_ = [("p", c_void_p), ("m", c_void_p), ("v", c_void_p),
+              ("lr", c_double), ("beta1", c_double), ("beta2", c_double), ("eps", c_double),
+              ("weight_decay", c_double), ("step", c_int32), ("sparse", c_int32)]
+
+
+PAR_W_EN, PAR_B_EN, PAR_W_DE, PAR_B_DE = 0, 1, 2, 3
+ENTRY = {"rk_ae_encode_fwd": 1, "rk_decode_loss": 2, "rk_decode_bwd_dz": 3, "rk_decode_bwd_dw": 4,
+         "rk_ae_encode_bwd": 5, "rk_adam_table": 6}
+
+
+class RkAeStep(Structure):
+  """mirror of rk_ae_step_t"""
+  _fields_ = [
+    ("blk", POINTER(RkBlock)),
+    ("row_off", c_int32), ("B", c_int32), ("h", c_int32), ("act", c_int32), ("loss_kind", c_int32),
+    ("tied", c_int32),
+    ("confidence", c_float), ("inv_B", c_float), ("denom", c_float), ("noise_p", c_float),
+    ("seed", c_uint64), ("rng_step", c_uint64),
+    ("keep", c_void_p), ("users", c_void_p),
+    ("par", RkAdamParam * 4),
+    ("Z0", c_void_p), ("dZ0", c_void_p), ("dO", c_void_p), ("G_de", c_void_p), ("G_en", c_void_p),
+    ("gb_de", c_void_p), ("gb_part", c_void_p), ("gb_en", c_void_p), ("ws", c_void_p),
+    ("loss_part", c_void_p), ("loss_out", c_void_p),
+    ("stream_main", c_void_p), ("stream_aux", c_void_p),
+    ("ev_loss", c_void_p), ("ev_dz", c_void_p), ("ev_dw", c_void_p), ("ev_aux_done", c_void_p),
+    ("time_entry", c_int32), ("reserved", c_int32),
+    ("time_ev0", c_void_p), ("time_ev1", c_void_p),
   ]
 
 
@@ -64,6 +102,10 @@ SIGNATURES = {
   "rk_adam_dense": (c_int32, [_P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double,
                               c_double, c_int32, _P]),
   "rk_scatter_pos": (c_int32, [_P, _P, c_int32, c_int32, _P]),
+  "rk_event_create": (c_void_p, []),
+  "rk_event_destroy": (None, [c_void_p]),
+  "rk_event_elapsed_ms": (c_float, [c_void_p, c_void_p]),
+  "rk_ae_train_step": (c_int32, [POINTER(RkAeStep)]),
   "rk_topk_masked": (c_int32, [_P, c_int32, c_int32, c_int32, _BLK, c_int32, c_int32, _P, _P, _P]),
 }
 

@@ -3,73 +3,89 @@
 // Replaces RecommendationDataset._extract (reference data.py:64-83: CSR row
 // gather) and BatchCollator.collate (data.py:203-251: nonzero() ->
 // np.unique(return_inverse) -> per-slice COO) with HBM-resident integer work:
-//   rows     : degrees of the S sampled users -> exclusive scan (block CSR)
-//   mark     : stamp every touched item id            (scatter, 4 B / nnz)
-//   count    : per-2048-chunk population of the stamp array
-//   assign   : chunk-ordered exclusive scan -> pos[item] / items[] (ascending
-//              item id == np.unique order) and n_b
-//   zero     : clear the (row,col) and (col,row) bitmaps for n_b columns
-//   relabel  : cols[j] = pos[item_j], vals[j], set bitmap bits
-// All HBM-bound; one pass over the group's nnz + two passes over n_items ints.
+//   phase1 : ONE launch -- stamp every touched item id (scatter, 4 B / nnz),
+//            exclusive scan of the S row degrees (block CSR pointers), clear the
+//            transposed bitmap
+//   scan   : stamps -> pos[item] / items[] in ascending item id (== np.unique
+//            order) and n_b; one workgroup for catalogues <= 64k items, a
+//            count + assign pair of launches above that
+//   build  : per row (one wave): cols[j] = pos[item_j], vals[j], the row's bitmap
+//            words and their prefix popcounts assembled in LDS, transposed bits
+// Three launches (each tiny kernel costs ~4.5 us of dependent round trips + launch
+// tail, so the original seven were 1/6 of the step); all HBM/latency-bound integer
+// work: one pass over the group's nnz + two passes over n_items ints.
 #include "common.h"
 
 namespace {
 
-constexpr int ROWS_THREADS = 1024;
+constexpr int SMALL_SCAN_MAX = 1 << 16;   // catalogues up to 64k items: single-workgroup scan
+constexpr int SEG_WORDS = 2048;           // bitmap words a wave builds in LDS at a time
 
-// ---- rows: block CSR row pointers of the S sampled users (single block) ----
-__global__ __launch_bounds__(ROWS_THREADS) void collate_rows_kernel(
-    const int64_t *__restrict__ ds_indptr, const int64_t *__restrict__ users, int S,
-    int32_t *__restrict__ indptr, int32_t *__restrict__ counts) {
-  __shared__ int32_t wsum[ROWS_THREADS / 64];
-  __shared__ int32_t carry_s;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < S; base += ROWS_THREADS) {
-    const int i = base + tid;
-    int32_t d = 0;
-    if (i < S) {
-      const int64_t u = users[i];
-      d = (int32_t)(ds_indptr[u + 1] - ds_indptr[u]);
-    }
-    // inclusive wave scan
-    int32_t x = d;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      int32_t y = __shfl_up(x, off, 64);
-      if (lane >= off) x += y;
-    }
-    if (lane == 63) wsum[wid] = x;
-    __syncthreads();
-    int32_t woff = 0;
-    for (int w = 0; w < wid; ++w) woff += wsum[w];
-    const int32_t carry = carry_s;
-    if (i < S) indptr[i] = carry + woff + x - d;
-    __syncthreads();
-    if (tid == ROWS_THREADS - 1) carry_s = carry + woff + x;
-    __syncthreads();
-  }
-  if (tid == 0) {
-    indptr[S] = carry_s;
-    counts[1] = carry_s;
-    counts[3] = S;
-  }
-}
-
-// ---- mark: one wave per sampled row ----
-__global__ __launch_bounds__(256) void collate_mark_kernel(
+// ---- phase 1 (one launch): mark the touched items, scan the row degrees, clear
+//      the transposed bitmap.  Roles by block index:
+//        [0, nrow_blk)            one wave per sampled row: mark[item] = stamp
+//        nrow_blk                 block CSR row pointers (exclusive scan of degrees)
+//        (nrow_blk, gridDim.x)    zero bits_cr (capacity-sized, no dependency on n_b)
+__global__ __launch_bounds__(256) void collate_phase1_kernel(
     const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
-    const int64_t *__restrict__ users, int S, int32_t stamp, int32_t *__restrict__ mark) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= S) return;
-  const int lane = threadIdx.x & 63;
-  const int64_t u = users[row];
-  const int64_t beg = ds_indptr[u], end = ds_indptr[u + 1];
-  for (int64_t e = beg + lane; e < end; e += 64) mark[ds_indices[e]] = stamp;
+    const int64_t *__restrict__ users, int S, int32_t stamp, int all, int nrow_blk, rk_block_t b) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if ((int)blockIdx.x < nrow_blk) {
+    if (all) return;
+    const int row = blockIdx.x * 4 + wid;
+    if (row >= S) return;
+    const int64_t u = users[row];
+    const int64_t beg = ds_indptr[u], end = ds_indptr[u + 1];
+    for (int64_t e = beg + lane; e < end; e += 64) b.mark[ds_indices[e]] = stamp;
+    return;
+  }
+  if ((int)blockIdx.x == nrow_blk) {
+    __shared__ int32_t wsum[4];
+    __shared__ int32_t carry_s;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < S; base += 256) {
+      const int i = base + tid;
+      int32_t d = 0;
+      if (i < S) {
+        const int64_t u = users[i];
+        d = (int32_t)(ds_indptr[u + 1] - ds_indptr[u]);
+      }
+      int32_t x = d;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        int32_t y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+      }
+      if (lane == 63) wsum[wid] = x;
+      __syncthreads();
+      int32_t woff = 0;
+      for (int w = 0; w < wid; ++w) woff += wsum[w];
+      const int32_t carry = carry_s;
+      if (i < S) b.indptr[i] = carry + woff + x - d;
+      __syncthreads();
+      if (tid == 255) carry_s = carry + woff + x;
+      __syncthreads();
+    }
+    if (tid == 0) {
+      b.indptr[S] = carry_s;
+      b.counts[1] = carry_s;
+      b.counts[3] = S;
+    }
+    return;
+  }
+  if (b.bits_cr) {
+    const int zb = blockIdx.x - nrow_blk - 1, nz = gridDim.x - nrow_blk - 1;
+    const int64_t tot4 = ((int64_t)b.n_cap * b.ldw_cr) >> 2;     // uint4 granules
+    uint4 *p4 = reinterpret_cast<uint4 *>(b.bits_cr);
+    for (int64_t i = (int64_t)zb * 256 + tid; i < tot4; i += (int64_t)nz * 256)
+      p4[i] = make_uint4(0u, 0u, 0u, 0u);
+    const int64_t tail0 = tot4 << 2, tot = (int64_t)b.n_cap * b.ldw_cr;
+    if (zb == 0 && tail0 + tid < tot) b.bits_cr[tail0 + tid] = 0u;
+  }
 }
 
-// ---- count: marked items per chunk ----
+// ---- count: marked items per chunk (large catalogues) ----
 __global__ __launch_bounds__(256) void collate_count_kernel(
     const int32_t *__restrict__ mark, int n_items, int32_t stamp, int all,
     int32_t *__restrict__ scan_tmp) {
@@ -87,7 +103,7 @@ __global__ __launch_bounds__(256) void collate_count_kernel(
   if (threadIdx.x == 0) scan_tmp[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-// ---- assign: pos[] / items[] in ascending item order ----
+// ---- assign: pos[] / items[] in ascending item order (large catalogues) ----
 __global__ __launch_bounds__(256) void collate_assign_kernel(
     const int32_t *__restrict__ mark, int n_items, int32_t stamp, int all,
     const int32_t *__restrict__ scan_tmp, int n_chunks, int32_t *__restrict__ pos,
@@ -95,7 +111,6 @@ __global__ __launch_bounds__(256) void collate_assign_kernel(
   __shared__ int32_t red[4];
   __shared__ int32_t wsum[4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  // base = sum of the chunk counts before this chunk (fixed order, integer)
   int32_t part = 0;
   for (int i = tid; i < (int)blockIdx.x; i += 256) part += scan_tmp[i];
 #pragma unroll
@@ -109,7 +124,6 @@ __global__ __launch_bounds__(256) void collate_assign_kernel(
     counts[0] = n_b;
     counts[2] = (n_b + 31) & ~31;
   }
-  // each thread owns 8 consecutive items of the chunk
   const int it0 = blockIdx.x * RK_SCAN_CHUNK + tid * 8;
   int32_t f[8];
   int32_t local = 0;
@@ -134,77 +148,111 @@ __global__ __launch_bounds__(256) void collate_assign_kernel(
   for (int k = 0; k < 8; ++k) {
     const int it = it0 + k;
     if (it < n_items) {
-      if (f[k]) {
-        pos[it] = p;
-        items[p] = it;
-        ++p;
-      } else {
-        pos[it] = -1;
-      }
+      if (f[k]) { pos[it] = p; items[p] = it; ++p; } else { pos[it] = -1; }
     }
   }
 }
 
-// ---- zero the two bitmaps for the live region ----
-__global__ __launch_bounds__(256) void collate_zero_bits_kernel(rk_block_t b) {
-  const int n_b = b.counts[0];
-  const int S = b.counts[3];
-  const int wr = (n_b + 31) >> 5;   // words per row in use
-  const int wc = (S + 31) >> 5;     // words per column in use
-  const int64_t tot_rc = (int64_t)S * wr;
-  const int64_t tot_cr = b.bits_cr ? (int64_t)n_b * wc : 0;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot_rc; i += stride) {
-    const int r = (int)(i / wr), w = (int)(i % wr);
-    b.bits_rc[(int64_t)r * b.ldw_rc + w] = 0u;
-  }
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot_cr; i += stride) {
-    const int c = (int)(i / wc), w = (int)(i % wc);
-    b.bits_cr[(int64_t)c * b.ldw_cr + w] = 0u;
-  }
-}
-
-// ---- relabel: one wave per row ----
-__global__ __launch_bounds__(256) void collate_relabel_kernel(
-    const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
-    const float *__restrict__ ds_data, const int64_t *__restrict__ users, int S, rk_block_t b) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= S) return;
-  const int lane = threadIdx.x & 63;
-  const int64_t u = users[row];
-  const int64_t beg = ds_indptr[u];
-  const int n = (int)(ds_indptr[u + 1] - beg);
-  const int out0 = b.indptr[row];
-  for (int k = lane; k < n; k += 64) {
-    const int32_t it = ds_indices[beg + k];
-    const int32_t c = b.pos[it];
-    b.cols[out0 + k] = c;
-    b.vals[out0 + k] = ds_data ? ds_data[beg + k] : 1.0f;
-    atomicOr(&b.bits_rc[(int64_t)row * b.ldw_rc + (c >> 5)], 1u << (c & 31));
-    if (b.bits_cr) atomicOr(&b.bits_cr[(int64_t)c * b.ldw_cr + (row >> 5)], 1u << (row & 31));
-  }
-}
-
-// ---- prefix: per-row exclusive prefix popcount of the (row,col) bitmap ----
-__global__ __launch_bounds__(256) void collate_prefix_kernel(rk_block_t b, int S) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= S) return;
-  const int lane = threadIdx.x & 63;
-  const int wr = (b.counts[0] + 31) >> 5;
-  const uint32_t *bits = b.bits_rc + (int64_t)row * b.ldw_rc;
-  int32_t *pref = b.pref_rc + (int64_t)row * b.ldw_rc;
-  int32_t carry = 0;
-  for (int w0 = 0; w0 < wr; w0 += 64) {
-    const int w = w0 + lane;
-    const int32_t c = (w < wr) ? __popc(bits[w]) : 0;
-    int32_t x = c;
+// ---- scan (small catalogues): ONE workgroup does count + assign in one launch ----
+__global__ __launch_bounds__(1024) void collate_scan_small_kernel(
+    const int32_t *__restrict__ mark, int n_items, int32_t stamp, int all,
+    int32_t *__restrict__ pos, int32_t *__restrict__ items, int32_t *__restrict__ counts) {
+  __shared__ int32_t wsum[16];
+  __shared__ int32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n_items; base += 4096) {
+    const int it0 = base + tid * 4;
+    int32_t f[4];
+    int32_t local = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int it = it0 + k;
+      f[k] = (it < n_items && (all || mark[it] == stamp)) ? 1 : 0;
+      local += f[k];
+    }
+    int32_t x = local;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       int32_t y = __shfl_up(x, off, 64);
       if (lane >= off) x += y;
     }
-    if (w < wr) pref[w] = carry + x - c;
-    carry += __shfl(x, 63, 64);
+    if (lane == 63) wsum[wid] = x;
+    __syncthreads();
+    int32_t woff = 0;
+    for (int w = 0; w < wid; ++w) woff += wsum[w];
+    const int32_t carry = carry_s;
+    int32_t p = carry + woff + x - local;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int it = it0 + k;
+      if (it < n_items) {
+        if (f[k]) { pos[it] = p; items[p] = it; ++p; } else { pos[it] = -1; }
+      }
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + woff + x;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    counts[0] = carry_s;
+    counts[2] = (carry_s + 31) & ~31;
+  }
+}
+
+// ---- build: one wave per sampled row -- relabelled columns, values, the row's
+//      bitmap words + their exclusive prefix popcounts (assembled in LDS and
+//      written out whole: bits_rc needs no clearing), transposed-bitmap bits ----
+__global__ __launch_bounds__(256) void collate_build_kernel(
+    const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
+    const float *__restrict__ ds_data, const int64_t *__restrict__ users, int S, rk_block_t b) {
+  __shared__ uint32_t wbits[4][SEG_WORDS];
+  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + wid;
+  if (row >= S) return;
+  const int64_t u = users[row];
+  const int64_t beg = ds_indptr[u];
+  const int n = (int)(ds_indptr[u + 1] - beg);
+  const int out0 = b.indptr[row];
+  const int wr = (b.counts[0] + 31) >> 5;          // bitmap words in use
+  for (int k = lane; k < n; k += 64) {
+    const int32_t c = b.pos[ds_indices[beg + k]];
+    b.cols[out0 + k] = c;
+    b.vals[out0 + k] = ds_data ? ds_data[beg + k] : 1.0f;
+    if (b.bits_cr) atomicOr(&b.bits_cr[(int64_t)c * b.ldw_cr + (row >> 5)], 1u << (row & 31));
+  }
+  uint32_t *wb = wbits[wid];
+  uint32_t *bits = b.bits_rc + (int64_t)row * b.ldw_rc;
+  int32_t *pref = b.pref_rc ? b.pref_rc + (int64_t)row * b.ldw_rc : nullptr;
+  int32_t carry = 0;
+  for (int w0 = 0; w0 < wr; w0 += SEG_WORDS) {
+    const int nw = min(SEG_WORDS, wr - w0);
+    for (int w = lane; w < nw; w += 64) wb[w] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < n; k += 64) {
+      const int32_t c = b.pos[ds_indices[beg + k]];
+      const int w = (c >> 5) - w0;
+      if (w >= 0 && w < nw) atomicOr(&wb[w], 1u << (c & 31));
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int wq = 0; wq < nw; wq += 64) {
+      const int w = wq + lane;
+      const uint32_t word = (w < nw) ? wb[w] : 0u;
+      const int32_t c = __popc(word);
+      int32_t x = c;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        int32_t y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+      }
+      if (w < nw) {
+        bits[w0 + w] = word;
+        if (pref) pref[w0 + w] = carry + x - c;
+      }
+      carry += __shfl(x, 63, 64);
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -220,41 +268,37 @@ extern "C" int rk_collate(const int64_t *ds_indptr, const int32_t *ds_indices,
   RK_REQUIRE(blk->n_chunks == rk_cdiv(blk->n_items, RK_SCAN_CHUNK), "n_chunks mismatch");
   RK_REQUIRE(blk->ldw_rc * 32 >= blk->n_cap && blk->ldw_cr * 32 >= blk->S_cap, "bitmap ld");
   RK_REQUIRE(stamp != 0, "stamp must be non-zero");
+  RK_REQUIRE(phase >= 0 && phase <= 2, "phase must be 0, 1 or 2");
   if (S == 0) return 0;
   const int all = negative_sampling ? 0 : 1;
-  RK_REQUIRE(phase >= 0 && phase <= 2, "phase must be 0, 1 or 2");
   if (phase != 2) {
-  hipLaunchKernelGGL(collate_rows_kernel, dim3(1), dim3(ROWS_THREADS), 0, stream, ds_indptr,
-                     users, S, blk->indptr, blk->counts);
-  RK_CHECK_LAUNCH("collate_rows");
-  if (!all) {
-    hipLaunchKernelGGL(collate_mark_kernel, dim3(rk_cdiv(S, 4)), dim3(256), 0, stream,
-                       ds_indptr, ds_indices, users, S, stamp, blk->mark);
-    RK_CHECK_LAUNCH("collate_mark");
-  }
+    const int nrow_blk = rk_cdiv(S, 4);
+    int nzero = 0;
+    if (blk->bits_cr) {
+      nzero = rk_cdiv((int64_t)blk->n_cap * blk->ldw_cr, 4 * 256 * 8);
+      if (nzero < 1) nzero = 1;
+      if (nzero > 512) nzero = 512;
+    }
+    hipLaunchKernelGGL(collate_phase1_kernel, dim3(nrow_blk + 1 + nzero), dim3(256), 0, stream,
+                       ds_indptr, ds_indices, users, S, stamp, all, nrow_blk, *blk);
+    RK_CHECK_LAUNCH("collate_phase1");
   }
   if (phase == 1) return 0;
-  hipLaunchKernelGGL(collate_count_kernel, dim3(blk->n_chunks), dim3(256), 0, stream,
-                     blk->mark, blk->n_items, stamp, all, blk->scan_tmp);
-  RK_CHECK_LAUNCH("collate_count");
-  hipLaunchKernelGGL(collate_assign_kernel, dim3(blk->n_chunks), dim3(256), 0, stream,
-                     blk->mark, blk->n_items, stamp, all, blk->scan_tmp, blk->n_chunks,
-                     blk->pos, blk->items, blk->counts);
-  RK_CHECK_LAUNCH("collate_assign");
-  {
-    const int64_t words = (int64_t)S * blk->ldw_rc + (int64_t)blk->n_cap * blk->ldw_cr;
-    int grid = (int)((words + 255) / 256);
-    if (grid > 2048) grid = 2048;
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(collate_zero_bits_kernel, dim3(grid), dim3(256), 0, stream, *blk);
-    RK_CHECK_LAUNCH("collate_zero_bits");
+  if (blk->n_items <= SMALL_SCAN_MAX) {
+    hipLaunchKernelGGL(collate_scan_small_kernel, dim3(1), dim3(1024), 0, stream, blk->mark,
+                       blk->n_items, stamp, all, blk->pos, blk->items, blk->counts);
+    RK_CHECK_LAUNCH("collate_scan_small");
+  } else {
+    hipLaunchKernelGGL(collate_count_kernel, dim3(blk->n_chunks), dim3(256), 0, stream,
+                       blk->mark, blk->n_items, stamp, all, blk->scan_tmp);
+    RK_CHECK_LAUNCH("collate_count");
+    hipLaunchKernelGGL(collate_assign_kernel, dim3(blk->n_chunks), dim3(256), 0, stream,
+                       blk->mark, blk->n_items, stamp, all, blk->scan_tmp, blk->n_chunks,
+                       blk->pos, blk->items, blk->counts);
+    RK_CHECK_LAUNCH("collate_assign");
   }
-  hipLaunchKernelGGL(collate_relabel_kernel, dim3(rk_cdiv(S, 4)), dim3(256), 0, stream,
+  hipLaunchKernelGGL(collate_build_kernel, dim3(rk_cdiv(S, 4)), dim3(256), 0, stream,
                      ds_indptr, ds_indices, ds_data, users, S, *blk);
-  RK_CHECK_LAUNCH("collate_relabel");
-  if (blk->pref_rc) {
-    hipLaunchKernelGGL(collate_prefix_kernel, dim3(rk_cdiv(S, 4)), dim3(256), 0, stream, *blk, S);
-    RK_CHECK_LAUNCH("collate_prefix");
-  }
+  RK_CHECK_LAUNCH("collate_build");
   return 0;
 }

@@ -156,3 +156,45 @@ class Block:
                 vals=self.vals[:nnz].cpu().numpy(),
                 items=self.items[:n_b].cpu().numpy().astype(np.int64),
                 pos=self.pos.cpu().numpy())
+
+
+class CollatePrefetcher:
+  """Double-buffered collation on a side HIP stream: the block of step k+1 is
+  collated while step k trains (the reference gets the same overlap from its
+  DataLoader worker processes, data.py:135-136)."""
+
+  def __init__(self, make_block, dcsr, device=None, collate_fn=None):
+    self.device = device or require_gpu()
+    self.dcsr = dcsr
+    self.blocks = [make_block(), make_block()]
+    self.stream = torch.cuda.Stream(device=self.device)
+    self.ready = [torch.cuda.Event(), torch.cuda.Event()]
+    self.free = [torch.cuda.Event(), torch.cuda.Event()]
+    self._used = [False, False]
+    self.collate_fn = collate_fn      # e.g. DataParallel.collate (two-phase, union item set)
+
+  def submit(self, slot, users_dev):
+    """Enqueue the collation of `users_dev` into buffer `slot` on the side stream."""
+    blk = self.blocks[slot]
+    main = torch.cuda.current_stream()
+    with torch.cuda.stream(self.stream):
+      if self._used[slot]:
+        self.stream.wait_event(self.free[slot])      # previous consumer of this buffer is done
+      else:
+        self.stream.wait_stream(main)                # first use: order after setup work
+      if self.collate_fn is not None:
+        self.collate_fn(blk, self.dcsr, users_dev)
+      else:
+        blk.collate(self.dcsr, users_dev)
+      self.ready[slot].record(self.stream)
+    return blk
+
+  def acquire(self, slot):
+    """Make the current stream wait for buffer `slot`; returns the block."""
+    torch.cuda.current_stream().wait_event(self.ready[slot])
+    return self.blocks[slot]
+
+  def release(self, slot):
+    """Call after the last kernel reading buffer `slot` was enqueued."""
+    self.free[slot].record(torch.cuda.current_stream())
+    self._used[slot] = True

@@ -41,6 +41,7 @@ class TimedLib:
     self._lib = lib
     self.enabled = False
     self.records = {}       # entry point -> list of (start_event, end_event)
+    self.streams = {}       # raw hipStream_t value -> torch stream (for event placement)
 
   def __getattr__(self, name):
     fn = getattr(self._lib, name)
@@ -51,11 +52,13 @@ class TimedLib:
     def call(*args):
       if not self.enabled:
         return fn(*args)
+      st = self.streams.get(getattr(args[-1], "value", None)) if args else None
+      st = st or torch.cuda.current_stream()
       s = torch.cuda.Event(enable_timing=True)
       e = torch.cuda.Event(enable_timing=True)
-      s.record()
+      s.record(st)
       rc = fn(*args)
-      e.record()
+      e.record(st)
       self.records.setdefault(name, []).append((s, e))
       return rc
     return call
@@ -93,6 +96,9 @@ class FusedEngine:
     self.states = {}                       # name -> ParamState
     self.world_size = 1
     self.allreduce = None                  # callable(list of tensors) for data parallel
+    self.use_c_step = True                 # one-FFI-call step driver (rk_ae_train_step)
+    self.time_entry = None                 # C-ABI entry name to bracket with events (bench)
+    self._cstep = None
     if kind == "ae":
       self.h = list(model.hidden_layers)
       self.nl = len(self.h) - 1
@@ -250,8 +256,10 @@ class FusedEngine:
       return m.de_embedding_layer.weight, m.de_bias
     return m.item_embedding_layer.weight, m.bias
 
-  def _loss(self, z, B, tgt, row_off, denom_rows, stream, out=None):
-    """decode + loss; leaves dLoss/dLogits in self.dO. Returns device scalar."""
+  def _loss(self, z, B, tgt, row_off, denom_rows, stream, out=None, reduce_on=None):
+    """decode + loss; leaves dLoss/dLogits in self.dO. Returns device scalar.
+    reduce_on = (torch stream, raw stream, event): run the tiny partial-sum
+    reduction there instead of on `stream` (off the critical path)."""
     lib = self.lib
     W, b = self._decoder_params()
     inv_B = _f32(np.float32(1.0) / np.float32(denom_rows))
@@ -265,6 +273,11 @@ class FusedEngine:
       n_part = B
     else:
       n_part = cdiv(B, self.row_tile) * cdiv(tgt.n_cap, 128)
+    if reduce_on is not None:
+      t_stream, raw, event = reduce_on
+      event.record(torch.cuda.current_stream())
+      t_stream.wait_event(event)
+      stream = raw
     check(lib.rk_loss_reduce(ptr(self.loss_part), n_part, float(denom_rows), ptr(out), stream),
           "rk_loss_reduce")
     return out
@@ -280,14 +293,35 @@ class FusedEngine:
       z = self._mf_forward(blk.users[row_off:row_off + B], B, None, False, stream)
     return self._loss(z, B, tgt if tgt is not None else blk, row_off, B, stream, out)
 
+  def _aux(self):
+    """Second HIP stream + reusable events for the intra-step overlap."""
+    if getattr(self, "_aux_stream", None) is None:
+      self._aux_stream = torch.cuda.Stream(device=self.device)
+      if hasattr(self.lib, "streams"):
+        self.lib.streams[self._aux_stream.cuda_stream] = self._aux_stream
+      self._ev = {k: torch.cuda.Event() for k in ("loss", "dw", "dz", "aux_done")}
+    return self._aux_stream
+
   def train_step(self, blk, row_off, B, keep_noise=None, keep_drop=None, out=None,
                  global_rows=None):
     """One optimisation step on rows [row_off, row_off+B) of the collated
     block (model.py:383-404).  ``global_rows`` = rows summed over all ranks
-    (data parallel); the loss/gradients are normalised by it."""
+    (data parallel); the loss/gradients are normalised by it.
+
+    Two HIP streams: after the fused decode+loss the two backward GEMMs are
+    independent -- dW (+ the decoder-side Adam sweep, HBM-bound) runs on the
+    auxiliary stream while dZ -> encoder backward -> encoder-side Adam runs on
+    the caller's stream, so MFMA-bound and HBM-bound kernels overlap."""
     self.ensure_capacity(B, blk.n_cap)
     lib, m = self.lib, self.model
-    stream = current_stream()
+    main_s = torch.cuda.current_stream()
+    aux_s = self._aux()
+    if self.use_c_step and self.kind == "ae" and self.nl == 0 and not (m.dropout_prob > 0.0) \
+        and self.allreduce is None:
+      return self._c_train_step(blk, row_off, B, keep_noise, out, global_rows, main_s, aux_s)
+    ev = self._ev
+    stream = ctypes.c_void_p(main_s.cuda_stream)
+    aux = ctypes.c_void_p(aux_s.cuda_stream)
     self.rng_step += 1
     h0 = self.h[0]
     rows = B if global_rows is None else global_rows
@@ -296,10 +330,25 @@ class FusedEngine:
     else:
       users = blk.users[row_off:row_off + B]
       z = self._mf_forward(users, B, keep_drop, True, stream)
-    loss = self._loss(z, B, blk, row_off, rows, stream, out)
+    # the loss partial-sum reduction goes to the auxiliary stream (it records the
+    # "dO ready" event on the main stream and makes the auxiliary stream wait for it)
+    loss = self._loss(z, B, blk, row_off, rows, stream, out, reduce_on=(aux_s, aux, ev["loss"]))
     self._loss_target = loss
 
-    # ---- backward through the decoder (nn.py:280) ----
+    # ---- auxiliary stream: dW = dO^T . z  (+ decoder bias gradient) ----
+    if self.loss_id == LOSS_MNLL:
+      # dO was produced by rk_mnll_finish: column sums need a pass over dO
+      check(lib.rk_decode_bwd_dw(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(self.G_de),
+                                 ptr(self.gb_de), aux), "rk_decode_bwd_dw")
+    else:
+      # the loss epilogue already reduced dO per row tile: sum those few rows
+      check(lib.rk_colsum(ptr(self.gb_part), cdiv(B, self.row_tile), blk.n_cap, 0, ptr(blk.counts),
+                          ptr(self.gb_de), aux), "rk_colsum")
+      check(lib.rk_decode_bwd_dw(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(self.G_de), None,
+                                 aux), "rk_decode_bwd_dw")
+    ev["dw"].record(aux_s)
+
+    # ---- main stream: dZ = dO . W_de[T] and everything upstream of it ----
     W_de, _ = self._decoder_params()
     simple = (self.kind == "ae" and self.nl == 0 and not self.drop_active)
     dz = self.denc[0] if simple else self.dbott
@@ -308,16 +357,16 @@ class FusedEngine:
     check(lib.rk_decode_bwd_dz(ptr(self.dO), B, h0, blk.ref, ptr(W_de),
                                ptr(self.enc[0]) if simple else None, self.act, ptr(dz),
                                ptr(self.ws), stream), "rk_decode_bwd_dz")
-    if self.loss_id == LOSS_MNLL:
-      # dO was produced by rk_mnll_finish: column sums need a pass over dO
-      check(lib.rk_decode_bwd_dw(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(self.G_de),
-                                 ptr(self.gb_de), stream), "rk_decode_bwd_dw")
-    else:
-      # the loss epilogue already reduced dO per 128-row tile: sum those few rows
-      check(lib.rk_colsum(ptr(self.gb_part), cdiv(B, self.row_tile), blk.n_cap, 0, ptr(blk.counts),
-                          ptr(self.gb_de), stream), "rk_colsum")
-      check(lib.rk_decode_bwd_dw(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(self.G_de), None,
-                                 stream), "rk_decode_bwd_dw")
+    ev["dz"].record(main_s)
+
+    tied = self.kind == "ae" and bool(m.is_constrained)
+    overlap_updates = self.allreduce is None
+    if overlap_updates:
+      # decoder-side Adam on the auxiliary stream; it writes W_de, so it must
+      # follow the dZ GEMM that reads W_de
+      aux_s.wait_event(ev["dz"])
+      self._apply_updates(blk, row_off, B, aux, "decoder")
+      ev["aux_done"].record(aux_s)
 
     if self.kind == "ae":
       rh = list(reversed(self.h))
@@ -354,8 +403,9 @@ class FusedEngine:
         check(lib.rk_act_grad(ptr(self.denc[0]), ptr(self.enc[0]), B * h0, self.act, stream),
               "rk_act_grad")
       check(lib.rk_colsum(ptr(self.denc[0]), B, h0, h0, None, ptr(self.gb_en), stream), "rk_colsum")
-      tied = bool(m.is_constrained)
       G_en = self.G_de if tied else self.G_en
+      if tied:
+        main_s.wait_event(ev["dw"])      # accumulates on top of dW's rows
       check(lib.rk_ae_encode_bwd(blk.ref, row_off, B, ptr(self.denc[0]), h0, ptr(G_en),
                                  1 if tied else 0, stream), "rk_ae_encode_bwd")
     else:
@@ -366,10 +416,77 @@ class FusedEngine:
                              self.seed ^ 0xd0d0, self.rng_step, stream), "rk_dropout")
       check(lib.rk_act_grad(ptr(self.dbott), ptr(self.enc[0]), n, self.act, stream), "rk_act_grad")
 
-    if self.allreduce is not None:
+    if overlap_updates:
+      self._apply_updates(blk, row_off, B, stream, "encoder")
+      main_s.wait_event(ev["aux_done"])
+    else:
+      main_s.wait_event(ev["dw"])
       self._allreduce_grads(blk, B)
-    self._apply_updates(blk, row_off, B, stream)
+      self._apply_updates(blk, row_off, B, stream, "all")
     return loss
+
+  def _c_train_step(self, blk, row_off, B, keep_noise, out, global_rows, main_s, aux_s):
+    """The same step through rk_ae_train_step: one FFI call, kernels sequenced
+    in C on the two streams."""
+    from ._lib import ENTRY, PAR_B_DE, PAR_B_EN, PAR_W_DE, PAR_W_EN, RkAeStep
+    raw = _lib.load()
+    m, S = self.model, self.states
+    st = self._cstep
+    if st is None:
+      st = RkAeStep()
+      self._c_events = [raw.rk_event_create() for _ in range(4)]
+      st.ev_loss, st.ev_dz, st.ev_dw, st.ev_aux_done = self._c_events
+      self._c_time_pairs = []
+      self._c_time_idx = 0
+      self._cstep = st
+    self.rng_step += 1
+    rows = B if global_rows is None else global_rows
+    st.blk = ctypes.pointer(blk.c)
+    st.row_off, st.B, st.h, st.act = row_off, B, self.h[0], self.act
+    st.loss_kind, st.tied = self.loss_id, 1 if m.is_constrained else 0
+    st.confidence = self.confidence
+    st.inv_B = _f32(np.float32(1.0) / np.float32(rows))
+    st.denom = float(rows)
+    st.noise_p = float(m.noise_prob)
+    st.seed, st.rng_step = self.seed, self.rng_step
+    st.keep, st.users = ptr(keep_noise), ptr(blk.users)
+    names = {PAR_W_EN: "en_embedding_layer.weight",
+             PAR_B_EN: "_DynamicAutoencoder__en_linear_embedding_layer.bias",
+             PAR_W_DE: "de_embedding_layer.weight",
+             PAR_B_DE: "_DynamicAutoencoder__de_linear_embedding_layer.bias"}
+    for k, name in names.items():
+      if k == PAR_W_DE and m.is_constrained:
+        continue
+      s = S[name]
+      s.step += 1
+      lr, b1, b2, eps = self._adam_args(s)
+      a = st.par[k]
+      a.p, a.m, a.v = ptr(s.p), ptr(s.m), ptr(s.v)
+      a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = lr, b1, b2, eps, float(s.wd)
+      a.step, a.sparse = s.step, 1 if s.sparse else 0
+    out = self.loss_out if out is None else out
+    st.Z0, st.dZ0, st.dO = ptr(self.enc[0]), ptr(self.denc[0]), ptr(self.dO)
+    st.G_de, st.G_en, st.gb_de = ptr(self.G_de), ptr(self.G_en), ptr(self.gb_de)
+    st.gb_part, st.gb_en, st.ws = ptr(self.gb_part), ptr(self.gb_en), ptr(self.ws)
+    st.loss_part, st.loss_out = ptr(self.loss_part), ptr(out)
+    st.stream_main, st.stream_aux = main_s.cuda_stream, aux_s.cuda_stream
+    if self.time_entry is not None:
+      if not self._c_time_pairs:
+        self._c_time_pairs = [(raw.rk_event_create(), raw.rk_event_create()) for _ in range(512)]
+      e0, e1 = self._c_time_pairs[self._c_time_idx % len(self._c_time_pairs)]
+      self._c_time_idx += 1
+      st.time_entry, st.time_ev0, st.time_ev1 = ENTRY[self.time_entry], e0, e1
+    else:
+      st.time_entry = 0
+    check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
+    self._loss_target = out
+    return out
+
+  def timed_entry_ms(self):
+    """Per-launch durations (ms) of the bracketed entry since timing was enabled."""
+    raw = _lib.load()
+    n = min(self._c_time_idx, len(self._c_time_pairs))
+    return [raw.rk_event_elapsed_ms(e0, e1) for e0, e1 in self._c_time_pairs[:n]]
 
   # ------------------------------------------------------- data parallelism
   def grad_views(self, n_b):
@@ -391,10 +508,14 @@ class FusedEngine:
     self.allreduce(self, blk)
 
   # ---------------------------------------------------------------- updates
-  def _apply_updates(self, blk, row_off, B, stream):
+  def _apply_updates(self, blk, row_off, B, stream, part="all"):
+    """part: 'decoder' = the decoder / item table and its gathered bias (their
+    gradients come from the dW chain), 'encoder' = everything else, 'all'."""
     m, S = self.model, self.states
     h0 = self.h[0]
     n_items = blk.n_items
+    dec = part in ("all", "decoder")
+    enc = part in ("all", "encoder")
 
     def table(name, G):
       s = S[name]
@@ -404,35 +525,41 @@ class FusedEngine:
         self._adam_table(s, blk.pos, G, h0, n_items, stream)
 
     if self.kind == "ae":
-      from .nn import DynamicAutoencoder  # noqa: F401  (names below follow its state dict)
       en_w = "en_embedding_layer.weight"
       if m.is_constrained:
-        table(en_w, self.G_de)
+        if enc:
+          table(en_w, self.G_de)          # tied table: G_de holds dW + encoder rows
       else:
-        table(en_w, self.G_en)
-        table("de_embedding_layer.weight", self.G_de)
-      self._adam_dense(S["_DynamicAutoencoder__en_linear_embedding_layer.bias"], self.gb_en, stream)
-      for i in range(self.nl):
-        self._adam_dense(S["encoding_layers.%d.weight" % i], self.g_enc_w[i], stream)
-        self._adam_dense(S["encoding_layers.%d.bias" % i], self.g_enc_b[i], stream)
-        if not m.is_constrained:
-          self._adam_dense(S["decoding_layers.%d.weight" % i], self.g_dec_w[i], stream)
-        self._adam_dense(S["decoding_layers.%d.bias" % i], self.g_dec_b[i], stream)
-      # decoder bias: a dense [n_items] gradient (index_select backward), wd = 0
-      self._adam_table(S["_DynamicAutoencoder__de_linear_embedding_layer.bias"], blk.pos,
-                       self.gb_de, 1, n_items, stream)
+        if enc:
+          table(en_w, self.G_en)
+        if dec:
+          table("de_embedding_layer.weight", self.G_de)
+      if enc:
+        self._adam_dense(S["_DynamicAutoencoder__en_linear_embedding_layer.bias"], self.gb_en, stream)
+        for i in range(self.nl):
+          self._adam_dense(S["encoding_layers.%d.weight" % i], self.g_enc_w[i], stream)
+          self._adam_dense(S["encoding_layers.%d.bias" % i], self.g_enc_b[i], stream)
+          if not m.is_constrained:
+            self._adam_dense(S["decoding_layers.%d.weight" % i], self.g_dec_w[i], stream)
+          self._adam_dense(S["decoding_layers.%d.bias" % i], self.g_dec_b[i], stream)
+      if dec:
+        # decoder bias: a dense [n_items] gradient (index_select backward), wd = 0
+        self._adam_table(S["_DynamicAutoencoder__de_linear_embedding_layer.bias"], blk.pos,
+                         self.gb_de, 1, n_items, stream)
     else:
       lib = self.lib
-      users = blk.users[row_off:row_off + B]
-      su = S["user_embedding_layer.weight"]
-      if su.sparse:
-        self._adam_rows(su, None, users, None, B, self.dbott, h0, stream)
-      else:
-        check(lib.rk_scatter_pos(ptr(self.pos_u), ptr(users), B, 0, stream), "rk_scatter_pos")
-        self._adam_table(su, self.pos_u, self.dbott, h0, m.num_users, stream)
-        check(lib.rk_scatter_pos(ptr(self.pos_u), ptr(users), B, 1, stream), "rk_scatter_pos")
-      table("item_embedding_layer.weight", self.G_de)
-      self._adam_table(S["bias"], blk.pos, self.gb_de, 1, n_items, stream)
+      if enc:
+        users = blk.users[row_off:row_off + B]
+        su = S["user_embedding_layer.weight"]
+        if su.sparse:
+          self._adam_rows(su, None, users, None, B, self.dbott, h0, stream)
+        else:
+          check(lib.rk_scatter_pos(ptr(self.pos_u), ptr(users), B, 0, stream), "rk_scatter_pos")
+          self._adam_table(su, self.pos_u, self.dbott, h0, m.num_users, stream)
+          check(lib.rk_scatter_pos(ptr(self.pos_u), ptr(users), B, 1, stream), "rk_scatter_pos")
+      if dec:
+        table("item_embedding_layer.weight", self.G_de)
+        self._adam_table(S["bias"], blk.pos, self.gb_de, 1, n_items, stream)
 
   # ------------------------------------------------------------- inference
   def predict_scores(self, blk, row_off, B, out, ld_out, tgt_items_blk):

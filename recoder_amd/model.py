@@ -311,11 +311,13 @@ class Recoder(object):
     ds = dataloader.dataset
     dcsr = ds.device_csr()
     B, S = dataloader.batch_size, dataloader.num_sampling_users
-    blk = getattr(self, "_train_blk", None)
-    if blk is None or blk.S_cap < S or blk.n_items != dcsr.n_items or \
-        blk.negative_sampling != dataloader.negative_sampling:
-      blk = self._make_block(dcsr, S, dataloader.negative_sampling)
-      self._train_blk = blk
+    pf = getattr(self, "_train_pf", None)
+    if pf is None or pf.dcsr is not dcsr or pf.blocks[0].S_cap < S or \
+        pf.blocks[0].negative_sampling != dataloader.negative_sampling:
+      from .device import CollatePrefetcher
+      ns = dataloader.negative_sampling
+      pf = CollatePrefetcher(lambda: self._make_block(dcsr, S, ns), dcsr, self.device)
+      self._train_pf = pf
     n = len(ds)
     order = None
     if self.user_order_hook is not None:
@@ -323,10 +325,16 @@ class Recoder(object):
     if order is None:
       order = epoch_user_order(n)
     order_dev = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int64)).to(self.device)
-    for off in range(0, n, S):
-      users = order_dev[off:off + S]
-      blk.collate(dcsr, users)
-      Sg = int(users.numel())
+    offs = [o for o in range(0, n, S) if order_dev[o:o + S].numel() > 0]
+    # the group after the current one is collated on the prefetcher's side stream
+    if offs:
+      pf.submit(0, order_dev[offs[0]:offs[0] + S])
+    for gi, off in enumerate(offs):
+      slot = gi % 2
+      if gi + 1 < len(offs):
+        pf.submit((gi + 1) % 2, order_dev[offs[gi + 1]:offs[gi + 1] + S])
+      blk = pf.acquire(slot)
+      Sg = int(order_dev[off:off + S].numel())
       keep_noise = keep_drop = None
       if self.mask_hook is not None:
         keep_noise, keep_drop = self.mask_hook(self._global_step, order[off:off + S])
@@ -336,6 +344,7 @@ class Recoder(object):
         if keep_drop is not None:
           kd = keep_drop[r:r + rows].contiguous()
         yield blk, r, rows, keep_noise, kd
+      pf.release(slot)
 
   def _train(self, train_dataloader, val_dataloader, num_epochs, current_epoch, lr_scheduler,
              batch_size, model_checkpoint_prefix, checkpoint_freq, eval_freq, metrics,
