@@ -1,0 +1,85 @@
+"""CPU: the C-ABI library loads and exports every symbol include/recoder_hip.h
+declares; the ctypes mirrors have the C struct layouts; the product fails loudly
+without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "recoder_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+  from recoder_amd import _lib
+  if not os.path.exists(_lib.LIB_PATH):
+    from recoder_amd.build import build_library
+    build_library(verbose=False)
+  return _lib.load()
+
+
+def declared_symbols():
+  src = open(HEADER).read()
+  src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+  return sorted(set(re.findall(r"\b(rk_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+  from recoder_amd import _lib
+  syms = declared_symbols()
+  assert len(syms) >= 25
+  for s in syms:
+    assert hasattr(lib, s), "missing export: " + s
+    assert s in _lib.SIGNATURES, "no ctypes signature for " + s
+  for s in _lib.SIGNATURES:
+    assert s in syms, "bound but not declared in the header: " + s
+
+
+def test_struct_layouts_match_the_header(tmp_path, lib):
+  from recoder_amd import _lib
+  c = tmp_path / "sz.c"
+  c.write_text('#include <stdio.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu\\n", '
+               'sizeof(rk_block_t), sizeof(rk_adam_param_t), sizeof(rk_ae_step_t));return 0;}\n' % HEADER)
+  exe = tmp_path / "sz"
+  subprocess.check_call(["gcc", str(c), "-o", str(exe)])
+  sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+  assert sizes == [ctypes.sizeof(_lib.RkBlock), ctypes.sizeof(_lib.RkAdamParam),
+                   ctypes.sizeof(_lib.RkAeStep)]
+
+
+def test_version_and_error_string(lib):
+  assert lib.rk_version() >= 100
+  assert isinstance(lib.rk_last_error(), bytes)
+  assert lib.rk_dz_workspace_bytes(500, 200) == 64 * 500 * 200 * 4
+  assert lib.rk_decode_row_tile() in (32, 64, 128)
+
+
+def test_fails_loudly_without_gpu():
+  import torch
+  if torch.cuda.is_available():
+    pytest.skip("GPU present")
+  from recoder_amd._lib import RecoderHipError
+  from recoder_amd.device import require_gpu
+  with pytest.raises(RecoderHipError):
+    require_gpu()
+  from recoder_amd.data import BatchCollator, RecommendationDataset
+  import numpy as np
+  import scipy.sparse as sp
+  ds = RecommendationDataset(sp.csr_matrix(np.eye(4, dtype=np.float32)))
+  ui, _ = ds[[0, 1]]
+  with pytest.raises(RecoderHipError):
+    BatchCollator(2, True).collate(ui)
+
+
+def test_product_never_imports_the_oracle():
+  """The oracle is test infrastructure: nothing under recoder_amd/ may import it."""
+  pkg = os.path.join(ROOT, "recoder_amd")
+  for dirpath, _, files in os.walk(pkg):
+    for f in files:
+      if f.endswith(".py"):
+        src = open(os.path.join(dirpath, f)).read()
+        assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# oracle", ""), f
