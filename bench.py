@@ -133,9 +133,13 @@ def main():
   torch.cuda.set_device(local_rank)
   device = torch.device("cuda", local_rank)
   dp = None
-  if world > 1:
+  # RK_FORCE_DP=1 exercises the data-parallel plumbing (two-phase collation, RCCL
+  # all-reduces) with a 1-rank group on a single GPU
+  force_dp = os.environ.get("RK_FORCE_DP") == "1"
+  if world > 1 or force_dp:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     from recoder_amd.parallel import DataParallel, shard_range
     dp = DataParallel()
@@ -248,7 +252,7 @@ def main():
   if c_path:
     eng._c_time_idx = 0
 
-  if world > 1:
+  if dp is not None:
     import torch.distributed as dist
     dist.barrier()
   torch.cuda.synchronize()
@@ -257,10 +261,10 @@ def main():
     step(i)
   t_enqueue = time.perf_counter() - t0      # host time to enqueue the timed steps
   torch.cuda.synchronize()
-  if world > 1:
+  if dp is not None:
     dist.barrier()
   dt = time.perf_counter() - t0
-  if world > 1:
+  if dp is not None:
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -287,8 +291,18 @@ def main():
     bound, work, unit = algorithmic_work(only, B, h0, n_b, nnz, n_items)
     achieved = work / (ms * 1e-3) if ms == ms and ms > 0 else float("nan")
     peak = PEAK_MFMA_F32_TF if bound == "mfma" else PEAK_HBM_GBS
+    # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload
+    # (profiles/r*_pmc_traffic.json, tools/pmc_traffic.py); null for other configs
+    traffic = None
+    if args.config == "c2":
+      import glob
+      files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+      if files:
+        ent = json.load(open(files[-1]))["entries"].get(only)
+        if ent:
+          traffic = ent["hbm_bytes_per_launch"]
     roofline = dict(bound=bound, achieved=achieved, peak=peak, unit=unit, frac=achieved / peak,
-                    traffic=None, kernel=only, avg_launch_ms=ms, calls_per_step=calls_per_step,
+                    traffic=traffic, kernel=only, avg_launch_ms=ms, calls_per_step=calls_per_step,
                     warmup_profile_ms={k: round(v[0] * v[1] / max(1, half - 1), 4)
                                        for k, v in sorted(prof.items())})
     out = {
@@ -302,10 +316,10 @@ def main():
                  "host_enqueue_ms_per_step": t_enqueue / args.steps * 1e3},
       "roofline": roofline,
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not force_dp and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline(cfg, csr_full, args.cpu_steps)
     print(json.dumps(out))
-  if world > 1:
+  if dp is not None:
     dist.destroy_process_group()
 
 
