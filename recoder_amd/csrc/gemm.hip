@@ -20,6 +20,8 @@
 // multiple of 16 B -> conflict-free ds_read_b128: one read feeds 4 MFMA k-steps
 // because the two lane halves take k = {0..3} / {4..7} of each 8-group);
 // k-major operands sit as [16][tile] and are read with ds_read_b32.
+#include <stdlib.h>
+
 #include "common.h"
 
 #ifdef RK_PROBE
@@ -662,7 +664,8 @@ extern "C" int64_t rk_dz_workspace_bytes(int32_t B, int32_t h) {
 extern "C" int32_t rk_decode_row_tile(void) { return DEC_BM; }
 
 extern "C" int32_t rk_loss_partials(int32_t B, int32_t n_cap) {
-  const int tiles = rk_cdiv(B, DEC_BM) * rk_cdiv(n_cap, 128);
+  // worst case over the decode tilings (64-row x 64-column tiles); MNLL uses one per row
+  const int tiles = rk_cdiv(B, DEC_BM) * rk_cdiv(n_cap, 64);
   return tiles > B ? tiles : B;
 }
 
@@ -693,7 +696,19 @@ extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_blo
     // it is allocated zeroed and rk_loss_reduce re-zeroes what it consumed
     RK_REQUIRE(tgt->implicit || tgt->pref_rc != nullptr, "explicit values need pref_rc");
     p.ld_dev = tgt->counts + 2;
-    if (loss_kind == RK_LOSS_MSE)
+    static const int cfg = getenv("RK_DEC_CFG") ? atoi(getenv("RK_DEC_CFG")) : 0;   // tuning switch
+    if (loss_kind == RK_LOSS_MSE && cfg == 1) {
+      const int t64 = rk_cdiv(p.tiles_m * rk_cdiv(tgt->n_cap, 64), 8) * 8;
+      hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 1, 0, 0, EPI_LOSS_MSE, true, 32>), dim3(t64, 1),
+                         dim3(256), 0, stream, p);
+    } else if (loss_kind == RK_LOSS_MSE && cfg == 2) {
+      hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 2, 0, 0, EPI_LOSS_MSE, true, 16>), dim3(tiles, 1),
+                         dim3(256), 0, stream, p);
+    } else if (loss_kind == RK_LOSS_MSE && cfg == 3) {
+      const int t64 = rk_cdiv(p.tiles_m * rk_cdiv(tgt->n_cap, 64), 8) * 8;
+      hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 1, 0, 0, EPI_LOSS_MSE, true, 16>), dim3(t64, 1),
+                         dim3(256), 0, stream, p);
+    } else if (loss_kind == RK_LOSS_MSE)
       hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 2, 0, 0, EPI_LOSS_MSE, true, 32>), dim3(tiles, 1),
                          dim3(256), 0, stream, p);
     else

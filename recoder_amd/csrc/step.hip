@@ -86,7 +86,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     RK_TRY(rk_decode_loss(a->Z0, B, h, blk, a->row_off, W_de, a->par[RK_PAR_B_DE].p, a->loss_kind,
                           a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, sm));
   }
-  int n_part = row_tiles * rk_cdiv(blk->n_cap, 128);
+  int n_part = rk_loss_partials(B, blk->n_cap);   // all slots (unused ones hold 0)
   if (a->loss_kind == RK_LOSS_MNLL) {
     RK_TRY(rk_mnll_finish(a->dO, B, blk, a->row_off, a->inv_B, a->loss_part, sm));
     n_part = B;

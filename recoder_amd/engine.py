@@ -272,7 +272,7 @@ class FusedEngine:
                                stream), "rk_mnll_finish")
       n_part = B
     else:
-      n_part = cdiv(B, self.row_tile) * cdiv(tgt.n_cap, 128)
+      n_part = self.lib.rk_loss_partials(B, tgt.n_cap)     # all slots (unused ones hold 0)
     if reduce_on is not None:
       t_stream, raw, event = reduce_on
       event.record(torch.cuda.current_stream())

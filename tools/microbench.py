@@ -66,6 +66,7 @@ def main():
     gbp = torch.empty((B // 64 + 1) * blk.ld_cap, **f)
     ws = torch.empty(lib.rk_dz_workspace_bytes(B, h) // 4, **f)
     part = torch.zeros(lib.rk_loss_partials(B, blk.n_cap), **f)
+    gbp = torch.empty((B // 32 + 1) * blk.ld_cap, **f)
     r = {}
     r["collate"] = timeit(lambda: blk.collate(dcsr, users))
     r["dec_mse"] = timeit(lambda: check(lib.rk_decode_loss(
