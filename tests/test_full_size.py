@@ -1,0 +1,178 @@
+"""GPU tests at BASELINE.json's full sizes: size-independent properties
+(sortedness, inverse maps, popcount == nnz, idempotence, permutation invariance,
+determinism, decreasing loss) plus the first steps of C2 against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import recoder_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+  return torch.device("cuda")
+
+
+@pytest.fixture(scope="module")
+def ml20m():
+  from recoder_amd import synthetic
+  return synthetic.ml20m_like(seed=0)
+
+
+def popcount(a):
+  return int(np.unpackbits(np.ascontiguousarray(a).view(np.uint8)).sum())
+
+
+def test_c2_collation_properties(ml20m):
+  from recoder_amd.device import Block, DeviceCSR
+  csr = ml20m
+  assert csr.shape == (116677, 20108)
+  dcsr = DeviceCSR(csr)
+  S = 500
+  deg = np.diff(csr.indptr)
+  blk = Block(S, int(np.sort(deg)[-S:].sum()), csr.shape[1])
+  rng = np.random.RandomState(0)
+  users = rng.permutation(csr.shape[0])[:S].astype(np.int64)
+  blk.collate(dcsr, torch.from_numpy(users).to(dev()))
+  h1 = blk.to_host()
+  n_b, nnz = h1["n_b"], h1["nnz"]
+  assert nnz == int(deg[users].sum())
+  assert np.all(np.diff(h1["items"]) > 0)                              # sorted, unique
+  assert np.array_equal(h1["items"], np.unique(csr[users].indices))     # == np.unique
+  pos = h1["pos"]
+  assert np.array_equal(np.nonzero(pos >= 0)[0], h1["items"])          # inverse map
+  assert np.array_equal(pos[h1["items"]], np.arange(n_b))
+  assert h1["cols"].min() >= 0 and h1["cols"].max() < n_b
+  assert np.array_equal(h1["items"][h1["cols"]], csr[users].indices)   # relabel round trip
+  for r in range(0, S, 37):                                             # rows stay column-sorted
+    seg = h1["cols"][h1["indptr"][r]:h1["indptr"][r + 1]]
+    assert np.all(np.diff(seg) > 0)
+  bits = blk.bits_rc.cpu().numpy().view(np.uint32).reshape(blk.S_cap, blk.ldw_rc)[:S, :(n_b + 31) // 32]
+  assert popcount(bits) == nnz
+  bits_t = blk.bits_cr.cpu().numpy().view(np.uint32).reshape(-1, blk.ldw_cr)[:n_b]
+  assert popcount(bits_t) == nnz
+  pref = blk.pref_rc.cpu().numpy().reshape(blk.S_cap, blk.ldw_rc)[:S, :(n_b + 31) // 32]
+  pc = np.unpackbits(bits.view(np.uint8), axis=1).reshape(S, -1, 32).sum(axis=2)
+  assert np.array_equal(pref, np.cumsum(pc, axis=1) - pc)              # exclusive prefix popcount
+  # idempotence: the same users again (new stamp) give the same block
+  blk.collate(dcsr, torch.from_numpy(users).to(dev()))
+  h2 = blk.to_host()
+  for k in ("items", "cols", "vals", "indptr", "pos"):
+    assert np.array_equal(h1[k], h2[k]), k
+  # permutation invariance of the item set
+  perm = rng.permutation(S)
+  blk.collate(dcsr, torch.from_numpy(users[perm]).to(dev()))
+  h3 = blk.to_host()
+  assert np.array_equal(h3["items"], h1["items"]) and h3["nnz"] == nnz
+  assert np.array_equal(np.diff(h3["indptr"]), np.diff(h1["indptr"])[perm])
+
+
+def _train(csr, cfg, steps, order, B=500, seed=0):
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder, MatrixFactorization
+  torch.manual_seed(seed)
+  if cfg["kind"] == "ae":
+    model = DynamicAutoencoder(hidden_layers=cfg["hidden_layers"], activation_type=cfg.get("act", "tanh"),
+                               noise_prob=cfg.get("noise_prob", 0.0), dropout_prob=cfg.get("dropout_prob", 0.0),
+                               sparse=cfg.get("sparse", False))
+  else:
+    model = MatrixFactorization(embedding_size=cfg["d"], activation_type="none", sparse=cfg.get("sparse", False))
+  rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss=cfg["loss"])
+  rec.user_order_hook = lambda epoch, n: order
+  ds = RecommendationDataset(csr)
+  rec._Recoder__init_training(ds, 1e-3, cfg.get("wd", 2e-5))
+  init = {k: v.detach().cpu().clone() for k, v in model.named_parameters()}
+  rec.train(ds, batch_size=B, lr=1e-3, weight_decay=cfg.get("wd", 2e-5), num_epochs=1,
+            iters_per_epoch=steps, negative_sampling=True)
+  return rec, model, init, rec.last_epoch_losses.copy()
+
+
+def test_c2_first_steps_match_oracle_and_are_deterministic(ml20m):
+  csr = ml20m
+  cfg = dict(kind="ae", hidden_layers=[200], loss="mse", noise_prob=0.0, sparse=False)
+  rng = np.random.RandomState(1)
+  order = rng.permutation(csr.shape[0]).astype(np.int64)
+  rec, model, init, losses = _train(csr, cfg, 40, order)
+  assert len(losses) == 40 and np.all(np.isfinite(losses))
+  assert losses[-10:].mean() < losses[:10].mean()
+  # the oracle on the same batches (3 steps at the full C2 shape)
+  o = orc.OracleRecoder("ae", init, hidden_layers=[200], activation_type="tanh", loss="mse",
+                        lr=1e-3, weight_decay=2e-5)
+  for i in range(3):
+    users = order[i * 500:(i + 1) * 500]
+    b = orc.collate(orc.extract_rows(csr, users), users, 500, True)[0]
+    want = o.train_step(b)
+    assert abs(losses[i] - want) / abs(want) < 1e-5, (i, losses[i], want)
+  # bitwise determinism at full size
+  _, model2, _, losses2 = _train(csr, cfg, 40, order)
+  assert np.array_equal(losses, losses2)
+  for (k, a), (_, b2) in zip(model.named_parameters(), model2.named_parameters()):
+    assert torch.equal(a, b2), k
+
+
+def test_c3_msd_like_two_layer_mnll():
+  from recoder_amd import synthetic
+  csr = synthetic.lognormal_zipf(60000, 41140, 59, seed=1)      # MSD item count, users scaled
+  cfg = dict(kind="ae", hidden_layers=[200, 200], loss="logloss", noise_prob=0.5, sparse=False)
+  order = np.random.RandomState(2).permutation(csr.shape[0]).astype(np.int64)
+  rec, model, init, losses = _train(csr, cfg, 30, order)
+  assert np.all(np.isfinite(losses)) and losses[-8:].mean() < losses[:8].mean()
+  o = orc.OracleRecoder("ae", init, hidden_layers=[200, 200], activation_type="tanh", noise_prob=0.0,
+                        loss="logloss", lr=1e-3, weight_decay=2e-5)
+  # (noise masks differ from the oracle's, so compare an eval-mode loss on one batch instead)
+  from recoder_amd.device import Block, DeviceCSR
+  dcsr = DeviceCSR(csr)
+  users = order[:500]
+  blk = Block(500, int(np.diff(csr.indptr)[users].sum()), csr.shape[1])
+  blk.collate(dcsr, torch.from_numpy(users).to(dev()))
+  model.eval()
+  got = float(rec._engine().compute_loss(blk, 0, 500).item())
+  st = {k: v.detach().cpu() for k, v in model.named_parameters()}
+  o2 = orc.OracleRecoder("ae", st, hidden_layers=[200, 200], activation_type="tanh", loss="logloss")
+  o2.training = False
+  b = orc.collate(orc.extract_rows(csr, users), users, 500, True)[0]
+  with torch.no_grad():
+    want = float(o2.compute_loss(b).item())
+  assert abs(got - want) / abs(want) < 1e-5, (got, want)
+
+
+def test_c4_mf_sparse_d128():
+  from recoder_amd import synthetic
+  csr = synthetic.lognormal_zipf(100000, 50000, 50, seed=2)
+  cfg = dict(kind="mf", d=128, loss="mse", sparse=True)
+  order = np.random.RandomState(3).permutation(csr.shape[0]).astype(np.int64)
+  rec, model, init, losses = _train(csr, cfg, 30, order)
+  assert np.all(np.isfinite(losses))
+  o = orc.OracleRecoder("mf", init, activation_type="none", sparse=True, loss="mse", lr=1e-3, weight_decay=2e-5)
+  for i in range(2):
+    users = order[i * 500:(i + 1) * 500]
+    b = orc.collate(orc.extract_rows(csr, users), users, 500, True)[0]
+    want = o.train_step(b)
+    assert abs(losses[i] - want) / abs(want) < 1e-5, (i, losses[i], want)
+
+
+def test_c5_shaped_large_catalogue_h512_sparse():
+  """1 M items (multi-workgroup scan path), uniform popularity, AE [512], SparseAdam."""
+  from recoder_amd import synthetic
+  csr = synthetic.uniform(40000, 1000000, 100, seed=3)
+  cfg = dict(kind="ae", hidden_layers=[512], loss="mse", noise_prob=0.0, sparse=True, wd=0.0)
+  order = np.random.RandomState(4).permutation(csr.shape[0]).astype(np.int64)
+  rec, model, init, losses = _train(csr, cfg, 12, order)
+  assert np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+  # collation at this size against np.unique
+  from recoder_amd.device import Block, DeviceCSR
+  dcsr = DeviceCSR(csr)
+  users = order[:500]
+  blk = Block(500, int(np.diff(csr.indptr)[users].sum()), csr.shape[1])
+  blk.collate(dcsr, torch.from_numpy(users).to(dev()))
+  h = blk.to_host()
+  assert np.array_equal(h["items"], np.unique(csr[users].indices))
+  assert np.array_equal(h["items"][h["cols"]], csr[users].indices)
+  # first step against the oracle (500 x ~48.8k dense on the CPU)
+  o = orc.OracleRecoder("ae", init, hidden_layers=[512], activation_type="tanh", sparse=True, loss="mse",
+                        lr=1e-3, weight_decay=0.0)
+  b = orc.collate(orc.extract_rows(csr, users), users, 500, True)[0]
+  want = o.train_step(b)
+  assert abs(losses[0] - want) / abs(want) < 1e-5, (losses[0], want)
