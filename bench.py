@@ -218,7 +218,7 @@ def main():
   timed = {k: v for k, v in prof.items() if k in ENTRY}
   dominant = max(timed, key=lambda k: timed[k][0] * timed[k][1]) if timed else "rk_decode_loss"
   only = dominant
-  c_path = dp is None
+  c_path = True                 # rk_ae_train_step handles single-GPU and data-parallel steps
   eng.use_c_step = c_path
   if c_path:
     eng.time_entry = only        # the C driver brackets this entry on its launch stream

@@ -252,7 +252,8 @@ typedef struct rk_ae_step {
   void *stream_main, *stream_aux;                  /* hipStream_t */
   void *ev_loss, *ev_dz, *ev_dw, *ev_aux_done;     /* hipEvent_t (rk_event_create) */
   int32_t time_entry;        /* RK_ENTRY_*: bracket that entry with the two events below */
-  int32_t reserved;
+  int32_t phase;             /* 0 = whole step; 1 = forward + backward only; 2 = Adam updates
+                                only (data parallel: all-reduce the gradients in between) */
   void *time_ev0, *time_ev1;
 } rk_ae_step_t;
 

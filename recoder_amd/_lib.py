@@ -63,7 +63,7 @@ class RkAeStep(Structure):
     ("loss_part", c_void_p), ("loss_out", c_void_p),
     ("stream_main", c_void_p), ("stream_aux", c_void_p),
     ("ev_loss", c_void_p), ("ev_dz", c_void_p), ("ev_dw", c_void_p), ("ev_aux_done", c_void_p),
-    ("time_entry", c_int32), ("reserved", c_int32),
+    ("time_entry", c_int32), ("phase", c_int32),
     ("time_ev0", c_void_p), ("time_ev1", c_void_p),
   ]
 

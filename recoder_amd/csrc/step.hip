@@ -74,7 +74,9 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   const int B = a->B, h = a->h, n_items = blk->n_items;
   const int row_tiles = rk_cdiv(B, rk_decode_row_tile());
   const float *W_de = a->tied ? a->par[RK_PAR_W_EN].p : a->par[RK_PAR_W_DE].p;
-
+  float *G_en = a->tied ? a->G_de : a->G_en;
+  RK_REQUIRE(a->phase >= 0 && a->phase <= 2, "phase must be 0, 1 or 2");
+  if (a->phase != 2) {
   // ---- forward: encoder SpMM, decoder GEMM + fused loss ----
   {
     Timer t(a, RK_ENTRY_ENCODE_FWD, sm);
@@ -113,6 +115,16 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   }
   (void)hipEventRecord((hipEvent_t)a->ev_dz, sm);
 
+  // ---- main stream: encoder bias / row gradients ----
+  RK_TRY(rk_colsum(a->dZ0, B, h, h, nullptr, a->gb_en, sm));
+  if (a->tied) (void)hipStreamWaitEvent(sm, (hipEvent_t)a->ev_dw, 0);
+  {
+    Timer t(a, RK_ENTRY_ENCODE_BWD, sm);
+    RK_TRY(rk_ae_encode_bwd(blk, a->row_off, B, a->dZ0, h, G_en, a->tied ? 1 : 0, sm));
+  }
+  }  // phase != 2
+  if (a->phase == 1) return 0;
+
   // decoder-side Adam on the auxiliary stream; it writes W_de, so it follows dZ
   (void)hipStreamWaitEvent(sa, (hipEvent_t)a->ev_dz, 0);
   if (!a->tied) {
@@ -126,14 +138,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
                        a->par[RK_PAR_B_DE].weight_decay, a->par[RK_PAR_B_DE].step, sa));
   (void)hipEventRecord((hipEvent_t)a->ev_aux_done, sa);
 
-  // ---- main stream: encoder bias / row gradients + encoder-side Adam ----
-  RK_TRY(rk_colsum(a->dZ0, B, h, h, nullptr, a->gb_en, sm));
-  float *G_en = a->tied ? a->G_de : a->G_en;
-  if (a->tied) (void)hipStreamWaitEvent(sm, (hipEvent_t)a->ev_dw, 0);
-  {
-    Timer t(a, RK_ENTRY_ENCODE_BWD, sm);
-    RK_TRY(rk_ae_encode_bwd(blk, a->row_off, B, a->dZ0, h, G_en, a->tied ? 1 : 0, sm));
-  }
+  // ---- main stream: encoder-side Adam ----
   RK_TRY(adam_param(a, RK_PAR_W_EN, n_items, h, blk->pos, blk->items, blk->counts, blk->n_cap, G_en,
                     true, sm));
   RK_TRY(adam_param(a, RK_PAR_B_EN, 1, h, nullptr, nullptr, nullptr, 0, a->gb_en, false, sm));

@@ -143,6 +143,15 @@ class Block:
     self.counts.copy_(torch.tensor([n, 0, cdiv(n, 32) * 32, S], dtype=torch.int32), non_blocking=False)
     self.S = S
 
+  def host_n_b(self):
+    """n_b on the host.  After a CollatePrefetcher.submit this waits only for the
+    (long finished) async copy; otherwise it synchronises on the counts."""
+    ev = getattr(self, "counts_event", None)
+    if ev is not None:
+      ev.synchronize()
+      return int(self.counts_pinned[0])
+    return int(self.counts[0].item())
+
   # ---- host views (synchronising; tests / API compatibility only) ----
   def counts_host(self):
     c = self.counts.cpu().numpy()
@@ -186,6 +195,13 @@ class CollatePrefetcher:
         self.collate_fn(blk, self.dcsr, users_dev)
       else:
         blk.collate(self.dcsr, users_dev)
+      # the device-resident counts also go to pinned host memory: consumers that need
+      # n_b on the host (RCCL message sizes) read it later without stalling a stream
+      if getattr(blk, "counts_pinned", None) is None:
+        blk.counts_pinned = torch.zeros(4, dtype=torch.int32).pin_memory()
+        blk.counts_event = torch.cuda.Event()
+      blk.counts_pinned.copy_(blk.counts, non_blocking=True)
+      blk.counts_event.record(self.stream)
       self.ready[slot].record(self.stream)
     return blk
 

@@ -123,10 +123,15 @@ class FusedEngine:
     self.dO = torch.empty(B_cap * ld_cap, **f)
     self.G_de = torch.empty(n_cap * h0, **f)
     self.G_en = torch.empty(n_cap * h0, **f)
-    self.gb_de = torch.empty(n_cap, **f)
+    # small gradients in ONE buffer [gb_en (h0) | loss | pad | gb_de (n_cap)] so that a
+    # data-parallel step reduces them with a single collective over [0, off + n_b)
+    self.small_off = cdiv(h0 + 1, 4) * 4
+    self.small = torch.zeros(self.small_off + n_cap, **f)
+    self.gb_de = self.small[self.small_off:]
     self.row_tile = self.lib.rk_decode_row_tile()
     self.gb_part = torch.empty(cdiv(B_cap, self.row_tile) * ld_cap, **f)   # per-row-tile colsums of dO
-    self.gb_en = torch.empty(h0, **f)
+    self.gb_en = self.small[:h0]
+    self.loss_dp = self.small[h0:h0 + 1]
     self.ws = torch.empty(self.lib.rk_dz_workspace_bytes(B_cap, h0) // 4, **f)
     self.n_part = self.lib.rk_loss_partials(B_cap, n_cap)
     self.loss_part = torch.zeros(self.n_part, **f)
@@ -316,8 +321,7 @@ class FusedEngine:
     lib, m = self.lib, self.model
     main_s = torch.cuda.current_stream()
     aux_s = self._aux()
-    if self.use_c_step and self.kind == "ae" and self.nl == 0 and not (m.dropout_prob > 0.0) \
-        and self.allreduce is None:
+    if self.use_c_step and self.kind == "ae" and self.nl == 0 and not (m.dropout_prob > 0.0):
       return self._c_train_step(blk, row_off, B, keep_noise, out, global_rows, main_s, aux_s)
     ev = self._ev
     stream = ctypes.c_void_p(main_s.cuda_stream)
@@ -347,6 +351,13 @@ class FusedEngine:
       check(lib.rk_decode_bwd_dw(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(self.G_de), None,
                                  aux), "rk_decode_bwd_dw")
     ev["dw"].record(aux_s)
+    dp_dec = None
+    if self.allreduce is not None:
+      # data parallel: the decoder-side gradients start their RCCL all-reduce now,
+      # from the auxiliary stream, and travel while dZ / the encoder backward run
+      n_b_host = self.allreduce.n_b(blk)
+      with torch.cuda.stream(aux_s):
+        dp_dec = self.allreduce.reduce_async(self.grad_views(n_b_host, "decoder"))
 
     # ---- main stream: dZ = dO . W_de[T] and everything upstream of it ----
     W_de, _ = self._decoder_params()
@@ -420,9 +431,17 @@ class FusedEngine:
       self._apply_updates(blk, row_off, B, stream, "encoder")
       main_s.wait_event(ev["aux_done"])
     else:
-      main_s.wait_event(ev["dw"])
-      self._allreduce_grads(blk, B)
-      self._apply_updates(blk, row_off, B, stream, "all")
+      # data parallel: encoder-side all-reduce from the main stream; each side's Adam
+      # waits only for its own collective
+      dp_enc = self.allreduce.reduce_async(self.grad_views(n_b_host, "encoder"))
+      aux_s.wait_event(ev["dz"])            # decoder Adam writes W_de: after dZ read it
+      with torch.cuda.stream(aux_s):
+        self.allreduce.wait(dp_dec)
+        self._apply_updates(blk, row_off, B, aux, "decoder")
+        ev["aux_done"].record(aux_s)
+      self.allreduce.wait(dp_enc)
+      self._apply_updates(blk, row_off, B, stream, "encoder")
+      main_s.wait_event(ev["aux_done"])
     return loss
 
   def _c_train_step(self, blk, row_off, B, keep_noise, out, global_rows, main_s, aux_s):
@@ -465,10 +484,12 @@ class FusedEngine:
       a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = lr, b1, b2, eps, float(s.wd)
       a.step, a.sparse = s.step, 1 if s.sparse else 0
     out = self.loss_out if out is None else out
+    dp = self.allreduce
+    loss_dst = self.loss_dp if dp is not None else out
     st.Z0, st.dZ0, st.dO = ptr(self.enc[0]), ptr(self.denc[0]), ptr(self.dO)
     st.G_de, st.G_en, st.gb_de = ptr(self.G_de), ptr(self.G_en), ptr(self.gb_de)
     st.gb_part, st.gb_en, st.ws = ptr(self.gb_part), ptr(self.gb_en), ptr(self.ws)
-    st.loss_part, st.loss_out = ptr(self.loss_part), ptr(out)
+    st.loss_part, st.loss_out = ptr(self.loss_part), ptr(loss_dst)
     st.stream_main, st.stream_aux = main_s.cuda_stream, aux_s.cuda_stream
     if self.time_entry is not None:
       if not self._c_time_pairs:
@@ -478,7 +499,33 @@ class FusedEngine:
       st.time_entry, st.time_ev0, st.time_ev1 = ENTRY[self.time_entry], e0, e1
     else:
       st.time_entry = 0
-    check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
+    if dp is None:
+      st.phase = 0
+      check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
+    else:
+      # data parallel: forward + backward, all-reduce (SUM) of the gradients over the
+      # ranks while the rest of the backward runs, then the identical Adam everywhere
+      h0 = self.h[0]
+      st.phase = 1
+      check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
+      n_b = dp.n_b(blk)
+      tied = bool(m.is_constrained)
+      pend_dec = None
+      if not tied:
+        with torch.cuda.stream(aux_s):          # right behind dW on the auxiliary stream
+          pend_dec = dp.reduce_async([self.G_de[:n_b * h0]], coalesce=False)
+      main_s.wait_stream(aux_s)                 # gb_de / loss (aux) join gb_en (main)
+      G_enc = self.G_de if tied else self.G_en
+      pend_enc = dp.reduce_async([G_enc[:n_b * h0], self.small[:self.small_off + n_b]],
+                                 coalesce=False)
+      with torch.cuda.stream(aux_s):
+        if pend_dec is not None:
+          dp.wait(pend_dec)
+        dp.wait(pend_enc)
+      dp.wait(pend_enc)
+      out.copy_(self.loss_dp)
+      st.phase = 2
+      check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
     self._loss_target = out
     return out
 
@@ -489,23 +536,24 @@ class FusedEngine:
     return [raw.rk_event_elapsed_ms(e0, e1) for e0, e1 in self._c_time_pairs[:n]]
 
   # ------------------------------------------------------- data parallelism
-  def grad_views(self, n_b):
+  def grad_views(self, n_b, part="all"):
     """Views of everything a data-parallel step must SUM over the ranks: the
     live n_b gradient rows, the gathered-bias gradient, the dense gradients and
-    the (already 1/(N*B)-scaled) loss.  MF user-row gradients are rank-private
-    (each user lives on one rank) and are not reduced."""
+    the (already 1/(N*B)-scaled) loss.  'decoder' = what the dW chain produces,
+    'encoder' = the rest.  MF user-row gradients are rank-private (each user
+    lives on one rank) and are not reduced."""
     h0 = self.h[0]
-    ts = [self.G_de[:n_b * h0], self.gb_de[:n_b], self._loss_target]
+    tied = self.kind == "ae" and bool(self.model.is_constrained)
+    dec = [self.gb_de[:n_b], self._loss_target]
+    if not tied:
+      dec.append(self.G_de[:n_b * h0])
+    enc = []
     if self.kind == "ae":
       m = self.model
-      if not m.is_constrained:
-        ts.append(self.G_en[:n_b * h0])
-      ts.append(self.gb_en)
-      ts += self.g_enc_w + self.g_enc_b + [g for g in self.g_dec_w if g is not None] + self.g_dec_b
-    return ts
-
-  def _allreduce_grads(self, blk, B):
-    self.allreduce(self, blk)
+      enc.append(self.G_de[:n_b * h0] if tied else self.G_en[:n_b * h0])
+      enc.append(self.gb_en)
+      enc += self.g_enc_w + self.g_enc_b + [g for g in self.g_dec_w if g is not None] + self.g_dec_b
+    return dec if part == "decoder" else enc if part == "encoder" else dec + enc
 
   # ---------------------------------------------------------------- updates
   def _apply_updates(self, blk, row_off, B, stream, part="all"):

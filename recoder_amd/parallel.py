@@ -72,10 +72,38 @@ class DataParallel:
     blk.collate(dcsr, users_dev, phase=2)
 
   def attach(self, engine):
+    """Install the gradient exchange on a FusedEngine.  The engine calls
+    ``reduce_async(views)`` as soon as a group of gradients is complete (decoder
+    side right after dW, encoder side after the encoder backward) with the
+    producing stream current, and ``wait(handles)`` before the matching Adam, so
+    the RCCL transfers overlap the rest of the backward pass."""
     engine.world_size = self.world
-
-    def _allreduce(engine_, blk):
-      n_b = int(blk.counts[0].item())      # host sync: the collective needs a host count
-      allreduce_sum(engine_.grad_views(n_b), self.group)
-    engine.allreduce = _allreduce
+    engine.allreduce = self
     return engine
+
+  def n_b(self, blk):
+    return blk.host_n_b()
+
+  def reduce_async(self, views, small_threshold=65536, coalesce=True):
+    if not coalesce:
+      small_threshold = -1
+    small = [v for v in views if v.numel() <= small_threshold]
+    large = [v for v in views if v.numel() > small_threshold]
+    handles = [dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+               for v in large]
+    flat = None
+    if small:
+      flat = torch.cat([v.reshape(-1) for v in small])
+      handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+    return handles, small, flat
+
+  def wait(self, pending):
+    handles, small, flat = pending
+    for h in handles:
+      h.wait()                 # the current stream waits for the collective
+    if flat is not None:
+      off = 0
+      for v in small:
+        n = v.numel()
+        v.copy_(flat[off:off + n].view_as(v))
+        off += n
