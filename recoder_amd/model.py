@@ -268,6 +268,7 @@ class Recoder(object):
       "number of sampling users should be a multiple of the batch size"
 
     self.__init_training(train_dataset=train_dataset, lr=lr, weight_decay=weight_decay)
+    train_dataset = self._setup_data_parallel(train_dataset)
 
     train_dataloader = RecommendationDataLoader(train_dataset, batch_size=batch_size,
                                                 negative_sampling=negative_sampling,
@@ -300,9 +301,38 @@ class Recoder(object):
                 iters_per_epoch=iters_per_epoch, eval_num_users=eval_num_users,
                 eval_batch_size=eval_batch_size)
 
+  def _setup_data_parallel(self, train_dataset):
+    """Under an initialised torch.distributed group (one process per GPU, backend
+    'nccl' = RCCL) the users are sharded over the ranks and the gradients are
+    all-reduced (recoder_amd/parallel.py).  Returns this rank's shard."""
+    import torch.distributed as dist
+    self._dp = None
+    if not (dist.is_available() and dist.is_initialized()):
+      return train_dataset
+    if dist.get_world_size() == 1 and os.environ.get("RK_FORCE_DP") != "1":
+      return train_dataset
+    if self._fused_kind() != "ae":
+      raise NotImplementedError("data-parallel training is implemented for DynamicAutoencoder; "
+                                "MatrixFactorization user rows are rank-private (DESIGN.md section 6)")
+    from .parallel import DataParallel, shard_range
+    dp = DataParallel()
+    for p_ in self.model.parameters():          # identical replicas: rank 0's initial weights
+      dist.broadcast(p_.data, src=0)
+    dp.attach(self._engine())
+    self._dp = dp
+    n = len(train_dataset)
+    lo, hi = shard_range(n, dp.rank, dp.world)
+    shard = RecommendationDataset(train_dataset.interactions_matrix[lo:hi])
+    # every rank runs the same number of equally sized steps (collectives in lockstep)
+    self._dp_users_per_epoch = n // dp.world
+    return shard
+
   def _make_block(self, dcsr, S, negative_sampling):
     nnz_cap = max(1, _top_sum(dcsr.degrees, S))
-    return Block(S, nnz_cap, dcsr.n_items, self.device, negative_sampling=negative_sampling)
+    world = self._dp.world if getattr(self, "_dp", None) is not None else 1
+    # a data-parallel union item set can exceed one rank's nnz bound
+    return Block(S, nnz_cap, dcsr.n_items, self.device, negative_sampling=negative_sampling,
+                 n_cap=nnz_cap * world)
 
   def _step_generator(self, dataloader):
     """Yields (blk, row_off, B, keep_noise, keep_drop) for one pass over the
@@ -316,7 +346,9 @@ class Recoder(object):
         pf.blocks[0].negative_sampling != dataloader.negative_sampling:
       from .device import CollatePrefetcher
       ns = dataloader.negative_sampling
-      pf = CollatePrefetcher(lambda: self._make_block(dcsr, S, ns), dcsr, self.device)
+      dp = getattr(self, "_dp", None)
+      pf = CollatePrefetcher(lambda: self._make_block(dcsr, S, ns), dcsr, self.device,
+                             collate_fn=(dp.collate if dp is not None else None))
       self._train_pf = pf
     n = len(ds)
     order = None
@@ -324,6 +356,9 @@ class Recoder(object):
       order = self.user_order_hook(self.current_epoch, n)
     if order is None:
       order = epoch_user_order(n)
+    if getattr(self, "_dp", None) is not None:
+      order = order[:self._dp_users_per_epoch]      # equal step counts on every rank
+      n = len(order)
     order_dev = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int64)).to(self.device)
     offs = [o for o in range(0, n, S) if order_dev[o:o + S].numel() > 0]
     # the group after the current one is collated on the prefetcher's side stream
@@ -372,8 +407,10 @@ class Recoder(object):
 
       n_done = 0
       for batch_itr, (blk, row_off, rows, keep_noise, keep_drop) in iterator:
+        dp = getattr(self, "_dp", None)
         engine.train_step(blk, row_off, rows, keep_noise, keep_drop,
-                          out=loss_buf[n_done:n_done + 1])
+                          out=loss_buf[n_done:n_done + 1],
+                          global_rows=(rows * dp.world if dp is not None else None))
         n_done += 1
         self._global_step += 1
         if batch_itr % iters_per_epoch == 0:

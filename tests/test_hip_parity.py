@@ -519,3 +519,36 @@ def test_dataframe_to_csr_matrix_contract():
     assert m[umap[u], imap[it]] == 1.0
   m2, _, _ = dataframe_to_csr_matrix(df[:100], "user", "item", "inter", item_id_map=imap, user_id_map=umap)
   assert m2.shape == m.shape
+
+
+def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch):
+  """Recoder.train under an initialised torch.distributed group (RCCL, 1 rank):
+  two-phase collation + all-reduced gradients must reproduce the plain run."""
+  import torch.distributed as dist
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.model import Recoder
+  csr = synth_csr(1200, 2500, 25, seed=9)
+  c = STEP_CASES[0][1]
+
+  def run(dp):
+    torch.manual_seed(11)
+    model = make_model(c)
+    rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss="mse")
+    rec.user_order_hook = lambda epoch, n: np.arange(n, dtype=np.int64)
+    rec.train(RecommendationDataset(csr), batch_size=300, lr=1e-3, weight_decay=2e-5, num_epochs=2,
+              negative_sampling=True)
+    assert (rec._dp is not None) == dp
+    return np.concatenate(rec.loss_history), {k: v.detach().cpu().clone() for k, v in model.named_parameters()}
+
+  base_l, base_p = run(False)
+  monkeypatch.setenv("RK_FORCE_DP", "1")
+  monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+  monkeypatch.setenv("MASTER_PORT", "29577")
+  dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+  try:
+    dp_l, dp_p = run(True)
+  finally:
+    dist.destroy_process_group()
+  assert np.allclose(dp_l, base_l, rtol=1e-6, atol=0)
+  for k in base_p:
+    assert torch.allclose(dp_p[k], base_p[k], rtol=1e-5, atol=1e-7), k
