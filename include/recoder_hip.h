@@ -115,11 +115,13 @@ int rk_ae_encode_fwd(const rk_block_t *blk, int32_t row_off, int32_t B,
  * rk_ae_encode_bwd -- autograd of the above w.r.t. the gathered encoder rows
  * (model.py:397): G_en[c,:] (+)= sum_r svals[r,c] * dZ0pre[r,:]  (deterministic
  * ascending-row order via the transposed bitmap).  accumulate != 0 adds into
- * G_en (tied weights, nn.py:191-202).
+ * G_en (tied weights, nn.py:191-202).  gb_en (nullable): also the encoder-bias
+ * gradient gb_en[h] = colsum(dZ0pre), computed by a few extra workgroups of the
+ * same launch.
  */
 int rk_ae_encode_bwd(const rk_block_t *blk, int32_t row_off, int32_t B,
                      const float *dZ0pre, int32_t h, float *G_en,
-                     int32_t accumulate, void *stream);
+                     int32_t accumulate, float *gb_en, void *stream);
 
 /*
  * rk_decode_loss -- LinearEmbedding(output) (nn.py:271-280) fused with the
@@ -222,15 +224,20 @@ int rk_scatter_pos(int32_t *pos, const int64_t *rows, int32_t B, int32_t clear,
  * rk_ae_train_step -- one call = one optimisation step of Recoder._train's hot
  * loop (model.py:383-404) for DynamicAutoencoder(hidden_layers=[h]) without
  * bottleneck dropout: zero_grad / __compute_loss (model.py:454-485) / backward /
- * optimizer.step + sparse_optimizer.step, sequenced on two HIP streams (the dW
- * chain and the decoder-side Adam overlap the dZ chain).  It launches exactly
- * the entry points above; it exists so that the host pays one FFI call per
- * step instead of ~35.
+ * optimizer.step + sparse_optimizer.step as a chain of 8 launches on one HIP
+ * stream: encode_fwd, decode+loss, dW, dZ (split-K GEMM + reduce), encode_bwd
+ * (+ encoder-bias gradient), rk_adam_multi (all updates + the loss scalar).  It
+ * launches exactly the entry points of this header; it exists so that the host
+ * pays one FFI call per step instead of ~35.
  */
 enum { RK_PAR_W_EN = 0, RK_PAR_B_EN = 1, RK_PAR_W_DE = 2, RK_PAR_B_DE = 3, RK_PAR_COUNT = 4 };
 enum { RK_ENTRY_NONE = 0, RK_ENTRY_ENCODE_FWD = 1, RK_ENTRY_DECODE_LOSS = 2,
        RK_ENTRY_DECODE_BWD_DZ = 3, RK_ENTRY_DECODE_BWD_DW = 4, RK_ENTRY_ENCODE_BWD = 5,
-       RK_ENTRY_ADAM_TABLE = 6 };
+       RK_ENTRY_ADAM_MULTI = 6 };
+/* rk_ae_step_t.phase: which part of the step to enqueue (0 = all).  Data parallel
+ * callers run FWD_DW, all-reduce the decoder-side gradients, DZ_ENC, all-reduce the
+ * encoder side, then UPDATE. */
+enum { RK_STEP_FWD_DW = 1, RK_STEP_DZ_ENC = 2, RK_STEP_UPDATE = 4, RK_STEP_ALL = 7 };
 
 typedef struct rk_adam_param {
   float *p, *m, *v;          /* parameter and its Adam moments */
@@ -238,6 +245,33 @@ typedef struct rk_adam_param {
   int32_t step;              /* 1-based step of THIS update */
   int32_t sparse;            /* tables only: SparseAdam on the touched rows */
 } rk_adam_param_t;
+
+/*
+ * rk_adam_multi -- all parameter updates of one step (optimizer.step +
+ * sparse_optimizer.step, model.py:398-402) and, optionally, the loss scalar in
+ * ONE launch: up to RK_ADAM_MULTI_MAX jobs, each the exact arithmetic of
+ * rk_adam_table (pos != NULL), rk_adam_dense (pos == NULL) or rk_adam_rows
+ * (par.sparse: rows / n_dev / n_cap).  The gradient of a dense job may be the
+ * sum of g_parts arrays g + t * stride (t ascending; stride = *gstride_dev when
+ * given, else g_stride) -- the decoder-bias gradient is consumed straight from
+ * rk_decode_loss's per-row-tile partials this way.  loss_part != NULL: the last
+ * workgroup does what rk_loss_reduce does.
+ */
+#define RK_ADAM_MULTI_MAX 6
+typedef struct rk_adam_job {
+  rk_adam_param_t par;
+  int32_t n_rows, h;           /* table shape ([1, n] for a flat tensor) */
+  const int32_t *pos;          /* dense table job: row -> compact gradient row or -1 */
+  const int32_t *rows;         /* SparseAdam job: compact row -> table row */
+  const int32_t *n_dev;        /* SparseAdam job: device-resident live row count */
+  int32_t n_cap;               /* SparseAdam job: capacity of rows (launch size) */
+  int32_t g_parts, g_stride;
+  const int32_t *gstride_dev;
+  const float *g;
+} rk_adam_job_t;
+
+int rk_adam_multi(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part,
+                  int32_t n_part, float denom, float *loss_out, void *stream);
 
 typedef struct rk_ae_step {
   const rk_block_t *blk;
@@ -249,15 +283,14 @@ typedef struct rk_ae_step {
   rk_adam_param_t par[RK_PAR_COUNT];
   /* workspaces (sizes as FusedEngine.ensure_capacity allocates them) */
   float *Z0, *dZ0, *dO, *G_de, *G_en, *gb_de, *gb_part, *gb_en, *ws, *loss_part, *loss_out;
-  void *stream_main, *stream_aux;                  /* hipStream_t */
-  void *ev_loss, *ev_dz, *ev_dw, *ev_aux_done;     /* hipEvent_t (rk_event_create) */
+  void *stream;              /* hipStream_t: every kernel of the step goes here, in order */
   int32_t time_entry;        /* RK_ENTRY_*: bracket that entry with the two events below */
-  int32_t phase;             /* 0 = whole step; 1 = forward + backward only; 2 = Adam updates
-                                only (data parallel: all-reduce the gradients in between) */
-  void *time_ev0, *time_ev1;
+  int32_t phase;             /* mask of RK_STEP_* (0 = RK_STEP_ALL) */
+  void *time_ev0, *time_ev1; /* rk_timing_event_create */
 } rk_ae_step_t;
 
-void *rk_event_create(void);
+void *rk_event_create(void);          /* ordering-only (no timing, device-scope fence) */
+void *rk_timing_event_create(void);   /* for time_ev0 / time_ev1 and rk_event_elapsed_ms */
 void rk_event_destroy(void *event);
 float rk_event_elapsed_ms(void *ev0, void *ev1);   /* synchronises on ev1 */
 int rk_ae_train_step(const rk_ae_step_t *step);

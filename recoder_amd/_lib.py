@@ -45,7 +45,7 @@ class RkAdamParam(Structure):
 
 PAR_W_EN, PAR_B_EN, PAR_W_DE, PAR_B_DE = 0, 1, 2, 3
 ENTRY = {"rk_ae_encode_fwd": 1, "rk_decode_loss": 2, "rk_decode_bwd_dz": 3, "rk_decode_bwd_dw": 4,
-         "rk_ae_encode_bwd": 5, "rk_adam_table": 6}
+         "rk_ae_encode_bwd": 5, "rk_adam_multi": 6}
 
 
 class RkAeStep(Structure):
@@ -61,11 +61,24 @@ class RkAeStep(Structure):
     ("Z0", c_void_p), ("dZ0", c_void_p), ("dO", c_void_p), ("G_de", c_void_p), ("G_en", c_void_p),
     ("gb_de", c_void_p), ("gb_part", c_void_p), ("gb_en", c_void_p), ("ws", c_void_p),
     ("loss_part", c_void_p), ("loss_out", c_void_p),
-    ("stream_main", c_void_p), ("stream_aux", c_void_p),
-    ("ev_loss", c_void_p), ("ev_dz", c_void_p), ("ev_dw", c_void_p), ("ev_aux_done", c_void_p),
+    ("stream", c_void_p),
     ("time_entry", c_int32), ("phase", c_int32),
     ("time_ev0", c_void_p), ("time_ev1", c_void_p),
   ]
+
+
+class RkAdamJob(Structure):
+  """mirror of rk_adam_job_t"""
+  _fields_ = [
+    ("par", RkAdamParam),
+    ("n_rows", c_int32), ("h", c_int32),
+    ("pos", c_void_p), ("rows", c_void_p), ("n_dev", c_void_p),
+    ("n_cap", c_int32), ("g_parts", c_int32), ("g_stride", c_int32),
+    ("gstride_dev", c_void_p), ("g", c_void_p),
+  ]
+
+
+STEP_FWD_DW, STEP_DZ_ENC, STEP_UPDATE, STEP_ALL = 1, 2, 4, 7
 
 
 _P = c_void_p
@@ -79,7 +92,7 @@ SIGNATURES = {
   "rk_collate": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _BLK, _P]),
   "rk_ae_encode_fwd": (c_int32, [_BLK, c_int32, c_int32, _P, _P, c_int32, _P, c_float, c_uint64,
                                  c_uint64, _P, c_int32, _P, _P]),
-  "rk_ae_encode_bwd": (c_int32, [_BLK, c_int32, c_int32, _P, c_int32, _P, c_int32, _P]),
+  "rk_ae_encode_bwd": (c_int32, [_BLK, c_int32, c_int32, _P, c_int32, _P, c_int32, _P, _P]),
   "rk_loss_partials": (c_int32, [c_int32, c_int32]),
   "rk_decode_row_tile": (c_int32, []),
   "rk_decode_loss": (c_int32, [_P, c_int32, c_int32, _BLK, c_int32, _P, _P, c_int32, c_float,
@@ -101,8 +114,10 @@ SIGNATURES = {
                              c_double, c_double, c_int32, _P]),
   "rk_adam_dense": (c_int32, [_P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double,
                               c_double, c_int32, _P]),
+  "rk_adam_multi": (c_int32, [POINTER(RkAdamJob), c_int32, _P, c_int32, c_float, _P, _P]),
   "rk_scatter_pos": (c_int32, [_P, _P, c_int32, c_int32, _P]),
   "rk_event_create": (c_void_p, []),
+  "rk_timing_event_create": (c_void_p, []),
   "rk_event_destroy": (None, [c_void_p]),
   "rk_event_elapsed_ms": (c_float, [c_void_p, c_void_p]),
   "rk_ae_train_step": (c_int32, [POINTER(RkAeStep)]),

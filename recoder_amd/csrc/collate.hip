@@ -279,25 +279,25 @@ extern "C" int rk_collate(const int64_t *ds_indptr, const int32_t *ds_indices,
       if (nzero < 1) nzero = 1;
       if (nzero > 512) nzero = 512;
     }
-    hipLaunchKernelGGL(collate_phase1_kernel, dim3(nrow_blk + 1 + nzero), dim3(256), 0, stream,
+    RK_LAUNCH(collate_phase1_kernel, dim3(nrow_blk + 1 + nzero), dim3(256), 0, stream,
                        ds_indptr, ds_indices, users, S, stamp, all, nrow_blk, *blk);
     RK_CHECK_LAUNCH("collate_phase1");
   }
   if (phase == 1) return 0;
   if (blk->n_items <= SMALL_SCAN_MAX) {
-    hipLaunchKernelGGL(collate_scan_small_kernel, dim3(1), dim3(1024), 0, stream, blk->mark,
+    RK_LAUNCH(collate_scan_small_kernel, dim3(1), dim3(1024), 0, stream, blk->mark,
                        blk->n_items, stamp, all, blk->pos, blk->items, blk->counts);
     RK_CHECK_LAUNCH("collate_scan_small");
   } else {
-    hipLaunchKernelGGL(collate_count_kernel, dim3(blk->n_chunks), dim3(256), 0, stream,
+    RK_LAUNCH(collate_count_kernel, dim3(blk->n_chunks), dim3(256), 0, stream,
                        blk->mark, blk->n_items, stamp, all, blk->scan_tmp);
     RK_CHECK_LAUNCH("collate_count");
-    hipLaunchKernelGGL(collate_assign_kernel, dim3(blk->n_chunks), dim3(256), 0, stream,
+    RK_LAUNCH(collate_assign_kernel, dim3(blk->n_chunks), dim3(256), 0, stream,
                        blk->mark, blk->n_items, stamp, all, blk->scan_tmp, blk->n_chunks,
                        blk->pos, blk->items, blk->counts);
     RK_CHECK_LAUNCH("collate_assign");
   }
-  hipLaunchKernelGGL(collate_build_kernel, dim3(rk_cdiv(S, 4)), dim3(256), 0, stream,
+  RK_LAUNCH(collate_build_kernel, dim3(rk_cdiv(S, 4)), dim3(256), 0, stream,
                      ds_indptr, ds_indices, ds_data, users, S, *blk);
   RK_CHECK_LAUNCH("collate_build");
   return 0;

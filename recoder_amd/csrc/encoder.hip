@@ -126,15 +126,34 @@ __global__ __launch_bounds__(256) void ae_encode_fwd_kernel(
 template <int HV>
 __global__ __launch_bounds__(256) void ae_encode_bwd_kernel(
     rk_block_t b, int row_off, int B, const float *__restrict__ dZ, int h,
-    float *__restrict__ G, int accumulate) {
+    float *__restrict__ G, int accumulate, float *__restrict__ gb, int n_gb) {
   // one workgroup per sampled item column; its 4 waves take the 64-row groups
   // round-robin (popular items hold hundreds of entries -- a single wave per
   // column serialised them into the kernel's tail) and combine in fixed order
   __shared__ __attribute__((aligned(16))) float part[3][HV * 256];
-  const int n_b = b.counts[0];
-  const int c = blockIdx.x;
-  if (c >= n_b) return;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if ((int)blockIdx.x < n_gb) {
+    // encoder-bias gradient: gb[j] = sum_r dZ[r, j] for 64 columns; the 4 waves take
+    // interleaved quarters of the rows, combined in fixed order
+    const int j = blockIdx.x * 64 + lane;
+    float a0 = 0.f, a1 = 0.f;
+    if (j < h) {
+      int r = wid;
+      for (; r + 4 < B; r += 8) {
+        a0 += dZ[(int64_t)r * h + j];
+        a1 += dZ[(int64_t)(r + 4) * h + j];
+      }
+      if (r < B) a0 += dZ[(int64_t)r * h + j];
+    }
+    part[0][wid * 64 + lane] = a0 + a1;
+    __syncthreads();
+    if (wid == 0 && j < h)
+      gb[j] = (part[0][lane] + part[0][64 + lane]) + (part[0][128 + lane] + part[0][192 + lane]);
+    return;
+  }
+  const int n_b = b.counts[0];
+  const int c = (int)blockIdx.x - n_gb;
+  if (c >= n_b) return;
   const uint32_t *colbits = b.bits_cr + (int64_t)c * b.ldw_cr;
   float4 acc[HV];
 #pragma unroll
@@ -224,7 +243,7 @@ extern "C" int rk_ae_encode_fwd(const rk_block_t *blk, int32_t row_off, int32_t 
   const float scale = 1.0f / (float)(1.0 - (double)p);
   const int hv = rk_cdiv(h, 256);
 #define LAUNCH(HV)                                                                         \
-  hipLaunchKernelGGL(ae_encode_fwd_kernel<HV>, dim3(B), dim3(256), 0, stream, *blk, row_off, \
+  RK_LAUNCH(ae_encode_fwd_kernel<HV>, dim3(B), dim3(256), 0, stream, *blk, row_off, \
                      B, W_en, b_en, h, keep, p, scale, seed, rng_step, users, act, Z0)
   if (hv == 1) LAUNCH(1); else if (hv == 2) LAUNCH(2); else LAUNCH(4);
 #undef LAUNCH
@@ -234,17 +253,18 @@ extern "C" int rk_ae_encode_fwd(const rk_block_t *blk, int32_t row_off, int32_t 
 
 extern "C" int rk_ae_encode_bwd(const rk_block_t *blk, int32_t row_off, int32_t B,
                                 const float *dZ0pre, int32_t h, float *G_en,
-                                int32_t accumulate, void *stream_) {
+                                int32_t accumulate, float *gb_en, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(h > 0 && h % 4 == 0 && h <= 1024, "h must be a multiple of 4, <= 1024");
   RK_REQUIRE(row_off >= 0 && B >= 0 && row_off + B <= blk->S_cap, "row slice out of range");
   RK_REQUIRE(blk->bits_cr != nullptr && blk->pref_rc != nullptr,
              "block was built without the transposed bitmap / prefix index");
-  const int grid = blk->n_cap;
+  const int n_gb = gb_en ? rk_cdiv(h, 64) : 0;
+  const int grid = blk->n_cap + n_gb;
   const int hv = rk_cdiv(h, 256);
 #define LAUNCH(HV)                                                                           \
-  hipLaunchKernelGGL(ae_encode_bwd_kernel<HV>, dim3(grid), dim3(256), 0, stream, *blk, row_off, \
-                     B, dZ0pre, h, G_en, accumulate)
+  RK_LAUNCH(ae_encode_bwd_kernel<HV>, dim3(grid), dim3(256), 0, stream, *blk, row_off, \
+                     B, dZ0pre, h, G_en, accumulate, gb_en, n_gb)
   if (hv == 1) LAUNCH(1); else if (hv == 2) LAUNCH(2); else LAUNCH(4);
 #undef LAUNCH
   RK_CHECK_LAUNCH("ae_encode_bwd");

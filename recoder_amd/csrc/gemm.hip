@@ -699,25 +699,25 @@ extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_blo
     static const int cfg = getenv("RK_DEC_CFG") ? atoi(getenv("RK_DEC_CFG")) : 0;   // tuning switch
     if (loss_kind == RK_LOSS_MSE && cfg == 1) {
       const int t64 = rk_cdiv(p.tiles_m * rk_cdiv(tgt->n_cap, 64), 8) * 8;
-      hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 1, 0, 0, EPI_LOSS_MSE, true, 32>), dim3(t64, 1),
+      RK_LAUNCH((gemm_kernel<2, 2, 1, 1, 0, 0, EPI_LOSS_MSE, true, 32>), dim3(t64, 1),
                          dim3(256), 0, stream, p);
     } else if (loss_kind == RK_LOSS_MSE && cfg == 2) {
-      hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 2, 0, 0, EPI_LOSS_MSE, true, 16>), dim3(tiles, 1),
+      RK_LAUNCH((gemm_kernel<2, 2, 1, 2, 0, 0, EPI_LOSS_MSE, true, 16>), dim3(tiles, 1),
                          dim3(256), 0, stream, p);
     } else if (loss_kind == RK_LOSS_MSE && cfg == 3) {
       const int t64 = rk_cdiv(p.tiles_m * rk_cdiv(tgt->n_cap, 64), 8) * 8;
-      hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 1, 0, 0, EPI_LOSS_MSE, true, 16>), dim3(t64, 1),
+      RK_LAUNCH((gemm_kernel<2, 2, 1, 1, 0, 0, EPI_LOSS_MSE, true, 16>), dim3(t64, 1),
                          dim3(256), 0, stream, p);
     } else if (loss_kind == RK_LOSS_MSE)
-      hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 2, 0, 0, EPI_LOSS_MSE, true, 32>), dim3(tiles, 1),
+      RK_LAUNCH((gemm_kernel<2, 2, 1, 2, 0, 0, EPI_LOSS_MSE, true, 32>), dim3(tiles, 1),
                          dim3(256), 0, stream, p);
     else
-      hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 2, 0, 0, EPI_LOSS_BCE, true, 32>), dim3(tiles, 1),
+      RK_LAUNCH((gemm_kernel<2, 2, 1, 2, 0, 0, EPI_LOSS_BCE, true, 32>), dim3(tiles, 1),
                          dim3(256), 0, stream, p);
   } else {
     if (loss_kind == RK_LOSS_MNLL) { p.ldc = 0; p.ld_dev = tgt->counts + 2; }
     else { RK_REQUIRE(ld_out > 0, "ld_out"); p.ldc = ld_out; }
-    hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 2, 0, 0, EPI_STORE, true, 32>), dim3(tiles, 1), dim3(256),
+    RK_LAUNCH((gemm_kernel<2, 2, 1, 2, 0, 0, EPI_STORE, true, 32>), dim3(tiles, 1), dim3(256),
                        0, stream, p);
   }
   RK_CHECK_LAUNCH("decode_loss");
@@ -729,7 +729,7 @@ extern "C" int rk_mnll_finish(float *dO, int32_t B, const rk_block_t *tgt, int32
   hipStream_t stream = (hipStream_t)stream_;
   if (B == 0) return 0;
   RK_REQUIRE(tgt->implicit || tgt->pref_rc != nullptr, "explicit values need pref_rc");
-  hipLaunchKernelGGL(mnll_finish_kernel, dim3(B), dim3(256), 0, stream, dO, *tgt, row_off, inv_B,
+  RK_LAUNCH(mnll_finish_kernel, dim3(B), dim3(256), 0, stream, dO, *tgt, row_off, inv_B,
                      loss_part);
   RK_CHECK_LAUNCH("mnll_finish");
   return 0;
@@ -738,7 +738,7 @@ extern "C" int rk_mnll_finish(float *dO, int32_t B, const rk_block_t *tgt, int32
 extern "C" int rk_loss_reduce(float *loss_part, int32_t n, float denom, float *loss,
                               void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(64), 0, stream, loss_part, n, denom, loss);
+  RK_LAUNCH(loss_reduce_kernel, dim3(1), dim3(64), 0, stream, loss_part, n, denom, loss);
   RK_CHECK_LAUNCH("loss_reduce");
   return 0;
 }
@@ -765,14 +765,14 @@ extern "C" int rk_decode_bwd_dz(const float *dO, int32_t B, int32_t h, const rk_
   p.tiles_m = rk_cdiv(B, 128);
   const int tiles = p.tiles_m * rk_cdiv(h, 32 * tn);   // x 64 splits: a multiple of 8
 #define LAUNCH(TN)                                                                              \
-  hipLaunchKernelGGL((gemm_kernel<4, 1, 1, TN, 0, 1, EPI_SPLITK, true>), dim3(tiles, splits),   \
+  RK_LAUNCH((gemm_kernel<4, 1, 1, TN, 0, 1, EPI_SPLITK, true>), dim3(tiles, splits),   \
                      dim3(256), 0, stream, p)
   if (tn == 2) LAUNCH(2); else if (tn == 4) LAUNCH(4); else if (tn == 7) LAUNCH(7); else LAUNCH(8);
 #undef LAUNCH
   RK_CHECK_LAUNCH("decode_bwd_dz");
   int grid = rk_cdiv((int64_t)B * h / 4, 64);
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(64), 0, stream, workspace, B, h,
+  RK_LAUNCH_ORDERED(splitk_reduce_kernel, dim3(grid), dim3(64), 0, stream, workspace, B, h,
                      tgt->counts, kchunk, splits, Zact, act, dZ);
   RK_CHECK_LAUNCH("splitk_reduce");
   return 0;
@@ -797,7 +797,7 @@ extern "C" int rk_decode_bwd_dw(const float *dO, const float *Z, int32_t B, int3
     // 32 x 128 tiles, BK = 32 (two workgroups per CU at h = 200)
     p.n_fastest = 1;   // the h/128 column tiles of one dO panel stay on one XCD
     const int tiles = rk_cdiv(p.tiles_m * rk_cdiv(h, 128), 8) * 8;
-    hipLaunchKernelGGL((gemm_kernel<1, 4, 1, 1, 1, 1, EPI_STORE, true, 32>), dim3(tiles, 1),
+    RK_LAUNCH((gemm_kernel<1, 4, 1, 1, 1, 1, EPI_STORE, true, 32>), dim3(tiles, 1),
                        dim3(256), 0, stream, p);
   }
   RK_CHECK_LAUNCH("decode_bwd_dw");
@@ -809,10 +809,10 @@ namespace {
 template <int AMODE, int BMODE>
 void launch_small(const GemmP &p, int tiles, bool vec, hipStream_t stream) {
   if (vec)
-    hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 1, AMODE, BMODE, EPI_STORE, true>), dim3(tiles, 1),
+    RK_LAUNCH((gemm_kernel<2, 2, 1, 1, AMODE, BMODE, EPI_STORE, true>), dim3(tiles, 1),
                        dim3(256), 0, stream, p);
   else
-    hipLaunchKernelGGL((gemm_kernel<2, 2, 1, 1, AMODE, BMODE, EPI_STORE, false>), dim3(tiles, 1),
+    RK_LAUNCH((gemm_kernel<2, 2, 1, 1, AMODE, BMODE, EPI_STORE, false>), dim3(tiles, 1),
                        dim3(256), 0, stream, p);
 }
 }  // namespace

@@ -171,6 +171,137 @@ __global__ __launch_bounds__(256) void scatter_pos_kernel(int32_t *pos, const in
   if (i < B) pos[rows[i]] = clear ? -1 : i;
 }
 
+// ---------------------------------------------------------------------------
+// rk_adam_multi: every Adam / SparseAdam update of one optimisation step (and the
+// loss scalar) in ONE launch.  The step is a serial chain of kernels on one
+// stream, so each separate small launch (bias tables, column sums, the loss
+// reduction: 4-10 us apiece) was pure critical path.  Workgroup ranges select the
+// job; within a job the arithmetic is exactly adam1 / sadam1 above.
+// ---------------------------------------------------------------------------
+struct UJob {
+  float *p, *m, *v;
+  const float *g;
+  const int32_t *pos;          // dense table: row -> compact gradient row or -1
+  const int32_t *rows;         // SparseAdam: compact row -> table row
+  const int32_t *n_dev;        // SparseAdam: live compact rows
+  const int32_t *gstride_dev;  // device-resident stride between gradient parts (or null)
+  int n_rows, h, g_parts, g_stride, sparse, blk0, nblk;
+  AdamC c;
+};
+
+struct UArgs {
+  UJob job[RK_ADAM_MULTI_MAX];
+  int n_jobs;
+  float *loss_part;
+  int n_part;
+  float denom;
+  float *loss_out;
+};
+
+template <typename T> struct VecOps;
+template <> struct VecOps<float4> {
+  static constexpr int W = 4;
+  static __device__ __forceinline__ float4 zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  static __device__ __forceinline__ void add(float4 &a, const float4 &b) {
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  static __device__ __forceinline__ void adam(float4 &p, float4 &m, float4 &v, const float4 &g,
+                                              const AdamC &c) {
+    adam1(p.x, m.x, v.x, g.x, c); adam1(p.y, m.y, v.y, g.y, c);
+    adam1(p.z, m.z, v.z, g.z, c); adam1(p.w, m.w, v.w, g.w, c);
+  }
+  static __device__ __forceinline__ void sadam(float4 &p, float4 &m, float4 &v, const float4 &g,
+                                               const AdamC &c) {
+    sadam1(p.x, m.x, v.x, g.x, c); sadam1(p.y, m.y, v.y, g.y, c);
+    sadam1(p.z, m.z, v.z, g.z, c); sadam1(p.w, m.w, v.w, g.w, c);
+  }
+};
+template <> struct VecOps<float> {
+  static constexpr int W = 1;
+  static __device__ __forceinline__ float zero() { return 0.f; }
+  static __device__ __forceinline__ void add(float &a, const float &b) { a += b; }
+  static __device__ __forceinline__ void adam(float &p, float &m, float &v, const float &g,
+                                              const AdamC &c) { adam1(p, m, v, g, c); }
+  static __device__ __forceinline__ void sadam(float &p, float &m, float &v, const float &g,
+                                               const AdamC &c) { sadam1(p, m, v, g, c); }
+};
+
+template <typename T>
+__device__ __forceinline__ void update_job(const UJob &J, int lb) {
+  using V = VecOps<T>;
+  const int hq = J.h / V::W;
+  const int64_t stride = J.gstride_dev ? (int64_t)*J.gstride_dev : (int64_t)J.g_stride;
+  T *P = reinterpret_cast<T *>(J.p), *M = reinterpret_cast<T *>(J.m), *Vv = reinterpret_cast<T *>(J.v);
+  const int64_t step = (int64_t)J.nblk * 256;
+  if (J.sparse) {
+    const int n = *J.n_dev;
+    const int64_t tot = (int64_t)n * hq;
+    for (int64_t i = (int64_t)lb * 256 + threadIdx.x; i < tot; i += step) {
+      const int r = (int)(i / hq), q = (int)(i % hq);
+      const int64_t o = (int64_t)J.rows[r] * hq + q;
+      const T g = *reinterpret_cast<const T *>(J.g + i * V::W);
+      T p1 = P[o], m1 = M[o], v1 = Vv[o];
+      V::sadam(p1, m1, v1, g, J.c);
+      P[o] = p1; M[o] = m1; Vv[o] = v1;
+    }
+    return;
+  }
+  const int64_t tot = (int64_t)J.n_rows * hq;
+  for (int64_t i = (int64_t)lb * 256 + threadIdx.x; i < tot; i += step) {
+    int64_t go = i * V::W;
+    bool have = true;
+    if (J.pos) {
+      const int row = (int)(i / hq), q = (int)(i % hq);
+      const int pr = J.pos[row];
+      have = pr >= 0;
+      go = (int64_t)pr * J.h + q * V::W;
+    }
+    T g = V::zero();
+    if (have) {
+      g = *reinterpret_cast<const T *>(J.g + go);
+      for (int t = 1; t < J.g_parts; ++t)            // partial gradients, fixed order
+        V::add(g, *reinterpret_cast<const T *>(J.g + t * stride + go));
+    }
+    T p1 = P[i], m1 = M[i], v1 = Vv[i];
+    V::adam(p1, m1, v1, g, J.c);
+    P[i] = p1; M[i] = m1; Vv[i] = v1;
+  }
+}
+
+__device__ __forceinline__ void run_job(const UJob &J, int b) {
+  if ((J.h & 3) == 0) update_job<float4>(J, b - J.blk0);
+  else update_job<float>(J, b - J.blk0);
+}
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(UArgs a) {
+  const int b = blockIdx.x;
+  if (a.loss_part && b == (int)gridDim.x - 1) {
+    // loss = sum(partials) / denom in double, fixed order; the partials are re-zeroed
+    // for the next rk_decode_loss
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < a.n_part; i += 256) {
+      s += (double)a.loss_part[i];
+      a.loss_part[i] = 0.f;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+      if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) a.loss_out[0] = (float)red[0] / a.denom;
+    return;
+  }
+  // static indices only (a dynamically indexed by-value struct would go to scratch)
+  if (a.n_jobs > 5 && b >= a.job[5].blk0) run_job(a.job[5], b);
+  else if (a.n_jobs > 4 && b >= a.job[4].blk0) run_job(a.job[4], b);
+  else if (a.n_jobs > 3 && b >= a.job[3].blk0) run_job(a.job[3], b);
+  else if (a.n_jobs > 2 && b >= a.job[2].blk0) run_job(a.job[2], b);
+  else if (a.n_jobs > 1 && b >= a.job[1].blk0) run_job(a.job[1], b);
+  else run_job(a.job[0], b);
+}
+
 AdamC make_consts(double lr, double b1, double b2, double eps, double wd, int step) {
   AdamC c;
   c.one_m_b1 = (float)(1.0 - b1);
@@ -204,10 +335,10 @@ extern "C" int rk_adam_table(float *W, float *m, float *v, int32_t n_rows, int32
   if (n_rows == 0) return 0;
   const AdamC c = make_consts(lr, beta1, beta2, eps, weight_decay, step);
   if (h % 4 == 0 && (((uintptr_t)W | (uintptr_t)m | (uintptr_t)v | (uintptr_t)G) & 15) == 0) {
-    hipLaunchKernelGGL(adam_table_kernel, dim3(grid_for((int64_t)n_rows * h / 4)), dim3(256), 0,
+    RK_LAUNCH(adam_table_kernel, dim3(grid_for((int64_t)n_rows * h / 4)), dim3(256), 0,
                        stream, W, m, v, n_rows, h, pos, G, c);
   } else {
-    hipLaunchKernelGGL(adam_table_scalar_kernel, dim3(grid_for((int64_t)n_rows * h)), dim3(256), 0,
+    RK_LAUNCH(adam_table_scalar_kernel, dim3(grid_for((int64_t)n_rows * h)), dim3(256), 0,
                        stream, W, m, v, n_rows, h, pos, G, c);
   }
   RK_CHECK_LAUNCH("adam_table");
@@ -223,7 +354,7 @@ extern "C" int rk_adam_rows(float *W, float *m, float *v, int32_t h, const int32
   RK_REQUIRE((idx32 != nullptr) != (idx64 != nullptr), "exactly one index array");
   if (n_cap == 0) return 0;
   const AdamC c = make_consts(lr, beta1, beta2, eps, 0.0, step);
-  hipLaunchKernelGGL(adam_rows_kernel, dim3(grid_for((int64_t)n_cap * h)), dim3(256), 0, stream, W,
+  RK_LAUNCH(adam_rows_kernel, dim3(grid_for((int64_t)n_cap * h)), dim3(256), 0, stream, W,
                      m, v, h, idx32, idx64, n_dev, n_cap, G, c);
   RK_CHECK_LAUNCH("adam_rows");
   return 0;
@@ -237,9 +368,55 @@ extern "C" int rk_adam_dense(float *p, float *m, float *v, const float *g, int64
   RK_REQUIRE(n < (int64_t)1 << 31, "tensor too large for one call");
   if (n == 0) return 0;
   const AdamC c = make_consts(lr, beta1, beta2, eps, weight_decay, step);
-  hipLaunchKernelGGL(adam_table_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, m, v,
+  RK_LAUNCH(adam_table_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, m, v,
                      (int)n, 1, (const int32_t *)nullptr, g, c);
   RK_CHECK_LAUNCH("adam_dense");
+  return 0;
+}
+
+extern "C" int rk_adam_multi(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part,
+                             int32_t n_part, float denom, float *loss_out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(n_jobs >= 0 && n_jobs <= RK_ADAM_MULTI_MAX, "too many jobs for one launch");
+  RK_REQUIRE(n_jobs == 0 || jobs != nullptr, "null jobs");
+  RK_REQUIRE((loss_part == nullptr) == (loss_out == nullptr), "loss_part and loss_out go together");
+  UArgs a = {};
+  int blocks = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    const rk_adam_job_t &s = jobs[j];
+    UJob &d = a.job[a.n_jobs];
+    RK_REQUIRE(s.par.step >= 1, "step must be >= 1");
+    RK_REQUIRE(s.h >= 1 && s.n_rows >= 0, "bad job shape");
+    RK_REQUIRE(!(s.par.sparse && (s.rows == nullptr || s.n_dev == nullptr)),
+               "SparseAdam job needs rows and n_dev");
+    RK_REQUIRE(s.g_parts >= 1, "g_parts must be >= 1");
+    const bool vec = s.h % 4 == 0;
+    RK_REQUIRE(!vec || ((((uintptr_t)s.par.p | (uintptr_t)s.par.m | (uintptr_t)s.par.v |
+                          (uintptr_t)s.g) & 15) == 0 && (s.g_parts == 1 || s.gstride_dev == nullptr) &&
+                        s.g_stride % 4 == 0),
+               "vector jobs need 16-byte aligned operands / strides");
+    const int64_t rows = s.par.sparse ? s.n_cap : s.n_rows;
+    if (rows == 0) continue;
+    d.p = s.par.p; d.m = s.par.m; d.v = s.par.v; d.g = s.g;
+    d.pos = s.par.sparse ? nullptr : s.pos;
+    d.rows = s.rows; d.n_dev = s.n_dev; d.gstride_dev = s.gstride_dev;
+    d.n_rows = s.n_rows; d.h = s.h; d.g_parts = s.g_parts; d.g_stride = s.g_stride;
+    d.sparse = s.par.sparse ? 1 : 0;
+    d.c = make_consts(s.par.lr, s.par.beta1, s.par.beta2, s.par.eps,
+                      s.par.sparse ? 0.0 : s.par.weight_decay, s.par.step);
+    d.blk0 = blocks;
+    d.nblk = grid_for(rows * s.h / (vec ? 4 : 1));
+    blocks += d.nblk;
+    ++a.n_jobs;
+  }
+  if (loss_part) {
+    a.loss_part = loss_part; a.n_part = n_part; a.denom = denom; a.loss_out = loss_out;
+    blocks += 1;
+  }
+  if (blocks == 0) return 0;
+  if (a.n_jobs == 0) { a.n_jobs = 1; a.job[0].nblk = 0; a.job[0].h = 1; }   // loss only
+  RK_LAUNCH(adam_multi_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  RK_CHECK_LAUNCH("adam_multi");
   return 0;
 }
 
@@ -247,7 +424,7 @@ extern "C" int rk_scatter_pos(int32_t *pos, const int64_t *rows, int32_t B, int3
                               void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B == 0) return 0;
-  hipLaunchKernelGGL(scatter_pos_kernel, dim3(rk_cdiv(B, 256)), dim3(256), 0, stream, pos, rows, B,
+  RK_LAUNCH(scatter_pos_kernel, dim3(rk_cdiv(B, 256)), dim3(256), 0, stream, pos, rows, B,
                      clear);
   RK_CHECK_LAUNCH("scatter_pos");
   return 0;
@@ -256,7 +433,7 @@ extern "C" int rk_scatter_pos(int32_t *pos, const int64_t *rows, int32_t B, int3
 extern "C" int rk_act_grad(float *dY, const float *Y, int64_t n, int32_t act, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (n == 0 || act == RK_ACT_NONE) return 0;
-  hipLaunchKernelGGL(act_grad_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dY, Y, n, act);
+  RK_LAUNCH(act_grad_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dY, Y, n, act);
   RK_CHECK_LAUNCH("act_grad");
   return 0;
 }
@@ -267,7 +444,7 @@ extern "C" int rk_dropout(float *X, const uint8_t *keep, int64_t n, int32_t ncol
   RK_REQUIRE(p >= 0.f && p < 1.f, "dropout prob must be in [0,1)");
   if (n == 0 || p == 0.f) return 0;
   const float scale = 1.0f / (float)(1.0 - (double)p);
-  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, stream, X, keep, n, ncols, p,
+  RK_LAUNCH(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, stream, X, keep, n, ncols, p,
                      scale, seed, rng_step);
   RK_CHECK_LAUNCH("dropout");
   return 0;
@@ -277,7 +454,7 @@ extern "C" int rk_colsum(const float *X, int32_t rows, int32_t cols, int32_t ld,
                          const int32_t *counts_dev, float *out, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (cols == 0) return 0;
-  hipLaunchKernelGGL(colsum_kernel, dim3(rk_cdiv(cols, 64)), dim3(1024), 0, stream, X, rows, cols, ld,
+  RK_LAUNCH(colsum_kernel, dim3(rk_cdiv(cols, 64)), dim3(1024), 0, stream, X, rows, cols, ld,
                      counts_dev, out);
   RK_CHECK_LAUNCH("colsum");
   return 0;
@@ -287,7 +464,7 @@ extern "C" int rk_gather_rows(const float *E, const int64_t *rows, int32_t B, in
                               int32_t act, float *out, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B == 0) return 0;
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((int64_t)B * d)), dim3(256), 0, stream, E,
+  RK_LAUNCH(gather_rows_kernel, dim3(grid_for((int64_t)B * d)), dim3(256), 0, stream, E,
                      rows, B, d, act, out);
   RK_CHECK_LAUNCH("gather_rows");
   return 0;

@@ -8,6 +8,17 @@
 #include "common.h"
 
 extern "C" void *rk_event_create(void) {
+  // ordering-only events between streams of ONE device: no timing, and no
+  // system-scope fence (host / peer visibility is not needed for them)
+  hipEvent_t e = nullptr;
+  if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
+    rk_set_error("hipEventCreate failed");
+    return nullptr;
+  }
+  return (void *)e;
+}
+
+extern "C" void *rk_timing_event_create(void) {
   hipEvent_t e = nullptr;
   if (hipEventCreate(&e) != hipSuccess) {
     rk_set_error("hipEventCreate failed");
@@ -43,18 +54,20 @@ struct Timer {
   }
 };
 
-int adam_param(const rk_ae_step_t *a, int k, int n_rows, int h, const int32_t *pos,
-               const int32_t *items, const int32_t *counts, int n_cap, const float *G, bool table,
-               void *stream) {
-  const rk_adam_param_t &p = a->par[k];
-  if (table && p.sparse)
-    return rk_adam_rows(p.p, p.m, p.v, h, items, nullptr, counts, n_cap, G, p.lr, p.beta1, p.beta2,
-                        p.eps, p.step, stream);
-  if (table)
-    return rk_adam_table(p.p, p.m, p.v, n_rows, h, pos, G, p.lr, p.beta1, p.beta2, p.eps,
-                         p.weight_decay, p.step, stream);
-  return rk_adam_dense(p.p, p.m, p.v, G, (int64_t)n_rows * h, p.lr, p.beta1, p.beta2, p.eps,
-                       p.weight_decay, p.step, stream);
+// one rk_adam_multi job for a [n_rows, h] table (dense Adam through pos, or SparseAdam
+// on the block's item rows) or a flat tensor (pos == items == null)
+rk_adam_job_t table_job(const rk_adam_param_t &par, const rk_block_t *blk, int n_rows, int h,
+                        const float *G, bool table) {
+  rk_adam_job_t j = {};
+  j.par = par;
+  j.n_rows = n_rows; j.h = h; j.g = G; j.g_parts = 1;
+  if (table && par.sparse) {
+    j.rows = blk->items; j.n_dev = blk->counts; j.n_cap = blk->n_cap;
+  } else {
+    j.par.sparse = 0;
+    if (table) j.pos = blk->pos;
+  }
+  return j;
 }
 
 }  // namespace
@@ -65,83 +78,72 @@ int adam_param(const rk_ae_step_t *a, int k, int n_rows, int h, const int32_t *p
     if (rc__ != 0) return rc__; \
   } while (0)
 
+// The whole step is a serial chain on ONE stream:
+//   encode_fwd ; decode+loss ; dW ; dZ split-K ; reduce ; encode_bwd (+gb_en) ; update
+// (an earlier version ran the dW chain on a second stream: each cross-stream event
+// costs 10-20 us of dependency latency on this stack -- tools/sync_cost2.py -- which
+// ate the overlap; the small kernels it needed are folded into the big ones instead).
 extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   RK_REQUIRE(a && a->blk, "null step / block");
-  RK_REQUIRE(a->stream_main != a->stream_aux, "the two streams must differ");
-  RK_REQUIRE(a->ev_loss && a->ev_dz && a->ev_dw && a->ev_aux_done, "events missing");
+  RK_REQUIRE(a->phase >= 0 && a->phase <= 7, "phase is a mask of RK_STEP_*");
+  const int phase = a->phase == 0 ? RK_STEP_ALL : a->phase;
+  const bool whole = phase == RK_STEP_ALL;
   const rk_block_t *blk = a->blk;
-  hipStream_t sm = (hipStream_t)a->stream_main, sa = (hipStream_t)a->stream_aux;
+  hipStream_t sm = (hipStream_t)a->stream;
   const int B = a->B, h = a->h, n_items = blk->n_items;
   const int row_tiles = rk_cdiv(B, rk_decode_row_tile());
+  const bool mnll = a->loss_kind == RK_LOSS_MNLL;
   const float *W_de = a->tied ? a->par[RK_PAR_W_EN].p : a->par[RK_PAR_W_DE].p;
   float *G_en = a->tied ? a->G_de : a->G_en;
-  RK_REQUIRE(a->phase >= 0 && a->phase <= 2, "phase must be 0, 1 or 2");
-  if (a->phase != 2) {
-  // ---- forward: encoder SpMM, decoder GEMM + fused loss ----
-  {
-    Timer t(a, RK_ENTRY_ENCODE_FWD, sm);
-    RK_TRY(rk_ae_encode_fwd(blk, a->row_off, B, a->par[RK_PAR_W_EN].p, a->par[RK_PAR_B_EN].p, h,
-                            a->keep, a->noise_p, a->seed, a->rng_step, a->users, a->act, a->Z0, sm));
-  }
-  {
-    Timer t(a, RK_ENTRY_DECODE_LOSS, sm);
-    RK_TRY(rk_decode_loss(a->Z0, B, h, blk, a->row_off, W_de, a->par[RK_PAR_B_DE].p, a->loss_kind,
-                          a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, sm));
-  }
-  int n_part = rk_loss_partials(B, blk->n_cap);   // all slots (unused ones hold 0)
-  if (a->loss_kind == RK_LOSS_MNLL) {
-    RK_TRY(rk_mnll_finish(a->dO, B, blk, a->row_off, a->inv_B, a->loss_part, sm));
-    n_part = B;
-  }
-  if (hipEventRecord((hipEvent_t)a->ev_loss, sm) != hipSuccess) { rk_set_error("event record"); return -1; }
-  if (hipStreamWaitEvent(sa, (hipEvent_t)a->ev_loss, 0) != hipSuccess) { rk_set_error("event wait"); return -1; }
+  const int n_part = mnll ? B : rk_loss_partials(B, blk->n_cap);   // unused slots hold 0
 
-  // ---- auxiliary stream: loss scalar, dW (+ decoder bias gradient) ----
-  RK_TRY(rk_loss_reduce(a->loss_part, n_part, a->denom, a->loss_out, sa));
-  if (a->loss_kind == RK_LOSS_MNLL) {
-    Timer t(a, RK_ENTRY_DECODE_BWD_DW, sa);
-    RK_TRY(rk_decode_bwd_dw(a->dO, a->Z0, B, h, blk, a->G_de, a->gb_de, sa));
-  } else {
-    RK_TRY(rk_colsum(a->gb_part, row_tiles, blk->n_cap, 0, blk->counts, a->gb_de, sa));
-    Timer t(a, RK_ENTRY_DECODE_BWD_DW, sa);
-    RK_TRY(rk_decode_bwd_dw(a->dO, a->Z0, B, h, blk, a->G_de, nullptr, sa));
+  if (phase & RK_STEP_FWD_DW) {
+    {
+      Timer t(a, RK_ENTRY_ENCODE_FWD, sm);
+      RK_TRY(rk_ae_encode_fwd(blk, a->row_off, B, a->par[RK_PAR_W_EN].p, a->par[RK_PAR_B_EN].p, h,
+                              a->keep, a->noise_p, a->seed, a->rng_step, a->users, a->act, a->Z0, sm));
+    }
+    {
+      Timer t(a, RK_ENTRY_DECODE_LOSS, sm);
+      RK_TRY(rk_decode_loss(a->Z0, B, h, blk, a->row_off, W_de, a->par[RK_PAR_B_DE].p, a->loss_kind,
+                            a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, sm));
+      if (mnll) RK_TRY(rk_mnll_finish(a->dO, B, blk, a->row_off, a->inv_B, a->loss_part, sm));
+    }
+    {
+      Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
+      RK_TRY(rk_decode_bwd_dw(a->dO, a->Z0, B, h, blk, a->G_de, mnll ? a->gb_de : nullptr, sm));
+    }
+    if (!whole) {
+      // the data-parallel exchange needs gb_de and the loss scalar as arrays of their own
+      if (!mnll) RK_TRY(rk_colsum(a->gb_part, row_tiles, blk->n_cap, 0, blk->counts, a->gb_de, sm));
+      RK_TRY(rk_loss_reduce(a->loss_part, n_part, a->denom, a->loss_out, sm));
+    }
   }
-  (void)hipEventRecord((hipEvent_t)a->ev_dw, sa);
-
-  // ---- main stream: dZ (x act') ----
-  {
-    Timer t(a, RK_ENTRY_DECODE_BWD_DZ, sm);
-    RK_TRY(rk_decode_bwd_dz(a->dO, B, h, blk, W_de, a->Z0, a->act, a->dZ0, a->ws, sm));
+  if (phase & RK_STEP_DZ_ENC) {
+    {
+      Timer t(a, RK_ENTRY_DECODE_BWD_DZ, sm);
+      RK_TRY(rk_decode_bwd_dz(a->dO, B, h, blk, W_de, a->Z0, a->act, a->dZ0, a->ws, sm));
+    }
+    {
+      Timer t(a, RK_ENTRY_ENCODE_BWD, sm);
+      RK_TRY(rk_ae_encode_bwd(blk, a->row_off, B, a->dZ0, h, G_en, a->tied ? 1 : 0, a->gb_en, sm));
+    }
   }
-  (void)hipEventRecord((hipEvent_t)a->ev_dz, sm);
-
-  // ---- main stream: encoder bias / row gradients ----
-  RK_TRY(rk_colsum(a->dZ0, B, h, h, nullptr, a->gb_en, sm));
-  if (a->tied) (void)hipStreamWaitEvent(sm, (hipEvent_t)a->ev_dw, 0);
-  {
-    Timer t(a, RK_ENTRY_ENCODE_BWD, sm);
-    RK_TRY(rk_ae_encode_bwd(blk, a->row_off, B, a->dZ0, h, G_en, a->tied ? 1 : 0, sm));
+  if (phase & RK_STEP_UPDATE) {
+    rk_adam_job_t jobs[4];
+    int n = 0;
+    jobs[n++] = table_job(a->par[RK_PAR_W_EN], blk, n_items, h, G_en, true);
+    if (!a->tied) jobs[n++] = table_job(a->par[RK_PAR_W_DE], blk, n_items, h, a->G_de, true);
+    jobs[n] = table_job(a->par[RK_PAR_B_DE], blk, n_items, 1, a->gb_de, true);
+    jobs[n].par.sparse = 0; jobs[n].rows = nullptr; jobs[n].n_dev = nullptr; jobs[n].pos = blk->pos;
+    if (whole && !mnll) {          // straight from the decode epilogue's row-tile partials
+      jobs[n].g = a->gb_part; jobs[n].g_parts = row_tiles; jobs[n].gstride_dev = blk->counts + 2;
+    }
+    ++n;
+    jobs[n++] = table_job(a->par[RK_PAR_B_EN], blk, 1, h, a->gb_en, false);
+    Timer t(a, RK_ENTRY_ADAM_MULTI, sm);
+    RK_TRY(rk_adam_multi(jobs, n, whole ? a->loss_part : nullptr, n_part, a->denom,
+                         whole ? a->loss_out : nullptr, sm));
   }
-  }  // phase != 2
-  if (a->phase == 1) return 0;
-
-  // decoder-side Adam on the auxiliary stream; it writes W_de, so it follows dZ
-  (void)hipStreamWaitEvent(sa, (hipEvent_t)a->ev_dz, 0);
-  if (!a->tied) {
-    Timer t(a, RK_ENTRY_ADAM_TABLE, sa);
-    RK_TRY(adam_param(a, RK_PAR_W_DE, n_items, h, blk->pos, blk->items, blk->counts, blk->n_cap,
-                      a->G_de, true, sa));
-  }
-  RK_TRY(rk_adam_table(a->par[RK_PAR_B_DE].p, a->par[RK_PAR_B_DE].m, a->par[RK_PAR_B_DE].v, n_items,
-                       1, blk->pos, a->gb_de, a->par[RK_PAR_B_DE].lr, a->par[RK_PAR_B_DE].beta1,
-                       a->par[RK_PAR_B_DE].beta2, a->par[RK_PAR_B_DE].eps,
-                       a->par[RK_PAR_B_DE].weight_decay, a->par[RK_PAR_B_DE].step, sa));
-  (void)hipEventRecord((hipEvent_t)a->ev_aux_done, sa);
-
-  // ---- main stream: encoder-side Adam ----
-  RK_TRY(adam_param(a, RK_PAR_W_EN, n_items, h, blk->pos, blk->items, blk->counts, blk->n_cap, G_en,
-                    true, sm));
-  RK_TRY(adam_param(a, RK_PAR_B_EN, 1, h, nullptr, nullptr, nullptr, 0, a->gb_en, false, sm));
-  (void)hipStreamWaitEvent(sm, (hipEvent_t)a->ev_aux_done, 0);
   return 0;
 }

@@ -134,7 +134,7 @@ extern "C" int rk_topk_masked(const float *scores, int32_t B, int32_t n, int32_t
   RK_REQUIRE(k <= n, "k larger than the number of items");
   if (B == 0) return 0;
   rk_block_t dummy = {};
-  hipLaunchKernelGGL(topk_masked_kernel, dim3(B), dim3(256), 0, stream, scores, n, ld,
+  RK_LAUNCH(topk_masked_kernel, dim3(B), dim3(256), 0, stream, scores, n, ld,
                      seen ? *seen : dummy, seen ? 1 : 0, row_off, k, out_idx, out_val);
   RK_CHECK_LAUNCH("topk_masked");
   return 0;

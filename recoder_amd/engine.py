@@ -8,6 +8,7 @@ host synchronisation.  All arithmetic is in the HIP library; torch is used for
 device memory and streams only.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -98,6 +99,8 @@ class FusedEngine:
     self.allreduce = None                  # callable(list of tensors) for data parallel
     self.use_c_step = True                 # one-FFI-call step driver (rk_ae_train_step)
     self.time_entry = None                 # C-ABI entry name to bracket with events (bench)
+    self.time_every = 4                    # ... on every time_every-th step
+    self._gb_lazy = None
     self._cstep = None
     if kind == "ae":
       self.h = list(model.hidden_layers)
@@ -261,10 +264,8 @@ class FusedEngine:
       return m.de_embedding_layer.weight, m.de_bias
     return m.item_embedding_layer.weight, m.bias
 
-  def _loss(self, z, B, tgt, row_off, denom_rows, stream, out=None, reduce_on=None):
-    """decode + loss; leaves dLoss/dLogits in self.dO. Returns device scalar.
-    reduce_on = (torch stream, raw stream, event): run the tiny partial-sum
-    reduction there instead of on `stream` (off the critical path)."""
+  def _loss(self, z, B, tgt, row_off, denom_rows, stream, out=None):
+    """decode + loss; leaves dLoss/dLogits in self.dO. Returns device scalar."""
     lib = self.lib
     W, b = self._decoder_params()
     inv_B = _f32(np.float32(1.0) / np.float32(denom_rows))
@@ -278,11 +279,6 @@ class FusedEngine:
       n_part = B
     else:
       n_part = self.lib.rk_loss_partials(B, tgt.n_cap)     # all slots (unused ones hold 0)
-    if reduce_on is not None:
-      t_stream, raw, event = reduce_on
-      event.record(torch.cuda.current_stream())
-      t_stream.wait_event(event)
-      stream = raw
     check(lib.rk_loss_reduce(ptr(self.loss_part), n_part, float(denom_rows), ptr(out), stream),
           "rk_loss_reduce")
     return out
@@ -298,34 +294,23 @@ class FusedEngine:
       z = self._mf_forward(blk.users[row_off:row_off + B], B, None, False, stream)
     return self._loss(z, B, tgt if tgt is not None else blk, row_off, B, stream, out)
 
-  def _aux(self):
-    """Second HIP stream + reusable events for the intra-step overlap."""
-    if getattr(self, "_aux_stream", None) is None:
-      self._aux_stream = torch.cuda.Stream(device=self.device)
-      if hasattr(self.lib, "streams"):
-        self.lib.streams[self._aux_stream.cuda_stream] = self._aux_stream
-      self._ev = {k: torch.cuda.Event() for k in ("loss", "dw", "dz", "aux_done")}
-    return self._aux_stream
-
   def train_step(self, blk, row_off, B, keep_noise=None, keep_drop=None, out=None,
                  global_rows=None):
     """One optimisation step on rows [row_off, row_off+B) of the collated
     block (model.py:383-404).  ``global_rows`` = rows summed over all ranks
     (data parallel); the loss/gradients are normalised by it.
 
-    Two HIP streams: after the fused decode+loss the two backward GEMMs are
-    independent -- dW (+ the decoder-side Adam sweep, HBM-bound) runs on the
-    auxiliary stream while dZ -> encoder backward -> encoder-side Adam runs on
-    the caller's stream, so MFMA-bound and HBM-bound kernels overlap."""
+    Everything is enqueued in order on the caller's stream (cross-stream events
+    cost 10-20 us of dependency latency each, more than the overlap they bought);
+    under data parallelism the RCCL all-reduces run on the collective's own
+    stream while the rest of the backward pass continues here."""
     self.ensure_capacity(B, blk.n_cap)
     lib, m = self.lib, self.model
     main_s = torch.cuda.current_stream()
-    aux_s = self._aux()
     if self.use_c_step and self.kind == "ae" and self.nl == 0 and not (m.dropout_prob > 0.0):
-      return self._c_train_step(blk, row_off, B, keep_noise, out, global_rows, main_s, aux_s)
-    ev = self._ev
+      return self._c_train_step(blk, row_off, B, keep_noise, out, global_rows, main_s)
+    self._gb_lazy = None
     stream = ctypes.c_void_p(main_s.cuda_stream)
-    aux = ctypes.c_void_p(aux_s.cuda_stream)
     self.rng_step += 1
     h0 = self.h[0]
     rows = B if global_rows is None else global_rows
@@ -334,32 +319,30 @@ class FusedEngine:
     else:
       users = blk.users[row_off:row_off + B]
       z = self._mf_forward(users, B, keep_drop, True, stream)
-    # the loss partial-sum reduction goes to the auxiliary stream (it records the
-    # "dO ready" event on the main stream and makes the auxiliary stream wait for it)
-    loss = self._loss(z, B, blk, row_off, rows, stream, out, reduce_on=(aux_s, aux, ev["loss"]))
+    loss = self._loss(z, B, blk, row_off, rows, stream, out)
     self._loss_target = loss
 
-    # ---- auxiliary stream: dW = dO^T . z  (+ decoder bias gradient) ----
+    # ---- dW = dO^T . z  (+ decoder bias gradient) ----
     if self.loss_id == LOSS_MNLL:
       # dO was produced by rk_mnll_finish: column sums need a pass over dO
       check(lib.rk_decode_bwd_dw(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(self.G_de),
-                                 ptr(self.gb_de), aux), "rk_decode_bwd_dw")
+                                 ptr(self.gb_de), stream), "rk_decode_bwd_dw")
     else:
       # the loss epilogue already reduced dO per row tile: sum those few rows
       check(lib.rk_colsum(ptr(self.gb_part), cdiv(B, self.row_tile), blk.n_cap, 0, ptr(blk.counts),
-                          ptr(self.gb_de), aux), "rk_colsum")
+                          ptr(self.gb_de), stream), "rk_colsum")
       check(lib.rk_decode_bwd_dw(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(self.G_de), None,
-                                 aux), "rk_decode_bwd_dw")
-    ev["dw"].record(aux_s)
+                                 stream), "rk_decode_bwd_dw")
+    tied = self.kind == "ae" and bool(m.is_constrained)
     dp_dec = None
     if self.allreduce is not None:
-      # data parallel: the decoder-side gradients start their RCCL all-reduce now,
-      # from the auxiliary stream, and travel while dZ / the encoder backward run
+      # data parallel: the decoder-side gradients start their RCCL all-reduce now and
+      # travel while dZ / the encoder backward run (tied weights: G_de is still being
+      # accumulated into, it goes with the encoder side)
       n_b_host = self.allreduce.n_b(blk)
-      with torch.cuda.stream(aux_s):
-        dp_dec = self.allreduce.reduce_async(self.grad_views(n_b_host, "decoder"))
+      dp_dec = self.allreduce.reduce_async(self.grad_views(n_b_host, "decoder"))
 
-    # ---- main stream: dZ = dO . W_de[T] and everything upstream of it ----
+    # ---- dZ = dO . W_de[T] and everything upstream of it ----
     W_de, _ = self._decoder_params()
     simple = (self.kind == "ae" and self.nl == 0 and not self.drop_active)
     dz = self.denc[0] if simple else self.dbott
@@ -368,16 +351,6 @@ class FusedEngine:
     check(lib.rk_decode_bwd_dz(ptr(self.dO), B, h0, blk.ref, ptr(W_de),
                                ptr(self.enc[0]) if simple else None, self.act, ptr(dz),
                                ptr(self.ws), stream), "rk_decode_bwd_dz")
-    ev["dz"].record(main_s)
-
-    tied = self.kind == "ae" and bool(m.is_constrained)
-    overlap_updates = self.allreduce is None
-    if overlap_updates:
-      # decoder-side Adam on the auxiliary stream; it writes W_de, so it must
-      # follow the dZ GEMM that reads W_de
-      aux_s.wait_event(ev["dz"])
-      self._apply_updates(blk, row_off, B, aux, "decoder")
-      ev["aux_done"].record(aux_s)
 
     if self.kind == "ae":
       rh = list(reversed(self.h))
@@ -413,12 +386,9 @@ class FusedEngine:
       if not simple:
         check(lib.rk_act_grad(ptr(self.denc[0]), ptr(self.enc[0]), B * h0, self.act, stream),
               "rk_act_grad")
-      check(lib.rk_colsum(ptr(self.denc[0]), B, h0, h0, None, ptr(self.gb_en), stream), "rk_colsum")
-      G_en = self.G_de if tied else self.G_en
-      if tied:
-        main_s.wait_event(ev["dw"])      # accumulates on top of dW's rows
+      G_en = self.G_de if tied else self.G_en      # tied: accumulates on top of dW's rows
       check(lib.rk_ae_encode_bwd(blk.ref, row_off, B, ptr(self.denc[0]), h0, ptr(G_en),
-                                 1 if tied else 0, stream), "rk_ae_encode_bwd")
+                                 1 if tied else 0, ptr(self.gb_en), stream), "rk_ae_encode_bwd")
     else:
       # MF: gradient of the gathered user rows = dU * act'(U) (after dropout)
       n = B * h0
@@ -427,38 +397,29 @@ class FusedEngine:
                              self.seed ^ 0xd0d0, self.rng_step, stream), "rk_dropout")
       check(lib.rk_act_grad(ptr(self.dbott), ptr(self.enc[0]), n, self.act, stream), "rk_act_grad")
 
-    if overlap_updates:
-      self._apply_updates(blk, row_off, B, stream, "encoder")
-      main_s.wait_event(ev["aux_done"])
-    else:
-      # data parallel: encoder-side all-reduce from the main stream; each side's Adam
-      # waits only for its own collective
+    if self.allreduce is not None:
       dp_enc = self.allreduce.reduce_async(self.grad_views(n_b_host, "encoder"))
-      aux_s.wait_event(ev["dz"])            # decoder Adam writes W_de: after dZ read it
-      with torch.cuda.stream(aux_s):
-        self.allreduce.wait(dp_dec)
-        self._apply_updates(blk, row_off, B, aux, "decoder")
-        ev["aux_done"].record(aux_s)
+      self.allreduce.wait(dp_dec)
       self.allreduce.wait(dp_enc)
-      self._apply_updates(blk, row_off, B, stream, "encoder")
-      main_s.wait_event(ev["aux_done"])
+    self._apply_updates(blk, row_off, B, stream, "all")
     return loss
 
-  def _c_train_step(self, blk, row_off, B, keep_noise, out, global_rows, main_s, aux_s):
-    """The same step through rk_ae_train_step: one FFI call, kernels sequenced
-    in C on the two streams."""
-    from ._lib import ENTRY, PAR_B_DE, PAR_B_EN, PAR_W_DE, PAR_W_EN, RkAeStep
+  def _c_train_step(self, blk, row_off, B, keep_noise, out, global_rows, main_s):
+    """The same step through rk_ae_train_step: one FFI call, the kernels
+    sequenced in C on the caller's stream."""
+    from ._lib import (ENTRY, PAR_B_DE, PAR_B_EN, PAR_W_DE, PAR_W_EN, STEP_ALL, STEP_DZ_ENC,
+                       STEP_FWD_DW, STEP_UPDATE, RkAeStep)
     raw = _lib.load()
     m, S = self.model, self.states
     st = self._cstep
     if st is None:
       st = RkAeStep()
-      self._c_events = [raw.rk_event_create() for _ in range(4)]
-      st.ev_loss, st.ev_dz, st.ev_dw, st.ev_aux_done = self._c_events
       self._c_time_pairs = []
       self._c_time_idx = 0
+      self._c_calls = 0
       self._cstep = st
     self.rng_step += 1
+    self._gb_lazy = None
     rows = B if global_rows is None else global_rows
     st.blk = ctypes.pointer(blk.c)
     st.row_off, st.B, st.h, st.act = row_off, B, self.h[0], self.act
@@ -490,44 +451,57 @@ class FusedEngine:
     st.G_de, st.G_en, st.gb_de = ptr(self.G_de), ptr(self.G_en), ptr(self.gb_de)
     st.gb_part, st.gb_en, st.ws = ptr(self.gb_part), ptr(self.gb_en), ptr(self.ws)
     st.loss_part, st.loss_out = ptr(self.loss_part), ptr(loss_dst)
-    st.stream_main, st.stream_aux = main_s.cuda_stream, aux_s.cuda_stream
-    if self.time_entry is not None:
+    st.stream = main_s.cuda_stream
+    self._c_calls += 1
+    if self.time_entry is not None and self._c_calls % self.time_every == 0:
+      # the bracketing events cost a few us of stream time each: sample the launches
       if not self._c_time_pairs:
-        self._c_time_pairs = [(raw.rk_event_create(), raw.rk_event_create()) for _ in range(512)]
+        self._c_time_pairs = [(raw.rk_timing_event_create(), raw.rk_timing_event_create())
+                              for _ in range(512)]
       e0, e1 = self._c_time_pairs[self._c_time_idx % len(self._c_time_pairs)]
       self._c_time_idx += 1
       st.time_entry, st.time_ev0, st.time_ev1 = ENTRY[self.time_entry], e0, e1
     else:
       st.time_entry = 0
     if dp is None:
-      st.phase = 0
+      st.phase = STEP_ALL
       check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
+      if self.loss_id != LOSS_MNLL:
+        self._gb_lazy = (cdiv(B, self.row_tile), blk)
     else:
-      # data parallel: forward + backward, all-reduce (SUM) of the gradients over the
-      # ranks while the rest of the backward runs, then the identical Adam everywhere
+      # data parallel: the gradients are all-reduced (SUM) over the ranks between the
+      # backward pass and the identical Adam everywhere; the decoder side travels on
+      # RCCL's stream while dZ and the encoder backward run here
       h0 = self.h[0]
-      st.phase = 1
-      check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
-      n_b = dp.n_b(blk)
       tied = bool(m.is_constrained)
+      n_b = dp.n_b(blk)
+      st.phase = STEP_FWD_DW
+      check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
       pend_dec = None
       if not tied:
-        with torch.cuda.stream(aux_s):          # right behind dW on the auxiliary stream
-          pend_dec = dp.reduce_async([self.G_de[:n_b * h0]], coalesce=False)
-      main_s.wait_stream(aux_s)                 # gb_de / loss (aux) join gb_en (main)
+        pend_dec = dp.reduce_async([self.G_de[:n_b * h0]], coalesce=False)
+      st.phase = STEP_DZ_ENC
+      check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
       G_enc = self.G_de if tied else self.G_en
       pend_enc = dp.reduce_async([G_enc[:n_b * h0], self.small[:self.small_off + n_b]],
                                  coalesce=False)
-      with torch.cuda.stream(aux_s):
-        if pend_dec is not None:
-          dp.wait(pend_dec)
-        dp.wait(pend_enc)
+      if pend_dec is not None:
+        dp.wait(pend_dec)
       dp.wait(pend_enc)
       out.copy_(self.loss_dp)
-      st.phase = 2
+      st.phase = STEP_UPDATE
       check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
     self._loss_target = out
     return out
+
+  def decoder_bias_grad(self, n_b):
+    """gb_de[:n_b] of the last training step (tests).  The one-call step consumes the
+    decode epilogue's row-tile partials directly and never materialises gb_de."""
+    if self._gb_lazy is None:
+      return self.gb_de[:n_b].clone()
+    tiles, blk = self._gb_lazy
+    ld = blk.counts_host()[2]
+    return self.gb_part[:tiles * ld].view(tiles, ld)[:, :n_b].sum(0)
 
   def timed_entry_ms(self):
     """Per-launch durations (ms) of the bracketed entry since timing was enabled."""

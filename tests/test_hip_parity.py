@@ -352,7 +352,7 @@ def test_steps_match_oracle(name, c, shape, B, S):
     assert frac < 1e-3, (label, frac, mx, scale)
 
   G_de = eng.G_de[:n_b * h0].view(n_b, h0).cpu().numpy()
-  gb_de = eng.gb_de[:n_b].cpu().numpy()
+  gb_de = eng.decoder_bias_grad(n_b).cpu().numpy()
   if c["kind"] == "ae":
     if c.get("is_constrained"):
       check("W_en(tied)[items]", G_de, grads[orc.AE_EN_W][items_idx].numpy())

@@ -81,7 +81,7 @@ def main():
         ptr(dO), ptr(Z), B, h, blk.ref, ptr(G), None, st)))
     r["enc_fwd"] = timeit(lambda: check(lib.rk_ae_encode_fwd(
         blk.ref, 0, B, ptr(W), ptr(bias), h, None, 0.5, 1, 1, ptr(users), 1, ptr(Z0), st)))
-    r["enc_bwd"] = timeit(lambda: check(lib.rk_ae_encode_bwd(blk.ref, 0, B, ptr(dZ), h, ptr(G), 0, st)))
+    r["enc_bwd"] = timeit(lambda: check(lib.rk_ae_encode_bwd(blk.ref, 0, B, ptr(dZ), h, ptr(G), 0, None, st)))
     r["adam_tab"] = timeit(lambda: check(lib.rk_adam_table(
         ptr(W), ptr(m), ptr(v), n_items, h, ptr(blk.pos), ptr(G), 1e-3, 0.9, 0.999, 1e-8, 2e-5, 1, st)))
     gf = 2.0 * B * h * n_b / 1e9
