@@ -131,6 +131,9 @@ def main():
   ap.add_argument("--config", default="c2")
   ap.add_argument("--cpu-steps", type=int, default=1000)   # bounded by RK_CPU_SECONDS (20 s)
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  # diagnostics only (the JSON line is marked invalid): train every step on the first
+  # collated block, i.e. without the collation the real loop overlaps on its side stream
+  ap.add_argument("--diag-reuse-block", action="store_true")
   args = ap.parse_args()
   cfg = CONFIGS[args.config]
 
@@ -186,7 +189,8 @@ def main():
   nnz_bound = _top_sum(dcsr.degrees, B)
   pf = CollatePrefetcher(
       lambda: Block(B, nnz_bound, n_items, device, negative_sampling=True, n_cap=nnz_bound * world),
-      dcsr, device, collate_fn=(dp.collate if dp is not None else None))
+      dcsr, device, collate_fn=(dp.collate if dp is not None else None), group=rec.prefetch_group)
+  G = pf.group
 
   total = args.warmup + args.steps
   rng = np.random.RandomState(100 + rank)
@@ -199,16 +203,27 @@ def main():
   def users_of(i):
     return order_dev[i * B:(i + 1) * B]
 
-  def step(i):
-    # collation of step i+1 runs on the prefetcher's side stream while step i trains
-    if i + 1 < total:
-      pf.submit((i + 1) % 2, users_of(i + 1))
-    blk = pf.acquire(i % 2)
-    eng.train_step(blk, 0, B, out=loss_buf[i:i + 1],
-                   global_rows=global_rows if dp is not None else None)
-    pf.release(i % 2)
+  def chunk_users(c):
+    return [users_of(i) for i in range(c * G, min(total, (c + 1) * G))]
 
-  pf.submit(0, users_of(0))
+  cur = {}
+
+  def step(i):
+    # the collation of the next G steps runs on the prefetcher's side stream while these train
+    if args.diag_reuse_block and i >= G:
+      eng.train_step(cur["blks"][0], 0, B, out=loss_buf[i:i + 1])
+      return
+    c = i // G
+    if i % G == 0:
+      if (c + 1) * G < total:
+        pf.submit((c + 1) % 2, chunk_users(c + 1))
+      cur["blks"] = pf.acquire(c % 2)
+    eng.train_step(cur["blks"][i % G], 0, B, out=loss_buf[i:i + 1],
+                   global_rows=global_rows if dp is not None else None)
+    if i % G == G - 1 or i == total - 1:
+      pf.release(c % 2)
+
+  pf.submit(0, chunk_users(0))
 
   # ---- warm-up (untimed).  The first half runs the per-entry Python sequencing
   # with every C-ABI entry bracketed by HIP events -> picks the dominant entry;
@@ -291,7 +306,8 @@ def main():
       "metric": "train_users_per_sec", "value": value, "unit": "users/s",
       "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
       "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-      "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+      "vs_baseline": None, "dtype": "f32",
+      "data": "synthetic" if not args.diag_reuse_block else "INVALID (diagnostic: no collation)",
       "config": {"workload": cfg["workload"], "batch_size_per_gpu": B, "global_batch": B * world,
                  "parallelism": "dp%d" % world, "avg_sampled_items": n_b, "avg_nnz_per_batch": nnz,
                  "first_loss": float(losses[0]), "last_loss": float(losses[-1]),

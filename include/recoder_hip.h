@@ -69,6 +69,8 @@ typedef struct rk_block {
   int32_t *pref_rc;   /* [S_cap][ldw_rc] exclusive prefix popcount of bits_rc per row:
                          entry index of (r,c) = indptr[r] + pref_rc[r][c>>5]
                          + popc(bits_rc[r][c>>5] & ((1<<(c&31))-1)) */
+  int32_t *gcols;     /* [nnz_cap] global item id of every entry (= items[cols[j]]):
+                         saves the encoder forward one dependent load per entry */
 } rk_block_t;
 
 #define RK_SCAN_CHUNK 2048
@@ -167,6 +169,13 @@ int rk_decode_bwd_dz(const float *dO, int32_t B, int32_t h,
 int rk_decode_bwd_dw(const float *dO, const float *Z, int32_t B, int32_t h,
                      const rk_block_t *tgt, float *G_de, float *gb_de,
                      void *stream);
+/* rk_decode_bwd_dw + rk_ae_encode_bwd(accumulate = 0) on the same block in ONE
+ * launch: the MFMA-bound dW tiles and the latency-bound encoder-backward gathers
+ * are independent and share the GPU (untied weights only). */
+int rk_decode_bwd_dw_encode_bwd(const float *dO, const float *Z, int32_t B, int32_t h,
+                                const rk_block_t *blk, float *G_de, int32_t row_off,
+                                const float *dZ0pre, float *G_en, float *gb_en,
+                                void *stream);
 
 /*
  * Hidden nn.Linear stack (nn.py:242-249): Y = act(X W^T + b), and backward.

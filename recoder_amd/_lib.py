@@ -32,7 +32,7 @@ class RkBlock(Structure):
     ("counts", c_void_p), ("indptr", c_void_p), ("cols", c_void_p), ("vals", c_void_p),
     ("svals", c_void_p), ("items", c_void_p), ("pos", c_void_p), ("mark", c_void_p),
     ("bits_rc", c_void_p), ("bits_cr", c_void_p), ("scan_tmp", c_void_p),
-    ("pref_rc", c_void_p),
+    ("pref_rc", c_void_p), ("gcols", c_void_p),
   ]
 
 
@@ -101,6 +101,7 @@ SIGNATURES = {
   "rk_loss_reduce": (c_int32, [_P, c_int32, c_float, _P, _P]),
   "rk_decode_bwd_dz": (c_int32, [_P, c_int32, c_int32, _BLK, _P, _P, c_int32, _P, _P, _P]),
   "rk_decode_bwd_dw": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P]),
+  "rk_decode_bwd_dw_encode_bwd": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, c_int32, _P, _P, _P, _P]),
   "rk_linear_fwd": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
   "rk_linear_bwd": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P,
                               c_int32, _P, _P]),

@@ -4,7 +4,6 @@
 #include "common.h"
 
 static thread_local char g_err[512] = "";
-thread_local unsigned rk_launch_flags = 0;
 
 void rk_set_error(const char *fmt, ...) {
   va_list ap;

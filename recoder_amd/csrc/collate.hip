@@ -217,8 +217,10 @@ __global__ __launch_bounds__(256) void collate_build_kernel(
   const int out0 = b.indptr[row];
   const int wr = (b.counts[0] + 31) >> 5;          // bitmap words in use
   for (int k = lane; k < n; k += 64) {
-    const int32_t c = b.pos[ds_indices[beg + k]];
+    const int32_t gi = ds_indices[beg + k];
+    const int32_t c = b.pos[gi];
     b.cols[out0 + k] = c;
+    if (b.gcols) b.gcols[out0 + k] = gi;
     b.vals[out0 + k] = ds_data ? ds_data[beg + k] : 1.0f;
     if (b.bits_cr) atomicOr(&b.bits_cr[(int64_t)c * b.ldw_cr + (row >> 5)], 1u << (row & 31));
   }

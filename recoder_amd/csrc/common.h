@@ -1,7 +1,6 @@
 // Shared device helpers for librecoder_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -9,16 +8,8 @@
 
 void rk_set_error(const char *fmt, ...);
 
-// Every kernel of the library is launched through RK_LAUNCH.  rk_launch_flags is 0
-// (in-order: the AQL packet carries the barrier bit) except inside rk_ae_train_step,
-// which marks kernels that are independent of their predecessors in the SAME stream
-// with hipExtAnyOrderLaunch so that they overlap without a cross-stream event (a
-// cross-queue dependency costs 10-20 us of latency on this stack, tools/sync_cost2.py).
-extern thread_local unsigned rk_launch_flags;
 #define RK_LAUNCH(kernel, grid, block, shmem, stream, ...) \
-  hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, nullptr, rk_launch_flags, __VA_ARGS__)
-#define RK_LAUNCH_ORDERED(kernel, grid, block, shmem, stream, ...) \
-  hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, nullptr, nullptr, 0u, __VA_ARGS__)
+  hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__)
 
 #define RK_CHECK_LAUNCH(name)                                              \
   do {                                                                     \

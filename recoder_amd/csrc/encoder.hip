@@ -12,6 +12,7 @@
 // one wave per sampled item column; rows are visited in ascending order through
 // the transposed bitmap so the fp32 sum is order-deterministic (no atomics).
 #include "common.h"
+#include "encoder_bwd.h"
 
 namespace {
 
@@ -29,23 +30,37 @@ __global__ __launch_bounds__(256) void ae_encode_fwd_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int beg = b.indptr[row], end = b.indptr[row + 1];
   const int n = end - beg;
+  const bool implicit = b.implicit != 0;
+  const int64_t uid = users ? users[row] : (int64_t)row;
 
-  // ---- L2 norm of the row (F.normalize: x / max(||x||_2, 1e-12)) ----
-  float ss = 0.f;
-  for (int j = beg + tid; j < end; j += 256) {
-    const float v = b.vals[j];
-    ss += v * v;
-  }
-  ss = rk_wave_sum(ss);
-  if (lane == 0) red[wid] = ss;
-  __syncthreads();
-  const float nrm = fmaxf(sqrtf((red[0] + red[1]) + (red[2] + red[3])), 1e-12f);
-
-  // ---- each wave takes a contiguous quarter of the row's entries ----
+  // ---- each wave takes a contiguous quarter of the row's entries.  The first 64 of
+  // them are fetched (value + global item id, independent loads) BEFORE the norm is
+  // known, so the dependent chain is indptr -> entries -> W rows ----
   const int q = (n + 3) >> 2;
   const int wbeg = beg + wid * q;
   const int wend = min(end, wbeg + q);
-  const int64_t uid = users ? users[row] : (int64_t)row;
+  int item0 = 0;
+  float v0 = 0.f;
+  if (wbeg + lane < wend) {
+    item0 = b.gcols ? b.gcols[wbeg + lane] : b.items[b.cols[wbeg + lane]];
+    v0 = implicit ? 1.0f : b.vals[wbeg + lane];
+  }
+
+  // ---- L2 norm of the row (F.normalize: x / max(||x||_2, 1e-12)) ----
+  float nrm;
+  if (implicit) {
+    nrm = fmaxf(sqrtf((float)n), 1e-12f);      // n ones: the sum of squares is exactly n
+  } else {
+    float ss = 0.f;
+    for (int j = beg + tid; j < end; j += 256) {
+      const float v = b.vals[j];
+      ss += v * v;
+    }
+    ss = rk_wave_sum(ss);
+    if (lane == 0) red[wid] = ss;
+    __syncthreads();
+    nrm = fmaxf(sqrtf((red[0] + red[1]) + (red[2] + red[3])), 1e-12f);
+  }
 
   float4 acc[HV];
 #pragma unroll
@@ -53,39 +68,44 @@ __global__ __launch_bounds__(256) void ae_encode_fwd_kernel(
 
   for (int base = wbeg; base < wend; base += 64) {
     const int j = base + lane;
-    int item = 0;
+    int item = item0;
+    float val = v0;
+    if (base != wbeg && j < wend) {
+      item = b.gcols ? b.gcols[j] : b.items[b.cols[j]];
+      val = implicit ? 1.0f : b.vals[j];
+    }
     float s = 0.f;
     if (j < wend) {
-      const int c = b.cols[j];
-      item = b.items[c];
-      const float xh = b.vals[j] / nrm;
+      const float xh = val / nrm;
       bool kp = true;
       if (p > 0.f) kp = keep ? (keep[j] != 0) : rk_keep_draw(seed, rng_step, (uint64_t)uid, (uint64_t)item, p);
       s = (p > 0.f) ? (kp ? xh * scale : 0.f) : xh;
       b.svals[j] = s;
+    } else {
+      item = 0;
     }
     const int cnt = min(64, wend - base);
     // no branch on dropped entries (s == 0 contributes exactly +0): the row
     // loads of consecutive entries are independent and stay in flight together
     // (lanes past the wave's range carry item 0 / s 0, so rounding cnt up to a
-    // multiple of 4 only adds exact zeros)
-    for (int k = 0; k < cnt; k += 4) {
-      int it[4];
-      float sv[4];
+    // multiple of 8 only adds exact zeros)
+    for (int k = 0; k < cnt; k += 8) {
+      int it[8];
+      float sv[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        it[u] = __shfl(item, k + u, 64);
-        sv[u] = __shfl(s, k + u, 64);
+      for (int u = 0; u < 8; ++u) {
+        it[u] = __shfl(item, (k + u) & 63, 64);
+        sv[u] = (k + u < 64) ? __shfl(s, (k + u) & 63, 64) : 0.f;
       }
 #pragma unroll
       for (int v = 0; v < HV; ++v) {
         const int hh = min((v * 64 + lane) * 4, h - 4);
-        float4 w4[4];
+        float4 w4[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 8; ++u)
           w4[u] = *reinterpret_cast<const float4 *>(W + (int64_t)it[u] * h + hh);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
           acc[v].x = fmaf(sv[u], w4[u].x, acc[v].x);
           acc[v].y = fmaf(sv[u], w4[u].y, acc[v].y);
           acc[v].z = fmaf(sv[u], w4[u].z, acc[v].z);
@@ -127,105 +147,7 @@ template <int HV>
 __global__ __launch_bounds__(256) void ae_encode_bwd_kernel(
     rk_block_t b, int row_off, int B, const float *__restrict__ dZ, int h,
     float *__restrict__ G, int accumulate, float *__restrict__ gb, int n_gb) {
-  // one workgroup per sampled item column; its 4 waves take the 64-row groups
-  // round-robin (popular items hold hundreds of entries -- a single wave per
-  // column serialised them into the kernel's tail) and combine in fixed order
-  __shared__ __attribute__((aligned(16))) float part[3][HV * 256];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  if ((int)blockIdx.x < n_gb) {
-    // encoder-bias gradient: gb[j] = sum_r dZ[r, j] for 64 columns; the 4 waves take
-    // interleaved quarters of the rows, combined in fixed order
-    const int j = blockIdx.x * 64 + lane;
-    float a0 = 0.f, a1 = 0.f;
-    if (j < h) {
-      int r = wid;
-      for (; r + 4 < B; r += 8) {
-        a0 += dZ[(int64_t)r * h + j];
-        a1 += dZ[(int64_t)(r + 4) * h + j];
-      }
-      if (r < B) a0 += dZ[(int64_t)r * h + j];
-    }
-    part[0][wid * 64 + lane] = a0 + a1;
-    __syncthreads();
-    if (wid == 0 && j < h)
-      gb[j] = (part[0][lane] + part[0][64 + lane]) + (part[0][128 + lane] + part[0][192 + lane]);
-    return;
-  }
-  const int n_b = b.counts[0];
-  const int c = (int)blockIdx.x - n_gb;
-  if (c >= n_b) return;
-  const uint32_t *colbits = b.bits_cr + (int64_t)c * b.ldw_cr;
-  float4 acc[HV];
-#pragma unroll
-  for (int k = 0; k < HV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  const int rend = row_off + B;
-  for (int r0 = (row_off & ~63) + wid * 64; r0 < rend; r0 += 256) {
-    const int row = r0 + lane;
-    bool on = false;
-    float s = 0.f;
-    if (row >= row_off && row < rend) {
-      on = (colbits[row >> 5] >> (row & 31)) & 1u;
-      if (on) {
-        const uint32_t word = b.bits_rc[(int64_t)row * b.ldw_rc + (c >> 5)];
-        s = b.svals[rk_entry_index(b, row, c, word)];
-      }
-    }
-    unsigned long long mask = __ballot(on);
-    // ascending-row order, 8 row loads in flight per pass
-    while (mask) {
-      int kk[8];
-      float sv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const bool have = mask != 0ull;
-        const int k = have ? __builtin_ctzll(mask) : 0;
-        mask = have ? (mask & (mask - 1)) : 0ull;
-        kk[u] = have ? (r0 + k - row_off) : 0;
-        sv[u] = have ? __shfl(s, k, 64) : 0.f;
-      }
-#pragma unroll
-      for (int v = 0; v < HV; ++v) {
-        const int hh = min((v * 64 + lane) * 4, h - 4);
-        float4 d4[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          d4[u] = *reinterpret_cast<const float4 *>(dZ + (int64_t)kk[u] * h + hh);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          acc[v].x = fmaf(sv[u], d4[u].x, acc[v].x);
-          acc[v].y = fmaf(sv[u], d4[u].y, acc[v].y);
-          acc[v].z = fmaf(sv[u], d4[u].z, acc[v].z);
-          acc[v].w = fmaf(sv[u], d4[u].w, acc[v].w);
-        }
-      }
-    }
-  }
-  if (wid > 0) {
-#pragma unroll
-    for (int v = 0; v < HV; ++v)
-      *reinterpret_cast<float4 *>(&part[wid - 1][(v * 64 + lane) * 4]) = acc[v];
-  }
-  __syncthreads();
-  if (wid == 0) {
-    float *grow = G + (int64_t)c * h;
-#pragma unroll
-    for (int v = 0; v < HV; ++v) {
-      const int hh = (v * 64 + lane) * 4;
-      if (hh < h) {
-        float4 a = acc[v];
-        for (int w = 0; w < 3; ++w) {
-          const float4 o = *reinterpret_cast<const float4 *>(&part[w][hh]);
-          a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
-        }
-        if (accumulate) {
-          const float4 o = *reinterpret_cast<const float4 *>(grow + hh);
-          a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
-        }
-        *reinterpret_cast<float4 *>(grow + hh) = a;
-      }
-    }
-  }
+  ae_encode_bwd_body<HV>(b, row_off, B, dZ, h, G, accumulate, gb, n_gb, (int)blockIdx.x);
 }
 
 }  // namespace

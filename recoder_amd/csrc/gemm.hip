@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "encoder_bwd.h"
 
 #ifdef RK_PROBE
 __device__ unsigned long long rk_dbg[256];
@@ -96,7 +97,7 @@ __device__ __forceinline__ float4 mask4(float4 v, int valid) {
 }
 
 template <int WM, int WN, int TM, int TN, int AMODE, int BMODE, int EPI, bool VEC, int BK = 16>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+__device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int nsplit) {
   static_assert(WM * WN == 4, "4 waves per block");
   static_assert(BK == 16 || BK == 32, "BK");
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
@@ -123,10 +124,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   // same mt for a dO column panel, same split) then hit the same L2.  The live
   // tile count comes from the device-resident M/N, the grid from capacities.
   const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
-  const int nsplit = (int)gridDim.y;
   const int per_split = tm * tn;
   const int total = per_split * nsplit;
-  const int L = (int)(blockIdx.y * gridDim.x + blockIdx.x);
   const int chunk = (total + 7) >> 3;
   const int t = (L & 7) * chunk + (L >> 3);
   if ((L >> 3) >= chunk || t >= total) return;
@@ -545,30 +544,65 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   RK_T(9);
 }
 
+template <int WM, int WN, int TM, int TN, int AMODE, int BMODE, int EPI, bool VEC, int BK = 16>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+  gemm_body<WM, WN, TM, TN, AMODE, BMODE, EPI, VEC, BK>(
+      p, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)gridDim.y);
+}
+
+// dW GEMM tiles and the encoder backward in ONE launch (workgroups [0, n_dw) are dW
+// tiles, the rest encoder-backward columns).  The two are independent (both only read
+// dO / dZ0) and complementary -- MFMA-bound tiles next to latency-bound gathers --
+// and the step is a serial chain of launches, so running them side by side takes the
+// encoder backward off the critical path without a second stream.
+template <int HV>
+__global__ __launch_bounds__(256) void dw_encode_bwd_kernel(
+    GemmP p, int n_dw, rk_block_t b, int row_off, int B, const float *__restrict__ dZ, int h,
+    float *__restrict__ G_en, float *__restrict__ gb, int n_gb) {
+  if ((int)blockIdx.x < n_dw)
+    gemm_body<1, 4, 1, 1, 1, 1, EPI_STORE, true, 16>(p, (int)blockIdx.x, 1);
+  else
+    ae_encode_bwd_body<HV>(b, row_off, B, dZ, h, G_en, 0, gb, n_gb, (int)blockIdx.x - n_dw);
+}
+
 // ws[split][M][N] -> out[M][N] (fixed split order), optional * act'(Zact)
-__global__ __launch_bounds__(64) void splitk_reduce_kernel(
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(
     const float *__restrict__ ws, int M, int N, const int32_t *__restrict__ Kdev, int unused,
     int max_splits, const float *__restrict__ Zact, int act, float *__restrict__ out) {
+  // 64 float4 outputs per workgroup; the 4 waves each sum a quarter of the splits
+  // (8 loads in flight), combined in fixed order through LDS
+  __shared__ float4 part[3][64];
   const int K = *Kdev;
   const int kchunk = ((K + max_splits - 1) / max_splits + 15) & ~15;   // as the GEMM derives it
   int ns = (K + kchunk - 1) / kchunk;
   if (ns > max_splits) ns = max_splits;
   const int64_t tot4 = ((int64_t)M * N) >> 2;      // M*N is a multiple of 4 (N = h)
   const float4 *ws4 = reinterpret_cast<const float4 *>(ws);
-  for (int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x; i < tot4; i += (int64_t)gridDim.x * 64) {
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    int z = 0;
-    for (; z + 8 <= ns; z += 8) {          // 8 loads in flight, summed in split order
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const int per = (ns + 3) >> 2;
+  const int z1 = min(ns, (q + 1) * per);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < tot4) {
+    int z = q * per;
+    for (; z + 8 <= z1; z += 8) {
       float4 v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = ws4[(int64_t)(z + u) * tot4 + i];
 #pragma unroll
       for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
     }
-    for (; z < ns; ++z) {
+    for (; z < z1; ++z) {
       const float4 v = ws4[(int64_t)z * tot4 + i];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
+  }
+  if (q > 0) part[q - 1][lane] = s;
+  __syncthreads();
+  if (q == 0 && i < tot4) {
+    const float4 a = part[0][lane], b = part[1][lane], c = part[2][lane];
+    s.x = (s.x + a.x) + (b.x + c.x); s.y = (s.y + a.y) + (b.y + c.y);
+    s.z = (s.z + a.z) + (b.z + c.z); s.w = (s.w + a.w) + (b.w + c.w);
     if (Zact) {
       const float4 y = reinterpret_cast<const float4 *>(Zact)[i];
       s.x *= rk_act_dy(y.x, act); s.y *= rk_act_dy(y.y, act);
@@ -770,9 +804,8 @@ extern "C" int rk_decode_bwd_dz(const float *dO, int32_t B, int32_t h, const rk_
   if (tn == 2) LAUNCH(2); else if (tn == 4) LAUNCH(4); else if (tn == 7) LAUNCH(7); else LAUNCH(8);
 #undef LAUNCH
   RK_CHECK_LAUNCH("decode_bwd_dz");
-  int grid = rk_cdiv((int64_t)B * h / 4, 64);
-  if (grid > 4096) grid = 4096;
-  RK_LAUNCH_ORDERED(splitk_reduce_kernel, dim3(grid), dim3(64), 0, stream, workspace, B, h,
+  const int grid = rk_cdiv((int64_t)B * h / 4, 64);
+  RK_LAUNCH(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, workspace, B, h,
                      tgt->counts, kchunk, splits, Zact, act, dZ);
   RK_CHECK_LAUNCH("splitk_reduce");
   return 0;
@@ -802,6 +835,39 @@ extern "C" int rk_decode_bwd_dw(const float *dO, const float *Z, int32_t B, int3
   }
   RK_CHECK_LAUNCH("decode_bwd_dw");
   if (gb_de) return rk_colsum(dO, B, tgt->n_cap, 0, tgt->counts, gb_de, stream_);
+  return 0;
+}
+
+// rk_decode_bwd_dw + rk_ae_encode_bwd (untied weights, same block) in one launch
+extern "C" int rk_decode_bwd_dw_encode_bwd(const float *dO, const float *Z, int32_t B, int32_t h,
+                                           const rk_block_t *blk, float *G_de, int32_t row_off,
+                                           const float *dZ0pre, float *G_en, float *gb_en,
+                                           void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(h > 0 && h % 4 == 0 && h <= 1024, "h must be a multiple of 4, <= 1024");
+  RK_REQUIRE(aligned16(dO) && aligned16(Z) && aligned16(G_de), "operands must be 16-byte aligned");
+  RK_REQUIRE(row_off >= 0 && B >= 0 && row_off + B <= blk->S_cap, "row slice out of range");
+  RK_REQUIRE(blk->bits_cr != nullptr && blk->pref_rc != nullptr,
+             "block was built without the transposed bitmap / prefix index");
+  if (B == 0) return 0;
+  GemmP p = {};
+  p.A = dO; p.lda_dev = blk->counts + 2;
+  p.Bm = Z; p.ldb = h;
+  p.M = blk->n_cap; p.Mdev = blk->counts; p.N = h; p.K = B;
+  p.kchunk = B;
+  p.C = G_de; p.ldc = h; p.act = RK_ACT_NONE;
+  p.tiles_m = rk_cdiv(blk->n_cap, 32);
+  p.n_fastest = 1;
+  const int n_dw = rk_cdiv(p.tiles_m * rk_cdiv(h, 128), 8) * 8;
+  const int n_gb = gb_en ? rk_cdiv(h, 64) : 0;
+  const int grid = n_dw + blk->n_cap + n_gb;
+  const int hv = rk_cdiv(h, 256);
+#define LAUNCH(HV)                                                                             \
+  RK_LAUNCH(dw_encode_bwd_kernel<HV>, dim3(grid), dim3(256), 0, stream, p, n_dw, *blk, row_off, B, \
+            dZ0pre, h, G_en, gb_en, n_gb)
+  if (hv == 1) LAUNCH(1); else if (hv == 2) LAUNCH(2); else LAUNCH(4);
+#undef LAUNCH
+  RK_CHECK_LAUNCH("decode_bwd_dw_encode_bwd");
   return 0;
 }
 

@@ -109,7 +109,10 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
                             a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, sm));
       if (mnll) RK_TRY(rk_mnll_finish(a->dO, B, blk, a->row_off, a->inv_B, a->loss_part, sm));
     }
-    {
+    // dW: on its own (tied weights: the encoder backward accumulates onto its rows;
+    // MNLL: + column sums of dO; data parallel: G_de must travel early), otherwise
+    // fused with the encoder backward below
+    if (a->tied || mnll || !whole) {
       Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
       RK_TRY(rk_decode_bwd_dw(a->dO, a->Z0, B, h, blk, a->G_de, mnll ? a->gb_de : nullptr, sm));
     }
@@ -124,9 +127,13 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       Timer t(a, RK_ENTRY_DECODE_BWD_DZ, sm);
       RK_TRY(rk_decode_bwd_dz(a->dO, B, h, blk, W_de, a->Z0, a->act, a->dZ0, a->ws, sm));
     }
-    {
+    if (a->tied || mnll || !whole) {
       Timer t(a, RK_ENTRY_ENCODE_BWD, sm);
       RK_TRY(rk_ae_encode_bwd(blk, a->row_off, B, a->dZ0, h, G_en, a->tied ? 1 : 0, a->gb_en, sm));
+    } else {
+      Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
+      RK_TRY(rk_decode_bwd_dw_encode_bwd(a->dO, a->Z0, B, h, blk, a->G_de, a->row_off, a->dZ0, G_en,
+                                         a->gb_en, sm));
     }
   }
   if (phase & RK_STEP_UPDATE) {

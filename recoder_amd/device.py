@@ -102,6 +102,7 @@ class Block:
     self.bits_cr = torch.zeros(self.n_cap * self.ldw_cr, **i32) if need_bits_cr else None
     self.scan_tmp = torch.zeros(self.n_chunks + 1, **i32)
     self.pref_rc = torch.zeros(S_cap * self.ldw_rc, **i32)
+    self.gcols = torch.zeros(nnz_cap, **i32)
     self.stamp = 0
     self.users = None      # int64 device tensor of the rows of the last collate
     self.S = 0
@@ -111,7 +112,7 @@ class Block:
         counts=ptr(self.counts), indptr=ptr(self.indptr), cols=ptr(self.cols),
         vals=ptr(self.vals), svals=ptr(self.svals), items=ptr(self.items), pos=ptr(self.pos),
         mark=ptr(self.mark), bits_rc=ptr(self.bits_rc), bits_cr=ptr(self.bits_cr),
-        scan_tmp=ptr(self.scan_tmp), pref_rc=ptr(self.pref_rc))
+        scan_tmp=ptr(self.scan_tmp), pref_rc=ptr(self.pref_rc), gcols=ptr(self.gcols))
     self.ref = ctypes.byref(self.c)
 
   def collate(self, dcsr, users_dev, negative_sampling=None, phase=0):
@@ -168,49 +169,64 @@ class Block:
 
 
 class CollatePrefetcher:
-  """Double-buffered collation on a side HIP stream: the block of step k+1 is
-  collated while step k trains (the reference gets the same overlap from its
-  DataLoader worker processes, data.py:135-136)."""
+  """Double-buffered collation on a side HIP stream: the blocks of the next
+  `group` steps are collated while the current ones train (the reference gets the
+  same overlap from its DataLoader worker processes, data.py:135-136).
 
-  def __init__(self, make_block, dcsr, device=None, collate_fn=None):
+  Each of the two slots holds `group` blocks and ONE pair of events: a
+  cross-stream dependency costs 10-20 us of latency on the stream it lands on
+  (tools/sync_cost2.py), so the hand-over is paid once per `group` steps instead
+  of once per step."""
+
+  def __init__(self, make_block, dcsr, device=None, collate_fn=None, group=1):
     self.device = device or require_gpu()
     self.dcsr = dcsr
-    self.blocks = [make_block(), make_block()]
+    self.group = int(group)
+    self.blocks = [[make_block() for _ in range(self.group)] for _ in range(2)]
     self.stream = torch.cuda.Stream(device=self.device)
     self.ready = [torch.cuda.Event(), torch.cuda.Event()]
     self.free = [torch.cuda.Event(), torch.cuda.Event()]
     self._used = [False, False]
+    self._count = [0, 0]
     self.collate_fn = collate_fn      # e.g. DataParallel.collate (two-phase, union item set)
 
-  def submit(self, slot, users_dev):
-    """Enqueue the collation of `users_dev` into buffer `slot` on the side stream."""
-    blk = self.blocks[slot]
+  def reset(self):
+    """Forget the hand-over state (a consumer abandoned its slots): the next
+    submits order themselves after everything enqueued on the current stream."""
+    self._used = [False, False]
+
+  def submit(self, slot, users_list):
+    """Enqueue the collation of up to `group` user batches into the blocks of
+    `slot` on the side stream."""
+    assert 0 < len(users_list) <= self.group
     main = torch.cuda.current_stream()
     with torch.cuda.stream(self.stream):
       if self._used[slot]:
-        self.stream.wait_event(self.free[slot])      # previous consumer of this buffer is done
+        self.stream.wait_event(self.free[slot])      # previous consumer of these buffers is done
       else:
         self.stream.wait_stream(main)                # first use: order after setup work
-      if self.collate_fn is not None:
-        self.collate_fn(blk, self.dcsr, users_dev)
-      else:
-        blk.collate(self.dcsr, users_dev)
-      # the device-resident counts also go to pinned host memory: consumers that need
-      # n_b on the host (RCCL message sizes) read it later without stalling a stream
-      if getattr(blk, "counts_pinned", None) is None:
-        blk.counts_pinned = torch.zeros(4, dtype=torch.int32).pin_memory()
-        blk.counts_event = torch.cuda.Event()
-      blk.counts_pinned.copy_(blk.counts, non_blocking=True)
-      blk.counts_event.record(self.stream)
+      for blk, users_dev in zip(self.blocks[slot], users_list):
+        if self.collate_fn is not None:
+          self.collate_fn(blk, self.dcsr, users_dev)
+        else:
+          blk.collate(self.dcsr, users_dev)
+        # the device-resident counts also go to pinned host memory: consumers that need
+        # n_b on the host (RCCL message sizes) read it later without stalling a stream
+        if getattr(blk, "counts_pinned", None) is None:
+          blk.counts_pinned = torch.zeros(4, dtype=torch.int32).pin_memory()
+          blk.counts_event = torch.cuda.Event()
+        blk.counts_pinned.copy_(blk.counts, non_blocking=True)
+        blk.counts_event.record(self.stream)
       self.ready[slot].record(self.stream)
-    return blk
+    self._count[slot] = len(users_list)
+    return self.blocks[slot][:len(users_list)]
 
   def acquire(self, slot):
-    """Make the current stream wait for buffer `slot`; returns the block."""
+    """Make the current stream wait for the blocks of `slot`; returns them."""
     torch.cuda.current_stream().wait_event(self.ready[slot])
-    return self.blocks[slot]
+    return self.blocks[slot][:self._count[slot]]
 
   def release(self, slot):
-    """Call after the last kernel reading buffer `slot` was enqueued."""
+    """Call after the last kernel reading the blocks of `slot` was enqueued."""
     self.free[slot].record(torch.cuda.current_stream())
     self._used[slot] = True

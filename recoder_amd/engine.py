@@ -99,7 +99,7 @@ class FusedEngine:
     self.allreduce = None                  # callable(list of tensors) for data parallel
     self.use_c_step = True                 # one-FFI-call step driver (rk_ae_train_step)
     self.time_entry = None                 # C-ABI entry name to bracket with events (bench)
-    self.time_every = 4                    # ... on every time_every-th step
+    self.time_every = 8                    # ... on every time_every-th step
     self._gb_lazy = None
     self._cstep = None
     if kind == "ae":
@@ -653,6 +653,7 @@ def ae_dense_forward(model, x, input_items=None, target_items=None):
   blk.collate(dcsr, users, negative_sampling=False)
   if input_items is not None:
     blk.items[:n_in].copy_(input_items.to(dev).to(torch.int32))
+    blk.c.gcols = None        # the per-entry global ids of the collation no longer apply
   n_items = model.num_items
   if target_items is not None:
     t = target_items.to(dev).to(torch.int32).contiguous()

@@ -69,6 +69,8 @@ class Recoder(object):
     self.users = None
     self.user_order_hook = None
     self.mask_hook = None
+    # steps collated per side-stream hand-over (CollatePrefetcher)
+    self.prefetch_group = int(os.environ.get("RK_PREFETCH_GROUP", "4"))
     self.last_epoch_losses = None
     self.loss_history = []      # per-epoch arrays of the per-step training losses
     self.__model_initialized = False
@@ -342,14 +344,16 @@ class Recoder(object):
     dcsr = ds.device_csr()
     B, S = dataloader.batch_size, dataloader.num_sampling_users
     pf = getattr(self, "_train_pf", None)
-    if pf is None or pf.dcsr is not dcsr or pf.blocks[0].S_cap < S or \
-        pf.blocks[0].negative_sampling != dataloader.negative_sampling:
+    if pf is None or pf.dcsr is not dcsr or pf.blocks[0][0].S_cap < S or \
+        pf.blocks[0][0].negative_sampling != dataloader.negative_sampling:
       from .device import CollatePrefetcher
       ns = dataloader.negative_sampling
       dp = getattr(self, "_dp", None)
       pf = CollatePrefetcher(lambda: self._make_block(dcsr, S, ns), dcsr, self.device,
-                             collate_fn=(dp.collate if dp is not None else None))
+                             collate_fn=(dp.collate if dp is not None else None),
+                             group=self.prefetch_group)
       self._train_pf = pf
+    pf.reset()
     n = len(ds)
     order = None
     if self.user_order_hook is not None:
@@ -361,24 +365,27 @@ class Recoder(object):
       n = len(order)
     order_dev = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int64)).to(self.device)
     offs = [o for o in range(0, n, S) if order_dev[o:o + S].numel() > 0]
-    # the group after the current one is collated on the prefetcher's side stream
-    if offs:
-      pf.submit(0, order_dev[offs[0]:offs[0] + S])
-    for gi, off in enumerate(offs):
-      slot = gi % 2
-      if gi + 1 < len(offs):
-        pf.submit((gi + 1) % 2, order_dev[offs[gi + 1]:offs[gi + 1] + S])
-      blk = pf.acquire(slot)
-      Sg = int(order_dev[off:off + S].numel())
-      keep_noise = keep_drop = None
-      if self.mask_hook is not None:
-        keep_noise, keep_drop = self.mask_hook(self._global_step, order[off:off + S])
-      for r in range(0, Sg, B):
-        rows = min(B, Sg - r)
-        kd = None
-        if keep_drop is not None:
-          kd = keep_drop[r:r + rows].contiguous()
-        yield blk, r, rows, keep_noise, kd
+    G = pf.group
+    chunks = [offs[i:i + G] for i in range(0, len(offs), G)]
+    users_of = lambda chunk: [order_dev[o:o + S] for o in chunk]
+    # the chunk after the current one is collated on the prefetcher's side stream
+    if chunks:
+      pf.submit(0, users_of(chunks[0]))
+    for ci, chunk in enumerate(chunks):
+      slot = ci % 2
+      if ci + 1 < len(chunks):
+        pf.submit((ci + 1) % 2, users_of(chunks[ci + 1]))
+      for blk, off in zip(pf.acquire(slot), chunk):
+        Sg = int(order_dev[off:off + S].numel())
+        keep_noise = keep_drop = None
+        if self.mask_hook is not None:
+          keep_noise, keep_drop = self.mask_hook(self._global_step, order[off:off + S])
+        for r in range(0, Sg, B):
+          rows = min(B, Sg - r)
+          kd = None
+          if keep_drop is not None:
+            kd = keep_drop[r:r + rows].contiguous()
+          yield blk, r, rows, keep_noise, kd
       pf.release(slot)
 
   def _train(self, train_dataloader, val_dataloader, num_epochs, current_epoch, lr_scheduler,
