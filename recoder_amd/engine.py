@@ -503,6 +503,22 @@ class FusedEngine:
     ld = blk.counts_host()[2]
     return self.gb_part[:tiles * ld].view(tiles, ld)[:, :n_b].sum(0)
 
+  def event_pair_overhead_ms(self, n=64):
+    """Elapsed time of a timing-event pair with nothing between the two records."""
+    raw = _lib.load()
+    hip = ctypes.CDLL("libamdhip64.so")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    pairs = [(raw.rk_timing_event_create(), raw.rk_timing_event_create()) for _ in range(n)]
+    torch.cuda.synchronize()
+    for e0, e1 in pairs:
+      hip.hipEventRecord(ctypes.c_void_p(e0), st)
+      hip.hipEventRecord(ctypes.c_void_p(e1), st)
+    ms = sorted(raw.rk_event_elapsed_ms(e0, e1) for e0, e1 in pairs)
+    for e0, e1 in pairs:
+      raw.rk_event_destroy(e0)
+      raw.rk_event_destroy(e1)
+    return float(ms[len(ms) // 2])
+
   def timed_entry_ms(self):
     """Per-launch durations (ms) of the bracketed entry since timing was enabled."""
     raw = _lib.load()

@@ -1,0 +1,16 @@
+#!/bin/bash
+# usage (on the GPU box): tools/profile_round.sh <tag>
+# kernel-trace stats + the two PMC traffic passes of the default bench -> gpurun_out/<tag>/
+tag=${1:-prof}
+export TMPDIR=/tmp
+out=$GRAFT_REPO_ROOT/gpurun_out/$tag
+rm -rf $out; mkdir -p $out
+B="python bench.py --steps 200 --warmup 20 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format rocpd -d $out -o stats -- $B > $out/stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format rocpd -d $out -o fetch -- $B > $out/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format rocpd -d $out -o write -- $B > $out/write.log 2>&1
+python tools/rocpd_stats.py $(find $out -name 'stats_results.db') > $out/kernel_stats.md
+python tools/pmc_traffic.py $(find $out -name 'fetch_results.db') $(find $out -name 'write_results.db') > $out/pmc_traffic.json
+python tools/rocpd_timeline.py $(find $out -name 'stats_results.db') 150 > $out/timeline.txt
+grep metric $out/stats.log > $out/bench_profiled.json
+cat $out/kernel_stats.md; cat $out/pmc_traffic.json; cat $out/timeline.txt
