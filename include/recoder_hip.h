@@ -99,6 +99,16 @@ int rk_collate(const int64_t *ds_indptr, const int32_t *ds_indices,
                void *stream);
 
 /*
+ * rk_densify -- rows [row_off, row_off+B) of a collated block as a dense
+ * [B, ld] fp32 matrix with n live columns (model.py:457-458, the reference's
+ * `torch.sparse.FloatTensor(indices, values, size).to_dense()`).  The fused path
+ * never densifies; this feeds the generic torch-autograd path (user-defined
+ * FactorizationModel subclasses, nn.Module losses, sgd/adagrad/rmsprop).
+ */
+int rk_densify(const rk_block_t *blk, int32_t row_off, int32_t B, int32_t n,
+               float *out, int32_t ld, void *stream);
+
+/*
  * rk_ae_encode_fwd -- DynamicAutoencoder.forward first layer (nn.py:235-240):
  * F.normalize(p=2,dim=1) -> input dropout -> LinearEmbedding(input_based)
  * (nn.py:269-278) -> activation, as one CSR x embedding SpMM over rows

@@ -260,6 +260,32 @@ __global__ __launch_bounds__(256) void collate_build_kernel(
 
 }  // namespace
 
+// ---- densify: rows [row_off, row_off+B) of the block as a dense [B, ld] fp32 matrix
+//      (model.py:457-458 `torch.sparse.FloatTensor(...).to_dense()`); only the generic
+//      torch-autograd path (user-defined models / losses / optimizers) needs it ----
+namespace {
+__global__ __launch_bounds__(256) void densify_kernel(rk_block_t b, int row_off, int n, int ld,
+                                                      float *__restrict__ out) {
+  const int r = blockIdx.x;
+  float *orow = out + (int64_t)r * ld;
+  for (int c = threadIdx.x; c < n; c += 256) orow[c] = 0.f;
+  __syncthreads();
+  const int beg = b.indptr[row_off + r], end = b.indptr[row_off + r + 1];
+  for (int j = beg + threadIdx.x; j < end; j += 256) orow[b.cols[j]] = b.vals[j];
+}
+}  // namespace
+
+extern "C" int rk_densify(const rk_block_t *blk, int32_t row_off, int32_t B, int32_t n, float *out,
+                          int32_t ld, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(row_off >= 0 && B >= 0 && row_off + B <= blk->S_cap, "row slice out of range");
+  RK_REQUIRE(n >= 0 && n <= ld, "n must not exceed the leading dimension");
+  if (B == 0 || n == 0) return 0;
+  RK_LAUNCH(densify_kernel, dim3(B), dim3(256), 0, stream, *blk, row_off, n, ld, out);
+  RK_CHECK_LAUNCH("densify");
+  return 0;
+}
+
 extern "C" int rk_collate(const int64_t *ds_indptr, const int32_t *ds_indices,
                           const float *ds_data, const int64_t *users, int32_t S,
                           int32_t negative_sampling, int32_t stamp, int32_t phase,

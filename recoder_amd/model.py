@@ -93,13 +93,20 @@ class Recoder(object):
       return "ae"
     if isinstance(self.model, MatrixFactorization):
       return "mf"
-    raise NotImplementedError(
-        "only DynamicAutoencoder and MatrixFactorization have HIP kernels; user-defined "
-        "FactorizationModel subclasses are outside this build's hot path")
+    return None
+
+  def _use_generic(self):
+    """True when the combination has no fused HIP step and trains through torch
+    autograd on the GPU instead (recoder_amd/generic.py): user-defined
+    FactorizationModel subclasses, arbitrary nn.Module losses, sgd/adagrad/rmsprop."""
+    named = isinstance(self.loss, str) or isinstance(
+        self.loss, (MSELoss, MultinomialNLLLoss, torch.nn.BCEWithLogitsLoss))
+    return self._fused_kind() is None or not named or self.optimizer_type != "adam"
 
   def __init_loss_module(self):
     """model.py:87-99 -- same names, same errors."""
     if issubclass(self.loss.__class__, torch.nn.Module):
+      self.loss_module = self.loss
       if isinstance(self.loss, MSELoss):
         self._loss_name, self._loss_params = "mse", {"confidence": self.loss.confidence}
       elif isinstance(self.loss, MultinomialNLLLoss):
@@ -107,20 +114,20 @@ class Recoder(object):
       elif isinstance(self.loss, torch.nn.BCEWithLogitsLoss):
         self._loss_name, self._loss_params = "logistic", {}
       else:
-        raise NotImplementedError(
-            "arbitrary loss modules are outside this build's fused hot path; use 'mse', "
-            "'logistic', 'logloss' or recoder_amd.losses.MSELoss / MultinomialNLLLoss")
+        self._loss_name, self._loss_params = None, {}       # generic path only
     elif self.loss == "logistic":
       self._loss_name, self._loss_params = "logistic", dict(self.loss_params)
+      self.loss_module = torch.nn.BCEWithLogitsLoss(reduction="sum", **self.loss_params)
     elif self.loss == "mse":
       self._loss_name, self._loss_params = "mse", dict(self.loss_params)
+      self.loss_module = MSELoss(reduction="sum", **self.loss_params)
     elif self.loss == "logloss":
       self._loss_name, self._loss_params = "logloss", {}
+      self.loss_module = MultinomialNLLLoss(reduction="sum")
     elif self.loss is None:
       raise ValueError("No loss function defined")
     else:
       raise ValueError("Unknown loss function {}".format(self.loss))
-    self.loss_module = self.loss
 
   def __init_optimizer(self, lr, weight_decay):
     """model.py:101-164: dense / sparse parameter split, one group per tensor,
@@ -150,12 +157,16 @@ class Recoder(object):
       if len(sparse_params) > 0:
         self.sparse_optimizer = optim.SparseAdam(sparse_params, lr=lr)
     elif self.optimizer_type in ("adagrad", "sgd", "rmsprop"):
+      # model.py:140-154; these run through torch on the GPU (generic path)
       if len(sparse_params) > 0:
         raise ValueError("Sparse gradients optimization not supported with {}"
                          .format(self.optimizer_type))
-      raise NotImplementedError(
-          "optimizer_type='{}' has no HIP kernel in this build (the hot path is Adam / "
-          "SparseAdam, model.py:135,138)".format(self.optimizer_type))
+      if self.optimizer_type == "adagrad":
+        self.optimizer = optim.Adagrad(params, lr=lr)
+      elif self.optimizer_type == "sgd":
+        self.optimizer = optim.SGD(params, lr=lr, momentum=0.9)
+      else:
+        self.optimizer = optim.RMSprop(params, lr=lr, momentum=0.9)
     else:
       raise Exception("Unknown optimizer kind")
 
@@ -170,8 +181,12 @@ class Recoder(object):
   def _engine(self):
     if self.__engine is None:
       self.__init_loss_module()
-      self.__engine = FusedEngine(self.model, self._fused_kind(), self._loss_name,
-                                  self._loss_params, self.device)
+      if self._use_generic():
+        from .generic import GenericEngine
+        self.__engine = GenericEngine(self.model, self.loss_module, self.device)
+      else:
+        self.__engine = FusedEngine(self.model, self._fused_kind(), self._loss_name,
+                                    self._loss_params, self.device)
     return self.__engine
 
   # ------------------------------------------------------------ checkpoint
@@ -313,9 +328,10 @@ class Recoder(object):
       return train_dataset
     if dist.get_world_size() == 1 and os.environ.get("RK_FORCE_DP") != "1":
       return train_dataset
-    if self._fused_kind() != "ae":
-      raise NotImplementedError("data-parallel training is implemented for DynamicAutoencoder; "
-                                "MatrixFactorization user rows are rank-private (DESIGN.md section 6)")
+    if self._use_generic() or self._fused_kind() != "ae":
+      raise NotImplementedError("data-parallel training is implemented for the fused "
+                                "DynamicAutoencoder path; MatrixFactorization user rows are "
+                                "rank-private (DESIGN.md section 6)")
     from .parallel import DataParallel, shard_range
     dp = DataParallel()
     for p_ in self.model.parameters():          # identical replicas: rank 0's initial weights

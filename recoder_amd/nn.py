@@ -14,7 +14,23 @@ hands the tensors to the HIP kernels (recoder_amd.engine); training goes through
 import torch
 from torch import nn
 
+import torch.nn.functional as F
+
 _ACTS = ("none", "tanh", "sigmoid", "relu", "selu", "elu")
+
+
+def _activate(x, act):
+  return x if act == "none" else getattr(torch, act)(x)
+
+
+def _embedding_linear(table, bias, ids, x, input_based, sparse):
+  """LinearEmbedding (nn.py:269-280) in torch ops: a linear layer whose weight is the
+  row subset ``ids`` of an embedding table (all rows when ids is None)."""
+  w = table.weight if ids is None else F.embedding(ids, table.weight, sparse=sparse)
+  if input_based:
+    return F.linear(x, w.t(), bias)
+  b = bias if ids is None or bias is None else bias.index_select(0, ids)
+  return F.linear(x, w, b)
 
 
 class FactorizationModel(nn.Module):
@@ -147,6 +163,27 @@ class DynamicAutoencoder(FactorizationModel):
     from .engine import ae_dense_forward
     return ae_dense_forward(self, input, input_items, target_items)
 
+  def torch_forward(self, input, input_users=None, input_items=None, target_users=None,
+                    target_items=None):
+    """The same forward in differentiable torch ops (on the GPU).  Only the generic
+    path of Recoder uses it: nn.Module losses and the sgd/adagrad/rmsprop optimizers
+    have no fused kernels and train through autograd (recoder_amd/generic.py)."""
+    act, nl = self.activation_type, len(self.hidden_layers) - 1
+    z = F.normalize(input, p=2, dim=1)
+    if self.noise_layer is not None:
+      z = self.noise_layer(z)
+    z = _activate(_embedding_linear(self.en_embedding_layer, self.en_bias, input_items, z, True,
+                                    self.sparse), act)
+    for layer in self.encoding_layers:
+      z = _activate(layer(z), act)
+    if self.dropout_layer is not None:
+      z = self.dropout_layer(z)
+    for i, layer in enumerate(self.decoding_layers):
+      w = self.encoding_layers[nl - 1 - i].weight.t() if self.is_constrained else layer.weight
+      z = _activate(F.linear(z, w, layer.bias), act)
+    return _embedding_linear(self.de_embedding_layer, self.de_bias, target_items, z, False,
+                             self.sparse)
+
 
 class MatrixFactorization(FactorizationModel):
   """Matrix factorization (nn.py:283-362): act(E_u[users]) . E_i[T]^T + b[T]."""
@@ -192,3 +229,14 @@ class MatrixFactorization(FactorizationModel):
               target_items=None):
     from .engine import mf_dense_forward
     return mf_dense_forward(self, input_users, target_items)
+
+  def torch_forward(self, input, input_users=None, input_items=None, target_users=None,
+                    target_items=None):
+    """Differentiable torch-op forward for the generic path (see DynamicAutoencoder)."""
+    u = _activate(self.user_embedding_layer(input_users), self.activation_type)
+    if self.dropout_layer is not None:
+      u = self.dropout_layer(u)
+    if target_items is None:
+      return F.linear(u, self.item_embedding_layer.weight, self.bias)
+    return F.linear(u, self.item_embedding_layer(target_items),
+                    self.bias.index_select(0, target_items))
