@@ -317,6 +317,25 @@ class Recoder(object):
                 eval_num_recommendations=eval_num_recommendations,
                 iters_per_epoch=iters_per_epoch, eval_num_users=eval_num_users,
                 eval_batch_size=eval_batch_size)
+    self._sync_user_rows()
+
+  def _sync_user_rows(self):
+    """MatrixFactorization under data parallelism: user rows are rank-private while
+    training (only the owner sees their gradients); bring every replica up to date --
+    parameters and Adam moments -- so that the result equals the single-process run
+    with batch_size = N * B (called at the end of train() and before evaluation)."""
+    if getattr(self, "_dp", None) is None or self._fused_kind() != "mf":
+      return
+    from .parallel import sync_owned_rows
+    w = self.model.user_embedding_layer.weight
+    tensors = [w.data]
+    for opt in (self.optimizer, self.sparse_optimizer):
+      st = opt.state.get(w) if opt is not None else None
+      if st:
+        tensors += [st["exp_avg"], st["exp_avg_sq"]]
+    if self._dp_n_users < w.shape[0]:
+      tensors = [t[:self._dp_n_users] for t in tensors]
+    sync_owned_rows(tensors, self._dp_n_users, self._dp.group)
 
   def _setup_data_parallel(self, train_dataset):
     """Under an initialised torch.distributed group (one process per GPU, backend
@@ -328,10 +347,9 @@ class Recoder(object):
       return train_dataset
     if dist.get_world_size() == 1 and os.environ.get("RK_FORCE_DP") != "1":
       return train_dataset
-    if self._use_generic() or self._fused_kind() != "ae":
+    if self._use_generic():
       raise NotImplementedError("data-parallel training is implemented for the fused "
-                                "DynamicAutoencoder path; MatrixFactorization user rows are "
-                                "rank-private (DESIGN.md section 6)")
+                                "DynamicAutoencoder / MatrixFactorization paths")
     from .parallel import DataParallel, shard_range
     dp = DataParallel()
     for p_ in self.model.parameters():          # identical replicas: rank 0's initial weights
@@ -340,6 +358,8 @@ class Recoder(object):
     self._dp = dp
     n = len(train_dataset)
     lo, hi = shard_range(n, dp.rank, dp.world)
+    dp.user_offset = lo
+    self._dp_n_users = n
     shard = RecommendationDataset(train_dataset.interactions_matrix[lo:hi])
     # every rank runs the same number of equally sized steps (collectives in lockstep)
     self._dp_users_per_epoch = n // dp.world
@@ -443,6 +463,7 @@ class Recoder(object):
       self.loss_history.append(self.last_epoch_losses)
       postfix = {"loss": float(self.last_epoch_losses[-1]) if n_done else float("nan")}
       if eval_freq > 0 and epoch % eval_freq == 0 and val_dataloader is not None:
+        self._sync_user_rows()
         postfix["val_loss"] = self._validate(val_dataloader)
         if metrics is not None and eval_num_recommendations is not None:
           results = self._evaluate(val_dataloader.dataset,
@@ -455,6 +476,7 @@ class Recoder(object):
       self.last_epoch_summary = postfix
       if model_checkpoint_prefix and \
           ((checkpoint_freq > 0 and epoch % checkpoint_freq == 0) or epoch == num_epochs):
+        self._sync_user_rows()
         self.save_state(model_checkpoint_prefix)
 
   def _validate(self, val_dataloader):

@@ -56,6 +56,20 @@ def allreduce_sum(views, group=None, small_threshold=65536):
       off += n
 
 
+def sync_owned_rows(tensors, n_rows, group=None):
+  """Each rank owns the contiguous row range shard_range(n_rows, rank, world) of every
+  tensor in ``tensors`` (first dimension n_rows): after the call every replica holds the
+  owners' rows.  MatrixFactorization under data parallelism: a user's embedding row (and
+  its optimizer moments) only receives gradients on the rank that holds the user."""
+  world = dist.get_world_size(group)
+  for r in range(world):
+    lo, hi = shard_range(n_rows, r, world)
+    if hi > lo:
+      for t in tensors:
+        dist.broadcast(t[lo:hi], src=r if group is None else dist.get_global_rank(group, r),
+                       group=group)
+
+
 class DataParallel:
   """Glue between a FusedEngine and torch.distributed."""
 
@@ -64,12 +78,17 @@ class DataParallel:
     self.group = group
     self.rank = dist.get_rank(group)
     self.world = dist.get_world_size(group)
+    self.user_offset = 0          # first global user id of this rank's shard
 
   def collate(self, blk, dcsr, users_dev):
-    """Two-phase collation with the union item set."""
+    """Two-phase collation with the union item set.  ``users_dev`` are rows of this
+    rank's shard; the block carries their GLOBAL ids (MatrixFactorization looks its
+    user rows up by them, the dropout RNG is keyed on them)."""
     blk.collate(dcsr, users_dev, phase=1)
     union_marks(blk.mark, self.group)
     blk.collate(dcsr, users_dev, phase=2)
+    if self.user_offset:
+      blk.users = users_dev + self.user_offset
 
   def attach(self, engine):
     """Install the gradient exchange on a FusedEngine.  The engine calls

@@ -521,19 +521,22 @@ def test_dataframe_to_csr_matrix_contract():
   assert m2.shape == m.shape
 
 
-def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch):
+@pytest.mark.parametrize("kind", ["ae", "mf", "mf_sparse"])
+def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind):
   """Recoder.train under an initialised torch.distributed group (RCCL, 1 rank):
   two-phase collation + all-reduced gradients must reproduce the plain run."""
   import torch.distributed as dist
   from recoder_amd.data import RecommendationDataset
   from recoder_amd.model import Recoder
   csr = synth_csr(1200, 2500, 25, seed=9)
-  c = STEP_CASES[0][1]
+  c = STEP_CASES[0][1] if kind == "ae" else dict(kind="mf", embedding_size=32,
+                                                 activation_type="tanh", sparse=(kind == "mf_sparse"))
 
   def run(dp):
     torch.manual_seed(11)
     model = make_model(c)
-    rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss="mse")
+    rec = Recoder(model=model, use_cuda=True, optimizer_type="adam",
+                  loss="mse" if kind == "ae" else "logistic")
     rec.user_order_hook = lambda epoch, n: np.arange(n, dtype=np.int64)
     rec.train(RecommendationDataset(csr), batch_size=300, lr=1e-3, weight_decay=2e-5, num_epochs=2,
               negative_sampling=True)
@@ -543,7 +546,7 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch):
   base_l, base_p = run(False)
   monkeypatch.setenv("RK_FORCE_DP", "1")
   monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
-  monkeypatch.setenv("MASTER_PORT", "29577")
+  monkeypatch.setenv("MASTER_PORT", str(29577 + ["ae", "mf", "mf_sparse"].index(kind)))
   dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
   try:
     dp_l, dp_p = run(True)

@@ -121,6 +121,95 @@ def test_two_rank_data_parallel_equals_single_process(tmp_path):
     assert torch.allclose(got["state"][k], v, rtol=1e-4, atol=1e-6), k
 
 
+def _mf_worker(rank, world, port, out):
+  sys.path.insert(0, ROOT)
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  torch.set_num_threads(1)
+  from oracle import recoder_oracle as orc
+  from recoder_amd.parallel import allreduce_sum, shard_range, sync_owned_rows, union_marks
+
+  n_users, n_items, B, d = 64, 90, 8, 10
+  csr = _csr(n_users, n_items, 6)
+  torch.manual_seed(4)
+  st0 = orc.init_mf_state(n_items, n_users, d)
+  o = orc.OracleRecoder("mf", st0, activation_type="tanh", loss="logistic", lr=1e-2,
+                        weight_decay=1e-4)
+  lo, hi = shard_range(n_users, rank, world)
+  shard = csr[lo:hi]
+  mark = torch.zeros(n_items, dtype=torch.int32)
+  losses = []
+  for step in range(3):
+    users = np.arange(step * B, (step + 1) * B)
+    rows = shard[users]
+    stamp = step + 1
+    mark[torch.from_numpy(np.unique(rows.indices).astype(np.int64))] = stamp
+    union_marks(mark)
+    items = np.nonzero(mark.numpy() == stamp)[0].astype(np.int64)
+    pos = np.full(n_items, -1, dtype=np.int64)
+    pos[items] = np.arange(len(items))
+    coo = rows.tocoo()
+    batch = orc.Batch(users=users + lo, items=items,
+                      indices=np.stack([coo.row.astype(np.int64), pos[coo.col]]),
+                      values=coo.data.astype(np.float32), size=(B, len(items)))
+    o.optimizer.zero_grad()
+    out_, t = o.forward(batch)
+    loss = o._loss(out_, t) / torch.FloatTensor([B * world])
+    loss.backward()
+    # item rows + gathered bias + loss are summed over the ranks; user rows stay private
+    idx = torch.from_numpy(items)
+    tables = []
+    for name in ("item_embedding_layer.weight", "bias"):
+      p = o.params[name]
+      tables.append((p, p.grad[idx].contiguous()))
+    lt = loss.detach().clone()
+    allreduce_sum([r for _, r in tables] + [lt], small_threshold=64)
+    for p, r in tables:
+      p.grad.zero_()
+      p.grad[idx] = r
+    o.optimizer.step()
+    losses.append(float(lt))
+  # owners publish their user rows (parameters and Adam moments)
+  w = o.params["user_embedding_layer.weight"]
+  st = o.optimizer.state[w]
+  sync_owned_rows([w.data, st["exp_avg"], st["exp_avg_sq"]], n_users)
+  if rank == 1:
+    torch.save({"losses": losses, "state": {k: v.detach() for k, v in o.params.items()},
+                "m": st["exp_avg"].clone(), "v": st["exp_avg_sq"].clone()}, out)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_rank_matrix_factorization_private_user_rows(tmp_path):
+  """MF under data parallelism: item table + bias all-reduced, user rows rank-private and
+  published by their owners at the end == single process with batch_size = N * B."""
+  from oracle import recoder_oracle as orc
+  from recoder_amd.parallel import shard_range
+  world = 2
+  out = str(tmp_path / "dp_mf.pt")
+  mp.spawn(_mf_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+  got = torch.load(out, weights_only=False)
+  n_users, n_items, B, d = 64, 90, 8, 10
+  csr = _csr(n_users, n_items, 6)
+  torch.manual_seed(4)
+  st0 = orc.init_mf_state(n_items, n_users, d)
+  o = orc.OracleRecoder("mf", st0, activation_type="tanh", loss="logistic", lr=1e-2,
+                        weight_decay=1e-4)
+  ref_losses = []
+  for step in range(3):
+    users = np.concatenate([np.arange(step * B, (step + 1) * B) + shard_range(n_users, r, world)[0]
+                            for r in range(world)])
+    b = orc.collate(csr[users], users, B * world, True)[0]
+    ref_losses.append(o.train_step(b))
+  assert np.allclose(got["losses"], ref_losses, rtol=1e-5, atol=0)
+  for k, v in o.state().items():
+    assert torch.allclose(got["state"][k], v, rtol=1e-4, atol=1e-6), k
+  w = o.params["user_embedding_layer.weight"]
+  assert torch.allclose(got["m"], o.optimizer.state[w]["exp_avg"], rtol=1e-4, atol=1e-7)
+  assert torch.allclose(got["v"], o.optimizer.state[w]["exp_avg_sq"], rtol=1e-4, atol=1e-9)
+
+
 def test_shard_range_partitions():
   from recoder_amd.parallel import shard_range
   for n, w in [(10, 3), (116677, 8), (7, 8), (64, 2)]:
