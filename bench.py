@@ -143,17 +143,22 @@ def main():
   assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
   torch.cuda.set_device(local_rank)
   device = torch.device("cuda", local_rank)
-  dp = None
-  # RK_FORCE_DP=1 exercises the data-parallel plumbing (two-phase collation, RCCL
-  # all-reduces) with a 1-rank group on a single GPU
+  dp = ip = None
+  # Multi-GPU (one process per GPU, RCCL): the ITEM dimension is sharded by default
+  # (parallel.ItemParallel: every rank runs the whole global batch of world*B users against
+  # its items, two [world*B, h] all-reduces per step); RK_PARALLEL=users shards the users
+  # instead (gradient-row all-reduce).  RK_FORCE_DP=1 exercises either with a 1-rank group.
   force_dp = os.environ.get("RK_FORCE_DP") == "1"
   if world > 1 or force_dp:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    from recoder_amd.parallel import DataParallel, shard_range
-    dp = DataParallel()
+    from recoder_amd.parallel import DataParallel, ItemParallel, shard_range
+    if os.environ.get("RK_PARALLEL", "items") == "users":
+      dp = DataParallel()
+    else:
+      ip = ItemParallel()
 
   from recoder_amd._lib import ENTRY
   from recoder_amd.device import Block, DeviceCSR
@@ -162,13 +167,15 @@ def main():
   from recoder_amd.nn import DynamicAutoencoder
 
   csr_full = make_csr(cfg)
-  if world > 1:
+  if dp is not None and world > 1:
     lo, hi = shard_range(csr_full.shape[0], rank, world)
     csr = csr_full[lo:hi]
+  elif ip is not None:
+    csr = ip.shard_csr(csr_full)            # every user, this rank's item columns
   else:
     csr = csr_full
   n_users, n_items = csr.shape
-  B = cfg["batch_size"]
+  B = cfg["batch_size"] * (world if ip is not None else 1)   # rows this rank runs per step
   h0 = cfg["hidden_layers"][0]
 
   torch.manual_seed(0)       # same initial weights on every rank
@@ -183,22 +190,26 @@ def main():
   eng = rec._engine()
   if dp is not None:
     dp.attach(eng)
+  if ip is not None:
+    ip.user_norm_dev = torch.from_numpy(ItemParallel.user_norms(csr_full)).to(device)
+    eng.item_parallel = ip
   dcsr = ds.device_csr()                      # CSR resident in HBM before timing
   # the union item set over all ranks can exceed one rank's nnz bound
   from recoder_amd.device import CollatePrefetcher
   nnz_bound = _top_sum(dcsr.degrees, B)
   pf = CollatePrefetcher(
-      lambda: Block(B, nnz_bound, n_items, device, negative_sampling=True, n_cap=nnz_bound * world),
+      lambda: Block(B, nnz_bound, n_items, device, negative_sampling=True,
+                    n_cap=nnz_bound * (world if dp is not None else 1)),
       dcsr, device, collate_fn=(dp.collate if dp is not None else None), group=rec.prefetch_group)
   G = pf.group
 
   total = args.warmup + args.steps
-  rng = np.random.RandomState(100 + rank)
+  rng = np.random.RandomState(100 + (rank if dp is not None else 0))   # item shards share the order
   order = np.concatenate([rng.permutation(n_users) for _ in range((total * B) // n_users + 1)])
   order = order[: total * B].astype(np.int64)
   order_dev = torch.from_numpy(order).to(device)
   loss_buf = torch.zeros(total, dtype=torch.float32, device=device)
-  global_rows = B * world
+  global_rows = B * world if dp is not None else B      # users all ranks consume per step
 
   def users_of(i):
     return order_dev[i * B:(i + 1) * B]
@@ -231,19 +242,24 @@ def main():
   step(0)
   torch.cuda.synchronize()
   half = max(2, args.warmup // 2)
-  eng.use_c_step = False
-  eng.lib.enabled = True
-  for i in range(1, half):
-    step(i)
-  prof = eng.lib.summary()
-  eng.lib.reset()
-  eng.lib.enabled = False
-  timed = {k: v for k, v in prof.items() if k in ENTRY}
-  # the production path issues all Adam updates as one rk_adam_multi launch
-  upd = ("rk_adam_table", "rk_adam_dense", "rk_adam_rows")
-  n_prof = max(1, half - 1)
-  timed["rk_adam_multi"] = (n_prof, sum(prof[k][0] * prof[k][1] for k in upd if k in prof) / n_prof)
-  dominant = max(timed, key=lambda k: timed[k][0] * timed[k][1]) if timed else "rk_decode_loss"
+  if ip is None:
+    eng.use_c_step = False
+    eng.lib.enabled = True
+    for i in range(1, half):
+      step(i)
+    prof = eng.lib.summary()
+    eng.lib.reset()
+    eng.lib.enabled = False
+    timed = {k: v for k, v in prof.items() if k in ENTRY}
+    # the production path issues all Adam updates as one rk_adam_multi launch
+    upd = ("rk_adam_table", "rk_adam_dense", "rk_adam_rows")
+    n_prof = max(1, half - 1)
+    timed["rk_adam_multi"] = (n_prof, sum(prof[k][0] * prof[k][1] for k in upd if k in prof) / n_prof)
+    dominant = max(timed, key=lambda k: timed[k][0] * timed[k][1]) if timed else "rk_decode_loss"
+  else:
+    # item shards only run the one-call step; its Adam sweep covers 1/world of the tables, the
+    # decoder contraction is the largest kernel
+    half, prof, dominant = 1, {}, "rk_decode_loss"
   only = dominant
   c_path = True                 # rk_ae_train_step handles single-GPU and data-parallel steps
   eng.use_c_step = True
@@ -253,7 +269,7 @@ def main():
   torch.cuda.synchronize()
   eng._c_time_idx = 0
 
-  if dp is not None:
+  if dp is not None or ip is not None:
     import torch.distributed as dist
     dist.barrier()
   torch.cuda.synchronize()
@@ -262,17 +278,20 @@ def main():
     step(i)
   t_enqueue = time.perf_counter() - t0      # host time to enqueue the timed steps
   torch.cuda.synchronize()
-  if dp is not None:
+  multi = dp is not None or ip is not None
+  if multi:
     dist.barrier()
   dt = time.perf_counter() - t0
-  if dp is not None:
+  if multi:
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+  if ip is not None:
+    ip.allreduce_sum(loss_buf)             # every rank holds its items' share of the loss
 
   losses = loss_buf.cpu().numpy()
   assert np.all(np.isfinite(losses)), "non-finite loss"
-  value = args.steps * B * world / dt
+  value = args.steps * global_rows / dt     # users consumed by all ranks per second
 
   if rank == 0:
     # per-step n_b / nnz of the timed steps (host recomputation, outside the timing)
@@ -314,8 +333,11 @@ def main():
       "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
       "vs_baseline": None, "dtype": "f32",
       "data": "synthetic" if not args.diag_reuse_block else "INVALID (diagnostic: no collation)",
-      "config": {"workload": cfg["workload"], "batch_size_per_gpu": B, "global_batch": B * world,
-                 "parallelism": "dp%d" % world, "avg_sampled_items": n_b, "avg_nnz_per_batch": nnz,
+      "config": {"workload": cfg["workload"], "batch_size_per_gpu": cfg["batch_size"],
+                 "global_batch": global_rows,
+                 "parallelism": ("items%d (item-sharded tables, all users on every rank)" % world
+                                 if ip is not None else "dp%d" % world),
+                 "avg_sampled_items": n_b, "avg_nnz_per_batch": nnz,
                  "first_loss": float(losses[0]), "last_loss": float(losses[-1]),
                  "host_enqueue_ms_per_step": t_enqueue / args.steps * 1e3},
       "roofline": roofline,
@@ -323,7 +345,7 @@ def main():
     if world == 1 and not force_dp and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline(cfg, csr_full, args.cpu_steps)
     print(json.dumps(out))
-  if dp is not None:
+  if multi:
     dist.destroy_process_group()
 
 

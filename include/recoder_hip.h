@@ -124,6 +124,22 @@ int rk_ae_encode_fwd(const rk_block_t *blk, int32_t row_off, int32_t B,
                      float *Z0, void *stream);
 
 /*
+ * rk_ae_encode_fwd_partial -- the raw partial sum of rk_ae_encode_fwd (no bias, no
+ * activation) over the columns the block holds, normalised by user_norm[users[r]]
+ * (the L2 norm of the user's WHOLE row; NULL: computed from the block as above).
+ * Item-parallel training: every rank holds a column shard of the interactions,
+ * the partial sums are all-reduced, then rk_bias_act finishes the layer.
+ */
+int rk_ae_encode_fwd_partial(const rk_block_t *blk, int32_t row_off, int32_t B,
+                             const float *W_en, int32_t h, const uint8_t *keep,
+                             float p, uint64_t seed, uint64_t rng_step,
+                             const int64_t *users, const float *user_norm,
+                             float *Zpart, void *stream);
+/* X[r,c] = act(X[r,c] + bias[c]) in place (bias nullable) */
+int rk_bias_act(float *X, const float *bias, int32_t rows, int32_t cols,
+                int32_t act, void *stream);
+
+/*
  * rk_ae_encode_bwd -- autograd of the above w.r.t. the gathered encoder rows
  * (model.py:397): G_en[c,:] (+)= sum_r svals[r,c] * dZ0pre[r,:]  (deterministic
  * ascending-row order via the transposed bitmap).  accumulate != 0 adds into
@@ -257,6 +273,10 @@ enum { RK_ENTRY_NONE = 0, RK_ENTRY_ENCODE_FWD = 1, RK_ENTRY_DECODE_LOSS = 2,
  * callers run FWD_DW, all-reduce the decoder-side gradients, DZ_ENC, all-reduce the
  * encoder side, then UPDATE. */
 enum { RK_STEP_FWD_DW = 1, RK_STEP_DZ_ENC = 2, RK_STEP_UPDATE = 4, RK_STEP_ALL = 7 };
+/* Item-parallel segments (item i owned by rank i % own_world; the block holds every
+ * user of the global batch restricted to the rank's items): IP_ENC, all-reduce(SUM) of
+ * Z0[B,h], IP_MID, all-reduce(SUM) of dZ0[B,h], IP_TAIL.  See step.hip. */
+enum { RK_STEP_IP_ENC = 8, RK_STEP_IP_MID = 16, RK_STEP_IP_TAIL = 32, RK_STEP_IP_ALL = 56 };
 
 typedef struct rk_adam_param {
   float *p, *m, *v;          /* parameter and its Adam moments */
@@ -287,6 +307,9 @@ typedef struct rk_adam_job {
   int32_t g_parts, g_stride;
   const int32_t *gstride_dev;
   const float *g;
+  int32_t row0, row_step;      /* dense jobs: only rows row0, row0 + row_step, ... are updated
+                                  (item-parallel ownership: item i lives on rank i % N);
+                                  row_step 0 = 1 */
 } rk_adam_job_t;
 
 int rk_adam_multi(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part,
@@ -306,6 +329,9 @@ typedef struct rk_ae_step {
   int32_t time_entry;        /* RK_ENTRY_*: bracket that entry with the two events below */
   int32_t phase;             /* mask of RK_STEP_* (0 = RK_STEP_ALL) */
   void *time_ev0, *time_ev1; /* rk_timing_event_create */
+  /* item-parallel segments only */
+  const float *user_norm;    /* [n_users] L2 norm of every user's whole row (by global user id) */
+  int32_t own_rank, own_world;
 } rk_ae_step_t;
 
 void *rk_event_create(void);          /* ordering-only (no timing, device-scope fence) */

@@ -64,6 +64,7 @@ class RkAeStep(Structure):
     ("stream", c_void_p),
     ("time_entry", c_int32), ("phase", c_int32),
     ("time_ev0", c_void_p), ("time_ev1", c_void_p),
+    ("user_norm", c_void_p), ("own_rank", c_int32), ("own_world", c_int32),
   ]
 
 
@@ -75,10 +76,12 @@ class RkAdamJob(Structure):
     ("pos", c_void_p), ("rows", c_void_p), ("n_dev", c_void_p),
     ("n_cap", c_int32), ("g_parts", c_int32), ("g_stride", c_int32),
     ("gstride_dev", c_void_p), ("g", c_void_p),
+    ("row0", c_int32), ("row_step", c_int32),
   ]
 
 
 STEP_FWD_DW, STEP_DZ_ENC, STEP_UPDATE, STEP_ALL = 1, 2, 4, 7
+STEP_IP_ENC, STEP_IP_MID, STEP_IP_TAIL = 8, 16, 32
 
 
 _P = c_void_p
@@ -90,6 +93,9 @@ SIGNATURES = {
   "rk_last_error": (c_char_p, []),
   "rk_dz_workspace_bytes": (c_int64, [c_int32, c_int32]),
   "rk_collate": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _BLK, _P]),
+  "rk_ae_encode_fwd_partial": (c_int32, [_BLK, c_int32, c_int32, _P, c_int32, _P, c_float, c_uint64,
+                                         c_uint64, _P, _P, _P, _P]),
+  "rk_bias_act": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P]),
   "rk_densify": (c_int32, [_BLK, c_int32, c_int32, c_int32, _P, c_int32, _P]),
   "rk_ae_encode_fwd": (c_int32, [_BLK, c_int32, c_int32, _P, _P, c_int32, _P, c_float, c_uint64,
                                  c_uint64, _P, c_int32, _P, _P]),

@@ -21,7 +21,8 @@ template <int HV>
 __global__ __launch_bounds__(256) void ae_encode_fwd_kernel(
     rk_block_t b, int row_off, int B, const float *__restrict__ W, const float *__restrict__ bias,
     int h, const uint8_t *__restrict__ keep, float p, float scale, uint64_t seed,
-    uint64_t rng_step, const int64_t *__restrict__ users, int act, float *__restrict__ Z0) {
+    uint64_t rng_step, const int64_t *__restrict__ users, const float *__restrict__ user_norm,
+    int act, float *__restrict__ Z0) {
   __shared__ float red[4];
   __shared__ __attribute__((aligned(16))) float part[3][HV * 256];
   const int r = blockIdx.x;            // row within the slice
@@ -48,7 +49,11 @@ __global__ __launch_bounds__(256) void ae_encode_fwd_kernel(
 
   // ---- L2 norm of the row (F.normalize: x / max(||x||_2, 1e-12)) ----
   float nrm;
-  if (implicit) {
+  if (user_norm) {
+    // item-parallel shards: the block holds only this rank's columns of the row; the
+    // norm of the WHOLE row comes precomputed per user
+    nrm = fmaxf(user_norm[uid], 1e-12f);
+  } else if (implicit) {
     nrm = fmaxf(sqrtf((float)n), 1e-12f);      // n ones: the sum of squares is exactly n
   } else {
     float ss = 0.f;
@@ -131,7 +136,8 @@ __global__ __launch_bounds__(256) void ae_encode_fwd_kernel(
           const float4 o = *reinterpret_cast<const float4 *>(&part[w][hh]);
           a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
         }
-        const float4 bb = *reinterpret_cast<const float4 *>(bias + hh);
+        const float4 bb = bias ? *reinterpret_cast<const float4 *>(bias + hh)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
         float4 y;
         y.x = rk_act(a.x + bb.x, act);
         y.y = rk_act(a.y + bb.y, act);
@@ -152,25 +158,43 @@ __global__ __launch_bounds__(256) void ae_encode_bwd_kernel(
 
 }  // namespace
 
-extern "C" int rk_ae_encode_fwd(const rk_block_t *blk, int32_t row_off, int32_t B,
-                                const float *W_en, const float *b_en, int32_t h,
-                                const uint8_t *keep, float p, uint64_t seed, uint64_t rng_step,
-                                const int64_t *users, int32_t act, float *Z0, void *stream_) {
+static int encode_fwd_launch(const rk_block_t *blk, int32_t row_off, int32_t B, const float *W_en,
+                             const float *b_en, int32_t h, const uint8_t *keep, float p,
+                             uint64_t seed, uint64_t rng_step, const int64_t *users,
+                             const float *user_norm, int32_t act, float *Z0, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(h > 0 && h % 4 == 0 && h <= 1024, "h must be a multiple of 4, <= 1024");
   RK_REQUIRE(p >= 0.f && p < 1.f, "noise_prob must be in [0,1)");
   RK_REQUIRE(row_off >= 0 && B >= 0 && row_off + B <= blk->S_cap, "row slice out of range");
+  RK_REQUIRE(user_norm == nullptr || users != nullptr, "user_norm is indexed by users[]");
   if (B == 0) return 0;
   // ATen dropout: noise = bernoulli(1-p) / (1-p), computed in fp32
   const float scale = 1.0f / (float)(1.0 - (double)p);
   const int hv = rk_cdiv(h, 256);
 #define LAUNCH(HV)                                                                         \
   RK_LAUNCH(ae_encode_fwd_kernel<HV>, dim3(B), dim3(256), 0, stream, *blk, row_off, \
-                     B, W_en, b_en, h, keep, p, scale, seed, rng_step, users, act, Z0)
+                     B, W_en, b_en, h, keep, p, scale, seed, rng_step, users, user_norm, act, Z0)
   if (hv == 1) LAUNCH(1); else if (hv == 2) LAUNCH(2); else LAUNCH(4);
 #undef LAUNCH
   RK_CHECK_LAUNCH("ae_encode_fwd");
   return 0;
+}
+
+extern "C" int rk_ae_encode_fwd(const rk_block_t *blk, int32_t row_off, int32_t B,
+                                const float *W_en, const float *b_en, int32_t h,
+                                const uint8_t *keep, float p, uint64_t seed, uint64_t rng_step,
+                                const int64_t *users, int32_t act, float *Z0, void *stream_) {
+  RK_REQUIRE(b_en != nullptr, "b_en is required");
+  return encode_fwd_launch(blk, row_off, B, W_en, b_en, h, keep, p, seed, rng_step, users, nullptr,
+                           act, Z0, stream_);
+}
+
+extern "C" int rk_ae_encode_fwd_partial(const rk_block_t *blk, int32_t row_off, int32_t B,
+                                        const float *W_en, int32_t h, const uint8_t *keep, float p,
+                                        uint64_t seed, uint64_t rng_step, const int64_t *users,
+                                        const float *user_norm, float *Zpart, void *stream_) {
+  return encode_fwd_launch(blk, row_off, B, W_en, nullptr, h, keep, p, seed, rng_step, users,
+                           user_norm, RK_ACT_NONE, Zpart, stream_);
 }
 
 extern "C" int rk_ae_encode_bwd(const rk_block_t *blk, int32_t row_off, int32_t B,

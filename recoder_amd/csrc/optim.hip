@@ -105,6 +105,14 @@ __global__ __launch_bounds__(256) void adam_rows_kernel(float *W, float *m, floa
   }
 }
 
+// X[r, c] = act(X[r, c] + bias[c])   (item-parallel: after the all-reduce of the partial
+// encoder sums)
+__global__ __launch_bounds__(256) void bias_act_kernel(float *X, const float *bias, int64_t n,
+                                                       int cols, int act) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    X[i] = rk_act(X[i] + (bias ? bias[i % cols] : 0.f), act);
+}
+
 __global__ __launch_bounds__(256) void act_grad_kernel(float *dY, const float *Y, int64_t n, int act) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
     dY[i] = dY[i] * rk_act_dy(Y[i], act);
@@ -186,6 +194,7 @@ struct UJob {
   const int32_t *n_dev;        // SparseAdam: live compact rows
   const int32_t *gstride_dev;  // device-resident stride between gradient parts (or null)
   int n_rows, h, g_parts, g_stride, sparse, blk0, nblk;
+  int row0, row_step;          // the job covers rows row0, row0 + row_step, ... (owned rows)
   AdamC c;
 };
 
@@ -246,15 +255,22 @@ __device__ __forceinline__ void update_job(const UJob &J, int lb) {
     }
     return;
   }
-  const int64_t tot = (int64_t)J.n_rows * hq;
+  const int rows_live = J.row0 < J.n_rows ? (J.n_rows - J.row0 + J.row_step - 1) / J.row_step : 0;
+  const int64_t tot = (int64_t)rows_live * hq;
+  const bool by_row = J.pos != nullptr || J.row_step != 1 || J.row0 != 0;
   for (int64_t i = (int64_t)lb * 256 + threadIdx.x; i < tot; i += step) {
-    int64_t go = i * V::W;
+    int64_t e = i;                      // element (in units of T) of the parameter
+    int64_t go = i * V::W;              // gradient offset (floats)
     bool have = true;
-    if (J.pos) {
-      const int row = (int)(i / hq), q = (int)(i % hq);
-      const int pr = J.pos[row];
-      have = pr >= 0;
-      go = (int64_t)pr * J.h + q * V::W;
+    if (by_row) {
+      const int row = J.row0 + (int)(i / hq) * J.row_step, q = (int)(i % hq);
+      e = (int64_t)row * hq + q;
+      go = e * V::W;
+      if (J.pos) {
+        const int pr = J.pos[row];
+        have = pr >= 0;
+        go = (int64_t)pr * J.h + q * V::W;
+      }
     }
     T g = V::zero();
     if (have) {
@@ -262,9 +278,9 @@ __device__ __forceinline__ void update_job(const UJob &J, int lb) {
       for (int t = 1; t < J.g_parts; ++t)            // partial gradients, fixed order
         V::add(g, *reinterpret_cast<const T *>(J.g + t * stride + go));
     }
-    T p1 = P[i], m1 = M[i], v1 = Vv[i];
+    T p1 = P[e], m1 = M[e], v1 = Vv[e];
     V::adam(p1, m1, v1, g, J.c);
-    P[i] = p1; M[i] = m1; Vv[i] = v1;
+    P[e] = p1; M[e] = m1; Vv[e] = v1;
   }
 }
 
@@ -395,13 +411,18 @@ extern "C" int rk_adam_multi(const rk_adam_job_t *jobs, int32_t n_jobs, float *l
                           (uintptr_t)s.g) & 15) == 0 && (s.g_parts == 1 || s.gstride_dev == nullptr) &&
                         s.g_stride % 4 == 0),
                "vector jobs need 16-byte aligned operands / strides");
-    const int64_t rows = s.par.sparse ? s.n_cap : s.n_rows;
+    const int row_step = s.row_step > 0 ? s.row_step : 1;
+    RK_REQUIRE(s.row0 >= 0 && (s.par.sparse == 0 || (s.row0 == 0 && row_step == 1)),
+               "row0 / row_step apply to dense jobs");
+    const int64_t rows = s.par.sparse ? s.n_cap
+                                      : (s.row0 < s.n_rows ? (s.n_rows - s.row0 + row_step - 1) / row_step : 0);
     if (rows == 0) continue;
     d.p = s.par.p; d.m = s.par.m; d.v = s.par.v; d.g = s.g;
     d.pos = s.par.sparse ? nullptr : s.pos;
     d.rows = s.rows; d.n_dev = s.n_dev; d.gstride_dev = s.gstride_dev;
     d.n_rows = s.n_rows; d.h = s.h; d.g_parts = s.g_parts; d.g_stride = s.g_stride;
     d.sparse = s.par.sparse ? 1 : 0;
+    d.row0 = s.row0; d.row_step = row_step;
     d.c = make_consts(s.par.lr, s.par.beta1, s.par.beta2, s.par.eps,
                       s.par.sparse ? 0.0 : s.par.weight_decay, s.par.step);
     d.blk0 = blocks;
@@ -427,6 +448,16 @@ extern "C" int rk_scatter_pos(int32_t *pos, const int64_t *rows, int32_t B, int3
   RK_LAUNCH(scatter_pos_kernel, dim3(rk_cdiv(B, 256)), dim3(256), 0, stream, pos, rows, B,
                      clear);
   RK_CHECK_LAUNCH("scatter_pos");
+  return 0;
+}
+
+extern "C" int rk_bias_act(float *X, const float *bias, int32_t rows, int32_t cols, int32_t act,
+                           void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t n = (int64_t)rows * cols;
+  if (n == 0) return 0;
+  RK_LAUNCH(bias_act_kernel, dim3(grid_for(n)), dim3(256), 0, stream, X, bias, n, cols, act);
+  RK_CHECK_LAUNCH("bias_act");
   return 0;
 }
 

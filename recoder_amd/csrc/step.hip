@@ -78,6 +78,72 @@ rk_adam_job_t table_job(const rk_adam_param_t &par, const rk_block_t *blk, int n
     if (rc__ != 0) return rc__; \
   } while (0)
 
+// Item-parallel step (rk_ae_step_t.own_world ranks, item i owned by rank i % own_world).
+// The block holds the rows of ALL users of the global batch restricted to this rank's
+// items; three segments with an all-reduce (SUM) of a [B, h] matrix between them:
+//   IP_ENC : Z0 = partial encoder sums over the local items (whole-row norms)
+//   -- all-reduce Z0 --
+//   IP_MID : Z0 = act(Z0 + b_en) ; decode + loss over the local items ; dZ0 = dO . W_de (raw)
+//   -- all-reduce dZ0 --
+//   IP_TAIL: dZ0 *= act'(Z0) ; dW || encoder backward ; Adam on the OWNED rows (+ b_en, which is
+//            replicated: every rank computes the identical update) ; local loss partial
+static int step_item_parallel(const rk_ae_step_t *a, int phase) {
+  const rk_block_t *blk = a->blk;
+  hipStream_t sm = (hipStream_t)a->stream;
+  const int B = a->B, h = a->h, n_items = blk->n_items;
+  const int row_tiles = rk_cdiv(B, rk_decode_row_tile());
+  const bool mnll = a->loss_kind == RK_LOSS_MNLL;
+  const float *W_de = a->tied ? a->par[RK_PAR_W_EN].p : a->par[RK_PAR_W_DE].p;
+  float *G_en = a->tied ? a->G_de : a->G_en;
+  const int n_part = mnll ? B : rk_loss_partials(B, blk->n_cap);
+  RK_REQUIRE(a->own_world >= 1 && a->own_rank >= 0 && a->own_rank < a->own_world, "bad ownership");
+  // the softmax of the multinomial loss spans every target item of a row, i.e. all ranks
+  RK_REQUIRE(!mnll, "item-parallel training supports the mse / logistic losses");
+  if (phase & RK_STEP_IP_ENC) {
+    Timer t(a, RK_ENTRY_ENCODE_FWD, sm);
+    RK_TRY(rk_ae_encode_fwd_partial(blk, a->row_off, B, a->par[RK_PAR_W_EN].p, h, a->keep, a->noise_p,
+                                    a->seed, a->rng_step, a->users, a->user_norm, a->Z0, sm));
+  }
+  if (phase & RK_STEP_IP_MID) {
+    RK_TRY(rk_bias_act(a->Z0, a->par[RK_PAR_B_EN].p, B, h, a->act, sm));
+    {
+      Timer t(a, RK_ENTRY_DECODE_LOSS, sm);
+      RK_TRY(rk_decode_loss(a->Z0, B, h, blk, a->row_off, W_de, a->par[RK_PAR_B_DE].p, a->loss_kind,
+                            a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, sm));
+      if (mnll) RK_TRY(rk_mnll_finish(a->dO, B, blk, a->row_off, a->inv_B, a->loss_part, sm));
+    }
+    Timer t(a, RK_ENTRY_DECODE_BWD_DZ, sm);
+    RK_TRY(rk_decode_bwd_dz(a->dO, B, h, blk, W_de, nullptr, RK_ACT_NONE, a->dZ0, a->ws, sm));
+  }
+  if (phase & RK_STEP_IP_TAIL) {
+    RK_TRY(rk_act_grad(a->dZ0, a->Z0, (int64_t)B * h, a->act, sm));
+    if (a->tied || mnll) {
+      RK_TRY(rk_decode_bwd_dw(a->dO, a->Z0, B, h, blk, a->G_de, mnll ? a->gb_de : nullptr, sm));
+      RK_TRY(rk_ae_encode_bwd(blk, a->row_off, B, a->dZ0, h, G_en, a->tied ? 1 : 0, a->gb_en, sm));
+    } else {
+      Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
+      RK_TRY(rk_decode_bwd_dw_encode_bwd(a->dO, a->Z0, B, h, blk, a->G_de, a->row_off, a->dZ0, G_en,
+                                         a->gb_en, sm));
+    }
+    rk_adam_job_t jobs[4];
+    int n = 0;
+    jobs[n++] = table_job(a->par[RK_PAR_W_EN], blk, n_items, h, G_en, true);
+    if (!a->tied) jobs[n++] = table_job(a->par[RK_PAR_W_DE], blk, n_items, h, a->G_de, true);
+    jobs[n] = table_job(a->par[RK_PAR_B_DE], blk, n_items, 1, a->gb_de, true);
+    jobs[n].par.sparse = 0; jobs[n].rows = nullptr; jobs[n].n_dev = nullptr; jobs[n].pos = blk->pos;
+    if (!mnll) {
+      jobs[n].g = a->gb_part; jobs[n].g_parts = row_tiles; jobs[n].gstride_dev = blk->counts + 2;
+    }
+    ++n;
+    for (int j = 0; j < n; ++j)
+      if (!jobs[j].par.sparse) { jobs[j].row0 = a->own_rank; jobs[j].row_step = a->own_world; }
+    jobs[n++] = table_job(a->par[RK_PAR_B_EN], blk, 1, h, a->gb_en, false);
+    Timer t(a, RK_ENTRY_ADAM_MULTI, sm);
+    RK_TRY(rk_adam_multi(jobs, n, a->loss_part, n_part, a->denom, a->loss_out, sm));
+  }
+  return 0;
+}
+
 // The whole step is a serial chain on ONE stream:
 //   encode_fwd ; decode+loss ; dW ; dZ split-K ; reduce ; encode_bwd (+gb_en) ; update
 // (an earlier version ran the dW chain on a second stream: each cross-stream event
@@ -85,7 +151,11 @@ rk_adam_job_t table_job(const rk_adam_param_t &par, const rk_block_t *blk, int n
 // ate the overlap; the small kernels it needed are folded into the big ones instead).
 extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   RK_REQUIRE(a && a->blk, "null step / block");
-  RK_REQUIRE(a->phase >= 0 && a->phase <= 7, "phase is a mask of RK_STEP_*");
+  RK_REQUIRE(a->phase >= 0 && a->phase <= 63, "phase is a mask of RK_STEP_*");
+  if (a->phase & RK_STEP_IP_ALL) {
+    RK_REQUIRE((a->phase & RK_STEP_ALL) == 0, "item-parallel and data-parallel phases do not mix");
+    return step_item_parallel(a, a->phase);
+  }
   const int phase = a->phase == 0 ? RK_STEP_ALL : a->phase;
   const bool whole = phase == RK_STEP_ALL;
   const rk_block_t *blk = a->blk;

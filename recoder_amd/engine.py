@@ -101,6 +101,7 @@ class FusedEngine:
     self.time_entry = None                 # C-ABI entry name to bracket with events (bench)
     self.time_every = 8                    # ... on every time_every-th step
     self._gb_lazy = None
+    self.item_parallel = None              # parallel.ItemParallel when the items are sharded
     self._cstep = None
     if kind == "ae":
       self.h = list(model.hidden_layers)
@@ -309,6 +310,9 @@ class FusedEngine:
     main_s = torch.cuda.current_stream()
     if self.use_c_step and self.kind == "ae" and self.nl == 0 and not (m.dropout_prob > 0.0):
       return self._c_train_step(blk, row_off, B, keep_noise, out, global_rows, main_s)
+    if self.item_parallel is not None:
+      raise NotImplementedError("item-parallel training runs through rk_ae_train_step only "
+                                "(DynamicAutoencoder([h]) without bottleneck dropout)")
     self._gb_lazy = None
     stream = ctypes.c_void_p(main_s.cuda_stream)
     self.rng_step += 1
@@ -463,7 +467,26 @@ class FusedEngine:
       st.time_entry, st.time_ev0, st.time_ev1 = ENTRY[self.time_entry], e0, e1
     else:
       st.time_entry = 0
-    if dp is None:
+    ip = self.item_parallel
+    if ip is not None:
+      # item parallel (parallel.ItemParallel): the block holds every user of the global
+      # batch restricted to this rank's items; two [B, h] all-reduces per step.  `out` gets
+      # this rank's share of the loss (summed over the ranks once per epoch).
+      from ._lib import STEP_IP_ENC, STEP_IP_MID, STEP_IP_TAIL
+      h0 = self.h[0]
+      st.user_norm = ptr(ip.user_norm_dev)
+      st.own_rank, st.own_world = ip.rank, ip.world
+      st.phase = STEP_IP_ENC
+      check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
+      ip.allreduce_sum(self.enc[0][:B * h0])
+      st.phase = STEP_IP_MID
+      check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
+      ip.allreduce_sum(self.denc[0][:B * h0])
+      st.phase = STEP_IP_TAIL
+      check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
+      if self.loss_id != LOSS_MNLL:
+        self._gb_lazy = (cdiv(B, self.row_tile), blk)
+    elif dp is None:
       st.phase = STEP_ALL
       check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
       if self.loss_id != LOSS_MNLL:

@@ -286,6 +286,10 @@ class Recoder(object):
 
     self.__init_training(train_dataset=train_dataset, lr=lr, weight_decay=weight_decay)
     train_dataset = self._setup_data_parallel(train_dataset)
+    if getattr(self, "_ip", None) is not None:
+      # item parallel: every rank processes the whole global batch against its items
+      batch_size *= self._ip.world
+      num_sampling_users *= self._ip.world
 
     train_dataloader = RecommendationDataLoader(train_dataset, batch_size=batch_size,
                                                 negative_sampling=negative_sampling,
@@ -320,10 +324,27 @@ class Recoder(object):
     self._sync_user_rows()
 
   def _sync_user_rows(self):
-    """MatrixFactorization under data parallelism: user rows are rank-private while
-    training (only the owner sees their gradients); bring every replica up to date --
-    parameters and Adam moments -- so that the result equals the single-process run
-    with batch_size = N * B (called at the end of train() and before evaluation)."""
+    """Bring every replica up to date with the rows other ranks own -- parameters and
+    Adam moments -- so that the result equals the single-process run with
+    batch_size = N * B (called at the end of train(), before evaluation and before
+    checkpoints).  Item parallel: item i's embedding rows / bias live on rank i % N.
+    MatrixFactorization under data parallelism: a user's row only receives gradients
+    on the rank that holds the user."""
+    ip = getattr(self, "_ip", None)
+    if ip is not None:
+      m = self.model
+      params = [m.en_embedding_layer.weight, m.de_bias]
+      if not m.is_constrained:
+        params.append(m.de_embedding_layer.weight)
+      tensors = []
+      for w in params:
+        tensors.append(w.data)
+        for opt in (self.optimizer, self.sparse_optimizer):
+          st = opt.state.get(w) if opt is not None else None
+          if st:
+            tensors += [st["exp_avg"], st["exp_avg_sq"]]
+      ip.sync_owned(tensors, self.num_items)
+      return
     if getattr(self, "_dp", None) is None or self._fused_kind() != "mf":
       return
     from .parallel import sync_owned_rows
@@ -343,17 +364,35 @@ class Recoder(object):
     all-reduced (recoder_amd/parallel.py).  Returns this rank's shard."""
     import torch.distributed as dist
     self._dp = None
+    self._ip = None
+    if getattr(self, "_ip_override", None) is not None:
+      # tests: several virtual ranks in one process, collectives injected
+      return self._enable_item_parallel(self._ip_override, train_dataset)
     if not (dist.is_available() and dist.is_initialized()):
       return train_dataset
     if dist.get_world_size() == 1 and os.environ.get("RK_FORCE_DP") != "1":
       return train_dataset
     if self._use_generic():
-      raise NotImplementedError("data-parallel training is implemented for the fused "
+      raise NotImplementedError("multi-GPU training is implemented for the fused "
                                 "DynamicAutoencoder / MatrixFactorization paths")
-    from .parallel import DataParallel, shard_range
-    dp = DataParallel()
     for p_ in self.model.parameters():          # identical replicas: rank 0's initial weights
       dist.broadcast(p_.data, src=0)
+    # RK_PARALLEL = items | users | auto: shard the ITEM dimension (two small [N*B, h]
+    # all-reduces per step, 1/N of the Adam sweep) where the step supports it, else the users
+    m = self.model
+    ip_ok = (self._fused_kind() == "ae" and len(m.hidden_layers) == 1 and not m.dropout_prob > 0.0
+             and self._loss_name in ("mse", "logistic"))
+    mode = os.environ.get("RK_PARALLEL", "auto")
+    if mode == "auto":
+      mode = "items" if ip_ok else "users"
+    if mode == "items":
+      if not ip_ok:
+        raise NotImplementedError("item-parallel training covers DynamicAutoencoder([h]) with "
+                                  "the mse / logistic losses; use RK_PARALLEL=users")
+      from .parallel import ItemParallel
+      return self._enable_item_parallel(ItemParallel(), train_dataset)
+    from .parallel import DataParallel, shard_range
+    dp = DataParallel()
     dp.attach(self._engine())
     self._dp = dp
     n = len(train_dataset)
@@ -364,6 +403,14 @@ class Recoder(object):
     # every rank runs the same number of equally sized steps (collectives in lockstep)
     self._dp_users_per_epoch = n // dp.world
     return shard
+
+  def _enable_item_parallel(self, ip, train_dataset):
+    from .parallel import ItemParallel
+    full = train_dataset.interactions_matrix
+    ip.user_norm_dev = torch.from_numpy(ItemParallel.user_norms(full)).to(self.device)
+    self._engine().item_parallel = ip
+    self._ip = ip
+    return RecommendationDataset(ip.shard_csr(full))
 
   def _make_block(self, dcsr, S, negative_sampling):
     nnz_cap = max(1, _top_sum(dcsr.degrees, S))
@@ -396,6 +443,9 @@ class Recoder(object):
       order = self.user_order_hook(self.current_epoch, n)
     if order is None:
       order = epoch_user_order(n)
+    if getattr(self, "_ip", None) is not None:
+      o = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int64)).to(self.device)
+      order = self._ip.broadcast(o).cpu().numpy()   # one user order for all item shards
     if getattr(self, "_dp", None) is not None:
       order = order[:self._dp_users_per_epoch]      # equal step counts on every rank
       n = len(order)
@@ -458,6 +508,8 @@ class Recoder(object):
         self._global_step += 1
         if batch_itr % iters_per_epoch == 0:
           break
+      if getattr(self, "_ip", None) is not None and n_done:
+        self._ip.allreduce_sum(loss_buf[:n_done])   # every rank holds its items' share
       # one device->host read per epoch instead of loss.item() per step (model.py:404)
       self.last_epoch_losses = loss_buf[:n_done].cpu().numpy().copy()
       self.loss_history.append(self.last_epoch_losses)

@@ -521,7 +521,7 @@ def test_dataframe_to_csr_matrix_contract():
   assert m2.shape == m.shape
 
 
-@pytest.mark.parametrize("kind", ["ae", "mf", "mf_sparse"])
+@pytest.mark.parametrize("kind", ["ae", "ae_items", "mf", "mf_sparse"])
 def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind):
   """Recoder.train under an initialised torch.distributed group (RCCL, 1 rank):
   two-phase collation + all-reduced gradients must reproduce the plain run."""
@@ -529,6 +529,10 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
   from recoder_amd.data import RecommendationDataset
   from recoder_amd.model import Recoder
   csr = synth_csr(1200, 2500, 25, seed=9)
+  # "ae" = users sharded (gradient all-reduce), "ae_items" = items sharded (parallel.ItemParallel)
+  monkeypatch.setenv("RK_PARALLEL", "items" if kind == "ae_items" else "users")
+  items_mode = kind == "ae_items"
+  kind = "ae" if items_mode else kind
   c = STEP_CASES[0][1] if kind == "ae" else dict(kind="mf", embedding_size=32,
                                                  activation_type="tanh", sparse=(kind == "mf_sparse"))
 
@@ -540,13 +544,13 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
     rec.user_order_hook = lambda epoch, n: np.arange(n, dtype=np.int64)
     rec.train(RecommendationDataset(csr), batch_size=300, lr=1e-3, weight_decay=2e-5, num_epochs=2,
               negative_sampling=True)
-    assert (rec._dp is not None) == dp
+    assert ((rec._ip if items_mode else rec._dp) is not None) == dp
     return np.concatenate(rec.loss_history), {k: v.detach().cpu().clone() for k, v in model.named_parameters()}
 
   base_l, base_p = run(False)
   monkeypatch.setenv("RK_FORCE_DP", "1")
   monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
-  monkeypatch.setenv("MASTER_PORT", str(29577 + ["ae", "mf", "mf_sparse"].index(kind)))
+  monkeypatch.setenv("MASTER_PORT", str(29577 + ["ae", "mf", "mf_sparse"].index(kind) + 5 * items_mode))
   dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
   try:
     dp_l, dp_p = run(True)
@@ -555,3 +559,103 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
   assert np.allclose(dp_l, base_l, rtol=1e-6, atol=0)
   for k in base_p:
     assert torch.allclose(dp_p[k], base_p[k], rtol=1e-5, atol=1e-7), k
+
+
+class _VirtualRanks:
+  """In-process stand-in for the collectives of parallel.ItemParallel: `world` threads,
+  one virtual rank each, on ONE GPU."""
+
+  def __init__(self, world):
+    import threading
+    self.world = world
+    self.barrier = threading.Barrier(world)
+    self.slots = [None] * world
+
+  def _exchange(self, rank, t):
+    torch.cuda.synchronize()
+    self.slots[rank] = t
+    self.barrier.wait()
+    parts = [self.slots[r].clone() for r in range(self.world)]
+    torch.cuda.synchronize()
+    self.barrier.wait()
+    return parts
+
+  def allreduce(self, rank):
+    def fn(t):
+      parts = self._exchange(rank, t)
+      acc = parts[0]
+      for q in parts[1:]:          # same order on every rank
+        acc = acc + q
+      t.copy_(acc)
+      torch.cuda.synchronize()
+      self.barrier.wait()
+      return t
+    return fn
+
+  def allgather(self, rank):
+    return lambda t: self._exchange(rank, t)
+
+
+@pytest.mark.parametrize("case", ["mse_dense", "bce_sparse_tied"])
+def test_item_parallel_two_virtual_ranks_equal_single_process(case):
+  """parallel.ItemParallel with N = 2 on one GPU (two threads, injected collectives):
+  item i on rank i % 2, every rank sees all users; after training and the owners'
+  publication both replicas equal the single-process run."""
+  import threading
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder
+  from recoder_amd.parallel import ItemParallel
+  csr = synth_csr(900, 1500, 20, seed=21)
+  if case == "mse_dense":
+    mk = lambda: DynamicAutoencoder([64], activation_type="tanh", noise_prob=0.0, sparse=False)
+    loss, wd = "mse", 2e-5
+  else:
+    mk = lambda: DynamicAutoencoder([32], activation_type="sigmoid", noise_prob=0.0, sparse=True,
+                                    is_constrained=True)
+    loss, wd = "logistic", 0.0
+  order = np.random.RandomState(5).permutation(csr.shape[0]).astype(np.int64)
+  kw = dict(lr=1e-3, weight_decay=wd, num_epochs=2, negative_sampling=True)
+
+  def new(batch):
+    torch.manual_seed(17)
+    model = mk()
+    rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss=loss)
+    rec.user_order_hook = lambda epoch, n: order
+    return model, rec
+
+  model0, rec0 = new(300)
+  rec0.train(RecommendationDataset(csr), batch_size=300, **kw)
+  base_l = np.concatenate(rec0.loss_history)
+  base_p = {k: v.detach().cpu().clone() for k, v in model0.named_parameters()}
+
+  world = 2
+  vr = _VirtualRanks(world)
+  reps = []
+  for r in range(world):
+    model, rec = new(150)
+    rec._Recoder__init_training(RecommendationDataset(csr), kw["lr"], wd)   # same seed, main thread
+    rec._ip_override = ItemParallel(rank=r, world=world, allreduce_fn=vr.allreduce(r),
+                                    allgather_fn=vr.allgather(r))
+    reps.append((model, rec))
+  errs = []
+
+  def run(r):
+    try:
+      torch.cuda.set_device(0)
+      reps[r][1].train(RecommendationDataset(csr), batch_size=150, **kw)
+    except BaseException as e:       # noqa: B036 -- release the other thread
+      errs.append(e)
+      vr.barrier.abort()
+  threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=300)
+  assert not errs, errs
+  for model, rec in reps:
+    got_l = np.concatenate(rec.loss_history)
+    assert np.allclose(got_l, base_l, rtol=2e-5, atol=0), (got_l[:3], base_l[:3])
+    for k, v in model.named_parameters():
+      frac, mx, scale = close_stats(v.detach().cpu().numpy(), base_p[k].numpy(), 1e-4, 2e-6)
+      assert frac < 2e-3, (k, frac, mx, scale)

@@ -210,6 +210,87 @@ def test_two_rank_matrix_factorization_private_user_rows(tmp_path):
   assert torch.allclose(got["v"], o.optimizer.state[w]["exp_avg_sq"], rtol=1e-4, atol=1e-9)
 
 
+def _ip_worker(rank, world, port, out):
+  """Item-parallel formulation (parallel.ItemParallel) with real gloo collectives: the
+  arithmetic of the three step segments restated with torch autograd on CPU tensors."""
+  sys.path.insert(0, ROOT)
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  torch.set_num_threads(1)
+  from oracle import recoder_oracle as orc
+  from recoder_amd.parallel import ItemParallel
+
+  n_users, n_items, S, h = 64, 91, 16, 12          # n_items not a multiple of the world size
+  csr = _csr(n_users, n_items, 7)
+  torch.manual_seed(5)
+  st0 = orc.init_ae_state(n_items, [h])
+  o = orc.OracleRecoder("ae", st0, hidden_layers=[h], activation_type="tanh", loss="mse",
+                        lr=1e-2, weight_decay=1e-4)
+  P = o.params
+  ip = ItemParallel()
+  shard = ip.shard_csr(csr)
+  assert np.all(shard.indices % world == rank)
+  norms = torch.from_numpy(ItemParallel.user_norms(csr))
+  losses = []
+  for step in range(3):
+    users = np.arange(step * S, (step + 1) * S)          # the SAME global batch on every rank
+    rows = shard[users]
+    items = np.unique(rows.indices).astype(np.int64)     # owned items only
+    idx = torch.from_numpy(items)
+    X = torch.from_numpy(np.asarray(rows[:, items].todense(), dtype=np.float32))
+    Xn = X / norms[users].clamp_min(1e-12)[:, None]
+    o.optimizer.zero_grad()
+    # segment 1: partial encoder sums over the local items, all-reduced
+    Zp = Xn @ P[orc.AE_EN_W][idx]
+    Z0 = ip.allreduce_sum(Zp.detach().clone()).requires_grad_()
+    # segment 2: finish the layer, decode + loss on the local items, partial dLoss/dZ0
+    z = torch.tanh(Z0 + P[orc.AE_EN_B])
+    out_ = z @ P[orc.AE_DE_W][idx].t() + P[orc.AE_DE_B][idx]
+    loss = ((out_ - X) ** 2).sum() / S
+    loss.backward()
+    dZ = ip.allreduce_sum(Z0.grad.clone())
+    # segment 3: encoder-bias gradient from the FULL dZ0, encoder rows of the local items
+    P[orc.AE_EN_B].grad = dZ.sum(0)
+    Zp.backward(dZ)
+    o.optimizer.step()        # non-owned rows only see the decay: overwritten by their owners below
+    losses.append(float(ip.allreduce_sum(loss.detach().clone())))
+  tensors = []
+  for name in (orc.AE_EN_W, orc.AE_DE_W, orc.AE_DE_B):
+    st = o.optimizer.state[P[name]]
+    tensors += [P[name].data, st["exp_avg"], st["exp_avg_sq"]]
+  ip.sync_owned(tensors, n_items)
+  if rank == 1:
+    torch.save({"losses": losses, "state": {k: v.detach() for k, v in P.items()},
+                "m_en": o.optimizer.state[P[orc.AE_EN_W]]["exp_avg"].clone()}, out)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_rank_item_parallel_equals_single_process(tmp_path):
+  from oracle import recoder_oracle as orc
+  world = 2
+  out = str(tmp_path / "ip.pt")
+  mp.spawn(_ip_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+  got = torch.load(out, weights_only=False)
+  n_users, n_items, S, h = 64, 91, 16, 12
+  csr = _csr(n_users, n_items, 7)
+  torch.manual_seed(5)
+  st0 = orc.init_ae_state(n_items, [h])
+  o = orc.OracleRecoder("ae", st0, hidden_layers=[h], activation_type="tanh", loss="mse",
+                        lr=1e-2, weight_decay=1e-4)
+  ref_losses = []
+  for step in range(3):
+    users = np.arange(step * S, (step + 1) * S)
+    b = orc.collate(csr[users], users, S, True)[0]
+    ref_losses.append(o.train_step(b))
+  assert np.allclose(got["losses"], ref_losses, rtol=1e-5, atol=0)
+  for k, v in o.state().items():
+    assert torch.allclose(got["state"][k], v, rtol=1e-4, atol=1e-6), k
+  assert torch.allclose(got["m_en"], o.optimizer.state[o.params[orc.AE_EN_W]]["exp_avg"],
+                        rtol=1e-4, atol=1e-7)
+
+
 def test_shard_range_partitions():
   from recoder_amd.parallel import shard_range
   for n, w in [(10, 3), (116677, 8), (7, 8), (64, 2)]:
