@@ -134,6 +134,9 @@ def main():
   # diagnostics only (the JSON line is marked invalid): train every step on the first
   # collated block, i.e. without the collation the real loop overlaps on its side stream
   ap.add_argument("--diag-reuse-block", action="store_true")
+  # diagnostics only (marked invalid): run rank 0's share of an N-way item-parallel step on
+  # this one GPU with the collectives replaced by no-ops -> the per-rank compute time at N GPUs
+  ap.add_argument("--diag-virtual-world", type=int, default=0)
   args = ap.parse_args()
   cfg = CONFIGS[args.config]
 
@@ -166,6 +169,11 @@ def main():
   from recoder_amd.model import Recoder, _top_sum
   from recoder_amd.nn import DynamicAutoencoder
 
+  if args.diag_virtual_world:
+    from recoder_amd.parallel import ItemParallel
+    ip = ItemParallel(rank=0, world=args.diag_virtual_world, allreduce_fn=lambda t: t,
+                      allgather_fn=lambda t: [t] * args.diag_virtual_world)
+  vworld = args.diag_virtual_world or world
   csr_full = make_csr(cfg)
   if dp is not None and world > 1:
     lo, hi = shard_range(csr_full.shape[0], rank, world)
@@ -175,7 +183,7 @@ def main():
   else:
     csr = csr_full
   n_users, n_items = csr.shape
-  B = cfg["batch_size"] * (world if ip is not None else 1)   # rows this rank runs per step
+  B = cfg["batch_size"] * (vworld if ip is not None else 1)   # rows this rank runs per step
   h0 = cfg["hidden_layers"][0]
 
   torch.manual_seed(0)       # same initial weights on every rank
@@ -198,8 +206,11 @@ def main():
   from recoder_amd.device import CollatePrefetcher
   nnz_bound = _top_sum(dcsr.degrees, B)
   pf = CollatePrefetcher(
+      # capacity of the item set: the union over all ranks under data parallelism; at most the
+      # owned items under item parallelism (grids are capacity-sized: keep it tight)
       lambda: Block(B, nnz_bound, n_items, device, negative_sampling=True,
-                    n_cap=nnz_bound * (world if dp is not None else 1)),
+                    n_cap=(nnz_bound * world if dp is not None else
+                           min(nnz_bound, -(-n_items // vworld)) if ip is not None else nnz_bound)),
       dcsr, device, collate_fn=(dp.collate if dp is not None else None), group=rec.prefetch_group)
   G = pf.group
 
@@ -269,7 +280,8 @@ def main():
   torch.cuda.synchronize()
   eng._c_time_idx = 0
 
-  if dp is not None or ip is not None:
+  multi = (dp is not None or ip is not None) and not args.diag_virtual_world
+  if multi:
     import torch.distributed as dist
     dist.barrier()
   torch.cuda.synchronize()
@@ -278,7 +290,6 @@ def main():
     step(i)
   t_enqueue = time.perf_counter() - t0      # host time to enqueue the timed steps
   torch.cuda.synchronize()
-  multi = dp is not None or ip is not None
   if multi:
     dist.barrier()
   dt = time.perf_counter() - t0
@@ -332,7 +343,9 @@ def main():
       "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
       "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
       "vs_baseline": None, "dtype": "f32",
-      "data": "synthetic" if not args.diag_reuse_block else "INVALID (diagnostic: no collation)",
+      "data": ("INVALID (diagnostic: no collation)" if args.diag_reuse_block else
+               "INVALID (diagnostic: one rank's share, no collectives)" if args.diag_virtual_world
+               else "synthetic"),
       "config": {"workload": cfg["workload"], "batch_size_per_gpu": cfg["batch_size"],
                  "global_batch": global_rows,
                  "parallelism": ("items%d (item-sharded tables, all users on every rank)" % world

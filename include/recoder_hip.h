@@ -197,11 +197,20 @@ int rk_decode_bwd_dw(const float *dO, const float *Z, int32_t B, int32_t h,
                      void *stream);
 /* rk_decode_bwd_dw + rk_ae_encode_bwd(accumulate = 0) on the same block in ONE
  * launch: the MFMA-bound dW tiles and the latency-bound encoder-backward gathers
- * are independent and share the GPU (untied weights only). */
+ * are independent and share the GPU (untied weights only).  For large B the dW
+ * contraction is split along K into `workspace` slabs, summed in fixed order. */
 int rk_decode_bwd_dw_encode_bwd(const float *dO, const float *Z, int32_t B, int32_t h,
                                 const rk_block_t *blk, float *G_de, int32_t row_off,
                                 const float *dZ0pre, float *G_en, float *gb_en,
-                                void *stream);
+                                float *workspace, void *stream);
+/* workspace of the call above (0: none needed; NULL is always accepted and disables the
+ * split-K of large batches) */
+int64_t rk_dw_workspace_bytes(int32_t B, int32_t h, int32_t n_cap);
+/* The fused call writes G_en as rk_encode_bwd_segments(B) partial arrays of n_cap*h floats
+ * each (row segments of long item columns; 1 below 513 rows) and gb_en as as many partial
+ * vectors of h floats: the gradients are their sums in segment order -- rk_adam_multi
+ * consumes them through g_parts / g_stride. */
+int32_t rk_encode_bwd_segments(int32_t B);
 
 /*
  * Hidden nn.Linear stack (nn.py:242-249): Y = act(X W^T + b), and backward.

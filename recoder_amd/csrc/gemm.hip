@@ -555,14 +555,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 // dO / dZ0) and complementary -- MFMA-bound tiles next to latency-bound gathers --
 // and the step is a serial chain of launches, so running them side by side takes the
 // encoder backward off the critical path without a second stream.
-template <int HV>
+template <int HV, bool SPLIT>
 __global__ __launch_bounds__(256) void dw_encode_bwd_kernel(
-    GemmP p, int n_dw, rk_block_t b, int row_off, int B, const float *__restrict__ dZ, int h,
-    float *__restrict__ G_en, float *__restrict__ gb, int n_gb) {
+    GemmP p, int n_dw, int nsplit, rk_block_t b, int row_off, int B, const float *__restrict__ dZ,
+    int h, float *__restrict__ G_en, float *__restrict__ gb, int n_gb, int n_seg,
+    int64_t seg_stride) {
   if ((int)blockIdx.x < n_dw)
-    gemm_body<1, 4, 1, 1, 1, 1, EPI_STORE, true, 16>(p, (int)blockIdx.x, 1);
+    gemm_body<1, 4, 1, 1, 1, 1, SPLIT ? EPI_SPLITK : EPI_STORE, true, 16>(p, (int)blockIdx.x, nsplit);
   else
-    ae_encode_bwd_body<HV>(b, row_off, B, dZ, h, G_en, 0, gb, n_gb, (int)blockIdx.x - n_dw);
+    ae_encode_bwd_body<HV>(b, row_off, B, dZ, h, G_en, 0, gb, n_gb, (int)blockIdx.x - n_dw, n_seg,
+                           seg_stride);
 }
 
 // ws[split][M][N] -> out[M][N] (fixed split order), optional * act'(Zact)
@@ -610,6 +612,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(
     }
     reinterpret_cast<float4 *>(out)[i] = s;
   }
+}
+
+// out[i] = sum_z ws[z][i] over the live rows of a [splits][M_cap][N] slab stack (dW split-K)
+__global__ __launch_bounds__(256) void slab_sum_kernel(const float *__restrict__ ws, int M_cap, int N,
+                                                       const int32_t *__restrict__ Mdev, int splits,
+                                                       float *__restrict__ out) {
+  const int64_t live4 = ((int64_t)(*Mdev) * N) >> 2, slab4 = ((int64_t)M_cap * N) >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= live4) return;
+  const float4 *w = reinterpret_cast<const float4 *>(ws);
+  float4 s = w[i];
+  for (int z = 1; z < splits; ++z) {
+    const float4 v = w[(int64_t)z * slab4 + i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  reinterpret_cast<float4 *>(out)[i] = s;
 }
 
 // MNLL second pass, one block per row (see rk_mnll_finish in the header)
@@ -686,13 +704,42 @@ __global__ __launch_bounds__(64) void loss_reduce_kernel(float *part, int n, flo
 
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
-constexpr int DZ_SPLITS = 64;
+constexpr int DZ_SPLITS = 64;        // at most; see dz_splits
+// split-K factor of the dZ GEMM: enough (row tile, split) pairs to fill the chip twice, a
+// multiple of 8 (the XCD tile mapping), never more than DZ_SPLITS -- at B = 500 that is 64, at
+// B = 4000 (item-parallel global batches) 16, so the partial slabs stay ~6x the output
+// split-K factor of the dW GEMM (K = B): its output has only n_b/32 x h/128 tiles, too few to
+// fill the chip once the batch is large and the item shard small (item-parallel ranks)
+inline int dw_splits(int B) {
+  static const int force = getenv("RK_DW_SPLITS") ? atoi(getenv("RK_DW_SPLITS")) : 0;   // tuning probe
+  if (force > 0) return force;
+  return B >= 3000 ? 4 : (B >= 1500 ? 2 : 1);
+}
+
+inline int dz_splits(int B) {
+  const int tiles_m = rk_cdiv(B, 128);
+  int s = (512 / tiles_m) & ~7;
+  return s < 8 ? 8 : (s > DZ_SPLITS ? DZ_SPLITS : s);
+}
 constexpr int DEC_BM = 64;          // rows per decode tile (rk_loss_partials, gb_part rows)
 
 }  // namespace
 
 extern "C" int64_t rk_dz_workspace_bytes(int32_t B, int32_t h) {
-  return (int64_t)DZ_SPLITS * B * h * sizeof(float);
+  return (int64_t)dz_splits(B) * B * h * sizeof(float);
+}
+
+// row segments of the encoder backward inside rk_decode_bwd_dw_encode_bwd (see encoder_bwd.h)
+extern "C" int32_t rk_encode_bwd_segments(int32_t B) {
+  static const int force = getenv("RK_ENC_SEGS") ? atoi(getenv("RK_ENC_SEGS")) : 0;   // tuning probe
+  if (force > 0) return force;
+  const int s = rk_cdiv(B, 512);
+  return s < 1 ? 1 : (s > 8 ? 8 : s);
+}
+
+extern "C" int64_t rk_dw_workspace_bytes(int32_t B, int32_t h, int32_t n_cap) {
+  const int s = dw_splits(B);
+  return s > 1 ? (int64_t)s * n_cap * h * sizeof(float) : 0;
 }
 
 extern "C" int32_t rk_decode_row_tile(void) { return DEC_BM; }
@@ -792,7 +839,7 @@ extern "C" int rk_decode_bwd_dz(const float *dO, int32_t B, int32_t h, const rk_
   p.M = B; p.N = h; p.K = tgt->n_cap; p.Kdev = tgt->counts;
   p.C = workspace;
   p.kchunk = 0;                       // derived in-kernel from the device-resident n_t
-  const int splits = DZ_SPLITS;
+  const int splits = dz_splits(B);
   const int kchunk = 0;
   // wave tile 32 x (32*TN): pick TN by h
   const int tn = h <= 64 ? 2 : (h <= 128 ? 4 : (h <= 224 ? 7 : 8));
@@ -825,10 +872,12 @@ extern "C" int rk_decode_bwd_dw(const float *dO, const float *Z, int32_t B, int3
   p.M = tgt->n_cap; p.Mdev = tgt->counts; p.N = h; p.K = B;
   p.kchunk = B;
   p.C = G_de; p.ldc = h; p.act = RK_ACT_NONE;
-  p.tiles_m = rk_cdiv(tgt->n_cap, 32);
   {
-    // 32 x 128 tiles, BK = 32 (two workgroups per CU at h = 200)
+    // 32 x 128 tiles, BK = 32 (two workgroups per CU at h = 200).  Larger tiles (64x64 ...
+    // 128x128) were probed at B = 500 and at item-parallel shapes (B = 4000, n_b = 2.3k):
+    // none is faster -- the contraction has too few output tiles, split-K is what helps.
     p.n_fastest = 1;   // the h/128 column tiles of one dO panel stay on one XCD
+    p.tiles_m = rk_cdiv(tgt->n_cap, 32);
     const int tiles = rk_cdiv(p.tiles_m * rk_cdiv(h, 128), 8) * 8;
     RK_LAUNCH((gemm_kernel<1, 4, 1, 1, 1, 1, EPI_STORE, true, 32>), dim3(tiles, 1),
                        dim3(256), 0, stream, p);
@@ -842,32 +891,47 @@ extern "C" int rk_decode_bwd_dw(const float *dO, const float *Z, int32_t B, int3
 extern "C" int rk_decode_bwd_dw_encode_bwd(const float *dO, const float *Z, int32_t B, int32_t h,
                                            const rk_block_t *blk, float *G_de, int32_t row_off,
                                            const float *dZ0pre, float *G_en, float *gb_en,
-                                           void *stream_) {
+                                           float *workspace, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(h > 0 && h % 4 == 0 && h <= 1024, "h must be a multiple of 4, <= 1024");
-  RK_REQUIRE(aligned16(dO) && aligned16(Z) && aligned16(G_de), "operands must be 16-byte aligned");
+  RK_REQUIRE(aligned16(dO) && aligned16(Z) && aligned16(G_de) && aligned16(workspace),
+             "operands must be 16-byte aligned");
   RK_REQUIRE(row_off >= 0 && B >= 0 && row_off + B <= blk->S_cap, "row slice out of range");
   RK_REQUIRE(blk->bits_cr != nullptr && blk->pref_rc != nullptr,
              "block was built without the transposed bitmap / prefix index");
   if (B == 0) return 0;
+  // large batches: split K (= B) so that the few dW tiles still fill the chip; the slabs go to
+  // `workspace` (rk_dw_workspace_bytes) and are summed in split order by slab_sum_kernel
+  const int splits = workspace ? dw_splits(B) : 1;
   GemmP p = {};
   p.A = dO; p.lda_dev = blk->counts + 2;
   p.Bm = Z; p.ldb = h;
   p.M = blk->n_cap; p.Mdev = blk->counts; p.N = h; p.K = B;
-  p.kchunk = B;
-  p.C = G_de; p.ldc = h; p.act = RK_ACT_NONE;
+  p.kchunk = splits > 1 ? ((rk_cdiv(B, splits) + 31) & ~31) : B;
+  p.C = splits > 1 ? workspace : G_de; p.ldc = h; p.act = RK_ACT_NONE;
   p.tiles_m = rk_cdiv(blk->n_cap, 32);
   p.n_fastest = 1;
-  const int n_dw = rk_cdiv(p.tiles_m * rk_cdiv(h, 128), 8) * 8;
-  const int n_gb = gb_en ? rk_cdiv(h, 64) : 0;
-  const int grid = n_dw + blk->n_cap + n_gb;
+  const int n_dw = rk_cdiv(p.tiles_m * rk_cdiv(h, 128), 8) * 8 * splits;
+  const int n_seg = rk_encode_bwd_segments(B);
+  const int n_gb = gb_en ? rk_cdiv(h, 64) * n_seg : 0;
+  const int64_t seg_stride = (int64_t)blk->n_cap * h;
+  const int grid = n_dw + blk->n_cap * n_seg + n_gb;
   const int hv = rk_cdiv(h, 256);
-#define LAUNCH(HV)                                                                             \
-  RK_LAUNCH(dw_encode_bwd_kernel<HV>, dim3(grid), dim3(256), 0, stream, p, n_dw, *blk, row_off, B, \
-            dZ0pre, h, G_en, gb_en, n_gb)
-  if (hv == 1) LAUNCH(1); else if (hv == 2) LAUNCH(2); else LAUNCH(4);
+#define LAUNCH(HV, SPLIT)                                                                       \
+  RK_LAUNCH((dw_encode_bwd_kernel<HV, SPLIT>), dim3(grid), dim3(256), 0, stream, p, n_dw, splits, \
+            *blk, row_off, B, dZ0pre, h, G_en, gb_en, n_gb, n_seg, seg_stride)
+  if (splits > 1) {
+    if (hv == 1) LAUNCH(1, true); else if (hv == 2) LAUNCH(2, true); else LAUNCH(4, true);
+  } else {
+    if (hv == 1) LAUNCH(1, false); else if (hv == 2) LAUNCH(2, false); else LAUNCH(4, false);
+  }
 #undef LAUNCH
   RK_CHECK_LAUNCH("decode_bwd_dw_encode_bwd");
+  if (splits > 1) {
+    RK_LAUNCH(slab_sum_kernel, dim3(rk_cdiv((int64_t)blk->n_cap * h / 4, 256)), dim3(256), 0, stream,
+              workspace, blk->n_cap, h, blk->counts, splits, G_de);
+    RK_CHECK_LAUNCH("slab_sum");
+  }
   return 0;
 }
 

@@ -248,7 +248,9 @@ __device__ __forceinline__ void update_job(const UJob &J, int lb) {
     for (int64_t i = (int64_t)lb * 256 + threadIdx.x; i < tot; i += step) {
       const int r = (int)(i / hq), q = (int)(i % hq);
       const int64_t o = (int64_t)J.rows[r] * hq + q;
-      const T g = *reinterpret_cast<const T *>(J.g + i * V::W);
+      T g = *reinterpret_cast<const T *>(J.g + i * V::W);
+      for (int t = 1; t < J.g_parts; ++t)
+        V::add(g, *reinterpret_cast<const T *>(J.g + t * stride + i * V::W));
       T p1 = P[o], m1 = M[o], v1 = Vv[o];
       V::sadam(p1, m1, v1, g, J.c);
       P[o] = p1; M[o] = m1; Vv[o] = v1;
@@ -275,7 +277,15 @@ __device__ __forceinline__ void update_job(const UJob &J, int lb) {
     T g = V::zero();
     if (have) {
       g = *reinterpret_cast<const T *>(J.g + go);
-      for (int t = 1; t < J.g_parts; ++t)            // partial gradients, fixed order
+      int t = 1;
+      for (; t + 8 <= J.g_parts; t += 8) {           // partial gradients, fixed order; the
+        T v[8];                                      // loads of a group are independent
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const T *>(J.g + (t + u) * stride + go);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) V::add(g, v[u]);
+      }
+      for (; t < J.g_parts; ++t)
         V::add(g, *reinterpret_cast<const T *>(J.g + t * stride + go));
     }
     T p1 = P[e], m1 = M[e], v1 = Vv[e];
@@ -290,16 +300,27 @@ __device__ __forceinline__ void run_job(const UJob &J, int b) {
 }
 
 __global__ __launch_bounds__(256) void adam_multi_kernel(UArgs a) {
-  const int b = blockIdx.x;
-  if (a.loss_part && b == (int)gridDim.x - 1) {
-    // loss = sum(partials) / denom in double, fixed order; the partials are re-zeroed
-    // for the next rk_decode_loss
+  int b = blockIdx.x;
+  if (a.loss_part) {
+    if (b != 0) {
+      --b;
+    } else {
+    // workgroup 0 (dispatched first: its dependent-load chain hides behind the sweeps):
+    // loss = sum(partials) / denom in double, fixed order; loads first (they pipeline), then
+    // the partials are re-zeroed for the next rk_decode_loss
     __shared__ double red[256];
     double s = 0.0;
-    for (int i = threadIdx.x; i < a.n_part; i += 256) {
-      s += (double)a.loss_part[i];
-      a.loss_part[i] = 0.f;
+    int i = threadIdx.x;
+    for (; i + 7 * 256 < a.n_part; i += 8 * 256) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = a.loss_part[i + u * 256];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
     }
+    for (; i < a.n_part; i += 256) s += (double)a.loss_part[i];
+    __syncthreads();
+    for (i = threadIdx.x; i < a.n_part; i += 256) a.loss_part[i] = 0.f;
     red[threadIdx.x] = s;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
@@ -308,6 +329,7 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(UArgs a) {
     }
     if (threadIdx.x == 0) a.loss_out[0] = (float)red[0] / a.denom;
     return;
+    }
   }
   // static indices only (a dynamically indexed by-value struct would go to scratch)
   if (a.n_jobs > 5 && b >= a.job[5].blk0) run_job(a.job[5], b);

@@ -123,7 +123,7 @@ static int step_item_parallel(const rk_ae_step_t *a, int phase) {
     } else {
       Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
       RK_TRY(rk_decode_bwd_dw_encode_bwd(a->dO, a->Z0, B, h, blk, a->G_de, a->row_off, a->dZ0, G_en,
-                                         a->gb_en, sm));
+                                         a->gb_en, a->ws, sm));
     }
     rk_adam_job_t jobs[4];
     int n = 0;
@@ -135,9 +135,14 @@ static int step_item_parallel(const rk_ae_step_t *a, int phase) {
       jobs[n].g = a->gb_part; jobs[n].g_parts = row_tiles; jobs[n].gstride_dev = blk->counts + 2;
     }
     ++n;
+    if (!(a->tied || mnll)) {        // the fused launch wrote G_en in row segments
+      jobs[0].g_parts = rk_encode_bwd_segments(B); jobs[0].g_stride = blk->n_cap * h;
+    }
     for (int j = 0; j < n; ++j)
       if (!jobs[j].par.sparse) { jobs[j].row0 = a->own_rank; jobs[j].row_step = a->own_world; }
-    jobs[n++] = table_job(a->par[RK_PAR_B_EN], blk, 1, h, a->gb_en, false);
+    jobs[n] = table_job(a->par[RK_PAR_B_EN], blk, 1, h, a->gb_en, false);
+    if (!(a->tied || mnll)) { jobs[n].g_parts = rk_encode_bwd_segments(B); jobs[n].g_stride = h; }
+    ++n;
     Timer t(a, RK_ENTRY_ADAM_MULTI, sm);
     RK_TRY(rk_adam_multi(jobs, n, a->loss_part, n_part, a->denom, a->loss_out, sm));
   }
@@ -203,13 +208,16 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     } else {
       Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
       RK_TRY(rk_decode_bwd_dw_encode_bwd(a->dO, a->Z0, B, h, blk, a->G_de, a->row_off, a->dZ0, G_en,
-                                         a->gb_en, sm));
+                                         a->gb_en, a->ws, sm));
     }
   }
   if (phase & RK_STEP_UPDATE) {
     rk_adam_job_t jobs[4];
     int n = 0;
     jobs[n++] = table_job(a->par[RK_PAR_W_EN], blk, n_items, h, G_en, true);
+    if (whole && !(a->tied || mnll)) {   // the fused launch wrote G_en in row segments
+      jobs[0].g_parts = rk_encode_bwd_segments(B); jobs[0].g_stride = blk->n_cap * h;
+    }
     if (!a->tied) jobs[n++] = table_job(a->par[RK_PAR_W_DE], blk, n_items, h, a->G_de, true);
     jobs[n] = table_job(a->par[RK_PAR_B_DE], blk, n_items, 1, a->gb_de, true);
     jobs[n].par.sparse = 0; jobs[n].rows = nullptr; jobs[n].n_dev = nullptr; jobs[n].pos = blk->pos;
@@ -217,7 +225,11 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       jobs[n].g = a->gb_part; jobs[n].g_parts = row_tiles; jobs[n].gstride_dev = blk->counts + 2;
     }
     ++n;
-    jobs[n++] = table_job(a->par[RK_PAR_B_EN], blk, 1, h, a->gb_en, false);
+    jobs[n] = table_job(a->par[RK_PAR_B_EN], blk, 1, h, a->gb_en, false);
+    if (whole && !(a->tied || mnll)) {
+      jobs[n].g_parts = rk_encode_bwd_segments(B); jobs[n].g_stride = h;
+    }
+    ++n;
     Timer t(a, RK_ENTRY_ADAM_MULTI, sm);
     RK_TRY(rk_adam_multi(jobs, n, whole ? a->loss_part : nullptr, n_part, a->denom,
                          whole ? a->loss_out : nullptr, sm));

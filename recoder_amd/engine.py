@@ -46,7 +46,7 @@ class TimedLib:
 
   def __getattr__(self, name):
     fn = getattr(self._lib, name)
-    if not name.startswith("rk_") or name in ("rk_dz_workspace_bytes", "rk_loss_partials", "rk_decode_row_tile",
+    if not name.startswith("rk_") or name in ("rk_dz_workspace_bytes", "rk_dw_workspace_bytes", "rk_encode_bwd_segments", "rk_loss_partials", "rk_decode_row_tile",
                                               "rk_last_error", "rk_version"):
       return fn
 
@@ -126,7 +126,8 @@ class FusedEngine:
     self.B_cap, self.n_cap, self.ld_cap = B_cap, n_cap, ld_cap
     self.dO = torch.empty(B_cap * ld_cap, **f)
     self.G_de = torch.empty(n_cap * h0, **f)
-    self.G_en = torch.empty(n_cap * h0, **f)
+    # the fused dW + encoder-backward launch writes G_en in row segments (long item columns)
+    self.G_en = torch.empty(n_cap * h0 * self.lib.rk_encode_bwd_segments(B_cap), **f)
     # small gradients in ONE buffer [gb_en (h0) | loss | pad | gb_de (n_cap)] so that a
     # data-parallel step reduces them with a single collective over [0, off + n_b)
     self.small_off = cdiv(h0 + 1, 4) * 4
@@ -135,8 +136,11 @@ class FusedEngine:
     self.row_tile = self.lib.rk_decode_row_tile()
     self.gb_part = torch.empty(cdiv(B_cap, self.row_tile) * ld_cap, **f)   # per-row-tile colsums of dO
     self.gb_en = self.small[:h0]
+    # the one-call step gets the encoder-bias gradient as row-segment partial vectors
+    self.gb_en_parts = torch.zeros(8 * h0, **f)
     self.loss_dp = self.small[h0:h0 + 1]
-    self.ws = torch.empty(self.lib.rk_dz_workspace_bytes(B_cap, h0) // 4, **f)
+    self.ws = torch.empty(max(self.lib.rk_dz_workspace_bytes(B_cap, h0),
+                              self.lib.rk_dw_workspace_bytes(B_cap, h0, n_cap)) // 4, **f)
     self.n_part = self.lib.rk_loss_partials(B_cap, n_cap)
     self.loss_part = torch.zeros(self.n_part, **f)
     self.loss_out = torch.zeros(1, **f)
@@ -314,6 +318,7 @@ class FusedEngine:
       raise NotImplementedError("item-parallel training runs through rk_ae_train_step only "
                                 "(DynamicAutoencoder([h]) without bottleneck dropout)")
     self._gb_lazy = None
+    self._gb_en_segs = 0
     stream = ctypes.c_void_p(main_s.cuda_stream)
     self.rng_step += 1
     h0 = self.h[0]
@@ -453,7 +458,10 @@ class FusedEngine:
     loss_dst = self.loss_dp if dp is not None else out
     st.Z0, st.dZ0, st.dO = ptr(self.enc[0]), ptr(self.denc[0]), ptr(self.dO)
     st.G_de, st.G_en, st.gb_de = ptr(self.G_de), ptr(self.G_en), ptr(self.gb_de)
-    st.gb_part, st.gb_en, st.ws = ptr(self.gb_part), ptr(self.gb_en), ptr(self.ws)
+    st.gb_part, st.ws = ptr(self.gb_part), ptr(self.ws)
+    segmented = dp is None and not m.is_constrained and self.loss_id != LOSS_MNLL
+    st.gb_en = ptr(self.gb_en_parts if segmented else self.gb_en)
+    self._gb_en_segs = self.lib.rk_encode_bwd_segments(B) if segmented else 0
     st.loss_part, st.loss_out = ptr(self.loss_part), ptr(loss_dst)
     st.stream = main_s.cuda_stream
     self._c_calls += 1
@@ -525,6 +533,14 @@ class FusedEngine:
     tiles, blk = self._gb_lazy
     ld = blk.counts_host()[2]
     return self.gb_part[:tiles * ld].view(tiles, ld)[:, :n_b].sum(0)
+
+  def encoder_bias_grad(self):
+    """gb_en of the last training step (tests): the one-call step leaves it as row-segment
+    partial vectors for rk_adam_multi."""
+    n, h0 = getattr(self, "_gb_en_segs", 0), self.h[0]
+    if not n:
+      return self.gb_en.clone()
+    return self.gb_en_parts[:n * h0].view(n, h0).sum(0)
 
   def event_pair_overhead_ms(self, n=64):
     """Elapsed time of a timing-event pair with nothing between the two records."""

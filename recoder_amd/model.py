@@ -414,10 +414,13 @@ class Recoder(object):
 
   def _make_block(self, dcsr, S, negative_sampling):
     nnz_cap = max(1, _top_sum(dcsr.degrees, S))
-    world = self._dp.world if getattr(self, "_dp", None) is not None else 1
-    # a data-parallel union item set can exceed one rank's nnz bound
+    n_cap = nnz_cap
+    if getattr(self, "_dp", None) is not None:
+      n_cap = nnz_cap * self._dp.world      # the union item set can exceed one rank's nnz bound
+    if getattr(self, "_ip", None) is not None and negative_sampling:
+      n_cap = min(nnz_cap, -(-dcsr.n_items // self._ip.world))   # at most the owned items
     return Block(S, nnz_cap, dcsr.n_items, self.device, negative_sampling=negative_sampling,
-                 n_cap=nnz_cap * world)
+                 n_cap=n_cap)
 
   def _step_generator(self, dataloader):
     """Yields (blk, row_off, B, keep_noise, keep_drop) for one pass over the

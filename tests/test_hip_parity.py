@@ -361,7 +361,7 @@ def test_steps_match_oracle(name, c, shape, B, S):
       G_en = eng.G_en[:n_b * h0].view(n_b, h0).cpu().numpy()
       check("W_en[items]", G_en, grads[orc.AE_EN_W][items_idx].numpy())
     check("b_de[items]", gb_de, grads[orc.AE_DE_B][items_idx].numpy())
-    check("b_en", eng.gb_en.cpu().numpy(), grads[orc.AE_EN_B].numpy())
+    check("b_en", eng.encoder_bias_grad().cpu().numpy(), grads[orc.AE_EN_B].numpy())
     for i in range(eng.nl):
       check("enc%d.W" % i, eng.g_enc_w[i].cpu().numpy(), grads["encoding_layers.%d.weight" % i].numpy())
       check("enc%d.b" % i, eng.g_enc_b[i].cpu().numpy(), grads["encoding_layers.%d.bias" % i].numpy())
@@ -606,7 +606,11 @@ def test_item_parallel_two_virtual_ranks_equal_single_process(case):
   from recoder_amd.model import Recoder
   from recoder_amd.nn import DynamicAutoencoder
   from recoder_amd.parallel import ItemParallel
-  csr = synth_csr(900, 1500, 20, seed=21)
+  # mse_dense runs a global batch of 1600 rows: split-K dW (2 slabs) and 4 row segments in the
+  # encoder backward; the other case stays below both thresholds
+  big = case == "mse_dense"
+  csr = synth_csr(3300 if big else 900, 1500, 20, seed=21)
+  gb = 1600 if big else 300
   if case == "mse_dense":
     mk = lambda: DynamicAutoencoder([64], activation_type="tanh", noise_prob=0.0, sparse=False)
     loss, wd = "mse", 2e-5
@@ -624,8 +628,8 @@ def test_item_parallel_two_virtual_ranks_equal_single_process(case):
     rec.user_order_hook = lambda epoch, n: order
     return model, rec
 
-  model0, rec0 = new(300)
-  rec0.train(RecommendationDataset(csr), batch_size=300, **kw)
+  model0, rec0 = new(gb)
+  rec0.train(RecommendationDataset(csr), batch_size=gb, **kw)
   base_l = np.concatenate(rec0.loss_history)
   base_p = {k: v.detach().cpu().clone() for k, v in model0.named_parameters()}
 
@@ -633,7 +637,7 @@ def test_item_parallel_two_virtual_ranks_equal_single_process(case):
   vr = _VirtualRanks(world)
   reps = []
   for r in range(world):
-    model, rec = new(150)
+    model, rec = new(gb // world)
     rec._Recoder__init_training(RecommendationDataset(csr), kw["lr"], wd)   # same seed, main thread
     rec._ip_override = ItemParallel(rank=r, world=world, allreduce_fn=vr.allreduce(r),
                                     allgather_fn=vr.allgather(r))
@@ -643,7 +647,7 @@ def test_item_parallel_two_virtual_ranks_equal_single_process(case):
   def run(r):
     try:
       torch.cuda.set_device(0)
-      reps[r][1].train(RecommendationDataset(csr), batch_size=150, **kw)
+      reps[r][1].train(RecommendationDataset(csr), batch_size=gb // world, **kw)
     except BaseException as e:       # noqa: B036 -- release the other thread
       errs.append(e)
       vr.barrier.abort()

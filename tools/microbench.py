@@ -44,6 +44,10 @@ def main():
   dev = torch.device("cuda")
   h = int(os.environ.get("H", "200"))
   csr = synthetic.ml20m_like(seed=0, n_users=20000)
+  shard = int(os.environ.get("SHARD", "1"))       # item-parallel shard of rank 0 (items % SHARD == 0)
+  if shard > 1:
+    from recoder_amd.parallel import ItemParallel
+    csr = ItemParallel(rank=0, world=shard, allreduce_fn=lambda t: t).shard_csr(csr)
   dcsr = DeviceCSR(csr)
   n_items = csr.shape[1]
   f = dict(dtype=torch.float32, device=dev)
@@ -54,7 +58,8 @@ def main():
   st = current_stream()
   for B in Bs:
     users = torch.arange(B, dtype=torch.int64, device=dev)
-    blk = Block(B, int(np.sort(dcsr.degrees)[-B:].sum()), n_items, dev)
+    blk = Block(B, int(np.sort(dcsr.degrees)[-B:].sum()), n_items, dev,
+                n_cap=(-(-n_items // shard) if shard > 1 else None))
     blk.collate(dcsr, users)
     n_b, nnz, ld, S = blk.counts_host()
     Z = torch.randn(B, h, **f)
@@ -82,6 +87,13 @@ def main():
     r["enc_fwd"] = timeit(lambda: check(lib.rk_ae_encode_fwd(
         blk.ref, 0, B, ptr(W), ptr(bias), h, None, 0.5, 1, 1, ptr(users), 1, ptr(Z0), st)))
     r["enc_bwd"] = timeit(lambda: check(lib.rk_ae_encode_bwd(blk.ref, 0, B, ptr(dZ), h, ptr(G), 0, None, st)))
+    nseg = lib.rk_encode_bwd_segments(B)
+    Gs = torch.empty(blk.n_cap * h * nseg, **f)
+    wsd = torch.empty(max(4, lib.rk_dw_workspace_bytes(B, h, blk.n_cap) // 4), **f)
+    r["dw+enc_bwd"] = timeit(lambda: check(lib.rk_decode_bwd_dw_encode_bwd(
+        ptr(dO), ptr(Z), B, h, blk.ref, ptr(G), 0, ptr(dZ), ptr(Gs), None, ptr(wsd), st)))
+    r["dw+enc_nosplit"] = timeit(lambda: check(lib.rk_decode_bwd_dw_encode_bwd(
+        ptr(dO), ptr(Z), B, h, blk.ref, ptr(G), 0, ptr(dZ), ptr(Gs), None, None, st)))
     r["adam_tab"] = timeit(lambda: check(lib.rk_adam_table(
         ptr(W), ptr(m), ptr(v), n_items, h, ptr(blk.pos), ptr(G), 1e-3, 0.9, 0.999, 1e-8, 2e-5, 1, st)))
     gf = 2.0 * B * h * n_b / 1e9
