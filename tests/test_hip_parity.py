@@ -275,6 +275,18 @@ STEP_CASES = [
                                sparse=False, loss="logistic", loss_params=None, lr=1e-3,
                                weight_decay=2e-5),
    (800, 1500, 25), 256, 256),
+  # edge shapes (names starting with "edge": every 5th user has NO interactions): fewer than 32
+  # sampled items, a ragged last batch (37 users in batches of 16), one-row batches
+  ("edge_tiny_ae8", dict(kind="ae", hidden_layers=[8], activation_type="tanh", noise_prob=0.0,
+                         sparse=False, loss="mse", loss_params=None, lr=1e-3, weight_decay=2e-5),
+   (37, 40, 4), 16, 16),
+  ("edge_tiny_ae8_bce_sparse", dict(kind="ae", hidden_layers=[8], activation_type="relu", noise_prob=0.0,
+                                    sparse=True, loss="logistic", loss_params=None, lr=1e-3,
+                                    weight_decay=0.0),
+   (37, 40, 4), 7, 21),
+  ("edge_b1_mf4", dict(kind="mf", embedding_size=4, activation_type="tanh", sparse=False,
+                       loss="mse", loss_params=None, lr=1e-3, weight_decay=2e-5),
+   (9, 33, 3), 1, 1),
 ]
 
 
@@ -284,6 +296,12 @@ def test_steps_match_oracle(name, c, shape, B, S):
   from recoder_amd.model import Recoder
   n_users, n_items, deg = shape
   csr = synth_csr(n_users, n_items, deg, seed=len(name), ratings=(c["loss"] == "mse"))
+  if name.startswith("edge"):
+    keep = np.ones(n_users, dtype=bool)
+    keep[::5] = False
+    csr = sp.diags(keep.astype(np.float32)).dot(csr).tocsr()
+    csr.eliminate_zeros()
+    csr.sort_indices()
   ns = c.get("negative_sampling", True)
   torch.manual_seed(7)
   model = make_model(c)
