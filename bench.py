@@ -200,6 +200,7 @@ def main():
     dp.attach(eng)
   if ip is not None:
     ip.user_norm_dev = torch.from_numpy(ItemParallel.user_norms(csr_full)).to(device)
+    ip.prepare(device)
     eng.item_parallel = ip
   dcsr = ds.device_csr()                      # CSR resident in HBM before timing
   # the union item set over all ranks can exceed one rank's nnz bound

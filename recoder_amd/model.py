@@ -408,6 +408,7 @@ class Recoder(object):
     from .parallel import ItemParallel
     full = train_dataset.interactions_matrix
     ip.user_norm_dev = torch.from_numpy(ItemParallel.user_norms(full)).to(self.device)
+    ip.prepare(self.device)
     self._engine().item_parallel = ip
     self._ip = ip
     return RecommendationDataset(ip.shard_csr(full))

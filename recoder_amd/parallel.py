@@ -28,6 +28,8 @@ the single-process run with batch_size = N * B.
 Nothing here touches the HIP library, so the same code runs under gloo on CPU
 tensors in tests/test_parallel.py.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -150,6 +152,31 @@ class ItemParallel:
     self._allreduce = allreduce_fn
     self._allgather = allgather_fn
     self.user_norm_dev = None
+    self._rccl = None
+    self._rccl_tried = False
+
+  def _direct(self, t):
+    """Our own RCCL communicator (recoder_amd/rccl.py: collectives enqueued in order on the
+    step's stream, no cross-stream event pairs) for device tensors on the nccl backend;
+    RK_COMM=torch, or any failure while creating it, keeps torch.distributed."""
+    if not self._rccl_tried:
+      self._rccl_tried = True
+      if t.is_cuda and dist.get_backend(self.group) == "nccl" and \
+          os.environ.get("RK_COMM", "rccl") != "torch":
+        try:
+          from .rccl import RcclComm
+          self._rccl = RcclComm(self.group, t.device)
+        except Exception as e:      # noqa: BLE001 -- any bootstrap problem: torch.distributed
+          import warnings
+          warnings.warn("direct RCCL communicator unavailable (%s); using torch.distributed" % e)
+          self._rccl = None
+    return self._rccl if t.is_cuda else None
+
+  def prepare(self, device):
+    """Create the direct communicator now (a collective: every rank calls it)."""
+    if self._allreduce is None and dist.is_initialized():
+      self._direct(torch.zeros(1, dtype=torch.float32, device=device))
+    return self
 
   def owns(self, item_ids):
     return (np.asarray(item_ids) % self.world) == self.rank
@@ -176,6 +203,9 @@ class ItemParallel:
     """In-place SUM over the ranks, ordered on the current stream."""
     if self._allreduce is not None:
       return self._allreduce(t)
+    comm = self._direct(t)
+    if comm is not None:
+      return comm.all_reduce(t)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
     return t
 

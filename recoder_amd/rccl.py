@@ -1,0 +1,92 @@
+"""Thin RCCL binding for the exchanges of the training step.
+
+torch.distributed runs every collective on ProcessGroupNCCL's own stream and joins it
+to the caller's stream with an event pair on each side; on this stack a cross-stream
+dependency costs 10-20 us of latency (tools/sync_cost2.py), i.e. several tens of us per
+all-reduce of a step that takes 160-370 us.  A communicator of our own lets the
+collective be enqueued IN ORDER on the step's stream: ncclAllReduce(..., stream).
+
+The communicator is bootstrapped through the already initialised torch.distributed
+group (rank 0's ncclUniqueId is broadcast with it) and uses the librccl.so that torch
+itself loaded.  If anything fails, callers fall back to torch.distributed.
+"""
+import ctypes
+import os
+
+import torch
+import torch.distributed as dist
+
+NCCL_UNIQUE_ID_BYTES = 128
+ncclSum, ncclMax = 0, 2
+ncclInt32, ncclFloat32 = 2, 7
+
+
+class _UniqueId(ctypes.Structure):
+  _fields_ = [("internal", ctypes.c_ubyte * NCCL_UNIQUE_ID_BYTES)]   # opaque bytes (NULs inside)
+
+
+_lib = None
+
+
+def _load():
+  global _lib
+  if _lib is None:
+    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    lib = ctypes.CDLL(path)
+    lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(_UniqueId)]
+    lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _UniqueId,
+                                     ctypes.c_int]
+    lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                  ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    lib.ncclGetErrorString.restype = ctypes.c_char_p
+    lib.ncclGetErrorString.argtypes = [ctypes.c_int]
+    _lib = lib
+  return _lib
+
+
+def _check(rc, what):
+  if rc != 0:
+    raise RuntimeError("%s failed: %s" % (what, _load().ncclGetErrorString(rc).decode()))
+
+
+class RcclComm:
+  """One RCCL communicator spanning a torch.distributed group (default: the world)."""
+
+  def __init__(self, group=None, device=None):
+    lib = _load()
+    self.rank = dist.get_rank(group)
+    self.world = dist.get_world_size(group)
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    uid = _UniqueId()
+    if self.rank == 0:
+      _check(lib.ncclGetUniqueId(ctypes.byref(uid)), "ncclGetUniqueId")
+    t = torch.frombuffer(bytearray(ctypes.string_at(ctypes.byref(uid), NCCL_UNIQUE_ID_BYTES)),
+                         dtype=torch.uint8).to(device)
+    src = 0 if group is None else dist.get_global_rank(group, 0)
+    dist.broadcast(t, src=src, group=group)
+    raw = bytes(t.cpu().numpy().tobytes())
+    ctypes.memmove(ctypes.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
+    self.comm = ctypes.c_void_p()
+    torch.cuda.synchronize(device)
+    _check(lib.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank),
+           "ncclCommInitRank")
+
+  def all_reduce(self, t, op=ncclSum, stream=None):
+    """In place on the given (default: current) stream, ordered with the kernels around it."""
+    assert t.is_cuda and t.is_contiguous()
+    if t.dtype == torch.float32:
+      dt = ncclFloat32
+    elif t.dtype == torch.int32:
+      dt = ncclInt32
+    else:
+      raise TypeError("unsupported dtype %s" % t.dtype)
+    s = stream if stream is not None else torch.cuda.current_stream()
+    _check(_load().ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), dt, op, self.comm,
+                                 ctypes.c_void_p(s.cuda_stream)), "ncclAllReduce")
+    return t
+
+  def destroy(self):
+    if self.comm:
+      _load().ncclCommDestroy(self.comm)
+      self.comm = ctypes.c_void_p()
