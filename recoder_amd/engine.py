@@ -221,10 +221,21 @@ class FusedEngine:
   def _ae_forward(self, blk, row_off, B, keep_noise, keep_drop, train, stream):
     m, lib = self.model, self.lib
     p_noise = float(m.noise_prob) if train else 0.0
-    check(lib.rk_ae_encode_fwd(blk.ref, row_off, B, ptr(m.en_embedding_layer.weight),
-                               ptr(m.en_bias), self.h[0], ptr(keep_noise), p_noise, self.seed,
-                               self.rng_step, ptr(blk.users), self.act, ptr(self.enc[0]), stream),
-          "rk_ae_encode_fwd")
+    ip = self.item_parallel if train else None
+    if ip is not None:
+      # item parallel: partial sums over this rank's items -> all-reduce -> bias + activation
+      h0 = self.h[0]
+      check(lib.rk_ae_encode_fwd_partial(blk.ref, row_off, B, ptr(m.en_embedding_layer.weight), h0,
+                                         ptr(keep_noise), p_noise, self.seed, self.rng_step,
+                                         ptr(blk.users), ptr(ip.user_norm_dev), ptr(self.enc[0]),
+                                         stream), "rk_ae_encode_fwd_partial")
+      ip.allreduce_sum(self.enc[0][:B * h0])
+      check(lib.rk_bias_act(ptr(self.enc[0]), ptr(m.en_bias), B, h0, self.act, stream), "rk_bias_act")
+    else:
+      check(lib.rk_ae_encode_fwd(blk.ref, row_off, B, ptr(m.en_embedding_layer.weight),
+                                 ptr(m.en_bias), self.h[0], ptr(keep_noise), p_noise, self.seed,
+                                 self.rng_step, ptr(blk.users), self.act, ptr(self.enc[0]), stream),
+            "rk_ae_encode_fwd")
     for i, layer in enumerate(m.encoding_layers):
       check(lib.rk_linear_fwd(ptr(self.enc[i]), ptr(layer.weight), ptr(layer.bias), B, self.h[i + 1],
                               self.h[i], 0, self.act, ptr(self.enc[i + 1]), stream), "rk_linear_fwd")
@@ -314,9 +325,10 @@ class FusedEngine:
     main_s = torch.cuda.current_stream()
     if self.use_c_step and self.kind == "ae" and self.nl == 0 and not (m.dropout_prob > 0.0):
       return self._c_train_step(blk, row_off, B, keep_noise, out, global_rows, main_s)
-    if self.item_parallel is not None:
-      raise NotImplementedError("item-parallel training runs through rk_ae_train_step only "
-                                "(DynamicAutoencoder([h]) without bottleneck dropout)")
+    ip = self.item_parallel
+    if ip is not None and self.loss_id == LOSS_MNLL:
+      raise NotImplementedError("item-parallel training supports the mse / logistic losses (the "
+                                "softmax of the multinomial loss spans every rank's items)")
     self._gb_lazy = None
     self._gb_en_segs = 0
     stream = ctypes.c_void_p(main_s.cuda_stream)
@@ -357,9 +369,14 @@ class FusedEngine:
     dz = self.denc[0] if simple else self.dbott
     if self.kind == "ae" and self.nl > 0:
       dz = self.ddec[self.nl - 1]
+    fuse_act = simple and ip is None        # act' folded into the split-K reduce
     check(lib.rk_decode_bwd_dz(ptr(self.dO), B, h0, blk.ref, ptr(W_de),
-                               ptr(self.enc[0]) if simple else None, self.act, ptr(dz),
+                               ptr(self.enc[0]) if fuse_act else None, self.act, ptr(dz),
                                ptr(self.ws), stream), "rk_decode_bwd_dz")
+    if ip is not None:
+      # item parallel: dLoss/d(decoder input) summed over the ranks' item shards; everything
+      # upstream (hidden stacks, user rows) is replicated and sees identical inputs
+      ip.allreduce_sum(dz[:B * h0])
 
     if self.kind == "ae":
       rh = list(reversed(self.h))
@@ -392,7 +409,7 @@ class FusedEngine:
                                 ptr(self.denc[i]), ptr(self.g_enc_w[i]),
                                 1 if m.is_constrained else 0, ptr(self.g_enc_b[i]), stream),
               "rk_linear_bwd")
-      if not simple:
+      if not fuse_act:
         check(lib.rk_act_grad(ptr(self.denc[0]), ptr(self.enc[0]), B * h0, self.act, stream),
               "rk_act_grad")
       G_en = self.G_de if tied else self.G_en      # tied: accumulates on top of dW's rows

@@ -333,9 +333,12 @@ class Recoder(object):
     ip = getattr(self, "_ip", None)
     if ip is not None:
       m = self.model
-      params = [m.en_embedding_layer.weight, m.de_bias]
-      if not m.is_constrained:
-        params.append(m.de_embedding_layer.weight)
+      if self._fused_kind() == "mf":
+        params = [m.item_embedding_layer.weight, m.bias]     # user rows are replicated
+      else:
+        params = [m.en_embedding_layer.weight, m.de_bias]
+        if not m.is_constrained:
+          params.append(m.de_embedding_layer.weight)
       tensors = []
       for w in params:
         tensors.append(w.data)
@@ -380,15 +383,14 @@ class Recoder(object):
     # RK_PARALLEL = items | users | auto: shard the ITEM dimension (two small [N*B, h]
     # all-reduces per step, 1/N of the Adam sweep) where the step supports it, else the users
     m = self.model
-    ip_ok = (self._fused_kind() == "ae" and len(m.hidden_layers) == 1 and not m.dropout_prob > 0.0
-             and self._loss_name in ("mse", "logistic"))
+    ip_ok = self._loss_name in ("mse", "logistic")
     mode = os.environ.get("RK_PARALLEL", "auto")
     if mode == "auto":
       mode = "items" if ip_ok else "users"
     if mode == "items":
       if not ip_ok:
-        raise NotImplementedError("item-parallel training covers DynamicAutoencoder([h]) with "
-                                  "the mse / logistic losses; use RK_PARALLEL=users")
+        raise NotImplementedError("item-parallel training covers the mse / logistic losses (the "
+                                  "multinomial softmax spans all items); use RK_PARALLEL=users")
       from .parallel import ItemParallel
       return self._enable_item_parallel(ItemParallel(), train_dataset)
     from .parallel import DataParallel, shard_range

@@ -614,7 +614,7 @@ class _VirtualRanks:
     return lambda t: self._exchange(rank, t)
 
 
-@pytest.mark.parametrize("case", ["mse_dense", "bce_sparse_tied"])
+@pytest.mark.parametrize("case", ["mse_dense", "bce_sparse_tied", "ae2_dropout", "mf_dense", "mf_sparse"])
 def test_item_parallel_two_virtual_ranks_equal_single_process(case):
   """parallel.ItemParallel with N = 2 on one GPU (two threads, injected collectives):
   item i on rank i % 2, every rank sees all users; after training and the owners'
@@ -622,7 +622,7 @@ def test_item_parallel_two_virtual_ranks_equal_single_process(case):
   import threading
   from recoder_amd.data import RecommendationDataset
   from recoder_amd.model import Recoder
-  from recoder_amd.nn import DynamicAutoencoder
+  from recoder_amd.nn import DynamicAutoencoder, MatrixFactorization
   from recoder_amd.parallel import ItemParallel
   # mse_dense runs a global batch of 1600 rows: split-K dW (2 slabs) and 4 row segments in the
   # encoder backward; the other case stays below both thresholds
@@ -632,10 +632,19 @@ def test_item_parallel_two_virtual_ranks_equal_single_process(case):
   if case == "mse_dense":
     mk = lambda: DynamicAutoencoder([64], activation_type="tanh", noise_prob=0.0, sparse=False)
     loss, wd = "mse", 2e-5
-  else:
+  elif case == "bce_sparse_tied":
     mk = lambda: DynamicAutoencoder([32], activation_type="sigmoid", noise_prob=0.0, sparse=True,
                                     is_constrained=True)
     loss, wd = "logistic", 0.0
+  elif case == "ae2_dropout":
+    # hidden stack + bottleneck dropout (counter RNG keyed on the batch row: identical on all
+    # ranks): the per-entry Python sequencing of the step
+    mk = lambda: DynamicAutoencoder([48, 24], activation_type="tanh", noise_prob=0.0, dropout_prob=0.3,
+                                    sparse=False)
+    loss, wd = "mse", 1e-5
+  else:
+    mk = lambda: MatrixFactorization(24, activation_type="tanh", sparse=(case == "mf_sparse"))
+    loss, wd = "logistic", (0.0 if case == "mf_sparse" else 2e-5)
   order = np.random.RandomState(5).permutation(csr.shape[0]).astype(np.int64)
   kw = dict(lr=1e-3, weight_decay=wd, num_epochs=2, negative_sampling=True)
 
