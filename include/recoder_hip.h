@@ -177,6 +177,15 @@ int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
  * dO <- (softmax * sum_t - t) * inv_B  (losses.py:68-71 + autograd). */
 int rk_mnll_finish(float *dO, int32_t B, const rk_block_t *tgt, int32_t row_off,
                    float inv_B, float *loss_part, void *stream);
+/* Item-parallel form of the above (the softmax spans every rank's items):
+ * rk_mnll_row_stats writes stats[r] = {max, sum exp(o - max)} over the block's shard of row r;
+ * the caller combines them over the ranks and passes, per row, the global max, the log of the
+ * global sum (relative to that max) and the target sum of the WHOLE row to rk_mnll_finish_ext. */
+int rk_mnll_row_stats(const float *logits, int32_t B, const rk_block_t *tgt, float *stats,
+                      void *stream);
+int rk_mnll_finish_ext(float *dO, int32_t B, const rk_block_t *tgt, int32_t row_off,
+                       float inv_B, const float *row_max, const float *row_logsum,
+                       const float *row_tsum, float *loss_part, void *stream);
 /* sum the (unscaled) loss partials in a fixed order (double) and divide by
  * denom = rows of the slice in fp32 (model.py:483-484) -> loss[0]; the consumed
  * partials are reset to 0 (rk_decode_loss requires loss_part zeroed on entry) */

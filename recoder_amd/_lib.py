@@ -105,6 +105,8 @@ SIGNATURES = {
   "rk_decode_loss": (c_int32, [_P, c_int32, c_int32, _BLK, c_int32, _P, _P, c_int32, c_float,
                                c_float, _P, c_int32, _P, _P, _P]),
   "rk_mnll_finish": (c_int32, [_P, c_int32, _BLK, c_int32, c_float, _P, _P]),
+  "rk_mnll_row_stats": (c_int32, [_P, c_int32, _BLK, _P, _P]),
+  "rk_mnll_finish_ext": (c_int32, [_P, c_int32, _BLK, c_int32, c_float, _P, _P, _P, _P, _P]),
   "rk_loss_reduce": (c_int32, [_P, c_int32, c_float, _P, _P]),
   "rk_decode_bwd_dz": (c_int32, [_P, c_int32, c_int32, _BLK, _P, _P, c_int32, _P, _P, _P]),
   "rk_decode_bwd_dw": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P]),

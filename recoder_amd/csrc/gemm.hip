@@ -631,8 +631,12 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float *__restrict__
 }
 
 // MNLL second pass, one block per row (see rk_mnll_finish in the header)
+// ext_* (nullable, per row): the softmax statistics and the target sum of the WHOLE row when
+// the block only holds a shard of its items (item-parallel training)
 __global__ __launch_bounds__(256) void mnll_finish_kernel(float *dO, rk_block_t b, int row_off,
-                                                          float inv_B, float *loss_part) {
+                                                          float inv_B, float *loss_part,
+                                                          const float *ext_max, const float *ext_logsum,
+                                                          const float *ext_tsum) {
   __shared__ float red[4];
   __shared__ float bc[2];
   const int r = blockIdx.x, row = row_off + r;
@@ -640,20 +644,25 @@ __global__ __launch_bounds__(256) void mnll_finish_kernel(float *dO, rk_block_t 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const bool implicit = b.implicit != 0;
   float *orow = dO + (int64_t)r * ld;
-  float mx = -INFINITY;
-  for (int c = tid; c < n; c += 256) mx = fmaxf(mx, orow[c]);
-  mx = rk_wave_max(mx);
-  if (lane == 0) red[wid] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  __syncthreads();
-  float se = 0.f;
-  for (int c = tid; c < n; c += 256) se += expf(orow[c] - mx);
-  se = rk_wave_sum(se);
-  if (lane == 0) red[wid] = se;
-  __syncthreads();
-  const float lsum = logf((red[0] + red[1]) + (red[2] + red[3]));
-  __syncthreads();
+  float mx = -INFINITY, lsum;
+  if (ext_max) {
+    mx = ext_max[r];
+    lsum = ext_logsum[r];
+  } else {
+    for (int c = tid; c < n; c += 256) mx = fmaxf(mx, orow[c]);
+    mx = rk_wave_max(mx);
+    if (lane == 0) red[wid] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float se = 0.f;
+    for (int c = tid; c < n; c += 256) se += expf(orow[c] - mx);
+    se = rk_wave_sum(se);
+    if (lane == 0) red[wid] = se;
+    __syncthreads();
+    lsum = logf((red[0] + red[1]) + (red[2] + red[3]));
+    __syncthreads();
+  }
   // sparse part: loss = -sum_t t*lsm ; sum_g = sum_t (-t*inv_B)
   const int beg = b.indptr[row], end = b.indptr[row + 1];
   float lp = 0.f, sg = 0.f;
@@ -673,7 +682,7 @@ __global__ __launch_bounds__(256) void mnll_finish_kernel(float *dO, rk_block_t 
   __syncthreads();
   if (tid == 0) bc[0] = (red[0] + red[1]) + (red[2] + red[3]);
   __syncthreads();
-  const float sum_g = bc[0];
+  const float sum_g = ext_tsum ? -ext_tsum[r] * inv_B : bc[0];
   // dense part: dO = g - softmax * sum_g,  g = -t*inv_B at stored positions
   for (int c = tid; c < n; c += 256) {
     const float e = expf((orow[c] - mx) - lsum);
@@ -684,6 +693,32 @@ __global__ __launch_bounds__(256) void mnll_finish_kernel(float *dO, rk_block_t 
       g = -t * inv_B;
     }
     orow[c] = g - e * sum_g;
+  }
+}
+
+// local softmax statistics of a row's shard: stats[r] = {max, sum exp(o - max)}
+__global__ __launch_bounds__(256) void mnll_row_stats_kernel(const float *dO, rk_block_t b,
+                                                             float *stats) {
+  __shared__ float red[4];
+  const int r = blockIdx.x;
+  const int n = b.counts[0], ld = b.counts[2];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float *orow = dO + (int64_t)r * ld;
+  float mx = -INFINITY;
+  for (int c = tid; c < n; c += 256) mx = fmaxf(mx, orow[c]);
+  mx = rk_wave_max(mx);
+  if (lane == 0) red[wid] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float se = 0.f;
+  for (int c = tid; c < n; c += 256) se += expf(orow[c] - mx);
+  se = rk_wave_sum(se);
+  if (lane == 0) red[wid] = se;
+  __syncthreads();
+  if (tid == 0) {
+    stats[2 * r] = mx;
+    stats[2 * r + 1] = (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
 
@@ -824,8 +859,30 @@ extern "C" int rk_mnll_finish(float *dO, int32_t B, const rk_block_t *tgt, int32
   if (B == 0) return 0;
   RK_REQUIRE(tgt->implicit || tgt->pref_rc != nullptr, "explicit values need pref_rc");
   RK_LAUNCH(mnll_finish_kernel, dim3(B), dim3(256), 0, stream, dO, *tgt, row_off, inv_B,
-                     loss_part);
+                     loss_part, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr);
   RK_CHECK_LAUNCH("mnll_finish");
+  return 0;
+}
+
+extern "C" int rk_mnll_row_stats(const float *logits, int32_t B, const rk_block_t *tgt, float *stats,
+                                 void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B == 0) return 0;
+  RK_LAUNCH(mnll_row_stats_kernel, dim3(B), dim3(256), 0, stream, logits, *tgt, stats);
+  RK_CHECK_LAUNCH("mnll_row_stats");
+  return 0;
+}
+
+extern "C" int rk_mnll_finish_ext(float *dO, int32_t B, const rk_block_t *tgt, int32_t row_off,
+                                  float inv_B, const float *row_max, const float *row_logsum,
+                                  const float *row_tsum, float *loss_part, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B == 0) return 0;
+  RK_REQUIRE(tgt->implicit || tgt->pref_rc != nullptr, "explicit values need pref_rc");
+  RK_REQUIRE(row_max && row_logsum && row_tsum, "row statistics missing");
+  RK_LAUNCH(mnll_finish_kernel, dim3(B), dim3(256), 0, stream, dO, *tgt, row_off, inv_B, loss_part,
+            row_max, row_logsum, row_tsum);
+  RK_CHECK_LAUNCH("mnll_finish_ext");
   return 0;
 }
 

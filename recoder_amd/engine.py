@@ -280,8 +280,10 @@ class FusedEngine:
       return m.de_embedding_layer.weight, m.de_bias
     return m.item_embedding_layer.weight, m.bias
 
-  def _loss(self, z, B, tgt, row_off, denom_rows, stream, out=None):
-    """decode + loss; leaves dLoss/dLogits in self.dO. Returns device scalar."""
+  def _loss(self, z, B, tgt, row_off, denom_rows, stream, out=None, ip=None):
+    """decode + loss; leaves dLoss/dLogits in self.dO. Returns device scalar.  ip: the
+    block holds an item shard (parallel.ItemParallel) -- only the multinomial loss needs to
+    know: its softmax statistics are combined over the ranks."""
     lib = self.lib
     W, b = self._decoder_params()
     inv_B = _f32(np.float32(1.0) / np.float32(denom_rows))
@@ -289,7 +291,19 @@ class FusedEngine:
     check(lib.rk_decode_loss(ptr(z), B, self.h[0], tgt.ref, row_off, ptr(W), ptr(b), self.loss_id,
                              self.confidence, inv_B, ptr(self.dO), 0, ptr(self.loss_part),
                              ptr(self.gb_part), stream), "rk_decode_loss")
-    if self.loss_id == LOSS_MNLL:
+    if self.loss_id == LOSS_MNLL and ip is not None:
+      # per-row {max, sum exp} of the local logits -> all ranks' pairs -> global log-sum-exp
+      stats = torch.empty(B, 2, dtype=torch.float32, device=self.device)
+      check(lib.rk_mnll_row_stats(ptr(self.dO), B, tgt.ref, ptr(stats), stream), "rk_mnll_row_stats")
+      st = torch.stack(ip.allgather(stats))                      # [N, B, 2]
+      gmax = st[..., 0].max(dim=0).values
+      glog = torch.log((st[..., 1] * torch.exp(st[..., 0] - gmax)).sum(dim=0))
+      tsum = ip.user_tsum_dev[tgt.users[row_off:row_off + B]].contiguous()
+      gmax, glog = gmax.contiguous(), glog.contiguous()
+      check(lib.rk_mnll_finish_ext(ptr(self.dO), B, tgt.ref, row_off, inv_B, ptr(gmax), ptr(glog),
+                                   ptr(tsum), ptr(self.loss_part), stream), "rk_mnll_finish_ext")
+      n_part = B
+    elif self.loss_id == LOSS_MNLL:
       check(lib.rk_mnll_finish(ptr(self.dO), B, tgt.ref, row_off, inv_B, ptr(self.loss_part),
                                stream), "rk_mnll_finish")
       n_part = B
@@ -323,12 +337,10 @@ class FusedEngine:
     self.ensure_capacity(B, blk.n_cap)
     lib, m = self.lib, self.model
     main_s = torch.cuda.current_stream()
-    if self.use_c_step and self.kind == "ae" and self.nl == 0 and not (m.dropout_prob > 0.0):
-      return self._c_train_step(blk, row_off, B, keep_noise, out, global_rows, main_s)
     ip = self.item_parallel
-    if ip is not None and self.loss_id == LOSS_MNLL:
-      raise NotImplementedError("item-parallel training supports the mse / logistic losses (the "
-                                "softmax of the multinomial loss spans every rank's items)")
+    if self.use_c_step and self.kind == "ae" and self.nl == 0 and not (m.dropout_prob > 0.0) and \
+        not (ip is not None and self.loss_id == LOSS_MNLL):
+      return self._c_train_step(blk, row_off, B, keep_noise, out, global_rows, main_s)
     self._gb_lazy = None
     self._gb_en_segs = 0
     stream = ctypes.c_void_p(main_s.cuda_stream)
@@ -340,7 +352,7 @@ class FusedEngine:
     else:
       users = blk.users[row_off:row_off + B]
       z = self._mf_forward(users, B, keep_drop, True, stream)
-    loss = self._loss(z, B, blk, row_off, rows, stream, out)
+    loss = self._loss(z, B, blk, row_off, rows, stream, out, ip=ip)
     self._loss_target = loss
 
     # ---- dW = dO^T . z  (+ decoder bias gradient) ----

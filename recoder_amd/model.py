@@ -383,7 +383,7 @@ class Recoder(object):
     # RK_PARALLEL = items | users | auto: shard the ITEM dimension (two small [N*B, h]
     # all-reduces per step, 1/N of the Adam sweep) where the step supports it, else the users
     m = self.model
-    ip_ok = self._loss_name in ("mse", "logistic")
+    ip_ok = True
     mode = os.environ.get("RK_PARALLEL", "auto")
     if mode == "auto":
       mode = "items" if ip_ok else "users"
@@ -410,6 +410,7 @@ class Recoder(object):
     from .parallel import ItemParallel
     full = train_dataset.interactions_matrix
     ip.user_norm_dev = torch.from_numpy(ItemParallel.user_norms(full)).to(self.device)
+    ip.user_tsum_dev = torch.from_numpy(ItemParallel.user_target_sums(full)).to(self.device)
     ip.prepare(self.device)
     self._engine().item_parallel = ip
     self._ip = ip

@@ -152,6 +152,7 @@ class ItemParallel:
     self._allreduce = allreduce_fn
     self._allgather = allgather_fn
     self.user_norm_dev = None
+    self.user_tsum_dev = None
     self._rccl = None
     self._rccl_tried = False
 
@@ -198,6 +199,19 @@ class ItemParallel:
     csr = csr.tocsr()
     sq = np.asarray(csr.multiply(csr).sum(axis=1), dtype=np.float64).reshape(-1)
     return np.sqrt(sq).astype(np.float32)
+
+  @staticmethod
+  def user_target_sums(csr):
+    """Sum of every user's interaction values (the multinomial loss's sum_t t per row), fp32."""
+    return np.asarray(csr.tocsr().sum(axis=1), dtype=np.float64).reshape(-1).astype(np.float32)
+
+  def allgather(self, t):
+    """[t of rank 0, ..., t of rank N-1] (same shape on every rank)."""
+    if self._allgather is not None:
+      return self._allgather(t)
+    parts = [torch.empty_like(t) for _ in range(self.world)]
+    dist.all_gather(parts, t.contiguous(), group=self.group)
+    return parts
 
   def allreduce_sum(self, t):
     """In-place SUM over the ranks, ordered on the current stream."""

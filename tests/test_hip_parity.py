@@ -614,7 +614,8 @@ class _VirtualRanks:
     return lambda t: self._exchange(rank, t)
 
 
-@pytest.mark.parametrize("case", ["mse_dense", "bce_sparse_tied", "ae2_dropout", "mf_dense", "mf_sparse"])
+@pytest.mark.parametrize("case", ["mse_dense", "bce_sparse_tied", "ae2_dropout", "ae_logloss", "mf_dense",
+                                  "mf_sparse"])
 def test_item_parallel_two_virtual_ranks_equal_single_process(case):
   """parallel.ItemParallel with N = 2 on one GPU (two threads, injected collectives):
   item i on rank i % 2, every rank sees all users; after training and the owners'
@@ -642,6 +643,10 @@ def test_item_parallel_two_virtual_ranks_equal_single_process(case):
     mk = lambda: DynamicAutoencoder([48, 24], activation_type="tanh", noise_prob=0.0, dropout_prob=0.3,
                                     sparse=False)
     loss, wd = "mse", 1e-5
+  elif case == "ae_logloss":
+    # multinomial loss: the softmax statistics are combined over the item shards
+    mk = lambda: DynamicAutoencoder([32], activation_type="tanh", noise_prob=0.0, sparse=False)
+    loss, wd = "logloss", 2e-5
   else:
     mk = lambda: MatrixFactorization(24, activation_type="tanh", sparse=(case == "mf_sparse"))
     loss, wd = "logistic", (0.0 if case == "mf_sparse" else 2e-5)
