@@ -815,18 +815,17 @@ extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_blo
     // it is allocated zeroed and rk_loss_reduce re-zeroes what it consumed
     RK_REQUIRE(tgt->implicit || tgt->pref_rc != nullptr, "explicit values need pref_rc");
     p.ld_dev = tgt->counts + 2;
-    static const int cfg = getenv("RK_DEC_CFG") ? atoi(getenv("RK_DEC_CFG")) : 0;   // tuning switch
-    if (loss_kind == RK_LOSS_MSE && cfg == 1) {
+    // large batches (item-parallel ranks: thousands of rows against a small item shard) run
+    // 64 x 64 tiles with BK = 16 -- 4-5 workgroups per CU instead of 2 keep the matrix pipe
+    // busier once every CU holds many tiles (-20 % at B = 4000, n_b = 2.3k; no gain at B = 500)
+    if (B >= 1500) {
       const int t64 = rk_cdiv(p.tiles_m * rk_cdiv(tgt->n_cap, 64), 8) * 8;
-      RK_LAUNCH((gemm_kernel<2, 2, 1, 1, 0, 0, EPI_LOSS_MSE, true, 32>), dim3(t64, 1),
-                         dim3(256), 0, stream, p);
-    } else if (loss_kind == RK_LOSS_MSE && cfg == 2) {
-      RK_LAUNCH((gemm_kernel<2, 2, 1, 2, 0, 0, EPI_LOSS_MSE, true, 16>), dim3(tiles, 1),
-                         dim3(256), 0, stream, p);
-    } else if (loss_kind == RK_LOSS_MSE && cfg == 3) {
-      const int t64 = rk_cdiv(p.tiles_m * rk_cdiv(tgt->n_cap, 64), 8) * 8;
-      RK_LAUNCH((gemm_kernel<2, 2, 1, 1, 0, 0, EPI_LOSS_MSE, true, 16>), dim3(t64, 1),
-                         dim3(256), 0, stream, p);
+      if (loss_kind == RK_LOSS_MSE)
+        RK_LAUNCH((gemm_kernel<2, 2, 1, 1, 0, 0, EPI_LOSS_MSE, true, 16>), dim3(t64, 1), dim3(256), 0,
+                  stream, p);
+      else
+        RK_LAUNCH((gemm_kernel<2, 2, 1, 1, 0, 0, EPI_LOSS_BCE, true, 16>), dim3(t64, 1), dim3(256), 0,
+                  stream, p);
     } else if (bk40 && loss_kind == RK_LOSS_MSE)
       RK_LAUNCH((gemm_kernel<2, 2, 1, 2, 0, 0, EPI_LOSS_MSE, true, 40>), dim3(tiles, 1),
                          dim3(256), 0, stream, p);

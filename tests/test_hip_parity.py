@@ -627,7 +627,7 @@ def test_item_parallel_two_virtual_ranks_equal_single_process(case):
   from recoder_amd.parallel import ItemParallel
   # mse_dense runs a global batch of 1600 rows: split-K dW (2 slabs) and 4 row segments in the
   # encoder backward; the other case stays below both thresholds
-  big = case == "mse_dense"
+  big = case in ("mse_dense", "bce_sparse_tied")     # (the BCE epilogue's large-batch tiling too)
   csr = synth_csr(3300 if big else 900, 1500, 20, seed=21)
   gb = 1600 if big else 300
   if case == "mse_dense":
