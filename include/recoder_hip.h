@@ -215,6 +215,9 @@ int rk_decode_bwd_dw_encode_bwd(const float *dO, const float *Z, int32_t B, int3
 /* workspace of the call above (0: none needed; NULL is always accepted and disables the
  * split-K of large batches) */
 int64_t rk_dw_workspace_bytes(int32_t B, int32_t h, int32_t n_cap);
+/* tuning probe (tools/gemm_probe.py): device buffer of 8 uint64 per workgroup of the largest
+ * GEMM grid, or NULL (default) to switch it off */
+void rk_gemm_probe(unsigned long long *buffer);
 /* The fused call writes G_en as rk_encode_bwd_segments(B) partial arrays of n_cap*h floats
  * each (row segments of long item columns; 1 below 513 rows) and gb_en as as many partial
  * vectors of h floats: the gradients are their sums in segment order -- rk_adam_multi

@@ -25,6 +25,14 @@
 #include "common.h"
 #include "encoder_bwd.h"
 
+// rk_gemm_probe(buffer): when set, every GEMM workgroup records wall_clock64() at entry, after
+// the prologue (first tile staged), after the k-loop, after the epilogue, plus its tile index
+// (tools/gemm_probe.py turns that into a per-phase timeline).  One uniform branch per stamp.
+static unsigned long long *g_gemm_probe = nullptr;
+#define RK_STAMP(k)                                                                  \
+  do {                                                                               \
+    if (p.probe && threadIdx.x == 0) p.probe[(size_t)L * 8 + (k)] = wall_clock64();  \
+  } while (0)
 #ifdef RK_PROBE
 __device__ unsigned long long rk_dbg[256];
 #define RK_T(slot) do { if (blockIdx.x == 8 && blockIdx.y == 0 && threadIdx.x == 0) rk_dbg[slot] = __builtin_readcyclecounter(); } while (0)
@@ -39,6 +47,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 enum { EPI_STORE = 0, EPI_LOSS_MSE = 1, EPI_SPLITK = 2, EPI_LOSS_BCE = 3 };
 
 struct GemmP {
+  unsigned long long *probe;   // tuning probe (null in production): 5 wall-clock stamps per workgroup
   const float *A;
   const float *Bm;
   const int32_t *bidx;      // gather rows of the B operand (item ids) or null
@@ -139,6 +148,7 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
   const int kend = min(K, kbeg + kchunk);
   if (kbeg >= kend) return;
 
+  RK_STAMP(0);
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WN, wn = wid % WN;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -353,6 +363,7 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
   sstore(0, ra0, rb0, 0);
   __syncthreads();
   RK_T(1);
+  RK_STAMP(1);
   for (int kt = 0; kt < nk; kt += 2) {
     if (kt == 2) RK_T(2);
     // prefetch UNCONDITIONALLY (past the end: re-read the last tile, never stored):
@@ -379,6 +390,7 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
   // read back row-major a lane owns 4 x (one row, 4 consecutive columns), so the
   // epilogue issues 4x fewer, 16-byte-wide global stores / loads per tile.
   RK_T(8);
+  RK_STAMP(2);
   constexpr int TLD = 36;                                   // 32 + 4 floats: 16-B aligned rows
   float *wlds = smem + wid * (32 * TLD);                    // private to this wave
   const int rr0 = lane >> 3, c4 = lane & 7;                 // row-major role of the lane
@@ -542,6 +554,8 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
     }
   }
   RK_T(9);
+  RK_STAMP(3);
+  if (p.probe && threadIdx.x == 0) p.probe[(size_t)L * 8 + 4] = (unsigned long long)t + 1;
 }
 
 template <int WM, int WN, int TM, int TN, int AMODE, int BMODE, int EPI, bool VEC, int BK = 16>
@@ -760,6 +774,8 @@ constexpr int DEC_BM = 64;          // rows per decode tile (rk_loss_partials, g
 
 }  // namespace
 
+extern "C" void rk_gemm_probe(unsigned long long *buffer) { g_gemm_probe = buffer; }
+
 extern "C" int64_t rk_dz_workspace_bytes(int32_t B, int32_t h) {
   return (int64_t)dz_splits(B) * B * h * sizeof(float);
 }
@@ -795,6 +811,7 @@ extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_blo
   RK_REQUIRE(row_off >= 0 && row_off + B <= tgt->S_cap, "row slice out of range");
   if (B == 0) return 0;
   GemmP p = {};
+  p.probe = g_gemm_probe;
   p.A = Z; p.lda = h;
   p.Bm = W_de; p.ldb = h; p.bidx = tgt->items;
   p.M = B; p.N = tgt->n_cap; p.K = h;
@@ -903,6 +920,7 @@ extern "C" int rk_decode_bwd_dz(const float *dO, int32_t B, int32_t h, const rk_
              "operands must be 16-byte aligned");
   if (B == 0) return 0;
   GemmP p = {};
+  p.probe = g_gemm_probe;
   p.A = dO; p.lda_dev = tgt->counts + 2;
   p.Bm = W_de; p.ldb = h; p.bidx = tgt->items;
   p.M = B; p.N = h; p.K = tgt->n_cap; p.Kdev = tgt->counts;
@@ -936,6 +954,7 @@ extern "C" int rk_decode_bwd_dw(const float *dO, const float *Z, int32_t B, int3
   RK_REQUIRE(aligned16(dO) && aligned16(Z) && aligned16(G_de), "operands must be 16-byte aligned");
   if (B == 0) return 0;
   GemmP p = {};
+  p.probe = g_gemm_probe;
   p.A = dO; p.lda_dev = tgt->counts + 2;
   p.Bm = Z; p.ldb = h;
   p.M = tgt->n_cap; p.Mdev = tgt->counts; p.N = h; p.K = B;
@@ -973,6 +992,7 @@ extern "C" int rk_decode_bwd_dw_encode_bwd(const float *dO, const float *Z, int3
   // `workspace` (rk_dw_workspace_bytes) and are summed in split order by slab_sum_kernel
   const int splits = workspace ? dw_splits(B) : 1;
   GemmP p = {};
+  p.probe = g_gemm_probe;
   p.A = dO; p.lda_dev = blk->counts + 2;
   p.Bm = Z; p.ldb = h;
   p.M = blk->n_cap; p.Mdev = blk->counts; p.N = h; p.K = B;
@@ -1023,6 +1043,7 @@ extern "C" int rk_linear_fwd(const float *X, const float *W, const float *b, int
   hipStream_t stream = (hipStream_t)stream_;
   if (B == 0) return 0;
   GemmP p = {};
+  p.probe = g_gemm_probe;
   p.A = X; p.lda = K;
   p.Bm = W; p.ldb = w_transposed ? N : K;
   p.M = B; p.N = N; p.K = K; p.kchunk = K;
@@ -1047,6 +1068,7 @@ extern "C" int rk_linear_bwd(float *dY, const float *Y, const float *X, const fl
   const int ldw = w_transposed ? N : K;
   if (dX) {  // dX[B,K] = dY[B,N] . Weff[N,K]
     GemmP p = {};
+  p.probe = g_gemm_probe;
     p.A = dY; p.lda = N;
     p.Bm = W; p.ldb = ldw;
     p.M = B; p.N = K; p.K = N; p.kchunk = N;
@@ -1060,6 +1082,7 @@ extern "C" int rk_linear_bwd(float *dY, const float *Y, const float *X, const fl
   }
   if (dW) {
     GemmP p = {};
+  p.probe = g_gemm_probe;
     p.K = B; p.kchunk = B; p.act = RK_ACT_NONE; p.accumulate = dw_accumulate; p.C = dW;
     if (!w_transposed) {  // dW[N,K] = dY^T . X
       p.A = dY; p.lda = N; p.Bm = X; p.ldb = K; p.M = N; p.N = K; p.ldc = K;
