@@ -59,7 +59,8 @@ def main():
   for B in Bs:
     users = torch.arange(B, dtype=torch.int64, device=dev)
     blk = Block(B, int(np.sort(dcsr.degrees)[-B:].sum()), n_items, dev,
-                n_cap=(-(-n_items // shard) if shard > 1 else None))
+                n_cap=(int(os.environ["NCAP"]) if "NCAP" in os.environ else
+                       -(-n_items // shard) if shard > 1 else None))
     blk.collate(dcsr, users)
     n_b, nnz, ld, S = blk.counts_host()
     Z = torch.randn(B, h, **f)
