@@ -166,7 +166,14 @@ class ItemParallel:
           os.environ.get("RK_COMM", "rccl") != "torch":
         try:
           from .rccl import RcclComm
-          self._rccl = RcclComm(self.group, t.device)
+          comm = RcclComm(self.group, t.device)
+          # self-check before trusting it with gradients: sum of (rank + 1) over the ranks
+          probe = torch.full((8,), float(self.rank + 1), dtype=torch.float32, device=t.device)
+          comm.all_reduce(probe)
+          want = self.world * (self.world + 1) / 2.0
+          if not bool((probe == want).all().item()):
+            raise RuntimeError("self-check all-reduce returned %r, expected %r" % (probe[0].item(), want))
+          self._rccl = comm
         except Exception as e:      # noqa: BLE001 -- any bootstrap problem: torch.distributed
           import warnings
           warnings.warn("direct RCCL communicator unavailable (%s); using torch.distributed" % e)
