@@ -491,6 +491,7 @@ class FusedEngine:
     segmented = dp is None and not m.is_constrained and self.loss_id != LOSS_MNLL
     st.gb_en = ptr(self.gb_en_parts if segmented else self.gb_en)
     self._gb_en_segs = self.lib.rk_encode_bwd_segments(B) if segmented else 0
+    self.n_cap_last = blk.n_cap
     st.loss_part, st.loss_out = ptr(self.loss_part), ptr(loss_dst)
     st.stream = main_s.cuda_stream
     self._c_calls += 1
@@ -570,6 +571,15 @@ class FusedEngine:
     if not n:
       return self.gb_en.clone()
     return self.gb_en_parts[:n * h0].view(n, h0).sum(0)
+
+  def encoder_row_grad(self, n_b):
+    """G_en[:n_b] of the last training step (tests): the one-call step leaves it as
+    row-segment partial arrays for rk_adam_multi when the batch has more than 512 rows."""
+    n, h0 = getattr(self, "_gb_en_segs", 0), self.h[0]
+    if n <= 1:
+      return self.G_en[:n_b * h0].view(n_b, h0).clone()
+    stride = self.n_cap_last * h0
+    return sum(self.G_en[k * stride:k * stride + n_b * h0].view(n_b, h0) for k in range(n))
 
   def event_pair_overhead_ms(self, n=64):
     """Elapsed time of a timing-event pair with nothing between the two records."""

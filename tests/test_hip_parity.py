@@ -290,6 +290,39 @@ STEP_CASES = [
 ]
 
 
+def _fuzz_cases(n=20, seed=2024):
+  """Deterministic random shapes around the tiling boundaries (rows 64/128/512, items 32/64/128,
+  h 4..512) x losses x Adam kinds x tied / hidden stacks."""
+  rng = np.random.RandomState(seed)
+  out = []
+  for i in range(n):
+    kind = "mf" if i % 5 == 4 else "ae"
+    B = int(rng.choice([1, 3, 31, 64, 65, 127, 128, 129, 200, 255, 256, 300, 511, 512, 513, 700]))
+    n_items = int(rng.choice([33, 64, 65, 127, 129, 300, 1000, 2500]))
+    n_users = max(B + 7, int(B * rng.uniform(1.1, 2.5)))
+    deg = int(rng.choice([2, 5, 12, 30]))
+    loss = str(rng.choice(["mse", "logistic", "logloss"]))
+    sparse = bool(rng.rand() < 0.4)
+    if kind == "ae":
+      h0 = int(rng.choice([4, 8, 36, 64, 100, 200, 256, 260, 512]))
+      layers = [h0] if rng.rand() < 0.6 else [h0, int(rng.choice([8, 24, 40]))]
+      c = dict(kind="ae", hidden_layers=layers, activation_type=str(rng.choice(["tanh", "relu", "sigmoid"])),
+               noise_prob=float(rng.choice([0.0, 0.3])), dropout_prob=float(rng.choice([0.0, 0.0, 0.25])),
+               is_constrained=bool(rng.rand() < 0.25), sparse=sparse, loss=loss,
+               loss_params=(dict(confidence=2) if loss == "mse" and rng.rand() < 0.5 else None),
+               lr=1e-3, weight_decay=(0.0 if sparse else 2e-5))
+    else:
+      c = dict(kind="mf", embedding_size=int(rng.choice([4, 16, 128])),
+               activation_type=str(rng.choice(["none", "tanh"])), dropout_prob=float(rng.choice([0.0, 0.2])),
+               sparse=sparse, loss=loss, loss_params=None, lr=1e-3, weight_decay=(0.0 if sparse else 2e-5))
+    S = B * int(rng.choice([1, 1, 2]))
+    out.append(("fuzz%02d_%s_%s_B%d_n%d" % (i, kind, loss, B, n_items), c, (n_users, n_items, deg), B, S))
+  return out
+
+
+STEP_CASES += _fuzz_cases(40)
+
+
 @pytest.mark.parametrize("name,c,shape,B,S", STEP_CASES, ids=[x[0] for x in STEP_CASES])
 def test_steps_match_oracle(name, c, shape, B, S):
   from recoder_amd.data import RecommendationDataset
@@ -376,7 +409,7 @@ def test_steps_match_oracle(name, c, shape, B, S):
       check("W_en(tied)[items]", G_de, grads[orc.AE_EN_W][items_idx].numpy())
     else:
       check("W_de[items]", G_de, grads[orc.AE_DE_W][items_idx].numpy())
-      G_en = eng.G_en[:n_b * h0].view(n_b, h0).cpu().numpy()
+      G_en = eng.encoder_row_grad(n_b).cpu().numpy()
       check("W_en[items]", G_en, grads[orc.AE_EN_W][items_idx].numpy())
     check("b_de[items]", gb_de, grads[orc.AE_DE_B][items_idx].numpy())
     check("b_en", eng.encoder_bias_grad().cpu().numpy(), grads[orc.AE_EN_B].numpy())
