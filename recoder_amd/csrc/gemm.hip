@@ -33,12 +33,6 @@ static unsigned long long *g_gemm_probe = nullptr;
   do {                                                                               \
     if (p.probe && threadIdx.x == 0) p.probe[(size_t)L * 8 + (k)] = wall_clock64();  \
   } while (0)
-#ifdef RK_PROBE
-__device__ unsigned long long rk_dbg[256];
-#define RK_T(slot) do { if (blockIdx.x == 8 && blockIdx.y == 0 && threadIdx.x == 0) rk_dbg[slot] = __builtin_readcyclecounter(); } while (0)
-#else
-#define RK_T(slot) do {} while (0)
-#endif
 
 namespace {
 
@@ -357,39 +351,30 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
         }
     }
   }
-  RK_T(0);
   gload(ra0, rb0, 0);
   gload(ra1, rb1, min(1, nk - 1));
   sstore(0, ra0, rb0, 0);
   __syncthreads();
-  RK_T(1);
   RK_STAMP(1);
   for (int kt = 0; kt < nk; kt += 2) {
-    if (kt == 2) RK_T(2);
     // prefetch UNCONDITIONALLY (past the end: re-read the last tile, never stored):
     // a branch around the loads makes hipcc merge the vmcnt state pessimistically
     // and wait for the loads just issued before every LDS store
     gload(ra0, rb0, min(kt + 2, nk - 1));
-    if (kt == 2) RK_T(3);
     compute(0);
-    if (kt == 2) RK_T(4);
     if (kt + 1 < nk) sstore(1, ra1, rb1, kt + 1);
-    if (kt == 2) RK_T(5);
     __syncthreads();
-    if (kt == 2) RK_T(6);
     if (kt + 1 >= nk) break;
     gload(ra1, rb1, min(kt + 3, nk - 1));
     compute(1);
     if (kt + 2 < nk) sstore(0, ra0, rb0, kt + 2);
     __syncthreads();
-    if (kt == 2) RK_T(7);
   }
   // ------------------------------------------------------------- epilogues
   // Every 32x32 accumulator tile goes through a per-wave LDS transpose: the MFMA
   // layout gives a lane 16 rows of ONE column (16 scalar stores, 16 bitmap words);
   // read back row-major a lane owns 4 x (one row, 4 consecutive columns), so the
   // epilogue issues 4x fewer, 16-byte-wide global stores / loads per tile.
-  RK_T(8);
   RK_STAMP(2);
   constexpr int TLD = 36;                                   // 32 + 4 floats: 16-B aligned rows
   float *wlds = smem + wid * (32 * TLD);                    // private to this wave
@@ -553,7 +538,6 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
       }
     }
   }
-  RK_T(9);
   RK_STAMP(3);
   if (p.probe && threadIdx.x == 0) p.probe[(size_t)L * 8 + 4] = (unsigned long long)t + 1;
 }
