@@ -22,6 +22,8 @@
 // k-major operands sit as [16][tile] and are read with ds_read_b32.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "encoder_bwd.h"
 
@@ -38,7 +40,40 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 enum { EPI_STORE = 0, EPI_LOSS_MSE = 1, EPI_SPLITK = 2, EPI_LOSS_BCE = 3 };
+// operand precision of the contraction
+//   PREC_F32 : v_mfma_f32_32x32x2_f32 on the fp32 values (64 cycles per 2 k; exact fma chains)
+//   PREC_H3  : gfx950 has no fast fp32 matrix path (157 TF vs 2.5 PF for 16-bit operands), so
+//              every fp32 operand x is split when it is staged into LDS:
+//                  s.x = hi + lo + r,  hi = fp16_rne(s.x),  lo = fp16_rne(s.x - hi)
+//              (s = a power of two that puts the matrix into fp16's range, exact; s.x - hi is
+//              exact in fp32; |r| <= 2^-22 |s.x| or 2^-25 absolute in the subnormal range) and
+//              a.b is accumulated in fp32 as lo.hi + hi.lo + hi.hi on
+//              v_mfma_f32_32x32x16_f16 (32 cycles per 16 k: 3 MFMAs do the work of 8 fp32 ones,
+//              5.3x the matrix rate).  The dropped lo.lo and r terms are zero-mean (round to
+//              nearest on both levels) and <= 3 . 2^-22 relative per product -- the size of the
+//              rounding an fp32 fma chain of this length accumulates itself.  The accumulator
+//              is rescaled by 1 / (s_a s_b) (exact) before the epilogue.
+//              Range: |s.x| must stay below 65504 (else inf -> NaN loss, loudly): with the
+//              scales below |W|, |Z| < 4096 and |dLoss/dLogit| < 64.
+enum { PREC_F32 = 0, PREC_H3 = 1 };
+constexpr float SCALE_WZ = 16.0f;      // embedding rows and activations
+constexpr float SCALE_DO = 1024.0f;    // dLoss/dLogits (already divided by the batch size)
+
+// 4 consecutive-k fp32 values -> 4 fp16 "hi" + 4 fp16 "lo" of s.x
+// (v_pk_mul_f32, v_cvt_pk_f16_f32, v_cvt_f32_f16, v_pk_fma_f32)
+__device__ __forceinline__ void split4(const float4 v, const float s, uint2 &hi, uint2 &lo) {
+  const f32x2 a = {v.x * s, v.y * s}, b = {v.z * s, v.w * s};
+  const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
+  const f32x2 la = a - __builtin_convertvector(ha, f32x2), lb = b - __builtin_convertvector(hb, f32x2);
+  const f16x2 qa = __builtin_convertvector(la, f16x2), qb = __builtin_convertvector(lb, f16x2);
+  hi.x = __builtin_bit_cast(uint32_t, ha); hi.y = __builtin_bit_cast(uint32_t, hb);
+  lo.x = __builtin_bit_cast(uint32_t, qa); lo.y = __builtin_bit_cast(uint32_t, qb);
+}
 
 struct GemmP {
   unsigned long long *probe;   // tuning probe (null in production): 5 wall-clock stamps per workgroup
@@ -52,6 +87,7 @@ struct GemmP {
   int tiles_m;              // host: ceil(Mcap / BM) (grid sizing only)
   int n_fastest;            // tile order inside a split: nt fastest (else mt fastest)
   int kchunk;               // K range per blockIdx.y
+  float a_scale, b_scale;   // PREC_H3: powers of two applied to the operands before the fp16 split
   // store epilogue
   float *C;
   int ldc;                  // <=0 : read ld from ld_dev
@@ -99,17 +135,28 @@ __device__ __forceinline__ float4 mask4(float4 v, int valid) {
   return r;
 }
 
-template <int WM, int WN, int TM, int TN, int AMODE, int BMODE, int EPI, bool VEC, int BK = 16>
+template <int WM, int WN, int TM, int TN, int AMODE, int BMODE, int EPI, bool VEC, int BK = 16,
+          int PREC = PREC_F32>
 __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int nsplit) {
   static_assert(WM * WN == 4, "4 waves per block");
-  static_assert(BK == 16 || BK == 32 || BK == 40, "BK");
+  static_assert(BK == 16 || BK == 32 || BK == 40 || BK == 64, "BK");
+  static_assert(PREC == PREC_F32 || (VEC && BK % 16 == 0), "split-fp16 tiles: 16-B loads, k-steps of 16");
+  constexpr bool H3 = (PREC == PREC_H3);
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   constexpr int LDK = BK + 4;          // K-contiguous LDS row stride (odd multiple of 16 B)
   constexpr int QK = BK / 4;           // float4 per K-contiguous row
-  constexpr int A_SZ = (AMODE == 0) ? BM * LDK : BK * BM;
-  constexpr int B_SZ = (BMODE == 0) ? BN * LDK : BK * BN;
+  // PREC_H3: every operand sits K-contiguous in LDS, a row = BK fp16 "hi" then BK fp16 "lo" (+16 B:
+  // the same 4*(BK+4)-byte stride, conflict-free ds_read_b128); k-major operands are transposed
+  // on the way in (4k x 4m register blocks)
+  constexpr int LDB = 4 * LDK;         // that row stride in bytes
+  constexpr int A_SZ = (AMODE == 0 || H3) ? BM * LDK : BK * BM;
+  constexpr int B_SZ = (BMODE == 0 || H3) ? BN * LDK : BK * BN;
   constexpr int A_F4 = BM * BK / 4, B_F4 = BN * BK / 4;      // float4 per tile
-  constexpr int A_PT = (A_F4 + 255) / 256, B_PT = (B_F4 + 255) / 256;
+  // k-major operands under PREC_H3 are staged in units of 4 k-rows x one float4 (4 loads per unit)
+  constexpr bool A_UNIT = H3 && AMODE == 1, B_UNIT = H3 && BMODE == 1;
+  constexpr int A_UN = A_F4 / 4, B_UN = B_F4 / 4;            // units per tile
+  constexpr int A_PT = A_UNIT ? 4 * ((A_UN + 255) / 256) : (A_F4 + 255) / 256;
+  constexpr int B_PT = B_UNIT ? 4 * ((B_UN + 255) / 256) : (B_F4 + 255) / 256;
   // staging double buffer; the epilogue reuses it (4 per-wave 32x36 transpose areas +
   // the loss partials), so it is at least that large
   constexpr int STAGE_F = 2 * (A_SZ + B_SZ);
@@ -172,7 +219,10 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
       a_k[i] = q * 4;
       a_ptr[i] = p.A + (int64_t)min(m0 + row, M - 1) * lda + q * 4 + kbeg;
     } else {
-      const int k = idx / (BM / 4), m4 = idx % (BM / 4);
+      // unit u = (k-quad kq, column group m4), kq fastest over the lanes; load i&3 is row kq*4 + (i&3)
+      const int u = min(tid + (i >> 2) * 256, A_UN - 1);
+      const int k = A_UNIT ? (u % QK) * 4 + (i & 3) : idx / (BM / 4);
+      const int m4 = A_UNIT ? u / QK : idx % (BM / 4);
       const int m = m0 + m4 * 4;
       a_k[i] = k;
       a_ptr[i] = p.A + (int64_t)(kbeg + k) * lda + ((m + 3 < lda) ? m : 0);
@@ -189,7 +239,9 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
       b_n[i] = 0;
       b_ptr[i] = p.Bm + src * ldb + q * 4 + kbeg;
     } else {
-      const int k = idx / (BN / 4), n4 = idx % (BN / 4);
+      const int u = min(tid + (i >> 2) * 256, B_UN - 1);
+      const int k = B_UNIT ? (u % QK) * 4 + (i & 3) : idx / (BN / 4);
+      const int n4 = B_UNIT ? u / QK : idx % (BN / 4);
       const int n = n0 + n4 * 4;
       b_k[i] = k;
       b_n[i] = (n + 3 < ldb) ? n : 0;
@@ -252,6 +304,52 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
     const bool tail = (kb + BK > klen);
     float *As = smem + buf * (A_SZ + B_SZ);
     float *Bs = As + A_SZ;
+    if (H3) {
+      // split into fp16 hi / lo and store K-contiguous: row r holds hi[0..BK) | lo[0..BK)
+      auto put = [&](float *base, float scale, int row, int kq, const float4 v) {
+        uint2 hi, lo;
+        split4(v, scale, hi, lo);
+        char *d = reinterpret_cast<char *>(base) + row * LDB + kq * 8;
+        *reinterpret_cast<uint2 *>(d) = hi;
+        *reinterpret_cast<uint2 *>(d + BK * 2) = lo;
+      };
+      auto stage = [&](float *base, float scale, auto &regs, auto &kk, auto unit_tag, auto pt_tag, int f4, int un) {
+        constexpr bool UNIT = decltype(unit_tag)::value;
+        constexpr int PT = decltype(pt_tag)::value;
+        if (!UNIT) {
+#pragma unroll
+          for (int i = 0; i < PT; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < f4) {
+              float4 v = regs[i];
+              if (tail) v = mask4(v, klen - kb - kk[i]);
+              put(base, scale, idx / QK, idx % QK, v);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < PT / 4; ++j) {
+            const int u = tid + j * 256;
+            if (u < un) {
+              float4 v[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                v[r] = regs[j * 4 + r];
+                if (tail) v[r] = mask4(v[r], (kb + kk[j * 4 + r] < klen) ? 4 : 0);
+              }
+              const int kq = u % QK, c4 = u / QK;
+              put(base, scale, c4 * 4 + 0, kq, make_float4(v[0].x, v[1].x, v[2].x, v[3].x));
+              put(base, scale, c4 * 4 + 1, kq, make_float4(v[0].y, v[1].y, v[2].y, v[3].y));
+              put(base, scale, c4 * 4 + 2, kq, make_float4(v[0].z, v[1].z, v[2].z, v[3].z));
+              put(base, scale, c4 * 4 + 3, kq, make_float4(v[0].w, v[1].w, v[2].w, v[3].w));
+            }
+          }
+        }
+      };
+      stage(As, p.a_scale, ra, a_k, std::integral_constant<bool, A_UNIT>{}, std::integral_constant<int, A_PT>{}, A_F4, A_UN);
+      stage(Bs, p.b_scale, rb, b_k, std::integral_constant<bool, B_UNIT>{}, std::integral_constant<int, B_PT>{}, B_F4, B_UN);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < A_PT; ++i) {
       const int idx = tid + i * 256;
@@ -284,9 +382,49 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
     }
   };
 
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf, int kt) {
     const float *As = smem + buf * (A_SZ + B_SZ);
     const float *Bs = As + A_SZ;
+    if (H3) {
+      const int nks = min(BK / 16, (klen - kt * BK + 15) >> 4);   // live k-steps of this tile
+      const char *Ab = reinterpret_cast<const char *>(As) + ((wm * TM) * 32 + l31) * LDB + lh * 16;
+      const char *Bb = reinterpret_cast<const char *>(Bs) + ((wn * TN) * 32 + l31) * LDB + lh * 16;
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        if (ks < nks) {
+          f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const char *q = Ab + i * 32 * LDB + ks * 32;
+            ah[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q));
+            al[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q + BK * 2));
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const char *q = Bb + j * 32 * LDB + ks * 32;
+            bh[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q));
+            bl[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q + BK * 2));
+          }
+          // small terms first
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int kg = 0; kg < BK / 8; ++kg) {
       float af[TM][4], bf[TN][4];
@@ -361,12 +499,12 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
     // a branch around the loads makes hipcc merge the vmcnt state pessimistically
     // and wait for the loads just issued before every LDS store
     gload(ra0, rb0, min(kt + 2, nk - 1));
-    compute(0);
+    compute(0, kt);
     if (kt + 1 < nk) sstore(1, ra1, rb1, kt + 1);
     __syncthreads();
     if (kt + 1 >= nk) break;
     gload(ra1, rb1, min(kt + 3, nk - 1));
-    compute(1);
+    compute(1, kt + 1);
     if (kt + 2 < nk) sstore(0, ra0, rb0, kt + 2);
     __syncthreads();
   }
@@ -375,6 +513,15 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
   // layout gives a lane 16 rows of ONE column (16 scalar stores, 16 bitmap words);
   // read back row-major a lane owns 4 x (one row, 4 consecutive columns), so the
   // epilogue issues 4x fewer, 16-byte-wide global stores / loads per tile.
+  if (H3) {
+    const float inv = 1.0f / (p.a_scale * p.b_scale);     // exact: powers of two
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
+  }
   RK_STAMP(2);
   constexpr int TLD = 36;                                   // 32 + 4 floats: 16-B aligned rows
   float *wlds = smem + wid * (32 * TLD);                    // private to this wave
@@ -542,9 +689,10 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
   if (p.probe && threadIdx.x == 0) p.probe[(size_t)L * 8 + 4] = (unsigned long long)t + 1;
 }
 
-template <int WM, int WN, int TM, int TN, int AMODE, int BMODE, int EPI, bool VEC, int BK = 16>
+template <int WM, int WN, int TM, int TN, int AMODE, int BMODE, int EPI, bool VEC, int BK = 16,
+          int PREC = PREC_F32>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
-  gemm_body<WM, WN, TM, TN, AMODE, BMODE, EPI, VEC, BK>(
+  gemm_body<WM, WN, TM, TN, AMODE, BMODE, EPI, VEC, BK, PREC>(
       p, (int)(blockIdx.y * gridDim.x + blockIdx.x), (int)gridDim.y);
 }
 
@@ -553,13 +701,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 // dO / dZ0) and complementary -- MFMA-bound tiles next to latency-bound gathers --
 // and the step is a serial chain of launches, so running them side by side takes the
 // encoder backward off the critical path without a second stream.
-template <int HV, bool SPLIT>
+template <int HV, bool SPLIT, int PREC>
 __global__ __launch_bounds__(256) void dw_encode_bwd_kernel(
     GemmP p, int n_dw, int nsplit, rk_block_t b, int row_off, int B, const float *__restrict__ dZ,
     int h, float *__restrict__ G_en, float *__restrict__ gb, int n_gb, int n_seg,
     int64_t seg_stride) {
   if ((int)blockIdx.x < n_dw)
-    gemm_body<1, 4, 1, 1, 1, 1, SPLIT ? EPI_SPLITK : EPI_STORE, true, 16>(p, (int)blockIdx.x, nsplit);
+    gemm_body<1, 4, 1, 1, 1, 1, SPLIT ? EPI_SPLITK : EPI_STORE, true, PREC == PREC_H3 ? 32 : 16, PREC>(
+        p, (int)blockIdx.x, nsplit);
   else
     ae_encode_bwd_body<HV>(b, row_off, B, dZ, h, G_en, 0, gb, n_gb, (int)blockIdx.x - n_dw, n_seg,
                            seg_stride);
@@ -756,6 +905,20 @@ inline int dz_splits(int B) {
 }
 constexpr int DEC_BM = 64;          // rows per decode tile (rk_loss_partials, gb_part rows)
 
+// RK_GEMM_PREC = f32 : the three decoder contractions on the fp32 MFMA (exact fma chains);
+// default: the split-fp16 path (PREC_H3 above).
+inline bool use_h3() {
+  static const int v = [] {
+    const char *e = getenv("RK_GEMM_PREC");
+    return (e && (e[0] == 'f' || e[0] == 'F')) ? 0 : 1;
+  }();
+  return v != 0;
+}
+inline int tune(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
 }  // namespace
 
 extern "C" void rk_gemm_probe(unsigned long long *buffer) { g_gemm_probe = buffer; }
@@ -798,6 +961,7 @@ extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_blo
   p.probe = g_gemm_probe;
   p.A = Z; p.lda = h;
   p.Bm = W_de; p.ldb = h; p.bidx = tgt->items;
+  p.a_scale = SCALE_WZ; p.b_scale = SCALE_WZ;
   p.M = B; p.N = tgt->n_cap; p.K = h;
   p.Ndev = tgt->counts;          // n_t
   p.tiles_m = rk_cdiv(B, DEC_BM);
@@ -816,6 +980,26 @@ extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_blo
     // it is allocated zeroed and rk_loss_reduce re-zeroes what it consumed
     RK_REQUIRE(tgt->implicit || tgt->pref_rc != nullptr, "explicit values need pref_rc");
     p.ld_dev = tgt->counts + 2;
+    if (use_h3()) {
+      static const int cfg = tune("RK_DEC_CFG", 0);
+      const bool mse = (loss_kind == RK_LOSS_MSE);
+      const int bn = cfg == 1 ? 256 : (cfg == 2 ? 64 : 128);
+      const int g = rk_cdiv(p.tiles_m * rk_cdiv(tgt->n_cap, bn), 8) * 8;
+#define LAUNCH(TN, BKK)                                                                          \
+  do {                                                                                           \
+    if (mse)                                                                                     \
+      RK_LAUNCH((gemm_kernel<2, 2, 1, TN, 0, 0, EPI_LOSS_MSE, true, BKK, PREC_H3>), dim3(g, 1),  \
+                dim3(256), 0, stream, p);                                                        \
+    else                                                                                         \
+      RK_LAUNCH((gemm_kernel<2, 2, 1, TN, 0, 0, EPI_LOSS_BCE, true, BKK, PREC_H3>), dim3(g, 1),  \
+                dim3(256), 0, stream, p);                                                        \
+  } while (0)
+      if (cfg == 1) LAUNCH(4, 32); else if (cfg == 2) LAUNCH(1, 32); else if (cfg == 3) LAUNCH(2, 64);
+      else LAUNCH(2, 32);
+#undef LAUNCH
+      RK_CHECK_LAUNCH("decode_loss");
+      return 0;
+    }
     // large batches (item-parallel ranks: thousands of rows against a small item shard) run
     // 64 x 64 tiles with BK = 16 -- 4-5 workgroups per CU instead of 2 keep the matrix pipe
     // busier once every CU holds many tiles (-20 % at B = 4000, n_b = 2.3k; no gain at B = 500)
@@ -842,7 +1026,10 @@ extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_blo
   } else {
     if (loss_kind == RK_LOSS_MNLL) { p.ldc = 0; p.ld_dev = tgt->counts + 2; }
     else { RK_REQUIRE(ld_out > 0, "ld_out"); p.ldc = ld_out; }
-    if (bk40)
+    if (use_h3())
+      RK_LAUNCH((gemm_kernel<2, 2, 1, 2, 0, 0, EPI_STORE, true, 32, PREC_H3>), dim3(tiles, 1),
+                dim3(256), 0, stream, p);
+    else if (bk40)
       RK_LAUNCH((gemm_kernel<2, 2, 1, 2, 0, 0, EPI_STORE, true, 40>), dim3(tiles, 1), dim3(256),
                          0, stream, p);
     else
@@ -907,6 +1094,7 @@ extern "C" int rk_decode_bwd_dz(const float *dO, int32_t B, int32_t h, const rk_
   p.probe = g_gemm_probe;
   p.A = dO; p.lda_dev = tgt->counts + 2;
   p.Bm = W_de; p.ldb = h; p.bidx = tgt->items;
+  p.a_scale = SCALE_DO; p.b_scale = SCALE_WZ;
   p.M = B; p.N = h; p.K = tgt->n_cap; p.Kdev = tgt->counts;
   p.C = workspace;
   p.kchunk = 0;                       // derived in-kernel from the device-resident n_t
@@ -917,8 +1105,14 @@ extern "C" int rk_decode_bwd_dz(const float *dO, int32_t B, int32_t h, const rk_
   p.tiles_m = rk_cdiv(B, 128);
   const int tiles = p.tiles_m * rk_cdiv(h, 32 * tn);   // x 64 splits: a multiple of 8
 #define LAUNCH(TN)                                                                              \
-  RK_LAUNCH((gemm_kernel<4, 1, 1, TN, 0, 1, EPI_SPLITK, true>), dim3(tiles, splits),   \
-                     dim3(256), 0, stream, p)
+  do {                                                                                          \
+    if (use_h3())                                                                              \
+      RK_LAUNCH((gemm_kernel<4, 1, 1, TN, 0, 1, EPI_SPLITK, true, 32, PREC_H3>),               \
+                dim3(tiles, splits), dim3(256), 0, stream, p);                                  \
+    else                                                                                        \
+      RK_LAUNCH((gemm_kernel<4, 1, 1, TN, 0, 1, EPI_SPLITK, true>), dim3(tiles, splits),        \
+                dim3(256), 0, stream, p);                                                       \
+  } while (0)
   if (tn == 2) LAUNCH(2); else if (tn == 4) LAUNCH(4); else if (tn == 7) LAUNCH(7); else LAUNCH(8);
 #undef LAUNCH
   RK_CHECK_LAUNCH("decode_bwd_dz");
@@ -941,6 +1135,7 @@ extern "C" int rk_decode_bwd_dw(const float *dO, const float *Z, int32_t B, int3
   p.probe = g_gemm_probe;
   p.A = dO; p.lda_dev = tgt->counts + 2;
   p.Bm = Z; p.ldb = h;
+  p.a_scale = SCALE_DO; p.b_scale = SCALE_WZ;
   p.M = tgt->n_cap; p.Mdev = tgt->counts; p.N = h; p.K = B;
   p.kchunk = B;
   p.C = G_de; p.ldc = h; p.act = RK_ACT_NONE;
@@ -951,8 +1146,12 @@ extern "C" int rk_decode_bwd_dw(const float *dO, const float *Z, int32_t B, int3
     p.n_fastest = 1;   // the h/128 column tiles of one dO panel stay on one XCD
     p.tiles_m = rk_cdiv(tgt->n_cap, 32);
     const int tiles = rk_cdiv(p.tiles_m * rk_cdiv(h, 128), 8) * 8;
-    RK_LAUNCH((gemm_kernel<1, 4, 1, 1, 1, 1, EPI_STORE, true, 32>), dim3(tiles, 1),
-                       dim3(256), 0, stream, p);
+    if (use_h3())
+      RK_LAUNCH((gemm_kernel<1, 4, 1, 1, 1, 1, EPI_STORE, true, 32, PREC_H3>), dim3(tiles, 1),
+                dim3(256), 0, stream, p);
+    else
+      RK_LAUNCH((gemm_kernel<1, 4, 1, 1, 1, 1, EPI_STORE, true, 32>), dim3(tiles, 1),
+                dim3(256), 0, stream, p);
   }
   RK_CHECK_LAUNCH("decode_bwd_dw");
   if (gb_de) return rk_colsum(dO, B, tgt->n_cap, 0, tgt->counts, gb_de, stream_);
@@ -979,6 +1178,7 @@ extern "C" int rk_decode_bwd_dw_encode_bwd(const float *dO, const float *Z, int3
   p.probe = g_gemm_probe;
   p.A = dO; p.lda_dev = blk->counts + 2;
   p.Bm = Z; p.ldb = h;
+  p.a_scale = SCALE_DO; p.b_scale = SCALE_WZ;
   p.M = blk->n_cap; p.Mdev = blk->counts; p.N = h; p.K = B;
   p.kchunk = splits > 1 ? ((rk_cdiv(B, splits) + 31) & ~31) : B;
   p.C = splits > 1 ? workspace : G_de; p.ldc = h; p.act = RK_ACT_NONE;
@@ -991,8 +1191,14 @@ extern "C" int rk_decode_bwd_dw_encode_bwd(const float *dO, const float *Z, int3
   const int grid = n_dw + blk->n_cap * n_seg + n_gb;
   const int hv = rk_cdiv(h, 256);
 #define LAUNCH(HV, SPLIT)                                                                       \
-  RK_LAUNCH((dw_encode_bwd_kernel<HV, SPLIT>), dim3(grid), dim3(256), 0, stream, p, n_dw, splits, \
-            *blk, row_off, B, dZ0pre, h, G_en, gb_en, n_gb, n_seg, seg_stride)
+  do {                                                                                          \
+    if (use_h3())                                                                              \
+      RK_LAUNCH((dw_encode_bwd_kernel<HV, SPLIT, PREC_H3>), dim3(grid), dim3(256), 0, stream, p, \
+                n_dw, splits, *blk, row_off, B, dZ0pre, h, G_en, gb_en, n_gb, n_seg, seg_stride); \
+    else                                                                                        \
+      RK_LAUNCH((dw_encode_bwd_kernel<HV, SPLIT, PREC_F32>), dim3(grid), dim3(256), 0, stream, p, \
+                n_dw, splits, *blk, row_off, B, dZ0pre, h, G_en, gb_en, n_gb, n_seg, seg_stride); \
+  } while (0)
   if (splits > 1) {
     if (hv == 1) LAUNCH(1, true); else if (hv == 2) LAUNCH(2, true); else LAUNCH(4, true);
   } else {
