@@ -184,7 +184,7 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
   const int nt = p.n_fastest ? rt % tn : rt / tm;
   const int m0 = mt * BM, n0 = nt * BN;
   // split-K: the chunk follows the device-resident K so that every split is live
-  const int kchunk = (p.kchunk > 0) ? p.kchunk : (((K + nsplit - 1) / nsplit + 15) & ~15);
+  const int kchunk = (p.kchunk > 0) ? p.kchunk : (((K + nsplit - 1) / nsplit + 31) & ~31);
   const int kbeg = split * kchunk;
   const int kend = min(K, kbeg + kchunk);
   if (kbeg >= kend) return;
@@ -313,16 +313,22 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
         *reinterpret_cast<uint2 *>(d) = hi;
         *reinterpret_cast<uint2 *>(d + BK * 2) = lo;
       };
-      auto stage = [&](float *base, float scale, auto &regs, auto &kk, auto unit_tag, auto pt_tag, int f4, int un) {
-        constexpr bool UNIT = decltype(unit_tag)::value;
+      // (sizes as types: a run-time bound here leaves exec-masked branches around the LDS stores
+      // and hipcc then waits for the loads it has just issued -- see the note at the k-loop)
+      auto stage = [&](float *base, float scale, auto &regs, auto &kk, auto mode_tag, auto pt_tag,
+                       auto f4_tag, auto un_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool UNIT = (MODE == 1);
         constexpr int PT = decltype(pt_tag)::value;
+        constexpr int f4 = decltype(f4_tag)::value, un = decltype(un_tag)::value;
         if (!UNIT) {
 #pragma unroll
           for (int i = 0; i < PT; ++i) {
             const int idx = tid + i * 256;
-            if (idx < f4) {
-              float4 v = regs[i];
-              if (tail) v = mask4(v, klen - kb - kk[i]);
+            if ((f4 % 256 == 0) || idx < f4) {
+              // (selects, not a branch on `tail`: control flow between the staged loads and their
+              // LDS stores makes hipcc drain vmcnt at the top of every iteration)
+              const float4 v = mask4(regs[i], tail ? klen - kb - kk[i] : 4);
               put(base, scale, idx / QK, idx % QK, v);
             }
           }
@@ -330,12 +336,11 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
 #pragma unroll
           for (int j = 0; j < PT / 4; ++j) {
             const int u = tid + j * 256;
-            if (u < un) {
+            if ((un % 256 == 0) || u < un) {
               float4 v[4];
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                v[r] = regs[j * 4 + r];
-                if (tail) v[r] = mask4(v[r], (kb + kk[j * 4 + r] < klen) ? 4 : 0);
+                v[r] = mask4(regs[j * 4 + r], (!tail || kb + kk[j * 4 + r] < klen) ? 4 : 0);
               }
               const int kq = u % QK, c4 = u / QK;
               put(base, scale, c4 * 4 + 0, kq, make_float4(v[0].x, v[1].x, v[2].x, v[3].x));
@@ -346,8 +351,10 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
           }
         }
       };
-      stage(As, p.a_scale, ra, a_k, std::integral_constant<bool, A_UNIT>{}, std::integral_constant<int, A_PT>{}, A_F4, A_UN);
-      stage(Bs, p.b_scale, rb, b_k, std::integral_constant<bool, B_UNIT>{}, std::integral_constant<int, B_PT>{}, B_F4, B_UN);
+      stage(As, p.a_scale, ra, a_k, std::integral_constant<int, AMODE>{}, std::integral_constant<int, A_PT>{},
+            std::integral_constant<int, A_F4>{}, std::integral_constant<int, A_UN>{});
+      stage(Bs, p.b_scale, rb, b_k, std::integral_constant<int, BMODE>{}, std::integral_constant<int, B_PT>{},
+            std::integral_constant<int, B_F4>{}, std::integral_constant<int, B_UN>{});
       return;
     }
 #pragma unroll
@@ -386,12 +393,12 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
     const float *As = smem + buf * (A_SZ + B_SZ);
     const float *Bs = As + A_SZ;
     if (H3) {
-      const int nks = min(BK / 16, (klen - kt * BK + 15) >> 4);   // live k-steps of this tile
+      // every k-step of the tile is computed: the K padding holds zeros (masked / zero padded)
       const char *Ab = reinterpret_cast<const char *>(As) + ((wm * TM) * 32 + l31) * LDB + lh * 16;
       const char *Bb = reinterpret_cast<const char *>(Bs) + ((wn * TN) * 32 + l31) * LDB + lh * 16;
 #pragma unroll
       for (int ks = 0; ks < BK / 16; ++ks) {
-        if (ks < nks) {
+        {
           f16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
@@ -676,12 +683,19 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
     __syncthreads();
     if (tid == 0) p.loss_part[rt] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
     if (p.gb_part && tid < BN) {
+      // one gb_part row per DEC_BM (= 64) rows of dO: a tile of BM rows writes BM / 64 of them
+      constexpr int GR = BM >= 64 ? BM / 64 : 1;   // row groups per tile
+      constexpr int WPG = WM >= GR ? WM / GR : 1;  // waves (along M) per group
+      static_assert(!LOSS || (BM % 64 == 0 && WM % GR == 0), "decode tiles are multiples of 64 rows");
       const int n = n0 + tid;
       if (n < N) {
-        float s2 = cpart[tid];
 #pragma unroll
-        for (int w2 = 1; w2 < WM; ++w2) s2 += cpart[w2 * BN + tid];
-        p.gb_part[(int64_t)mt * ldc + n] = s2;
+        for (int g = 0; g < GR; ++g) {
+          float s2 = cpart[g * WPG * BN + tid];
+#pragma unroll
+          for (int w2 = 1; w2 < WPG; ++w2) s2 += cpart[(g * WPG + w2) * BN + tid];
+          if (m0 + g * 64 < M) p.gb_part[(int64_t)(mt * GR + g) * ldc + n] = s2;
+        }
       }
     }
   }
@@ -701,14 +715,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 // dO / dZ0) and complementary -- MFMA-bound tiles next to latency-bound gathers --
 // and the step is a serial chain of launches, so running them side by side takes the
 // encoder backward off the critical path without a second stream.
-template <int HV, bool SPLIT, int PREC>
+template <int HV, bool SPLIT>
 __global__ __launch_bounds__(256) void dw_encode_bwd_kernel(
     GemmP p, int n_dw, int nsplit, rk_block_t b, int row_off, int B, const float *__restrict__ dZ,
     int h, float *__restrict__ G_en, float *__restrict__ gb, int n_gb, int n_seg,
     int64_t seg_stride) {
   if ((int)blockIdx.x < n_dw)
-    gemm_body<1, 4, 1, 1, 1, 1, SPLIT ? EPI_SPLITK : EPI_STORE, true, PREC == PREC_H3 ? 32 : 16, PREC>(
-        p, (int)blockIdx.x, nsplit);
+    gemm_body<1, 4, 1, 1, 1, 1, SPLIT ? EPI_SPLITK : EPI_STORE, true, 16>(p, (int)blockIdx.x, nsplit);
   else
     ae_encode_bwd_body<HV>(b, row_off, B, dZ, h, G_en, 0, gb, n_gb, (int)blockIdx.x - n_dw, n_seg,
                            seg_stride);
@@ -722,7 +735,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(
   // (8 loads in flight), combined in fixed order through LDS
   __shared__ float4 part[3][64];
   const int K = *Kdev;
-  const int kchunk = ((K + max_splits - 1) / max_splits + 15) & ~15;   // as the GEMM derives it
+  const int kchunk = ((K + max_splits - 1) / max_splits + 31) & ~31;   // as the GEMM derives it
   int ns = (K + kchunk - 1) / kchunk;
   if (ns > max_splits) ns = max_splits;
   const int64_t tot4 = ((int64_t)M * N) >> 2;      // M*N is a multiple of 4 (N = h)
@@ -884,6 +897,7 @@ __global__ __launch_bounds__(64) void loss_reduce_kernel(float *part, int n, flo
   if (lane == 0) loss[0] = (float)s / denom;
 }
 
+
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 constexpr int DZ_SPLITS = 64;        // at most; see dz_splits
@@ -948,6 +962,7 @@ extern "C" int32_t rk_loss_partials(int32_t B, int32_t n_cap) {
   return tiles > B ? tiles : B;
 }
 
+
 extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
                               int32_t row_off, const float *W_de, const float *b_de,
                               int32_t loss_kind, float confidence, float inv_B, float *dO,
@@ -983,19 +998,22 @@ extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_blo
     if (use_h3()) {
       static const int cfg = tune("RK_DEC_CFG", 0);
       const bool mse = (loss_kind == RK_LOSS_MSE);
-      const int bn = cfg == 1 ? 256 : (cfg == 2 ? 64 : 128);
+      const int bm = (cfg == 4 || cfg == 5) ? 128 : 64;
+      const int bn = (cfg == 1 || cfg == 5) ? 256 : (cfg == 2 ? 64 : 128);
+      p.tiles_m = rk_cdiv(B, bm);
       const int g = rk_cdiv(p.tiles_m * rk_cdiv(tgt->n_cap, bn), 8) * 8;
-#define LAUNCH(TN, BKK)                                                                          \
+#define LAUNCH(TM, TN, BKK)                                                                      \
   do {                                                                                           \
     if (mse)                                                                                     \
-      RK_LAUNCH((gemm_kernel<2, 2, 1, TN, 0, 0, EPI_LOSS_MSE, true, BKK, PREC_H3>), dim3(g, 1),  \
+      RK_LAUNCH((gemm_kernel<2, 2, TM, TN, 0, 0, EPI_LOSS_MSE, true, BKK, PREC_H3>), dim3(g, 1), \
                 dim3(256), 0, stream, p);                                                        \
     else                                                                                         \
-      RK_LAUNCH((gemm_kernel<2, 2, 1, TN, 0, 0, EPI_LOSS_BCE, true, BKK, PREC_H3>), dim3(g, 1),  \
+      RK_LAUNCH((gemm_kernel<2, 2, TM, TN, 0, 0, EPI_LOSS_BCE, true, BKK, PREC_H3>), dim3(g, 1), \
                 dim3(256), 0, stream, p);                                                        \
   } while (0)
-      if (cfg == 1) LAUNCH(4, 32); else if (cfg == 2) LAUNCH(1, 32); else if (cfg == 3) LAUNCH(2, 64);
-      else LAUNCH(2, 32);
+      if (cfg == 1) LAUNCH(1, 4, 32); else if (cfg == 2) LAUNCH(1, 1, 32);
+      else if (cfg == 4) LAUNCH(2, 2, 32); else if (cfg == 5) LAUNCH(2, 4, 32);
+      else LAUNCH(1, 2, 32);
 #undef LAUNCH
       RK_CHECK_LAUNCH("decode_loss");
       return 0;
@@ -1106,7 +1124,7 @@ extern "C" int rk_decode_bwd_dz(const float *dO, int32_t B, int32_t h, const rk_
   const int tiles = p.tiles_m * rk_cdiv(h, 32 * tn);   // x 64 splits: a multiple of 8
 #define LAUNCH(TN)                                                                              \
   do {                                                                                          \
-    if (use_h3())                                                                              \
+    if (use_h3())                                                                          \
       RK_LAUNCH((gemm_kernel<4, 1, 1, TN, 0, 1, EPI_SPLITK, true, 32, PREC_H3>),               \
                 dim3(tiles, splits), dim3(256), 0, stream, p);                                  \
     else                                                                                        \
@@ -1146,12 +1164,10 @@ extern "C" int rk_decode_bwd_dw(const float *dO, const float *Z, int32_t B, int3
     p.n_fastest = 1;   // the h/128 column tiles of one dO panel stay on one XCD
     p.tiles_m = rk_cdiv(tgt->n_cap, 32);
     const int tiles = rk_cdiv(p.tiles_m * rk_cdiv(h, 128), 8) * 8;
-    if (use_h3())
-      RK_LAUNCH((gemm_kernel<1, 4, 1, 1, 1, 1, EPI_STORE, true, 32, PREC_H3>), dim3(tiles, 1),
-                dim3(256), 0, stream, p);
-    else
-      RK_LAUNCH((gemm_kernel<1, 4, 1, 1, 1, 1, EPI_STORE, true, 32>), dim3(tiles, 1),
-                dim3(256), 0, stream, p);
+    // (stays on the fp32 MFMA: Z would be re-split by every one of the ~500 workgroups, and the
+    // split-fp16 variant measured 31 vs 30 us alone and 53 vs 38 us fused with the encoder backward)
+    RK_LAUNCH((gemm_kernel<1, 4, 1, 1, 1, 1, EPI_STORE, true, 32>), dim3(tiles, 1), dim3(256), 0,
+              stream, p);
   }
   RK_CHECK_LAUNCH("decode_bwd_dw");
   if (gb_de) return rk_colsum(dO, B, tgt->n_cap, 0, tgt->counts, gb_de, stream_);
@@ -1191,14 +1207,8 @@ extern "C" int rk_decode_bwd_dw_encode_bwd(const float *dO, const float *Z, int3
   const int grid = n_dw + blk->n_cap * n_seg + n_gb;
   const int hv = rk_cdiv(h, 256);
 #define LAUNCH(HV, SPLIT)                                                                       \
-  do {                                                                                          \
-    if (use_h3())                                                                              \
-      RK_LAUNCH((dw_encode_bwd_kernel<HV, SPLIT, PREC_H3>), dim3(grid), dim3(256), 0, stream, p, \
-                n_dw, splits, *blk, row_off, B, dZ0pre, h, G_en, gb_en, n_gb, n_seg, seg_stride); \
-    else                                                                                        \
-      RK_LAUNCH((dw_encode_bwd_kernel<HV, SPLIT, PREC_F32>), dim3(grid), dim3(256), 0, stream, p, \
-                n_dw, splits, *blk, row_off, B, dZ0pre, h, G_en, gb_en, n_gb, n_seg, seg_stride); \
-  } while (0)
+  RK_LAUNCH((dw_encode_bwd_kernel<HV, SPLIT>), dim3(grid), dim3(256), 0, stream, p, n_dw, splits, \
+            *blk, row_off, B, dZ0pre, h, G_en, gb_en, n_gb, n_seg, seg_stride)
   if (splits > 1) {
     if (hv == 1) LAUNCH(1, true); else if (hv == 2) LAUNCH(2, true); else LAUNCH(4, true);
   } else {
