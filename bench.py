@@ -34,6 +34,11 @@ if ROOT not in sys.path:
 
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_MFMA_F32_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
+PEAK_MFMA_F16_TF = 2500.0      # v_mfma_f32_32x32x16_f16 dense peak (MI355X_MICROARCH.md, no sparsity)
+# decode / dZ run on the f16 pipe with every fp32 operand split into an fp16 pair: 3 MFMA flops per
+# algorithmic flop, so the ceiling for ALGORITHMIC flops of those two entries is a third of the pipe
+H3_ENTRIES = ("rk_decode_loss", "rk_decode_bwd_dz")
+GEMM_F32 = os.environ.get("RK_GEMM_PREC", "")[:1].lower() == "f"
 
 CONFIGS = {
   # C2 of BASELINE.json: ML-20M autoencoder, hidden [200], MSE, 1 x MI355X
@@ -64,7 +69,7 @@ def algorithmic_work(entry, B, h0, n_b, nnz, n_items, cfg_sparse=False):
   """(bound, work per launch, unit) of one C-ABI entry."""
   gemm = 2.0 * B * h0 * n_b
   if entry in ("rk_decode_loss", "rk_decode_bwd_dz", "rk_decode_bwd_dw"):
-    return "mfma", gemm / 1e12, "TFLOP/s"          # fp32 MFMA contraction
+    return "mfma", gemm / 1e12, "TFLOP/s"          # algorithmic flops of the contraction
   if entry == "rk_ae_encode_fwd":
     return "hbm", (nnz * (h0 * 4 + 12) + B * h0 * 4) / 1e9, "GB/s"
   if entry == "rk_ae_encode_bwd":
@@ -323,7 +328,12 @@ def main():
     ms = ms_raw - ev_over
     bound, work, unit = algorithmic_work(only, B, h0, n_b, nnz, n_items, bool(cfg["sparse"]))
     achieved = work / (ms * 1e-3) if ms == ms and ms > 0 else float("nan")
-    peak = PEAK_MFMA_F32_TF if bound == "mfma" else PEAK_HBM_GBS
+    if bound != "mfma":
+      peak = PEAK_HBM_GBS
+    elif only in H3_ENTRIES and not GEMM_F32:
+      peak = PEAK_MFMA_F16_TF / 3.0
+    else:
+      peak = PEAK_MFMA_F32_TF
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload
     # (profiles/r*_pmc_traffic.json, tools/pmc_traffic.py); null for other configs
     traffic = None
@@ -343,7 +353,9 @@ def main():
       "metric": "train_users_per_sec", "value": value, "unit": "users/s",
       "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
       "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-      "vs_baseline": None, "dtype": "f32",
+      # fp32 storage, accumulation and element-wise math everywhere; decode / dZ multiply fp16
+      # hi+lo pairs of the fp32 operands on the f16 MFMA (3 products, ~2^-22 relative), dW fp32 MFMA
+      "vs_baseline": None, "dtype": "f32" if GEMM_F32 else "f32 (decode/dZ: split-fp16 pairs, f32 acc)",
       "data": ("INVALID (diagnostic: no collation)" if args.diag_reuse_block else
                "INVALID (diagnostic: one rank's share, no collectives)" if args.diag_virtual_world
                else "synthetic"),

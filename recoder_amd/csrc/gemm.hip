@@ -59,10 +59,18 @@ enum { EPI_STORE = 0, EPI_LOSS_MSE = 1, EPI_SPLITK = 2, EPI_LOSS_BCE = 3 };
 //              rounding an fp32 fma chain of this length accumulates itself.  The accumulator
 //              is rescaled by 1 / (s_a s_b) (exact) before the epilogue.
 //              Range: |s.x| must stay below 65504 (else inf -> NaN loss, loudly): with the
-//              scales below |W|, |Z| < 4096 and |dLoss/dLogit| < 64.
+//              scales below |W| < 512 and |Z| < 2048; dLoss/dLogits is scaled from its own
+//              maximum, so it has no such limit.
 enum { PREC_F32 = 0, PREC_H3 = 1 };
-constexpr float SCALE_WZ = 16.0f;      // embedding rows and activations
-constexpr float SCALE_DO = 1024.0f;    // dLoss/dLogits (already divided by the batch size)
+// Full 22-bit precision needs |s.x| >= 2^-3 (below that the lo half goes subnormal: absolute error
+// 2^-25 / s); overflow at |s.x| >= 65504.
+constexpr float SCALE_W = 128.0f;      // embedding rows:  |w| < 512,  exact split for |w| >= 1e-3
+constexpr float SCALE_Z = 32.0f;       // activations:     |z| < 2048, exact split for |z| >= 4e-3
+// dLoss/dLogits scales with 1 / batch rows, the confidence weight and the logits themselves, so its
+// scale is chosen on the device from the running maximum |g| that the loss kernels publish in
+// rk_block_t.counts[8..15] (a_amax): max|g| . s lands in [2^13, 2^14).  SCALE_DO is the fallback for
+// a dO the caller filled without publishing a maximum (slots all zero).
+constexpr float SCALE_DO = 1024.0f;
 
 // 4 consecutive-k fp32 values -> 4 fp16 "hi" + 4 fp16 "lo" of s.x
 // (v_pk_mul_f32, v_cvt_pk_f16_f32, v_cvt_f32_f16, v_pk_fma_f32)
@@ -88,6 +96,7 @@ struct GemmP {
   int n_fastest;            // tile order inside a split: nt fastest (else mt fastest)
   int kchunk;               // K range per blockIdx.y
   float a_scale, b_scale;   // PREC_H3: powers of two applied to the operands before the fp16 split
+  const uint32_t *a_amax;   // PREC_H3, nullable: 8 slots of fp32 bit patterns, max |A| (see SCALE_DO)
   // store epilogue
   float *C;
   int ldc;                  // <=0 : read ld from ld_dev
@@ -168,6 +177,16 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
   const int K = p.Kdev ? *p.Kdev : p.K;
   const int lda = p.lda_dev ? *p.lda_dev : p.lda;
   const int ldb = p.ldb_dev ? *p.ldb_dev : p.ldb;
+  float a_scale = p.a_scale;
+  if (H3 && p.a_amax) {      // scale of A from its published maximum: max . s in [2^13, 2^14)
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) m = max(m, p.a_amax[i]);
+    if (m != 0) {
+      const int e = min(max((int)(m >> 23) - 127, -100), 100);
+      a_scale = __uint_as_float((uint32_t)(13 - e + 127) << 23);
+    }
+  }
   // XCD-aware tile mapping.  Workgroup L runs on XCD L % 8 (each XCD has its own
   // L2), so XCD x gets the contiguous chunk [x*chunk, (x+1)*chunk) of the LIVE
   // tile list -- tiles that share an operand panel (same nt for gathered W rows,
@@ -351,7 +370,7 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
           }
         }
       };
-      stage(As, p.a_scale, ra, a_k, std::integral_constant<int, AMODE>{}, std::integral_constant<int, A_PT>{},
+      stage(As, a_scale, ra, a_k, std::integral_constant<int, AMODE>{}, std::integral_constant<int, A_PT>{},
             std::integral_constant<int, A_F4>{}, std::integral_constant<int, A_UN>{});
       stage(Bs, p.b_scale, rb, b_k, std::integral_constant<int, BMODE>{}, std::integral_constant<int, B_PT>{},
             std::integral_constant<int, B_F4>{}, std::integral_constant<int, B_UN>{});
@@ -521,7 +540,7 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
   // read back row-major a lane owns 4 x (one row, 4 consecutive columns), so the
   // epilogue issues 4x fewer, 16-byte-wide global stores / loads per tile.
   if (H3) {
-    const float inv = 1.0f / (p.a_scale * p.b_scale);     // exact: powers of two
+    const float inv = 1.0f / (a_scale * p.b_scale);       // exact: powers of two
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -617,7 +636,7 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
     const int ldc = *p.ld_dev;
     const rk_block_t &b = p.blk;
     const bool implicit = b.implicit != 0;
-    float lsum = 0.f;
+    float lsum = 0.f, gmax = 0.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int nb = n0 + (wn * TN + j) * 32;   // multiple of 32: one bitmap word per row
@@ -659,7 +678,7 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
               const float sg = 1.0f / (1.0f + expf(-o));
               g[e] = (sg - t) * p.inv_B;
             }
-            if (ok) { lsum += l; cs[e] += g[e]; }
+            if (ok) { lsum += l; cs[e] += g[e]; gmax = fmaxf(gmax, fabsf(g[e])); }
           }
           // columns in [N, ld) are padding of the dO row: storing them is harmless
           if (m < M && n < N)
@@ -679,9 +698,16 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
       }
     }
     lsum = rk_wave_sum(lsum);
-    if (lane == 0) lred[wid] = lsum;
+    gmax = rk_wave_max(gmax);
+    if (lane == 0) { lred[wid] = lsum; lred[4 + wid] = gmax; }
     __syncthreads();
-    if (tid == 0) p.loss_part[rt] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
+    if (tid == 0) {
+      p.loss_part[rt] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
+      // running max |dLoss/dLogit| of this block (8 slots: one per XCD, fewer same-address
+      // atomics); the backward contraction picks its fp16 split scale from it
+      const float gm = fmaxf(fmaxf(lred[4], lred[5]), fmaxf(lred[6], lred[7]));
+      atomicMax(reinterpret_cast<unsigned int *>(b.counts) + 8 + (L & 7), __float_as_uint(gm));
+    }
     if (p.gb_part && tid < BN) {
       // one gb_part row per DEC_BM (= 64) rows of dO: a tile of BM rows writes BM / 64 of them
       constexpr int GR = BM >= 64 ? BM / 64 : 1;   // row groups per tile
@@ -843,6 +869,7 @@ __global__ __launch_bounds__(256) void mnll_finish_kernel(float *dO, rk_block_t 
   if (tid == 0) bc[0] = (red[0] + red[1]) + (red[2] + red[3]);
   __syncthreads();
   const float sum_g = ext_tsum ? -ext_tsum[r] * inv_B : bc[0];
+  float gmax = 0.f;
   // dense part: dO = g - softmax * sum_g,  g = -t*inv_B at stored positions
   for (int c = tid; c < n; c += 256) {
     const float e = expf((orow[c] - mx) - lsum);
@@ -852,8 +879,18 @@ __global__ __launch_bounds__(256) void mnll_finish_kernel(float *dO, rk_block_t 
       const float t = implicit ? 1.0f : b.vals[rk_entry_index(b, row, c, word)];
       g = -t * inv_B;
     }
-    orow[c] = g - e * sum_g;
+    const float go = g - e * sum_g;
+    gmax = fmaxf(gmax, fabsf(go));
+    orow[c] = go;
   }
+  // running max |dLoss/dLogit| of the block, as the MSE / BCE epilogue publishes it
+  gmax = rk_wave_max(gmax);
+  __syncthreads();
+  if (lane == 0) red[wid] = gmax;
+  __syncthreads();
+  if (tid == 0)
+    atomicMax(reinterpret_cast<unsigned int *>(b.counts) + 8 + (r & 7),
+              __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
 }
 
 // local softmax statistics of a row's shard: stats[r] = {max, sum exp(o - max)}
@@ -976,7 +1013,7 @@ extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_blo
   p.probe = g_gemm_probe;
   p.A = Z; p.lda = h;
   p.Bm = W_de; p.ldb = h; p.bidx = tgt->items;
-  p.a_scale = SCALE_WZ; p.b_scale = SCALE_WZ;
+  p.a_scale = SCALE_Z; p.b_scale = SCALE_W;
   p.M = B; p.N = tgt->n_cap; p.K = h;
   p.Ndev = tgt->counts;          // n_t
   p.tiles_m = rk_cdiv(B, DEC_BM);
@@ -1112,7 +1149,8 @@ extern "C" int rk_decode_bwd_dz(const float *dO, int32_t B, int32_t h, const rk_
   p.probe = g_gemm_probe;
   p.A = dO; p.lda_dev = tgt->counts + 2;
   p.Bm = W_de; p.ldb = h; p.bidx = tgt->items;
-  p.a_scale = SCALE_DO; p.b_scale = SCALE_WZ;
+  p.a_scale = SCALE_DO; p.b_scale = SCALE_W;
+  p.a_amax = reinterpret_cast<const uint32_t *>(tgt->counts) + 8;
   p.M = B; p.N = h; p.K = tgt->n_cap; p.Kdev = tgt->counts;
   p.C = workspace;
   p.kchunk = 0;                       // derived in-kernel from the device-resident n_t
@@ -1153,7 +1191,7 @@ extern "C" int rk_decode_bwd_dw(const float *dO, const float *Z, int32_t B, int3
   p.probe = g_gemm_probe;
   p.A = dO; p.lda_dev = tgt->counts + 2;
   p.Bm = Z; p.ldb = h;
-  p.a_scale = SCALE_DO; p.b_scale = SCALE_WZ;
+  p.a_scale = SCALE_DO; p.b_scale = SCALE_Z;     // (dW runs on the fp32 MFMA: unused)
   p.M = tgt->n_cap; p.Mdev = tgt->counts; p.N = h; p.K = B;
   p.kchunk = B;
   p.C = G_de; p.ldc = h; p.act = RK_ACT_NONE;
@@ -1194,7 +1232,7 @@ extern "C" int rk_decode_bwd_dw_encode_bwd(const float *dO, const float *Z, int3
   p.probe = g_gemm_probe;
   p.A = dO; p.lda_dev = blk->counts + 2;
   p.Bm = Z; p.ldb = h;
-  p.a_scale = SCALE_DO; p.b_scale = SCALE_WZ;
+  p.a_scale = SCALE_DO; p.b_scale = SCALE_Z;     // (dW runs on the fp32 MFMA: unused)
   p.M = blk->n_cap; p.Mdev = blk->counts; p.N = h; p.K = B;
   p.kchunk = splits > 1 ? ((rk_cdiv(B, splits) + 31) & ~31) : B;
   p.C = splits > 1 ? workspace : G_de; p.ldc = h; p.act = RK_ACT_NONE;

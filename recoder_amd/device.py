@@ -89,7 +89,7 @@ class Block:
     self.ldw_cr = cdiv(S_cap, 32)
     self.n_chunks = cdiv(self.n_items, SCAN_CHUNK)
     i32 = dict(dtype=torch.int32, device=device)
-    self.counts = torch.zeros(4, **i32)
+    self.counts = torch.zeros(16, **i32)    # rk_block_t.counts: 4 sizes + spare + 8 amax slots
     self.indptr = torch.zeros(S_cap + 1, **i32)
     self.cols = torch.zeros(nnz_cap, **i32)
     self.vals = torch.zeros(nnz_cap, dtype=torch.float32, device=device)
@@ -141,7 +141,7 @@ class Block:
     n = int(n)
     assert n <= self.n_cap
     self.items[:n].copy_(items_dev_i32[:n])
-    self.counts.copy_(torch.tensor([n, 0, cdiv(n, 32) * 32, S], dtype=torch.int32), non_blocking=False)
+    self.counts[:4].copy_(torch.tensor([n, 0, cdiv(n, 32) * 32, S], dtype=torch.int32), non_blocking=False)
     self.S = S
 
   def host_n_b(self):
@@ -215,7 +215,7 @@ class CollatePrefetcher:
         if getattr(blk, "counts_pinned", None) is None:
           blk.counts_pinned = torch.zeros(4, dtype=torch.int32).pin_memory()
           blk.counts_event = torch.cuda.Event()
-        blk.counts_pinned.copy_(blk.counts, non_blocking=True)
+        blk.counts_pinned.copy_(blk.counts[:4], non_blocking=True)
         blk.counts_event.record(self.stream)
       self.ready[slot].record(self.stream)
     self._count[slot] = len(users_list)

@@ -520,6 +520,13 @@ class Recoder(object):
       # one device->host read per epoch instead of loss.item() per step (model.py:404)
       self.last_epoch_losses = loss_buf[:n_done].cpu().numpy().copy()
       self.loss_history.append(self.last_epoch_losses)
+      if n_done and not np.all(np.isfinite(self.last_epoch_losses)):
+        # the reference keeps training on a NaN loss too; here there is one extra way to get one:
+        # the decoder GEMMs split their operands into fp16 pairs (range |W| < 512, |Z| < 2048,
+        # recoder_amd/csrc/gemm.hip) -- RK_GEMM_PREC=f32 runs them on the fp32 MFMA
+        log.warning(
+          "non-finite training loss in epoch %d; if activations / weights exceed the split-fp16 range "
+          "of the decoder GEMMs, rerun with RK_GEMM_PREC=f32", epoch)
       postfix = {"loss": float(self.last_epoch_losses[-1]) if n_done else float("nan")}
       if eval_freq > 0 and epoch % eval_freq == 0 and val_dataloader is not None:
         self._sync_user_rows()

@@ -1,0 +1,131 @@
+"""GPU tests of the split-fp16 decoder contractions (recoder_amd/csrc/gemm.hip, PREC_H3).
+
+decode (O = Z . W_de[T]^T, reference nn.py:271-280) and its backward dZ = dO . W_de[T]
+multiply fp16 hi+lo pairs of the fp32 operands on the f16 MFMA pipe.  These tests pin
+  * the accuracy of that arithmetic against a float64 product over the magnitudes the
+    power-of-two operand scales are specified for (include/recoder_hip.h), next to the error
+    an fp32 matmul of the same operands makes,
+  * the fp32-MFMA fallback (RK_GEMM_PREC=f32): same golden parity in a sub-process.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _block(B, n_items, n_t, dev, seed):
+  """A collated block whose item set has n_t items (one user row touching them all)."""
+  import scipy.sparse as sp
+  from recoder_amd.device import Block, DeviceCSR
+  rng = np.random.RandomState(seed)
+  items = np.sort(rng.choice(n_items, size=n_t, replace=False))
+  rows = np.concatenate([np.zeros(n_t, np.int64), rng.randint(0, B, size=4 * B)])
+  cols = np.concatenate([items, rng.choice(items, size=4 * B)])
+  csr = sp.coo_matrix((np.ones(len(rows), np.float32), (rows, cols)), shape=(B, n_items)).tocsr()
+  csr.sum_duplicates()
+  csr.data[:] = 1.0
+  csr.sort_indices()
+  dcsr = DeviceCSR(csr)
+  blk = Block(B, int(csr.nnz), n_items, dev)
+  blk.collate(dcsr, torch.arange(B, dtype=torch.int64, device=dev))
+  n_b = blk.counts_host()[0]
+  assert n_b == n_t
+  return blk, items
+
+
+# (top magnitude of Z, of W): typical training values, the top of the documented range
+# (|Z| < 2048, |W| < 512), and small operands -- below |z| ~ 4e-3 / |w| ~ 1e-3 the lo halves go
+# subnormal and the split keeps an ABSOLUTE error of 2^-25 / scale per element instead
+@pytest.mark.parametrize("zmag,wmag,tol", [(1.0, 0.05, 6e-7), (1.0, 0.5, 6e-7), (1500.0, 0.3, 6e-7),
+                                           (30.0, 400.0, 6e-7), (0.05, 0.02, 6e-7),
+                                           (1e-3, 1e-3, 3e-5)])
+@pytest.mark.parametrize("B,h,n_t", [(96, 200, 333), (500, 64, 1000)])
+def test_decode_logits_match_float64(zmag, wmag, tol, B, h, n_t):
+  from recoder_amd import _lib
+  from recoder_amd._lib import LOSS_NONE, check, ptr
+  from recoder_amd.device import current_stream
+  lib = _lib.load()
+  dev = torch.device("cuda")
+  n_items = 4000
+  blk, items = _block(B, n_items, n_t, dev, seed=B + n_t)
+  g = torch.Generator(device="cpu").manual_seed(7)
+  # a spread of magnitudes inside each operand (log-uniform over 2 decades below the top)
+  def spread(shape, top):
+    mag = top * 10.0 ** (-2.0 * torch.rand(shape, generator=g, dtype=torch.float64))
+    sign = torch.where(torch.rand(shape, generator=g) < 0.5, -1.0, 1.0).double()
+    return (mag * sign).float()
+  Z = spread((B, h), zmag)
+  W = spread((n_items, h), wmag)
+  b = torch.zeros(n_items)
+  ld = blk.ld_cap
+  out = torch.zeros(B * ld, device=dev)
+  Zd, Wd, bd = Z.to(dev), W.to(dev), b.to(dev)
+  check(lib.rk_decode_loss(ptr(Zd), B, h, blk.ref, 0, ptr(Wd), ptr(bd), LOSS_NONE, 0.0, 1.0, ptr(out),
+                           ld, None, None, current_stream()), "rk_decode_loss")
+  got = out.view(B, ld)[:, :n_t].cpu().double()
+  Wt = W[torch.from_numpy(items)].double()
+  exact = Z.double() @ Wt.t()
+  scale = Z.double().abs() @ Wt.abs().t()            # sum of |products|: what rounding scales with
+  err = ((got - exact).abs() / scale).max().item()
+  f32 = (Z @ W[torch.from_numpy(items)].t()).double()
+  err32 = ((f32 - exact).abs() / scale).max().item()
+  print("zmag %g wmag %g: split-fp16 %.2e   fp32 matmul %.2e" % (zmag, wmag, err, err32))
+  assert torch.isfinite(got).all()
+  # 3 . 2^-22 per product at worst, far less after summation; fp32 fma chains sit at ~1e-7 here
+  assert err < tol, (err, err32)
+
+
+@pytest.mark.parametrize("gtop", [2e-3, 40.0, 1e-7])
+def test_dz_matches_float64(gtop):
+  """dO's split scale comes from the maximum the loss kernels publish: any magnitude works."""
+  import struct
+  from recoder_amd import _lib
+  from recoder_amd._lib import check, ptr
+  from recoder_amd.device import current_stream
+  lib = _lib.load()
+  dev = torch.device("cuda")
+  B, h, n_t, n_items = 300, 200, 2500, 6000
+  blk, items = _block(B, n_items, n_t, dev, seed=3)
+  g = torch.Generator(device="cpu").manual_seed(11)
+  ld = blk.counts_host()[2]
+  dO = torch.zeros(B, blk.ld_cap)
+  # gradients as the loss produces them: ~1e-3 and smaller, many decades of spread
+  dO[:, :n_t] = (gtop * 10.0 ** (-3.0 * torch.rand((B, n_t), generator=g))
+                 * torch.where(torch.rand((B, n_t), generator=g) < 0.5, -1.0, 1.0))
+  # publish the maximum the way rk_decode_loss does (fp32 bit pattern in counts[8..15])
+  amax = float(dO.abs().max())
+  blk.counts[8] = struct.unpack("<i", struct.pack("<f", amax))[0]
+  dO_dev = torch.zeros(B * blk.ld_cap, device=dev)
+  dO_dev.view(-1)[:B * ld].view(B, ld)[:, :n_t] = dO[:, :n_t].to(dev)
+  W = (torch.randn(n_items, h, generator=g) * 0.05)
+  Wd = W.to(dev)
+  dZ = torch.zeros(B * h, device=dev)
+  ws = torch.zeros(lib.rk_dz_workspace_bytes(B, h) // 4, device=dev)
+  check(lib.rk_decode_bwd_dz(ptr(dO_dev), B, h, blk.ref, ptr(Wd), None, 0, ptr(dZ), ptr(ws),
+                             current_stream()), "rk_decode_bwd_dz")
+  Wt = W[torch.from_numpy(items)].double()
+  exact = dO[:, :n_t].double() @ Wt
+  scale = dO[:, :n_t].double().abs() @ Wt.abs()
+  err = ((dZ.view(B, h).cpu().double() - exact).abs() / scale).max().item()
+  f32 = (dO[:, :n_t] @ W[torch.from_numpy(items)]).double()
+  err32 = ((f32 - exact).abs() / scale).max().item()
+  print("dZ gtop %g: split-fp16 %.2e   fp32 matmul %.2e" % (gtop, err, err32))
+  assert err < 6e-7, (err, err32)
+
+
+def test_fp32_mfma_fallback_keeps_golden_parity():
+  """RK_GEMM_PREC=f32 (read once per process) routes the same entry points to the fp32 MFMA."""
+  env = dict(os.environ, RK_GEMM_PREC="f32")
+  r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
+                      os.path.join(ROOT, "tests", "test_hip_parity.py"), "-k",
+                      "replays_reference_golden or steps_match_oracle"],
+                     cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+  assert " passed" in r.stdout and "no tests ran" not in r.stdout, r.stdout[-500:]
