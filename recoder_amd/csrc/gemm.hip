@@ -919,21 +919,35 @@ __global__ __launch_bounds__(256) void mnll_row_stats_kernel(const float *dO, rk
   }
 }
 
-// one wave: lane-strided double sums + fixed shuffle tree (order-deterministic);
-// re-zeroes the partials so the next rk_decode_loss finds them clean
-__global__ __launch_bounds__(64) void loss_reduce_kernel(float *part, int n, float denom,
-                                                         float *loss) {
-  const int lane = threadIdx.x;
+// one workgroup of 1024 threads: thread-strided double sums (8 independent loads in flight per
+// thread -- item-heavy blocks have ~10^4 partials, which a single wave took 110 us to walk) and a
+// fixed LDS tree (order-deterministic); re-zeroes the partials so the next rk_decode_loss finds
+// them clean
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(float *part, int n, float denom,
+                                                           float *loss) {
+  __shared__ double red[1024];
+  const int tid = threadIdx.x;
   double s = 0.0;
-  for (int i = lane; i < n; i += 64) {
+  int i = tid;
+  for (; i + 7 * 1024 < n; i += 8 * 1024) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[i + u * 1024];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s += (double)v[u]; part[i + u * 1024] = 0.f; }
+  }
+  for (; i < n; i += 1024) {
     s += (double)part[i];
     part[i] = 0.f;
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if (lane == 0) loss[0] = (float)s / denom;
+  red[tid] = s;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if (tid < off) red[tid] += red[tid + off];
+    __syncthreads();
+  }
+  if (tid == 0) loss[0] = (float)red[0] / denom;
 }
-
 
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -1131,7 +1145,7 @@ extern "C" int rk_mnll_finish_ext(float *dO, int32_t B, const rk_block_t *tgt, i
 extern "C" int rk_loss_reduce(float *loss_part, int32_t n, float denom, float *loss,
                               void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  RK_LAUNCH(loss_reduce_kernel, dim3(1), dim3(64), 0, stream, loss_part, n, denom, loss);
+  RK_LAUNCH(loss_reduce_kernel, dim3(1), dim3(1024), 0, stream, loss_part, n, denom, loss);
   RK_CHECK_LAUNCH("loss_reduce");
   return 0;
 }
