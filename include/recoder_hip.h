@@ -54,7 +54,7 @@ typedef struct rk_block {
   int32_t n_chunks;   /* ceil(n_items / RK_SCAN_CHUNK) */
   int32_t implicit;   /* != 0: every stored value is 1.0 (vals is not read by the
                          loss / backward kernels) -- implicit-feedback data */
-  int32_t *counts;    /* [16] dev: n_b, nnz_b, ld (= round_up(n_b,32)), S, 4 spare; [8..15]: fp32 bit
+  int32_t *counts;    /* [72] dev: n_b, nnz_b, ld (= round_up(n_b,32)), S, 4 spare; [8..71]: fp32 bit
                          patterns of the running max |dLoss/dLogit| the loss kernels saw since
                          rk_collate zeroed them (rk_decode_bwd_dz scales its fp16 split by it) */
   int32_t *indptr;    /* [S_cap+1] block CSR row pointers */

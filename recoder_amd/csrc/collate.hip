@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void collate_phase1_kernel(
       b.indptr[S] = carry_s;
       b.counts[1] = carry_s;
       b.counts[3] = S;
-      for (int i = 8; i < 16; ++i) b.counts[i] = 0;   // max |dLoss/dLogit| slots (gemm.hip)
+      for (int i = 8; i < 72; ++i) b.counts[i] = 0;   // max |dLoss/dLogit| slots (gemm.hip)
     }
     return;
   }

@@ -68,7 +68,7 @@ constexpr float SCALE_W = 128.0f;      // embedding rows:  |w| < 512,  exact spl
 constexpr float SCALE_Z = 32.0f;       // activations:     |z| < 2048, exact split for |z| >= 4e-3
 // dLoss/dLogits scales with 1 / batch rows, the confidence weight and the logits themselves, so its
 // scale is chosen on the device from the running maximum |g| that the loss kernels publish in
-// rk_block_t.counts[8..15] (a_amax): max|g| . s lands in [2^13, 2^14).  SCALE_DO is the fallback for
+// rk_block_t.counts[8..71] (a_amax): max|g| . s lands in [2^13, 2^14).  SCALE_DO is the fallback for
 // a dO the caller filled without publishing a maximum (slots all zero).
 constexpr float SCALE_DO = 1024.0f;
 
@@ -81,6 +81,13 @@ __device__ __forceinline__ void split4(const float4 v, const float s, uint2 &hi,
   const f16x2 qa = __builtin_convertvector(la, f16x2), qb = __builtin_convertvector(lb, f16x2);
   hi.x = __builtin_bit_cast(uint32_t, ha); hi.y = __builtin_bit_cast(uint32_t, hb);
   lo.x = __builtin_bit_cast(uint32_t, qa); lo.y = __builtin_bit_cast(uint32_t, qb);
+}
+
+// running max |dLoss/dLogit| of a block: slot (0..63) of counts[8..71] <- max(slot, v) as fp32 bit
+// patterns (monotonic for v >= 0).  64 slots: with 8, the ~10^3 workgroups of a decode launch
+// queued ~140 deep on each address at the L2 and the launch grew by 4-8 us.
+__device__ __forceinline__ void publish_amax(int32_t *counts, int slot, float v) {
+  atomicMax(reinterpret_cast<unsigned int *>(counts) + 8 + (slot & 63), __float_as_uint(v));
 }
 
 struct GemmP {
@@ -96,7 +103,7 @@ struct GemmP {
   int n_fastest;            // tile order inside a split: nt fastest (else mt fastest)
   int kchunk;               // K range per blockIdx.y
   float a_scale, b_scale;   // PREC_H3: powers of two applied to the operands before the fp16 split
-  const uint32_t *a_amax;   // PREC_H3, nullable: 8 slots of fp32 bit patterns, max |A| (see SCALE_DO)
+  const uint32_t *a_amax;   // PREC_H3, nullable: 64 slots of fp32 bit patterns, max |A| (see SCALE_DO)
   // store epilogue
   float *C;
   int ldc;                  // <=0 : read ld from ld_dev
@@ -179,9 +186,9 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
   const int ldb = p.ldb_dev ? *p.ldb_dev : p.ldb;
   float a_scale = p.a_scale;
   if (H3 && p.a_amax) {      // scale of A from its published maximum: max . s in [2^13, 2^14)
-    uint32_t m = 0;
+    uint32_t m = p.a_amax[threadIdx.x & 63];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) m = max(m, p.a_amax[i]);
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
     if (m != 0) {
       const int e = min(max((int)(m >> 23) - 127, -100), 100);
       a_scale = __uint_as_float((uint32_t)(13 - e + 127) << 23);
@@ -706,7 +713,7 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
       // running max |dLoss/dLogit| of this block (8 slots: one per XCD, fewer same-address
       // atomics); the backward contraction picks its fp16 split scale from it
       const float gm = fmaxf(fmaxf(lred[4], lred[5]), fmaxf(lred[6], lred[7]));
-      atomicMax(reinterpret_cast<unsigned int *>(b.counts) + 8 + (L & 7), __float_as_uint(gm));
+      publish_amax(b.counts, L, gm);
     }
     if (p.gb_part && tid < BN) {
       // one gb_part row per DEC_BM (= 64) rows of dO: a tile of BM rows writes BM / 64 of them
@@ -888,9 +895,7 @@ __global__ __launch_bounds__(256) void mnll_finish_kernel(float *dO, rk_block_t 
   __syncthreads();
   if (lane == 0) red[wid] = gmax;
   __syncthreads();
-  if (tid == 0)
-    atomicMax(reinterpret_cast<unsigned int *>(b.counts) + 8 + (r & 7),
-              __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+  if (tid == 0) publish_amax(b.counts, r, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
 // local softmax statistics of a row's shard: stats[r] = {max, sum exp(o - max)}

@@ -89,7 +89,7 @@ class Block:
     self.ldw_cr = cdiv(S_cap, 32)
     self.n_chunks = cdiv(self.n_items, SCAN_CHUNK)
     i32 = dict(dtype=torch.int32, device=device)
-    self.counts = torch.zeros(16, **i32)    # rk_block_t.counts: 4 sizes + spare + 8 amax slots
+    self.counts = torch.zeros(72, **i32)    # rk_block_t.counts: 4 sizes + spare + 64 amax slots
     self.indptr = torch.zeros(S_cap + 1, **i32)
     self.cols = torch.zeros(nnz_cap, **i32)
     self.vals = torch.zeros(nnz_cap, dtype=torch.float32, device=device)

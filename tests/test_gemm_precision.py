@@ -99,7 +99,7 @@ def test_dz_matches_float64(gtop):
   # gradients as the loss produces them: ~1e-3 and smaller, many decades of spread
   dO[:, :n_t] = (gtop * 10.0 ** (-3.0 * torch.rand((B, n_t), generator=g))
                  * torch.where(torch.rand((B, n_t), generator=g) < 0.5, -1.0, 1.0))
-  # publish the maximum the way rk_decode_loss does (fp32 bit pattern in counts[8..15])
+  # publish the maximum the way rk_decode_loss does (fp32 bit pattern in counts[8..71])
   amax = float(dO.abs().max())
   blk.counts[8] = struct.unpack("<i", struct.pack("<f", amax))[0]
   dO_dev = torch.zeros(B * blk.ld_cap, device=dev)
