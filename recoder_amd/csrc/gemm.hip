@@ -341,8 +341,12 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
       };
       // (sizes as types: a run-time bound here leaves exec-masked branches around the LDS stores
       // and hipcc then waits for the loads it has just issued -- see the note at the k-loop)
+      // Only A is masked in the K tail: a product needs ONE zero factor, and the clamped tail
+      // loads of B are real (finite) table / activation values -- masking both cost 2 VALU per
+      // staged element on every tile, as much again as the split itself.
       auto stage = [&](float *base, float scale, auto &regs, auto &kk, auto mode_tag, auto pt_tag,
-                       auto f4_tag, auto un_tag) {
+                       auto f4_tag, auto un_tag, auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
         constexpr int MODE = decltype(mode_tag)::value;
         constexpr bool UNIT = (MODE == 1);
         constexpr int PT = decltype(pt_tag)::value;
@@ -354,7 +358,7 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
             if ((f4 % 256 == 0) || idx < f4) {
               // (selects, not a branch on `tail`: control flow between the staged loads and their
               // LDS stores makes hipcc drain vmcnt at the top of every iteration)
-              const float4 v = mask4(regs[i], tail ? klen - kb - kk[i] : 4);
+              const float4 v = MASK ? mask4(regs[i], tail ? klen - kb - kk[i] : 4) : regs[i];
               put(base, scale, idx / QK, idx % QK, v);
             }
           }
@@ -366,7 +370,8 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
               float4 v[4];
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                v[r] = mask4(regs[j * 4 + r], (!tail || kb + kk[j * 4 + r] < klen) ? 4 : 0);
+                v[r] = MASK ? mask4(regs[j * 4 + r], (!tail || kb + kk[j * 4 + r] < klen) ? 4 : 0)
+                            : regs[j * 4 + r];
               }
               const int kq = u % QK, c4 = u / QK;
               put(base, scale, c4 * 4 + 0, kq, make_float4(v[0].x, v[1].x, v[2].x, v[3].x));
@@ -378,9 +383,9 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
         }
       };
       stage(As, a_scale, ra, a_k, std::integral_constant<int, AMODE>{}, std::integral_constant<int, A_PT>{},
-            std::integral_constant<int, A_F4>{}, std::integral_constant<int, A_UN>{});
+            std::integral_constant<int, A_F4>{}, std::integral_constant<int, A_UN>{}, std::true_type{});
       stage(Bs, p.b_scale, rb, b_k, std::integral_constant<int, BMODE>{}, std::integral_constant<int, B_PT>{},
-            std::integral_constant<int, B_F4>{}, std::integral_constant<int, B_UN>{});
+            std::integral_constant<int, B_F4>{}, std::integral_constant<int, B_UN>{}, std::false_type{});
       return;
     }
 #pragma unroll
