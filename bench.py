@@ -139,6 +139,9 @@ def main():
   # diagnostics only (the JSON line is marked invalid): train every step on the first
   # collated block, i.e. without the collation the real loop overlaps on its side stream
   ap.add_argument("--diag-reuse-block", action="store_true")
+  # with --diag-reuse-block: N trivial kernels per step on a side stream (what does a second busy
+  # queue cost the training chain, independent of what its kernels do?)
+  ap.add_argument("--diag-side-noise", type=int, default=0)
   # diagnostics only (marked invalid): run rank 0's share of an N-way item-parallel step on
   # this one GPU with the collectives replaced by no-ops -> the per-rank compute time at N GPUs
   ap.add_argument("--diag-virtual-world", type=int, default=0)
@@ -239,6 +242,12 @@ def main():
   def step(i):
     # the collation of the next G steps runs on the prefetcher's side stream while these train
     if args.diag_reuse_block and i >= G:
+      if args.diag_side_noise:
+        if "noise" not in cur:
+          cur["noise"] = (torch.cuda.Stream(device=device), torch.zeros(64, device=device))
+        with torch.cuda.stream(cur["noise"][0]):
+          for _ in range(args.diag_side_noise):
+            cur["noise"][1].add_(1.0)
       eng.train_step(cur["blks"][0], 0, B, out=loss_buf[i:i + 1])
       return
     c = i // G
