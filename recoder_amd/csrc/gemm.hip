@@ -1181,7 +1181,13 @@ extern "C" int rk_decode_bwd_dz(const float *dO, int32_t B, int32_t h, const rk_
   const int splits = dz_splits(B);
   const int kchunk = 0;
   // wave tile 32 x (32*TN): pick TN by h
-  const int tn = h <= 64 ? 2 : (h <= 128 ? 4 : (h <= 224 ? 7 : 8));
+  static const int tn_force = tune("RK_DZ_TN", 0);     // tuning probe
+  // split-fp16: 128-column tiles up to h = 256 (two resident workgroups per CU at 74 KB of LDS;
+  // the 224-wide tile of the fp32 path needs 101 KB here: 29 vs 31 us at C2, 52 vs 57 us on an
+  // 8-way item shard, although dO is then split once per column tile)
+  const int tn = tn_force ? tn_force
+                          : use_h3() ? (h <= 64 ? 2 : (h <= 256 ? 4 : 8))
+                                     : (h <= 64 ? 2 : (h <= 128 ? 4 : (h <= 224 ? 7 : 8)));
   p.tiles_m = rk_cdiv(B, 128);
   const int tiles = p.tiles_m * rk_cdiv(h, 32 * tn);   // x 64 splits: a multiple of 8
 #define LAUNCH(TN)                                                                              \
