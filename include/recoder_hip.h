@@ -217,6 +217,11 @@ int rk_decode_bwd_dw_encode_bwd(const float *dO, const float *Z, int32_t B, int3
 /* workspace of the call above (0: none needed; NULL is always accepted and disables the
  * split-K of large batches) */
 int64_t rk_dw_workspace_bytes(int32_t B, int32_t h, int32_t n_cap);
+/* number of K slabs the call above cuts dW into for B rows (1 = none).  With more than one,
+ * G_de == NULL leaves them unsummed in `workspace` as rk_dw_splits(B) arrays of n_cap*h floats
+ * (G_de = their sum in slab order): rk_adam_multi consumes them through g_parts / g_stride and
+ * the summing launch disappears. */
+int32_t rk_dw_splits(int32_t B);
 /* tuning probe (tools/gemm_probe.py): device buffer of 8 uint64 per workgroup of the largest
  * GEMM grid, or NULL (default) to switch it off */
 void rk_gemm_probe(unsigned long long *buffer);

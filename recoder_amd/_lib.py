@@ -115,6 +115,7 @@ SIGNATURES = {
   "rk_dw_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
   "rk_gemm_probe": (None, [_P]),
   "rk_encode_bwd_segments": (c_int32, [c_int32]),
+  "rk_dw_splits": (c_int32, [c_int32]),
   "rk_linear_fwd": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
   "rk_linear_bwd": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P,
                               c_int32, _P, _P]),

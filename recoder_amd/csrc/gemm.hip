@@ -1017,6 +1017,8 @@ extern "C" int64_t rk_dw_workspace_bytes(int32_t B, int32_t h, int32_t n_cap) {
 
 extern "C" int32_t rk_decode_row_tile(void) { return DEC_BM; }
 
+extern "C" int32_t rk_dw_splits(int32_t B) { return dw_splits(B); }
+
 extern "C" int32_t rk_loss_partials(int32_t B, int32_t n_cap) {
   // worst case over the decode tilings (64-row x 64-column tiles); MNLL uses one per row
   const int tiles = rk_cdiv(B, DEC_BM) * rk_cdiv(n_cap, 64);
@@ -1254,6 +1256,8 @@ extern "C" int rk_decode_bwd_dw_encode_bwd(const float *dO, const float *Z, int3
   RK_REQUIRE(row_off >= 0 && B >= 0 && row_off + B <= blk->S_cap, "row slice out of range");
   RK_REQUIRE(blk->bits_cr != nullptr && blk->pref_rc != nullptr,
              "block was built without the transposed bitmap / prefix index");
+  RK_REQUIRE(G_de != nullptr || (workspace != nullptr && dw_splits(B) > 1),
+             "G_de == NULL (leave the split-K slabs in the workspace) needs rk_dw_splits(B) > 1");
   if (B == 0) return 0;
   // large batches: split K (= B) so that the few dW tiles still fill the chip; the slabs go to
   // `workspace` (rk_dw_workspace_bytes) and are summed in split order by slab_sum_kernel
@@ -1284,7 +1288,7 @@ extern "C" int rk_decode_bwd_dw_encode_bwd(const float *dO, const float *Z, int3
   }
 #undef LAUNCH
   RK_CHECK_LAUNCH("decode_bwd_dw_encode_bwd");
-  if (splits > 1) {
+  if (splits > 1 && G_de != nullptr) {
     RK_LAUNCH(slab_sum_kernel, dim3(rk_cdiv((int64_t)blk->n_cap * h / 4, 256)), dim3(256), 0, stream,
               workspace, blk->n_cap, h, blk->counts, splits, G_de);
     RK_CHECK_LAUNCH("slab_sum");

@@ -115,20 +115,27 @@ static int step_item_parallel(const rk_ae_step_t *a, int phase) {
     Timer t(a, RK_ENTRY_DECODE_BWD_DZ, sm);
     RK_TRY(rk_decode_bwd_dz(a->dO, B, h, blk, W_de, nullptr, RK_ACT_NONE, a->dZ0, a->ws, sm));
   }
+  const int dw_slabs = (a->tied || mnll || a->ws == nullptr) ? 1 : rk_dw_splits(B);
   if (phase & RK_STEP_IP_TAIL) {
     RK_TRY(rk_act_grad(a->dZ0, a->Z0, (int64_t)B * h, a->act, sm));
     if (a->tied || mnll) {
       RK_TRY(rk_decode_bwd_dw(a->dO, a->Z0, B, h, blk, a->G_de, mnll ? a->gb_de : nullptr, sm));
       RK_TRY(rk_ae_encode_bwd(blk, a->row_off, B, a->dZ0, h, G_en, a->tied ? 1 : 0, a->gb_en, sm));
     } else {
+      // large global batches: dW comes out as K slabs; rk_adam_multi sums them in slab order
+      // while it reads the gradient (g_parts), so the separate summing launch is skipped
       Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
-      RK_TRY(rk_decode_bwd_dw_encode_bwd(a->dO, a->Z0, B, h, blk, a->G_de, a->row_off, a->dZ0, G_en,
-                                         a->gb_en, a->ws, sm));
+      RK_TRY(rk_decode_bwd_dw_encode_bwd(a->dO, a->Z0, B, h, blk, dw_slabs > 1 ? nullptr : a->G_de,
+                                         a->row_off, a->dZ0, G_en, a->gb_en, a->ws, sm));
     }
     rk_adam_job_t jobs[4];
     int n = 0;
     jobs[n++] = table_job(a->par[RK_PAR_W_EN], blk, n_items, h, G_en, true);
-    if (!a->tied) jobs[n++] = table_job(a->par[RK_PAR_W_DE], blk, n_items, h, a->G_de, true);
+    if (!a->tied) {
+      jobs[n] = table_job(a->par[RK_PAR_W_DE], blk, n_items, h, a->G_de, true);
+      if (dw_slabs > 1) { jobs[n].g = a->ws; jobs[n].g_parts = dw_slabs; jobs[n].g_stride = blk->n_cap * h; }
+      ++n;
+    }
     jobs[n] = table_job(a->par[RK_PAR_B_DE], blk, n_items, 1, a->gb_de, true);
     jobs[n].par.sparse = 0; jobs[n].rows = nullptr; jobs[n].n_dev = nullptr; jobs[n].pos = blk->pos;
     if (!mnll) {

@@ -46,7 +46,7 @@ class TimedLib:
 
   def __getattr__(self, name):
     fn = getattr(self._lib, name)
-    if not name.startswith("rk_") or name in ("rk_dz_workspace_bytes", "rk_dw_workspace_bytes", "rk_encode_bwd_segments", "rk_loss_partials", "rk_decode_row_tile",
+    if not name.startswith("rk_") or name in ("rk_dz_workspace_bytes", "rk_dw_workspace_bytes", "rk_dw_splits", "rk_encode_bwd_segments", "rk_loss_partials", "rk_decode_row_tile",
                                               "rk_last_error", "rk_version"):
       return fn
 
