@@ -83,9 +83,10 @@ rk_adam_job_t table_job(const rk_adam_param_t &par, const rk_block_t *blk, int n
 // items; three segments with an all-reduce (SUM) of a [B, h] matrix between them:
 //   IP_ENC : Z0 = partial encoder sums over the local items (whole-row norms)
 //   -- all-reduce Z0 --
-//   IP_MID : Z0 = act(Z0 + b_en) ; decode + loss over the local items ; dZ0 = dO . W_de (raw)
+//   IP_MID : Z0 = act(Z0 + b_en) ; decode + loss over the local items ;
+//            dZ0 = (dO . W_de) * act'(Z0)   (this rank's share of the pre-activation gradient)
 //   -- all-reduce dZ0 --
-//   IP_TAIL: dZ0 *= act'(Z0) ; dW || encoder backward ; Adam on the OWNED rows (+ b_en, which is
+//   IP_TAIL: dW || encoder backward ; Adam on the OWNED rows (+ b_en, which is
 //            replicated: every rank computes the identical update) ; local loss partial
 static int step_item_parallel(const rk_ae_step_t *a, int phase) {
   const rk_block_t *blk = a->blk;
@@ -112,12 +113,14 @@ static int step_item_parallel(const rk_ae_step_t *a, int phase) {
                             a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, sm));
       if (mnll) RK_TRY(rk_mnll_finish(a->dO, B, blk, a->row_off, a->inv_B, a->loss_part, sm));
     }
+    // act'(Z0) is applied to this rank's PARTIAL dZ0 here, inside the split-K reduce: Z0 is the
+    // same on every rank, so sum_ranks(dZ0_r) * act'(Z0) = sum_ranks(dZ0_r * act'(Z0)) and the
+    // element-wise launch after the all-reduce disappears
     Timer t(a, RK_ENTRY_DECODE_BWD_DZ, sm);
-    RK_TRY(rk_decode_bwd_dz(a->dO, B, h, blk, W_de, nullptr, RK_ACT_NONE, a->dZ0, a->ws, sm));
+    RK_TRY(rk_decode_bwd_dz(a->dO, B, h, blk, W_de, a->Z0, a->act, a->dZ0, a->ws, sm));
   }
   const int dw_slabs = (a->tied || mnll || a->ws == nullptr) ? 1 : rk_dw_splits(B);
   if (phase & RK_STEP_IP_TAIL) {
-    RK_TRY(rk_act_grad(a->dZ0, a->Z0, (int64_t)B * h, a->act, sm));
     if (a->tied || mnll) {
       RK_TRY(rk_decode_bwd_dw(a->dO, a->Z0, B, h, blk, a->G_de, mnll ? a->gb_de : nullptr, sm));
       RK_TRY(rk_ae_encode_bwd(blk, a->row_off, B, a->dZ0, h, G_en, a->tied ? 1 : 0, a->gb_en, sm));
