@@ -1059,10 +1059,12 @@ extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_blo
     RK_REQUIRE(tgt->implicit || tgt->pref_rc != nullptr, "explicit values need pref_rc");
     p.ld_dev = tgt->counts + 2;
     if (use_h3()) {
+      // 64 x 128 tiles; RK_DEC_CFG = 2 / 4 are the 64 x 64 / 128 x 128 tuning probes (C2: 0.146 /
+      // 0.160 / 0.153 ms per step, 8-way item shard 0.223 / 0.249 / 0.238)
       static const int cfg = tune("RK_DEC_CFG", 0);
       const bool mse = (loss_kind == RK_LOSS_MSE);
-      const int bm = (cfg == 4 || cfg == 5) ? 128 : 64;
-      const int bn = (cfg == 1 || cfg == 5) ? 256 : (cfg == 2 ? 64 : 128);
+      const int bm = cfg == 4 ? 128 : 64;
+      const int bn = cfg == 2 ? 64 : 128;
       p.tiles_m = rk_cdiv(B, bm);
       const int g = rk_cdiv(p.tiles_m * rk_cdiv(tgt->n_cap, bn), 8) * 8;
 #define LAUNCH(TM, TN, BKK)                                                                      \
@@ -1074,9 +1076,7 @@ extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_blo
       RK_LAUNCH((gemm_kernel<2, 2, TM, TN, 0, 0, EPI_LOSS_BCE, true, BKK, PREC_H3>), dim3(g, 1), \
                 dim3(256), 0, stream, p);                                                        \
   } while (0)
-      if (cfg == 1) LAUNCH(1, 4, 32); else if (cfg == 2) LAUNCH(1, 1, 32);
-      else if (cfg == 4) LAUNCH(2, 2, 32); else if (cfg == 5) LAUNCH(2, 4, 32);
-      else LAUNCH(1, 2, 32);
+      if (cfg == 2) LAUNCH(1, 1, 32); else if (cfg == 4) LAUNCH(2, 2, 32); else LAUNCH(1, 2, 32);
 #undef LAUNCH
       RK_CHECK_LAUNCH("decode_loss");
       return 0;
