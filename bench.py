@@ -280,7 +280,10 @@ def main():
     # the production path issues all Adam updates as one rk_adam_multi launch
     upd = ("rk_adam_table", "rk_adam_dense", "rk_adam_rows")
     n_prof = max(1, half - 1)
-    timed["rk_adam_multi"] = (n_prof, sum(prof[k][0] * prof[k][1] for k in upd if k in prof) / n_prof)
+    if any(k in prof for k in upd):     # (the per-entry sequencing batches them into rk_adam_multi too)
+      extra = sum(prof[k][0] * prof[k][1] for k in upd if k in prof)
+      have = timed.get("rk_adam_multi", (0, 0.0))
+      timed["rk_adam_multi"] = (n_prof, (have[0] * have[1] + extra) / n_prof)
     dominant = max(timed, key=lambda k: timed[k][0] * timed[k][1]) if timed else "rk_decode_loss"
   else:
     # item shards only run the one-call step; its Adam sweep covers 1/world of the tables, the

@@ -95,6 +95,7 @@ class FusedEngine:
     self.seed = 0x5eed
     self.rng_step = 0
     self.states = {}                       # name -> ParamState
+    self._jobs = []                        # rk_adam_job_t records of the step being assembled
     self.world_size = 1
     self.allreduce = None                  # callable(list of tensors) for data parallel
     self.use_c_step = True                 # one-FFI-call step driver (rk_ae_train_step)
@@ -199,23 +200,45 @@ class FusedEngine:
     b1, b2 = g["betas"]
     return float(g["lr"]), float(b1), float(b2), float(g["eps"])
 
-  def _adam_table(self, s, pos, G, h, n_rows, stream):
+  # The updates of one step are collected as rk_adam_job_t records and issued through
+  # rk_adam_multi, six per launch (the same per-element arithmetic as rk_adam_table / rk_adam_rows /
+  # rk_adam_dense; a hidden-stack model has ~11 parameter tensors, i.e. ~11 launches and FFI calls
+  # otherwise).  Index arrays that are int64 (MF user rows) go through rk_adam_rows directly.
+  def _job(self, s, n_rows, h, g, pos=None, rows=None, n_dev=None, n_cap=0):
+    from ._lib import RkAdamJob
     s.step += 1
     lr, b1, b2, eps = self._adam_args(s)
-    check(self.lib.rk_adam_table(ptr(s.p), ptr(s.m), ptr(s.v), n_rows, h, ptr(pos), ptr(G), lr, b1,
-                                 b2, eps, float(s.wd), s.step, stream), "rk_adam_table")
+    j = RkAdamJob()
+    a = j.par
+    a.p, a.m, a.v = ptr(s.p), ptr(s.m), ptr(s.v)
+    a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = lr, b1, b2, eps, float(s.wd)
+    a.step, a.sparse = s.step, 1 if rows is not None else 0
+    j.n_rows, j.h, j.g, j.g_parts = n_rows, h, ptr(g), 1
+    j.pos, j.rows, j.n_dev, j.n_cap = ptr(pos), ptr(rows), ptr(n_dev), n_cap
+    self._jobs.append(j)
+
+  def _flush_jobs(self, stream):
+    from ._lib import RkAdamJob
+    jobs, self._jobs = self._jobs, []
+    for i in range(0, len(jobs), 6):
+      chunk = jobs[i:i + 6]
+      arr = (RkAdamJob * len(chunk))(*chunk)
+      check(self.lib.rk_adam_multi(arr, len(chunk), None, 0, 1.0, None, stream), "rk_adam_multi")
+
+  def _adam_table(self, s, pos, G, h, n_rows, stream):
+    self._job(s, n_rows, h, G, pos=pos)
 
   def _adam_rows(self, s, idx32, idx64, n_dev, n_cap, G, h, stream):
+    if idx32 is not None and n_dev is not None:
+      self._job(s, 0, h, G, rows=idx32, n_dev=n_dev, n_cap=n_cap)
+      return
     s.step += 1
     lr, b1, b2, eps = self._adam_args(s)
     check(self.lib.rk_adam_rows(ptr(s.p), ptr(s.m), ptr(s.v), h, ptr(idx32), ptr(idx64), ptr(n_dev),
                                 n_cap, ptr(G), lr, b1, b2, eps, s.step, stream), "rk_adam_rows")
 
   def _adam_dense(self, s, g, stream):
-    s.step += 1
-    lr, b1, b2, eps = self._adam_args(s)
-    check(self.lib.rk_adam_dense(ptr(s.p), ptr(s.m), ptr(s.v), ptr(g), s.p.numel(), lr, b1, b2,
-                                 eps, float(s.wd), s.step, stream), "rk_adam_dense")
+    self._job(s, 1, s.p.numel(), g)
 
   # --------------------------------------------------------------- forward
   def _ae_forward(self, blk, row_off, B, keep_noise, keep_drop, train, stream):
@@ -672,10 +695,16 @@ class FusedEngine:
         else:
           check(lib.rk_scatter_pos(ptr(self.pos_u), ptr(users), B, 0, stream), "rk_scatter_pos")
           self._adam_table(su, self.pos_u, self.dbott, h0, m.num_users, stream)
+          if dec:
+            table("item_embedding_layer.weight", self.G_de)
+            self._adam_table(S["bias"], blk.pos, self.gb_de, 1, n_items, stream)
+            dec = False
+          self._flush_jobs(stream)       # before the user-row map is cleared again
           check(lib.rk_scatter_pos(ptr(self.pos_u), ptr(users), B, 1, stream), "rk_scatter_pos")
       if dec:
         table("item_embedding_layer.weight", self.G_de)
         self._adam_table(S["bias"], blk.pos, self.gb_de, 1, n_items, stream)
+    self._flush_jobs(stream)
 
   # ------------------------------------------------------------- inference
   def predict_scores(self, blk, row_off, B, out, ld_out, tgt_items_blk):
