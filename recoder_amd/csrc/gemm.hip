@@ -974,6 +974,8 @@ inline int dw_splits(int B) {
 }
 
 inline int dz_splits(int B) {
+  static const int force = getenv("RK_DZ_SPLITS") ? atoi(getenv("RK_DZ_SPLITS")) : 0;   // tuning probe
+  if (force > 0) return force;
   const int tiles_m = rk_cdiv(B, 128);
   int s = (512 / tiles_m) & ~7;
   return s < 8 ? 8 : (s > DZ_SPLITS ? DZ_SPLITS : s);
