@@ -129,3 +129,35 @@ def test_fp32_mfma_fallback_keeps_golden_parity():
                      cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
   assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
   assert " passed" in r.stdout and "no tests ran" not in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.parametrize("loss_name", ["mse", "bce", "mnll"])
+def test_loss_kernels_publish_max_gradient(loss_name):
+  """rk_decode_loss (MSE / BCE epilogue) and rk_mnll_finish publish max |dLoss/dLogit| into
+  rk_block_t.counts[8..71] (fp32 bit patterns); rk_collate resets the slots."""
+  from recoder_amd import _lib
+  from recoder_amd._lib import LOSS_BCE, LOSS_MNLL, LOSS_MSE, check, ptr
+  from recoder_amd.device import current_stream
+  lib = _lib.load()
+  dev = torch.device("cuda")
+  B, h, n_t, n_items = 200, 64, 700, 3000
+  blk, items = _block(B, n_items, n_t, dev, seed=9)
+  assert int(blk.counts[8:72].abs().max()) == 0          # fresh from rk_collate
+  g = torch.Generator(device="cpu").manual_seed(3)
+  Z = torch.tanh(torch.randn(B, h, generator=g)).to(dev)
+  W = (torch.randn(n_items, h, generator=g) * 0.2).to(dev)
+  b = (torch.randn(n_items, generator=g) * 0.1).to(dev)
+  ld = blk.counts_host()[2]
+  dO = torch.zeros(B * blk.ld_cap, device=dev)
+  part = torch.zeros(lib.rk_loss_partials(B, blk.n_cap), device=dev)
+  kind = {"mse": LOSS_MSE, "bce": LOSS_BCE, "mnll": LOSS_MNLL}[loss_name]
+  st = current_stream()
+  check(lib.rk_decode_loss(ptr(Z), B, h, blk.ref, 0, ptr(W), ptr(b), kind, 0.5, 1.0 / B, ptr(dO), 0,
+                           ptr(part), None, st), "rk_decode_loss")
+  if loss_name == "mnll":
+    check(lib.rk_mnll_finish(ptr(dO), B, blk.ref, 0, 1.0 / B, ptr(part), st), "rk_mnll_finish")
+  torch.cuda.synchronize()
+  want = dO[:B * ld].view(B, ld)[:, :n_t].abs().max().cpu().numpy().astype(np.float32)
+  slots = blk.counts[8:72].cpu().numpy().astype(np.int32).view(np.float32)
+  assert slots.max() == want, (slots.max(), want)
+  assert want > 0
