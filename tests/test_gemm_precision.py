@@ -161,3 +161,26 @@ def test_loss_kernels_publish_max_gradient(loss_name):
   slots = blk.counts[8:72].cpu().numpy().astype(np.int32).view(np.float32)
   assert slots.max() == want, (slots.max(), want)
   assert want > 0
+
+
+def test_dw_slabs_contract():
+  """rk_dw_splits / G_de == NULL: leaving the dW split-K slabs unsummed is only valid when the call
+  cuts K at all; otherwise the entry point refuses (error code + message, nothing launched)."""
+  from recoder_amd import _lib
+  from recoder_amd._lib import ptr
+  from recoder_amd.device import current_stream
+  lib = _lib.load()
+  dev = torch.device("cuda")
+  assert lib.rk_dw_splits(500) == 1 and lib.rk_dw_splits(4000) > 1
+  B, h, n_t, n_items = 200, 64, 300, 2000
+  blk, _ = _block(B, n_items, n_t, dev, seed=4)
+  f = dict(dtype=torch.float32, device=dev)
+  dO = torch.zeros(B * blk.ld_cap, **f)
+  Z = torch.zeros(B * h, **f)
+  dZ = torch.zeros(B * h, **f)
+  G_en = torch.zeros(blk.n_cap * h, **f)
+  ws = torch.zeros(max(4, lib.rk_dw_workspace_bytes(B, h, blk.n_cap) // 4), **f)
+  rc = lib.rk_decode_bwd_dw_encode_bwd(ptr(dO), ptr(Z), B, h, blk.ref, None, 0, ptr(dZ), ptr(G_en), None,
+                                       ptr(ws), current_stream())
+  assert rc < 0
+  assert b"rk_dw_splits" in lib.rk_last_error()
