@@ -225,6 +225,35 @@ int32_t rk_dw_splits(int32_t B);
 /* tuning probe (tools/gemm_probe.py): device buffer of 8 uint64 per workgroup of the largest
  * GEMM grid, or NULL (default) to switch it off */
 void rk_gemm_probe(unsigned long long *buffer);
+/*
+ * rk_decode_bwd_dw3 -- the same contraction G_de[n_t,h] = dO^T . Z (autograd of F.linear,
+ * nn.py:280) on the 16-bit matrix pipe at fp32 accuracy and with no operand range: every fp32
+ * operand is cut into three bf16 pieces (x = hi + mid + lo exactly), six products per pair are
+ * accumulated in fp32 (csrc/dw3.hip).  dO tiles reach LDS by DMA; Z is split once per call into
+ * k-contiguous bf16 planes (rk_split_planes_t) at the head of `workspace`.
+ *   workspace : rk_dw3_workspace_bytes(B, h, tgt->n_cap) bytes, 256-byte aligned
+ *   G_de      : nullable.  The contraction is cut along K into counts[4] slabs (chosen on the
+ *               device from the live item count, <= rk_dw3_max_splits()); G_de != NULL receives
+ *               their sum, G_de == NULL leaves them at rk_dw3_slabs(workspace, B, h) as arrays of
+ *               n_cap*h floats for rk_adam_multi (rk_adam_job_t.gparts_dev = counts + 4).
+ */
+int64_t rk_dw3_workspace_bytes(int32_t B, int32_t h, int32_t n_cap);
+int32_t rk_dw3_max_splits(void);
+/* tuning probe: device buffer of 16 uint64 per workgroup (wall-clock stamps of the k-loop), or
+ * NULL (default) to switch it off */
+void rk_dw3_probe(unsigned long long *buffer);
+const float *rk_dw3_slabs(const void *workspace, int32_t B, int32_t h);
+int rk_decode_bwd_dw3(const float *dO, const float *Z, int32_t B, int32_t h,
+                      const rk_block_t *tgt, float *G_de, float *gb_de, void *workspace,
+                      void *stream);
+/* X[rows, cols] fp32 (leading dimension ld) -> three bf16 planes of X^T in the k-contiguous
+ * order the kernel above stages: element (k = row, n = col) of plane p at
+ * p*rows_pad*cols_pad + ((k/8)*cols_pad + n)*8 + k%8; the padding is written as zeros. */
+int rk_split_planes_t(const float *X, int32_t rows, int32_t cols, int32_t ld,
+                      int32_t rows_pad, int32_t cols_pad, void *planes, void *stream);
+/* != 0: the decoder contractions run on the 16-bit matrix pipe (default); RK_GEMM_PREC=f32 in
+ * the environment keeps all of them on the fp32 MFMA */
+int32_t rk_gemm_split16(void);
 /* The fused call writes G_en as rk_encode_bwd_segments(B) partial arrays of n_cap*h floats
  * each (row segments of long item columns; 1 below 513 rows) and gb_en as as many partial
  * vectors of h floats: the gradients are their sums in segment order -- rk_adam_multi
@@ -338,6 +367,9 @@ typedef struct rk_adam_job {
   int32_t row0, row_step;      /* dense jobs: only rows row0, row0 + row_step, ... are updated
                                   (item-parallel ownership: item i lives on rank i % N);
                                   row_step 0 = 1 */
+  const int32_t *gparts_dev;   /* nullable: the number of gradient parts is read from the device
+                                  (rk_decode_bwd_dw3 publishes its slab count in counts[4]);
+                                  g_parts is then the capacity */
 } rk_adam_job_t;
 
 int rk_adam_multi(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part,

@@ -77,6 +77,7 @@ class RkAdamJob(Structure):
     ("n_cap", c_int32), ("g_parts", c_int32), ("g_stride", c_int32),
     ("gstride_dev", c_void_p), ("g", c_void_p),
     ("row0", c_int32), ("row_step", c_int32),
+    ("gparts_dev", c_void_p),
   ]
 
 
@@ -113,6 +114,13 @@ SIGNATURES = {
   "rk_decode_bwd_dw_encode_bwd": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, c_int32, _P, _P, _P, _P,
                                             _P]),
   "rk_dw_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
+  "rk_dw3_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
+  "rk_dw3_max_splits": (c_int32, []),
+  "rk_dw3_probe": (None, [_P]),
+  "rk_dw3_slabs": (c_void_p, [_P, c_int32, c_int32]),
+  "rk_decode_bwd_dw3": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, _P]),
+  "rk_split_planes_t": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
+  "rk_gemm_split16": (c_int32, []),
   "rk_gemm_probe": (None, [_P]),
   "rk_encode_bwd_segments": (c_int32, [c_int32]),
   "rk_dw_splits": (c_int32, [c_int32]),

@@ -1000,6 +1000,8 @@ inline int tune(const char *name, int dflt) {
 
 extern "C" void rk_gemm_probe(unsigned long long *buffer) { g_gemm_probe = buffer; }
 
+extern "C" int32_t rk_gemm_split16(void) { return use_h3() ? 1 : 0; }
+
 extern "C" int64_t rk_dz_workspace_bytes(int32_t B, int32_t h) {
   return (int64_t)dz_splits(B) * B * h * sizeof(float);
 }

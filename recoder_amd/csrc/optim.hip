@@ -193,6 +193,7 @@ struct UJob {
   const int32_t *rows;         // SparseAdam: compact row -> table row
   const int32_t *n_dev;        // SparseAdam: live compact rows
   const int32_t *gstride_dev;  // device-resident stride between gradient parts (or null)
+  const int32_t *gparts_dev;   // device-resident number of gradient parts (or null: g_parts)
   int n_rows, h, g_parts, g_stride, sparse, blk0, nblk;
   int row0, row_step;          // the job covers rows row0, row0 + row_step, ... (owned rows)
   AdamC c;
@@ -240,6 +241,7 @@ __device__ __forceinline__ void update_job(const UJob &J, int lb) {
   using V = VecOps<T>;
   const int hq = J.h / V::W;
   const int64_t stride = J.gstride_dev ? (int64_t)*J.gstride_dev : (int64_t)J.g_stride;
+  const int g_parts = J.gparts_dev ? min(*J.gparts_dev, J.g_parts) : J.g_parts;
   T *P = reinterpret_cast<T *>(J.p), *M = reinterpret_cast<T *>(J.m), *Vv = reinterpret_cast<T *>(J.v);
   const int64_t step = (int64_t)J.nblk * 256;
   if (J.sparse) {
@@ -249,7 +251,7 @@ __device__ __forceinline__ void update_job(const UJob &J, int lb) {
       const int r = (int)(i / hq), q = (int)(i % hq);
       const int64_t o = (int64_t)J.rows[r] * hq + q;
       T g = *reinterpret_cast<const T *>(J.g + i * V::W);
-      for (int t = 1; t < J.g_parts; ++t)
+      for (int t = 1; t < g_parts; ++t)
         V::add(g, *reinterpret_cast<const T *>(J.g + t * stride + i * V::W));
       T p1 = P[o], m1 = M[o], v1 = Vv[o];
       V::sadam(p1, m1, v1, g, J.c);
@@ -278,14 +280,14 @@ __device__ __forceinline__ void update_job(const UJob &J, int lb) {
     if (have) {
       g = *reinterpret_cast<const T *>(J.g + go);
       int t = 1;
-      for (; t + 8 <= J.g_parts; t += 8) {           // partial gradients, fixed order; the
+      for (; t + 8 <= g_parts; t += 8) {           // partial gradients, fixed order; the
         T v[8];                                      // loads of a group are independent
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const T *>(J.g + (t + u) * stride + go);
 #pragma unroll
         for (int u = 0; u < 8; ++u) V::add(g, v[u]);
       }
-      for (; t < J.g_parts; ++t)
+      for (; t < g_parts; ++t)
         V::add(g, *reinterpret_cast<const T *>(J.g + t * stride + go));
     }
     T p1 = P[e], m1 = M[e], v1 = Vv[e];
@@ -441,7 +443,7 @@ extern "C" int rk_adam_multi(const rk_adam_job_t *jobs, int32_t n_jobs, float *l
     if (rows == 0) continue;
     d.p = s.par.p; d.m = s.par.m; d.v = s.par.v; d.g = s.g;
     d.pos = s.par.sparse ? nullptr : s.pos;
-    d.rows = s.rows; d.n_dev = s.n_dev; d.gstride_dev = s.gstride_dev;
+    d.rows = s.rows; d.n_dev = s.n_dev; d.gstride_dev = s.gstride_dev; d.gparts_dev = s.gparts_dev;
     d.n_rows = s.n_rows; d.h = s.h; d.g_parts = s.g_parts; d.g_stride = s.g_stride;
     d.sparse = s.par.sparse ? 1 : 0;
     d.row0 = s.row0; d.row_step = row_step;

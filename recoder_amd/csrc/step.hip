@@ -70,6 +70,15 @@ rk_adam_job_t table_job(const rk_adam_param_t &par, const rk_block_t *blk, int n
   return j;
 }
 
+// dW = dO^T . Z: the bf16-pipe kernel (dw3.hip) when the split contractions are on and the step
+// has a workspace, else the fp32-MFMA tiles.  G_de == NULL (dw3 only): the K slabs stay in the
+// workspace for rk_adam_multi.
+int dw_call(const rk_ae_step_t *a, float *G_de, float *gb_de) {
+  if (rk_gemm_split16() && a->ws)
+    return rk_decode_bwd_dw3(a->dO, a->Z0, a->B, a->h, a->blk, G_de, gb_de, a->ws, a->stream);
+  return rk_decode_bwd_dw(a->dO, a->Z0, a->B, a->h, a->blk, G_de, gb_de, a->stream);
+}
+
 }  // namespace
 
 #define RK_TRY(call)          \
@@ -122,7 +131,7 @@ static int step_item_parallel(const rk_ae_step_t *a, int phase) {
   const int dw_slabs = (a->tied || mnll || a->ws == nullptr) ? 1 : rk_dw_splits(B);
   if (phase & RK_STEP_IP_TAIL) {
     if (a->tied || mnll) {
-      RK_TRY(rk_decode_bwd_dw(a->dO, a->Z0, B, h, blk, a->G_de, mnll ? a->gb_de : nullptr, sm));
+      RK_TRY(dw_call(a, a->G_de, mnll ? a->gb_de : nullptr));
       RK_TRY(rk_ae_encode_bwd(blk, a->row_off, B, a->dZ0, h, G_en, a->tied ? 1 : 0, a->gb_en, sm));
     } else {
       // large global batches: dW comes out as K slabs; rk_adam_multi sums them in slab order
@@ -181,6 +190,9 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   const float *W_de = a->tied ? a->par[RK_PAR_W_EN].p : a->par[RK_PAR_W_DE].p;
   float *G_en = a->tied ? a->G_de : a->G_en;
   const int n_part = mnll ? B : rk_loss_partials(B, blk->n_cap);   // unused slots hold 0
+  // whole untied MSE / BCE steps on the 16-bit pipe: dW as its own bf16-pipe launch (slabs summed
+  // by the Adam sweep) + the plain encoder backward; otherwise the fused fp32 dW || encoder launch
+  const bool dw3 = whole && !(a->tied || mnll) && rk_gemm_split16() && a->ws != nullptr;
 
   if (phase & RK_STEP_FWD_DW) {
     {
@@ -199,7 +211,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     // fused with the encoder backward below
     if (a->tied || mnll || !whole) {
       Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
-      RK_TRY(rk_decode_bwd_dw(a->dO, a->Z0, B, h, blk, a->G_de, mnll ? a->gb_de : nullptr, sm));
+      RK_TRY(dw_call(a, a->G_de, mnll ? a->gb_de : nullptr));
     }
     if (!whole) {
       // the data-parallel exchange needs gb_de and the loss scalar as arrays of their own
@@ -215,6 +227,15 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     if (a->tied || mnll || !whole) {
       Timer t(a, RK_ENTRY_ENCODE_BWD, sm);
       RK_TRY(rk_ae_encode_bwd(blk, a->row_off, B, a->dZ0, h, G_en, a->tied ? 1 : 0, a->gb_en, sm));
+    } else if (dw3) {
+      // the dZ slabs in the workspace are consumed: the bf16-pipe dW takes it over (Z^T planes +
+      // its own K slabs, which rk_adam_multi sums while it reads the gradient)
+      {
+        Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
+        RK_TRY(dw_call(a, nullptr, nullptr));
+      }
+      Timer t(a, RK_ENTRY_ENCODE_BWD, sm);
+      RK_TRY(rk_ae_encode_bwd(blk, a->row_off, B, a->dZ0, h, G_en, 0, a->gb_en, sm));
     } else {
       Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
       RK_TRY(rk_decode_bwd_dw_encode_bwd(a->dO, a->Z0, B, h, blk, a->G_de, a->row_off, a->dZ0, G_en,
@@ -225,10 +246,17 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     rk_adam_job_t jobs[4];
     int n = 0;
     jobs[n++] = table_job(a->par[RK_PAR_W_EN], blk, n_items, h, G_en, true);
-    if (whole && !(a->tied || mnll)) {   // the fused launch wrote G_en in row segments
+    if (whole && !(a->tied || mnll) && !dw3) {   // the fused launch wrote G_en in row segments
       jobs[0].g_parts = rk_encode_bwd_segments(B); jobs[0].g_stride = blk->n_cap * h;
     }
-    if (!a->tied) jobs[n++] = table_job(a->par[RK_PAR_W_DE], blk, n_items, h, a->G_de, true);
+    if (!a->tied) {
+      jobs[n] = table_job(a->par[RK_PAR_W_DE], blk, n_items, h, a->G_de, true);
+      if (dw3) {
+        jobs[n].g = rk_dw3_slabs(a->ws, B, h); jobs[n].g_parts = rk_dw3_max_splits();
+        jobs[n].g_stride = blk->n_cap * h; jobs[n].gparts_dev = blk->counts + 4;
+      }
+      ++n;
+    }
     jobs[n] = table_job(a->par[RK_PAR_B_DE], blk, n_items, 1, a->gb_de, true);
     jobs[n].par.sparse = 0; jobs[n].rows = nullptr; jobs[n].n_dev = nullptr; jobs[n].pos = blk->pos;
     if (whole && !mnll) {          // straight from the decode epilogue's row-tile partials
@@ -236,7 +264,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     }
     ++n;
     jobs[n] = table_job(a->par[RK_PAR_B_EN], blk, 1, h, a->gb_en, false);
-    if (whole && !(a->tied || mnll)) {
+    if (whole && !(a->tied || mnll) && !dw3) {
       jobs[n].g_parts = rk_encode_bwd_segments(B); jobs[n].g_stride = h;
     }
     ++n;

@@ -49,21 +49,83 @@ def canonical_csr(m):
 
 
 class DeviceCSR:
+  """The interaction matrix in HBM: int64 indptr, int32 indices, fp32 data (elided when every
+  value is 1.0).  Built from a scipy matrix (canonicalised on the host), from arrays that are
+  already canonical (``from_arrays``: nothing but the upload happens on the host -- .npz files,
+  shards of a large matrix) or generated on the device (recoder_amd.synthetic)."""
+
   def __init__(self, matrix, device=None):
     device = device or require_gpu()
     m = canonical_csr(matrix)
-    self.shape = m.shape
-    self.nnz = int(m.nnz)
-    self.degrees = np.diff(m.indptr).astype(np.int64)
+    self._init_arrays(m.shape, torch.from_numpy(m.indptr.astype(np.int64)),
+                      torch.from_numpy(m.indices.astype(np.int32)),
+                      torch.from_numpy(m.data.astype(np.float32)), device)
+
+  def _init_arrays(self, shape, indptr, indices, data, device):
+    self.shape = (int(shape[0]), int(shape[1]))
     self.device = device
-    self.indptr = torch.from_numpy(m.indptr.astype(np.int64)).to(device)
-    self.indices = torch.from_numpy(m.indices.astype(np.int32)).to(device)
-    data = m.data.astype(np.float32)
-    self.implicit = bool(self.nnz == 0 or np.all(data == 1.0))
+    self.indptr = indptr.to(device=device, dtype=torch.int64).contiguous()
+    self.nnz = int(self.indptr[-1].item()) if self.indptr.numel() else 0
+    self.degrees = (self.indptr[1:] - self.indptr[:-1]).cpu().numpy().astype(np.int64)
+    self.indices = indices.to(device=device, dtype=torch.int32).contiguous()
+    if data is not None:
+      data = data.to(device=device, dtype=torch.float32).contiguous()
+    self.implicit = bool(self.nnz == 0 or data is None or bool((data == 1.0).all().item()))
     # implicit-feedback matrices (all values 1.0) elide the value stream
-    self.data = None if self.implicit else torch.from_numpy(data).to(device)
+    self.data = None if self.implicit else data
     if self.nnz == 0:
       self.indices = torch.zeros(1, dtype=torch.int32, device=device)
+
+  @classmethod
+  def from_arrays(cls, shape, indptr, indices, data=None, device=None, check=True):
+    """CSR arrays (numpy or torch, host or device) that are ALREADY canonical: column indices
+    strictly ascending inside every row, no explicit zeros.  ``check`` verifies that on the
+    device (one pass of element-wise kernels) and raises ValueError otherwise."""
+    device = device or require_gpu()
+    as_t = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
+    self = cls.__new__(cls)
+    self._init_arrays(shape, as_t(indptr), as_t(indices), None if data is None else as_t(data), device)
+    if check and self.nnz:
+      if int(self.indptr[0].item()) != 0 or self.indptr.numel() != self.shape[0] + 1:
+        raise ValueError("indptr must start at 0 and have n_rows + 1 entries")
+      idx = self.indices[:self.nnz].to(torch.int64)
+      if int(idx.min().item()) < 0 or int(idx.max().item()) >= self.shape[1]:
+        raise ValueError("column index out of range")
+      # ascending inside a row <=> idx[j] > idx[j-1] wherever j is not a row start
+      is_start = torch.zeros(self.nnz + 1, dtype=torch.bool, device=device)
+      is_start[self.indptr.clamp(max=self.nnz)] = True
+      bad = (idx[1:] <= idx[:-1]) & ~is_start[1:self.nnz]
+      if bool(bad.any().item()):
+        raise ValueError("column indices must be strictly ascending inside each row "
+                         "(sorted, no duplicates); pass the matrix itself to DeviceCSR(...) instead")
+      if self.data is not None and bool((self.data[:self.nnz] == 0).any().item()):
+        raise ValueError("explicit zeros are not allowed")
+    return self
+
+  @classmethod
+  def from_npz(cls, path, device=None):
+    """A matrix saved with ``scipy.sparse.save_npz`` (what the reference's preprocessing scripts
+    write, scripts/*/preprocess.py) straight into HBM; canonical CSR files skip the host-side
+    copy + sort of ``DeviceCSR(matrix)``, anything else falls back to it."""
+    with np.load(path, allow_pickle=False) as z:
+      fmt = z["format"].item()
+      fmt = fmt.decode() if isinstance(fmt, bytes) else str(fmt)
+      if fmt == "csr":
+        try:
+          return cls.from_arrays(tuple(z["shape"]), z["indptr"], z["indices"], z["data"], device)
+        except ValueError:
+          pass
+    return cls(sp.load_npz(path), device)
+
+  def row_slice(self, lo, hi):
+    """Rows [lo, hi) as a DeviceCSR of its own (device-side copy; data-parallel shards)."""
+    lo, hi = int(lo), int(hi)
+    a, b = int(self.indptr[lo].item()), int(self.indptr[hi].item())
+    out = DeviceCSR.__new__(DeviceCSR)
+    out._init_arrays((hi - lo, self.shape[1]), self.indptr[lo:hi + 1] - a, self.indices[a:max(b, a + 1)]
+                     if b > a else torch.zeros(1, dtype=torch.int32, device=self.device),
+                     None if self.data is None else self.data[a:b], self.device)
+    return out
 
   @property
   def n_items(self):

@@ -47,6 +47,7 @@ class TimedLib:
   def __getattr__(self, name):
     fn = getattr(self._lib, name)
     if not name.startswith("rk_") or name in ("rk_dz_workspace_bytes", "rk_dw_workspace_bytes", "rk_dw_splits", "rk_encode_bwd_segments", "rk_loss_partials", "rk_decode_row_tile",
+                                              "rk_dw3_workspace_bytes", "rk_dw3_max_splits", "rk_dw3_slabs", "rk_gemm_split16",
                                               "rk_last_error", "rk_version"):
       return fn
 
@@ -99,8 +100,10 @@ class FusedEngine:
     self.world_size = 1
     self.allreduce = None                  # callable(list of tensors) for data parallel
     self.use_c_step = True                 # one-FFI-call step driver (rk_ae_train_step)
-    self.time_entry = None                 # C-ABI entry name to bracket with events (bench)
-    self.time_every = 8                    # ... on every time_every-th step
+    # bench.py's roofline measurement: time_plan(call index) -> C-ABI entry name (or None) whose
+    # launch(es) the C step driver brackets with HIP events on the step's stream in that call
+    self.time_plan = None
+    self._time_samples = []                # (entry name, event0, event1)
     self._gb_lazy = None
     self.item_parallel = None              # parallel.ItemParallel when the items are sharded
     self._cstep = None
@@ -140,8 +143,13 @@ class FusedEngine:
     # the one-call step gets the encoder-bias gradient as row-segment partial vectors
     self.gb_en_parts = torch.zeros(8 * h0, **f)
     self.loss_dp = self.small[h0:h0 + 1]
-    self.ws = torch.empty(max(self.lib.rk_dz_workspace_bytes(B_cap, h0),
-                              self.lib.rk_dw_workspace_bytes(B_cap, h0, n_cap)) // 4, **f)
+    # one workspace, used in turn by the dZ split-K slabs, then by dW (bf16-pipe kernel: Z^T
+    # planes + K slabs, which stay live until the Adam sweep has read them)
+    self.ws = torch.zeros(max(self.lib.rk_dz_workspace_bytes(B_cap, h0),
+                              self.lib.rk_dw_workspace_bytes(B_cap, h0, n_cap),
+                              self.lib.rk_dw3_workspace_bytes(B_cap, h0, n_cap)) // 4 + 64, **f)
+    self.split16 = bool(self.lib.rk_gemm_split16())
+    self._dw_slabs = None
     self.n_part = self.lib.rk_loss_partials(B_cap, n_cap)
     self.loss_part = torch.zeros(self.n_part, **f)
     self.loss_out = torch.zeros(1, **f)
@@ -348,21 +356,29 @@ class FusedEngine:
     return self._loss(z, B, tgt if tgt is not None else blk, row_off, B, stream, out)
 
   def train_step(self, blk, row_off, B, keep_noise=None, keep_drop=None, out=None,
-                 global_rows=None):
+                 global_rows=None, tgt=None):
     """One optimisation step on rows [row_off, row_off+B) of the collated
     block (model.py:383-404).  ``global_rows`` = rows summed over all ranks
     (data parallel); the loss/gradients are normalised by it.
 
     Everything is enqueued in order on the caller's stream (cross-stream events
-    cost 10-20 us of dependency latency each, more than the overlap they bought);
-    under data parallelism the RCCL all-reduces run on the collective's own
-    stream while the rest of the backward pass continues here."""
-    self.ensure_capacity(B, blk.n_cap)
+    cost 10-20 us of dependency latency each, more than the overlap they bought),
+    the RCCL all-reduces of a data-parallel step included."""
+    # tgt: a separately collated TARGET block for the same rows (datasets with a target
+    # matrix, model.py:464-472): decode, loss, dW and the decoder-side updates run over ITS item
+    # set, the encoder side over the input block's
+    tb = blk if tgt is None else tgt
+    self.ensure_capacity(B, max(blk.n_cap, tb.n_cap))
     lib, m = self.lib, self.model
     main_s = torch.cuda.current_stream()
     ip = self.item_parallel
+    if tgt is not None:
+      if self.kind == "ae" and bool(m.is_constrained):
+        raise NotImplementedError("tied weights with a separate target matrix in training")
+      if ip is not None or self.allreduce is not None:
+        raise NotImplementedError("multi-GPU training with a separate target matrix")
     if self.use_c_step and self.kind == "ae" and self.nl == 0 and not (m.dropout_prob > 0.0) and \
-        not (ip is not None and self.loss_id == LOSS_MNLL):
+        tgt is None and not (ip is not None and self.loss_id == LOSS_MNLL):
       return self._c_train_step(blk, row_off, B, keep_noise, out, global_rows, main_s)
     self._gb_lazy = None
     self._gb_en_segs = 0
@@ -375,28 +391,20 @@ class FusedEngine:
     else:
       users = blk.users[row_off:row_off + B]
       z = self._mf_forward(users, B, keep_drop, True, stream)
-    loss = self._loss(z, B, blk, row_off, rows, stream, out, ip=ip)
+    loss = self._loss(z, B, tb, row_off, rows, stream, out, ip=ip)
     self._loss_target = loss
 
     # ---- dW = dO^T . z  (+ decoder bias gradient) ----
     if self.loss_id == LOSS_MNLL:
       # dO was produced by rk_mnll_finish: column sums need a pass over dO
-      check(lib.rk_decode_bwd_dw(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(self.G_de),
-                                 ptr(self.gb_de), stream), "rk_decode_bwd_dw")
+      self._dw(z, B, tb, self.gb_de, stream)
     else:
       # the loss epilogue already reduced dO per row tile: sum those few rows
-      check(lib.rk_colsum(ptr(self.gb_part), cdiv(B, self.row_tile), blk.n_cap, 0, ptr(blk.counts),
+      check(lib.rk_colsum(ptr(self.gb_part), cdiv(B, self.row_tile), tb.n_cap, 0, ptr(tb.counts),
                           ptr(self.gb_de), stream), "rk_colsum")
-      check(lib.rk_decode_bwd_dw(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(self.G_de), None,
-                                 stream), "rk_decode_bwd_dw")
+      self._dw(z, B, tb, None, stream)
     tied = self.kind == "ae" and bool(m.is_constrained)
-    dp_dec = None
-    if self.allreduce is not None:
-      # data parallel: the decoder-side gradients start their RCCL all-reduce now and
-      # travel while dZ / the encoder backward run (tied weights: G_de is still being
-      # accumulated into, it goes with the encoder side)
-      n_b_host = self.allreduce.n_b(blk)
-      dp_dec = self.allreduce.reduce_async(self.grad_views(n_b_host, "decoder"))
+    n_b_host = self.allreduce.n_b(blk) if self.allreduce is not None else None
 
     # ---- dZ = dO . W_de[T] and everything upstream of it ----
     W_de, _ = self._decoder_params()
@@ -405,7 +413,7 @@ class FusedEngine:
     if self.kind == "ae" and self.nl > 0:
       dz = self.ddec[self.nl - 1]
     fuse_act = simple and ip is None        # act' folded into the split-K reduce
-    check(lib.rk_decode_bwd_dz(ptr(self.dO), B, h0, blk.ref, ptr(W_de),
+    check(lib.rk_decode_bwd_dz(ptr(self.dO), B, h0, tb.ref, ptr(W_de),
                                ptr(self.enc[0]) if fuse_act else None, self.act, ptr(dz),
                                ptr(self.ws), stream), "rk_decode_bwd_dz")
     if ip is not None:
@@ -459,11 +467,23 @@ class FusedEngine:
       check(lib.rk_act_grad(ptr(self.dbott), ptr(self.enc[0]), n, self.act, stream), "rk_act_grad")
 
     if self.allreduce is not None:
-      dp_enc = self.allreduce.reduce_async(self.grad_views(n_b_host, "encoder"))
-      self.allreduce.wait(dp_dec)
-      self.allreduce.wait(dp_enc)
-    self._apply_updates(blk, row_off, B, stream, "all")
+      # data parallel over users: every gradient of the step (live rows of both tables, gathered
+      # bias, dense layers, loss) is SUM all-reduced as one in-order RCCL group on this stream
+      self.allreduce.reduce(self.grad_views(n_b_host, "all"))
+    self._apply_updates(blk, row_off, B, stream, "all", tgt=tb)
     return loss
+
+  def _dw(self, z, B, blk, gb_de, stream):
+    """G_de = dO^T . z (+ gb_de = colsum(dO) if asked): the bf16-pipe kernel (csrc/dw3.hip) unless
+    RK_GEMM_PREC=f32 keeps the contractions on the fp32 MFMA."""
+    h0 = self.h[0]
+    self._dw_slabs = None
+    if self.split16:
+      check(self.lib.rk_decode_bwd_dw3(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(self.G_de), ptr(gb_de),
+                                       ptr(self.ws), stream), "rk_decode_bwd_dw3")
+    else:
+      check(self.lib.rk_decode_bwd_dw(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(self.G_de), ptr(gb_de),
+                                      stream), "rk_decode_bwd_dw")
 
   def _c_train_step(self, blk, row_off, B, keep_noise, out, global_rows, main_s):
     """The same step through rk_ae_train_step: one FFI call, the kernels
@@ -475,8 +495,6 @@ class FusedEngine:
     st = self._cstep
     if st is None:
       st = RkAeStep()
-      self._c_time_pairs = []
-      self._c_time_idx = 0
       self._c_calls = 0
       self._cstep = st
     self.rng_step += 1
@@ -511,21 +529,23 @@ class FusedEngine:
     st.Z0, st.dZ0, st.dO = ptr(self.enc[0]), ptr(self.denc[0]), ptr(self.dO)
     st.G_de, st.G_en, st.gb_de = ptr(self.G_de), ptr(self.G_en), ptr(self.gb_de)
     st.gb_part, st.ws = ptr(self.gb_part), ptr(self.ws)
-    segmented = dp is None and not m.is_constrained and self.loss_id != LOSS_MNLL
+    plain = dp is None and not m.is_constrained and self.loss_id != LOSS_MNLL
+    # the fused fp32 dW || encoder-backward launch writes row-segment partials; the bf16-pipe dW
+    # (whole single-GPU steps) leaves its K slabs in the workspace and runs the plain encoder backward
+    dw3 = plain and self.split16 and self.item_parallel is None
+    segmented = plain and not dw3
+    self._dw_slabs = (blk, B) if dw3 else None
     st.gb_en = ptr(self.gb_en_parts if segmented else self.gb_en)
     self._gb_en_segs = self.lib.rk_encode_bwd_segments(B) if segmented else 0
     self.n_cap_last = blk.n_cap
     st.loss_part, st.loss_out = ptr(self.loss_part), ptr(loss_dst)
     st.stream = main_s.cuda_stream
     self._c_calls += 1
-    if self.time_entry is not None and self._c_calls % self.time_every == 0:
-      # the bracketing events cost a few us of stream time each: sample the launches
-      if not self._c_time_pairs:
-        self._c_time_pairs = [(raw.rk_timing_event_create(), raw.rk_timing_event_create())
-                              for _ in range(512)]
-      e0, e1 = self._c_time_pairs[self._c_time_idx % len(self._c_time_pairs)]
-      self._c_time_idx += 1
-      st.time_entry, st.time_ev0, st.time_ev1 = ENTRY[self.time_entry], e0, e1
+    name = self.time_plan(self._c_calls) if self.time_plan is not None else None
+    if name is not None:
+      e0, e1 = raw.rk_timing_event_create(), raw.rk_timing_event_create()
+      self._time_samples.append((name, e0, e1))
+      st.time_entry, st.time_ev0, st.time_ev1 = ENTRY[name], e0, e1
     else:
       st.time_entry = 0
     ip = self.item_parallel
@@ -553,25 +573,19 @@ class FusedEngine:
       if self.loss_id != LOSS_MNLL:
         self._gb_lazy = (cdiv(B, self.row_tile), blk)
     else:
-      # data parallel: the gradients are all-reduced (SUM) over the ranks between the
-      # backward pass and the identical Adam everywhere; the decoder side travels on
-      # RCCL's stream while dZ and the encoder backward run here
+      # data parallel over users: forward + whole backward locally, then the live gradient rows
+      # of both tables, the gathered-bias gradient, the encoder bias gradient and the loss go out
+      # as ONE in-order RCCL group on this stream, then the identical Adam on every replica
       h0 = self.h[0]
       tied = bool(m.is_constrained)
       n_b = dp.n_b(blk)
-      st.phase = STEP_FWD_DW
-      check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
-      pend_dec = None
-      if not tied:
-        pend_dec = dp.reduce_async([self.G_de[:n_b * h0]], coalesce=False)
-      st.phase = STEP_DZ_ENC
+      st.phase = STEP_FWD_DW | STEP_DZ_ENC
       check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
       G_enc = self.G_de if tied else self.G_en
-      pend_enc = dp.reduce_async([G_enc[:n_b * h0], self.small[:self.small_off + n_b]],
-                                 coalesce=False)
-      if pend_dec is not None:
-        dp.wait(pend_dec)
-      dp.wait(pend_enc)
+      views = [G_enc[:n_b * h0], self.small[:self.small_off + n_b]]
+      if not tied:
+        views.insert(0, self.G_de[:n_b * h0])
+      dp.reduce(views)
       out.copy_(self.loss_dp)
       st.phase = STEP_UPDATE
       check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
@@ -586,6 +600,18 @@ class FusedEngine:
     tiles, blk = self._gb_lazy
     ld = blk.counts_host()[2]
     return self.gb_part[:tiles * ld].view(tiles, ld)[:, :n_b].sum(0)
+
+  def decoder_row_grad(self, n_b):
+    """G_de[:n_b] of the last training step (tests): the one-call step leaves it as K slabs in the
+    workspace (summed by rk_adam_multi while it reads the gradient)."""
+    h0 = self.h[0]
+    if self._dw_slabs is None:
+      return self.G_de[:n_b * h0].view(n_b, h0).clone()
+    blk, B = self._dw_slabs
+    ns = int(blk.counts[4].item())
+    off = (self.lib.rk_dw3_slabs(ptr(self.ws), B, h0) - self.ws.data_ptr()) // 4
+    stride = blk.n_cap * h0
+    return sum(self.ws[off + k * stride:off + k * stride + n_b * h0].view(n_b, h0) for k in range(ns))
 
   def encoder_bias_grad(self):
     """gb_en of the last training step (tests): the one-call step leaves it as row-segment
@@ -620,11 +646,18 @@ class FusedEngine:
       raw.rk_event_destroy(e1)
     return float(ms[len(ms) // 2])
 
-  def timed_entry_ms(self):
-    """Per-launch durations (ms) of the bracketed entry since timing was enabled."""
+  def timed_samples_ms(self, clear=True):
+    """{entry name: [ms per bracketed call]} of the samples taken so far (synchronises)."""
     raw = _lib.load()
-    n = min(self._c_time_idx, len(self._c_time_pairs))
-    return [raw.rk_event_elapsed_ms(e0, e1) for e0, e1 in self._c_time_pairs[:n]]
+    out = {}
+    for name, e0, e1 in self._time_samples:
+      out.setdefault(name, []).append(raw.rk_event_elapsed_ms(e0, e1))
+    if clear:
+      for _, e0, e1 in self._time_samples:
+        raw.rk_event_destroy(e0)
+        raw.rk_event_destroy(e1)
+      self._time_samples = []
+    return out
 
   # ------------------------------------------------------- data parallelism
   def grad_views(self, n_b, part="all"):
@@ -647,21 +680,24 @@ class FusedEngine:
     return dec if part == "decoder" else enc if part == "encoder" else dec + enc
 
   # ---------------------------------------------------------------- updates
-  def _apply_updates(self, blk, row_off, B, stream, part="all"):
+  def _apply_updates(self, blk, row_off, B, stream, part="all", tgt=None):
     """part: 'decoder' = the decoder / item table and its gathered bias (their
-    gradients come from the dW chain), 'encoder' = everything else, 'all'."""
+    gradients come from the dW chain), 'encoder' = everything else, 'all'.  tgt: the block whose
+    item set the decoder-side gradient rows are indexed by (default: blk)."""
     m, S = self.model, self.states
     h0 = self.h[0]
     n_items = blk.n_items
+    tb = blk if tgt is None else tgt
     dec = part in ("all", "decoder")
     enc = part in ("all", "encoder")
 
-    def table(name, G):
+    def table(name, G, b=None):
+      b = blk if b is None else b
       s = S[name]
       if s.sparse:
-        self._adam_rows(s, blk.items, None, blk.counts, blk.n_cap, G, h0, stream)
+        self._adam_rows(s, b.items, None, b.counts, b.n_cap, G, h0, stream)
       else:
-        self._adam_table(s, blk.pos, G, h0, n_items, stream)
+        self._adam_table(s, b.pos, G, h0, n_items, stream)
 
     if self.kind == "ae":
       en_w = "en_embedding_layer.weight"
@@ -672,7 +708,7 @@ class FusedEngine:
         if enc:
           table(en_w, self.G_en)
         if dec:
-          table("de_embedding_layer.weight", self.G_de)
+          table("de_embedding_layer.weight", self.G_de, tb)
       if enc:
         self._adam_dense(S["_DynamicAutoencoder__en_linear_embedding_layer.bias"], self.gb_en, stream)
         for i in range(self.nl):
@@ -683,7 +719,7 @@ class FusedEngine:
           self._adam_dense(S["decoding_layers.%d.bias" % i], self.g_dec_b[i], stream)
       if dec:
         # decoder bias: a dense [n_items] gradient (index_select backward), wd = 0
-        self._adam_table(S["_DynamicAutoencoder__de_linear_embedding_layer.bias"], blk.pos,
+        self._adam_table(S["_DynamicAutoencoder__de_linear_embedding_layer.bias"], tb.pos,
                          self.gb_de, 1, n_items, stream)
     else:
       lib = self.lib
@@ -696,14 +732,14 @@ class FusedEngine:
           check(lib.rk_scatter_pos(ptr(self.pos_u), ptr(users), B, 0, stream), "rk_scatter_pos")
           self._adam_table(su, self.pos_u, self.dbott, h0, m.num_users, stream)
           if dec:
-            table("item_embedding_layer.weight", self.G_de)
-            self._adam_table(S["bias"], blk.pos, self.gb_de, 1, n_items, stream)
+            table("item_embedding_layer.weight", self.G_de, tb)
+            self._adam_table(S["bias"], tb.pos, self.gb_de, 1, n_items, stream)
             dec = False
           self._flush_jobs(stream)       # before the user-row map is cleared again
           check(lib.rk_scatter_pos(ptr(self.pos_u), ptr(users), B, 1, stream), "rk_scatter_pos")
       if dec:
-        table("item_embedding_layer.weight", self.G_de)
-        self._adam_table(S["bias"], blk.pos, self.gb_de, 1, n_items, stream)
+        table("item_embedding_layer.weight", self.G_de, tb)
+        self._adam_table(S["bias"], tb.pos, self.gb_de, 1, n_items, stream)
     self._flush_jobs(stream)
 
   # ------------------------------------------------------------- inference

@@ -64,7 +64,7 @@ class GenericEngine:
 
   # -------------------------------------------------------------------- steps
   def train_step(self, blk, row_off, B, keep_noise=None, keep_drop=None, out=None,
-                 global_rows=None):
+                 global_rows=None, tgt=None):
     if global_rows is not None and global_rows != B:
       raise NotImplementedError("data-parallel training is implemented for the fused path only")
     if keep_noise is not None or keep_drop is not None:
@@ -73,7 +73,7 @@ class GenericEngine:
     for opt in (self.optimizer, self.sparse_optimizer):
       if opt is not None:
         opt.zero_grad()
-    loss = self._loss(blk, row_off, B, None, B)
+    loss = self._loss(blk, row_off, B, tgt, B)
     loss.backward()
     for opt in (self.optimizer, self.sparse_optimizer):
       if opt is not None:

@@ -71,6 +71,10 @@ class Recoder(object):
     self.mask_hook = None
     # steps collated per side-stream hand-over (CollatePrefetcher)
     self.prefetch_group = int(os.environ.get("RK_PREFETCH_GROUP", "4"))
+    # {global step index: callable}: called right before that step's collation is submitted and
+    # its kernels are enqueued (the pipeline is cut there: nothing of the step is in flight yet);
+    # returning True ends the training.  bench.py brackets its timed region with two of these.
+    self.step_marks = {}
     self.last_epoch_losses = None
     self.loss_history = []      # per-epoch arrays of the per-step training losses
     self.__model_initialized = False
@@ -99,9 +103,26 @@ class Recoder(object):
     """True when the combination has no fused HIP step and trains through torch
     autograd on the GPU instead (recoder_amd/generic.py): user-defined
     FactorizationModel subclasses, arbitrary nn.Module losses, sgd/adagrad/rmsprop."""
-    named = isinstance(self.loss, str) or isinstance(
-        self.loss, (MSELoss, MultinomialNLLLoss, torch.nn.BCEWithLogitsLoss))
-    return self._fused_kind() is None or not named or self.optimizer_type != "adam"
+    if self._fused_kind() is None or self.optimizer_type != "adam":
+      return True
+    from .nn import fused_supported
+    if not fused_supported(self.model):
+      if not getattr(self, "_warned_generic", False):
+        self._warned_generic = True
+        log.warning("activation %r / first hidden size are outside the fused HIP kernels "
+                    "(activations none|tanh|sigmoid|relu|selu|elu, size %% 4 == 0): training through "
+                    "torch autograd on the GPU instead", self.model.activation_type)
+      return True
+    if isinstance(self.loss, str):
+      return False
+    # loss MODULES: the fused epilogues compute the plain summed loss -- anything else a module
+    # can be configured with (mean / none reduction, element or class weights) goes through torch
+    if isinstance(self.loss, (MSELoss, MultinomialNLLLoss)):
+      return self.loss.reduction != "sum"
+    if isinstance(self.loss, torch.nn.BCEWithLogitsLoss):
+      return self.loss.reduction != "sum" or self.loss.weight is not None or \
+          self.loss.pos_weight is not None
+    return True
 
   def __init_loss_module(self):
     """model.py:87-99 -- same names, same errors."""
@@ -233,7 +254,14 @@ class Recoder(object):
     if type(self.loss) is str:
       current_state["loss"] = self.loss
       current_state["loss_params"] = self.loss_params
-    torch.save(current_state, checkpoint_file)
+    # multi-GPU: the replicas are identical; one writer (concurrent writers of one path can
+    # truncate each other on a shared filesystem), the others wait for the file
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if not multi or dist.get_rank() == 0:
+      torch.save(current_state, checkpoint_file)
+    if multi:
+      dist.barrier()
     return checkpoint_file
 
   # --------------------------------------------------------------- training
@@ -285,7 +313,7 @@ class Recoder(object):
       "number of sampling users should be a multiple of the batch size"
 
     self.__init_training(train_dataset=train_dataset, lr=lr, weight_decay=weight_decay)
-    train_dataset = self._setup_data_parallel(train_dataset)
+    train_dataset = self._setup_data_parallel(train_dataset, negative_sampling)
     if getattr(self, "_ip", None) is not None:
       # item parallel: every rank processes the whole global batch against its items
       batch_size *= self._ip.world
@@ -361,47 +389,56 @@ class Recoder(object):
       tensors = [t[:self._dp_n_users] for t in tensors]
     sync_owned_rows(tensors, self._dp_n_users, self._dp.group)
 
-  def _setup_data_parallel(self, train_dataset):
+  def _setup_data_parallel(self, train_dataset, negative_sampling=True):
     """Under an initialised torch.distributed group (one process per GPU, backend
-    'nccl' = RCCL) the users are sharded over the ranks and the gradients are
-    all-reduced (recoder_amd/parallel.py).  Returns this rank's shard."""
+    'nccl' = RCCL) the USERS are sharded over the ranks and the gradients are
+    all-reduced (recoder_amd/parallel.DataParallel) -- north_star's partitioning and the
+    default.  RK_PARALLEL=items shards the item dimension instead (parallel.ItemParallel).
+    Returns this rank's shard."""
     import torch.distributed as dist
     self._dp = None
     self._ip = None
     if getattr(self, "_ip_override", None) is not None:
       # tests: several virtual ranks in one process, collectives injected
       return self._enable_item_parallel(self._ip_override, train_dataset)
-    if not (dist.is_available() and dist.is_initialized()):
-      return train_dataset
-    if dist.get_world_size() == 1 and os.environ.get("RK_FORCE_DP") != "1":
-      return train_dataset
+    dp = getattr(self, "_dp_override", None)
+    if dp is None:
+      if not (dist.is_available() and dist.is_initialized()):
+        return train_dataset
+      if dist.get_world_size() == 1 and os.environ.get("RK_FORCE_DP") != "1":
+        return train_dataset
     if self._use_generic():
       raise NotImplementedError("multi-GPU training is implemented for the fused "
                                 "DynamicAutoencoder / MatrixFactorization paths")
-    for p_ in self.model.parameters():          # identical replicas: rank 0's initial weights
-      dist.broadcast(p_.data, src=0)
-    # RK_PARALLEL = items | users | auto: shard the ITEM dimension (two small [N*B, h]
-    # all-reduces per step, 1/N of the Adam sweep) where the step supports it, else the users
-    m = self.model
-    ip_ok = True
-    mode = os.environ.get("RK_PARALLEL", "auto")
+    if train_dataset.device_target_csr() is not None:
+      raise NotImplementedError("multi-GPU training with a separate target matrix")
+    if dp is None:
+      for p_ in self.model.parameters():          # identical replicas: rank 0's initial weights
+        dist.broadcast(p_.data, src=0)
+    mode = os.environ.get("RK_PARALLEL", "users")
     if mode == "auto":
-      mode = "items" if ip_ok else "users"
-    if mode == "items":
-      if not ip_ok:
-        raise NotImplementedError("item-parallel training covers the mse / logistic losses (the "
-                                  "multinomial softmax spans all items); use RK_PARALLEL=users")
+      mode = "users"
+    if mode == "items" and not negative_sampling:
+      # without sampling every rank's block spans the whole catalogue, but an item shard only
+      # holds its own columns' targets: the loss over the other columns would be wrong
+      log.warning("RK_PARALLEL=items needs negative_sampling=True; sharding the users instead")
+      mode = "users"
+    if mode == "items" and dp is None:
       from .parallel import ItemParallel
       return self._enable_item_parallel(ItemParallel(), train_dataset)
     from .parallel import DataParallel, shard_range
-    dp = DataParallel()
+    if dp is None:
+      dp = DataParallel().prepare(self.device)
     dp.attach(self._engine())
     self._dp = dp
     n = len(train_dataset)
     lo, hi = shard_range(n, dp.rank, dp.world)
     dp.user_offset = lo
     self._dp_n_users = n
-    shard = RecommendationDataset(train_dataset.interactions_matrix[lo:hi])
+    if hasattr(train_dataset, "row_shard"):           # data.DeviceDataset: sliced in HBM
+      shard = train_dataset.row_shard(lo, hi)
+    else:
+      shard = RecommendationDataset(train_dataset.interactions_matrix[lo:hi])
     # every rank runs the same number of equally sized steps (collectives in lockstep)
     self._dp_users_per_epoch = n // dp.world
     return shard
@@ -416,32 +453,47 @@ class Recoder(object):
     self._ip = ip
     return RecommendationDataset(ip.shard_csr(full))
 
-  def _make_block(self, dcsr, S, negative_sampling):
+  def _make_block(self, dcsr, S, negative_sampling, train=False):
+    """train: a block of the (sharded) training matrix; validation / target blocks are
+    collated from unsharded matrices and get the plain capacity."""
     nnz_cap = max(1, _top_sum(dcsr.degrees, S))
     n_cap = nnz_cap
-    if getattr(self, "_dp", None) is not None:
+    if train and getattr(self, "_dp", None) is not None:
       n_cap = nnz_cap * self._dp.world      # the union item set can exceed one rank's nnz bound
-    if getattr(self, "_ip", None) is not None and negative_sampling:
+    if train and getattr(self, "_ip", None) is not None and negative_sampling:
       n_cap = min(nnz_cap, -(-dcsr.n_items // self._ip.world))   # at most the owned items
     return Block(S, nnz_cap, dcsr.n_items, self.device, negative_sampling=negative_sampling,
                  n_cap=n_cap)
 
   def _step_generator(self, dataloader):
-    """Yields (blk, row_off, B, keep_noise, keep_drop) for one pass over the
+    """Yields (blk, row_off, B, keep_noise, keep_drop, tgt_blk) for one pass over the
     dataset: the device-side equivalent of iterating the reference's
-    RecommendationDataLoader (data.py:138-144)."""
+    RecommendationDataLoader (data.py:138-144).  tgt_blk: the same rows collated from the
+    dataset's target matrix (its own item set, data.py:60-62), or None."""
     ds = dataloader.dataset
     dcsr = ds.device_csr()
+    dcsr_t = ds.device_target_csr()
+    tgt_blk = None
+    if dcsr_t is not None:
+      tgt_blk = getattr(self, "_train_tgt_blk", None)
+      if tgt_blk is None or tgt_blk.S_cap < dataloader.num_sampling_users or \
+          getattr(self, "_train_tgt_src", None) is not dcsr_t or \
+          tgt_blk.negative_sampling != dataloader.negative_sampling:
+        tgt_blk = self._make_block(dcsr_t, dataloader.num_sampling_users,
+                                   dataloader.negative_sampling)
+        self._train_tgt_blk, self._train_tgt_src = tgt_blk, dcsr_t
     B, S = dataloader.batch_size, dataloader.num_sampling_users
     pf = getattr(self, "_train_pf", None)
+    dp = getattr(self, "_dp", None)
     if pf is None or pf.dcsr is not dcsr or pf.blocks[0][0].S_cap < S or \
-        pf.blocks[0][0].negative_sampling != dataloader.negative_sampling:
+        pf.blocks[0][0].negative_sampling != dataloader.negative_sampling or \
+        getattr(pf, "owner_dp", None) is not dp:
       from .device import CollatePrefetcher
       ns = dataloader.negative_sampling
-      dp = getattr(self, "_dp", None)
-      pf = CollatePrefetcher(lambda: self._make_block(dcsr, S, ns), dcsr, self.device,
+      pf = CollatePrefetcher(lambda: self._make_block(dcsr, S, ns, train=True), dcsr, self.device,
                              collate_fn=(dp.collate if dp is not None else None),
                              group=self.prefetch_group)
+      pf.owner_dp = dp
       self._train_pf = pf
     pf.reset()
     n = len(ds)
@@ -459,17 +511,43 @@ class Recoder(object):
     order_dev = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int64)).to(self.device)
     offs = [o for o in range(0, n, S) if order_dev[o:o + S].numel() > 0]
     G = pf.group
-    chunks = [offs[i:i + G] for i in range(0, len(offs), G)]
+    # chunks of up to G sampling groups; a chunk never straddles a step mark
+    marks = self.step_marks
+    step0 = getattr(self, "_global_step", 0)
+    first_step, k = {}, step0
+    for o in offs:
+      first_step[o] = k
+      k += -(-min(S, n - o) // B)
+    chunks = []
+    for o in offs:
+      if not chunks or len(chunks[-1]) == G or first_step[o] in marks:
+        chunks.append([])
+      chunks[-1].append(o)
     users_of = lambda chunk: [order_dev[o:o + S] for o in chunk]
-    # the chunk after the current one is collated on the prefetcher's side stream
-    if chunks:
-      pf.submit(0, users_of(chunks[0]))
+    marked = lambda ci: first_step[chunks[ci][0]] in marks
+    submitted = set()
+
+    def submit(ci):
+      if ci < len(chunks) and ci not in submitted:
+        submitted.add(ci)
+        pf.submit(ci % 2, users_of(chunks[ci]))
+    # the chunk after the current one is collated on the prefetcher's side stream (unless it
+    # starts at a mark: then nothing of it may be in flight before the mark's callback ran)
+    if chunks and not marked(0):
+      submit(0)
     for ci, chunk in enumerate(chunks):
       slot = ci % 2
-      if ci + 1 < len(chunks):
-        pf.submit((ci + 1) % 2, users_of(chunks[ci + 1]))
+      if marked(ci):
+        if marks[first_step[chunk[0]]]():
+          self._stop_training = True
+          return
+      submit(ci)
+      if ci + 1 < len(chunks) and not marked(ci + 1):
+        submit(ci + 1)
       for blk, off in zip(pf.acquire(slot), chunk):
         Sg = int(order_dev[off:off + S].numel())
+        if tgt_blk is not None:
+          tgt_blk.collate(dcsr_t, order_dev[off:off + S])
         keep_noise = keep_drop = None
         if self.mask_hook is not None:
           keep_noise, keep_drop = self.mask_hook(self._global_step, order[off:off + S])
@@ -478,7 +556,7 @@ class Recoder(object):
           kd = None
           if keep_drop is not None:
             kd = keep_drop[r:r + rows].contiguous()
-          yield blk, r, rows, keep_noise, kd
+          yield blk, r, rows, keep_noise, kd, tgt_blk
       pf.release(slot)
 
   def _train(self, train_dataloader, val_dataloader, num_epochs, current_epoch, lr_scheduler,
@@ -494,7 +572,10 @@ class Recoder(object):
     loss_buf = torch.zeros(max(1, min(iters_per_epoch, num_batches)), dtype=torch.float32,
                            device=self.device)
     iterator = None
+    self._stop_training = False
     for epoch in range(current_epoch, num_epochs + 1):
+      if self._stop_training:
+        break
       self.current_epoch = epoch
       self.model.train()
       if lr_scheduler is not None:
@@ -506,11 +587,11 @@ class Recoder(object):
       iters_processed += iters_to_process
 
       n_done = 0
-      for batch_itr, (blk, row_off, rows, keep_noise, keep_drop) in iterator:
+      for batch_itr, (blk, row_off, rows, keep_noise, keep_drop, tgt_blk) in iterator:
         dp = getattr(self, "_dp", None)
         engine.train_step(blk, row_off, rows, keep_noise, keep_drop,
                           out=loss_buf[n_done:n_done + 1],
-                          global_rows=(rows * dp.world if dp is not None else None))
+                          global_rows=(rows * dp.world if dp is not None else None), tgt=tgt_blk)
         n_done += 1
         self._global_step += 1
         if batch_itr % iters_per_epoch == 0:

@@ -65,9 +65,18 @@ class LinearEmbedding(nn.Module):
 
 
 def _check_act(act):
-  if act not in _ACTS:
-    raise ValueError("activation %r is not supported by the HIP kernels (supported: %s)"
-                     % (act, ", ".join(_ACTS)))
+  """The reference takes 'none' or the name of any ``torch.<name>`` function (nn.py:6-9).  The
+  fused HIP kernels implement _ACTS; every other name trains through the generic torch-autograd
+  path on the GPU (recoder_amd/generic.py) -- unknown names fail here, as early as possible."""
+  if act not in _ACTS and not callable(getattr(torch, str(act), None)):
+    raise AttributeError("module 'torch' has no attribute %r (activation_type)" % (act,))
+
+
+def fused_supported(model):
+  """True when the HIP kernels cover this model instance: a fused activation and 16-byte
+  embedding rows (hidden_layers[0] / embedding_size a multiple of 4)."""
+  h0 = model.hidden_layers[0] if isinstance(model, DynamicAutoencoder) else model.embedding_size
+  return model.activation_type in _ACTS and h0 % 4 == 0
 
 
 class DynamicAutoencoder(FactorizationModel):
@@ -160,6 +169,9 @@ class DynamicAutoencoder(FactorizationModel):
   def forward(self, input, input_users=None, input_items=None, target_users=None,
               target_items=None):
     """Dense-input forward (nn.py:228-253) on the HIP kernels; no autograd."""
+    if not fused_supported(self):
+      with torch.no_grad():
+        return self.torch_forward(input, input_users, input_items, target_users, target_items)
     from .engine import ae_dense_forward
     return ae_dense_forward(self, input, input_items, target_items)
 
@@ -227,6 +239,9 @@ class MatrixFactorization(FactorizationModel):
 
   def forward(self, input, input_users=None, input_items=None, target_users=None,
               target_items=None):
+    if not fused_supported(self):
+      with torch.no_grad():
+        return self.torch_forward(input, input_users, input_items, target_users, target_items)
     from .engine import mf_dense_forward
     return mf_dense_forward(self, input_users, target_items)
 

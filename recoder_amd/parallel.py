@@ -15,8 +15,8 @@ mechanism (num_sampling_users = k * batch_size, data.py:216-223,231-249):
     fused Adam -- bit-for-bit the mathematics of a single process running
     batch_size = N * B_local.
 
-Item parallelism (class ItemParallel) is the second formulation, the one the
-multi-GPU bench uses for the autoencoder: the ITEM dimension is sharded instead
+Item parallelism (class ItemParallel, RK_PARALLEL=items) is the second formulation, kept as
+an opt-in: the ITEM dimension is sharded instead
 of the users (item i lives on rank i % N: embedding rows, their Adam moments and
 the matching columns of the interaction matrix).  Every rank processes all
 N * B users of the global batch against its own items; the only exchange is an
@@ -82,32 +82,82 @@ def sync_owned_rows(tensors, n_rows, group=None):
                        group=group)
 
 
-class DataParallel:
-  """Glue between a FusedEngine and torch.distributed."""
+def _make_rccl(group, device, rank, world):
+  """Our own RCCL communicator (recoder_amd/rccl.py: collectives enqueued IN ORDER on the stream
+  they are issued on -- no cross-stream event pairs) with a self-check; None (= use
+  torch.distributed) for RK_COMM=torch, non-nccl backends or any bootstrap failure.  A
+  collective: every rank calls it."""
+  if dist.get_backend(group) != "nccl" or os.environ.get("RK_COMM", "rccl") == "torch":
+    return None
+  try:
+    from .rccl import RcclComm
+    comm = RcclComm(group, device)
+    probe = torch.full((8,), float(rank + 1), dtype=torch.float32, device=device)
+    comm.all_reduce(probe)
+    want = world * (world + 1) / 2.0
+    if not bool((probe == want).all().item()):
+      raise RuntimeError("self-check all-reduce returned %r, expected %r" % (probe[0].item(), want))
+    return comm
+  except Exception as e:      # noqa: BLE001 -- any bootstrap problem: torch.distributed
+    import warnings
+    warnings.warn("direct RCCL communicator unavailable (%s); using torch.distributed" % e)
+    return None
 
-  def __init__(self, group=None):
-    assert dist.is_initialized()
+
+class DataParallel:
+  """Users sharded over the ranks (north_star's partitioning): glue between a FusedEngine and
+  the collectives.  Device tensors on the nccl backend go through two communicators of our own
+  (recoder_amd/rccl.py) -- one for the gradient bucket on the step's stream, one for the item-stamp
+  MAX on the collation side stream -- each enqueued in order on the stream it is issued on;
+  anything else (gloo in the CPU tests, RK_COMM=torch) through torch.distributed.  rank / world /
+  the collectives can be injected (tests: several virtual ranks on one GPU)."""
+
+  def __init__(self, group=None, rank=None, world=None, allreduce_fn=None, allreduce_max_fn=None):
     self.group = group
-    self.rank = dist.get_rank(group)
-    self.world = dist.get_world_size(group)
+    self._sum_fn, self._max_fn = allreduce_fn, allreduce_max_fn
+    self.virtual = allreduce_fn is not None
+    if not self.virtual:
+      assert dist.is_initialized()
+    self.rank = dist.get_rank(group) if rank is None else rank
+    self.world = dist.get_world_size(group) if world is None else world
     self.user_offset = 0          # first global user id of this rank's shard
+    self._grad_comm = self._mark_comm = None
+
+  def prepare(self, device):
+    """Create the two direct communicators now (a collective: every rank calls it)."""
+    if not self.virtual and device.type == "cuda":
+      self._grad_comm = _make_rccl(self.group, device, self.rank, self.world)
+      if self._grad_comm is not None:
+        self._mark_comm = _make_rccl(self.group, device, self.rank, self.world)
+    return self
+
+  @property
+  def direct(self):
+    return self._grad_comm is not None
+
+  def union_marks(self, mark):
+    """MAX all-reduce of the item stamps, in order on the current stream."""
+    if self._max_fn is not None:
+      return self._max_fn(mark)
+    if self._mark_comm is not None and mark.is_cuda:
+      from .rccl import ncclMax
+      return self._mark_comm.all_reduce(mark, op=ncclMax)
+    return union_marks(mark, self.group)
 
   def collate(self, blk, dcsr, users_dev):
     """Two-phase collation with the union item set.  ``users_dev`` are rows of this
     rank's shard; the block carries their GLOBAL ids (MatrixFactorization looks its
     user rows up by them, the dropout RNG is keyed on them)."""
     blk.collate(dcsr, users_dev, phase=1)
-    union_marks(blk.mark, self.group)
+    self.union_marks(blk.mark)
     blk.collate(dcsr, users_dev, phase=2)
     if self.user_offset:
       blk.users = users_dev + self.user_offset
 
   def attach(self, engine):
-    """Install the gradient exchange on a FusedEngine.  The engine calls
-    ``reduce_async(views)`` as soon as a group of gradients is complete (decoder
-    side right after dW, encoder side after the encoder backward) with the
-    producing stream current, and ``wait(handles)`` before the matching Adam, so
-    the RCCL transfers overlap the rest of the backward pass."""
+    """Install the gradient exchange on a FusedEngine: the engine calls ``reduce(views)`` with
+    the step's stream current once the backward pass is enqueued; the SUM all-reduces of all
+    views go out as ONE in-order RCCL group before the (identical) Adam of every replica."""
     engine.world_size = self.world
     engine.allreduce = self
     return engine
@@ -115,29 +165,15 @@ class DataParallel:
   def n_b(self, blk):
     return blk.host_n_b()
 
-  def reduce_async(self, views, small_threshold=65536, coalesce=True):
-    if not coalesce:
-      small_threshold = -1
-    small = [v for v in views if v.numel() <= small_threshold]
-    large = [v for v in views if v.numel() > small_threshold]
-    handles = [dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-               for v in large]
-    flat = None
-    if small:
-      flat = torch.cat([v.reshape(-1) for v in small])
-      handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-    return handles, small, flat
-
-  def wait(self, pending):
-    handles, small, flat = pending
-    for h in handles:
-      h.wait()                 # the current stream waits for the collective
-    if flat is not None:
-      off = 0
-      for v in small:
-        n = v.numel()
-        v.copy_(flat[off:off + n].view_as(v))
-        off += n
+  def reduce(self, views):
+    views = [v for v in views if v.numel() > 0]
+    if self._sum_fn is not None:
+      for v in views:
+        self._sum_fn(v)
+    elif self._grad_comm is not None and all(v.is_cuda for v in views):
+      self._grad_comm.all_reduce_many(views)
+    else:
+      allreduce_sum(views, self.group)
 
 
 class ItemParallel:
@@ -157,27 +193,11 @@ class ItemParallel:
     self._rccl_tried = False
 
   def _direct(self, t):
-    """Our own RCCL communicator (recoder_amd/rccl.py: collectives enqueued in order on the
-    step's stream, no cross-stream event pairs) for device tensors on the nccl backend;
-    RK_COMM=torch, or any failure while creating it, keeps torch.distributed."""
+    """Our own RCCL communicator for device tensors on the nccl backend (see _make_rccl)."""
     if not self._rccl_tried:
       self._rccl_tried = True
-      if t.is_cuda and dist.get_backend(self.group) == "nccl" and \
-          os.environ.get("RK_COMM", "rccl") != "torch":
-        try:
-          from .rccl import RcclComm
-          comm = RcclComm(self.group, t.device)
-          # self-check before trusting it with gradients: sum of (rank + 1) over the ranks
-          probe = torch.full((8,), float(self.rank + 1), dtype=torch.float32, device=t.device)
-          comm.all_reduce(probe)
-          want = self.world * (self.world + 1) / 2.0
-          if not bool((probe == want).all().item()):
-            raise RuntimeError("self-check all-reduce returned %r, expected %r" % (probe[0].item(), want))
-          self._rccl = comm
-        except Exception as e:      # noqa: BLE001 -- any bootstrap problem: torch.distributed
-          import warnings
-          warnings.warn("direct RCCL communicator unavailable (%s); using torch.distributed" % e)
-          self._rccl = None
+      if t.is_cuda:
+        self._rccl = _make_rccl(self.group, t.device, self.rank, self.world)
     return self._rccl if t.is_cuda else None
 
   def prepare(self, device):

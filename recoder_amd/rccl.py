@@ -39,6 +39,8 @@ def _load():
     lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
                                   ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    lib.ncclGroupStart.argtypes = []
+    lib.ncclGroupEnd.argtypes = []
     lib.ncclGetErrorString.restype = ctypes.c_char_p
     lib.ncclGetErrorString.argtypes = [ctypes.c_int]
     _lib = lib
@@ -85,6 +87,23 @@ class RcclComm:
     _check(_load().ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), dt, op, self.comm,
                                  ctypes.c_void_p(s.cuda_stream)), "ncclAllReduce")
     return t
+
+  def all_reduce_many(self, tensors, op=ncclSum, stream=None):
+    """The all-reduces of several tensors as ONE RCCL group (one fused launch), in place, in order
+    on the given (default: current) stream."""
+    tensors = [t for t in tensors if t.numel() > 0]
+    if not tensors:
+      return
+    if len(tensors) == 1:
+      self.all_reduce(tensors[0], op, stream)
+      return
+    lib = _load()
+    _check(lib.ncclGroupStart(), "ncclGroupStart")
+    try:
+      for t in tensors:
+        self.all_reduce(t, op, stream)
+    finally:
+      _check(lib.ncclGroupEnd(), "ncclGroupEnd")
 
   def destroy(self):
     if self.comm:

@@ -50,3 +50,37 @@ def uniform(n_users, n_items, degree, seed=3):
   rng = np.random.RandomState(seed)
   deg = np.full(n_users, degree, dtype=np.int64)
   return _zipf_csr(n_users, n_items, deg, rng, zipf_a=None)
+
+
+def device_csr(n_users, n_items, degree, seed=3, zipf_a=None, device=None, chunk_users=131072):
+  """Seeded user x item matrix generated ON THE DEVICE, never materialised on the host (C5 of
+  BASELINE.json: 10 M x 1 M at 0.01 % density is ~1e9 interactions; a data-parallel rank holds
+  its 1.25 M-user shard).  Every user draws ``degree`` items -- uniform, or Zipf(zipf_a) through
+  the inverse CDF -- duplicates inside a row are dropped, values are all 1.0 (implicit feedback).
+  Returns a recoder_amd.device.DeviceCSR."""
+  import torch
+  from .device import DeviceCSR, require_gpu
+  device = device or require_gpu()
+  g = torch.Generator(device=device)
+  g.manual_seed(int(seed))
+  cum = None
+  if zipf_a is not None:
+    pop = 1.0 / torch.arange(1, n_items + 1, dtype=torch.float64, device=device).pow(zipf_a)
+    cum = torch.cumsum(pop / pop.sum(), 0)
+  counts, cols = [], []
+  for lo in range(0, n_users, chunk_users):
+    n = min(chunk_users, n_users - lo)
+    if cum is None:
+      it = torch.randint(0, n_items, (n, degree), generator=g, device=device, dtype=torch.int64)
+    else:
+      u = torch.rand((n, degree), generator=g, device=device, dtype=torch.float64)
+      it = torch.searchsorted(cum, u).clamp_(max=n_items - 1)
+    it, _ = torch.sort(it, dim=1)
+    keep = torch.ones_like(it, dtype=torch.bool)
+    keep[:, 1:] = it[:, 1:] != it[:, :-1]
+    counts.append(keep.sum(dim=1))
+    cols.append(it[keep].to(torch.int32))
+  counts = torch.cat(counts)
+  indptr = torch.zeros(n_users + 1, dtype=torch.int64, device=device)
+  torch.cumsum(counts, 0, out=indptr[1:])
+  return DeviceCSR.from_arrays((n_users, n_items), indptr, torch.cat(cols), None, device, check=False)

@@ -18,6 +18,13 @@ GENERIC_CONFIGS = {
                                train=dict(batch_size=32, lr=1e-2, weight_decay=0.0, num_epochs=2,
                                           negative_sampling=False),
                                data=dict(seed=33, **_DATA)),
+  # an activation the fused kernels do not implement (any torch.<name> is legal, reference
+  # nn.py:6-9) and a first hidden size that is not a multiple of 4: both route to the generic path
+  "ae_erf_h30_adam": dict(kind="ae", model=dict(hidden_layers=[30], activation_type="erf", sparse=True),
+                          loss="mse", optimizer="adam",
+                          train=dict(batch_size=32, lr=1e-3, weight_decay=1e-5, num_epochs=2,
+                                     negative_sampling=True),
+                          data=dict(seed=35, **_DATA)),
   "twotower_adam": dict(kind="custom", model=dict(d=8), loss="logistic", optimizer="adam",
                         train=dict(batch_size=32, lr=1e-3, weight_decay=1e-5, num_epochs=2,
                                    negative_sampling=True),

@@ -184,3 +184,98 @@ def test_dw_slabs_contract():
                                        ptr(ws), current_stream())
   assert rc < 0
   assert b"rk_dw_splits" in lib.rk_last_error()
+
+
+# ---------------------------------------------------------------------------------------------
+# bf16-pipe dW (csrc/dw3.hip): three bf16 pieces per fp32 operand, six products, no operand range
+# ---------------------------------------------------------------------------------------------
+def _dw3_case(B, h, n_t, gtop, ztop, give_G, seed=5, n_items=None):
+  from recoder_amd import _lib
+  from recoder_amd._lib import check, ptr
+  from recoder_amd.device import current_stream
+  lib = _lib.load()
+  dev = torch.device("cuda")
+  n_items = n_items or max(2 * n_t, 4000)
+  blk, items = _block(B, n_items, n_t, dev, seed=seed)
+  g = torch.Generator(device="cpu").manual_seed(seed)
+  ld = blk.counts_host()[2]
+
+  def spread(shape, top, decades):
+    mag = top * 10.0 ** (-decades * torch.rand(shape, generator=g, dtype=torch.float64))
+    sign = torch.where(torch.rand(shape, generator=g) < 0.5, -1.0, 1.0).double()
+    return (mag * sign).float()
+  dO = spread((B, n_t), gtop, 4.0)
+  Z = spread((B, h), ztop, 3.0)
+  # everything outside the live region is poisoned: the kernel must not let it reach the result
+  dO_dev = torch.full((B * blk.ld_cap + 64,), float("nan"), device=dev)
+  live = dO_dev[:B * ld].view(B, ld)
+  live[:, :] = 0.0                     # the decode epilogue writes finite values up to ld
+  live[:, :n_t] = dO.to(dev)
+  Zd = Z.to(dev)
+  nbytes = lib.rk_dw3_workspace_bytes(B, h, blk.n_cap)
+  ws = torch.full((nbytes // 4 + 64,), float("nan"), device=dev)
+  G = torch.full((blk.n_cap * h,), float("nan"), device=dev) if give_G else None
+  check(lib.rk_decode_bwd_dw3(ptr(dO_dev), ptr(Zd), B, h, blk.ref, ptr(G), None, ptr(ws),
+                              current_stream()), "rk_decode_bwd_dw3")
+  torch.cuda.synchronize()
+  ns = int(blk.counts[4].item())
+  assert 1 <= ns <= lib.rk_dw3_max_splits()
+  if give_G:
+    got = G[:n_t * h].view(n_t, h)
+  else:
+    off = (lib.rk_dw3_slabs(ptr(ws), B, h) - ws.data_ptr()) // 4
+    stride = blk.n_cap * h
+    got = sum(ws[off + k * stride:off + k * stride + n_t * h].view(n_t, h) for k in range(ns))
+  got = got.cpu().double()
+  exact = dO.double().t() @ Z.double()
+  scale = dO.double().abs().t() @ Z.double().abs()
+  err = ((got - exact).abs() / scale).max().item()
+  f32 = (dO.t() @ Z).double()
+  err32 = ((f32 - exact).abs() / scale).max().item()
+  assert torch.isfinite(got).all()
+  return err, err32, ns
+
+
+@pytest.mark.parametrize("B,h,n_t", [(500, 200, 7842), (96, 64, 333), (37, 200, 65), (512, 512, 3000),
+                                     (1000, 128, 129), (64, 256, 4097), (300, 20, 1000)])
+@pytest.mark.parametrize("give_G", [True, False])
+def test_dw3_matches_float64(B, h, n_t, give_G):
+  err, err32, ns = _dw3_case(B, h, n_t, 2e-3, 1.0, give_G)
+  print("B %d h %d n_t %d slabs %d: bf16x3 %.2e   fp32 matmul %.2e" % (B, h, n_t, ns, err, err32))
+  # error / sum |products|: an fp32 matmul of the same operands sits at 2-6e-7 on this data
+  assert err < max(5e-7, 1.05 * err32), (err, err32)
+
+
+@pytest.mark.parametrize("gtop,ztop", [(1e-7, 1.0), (40.0, 1e4), (3e4, 3e4), (1e-12, 1e-3), (1e15, 1e15)])
+def test_dw3_has_no_operand_range(gtop, ztop):
+  """bf16 carries fp32's exponent: magnitudes that overflow an fp16 split (|x| >= 65504 / scale)
+  and magnitudes far below it come out with the same relative accuracy."""
+  err, err32, ns = _dw3_case(200, 200, 1500, gtop, ztop, True, seed=9)
+  print("gtop %g ztop %g: bf16x3 %.2e   fp32 matmul %.2e" % (gtop, ztop, err, err32))
+  assert err < max(5e-7, 1.05 * err32), (err, err32)
+
+
+def test_split_planes_t_is_exact():
+  """x = hi + mid + lo exactly (the three bf16 planes) for every fp32 whose pieces stay above the
+  subnormal range (|x| >= 2^-100 or so), zero padding."""
+  from recoder_amd import _lib
+  from recoder_amd._lib import check, ptr
+  from recoder_amd.device import current_stream
+  lib = _lib.load()
+  dev = torch.device("cuda")
+  rows, cols, rp, cp = 37, 21, 64, 128
+  g = torch.Generator(device="cpu").manual_seed(1)
+  X = (torch.randn(rows, cols, generator=g) * 10.0 ** (torch.rand(rows, cols, generator=g) * 12 - 6)).float()
+  X[0, 0] = 0.0
+  X[1, 1] = 3.0e38
+  X[2, 2] = 1.0e-30
+  planes = torch.zeros(3 * rp * cp, dtype=torch.int16, device=dev)
+  planes.fill_(0x7fc0)                     # NaN pattern: the padding must be overwritten
+  check(lib.rk_split_planes_t(ptr(X.to(dev)), rows, cols, cols, rp, cp, ptr(planes), current_stream()),
+        "rk_split_planes_t")
+  p = planes.view(3, rp // 8, cp, 8).cpu()
+  as_f32 = (p.to(torch.int32) << 16).view(torch.float32).double()          # bf16 -> fp32 bits
+  tot = as_f32.sum(0)                                                      # [k/8][n][8]
+  back = tot.permute(0, 2, 1).reshape(rp, cp)                               # [k][n]
+  assert torch.equal(back[:rows, :cols], X.double())
+  assert (back[rows:] == 0).all() and (back[:, cols:] == 0).all()

