@@ -203,13 +203,24 @@ def main():
       dist.barrier()
       torch.cuda.synchronize()
 
+  G = max(1, int(rec.prefetch_group))       # steps per replayed graph (recoder_amd/graph.py)
+
+  def plan_warm(i):
+    # warm-up: the first group of steps runs eagerly with every launch group bracketed, the rest
+    # replays the captured graphs (so that the timed region starts with warm graphs)
+    return "all" if i < min(G, max(1, W // 2)) else None
+
+  def plan_timed(i):
+    # timed region: the LAST whole group is enqueued eagerly with every launch group bracketed
+    # (HIP events cannot sit inside a replayed graph); everything else is graph replay
+    last = W + ((K // G) - 1) * G if K >= 2 * G else W + K
+    return "all" if last <= i < last + G else None
+
   def start():
     eng = rec._engine()
     sync_all()
-    T["warm"] = eng.timed_samples_ms() if hasattr(eng, "timed_samples_ms") else {}
-    means = {k: float(np.median(v)) for k, v in T["warm"].items() if v}
-    T["dominant"] = max(means, key=means.get) if means else "rk_adam_multi"
-    eng.time_plan = lambda i: T["dominant"] if i % 8 == 0 else None
+    T["warm"] = eng.timed_samples_ms()
+    eng.time_plan = plan_timed
     sync_all()
     T["t0"] = time.perf_counter()
     return False
@@ -221,8 +232,7 @@ def main():
     return True                                      # end the training here
 
   def install():
-    # warm-up: every launch group of the production step is bracketed in turn
-    rec._engine().time_plan = lambda i: ENTRIES[i % len(ENTRIES)]
+    rec._engine().time_plan = plan_warm
     return False
 
   rec.step_marks = {0: install, W: start, W + K: stop}
@@ -260,7 +270,6 @@ def main():
       n_b = float("nan")          # the union item set over the ranks is larger than one shard's
     ev_over = eng.event_pair_overhead_ms()
     timed = eng.timed_samples_ms()
-    dominant = T["dominant"]
 
     def line(entry, ms_list, where):
       ms = float(np.median(ms_list)) - ev_over     # (median: the first bracketed call of a kernel
@@ -271,8 +280,15 @@ def main():
       return dict(name=entry, kernels=KERNELS.get(entry, []), avg_us=ms * 1e3, samples=len(ms_list),
                   sampled=where, bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak,
                   ideal_us=work / peak * 1e6)
-    kernels = [line(e, T["warm"][e], "warm-up") for e in ENTRIES if T["warm"].get(e)]
-    dom = line(dominant, timed.get(dominant, T["warm"].get(dominant, [float("nan")])), "timed region")
+    # every launch group of the production step: from the timed region where it was sampled there
+    kernels = []
+    for e in ENTRIES:
+      if timed.get(e):
+        kernels.append(line(e, timed[e], "timed region"))
+      elif T["warm"].get(e):
+        kernels.append(line(e, T["warm"][e], "warm-up"))
+    dom = max(kernels, key=lambda k: k["avg_us"])
+    dominant = dom["name"]
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload
     # (profiles/r*_pmc_traffic.json, tools/pmc_traffic.py); null for other configs
     traffic = None
@@ -308,7 +324,9 @@ def main():
                                 if multi else "dp1",
                  "avg_sampled_items": n_b, "avg_nnz_per_batch": nnz,
                  "first_loss": float(losses[0]), "last_loss": float(losses[-1]),
-                 "host_enqueue_ms_per_step": T["enqueue"] / K * 1e3},
+                 "host_enqueue_ms_per_step": T["enqueue"] / K * 1e3,
+                 "graph_replay": bool(getattr(rec, "_graph_stepper", None) is not None),
+                 "steps_per_graph": G},
       "roofline": roofline,
     }
     if world == 1 and not multi and not args.no_cpu_baseline:

@@ -245,7 +245,21 @@ void rk_dw3_probe(unsigned long long *buffer);
 const float *rk_dw3_slabs(const void *workspace, int32_t B, int32_t h);
 int rk_decode_bwd_dw3(const float *dO, const float *Z, int32_t B, int32_t h,
                       const rk_block_t *tgt, float *G_de, float *gb_de, void *workspace,
+                      const void *zt_planes /* nullable: made from Z into workspace */,
                       void *stream);
+/* The Z^T planes of rk_decode_bwd_dw3 can be written by the kernel that produces Z:
+ * rk_ae_encode_fwd_planes = rk_ae_encode_fwd + the three bf16 planes of its output, into a
+ * buffer of rk_dw3_planes_bytes(B, h) bytes that the caller allocated ZEROED (16-byte aligned;
+ * rows x columns padded to rk_dw3_rows_pad(B) x rk_dw3_cols_pad(h); the padding rows are
+ * rewritten as zeros by every call, the padding columns are never touched). */
+int64_t rk_dw3_planes_bytes(int32_t B, int32_t h);
+int32_t rk_dw3_rows_pad(int32_t B);
+int32_t rk_dw3_cols_pad(int32_t h);
+int rk_ae_encode_fwd_planes(const rk_block_t *blk, int32_t row_off, int32_t B,
+                            const float *W_en, const float *b_en, int32_t h,
+                            const uint8_t *keep, float p, uint64_t seed,
+                            uint64_t rng_step, const int64_t *users, int32_t act,
+                            float *Z0, void *zt_planes, void *stream);
 /* X[rows, cols] fp32 (leading dimension ld) -> three bf16 planes of X^T in the k-contiguous
  * order the kernel above stages: element (k = row, n = col) of plane p at
  * p*rows_pad*cols_pad + ((k/8)*cols_pad + n)*8 + k%8; the padding is written as zeros. */
@@ -325,7 +339,8 @@ int rk_scatter_pos(int32_t *pos, const int64_t *rows, int32_t B, int32_t clear,
 enum { RK_PAR_W_EN = 0, RK_PAR_B_EN = 1, RK_PAR_W_DE = 2, RK_PAR_B_DE = 3, RK_PAR_COUNT = 4 };
 enum { RK_ENTRY_NONE = 0, RK_ENTRY_ENCODE_FWD = 1, RK_ENTRY_DECODE_LOSS = 2,
        RK_ENTRY_DECODE_BWD_DZ = 3, RK_ENTRY_DECODE_BWD_DW = 4, RK_ENTRY_ENCODE_BWD = 5,
-       RK_ENTRY_ADAM_MULTI = 6 };
+       RK_ENTRY_ADAM_MULTI = 6, RK_ENTRY_COUNT = 7,
+       RK_ENTRY_ALL = -1 /* bracket every entry: rk_ae_step_t.time_all */ };
 /* rk_ae_step_t.phase: which part of the step to enqueue (0 = all).  Data parallel
  * callers run FWD_DW, all-reduce the decoder-side gradients, DZ_ENC, all-reduce the
  * encoder side, then UPDATE. */
@@ -392,6 +407,26 @@ typedef struct rk_ae_step {
   /* item-parallel segments only */
   const float *user_norm;    /* [n_users] L2 norm of every user's whole row (by global user id) */
   int32_t own_rank, own_world;
+  void *zt_planes;           /* nullable: rk_dw3_planes_bytes(B_cap, h) bytes, zeroed once: the
+                                encoder forward writes the Z^T planes of the dW kernel there */
+  /* HIP-graph replay (whole steps only): a replayed launch cannot take new arguments, so what
+   * changes per step is derived ON THE DEVICE from cursor = {global index of the next step,
+   * global index of the epoch's first step} (device memory) and this launch's offset in the
+   * replayed group: rng_step = cursor[0] + off + 1, Adam constants = adam_table[(cursor[0] -
+   * cursor[1] + off) * RK_PAR_COUNT + par] (8 floats each, rk_adam_consts), the loss goes to
+   * loss_out[cursor[0] - cursor[1] + off].  cursor == NULL: the host values above are used. */
+  const int64_t *cursor;
+  int32_t cursor_off, pad_;
+  const void *adam_table;
+  void *const *time_all;     /* time_entry == RK_ENTRY_ALL: host array of 2 * RK_ENTRY_COUNT timing
+                                events, entry e is bracketed by [2e] and [2e + 1] */
+  /* Optional second branch (whole untied MSE / BCE steps on the 16-bit pipe): dW only needs dO
+   * and Z, so with stream2 != NULL it is enqueued on stream2 between two event edges (after the
+   * decode, before the Adam sweep) and runs beside dZ -> reduce -> encoder backward.  Inside a
+   * graph capture the edges become graph dependencies.  ws2: a dW workspace of its own
+   * (rk_dw3_workspace_bytes), since `ws` is busy with the dZ slabs meanwhile. */
+  void *stream2, *ev_fork, *ev_join;
+  float *ws2;
 } rk_ae_step_t;
 
 void *rk_event_create(void);          /* ordering-only (no timing, device-scope fence) */
@@ -401,6 +436,30 @@ float rk_event_elapsed_ms(void *ev0, void *ev1);   /* synchronises on ev1 */
 int rk_ae_train_step(const rk_ae_step_t *step);
 
 /*
+ * Graph replay of the hot loop.  rk_collate_at = rk_collate (phase 0) on the users
+ * users_base[(cursor[0] - cursor[1] + off) * S ...] with the stamp of global step cursor[0] + off;
+ * rk_cursor_set / rk_cursor_advance maintain the cursor with 1-thread launches (in order on the
+ * stream, capturable); rk_adam_consts fills one entry of the per-step constants table on the
+ * host.  rk_graph_* wrap hipStreamBeginCapture / EndCapture / hipGraphInstantiate / Launch for a
+ * caller that holds raw hipStream_t values: everything enqueued on `stream` (and on streams
+ * forked from it with events) between begin and end becomes one replayable launch.
+ */
+int rk_collate_at(const int64_t *ds_indptr, const int32_t *ds_indices, const float *ds_data,
+                  const int64_t *users_base, int32_t S, int32_t negative_sampling,
+                  const int64_t *cursor, int32_t off, const rk_block_t *blk, void *stream);
+int rk_cursor_set(int64_t *cursor, int64_t step, int64_t epoch_base, void *stream);
+int rk_cursor_advance(int64_t *cursor, int64_t n, void *stream);
+int rk_adam_consts(double lr, double beta1, double beta2, double eps, double weight_decay,
+                   int32_t step, float *out8_host);
+int rk_graph_begin(void *stream);
+void *rk_graph_end(void *stream);              /* -> executable graph handle, NULL on error */
+int rk_graph_launch(void *graph_exec, void *stream);
+void rk_graph_destroy(void *graph_exec);
+/* cross-stream edges inside a capture (fork / join): event from rk_event_create */
+int rk_event_record(void *event, void *stream);
+int rk_stream_wait_event(void *stream, void *event);
+
+/*
  * rk_topk_masked -- Recoder.recommend (model.py:525-544): scores[B,ld] with the
  * seen items (bits_rc of the non-sampled block) set to -inf, top-k sorted
  * descending (ties: lower index first, as torch.topk on CPU).
@@ -408,6 +467,15 @@ int rk_ae_train_step(const rk_ae_step_t *step);
 int rk_topk_masked(const float *scores, int32_t B, int32_t n, int32_t ld,
                    const rk_block_t *seen, int32_t row_off, int32_t k,
                    int64_t *out_idx, float *out_val, void *stream);
+/* The same on a STRIP of the catalogue: score column c is item col_off + c (mask lookup and
+ * returned indices are global), row r's k results go to out_idx / out_val [r * out_ld ...].  Only
+ * positive stored interactions are masked (model.py:537 `output[input > 0]`).  Recoder.recommend
+ * decodes a bounded strip of items at a time, keeps each strip's top k and merges them with one
+ * more call (seen == NULL) -- the [B, n_items] score matrix never exists. */
+int rk_topk_masked_strip(const float *scores, int32_t B, int32_t n, int32_t ld,
+                         const rk_block_t *seen, int32_t row_off, int32_t k, int32_t col_off,
+                         int64_t *out_idx, float *out_val, int32_t out_ld, void *stream);
+int32_t rk_topk_max_k(void);
 
 #ifdef __cplusplus
 }

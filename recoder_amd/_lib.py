@@ -44,6 +44,7 @@ class RkAdamParam(Structure):
 
 
 PAR_W_EN, PAR_B_EN, PAR_W_DE, PAR_B_DE = 0, 1, 2, 3
+ENTRY_ALL = -1
 ENTRY = {"rk_ae_encode_fwd": 1, "rk_decode_loss": 2, "rk_decode_bwd_dz": 3, "rk_decode_bwd_dw": 4,
          "rk_ae_encode_bwd": 5, "rk_adam_multi": 6}
 
@@ -65,6 +66,10 @@ class RkAeStep(Structure):
     ("time_entry", c_int32), ("phase", c_int32),
     ("time_ev0", c_void_p), ("time_ev1", c_void_p),
     ("user_norm", c_void_p), ("own_rank", c_int32), ("own_world", c_int32),
+    ("zt_planes", c_void_p),
+    ("cursor", c_void_p), ("cursor_off", c_int32), ("pad_", c_int32), ("adam_table", c_void_p),
+    ("time_all", POINTER(c_void_p)),
+    ("stream2", c_void_p), ("ev_fork", c_void_p), ("ev_join", c_void_p), ("ws2", c_void_p),
   ]
 
 
@@ -118,7 +123,12 @@ SIGNATURES = {
   "rk_dw3_max_splits": (c_int32, []),
   "rk_dw3_probe": (None, [_P]),
   "rk_dw3_slabs": (c_void_p, [_P, c_int32, c_int32]),
-  "rk_decode_bwd_dw3": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, _P]),
+  "rk_decode_bwd_dw3": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, _P, _P]),
+  "rk_dw3_planes_bytes": (c_int64, [c_int32, c_int32]),
+  "rk_dw3_rows_pad": (c_int32, [c_int32]),
+  "rk_dw3_cols_pad": (c_int32, [c_int32]),
+  "rk_ae_encode_fwd_planes": (c_int32, [_BLK, c_int32, c_int32, _P, _P, c_int32, _P, c_float, c_uint64,
+                                        c_uint64, _P, c_int32, _P, _P, _P]),
   "rk_split_planes_t": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
   "rk_gemm_split16": (c_int32, []),
   "rk_gemm_probe": (None, [_P]),
@@ -144,7 +154,20 @@ SIGNATURES = {
   "rk_event_destroy": (None, [c_void_p]),
   "rk_event_elapsed_ms": (c_float, [c_void_p, c_void_p]),
   "rk_ae_train_step": (c_int32, [POINTER(RkAeStep)]),
+  "rk_collate_at": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, c_int32, _BLK, _P]),
+  "rk_cursor_set": (c_int32, [_P, c_int64, c_int64, _P]),
+  "rk_cursor_advance": (c_int32, [_P, c_int64, _P]),
+  "rk_adam_consts": (c_int32, [c_double, c_double, c_double, c_double, c_double, c_int32, _P]),
+  "rk_graph_begin": (c_int32, [_P]),
+  "rk_graph_end": (c_void_p, [_P]),
+  "rk_graph_launch": (c_int32, [_P, _P]),
+  "rk_graph_destroy": (None, [_P]),
+  "rk_event_record": (c_int32, [_P, _P]),
+  "rk_stream_wait_event": (c_int32, [_P, _P]),
   "rk_topk_masked": (c_int32, [_P, c_int32, c_int32, c_int32, _BLK, c_int32, c_int32, _P, _P, _P]),
+  "rk_topk_masked_strip": (c_int32, [_P, c_int32, c_int32, c_int32, _BLK, c_int32, c_int32, c_int32, _P, _P,
+                                     c_int32, _P]),
+  "rk_topk_max_k": (c_int32, []),
 }
 
 _lib = None

@@ -28,8 +28,10 @@ constexpr int SEG_WORDS = 2048;           // bitmap words a wave builds in LDS a
 //        (nrow_blk, gridDim.x)    zero bits_cr (capacity-sized, no dependency on n_b)
 __global__ __launch_bounds__(256) void collate_phase1_kernel(
     const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
-    const int64_t *__restrict__ users, int S, int32_t stamp, int all, int nrow_blk, rk_block_t b) {
+    const int64_t *__restrict__ users, int S, int32_t stamp, int all, int nrow_blk, rk_block_t b,
+    rk_cur_t cur) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (cur.cursor) { users += rk_cur_local(cur) * S; stamp = rk_cur_stamp(cur); }
   if ((int)blockIdx.x < nrow_blk) {
     if (all) return;
     const int row = blockIdx.x * 4 + wid;
@@ -89,8 +91,9 @@ __global__ __launch_bounds__(256) void collate_phase1_kernel(
 // ---- count: marked items per chunk (large catalogues) ----
 __global__ __launch_bounds__(256) void collate_count_kernel(
     const int32_t *__restrict__ mark, int n_items, int32_t stamp, int all,
-    int32_t *__restrict__ scan_tmp) {
+    int32_t *__restrict__ scan_tmp, rk_cur_t cur) {
   __shared__ int32_t ws[4];
+  if (cur.cursor) stamp = rk_cur_stamp(cur);
   const int base = blockIdx.x * RK_SCAN_CHUNK;
   int32_t c = 0;
   for (int i = threadIdx.x; i < RK_SCAN_CHUNK; i += 256) {
@@ -108,8 +111,9 @@ __global__ __launch_bounds__(256) void collate_count_kernel(
 __global__ __launch_bounds__(256) void collate_assign_kernel(
     const int32_t *__restrict__ mark, int n_items, int32_t stamp, int all,
     const int32_t *__restrict__ scan_tmp, int n_chunks, int32_t *__restrict__ pos,
-    int32_t *__restrict__ items, int32_t *__restrict__ counts) {
+    int32_t *__restrict__ items, int32_t *__restrict__ counts, rk_cur_t cur) {
   __shared__ int32_t red[4];
+  if (cur.cursor) stamp = rk_cur_stamp(cur);
   __shared__ int32_t wsum[4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   int32_t part = 0;
@@ -157,10 +161,12 @@ __global__ __launch_bounds__(256) void collate_assign_kernel(
 // ---- scan (small catalogues): ONE workgroup does count + assign in one launch ----
 __global__ __launch_bounds__(1024) void collate_scan_small_kernel(
     const int32_t *__restrict__ mark, int n_items, int32_t stamp, int all,
-    int32_t *__restrict__ pos, int32_t *__restrict__ items, int32_t *__restrict__ counts) {
+    int32_t *__restrict__ pos, int32_t *__restrict__ items, int32_t *__restrict__ counts,
+    rk_cur_t cur) {
   __shared__ int32_t wsum[16];
   __shared__ int32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (cur.cursor) stamp = rk_cur_stamp(cur);
   if (tid == 0) carry_s = 0;
   __syncthreads();
   for (int base = 0; base < n_items; base += 4096) {
@@ -207,8 +213,10 @@ __global__ __launch_bounds__(1024) void collate_scan_small_kernel(
 //      written out whole: bits_rc needs no clearing), transposed-bitmap bits ----
 __global__ __launch_bounds__(256) void collate_build_kernel(
     const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
-    const float *__restrict__ ds_data, const int64_t *__restrict__ users, int S, rk_block_t b) {
+    const float *__restrict__ ds_data, const int64_t *__restrict__ users, int S, rk_block_t b,
+    rk_cur_t cur) {
   __shared__ uint32_t wbits[4][SEG_WORDS];
+  if (cur.cursor) users += rk_cur_local(cur) * S;
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + wid;
   if (row >= S) return;
@@ -287,10 +295,10 @@ extern "C" int rk_densify(const rk_block_t *blk, int32_t row_off, int32_t B, int
   return 0;
 }
 
-extern "C" int rk_collate(const int64_t *ds_indptr, const int32_t *ds_indices,
-                          const float *ds_data, const int64_t *users, int32_t S,
-                          int32_t negative_sampling, int32_t stamp, int32_t phase,
-                          const rk_block_t *blk, void *stream_) {
+static int collate_impl(const int64_t *ds_indptr, const int32_t *ds_indices,
+                        const float *ds_data, const int64_t *users, int32_t S,
+                        int32_t negative_sampling, int32_t stamp, int32_t phase,
+                        const rk_block_t *blk, rk_cur_t cur, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(blk != nullptr, "null block");
   RK_REQUIRE(S >= 0 && S <= blk->S_cap, "S exceeds block capacity");
@@ -309,25 +317,67 @@ extern "C" int rk_collate(const int64_t *ds_indptr, const int32_t *ds_indices,
       if (nzero > 512) nzero = 512;
     }
     RK_LAUNCH(collate_phase1_kernel, dim3(nrow_blk + 1 + nzero), dim3(256), 0, stream,
-                       ds_indptr, ds_indices, users, S, stamp, all, nrow_blk, *blk);
+                       ds_indptr, ds_indices, users, S, stamp, all, nrow_blk, *blk, cur);
     RK_CHECK_LAUNCH("collate_phase1");
   }
   if (phase == 1) return 0;
   if (blk->n_items <= SMALL_SCAN_MAX) {
     RK_LAUNCH(collate_scan_small_kernel, dim3(1), dim3(1024), 0, stream, blk->mark,
-                       blk->n_items, stamp, all, blk->pos, blk->items, blk->counts);
+                       blk->n_items, stamp, all, blk->pos, blk->items, blk->counts, cur);
     RK_CHECK_LAUNCH("collate_scan_small");
   } else {
     RK_LAUNCH(collate_count_kernel, dim3(blk->n_chunks), dim3(256), 0, stream,
-                       blk->mark, blk->n_items, stamp, all, blk->scan_tmp);
+                       blk->mark, blk->n_items, stamp, all, blk->scan_tmp, cur);
     RK_CHECK_LAUNCH("collate_count");
     RK_LAUNCH(collate_assign_kernel, dim3(blk->n_chunks), dim3(256), 0, stream,
                        blk->mark, blk->n_items, stamp, all, blk->scan_tmp, blk->n_chunks,
-                       blk->pos, blk->items, blk->counts);
+                       blk->pos, blk->items, blk->counts, cur);
     RK_CHECK_LAUNCH("collate_assign");
   }
   RK_LAUNCH(collate_build_kernel, dim3(rk_cdiv(S, 4)), dim3(256), 0, stream,
-                     ds_indptr, ds_indices, ds_data, users, S, *blk);
+                     ds_indptr, ds_indices, ds_data, users, S, *blk, cur);
   RK_CHECK_LAUNCH("collate_build");
+  return 0;
+}
+
+extern "C" int rk_collate(const int64_t *ds_indptr, const int32_t *ds_indices,
+                          const float *ds_data, const int64_t *users, int32_t S,
+                          int32_t negative_sampling, int32_t stamp, int32_t phase,
+                          const rk_block_t *blk, void *stream_) {
+  const rk_cur_t none = {nullptr, 0};
+  return collate_impl(ds_indptr, ds_indices, ds_data, users, S, negative_sampling, stamp, phase, blk,
+                      none, stream_);
+}
+
+extern "C" int rk_collate_at(const int64_t *ds_indptr, const int32_t *ds_indices,
+                             const float *ds_data, const int64_t *users_base, int32_t S,
+                             int32_t negative_sampling, const int64_t *cursor, int32_t off,
+                             const rk_block_t *blk, void *stream_) {
+  RK_REQUIRE(cursor != nullptr, "null cursor");
+  const rk_cur_t cur = {cursor, off};
+  return collate_impl(ds_indptr, ds_indices, ds_data, users_base, S, negative_sampling, 1, 0, blk, cur,
+                      stream_);
+}
+
+namespace {
+__global__ void cursor_set_kernel(int64_t *cursor, int64_t step, int64_t epoch_base, int64_t add) {
+  if (add) { cursor[0] += add; return; }
+  cursor[0] = step;
+  cursor[1] = epoch_base;
+}
+}  // namespace
+
+extern "C" int rk_cursor_set(int64_t *cursor, int64_t step, int64_t epoch_base, void *stream_) {
+  RK_LAUNCH(cursor_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, cursor, step, epoch_base,
+            (int64_t)0);
+  RK_CHECK_LAUNCH("cursor_set");
+  return 0;
+}
+
+extern "C" int rk_cursor_advance(int64_t *cursor, int64_t n, void *stream_) {
+  RK_REQUIRE(n > 0, "n must be positive");
+  RK_LAUNCH(cursor_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, cursor, (int64_t)0,
+            (int64_t)0, n);
+  RK_CHECK_LAUNCH("cursor_advance");
   return 0;
 }

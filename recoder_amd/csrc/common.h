@@ -30,6 +30,15 @@ void rk_set_error(const char *fmt, ...);
 
 static inline int rk_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// internal entry points shared between translation units (not part of the C ABI)
+int rk_ae_encode_fwd_at(const rk_block_t *blk, int32_t row_off, int32_t B, const float *W_en,
+                        const float *b_en, int32_t h, const uint8_t *keep, float p, uint64_t seed,
+                        const int64_t *cursor, int32_t cursor_off, const int64_t *users, int32_t act,
+                        float *Z0, void *zt_planes, void *stream);
+int rk_adam_multi_at(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part, int32_t n_part,
+                     float denom, float *loss_out, const int64_t *cursor, int32_t cursor_off,
+                     const void *table, int32_t tab_stride, const int32_t *tab_slots, void *stream);
+
 // ---------------------------------------------------------------- activations
 // y = act(x);  derivative expressed through y (what autograd of torch.tanh /
 // sigmoid / relu / selu / elu evaluates to for the saved output).
@@ -79,6 +88,43 @@ __device__ __forceinline__ bool rk_keep_draw(uint64_t seed, uint64_t step, uint6
   // 24 uniform bits -> [0,1)
   float u = (float)(z >> 40) * (1.0f / 16777216.0f);
   return u >= p;
+}
+
+// ------------------------------------------------------- device-resident step cursor
+// HIP-graph replay bakes every kernel argument in; what changes from step to step (which users,
+// which stamp, the RNG step, Adam's bias corrections, where the loss goes) is therefore derived
+// IN the kernels from a cursor in device memory: cursor[0] = global index of the next step,
+// cursor[1] = global index of the first step of the current epoch.  `off` = position of the
+// launch inside the replayed group.  cursor == null: the host-provided values are used as given.
+struct rk_cur_t {
+  const int64_t *cursor;
+  int32_t off;
+};
+__device__ __forceinline__ int64_t rk_cur_global(const rk_cur_t &c) { return c.cursor[0] + c.off; }
+__device__ __forceinline__ int64_t rk_cur_local(const rk_cur_t &c) {
+  return c.cursor[0] - c.cursor[1] + c.off;
+}
+// the collation stamp of global step s (non-zero, unique over 2^30 steps)
+__device__ __forceinline__ int32_t rk_cur_stamp(const rk_cur_t &c) {
+  return (int32_t)(rk_cur_global(c) & 0x3fffffff) + 1;
+}
+
+// --------------------------------------------------- fp32 -> three bf16 pieces
+// (a, b) -> packed bf16 pairs hi / mid / lo with a = hi.x + mid.x + lo.x exactly (same for b):
+// round to nearest at each level, the residuals are exact in fp32 (csrc/dw3.hip)
+typedef __bf16 rk_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float rk_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void rk_split_bf16_pair(float a, float b, uint32_t &h, uint32_t &m,
+                                                   uint32_t &l) {
+  const rk_f32x2 x = {a, b};
+  const rk_bf16x2 hh = __builtin_convertvector(x, rk_bf16x2);
+  const rk_f32x2 r1 = x - __builtin_convertvector(hh, rk_f32x2);
+  const rk_bf16x2 mm = __builtin_convertvector(r1, rk_bf16x2);
+  const rk_f32x2 r2 = r1 - __builtin_convertvector(mm, rk_f32x2);
+  const rk_bf16x2 ll = __builtin_convertvector(r2, rk_bf16x2);
+  h = __builtin_bit_cast(uint32_t, hh);
+  m = __builtin_bit_cast(uint32_t, mm);
+  l = __builtin_bit_cast(uint32_t, ll);
 }
 
 // ------------------------------------------------------------ wave helpers

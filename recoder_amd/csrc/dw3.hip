@@ -15,6 +15,11 @@
 //   * Z [B, h] is small and re-read by every workgroup: it is split ONCE per step into bf16 planes
 //     stored in fragment order -- [plane][k/8][n][8] -- (rk_split_planes_t below) and goes from
 //     L2 straight into the registers of the one wave that owns those columns.
+//   * What bounds the kernel is what a CU can FETCH: ~290 cache lines (128 B) per us and CU from
+//     L2, whatever the path -- an LDS-DMA ring of any depth, register prefetch, a rotated K order
+//     and fp32 instead of pre-split operands were all measured at the same line rate; hence full
+//     lines everywhere, the 64 x 256 tile (Z^T is re-read once per 64 items), no loads for
+//     all-padding columns.
 //   * split-K sized ON THE DEVICE from the live item count (counts[0]); the slabs are consumed by
 //     rk_adam_multi (g_parts read from counts[4]) or summed by slab_sum3.
 #include <algorithm>
@@ -23,23 +28,12 @@
 
 namespace {
 
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-// (a, b) -> packed bf16 pairs hi / mid / lo with a = hi.x + mid.x + lo.x exactly (same for b)
 __device__ __forceinline__ void split_pair(float a, float b, uint32_t &h, uint32_t &m, uint32_t &l) {
-  const f32x2 x = {a, b};
-  const bf16x2 hh = __builtin_convertvector(x, bf16x2);
-  const f32x2 r1 = x - __builtin_convertvector(hh, f32x2);
-  const bf16x2 mm = __builtin_convertvector(r1, bf16x2);
-  const f32x2 r2 = r1 - __builtin_convertvector(mm, f32x2);
-  const bf16x2 ll = __builtin_convertvector(r2, bf16x2);
-  h = __builtin_bit_cast(uint32_t, hh);
-  m = __builtin_bit_cast(uint32_t, mm);
-  l = __builtin_bit_cast(uint32_t, ll);
+  rk_split_bf16_pair(a, b, h, m, l);
 }
 
 // X[rows, cols] fp32 (row-major, ld) -> bf16 planes [3][rows_pad/8][cols_pad][8] of X^T's
@@ -196,15 +190,21 @@ __global__ __launch_bounds__(512) void dw3_kernel(Dw3P p) {
   const int nk = 2 * na;
   const uint16_t *b_src = p.planes + ((int64_t)((kbeg >> 3) + lh) * p.cols_pad + n0 + wn * 32 + l31) * 8;
   const int64_t b_step = (int64_t)2 * p.cols_pad * 8;
+  // (a wave whose 32 columns all lie past h -- h = 200: the last of the eight -- neither loads
+  // nor multiplies: the fetch rate is what bounds the kernel)
+  const bool wave_live = n0 + wn * 32 < p.h;
   auto loadB = [&](uint4 (&dst)[3], int kt) {
     const uint16_t *q = b_src + (int64_t)(2 * stage_of(kt >> 1) + (kt & 1)) * b_step;
+    if (wave_live) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) dst[pl] = *reinterpret_cast<const uint4 *>(q + pl * p.plane_stride);
+      for (int pl = 0; pl < 3; ++pl) dst[pl] = *reinterpret_cast<const uint4 *>(q + pl * p.plane_stride);
+    }
   };
 
   auto compute = [&](int buf, int ks, const uint4 (&b)[3]) {
     const bf16x8 Bh = __builtin_bit_cast(bf16x8, b[0]), Bm = __builtin_bit_cast(bf16x8, b[1]),
                  Bl = __builtin_bit_cast(bf16x8, b[2]);
+    if (!wave_live) return;
     bf16x8 Ah[MT], Am[MT], Al[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
@@ -336,9 +336,13 @@ extern "C" int rk_split_planes_t(const float *X, int32_t rows, int32_t cols, int
 }
 
 // G_de[n_t,h] = dO^T . Z on the bf16 pipe (see the head of this file and recoder_hip.h)
+extern "C" int64_t rk_dw3_planes_bytes(int32_t B, int32_t h) { return dw3_plane_bytes(B, h); }
+extern "C" int32_t rk_dw3_cols_pad(int32_t h) { return dw3_cols_pad(h); }
+extern "C" int32_t rk_dw3_rows_pad(int32_t B) { return dw3_rows_pad(B); }
+
 extern "C" int rk_decode_bwd_dw3(const float *dO, const float *Z, int32_t B, int32_t h,
                                  const rk_block_t *tgt, float *G_de, float *gb_de, void *workspace,
-                                 void *stream_) {
+                                 const void *zt_planes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(h > 0 && h % 4 == 0, "h must be a multiple of 4");
   RK_REQUIRE(workspace != nullptr && (((uintptr_t)workspace) & 255) == 0, "workspace: 256-byte aligned");
@@ -347,11 +351,17 @@ extern "C" int rk_decode_bwd_dw3(const float *dO, const float *Z, int32_t B, int
   const int bn = dw3_bn(h);
   const int cols_pad = dw3_cols_pad(h), Bp = dw3_rows_pad(B);
   const int64_t planes_b = (dw3_plane_bytes(B, h) + 255) & ~(int64_t)255;
-  int rc = rk_split_planes_t(Z, B, h, h, Bp, cols_pad, workspace, stream_);
-  if (rc) return rc;
+  // Z^T planes: the caller's (rk_ae_encode_fwd_planes wrote them with Z) or made here
+  if (zt_planes == nullptr) {
+    RK_REQUIRE(Z != nullptr, "Z or zt_planes");
+    int rc = rk_split_planes_t(Z, B, h, h, Bp, cols_pad, workspace, stream_);
+    if (rc) return rc;
+    zt_planes = workspace;
+  }
+  RK_REQUIRE((((uintptr_t)zt_planes) & 15) == 0, "zt_planes must be 16-byte aligned");
   Dw3P p = {};
   p.dO = dO; p.counts = tgt->counts;
-  p.planes = (const uint16_t *)workspace; p.plane_stride = (int64_t)Bp * cols_pad;
+  p.planes = (const uint16_t *)zt_planes; p.plane_stride = (int64_t)Bp * cols_pad;
   p.cols_pad = cols_pad; p.B = B; p.Bp = Bp; p.h = h;
   p.tiles_n = cols_pad / bn; p.max_splits = DW3_MAX_SPLITS;
   p.G = G_de; p.slabs = (float *)((char *)workspace + planes_b);

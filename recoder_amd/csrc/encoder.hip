@@ -22,11 +22,26 @@ __global__ __launch_bounds__(256) void ae_encode_fwd_kernel(
     rk_block_t b, int row_off, int B, const float *__restrict__ W, const float *__restrict__ bias,
     int h, const uint8_t *__restrict__ keep, float p, float scale, uint64_t seed,
     uint64_t rng_step, const int64_t *__restrict__ users, const float *__restrict__ user_norm,
-    int act, float *__restrict__ Z0) {
+    int act, float *__restrict__ Z0, uint16_t *__restrict__ planes, int64_t plane_stride,
+    int cols_pad, rk_cur_t cur) {
   __shared__ float red[4];
+  if (cur.cursor) {          // graph replay (common.h): the step's RNG index and user ids
+    rng_step = (uint64_t)(rk_cur_global(cur) + 1);
+    if (users) users += rk_cur_local(cur) * B;       // (replayed steps are whole batches: S == B)
+  }
   __shared__ __attribute__((aligned(16))) float part[3][HV * 256];
   const int r = blockIdx.x;            // row within the slice
-  if (r >= B) return;
+  if (r >= B) {
+    // planes != null: the grid covers the rows up to the next multiple of 64; the padding rows
+    // of the Z^T planes are (re)written as zeros (the dW kernel's K padding relies on it)
+    if (planes) {
+      for (int n = threadIdx.x; n < h; n += 256) {
+        const int64_t o = ((int64_t)(r >> 3) * cols_pad + n) * 8 + (r & 7);
+        planes[o] = 0; planes[o + plane_stride] = 0; planes[o + 2 * plane_stride] = 0;
+      }
+    }
+    return;
+  }
   const int row = row_off + r;         // row within the block
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int beg = b.indptr[row], end = b.indptr[row + 1];
@@ -144,6 +159,22 @@ __global__ __launch_bounds__(256) void ae_encode_fwd_kernel(
         y.z = rk_act(a.z + bb.z, act);
         y.w = rk_act(a.w + bb.w, act);
         *reinterpret_cast<float4 *>(Z0 + (int64_t)r * h + hh) = y;
+        if (planes) {
+          // Z^T as three bf16 planes in the fragment order of the dW kernel (csrc/dw3.hip):
+          // element (k = r, n) at ((k/8)*cols_pad + n)*8 + k%8 -- written here, with the value
+          // still in registers, instead of by a pass of its own
+          uint32_t hp[2], mp[2], lp[2];
+          rk_split_bf16_pair(y.x, y.y, hp[0], mp[0], lp[0]);
+          rk_split_bf16_pair(y.z, y.w, hp[1], mp[1], lp[1]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int64_t o = ((int64_t)(r >> 3) * cols_pad + hh + e) * 8 + (r & 7);
+            const int sh = (e & 1) * 16;
+            planes[o] = (uint16_t)(hp[e >> 1] >> sh);
+            planes[o + plane_stride] = (uint16_t)(mp[e >> 1] >> sh);
+            planes[o + 2 * plane_stride] = (uint16_t)(lp[e >> 1] >> sh);
+          }
+        }
       }
     }
   }
@@ -161,7 +192,8 @@ __global__ __launch_bounds__(256) void ae_encode_bwd_kernel(
 static int encode_fwd_launch(const rk_block_t *blk, int32_t row_off, int32_t B, const float *W_en,
                              const float *b_en, int32_t h, const uint8_t *keep, float p,
                              uint64_t seed, uint64_t rng_step, const int64_t *users,
-                             const float *user_norm, int32_t act, float *Z0, void *stream_) {
+                             const float *user_norm, int32_t act, float *Z0, void *stream_,
+                             void *zt_planes = nullptr, rk_cur_t cur = {nullptr, 0}) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(h > 0 && h % 4 == 0 && h <= 1024, "h must be a multiple of 4, <= 1024");
   RK_REQUIRE(p >= 0.f && p < 1.f, "noise_prob must be in [0,1)");
@@ -171,9 +203,13 @@ static int encode_fwd_launch(const rk_block_t *blk, int32_t row_off, int32_t B, 
   // ATen dropout: noise = bernoulli(1-p) / (1-p), computed in fp32
   const float scale = 1.0f / (float)(1.0 - (double)p);
   const int hv = rk_cdiv(h, 256);
+  const int rows = zt_planes ? rk_dw3_rows_pad(B) : B;
+  const int cols_pad = rk_dw3_cols_pad(h);
+  const int64_t plane_stride = (int64_t)rk_dw3_rows_pad(B) * cols_pad;
 #define LAUNCH(HV)                                                                         \
-  RK_LAUNCH(ae_encode_fwd_kernel<HV>, dim3(B), dim3(256), 0, stream, *blk, row_off, \
-                     B, W_en, b_en, h, keep, p, scale, seed, rng_step, users, user_norm, act, Z0)
+  RK_LAUNCH(ae_encode_fwd_kernel<HV>, dim3(rows), dim3(256), 0, stream, *blk, row_off, \
+                     B, W_en, b_en, h, keep, p, scale, seed, rng_step, users, user_norm, act, Z0, \
+                     (uint16_t *)zt_planes, plane_stride, cols_pad, cur)
   if (hv == 1) LAUNCH(1); else if (hv == 2) LAUNCH(2); else LAUNCH(4);
 #undef LAUNCH
   RK_CHECK_LAUNCH("ae_encode_fwd");
@@ -187,6 +223,28 @@ extern "C" int rk_ae_encode_fwd(const rk_block_t *blk, int32_t row_off, int32_t 
   RK_REQUIRE(b_en != nullptr, "b_en is required");
   return encode_fwd_launch(blk, row_off, B, W_en, b_en, h, keep, p, seed, rng_step, users, nullptr,
                            act, Z0, stream_);
+}
+
+extern "C" int rk_ae_encode_fwd_planes(const rk_block_t *blk, int32_t row_off, int32_t B,
+                                       const float *W_en, const float *b_en, int32_t h,
+                                       const uint8_t *keep, float p, uint64_t seed, uint64_t rng_step,
+                                       const int64_t *users, int32_t act, float *Z0, void *zt_planes,
+                                       void *stream_) {
+  RK_REQUIRE(b_en != nullptr, "b_en is required");
+  RK_REQUIRE(zt_planes != nullptr && (((uintptr_t)zt_planes) & 15) == 0, "zt_planes: 16-byte aligned");
+  return encode_fwd_launch(blk, row_off, B, W_en, b_en, h, keep, p, seed, rng_step, users, nullptr,
+                           act, Z0, stream_, zt_planes);
+}
+
+// rk_ae_encode_fwd(_planes) for graph replay: the dropout RNG step is cursor[0] + off + 1, read
+// on the device (zt_planes nullable)
+int rk_ae_encode_fwd_at(const rk_block_t *blk, int32_t row_off, int32_t B, const float *W_en,
+                        const float *b_en, int32_t h, const uint8_t *keep, float p, uint64_t seed,
+                        const int64_t *cursor, int32_t cursor_off, const int64_t *users, int32_t act,
+                        float *Z0, void *zt_planes, void *stream_) {
+  const rk_cur_t cur = {cursor, cursor_off};
+  return encode_fwd_launch(blk, row_off, B, W_en, b_en, h, keep, p, seed, 0, users, nullptr, act, Z0,
+                           stream_, zt_planes, cur);
 }
 
 extern "C" int rk_ae_encode_fwd_partial(const rk_block_t *blk, int32_t row_off, int32_t B,
@@ -206,8 +264,8 @@ extern "C" int rk_ae_encode_bwd(const rk_block_t *blk, int32_t row_off, int32_t 
   RK_REQUIRE(blk->bits_cr != nullptr && blk->pref_rc != nullptr,
              "block was built without the transposed bitmap / prefix index");
   const int n_gb = gb_en ? rk_cdiv(h, 64) : 0;
-  const int grid = blk->n_cap + n_gb;
   const int hv = rk_cdiv(h, 256);
+  const int grid = blk->n_cap + n_gb;
 #define LAUNCH(HV)                                                                           \
   RK_LAUNCH(ae_encode_bwd_kernel<HV>, dim3(grid), dim3(256), 0, stream, *blk, row_off, \
                      B, dZ0pre, h, G_en, accumulate, gb_en, n_gb)

@@ -11,6 +11,8 @@
 // SparseAdam: torch.optim.SparseAdam (`_functional.sparse_adam`) on the touched
 //            rows only (model.py:138,401-402): no weight decay, eps added to
 //            the raw sqrt, bias correction folded into the step size.
+#include <string.h>
+
 #include "common.h"
 
 namespace {
@@ -196,6 +198,7 @@ struct UJob {
   const int32_t *gparts_dev;   // device-resident number of gradient parts (or null: g_parts)
   int n_rows, h, g_parts, g_stride, sparse, blk0, nblk;
   int row0, row_step;          // the job covers rows row0, row0 + row_step, ... (owned rows)
+  int tab_slot;                // >= 0: the constants come from the device table (UArgs.ctab)
   AdamC c;
 };
 
@@ -206,6 +209,11 @@ struct UArgs {
   int n_part;
   float denom;
   float *loss_out;
+  // graph replay (rk_cur_t, common.h): per-step constants table [step in epoch][tab_stride] and
+  // the loss slot loss_out[step in epoch]
+  rk_cur_t cur;
+  const AdamC *ctab;
+  int tab_stride;
 };
 
 template <typename T> struct VecOps;
@@ -237,7 +245,7 @@ template <> struct VecOps<float> {
 };
 
 template <typename T>
-__device__ __forceinline__ void update_job(const UJob &J, int lb) {
+__device__ __forceinline__ void update_job(const UJob &J, int lb, const AdamC &C) {
   using V = VecOps<T>;
   const int hq = J.h / V::W;
   const int64_t stride = J.gstride_dev ? (int64_t)*J.gstride_dev : (int64_t)J.g_stride;
@@ -254,7 +262,7 @@ __device__ __forceinline__ void update_job(const UJob &J, int lb) {
       for (int t = 1; t < g_parts; ++t)
         V::add(g, *reinterpret_cast<const T *>(J.g + t * stride + i * V::W));
       T p1 = P[o], m1 = M[o], v1 = Vv[o];
-      V::sadam(p1, m1, v1, g, J.c);
+      V::sadam(p1, m1, v1, g, C);
       P[o] = p1; M[o] = m1; Vv[o] = v1;
     }
     return;
@@ -291,14 +299,16 @@ __device__ __forceinline__ void update_job(const UJob &J, int lb) {
         V::add(g, *reinterpret_cast<const T *>(J.g + t * stride + go));
     }
     T p1 = P[e], m1 = M[e], v1 = Vv[e];
-    V::adam(p1, m1, v1, g, J.c);
+    V::adam(p1, m1, v1, g, C);
     P[e] = p1; M[e] = m1; Vv[e] = v1;
   }
 }
 
-__device__ __forceinline__ void run_job(const UJob &J, int b) {
-  if ((J.h & 3) == 0) update_job<float4>(J, b - J.blk0);
-  else update_job<float>(J, b - J.blk0);
+__device__ __forceinline__ void run_job(const UJob &J, int b, const UArgs &a) {
+  AdamC C = J.c;
+  if (a.ctab && J.tab_slot >= 0) C = a.ctab[rk_cur_local(a.cur) * a.tab_stride + J.tab_slot];
+  if ((J.h & 3) == 0) update_job<float4>(J, b - J.blk0, C);
+  else update_job<float>(J, b - J.blk0, C);
 }
 
 __global__ __launch_bounds__(256) void adam_multi_kernel(UArgs a) {
@@ -329,17 +339,17 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(UArgs a) {
       if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
       __syncthreads();
     }
-    if (threadIdx.x == 0) a.loss_out[0] = (float)red[0] / a.denom;
+    if (threadIdx.x == 0) a.loss_out[a.cur.cursor ? rk_cur_local(a.cur) : 0] = (float)red[0] / a.denom;
     return;
     }
   }
   // static indices only (a dynamically indexed by-value struct would go to scratch)
-  if (a.n_jobs > 5 && b >= a.job[5].blk0) run_job(a.job[5], b);
-  else if (a.n_jobs > 4 && b >= a.job[4].blk0) run_job(a.job[4], b);
-  else if (a.n_jobs > 3 && b >= a.job[3].blk0) run_job(a.job[3], b);
-  else if (a.n_jobs > 2 && b >= a.job[2].blk0) run_job(a.job[2], b);
-  else if (a.n_jobs > 1 && b >= a.job[1].blk0) run_job(a.job[1], b);
-  else run_job(a.job[0], b);
+  if (a.n_jobs > 5 && b >= a.job[5].blk0) run_job(a.job[5], b, a);
+  else if (a.n_jobs > 4 && b >= a.job[4].blk0) run_job(a.job[4], b, a);
+  else if (a.n_jobs > 3 && b >= a.job[3].blk0) run_job(a.job[3], b, a);
+  else if (a.n_jobs > 2 && b >= a.job[2].blk0) run_job(a.job[2], b, a);
+  else if (a.n_jobs > 1 && b >= a.job[1].blk0) run_job(a.job[1], b, a);
+  else run_job(a.job[0], b, a);
 }
 
 AdamC make_consts(double lr, double b1, double b2, double eps, double wd, int step) {
@@ -414,8 +424,12 @@ extern "C" int rk_adam_dense(float *p, float *m, float *v, const float *g, int64
   return 0;
 }
 
-extern "C" int rk_adam_multi(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part,
-                             int32_t n_part, float denom, float *loss_out, void *stream_) {
+// cursor / table: graph replay -- job j takes its constants from table[(step in epoch) *
+// tab_stride + tab_slots[j]] (tab_slots[j] < 0: its own par) and the loss goes to
+// loss_out[step in epoch]
+int rk_adam_multi_at(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part, int32_t n_part,
+                     float denom, float *loss_out, const int64_t *cursor, int32_t cursor_off,
+                     const void *table, int32_t tab_stride, const int32_t *tab_slots, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(n_jobs >= 0 && n_jobs <= RK_ADAM_MULTI_MAX, "too many jobs for one launch");
   RK_REQUIRE(n_jobs == 0 || jobs != nullptr, "null jobs");
@@ -447,6 +461,7 @@ extern "C" int rk_adam_multi(const rk_adam_job_t *jobs, int32_t n_jobs, float *l
     d.n_rows = s.n_rows; d.h = s.h; d.g_parts = s.g_parts; d.g_stride = s.g_stride;
     d.sparse = s.par.sparse ? 1 : 0;
     d.row0 = s.row0; d.row_step = row_step;
+    d.tab_slot = (table && tab_slots) ? tab_slots[j] : -1;
     d.c = make_consts(s.par.lr, s.par.beta1, s.par.beta2, s.par.eps,
                       s.par.sparse ? 0.0 : s.par.weight_decay, s.par.step);
     d.blk0 = blocks;
@@ -460,8 +475,27 @@ extern "C" int rk_adam_multi(const rk_adam_job_t *jobs, int32_t n_jobs, float *l
   }
   if (blocks == 0) return 0;
   if (a.n_jobs == 0) { a.n_jobs = 1; a.job[0].nblk = 0; a.job[0].h = 1; }   // loss only
+  a.cur.cursor = cursor; a.cur.off = cursor_off;
+  a.ctab = (const AdamC *)table; a.tab_stride = tab_stride;
   RK_LAUNCH(adam_multi_kernel, dim3(blocks), dim3(256), 0, stream, a);
   RK_CHECK_LAUNCH("adam_multi");
+  return 0;
+}
+
+extern "C" int rk_adam_multi(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part,
+                             int32_t n_part, float denom, float *loss_out, void *stream_) {
+  return rk_adam_multi_at(jobs, n_jobs, loss_part, n_part, denom, loss_out, nullptr, 0, nullptr, 0,
+                          nullptr, stream_);
+}
+
+// one entry of the per-step constants table (8 floats): exactly what rk_adam_multi derives from
+// the same hyper-parameters for step `step`
+extern "C" int rk_adam_consts(double lr, double beta1, double beta2, double eps, double weight_decay,
+                              int32_t step, float *out8) {
+  RK_REQUIRE(step >= 1 && out8 != nullptr, "step >= 1, out8 != NULL");
+  static_assert(sizeof(AdamC) == 32, "AdamC is 8 floats");
+  const AdamC c = make_consts(lr, beta1, beta2, eps, weight_decay, step);
+  memcpy(out8, &c, sizeof(c));
   return 0;
 }
 

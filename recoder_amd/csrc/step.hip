@@ -38,19 +38,80 @@ extern "C" float rk_event_elapsed_ms(void *e0, void *e1) {
   return ms;
 }
 
+extern "C" int rk_event_record(void *event, void *stream) {
+  if (hipEventRecord((hipEvent_t)event, (hipStream_t)stream) != hipSuccess) {
+    rk_set_error("hipEventRecord failed");
+    return -1;
+  }
+  return 0;
+}
+
+extern "C" int rk_stream_wait_event(void *stream, void *event) {
+  if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0) != hipSuccess) {
+    rk_set_error("hipStreamWaitEvent failed");
+    return -1;
+  }
+  return 0;
+}
+
+extern "C" int rk_graph_begin(void *stream) {
+  // relaxed mode: other threads (torch's allocator, a second virtual rank) may call into HIP
+  const hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed);
+  if (e != hipSuccess) {
+    rk_set_error("hipStreamBeginCapture: %s", hipGetErrorString(e));
+    return -1;
+  }
+  return 0;
+}
+
+extern "C" void *rk_graph_end(void *stream) {
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture((hipStream_t)stream, &graph);
+  if (e != hipSuccess || graph == nullptr) {
+    rk_set_error("hipStreamEndCapture: %s", hipGetErrorString(e));
+    return nullptr;
+  }
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) {
+    rk_set_error("hipGraphInstantiate: %s", hipGetErrorString(e));
+    return nullptr;
+  }
+  // move the executable graph to the device now, not inside its first (timed) launch
+  (void)hipGraphUpload(exec, (hipStream_t)stream);
+  (void)hipGetLastError();
+  return (void *)exec;
+}
+
+extern "C" int rk_graph_launch(void *graph_exec, void *stream) {
+  const hipError_t e = hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream);
+  if (e != hipSuccess) {
+    rk_set_error("hipGraphLaunch: %s", hipGetErrorString(e));
+    return -1;
+  }
+  return 0;
+}
+
+extern "C" void rk_graph_destroy(void *graph_exec) {
+  if (graph_exec) (void)hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+}
+
 namespace {
 
 struct Timer {
-  const rk_ae_step_t *a;
-  int id;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
   hipStream_t s;
-  bool on;
-  Timer(const rk_ae_step_t *a_, int id_, void *stream) : a(a_), id(id_), s((hipStream_t)stream) {
-    on = (a->time_entry == id) && a->time_ev0 && a->time_ev1;
-    if (on) (void)hipEventRecord((hipEvent_t)a->time_ev0, s);
+  Timer(const rk_ae_step_t *a, int id, void *stream) : s((hipStream_t)stream) {
+    if (a->time_entry == id && a->time_ev0 && a->time_ev1) {
+      e0 = (hipEvent_t)a->time_ev0; e1 = (hipEvent_t)a->time_ev1;
+    } else if (a->time_entry == RK_ENTRY_ALL && a->time_all) {
+      e0 = (hipEvent_t)a->time_all[2 * id]; e1 = (hipEvent_t)a->time_all[2 * id + 1];
+    }
+    if (e0) (void)hipEventRecord(e0, s);
   }
   ~Timer() {
-    if (on) (void)hipEventRecord((hipEvent_t)a->time_ev1, s);
+    if (e1) (void)hipEventRecord(e1, s);
   }
 };
 
@@ -73,9 +134,11 @@ rk_adam_job_t table_job(const rk_adam_param_t &par, const rk_block_t *blk, int n
 // dW = dO^T . Z: the bf16-pipe kernel (dw3.hip) when the split contractions are on and the step
 // has a workspace, else the fp32-MFMA tiles.  G_de == NULL (dw3 only): the K slabs stay in the
 // workspace for rk_adam_multi.
-int dw_call(const rk_ae_step_t *a, float *G_de, float *gb_de) {
+int dw_call(const rk_ae_step_t *a, float *G_de, float *gb_de, bool have_planes,
+            float *ws = nullptr, void *stream = nullptr) {
   if (rk_gemm_split16() && a->ws)
-    return rk_decode_bwd_dw3(a->dO, a->Z0, a->B, a->h, a->blk, G_de, gb_de, a->ws, a->stream);
+    return rk_decode_bwd_dw3(a->dO, a->Z0, a->B, a->h, a->blk, G_de, gb_de, ws ? ws : a->ws,
+                             have_planes ? a->zt_planes : nullptr, stream ? stream : a->stream);
   return rk_decode_bwd_dw(a->dO, a->Z0, a->B, a->h, a->blk, G_de, gb_de, a->stream);
 }
 
@@ -106,6 +169,7 @@ static int step_item_parallel(const rk_ae_step_t *a, int phase) {
   const float *W_de = a->tied ? a->par[RK_PAR_W_EN].p : a->par[RK_PAR_W_DE].p;
   float *G_en = a->tied ? a->G_de : a->G_en;
   const int n_part = mnll ? B : rk_loss_partials(B, blk->n_cap);
+  const bool planes = false;     // (the partial encoder sums are not Z yet)
   RK_REQUIRE(a->own_world >= 1 && a->own_rank >= 0 && a->own_rank < a->own_world, "bad ownership");
   // the softmax of the multinomial loss spans every target item of a row, i.e. all ranks
   RK_REQUIRE(!mnll, "item-parallel training supports the mse / logistic losses");
@@ -131,7 +195,7 @@ static int step_item_parallel(const rk_ae_step_t *a, int phase) {
   const int dw_slabs = (a->tied || mnll || a->ws == nullptr) ? 1 : rk_dw_splits(B);
   if (phase & RK_STEP_IP_TAIL) {
     if (a->tied || mnll) {
-      RK_TRY(dw_call(a, a->G_de, mnll ? a->gb_de : nullptr));
+      RK_TRY(dw_call(a, a->G_de, mnll ? a->gb_de : nullptr, planes));
       RK_TRY(rk_ae_encode_bwd(blk, a->row_off, B, a->dZ0, h, G_en, a->tied ? 1 : 0, a->gb_en, sm));
     } else {
       // large global batches: dW comes out as K slabs; rk_adam_multi sums them in slab order
@@ -176,6 +240,7 @@ static int step_item_parallel(const rk_ae_step_t *a, int phase) {
 extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   RK_REQUIRE(a && a->blk, "null step / block");
   RK_REQUIRE(a->phase >= 0 && a->phase <= 63, "phase is a mask of RK_STEP_*");
+  RK_REQUIRE(a->time_entry >= RK_ENTRY_ALL && a->time_entry < RK_ENTRY_COUNT, "time_entry");
   if (a->phase & RK_STEP_IP_ALL) {
     RK_REQUIRE((a->phase & RK_STEP_ALL) == 0, "item-parallel and data-parallel phases do not mix");
     return step_item_parallel(a, a->phase);
@@ -193,12 +258,26 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   // whole untied MSE / BCE steps on the 16-bit pipe: dW as its own bf16-pipe launch (slabs summed
   // by the Adam sweep) + the plain encoder backward; otherwise the fused fp32 dW || encoder launch
   const bool dw3 = whole && !(a->tied || mnll) && rk_gemm_split16() && a->ws != nullptr;
+  // the encoder forward writes the Z^T planes of the bf16-pipe dW kernel along with Z
+  const bool planes = rk_gemm_split16() && a->ws != nullptr && a->zt_planes != nullptr &&
+                      (phase & RK_STEP_FWD_DW) != 0;
+  const bool branch = dw3 && a->stream2 != nullptr && a->ev_fork != nullptr && a->ev_join != nullptr &&
+                      a->ws2 != nullptr;
 
   if (phase & RK_STEP_FWD_DW) {
     {
       Timer t(a, RK_ENTRY_ENCODE_FWD, sm);
-      RK_TRY(rk_ae_encode_fwd(blk, a->row_off, B, a->par[RK_PAR_W_EN].p, a->par[RK_PAR_B_EN].p, h,
-                              a->keep, a->noise_p, a->seed, a->rng_step, a->users, a->act, a->Z0, sm));
+      if (a->cursor)
+        RK_TRY(rk_ae_encode_fwd_at(blk, a->row_off, B, a->par[RK_PAR_W_EN].p, a->par[RK_PAR_B_EN].p, h,
+                                   a->keep, a->noise_p, a->seed, a->cursor, a->cursor_off, a->users,
+                                   a->act, a->Z0, planes ? a->zt_planes : nullptr, sm));
+      else if (planes)
+        RK_TRY(rk_ae_encode_fwd_planes(blk, a->row_off, B, a->par[RK_PAR_W_EN].p, a->par[RK_PAR_B_EN].p,
+                                       h, a->keep, a->noise_p, a->seed, a->rng_step, a->users, a->act,
+                                       a->Z0, a->zt_planes, sm));
+      else
+        RK_TRY(rk_ae_encode_fwd(blk, a->row_off, B, a->par[RK_PAR_W_EN].p, a->par[RK_PAR_B_EN].p, h,
+                                a->keep, a->noise_p, a->seed, a->rng_step, a->users, a->act, a->Z0, sm));
     }
     {
       Timer t(a, RK_ENTRY_DECODE_LOSS, sm);
@@ -206,12 +285,19 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
                             a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, sm));
       if (mnll) RK_TRY(rk_mnll_finish(a->dO, B, blk, a->row_off, a->inv_B, a->loss_part, sm));
     }
+    if (branch) {
+      // second branch: dW beside dZ -> reduce -> encoder backward (joined before the Adam sweep)
+      RK_TRY(rk_event_record(a->ev_fork, sm));
+      RK_TRY(rk_stream_wait_event(a->stream2, a->ev_fork));
+      RK_TRY(dw_call(a, nullptr, nullptr, planes, a->ws2, a->stream2));
+      RK_TRY(rk_event_record(a->ev_join, a->stream2));
+    }
     // dW: on its own (tied weights: the encoder backward accumulates onto its rows;
     // MNLL: + column sums of dO; data parallel: G_de must travel early), otherwise
     // fused with the encoder backward below
     if (a->tied || mnll || !whole) {
       Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
-      RK_TRY(dw_call(a, a->G_de, mnll ? a->gb_de : nullptr));
+      RK_TRY(dw_call(a, a->G_de, mnll ? a->gb_de : nullptr, planes));
     }
     if (!whole) {
       // the data-parallel exchange needs gb_de and the loss scalar as arrays of their own
@@ -230,9 +316,9 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     } else if (dw3) {
       // the dZ slabs in the workspace are consumed: the bf16-pipe dW takes it over (Z^T planes +
       // its own K slabs, which rk_adam_multi sums while it reads the gradient)
-      {
+      if (!branch) {
         Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
-        RK_TRY(dw_call(a, nullptr, nullptr));
+        RK_TRY(dw_call(a, nullptr, nullptr, planes));
       }
       Timer t(a, RK_ENTRY_ENCODE_BWD, sm);
       RK_TRY(rk_ae_encode_bwd(blk, a->row_off, B, a->dZ0, h, G_en, 0, a->gb_en, sm));
@@ -244,7 +330,9 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   }
   if (phase & RK_STEP_UPDATE) {
     rk_adam_job_t jobs[4];
+    int32_t slots[4];
     int n = 0;
+    slots[n] = RK_PAR_W_EN;
     jobs[n++] = table_job(a->par[RK_PAR_W_EN], blk, n_items, h, G_en, true);
     if (whole && !(a->tied || mnll) && !dw3) {   // the fused launch wrote G_en in row segments
       jobs[0].g_parts = rk_encode_bwd_segments(B); jobs[0].g_stride = blk->n_cap * h;
@@ -252,25 +340,32 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     if (!a->tied) {
       jobs[n] = table_job(a->par[RK_PAR_W_DE], blk, n_items, h, a->G_de, true);
       if (dw3) {
-        jobs[n].g = rk_dw3_slabs(a->ws, B, h); jobs[n].g_parts = rk_dw3_max_splits();
+        jobs[n].g = rk_dw3_slabs(branch ? a->ws2 : a->ws, B, h); jobs[n].g_parts = rk_dw3_max_splits();
         jobs[n].g_stride = blk->n_cap * h; jobs[n].gparts_dev = blk->counts + 4;
       }
+      slots[n] = RK_PAR_W_DE;
       ++n;
     }
+    slots[n] = RK_PAR_B_DE;
     jobs[n] = table_job(a->par[RK_PAR_B_DE], blk, n_items, 1, a->gb_de, true);
     jobs[n].par.sparse = 0; jobs[n].rows = nullptr; jobs[n].n_dev = nullptr; jobs[n].pos = blk->pos;
     if (whole && !mnll) {          // straight from the decode epilogue's row-tile partials
       jobs[n].g = a->gb_part; jobs[n].g_parts = row_tiles; jobs[n].gstride_dev = blk->counts + 2;
     }
     ++n;
+    slots[n] = RK_PAR_B_EN;
     jobs[n] = table_job(a->par[RK_PAR_B_EN], blk, 1, h, a->gb_en, false);
     if (whole && !(a->tied || mnll) && !dw3) {
       jobs[n].g_parts = rk_encode_bwd_segments(B); jobs[n].g_stride = h;
     }
     ++n;
+    RK_REQUIRE(a->cursor == nullptr || (whole && a->adam_table != nullptr),
+               "graph replay covers whole steps and needs the Adam constants table");
+    if (branch) RK_TRY(rk_stream_wait_event(sm, a->ev_join));
     Timer t(a, RK_ENTRY_ADAM_MULTI, sm);
-    RK_TRY(rk_adam_multi(jobs, n, whole ? a->loss_part : nullptr, n_part, a->denom,
-                         whole ? a->loss_out : nullptr, sm));
+    RK_TRY(rk_adam_multi_at(jobs, n, whole ? a->loss_part : nullptr, n_part, a->denom,
+                            whole ? a->loss_out : nullptr, a->cursor, a->cursor_off, a->adam_table,
+                            RK_PAR_COUNT, slots, sm));
   }
   return 0;
 }

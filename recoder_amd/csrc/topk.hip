@@ -22,7 +22,7 @@ __device__ __forceinline__ float key2f(uint32_t k) {
 __global__ __launch_bounds__(256) void topk_masked_kernel(const float *scores, int n, int ld,
                                                           rk_block_t seen, int has_seen,
                                                           int row_off, int k, int64_t *out_idx,
-                                                          float *out_val) {
+                                                          float *out_val, int col_off, int out_ld) {
   __shared__ uint32_t hist[256];
   __shared__ unsigned long long cand[KMAX];
   __shared__ uint32_t s_prefix, s_need, s_cnt, s_tie;
@@ -32,9 +32,19 @@ __global__ __launch_bounds__(256) void topk_masked_kernel(const float *scores, i
   const float *srow = scores + (int64_t)r * ld;
   const uint32_t *bits = has_seen ? seen.bits_rc + (int64_t)row * seen.ldw_rc : nullptr;
 
+  // score column c is item col_off + c of the (unsampled) input block; as the reference does
+  // (`output[input > 0] = -inf`), only POSITIVE stored interactions are masked
+  const bool implicit = seen.implicit != 0;
   auto key_at = [&](int c) -> uint32_t {
     float f = srow[c];
-    if (bits && ((bits[c >> 5] >> (c & 31)) & 1u)) f = -INFINITY;
+    if (bits) {
+      const int gc = col_off + c;
+      const uint32_t word = bits[gc >> 5];
+      if ((word >> (gc & 31)) & 1u) {
+        const float v = implicit ? 1.0f : seen.vals[rk_entry_index(seen, row, gc, word)];
+        if (v > 0.f) f = -INFINITY;
+      }
+    }
     return f2key(f);
   };
 
@@ -119,23 +129,34 @@ __global__ __launch_bounds__(256) void topk_masked_kernel(const float *scores, i
   for (int i = tid; i < k; i += 256) {
     const unsigned long long e = cand[i];
     const uint32_t c = ~(uint32_t)(e & 0xffffffffull);
-    out_idx[(int64_t)r * k + i] = (int64_t)c;
-    if (out_val) out_val[(int64_t)r * k + i] = key2f((uint32_t)(e >> 32));
+    out_idx[(int64_t)r * out_ld + i] = (int64_t)c + col_off;
+    if (out_val) out_val[(int64_t)r * out_ld + i] = key2f((uint32_t)(e >> 32));
   }
 }
 
 }  // namespace
 
-extern "C" int rk_topk_masked(const float *scores, int32_t B, int32_t n, int32_t ld,
-                              const rk_block_t *seen, int32_t row_off, int32_t k,
-                              int64_t *out_idx, float *out_val, void *stream_) {
+extern "C" int rk_topk_masked_strip(const float *scores, int32_t B, int32_t n, int32_t ld,
+                                    const rk_block_t *seen, int32_t row_off, int32_t k,
+                                    int32_t col_off, int64_t *out_idx, float *out_val,
+                                    int32_t out_ld, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(k >= 1 && k <= KMAX, "k must be in [1, 1024]");
-  RK_REQUIRE(k <= n, "k larger than the number of items");
+  RK_REQUIRE(k <= n, "k larger than the number of score columns");
+  RK_REQUIRE(out_ld >= k && col_off >= 0, "bad output layout");
+  RK_REQUIRE(seen == nullptr || seen->implicit || seen->pref_rc != nullptr, "explicit values need pref_rc");
   if (B == 0) return 0;
   rk_block_t dummy = {};
   RK_LAUNCH(topk_masked_kernel, dim3(B), dim3(256), 0, stream, scores, n, ld,
-                     seen ? *seen : dummy, seen ? 1 : 0, row_off, k, out_idx, out_val);
+                     seen ? *seen : dummy, seen ? 1 : 0, row_off, k, out_idx, out_val, col_off, out_ld);
   RK_CHECK_LAUNCH("topk_masked");
   return 0;
 }
+
+extern "C" int rk_topk_masked(const float *scores, int32_t B, int32_t n, int32_t ld,
+                              const rk_block_t *seen, int32_t row_off, int32_t k,
+                              int64_t *out_idx, float *out_val, void *stream_) {
+  return rk_topk_masked_strip(scores, B, n, ld, seen, row_off, k, 0, out_idx, out_val, k, stream_);
+}
+
+extern "C" int32_t rk_topk_max_k(void) { return KMAX; }

@@ -48,6 +48,7 @@ class TimedLib:
     fn = getattr(self._lib, name)
     if not name.startswith("rk_") or name in ("rk_dz_workspace_bytes", "rk_dw_workspace_bytes", "rk_dw_splits", "rk_encode_bwd_segments", "rk_loss_partials", "rk_decode_row_tile",
                                               "rk_dw3_workspace_bytes", "rk_dw3_max_splits", "rk_dw3_slabs", "rk_gemm_split16",
+                                              "rk_dw3_planes_bytes", "rk_dw3_rows_pad", "rk_dw3_cols_pad",
                                               "rk_last_error", "rk_version"):
       return fn
 
@@ -104,9 +105,11 @@ class FusedEngine:
     # launch(es) the C step driver brackets with HIP events on the step's stream in that call
     self.time_plan = None
     self._time_samples = []                # (entry name, event0, event1)
+    self._time_keep = []
     self._gb_lazy = None
     self.item_parallel = None              # parallel.ItemParallel when the items are sharded
     self._cstep = None
+    self._c_calls = 0
     if kind == "ae":
       self.h = list(model.hidden_layers)
       self.nl = len(self.h) - 1
@@ -150,6 +153,9 @@ class FusedEngine:
                               self.lib.rk_dw3_workspace_bytes(B_cap, h0, n_cap)) // 4 + 64, **f)
     self.split16 = bool(self.lib.rk_gemm_split16())
     self._dw_slabs = None
+    # Z^T as bf16 planes for the dW kernel, written by the encoder forward of the one-call step
+    # (zeroed once: the padding columns are never written)
+    self.zt_planes = torch.zeros(self.lib.rk_dw3_planes_bytes(B_cap, h0) // 4 + 16, **f)
     self.n_part = self.lib.rk_loss_partials(B_cap, n_cap)
     self.loss_part = torch.zeros(self.n_part, **f)
     self.loss_out = torch.zeros(1, **f)
@@ -377,8 +383,7 @@ class FusedEngine:
         raise NotImplementedError("tied weights with a separate target matrix in training")
       if ip is not None or self.allreduce is not None:
         raise NotImplementedError("multi-GPU training with a separate target matrix")
-    if self.use_c_step and self.kind == "ae" and self.nl == 0 and not (m.dropout_prob > 0.0) and \
-        tgt is None and not (ip is not None and self.loss_id == LOSS_MNLL):
+    if self.c_step_eligible() and tgt is None and not (ip is not None and self.loss_id == LOSS_MNLL):
       return self._c_train_step(blk, row_off, B, keep_noise, out, global_rows, main_s)
     self._gb_lazy = None
     self._gb_en_segs = 0
@@ -480,24 +485,35 @@ class FusedEngine:
     self._dw_slabs = None
     if self.split16:
       check(self.lib.rk_decode_bwd_dw3(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(self.G_de), ptr(gb_de),
-                                       ptr(self.ws), stream), "rk_decode_bwd_dw3")
+                                       ptr(self.ws), None, stream), "rk_decode_bwd_dw3")
     else:
       check(self.lib.rk_decode_bwd_dw(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(self.G_de), ptr(gb_de),
                                       stream), "rk_decode_bwd_dw")
 
-  def _c_train_step(self, blk, row_off, B, keep_noise, out, global_rows, main_s):
+  def c_step_eligible(self):
+    """The one-call step (rk_ae_train_step) covers DynamicAutoencoder([h]) without bottleneck
+    dropout; everything else runs the per-entry sequencing."""
+    m = self.model
+    return self.use_c_step and self.kind == "ae" and self.nl == 0 and not (m.dropout_prob > 0.0)
+
+  def _c_train_step(self, blk, row_off, B, keep_noise, out, global_rows, main_s, replay=None):
     """The same step through rk_ae_train_step: one FFI call, the kernels
-    sequenced in C on the caller's stream."""
+    sequenced in C on the caller's stream.
+
+    replay (graph.GraphStepper): dict(st=RkAeStep of its own, cursor=device int64[2], off=position
+    in the replayed group, table=Adam constants table) -- what changes per step is then derived on
+    the device (rk_ae_step_t.cursor); `out` is the BASE of the epoch's loss buffer and the host
+    counters (Adam steps, rng step) are advanced by the caller."""
     from ._lib import (ENTRY, PAR_B_DE, PAR_B_EN, PAR_W_DE, PAR_W_EN, STEP_ALL, STEP_DZ_ENC,
                        STEP_FWD_DW, STEP_UPDATE, RkAeStep)
     raw = _lib.load()
     m, S = self.model, self.states
-    st = self._cstep
+    st = self._cstep if replay is None else replay["st"]
     if st is None:
       st = RkAeStep()
-      self._c_calls = 0
       self._cstep = st
-    self.rng_step += 1
+    if replay is None:
+      self.rng_step += 1
     self._gb_lazy = None
     rows = B if global_rows is None else global_rows
     st.blk = ctypes.pointer(blk.c)
@@ -517,18 +533,20 @@ class FusedEngine:
       if k == PAR_W_DE and m.is_constrained:
         continue
       s = S[name]
-      s.step += 1
+      if replay is None:
+        s.step += 1
       lr, b1, b2, eps = self._adam_args(s)
       a = st.par[k]
       a.p, a.m, a.v = ptr(s.p), ptr(s.m), ptr(s.v)
       a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = lr, b1, b2, eps, float(s.wd)
-      a.step, a.sparse = s.step, 1 if s.sparse else 0
+      a.step, a.sparse = max(1, s.step), 1 if s.sparse else 0
     out = self.loss_out if out is None else out
     dp = self.allreduce
     loss_dst = self.loss_dp if dp is not None else out
     st.Z0, st.dZ0, st.dO = ptr(self.enc[0]), ptr(self.denc[0]), ptr(self.dO)
     st.G_de, st.G_en, st.gb_de = ptr(self.G_de), ptr(self.G_en), ptr(self.gb_de)
     st.gb_part, st.ws = ptr(self.gb_part), ptr(self.ws)
+    st.zt_planes = ptr(self.zt_planes)
     plain = dp is None and not m.is_constrained and self.loss_id != LOSS_MNLL
     # the fused fp32 dW || encoder-backward launch writes row-segment partials; the bf16-pipe dW
     # (whole single-GPU steps) leaves its K slabs in the workspace and runs the plain encoder backward
@@ -540,9 +558,35 @@ class FusedEngine:
     self.n_cap_last = blk.n_cap
     st.loss_part, st.loss_out = ptr(self.loss_part), ptr(loss_dst)
     st.stream = main_s.cuda_stream
+    st.stream2, st.ev_fork, st.ev_join, st.ws2 = None, None, None, None
+    if replay is not None and replay.get("branch") is not None and dw3:
+      # dW on a second branch of the captured graph (rk_ae_step_t.stream2)
+      if getattr(self, "ws2", None) is None or self.ws2.numel() * 4 < \
+          self.lib.rk_dw3_workspace_bytes(self.B_cap, self.h[0], self.n_cap):
+        self.ws2 = torch.zeros(self.lib.rk_dw3_workspace_bytes(self.B_cap, self.h[0], self.n_cap) // 4 + 64,
+                               dtype=torch.float32, device=self.device)
+      st.stream2, st.ev_fork, st.ev_join = replay["branch"]
+      st.ws2 = ptr(self.ws2)
+    st.cursor, st.cursor_off, st.adam_table = None, 0, None
+    if replay is not None:
+      st.cursor, st.cursor_off, st.adam_table = replay["cursor"], replay["off"], replay["table"]
+      st.users = replay["users"]             # base of the epoch's user order (offset on the device)
     self._c_calls += 1
-    name = self.time_plan(self._c_calls) if self.time_plan is not None else None
-    if name is not None:
+    name = None
+    if self.time_plan is not None and (replay is None or replay.get("timed")):
+      name = self.time_plan(replay["index"] if replay is not None else self._c_calls)
+    st.time_all = None
+    if name == "all":
+      # every launch group of this step gets its own pair of timing events
+      from ._lib import ENTRY_ALL
+      n_ent = max(ENTRY.values()) + 1
+      evs = (ctypes.c_void_p * (2 * n_ent))()
+      for ename, eid in ENTRY.items():
+        evs[2 * eid], evs[2 * eid + 1] = raw.rk_timing_event_create(), raw.rk_timing_event_create()
+        self._time_samples.append((ename, evs[2 * eid], evs[2 * eid + 1]))
+      self._time_keep.append(evs)          # (the array must outlive the call)
+      st.time_entry, st.time_all = ENTRY_ALL, evs
+    elif name is not None:
       e0, e1 = raw.rk_timing_event_create(), raw.rk_timing_event_create()
       self._time_samples.append((name, e0, e1))
       st.time_entry, st.time_ev0, st.time_ev1 = ENTRY[name], e0, e1
@@ -651,12 +695,15 @@ class FusedEngine:
     raw = _lib.load()
     out = {}
     for name, e0, e1 in self._time_samples:
-      out.setdefault(name, []).append(raw.rk_event_elapsed_ms(e0, e1))
+      ms = raw.rk_event_elapsed_ms(e0, e1)
+      if ms >= 0:                          # (an entry this step variant never launches: unrecorded)
+        out.setdefault(name, []).append(ms)
     if clear:
       for _, e0, e1 in self._time_samples:
         raw.rk_event_destroy(e0)
         raw.rk_event_destroy(e1)
       self._time_samples = []
+      self._time_keep = []
     return out
 
   # ------------------------------------------------------- data parallelism
@@ -743,6 +790,23 @@ class FusedEngine:
     self._flush_jobs(stream)
 
   # ------------------------------------------------------------- inference
+  def encode_eval(self, blk, row_off, B):
+    """Evaluation-mode encoder output of rows of `blk` (the input of the decoder GEMM)."""
+    self.ensure_capacity(B, blk.n_cap)
+    stream = current_stream()
+    if self.kind == "ae":
+      return self._ae_forward(blk, row_off, B, None, None, False, stream)
+    return self._mf_forward(blk.users[row_off:row_off + B], B, None, False, stream)
+
+  def decode_scores(self, z, B, items_blk, out, ld_out):
+    """Logits of `z` against the item set of `items_blk` (any subset / strip of the catalogue)."""
+    self.ensure_capacity(B, items_blk.n_cap)
+    W, b = self._decoder_params()
+    check(self.lib.rk_decode_loss(ptr(z), B, self.h[0], items_blk.ref, 0, ptr(W), ptr(b), LOSS_NONE,
+                                  0.0, 1.0, ptr(out), ld_out, None, None, current_stream()),
+          "rk_decode_loss")
+    return out
+
   def predict_scores(self, blk, row_off, B, out, ld_out, tgt_items_blk):
     """Logits for rows of ``blk`` against the item set of ``tgt_items_blk``
     (model.py:487-511 with input_items=None: the whole catalogue)."""

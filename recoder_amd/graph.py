@@ -1,0 +1,200 @@
+"""HIP-graph replay of the hot loop (reference model.py:383-418).
+
+One optimisation step of the common autoencoder case is 6 collation launches + 7 training launches;
+enqueued one by one the host spends 50-120 us per step on them -- as much as the GPU needs to run
+them.  ``GraphStepper`` captures a GROUP of G steps as one HIP graph,
+
+    main stream :  step(block[v][0]) ... step(block[v][G-1])  ->  cursor += G
+    side stream :  collate(block[1-v][0..G-1])  for the NEXT group      (forked / joined by events)
+
+and replays it with one ``hipGraphLaunch`` per G steps.  A replayed launch cannot take new
+arguments, so everything that changes from step to step is derived ON THE DEVICE from a cursor
+(``rk_ae_step_t.cursor``, csrc/common.h ``rk_cur_t``): which users are collated (an offset into the
+epoch's user order, resident in HBM), the collation stamp, the dropout RNG step, Adam's bias
+corrections and step size (a per-epoch table of constants, ``rk_adam_consts``) and the slot of the
+per-step loss.  The captured kernels are the same C-ABI entry points the eager path launches
+(``rk_collate_at``, ``rk_ae_train_step``); steps that do not fill a group (the tail of an epoch,
+the ragged last batch, groups bench.py brackets with timing events) run eagerly through them.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import PAR_B_DE, PAR_B_EN, PAR_W_DE, PAR_W_EN, RkAeStep, check, ptr
+
+_PAR_NAMES = {PAR_W_EN: "en_embedding_layer.weight",
+              PAR_B_EN: "_DynamicAutoencoder__en_linear_embedding_layer.bias",
+              PAR_W_DE: "de_embedding_layer.weight",
+              PAR_B_DE: "_DynamicAutoencoder__de_linear_embedding_layer.bias"}
+
+
+class GraphStepper:
+  def __init__(self, engine, dcsr, make_block, B, negative_sampling, group, n_users, device):
+    self.lib = _lib.load()
+    self.eng, self.dcsr, self.B, self.ns, self.G = engine, dcsr, int(B), bool(negative_sampling), int(group)
+    self.device = device
+    self.blocks = [[make_block() for _ in range(self.G)] for _ in range(2)]
+    self.tail_blk = make_block()            # ragged last batch: eager, host-provided arguments
+    engine.ensure_capacity(self.B, self.blocks[0][0].n_cap)
+    self.cursor = torch.zeros(2, dtype=torch.int64, device=device)
+    self.steps_cap = -(-n_users // self.B)
+    # the epoch's user order, padded so that the look-ahead collation of the group after the last
+    # one reads valid user ids (its blocks are never trained on)
+    self.order = torch.zeros((self.steps_cap + 2 * self.G) * self.B, dtype=torch.int64, device=device)
+    self.loss_buf = torch.zeros(self.steps_cap + self.G, dtype=torch.float32, device=device)
+    self.table = torch.zeros((self.steps_cap + self.G) * 4 * 8, dtype=torch.float32, device=device)
+    self.table_host = torch.zeros((self.steps_cap + self.G) * 4 * 8, dtype=torch.float32).pin_memory()
+    # stream capture needs a stream of its own (not the default stream torch work runs on)
+    self.main = torch.cuda.Stream(device=device)
+    self.side = torch.cuda.Stream(device=device)
+    self.ev_fork, self.ev_join = self.lib.rk_event_create(), self.lib.rk_event_create()
+    self.st = [[RkAeStep() for _ in range(self.G)] for _ in range(2)]
+    # RK_GRAPH_BRANCH=1: dW on a second branch of every captured step (step.hip `branch`)
+    import os
+    self.branch = os.environ.get("RK_GRAPH_BRANCH", "0") == "1"
+    self.stream2 = torch.cuda.Stream(device=device)
+    self.bev = [[(self.lib.rk_event_create(), self.lib.rk_event_create()) for _ in range(self.G)]
+                for _ in range(2)]
+    self.exec = [None, None]
+    self.global_step = 0                   # steps this stepper's cursor has seen
+    self.epoch_base = 0
+
+  def close(self):
+    for e in self.exec:
+      if e:
+        self.lib.rk_graph_destroy(e)
+    self.exec = [None, None]
+    for e in (self.ev_fork, self.ev_join):
+      self.lib.rk_event_destroy(e)
+
+  # ----------------------------------------------------------------- pieces
+  def _h(self, stream):
+    return ctypes.c_void_p(stream.cuda_stream)
+
+  def _collate(self, blk, off, stream):
+    d = self.dcsr
+    blk.c.implicit = 1 if d.data is None else 0
+    blk.S = self.B
+    check(self.lib.rk_collate_at(ptr(d.indptr), ptr(d.indices), ptr(d.data), ptr(self.order), self.B,
+                                 1 if self.ns else 0, ptr(self.cursor), off, blk.ref, self._h(stream)),
+          "rk_collate_at")
+
+  def _step(self, slot, g, index=None):
+    """Enqueue the training step of block [slot][g] (cursor offset g) on the main stream; index
+    != None: an eager step that bench.py's time plan may bracket."""
+    replay = dict(st=self.st[slot][g], cursor=ptr(self.cursor), off=g, table=ptr(self.table),
+                  users=ptr(self.order), timed=index is not None, index=index)
+    if self.branch and index is None:          # (captured steps only: eager edges cost 10-20 us)
+      replay["branch"] = (self.stream2.cuda_stream,) + self.bev[slot][g]
+    self.eng._c_train_step(self.blocks[slot][g], 0, self.B, None, self.loss_buf, None, self.main,
+                           replay=replay)
+
+  def _group(self, slot, n_steps=None, first_index=None):
+    """One group on slot `slot`: its steps on the main stream, the collation of the NEXT group's
+    blocks on the side stream, the cursor advance.  Called inside a capture or eagerly."""
+    lib, G = self.lib, self.G
+    n_steps = G if n_steps is None else n_steps
+    check(lib.rk_event_record(self.ev_fork, self._h(self.main)), "rk_event_record")
+    check(lib.rk_stream_wait_event(self._h(self.side), self.ev_fork), "rk_stream_wait_event")
+    for g in range(G):
+      self._collate(self.blocks[1 - slot][g], n_steps + g, self.side)
+    for g in range(n_steps):
+      self._step(slot, g, None if first_index is None else first_index + g)
+    check(lib.rk_event_record(self.ev_join, self._h(self.side)), "rk_event_record")
+    check(lib.rk_stream_wait_event(self._h(self.main), self.ev_join), "rk_stream_wait_event")
+    check(lib.rk_cursor_advance(ptr(self.cursor), n_steps, self._h(self.main)), "rk_cursor_advance")
+
+  def _capture(self, slot):
+    check(self.lib.rk_graph_begin(self._h(self.main)), "rk_graph_begin")
+    try:
+      self._group(slot)
+    finally:
+      ex = self.lib.rk_graph_end(self._h(self.main))
+    if not ex:
+      raise _lib.RecoderHipError("graph capture failed: %s" % self.lib.rk_last_error().decode())
+    self.exec[slot] = ex
+
+  # ------------------------------------------------------------------ epoch
+  def begin_epoch(self, order_np, global_step):
+    """Upload the epoch's user order and Adam constants; point the cursor at its first step.
+    Returns the number of whole-batch steps."""
+    assert torch.cuda.current_stream() == self.main, "run the epoch under torch.cuda.stream(stepper.main)"
+    n = len(order_np)
+    n_full = n // self.B
+    assert n_full <= self.steps_cap
+    self.order[:n].copy_(torch.from_numpy(np.ascontiguousarray(order_np, dtype=np.int64)), non_blocking=False)
+    # Adam constants of every step of the epoch (exactly what rk_adam_multi derives itself)
+    th = self.table_host
+    buf = (ctypes.c_float * 8)()
+    S = self.eng.states
+    tied = bool(self.eng.model.is_constrained)
+    arr = th.numpy().reshape(-1, 4, 8)
+    for k, name in _PAR_NAMES.items():
+      if k == PAR_W_DE and tied:
+        continue
+      s = S[name]
+      lr, b1, b2, eps = self.eng._adam_args(s)
+      wd = 0.0 if s.sparse else float(s.wd)
+      for i in range(n_full + self.G):
+        check(self.lib.rk_adam_consts(lr, b1, b2, eps, wd, s.step + i + 1, buf), "rk_adam_consts")
+        arr[i, k, :] = np.frombuffer(buf, dtype=np.float32)
+    self.table.copy_(th, non_blocking=False)
+    self.global_step = int(global_step)
+    self.epoch_base = int(global_step)
+    check(self.lib.rk_cursor_set(ptr(self.cursor), self.global_step, self.epoch_base, self._h(self.main)),
+          "rk_cursor_set")
+    self._collated = None                # slot whose blocks hold the steps at the cursor
+    return n_full
+
+  def run(self, n_steps, eager_plan=None):
+    """Run `n_steps` whole-batch steps starting at the cursor.  eager_plan(global index) -> bool:
+    groups containing a step for which it is True are enqueued eagerly (timing events)."""
+    lib, G = self.lib, self.G
+    if n_steps <= 0:
+      return
+    slot = 0
+    if self._collated is None:
+      # nothing of the first group is in flight yet: collate it now
+      for g in range(min(G, n_steps)):
+        self._collate(self.blocks[0][g], g, self.main)
+    else:
+      slot = self._collated
+    done = 0
+    while done < n_steps:
+      left = n_steps - done
+      idx0 = self.global_step
+      if left >= G:
+        eager = eager_plan is not None and any(eager_plan(idx0 + g) for g in range(G))
+        if eager:
+          self._group(slot, G, first_index=idx0)
+        else:
+          if self.exec[slot] is None:
+            self._capture(slot)         # (capturing enqueues nothing)
+          check(lib.rk_graph_launch(self.exec[slot], self._h(self.main)), "rk_graph_launch")
+        k = G
+      else:
+        self._group(slot, left, first_index=idx0)      # tail: fewer than G steps, eager
+        k = left
+      self._advance_host(k)
+      done += k
+      slot = 1 - slot
+    self._collated = slot                # the look-ahead blocks of the next group
+
+  def cut(self):
+    """Forget the look-ahead blocks (a step mark / an eager ragged step follows)."""
+    self._collated = None
+
+  def _advance_host(self, k):
+    self.global_step += k
+    S = self.eng.states
+    tied = bool(self.eng.model.is_constrained)
+    for key, name in _PAR_NAMES.items():
+      if key == PAR_W_DE and tied:
+        continue
+      S[name].step += k
+    self.eng.rng_step += k
+
+  def losses(self, n):
+    return self.loss_buf[:n]

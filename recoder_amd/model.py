@@ -586,6 +586,15 @@ class Recoder(object):
       iters_to_process = min(iters_per_epoch, num_batches - iters_processed)
       iters_processed += iters_to_process
 
+      if self._graph_ok(train_dataloader, iters_per_epoch, num_batches):
+        # whole epochs of the one-call autoencoder step: replayed as HIP graphs (graph.py)
+        iters_processed = num_batches
+        self.last_epoch_losses = self._train_epoch_graph(train_dataloader)
+        self._epoch_end(epoch, num_epochs, len(self.last_epoch_losses), val_dataloader, eval_freq,
+                        metrics, eval_num_recommendations, eval_batch_size, eval_num_users,
+                        model_checkpoint_prefix, checkpoint_freq)
+        continue
+
       n_done = 0
       for batch_itr, (blk, row_off, rows, keep_noise, keep_drop, tgt_blk) in iterator:
         dp = getattr(self, "_dp", None)
@@ -600,31 +609,114 @@ class Recoder(object):
         self._ip.allreduce_sum(loss_buf[:n_done])   # every rank holds its items' share
       # one device->host read per epoch instead of loss.item() per step (model.py:404)
       self.last_epoch_losses = loss_buf[:n_done].cpu().numpy().copy()
-      self.loss_history.append(self.last_epoch_losses)
-      if n_done and not np.all(np.isfinite(self.last_epoch_losses)):
-        # the reference keeps training on a NaN loss too; here there is one extra way to get one:
-        # the decoder GEMMs split their operands into fp16 pairs (range |W| < 512, |Z| < 2048,
-        # recoder_amd/csrc/gemm.hip) -- RK_GEMM_PREC=f32 runs them on the fp32 MFMA
-        log.warning(
-          "non-finite training loss in epoch %d; if activations / weights exceed the split-fp16 range "
-          "of the decoder GEMMs, rerun with RK_GEMM_PREC=f32", epoch)
-      postfix = {"loss": float(self.last_epoch_losses[-1]) if n_done else float("nan")}
-      if eval_freq > 0 and epoch % eval_freq == 0 and val_dataloader is not None:
-        self._sync_user_rows()
-        postfix["val_loss"] = self._validate(val_dataloader)
-        if metrics is not None and eval_num_recommendations is not None:
-          results = self._evaluate(val_dataloader.dataset,
-                                   num_recommendations=eval_num_recommendations,
-                                   metrics=metrics, batch_size=eval_batch_size,
-                                   num_users=eval_num_users)
-          for metric in results:
-            postfix[str(metric)] = np.mean(results[metric])
-      log.info("Epoch {}/{} {}".format(epoch, num_epochs, postfix))
-      self.last_epoch_summary = postfix
-      if model_checkpoint_prefix and \
-          ((checkpoint_freq > 0 and epoch % checkpoint_freq == 0) or epoch == num_epochs):
-        self._sync_user_rows()
-        self.save_state(model_checkpoint_prefix)
+      self._epoch_end(epoch, num_epochs, n_done, val_dataloader, eval_freq, metrics,
+                      eval_num_recommendations, eval_batch_size, eval_num_users,
+                      model_checkpoint_prefix, checkpoint_freq)
+
+  def _epoch_end(self, epoch, num_epochs, n_done, val_dataloader, eval_freq, metrics,
+                 eval_num_recommendations, eval_batch_size, eval_num_users, model_checkpoint_prefix,
+                 checkpoint_freq):
+    """model.py:406-437: the epoch's log line, validation / evaluation, checkpoint."""
+    self.loss_history.append(self.last_epoch_losses)
+    if n_done and not np.all(np.isfinite(self.last_epoch_losses)):
+      # the reference keeps training on a NaN loss too; here there is one extra way to get one:
+      # the decode / dZ GEMMs split their operands into fp16 pairs (range |W| < 512, |Z| < 2048,
+      # recoder_amd/csrc/gemm.hip) -- RK_GEMM_PREC=f32 runs them on the fp32 MFMA
+      log.warning(
+        "non-finite training loss in epoch %d; if activations / weights exceed the split-fp16 range "
+        "of the decoder GEMMs, rerun with RK_GEMM_PREC=f32", epoch)
+    postfix = {"loss": float(self.last_epoch_losses[-1]) if n_done else float("nan")}
+    if eval_freq > 0 and epoch % eval_freq == 0 and val_dataloader is not None:
+      self._sync_user_rows()
+      postfix["val_loss"] = self._validate(val_dataloader)
+      if metrics is not None and eval_num_recommendations is not None:
+        results = self._evaluate(val_dataloader.dataset,
+                                 num_recommendations=eval_num_recommendations,
+                                 metrics=metrics, batch_size=eval_batch_size,
+                                 num_users=eval_num_users)
+        for metric in results:
+          postfix[str(metric)] = np.mean(results[metric])
+    log.info("Epoch {}/{} {}".format(epoch, num_epochs, postfix))
+    self.last_epoch_summary = postfix
+    if model_checkpoint_prefix and \
+        ((checkpoint_freq > 0 and epoch % checkpoint_freq == 0) or epoch == num_epochs):
+      self._sync_user_rows()
+      self.save_state(model_checkpoint_prefix)
+
+  # ------------------------------------------------------------ graph replay
+  def _graph_ok(self, dataloader, iters_per_epoch, num_batches):
+    if os.environ.get("RK_GRAPH", "1") == "0":
+      return False
+    eng = self._engine()
+    if getattr(eng, "generic", False) or not eng.c_step_eligible():
+      return False
+    if getattr(self, "_dp", None) is not None or getattr(self, "_ip", None) is not None:
+      return False
+    ds = dataloader.dataset
+    return (self.mask_hook is None and dataloader.num_sampling_users == dataloader.batch_size and
+            ds.device_target_csr() is None and iters_per_epoch == num_batches and
+            len(ds) >= dataloader.batch_size)
+
+  def _train_epoch_graph(self, dataloader):
+    """One pass over the dataset with the whole-batch steps replayed as HIP graphs
+    (recoder_amd/graph.py); returns the per-step losses."""
+    from .graph import GraphStepper
+    eng = self._engine()
+    ds = dataloader.dataset
+    dcsr = ds.device_csr()
+    B, ns, n = dataloader.batch_size, dataloader.negative_sampling, len(ds)
+    gs = getattr(self, "_graph_stepper", None)
+    if gs is None or gs.dcsr is not dcsr or gs.B != B or gs.ns != ns or gs.G != self.prefetch_group:
+      if gs is not None:
+        gs.close()
+      gs = GraphStepper(eng, dcsr, lambda: self._make_block(dcsr, B, ns, train=True), B, ns,
+                        self.prefetch_group, n, self.device)
+      self._graph_stepper = gs
+    order = None
+    if self.user_order_hook is not None:
+      order = self.user_order_hook(self.current_epoch, n)
+    if order is None:
+      order = epoch_user_order(n)
+    order = np.ascontiguousarray(order, dtype=np.int64)
+    caller = torch.cuda.current_stream()
+    gs.main.wait_stream(caller)
+    with torch.cuda.stream(gs.main):
+      losses = self._run_epoch_graph(gs, eng, dcsr, order, n, B)
+    caller.wait_stream(gs.main)
+    return losses
+
+  def _run_epoch_graph(self, gs, eng, dcsr, order, n, B):
+    n_full = gs.begin_epoch(order, eng.rng_step)
+    n_total = n_full + (1 if n % B else 0)
+    g0 = self._global_step
+    marks = sorted(m - g0 for m in self.step_marks if g0 <= m <= g0 + n_total)
+    # (looked up per group: a step mark may install / change the engine's time plan)
+    plan = lambda i: eng.time_plan is not None and eng.time_plan(i) is not None
+    pos, stopped = 0, False
+    for m in marks + [None]:
+      target = n_full if m is None else min(m, n_full)
+      if target > pos:
+        gs.run(target - pos, plan)
+        self._global_step += target - pos
+        pos = target
+      if m is None or m > n_full:
+        break                            # (a mark behind the ragged step is handled below)
+      gs.cut()                           # nothing of the steps after the mark may be in flight
+      if self.step_marks[g0 + m]():
+        self._stop_training = stopped = True
+        break
+    losses = gs.losses(pos)
+    if not stopped and n % B:
+      # the ragged last batch: eager, host-provided arguments (its own block)
+      users = torch.from_numpy(order[n_full * B:]).to(self.device)
+      gs.tail_blk.collate(dcsr, users)
+      out = torch.zeros(1, dtype=torch.float32, device=self.device)
+      eng.train_step(gs.tail_blk, 0, int(users.numel()), out=out)
+      self._global_step += 1
+      losses = torch.cat([losses, out])
+      if n_total > n_full and (g0 + n_total) in self.step_marks and self.step_marks[g0 + n_total]():
+        self._stop_training = True
+    return losses.cpu().numpy().copy()
 
   def _validate(self, val_dataloader):
     """model.py:439-452: mean over batches of the eval-mode loss; input and
@@ -677,8 +769,9 @@ class Recoder(object):
       return out, dense
     return out, out
 
-  def _predict_scores(self, users_interactions):
-    engine = self._engine()
+  def _input_block(self, users_interactions):
+    """The users' interactions as an unsampled device block (bitmap over the whole catalogue),
+    in buffers that are kept and reused across predict / recommend calls."""
     m = users_interactions.interactions_matrix
     B = m.shape[0]
     n_items = self.num_items if self.num_items is not None else m.shape[1]
@@ -686,13 +779,24 @@ class Recoder(object):
     assert dcsr.n_items <= n_items
     if dcsr.n_items != n_items:
       dcsr.shape = (B, n_items)
-    blk = Block(B, max(1, dcsr.nnz), n_items, self.device, negative_sampling=False,
-                need_bits_cr=False)
+    ws = getattr(self, "_eval_ws", None)
+    if ws is None or ws["n_items"] != n_items:
+      ws = self._eval_ws = dict(n_items=n_items, blk=None, strips={}, scores=None, cand=None)
+    blk = ws["blk"]
+    if blk is None or blk.S_cap < B or blk.nnz_cap < max(1, dcsr.nnz):
+      blk = ws["blk"] = Block(max(B, blk.S_cap if blk else 0),
+                              max(1, dcsr.nnz, blk.nnz_cap if blk else 0), n_items, self.device,
+                              negative_sampling=False, need_bits_cr=False)
     rows = torch.arange(B, dtype=torch.int64, device=self.device)
     blk.collate(dcsr, rows, negative_sampling=False)
     # MF looks user rows up by their global ids
     blk.users = torch.as_tensor(np.asarray(users_interactions.users), dtype=torch.int64) \
         .to(self.device)
+    return blk, B, n_items
+
+  def _predict_scores(self, users_interactions):
+    engine = self._engine()
+    blk, B, n_items = self._input_block(users_interactions)
     ld = blk.ld_cap
     out = torch.empty(B, ld, dtype=torch.float32, device=self.device)
     engine.predict_scores(blk, 0, B, out, ld, blk)
@@ -707,19 +811,73 @@ class Recoder(object):
     evaluator = RecommenderEvaluator(recommender, metrics)
     return evaluator.evaluate(eval_dataset, batch_size=batch_size, num_users=num_users)
 
+  # items decoded at a time by recommend(): [B, strip] fp32 scores stay cache-resident
+  # (B = 500: 128 MB) instead of a [B, n_items] matrix in HBM (2 GB at C5's 1 M items)
+  eval_strip_items = int(os.environ.get("RK_EVAL_STRIP", "65536"))
+
   def recommend(self, users_interactions, num_recommendations):
-    """model.py:525-544: scores with the seen items at -inf, top-k sorted."""
+    """model.py:525-544: scores with the seen (positive) items at -inf, top-k sorted.
+
+    The fused engines never materialise the [B, n_items] score matrix: the catalogue is decoded
+    in strips of ``eval_strip_items`` items, each strip's masked top k is kept
+    (``rk_topk_masked_strip``) and the per-strip winners are merged with one more top-k pass --
+    ties resolve to the lower item id at both levels, as torch.topk on the full row would."""
     self.model.eval()
-    out, blk, B = self._predict_scores(users_interactions)
-    n_items = out.shape[1]
     k = int(num_recommendations)
-    idx = torch.empty(B, k, dtype=torch.int64, device=self.device)
     from . import _lib
     from .device import current_stream
-    _lib.check(_lib.load().rk_topk_masked(out.data_ptr(), B, n_items, out.stride(0), blk.ref, 0, k,
-                                          idx.data_ptr(), None, current_stream()),
-               "rk_topk_masked")
-    return idx.cpu().tolist()
+    lib = _lib.load()
+    engine = self._engine()
+    if getattr(engine, "generic", False) or k > lib.rk_topk_max_k():
+      return self._recommend_dense(users_interactions, k)
+    blk, B, n_items = self._input_block(users_interactions)
+    ws = self._eval_ws
+    z = engine.encode_eval(blk, 0, B)
+    strip = max(k, min(n_items, int(self.eval_strip_items)))
+    bounds = [(lo, min(n_items, lo + strip)) for lo in range(0, n_items, strip)]
+    if len(bounds) > 1 and bounds[-1][1] - bounds[-1][0] < k:      # a last strip shorter than k:
+      lo0 = bounds[-2][0]                                         # merge it into the one before
+      bounds = bounds[:-2] + [(lo0, n_items)]
+    ns = len(bounds)
+    width = max(hi - lo for lo, hi in bounds)
+    ld = -(-width // 32) * 32
+    if ws["scores"] is None or ws["scores"].numel() < B * ld:
+      ws["scores"] = torch.empty(B * ld, dtype=torch.float32, device=self.device)
+    if ws["cand"] is None or ws["cand"][0].shape[0] < B or ws["cand"][0].shape[1] != ns * k:
+      ws["cand"] = (torch.empty(B, ns * k, dtype=torch.int64, device=self.device),
+                    torch.empty(B, ns * k, dtype=torch.float32, device=self.device))
+    cand_idx, cand_val = ws["cand"][0][:B], ws["cand"][1][:B]
+    scores = ws["scores"]
+    for s, (lo, hi) in enumerate(bounds):
+      key = (lo, hi, B)
+      sblk = ws["strips"].get(key)
+      if sblk is None:
+        sblk = Block(B, 1, n_items, self.device, negative_sampling=True, need_bits_cr=False,
+                     n_cap=hi - lo)
+        sblk.set_items(torch.arange(lo, hi, dtype=torch.int32, device=self.device), hi - lo, B)
+        if len(ws["strips"]) > 64:
+          ws["strips"].clear()
+        ws["strips"][key] = sblk
+      engine.decode_scores(z, B, sblk, scores, ld)
+      _lib.check(lib.rk_topk_masked_strip(scores.data_ptr(), B, hi - lo, ld, blk.ref, 0, k, lo,
+                                          cand_idx[:, s * k:].data_ptr(), cand_val[:, s * k:].data_ptr(),
+                                          ns * k, current_stream()), "rk_topk_masked_strip")
+    if ns == 1:
+      return cand_idx[:, :k].cpu().tolist()
+    # merge: top k of the ns * k candidates (positions), then their item ids.  Candidates are laid
+    # out strip by strip, each sorted by (score desc, id asc): equal scores keep ascending ids
+    pos = torch.empty(B, k, dtype=torch.int64, device=self.device)
+    _lib.check(lib.rk_topk_masked(cand_val.data_ptr(), B, ns * k, ns * k, None, 0, k, pos.data_ptr(),
+                                  None, current_stream()), "rk_topk_masked")
+    return torch.gather(cand_idx, 1, pos).cpu().tolist()
+
+  def _recommend_dense(self, users_interactions, k):
+    """Full score matrix + torch.topk: the generic (torch-autograd) engine and k above the
+    top-k kernel's limit."""
+    out, dense = self.predict(users_interactions, return_input=True)
+    out = out.clone()
+    out[dense > 0] = -float("inf")
+    return torch.topk(out, k, dim=1, sorted=True)[1].cpu().tolist()
 
   def evaluate(self, eval_dataset, num_recommendations, metrics, batch_size=1, num_users=None):
     """model.py:546-559."""

@@ -6,6 +6,8 @@ container only; import shims as in make_golden.py):
                           and both id maps; plus the call with the maps passed in on a subset.
   ref_ckpt_<name>.model   a checkpoint file written by the reference's Recoder.save_state
                           (model.py:193-224) -- a torch pickle of tensors / arrays / scalars: data.
+  train_target_<name>.npz training on a dataset WITH a target matrix (data.py:60-62): CSRs, initial
+                          parameters, user order, per-step losses, final parameters.
   ref_ckpt_<name>.npz     what produced it (CSR, initial parameters, every batch's users) and
                           what the reference does with it after init_from_model_file in a fresh
                           trainer: top-k recommendations, scores, the losses of one more epoch.
@@ -143,6 +145,67 @@ def make_checkpoint_fixture(name, cfg):
         int(gold["resumed_epoch"]))
 
 
+TARGET_CONFIGS = {
+  # datasets WITH a target matrix in training (reference data.py:60-62, model.py:464-472): the
+  # decoder side runs over the target batch's item set, the encoder side over the input's
+  "ae": dict(kind="ae", model=dict(hidden_layers=[20], activation_type="tanh", sparse=False),
+             loss="mse", train=dict(batch_size=32, lr=1e-3, weight_decay=2e-5, num_epochs=2,
+                                    negative_sampling=True),
+             data=dict(n_users=130, n_items=110, mean_deg=9, seed=51)),
+  "ae2_sparse": dict(kind="ae", model=dict(hidden_layers=[24, 12], activation_type="sigmoid", sparse=True),
+                     loss="logistic", train=dict(batch_size=32, lr=1e-3, weight_decay=0.0, num_epochs=2,
+                                                 negative_sampling=True),
+                     data=dict(n_users=130, n_items=110, mean_deg=9, seed=52)),
+  "mf": dict(kind="mf", model=dict(embedding_size=12, activation_type="tanh", sparse=False),
+             loss="logloss", train=dict(batch_size=32, lr=1e-3, weight_decay=1e-5, num_epochs=2,
+                                        negative_sampling=True),
+             data=dict(n_users=130, n_items=110, mean_deg=9, seed=53)),
+}
+
+
+def make_target_fixture(name, cfg):
+  from recoder.data import RecommendationDataset
+  from recoder.model import Recoder
+  from recoder.nn import DynamicAutoencoder, MatrixFactorization
+  csr = synth_csr(**cfg["data"])
+  d2 = dict(cfg["data"]); d2["seed"] += 500
+  csr_t = synth_csr(**d2)
+  torch.manual_seed(8642)
+  model = DynamicAutoencoder(**cfg["model"]) if cfg["kind"] == "ae" else MatrixFactorization(**cfg["model"])
+  trainer = Recoder(model=model, use_cuda=False, optimizer_type="adam", loss=cfg["loss"])
+  holder, rec = {}, dict(users=[], losses=[])
+  orig_init = model.init_model
+
+  def init_model(num_items=None, num_users=None):
+    orig_init(num_items, num_users)
+    holder["init"] = {k: v.detach().clone().numpy() for k, v in model.named_parameters()}
+  model.init_model = init_model
+  orig = trainer._Recoder__compute_loss
+
+  def compute_loss(input, target):
+    assert target is not None
+    loss = orig(input, target)
+    if model.training:
+      rec["users"].append(input.users.numpy().copy())
+      rec["losses"].append(float(loss.item()))
+    return loss
+  trainer._Recoder__compute_loss = compute_loss
+  trainer.train(train_dataset=RecommendationDataset(csr, csr_t), **cfg["train"])
+  gold = {"csr/indptr": csr.indptr.astype(np.int64), "csr/indices": csr.indices.astype(np.int32),
+          "csr/data": csr.data.astype(np.float32), "csr/shape": np.asarray(csr.shape),
+          "csr_t/indptr": csr_t.indptr.astype(np.int64), "csr_t/indices": csr_t.indices.astype(np.int32),
+          "csr_t/data": csr_t.data.astype(np.float32),
+          "order": np.concatenate(rec["users"]).astype(np.int64),
+          "losses": np.asarray(rec["losses"], dtype=np.float64)}
+  for k, v in holder["init"].items():
+    gold["init/" + k] = v
+  for k, v in model.named_parameters():
+    gold["final/" + k] = v.detach().numpy().copy()
+  np.savez_compressed(os.path.join(HERE, "train_target_%s.npz" % name), **gold)
+  print("wrote train_target_%s.npz:" % name, len(rec["losses"]), "steps, loss", rec["losses"][0], "->",
+        rec["losses"][-1])
+
+
 if __name__ == "__main__":
   import_reference()
   # fifth shim (this torch, not the reference's 1.8.1): torch.load defaults to weights_only=True
@@ -153,3 +216,5 @@ if __name__ == "__main__":
   make_dataframe_fixture()
   for name, cfg in CKPT_CONFIGS.items():
     make_checkpoint_fixture(name, cfg)
+  for name, cfg in TARGET_CONFIGS.items():
+    make_target_fixture(name, cfg)

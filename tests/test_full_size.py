@@ -246,3 +246,113 @@ def test_c5_shaped_large_catalogue_h512_sparse():
   b = orc.collate(orc.extract_rows(csr, users), users, 500, True)[0]
   want = o.train_step(b)
   assert abs(losses[0] - want) / abs(want) < 1e-5, (losses[0], want)
+
+
+# ---------------------------------------------------------------------------------------------
+# the other BASELINE configurations at their STATED shapes
+# ---------------------------------------------------------------------------------------------
+def _masked_steps_vs_oracle(csr, cfg, o_kwargs, steps, seed, B=500):
+  """`steps` training steps through Recoder.train with INJECTED dropout masks (mask_hook) against
+  the oracle fed the same masks: per-step losses to 1e-5."""
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder
+  rng = np.random.RandomState(seed)
+  order = rng.permutation(csr.shape[0]).astype(np.int64)
+  torch.manual_seed(seed)
+  model = DynamicAutoencoder(hidden_layers=cfg["hidden_layers"], activation_type="tanh",
+                             noise_prob=cfg["noise_prob"], dropout_prob=cfg.get("dropout_prob", 0.0),
+                             sparse=cfg.get("sparse", False))
+  rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss=cfg["loss"])
+  rec.user_order_hook = lambda epoch, n: order
+  masks = {}
+
+  def hook(step, users):
+    nnz = int(np.diff(csr.indptr)[users].sum())
+    keep = (rng.random_sample(nnz) >= cfg["noise_prob"]).astype(np.uint8)
+    masks[step] = keep
+    return torch.from_numpy(keep).to(dev()), None
+  rec.mask_hook = hook
+  ds = RecommendationDataset(csr)
+  rec._Recoder__init_training(ds, 1e-3, 2e-5)
+  init = {k: v.detach().cpu().clone() for k, v in model.named_parameters()}
+  rec.train(ds, batch_size=B, lr=1e-3, weight_decay=2e-5, num_epochs=1, iters_per_epoch=steps,
+            negative_sampling=True)
+  losses = rec.last_epoch_losses
+  o = orc.OracleRecoder("ae", init, lr=1e-3, weight_decay=2e-5, **o_kwargs)
+  for i in range(steps):
+    users = order[i * B:(i + 1) * B]
+    b = orc.collate(orc.extract_rows(csr, users), users, B, True)[0]
+    want = o.train_step(b, None, masks[i], None)
+    assert abs(losses[i] - want) / abs(want) < 1e-5, (i, losses[i], want)
+  return rec, model, o
+
+
+def test_c3_full_shape_msd_with_noise_masks():
+  """C3 at its stated shape: 471,355 users x 41,140 items, AE [200, 200], multinomial NLL, input
+  noise 0.5 (masks injected on both sides), 3 steps against the oracle."""
+  from recoder_amd import synthetic
+  csr = synthetic.msd_like(seed=1)
+  assert csr.shape == (471355, 41140)
+  rec, model, o = _masked_steps_vs_oracle(
+      csr, dict(hidden_layers=[200, 200], loss="logloss", noise_prob=0.5),
+      dict(hidden_layers=[200, 200], activation_type="tanh", noise_prob=0.5, loss="logloss"), 3, seed=5)
+  ost = o.state()
+  for k, p in model.named_parameters():
+    err = (p.detach().cpu() - ost[k]).abs()
+    bad = (err > 2e-6 + 1e-4 * ost[k].abs()).float().mean().item()
+    assert bad < 2e-3, (k, bad, float(err.max()))
+
+
+def test_c4_full_shape_msd_big_standin_mf_d128():
+  """C4 at the stated stand-in shape (the true MSD-big size is unpublished):
+  1,000,000 users x 250,000 items, mean degree 50, MF d = 128, SparseAdam, 3 steps vs the oracle."""
+  from recoder_amd import synthetic
+  csr = synthetic.lognormal_zipf(1000000, 250000, 50, seed=2)
+  cfg = dict(kind="mf", d=128, loss="mse", sparse=True)
+  order = np.random.RandomState(3).permutation(csr.shape[0]).astype(np.int64)
+  rec, model, init, losses = _train(csr, cfg, 3, order)
+  o = orc.OracleRecoder("mf", init, activation_type="none", sparse=True, loss="mse", lr=1e-3, weight_decay=2e-5)
+  for i in range(3):
+    users = order[i * 500:(i + 1) * 500]
+    b = orc.collate(orc.extract_rows(csr, users), users, 500, True)[0]
+    want = o.train_step(b)
+    assert abs(losses[i] - want) / abs(want) < 1e-5, (i, losses[i], want)
+
+
+def test_c5_rank_shard_resident_generated_on_device():
+  """C5 as one of its 8 ranks sees it: the 1.25 M-user x 1 M-item shard (125 M interactions,
+  density 1e-4) GENERATED ON THE DEVICE and resident in HBM (never a host array), AE [512],
+  SparseAdam; the first step against the oracle on the same 500 users, then 20 more steps."""
+  import scipy.sparse as sp
+  from recoder_amd import synthetic
+  from recoder_amd.data import DeviceDataset
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder
+  n_users, n_items = 1250000, 1000000
+  dcsr = synthetic.device_csr(n_users, n_items, 100, seed=3)
+  assert dcsr.shape == (n_users, n_items) and 1.2e8 < dcsr.nnz <= 1.25e8
+  order = np.random.RandomState(4).permutation(n_users).astype(np.int64)
+  torch.manual_seed(0)
+  model = DynamicAutoencoder(hidden_layers=[512], activation_type="tanh", noise_prob=0.0, sparse=True)
+  rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss="mse")
+  rec.user_order_hook = lambda epoch, n: order
+  ds = DeviceDataset(dcsr)
+  rec._Recoder__init_training(ds, 1e-3, 0.0)
+  init = {k: v.detach().cpu().clone() for k, v in model.named_parameters()}
+  rec.train(ds, batch_size=500, lr=1e-3, weight_decay=0.0, num_epochs=1, iters_per_epoch=21,
+            negative_sampling=True)
+  losses = rec.last_epoch_losses
+  assert len(losses) == 21 and np.all(np.isfinite(losses)) and losses[-1] < losses[0]
+  # the first batch's rows, pulled from HBM, for the oracle
+  users = order[:500]
+  ip = dcsr.indptr.cpu().numpy()
+  idx = dcsr.indices
+  rows = [idx[ip[u]:ip[u + 1]].cpu().numpy() for u in users]
+  indptr = np.concatenate([[0], np.cumsum([len(r) for r in rows])])
+  sub = sp.csr_matrix((np.ones(indptr[-1], np.float32), np.concatenate(rows), indptr), shape=(500, n_items))
+  o = orc.OracleRecoder("ae", init, hidden_layers=[512], activation_type="tanh", sparse=True, loss="mse",
+                        lr=1e-3, weight_decay=0.0)
+  b = orc.collate(sub, users, 500, True)[0]
+  want = o.train_step(b)
+  assert abs(losses[0] - want) / abs(want) < 1e-5, (losses[0], want)

@@ -215,7 +215,7 @@ def _dw3_case(B, h, n_t, gtop, ztop, give_G, seed=5, n_items=None):
   nbytes = lib.rk_dw3_workspace_bytes(B, h, blk.n_cap)
   ws = torch.full((nbytes // 4 + 64,), float("nan"), device=dev)
   G = torch.full((blk.n_cap * h,), float("nan"), device=dev) if give_G else None
-  check(lib.rk_decode_bwd_dw3(ptr(dO_dev), ptr(Zd), B, h, blk.ref, ptr(G), None, ptr(ws),
+  check(lib.rk_decode_bwd_dw3(ptr(dO_dev), ptr(Zd), B, h, blk.ref, ptr(G), None, ptr(ws), None,
                               current_stream()), "rk_decode_bwd_dw3")
   torch.cuda.synchronize()
   ns = int(blk.counts[4].item())

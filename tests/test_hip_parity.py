@@ -229,6 +229,20 @@ def test_eval_matches_reference_golden(name):
   same = (recs == gold).mean()
   print(name, "top-k positions identical: %.4f" % same)
   assert same > 0.99
+  # index work is exact given equal scores: a position may only differ from the reference's where
+  # the two items' scores are tied to rounding (1e-5 relative)
+  for i in np.nonzero((recs != gold).any(axis=1))[0]:
+    sc = rec.predict(UsersInteractions(users[i:i + 1], g.csr[users[i:i + 1]]))[0][0].cpu().numpy()
+    for p in np.nonzero(recs[i] != gold[i])[0]:
+      a, b = sc[recs[i][p]], sc[gold[i][p]]
+      assert abs(a - b) <= 1e-5 * max(abs(a), abs(b), 1e-30), (i, p, a, b)
+  # the strip-wise path (catalogue decoded 40 items at a time, winners merged) gives the same lists
+  rec.eval_strip_items = 40
+  recs_s = []
+  for off in range(0, len(users), 50):
+    u = users[off:off + 50]
+    recs_s += rec.recommend(UsersInteractions(u, g.csr[u]), 20)
+  assert np.array_equal(np.asarray(recs_s), recs)
   r20, r5, n20 = Recall(20), Recall(5), NDCG(20)
   v = {"recall20": [], "recall5": [], "ndcg20": []}
   for i, u in enumerate(users):
@@ -650,6 +664,18 @@ class _VirtualRanks:
   def allgather(self, rank):
     return lambda t: self._exchange(rank, t)
 
+  def allreduce_max(self, rank):
+    def fn(t):
+      parts = self._exchange(rank, t)
+      acc = parts[0]
+      for q in parts[1:]:
+        acc = torch.maximum(acc, q)
+      t.copy_(acc)
+      torch.cuda.synchronize()
+      self.barrier.wait()
+      return t
+    return fn
+
 
 @pytest.mark.parametrize("case", ["mse_dense", "bce_sparse_tied", "ae2_dropout", "ae_logloss", "mf_dense",
                                   "mf_sparse"])
@@ -732,3 +758,188 @@ def test_item_parallel_two_virtual_ranks_equal_single_process(case):
     for k, v in model.named_parameters():
       frac, mx, scale = close_stats(v.detach().cpu().numpy(), base_p[k].numpy(), 1e-4, 2e-6)
       assert frac < 2e-3, (k, frac, mx, scale)
+
+
+@pytest.mark.parametrize("case", ["mse_dense", "bce_sparse_tied", "ae2_dropout", "ae_logloss"])
+def test_data_parallel_two_virtual_ranks_equal_single_process(case):
+  """parallel.DataParallel (users sharded -- north_star's partitioning, the multi-GPU default)
+  with N = 2 on one GPU: two threads drive the REAL product class -- two-phase collation with the
+  MAX-reduced item stamps, the engine's data-parallel phases of rk_ae_train_step, one group of
+  SUM all-reduces per step -- with in-process collectives.  Both replicas must equal the
+  single-process run with batch_size = 2 * B over the interleaved user order (the reference's own
+  "one item set, several row blocks" semantics, data.py:216-223,231-249)."""
+  import threading
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder
+  from recoder_amd.parallel import DataParallel, shard_range
+  csr = synth_csr(1200, 1500, 20, seed=23)
+  B, world = 150, 2
+  if case == "mse_dense":
+    mk = lambda: DynamicAutoencoder([64], activation_type="tanh", noise_prob=0.0, sparse=False)
+    loss, wd = "mse", 2e-5
+  elif case == "bce_sparse_tied":
+    mk = lambda: DynamicAutoencoder([32], activation_type="sigmoid", noise_prob=0.0, sparse=True,
+                                    is_constrained=True)
+    loss, wd = "logistic", 0.0
+  elif case == "ae2_dropout":
+    mk = lambda: DynamicAutoencoder([48, 24], activation_type="tanh", noise_prob=0.0, dropout_prob=0.0,
+                                    sparse=False)
+    loss, wd = "mse", 1e-5
+  else:
+    mk = lambda: DynamicAutoencoder([32], activation_type="tanh", noise_prob=0.0, sparse=False)
+    loss, wd = "logloss", 2e-5
+  n = csr.shape[0]
+  per = n // world
+  rng = np.random.RandomState(6)
+  shard_orders = [rng.permutation(shard_range(n, r, world)[1] - shard_range(n, r, world)[0])[:per]
+                  .astype(np.int64) for r in range(world)]
+  kw = dict(lr=1e-3, weight_decay=wd, num_epochs=2, negative_sampling=True)
+
+  def new():
+    torch.manual_seed(19)
+    model = mk()
+    return model, Recoder(model=model, use_cuda=True, optimizer_type="adam", loss=loss)
+
+  # single process: global batch = rank 0's B users followed by rank 1's B users, step by step
+  lo1 = shard_range(n, 1, world)[0]
+  glob = []
+  for off in range(0, per, B):
+    glob += list(shard_orders[0][off:off + B]) + list(lo1 + shard_orders[1][off:off + B])
+  glob = np.asarray(glob, dtype=np.int64)
+  assert len(glob) == n
+  model0, rec0 = new()
+  rec0.user_order_hook = lambda epoch, n_: glob
+  rec0.train(RecommendationDataset(csr), batch_size=world * B, **kw)
+  base_l = np.concatenate(rec0.loss_history)
+  base_p = {k: v.detach().cpu().clone() for k, v in model0.named_parameters()}
+
+  vr = _VirtualRanks(world)
+  reps = []
+  for r in range(world):
+    model, rec = new()
+    rec._Recoder__init_training(RecommendationDataset(csr), kw["lr"], wd)   # same seed, main thread
+    rec._dp_override = DataParallel(rank=r, world=world, allreduce_fn=vr.allreduce(r),
+                                    allreduce_max_fn=vr.allreduce_max(r))
+    rec.user_order_hook = (lambda rr: (lambda epoch, n_: shard_orders[rr]))(r)
+    reps.append((model, rec))
+  errs = []
+
+  def run(r):
+    try:
+      torch.cuda.set_device(0)
+      reps[r][1].train(RecommendationDataset(csr), batch_size=B, **kw)
+    except BaseException as e:       # noqa: B036 -- release the other thread
+      errs.append(e)
+      vr.barrier.abort()
+  threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=300)
+  assert not errs, errs
+  for model, rec in reps:
+    assert rec._dp is not None and rec._ip is None
+    got_l = np.concatenate(rec.loss_history)
+    assert len(got_l) == len(base_l)
+    assert np.allclose(got_l, base_l, rtol=2e-5, atol=0), (got_l[:3], base_l[:3])
+    for k, v in model.named_parameters():
+      frac, mx, scale = close_stats(v.detach().cpu().numpy(), base_p[k].numpy(), 1e-4, 2e-6)
+      assert frac < 2e-3, (k, frac, mx, scale)
+
+
+@pytest.mark.parametrize("case", ["dense_noise", "sparse_tied_bce", "logloss"])
+def test_graph_replay_is_bitwise_equal_to_eager_steps(case, monkeypatch):
+  """recoder_amd/graph.py: groups of steps replayed as HIP graphs (users, stamps, RNG step, Adam
+  constants and loss slot derived on the device from a cursor) must reproduce the eagerly
+  enqueued steps bit for bit -- over several epochs, with a ragged last batch, a tail that does not
+  fill a group and a step mark that cuts a group."""
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder
+  csr = synth_csr(1430, 900, 18, seed=31)          # 1430 = 11 x 128 + 22: ragged tail
+  if case == "dense_noise":
+    mk = lambda: DynamicAutoencoder([64], activation_type="tanh", noise_prob=0.4, sparse=False)
+    loss, wd = "mse", 2e-5
+  elif case == "sparse_tied_bce":
+    mk = lambda: DynamicAutoencoder([32], activation_type="sigmoid", noise_prob=0.0, sparse=True,
+                                    is_constrained=True)
+    loss, wd = "logistic", 0.0
+  else:
+    mk = lambda: DynamicAutoencoder([32], activation_type="tanh", noise_prob=0.3, sparse=False)
+    loss, wd = "logloss", 1e-5
+  orders = [np.random.RandomState(40 + e).permutation(csr.shape[0]).astype(np.int64) for e in range(4)]
+
+  def run(graph):
+    monkeypatch.setenv("RK_GRAPH", "1" if graph else "0")
+    torch.manual_seed(23)
+    model = mk()
+    rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss=loss)
+    rec.user_order_hook = lambda epoch, n: orders[epoch]
+    seen = []
+    rec.step_marks = {7: lambda: seen.append(7) or False, 18: lambda: seen.append(18) or False}
+    rec.train(RecommendationDataset(csr), batch_size=128, lr=1e-3, weight_decay=wd, num_epochs=3,
+              negative_sampling=True, lr_milestones=[2])
+    assert seen == [7, 18]
+    assert (getattr(rec, "_graph_stepper", None) is not None) == graph
+    return (np.concatenate(rec.loss_history),
+            {k: v.detach().cpu().clone() for k, v in model.named_parameters()},
+            {k: (int(s.step), s.m.detach().cpu().clone()) for k, s in rec._engine().states.items()})
+  l0, p0, a0 = run(False)
+  l1, p1, a1 = run(True)
+  assert len(l0) == 36 and np.array_equal(l0, l1), np.abs(l0 - l1).max()
+  for k in p0:
+    assert torch.equal(p0[k], p1[k]), k
+  for k in a0:
+    assert a0[k][0] == a1[k][0] and torch.equal(a0[k][1], a1[k][1]), k
+
+
+def test_topk_tie_rule_and_strip_merge():
+  """rk_topk_masked: exact ties resolve to the LOWER item id; only POSITIVE stored interactions are
+  masked (model.py:537); the strip-wise top-k + merge equals the one-pass top-k."""
+  import scipy.sparse as sp
+  from recoder_amd import _lib
+  from recoder_amd._lib import check
+  from recoder_amd.device import Block, DeviceCSR, current_stream
+  lib = _lib.load()
+  dev = torch.device("cuda")
+  B, n, k = 37, 3000, 25
+  rng = np.random.RandomState(3)
+  # heavily quantised scores: many exact ties
+  sc = (rng.randint(0, 40, size=(B, n)) / 8.0).astype(np.float32)
+  rows = np.repeat(np.arange(B), 30)
+  cols = rng.randint(0, n, size=len(rows))
+  vals = rng.choice([-2.0, 1.0, 3.0], size=len(rows)).astype(np.float32)    # negatives: NOT masked
+  m = sp.coo_matrix((vals, (rows, cols)), shape=(B, n)).tocsr()
+  m.sum_duplicates()
+  m.eliminate_zeros()
+  dcsr = DeviceCSR(m)
+  blk = Block(B, int(m.nnz), n, dev, negative_sampling=False, need_bits_cr=False)
+  blk.collate(dcsr, torch.arange(B, dtype=torch.int64, device=dev), negative_sampling=False)
+  dense = np.asarray(m.todense())
+  masked = sc.copy()
+  masked[dense > 0] = -np.inf
+  want = np.argsort(-masked, axis=1, kind="stable")[:, :k]       # ties: lower index first
+  ld = 3008
+  sd = torch.zeros(B, ld, device=dev)
+  sd[:, :n] = torch.from_numpy(sc).to(dev)
+  idx = torch.empty(B, k, dtype=torch.int64, device=dev)
+  val = torch.empty(B, k, dtype=torch.float32, device=dev)
+  check(lib.rk_topk_masked(sd.data_ptr(), B, n, ld, blk.ref, 0, k, idx.data_ptr(), val.data_ptr(),
+                           current_stream()), "rk_topk_masked")
+  assert np.array_equal(idx.cpu().numpy(), want)
+  assert np.array_equal(val.cpu().numpy(), np.take_along_axis(masked, want, 1))
+  # strips of 700 columns (the last one 200 wide), then the merge
+  strip, ns = 700, 5
+  cidx = torch.empty(B, ns * k, dtype=torch.int64, device=dev)
+  cval = torch.empty(B, ns * k, dtype=torch.float32, device=dev)
+  for s_ in range(ns):
+    lo, hi = s_ * strip, min(n, (s_ + 1) * strip)
+    part = sd[:, lo:hi].contiguous()
+    check(lib.rk_topk_masked_strip(part.data_ptr(), B, hi - lo, hi - lo, blk.ref, 0, k, lo,
+                                   cidx[:, s_ * k:].data_ptr(), cval[:, s_ * k:].data_ptr(), ns * k,
+                                   current_stream()), "rk_topk_masked_strip")
+  pos = torch.empty(B, k, dtype=torch.int64, device=dev)
+  check(lib.rk_topk_masked(cval.data_ptr(), B, ns * k, ns * k, None, 0, k, pos.data_ptr(), None,
+                           current_stream()), "rk_topk_masked")
+  assert np.array_equal(torch.gather(cidx, 1, pos).cpu().numpy(), want)

@@ -228,3 +228,36 @@ def test_train_from_device_dataset_equals_host_dataset():
   a = run(RecommendationDataset(m))
   b = run(DeviceDataset(DeviceCSR.from_arrays(m.shape, m.indptr, m.indices, None)))
   assert np.array_equal(a, b)
+
+
+# ------------------------------------------------- training on a dataset WITH a target matrix
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ae", "ae2_sparse", "mf"])
+def test_training_with_target_matrix_replays_reference(name):
+  """reference data.py:60-62 + model.py:464-472: (input, target) batches in the hot loop -- decode,
+  loss, dW and the decoder-side updates over the TARGET batch's item set, the encoder side over the
+  input's.  Golden losses / final parameters from the reference itself."""
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder, MatrixFactorization
+  from tests.golden.make_golden_io import TARGET_CONFIGS
+  cfg = TARGET_CONFIGS[name]
+  g = np.load(os.path.join(GOLD, "train_target_%s.npz" % name))
+  shape = tuple(int(x) for x in g["csr/shape"])
+  csr = sp.csr_matrix((g["csr/data"], g["csr/indices"], g["csr/indptr"]), shape=shape)
+  csr_t = sp.csr_matrix((g["csr_t/data"], g["csr_t/indices"], g["csr_t/indptr"]), shape=shape)
+  torch.manual_seed(8642)
+  model = DynamicAutoencoder(**cfg["model"]) if cfg["kind"] == "ae" else MatrixFactorization(**cfg["model"])
+  rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss=cfg["loss"])
+  n = shape[0]
+  rec.user_order_hook = lambda epoch, n_: g["order"][(epoch - 1) * n:epoch * n]
+  rec.train(RecommendationDataset(csr, csr_t), **cfg["train"])
+  for k, p in model.named_parameters():
+    pass
+  losses = np.concatenate(rec.loss_history)
+  assert len(losses) == len(g["losses"])
+  rel = np.abs(losses - g["losses"]) / np.abs(g["losses"])
+  assert rel.max() < 1e-5, (rel.argmax(), rel.max(), losses[:3], g["losses"][:3])
+  for k, p in model.named_parameters():
+    want = g["final/" + k]
+    assert np.abs(p.detach().cpu().numpy() - want).max() < 2e-4 * max(1.0, np.abs(want).max()), k

@@ -36,7 +36,7 @@ def main():
   for it in range(3):
     probe.zero_()
     lib.rk_dw3_probe(probe.data_ptr())
-    check(lib.rk_decode_bwd_dw3(ptr(dO), ptr(Z), B, h, blk.ref, None, None, ptr(ws), st))
+    check(lib.rk_decode_bwd_dw3(ptr(dO), ptr(Z), B, h, blk.ref, None, None, ptr(ws), None, st))
     torch.cuda.synchronize()
   lib.rk_dw3_probe(None)
   p = probe.cpu().numpy().reshape(n_wg, 16)

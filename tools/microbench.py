@@ -82,17 +82,15 @@ def main():
         ptr(Z), B, h, blk.ref, 0, ptr(W), ptr(bias), LOSS_NONE, 0.0, 1.0, ptr(out), blk.ld_cap, None,
         None, st)))
     r["dz"] = timeit(lambda: check(lib.rk_decode_bwd_dz(
-        ptr(dO), B, h, blk.ref, ptr(W), None, 0, ptr(dZ), ptr(ws), st)))
+        ptr(dO), B, h, blk.ref, ptr(W), None, 0, ptr(dZ), ptr(ws), None, st)))
     r["dw"] = timeit(lambda: check(lib.rk_decode_bwd_dw(
         ptr(dO), ptr(Z), B, h, blk.ref, ptr(G), None, st)))
     ws3 = torch.zeros(lib.rk_dw3_workspace_bytes(B, h, blk.n_cap) // 4 + 64, **f)
     dO.normal_()
     r["dw3_slabs"] = timeit(lambda: check(lib.rk_decode_bwd_dw3(
-        ptr(dO), ptr(Z), B, h, blk.ref, None, None, ptr(ws3), st)))
+        ptr(dO), ptr(Z), B, h, blk.ref, None, None, ptr(ws3), None, st)))
     r["dw3_G"] = timeit(lambda: check(lib.rk_decode_bwd_dw3(
-        ptr(dO), ptr(Z), B, h, blk.ref, ptr(G), None, ptr(ws3), st)))
-    r["planes"] = timeit(lambda: check(lib.rk_split_planes_t(
-        ptr(Z), B, h, h, -(-B // 64) * 64, 256 * (-(-h // 256)) if h > 128 else 128, ptr(ws3), st)))
+        ptr(dO), ptr(Z), B, h, blk.ref, ptr(G), None, ptr(ws3), None, st)))
     r["enc_fwd"] = timeit(lambda: check(lib.rk_ae_encode_fwd(
         blk.ref, 0, B, ptr(W), ptr(bias), h, None, 0.5, 1, 1, ptr(users), 1, ptr(Z0), st)))
     r["enc_bwd"] = timeit(lambda: check(lib.rk_ae_encode_bwd(blk.ref, 0, B, ptr(dZ), h, ptr(G), 0, None, st)))
