@@ -203,7 +203,7 @@ def main():
       dist.barrier()
       torch.cuda.synchronize()
 
-  G = max(1, int(rec.prefetch_group))       # steps per replayed graph (recoder_amd/graph.py)
+  G = max(1, int(rec.graph_group))          # steps per replayed graph (recoder_amd/graph.py)
 
   def plan_warm(i):
     # warm-up: the first group of steps runs eagerly with every launch group bracketed, the rest

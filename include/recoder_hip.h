@@ -416,17 +416,15 @@ typedef struct rk_ae_step {
    * cursor[1] + off) * RK_PAR_COUNT + par] (8 floats each, rk_adam_consts), the loss goes to
    * loss_out[cursor[0] - cursor[1] + off].  cursor == NULL: the host values above are used. */
   const int64_t *cursor;
-  int32_t cursor_off, pad_;
+  int32_t cursor_off;
+  int32_t cursor_advance;    /* with cursor_next: the last step of a replayed group publishes the
+                                cursor of the NEXT group, {cursor[0] + cursor_advance, cursor[1]},
+                                into cursor_next (a second buffer -- launches of this group may
+                                still be reading `cursor`); done by the Adam launch, no extra kernel */
   const void *adam_table;
+  int64_t *cursor_next;
   void *const *time_all;     /* time_entry == RK_ENTRY_ALL: host array of 2 * RK_ENTRY_COUNT timing
                                 events, entry e is bracketed by [2e] and [2e + 1] */
-  /* Optional second branch (whole untied MSE / BCE steps on the 16-bit pipe): dW only needs dO
-   * and Z, so with stream2 != NULL it is enqueued on stream2 between two event edges (after the
-   * decode, before the Adam sweep) and runs beside dZ -> reduce -> encoder backward.  Inside a
-   * graph capture the edges become graph dependencies.  ws2: a dW workspace of its own
-   * (rk_dw3_workspace_bytes), since `ws` is busy with the dZ slabs meanwhile. */
-  void *stream2, *ev_fork, *ev_join;
-  float *ws2;
 } rk_ae_step_t;
 
 void *rk_event_create(void);          /* ordering-only (no timing, device-scope fence) */

@@ -67,9 +67,9 @@ class RkAeStep(Structure):
     ("time_ev0", c_void_p), ("time_ev1", c_void_p),
     ("user_norm", c_void_p), ("own_rank", c_int32), ("own_world", c_int32),
     ("zt_planes", c_void_p),
-    ("cursor", c_void_p), ("cursor_off", c_int32), ("pad_", c_int32), ("adam_table", c_void_p),
+    ("cursor", c_void_p), ("cursor_off", c_int32), ("cursor_advance", c_int32), ("adam_table", c_void_p),
+    ("cursor_next", c_void_p),
     ("time_all", POINTER(c_void_p)),
-    ("stream2", c_void_p), ("ev_fork", c_void_p), ("ev_join", c_void_p), ("ws2", c_void_p),
   ]
 
 

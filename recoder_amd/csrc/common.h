@@ -37,7 +37,8 @@ int rk_ae_encode_fwd_at(const rk_block_t *blk, int32_t row_off, int32_t B, const
                         float *Z0, void *zt_planes, void *stream);
 int rk_adam_multi_at(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part, int32_t n_part,
                      float denom, float *loss_out, const int64_t *cursor, int32_t cursor_off,
-                     const void *table, int32_t tab_stride, const int32_t *tab_slots, void *stream);
+                     const void *table, int32_t tab_stride, const int32_t *tab_slots,
+                     int64_t *cursor_next, int32_t advance, void *stream);
 
 // ---------------------------------------------------------------- activations
 // y = act(x);  derivative expressed through y (what autograd of torch.tanh /

@@ -214,6 +214,10 @@ struct UArgs {
   rk_cur_t cur;
   const AdamC *ctab;
   int tab_stride;
+  // last step of a replayed group: the cursor the NEXT group reads (a second buffer: this
+  // group's other launches may still be reading `cur`) <- this one advanced by `advance`
+  int64_t *cursor_next;
+  int advance;
 };
 
 template <typename T> struct VecOps;
@@ -339,7 +343,13 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(UArgs a) {
       if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
       __syncthreads();
     }
-    if (threadIdx.x == 0) a.loss_out[a.cur.cursor ? rk_cur_local(a.cur) : 0] = (float)red[0] / a.denom;
+    if (threadIdx.x == 0) {
+      a.loss_out[a.cur.cursor ? rk_cur_local(a.cur) : 0] = (float)red[0] / a.denom;
+      if (a.cursor_next) {
+        a.cursor_next[0] = a.cur.cursor[0] + a.advance;
+        a.cursor_next[1] = a.cur.cursor[1];
+      }
+    }
     return;
     }
   }
@@ -429,7 +439,8 @@ extern "C" int rk_adam_dense(float *p, float *m, float *v, const float *g, int64
 // loss_out[step in epoch]
 int rk_adam_multi_at(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part, int32_t n_part,
                      float denom, float *loss_out, const int64_t *cursor, int32_t cursor_off,
-                     const void *table, int32_t tab_stride, const int32_t *tab_slots, void *stream_) {
+                     const void *table, int32_t tab_stride, const int32_t *tab_slots,
+                     int64_t *cursor_next, int32_t advance, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(n_jobs >= 0 && n_jobs <= RK_ADAM_MULTI_MAX, "too many jobs for one launch");
   RK_REQUIRE(n_jobs == 0 || jobs != nullptr, "null jobs");
@@ -477,6 +488,9 @@ int rk_adam_multi_at(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part
   if (a.n_jobs == 0) { a.n_jobs = 1; a.job[0].nblk = 0; a.job[0].h = 1; }   // loss only
   a.cur.cursor = cursor; a.cur.off = cursor_off;
   a.ctab = (const AdamC *)table; a.tab_stride = tab_stride;
+  RK_REQUIRE(cursor_next == nullptr || (cursor != nullptr && loss_part != nullptr && cursor_next != cursor),
+             "cursor_next needs a cursor, the loss block and a buffer of its own");
+  a.cursor_next = cursor_next; a.advance = advance;
   RK_LAUNCH(adam_multi_kernel, dim3(blocks), dim3(256), 0, stream, a);
   RK_CHECK_LAUNCH("adam_multi");
   return 0;
@@ -485,7 +499,7 @@ int rk_adam_multi_at(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part
 extern "C" int rk_adam_multi(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part,
                              int32_t n_part, float denom, float *loss_out, void *stream_) {
   return rk_adam_multi_at(jobs, n_jobs, loss_part, n_part, denom, loss_out, nullptr, 0, nullptr, 0,
-                          nullptr, stream_);
+                          nullptr, nullptr, 0, stream_);
 }
 
 // one entry of the per-step constants table (8 floats): exactly what rk_adam_multi derives from

@@ -134,11 +134,10 @@ rk_adam_job_t table_job(const rk_adam_param_t &par, const rk_block_t *blk, int n
 // dW = dO^T . Z: the bf16-pipe kernel (dw3.hip) when the split contractions are on and the step
 // has a workspace, else the fp32-MFMA tiles.  G_de == NULL (dw3 only): the K slabs stay in the
 // workspace for rk_adam_multi.
-int dw_call(const rk_ae_step_t *a, float *G_de, float *gb_de, bool have_planes,
-            float *ws = nullptr, void *stream = nullptr) {
+int dw_call(const rk_ae_step_t *a, float *G_de, float *gb_de, bool have_planes) {
   if (rk_gemm_split16() && a->ws)
-    return rk_decode_bwd_dw3(a->dO, a->Z0, a->B, a->h, a->blk, G_de, gb_de, ws ? ws : a->ws,
-                             have_planes ? a->zt_planes : nullptr, stream ? stream : a->stream);
+    return rk_decode_bwd_dw3(a->dO, a->Z0, a->B, a->h, a->blk, G_de, gb_de, a->ws,
+                             have_planes ? a->zt_planes : nullptr, a->stream);
   return rk_decode_bwd_dw(a->dO, a->Z0, a->B, a->h, a->blk, G_de, gb_de, a->stream);
 }
 
@@ -261,8 +260,6 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   // the encoder forward writes the Z^T planes of the bf16-pipe dW kernel along with Z
   const bool planes = rk_gemm_split16() && a->ws != nullptr && a->zt_planes != nullptr &&
                       (phase & RK_STEP_FWD_DW) != 0;
-  const bool branch = dw3 && a->stream2 != nullptr && a->ev_fork != nullptr && a->ev_join != nullptr &&
-                      a->ws2 != nullptr;
 
   if (phase & RK_STEP_FWD_DW) {
     {
@@ -284,13 +281,6 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       RK_TRY(rk_decode_loss(a->Z0, B, h, blk, a->row_off, W_de, a->par[RK_PAR_B_DE].p, a->loss_kind,
                             a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, sm));
       if (mnll) RK_TRY(rk_mnll_finish(a->dO, B, blk, a->row_off, a->inv_B, a->loss_part, sm));
-    }
-    if (branch) {
-      // second branch: dW beside dZ -> reduce -> encoder backward (joined before the Adam sweep)
-      RK_TRY(rk_event_record(a->ev_fork, sm));
-      RK_TRY(rk_stream_wait_event(a->stream2, a->ev_fork));
-      RK_TRY(dw_call(a, nullptr, nullptr, planes, a->ws2, a->stream2));
-      RK_TRY(rk_event_record(a->ev_join, a->stream2));
     }
     // dW: on its own (tied weights: the encoder backward accumulates onto its rows;
     // MNLL: + column sums of dO; data parallel: G_de must travel early), otherwise
@@ -316,7 +306,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     } else if (dw3) {
       // the dZ slabs in the workspace are consumed: the bf16-pipe dW takes it over (Z^T planes +
       // its own K slabs, which rk_adam_multi sums while it reads the gradient)
-      if (!branch) {
+      {
         Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
         RK_TRY(dw_call(a, nullptr, nullptr, planes));
       }
@@ -340,7 +330,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     if (!a->tied) {
       jobs[n] = table_job(a->par[RK_PAR_W_DE], blk, n_items, h, a->G_de, true);
       if (dw3) {
-        jobs[n].g = rk_dw3_slabs(branch ? a->ws2 : a->ws, B, h); jobs[n].g_parts = rk_dw3_max_splits();
+        jobs[n].g = rk_dw3_slabs(a->ws, B, h); jobs[n].g_parts = rk_dw3_max_splits();
         jobs[n].g_stride = blk->n_cap * h; jobs[n].gparts_dev = blk->counts + 4;
       }
       slots[n] = RK_PAR_W_DE;
@@ -361,11 +351,10 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     ++n;
     RK_REQUIRE(a->cursor == nullptr || (whole && a->adam_table != nullptr),
                "graph replay covers whole steps and needs the Adam constants table");
-    if (branch) RK_TRY(rk_stream_wait_event(sm, a->ev_join));
     Timer t(a, RK_ENTRY_ADAM_MULTI, sm);
     RK_TRY(rk_adam_multi_at(jobs, n, whole ? a->loss_part : nullptr, n_part, a->denom,
                             whole ? a->loss_out : nullptr, a->cursor, a->cursor_off, a->adam_table,
-                            RK_PAR_COUNT, slots, sm));
+                            RK_PAR_COUNT, slots, a->cursor_next, a->cursor_advance, sm));
   }
   return 0;
 }

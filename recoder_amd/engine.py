@@ -558,18 +558,11 @@ class FusedEngine:
     self.n_cap_last = blk.n_cap
     st.loss_part, st.loss_out = ptr(self.loss_part), ptr(loss_dst)
     st.stream = main_s.cuda_stream
-    st.stream2, st.ev_fork, st.ev_join, st.ws2 = None, None, None, None
-    if replay is not None and replay.get("branch") is not None and dw3:
-      # dW on a second branch of the captured graph (rk_ae_step_t.stream2)
-      if getattr(self, "ws2", None) is None or self.ws2.numel() * 4 < \
-          self.lib.rk_dw3_workspace_bytes(self.B_cap, self.h[0], self.n_cap):
-        self.ws2 = torch.zeros(self.lib.rk_dw3_workspace_bytes(self.B_cap, self.h[0], self.n_cap) // 4 + 64,
-                               dtype=torch.float32, device=self.device)
-      st.stream2, st.ev_fork, st.ev_join = replay["branch"]
-      st.ws2 = ptr(self.ws2)
-    st.cursor, st.cursor_off, st.adam_table = None, 0, None
+    st.cursor, st.cursor_off, st.adam_table, st.cursor_next, st.cursor_advance = None, 0, None, None, 0
     if replay is not None:
       st.cursor, st.cursor_off, st.adam_table = replay["cursor"], replay["off"], replay["table"]
+      if replay.get("next") is not None:         # last step of a group: publish the next cursor
+        st.cursor_next, st.cursor_advance = replay["next"]
       st.users = replay["users"]             # base of the epoch's user order (offset on the device)
     self._c_calls += 1
     name = None

@@ -4,7 +4,7 @@ One optimisation step of the common autoencoder case is 6 collation launches + 7
 enqueued one by one the host spends 50-120 us per step on them -- as much as the GPU needs to run
 them.  ``GraphStepper`` captures a GROUP of G steps as one HIP graph,
 
-    main stream :  step(block[v][0]) ... step(block[v][G-1])  ->  cursor += G
+    main stream :  step(block[v][0]) ... step(block[v][G-1])   (the last one publishes cursor + G)
     side stream :  collate(block[1-v][0..G-1])  for the NEXT group      (forked / joined by events)
 
 and replays it with one ``hipGraphLaunch`` per G steps.  A replayed launch cannot take new
@@ -38,7 +38,9 @@ class GraphStepper:
     self.blocks = [[make_block() for _ in range(self.G)] for _ in range(2)]
     self.tail_blk = make_block()            # ragged last batch: eager, host-provided arguments
     engine.ensure_capacity(self.B, self.blocks[0][0].n_cap)
-    self.cursor = torch.zeros(2, dtype=torch.int64, device=device)
+    # two cursors: the group on slot v reads cursor[v]; its last Adam launch writes cursor[1 - v]
+    # (= its own + the steps it ran) for the group that follows on the other slot
+    self.cursors = torch.zeros(2, 2, dtype=torch.int64, device=device)
     self.steps_cap = -(-n_users // self.B)
     # the epoch's user order, padded so that the look-ahead collation of the group after the last
     # one reads valid user ids (its blocks are never trained on)
@@ -51,13 +53,8 @@ class GraphStepper:
     self.side = torch.cuda.Stream(device=device)
     self.ev_fork, self.ev_join = self.lib.rk_event_create(), self.lib.rk_event_create()
     self.st = [[RkAeStep() for _ in range(self.G)] for _ in range(2)]
-    # RK_GRAPH_BRANCH=1: dW on a second branch of every captured step (step.hip `branch`)
-    import os
-    self.branch = os.environ.get("RK_GRAPH_BRANCH", "0") == "1"
-    self.stream2 = torch.cuda.Stream(device=device)
-    self.bev = [[(self.lib.rk_event_create(), self.lib.rk_event_create()) for _ in range(self.G)]
-                for _ in range(2)]
     self.exec = [None, None]
+    self.warmed = False
     self.global_step = 0                   # steps this stepper's cursor has seen
     self.epoch_base = 0
 
@@ -73,21 +70,24 @@ class GraphStepper:
   def _h(self, stream):
     return ctypes.c_void_p(stream.cuda_stream)
 
-  def _collate(self, blk, off, stream):
+  def _cur(self, slot):
+    return self.cursors.data_ptr() + 16 * slot
+
+  def _collate(self, blk, off, stream, slot):
     d = self.dcsr
     blk.c.implicit = 1 if d.data is None else 0
     blk.S = self.B
     check(self.lib.rk_collate_at(ptr(d.indptr), ptr(d.indices), ptr(d.data), ptr(self.order), self.B,
-                                 1 if self.ns else 0, ptr(self.cursor), off, blk.ref, self._h(stream)),
+                                 1 if self.ns else 0, self._cur(slot), off, blk.ref, self._h(stream)),
           "rk_collate_at")
 
-  def _step(self, slot, g, index=None):
+  def _step(self, slot, g, index=None, advance=None):
     """Enqueue the training step of block [slot][g] (cursor offset g) on the main stream; index
-    != None: an eager step that bench.py's time plan may bracket."""
-    replay = dict(st=self.st[slot][g], cursor=ptr(self.cursor), off=g, table=ptr(self.table),
-                  users=ptr(self.order), timed=index is not None, index=index)
-    if self.branch and index is None:          # (captured steps only: eager edges cost 10-20 us)
-      replay["branch"] = (self.stream2.cuda_stream,) + self.bev[slot][g]
+    != None: an eager step that bench.py's time plan may bracket; advance: the group's last step
+    publishes the other slot's cursor."""
+    replay = dict(st=self.st[slot][g], cursor=self._cur(slot), off=g, table=ptr(self.table),
+                  users=ptr(self.order), timed=index is not None, index=index,
+                  next=None if advance is None else (self._cur(1 - slot), advance))
     self.eng._c_train_step(self.blocks[slot][g], 0, self.B, None, self.loss_buf, None, self.main,
                            replay=replay)
 
@@ -99,12 +99,12 @@ class GraphStepper:
     check(lib.rk_event_record(self.ev_fork, self._h(self.main)), "rk_event_record")
     check(lib.rk_stream_wait_event(self._h(self.side), self.ev_fork), "rk_stream_wait_event")
     for g in range(G):
-      self._collate(self.blocks[1 - slot][g], n_steps + g, self.side)
+      self._collate(self.blocks[1 - slot][g], n_steps + g, self.side, slot)
     for g in range(n_steps):
-      self._step(slot, g, None if first_index is None else first_index + g)
+      self._step(slot, g, None if first_index is None else first_index + g,
+                 advance=n_steps if g == n_steps - 1 else None)
     check(lib.rk_event_record(self.ev_join, self._h(self.side)), "rk_event_record")
     check(lib.rk_stream_wait_event(self._h(self.main), self.ev_join), "rk_stream_wait_event")
-    check(lib.rk_cursor_advance(ptr(self.cursor), n_steps, self._h(self.main)), "rk_cursor_advance")
 
   def _capture(self, slot):
     check(self.lib.rk_graph_begin(self._h(self.main)), "rk_graph_begin")
@@ -143,8 +143,6 @@ class GraphStepper:
     self.table.copy_(th, non_blocking=False)
     self.global_step = int(global_step)
     self.epoch_base = int(global_step)
-    check(self.lib.rk_cursor_set(ptr(self.cursor), self.global_step, self.epoch_base, self._h(self.main)),
-          "rk_cursor_set")
     self._collated = None                # slot whose blocks hold the steps at the cursor
     return n_full
 
@@ -156,9 +154,11 @@ class GraphStepper:
       return
     slot = 0
     if self._collated is None:
-      # nothing of the first group is in flight yet: collate it now
+      # nothing of the first group is in flight yet: point slot 0's cursor at it, collate it now
+      check(lib.rk_cursor_set(self._cur(0), self.global_step, self.epoch_base, self._h(self.main)),
+            "rk_cursor_set")
       for g in range(min(G, n_steps)):
-        self._collate(self.blocks[0][g], g, self.main)
+        self._collate(self.blocks[0][g], g, self.main, 0)
     else:
       slot = self._collated
     done = 0
@@ -167,11 +167,18 @@ class GraphStepper:
       idx0 = self.global_step
       if left >= G:
         eager = eager_plan is not None and any(eager_plan(idx0 + g) for g in range(G))
-        if eager:
+        # the very first group always runs eagerly: every kernel has then been launched (its code
+        # object loaded) before it is captured -- graphs captured cold replayed ~8x slower on the
+        # host -- and both graphs are captured right behind it (capturing enqueues nothing), i.e.
+        # in the warm-up of a benchmark, never inside its timed region
+        if eager or not self.warmed:
           self._group(slot, G, first_index=idx0)
+          if not self.warmed:
+            self.warmed = True
+            for v in (0, 1):
+              if self.exec[v] is None:
+                self._capture(v)
         else:
-          if self.exec[slot] is None:
-            self._capture(slot)         # (capturing enqueues nothing)
           check(lib.rk_graph_launch(self.exec[slot], self._h(self.main)), "rk_graph_launch")
         k = G
       else:

@@ -71,6 +71,8 @@ class Recoder(object):
     self.mask_hook = None
     # steps collated per side-stream hand-over (CollatePrefetcher)
     self.prefetch_group = int(os.environ.get("RK_PREFETCH_GROUP", "4"))
+    # steps per replayed HIP graph (graph.py)
+    self.graph_group = int(os.environ.get("RK_GRAPH_GROUP", "4"))
     # {global step index: callable}: called right before that step's collation is submitted and
     # its kernels are enqueued (the pipeline is cut there: nothing of the step is in flight yet);
     # returning True ends the training.  bench.py brackets its timed region with two of these.
@@ -666,11 +668,12 @@ class Recoder(object):
     dcsr = ds.device_csr()
     B, ns, n = dataloader.batch_size, dataloader.negative_sampling, len(ds)
     gs = getattr(self, "_graph_stepper", None)
-    if gs is None or gs.dcsr is not dcsr or gs.B != B or gs.ns != ns or gs.G != self.prefetch_group:
+    G = max(1, min(self.graph_group, n // B))
+    if gs is None or gs.dcsr is not dcsr or gs.B != B or gs.ns != ns or gs.G != G:
       if gs is not None:
         gs.close()
-      gs = GraphStepper(eng, dcsr, lambda: self._make_block(dcsr, B, ns, train=True), B, ns,
-                        self.prefetch_group, n, self.device)
+      gs = GraphStepper(eng, dcsr, lambda: self._make_block(dcsr, B, ns, train=True), B, ns, G, n,
+                        self.device)
       self._graph_stepper = gs
     order = None
     if self.user_order_hook is not None:

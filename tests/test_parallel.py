@@ -39,7 +39,10 @@ def _worker(rank, world, port, out):
   dist.init_process_group("gloo", rank=rank, world_size=world)
   torch.set_num_threads(1)
   from oracle import recoder_oracle as orc
-  from recoder_amd.parallel import allreduce_sum, shard_range, union_marks
+  from recoder_amd.parallel import DataParallel, shard_range
+  # the product class (users sharded; on CPU tensors its collectives go through torch.distributed)
+  dp = DataParallel().prepare(torch.device("cpu"))
+  assert dp.world == world and dp.rank == rank and not dp.direct
 
   n_users, n_items, B, h = 64, 90, 8, 12
   csr = _csr(n_users, n_items, 5)
@@ -56,7 +59,7 @@ def _worker(rank, world, port, out):
     rows = shard[users]
     stamp = step + 1
     mark[torch.from_numpy(np.unique(rows.indices).astype(np.int64))] = stamp   # phase 1
-    union_marks(mark)                                                      # all-reduce MAX
+    dp.union_marks(mark)                                                   # all-reduce MAX
     items = np.nonzero(mark.numpy() == stamp)[0].astype(np.int64)         # phase 2 (same on all ranks)
     pos = np.full(n_items, -1, dtype=np.int64)
     pos[items] = np.arange(len(items))
@@ -84,7 +87,7 @@ def _worker(rank, world, port, out):
         views.append(p.grad)
     lt = loss.detach().clone()
     views.append(lt)
-    allreduce_sum(views, small_threshold=64)
+    dp.reduce(views)                     # ONE exchange per step: every gradient + the loss
     for p, r in tables:
       p.grad.zero_()
       p.grad[idx] = r
