@@ -1,16 +1,18 @@
 #!/bin/bash
 # usage (on the GPU box): tools/profile_round.sh <tag>
-# kernel-trace stats + the two PMC traffic passes of the default bench -> gpurun_out/<tag>/
+# kernel-trace stats of the default bench (graph replay) + the two PMC traffic passes (eager
+# enqueue of the same kernels: RK_GRAPH=0) -> gpurun_out/<tag>/
 tag=${1:-prof}
 export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 rm -rf $out; mkdir -p $out
-B="python bench.py --steps 200 --warmup 20 --no-cpu-baseline"
+B="python bench.py --steps 200 --warmup 24 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format rocpd -d $out -o stats -- $B > $out/stats.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format rocpd -d $out -o fetch -- $B > $out/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format rocpd -d $out -o write -- $B > $out/write.log 2>&1
+RK_GRAPH=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format rocpd -d $out -o fetch -- $B > $out/fetch.log 2>&1
+RK_GRAPH=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format rocpd -d $out -o write -- $B > $out/write.log 2>&1
 python tools/rocpd_stats.py $(find $out -name 'stats_results.db') > $out/kernel_stats.md
 python tools/pmc_traffic.py $(find $out -name 'fetch_results.db') $(find $out -name 'write_results.db') > $out/pmc_traffic.json
-python tools/rocpd_timeline.py $(find $out -name 'stats_results.db') 150 > $out/timeline.txt
+python tools/rocpd_gaps.py $(find $out -name 'stats_results.db') 60 120 > $out/timeline.txt
 grep metric $out/stats.log > $out/bench_profiled.json
-cat $out/kernel_stats.md; cat $out/pmc_traffic.json; cat $out/timeline.txt
+$B > $out/bench.json 2> $out/bench.err
+cat $out/kernel_stats.md | head -20; cat $out/pmc_traffic.json; cat $out/timeline.txt
