@@ -15,10 +15,12 @@ rank per GPU; the USERS are sharded over the ranks (north_star's partitioning; w
 B users per rank per step) with one in-order RCCL group of gradient all-reduces per step.
 
 Also reported:
-  roofline     -- every launch group of the production step (rk_ae_train_step), timed with HIP
-                  events on the step's stream: all of them during the warm-up steps (rotating),
-                  the dominant one on every 8th step of the timed region, against its
-                  algorithmic flops / bytes.
+  roofline     -- every launch group of the production step (rk_ae_train_step) bracketed with HIP
+                  events on the step's stream, in the first (eager) group of the warm-up and in the
+                  LAST whole group of the timed region (enqueued eagerly: events cannot sit inside
+                  a replayed graph; all other groups are graph replays), against its algorithmic
+                  flops / bytes; the slowest one is reported as the dominant
+                  kernel.
   cpu_baseline -- oracle/recoder_oracle.py (the pinned CPU restatement of the
                   reference op sequence, PyTorch-CPU eager) timed on this host's
                   cores on a bounded sample of the same workload (rank 0, N=1).
@@ -91,9 +93,13 @@ def algorithmic_work(entry, B, h0, n_b, nnz, n_items, cfg_sparse=False):
     # ONE launch for every update of the step: two [n_items,h0] dense-Adam sweeps (p, m, v
     # read + written = 24 B/elem, + compact gradient rows + pos), the decoder bias table
     # (24 B/elem + pos + 8 row-tile partials per sampled item), the encoder bias, the loss
+    # (the decoder-side gradient arrives as `slabs` K slabs of the bf16-pipe dW kernel, summed here)
+    tiles = -(-int(n_b) // 64) * -(-h0 // (128 if h0 <= 128 else 256))
+    slabs = 1 if GEMM_F32 else max(1, min(256 // max(tiles, 1), 4, (-(-B // 64) * 64) // 64))
+    extra = (slabs - 1) * n_b * h0 * 4
     if cfg_sparse:
-      return "hbm", (2 * n_b * h0 * 28 + n_items * 28 + n_b * 32) / 1e9, "GB/s"
-    return "hbm", (2 * (n_items * h0 * 24 + n_b * h0 * 4 + n_items * 4)
+      return "hbm", (2 * n_b * h0 * 28 + extra + n_items * 28 + n_b * 32) / 1e9, "GB/s"
+    return "hbm", (2 * (n_items * h0 * 24 + n_b * h0 * 4 + n_items * 4) + extra
                    + n_items * 28 + n_b * 32 + h0 * 28) / 1e9, "GB/s"
   return "hbm", 0.0, "GB/s"
 
@@ -272,8 +278,11 @@ def main():
     timed = eng.timed_samples_ms()
 
     def line(entry, ms_list, where):
-      ms = float(np.median(ms_list)) - ev_over     # (median: the first bracketed call of a kernel
-                                                    # includes its one-time code-object load)
+      # median of the bracketed launches (the first bracketed call of a kernel includes its
+      # one-time code-object load).  NOT corrected by the empty-pair reading (event_pair_overhead_ms,
+      # reported for information): the raw figure is the one that agrees with the rocprofv3
+      # kernel-trace average of the same kernel (profiles/r02_*kernel_stats.md)
+      ms = float(np.median(ms_list))
       bound, work, unit = algorithmic_work(entry, B, h0, n_b, nnz, n_items, bool(cfg["sparse"]))
       peak = peak_of(entry, bound)
       ach = work / (ms * 1e-3) if ms > 0 else float("nan")

@@ -174,7 +174,18 @@ int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
                    int32_t row_off, const float *W_de, const float *b_de,
                    int32_t loss_kind, float confidence, float inv_B,
                    float *dO, int32_t ld_out, float *loss_part, float *gb_part,
-                   void *stream);
+                   const int32_t *ranges /* nullable, below */, void *stream);
+/*
+ * Operand ranges of the split-fp16 contractions (rk_decode_loss, rk_decode_bwd_dz): `ranges` is a
+ * device array of 128 int32 = fp32 bit patterns, [0..63] maxima / upper bounds of |Z|, [64..127] of
+ * |W_de| (the maximum over the slots of a half is used; an all-zero half or ranges == NULL means
+ * the documented static range |Z| < 2048, |W_de| < 512).  The kernels pick power-of-two split
+ * scales from them on the device, so no operand magnitude can overflow the fp16 pieces.
+ * rk_amax writes max |x| into slots[0] and zeroes slots[1..63] (one small launch; the trainer
+ * calls it on Z only when the activation is unbounded -- tanh / sigmoid need nothing);
+ * rk_adam_job_t.amax_out keeps the running maximum of a parameter tensor inside the Adam sweep.
+ */
+int rk_amax(const float *x, int64_t n, int32_t *slots, void *stream);
 /* MNLL second pass: row max / logsumexp over the logits in dO, loss, and
  * dO <- (softmax * sum_t - t) * inv_B  (losses.py:68-71 + autograd). */
 int rk_mnll_finish(float *dO, int32_t B, const rk_block_t *tgt, int32_t row_off,
@@ -202,7 +213,8 @@ int rk_loss_reduce(float *loss_part, int32_t n, float denom, float *loss,
 int rk_decode_bwd_dz(const float *dO, int32_t B, int32_t h,
                      const rk_block_t *tgt, const float *W_de,
                      const float *Zact /* nullable */, int32_t act,
-                     float *dZ, float *workspace, void *stream);
+                     float *dZ, float *workspace, const int32_t *ranges /* nullable */,
+                     void *stream);
 int rk_decode_bwd_dw(const float *dO, const float *Z, int32_t B, int32_t h,
                      const rk_block_t *tgt, float *G_de, float *gb_de,
                      void *stream);
@@ -382,6 +394,8 @@ typedef struct rk_adam_job {
   int32_t row0, row_step;      /* dense jobs: only rows row0, row0 + row_step, ... are updated
                                   (item-parallel ownership: item i lives on rank i % N);
                                   row_step 0 = 1 */
+  int32_t *amax_out;           /* nullable: 64 slots (fp32 bit patterns): running maximum of |p|
+                                  over everything this job writes (atomicMax, never reset) */
   const int32_t *gparts_dev;   /* nullable: the number of gradient parts is read from the device
                                   (rk_decode_bwd_dw3 publishes its slab count in counts[4]);
                                   g_parts is then the capacity */
@@ -415,6 +429,10 @@ typedef struct rk_ae_step {
    * replayed group: rng_step = cursor[0] + off + 1, Adam constants = adam_table[(cursor[0] -
    * cursor[1] + off) * RK_PAR_COUNT + par] (8 floats each, rk_adam_consts), the loss goes to
    * loss_out[cursor[0] - cursor[1] + off].  cursor == NULL: the host values above are used. */
+  int32_t *ranges;           /* nullable: 128 slots, operand ranges of the decoder contractions
+                                (rk_decode_loss): the step keeps [64..127] up to date from its Adam
+                                sweep of the decoder table and fills [0..63] with rk_amax(Z) when
+                                the activation is unbounded */
   const int64_t *cursor;
   int32_t cursor_off;
   int32_t cursor_advance;    /* with cursor_next: the last step of a replayed group publishes the

@@ -252,6 +252,13 @@ class OracleRecoder:
 
   # nn.py:228-253
   def _ae_forward(self, x, input_items, target_items, noise_keep, drop_keep):
+    z = self._ae_hidden(x, input_items, noise_keep, drop_keep)
+    P = self.params
+    de_w = P[AE_EN_W] if self.is_constrained else P[AE_DE_W]
+    return self._linear_embedding(de_w, P[AE_DE_B], target_items, z, False)
+
+  # nn.py:228-250: everything before the output embedding (what the decoder GEMM reads)
+  def _ae_hidden(self, x, input_items, noise_keep, drop_keep):
     P = self.params
     nl = len(self.hidden_layers) - 1
     z = F.normalize(x, p=2, dim=1)                             # nn.py:235
@@ -270,8 +277,7 @@ class OracleRecoder:
       else:
         w = P["decoding_layers.%d.weight" % i]
       z = _act(F.linear(z, w, P["decoding_layers.%d.bias" % i]), self.act)
-    de_w = P[AE_EN_W] if self.is_constrained else P[AE_DE_W]
-    return self._linear_embedding(de_w, P[AE_DE_B], target_items, z, False)
+    return z
 
   # nn.py:344-362
   def _mf_forward(self, input_users, target_items, drop_keep):
@@ -323,6 +329,14 @@ class OracleRecoder:
     else:
       out = self._mf_forward(in_users, t_items, dk)
     return out, t
+
+  def decoder_input(self, batch: Batch, noise_keep=None, drop_keep=None):
+    """The activations the output embedding multiplies (autoencoder; tests that size them)."""
+    in_items = None if batch.items is None else torch.from_numpy(batch.items)
+    nk = None if noise_keep is None else dense_mask_from_nnz(batch, noise_keep)
+    dk = None if drop_keep is None else torch.from_numpy(np.asarray(drop_keep, dtype=np.float32))
+    with torch.no_grad():
+      return self._ae_hidden(densify(batch), in_items, nk, dk)
 
   def compute_loss(self, batch, target=None, noise_keep=None, drop_keep=None):
     out, t = self.forward(batch, target, noise_keep, drop_keep)

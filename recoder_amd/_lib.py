@@ -67,6 +67,7 @@ class RkAeStep(Structure):
     ("time_ev0", c_void_p), ("time_ev1", c_void_p),
     ("user_norm", c_void_p), ("own_rank", c_int32), ("own_world", c_int32),
     ("zt_planes", c_void_p),
+    ("ranges", c_void_p),
     ("cursor", c_void_p), ("cursor_off", c_int32), ("cursor_advance", c_int32), ("adam_table", c_void_p),
     ("cursor_next", c_void_p),
     ("time_all", POINTER(c_void_p)),
@@ -82,7 +83,7 @@ class RkAdamJob(Structure):
     ("n_cap", c_int32), ("g_parts", c_int32), ("g_stride", c_int32),
     ("gstride_dev", c_void_p), ("g", c_void_p),
     ("row0", c_int32), ("row_step", c_int32),
-    ("gparts_dev", c_void_p),
+    ("amax_out", c_void_p), ("gparts_dev", c_void_p),
   ]
 
 
@@ -109,12 +110,13 @@ SIGNATURES = {
   "rk_loss_partials": (c_int32, [c_int32, c_int32]),
   "rk_decode_row_tile": (c_int32, []),
   "rk_decode_loss": (c_int32, [_P, c_int32, c_int32, _BLK, c_int32, _P, _P, c_int32, c_float,
-                               c_float, _P, c_int32, _P, _P, _P]),
+                               c_float, _P, c_int32, _P, _P, _P, _P]),
+  "rk_amax": (c_int32, [_P, c_int64, _P, _P]),
   "rk_mnll_finish": (c_int32, [_P, c_int32, _BLK, c_int32, c_float, _P, _P]),
   "rk_mnll_row_stats": (c_int32, [_P, c_int32, _BLK, _P, _P]),
   "rk_mnll_finish_ext": (c_int32, [_P, c_int32, _BLK, c_int32, c_float, _P, _P, _P, _P, _P]),
   "rk_loss_reduce": (c_int32, [_P, c_int32, c_float, _P, _P]),
-  "rk_decode_bwd_dz": (c_int32, [_P, c_int32, c_int32, _BLK, _P, _P, c_int32, _P, _P, _P]),
+  "rk_decode_bwd_dz": (c_int32, [_P, c_int32, c_int32, _BLK, _P, _P, c_int32, _P, _P, _P, _P]),
   "rk_decode_bwd_dw": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P]),
   "rk_decode_bwd_dw_encode_bwd": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, c_int32, _P, _P, _P, _P,
                                             _P]),

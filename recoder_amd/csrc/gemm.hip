@@ -58,9 +58,12 @@ enum { EPI_STORE = 0, EPI_LOSS_MSE = 1, EPI_SPLITK = 2, EPI_LOSS_BCE = 3 };
 //              nearest on both levels) and <= 3 . 2^-22 relative per product -- the size of the
 //              rounding an fp32 fma chain of this length accumulates itself.  The accumulator
 //              is rescaled by 1 / (s_a s_b) (exact) before the epilogue.
-//              Range: |s.x| must stay below 65504 (else inf -> NaN loss, loudly): with the
-//              scales below |W| < 512 and |Z| < 2048; dLoss/dLogits is scaled from its own
-//              maximum, so it has no such limit.
+//              Range: |s.x| must stay below 65504.  Every operand therefore gets its scale ON THE
+//              DEVICE from a published maximum / upper bound of its magnitude (a_amax / b_amax:
+//              dLoss/dLogits from the loss kernels, Z from rk_amax when the activation is
+//              unbounded, W_de from the running maximum the Adam sweep keeps) -- max . s in
+//              [2^13, 2^14); the constants below only serve callers that pass no bound (then
+//              |W| < 512, |Z| < 2048).
 enum { PREC_F32 = 0, PREC_H3 = 1 };
 // Full 22-bit precision needs |s.x| >= 2^-3 (below that the lo half goes subnormal: absolute error
 // 2^-25 / s); overflow at |s.x| >= 65504.
@@ -104,6 +107,7 @@ struct GemmP {
   int kchunk;               // K range per blockIdx.y
   float a_scale, b_scale;   // PREC_H3: powers of two applied to the operands before the fp16 split
   const uint32_t *a_amax;   // PREC_H3, nullable: 64 slots of fp32 bit patterns, max |A| (see SCALE_DO)
+  const uint32_t *b_amax;   // the same for the B operand (all slots zero: b_scale as given)
   // store epilogue
   float *C;
   int ldc;                  // <=0 : read ld from ld_dev
@@ -184,16 +188,20 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
   const int K = p.Kdev ? *p.Kdev : p.K;
   const int lda = p.lda_dev ? *p.lda_dev : p.lda;
   const int ldb = p.ldb_dev ? *p.ldb_dev : p.ldb;
-  float a_scale = p.a_scale;
-  if (H3 && p.a_amax) {      // scale of A from its published maximum: max . s in [2^13, 2^14)
-    uint32_t m = p.a_amax[threadIdx.x & 63];
+  // scale of an operand from its published maximum (64 slots of fp32 bit patterns; an upper bound
+  // is as good): max . s in [2^13, 2^14) -- nothing can overflow fp16, and every element within
+  // 2^-17 of the maximum keeps its full 22 bits
+  auto scale_from = [&](const uint32_t *slots, float dflt) -> float {
+    if (!H3 || slots == nullptr) return dflt;
+    uint32_t m = slots[threadIdx.x & 63];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
-    if (m != 0) {
-      const int e = min(max((int)(m >> 23) - 127, -100), 100);
-      a_scale = __uint_as_float((uint32_t)(13 - e + 127) << 23);
-    }
-  }
+    if (m == 0) return dflt;
+    const int e = min(max((int)(m >> 23) - 127, -100), 100);
+    return __uint_as_float((uint32_t)(13 - e + 127) << 23);
+  };
+  const float a_scale = scale_from(p.a_amax, p.a_scale);
+  const float b_scale = scale_from(p.b_amax, p.b_scale);
   // XCD-aware tile mapping.  Workgroup L runs on XCD L % 8 (each XCD has its own
   // L2), so XCD x gets the contiguous chunk [x*chunk, (x+1)*chunk) of the LIVE
   // tile list -- tiles that share an operand panel (same nt for gathered W rows,
@@ -384,7 +392,7 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
       };
       stage(As, a_scale, ra, a_k, std::integral_constant<int, AMODE>{}, std::integral_constant<int, A_PT>{},
             std::integral_constant<int, A_F4>{}, std::integral_constant<int, A_UN>{}, std::true_type{});
-      stage(Bs, p.b_scale, rb, b_k, std::integral_constant<int, BMODE>{}, std::integral_constant<int, B_PT>{},
+      stage(Bs, b_scale, rb, b_k, std::integral_constant<int, BMODE>{}, std::integral_constant<int, B_PT>{},
             std::integral_constant<int, B_F4>{}, std::integral_constant<int, B_UN>{}, std::false_type{});
       return;
     }
@@ -552,7 +560,7 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
   // read back row-major a lane owns 4 x (one row, 4 consecutive columns), so the
   // epilogue issues 4x fewer, 16-byte-wide global stores / loads per tile.
   if (H3) {
-    const float inv = 1.0f / (a_scale * p.b_scale);       // exact: powers of two
+    const float inv = 1.0f / (a_scale * b_scale);         // exact: powers of two
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -968,14 +976,10 @@ constexpr int DZ_SPLITS = 64;        // at most; see dz_splits
 // split-K factor of the dW GEMM (K = B): its output has only n_b/32 x h/128 tiles, too few to
 // fill the chip once the batch is large and the item shard small (item-parallel ranks)
 inline int dw_splits(int B) {
-  static const int force = getenv("RK_DW_SPLITS") ? atoi(getenv("RK_DW_SPLITS")) : 0;   // tuning probe
-  if (force > 0) return force;
   return B >= 3000 ? 4 : (B >= 1500 ? 2 : 1);
 }
 
 inline int dz_splits(int B) {
-  static const int force = getenv("RK_DZ_SPLITS") ? atoi(getenv("RK_DZ_SPLITS")) : 0;   // tuning probe
-  if (force > 0) return force;
   const int tiles_m = rk_cdiv(B, 128);
   int s = (512 / tiles_m) & ~7;
   return s < 8 ? 8 : (s > DZ_SPLITS ? DZ_SPLITS : s);
@@ -991,12 +995,40 @@ inline bool use_h3() {
   }();
   return v != 0;
 }
-inline int tune(const char *name, int dflt) {
-  const char *e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
 
 }  // namespace
+
+namespace {
+// slots[0] <- max |x| as an fp32 bit pattern, slots[1..63] <- 0 (one workgroup; x is [B, h]-sized)
+__global__ __launch_bounds__(1024) void amax_kernel(const float *__restrict__ x, int64_t n,
+                                                    uint32_t *__restrict__ slots) {
+  __shared__ float red[16];
+  float m = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = threadIdx.x; i < n4; i += 1024) {
+    const float4 v = reinterpret_cast<const float4 *>(x)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(x[i]));
+  m = rk_wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float t = 0.f;
+    if (threadIdx.x == 0)
+      for (int k = 0; k < 16; ++k) t = fmaxf(t, red[k]);
+    slots[threadIdx.x] = threadIdx.x == 0 ? __float_as_uint(t) : 0u;
+  }
+}
+}  // namespace
+
+extern "C" int rk_amax(const float *x, int64_t n, int32_t *slots, void *stream_) {
+  RK_REQUIRE(x != nullptr && slots != nullptr && (((uintptr_t)x) & 15) == 0, "x (16-byte aligned), slots");
+  RK_LAUNCH(amax_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream_, x, n,
+            reinterpret_cast<uint32_t *>(slots));
+  RK_CHECK_LAUNCH("amax");
+  return 0;
+}
 
 extern "C" void rk_gemm_probe(unsigned long long *buffer) { g_gemm_probe = buffer; }
 
@@ -1008,8 +1040,6 @@ extern "C" int64_t rk_dz_workspace_bytes(int32_t B, int32_t h) {
 
 // row segments of the encoder backward inside rk_decode_bwd_dw_encode_bwd (see encoder_bwd.h)
 extern "C" int32_t rk_encode_bwd_segments(int32_t B) {
-  static const int force = getenv("RK_ENC_SEGS") ? atoi(getenv("RK_ENC_SEGS")) : 0;   // tuning probe
-  if (force > 0) return force;
   const int s = rk_cdiv(B, 512);
   return s < 1 ? 1 : (s > 8 ? 8 : s);
 }
@@ -1033,7 +1063,8 @@ extern "C" int32_t rk_loss_partials(int32_t B, int32_t n_cap) {
 extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
                               int32_t row_off, const float *W_de, const float *b_de,
                               int32_t loss_kind, float confidence, float inv_B, float *dO,
-                              int32_t ld_out, float *loss_part, float *gb_part, void *stream_) {
+                              int32_t ld_out, float *loss_part, float *gb_part,
+                              const int32_t *ranges, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(h % 4 == 0, "h must be a multiple of 4");
   RK_REQUIRE(aligned16(Z) && aligned16(W_de), "Z and W_de must be 16-byte aligned");
@@ -1044,6 +1075,10 @@ extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_blo
   p.A = Z; p.lda = h;
   p.Bm = W_de; p.ldb = h; p.bidx = tgt->items;
   p.a_scale = SCALE_Z; p.b_scale = SCALE_W;
+  if (ranges) {      // published bounds of |Z| / |W_de| (rk_amax, rk_adam_job_t.amax_out)
+    p.a_amax = reinterpret_cast<const uint32_t *>(ranges);
+    p.b_amax = reinterpret_cast<const uint32_t *>(ranges) + 64;
+  }
   p.M = B; p.N = tgt->n_cap; p.K = h;
   p.Ndev = tgt->counts;          // n_t
   p.tiles_m = rk_cdiv(B, DEC_BM);
@@ -1063,14 +1098,11 @@ extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_blo
     RK_REQUIRE(tgt->implicit || tgt->pref_rc != nullptr, "explicit values need pref_rc");
     p.ld_dev = tgt->counts + 2;
     if (use_h3()) {
-      // 64 x 128 tiles; RK_DEC_CFG = 2 / 4 are the 64 x 64 / 128 x 128 tuning probes (C2: 0.146 /
-      // 0.160 / 0.153 ms per step, 8-way item shard 0.223 / 0.249 / 0.238)
-      static const int cfg = tune("RK_DEC_CFG", 0);
+      // 64 x 128 tiles (measured against 64 x 64 / 128 x 128 at C2: 0.146 / 0.160 / 0.153 ms per
+      // step, on an 8-way item shard 0.223 / 0.249 / 0.238)
       const bool mse = (loss_kind == RK_LOSS_MSE);
-      const int bm = cfg == 4 ? 128 : 64;
-      const int bn = cfg == 2 ? 64 : 128;
-      p.tiles_m = rk_cdiv(B, bm);
-      const int g = rk_cdiv(p.tiles_m * rk_cdiv(tgt->n_cap, bn), 8) * 8;
+      p.tiles_m = rk_cdiv(B, DEC_BM);
+      const int g = rk_cdiv(p.tiles_m * rk_cdiv(tgt->n_cap, 128), 8) * 8;
 #define LAUNCH(TM, TN, BKK)                                                                      \
   do {                                                                                           \
     if (mse)                                                                                     \
@@ -1080,7 +1112,7 @@ extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_blo
       RK_LAUNCH((gemm_kernel<2, 2, TM, TN, 0, 0, EPI_LOSS_BCE, true, BKK, PREC_H3>), dim3(g, 1), \
                 dim3(256), 0, stream, p);                                                        \
   } while (0)
-      if (cfg == 2) LAUNCH(1, 1, 32); else if (cfg == 4) LAUNCH(2, 2, 32); else LAUNCH(1, 2, 32);
+      LAUNCH(1, 2, 32);
 #undef LAUNCH
       RK_CHECK_LAUNCH("decode_loss");
       return 0;
@@ -1169,7 +1201,7 @@ extern "C" int rk_loss_reduce(float *loss_part, int32_t n, float denom, float *l
 // dZ = dO . W_de[T]   (M = B, N = h, K = n_t) split-K, then reduce (* act')
 extern "C" int rk_decode_bwd_dz(const float *dO, int32_t B, int32_t h, const rk_block_t *tgt,
                                 const float *W_de, const float *Zact, int32_t act, float *dZ,
-                                float *workspace, void *stream_) {
+                                float *workspace, const int32_t *ranges, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(h % 4 == 0, "h must be a multiple of 4");
   RK_REQUIRE(aligned16(dO) && aligned16(W_de) && aligned16(workspace) && aligned16(dZ),
@@ -1181,19 +1213,18 @@ extern "C" int rk_decode_bwd_dz(const float *dO, int32_t B, int32_t h, const rk_
   p.Bm = W_de; p.ldb = h; p.bidx = tgt->items;
   p.a_scale = SCALE_DO; p.b_scale = SCALE_W;
   p.a_amax = reinterpret_cast<const uint32_t *>(tgt->counts) + 8;
+  if (ranges) p.b_amax = reinterpret_cast<const uint32_t *>(ranges) + 64;
   p.M = B; p.N = h; p.K = tgt->n_cap; p.Kdev = tgt->counts;
   p.C = workspace;
   p.kchunk = 0;                       // derived in-kernel from the device-resident n_t
   const int splits = dz_splits(B);
   const int kchunk = 0;
   // wave tile 32 x (32*TN): pick TN by h
-  static const int tn_force = tune("RK_DZ_TN", 0);     // tuning probe
   // split-fp16: 128-column tiles up to h = 256 (two resident workgroups per CU at 74 KB of LDS;
   // the 224-wide tile of the fp32 path needs 101 KB here: 29 vs 31 us at C2, 52 vs 57 us on an
   // 8-way item shard, although dO is then split once per column tile)
-  const int tn = tn_force ? tn_force
-                          : use_h3() ? (h <= 64 ? 2 : (h <= 256 ? 4 : 8))
-                                     : (h <= 64 ? 2 : (h <= 128 ? 4 : (h <= 224 ? 7 : 8)));
+  const int tn = use_h3() ? (h <= 64 ? 2 : (h <= 256 ? 4 : 8))
+                          : (h <= 64 ? 2 : (h <= 128 ? 4 : (h <= 224 ? 7 : 8)));
   p.tiles_m = rk_cdiv(B, 128);
   const int tiles = p.tiles_m * rk_cdiv(h, 32 * tn);   // x 64 splits: a multiple of 8
 #define LAUNCH(TN)                                                                              \

@@ -199,6 +199,7 @@ struct UJob {
   int n_rows, h, g_parts, g_stride, sparse, blk0, nblk;
   int row0, row_step;          // the job covers rows row0, row0 + row_step, ... (owned rows)
   int tab_slot;                // >= 0: the constants come from the device table (UArgs.ctab)
+  uint32_t *amax_out;          // nullable: 64 slots, running max |p| after the update (bit patterns)
   AdamC c;
 };
 
@@ -248,9 +249,28 @@ template <> struct VecOps<float> {
                                                const AdamC &c) { sadam1(p, m, v, g, c); }
 };
 
+template <typename T> __device__ __forceinline__ float absmax_of(const T &v);
+template <> __device__ __forceinline__ float absmax_of<float4>(const float4 &v) {
+  return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+}
+template <> __device__ __forceinline__ float absmax_of<float>(const float &v) { return fabsf(v); }
+
+// running maximum of |p| over everything this job has ever written: the decoder GEMMs take the
+// fp16 split scale of their weight operand from it (gemm.hip b_amax); one atomic per workgroup
+__device__ __forceinline__ void publish_pmax(uint32_t *slots, float m) {
+  __shared__ float wmax[4];
+  m = rk_wave_max(m);
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax(slots + (blockIdx.x & 63),
+              __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+}
+
 template <typename T>
 __device__ __forceinline__ void update_job(const UJob &J, int lb, const AdamC &C) {
   using V = VecOps<T>;
+  float pmax = 0.f;
   const int hq = J.h / V::W;
   const int64_t stride = J.gstride_dev ? (int64_t)*J.gstride_dev : (int64_t)J.g_stride;
   const int g_parts = J.gparts_dev ? min(*J.gparts_dev, J.g_parts) : J.g_parts;
@@ -268,7 +288,9 @@ __device__ __forceinline__ void update_job(const UJob &J, int lb, const AdamC &C
       T p1 = P[o], m1 = M[o], v1 = Vv[o];
       V::sadam(p1, m1, v1, g, C);
       P[o] = p1; M[o] = m1; Vv[o] = v1;
+      pmax = fmaxf(pmax, absmax_of<T>(p1));
     }
+    if (J.amax_out) publish_pmax(J.amax_out, pmax);
     return;
   }
   const int rows_live = J.row0 < J.n_rows ? (J.n_rows - J.row0 + J.row_step - 1) / J.row_step : 0;
@@ -305,7 +327,9 @@ __device__ __forceinline__ void update_job(const UJob &J, int lb, const AdamC &C
     T p1 = P[e], m1 = M[e], v1 = Vv[e];
     V::adam(p1, m1, v1, g, C);
     P[e] = p1; M[e] = m1; Vv[e] = v1;
+    pmax = fmaxf(pmax, absmax_of<T>(p1));
   }
+  if (J.amax_out) publish_pmax(J.amax_out, pmax);
 }
 
 __device__ __forceinline__ void run_job(const UJob &J, int b, const UArgs &a) {
@@ -473,6 +497,7 @@ int rk_adam_multi_at(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part
     d.sparse = s.par.sparse ? 1 : 0;
     d.row0 = s.row0; d.row_step = row_step;
     d.tab_slot = (table && tab_slots) ? tab_slots[j] : -1;
+    d.amax_out = reinterpret_cast<uint32_t *>(s.amax_out);
     d.c = make_consts(s.par.lr, s.par.beta1, s.par.beta2, s.par.eps,
                       s.par.sparse ? 0.0 : s.par.weight_decay, s.par.step);
     d.blk0 = blocks;

@@ -115,6 +115,9 @@ struct Timer {
   }
 };
 
+// |act(x)| <= 1: the static split scale of Z is always in range
+inline bool act_bounded(int act) { return act == RK_ACT_TANH || act == RK_ACT_SIGMOID; }
+
 // one rk_adam_multi job for a [n_rows, h] table (dense Adam through pos, or SparseAdam
 // on the block's item rows) or a flat tensor (pos == items == null)
 rk_adam_job_t table_job(const rk_adam_param_t &par, const rk_block_t *blk, int n_rows, int h,
@@ -181,15 +184,16 @@ static int step_item_parallel(const rk_ae_step_t *a, int phase) {
     RK_TRY(rk_bias_act(a->Z0, a->par[RK_PAR_B_EN].p, B, h, a->act, sm));
     {
       Timer t(a, RK_ENTRY_DECODE_LOSS, sm);
+      if (a->ranges && !act_bounded(a->act)) RK_TRY(rk_amax(a->Z0, (int64_t)B * h, a->ranges, sm));
       RK_TRY(rk_decode_loss(a->Z0, B, h, blk, a->row_off, W_de, a->par[RK_PAR_B_DE].p, a->loss_kind,
-                            a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, sm));
+                            a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, a->ranges, sm));
       if (mnll) RK_TRY(rk_mnll_finish(a->dO, B, blk, a->row_off, a->inv_B, a->loss_part, sm));
     }
     // act'(Z0) is applied to this rank's PARTIAL dZ0 here, inside the split-K reduce: Z0 is the
     // same on every rank, so sum_ranks(dZ0_r) * act'(Z0) = sum_ranks(dZ0_r * act'(Z0)) and the
     // element-wise launch after the all-reduce disappears
     Timer t(a, RK_ENTRY_DECODE_BWD_DZ, sm);
-    RK_TRY(rk_decode_bwd_dz(a->dO, B, h, blk, W_de, a->Z0, a->act, a->dZ0, a->ws, sm));
+    RK_TRY(rk_decode_bwd_dz(a->dO, B, h, blk, W_de, a->Z0, a->act, a->dZ0, a->ws, a->ranges, sm));
   }
   const int dw_slabs = (a->tied || mnll || a->ws == nullptr) ? 1 : rk_dw_splits(B);
   if (phase & RK_STEP_IP_TAIL) {
@@ -206,8 +210,10 @@ static int step_item_parallel(const rk_ae_step_t *a, int phase) {
     rk_adam_job_t jobs[4];
     int n = 0;
     jobs[n++] = table_job(a->par[RK_PAR_W_EN], blk, n_items, h, G_en, true);
+    if (a->tied && a->ranges) jobs[0].amax_out = a->ranges + 64;     // the decoder reads this table
     if (!a->tied) {
       jobs[n] = table_job(a->par[RK_PAR_W_DE], blk, n_items, h, a->G_de, true);
+      if (a->ranges) jobs[n].amax_out = a->ranges + 64;
       if (dw_slabs > 1) { jobs[n].g = a->ws; jobs[n].g_parts = dw_slabs; jobs[n].g_stride = blk->n_cap * h; }
       ++n;
     }
@@ -278,8 +284,9 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     }
     {
       Timer t(a, RK_ENTRY_DECODE_LOSS, sm);
+      if (a->ranges && !act_bounded(a->act)) RK_TRY(rk_amax(a->Z0, (int64_t)B * h, a->ranges, sm));
       RK_TRY(rk_decode_loss(a->Z0, B, h, blk, a->row_off, W_de, a->par[RK_PAR_B_DE].p, a->loss_kind,
-                            a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, sm));
+                            a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, a->ranges, sm));
       if (mnll) RK_TRY(rk_mnll_finish(a->dO, B, blk, a->row_off, a->inv_B, a->loss_part, sm));
     }
     // dW: on its own (tied weights: the encoder backward accumulates onto its rows;
@@ -298,7 +305,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   if (phase & RK_STEP_DZ_ENC) {
     {
       Timer t(a, RK_ENTRY_DECODE_BWD_DZ, sm);
-      RK_TRY(rk_decode_bwd_dz(a->dO, B, h, blk, W_de, a->Z0, a->act, a->dZ0, a->ws, sm));
+      RK_TRY(rk_decode_bwd_dz(a->dO, B, h, blk, W_de, a->Z0, a->act, a->dZ0, a->ws, a->ranges, sm));
     }
     if (a->tied || mnll || !whole) {
       Timer t(a, RK_ENTRY_ENCODE_BWD, sm);
@@ -327,8 +334,10 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     if (whole && !(a->tied || mnll) && !dw3) {   // the fused launch wrote G_en in row segments
       jobs[0].g_parts = rk_encode_bwd_segments(B); jobs[0].g_stride = blk->n_cap * h;
     }
+    if (a->tied && a->ranges) jobs[0].amax_out = a->ranges + 64;     // the decoder reads this table
     if (!a->tied) {
       jobs[n] = table_job(a->par[RK_PAR_W_DE], blk, n_items, h, a->G_de, true);
+      if (a->ranges) jobs[n].amax_out = a->ranges + 64;
       if (dw3) {
         jobs[n].g = rk_dw3_slabs(a->ws, B, h); jobs[n].g_parts = rk_dw3_max_splits();
         jobs[n].g_stride = blk->n_cap * h; jobs[n].gparts_dev = blk->counts + 4;

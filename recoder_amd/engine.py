@@ -110,6 +110,13 @@ class FusedEngine:
     self.item_parallel = None              # parallel.ItemParallel when the items are sharded
     self._cstep = None
     self._c_calls = 0
+    # operand ranges of the split-fp16 decoder contractions (include/recoder_hip.h rk_amax):
+    # [0..63] max |Z| (filled per call when the activation is unbounded), [64..127] an upper bound
+    # of |decoder table| (its maximum now; the Adam sweep keeps it running from there)
+    self.ranges = torch.zeros(128, dtype=torch.int32, device=self.device)
+    self.act_bounded = model.activation_type in ("tanh", "sigmoid")
+    self._w_range_stale = True
+    self._w_range_key = None
     if kind == "ae":
       self.h = list(model.hidden_layers)
       self.nl = len(self.h) - 1
@@ -185,6 +192,7 @@ class FusedEngine:
     """Create / adopt the Adam moment tensors inside the torch.optim state
     (so ``optimizer.state_dict()`` has the reference layout, model.py:210)."""
     self.states = {}
+    self._w_range_stale = True
     names = {id(p): n for n, p in self.model.named_parameters()}
     for opt, is_sparse in ((optimizer, False), (sparse_optimizer, True)):
       if opt is None:
@@ -229,6 +237,8 @@ class FusedEngine:
     a.step, a.sparse = s.step, 1 if rows is not None else 0
     j.n_rows, j.h, j.g, j.g_parts = n_rows, h, ptr(g), 1
     j.pos, j.rows, j.n_dev, j.n_cap = ptr(pos), ptr(rows), ptr(n_dev), n_cap
+    if s.p is self._decoder_params()[0]:       # the table the decoder GEMMs read: keep its bound
+      j.amax_out = self.ranges.data_ptr() + 64 * 4
     self._jobs.append(j)
 
   def _flush_jobs(self, stream):
@@ -317,6 +327,31 @@ class FusedEngine:
       return m.de_embedding_layer.weight, m.de_bias
     return m.item_embedding_layer.weight, m.bias
 
+  def refresh_weight_range(self):
+    """(Re)compute the bound of |decoder table| from the table itself: after the parameters were
+    set from outside (construction, load_state_dict); training keeps it current on the device."""
+    W, _ = self._decoder_params()
+    m = torch.linalg.vector_norm(W.detach(), float("inf")).reshape(1).to(torch.float32)
+    self.ranges[64:].zero_()
+    self.ranges[64:65].copy_(m.view(torch.int32))
+    self._w_range_stale = False
+    self._w_range_key = (W.data_ptr(), W._version)
+
+  def _check_weight_range(self):
+    if not self._w_range_stale:
+      W, _ = self._decoder_params()
+      if (W.data_ptr(), W._version) == self._w_range_key:   # in-place writes from torch bump it
+        return
+    self.refresh_weight_range()
+
+  def _ranges(self, z, n, stream):
+    """Device pointer of the operand ranges for a decode of `z` (n elements)."""
+    self._check_weight_range()
+    if self.act_bounded:
+      return ptr(self.ranges)         # |Z| <= 1 (tanh / sigmoid): the static scale of Z is exact
+    check(self.lib.rk_amax(ptr(z), n, ptr(self.ranges), stream), "rk_amax")
+    return ptr(self.ranges)
+
   def _loss(self, z, B, tgt, row_off, denom_rows, stream, out=None, ip=None):
     """decode + loss; leaves dLoss/dLogits in self.dO. Returns device scalar.  ip: the
     block holds an item shard (parallel.ItemParallel) -- only the multinomial loss needs to
@@ -327,7 +362,8 @@ class FusedEngine:
     out = self.loss_out if out is None else out
     check(lib.rk_decode_loss(ptr(z), B, self.h[0], tgt.ref, row_off, ptr(W), ptr(b), self.loss_id,
                              self.confidence, inv_B, ptr(self.dO), 0, ptr(self.loss_part),
-                             ptr(self.gb_part), stream), "rk_decode_loss")
+                             ptr(self.gb_part), self._ranges(z, B * self.h[0], stream), stream),
+          "rk_decode_loss")
     if self.loss_id == LOSS_MNLL and ip is not None:
       # per-row {max, sum exp} of the local logits -> all ranks' pairs -> global log-sum-exp
       stats = torch.empty(B, 2, dtype=torch.float32, device=self.device)
@@ -420,7 +456,7 @@ class FusedEngine:
     fuse_act = simple and ip is None        # act' folded into the split-K reduce
     check(lib.rk_decode_bwd_dz(ptr(self.dO), B, h0, tb.ref, ptr(W_de),
                                ptr(self.enc[0]) if fuse_act else None, self.act, ptr(dz),
-                               ptr(self.ws), stream), "rk_decode_bwd_dz")
+                               ptr(self.ws), ptr(self.ranges), stream), "rk_decode_bwd_dz")
     if ip is not None:
       # item parallel: dLoss/d(decoder input) summed over the ranks' item shards; everything
       # upstream (hidden stacks, user rows) is replicated and sees identical inputs
@@ -547,6 +583,8 @@ class FusedEngine:
     st.G_de, st.G_en, st.gb_de = ptr(self.G_de), ptr(self.G_en), ptr(self.gb_de)
     st.gb_part, st.ws = ptr(self.gb_part), ptr(self.ws)
     st.zt_planes = ptr(self.zt_planes)
+    self._check_weight_range()
+    st.ranges = ptr(self.ranges)
     plain = dp is None and not m.is_constrained and self.loss_id != LOSS_MNLL
     # the fused fp32 dW || encoder-backward launch writes row-segment partials; the bf16-pipe dW
     # (whole single-GPU steps) leaves its K slabs in the workspace and runs the plain encoder backward
@@ -795,9 +833,10 @@ class FusedEngine:
     """Logits of `z` against the item set of `items_blk` (any subset / strip of the catalogue)."""
     self.ensure_capacity(B, items_blk.n_cap)
     W, b = self._decoder_params()
+    stream = current_stream()
     check(self.lib.rk_decode_loss(ptr(z), B, self.h[0], items_blk.ref, 0, ptr(W), ptr(b), LOSS_NONE,
-                                  0.0, 1.0, ptr(out), ld_out, None, None, current_stream()),
-          "rk_decode_loss")
+                                  0.0, 1.0, ptr(out), ld_out, None, None,
+                                  self._ranges(z, B * self.h[0], stream), stream), "rk_decode_loss")
     return out
 
   def predict_scores(self, blk, row_off, B, out, ld_out, tgt_items_blk):
@@ -811,8 +850,8 @@ class FusedEngine:
       z = self._mf_forward(blk.users[row_off:row_off + B], B, None, False, stream)
     W, b = self._decoder_params()
     check(self.lib.rk_decode_loss(ptr(z), B, self.h[0], tgt_items_blk.ref, 0, ptr(W), ptr(b),
-                                  LOSS_NONE, 0.0, 1.0, ptr(out), ld_out, None, None, stream),
-          "rk_decode_loss")
+                                  LOSS_NONE, 0.0, 1.0, ptr(out), ld_out, None, None,
+                                  self._ranges(z, B * self.h[0], stream), stream), "rk_decode_loss")
     return out
 
 
@@ -886,8 +925,10 @@ def ae_dense_forward(model, x, input_items=None, target_items=None):
   z = eng._ae_forward(blk, 0, B, None, None, train, stream)
   W, b = eng._decoder_params()
   out = torch.empty(B, n_t, dtype=torch.float32, device=dev)
+  eng._w_range_stale = True          # (a bare module: its weights may have been set from anywhere)
   check(eng.lib.rk_decode_loss(ptr(z), B, eng.h[0], tblk.ref, 0, ptr(W), ptr(b), LOSS_NONE, 0.0, 1.0,
-                               ptr(out), n_t, None, None, stream), "rk_decode_loss")
+                               ptr(out), n_t, None, None, eng._ranges(z, B * eng.h[0], stream), stream),
+        "rk_decode_loss")
   return out
 
 
@@ -911,6 +952,8 @@ def mf_dense_forward(model, input_users, target_items=None):
   z = eng._mf_forward(users, B, None, model.training, stream)
   W, b = eng._decoder_params()
   out = torch.empty(B, n_t, dtype=torch.float32, device=dev)
+  eng._w_range_stale = True          # (a bare module: its weights may have been set from anywhere)
   check(eng.lib.rk_decode_loss(ptr(z), B, eng.h[0], tblk.ref, 0, ptr(W), ptr(b), LOSS_NONE, 0.0, 1.0,
-                               ptr(out), n_t, None, None, stream), "rk_decode_loss")
+                               ptr(out), n_t, None, None, eng._ranges(z, B * eng.h[0], stream), stream),
+        "rk_decode_loss")
   return out

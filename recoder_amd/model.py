@@ -201,6 +201,13 @@ class Recoder(object):
       self.__sparse_optimizer_state_dict = None
     self._engine().bind_optimizers(self.optimizer, self.sparse_optimizer)
 
+  def _sync_ranges(self):
+    """Decoder-weight bound of the split-fp16 GEMMs from the table itself (engine.ranges): at every
+    public entry, because parameters may have been written from outside since the last call."""
+    eng = self._engine()
+    if hasattr(eng, "refresh_weight_range"):
+      eng.refresh_weight_range()
+
   def _engine(self):
     if self.__engine is None:
       self.__init_loss_module()
@@ -233,6 +240,8 @@ class Recoder(object):
     self.model.load_model_params(model_params)
     self.__init_model()
     self.model.load_state_dict(st["model"])
+    if self.__engine is not None and hasattr(self.__engine, "_w_range_stale"):
+      self.__engine._w_range_stale = True
 
   def save_state(self, model_checkpoint_prefix):
     """model.py:193-224 (same dict; like the reference the sparse optimizer's
@@ -580,6 +589,7 @@ class Recoder(object):
         break
       self.current_epoch = epoch
       self.model.train()
+      self._sync_ranges()
       if lr_scheduler is not None:
         lr_scheduler.step()     # at epoch start, as model.py:364-366
       if iters_processed == 0 or iters_processed == num_batches:
@@ -621,12 +631,10 @@ class Recoder(object):
     """model.py:406-437: the epoch's log line, validation / evaluation, checkpoint."""
     self.loss_history.append(self.last_epoch_losses)
     if n_done and not np.all(np.isfinite(self.last_epoch_losses)):
-      # the reference keeps training on a NaN loss too; here there is one extra way to get one:
-      # the decode / dZ GEMMs split their operands into fp16 pairs (range |W| < 512, |Z| < 2048,
-      # recoder_amd/csrc/gemm.hip) -- RK_GEMM_PREC=f32 runs them on the fp32 MFMA
-      log.warning(
-        "non-finite training loss in epoch %d; if activations / weights exceed the split-fp16 range "
-        "of the decoder GEMMs, rerun with RK_GEMM_PREC=f32", epoch)
+      # the reference keeps training on a NaN loss too (the split-fp16 decoder GEMMs take their
+      # operand scales from device-side maxima, recoder_amd/csrc/gemm.hip, so they add no way to
+      # get one that fp32 does not have)
+      log.warning("non-finite training loss in epoch %d", epoch)
     postfix = {"loss": float(self.last_epoch_losses[-1]) if n_done else float("nan")}
     if eval_freq > 0 and epoch % eval_freq == 0 and val_dataloader is not None:
       self._sync_user_rows()
@@ -765,6 +773,7 @@ class Recoder(object):
     if self.model is None:
       raise Exception("Model not initialized.")
     self.model.eval()
+    self._sync_ranges()
     out, blk, B = self._predict_scores(users_interactions)
     if return_input:
       m = users_interactions.interactions_matrix
@@ -826,6 +835,7 @@ class Recoder(object):
     (``rk_topk_masked_strip``) and the per-strip winners are merged with one more top-k pass --
     ties resolve to the lower item id at both levels, as torch.topk on the full row would."""
     self.model.eval()
+    self._sync_ranges()
     k = int(num_recommendations)
     from . import _lib
     from .device import current_stream

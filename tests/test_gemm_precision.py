@@ -68,7 +68,7 @@ def test_decode_logits_match_float64(zmag, wmag, tol, B, h, n_t):
   out = torch.zeros(B * ld, device=dev)
   Zd, Wd, bd = Z.to(dev), W.to(dev), b.to(dev)
   check(lib.rk_decode_loss(ptr(Zd), B, h, blk.ref, 0, ptr(Wd), ptr(bd), LOSS_NONE, 0.0, 1.0, ptr(out),
-                           ld, None, None, current_stream()), "rk_decode_loss")
+                           ld, None, None, None, current_stream()), "rk_decode_loss")
   got = out.view(B, ld)[:, :n_t].cpu().double()
   Wt = W[torch.from_numpy(items)].double()
   exact = Z.double() @ Wt.t()
@@ -108,7 +108,7 @@ def test_dz_matches_float64(gtop):
   Wd = W.to(dev)
   dZ = torch.zeros(B * h, device=dev)
   ws = torch.zeros(lib.rk_dz_workspace_bytes(B, h) // 4, device=dev)
-  check(lib.rk_decode_bwd_dz(ptr(dO_dev), B, h, blk.ref, ptr(Wd), None, 0, ptr(dZ), ptr(ws),
+  check(lib.rk_decode_bwd_dz(ptr(dO_dev), B, h, blk.ref, ptr(Wd), None, 0, ptr(dZ), ptr(ws), None,
                              current_stream()), "rk_decode_bwd_dz")
   Wt = W[torch.from_numpy(items)].double()
   exact = dO[:, :n_t].double() @ Wt
@@ -153,7 +153,7 @@ def test_loss_kernels_publish_max_gradient(loss_name):
   kind = {"mse": LOSS_MSE, "bce": LOSS_BCE, "mnll": LOSS_MNLL}[loss_name]
   st = current_stream()
   check(lib.rk_decode_loss(ptr(Z), B, h, blk.ref, 0, ptr(W), ptr(b), kind, 0.5, 1.0 / B, ptr(dO), 0,
-                           ptr(part), None, st), "rk_decode_loss")
+                           ptr(part), None, None, st), "rk_decode_loss")
   if loss_name == "mnll":
     check(lib.rk_mnll_finish(ptr(dO), B, blk.ref, 0, 1.0 / B, ptr(part), st), "rk_mnll_finish")
   torch.cuda.synchronize()

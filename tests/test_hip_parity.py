@@ -289,6 +289,17 @@ STEP_CASES = [
                                sparse=False, loss="logistic", loss_params=None, lr=1e-3,
                                weight_decay=2e-5),
    (800, 1500, 25), 256, 256),
+  # operand ranges of the split-fp16 decoder GEMMs follow the data (include/recoder_hip.h rk_amax):
+  # unbounded activation with |Z| ~ 1e4 and |W_de| ~ 1e3 -- far outside the static range
+  # (|Z| < 2048, |W| < 512), no environment variable involved
+  ("range_relu_big", dict(kind="ae", hidden_layers=[200], activation_type="relu", noise_prob=0.0,
+                          sparse=False, loss="mse", loss_params=None, lr=1e-3, weight_decay=2e-5,
+                          prescale=dict(z_max=1.0e4, w_max=1.0e3)),
+   (900, 2500, 25), 300, 300),
+  ("range_relu_big_sparse_2l", dict(kind="ae", hidden_layers=[64, 40], activation_type="relu",
+                                    noise_prob=0.0, sparse=True, loss="mse", loss_params=None, lr=1e-3,
+                                    weight_decay=0.0, prescale=dict(z_max=3.0e4, w_max=2.0e3)),
+   (500, 1200, 20), 128, 256),
   # edge shapes (names starting with "edge": every 5th user has NO interactions): fewer than 32
   # sampled items, a ragged last batch (37 users in batches of 16), one-row batches
   ("edge_tiny_ae8", dict(kind="ae", hidden_layers=[8], activation_type="tanh", noise_prob=0.0,
@@ -376,11 +387,30 @@ def test_steps_match_oracle(name, c, shape, B, S):
   # capture the initial state right after init: train with 0 iterations is not
   # possible, so initialise explicitly
   rec._Recoder__init_training(ds, c["lr"], c["weight_decay"])
+  if c.get("prescale"):
+    # blow the operands of the decoder GEMMs up: scale the encoder table until the bottleneck
+    # reaches z_max on the first batch, the decoder table until its largest entry is w_max
+    ps = c["prescale"]
+    with torch.no_grad():
+      pr = dict(model.named_parameters())
+      pr[orc.AE_DE_W].mul_(ps["w_max"] / pr[orc.AE_DE_W].abs().max().item())
+      o0 = make_oracle(c, {k: v.detach().cpu().clone() for k, v in pr.items()})
+      b0 = orc.collate(orc.extract_rows(csr, order[:S]), order[:S], B, ns)[0]
+      z0 = o0.decoder_input(b0).abs().max().item()
+      pr[orc.AE_EN_W].mul_(ps["z_max"] / z0)
+      for k, v in pr.items():
+        if k.endswith("bias"):
+          v.mul_(ps["z_max"] / z0)
   init = {k: v.detach().cpu().clone() for k, v in model.named_parameters()}
   rec.train(ds, batch_size=B, lr=c["lr"], weight_decay=c["weight_decay"], num_epochs=1,
             negative_sampling=ns, num_sampling_users=S)
   losses = rec.last_epoch_losses
   assert len(losses) == n_steps
+  if c.get("prescale"):
+    rg = rec._engine().ranges.view(torch.float32).cpu().numpy()
+    print("   ranges: |Z| <= %.4g, |W_de| <= %.4g" % (rg[:64].max(), rg[64:].max()))
+    assert rg[:64].max() > 2048 and rg[64:].max() > 512     # really outside the static range
+    assert np.all(np.isfinite(losses))
 
   o = make_oracle(c, init)
   ref_losses = []

@@ -51,9 +51,9 @@ def main():
   probe = torch.zeros(8 * 200000, dtype=torch.int64, device=dev)
   calls = {
     "decode+loss": lambda: lib.rk_decode_loss(ptr(Z), B, h, blk.ref, 0, ptr(W), ptr(bias), LOSS_MSE, 0.0,
-                                              1.0 / B, ptr(dO), 0, ptr(part), ptr(gbp), st),
+                                              1.0 / B, ptr(dO), 0, ptr(part), ptr(gbp), None, st),
     "dz (split-K GEMM only)": lambda: lib.rk_decode_bwd_dz(ptr(dO), B, h, blk.ref, ptr(W), None, 0,
-                                                           ptr(dZ), ptr(ws), st),
+                                                           ptr(dZ), ptr(ws), None, st),
     "dw": lambda: lib.rk_decode_bwd_dw(ptr(dO), ptr(Z), B, h, blk.ref, ptr(G), None, st),
   }
   for name, fn in calls.items():

@@ -77,10 +77,10 @@ def main():
     r["collate"] = timeit(lambda: blk.collate(dcsr, users))
     r["dec_mse"] = timeit(lambda: check(lib.rk_decode_loss(
         ptr(Z), B, h, blk.ref, 0, ptr(W), ptr(bias), LOSS_MSE, 0.0, 1.0 / B, ptr(dO), 0, ptr(part),
-        ptr(gbp), st)))
+        ptr(gbp), None, st)))
     r["dec_store"] = timeit(lambda: check(lib.rk_decode_loss(
         ptr(Z), B, h, blk.ref, 0, ptr(W), ptr(bias), LOSS_NONE, 0.0, 1.0, ptr(out), blk.ld_cap, None,
-        None, st)))
+        None, None, st)))
     r["dz"] = timeit(lambda: check(lib.rk_decode_bwd_dz(
         ptr(dO), B, h, blk.ref, ptr(W), None, 0, ptr(dZ), ptr(ws), None, st)))
     r["dw"] = timeit(lambda: check(lib.rk_decode_bwd_dw(

@@ -29,9 +29,9 @@ int main() {
   blk.S_cap = B; blk.nnz_cap = 1; blk.n_cap = n_t; blk.n_items = n_items; blk.ldw_rc = ld / 32; blk.ldw_cr = 16;
   blk.implicit = 1; blk.counts = counts; blk.items = items; blk.indptr = indptr; blk.bits_rc = bits; blk.pref_rc = pref;
   for (int rep = 0; rep < 3; ++rep) {
-    rk_decode_loss(Z, B, h, &blk, 0, W, bias, RK_LOSS_MSE, 0.f, 1.f / B, dO, 0, part, gbp, nullptr);
+    rk_decode_loss(Z, B, h, &blk, 0, W, bias, RK_LOSS_MSE, 0.f, 1.f / B, dO, 0, part, gbp, nullptr, nullptr);
     hipDeviceSynchronize(); if (rep == 2) dump("decode");
-    rk_decode_bwd_dz(dO, B, h, &blk, W, nullptr, 0, dZ, ws, nullptr);
+    rk_decode_bwd_dz(dO, B, h, &blk, W, nullptr, 0, dZ, ws, nullptr, nullptr);
     hipDeviceSynchronize(); if (rep == 2) dump("dz");
     rk_decode_bwd_dw(dO, Z, B, h, &blk, G, nullptr, nullptr);
     hipDeviceSynchronize(); if (rep == 2) dump("dw");
