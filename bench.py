@@ -216,11 +216,18 @@ def main():
     # replays the captured graphs (so that the timed region starts with warm graphs)
     return "all" if i < min(G, max(1, W // 2)) else None
 
+  SAMPLE_POST = os.environ.get("RK_BENCH_SAMPLE", "timed") == "post"
+
   def plan_timed(i):
     # timed region: the LAST whole group is enqueued eagerly with every launch group bracketed
     # (HIP events cannot sit inside a replayed graph); everything else is graph replay
+    if SAMPLE_POST:
+      return "all" if W + K <= i < W + K + G else None
+    # -- and of that group only as many steps as a 5 % sample of K (every bracket costs two event
+    # records = two barrier packets in the queue)
     last = W + ((K // G) - 1) * G if K >= 2 * G else W + K
-    return "all" if last <= i < last + G else None
+    n_br = min(G, max(1, K // 20))
+    return "all" if last + G - n_br <= i < last + G else ("eager" if last <= i < last + G else None)
 
   def start():
     eng = rec._engine()
@@ -235,13 +242,24 @@ def main():
     T["enqueue"] = time.perf_counter() - T["t0"]     # host time to enqueue the timed steps
     sync_all()
     T["dt"] = time.perf_counter() - T["t0"]
-    return True                                      # end the training here
+    return not SAMPLE_POST                           # end the training here
 
   def install():
     rec._engine().time_plan = plan_warm
     return False
 
   rec.step_marks = {0: install, W: start, W + K: stop}
+  if SAMPLE_POST:
+    rec.step_marks[W + K + G] = lambda: True
+  prewarm = float(os.environ.get("RK_BENCH_PREWARM", "0"))
+  if prewarm > 0:
+    xw = torch.randn(4096, 4096, device=device)
+    tw = time.perf_counter()
+    while time.perf_counter() - tw < prewarm:
+      for _ in range(20):
+        xw = (xw @ xw).clamp_(-1, 1)
+      torch.cuda.synchronize()
+    del xw
   rec.train(ds, batch_size=B, lr=cfg["lr"], weight_decay=cfg["weight_decay"], num_epochs=epochs,
             negative_sampling=True)
   assert "dt" in T, "the timed region did not complete (%d + %d steps)" % (W, K)

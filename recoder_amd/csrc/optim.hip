@@ -256,21 +256,24 @@ template <> __device__ __forceinline__ float absmax_of<float4>(const float4 &v) 
 template <> __device__ __forceinline__ float absmax_of<float>(const float &v) { return fabsf(v); }
 
 // running maximum of |p| over everything this job has ever written: the decoder GEMMs take the
-// fp16 split scale of their weight operand from it (gemm.hip b_amax); one atomic per workgroup
-__device__ __forceinline__ void publish_pmax(uint32_t *slots, float m) {
-  __shared__ float wmax[4];
+// fp16 split scale of their weight operand from it (gemm.hip b_amax).  The slot is read at the START
+// of the workgroup's sweep (with its other loads: a dependent read at the end costs the short-lived
+// workgroups 6-12 us per sweep, and so do thousands of unconditional atomics on 64 addresses) and
+// the atomic is only issued by a wave that would raise it -- the bound moves rarely
+__device__ __forceinline__ uint32_t *pmax_slot(uint32_t *slots) {
+  return slots + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 63);
+}
+__device__ __forceinline__ void publish_pmax(uint32_t *slots, uint32_t seen, float m) {
   m = rk_wave_max(m);
-  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0)
-    atomicMax(slots + (blockIdx.x & 63),
-              __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+  const uint32_t bits = __float_as_uint(m);
+  if ((threadIdx.x & 63) == 0 && bits > seen) atomicMax(pmax_slot(slots), bits);
 }
 
 template <typename T>
 __device__ __forceinline__ void update_job(const UJob &J, int lb, const AdamC &C) {
   using V = VecOps<T>;
   float pmax = 0.f;
+  const uint32_t seen = J.amax_out ? *pmax_slot(J.amax_out) : 0u;
   const int hq = J.h / V::W;
   const int64_t stride = J.gstride_dev ? (int64_t)*J.gstride_dev : (int64_t)J.g_stride;
   const int g_parts = J.gparts_dev ? min(*J.gparts_dev, J.g_parts) : J.g_parts;
@@ -290,7 +293,7 @@ __device__ __forceinline__ void update_job(const UJob &J, int lb, const AdamC &C
       P[o] = p1; M[o] = m1; Vv[o] = v1;
       pmax = fmaxf(pmax, absmax_of<T>(p1));
     }
-    if (J.amax_out) publish_pmax(J.amax_out, pmax);
+    if (J.amax_out) publish_pmax(J.amax_out, seen, pmax);
     return;
   }
   const int rows_live = J.row0 < J.n_rows ? (J.n_rows - J.row0 + J.row_step - 1) / J.row_step : 0;
@@ -329,7 +332,7 @@ __device__ __forceinline__ void update_job(const UJob &J, int lb, const AdamC &C
     P[e] = p1; M[e] = m1; Vv[e] = v1;
     pmax = fmaxf(pmax, absmax_of<T>(p1));
   }
-  if (J.amax_out) publish_pmax(J.amax_out, pmax);
+  if (J.amax_out) publish_pmax(J.amax_out, seen, pmax);
 }
 
 __device__ __forceinline__ void run_job(const UJob &J, int b, const UArgs &a) {

@@ -606,6 +606,8 @@ class FusedEngine:
     name = None
     if self.time_plan is not None and (replay is None or replay.get("timed")):
       name = self.time_plan(replay["index"] if replay is not None else self._c_calls)
+      if name == "eager":                  # (an eagerly enqueued step of a bracketed group: no events)
+        name = None
     st.time_all = None
     if name == "all":
       # every launch group of this step gets its own pair of timing events

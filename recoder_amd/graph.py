@@ -52,8 +52,13 @@ class GraphStepper:
     self.main = torch.cuda.Stream(device=device)
     self.side = torch.cuda.Stream(device=device)
     self.ev_fork, self.ev_join = self.lib.rk_event_create(), self.lib.rk_event_create()
+    # the group right behind a cut (epoch start, step mark) has no look-ahead blocks: its G
+    # collations are independent chains of small launches, run side by side on streams of their own
+    self.pre = [torch.cuda.Stream(device=device) for _ in range(self.G - 1)]
+    self.ev_pre = [self.lib.rk_event_create() for _ in range(self.G - 1)]
     self.st = [[RkAeStep() for _ in range(self.G)] for _ in range(2)]
     self.exec = [None, None]
+    self.exec_first = None                 # the group right behind a cut: its collation + slot 0's group
     self.warmed = False
     self.global_step = 0                   # steps this stepper's cursor has seen
     self.epoch_base = 0
@@ -63,7 +68,10 @@ class GraphStepper:
       if e:
         self.lib.rk_graph_destroy(e)
     self.exec = [None, None]
-    for e in (self.ev_fork, self.ev_join):
+    if self.exec_first:
+      self.lib.rk_graph_destroy(self.exec_first)
+      self.exec_first = None
+    for e in [self.ev_fork, self.ev_join] + self.ev_pre:
       self.lib.rk_event_destroy(e)
 
   # ----------------------------------------------------------------- pieces
@@ -106,15 +114,29 @@ class GraphStepper:
     check(lib.rk_event_record(self.ev_join, self._h(self.side)), "rk_event_record")
     check(lib.rk_stream_wait_event(self._h(self.main), self.ev_join), "rk_stream_wait_event")
 
-  def _capture(self, slot):
+  def _pre_collate(self, n0):
+    """Collate blocks[0][0..n0) side by side: block 0 on the main stream, the others on streams of
+    their own, joined back.  Called inside a capture or eagerly."""
+    lib = self.lib
+    if n0 > 1:
+      check(lib.rk_event_record(self.ev_fork, self._h(self.main)), "rk_event_record")
+    for g in range(1, n0):
+      check(lib.rk_stream_wait_event(self._h(self.pre[g - 1]), self.ev_fork), "rk_stream_wait_event")
+      self._collate(self.blocks[0][g], g, self.pre[g - 1], 0)
+      check(lib.rk_event_record(self.ev_pre[g - 1], self._h(self.pre[g - 1])), "rk_event_record")
+    self._collate(self.blocks[0][0], 0, self.main, 0)
+    for g in range(1, n0):
+      check(lib.rk_stream_wait_event(self._h(self.main), self.ev_pre[g - 1]), "rk_stream_wait_event")
+
+  def _capture(self, enqueue):
     check(self.lib.rk_graph_begin(self._h(self.main)), "rk_graph_begin")
     try:
-      self._group(slot)
+      enqueue()
     finally:
       ex = self.lib.rk_graph_end(self._h(self.main))
     if not ex:
       raise _lib.RecoderHipError("graph capture failed: %s" % self.lib.rk_last_error().decode())
-    self.exec[slot] = ex
+    return ex
 
   # ------------------------------------------------------------------ epoch
   def begin_epoch(self, order_np, global_step):
@@ -153,12 +175,12 @@ class GraphStepper:
     if n_steps <= 0:
       return
     slot = 0
-    if self._collated is None:
-      # nothing of the first group is in flight yet: point slot 0's cursor at it, collate it now
+    need_pre = self._collated is None
+    if need_pre:
+      # nothing of the first group is in flight yet: point slot 0's cursor at it; its blocks are
+      # collated in front of its steps (one graph with them, or eagerly)
       check(lib.rk_cursor_set(self._cur(0), self.global_step, self.epoch_base, self._h(self.main)),
             "rk_cursor_set")
-      for g in range(min(G, n_steps)):
-        self._collate(self.blocks[0][g], g, self.main, 0)
     else:
       slot = self._collated
     done = 0
@@ -169,21 +191,29 @@ class GraphStepper:
         eager = eager_plan is not None and any(eager_plan(idx0 + g) for g in range(G))
         # the very first group always runs eagerly: every kernel has then been launched (its code
         # object loaded) before it is captured -- graphs captured cold replayed ~8x slower on the
-        # host -- and both graphs are captured right behind it (capturing enqueues nothing), i.e.
+        # host -- and the graphs are captured right behind it (capturing enqueues nothing), i.e.
         # in the warm-up of a benchmark, never inside its timed region
         if eager or not self.warmed:
+          if need_pre:
+            self._pre_collate(G)
           self._group(slot, G, first_index=idx0)
           if not self.warmed:
             self.warmed = True
             for v in (0, 1):
               if self.exec[v] is None:
-                self._capture(v)
+                self.exec[v] = self._capture(lambda v=v: self._group(v))
+            if self.exec_first is None:
+              self.exec_first = self._capture(lambda: (self._pre_collate(G), self._group(0)))
         else:
-          check(lib.rk_graph_launch(self.exec[slot], self._h(self.main)), "rk_graph_launch")
+          check(lib.rk_graph_launch(self.exec_first if need_pre else self.exec[slot], self._h(self.main)),
+                "rk_graph_launch")
         k = G
       else:
+        if need_pre:
+          self._pre_collate(left)
         self._group(slot, left, first_index=idx0)      # tail: fewer than G steps, eager
         k = left
+      need_pre = False
       self._advance_host(k)
       done += k
       slot = 1 - slot
