@@ -242,6 +242,13 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
   // epilogue never stores.  Only the K direction needs real zeros, and only in
   // the last (partial) K-tile -- interior tiles take the lean path below: one
   // pointer per staged float4, no selects.
+  // split-fp16 staging of a K-contiguous operand: a thread's 8-byte hi / lo stores go to LDS rows of
+  // 144 bytes (an odd number of 16-byte slots: conflict-free ds_read_b128 fragments).  With 8
+  // consecutive lanes per row, the 4 rows a 32-lane store pass covers must lie 4 apart -- 144 r mod
+  // 256 for r, r+4, r+8, r+12 are the four disjoint 64-byte ranges; consecutive rows overlap (2-way
+  // conflicts on half the banks: SQ_LDS_BANK_CONFLICT 28 % of the decode's LDS cycles in round 1).
+  // So slot s of the staging order handles row row_of(s), a permutation inside every 16 rows.
+  auto row_of = [](int s) -> int { return H3 ? ((s & ~15) | ((s & 3) << 2) | ((s >> 2) & 3)) : s; };
   const float *a_ptr[A_PT], *b_ptr[B_PT];
   int a_k[A_PT], b_k[B_PT];           // k index of the element inside the tile
   int b_n[B_PT];                      // BMODE 1: column offset (row pointer varies with the gather)
@@ -249,7 +256,7 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
   for (int i = 0; i < A_PT; ++i) {
     const int idx = min(tid + i * 256, A_F4 - 1);
     if (AMODE == 0) {
-      const int row = idx / QK, q = idx % QK;
+      const int row = row_of(idx / QK), q = idx % QK;
       a_k[i] = q * 4;
       a_ptr[i] = p.A + (int64_t)min(m0 + row, M - 1) * lda + q * 4 + kbeg;
     } else {
@@ -266,7 +273,7 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
   for (int i = 0; i < B_PT; ++i) {
     const int idx = min(tid + i * 256, B_F4 - 1);
     if (BMODE == 0) {
-      const int row = idx / QK, q = idx % QK;
+      const int row = row_of(idx / QK), q = idx % QK;
       const int nc = min(n0 + row, N - 1);
       const int64_t src = p.bidx ? (int64_t)p.bidx[nc] : (int64_t)nc;   // gather index: once
       b_k[i] = q * 4;
@@ -367,7 +374,7 @@ __device__ __forceinline__ void gemm_body(const GemmP &p, const int L, const int
               // (selects, not a branch on `tail`: control flow between the staged loads and their
               // LDS stores makes hipcc drain vmcnt at the top of every iteration)
               const float4 v = MASK ? mask4(regs[i], tail ? klen - kb - kk[i] : 4) : regs[i];
-              put(base, scale, idx / QK, idx % QK, v);
+              put(base, scale, row_of(idx / QK), idx % QK, v);
             }
           }
         } else {

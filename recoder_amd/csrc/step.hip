@@ -34,7 +34,10 @@ extern "C" void rk_event_destroy(void *e) {
 extern "C" float rk_event_elapsed_ms(void *e0, void *e1) {
   float ms = -1.f;
   if (hipEventSynchronize((hipEvent_t)e1) != hipSuccess) return -1.f;
-  if (hipEventElapsedTime(&ms, (hipEvent_t)e0, (hipEvent_t)e1) != hipSuccess) return -1.f;
+  if (hipEventElapsedTime(&ms, (hipEvent_t)e0, (hipEvent_t)e1) != hipSuccess) {
+    (void)hipGetLastError();      // (an entry this step never launched: do not leave the error behind)
+    return -1.f;
+  }
   return ms;
 }
 
