@@ -16,26 +16,29 @@
 
 namespace {
 
-// HV = number of float4 per lane (h <= 256*HV)
+// HV = number of float4 per lane (h <= 256*HV); FW waves share one user row.  The launch lasts as
+// long as its LONGEST row (a C2 batch: mean 55 stored interactions, maximum 430-900), so the row is
+// cut into as many pieces as the register budget allows at two workgroups per CU
+constexpr int FW = 8;
 template <int HV>
-__global__ __launch_bounds__(256) void ae_encode_fwd_kernel(
+__global__ __launch_bounds__(FW * 64) void ae_encode_fwd_kernel(
     rk_block_t b, int row_off, int B, const float *__restrict__ W, const float *__restrict__ bias,
     int h, const uint8_t *__restrict__ keep, float p, float scale, uint64_t seed,
     uint64_t rng_step, const int64_t *__restrict__ users, const float *__restrict__ user_norm,
     int act, float *__restrict__ Z0, uint16_t *__restrict__ planes, int64_t plane_stride,
     int cols_pad, rk_cur_t cur) {
-  __shared__ float red[4];
+  __shared__ float red[FW];
   if (cur.cursor) {          // graph replay (common.h): the step's RNG index and user ids
     rng_step = (uint64_t)(rk_cur_global(cur) + 1);
     if (users) users += rk_cur_local(cur) * B;       // (replayed steps are whole batches: S == B)
   }
-  __shared__ __attribute__((aligned(16))) float part[3][HV * 256];
+  __shared__ __attribute__((aligned(16))) float part[FW - 1][HV * 256];
   const int r = blockIdx.x;            // row within the slice
   if (r >= B) {
     // planes != null: the grid covers the rows up to the next multiple of 64; the padding rows
     // of the Z^T planes are (re)written as zeros (the dW kernel's K padding relies on it)
     if (planes) {
-      for (int n = threadIdx.x; n < h; n += 256) {
+      for (int n = threadIdx.x; n < h; n += FW * 64) {
         const int64_t o = ((int64_t)(r >> 3) * cols_pad + n) * 8 + (r & 7);
         planes[o] = 0; planes[o + plane_stride] = 0; planes[o + 2 * plane_stride] = 0;
       }
@@ -49,10 +52,10 @@ __global__ __launch_bounds__(256) void ae_encode_fwd_kernel(
   const bool implicit = b.implicit != 0;
   const int64_t uid = users ? users[row] : (int64_t)row;
 
-  // ---- each wave takes a contiguous quarter of the row's entries.  The first 64 of
+  // ---- each wave takes a contiguous 1/FW of the row's entries.  The first 64 of
   // them are fetched (value + global item id, independent loads) BEFORE the norm is
   // known, so the dependent chain is indptr -> entries -> W rows ----
-  const int q = (n + 3) >> 2;
+  const int q = (n + FW - 1) / FW;
   const int wbeg = beg + wid * q;
   const int wend = min(end, wbeg + q);
   int item0 = 0;
@@ -72,14 +75,17 @@ __global__ __launch_bounds__(256) void ae_encode_fwd_kernel(
     nrm = fmaxf(sqrtf((float)n), 1e-12f);      // n ones: the sum of squares is exactly n
   } else {
     float ss = 0.f;
-    for (int j = beg + tid; j < end; j += 256) {
+    for (int j = beg + tid; j < end; j += FW * 64) {
       const float v = b.vals[j];
       ss += v * v;
     }
     ss = rk_wave_sum(ss);
     if (lane == 0) red[wid] = ss;
     __syncthreads();
-    nrm = fmaxf(sqrtf((red[0] + red[1]) + (red[2] + red[3])), 1e-12f);
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < FW; ++w) tot += red[w];
+    nrm = fmaxf(sqrtf(tot), 1e-12f);
   }
 
   float4 acc[HV];
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(256) void ae_encode_fwd_kernel(
       const int hh = (v * 64 + lane) * 4;
       if (hh < h) {
         float4 a = acc[v];
-        for (int w = 0; w < 3; ++w) {
+        for (int w = 0; w < FW - 1; ++w) {
           const float4 o = *reinterpret_cast<const float4 *>(&part[w][hh]);
           a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
         }
@@ -207,7 +213,7 @@ static int encode_fwd_launch(const rk_block_t *blk, int32_t row_off, int32_t B, 
   const int cols_pad = rk_dw3_cols_pad(h);
   const int64_t plane_stride = (int64_t)rk_dw3_rows_pad(B) * cols_pad;
 #define LAUNCH(HV)                                                                         \
-  RK_LAUNCH(ae_encode_fwd_kernel<HV>, dim3(rows), dim3(256), 0, stream, *blk, row_off, \
+  RK_LAUNCH(ae_encode_fwd_kernel<HV>, dim3(rows), dim3(FW * 64), 0, stream, *blk, row_off, \
                      B, W_en, b_en, h, keep, p, scale, seed, rng_step, users, user_norm, act, Z0, \
                      (uint16_t *)zt_planes, plane_stride, cols_pad, cur)
   if (hv == 1) LAUNCH(1); else if (hv == 2) LAUNCH(2); else LAUNCH(4);

@@ -197,13 +197,7 @@ class GraphStepper:
           if need_pre:
             self._pre_collate(G)
           self._group(slot, G, first_index=idx0)
-          if not self.warmed:
-            self.warmed = True
-            for v in (0, 1):
-              if self.exec[v] is None:
-                self.exec[v] = self._capture(lambda v=v: self._group(v))
-            if self.exec_first is None:
-              self.exec_first = self._capture(lambda: (self._pre_collate(G), self._group(0)))
+          self._warm_capture()
         else:
           check(lib.rk_graph_launch(self.exec_first if need_pre else self.exec[slot], self._h(self.main)),
                 "rk_graph_launch")
@@ -212,12 +206,25 @@ class GraphStepper:
         if need_pre:
           self._pre_collate(left)
         self._group(slot, left, first_index=idx0)      # tail: fewer than G steps, eager
+        self._warm_capture()
         k = left
       need_pre = False
       self._advance_host(k)
       done += k
       slot = 1 - slot
     self._collated = slot                # the look-ahead blocks of the next group
+
+  def _warm_capture(self):
+    """Capture the graphs once every kernel has been launched eagerly (the first steps run)."""
+    if self.warmed:
+      return
+    self.warmed = True
+    G = self.G
+    for v in (0, 1):
+      if self.exec[v] is None:
+        self.exec[v] = self._capture(lambda v=v: self._group(v))
+    if self.exec_first is None:
+      self.exec_first = self._capture(lambda: (self._pre_collate(G), self._group(0)))
 
   def cut(self):
     """Forget the look-ahead blocks (a step mark / an eager ragged step follows)."""
