@@ -19,27 +19,43 @@ __device__ __forceinline__ void ae_encode_bwd_body(
   if (bid < n_gb) {
     // encoder-bias gradient, 64 columns x one of n_seg row segments per workgroup:
     // gb[seg][j] = sum over the segment's rows of dZ[r, j] (the Adam sweep adds the n_seg
-    // partial vectors in order).  The 4 waves take interleaved quarters of the rows, 4
-    // independent loads in flight each, combined in fixed order.
-    const int gseg = bid % n_seg, j = (bid / n_seg) * 64 + lane;
+    // partial vectors in order).  A lane owns 4 columns (one 16-byte load) of every 16th row: the
+    // 16 (wave, lane / 16) pairs take the rows round-robin, 8 independent loads in flight each --
+    // 4 workgroups are all this part has at h = 200, so its chain of load batches (not its
+    // bytes) set the length of the whole launch when it was 31 batches long.
+    const int gseg = bid % n_seg, j0 = (bid / n_seg) * 64 + (lane & 15) * 4;
     const int srows = ((B + n_seg - 1) / n_seg + 63) & ~63;
     const int r_lo = gseg * srows, r_hi = min(B, r_lo + srows);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (j < h) {
-      int r = r_lo + wid;
-      for (; r + 12 < r_hi; r += 16) {
-        a0 += dZ[(int64_t)r * h + j];
-        a1 += dZ[(int64_t)(r + 4) * h + j];
-        a2 += dZ[(int64_t)(r + 8) * h + j];
-        a3 += dZ[(int64_t)(r + 12) * h + j];
-      }
-      for (; r < r_hi; r += 4) a0 += dZ[(int64_t)r * h + j];
+    const int jj = min(j0, h - 4);                 // (clamped: columns past h are never stored)
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    int r = r_lo + wid * 4 + (lane >> 4);
+    for (; r + 7 * 16 < r_hi; r += 8 * 16) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(dZ + (int64_t)(r + u * 16) * h + jj);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
     }
-    part[0][wid * 64 + lane] = (a0 + a1) + (a2 + a3);
+    for (; r < r_hi; r += 16) {
+      const float4 v = *reinterpret_cast<const float4 *>(dZ + (int64_t)r * h + jj);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    // the 4 row-phases of the wave (lanes l, l^16, l^32, l^48), then the 4 waves, fixed order
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+      a.x += __shfl_xor(a.x, off, 64); a.y += __shfl_xor(a.y, off, 64);
+      a.z += __shfl_xor(a.z, off, 64); a.w += __shfl_xor(a.w, off, 64);
+    }
+    if (lane < 16) *reinterpret_cast<float4 *>(&part[0][wid * 64 + lane * 4]) = a;
     __syncthreads();
-    if (wid == 0 && j < h)
-      gb[gseg * h + j] =
-          (part[0][lane] + part[0][64 + lane]) + (part[0][128 + lane] + part[0][192 + lane]);
+    if (wid == 0 && lane < 16 && j0 < h) {
+      float4 o = a;
+      for (int w = 1; w < 4; ++w) {
+        const float4 q = *reinterpret_cast<const float4 *>(&part[0][w * 64 + lane * 4]);
+        o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+      }
+      *reinterpret_cast<float4 *>(gb + gseg * h + j0) = o;        // (h % 4 == 0: whole quads)
+    }
     return;
   }
   const int n_b = b.counts[0];

@@ -781,12 +781,14 @@ __global__ __launch_bounds__(256) void dw_encode_bwd_kernel(
 }
 
 // ws[split][M][N] -> out[M][N] (fixed split order), optional * act'(Zact)
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(
+constexpr int RED_W = 8;       // waves per workgroup: each sums 1/RED_W of the splits
+__global__ __launch_bounds__(RED_W * 64) void splitk_reduce_kernel(
     const float *__restrict__ ws, int M, int N, const int32_t *__restrict__ Kdev, int unused,
     int max_splits, const float *__restrict__ Zact, int act, float *__restrict__ out) {
-  // 64 float4 outputs per workgroup; the 4 waves each sum a quarter of the splits
-  // (8 loads in flight), combined in fixed order through LDS
-  __shared__ float4 part[3][64];
+  // 64 float4 outputs per workgroup; the waves each sum a contiguous share of the splits (all of
+  // its loads in flight at once: the slabs come from the Infinity Cache / HBM, and the launch is as
+  // long as one wave's chain of load batches), combined in fixed order through LDS
+  __shared__ float4 part[RED_W - 1][64];
   const int K = *Kdev;
   const int kchunk = ((K + max_splits - 1) / max_splits + 31) & ~31;   // as the GEMM derives it
   int ns = (K + kchunk - 1) / kchunk;
@@ -795,7 +797,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(
   const float4 *ws4 = reinterpret_cast<const float4 *>(ws);
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * 64 + lane;
-  const int per = (ns + 3) >> 2;
+  const int per = (ns + RED_W - 1) / RED_W;
   const int z1 = min(ns, (q + 1) * per);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i < tot4) {
@@ -815,9 +817,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(
   if (q > 0) part[q - 1][lane] = s;
   __syncthreads();
   if (q == 0 && i < tot4) {
-    const float4 a = part[0][lane], b = part[1][lane], c = part[2][lane];
-    s.x = (s.x + a.x) + (b.x + c.x); s.y = (s.y + a.y) + (b.y + c.y);
-    s.z = (s.z + a.z) + (b.z + c.z); s.w = (s.w + a.w) + (b.w + c.w);
+#pragma unroll
+    for (int w = 0; w < RED_W - 1; ++w) {
+      const float4 a = part[w][lane];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
     if (Zact) {
       const float4 y = reinterpret_cast<const float4 *>(Zact)[i];
       s.x *= rk_act_dy(y.x, act); s.y *= rk_act_dy(y.y, act);
@@ -1247,7 +1251,7 @@ extern "C" int rk_decode_bwd_dz(const float *dO, int32_t B, int32_t h, const rk_
 #undef LAUNCH
   RK_CHECK_LAUNCH("decode_bwd_dz");
   const int grid = rk_cdiv((int64_t)B * h / 4, 64);
-  RK_LAUNCH(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, workspace, B, h,
+  RK_LAUNCH(splitk_reduce_kernel, dim3(grid), dim3(RED_W * 64), 0, stream, workspace, B, h,
                      tgt->counts, kchunk, splits, Zact, act, dZ);
   RK_CHECK_LAUNCH("splitk_reduce");
   return 0;
