@@ -443,6 +443,14 @@ typedef struct rk_ae_step {
   int64_t *cursor_next;
   void *const *time_all;     /* time_entry == RK_ENTRY_ALL: host array of 2 * RK_ENTRY_COUNT timing
                                 events, entry e is bracketed by [2e] and [2e + 1] */
+  /* dW as a branch of the step (whole untied MSE / BCE steps on the 16-bit pipe): dW = dO^T . Z
+   * needs nothing of the dZ -> encoder-backward chain, so with dw_stream set it is enqueued on that
+   * stream behind dw_fork (recorded after the decode) AFTER the chain's launches -- in a stream
+   * capture the branch captured first keeps the launching queue, and the chain is the critical
+   * one -- and the Adam sweep waits for dw_join.  It then needs a workspace of its own, ws_dw
+   * (rk_dw3_workspace_bytes).  All NULL: dW runs in line on `stream`, in `ws`. */
+  float *ws_dw;
+  void *dw_stream, *dw_fork, *dw_join;
 } rk_ae_step_t;
 
 void *rk_event_create(void);          /* ordering-only (no timing, device-scope fence) */

@@ -71,6 +71,7 @@ class RkAeStep(Structure):
     ("cursor", c_void_p), ("cursor_off", c_int32), ("cursor_advance", c_int32), ("adam_table", c_void_p),
     ("cursor_next", c_void_p),
     ("time_all", POINTER(c_void_p)),
+    ("ws_dw", c_void_p), ("dw_stream", c_void_p), ("dw_fork", c_void_p), ("dw_join", c_void_p),
   ]
 
 

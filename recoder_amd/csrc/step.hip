@@ -140,11 +140,14 @@ rk_adam_job_t table_job(const rk_adam_param_t &par, const rk_block_t *blk, int n
 // dW = dO^T . Z: the bf16-pipe kernel (dw3.hip) when the split contractions are on and the step
 // has a workspace, else the fp32-MFMA tiles.  G_de == NULL (dw3 only): the K slabs stay in the
 // workspace for rk_adam_multi.
-int dw_call(const rk_ae_step_t *a, float *G_de, float *gb_de, bool have_planes) {
-  if (rk_gemm_split16() && a->ws)
-    return rk_decode_bwd_dw3(a->dO, a->Z0, a->B, a->h, a->blk, G_de, gb_de, a->ws,
-                             have_planes ? a->zt_planes : nullptr, a->stream);
-  return rk_decode_bwd_dw(a->dO, a->Z0, a->B, a->h, a->blk, G_de, gb_de, a->stream);
+int dw_call(const rk_ae_step_t *a, float *G_de, float *gb_de, bool have_planes,
+            float *ws = nullptr, void *stream = nullptr) {
+  ws = ws ? ws : a->ws;
+  stream = stream ? stream : a->stream;
+  if (rk_gemm_split16() && ws)
+    return rk_decode_bwd_dw3(a->dO, a->Z0, a->B, a->h, a->blk, G_de, gb_de, ws,
+                             have_planes ? a->zt_planes : nullptr, stream);
+  return rk_decode_bwd_dw(a->dO, a->Z0, a->B, a->h, a->blk, G_de, gb_de, stream);
 }
 
 }  // namespace
@@ -269,6 +272,9 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   // the encoder forward writes the Z^T planes of the bf16-pipe dW kernel along with Z
   const bool planes = rk_gemm_split16() && a->ws != nullptr && a->zt_planes != nullptr &&
                       (phase & RK_STEP_FWD_DW) != 0;
+  // dW on a stream of its own next to the dZ -> encoder-backward chain (rk_ae_step_t.dw_stream)
+  const bool dw_branch = dw3 && a->dw_stream != nullptr;
+  RK_REQUIRE(!dw_branch || (a->ws_dw && a->dw_fork && a->dw_join), "dw_stream needs ws_dw, dw_fork, dw_join");
 
   if (phase & RK_STEP_FWD_DW) {
     {
@@ -292,6 +298,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
                             a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, a->ranges, sm));
       if (mnll) RK_TRY(rk_mnll_finish(a->dO, B, blk, a->row_off, a->inv_B, a->loss_part, sm));
     }
+    if (dw_branch) RK_TRY(rk_event_record(a->dw_fork, sm));      // dO and the Z^T planes are ready
     // dW: on its own (tied weights: the encoder backward accumulates onto its rows;
     // MNLL: + column sums of dO; data parallel: G_de must travel early), otherwise
     // fused with the encoder backward below
@@ -313,6 +320,19 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     if (a->tied || mnll || !whole) {
       Timer t(a, RK_ENTRY_ENCODE_BWD, sm);
       RK_TRY(rk_ae_encode_bwd(blk, a->row_off, B, a->dZ0, h, G_en, a->tied ? 1 : 0, a->gb_en, sm));
+    } else if (dw_branch) {
+      {
+        Timer t(a, RK_ENTRY_ENCODE_BWD, sm);
+        RK_TRY(rk_ae_encode_bwd(blk, a->row_off, B, a->dZ0, h, G_en, 0, a->gb_en, sm));
+      }
+      // (enqueued behind the chain: see rk_ae_step_t.dw_stream)
+      RK_TRY(rk_stream_wait_event(a->dw_stream, a->dw_fork));
+      {
+        Timer t(a, RK_ENTRY_DECODE_BWD_DW, a->dw_stream);
+        RK_TRY(dw_call(a, nullptr, nullptr, planes, a->ws_dw, a->dw_stream));
+      }
+      RK_TRY(rk_event_record(a->dw_join, a->dw_stream));
+      RK_TRY(rk_stream_wait_event(sm, a->dw_join));
     } else if (dw3) {
       // the dZ slabs in the workspace are consumed: the bf16-pipe dW takes it over (Z^T planes +
       // its own K slabs, which rk_adam_multi sums while it reads the gradient)
@@ -342,7 +362,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       jobs[n] = table_job(a->par[RK_PAR_W_DE], blk, n_items, h, a->G_de, true);
       if (a->ranges) jobs[n].amax_out = a->ranges + 64;
       if (dw3) {
-        jobs[n].g = rk_dw3_slabs(a->ws, B, h); jobs[n].g_parts = rk_dw3_max_splits();
+        jobs[n].g = rk_dw3_slabs(dw_branch ? a->ws_dw : a->ws, B, h); jobs[n].g_parts = rk_dw3_max_splits();
         jobs[n].g_stride = blk->n_cap * h; jobs[n].gparts_dev = blk->counts + 4;
       }
       slots[n] = RK_PAR_W_DE;

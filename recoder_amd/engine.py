@@ -110,6 +110,9 @@ class FusedEngine:
     self.item_parallel = None              # parallel.ItemParallel when the items are sharded
     self._cstep = None
     self._c_calls = 0
+    # dW on a stream of its own next to the dZ -> encoder-backward chain; RK_DW_BRANCH=0: in line
+    self.dw_branch = os.environ.get("RK_DW_BRANCH", "1") != "0"
+    self._dw_objs = None
     # operand ranges of the split-fp16 decoder contractions (include/recoder_hip.h rk_amax):
     # [0..63] max |Z| (filled per call when the activation is unbounded), [64..127] an upper bound
     # of |decoder table| (its maximum now; the Adam sweep keeps it running from there)
@@ -160,6 +163,9 @@ class FusedEngine:
                               self.lib.rk_dw3_workspace_bytes(B_cap, h0, n_cap)) // 4 + 64, **f)
     self.split16 = bool(self.lib.rk_gemm_split16())
     self._dw_slabs = None
+    # dW as a branch of the one-call step (rk_ae_step_t.dw_stream): a workspace of its own
+    self.ws_dw = (torch.zeros(self.lib.rk_dw3_workspace_bytes(B_cap, h0, n_cap) // 4 + 64, **f)
+                  if self.split16 and self.dw_branch else None)
     # Z^T as bf16 planes for the dW kernel, written by the encoder forward of the one-call step
     # (zeroed once: the padding columns are never written)
     self.zt_planes = torch.zeros(self.lib.rk_dw3_planes_bytes(B_cap, h0) // 4 + 16, **f)
@@ -597,6 +603,17 @@ class FusedEngine:
     st.loss_part, st.loss_out = ptr(self.loss_part), ptr(loss_dst)
     st.stream = main_s.cuda_stream
     st.cursor, st.cursor_off, st.adam_table, st.cursor_next, st.cursor_advance = None, 0, None, None, 0
+    st.ws_dw = st.dw_stream = st.dw_fork = st.dw_join = None
+    self._ws_dw_live = False
+    if dw3 and self.ws_dw is not None:
+      if self._dw_objs is None:
+        raw0 = _lib.load()
+        self._dw_objs = (torch.cuda.Stream(device=self.device), raw0.rk_event_create(), raw0.rk_event_create())
+      # (the graph stepper lends its side stream: dW and its collation share one branch)
+      dws = replay.get("dw_stream") if replay is not None else None
+      st.ws_dw, st.dw_stream = ptr(self.ws_dw), (dws or self._dw_objs[0]).cuda_stream
+      st.dw_fork, st.dw_join = self._dw_objs[1], self._dw_objs[2]
+      self._ws_dw_live = True
     if replay is not None:
       st.cursor, st.cursor_off, st.adam_table = replay["cursor"], replay["off"], replay["table"]
       if replay.get("next") is not None:         # last step of a group: publish the next cursor
@@ -686,9 +703,10 @@ class FusedEngine:
       return self.G_de[:n_b * h0].view(n_b, h0).clone()
     blk, B = self._dw_slabs
     ns = int(blk.counts[4].item())
-    off = (self.lib.rk_dw3_slabs(ptr(self.ws), B, h0) - self.ws.data_ptr()) // 4
+    ws = self.ws_dw if getattr(self, "_ws_dw_live", False) else self.ws
+    off = (self.lib.rk_dw3_slabs(ptr(ws), B, h0) - ws.data_ptr()) // 4
     stride = blk.n_cap * h0
-    return sum(self.ws[off + k * stride:off + k * stride + n_b * h0].view(n_b, h0) for k in range(ns))
+    return sum(ws[off + k * stride:off + k * stride + n_b * h0].view(n_b, h0) for k in range(ns))
 
   def encoder_bias_grad(self):
     """gb_en of the last training step (tests): the one-call step leaves it as row-segment

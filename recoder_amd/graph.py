@@ -94,30 +94,31 @@ class GraphStepper:
     != None: an eager step that bench.py's time plan may bracket; advance: the group's last step
     publishes the other slot's cursor."""
     replay = dict(st=self.st[slot][g], cursor=self._cur(slot), off=g, table=ptr(self.table),
-                  users=ptr(self.order), timed=index is not None, index=index,
+                  users=ptr(self.order), timed=index is not None, index=index, dw_stream=self.side,
                   next=None if advance is None else (self._cur(1 - slot), advance))
     self.eng._c_train_step(self.blocks[slot][g], 0, self.B, None, self.loss_buf, None, self.main,
                            replay=replay)
 
-  def _group(self, slot, n_steps=None, first_index=None, steps_first=False):
+  def _group(self, slot, n_steps=None, first_index=None):
     """One group on slot `slot`: its steps on the main stream, the collation of the NEXT group's
     blocks on the side stream, the cursor advance.  Called inside a capture or eagerly."""
     lib, G = self.lib, self.G
     n_steps = G if n_steps is None else n_steps
     check(lib.rk_event_record(self.ev_fork, self._h(self.main)), "rk_event_record")
     check(lib.rk_stream_wait_event(self._h(self.side), self.ev_fork), "rk_stream_wait_event")
-    # the order of the two branches inside a capture decides which one the graph keeps on the
-    # launching stream's queue: with the steps captured first the training chain stays on one
-    # hardware queue from launch to launch (11 us between groups; with the collation first it moved
-    # to another queue every launch, 28-31 us).  Eagerly the side work is enqueued first.
-    if not steps_first:
-      for g in range(G):
-        self._collate(self.blocks[1 - slot][g], n_steps + g, self.side, slot)
-    for g in range(n_steps):
-      self._step(slot, g, None if first_index is None else first_index + g,
-                 advance=n_steps if g == n_steps - 1 else None)
-    if steps_first:
-      for g in range(G):
+    # ONE side stream carries both kinds of side work, interleaved: the dW kernel of step g (the
+    # engine enqueues it there behind the step's decode, engine.dw_branch) and then the collation of
+    # block g of the next group -- dW(g) is needed by the Adam sweep of step g, the collation only
+    # at the end of the group, and a third concurrent branch ends up behind one of the others on
+    # the same hardware queue.  The order of the branches inside a capture decides which one the
+    # graph keeps on the launching stream's queue: with step 0 captured first the training chain
+    # stays on one hardware queue from launch to launch (11 us between groups; with the collation
+    # first it moved to another queue every launch, 28-31 us).
+    for g in range(max(n_steps, G)):
+      if g < n_steps:
+        self._step(slot, g, None if first_index is None else first_index + g,
+                   advance=n_steps if g == n_steps - 1 else None)
+      if g < G:
         self._collate(self.blocks[1 - slot][g], n_steps + g, self.side, slot)
     check(lib.rk_event_record(self.ev_join, self._h(self.side)), "rk_event_record")
     check(lib.rk_stream_wait_event(self._h(self.main), self.ev_join), "rk_stream_wait_event")
@@ -230,9 +231,9 @@ class GraphStepper:
     G = self.G
     for v in (0, 1):
       if self.exec[v] is None:
-        self.exec[v] = self._capture(lambda v=v: self._group(v, steps_first=True))
+        self.exec[v] = self._capture(lambda v=v: self._group(v))
     if self.exec_first is None:
-      self.exec_first = self._capture(lambda: (self._pre_collate(G), self._group(0, steps_first=True)))
+      self.exec_first = self._capture(lambda: (self._pre_collate(G), self._group(0)))
 
   def cut(self):
     """Forget the look-ahead blocks (a step mark / an eager ragged step follows)."""
