@@ -326,7 +326,13 @@ def main():
         ent = json.load(open(files[-1]))["entries"].get(dominant)
         if ent:
           traffic = ent["hbm_bytes_per_launch"]
-    chain_us = sum(k["avg_us"] for k in kernels)
+    # the dW launch group runs on the side stream NEXT to dZ -> encoder backward
+    # (rk_ae_step_t.dw_stream): it is not a link of the step's chain then
+    side = ["rk_decode_bwd_dw"] if (getattr(eng, "ws_dw", None) is not None and not multi) else []
+    for k in kernels:
+      if k["name"] in side:
+        k["concurrent_with"] = ["rk_decode_bwd_dz", "rk_ae_encode_bwd"]
+    chain_us = sum(k["avg_us"] for k in kernels if k["name"] not in side)
     ideal_us = sum(k["ideal_us"] for k in kernels)
     roofline = dict(bound=dom["bound"], achieved=dom["achieved"], peak=dom["peak"], unit=dom["unit"],
                     frac=dom["frac"], traffic=traffic, kernel=dominant, kernel_names=dom["kernels"],
