@@ -52,7 +52,7 @@ KERNELS = {"rk_ae_encode_fwd": ["ae_encode_fwd_kernel"],
            "rk_decode_loss": ["gemm_kernel<2,2,1,2,0,0,EPI_LOSS,..,PREC_H3>"],
            "rk_decode_bwd_dz": ["gemm_kernel<4,1,1,4,0,1,EPI_SPLITK,..,PREC_H3>", "splitk_reduce_kernel"],
            "rk_decode_bwd_dw": ["split_planes_t_kernel", "dw3_kernel"],
-           "rk_ae_encode_bwd": ["ae_encode_bwd_kernel"],
+           "rk_ae_encode_bwd": ["ae_encode_bwd_cols_kernel", "ae_encode_bwd_kernel"],
            "rk_adam_multi": ["adam_multi_kernel"]}
 
 CONFIGS = {
