@@ -282,16 +282,25 @@ def main():
       lo, hi = shard_range(n_users, rank, world)
       shard = csr[lo:hi]
     nbs, nnzs = [], []
-    for i in range(W, min(W + K, W + 50)):
+    for i in range(W, min(W + K, W + (50 if not multi else 10))):
       ep, k = 1 + i // steps_per_epoch, i % steps_per_epoch
       if ep not in orders:
         continue
       rows = shard[orders[ep][k * B:(k + 1) * B]]
       nnzs.append(rows.nnz)
-      nbs.append(len(np.unique(rows.indices)))
+      items = np.unique(rows.indices)
+      if multi:
+        # every rank works on the UNION item set of the global batch (users-DP: the all-reduced
+        # stamps): rebuild the other ranks' batches from their seeded orders
+        from recoder_amd.parallel import shard_range
+        for r in range(world):
+          if r == rank:
+            continue
+          lo_r, hi_r = shard_range(n_users, r, world)
+          o_r = np.random.RandomState(100 + 1000 * ep + r).permutation(hi_r - lo_r)[k * B:(k + 1) * B]
+          items = np.union1d(items, np.unique(csr[lo_r:hi_r][o_r].indices))
+      nbs.append(len(items))
     n_b, nnz = float(np.mean(nbs)), float(np.mean(nnzs))
-    if multi:
-      n_b = float("nan")          # the union item set over the ranks is larger than one shard's
     ev_over = eng.event_pair_overhead_ms()
     timed = eng.timed_samples_ms()
 
@@ -364,7 +373,11 @@ def main():
     }
     if world == 1 and not multi and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline(cfg, csr, args.cpu_steps)
-    print(json.dumps(out))
+    # (RCCL writes its version banner through C stdio, which is fully buffered on a pipe and would
+    # come out AFTER this line at exit: flush it first, so that the JSON is the last line)
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps(out), flush=True)
   if multi:
     dist.destroy_process_group()
 
