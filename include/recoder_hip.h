@@ -474,7 +474,8 @@ int rk_collate_at(const int64_t *ds_indptr, const int32_t *ds_indices, const flo
 int rk_cursor_set(int64_t *cursor, int64_t step, int64_t epoch_base, void *stream);
 int rk_cursor_advance(int64_t *cursor, int64_t n, void *stream);
 int rk_adam_consts(double lr, double beta1, double beta2, double eps, double weight_decay,
-                   int32_t step, float *out8_host);
+                   int32_t step, int32_t n_steps, int32_t stride_floats, float *out_host);
+/* (entries of steps step .. step + n_steps - 1, 8 floats each, stride_floats apart) */
 int rk_graph_begin(void *stream);
 void *rk_graph_end(void *stream);              /* -> executable graph handle, NULL on error */
 int rk_graph_launch(void *graph_exec, void *stream);

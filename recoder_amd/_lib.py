@@ -160,7 +160,8 @@ SIGNATURES = {
   "rk_collate_at": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, c_int32, _BLK, _P]),
   "rk_cursor_set": (c_int32, [_P, c_int64, c_int64, _P]),
   "rk_cursor_advance": (c_int32, [_P, c_int64, _P]),
-  "rk_adam_consts": (c_int32, [c_double, c_double, c_double, c_double, c_double, c_int32, _P]),
+  "rk_adam_consts": (c_int32, [c_double, c_double, c_double, c_double, c_double, c_int32, c_int32,
+                               c_int32, _P]),
   "rk_graph_begin": (c_int32, [_P]),
   "rk_graph_end": (c_void_p, [_P]),
   "rk_graph_launch": (c_int32, [_P, _P]),

@@ -533,11 +533,14 @@ extern "C" int rk_adam_multi(const rk_adam_job_t *jobs, int32_t n_jobs, float *l
 // one entry of the per-step constants table (8 floats): exactly what rk_adam_multi derives from
 // the same hyper-parameters for step `step`
 extern "C" int rk_adam_consts(double lr, double beta1, double beta2, double eps, double weight_decay,
-                              int32_t step, float *out8) {
-  RK_REQUIRE(step >= 1 && out8 != nullptr, "step >= 1, out8 != NULL");
+                              int32_t step, int32_t n_steps, int32_t stride_floats, float *out) {
+  RK_REQUIRE(step >= 1 && n_steps >= 0 && out != nullptr && (n_steps <= 1 || stride_floats >= 8),
+             "step >= 1, out != NULL, stride >= 8 floats");
   static_assert(sizeof(AdamC) == 32, "AdamC is 8 floats");
-  const AdamC c = make_consts(lr, beta1, beta2, eps, weight_decay, step);
-  memcpy(out8, &c, sizeof(c));
+  for (int i = 0; i < n_steps; ++i) {
+    const AdamC c = make_consts(lr, beta1, beta2, eps, weight_decay, step + i);
+    memcpy(out + (int64_t)i * stride_floats, &c, sizeof(c));
+  }
   return 0;
 }
 

@@ -158,19 +158,17 @@ class GraphStepper:
     self.order[:n].copy_(torch.from_numpy(np.ascontiguousarray(order_np, dtype=np.int64)), non_blocking=False)
     # Adam constants of every step of the epoch (exactly what rk_adam_multi derives itself)
     th = self.table_host
-    buf = (ctypes.c_float * 8)()
     S = self.eng.states
     tied = bool(self.eng.model.is_constrained)
-    arr = th.numpy().reshape(-1, 4, 8)
     for k, name in _PAR_NAMES.items():
       if k == PAR_W_DE and tied:
         continue
       s = S[name]
       lr, b1, b2, eps = self.eng._adam_args(s)
       wd = 0.0 if s.sparse else float(s.wd)
-      for i in range(n_full + self.G):
-        check(self.lib.rk_adam_consts(lr, b1, b2, eps, wd, s.step + i + 1, buf), "rk_adam_consts")
-        arr[i, k, :] = np.frombuffer(buf, dtype=np.float32)
+      # entry (step i of the epoch, parameter k) at float offset (i * 4 + k) * 8
+      check(self.lib.rk_adam_consts(lr, b1, b2, eps, wd, s.step + 1, n_full + self.G, 4 * 8,
+                                    th.data_ptr() + k * 8 * 4), "rk_adam_consts")
     self.table.copy_(th, non_blocking=False)
     self.global_step = int(global_step)
     self.epoch_base = int(global_step)
