@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void collate_count_kernel(
 __global__ __launch_bounds__(256) void collate_assign_kernel(
     const int32_t *__restrict__ mark, int n_items, int32_t stamp, int all,
     const int32_t *__restrict__ scan_tmp, int n_chunks, int32_t *__restrict__ pos,
-    int32_t *__restrict__ items, int32_t *__restrict__ counts, rk_cur_t cur) {
+    int32_t *__restrict__ items, int32_t *__restrict__ counts, int n_cap, rk_cur_t cur) {
   __shared__ int32_t red[4];
   if (cur.cursor) stamp = rk_cur_stamp(cur);
   __shared__ int32_t wsum[4];
@@ -125,9 +125,12 @@ __global__ __launch_bounds__(256) void collate_assign_kernel(
   const int32_t base_cnt = red[0] + red[1] + red[2] + red[3];
   __syncthreads();
   if (blockIdx.x == (unsigned)(n_chunks - 1) && tid == 0) {
-    const int32_t n_b = base_cnt + scan_tmp[blockIdx.x];
+    // a block smaller than its item set (never by construction: recoder_amd sizes n_cap from the
+    // dataset) is truncated IN BOUNDS and flagged in counts[5] -- the host raises on it
+    const int32_t n_all = base_cnt + scan_tmp[blockIdx.x], n_b = min(n_all, n_cap);
     counts[0] = n_b;
     counts[2] = (n_b + 31) & ~31;
+    counts[5] = n_all > n_cap ? n_all : 0;
   }
   const int it0 = blockIdx.x * RK_SCAN_CHUNK + tid * 8;
   int32_t f[8];
@@ -153,7 +156,12 @@ __global__ __launch_bounds__(256) void collate_assign_kernel(
   for (int k = 0; k < 8; ++k) {
     const int it = it0 + k;
     if (it < n_items) {
-      if (f[k]) { pos[it] = p; items[p] = it; ++p; } else { pos[it] = -1; }
+      if (f[k]) {
+        if (p < n_cap) { pos[it] = p; items[p] = it; } else { pos[it] = -1; }
+        ++p;
+      } else {
+        pos[it] = -1;
+      }
     }
   }
 }
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(256) void collate_assign_kernel(
 __global__ __launch_bounds__(1024) void collate_scan_small_kernel(
     const int32_t *__restrict__ mark, int n_items, int32_t stamp, int all,
     int32_t *__restrict__ pos, int32_t *__restrict__ items, int32_t *__restrict__ counts,
-    rk_cur_t cur) {
+    int n_cap, rk_cur_t cur) {
   __shared__ int32_t wsum[16];
   __shared__ int32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -195,7 +203,12 @@ __global__ __launch_bounds__(1024) void collate_scan_small_kernel(
     for (int k = 0; k < 4; ++k) {
       const int it = it0 + k;
       if (it < n_items) {
-        if (f[k]) { pos[it] = p; items[p] = it; ++p; } else { pos[it] = -1; }
+        if (f[k]) {
+          if (p < n_cap) { pos[it] = p; items[p] = it; } else { pos[it] = -1; }
+          ++p;
+        } else {
+          pos[it] = -1;
+        }
       }
     }
     __syncthreads();
@@ -203,8 +216,10 @@ __global__ __launch_bounds__(1024) void collate_scan_small_kernel(
     __syncthreads();
   }
   if (tid == 0) {
-    counts[0] = carry_s;
-    counts[2] = (carry_s + 31) & ~31;
+    const int32_t n_b = min(carry_s, n_cap);        // (see collate_assign_kernel)
+    counts[0] = n_b;
+    counts[2] = (n_b + 31) & ~31;
+    counts[5] = carry_s > n_cap ? carry_s : 0;
   }
 }
 
@@ -227,11 +242,11 @@ __global__ __launch_bounds__(256) void collate_build_kernel(
   const int wr = (b.counts[0] + 31) >> 5;          // bitmap words in use
   for (int k = lane; k < n; k += 64) {
     const int32_t gi = ds_indices[beg + k];
-    const int32_t c = b.pos[gi];
-    b.cols[out0 + k] = c;
+    const int32_t c = b.pos[gi];            // (< 0 only in a truncated block, counts[5] != 0)
+    b.cols[out0 + k] = max(c, 0);
     if (b.gcols) b.gcols[out0 + k] = gi;
-    b.vals[out0 + k] = ds_data ? ds_data[beg + k] : 1.0f;
-    if (b.bits_cr) atomicOr(&b.bits_cr[(int64_t)c * b.ldw_cr + (row >> 5)], 1u << (row & 31));
+    b.vals[out0 + k] = c < 0 ? 0.0f : (ds_data ? ds_data[beg + k] : 1.0f);
+    if (b.bits_cr && c >= 0) atomicOr(&b.bits_cr[(int64_t)c * b.ldw_cr + (row >> 5)], 1u << (row & 31));
   }
   uint32_t *wb = wbits[wid];
   uint32_t *bits = b.bits_rc + (int64_t)row * b.ldw_rc;
@@ -244,7 +259,7 @@ __global__ __launch_bounds__(256) void collate_build_kernel(
     for (int k = lane; k < n; k += 64) {
       const int32_t c = b.pos[ds_indices[beg + k]];
       const int w = (c >> 5) - w0;
-      if (w >= 0 && w < nw) atomicOr(&wb[w], 1u << (c & 31));
+      if (c >= 0 && w >= 0 && w < nw) atomicOr(&wb[w], 1u << (c & 31));
     }
     __builtin_amdgcn_wave_barrier();
     for (int wq = 0; wq < nw; wq += 64) {
@@ -323,7 +338,7 @@ static int collate_impl(const int64_t *ds_indptr, const int32_t *ds_indices,
   if (phase == 1) return 0;
   if (blk->n_items <= SMALL_SCAN_MAX) {
     RK_LAUNCH(collate_scan_small_kernel, dim3(1), dim3(1024), 0, stream, blk->mark,
-                       blk->n_items, stamp, all, blk->pos, blk->items, blk->counts, cur);
+                       blk->n_items, stamp, all, blk->pos, blk->items, blk->counts, blk->n_cap, cur);
     RK_CHECK_LAUNCH("collate_scan_small");
   } else {
     RK_LAUNCH(collate_count_kernel, dim3(blk->n_chunks), dim3(256), 0, stream,
@@ -331,7 +346,7 @@ static int collate_impl(const int64_t *ds_indptr, const int32_t *ds_indices,
     RK_CHECK_LAUNCH("collate_count");
     RK_LAUNCH(collate_assign_kernel, dim3(blk->n_chunks), dim3(256), 0, stream,
                        blk->mark, blk->n_items, stamp, all, blk->scan_tmp, blk->n_chunks,
-                       blk->pos, blk->items, blk->counts, cur);
+                       blk->pos, blk->items, blk->counts, blk->n_cap, cur);
     RK_CHECK_LAUNCH("collate_assign");
   }
   RK_LAUNCH(collate_build_kernel, dim3(rk_cdiv(S, 4)), dim3(256), 0, stream,

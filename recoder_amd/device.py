@@ -218,7 +218,21 @@ class Block:
   # ---- host views (synchronising; tests / API compatibility only) ----
   def counts_host(self):
     c = self.counts.cpu().numpy()
+    self._raise_if_truncated(int(c[5]))
     return int(c[0]), int(c[1]), int(c[2]), int(c[3])
+
+  def _raise_if_truncated(self, n_all):
+    if n_all:
+      from ._lib import RecoderHipError
+      raise RecoderHipError("a collated block held %d distinct items but was sized for %d (rk_collate "
+                            "truncated it in bounds; everything computed from it is wrong)"
+                            % (n_all, self.n_cap))
+
+  def check(self):
+    """Raise if the last collation into this block overflowed its item capacity (counts[5]: the
+    device clamps in bounds and leaves the true count there).  One 4-byte read-back: call it where
+    the stream is drained anyway (the end of an epoch)."""
+    self._raise_if_truncated(int(self.counts[5].item()))
 
   def to_host(self):
     n_b, nnz, ld, S = self.counts_host()

@@ -629,6 +629,11 @@ class Recoder(object):
                  eval_num_recommendations, eval_batch_size, eval_num_users, model_checkpoint_prefix,
                  checkpoint_freq):
     """model.py:406-437: the epoch's log line, validation / evaluation, checkpoint."""
+    # (the stream is drained here: the one place where the blocks' overflow flags are read back)
+    for holder in (getattr(self, "_train_pf", None), getattr(self, "_graph_stepper", None)):
+      if holder is not None:
+        for blk in (b for row in holder.blocks for b in row):
+          blk.check()
     self.loss_history.append(self.last_epoch_losses)
     if n_done and not np.all(np.isfinite(self.last_epoch_losses)):
       # the reference keeps training on a NaN loss too (the split-fp16 decoder GEMMs take their

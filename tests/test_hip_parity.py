@@ -84,6 +84,39 @@ def test_collate_bit_exact(n_users, n_items, S, ns):
     assert np.array_equal(got_t, dense.T)
 
 
+@pytest.mark.parametrize("n_items", [300, 40000])        # one-workgroup scan / chunked scan
+def test_collate_overflow_is_clamped_in_bounds_and_raises(n_items):
+  """A block sized below its item set (never by construction): rk_collate truncates
+  in bounds, leaves the true count in counts[5], and the host raises when it looks."""
+  from recoder_amd._lib import RecoderHipError
+  from recoder_amd.device import Block, DeviceCSR
+  csr = synth_csr(200, n_items, 12, seed=3, ratings=True)
+  dcsr = DeviceCSR(csr)
+  S = 64
+  users = np.arange(S, dtype=np.int64)
+  ref = orc.collate(orc.extract_rows(csr, users), users, S, True)[0]
+  n_true = len(ref.items)
+  nnz_cap = int(np.sort(np.diff(csr.indptr))[-S:].sum())
+  blk = Block(S, nnz_cap, n_items, negative_sampling=True, n_cap=n_true - 17)
+  guard = torch.full((4096,), 12345, dtype=torch.int32, device=dev())       # something to trample on
+  blk.collate(dcsr, torch.from_numpy(users).to(dev()))
+  torch.cuda.synchronize()
+  c = blk.counts.cpu().numpy()
+  assert c[0] == n_true - 17 and c[5] == n_true
+  assert np.array_equal(blk.items[:c[0]].cpu().numpy(), ref.items[:c[0]])
+  assert int(blk.cols[:c[1]].min()) >= 0 and int(blk.cols[:c[1]].max()) < c[0]
+  assert bool((guard == 12345).all())
+  with pytest.raises(RecoderHipError):
+    blk.counts_host()
+  with pytest.raises(RecoderHipError):
+    blk.check()
+  # the same rows in a block that is large enough: clean
+  blk2 = Block(S, nnz_cap, n_items, negative_sampling=True)
+  blk2.collate(dcsr, torch.from_numpy(users).to(dev()))
+  assert blk2.counts_host()[0] == n_true
+  blk2.check()
+
+
 def test_batch_collator_api_matches_oracle():
   """The reference-style host API (BatchCollator.collate -> list[Batch])."""
   from recoder_amd.data import BatchCollator, RecommendationDataset
