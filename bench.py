@@ -165,6 +165,11 @@ def main():
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  # test switch (tools/probes/bench_two_ranks_one_gpu.sh): every rank on GPU 0 with the gloo backend,
+  # to run the multi-rank code of this file on a single-GPU box; the line is marked INVALID
+  same_dev = os.environ.get("RK_BENCH_ONE_GPU_GLOO") == "1"
+  if same_dev:
+    local_rank = 0
   assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
   torch.cuda.set_device(local_rank)
   device = torch.device("cuda", local_rank)
@@ -173,7 +178,11 @@ def main():
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if same_dev:
+      os.environ["RK_COMM"] = "torch"
+      dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+      dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
   from recoder_amd.data import RecommendationDataset
   from recoder_amd.model import Recoder
@@ -371,6 +380,8 @@ def main():
                  "steps_per_graph": G},
       "roofline": roofline,
     }
+    if same_dev:
+      out["INVALID"] = "RK_BENCH_ONE_GPU_GLOO: all ranks share one GPU, gloo collectives (a code-path test)"
     if world == 1 and not multi and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline(cfg, csr, args.cpu_steps)
     # (RCCL writes its version banner through C stdio, which is fully buffered on a pipe and would
