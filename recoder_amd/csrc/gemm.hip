@@ -861,21 +861,36 @@ __global__ __launch_bounds__(256) void mnll_finish_kernel(float *dO, rk_block_t 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const bool implicit = b.implicit != 0;
   float *orow = dO + (int64_t)r * ld;
+  // 16-byte accesses throughout (ld is a multiple of 32 floats, the row 16-byte aligned); a lane's
+  // 4 columns lie in one bitmap word.  Columns >= n of the last quad are padding: masked.
+  const float4 *orow4 = reinterpret_cast<const float4 *>(orow);
+  const int n4 = (n + 3) >> 2;
   float mx = -INFINITY, lsum;
   if (ext_max) {
     mx = ext_max[r];
     lsum = ext_logsum[r];
   } else {
-    for (int c = tid; c < n; c += 256) mx = fmaxf(mx, orow[c]);
-    mx = rk_wave_max(mx);
-    if (lane == 0) red[wid] = mx;
+    // ONE pass for the maximum and the sum of exponentials: running maximum, the partial sum is
+    // rescaled when it moves (online softmax); the (max, sum) pairs of the threads are merged the
+    // same way in fixed order
+    float m = -INFINITY, se = 0.f;
+    for (int i = tid; i < n4; i += 256) {
+      float4 x = orow4[i];
+      const int c = i << 2;
+      if (c + 1 >= n) x.y = -INFINITY;
+      if (c + 2 >= n) x.z = -INFINITY;
+      if (c + 3 >= n) x.w = -INFINITY;
+      const float m4 = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
+      if (m4 > m) { se *= expf(m - m4); m = m4; }      // (expf(-inf) = 0 on the first quad)
+      se += (expf(x.x - m) + expf(x.y - m)) + (expf(x.z - m) + expf(x.w - m));
+    }
+    const float wm = __shfl(rk_wave_max(m), 0, 64);      // (the reduction leaves it in lane 0)
+    se = rk_wave_sum(m == -INFINITY ? 0.f : se * expf(m - wm));     // (a thread without columns: 0)
+    if (lane == 0) red[wid] = wm;
     __syncthreads();
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
-    float se = 0.f;
-    for (int c = tid; c < n; c += 256) se += expf(orow[c] - mx);
-    se = rk_wave_sum(se);
-    if (lane == 0) red[wid] = se;
+    if (lane == 0) red[wid] = wm == -INFINITY ? 0.f : se * expf(wm - mx);
     __syncthreads();
     lsum = logf((red[0] + red[1]) + (red[2] + red[3]));
     __syncthreads();
@@ -902,17 +917,25 @@ __global__ __launch_bounds__(256) void mnll_finish_kernel(float *dO, rk_block_t 
   const float sum_g = ext_tsum ? -ext_tsum[r] * inv_B : bc[0];
   float gmax = 0.f;
   // dense part: dO = g - softmax * sum_g,  g = -t*inv_B at stored positions
-  for (int c = tid; c < n; c += 256) {
-    const float e = expf((orow[c] - mx) - lsum);
-    float g = 0.f;
-    const uint32_t word = b.bits_rc[(int64_t)row * b.ldw_rc + (c >> 5)];
-    if ((word >> (c & 31)) & 1u) {
-      const float t = implicit ? 1.0f : b.vals[rk_entry_index(b, row, c, word)];
-      g = -t * inv_B;
+  const uint32_t *brow = b.bits_rc + (int64_t)row * b.ldw_rc;
+  for (int i = tid; i < n4; i += 256) {
+    const float4 x = orow4[i];
+    const int c = i << 2;
+    const uint32_t word = brow[c >> 5];
+    const uint32_t nib = (word >> (c & 31)) & 15u;
+    float xs[4] = {x.x, x.y, x.z, x.w}, go[4];
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+      const float e = expf((xs[e4] - mx) - lsum);
+      float g = 0.f;
+      if ((nib >> e4) & 1u) {
+        const float t = implicit ? 1.0f : b.vals[rk_entry_index(b, row, c + e4, word)];
+        g = -t * inv_B;
+      }
+      go[e4] = (c + e4 < n) ? g - e * sum_g : 0.f;      // (padding columns of the last quad: 0)
+      gmax = fmaxf(gmax, fabsf(go[e4]));
     }
-    const float go = g - e * sum_g;
-    gmax = fmaxf(gmax, fabsf(go));
-    orow[c] = go;
+    reinterpret_cast<float4 *>(orow)[i] = make_float4(go[0], go[1], go[2], go[3]);
   }
   // running max |dLoss/dLogit| of the block, as the MSE / BCE epilogue publishes it
   gmax = rk_wave_max(gmax);
