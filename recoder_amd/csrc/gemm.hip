@@ -1257,7 +1257,10 @@ extern "C" int rk_decode_bwd_dz(const float *dO, int32_t B, int32_t h, const rk_
   // split-fp16: 128-column tiles up to h = 256 (two resident workgroups per CU at 74 KB of LDS;
   // the 224-wide tile of the fp32 path needs 101 KB here: 29 vs 31 us at C2, 52 vs 57 us on an
   // 8-way item shard, although dO is then split once per column tile)
-  const int tn = use_h3() ? (h <= 64 ? 2 : (h <= 256 ? 4 : 8))
+  // (long contractions -- a 1 M-item catalogue, K ~ 50 k -- run many k-tiles per workgroup: there
+  // the 128-column tile with two resident workgroups beats the 256-column one with a single one,
+  // 0.855 vs 0.912 ms per C5-shaped step)
+  const int tn = use_h3() ? (h <= 64 ? 2 : ((h <= 256 || tgt->n_cap >= 32768) ? 4 : 8))
                           : (h <= 64 ? 2 : (h <= 128 ? 4 : (h <= 224 ? 7 : 8)));
   p.tiles_m = rk_cdiv(B, 128);
   const int tiles = p.tiles_m * rk_cdiv(h, 32 * tn);   // x 64 splits: a multiple of 8
