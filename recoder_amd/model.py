@@ -833,7 +833,13 @@ class Recoder(object):
   eval_strip_items = int(os.environ.get("RK_EVAL_STRIP", "65536"))
 
   def recommend(self, users_interactions, num_recommendations):
-    """model.py:525-544: scores with the seen (positive) items at -inf, top-k sorted.
+    """model.py:525-544: scores with the seen (positive) items at -inf, top-k sorted; a list of
+    lists like the reference's (``recommend_array``: the same as one [users, k] int64 array)."""
+    return self.recommend_array(users_interactions, num_recommendations).tolist()
+
+  def recommend_array(self, users_interactions, num_recommendations):
+    """recommend() as a numpy array (what the evaluator consumes: 50 k Python ints per batch of
+    500 users cost more than scoring them).
 
     The fused engines never materialise the [B, n_items] score matrix: the catalogue is decoded
     in strips of ``eval_strip_items`` items, each strip's masked top k is kept
@@ -881,13 +887,13 @@ class Recoder(object):
                                           cand_idx[:, s * k:].data_ptr(), cand_val[:, s * k:].data_ptr(),
                                           ns * k, current_stream()), "rk_topk_masked_strip")
     if ns == 1:
-      return cand_idx[:, :k].cpu().tolist()
+      return cand_idx[:, :k].cpu().numpy().copy()
     # merge: top k of the ns * k candidates (positions), then their item ids.  Candidates are laid
     # out strip by strip, each sorted by (score desc, id asc): equal scores keep ascending ids
     pos = torch.empty(B, k, dtype=torch.int64, device=self.device)
     _lib.check(lib.rk_topk_masked(cand_val.data_ptr(), B, ns * k, ns * k, None, 0, k, pos.data_ptr(),
                                   None, current_stream()), "rk_topk_masked")
-    return torch.gather(cand_idx, 1, pos).cpu().tolist()
+    return torch.gather(cand_idx, 1, pos).cpu().numpy()
 
   def _recommend_dense(self, users_interactions, k):
     """Full score matrix + torch.topk: the generic (torch-autograd) engine and k above the
@@ -895,7 +901,7 @@ class Recoder(object):
     out, dense = self.predict(users_interactions, return_input=True)
     out = out.clone()
     out[dense > 0] = -float("inf")
-    return torch.topk(out, k, dim=1, sorted=True)[1].cpu().tolist()
+    return torch.topk(out, k, dim=1, sorted=True)[1].cpu().numpy()
 
   def evaluate(self, eval_dataset, num_recommendations, metrics, batch_size=1, num_users=None):
     """model.py:546-559."""

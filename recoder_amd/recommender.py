@@ -17,3 +17,7 @@ class InferenceRecommender(Recommender):
 
   def recommend(self, users_hist):
     return self.model.recommend(users_hist, self.num_recommendations)
+
+  def recommend_array(self, users_hist):
+    """The same lists as one [users, k] integer array (metrics.RecommenderEvaluator's fast path)."""
+    return self.model.recommend_array(users_hist, self.num_recommendations)

@@ -108,3 +108,41 @@ def test_recoder_error_behaviour_before_any_kernel():
   from recoder_amd.data import RecommendationDataset
   with pytest.raises(AssertionError):
     Recoder(m, optimizer_type="adam").train(RecommendationDataset(csr), batch_size=4, num_sampling_users=6)
+
+
+def test_batch_metrics_equal_the_per_user_functions():
+  """metrics.batch_metrics (what RecommenderEvaluator uses for the built-in metrics) against the
+  per-user functions of the reference's arithmetic, incl. users without targets (nan), k beyond the
+  list length, zero-valued stored entries, un-normalised variants; a user-defined metric or ragged
+  lists fall back to the per-user loop."""
+  import scipy.sparse as sp
+  from recoder_amd import metrics as M
+  rng = np.random.RandomState(0)
+  B, n_items, K = 57, 300, 25
+  recs = np.stack([rng.permutation(n_items)[:K] for _ in range(B)])
+  dens = rng.rand(B, n_items) < 0.06
+  dens[5] = False                                   # a user without targets
+  vals = np.where(dens, rng.choice([0.0, 1.0, 3.0], size=dens.shape, p=[0.1, 0.6, 0.3]), 0.0)
+  tm = sp.csr_matrix(vals)
+  tm_explicit_zeros = sp.csr_matrix((np.where(dens, vals, 0.0)[dens], np.nonzero(dens)), shape=dens.shape)
+  ms = [M.Recall(20), M.Recall(5, normalize=False), M.NDCG(10), M.NDCG(100), M.AveragePrecision(20),
+        M.AveragePrecision(7, normalize=False)]
+  for t in (tm, tm_explicit_zeros):
+    got = M.batch_metrics(recs.tolist(), t, ms)
+    assert got is not None
+    t = t.tocsr()
+    with np.errstate(divide="ignore", invalid="ignore"):
+      for i in range(B):
+        lo, hi = t.indptr[i], t.indptr[i + 1]
+        y = t.indices[lo:hi][t.data[lo:hi] != 0]
+        for m in ms:
+          want = m.evaluate(recs[i], y)
+          have = got[m][i]
+          assert (np.isnan(want) and np.isnan(have)) or abs(want - have) < 1e-12, (str(m), i, want, have)
+
+  class Mine(M.Metric):
+    def evaluate(self, x, y):
+      return 1.0
+  assert M.batch_metrics(recs.tolist(), tm, [M.Recall(5), Mine("mine")]) is None
+  ragged = [list(r[:K - (i % 2)]) for i, r in enumerate(recs)]
+  assert M.batch_metrics(ragged, tm, [M.Recall(5)]) is None
