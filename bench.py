@@ -151,6 +151,54 @@ def cpu_baseline(cfg, csr, steps, warmup=4):
                      % (done // B, B, warmup, dt, max_seconds))
 
 
+def alt_item_parallel(cfg, csr, B, W, K, world, rank, device, sync_all):
+  """The same workload with the ITEM dimension sharded (RK_PARALLEL=items): W warm-up + K timed steps
+  of B users per rank through Recoder.train, timed like the main run (barrier + synchronize on both
+  sides, MAX over the ranks).  Every rank sees the same global user order."""
+  import torch.distributed as dist
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder
+  n_users, n_items = csr.shape
+  prev = os.environ.get("RK_PARALLEL")
+  os.environ["RK_PARALLEL"] = "items"
+  try:
+    torch.manual_seed(0)
+    model = DynamicAutoencoder(hidden_layers=cfg["hidden_layers"], activation_type=cfg["activation_type"],
+                               noise_prob=cfg["noise_prob"], sparse=cfg["sparse"])
+    rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss=cfg["loss"],
+                  num_items=n_items, num_users=n_users)
+    rec.user_order_hook = lambda epoch, n: np.random.RandomState(7 + epoch).permutation(n).astype(np.int64)
+    steps_per_epoch = max(1, n_users // (B * world))
+    epochs = -(-(W + K) // steps_per_epoch) + 1
+    T = {}
+
+    def start():
+      sync_all()
+      T["t0"] = time.perf_counter()
+      return False
+
+    def stop():
+      sync_all()
+      T["dt"] = time.perf_counter() - T["t0"]
+      return True
+    rec.step_marks = {W: start, W + K: stop}
+    rec.train(RecommendationDataset(csr), batch_size=B, lr=cfg["lr"], weight_decay=cfg["weight_decay"],
+              num_epochs=epochs, negative_sampling=True)
+    t = torch.tensor([T["dt"]], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    assert rec._ip is not None, "item-parallel mode was not taken"
+    return {"parallelism": "ip%d (items sharded, two [N*B, h] all-reduces per step)" % world,
+            "value": K * B * world / dt, "unit": "users/s", "ms_per_step": dt / K * 1e3, "steps": K,
+            "warmup": W}
+  finally:
+    if prev is None:
+      os.environ.pop("RK_PARALLEL", None)
+    else:
+      os.environ["RK_PARALLEL"] = prev
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -283,6 +331,16 @@ def main():
   global_rows = B * world if multi else B
   value = K * global_rows / dt              # users consumed by all ranks per second
 
+  # multi-GPU runs: the OTHER exact formulation (item parallel) timed the same
+  # way right behind the graded one, reported inside the same JSON line (config.alt_item_parallel)
+  alt = None
+  if multi and (world > 1 or os.environ.get("RK_BENCH_ALT") == "1") and os.environ.get("RK_BENCH_ALT") != "0" \
+      and os.environ.get("RK_PARALLEL", "users") in ("users", "auto"):
+    try:
+      alt = alt_item_parallel(cfg, csr, B, W, K, world, rank, device, sync_all)
+    except Exception as e:          # noqa: BLE001 -- never lose the graded line to the extra one
+      alt = {"error": "%s: %s" % (type(e).__name__, e)}
+
   if rank == 0:
     # per-step n_b / nnz of (up to 50 of) the timed steps: host recomputation, outside the timing
     shard = csr
@@ -377,7 +435,7 @@ def main():
                  "first_loss": float(losses[0]), "last_loss": float(losses[-1]),
                  "host_enqueue_ms_per_step": T["enqueue"] / K * 1e3,
                  "graph_replay": bool(getattr(rec, "_graph_stepper", None) is not None),
-                 "steps_per_graph": G},
+                 "steps_per_graph": G, "alt_item_parallel": alt},
       "roofline": roofline,
     }
     if same_dev:
