@@ -136,6 +136,9 @@ class FusedEngine:
     if B_cap <= self.B_cap and n_cap <= self.n_cap:
       return
     B_cap, n_cap = max(B_cap, self.B_cap), max(n_cap, self.n_cap)
+    # every workspace below is re-allocated: captured HIP graphs hold the old addresses
+    # (graph.GraphStepper compares this counter and re-captures)
+    self.alloc_gen = getattr(self, "alloc_gen", 0) + 1
     dev = self.device
     f = dict(dtype=torch.float32, device=dev)
     h0 = self.h[0]
@@ -199,6 +202,7 @@ class FusedEngine:
     (so ``optimizer.state_dict()`` has the reference layout, model.py:210)."""
     self.states = {}
     self._w_range_stale = True
+    self.alloc_gen = getattr(self, "alloc_gen", 0) + 1     # (the moment tensors may be new ones)
     names = {id(p): n for n, p in self.model.named_parameters()}
     for opt, is_sparse in ((optimizer, False), (sparse_optimizer, True)):
       if opt is None:

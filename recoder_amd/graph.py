@@ -57,13 +57,16 @@ class GraphStepper:
     self.pre = [torch.cuda.Stream(device=device) for _ in range(self.G - 1)]
     self.ev_pre = [self.lib.rk_event_create() for _ in range(self.G - 1)]
     self.st = [[RkAeStep() for _ in range(self.G)] for _ in range(2)]
+    self._gen = None                       # engine.alloc_gen the graphs were captured under
+    self.recaptures = 0
+    self.regen = True                      # (tests switch it off to show what it protects from)
     self.exec = [None, None]
     self.exec_first = None                 # the group right behind a cut: its collation + slot 0's group
     self.warmed = False
     self.global_step = 0                   # steps this stepper's cursor has seen
     self.epoch_base = 0
 
-  def close(self):
+  def _drop_graphs(self):
     for e in self.exec:
       if e:
         self.lib.rk_graph_destroy(e)
@@ -71,6 +74,10 @@ class GraphStepper:
     if self.exec_first:
       self.lib.rk_graph_destroy(self.exec_first)
       self.exec_first = None
+    self.warmed = False
+
+  def close(self):
+    self._drop_graphs()
     for e in [self.ev_fork, self.ev_join] + self.ev_pre:
       self.lib.rk_event_destroy(e)
 
@@ -181,6 +188,13 @@ class GraphStepper:
     lib, G = self.lib, self.G
     if n_steps <= 0:
       return
+    if self.warmed and self._gen != getattr(self.eng, "alloc_gen", 0) and self.regen:
+      # the engine re-allocated its workspaces since the capture (an evaluation with a larger batch
+      # or item strip between two epochs, a loaded optimizer state): the graphs hold dead
+      # addresses -- drop them; the next group runs eagerly and they are captured again
+      torch.cuda.current_stream().synchronize()
+      self._drop_graphs()
+      self.recaptures += 1
     slot = 0
     need_pre = self._collated is None
     if need_pre:
@@ -226,6 +240,7 @@ class GraphStepper:
     if self.warmed:
       return
     self.warmed = True
+    self._gen = getattr(self.eng, "alloc_gen", 0)
     G = self.G
     for v in (0, 1):
       if self.exec[v] is None:

@@ -957,6 +957,41 @@ def test_graph_replay_is_bitwise_equal_to_eager_steps(case, monkeypatch):
     assert a0[k][0] == a1[k][0] and torch.equal(a0[k][1], a1[k][1]), k
 
 
+def test_graph_replay_survives_workspace_growth_between_epochs(monkeypatch):
+  """Validation / evaluation between two epochs with a LARGER batch and the whole catalogue as the
+  item strip make the engine re-allocate its workspaces; the captured graphs hold the old
+  addresses and must be dropped and captured again (GraphStepper.recaptures) -- results stay
+  bit-identical to the eager run."""
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.metrics import Recall
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder
+  csr = synth_csr(1100, 6000, 6, seed=37)           # few interactions per row: n_cap << n_items
+  val = synth_csr(400, 6000, 6, seed=38)
+  orders = [np.random.RandomState(50 + e).permutation(csr.shape[0]).astype(np.int64) for e in range(5)]
+
+  def run(graph):
+    monkeypatch.setenv("RK_GRAPH", "1" if graph else "0")
+    torch.manual_seed(29)
+    model = DynamicAutoencoder([32], activation_type="tanh", noise_prob=0.2, sparse=False)
+    rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss="mse")
+    rec.user_order_hook = lambda epoch, n: orders[epoch] if n == csr.shape[0] else None
+    rec.train(RecommendationDataset(csr), val_dataset=RecommendationDataset(val, val), batch_size=64,
+              lr=1e-3, weight_decay=1e-5, num_epochs=3, negative_sampling=True, eval_freq=1,
+              metrics=[Recall(5)], eval_num_recommendations=5, eval_batch_size=300)
+    gs = getattr(rec, "_graph_stepper", None)
+    assert (gs is not None) == graph
+    if graph:
+      assert gs.recaptures >= 1, "the evaluation was expected to grow the engine's workspaces"
+    return (np.concatenate(rec.loss_history),
+            {k: v.detach().cpu().clone() for k, v in model.named_parameters()})
+  l0, p0 = run(False)
+  l1, p1 = run(True)
+  assert np.array_equal(l0, l1), np.abs(l0 - l1).max()
+  for k in p0:
+    assert torch.equal(p0[k], p1[k]), k
+
+
 def test_topk_tie_rule_and_strip_merge():
   """rk_topk_masked: exact ties resolve to the LOWER item id; only POSITIVE stored interactions are
   masked (model.py:537); the strip-wise top-k + merge equals the one-pass top-k."""
