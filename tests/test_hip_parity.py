@@ -911,7 +911,8 @@ def test_data_parallel_two_virtual_ranks_equal_single_process(case):
       assert frac < 2e-3, (k, frac, mx, scale)
 
 
-@pytest.mark.parametrize("case", ["dense_noise", "sparse_tied_bce", "logloss"])
+@pytest.mark.parametrize("case", ["dense_noise", "sparse_tied_bce", "logloss", "ratings_all_items",
+                                  "ratings_relu_conf"])
 def test_graph_replay_is_bitwise_equal_to_eager_steps(case, monkeypatch):
   """recoder_amd/graph.py: groups of steps replayed as HIP graphs (users, stamps, RNG step, Adam
   constants and loss slot derived on the device from a cursor) must reproduce the eagerly
@@ -920,8 +921,15 @@ def test_graph_replay_is_bitwise_equal_to_eager_steps(case, monkeypatch):
   from recoder_amd.data import RecommendationDataset
   from recoder_amd.model import Recoder
   from recoder_amd.nn import DynamicAutoencoder
-  csr = synth_csr(1430, 900, 18, seed=31)          # 1430 = 11 x 128 + 22: ragged tail
-  if case == "dense_noise":
+  csr = synth_csr(1430, 900, 18, seed=31, ratings=case.startswith("ratings"))   # 1430 = 11 x 128 + 22: ragged tail
+  ns, loss_params = True, None
+  if case == "ratings_all_items":       # explicit values, NO negative sampling (the block is the catalogue)
+    mk = lambda: DynamicAutoencoder([40], activation_type="tanh", noise_prob=0.2, sparse=False)
+    loss, wd, ns = "mse", 2e-5, False
+  elif case == "ratings_relu_conf":     # explicit values, unbounded activation (rk_amax in the graph)
+    mk = lambda: DynamicAutoencoder([48], activation_type="relu", noise_prob=0.3, sparse=True)
+    loss, wd, loss_params = "mse", 0.0, {"confidence": 3}
+  elif case == "dense_noise":
     mk = lambda: DynamicAutoencoder([64], activation_type="tanh", noise_prob=0.4, sparse=False)
     loss, wd = "mse", 2e-5
   elif case == "sparse_tied_bce":
@@ -937,12 +945,12 @@ def test_graph_replay_is_bitwise_equal_to_eager_steps(case, monkeypatch):
     monkeypatch.setenv("RK_GRAPH", "1" if graph else "0")
     torch.manual_seed(23)
     model = mk()
-    rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss=loss)
+    rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss=loss, loss_params=loss_params)
     rec.user_order_hook = lambda epoch, n: orders[epoch]
     seen = []
     rec.step_marks = {7: lambda: seen.append(7) or False, 18: lambda: seen.append(18) or False}
     rec.train(RecommendationDataset(csr), batch_size=128, lr=1e-3, weight_decay=wd, num_epochs=3,
-              negative_sampling=True, lr_milestones=[2])
+              negative_sampling=ns, lr_milestones=[2])
     assert seen == [7, 18]
     assert (getattr(rec, "_graph_stepper", None) is not None) == graph
     return (np.concatenate(rec.loss_history),
