@@ -1000,6 +1000,54 @@ def test_graph_replay_survives_workspace_growth_between_epochs(monkeypatch):
     assert torch.equal(p0[k], p1[k]), k
 
 
+def test_graph_path_through_a_users_session(monkeypatch, tmp_path):
+  """What a user does with one trainer, on the default (graph replay) path and eagerly: train, evaluate
+  with a larger batch, train on (resume repeats the last epoch, as the reference), checkpoint, load the
+  file into a FRESH trainer and continue there.  Losses and parameters must be bit-identical."""
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.metrics import NDCG, Recall
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder
+  csr = synth_csr(900, 700, 10, seed=41)
+  held = synth_csr(200, 700, 10, seed=42)
+  mk = lambda: DynamicAutoencoder([48], activation_type="tanh", noise_prob=0.0, sparse=False)
+
+  def run(graph):
+    monkeypatch.setenv("RK_GRAPH", "1" if graph else "0")
+    order = lambda epoch, n: np.random.RandomState(60 + epoch).permutation(n).astype(np.int64)
+    kw = dict(batch_size=100, lr=1e-3, weight_decay=1e-5, negative_sampling=True)
+    torch.manual_seed(31)
+    model = mk()
+    rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss="mse")
+    rec.user_order_hook = order
+    ds = RecommendationDataset(csr)
+    rec.train(ds, num_epochs=2, **kw)
+    ev1 = rec.evaluate(RecommendationDataset(held, held), num_recommendations=10,
+                       metrics=[Recall(5), NDCG(10)], batch_size=160)
+    prefix = str(tmp_path / ("g" if graph else "e"))
+    rec.train(ds, num_epochs=4, model_checkpoint_prefix=prefix, checkpoint_freq=4, **kw)
+    losses = np.concatenate(rec.loss_history)
+    torch.manual_seed(99)
+    model2 = mk()
+    rec2 = Recoder(model=model2, use_cuda=True, optimizer_type="adam", loss="mse")
+    rec2.init_from_model_file(prefix + "_epoch_4.model")
+    rec2.user_order_hook = order
+    rec2.train(ds, num_epochs=5, **kw)
+    ev2 = rec2.evaluate(RecommendationDataset(held, held), num_recommendations=10,
+                        metrics=[Recall(5), NDCG(10)], batch_size=50)
+    return (losses, np.concatenate(rec2.loss_history),
+            {k: v.detach().cpu().clone() for k, v in model2.named_parameters()},
+            {str(k): np.asarray(v) for k, v in list(ev1.items()) + list(ev2.items())})
+  e = run(False)
+  g = run(True)
+  assert np.array_equal(e[0], g[0]) and np.array_equal(e[1], g[1])
+  assert len(e[0]) == 9 * 5 and len(e[1]) == 9 * 2        # epochs 1-2, then 2-4; the fresh trainer: 4-5
+  for k in e[2]:
+    assert torch.equal(e[2][k], g[2][k]), k
+  for k in e[3]:
+    assert np.array_equal(e[3][k], g[3][k], equal_nan=True), k
+
+
 def test_topk_tie_rule_and_strip_merge():
   """rk_topk_masked: exact ties resolve to the LOWER item id; only POSITIVE stored interactions are
   masked (model.py:537); the strip-wise top-k + merge equals the one-pass top-k."""
