@@ -61,7 +61,8 @@ class GraphStepper:
     self.recaptures = 0
     self.regen = True                      # (tests switch it off to show what it protects from)
     self.exec = [None, None]
-    self.exec_first = None                 # the group right behind a cut: its collation + slot 0's group
+    self._la_slot = 1                      # slot holding the newest look-ahead blocks
+    self.exec_first = [None, None]         # the group right behind a cut: its collation + its steps, per slot
     self.warmed = False
     self.global_step = 0                   # steps this stepper's cursor has seen
     self.epoch_base = 0
@@ -71,9 +72,10 @@ class GraphStepper:
       if e:
         self.lib.rk_graph_destroy(e)
     self.exec = [None, None]
-    if self.exec_first:
-      self.lib.rk_graph_destroy(self.exec_first)
-      self.exec_first = None
+    for e in self.exec_first:
+      if e:
+        self.lib.rk_graph_destroy(e)
+    self.exec_first = [None, None]
     self.warmed = False
 
   def close(self):
@@ -130,16 +132,16 @@ class GraphStepper:
     check(lib.rk_event_record(self.ev_join, self._h(self.side)), "rk_event_record")
     check(lib.rk_stream_wait_event(self._h(self.main), self.ev_join), "rk_stream_wait_event")
 
-  def _pre_collate(self, n0):
-    """Collate blocks[0][0..n0) side by side: block 0 on the main stream, the others on streams of
-    their own, joined back.  Called inside a capture or eagerly."""
+  def _pre_collate(self, n0, slot):
+    """Collate blocks[slot][0..n0) side by side: block 0 on the main stream, the others on streams
+    of their own, joined back.  Called inside a capture or eagerly."""
     lib = self.lib
     if n0 > 1:
       check(lib.rk_event_record(self.ev_fork, self._h(self.main)), "rk_event_record")
-    self._collate(self.blocks[0][0], 0, self.main, 0)
+    self._collate(self.blocks[slot][0], 0, self.main, slot)
     for g in range(1, n0):
       check(lib.rk_stream_wait_event(self._h(self.pre[g - 1]), self.ev_fork), "rk_stream_wait_event")
-      self._collate(self.blocks[0][g], g, self.pre[g - 1], 0)
+      self._collate(self.blocks[slot][g], g, self.pre[g - 1], slot)
       check(lib.rk_event_record(self.ev_pre[g - 1], self._h(self.pre[g - 1])), "rk_event_record")
     for g in range(1, n0):
       check(lib.rk_stream_wait_event(self._h(self.main), self.ev_pre[g - 1]), "rk_stream_wait_event")
@@ -195,12 +197,15 @@ class GraphStepper:
       torch.cuda.current_stream().synchronize()
       self._drop_graphs()
       self.recaptures += 1
-    slot = 0
     need_pre = self._collated is None
     if need_pre:
-      # nothing of the first group is in flight yet: point slot 0's cursor at it; its blocks are
-      # collated in front of its steps (one graph with them, or eagerly)
-      check(lib.rk_cursor_set(self._cur(0), self.global_step, self.epoch_base, self._h(self.main)),
+      # nothing of the first group is in flight yet: its blocks are collated in front of its steps
+      # (one graph with them, or eagerly).  It restarts on the slot that does NOT hold the stale
+      # look-ahead blocks: those were collated for the same step numbers -- i.e. with the same
+      # stamps (rk_cur_stamp) -- but possibly other users (the padding behind an epoch's last
+      # step), and a block collated twice in a row with one stamp keeps the first set's items.
+      slot = 1 - self._la_slot
+      check(lib.rk_cursor_set(self._cur(slot), self.global_step, self.epoch_base, self._h(self.main)),
             "rk_cursor_set")
     else:
       slot = self._collated
@@ -216,16 +221,16 @@ class GraphStepper:
         # in the warm-up of a benchmark, never inside its timed region
         if eager or not self.warmed:
           if need_pre:
-            self._pre_collate(G)
+            self._pre_collate(G, slot)
           self._group(slot, G, first_index=idx0)
           self._warm_capture()
         else:
-          check(lib.rk_graph_launch(self.exec_first if need_pre else self.exec[slot], self._h(self.main)),
-                "rk_graph_launch")
+          check(lib.rk_graph_launch(self.exec_first[slot] if need_pre else self.exec[slot],
+                                    self._h(self.main)), "rk_graph_launch")
         k = G
       else:
         if need_pre:
-          self._pre_collate(left)
+          self._pre_collate(left, slot)
         self._group(slot, left, first_index=idx0)      # tail: fewer than G steps, eager
         self._warm_capture()
         k = left
@@ -234,6 +239,7 @@ class GraphStepper:
       done += k
       slot = 1 - slot
     self._collated = slot                # the look-ahead blocks of the next group
+    self._la_slot = slot                 # (remembered across cuts / epochs: see the restart above)
 
   def _warm_capture(self):
     """Capture the graphs once every kernel has been launched eagerly (the first steps run)."""
@@ -245,8 +251,9 @@ class GraphStepper:
     for v in (0, 1):
       if self.exec[v] is None:
         self.exec[v] = self._capture(lambda v=v: self._group(v))
-    if self.exec_first is None:
-      self.exec_first = self._capture(lambda: (self._pre_collate(G), self._group(0)))
+    for v in (0, 1):
+      if self.exec_first[v] is None:
+        self.exec_first[v] = self._capture(lambda v=v: (self._pre_collate(G, v), self._group(v)))
 
   def cut(self):
     """Forget the look-ahead blocks (a step mark / an eager ragged step follows)."""

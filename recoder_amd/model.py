@@ -575,6 +575,7 @@ class Recoder(object):
              eval_num_recommendations, iters_per_epoch, eval_num_users, eval_batch_size):
     """model.py:349-437."""
     engine = self._engine()
+    self._order_ahead = None             # (an order drawn ahead belongs to ONE train() call)
     num_batches = len(train_dataloader)
     iters_processed = 0
     if iters_per_epoch is None:
@@ -601,7 +602,13 @@ class Recoder(object):
       if self._graph_ok(train_dataloader, iters_per_epoch, num_batches):
         # whole epochs of the one-call autoencoder step: replayed as HIP graphs (graph.py)
         iters_processed = num_batches
-        self.last_epoch_losses = self._train_epoch_graph(train_dataloader)
+        # the NEXT epoch's user order is drawn while the GPU still works on this one (torch.randperm
+        # of 10^5 users costs 2-11 ms of host time, a quarter of a C2 epoch) -- unless something
+        # else would draw from the global RNG in between (validation), a hook supplies the order or
+        # this is the last epoch: the SEQUENCE of draws stays the reference's
+        ahead = (epoch < num_epochs and self.user_order_hook is None and
+                 not (eval_freq > 0 and epoch % eval_freq == 0 and val_dataloader is not None))
+        self.last_epoch_losses = self._train_epoch_graph(train_dataloader, draw_next_order=ahead)
         self._epoch_end(epoch, num_epochs, len(self.last_epoch_losses), val_dataloader, eval_freq,
                         metrics, eval_num_recommendations, eval_batch_size, eval_num_users,
                         model_checkpoint_prefix, checkpoint_freq)
@@ -672,7 +679,7 @@ class Recoder(object):
             ds.device_target_csr() is None and iters_per_epoch == num_batches and
             len(ds) >= dataloader.batch_size)
 
-  def _train_epoch_graph(self, dataloader):
+  def _train_epoch_graph(self, dataloader, draw_next_order=False):
     """One pass over the dataset with the whole-batch steps replayed as HIP graphs
     (recoder_amd/graph.py); returns the per-step losses."""
     from .graph import GraphStepper
@@ -689,19 +696,22 @@ class Recoder(object):
                         self.device)
       self._graph_stepper = gs
     order = None
+    ahead, self._order_ahead = getattr(self, "_order_ahead", None), None
     if self.user_order_hook is not None:
       order = self.user_order_hook(self.current_epoch, n)
+    elif ahead is not None and ahead[0] == n:
+      order = ahead[1]                     # drawn at the end of the previous epoch
     if order is None:
       order = epoch_user_order(n)
     order = np.ascontiguousarray(order, dtype=np.int64)
     caller = torch.cuda.current_stream()
     gs.main.wait_stream(caller)
     with torch.cuda.stream(gs.main):
-      losses = self._run_epoch_graph(gs, eng, dcsr, order, n, B)
+      losses = self._run_epoch_graph(gs, eng, dcsr, order, n, B, draw_next_order)
     caller.wait_stream(gs.main)
     return losses
 
-  def _run_epoch_graph(self, gs, eng, dcsr, order, n, B):
+  def _run_epoch_graph(self, gs, eng, dcsr, order, n, B, draw_next_order=False):
     n_full = gs.begin_epoch(order, eng.rng_step)
     n_total = n_full + (1 if n % B else 0)
     g0 = self._global_step
@@ -732,6 +742,8 @@ class Recoder(object):
       losses = torch.cat([losses, out])
       if n_total > n_full and (g0 + n_total) in self.step_marks and self.step_marks[g0 + n_total]():
         self._stop_training = True
+    if draw_next_order and not self._stop_training:
+      self._order_ahead = (n, epoch_user_order(n))      # (everything of this epoch is enqueued)
     return losses.cpu().numpy().copy()
 
   def _validate(self, val_dataloader):

@@ -1048,6 +1048,34 @@ def test_graph_path_through_a_users_session(monkeypatch, tmp_path):
     assert np.array_equal(e[3][k], g[3][k], equal_nan=True), k
 
 
+@pytest.mark.parametrize("with_val", [False, True])
+def test_user_order_drawn_ahead_keeps_the_sequence_of_rng_draws(with_val, monkeypatch):
+  """No hooks: the user orders come from the global torch RNG exactly as the reference's
+  RandomSampler draws them.  The graph path draws the NEXT epoch's order at the end of an epoch
+  (while the GPU works) unless a validation pass -- which draws too -- sits in between; the eager
+  path draws at the start of every epoch.  Same sequence of draws <=> bit-identical training."""
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder
+  csr = synth_csr(1024, 600, 12, seed=43)
+  val = synth_csr(256, 600, 12, seed=44)
+
+  def run(graph):
+    monkeypatch.setenv("RK_GRAPH", "1" if graph else "0")
+    torch.manual_seed(37)
+    model = DynamicAutoencoder([32], activation_type="tanh", noise_prob=0.0, sparse=False)
+    rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss="mse")
+    kw = dict(val_dataset=RecommendationDataset(val, val), eval_freq=2) if with_val else {}
+    rec.train(RecommendationDataset(csr), batch_size=128, lr=1e-3, weight_decay=1e-5, num_epochs=4,
+              negative_sampling=True, **kw)
+    assert (getattr(rec, "_graph_stepper", None) is not None) == graph
+    return np.concatenate(rec.loss_history), torch.random.get_rng_state()
+  l0, s0 = run(False)
+  l1, s1 = run(True)
+  assert len(l0) == 32 and np.array_equal(l0, l1), np.abs(l0 - l1).max()
+  assert torch.equal(s0, s1)            # and the global RNG ends where the eager run leaves it
+
+
 def test_topk_tie_rule_and_strip_merge():
   """rk_topk_masked: exact ties resolve to the LOWER item id; only POSITIVE stored interactions are
   masked (model.py:537); the strip-wise top-k + merge equals the one-pass top-k."""
