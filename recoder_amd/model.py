@@ -715,7 +715,9 @@ class Recoder(object):
     n_full = gs.begin_epoch(order, eng.rng_step)
     n_total = n_full + (1 if n % B else 0)
     g0 = self._global_step
-    marks = sorted(m - g0 for m in self.step_marks if g0 <= m <= g0 + n_total)
+    # (a mark is called BEFORE step m is enqueued: one that coincides with the end of this epoch
+    # belongs to the first step of the next one -- as in the eager path)
+    marks = sorted(m - g0 for m in self.step_marks if g0 <= m < g0 + n_total)
     # (looked up per group: a step mark may install / change the engine's time plan)
     plan = lambda i: eng.time_plan is not None and eng.time_plan(i) is not None
     pos, stopped = 0, False
@@ -740,8 +742,6 @@ class Recoder(object):
       eng.train_step(gs.tail_blk, 0, int(users.numel()), out=out)
       self._global_step += 1
       losses = torch.cat([losses, out])
-      if n_total > n_full and (g0 + n_total) in self.step_marks and self.step_marks[g0 + n_total]():
-        self._stop_training = True
     if draw_next_order and not self._stop_training:
       self._order_ahead = (n, epoch_user_order(n))      # (everything of this epoch is enqueued)
     return losses.cpu().numpy().copy()

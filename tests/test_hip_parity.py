@@ -1076,6 +1076,54 @@ def test_user_order_drawn_ahead_keeps_the_sequence_of_rng_draws(with_val, monkey
   assert torch.equal(s0, s1)            # and the global RNG ends where the eager run leaves it
 
 
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_graph_vs_eager_random_schedules(seed, monkeypatch):
+  """Random epoch lengths (ragged or not, odd / even numbers of groups, shorter than one group),
+  group sizes, step marks and hooks: the graph path must equal the eager path bit for bit."""
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder
+  rng = np.random.RandomState(1000 + seed)
+  B = int(rng.choice([32, 64, 100]))
+  G = int(rng.choice([1, 2, 3, 4, 8]))
+  n_steps = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 9, 12, 16]))
+  n = n_steps * B + (int(rng.randint(1, B)) if rng.rand() < 0.5 else 0)
+  epochs = int(rng.choice([2, 3, 4]))
+  hooks = bool(rng.rand() < 0.5)
+  n_marks = int(rng.choice([0, 0, 1, 2]))
+  total = epochs * (n_steps + (1 if n % B else 0))
+  marks = sorted(set(int(x) for x in rng.randint(1, max(2, total), size=n_marks)))
+  sparse = bool(rng.rand() < 0.4)
+  noise = float(rng.choice([0.0, 0.3]))
+  csr = synth_csr(n, 400, 9, seed=500 + seed, ratings=bool(rng.rand() < 0.5))
+  orders = [np.random.RandomState(70 + e).permutation(n).astype(np.int64) for e in range(epochs + 1)]
+  monkeypatch.setenv("RK_GRAPH_GROUP", str(G))
+
+  def run(graph):
+    monkeypatch.setenv("RK_GRAPH", "1" if graph else "0")
+    torch.manual_seed(41 + seed)
+    model = DynamicAutoencoder([24], activation_type="tanh", noise_prob=noise, sparse=sparse)
+    rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss="mse")
+    if hooks:
+      rec.user_order_hook = lambda epoch, n_: orders[epoch]
+    seen = []
+    rec.step_marks = {m: (lambda m=m: seen.append(m) or False) for m in marks}
+    rec.train(RecommendationDataset(csr), batch_size=B, lr=1e-3, weight_decay=0.0 if sparse else 1e-5,
+              num_epochs=epochs, negative_sampling=True)
+    assert seen == [m for m in marks if m < total]      # (called BEFORE step m is enqueued)
+    return (np.concatenate(rec.loss_history),
+            {k: v.detach().cpu().clone() for k, v in model.named_parameters()},
+            getattr(rec, "_graph_stepper", None) is not None)
+  l0, p0, g0 = run(False)
+  l1, p1, g1 = run(True)
+  desc = dict(B=B, G=G, n=n, epochs=epochs, hooks=hooks, marks=marks, sparse=sparse, noise=noise, graph=g1)
+  assert not g0
+  assert len(l0) == len(l1) == total, desc
+  assert np.array_equal(l0, l1), (desc, np.abs(l0 - l1).max(), int(np.argmax(l0 != l1)))
+  for k in p0:
+    assert torch.equal(p0[k], p1[k]), (desc, k)
+
+
 def test_topk_tie_rule_and_strip_merge():
   """rk_topk_masked: exact ties resolve to the LOWER item id; only POSITIVE stored interactions are
   masked (model.py:537); the strip-wise top-k + merge equals the one-pass top-k."""
