@@ -54,9 +54,13 @@ typedef struct rk_block {
   int32_t n_chunks;   /* ceil(n_items / RK_SCAN_CHUNK) */
   int32_t implicit;   /* != 0: every stored value is 1.0 (vals is not read by the
                          loss / backward kernels) -- implicit-feedback data */
-  int32_t *counts;    /* [72] dev: n_b, nnz_b, ld (= round_up(n_b,32)), S, 4 spare; [8..71]: fp32 bit
-                         patterns of the running max |dLoss/dLogit| the loss kernels saw since
-                         rk_collate zeroed them (rk_decode_bwd_dz scales its fp16 split by it) */
+  int32_t *counts;    /* [72] dev: n_b, nnz_b, ld (= round_up(n_b,32)), S; [4]: K slabs the last
+                         rk_decode_bwd_dw3 wrote; [5] / [6]: overflow flags of the last rk_collate --
+                         the true number of distinct items / stored interactions when it exceeded
+                         n_cap / nnz_cap (the block is then truncated IN BOUNDS: the caller must
+                         check and discard it), else 0; [8..71]: fp32 bit patterns of the running max
+                         |dLoss/dLogit| the loss kernels saw since rk_collate zeroed them
+                         (rk_decode_bwd_dz scales its fp16 split by it) */
   int32_t *indptr;    /* [S_cap+1] block CSR row pointers */
   int32_t *cols;      /* [nnz_cap] relabelled column (index into items) */
   float   *vals;      /* [nnz_cap] interaction values */

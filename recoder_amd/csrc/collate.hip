@@ -64,14 +64,17 @@ __global__ __launch_bounds__(256) void collate_phase1_kernel(
       int32_t woff = 0;
       for (int w = 0; w < wid; ++w) woff += wsum[w];
       const int32_t carry = carry_s;
-      if (i < S) b.indptr[i] = carry + woff + x - d;
+      if (i < S) b.indptr[i] = min(carry + woff + x - d, b.nnz_cap);    // (clamped: see counts[6])
       __syncthreads();
       if (tid == 255) carry_s = carry + woff + x;
       __syncthreads();
     }
     if (tid == 0) {
-      b.indptr[S] = carry_s;
-      b.counts[1] = carry_s;
+      // more stored interactions than the block is sized for (never by construction): every row
+      // range is clamped into the arrays, the true count goes to counts[6] and the host raises
+      b.indptr[S] = min(carry_s, b.nnz_cap);
+      b.counts[1] = min(carry_s, b.nnz_cap);
+      b.counts[6] = carry_s > b.nnz_cap ? carry_s : 0;
       b.counts[3] = S;
       for (int i = 8; i < 72; ++i) b.counts[i] = 0;   // max |dLoss/dLogit| slots (gemm.hip)
     }
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256) void collate_count_kernel(
 __global__ __launch_bounds__(256) void collate_assign_kernel(
     const int32_t *__restrict__ mark, int n_items, int32_t stamp, int all,
     const int32_t *__restrict__ scan_tmp, int n_chunks, int32_t *__restrict__ pos,
-    int32_t *__restrict__ items, int32_t *__restrict__ counts, int n_cap, rk_cur_t cur) {
+    int32_t *__restrict__ items, int32_t *__restrict__ counts, int n_cap, int nnz_cap, rk_cur_t cur) {
   __shared__ int32_t red[4];
   if (cur.cursor) stamp = rk_cur_stamp(cur);
   __shared__ int32_t wsum[4];
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(256) void collate_assign_kernel(
 __global__ __launch_bounds__(1024) void collate_scan_small_kernel(
     const int32_t *__restrict__ mark, int n_items, int32_t stamp, int all,
     int32_t *__restrict__ pos, int32_t *__restrict__ items, int32_t *__restrict__ counts,
-    int n_cap, rk_cur_t cur) {
+    int n_cap, int nnz_cap, rk_cur_t cur) {
   __shared__ int32_t wsum[16];
   __shared__ int32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -237,9 +240,10 @@ __global__ __launch_bounds__(256) void collate_build_kernel(
   if (row >= S) return;
   const int64_t u = users[row];
   const int64_t beg = ds_indptr[u];
-  const int n = (int)(ds_indptr[u + 1] - beg);
+  int n = (int)(ds_indptr[u + 1] - beg);
   const int out0 = b.indptr[row];
   const int wr = (b.counts[0] + 31) >> 5;          // bitmap words in use
+  n = min(n, b.indptr[row + 1] - out0);            // (the clamped range of a truncated block)
   for (int k = lane; k < n; k += 64) {
     const int32_t gi = ds_indices[beg + k];
     const int32_t c = b.pos[gi];            // (< 0 only in a truncated block, counts[5] != 0)
@@ -338,7 +342,8 @@ static int collate_impl(const int64_t *ds_indptr, const int32_t *ds_indices,
   if (phase == 1) return 0;
   if (blk->n_items <= SMALL_SCAN_MAX) {
     RK_LAUNCH(collate_scan_small_kernel, dim3(1), dim3(1024), 0, stream, blk->mark,
-                       blk->n_items, stamp, all, blk->pos, blk->items, blk->counts, blk->n_cap, cur);
+                       blk->n_items, stamp, all, blk->pos, blk->items, blk->counts, blk->n_cap,
+                       blk->nnz_cap, cur);
     RK_CHECK_LAUNCH("collate_scan_small");
   } else {
     RK_LAUNCH(collate_count_kernel, dim3(blk->n_chunks), dim3(256), 0, stream,
@@ -346,7 +351,7 @@ static int collate_impl(const int64_t *ds_indptr, const int32_t *ds_indices,
     RK_CHECK_LAUNCH("collate_count");
     RK_LAUNCH(collate_assign_kernel, dim3(blk->n_chunks), dim3(256), 0, stream,
                        blk->mark, blk->n_items, stamp, all, blk->scan_tmp, blk->n_chunks,
-                       blk->pos, blk->items, blk->counts, blk->n_cap, cur);
+                       blk->pos, blk->items, blk->counts, blk->n_cap, blk->nnz_cap, cur);
     RK_CHECK_LAUNCH("collate_assign");
   }
   RK_LAUNCH(collate_build_kernel, dim3(rk_cdiv(S, 4)), dim3(256), 0, stream,

@@ -218,12 +218,16 @@ class Block:
   # ---- host views (synchronising; tests / API compatibility only) ----
   def counts_host(self):
     c = self.counts.cpu().numpy()
-    self._raise_if_truncated(int(c[5]))
+    self._raise_if_truncated(int(c[5]) if c[5] else -int(c[6]))
     return int(c[0]), int(c[1]), int(c[2]), int(c[3])
 
   def _raise_if_truncated(self, n_all):
     if n_all:
       from ._lib import RecoderHipError
+      if n_all < 0:
+        raise RecoderHipError("a collated block held %d stored interactions but was sized for %d "
+                              "(rk_collate dropped the surplus in bounds; everything computed from it "
+                              "is wrong)" % (-n_all, self.nnz_cap))
       raise RecoderHipError("a collated block held %d distinct items but was sized for %d (rk_collate "
                             "truncated it in bounds; everything computed from it is wrong)"
                             % (n_all, self.n_cap))
@@ -232,7 +236,8 @@ class Block:
     """Raise if the last collation into this block overflowed its item capacity (counts[5]: the
     device clamps in bounds and leaves the true count there).  One 4-byte read-back: call it where
     the stream is drained anyway (the end of an epoch)."""
-    self._raise_if_truncated(int(self.counts[5].item()))
+    f = self.counts[5:7].cpu().numpy()
+    self._raise_if_truncated(int(f[0]) if f[0] else -int(f[1]))
 
   def to_host(self):
     n_b, nnz, ld, S = self.counts_host()

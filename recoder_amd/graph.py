@@ -164,7 +164,14 @@ class GraphStepper:
     n = len(order_np)
     n_full = n // self.B
     assert n_full <= self.steps_cap
-    self.order[:n].copy_(torch.from_numpy(np.ascontiguousarray(order_np, dtype=np.int64)), non_blocking=False)
+    # the look-ahead collation of the group BEHIND the epoch's last one reads past the order: pad
+    # it with the order's own first users (B consecutive entries stay DISTINCT users, so a padding
+    # block never holds more interactions / items than the blocks are sized for -- B copies of one
+    # heavy user did, and overran them); those blocks are never trained on
+    pad = self.order.numel() - n
+    order_np = np.ascontiguousarray(order_np, dtype=np.int64)
+    self.order.copy_(torch.from_numpy(np.concatenate([order_np, np.resize(order_np, pad)])),
+                     non_blocking=False)
     # Adam constants of every step of the epoch (exactly what rk_adam_multi derives itself)
     th = self.table_host
     S = self.eng.states
@@ -205,6 +212,8 @@ class GraphStepper:
       # stamps (rk_cur_stamp) -- but possibly other users (the padding behind an epoch's last
       # step), and a block collated twice in a row with one stamp keeps the first set's items.
       slot = 1 - self._la_slot
+      if __import__("os").environ.get("RK_HACK_RESTART0"):
+        slot = 0
       check(lib.rk_cursor_set(self._cur(slot), self.global_step, self.epoch_base, self._h(self.main)),
             "rk_cursor_set")
     else:
