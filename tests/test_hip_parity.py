@@ -1152,6 +1152,48 @@ def test_graph_vs_eager_random_schedules(seed, monkeypatch):
     assert torch.equal(p0[k], p1[k]), (desc, k)
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_recommend_strips_equal_dense_topk_random_shapes(seed, monkeypatch):
+  """Strip-wise streaming decode + per-strip top-k + merge (Recoder.recommend) against the full
+  score matrix + torch.topk, for random catalogue sizes, strip widths (incl. a last strip shorter
+  than k), k and batch sizes; both model families."""
+  from recoder_amd.data import RecommendationDataset, UsersInteractions
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder, MatrixFactorization
+  rng = np.random.RandomState(2000 + seed)
+  n_items = int(rng.choice([90, 257, 1000, 4097]))
+  n_users = int(rng.choice([40, 130]))
+  k = int(rng.choice([1, 5, 20, 64]))
+  k = min(k, n_items // 2)
+  strip = int(rng.choice([k, k + 1, 64, 100, 333, 5000]))
+  B = int(rng.choice([1, 7, 33]))
+  kind = "mf" if seed % 4 == 3 else "ae"
+  csr = synth_csr(n_users, n_items, 8, seed=600 + seed, ratings=bool(rng.rand() < 0.5))
+  torch.manual_seed(50 + seed)
+  if kind == "ae":
+    model = DynamicAutoencoder([int(rng.choice([8, 32]))], activation_type="tanh", sparse=False)
+  else:
+    model = MatrixFactorization(16, activation_type="none", sparse=False)
+  rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss="mse")
+  rec.train(RecommendationDataset(csr), batch_size=32, lr=1e-2, weight_decay=0.0, num_epochs=1,
+            negative_sampling=True)
+  monkeypatch.setattr(type(rec), "eval_strip_items", strip, raising=False)
+  users = rng.permutation(n_users)[:B]
+  ui = UsersInteractions(users=users, interactions_matrix=csr[users])
+  got = rec.recommend_array(ui, k)
+  want = rec._recommend_dense(ui, k)
+  assert got.shape == (B, k)
+  if not np.array_equal(got, want):
+    # equal scores may be ordered differently by torch.topk: compare the scores instead
+    out, _ = rec.predict(ui)
+    out = out.cpu().numpy()
+    gs = np.take_along_axis(out, got, axis=1)
+    ws = np.take_along_axis(out, np.asarray(want), axis=1)
+    assert np.allclose(gs, ws, rtol=1e-6, atol=0), dict(n_items=n_items, k=k, strip=strip, B=B, kind=kind)
+  seen = csr[users].toarray() > 0
+  assert not np.take_along_axis(seen, got, axis=1).any()           # nothing already seen is recommended
+
+
 def test_topk_tie_rule_and_strip_merge():
   """rk_topk_masked: exact ties resolve to the LOWER item id; only POSITIVE stored interactions are
   masked (model.py:537); the strip-wise top-k + merge equals the one-pass top-k."""
