@@ -704,6 +704,9 @@ class Recoder(object):
     if order is None:
       order = epoch_user_order(n)
     order = np.ascontiguousarray(order, dtype=np.int64)
+    if order.shape != (n,):
+      raise ValueError("user_order_hook must return one entry per user of the dataset (%d), got %s"
+                       % (n, order.shape))
     caller = torch.cuda.current_stream()
     gs.main.wait_stream(caller)
     with torch.cuda.stream(gs.main):

@@ -925,6 +925,96 @@ def test_data_parallel_two_virtual_ranks_equal_single_process(case):
       assert frac < 2e-3, (k, frac, mx, scale)
 
 
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_data_parallel_virtual_ranks_random_shapes(seed):
+  """test_data_parallel_two_virtual_ranks_equal_single_process over random shapes: 2 or 3 virtual
+  ranks, shard sizes that leave ragged remainders, sampling on / off, dense / sparse / tied, the
+  three losses."""
+  import threading
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder
+  from recoder_amd.parallel import DataParallel, shard_range
+  rng = np.random.RandomState(3000 + seed)
+  world = int(rng.choice([2, 3]))
+  B = int(rng.choice([16, 50, 96]))
+  steps = int(rng.choice([1, 2, 3, 5]))
+  # (a remainder is dropped by every rank: then only the replicas can be compared with each other)
+  n = world * steps * B + (int(rng.randint(1, world * B)) if rng.rand() < 0.4 else 0)
+  n_items = int(rng.choice([120, 700]))
+  loss = str(rng.choice(["mse", "logistic", "logloss"]))
+  sparse = bool(rng.rand() < 0.4)
+  tied = bool(rng.rand() < 0.25) and loss != "logloss"
+  ns = bool(rng.rand() < 0.8)
+  act = str(rng.choice(["tanh", "sigmoid", "relu"]))
+  h = int(rng.choice([8, 32, 60]))
+  wd = 0.0 if sparse else 1e-5
+  csr = synth_csr(n, n_items, 10, seed=3100 + seed, ratings=(loss == "mse" and rng.rand() < 0.5))
+  per = n // world
+  n_st = per // B                                              # whole steps per rank and epoch
+  if n_st == 0:
+    pytest.skip("shard smaller than a batch")
+  shard_orders = [rng.permutation(shard_range(n, r, world)[1] - shard_range(n, r, world)[0])[:n_st * B]
+                  .astype(np.int64) for r in range(world)]
+  kw = dict(lr=1e-3, weight_decay=wd, num_epochs=2, negative_sampling=ns)
+  desc = dict(world=world, B=B, n=n, n_items=n_items, loss=loss, sparse=sparse, tied=tied, ns=ns, act=act, h=h)
+
+  def new():
+    torch.manual_seed(61 + seed)
+    model = DynamicAutoencoder([h], activation_type=act, noise_prob=0.0, sparse=sparse, is_constrained=tied)
+    return model, Recoder(model=model, use_cuda=True, optimizer_type="adam", loss=loss)
+  los = [shard_range(n, r, world)[0] for r in range(world)]
+  glob = []
+  for off in range(0, n_st * B, B):
+    for r in range(world):
+      glob += list(los[r] + shard_orders[r][off:off + B])
+  glob = np.asarray(glob, dtype=np.int64)
+  base_l = base_p = None
+  if len(glob) == n:       # no remainder dropped: the single-process run with batch world * B is the same training
+    model0, rec0 = new()
+    rec0.user_order_hook = lambda epoch, n_: glob
+    rec0.train(RecommendationDataset(csr), batch_size=world * B, **kw)
+    base_l = np.concatenate(rec0.loss_history)
+    base_p = {k: v.detach().cpu().clone() for k, v in model0.named_parameters()}
+  vr = _VirtualRanks(world)
+  reps = []
+  for r in range(world):
+    model, rec = new()
+    rec._Recoder__init_training(RecommendationDataset(csr), kw["lr"], wd)
+    rec._dp_override = DataParallel(rank=r, world=world, allreduce_fn=vr.allreduce(r),
+                                    allreduce_max_fn=vr.allreduce_max(r))
+    rec.user_order_hook = (lambda rr: (lambda epoch, n_: shard_orders[rr]))(r)
+    reps.append((model, rec))
+  errs = []
+
+  def run(r):
+    try:
+      torch.cuda.set_device(0)
+      reps[r][1].train(RecommendationDataset(csr), batch_size=B, **kw)
+    except BaseException as e:       # noqa: B036 -- release the other threads
+      errs.append(e)
+      vr.barrier.abort()
+  threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=300)
+  assert not errs, (desc, errs)
+  for model, rec in reps:
+    got_l = np.concatenate(rec.loss_history)
+    assert len(got_l) == 2 * n_st, desc
+    if base_l is not None:
+      assert np.allclose(got_l, base_l, rtol=2e-5, atol=0), (desc, got_l[:3], base_l[:3])
+      for k, v in model.named_parameters():
+        frac, mx, scale = close_stats(v.detach().cpu().numpy(), base_p[k].numpy(), 1e-4, 2e-6)
+        assert frac < 2e-3, (desc, k, frac, mx, scale)
+  # the replicas agree with each other bit for bit whatever the shapes
+  p_ref = {k: v.detach().cpu() for k, v in reps[0][0].named_parameters()}
+  for model, rec in reps[1:]:
+    for k, v in model.named_parameters():
+      assert torch.equal(v.detach().cpu(), p_ref[k]), (desc, k)
+
+
 @pytest.mark.parametrize("case", ["dense_noise", "sparse_tied_bce", "logloss", "ratings_all_items",
                                   "ratings_relu_conf"])
 def test_graph_replay_is_bitwise_equal_to_eager_steps(case, monkeypatch):
