@@ -837,6 +837,86 @@ def test_item_parallel_two_virtual_ranks_equal_single_process(case):
       assert frac < 2e-3, (k, frac, mx, scale)
 
 
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_item_parallel_virtual_ranks_random_shapes(seed):
+  """test_item_parallel_two_virtual_ranks_equal_single_process over random shapes: 2 or 3 virtual
+  ranks (item i on rank i % world), ragged last batches, both model families, the three losses,
+  hidden stacks / dropout (per-entry sequencing), dense / sparse / tied."""
+  import threading
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder, MatrixFactorization
+  from recoder_amd.parallel import ItemParallel
+  rng = np.random.RandomState(4000 + seed)
+  world = int(rng.choice([2, 3]))
+  b = int(rng.choice([8, 40, 75]))                 # per-rank batch; the global batch is world * b
+  gb = world * b
+  n = gb * int(rng.choice([1, 2, 4])) + (int(rng.randint(1, gb)) if rng.rand() < 0.5 else 0)
+  n_items = int(rng.choice([97, 600]))
+  kind = "mf" if rng.rand() < 0.25 else "ae"
+  loss = str(rng.choice(["mse", "logistic", "logloss"] if kind == "ae" else ["mse", "logistic"]))
+  sparse = bool(rng.rand() < 0.4)
+  wd = 0.0 if sparse else 1e-5
+  if kind == "ae":
+    layers = [int(rng.choice([8, 32]))] if rng.rand() < 0.7 else [32, 16]
+    tied = bool(rng.rand() < 0.25) and loss != "logloss"
+    drop = 0.25 if (len(layers) > 1 and rng.rand() < 0.5) else 0.0
+    act = str(rng.choice(["tanh", "sigmoid", "relu"]))
+    mk = lambda: DynamicAutoencoder(layers, activation_type=act, noise_prob=0.0, dropout_prob=drop,
+                                    sparse=sparse, is_constrained=tied)
+    desc = dict(kind=kind, layers=layers, tied=tied, drop=drop, act=act)
+  else:
+    d = int(rng.choice([8, 24]))
+    act = str(rng.choice(["none", "tanh"]))
+    mk = lambda: MatrixFactorization(d, activation_type=act, sparse=sparse)
+    desc = dict(kind=kind, d=d, act=act)
+  desc.update(world=world, b=b, n=n, n_items=n_items, loss=loss, sparse=sparse)
+  csr = synth_csr(n, n_items, 10, seed=4100 + seed, ratings=(loss == "mse" and rng.rand() < 0.5))
+  order = rng.permutation(n).astype(np.int64)
+  kw = dict(lr=1e-3, weight_decay=wd, num_epochs=2, negative_sampling=True)
+
+  def new():
+    torch.manual_seed(71 + seed)
+    model = mk()
+    rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss=loss)
+    rec.user_order_hook = lambda epoch, n_: order
+    return model, rec
+  model0, rec0 = new()
+  rec0.train(RecommendationDataset(csr), batch_size=gb, **kw)
+  base_l = np.concatenate(rec0.loss_history)
+  base_p = {k: v.detach().cpu().clone() for k, v in model0.named_parameters()}
+  vr = _VirtualRanks(world)
+  reps = []
+  for r in range(world):
+    model, rec = new()
+    rec._Recoder__init_training(RecommendationDataset(csr), kw["lr"], wd)
+    rec._ip_override = ItemParallel(rank=r, world=world, allreduce_fn=vr.allreduce(r),
+                                    allgather_fn=vr.allgather(r))
+    reps.append((model, rec))
+  errs = []
+
+  def run(r):
+    try:
+      torch.cuda.set_device(0)
+      reps[r][1].train(RecommendationDataset(csr), batch_size=b, **kw)
+    except BaseException as e:       # noqa: B036 -- release the other threads
+      errs.append(e)
+      vr.barrier.abort()
+  threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=300)
+  assert not errs, (desc, errs)
+  for model, rec in reps:
+    got_l = np.concatenate(rec.loss_history)
+    assert len(got_l) == len(base_l), desc
+    assert np.allclose(got_l, base_l, rtol=2e-5, atol=0), (desc, got_l[:3], base_l[:3])
+    for k, v in model.named_parameters():
+      frac, mx, scale = close_stats(v.detach().cpu().numpy(), base_p[k].numpy(), 1e-4, 2e-6)
+      assert frac < 2e-3, (desc, k, frac, mx, scale)
+
+
 @pytest.mark.parametrize("case", ["mse_dense", "bce_sparse_tied", "ae2_dropout", "ae_logloss"])
 def test_data_parallel_two_virtual_ranks_equal_single_process(case):
   """parallel.DataParallel (users sharded -- north_star's partitioning, the multi-GPU default)
