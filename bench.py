@@ -271,7 +271,8 @@ def main():
   def plan_warm(i):
     # warm-up: the first group of steps runs eagerly with every launch group bracketed, the rest
     # replays the captured graphs (so that the timed region starts with warm graphs)
-    return "all" if i < min(G, max(1, W // 2)) else None
+    # (i counts from 0 on the graph path and from 1 on the eagerly sequenced ones: <= covers both)
+    return "all" if i <= min(G, max(1, W // 2)) else None
 
   SAMPLE_POST = os.environ.get("RK_BENCH_SAMPLE", "timed") == "post"
 
@@ -390,7 +391,12 @@ def main():
         kernels.append(line(e, timed[e], "timed region"))
       elif T["warm"].get(e):
         kernels.append(line(e, T["warm"][e], "warm-up"))
-    dom = max(kernels, key=lambda k: k["avg_us"])
+    if not kernels:
+      # (no launch group was bracketed: a run too short for the sampling plan -- never lose the line)
+      kernels = [dict(name="rk_adam_multi", kernels=KERNELS.get("rk_adam_multi", []), avg_us=float("nan"),
+                      samples=0, sampled="none", bound="hbm", achieved=float("nan"), peak=PEAK_HBM_GBS,
+                      unit="GB/s", frac=float("nan"), ideal_us=float("nan"))]
+    dom = max(kernels, key=lambda k: (k["avg_us"] if k["avg_us"] == k["avg_us"] else -1.0))
     dominant = dom["name"]
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload
     # (profiles/r*_pmc_traffic.json, tools/pmc_traffic.py); null for other configs
