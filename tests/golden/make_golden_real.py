@@ -30,6 +30,9 @@ from tests.golden.make_golden import import_reference  # noqa: E402
 
 SEED, EPOCHS, B = 20240917, 6, 500
 LOSSES = ("logloss", "mse")
+# third run: SparseAdam + validation loss and evaluation INSIDE training every 2 epochs (their
+# loaders draw from the global RNG too: the training orders behind them depend on it), then the
+# reference's save_state -> fresh trainer -> init_from_model_file -> evaluate (tests/test_model.py:64-82)
 
 
 def split(csr, seed):
@@ -101,6 +104,35 @@ def main():
     gold[loss + "/top100"] = np.asarray(top, dtype=np.int64)
     print(loss, "steps", len(rec), "loss %.5f -> %.5f" % (rec[0], rec[-1]),
           {str(mt): round(float(np.nanmean(res[mt])), 6) for mt in metrics})
+  # ---- sparse + validation / evaluation inside training + checkpoint round trip ----
+  torch.manual_seed(SEED + 1)
+  model = DynamicAutoencoder(hidden_layers=[200], activation_type="tanh", noise_prob=0.0, sparse=True)
+  trainer = Recoder(model=model, use_cuda=False, optimizer_type="adam", loss="logloss")
+  rec, vals = [], []
+  orig = trainer._Recoder__compute_loss
+
+  def compute_loss2(input, target):
+    out = orig(input, target)
+    (rec if model.training else vals).append(float(out.item()))
+    return out
+  trainer._Recoder__compute_loss = compute_loss2
+  metrics = [Recall(k=20, normalize=True), NDCG(k=100)]
+  prefix = "/tmp/rk_real_ckpt"
+  trainer.train(train_dataset=RecommendationDataset(x), val_dataset=RecommendationDataset(x, y),
+                batch_size=B, lr=1e-3, weight_decay=0, num_epochs=4, negative_sampling=True,
+                eval_freq=2, metrics=metrics, eval_num_recommendations=100, eval_num_users=2000,
+                model_checkpoint_prefix=prefix, checkpoint_freq=4)
+  model2 = DynamicAutoencoder(sparse=True)
+  trainer2 = Recoder(model=model2, use_cuda=False, optimizer_type="adam", loss="logloss")
+  trainer2.init_from_model_file(prefix + "_epoch_4.model")
+  res = trainer2._evaluate(eval_dataset=RecommendationDataset(x, y), num_recommendations=100,
+                           metrics=metrics, batch_size=500)
+  gold["sv/losses"] = np.asarray(rec, dtype=np.float64)
+  gold["sv/val_losses"] = np.asarray(vals, dtype=np.float64)
+  for mt in metrics:
+    gold["sv/" + str(mt)] = np.asarray(res[mt], dtype=np.float64)
+  print("sparse+val steps", len(rec), "val batches", len(vals), "loss %.5f -> %.5f" % (rec[0], rec[-1]),
+        {str(mt): round(float(np.nanmean(res[mt])), 6) for mt in metrics})
   path = os.path.join(HERE, "real_ml20m_slice.npz")
   np.savez_compressed(path, **gold)
   print("wrote", path, "%.0f KB" % (os.path.getsize(path) / 1024), m.shape, m.nnz)

@@ -58,3 +58,40 @@ def test_reference_run_on_its_own_ml20m_slice(loss):
   want = z[loss + "/top100"]
   assert (top == want).mean() > 0.995     # positions; swaps only between scores a rounding apart
   assert all(set(a) == set(b) or len(set(a) ^ set(b)) <= 2 for a, b in zip(top, want))
+
+
+def test_reference_run_with_validation_evaluation_and_checkpoint(tmp_path):
+  """SparseAdam + the validation loss and an evaluation INSIDE training every 2 epochs (their
+  loaders draw from the global RNG as well: every training order behind them depends on the same
+  consumption), then the reference test's own epilogue (tests/test_model.py:64-82): save_state,
+  a fresh trainer, init_from_model_file, evaluate."""
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.metrics import NDCG, Recall
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder
+  z, x, y = load()
+  torch.manual_seed(int(z["seed"]) + 1)
+  model = DynamicAutoencoder(hidden_layers=[200], activation_type="tanh", noise_prob=0.0, sparse=True)
+  trainer = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss="logloss")
+  metrics = [Recall(k=20, normalize=True), NDCG(k=100)]
+  prefix = str(tmp_path / "ck")
+  trainer.train(train_dataset=RecommendationDataset(x), val_dataset=RecommendationDataset(x, y),
+                batch_size=int(z["batch_size"]), lr=1e-3, weight_decay=0, num_epochs=4,
+                negative_sampling=True, eval_freq=2, metrics=metrics, eval_num_recommendations=100,
+                eval_num_users=2000, model_checkpoint_prefix=prefix, checkpoint_freq=4)
+  losses, ref = np.concatenate(trainer.loss_history), z["sv/losses"]
+  assert len(losses) == len(ref) == 80
+  rel = np.abs(losses - ref) / np.abs(ref)
+  print("max rel loss error %.3g at step %d" % (rel.max(), int(rel.argmax())))
+  assert rel.max() < 1e-5
+  model2 = DynamicAutoencoder(sparse=True)
+  trainer2 = Recoder(model=model2, use_cuda=True, optimizer_type="adam", loss="logloss")
+  trainer2.init_from_model_file(prefix + "_epoch_4.model")
+  res = trainer2._evaluate(eval_dataset=RecommendationDataset(x, y), num_recommendations=100,
+                           metrics=metrics, batch_size=500)
+  for m in metrics:
+    got, want = np.asarray(res[m], dtype=np.float64), z["sv/" + str(m)]
+    same = np.isclose(got, want, rtol=0, atol=1e-12) | (np.isnan(got) & np.isnan(want))
+    print("   %-10s mean %.6f (reference %.6f), %d of 10000 users differ"
+          % (m, np.nanmean(got), np.nanmean(want), int((~same).sum())))
+    assert abs(np.nanmean(got) - np.nanmean(want)) < 5e-5 and (~same).sum() <= 20
