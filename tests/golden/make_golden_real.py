@@ -133,6 +133,30 @@ def main():
     gold["sv/" + str(mt)] = np.asarray(res[mt], dtype=np.float64)
   print("sparse+val steps", len(rec), "val batches", len(vals), "loss %.5f -> %.5f" % (rec[0], rec[-1]),
         {str(mt): round(float(np.nanmean(res[mt])), 6) for mt in metrics})
+  # ---- MatrixFactorization (the other model family north_star names) ----
+  from recoder.nn import MatrixFactorization
+  torch.manual_seed(SEED + 2)
+  model = MatrixFactorization(embedding_size=64, activation_type="tanh", dropout_prob=0, sparse=False)
+  trainer = Recoder(model=model, use_cuda=False, optimizer_type="adam", loss="logistic")
+  rec = []
+  orig_mf = trainer._Recoder__compute_loss
+
+  def compute_loss3(input, target):
+    out = orig_mf(input, target)
+    if model.training:
+      rec.append(float(out.item()))
+    return out
+  trainer._Recoder__compute_loss = compute_loss3
+  trainer.train(train_dataset=RecommendationDataset(x), batch_size=B, lr=1e-3, weight_decay=2e-5,
+                num_epochs=4, negative_sampling=True)
+  metrics = [Recall(k=20, normalize=True), NDCG(k=100)]
+  res = trainer._evaluate(eval_dataset=RecommendationDataset(x, y), num_recommendations=100,
+                          metrics=metrics, batch_size=500)
+  gold["mf/losses"] = np.asarray(rec, dtype=np.float64)
+  for mt in metrics:
+    gold["mf/" + str(mt)] = np.asarray(res[mt], dtype=np.float64)
+  print("mf steps", len(rec), "loss %.5f -> %.5f" % (rec[0], rec[-1]),
+        {str(mt): round(float(np.nanmean(res[mt])), 6) for mt in metrics})
   path = os.path.join(HERE, "real_ml20m_slice.npz")
   np.savez_compressed(path, **gold)
   print("wrote", path, "%.0f KB" % (os.path.getsize(path) / 1024), m.shape, m.nnz)
