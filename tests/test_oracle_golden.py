@@ -104,3 +104,34 @@ def test_oracle_recall(x, y, k, norm, exp):
 ])
 def test_oracle_ndcg(x, y, k, exp):
   assert np.isclose(orc.ndcg(x, y, k), exp, rtol=1e-9, atol=0)
+
+
+def test_oracle_replays_reference_on_its_ml20m_slice():
+  """The oracle against the REAL reference on REAL data (tests/golden/real_ml20m_slice.npz:
+  the reference's Recoder.train on the ML-20M slice its tests ship), from the seed alone: initial
+  weights (oracle.init_ae_state) and the per-epoch user orders (drawn as the reference's loader
+  draws them) come out of the global RNG; the first two epochs of per-step losses must be the
+  reference's -- exactly."""
+  import os
+  import scipy.sparse as sp
+  from recoder_amd.data import epoch_user_order          # host-side restatement of the sampler draw
+  z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "real_ml20m_slice.npz"))
+  shape = tuple(int(v) for v in z["shape"])
+  x = sp.csr_matrix((z["x/data"], z["x/indices"], z["x/indptr"]), shape=shape)
+  B = int(z["batch_size"])
+  for loss in ("logloss", "mse"):
+    torch.manual_seed(int(z["seed"]))
+    state = orc.init_ae_state(shape[1], [200])
+    o = orc.OracleRecoder("ae", state, hidden_layers=[200], activation_type="tanh", noise_prob=0.0,
+                          dropout_prob=0.0, sparse=False, loss=loss, loss_params=None, lr=1e-3,
+                          weight_decay=2e-5)
+    got = []
+    for epoch in range(2):
+      order = epoch_user_order(shape[0])
+      for off in range(0, shape[0], B):
+        users = order[off:off + B]
+        b = orc.collate(orc.extract_rows(x, users), users, B, True)[0]
+        got.append(o.train_step(b, None, None, None))
+    ref = z[loss + "/losses"][:len(got)]
+    assert len(got) == 40
+    assert np.array_equal(np.asarray(got, dtype=np.float64), ref), np.abs(np.asarray(got) - ref).max()
