@@ -383,6 +383,17 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     ++n;
     RK_REQUIRE(a->cursor == nullptr || (whole && a->adam_table != nullptr),
                "graph replay covers whole steps and needs the Adam constants table");
+    // the two bias jobs go FIRST in the grid (the launch dispatches its workgroups in order): a few
+    // dozen workgroups with a long chain of dependent loads (pos -> 8 partial gradient rows), which
+    // as the LAST ones dispatched were the tail of the whole sweep (43 vs 37 us in isolation)
+    {
+      rk_adam_job_t j2[4];
+      int32_t s2[4];
+      j2[0] = jobs[n - 2]; s2[0] = slots[n - 2];
+      j2[1] = jobs[n - 1]; s2[1] = slots[n - 1];
+      for (int k = 0; k < n - 2; ++k) { j2[2 + k] = jobs[k]; s2[2 + k] = slots[k]; }
+      for (int k = 0; k < n; ++k) { jobs[k] = j2[k]; slots[k] = s2[k]; }
+    }
     Timer t(a, RK_ENTRY_ADAM_MULTI, sm);
     RK_TRY(rk_adam_multi_at(jobs, n, whole ? a->loss_part : nullptr, n_part, a->denom,
                             whole ? a->loss_out : nullptr, a->cursor, a->cursor_off, a->adam_table,
