@@ -108,9 +108,10 @@ class GraphStepper:
     self.eng._c_train_step(self.blocks[slot][g], 0, self.B, None, self.loss_buf, None, self.main,
                            replay=replay)
 
-  def _group(self, slot, n_steps=None, first_index=None):
+  def _group(self, slot, n_steps=None, first_index=None, lookahead=True):
     """One group on slot `slot`: its steps on the main stream, the collation of the NEXT group's
-    blocks on the side stream, the cursor advance.  Called inside a capture or eagerly."""
+    blocks on the side stream (lookahead=False: the caller knows that a cut follows and nothing
+    would read them), the cursor advance.  Called inside a capture or eagerly."""
     lib, G = self.lib, self.G
     n_steps = G if n_steps is None else n_steps
     check(lib.rk_event_record(self.ev_fork, self._h(self.main)), "rk_event_record")
@@ -127,7 +128,7 @@ class GraphStepper:
       if g < n_steps:
         self._step(slot, g, None if first_index is None else first_index + g,
                    advance=n_steps if g == n_steps - 1 else None)
-      if g < G:
+      if g < G and lookahead:
         self._collate(self.blocks[1 - slot][g], n_steps + g, self.side, slot)
     check(lib.rk_event_record(self.ev_join, self._h(self.side)), "rk_event_record")
     check(lib.rk_stream_wait_event(self._h(self.main), self.ev_join), "rk_stream_wait_event")
@@ -212,8 +213,6 @@ class GraphStepper:
       # stamps (rk_cur_stamp) -- but possibly other users (the padding behind an epoch's last
       # step), and a block collated twice in a row with one stamp keeps the first set's items.
       slot = 1 - self._la_slot
-      if __import__("os").environ.get("RK_HACK_RESTART0"):
-        slot = 0
       check(lib.rk_cursor_set(self._cur(slot), self.global_step, self.epoch_base, self._h(self.main)),
             "rk_cursor_set")
     else:
@@ -231,24 +230,30 @@ class GraphStepper:
         if eager or not self.warmed:
           if need_pre:
             self._pre_collate(G, slot)
-          self._group(slot, G, first_index=idx0)
+          la = left > G                    # (run() ends with this group: a cut or the epoch's end
+          self._group(slot, G, first_index=idx0, lookahead=la)     # follows, nothing reads them)
           self._warm_capture()
         else:
+          la = True
           check(lib.rk_graph_launch(self.exec_first[slot] if need_pre else self.exec[slot],
                                     self._h(self.main)), "rk_graph_launch")
         k = G
       else:
         if need_pre:
           self._pre_collate(left, slot)
-        self._group(slot, left, first_index=idx0)      # tail: fewer than G steps, eager
+        la = False
+        self._group(slot, left, first_index=idx0, lookahead=False)   # tail: fewer than G steps, eager
         self._warm_capture()
         k = left
       need_pre = False
       self._advance_host(k)
       done += k
       slot = 1 - slot
-    self._collated = slot                # the look-ahead blocks of the next group
-    self._la_slot = slot                 # (remembered across cuts / epochs: see the restart above)
+    # the look-ahead blocks of the next group -- if the last group collated them (an eagerly
+    # enqueued last group does not: every caller cuts behind run(), see model._run_epoch_graph)
+    self._collated = slot if la else None
+    if la:
+      self._la_slot = slot               # (remembered across cuts / epochs: see the restart above)
 
   def _warm_capture(self):
     """Capture the graphs once every kernel has been launched eagerly (the first steps run)."""
