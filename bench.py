@@ -285,7 +285,9 @@ def main():
     # records = two barrier packets in the queue)
     last = W + ((K // G) - 1) * G if K >= 2 * G else W + K
     n_br = min(G, max(1, K // 20))
-    return "all" if last + G - n_br <= i < last + G else ("eager" if last <= i < last + G else None)
+    # (the group's other steps bracket the dominant launch only: more samples of the kernel the
+    # roofline is quoted on for one event pair each)
+    return "all" if last + G - n_br <= i < last + G else ("rk_adam_multi" if last <= i < last + G else None)
 
   def start():
     eng = rec._engine()
