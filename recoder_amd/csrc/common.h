@@ -40,6 +40,22 @@ int rk_adam_multi_at(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part
                      const void *table, int32_t tab_stride, const int32_t *tab_slots,
                      int64_t *cursor_next, int32_t advance, void *stream);
 
+// small dense contraction C[M,N] = act(A . B + bias) (csrc/linear.hip: the hidden nn.Linear stack)
+//   amode 0: A(m,k) = A[m * lda + k]     amode 1: A(m,k) = A[k * lda + m]
+//   bmode 0: B(k,n) = B[n * ldb + k]     bmode 1: B(k,n) = B[k * ldb + n]
+struct rk_small_gemm_t {
+  const float *A; int lda, amode;
+  const float *B; int ldb, bmode;
+  int M, N, K;
+  float *C; int ldc;
+  const float *bias;          // per output column, nullable
+  int act, accumulate;        // C = act(...) (+ C if accumulate)
+};
+bool rk_small_gemm_fits(int M, int N, int K);
+int rk_small_gemm(const rk_small_gemm_t *g, void *stream);
+// dY <- dY * act'(Y) in place, db[c] = column sums of the result ([rows, cols] row-major)
+int rk_act_grad_colsum(float *dY, const float *Y, int rows, int cols, int act, float *db, void *stream);
+
 // ---------------------------------------------------------------- activations
 // y = act(x);  derivative expressed through y (what autograd of torch.tanh /
 // sigmoid / relu / selu / elu evaluates to for the saved output).

@@ -1386,6 +1386,13 @@ extern "C" int rk_linear_fwd(const float *X, const float *W, const float *b, int
                              void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B == 0) return 0;
+  if (rk_small_gemm_fits(B, N, K) && g_gemm_probe == nullptr) {
+    rk_small_gemm_t g = {};
+    g.A = X; g.lda = K; g.amode = 0;
+    g.B = W; g.ldb = w_transposed ? N : K; g.bmode = w_transposed ? 1 : 0;
+    g.M = B; g.N = N; g.K = K; g.C = Y; g.ldc = N; g.bias = b; g.act = act;
+    return rk_small_gemm(&g, stream_);
+  }
   GemmP p = {};
   p.probe = g_gemm_probe;
   p.A = X; p.lda = K;
@@ -1406,10 +1413,31 @@ extern "C" int rk_linear_bwd(float *dY, const float *Y, const float *X, const fl
                              float *dW, int32_t dw_accumulate, float *db, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B == 0) return 0;
-  int rc = rk_act_grad(dY, Y, (int64_t)B * N, act, stream_);
+  int rc = db ? rk_act_grad_colsum(dY, Y, B, N, act, db, stream_)
+              : rk_act_grad(dY, Y, (int64_t)B * N, act, stream_);
   if (rc) return rc;
-  if (db) { rc = rk_colsum(dY, B, N, N, nullptr, db, stream_); if (rc) return rc; }
   const int ldw = w_transposed ? N : K;
+  const bool small = g_gemm_probe == nullptr && rk_small_gemm_fits(B, K, N) &&
+                     rk_small_gemm_fits(w_transposed ? K : N, w_transposed ? N : K, B);
+  if (small) {
+    if (dX) {  // dX[B,K] = dY[B,N] . Weff[N,K]: reduction over N
+      rk_small_gemm_t g = {};
+      g.A = dY; g.lda = N; g.amode = 0;
+      g.B = W; g.ldb = ldw; g.bmode = w_transposed ? 0 : 1;   // W[N,K]: k-major; Wst[K,N]: N contiguous
+      g.M = B; g.N = K; g.K = N; g.C = dX; g.ldc = K; g.act = RK_ACT_NONE;
+      rc = rk_small_gemm(&g, stream_);
+      if (rc) return rc;
+    }
+    if (dW) {  // reduction over the B rows: both operands k-major
+      rk_small_gemm_t g = {};
+      g.amode = 1; g.bmode = 1; g.K = B; g.act = RK_ACT_NONE; g.accumulate = dw_accumulate; g.C = dW;
+      if (!w_transposed) { g.A = dY; g.lda = N; g.B = X; g.ldb = K; g.M = N; g.N = K; g.ldc = K; }   // dW[N,K] = dY^T . X
+      else               { g.A = X; g.lda = K; g.B = dY; g.ldb = N; g.M = K; g.N = N; g.ldc = N; }   // dWst[K,N] = X^T . dY
+      rc = rk_small_gemm(&g, stream_);
+      if (rc) return rc;
+    }
+    return 0;
+  }
   if (dX) {  // dX[B,K] = dY[B,N] . Weff[N,K]
     GemmP p = {};
   p.probe = g_gemm_probe;

@@ -1413,3 +1413,51 @@ def test_topk_tie_rule_and_strip_merge():
   check(lib.rk_topk_masked(cval.data_ptr(), B, ns * k, ns * k, None, 0, k, pos.data_ptr(), None,
                            current_stream()), "rk_topk_masked")
   assert np.array_equal(torch.gather(cidx, 1, pos).cpu().numpy(), want)
+
+
+# --------------------------------------------------------------------------
+# hidden nn.Linear stack (reference nn.py:242-249): the C-ABI entry points against torch fp64
+# --------------------------------------------------------------------------
+@pytest.mark.parametrize("B,N,K,wt,act,acc", [
+  (500, 200, 200, 0, "tanh", 0), (500, 200, 200, 1, "tanh", 1),      # C3's layers (csrc/linear.hip)
+  (37, 129, 77, 0, "sigmoid", 0), (37, 129, 77, 1, "relu", 1),        # nothing aligned, ragged tiles
+  (1, 8, 4, 0, "none", 0), (64, 32, 600, 0, "selu", 0), (300, 50, 30, 1, "elu", 0),
+  (33, 1100, 40, 0, "tanh", 0), (33, 40, 1100, 1, "tanh", 1),         # past the small kernel: LDS-tiled path
+])
+def test_linear_layer_entry_points_match_torch(B, N, K, wt, act, acc):
+  from recoder_amd import _lib
+  from recoder_amd._lib import ACT, check, ptr
+  from recoder_amd.device import current_stream
+  lib = _lib.load()
+  g = torch.Generator(device="cpu").manual_seed(B * 7 + N * 3 + K)
+  f = lambda *s: torch.randn(*s, generator=g, dtype=torch.float32)
+  X, W, b, dY0, dW0 = f(B, K), f(N, K) * 0.2, f(N) * 0.1, f(B, N), f(N, K)
+  Wd = (W.t().contiguous() if wt else W).to(dev())          # wt: the layer is given as [K, N]
+  Xd, bd = X.to(dev()), b.to(dev())
+  Y = torch.empty(B, N, device=dev())
+  st = current_stream()
+  a = ACT[act]
+  check(lib.rk_linear_fwd(ptr(Xd), ptr(Wd), ptr(bd), B, N, K, wt, a, ptr(Y), st), "rk_linear_fwd")
+  pre = X.double() @ W.double().t() + b.double()
+  fn = dict(tanh=torch.tanh, sigmoid=torch.sigmoid, relu=torch.relu, selu=torch.selu,
+            elu=torch.nn.functional.elu, none=lambda x: x)[act]
+  pre.requires_grad_(True)
+  ref = fn(pre)
+  scale = max(1.0, float(K) ** 0.5)
+  assert torch.allclose(Y.cpu().double(), ref.detach(), rtol=1e-5, atol=2e-6 * scale)
+  # backward: dY is overwritten with dY * act'(Y); dX, dW (optionally accumulated), db
+  gpre, = torch.autograd.grad(ref, pre, dY0.double())
+  dY = dY0.to(dev()).clone()
+  dX = torch.empty(B, K, device=dev())
+  dWd = ((dW0.t().contiguous() if wt else dW0).to(dev()).clone() if acc
+         else torch.empty(K, N, device=dev()) if wt else torch.empty(N, K, device=dev()))
+  db = torch.empty(N, device=dev())
+  check(lib.rk_linear_bwd(ptr(dY), ptr(Y), ptr(Xd), ptr(Wd), B, N, K, wt, a, ptr(dX), ptr(dWd), acc, ptr(db),
+                          st), "rk_linear_bwd")
+  tol = dict(rtol=1e-4, atol=3e-6 * max(1.0, float(max(B, N)) ** 0.5))
+  assert torch.allclose(dY.cpu().double(), gpre, rtol=1e-4, atol=1e-6)
+  assert torch.allclose(dX.cpu().double(), gpre @ W.double(), **tol)
+  want_dW = gpre.t() @ X.double() + (dW0.double() if acc else 0.0)
+  got_dW = dWd.cpu().double()
+  assert torch.allclose(got_dW.t() if wt else got_dW, want_dW, **tol)
+  assert torch.allclose(db.cpu().double(), gpre.sum(0), **tol)
