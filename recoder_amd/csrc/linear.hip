@@ -9,11 +9,13 @@
 //   * one workgroup per 32 x 32 output tile (4x the workgroups), its four waves SPLIT K: wave w
 //     takes the 8-deep k-blocks w, w + 4, ...; the four accumulators are summed through LDS in wave
 //     order (deterministic) and every wave finishes 8 rows of the tile;
-//   * no LDS staging: the fp32 MFMA takes ONE value per lane and operand (A: row = lane % 32,
-//     k = lane / 32; B: k = lane / 32, column = lane % 32), so a lane loads the four k's of its
-//     half of a k-block straight from global memory -- one 16-byte load where K is the contiguous
-//     dimension, four coalesced 4-byte loads where the row / column index is -- and eight k-blocks
-//     are in flight per wave before the first MFMA issues;
+//   * operands in the layout the fp32 MFMA wants (ONE value per lane: A row = lane % 32, k = lane / 32;
+//     B k = lane / 32, column = lane % 32; a lane takes the four k's of its half of a k-block):
+//     a k-major operand ([K, rows]) straight from global memory -- 32 consecutive lanes read 128
+//     consecutive bytes -- and a K-contiguous one ([rows, K]) through a [32, 128]-float LDS panel
+//     that is fetched with consecutive lanes on consecutive 16 bytes (a lane-per-row fetch of it
+//     put 64 cache lines in flight per load instruction: 11 us for the forward product instead of
+//     7 for dW); the next chunk's loads are issued before the MFMAs of the current one;
 //   * the bias is fetched before the k-loop.
 //
 // Which k a (step, lane half) pair carries is free as long as both operands agree; the sums are
@@ -24,42 +26,64 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int SG_U = 8;      // k-blocks (8 k each) in flight per wave
+constexpr int SG_KC = 128;             // k per chunk: 16 k-blocks of 8, four per wave
+constexpr int SG_LD = SG_KC + 4;       // LDS row stride in floats (an odd number of 16-byte slots)
 
-// the lane's 4 values k .. k+3 of one operand row / column `rc` (clamped by the caller):
-//   MODE 0: X[rc * ld + k]  (K contiguous; one 16-byte load when `vec`)
-//   MODE 1: X[k * ld + rc]  (k-major)
-// entries with k >= K read a clamped (valid) address and are zeroed
-template <int MODE>
-__device__ __forceinline__ void load_quad(const float *__restrict__ X, int64_t ld, int rc, int k, int K,
-                                          bool vec, float (&v)[4]) {
-  if (MODE == 0) {
-    const float *row = X + (int64_t)rc * ld;
+// one K-contiguous operand panel [32 rows, SG_KC] of chunk `kc0`, fetched with consecutive lanes on
+// consecutive 16 bytes of a row (thread t, i: float4 number t + 256 i of the panel); k >= K -> 0
+__device__ __forceinline__ void panel_load(const float *__restrict__ X, int64_t ld, int row0, int rows,
+                                           int kc0, int K, bool vec, int tid, float4 (&v)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i;
+    const int rr = idx >> 5, k = kc0 + ((idx & 31) << 2);
+    const float *row = X + (int64_t)min(row0 + rr, rows - 1) * ld;
     if (vec) {
       const float4 q = *reinterpret_cast<const float4 *>(row + min(k, K - 4));
-      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+      v[i] = (k < K) ? q : make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
+      float e[4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) v[s] = row[min(k + s, K - 1)];
+      for (int s = 0; s < 4; ++s) e[s] = (k + s < K) ? row[min(k + s, K - 1)] : 0.f;
+      v[i] = make_float4(e[0], e[1], e[2], e[3]);
     }
-  } else {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) v[s] = X[(int64_t)min(k + s, K - 1) * ld + rc];
   }
+}
+__device__ __forceinline__ void panel_store(float *lds, int tid, const float4 (&v)[4]) {
 #pragma unroll
-  for (int s = 0; s < 4; ++s) v[s] = (k + s < K) ? v[s] : 0.f;
+  for (int i = 0; i < 4; ++i) {
+    const int idx = tid + 256 * i;
+    *reinterpret_cast<float4 *>(lds + (idx >> 5) * SG_LD + ((idx & 31) << 2)) = v[i];
+  }
+}
+// a k-major operand X[k * ld + rc]: the lane's quads of the wave's four k-blocks of chunk `kc0`,
+// straight from global memory (32 consecutive lanes = 128 consecutive bytes)
+__device__ __forceinline__ void direct_load(const float *__restrict__ X, int64_t ld, int rc, int kc0, int K,
+                                            int w, int hh, float (&v)[4][4]) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int k = kc0 + 8 * (w + 4 * u) + 4 * hh + s;
+      const float x = X[(int64_t)min(k, K - 1) * ld + rc];
+      v[u][s] = (k < K) ? x : 0.f;
+    }
 }
 
 template <int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void small_gemm_kernel(rk_small_gemm_t g, int tiles_n, int vec_a,
                                                          int vec_b) {
-  __shared__ float red[4][16][64];
+  // staging panels of the K-contiguous operands; the cross-wave reduction reuses the space
+  constexpr int PANEL = 32 * SG_LD;
+  constexpr int N_PANEL = (AMODE == 0 ? 1 : 0) + (BMODE == 0 ? 1 : 0);
+  constexpr int SM = (N_PANEL * PANEL > 4 * 16 * 64) ? N_PANEL * PANEL : 4 * 16 * 64;
+  __shared__ __attribute__((aligned(16))) float smem[SM];
+  float *As = smem, *Bs = smem + (AMODE == 0 ? PANEL : 0);
   const int mt = blockIdx.x / tiles_n, nt = blockIdx.x % tiles_n;
   const int m0 = mt * 32, n0 = nt * 32;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int K = g.K;
-  const int nblk = (K + 7) >> 3;
   const int col = n0 + r;
   const float bv = (g.bias != nullptr && col < g.N) ? g.bias[col] : 0.f;
   const int am = min(m0 + r, g.M - 1), bn = min(col, g.N - 1);
@@ -67,21 +91,58 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(rk_small_gemm_t g, int 
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  for (int j0 = w; j0 < nblk; j0 += 4 * SG_U) {
-    float a[SG_U][4], b[SG_U][4];
+  float4 pa[4], pb[4];          // the next chunk's panels on their way to LDS
+  float da[4][4], db[4][4];     // the next chunk's quads of a k-major operand
+  if (AMODE == 0) panel_load(g.A, g.lda, m0, g.M, 0, K, vec_a != 0, tid, pa);
+  else direct_load(g.A, g.lda, am, 0, K, w, hh, da);
+  if (BMODE == 0) panel_load(g.B, g.ldb, n0, g.N, 0, K, vec_b != 0, tid, pb);
+  else direct_load(g.B, g.ldb, bn, 0, K, w, hh, db);
+  for (int kc0 = 0; kc0 < K; kc0 += SG_KC) {
+    if (AMODE == 0 || BMODE == 0) {
+      if (kc0) __syncthreads();                 // the previous chunk's reads are done
+      if (AMODE == 0) panel_store(As, tid, pa);
+      if (BMODE == 0) panel_store(Bs, tid, pb);
+      __syncthreads();
+    }
+    float ca[4][4], cb[4][4];
+    if (AMODE == 1) {
 #pragma unroll
-    for (int u = 0; u < SG_U; ++u) {
-      const int k = 8 * (j0 + 4 * u) + 4 * hh;       // (blocks past the end: all four k >= K -> zeros)
-      load_quad<AMODE>(g.A, g.lda, am, k, K, vec_a != 0, a[u]);
-      load_quad<BMODE>(g.B, g.ldb, bn, k, K, vec_b != 0, b[u]);
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ca[u][s] = da[u][s];
+    }
+    if (BMODE == 1) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) cb[u][s] = db[u][s];
+    }
+    // (past the end: clamped addresses, all zeros, never used)
+    if (AMODE == 0) panel_load(g.A, g.lda, m0, g.M, kc0 + SG_KC, K, vec_a != 0, tid, pa);
+    else direct_load(g.A, g.lda, am, kc0 + SG_KC, K, w, hh, da);
+    if (BMODE == 0) panel_load(g.B, g.ldb, n0, g.N, kc0 + SG_KC, K, vec_b != 0, tid, pb);
+    else direct_load(g.B, g.ldb, bn, kc0 + SG_KC, K, w, hh, db);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int kb = 8 * (w + 4 * u) + 4 * hh;        // the lane's quad inside the chunk
+      if (AMODE == 0) {
+        const float4 q = *reinterpret_cast<const float4 *>(As + r * SG_LD + kb);
+        ca[u][0] = q.x; ca[u][1] = q.y; ca[u][2] = q.z; ca[u][3] = q.w;
+      }
+      if (BMODE == 0) {
+        const float4 q = *reinterpret_cast<const float4 *>(Bs + r * SG_LD + kb);
+        cb[u][0] = q.x; cb[u][1] = q.y; cb[u][2] = q.z; cb[u][3] = q.w;
+      }
     }
 #pragma unroll
-    for (int u = 0; u < SG_U; ++u)
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int s = 0; s < 4; ++s)
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][s], b[u][s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[u][s], cb[u][s], acc, 0, 0, 0);
   }
   // ---- the four K-slices of the tile: summed in wave order, wave w finishes registers 4w .. 4w+3
+  __syncthreads();
+  float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(smem);
 #pragma unroll
   for (int i = 0; i < 16; ++i) red[w][i][lane] = acc[i];
   __syncthreads();
@@ -99,43 +160,45 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(rk_small_gemm_t g, int 
   }
 }
 
-// dY <- dY * act'(Y) in place and db[c] = sum_r dY[r][c] of the result, in one pass: block = 64
-// columns x 16 row slices, 4 accumulators per thread, combined in a fixed order
+// dY <- dY * act'(Y) in place and db[c] = sum_r dY[r][c] of the result, in one pass: block = 32
+// columns x 32 row slices; a thread issues the loads of all its (<= 16 per round) rows before the
+// first store -- dY is read and written, so a load behind a store would wait for it -- and the
+// slices are combined in a fixed order
+constexpr int AG_R = 16;
 __global__ __launch_bounds__(1024) void act_grad_colsum_kernel(float *__restrict__ dY,
                                                                const float *__restrict__ Y, int rows,
                                                                int cols, int act, float *__restrict__ db) {
-  __shared__ float part[16][64];
-  const int lc = threadIdx.x & 63, s = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lc;
-  const int per = (rows + 15) >> 4;
-  const int r0 = s * per, r1 = min(rows, r0 + per);
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  __shared__ float part[32][33];
+  const int lc = threadIdx.x & 31, s = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + lc;
+  const int per = (rows + 31) >> 5;
+  const int r1 = min(rows, (s + 1) * per);
+  float a0 = 0.f, a1 = 0.f;
   if (c < cols) {
-    int r = r0;
-    for (; r + 3 < r1; r += 4) {
-      float v[4];
+    for (int r0 = s * per; r0 < r1; r0 += AG_R) {
+      float g[AG_R], y[AG_R];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int64_t o = (int64_t)(r + e) * cols + c;
-        v[e] = dY[o] * rk_act_dy(Y[o], act);
+      for (int e = 0; e < AG_R; ++e) {
+        const int64_t o = (int64_t)min(r0 + e, r1 - 1) * cols + c;
+        g[e] = dY[o];
+        y[e] = Y[o];
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dY[(int64_t)(r + e) * cols + c] = v[e];
-      a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
-    }
-    for (; r < r1; ++r) {
-      const int64_t o = (int64_t)r * cols + c;
-      const float v = dY[o] * rk_act_dy(Y[o], act);
-      dY[o] = v;
-      a0 += v;
+      for (int e = 0; e < AG_R; ++e) {
+        const float v = g[e] * rk_act_dy(y[e], act);
+        if (r0 + e < r1) {
+          dY[(int64_t)(r0 + e) * cols + c] = v;
+          if (e & 1) a1 += v; else a0 += v;
+        }
+      }
     }
   }
-  part[s][lc] = (a0 + a1) + (a2 + a3);
+  part[s][lc] = a0 + a1;
   __syncthreads();
   if (s == 0 && c < cols) {
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) t += part[i][lc];
+    for (int i = 0; i < 32; ++i) t += part[i][lc];
     db[c] = t;
   }
 }
@@ -170,7 +233,7 @@ int rk_small_gemm(const rk_small_gemm_t *g, void *stream_) {
 int rk_act_grad_colsum(float *dY, const float *Y, int rows, int cols, int act, float *db, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (cols == 0) return 0;
-  RK_LAUNCH(act_grad_colsum_kernel, dim3(rk_cdiv(cols, 64)), dim3(1024), 0, stream, dY, Y, rows, cols, act, db);
+  RK_LAUNCH(act_grad_colsum_kernel, dim3(rk_cdiv(cols, 32)), dim3(1024), 0, stream, dY, Y, rows, cols, act, db);
   RK_CHECK_LAUNCH("act_grad_colsum");
   return 0;
 }

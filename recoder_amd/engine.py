@@ -460,7 +460,10 @@ class FusedEngine:
     # ---- dZ = dO . W_de[T] and everything upstream of it ----
     W_de, _ = self._decoder_params()
     simple = (self.kind == "ae" and self.nl == 0 and not self.drop_active)
-    dz = self.denc[0] if simple else self.dbott
+    # gradient w.r.t. the decoder's input: straight into the encoder side's buffer unless the
+    # bottleneck dropout has to be undone on the way (MF: dbott is the gathered user rows' gradient)
+    bott_grad = self.denc[self.nl] if (self.kind == "ae" and not self.drop_active) else self.dbott
+    dz = bott_grad
     if self.kind == "ae" and self.nl > 0:
       dz = self.ddec[self.nl - 1]
     fuse_act = simple and ip is None        # act' folded into the split-K reduce
@@ -478,7 +481,7 @@ class FusedEngine:
       for i in range(self.nl - 1, -1, -1):
         layer = m.decoding_layers[i]
         x = self.dec[i - 1] if i > 0 else self.dec_in
-        dx = self.ddec[i - 1] if i > 0 else self.dbott
+        dx = self.ddec[i - 1] if i > 0 else bott_grad
         if m.is_constrained:
           j = self.nl - 1 - i
           w, wt, gw, acc = m.encoding_layers[j].weight, 1, self.g_enc_w[j], 0
@@ -487,13 +490,12 @@ class FusedEngine:
         check(lib.rk_linear_bwd(ptr(self.ddec[i]), ptr(self.dec[i]), ptr(x), ptr(w), B, rh[i + 1],
                                 rh[i], wt, self.act, ptr(dx), ptr(gw), acc, ptr(self.g_dec_b[i]),
                                 stream), "rk_linear_bwd")
-      if self.nl > 0 or self.drop_active:
+      if self.drop_active:
         # gradient w.r.t. the bottleneck activation: undo dropout, into denc[nl]
         n = B * self.h[-1]
-        if self.drop_active:
-          check(lib.rk_dropout(ptr(self.dbott), ptr(keep_drop), n, self.h[-1],
-                               float(m.dropout_prob), self.seed ^ 0xd0d0, self.rng_step, stream),
-                "rk_dropout")
+        check(lib.rk_dropout(ptr(self.dbott), ptr(keep_drop), n, self.h[-1],
+                             float(m.dropout_prob), self.seed ^ 0xd0d0, self.rng_step, stream),
+              "rk_dropout")
         self.denc[self.nl][:n].copy_(self.dbott[:n])
       # encoder Linear stack, last to first
       for i in range(self.nl - 1, -1, -1):
