@@ -334,15 +334,16 @@ def main():
   global_rows = B * world if multi else B
   value = K * global_rows / dt              # users consumed by all ranks per second
 
-  # multi-GPU runs: the OTHER exact formulation (item parallel) timed the same
-  # way right behind the graded one, reported inside the same JSON line (config.alt_item_parallel)
-  alt = None
-  if multi and (world > 1 or os.environ.get("RK_BENCH_ALT") == "1") and os.environ.get("RK_BENCH_ALT") != "0" \
-      and os.environ.get("RK_PARALLEL", "users") in ("users", "auto"):
-    try:
-      alt = alt_item_parallel(cfg, csr, B, W, K, world, rank, device, sync_all)
-    except Exception as e:          # noqa: BLE001 -- never lose the graded line to the extra one
-      alt = {"error": "%s: %s" % (type(e).__name__, e)}
+  want_alt = multi and (world > 1 or os.environ.get("RK_BENCH_ALT") == "1") and \
+      os.environ.get("RK_BENCH_ALT") != "0" and os.environ.get("RK_PARALLEL", "users") in ("users", "auto")
+  out = None
+
+  def emit():
+    # (RCCL writes its version banner through C stdio, which is fully buffered on a pipe and would
+    # come out AFTER this line at exit: flush it first, so that the JSON is the last line)
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    print(json.dumps(out), flush=True)
 
   if rank == 0:
     # per-step n_b / nnz of (up to 50 of) the timed steps: host recomputation, outside the timing
@@ -443,18 +444,40 @@ def main():
                  "first_loss": float(losses[0]), "last_loss": float(losses[-1]),
                  "host_enqueue_ms_per_step": T["enqueue"] / K * 1e3,
                  "graph_replay": bool(getattr(rec, "_graph_stepper", None) is not None),
-                 "steps_per_graph": G, "alt_item_parallel": alt},
+                 "steps_per_graph": G, "alt_item_parallel": None},
       "roofline": roofline,
     }
     if same_dev:
       out["INVALID"] = "RK_BENCH_ONE_GPU_GLOO: all ranks share one GPU, gloo collectives (a code-path test)"
     if world == 1 and not multi and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline(cfg, csr, args.cpu_steps)
-    # (RCCL writes its version banner through C stdio, which is fully buffered on a pipe and would
-    # come out AFTER this line at exit: flush it first, so that the JSON is the last line)
-    import ctypes
-    ctypes.CDLL(None).fflush(None)
-    print(json.dumps(out), flush=True)
+  if want_alt:
+    # multi-GPU runs: the OTHER exact formulation (item parallel) timed the same
+    # way right behind the graded one and reported inside the same JSON line
+    # (config.alt_item_parallel).  It must never cost the graded line: the line is complete before
+    # it starts, an exception becomes an "error" entry, and a watchdog on EVERY rank ends the
+    # process (rank 0 printing the line first) if the extra run does not come back -- one rank
+    # failing inside it leaves the others waiting in a collective.
+    import threading
+    limit = float(os.environ.get("RK_BENCH_ALT_TIMEOUT", "300"))
+    finished = threading.Event()
+
+    def watchdog():
+      if not finished.wait(limit):
+        if rank == 0:
+          out["config"]["alt_item_parallel"] = {"error": "no result after %.0f s (abandoned)" % limit}
+          emit()
+        os._exit(0)
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+      alt = alt_item_parallel(cfg, csr, B, W, K, world, rank, device, sync_all)
+    except Exception as e:          # noqa: BLE001
+      alt = {"error": "%s: %s" % (type(e).__name__, e)}
+    finished.set()
+    if rank == 0:
+      out["config"]["alt_item_parallel"] = alt
+  if rank == 0:
+    emit()
   if multi:
     dist.destroy_process_group()
 

@@ -45,15 +45,23 @@ def test_single_gpu_line():
   assert d["config"]["api"] == "Recoder.train" and d["config"]["graph_replay"] is True
 
 
-def test_two_rank_code_path_on_one_gpu():
+@pytest.mark.parametrize("abandon_alt", [False, True])
+def test_two_rank_code_path_on_one_gpu(abandon_alt):
+  """abandon_alt: the extra item-parallel run behind the graded one is cut off by its watchdog
+  (as if it hung): the graded line must still come out, last on stdout, and every rank exit 0."""
   env = dict(os.environ, RK_BENCH_ONE_GPU_GLOO="1", MASTER_ADDR="127.0.0.1")
+  if abandon_alt:
+    env["RK_BENCH_ALT_TIMEOUT"] = "0.05"
   cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-         "--master-addr", "127.0.0.1", "--master-port", "29597", "bench.py", "--gpus", "2",
-         "--steps", "6", "--warmup", "3"]
+         "--master-addr", "127.0.0.1", "--master-port", "29598" if abandon_alt else "29597", "bench.py",
+         "--gpus", "2", "--steps", "6", "--warmup", "3"]
   r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
   assert r.returncode == 0, r.stderr[-3000:]
   d = check_line(r.stdout, 2, 6, 3)
   assert d["config"]["global_batch"] == 2 * d["config"]["batch_size_per_gpu"]
   assert "INVALID" in d and d["config"]["parallelism"].startswith("dp2")
   alt = d["config"]["alt_item_parallel"]
-  assert alt and "error" not in alt and alt["value"] > 0 and alt["parallelism"].startswith("ip2")
+  if abandon_alt:
+    assert alt and "abandoned" in alt["error"]
+  else:
+    assert alt and "error" not in alt and alt["value"] > 0 and alt["parallelism"].startswith("ip2")
