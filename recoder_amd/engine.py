@@ -107,6 +107,7 @@ class FusedEngine:
     self._time_samples = []                # (entry name, event0, event1)
     self._time_keep = []
     self._gb_lazy = None
+    self._pending_loss = None
     self.item_parallel = None              # parallel.ItemParallel when the items are sharded
     self._cstep = None
     self._c_calls = 0
@@ -236,7 +237,9 @@ class FusedEngine:
   # rk_adam_multi, six per launch (the same per-element arithmetic as rk_adam_table / rk_adam_rows /
   # rk_adam_dense; a hidden-stack model has ~11 parameter tensors, i.e. ~11 launches and FFI calls
   # otherwise).  Index arrays that are int64 (MF user rows) go through rk_adam_rows directly.
-  def _job(self, s, n_rows, h, g, pos=None, rows=None, n_dev=None, n_cap=0):
+  def _job(self, s, n_rows, h, g, pos=None, rows=None, n_dev=None, n_cap=0, parts=None):
+    """parts = (pointer, g_parts, g_stride, gstride_dev, gparts_dev): the gradient is the sum, in
+    order, of that many partial arrays (rk_adam_job_t) instead of the single array `g`."""
     from ._lib import RkAdamJob
     s.step += 1
     lr, b1, b2, eps = self._adam_args(s)
@@ -247,6 +250,8 @@ class FusedEngine:
     a.step, a.sparse = s.step, 1 if rows is not None else 0
     j.n_rows, j.h, j.g, j.g_parts = n_rows, h, ptr(g), 1
     j.pos, j.rows, j.n_dev, j.n_cap = ptr(pos), ptr(rows), ptr(n_dev), n_cap
+    if parts is not None:
+      j.g, j.g_parts, j.g_stride, j.gstride_dev, j.gparts_dev = parts
     if s.p is self._decoder_params()[0]:       # the table the decoder GEMMs read: keep its bound
       j.amax_out = self.ranges.data_ptr() + 64 * 4
     self._jobs.append(j)
@@ -257,15 +262,24 @@ class FusedEngine:
     for i in range(0, len(jobs), 6):
       chunk = jobs[i:i + 6]
       arr = (RkAdamJob * len(chunk))(*chunk)
-      check(self.lib.rk_adam_multi(arr, len(chunk), None, 0, 1.0, None, stream), "rk_adam_multi")
+      pend = self._pending_loss if i + 6 >= len(jobs) else None
+      if pend is not None:
+        # the deferred reduction of the step's loss partials rides on the sweep (as in rk_ae_train_step)
+        n_part, denom, out = pend
+        self._pending_loss = None
+        check(self.lib.rk_adam_multi(arr, len(chunk), ptr(self.loss_part), n_part, denom, ptr(out), stream),
+              "rk_adam_multi")
+      else:
+        check(self.lib.rk_adam_multi(arr, len(chunk), None, 0, 1.0, None, stream), "rk_adam_multi")
 
-  def _adam_table(self, s, pos, G, h, n_rows, stream):
-    self._job(s, n_rows, h, G, pos=pos)
+  def _adam_table(self, s, pos, G, h, n_rows, stream, parts=None):
+    self._job(s, n_rows, h, G, pos=pos, parts=parts)
 
-  def _adam_rows(self, s, idx32, idx64, n_dev, n_cap, G, h, stream):
+  def _adam_rows(self, s, idx32, idx64, n_dev, n_cap, G, h, stream, parts=None):
     if idx32 is not None and n_dev is not None:
-      self._job(s, 0, h, G, rows=idx32, n_dev=n_dev, n_cap=n_cap)
+      self._job(s, 0, h, G, rows=idx32, n_dev=n_dev, n_cap=n_cap, parts=parts)
       return
+    assert parts is None
     s.step += 1
     lr, b1, b2, eps = self._adam_args(s)
     check(self.lib.rk_adam_rows(ptr(s.p), ptr(s.m), ptr(s.v), h, ptr(idx32), ptr(idx64), ptr(n_dev),
@@ -362,7 +376,7 @@ class FusedEngine:
     check(self.lib.rk_amax(ptr(z), n, ptr(self.ranges), stream), "rk_amax")
     return ptr(self.ranges)
 
-  def _loss(self, z, B, tgt, row_off, denom_rows, stream, out=None, ip=None):
+  def _loss(self, z, B, tgt, row_off, denom_rows, stream, out=None, ip=None, defer=False):
     """decode + loss; leaves dLoss/dLogits in self.dO. Returns device scalar.  ip: the
     block holds an item shard (parallel.ItemParallel) -- only the multinomial loss needs to
     know: its softmax statistics are combined over the ranks."""
@@ -392,6 +406,9 @@ class FusedEngine:
       n_part = B
     else:
       n_part = self.lib.rk_loss_partials(B, tgt.n_cap)     # all slots (unused ones hold 0)
+    if defer:        # (train_step: summed by the step's Adam launch, see _flush_jobs)
+      self._pending_loss = (n_part, float(denom_rows), out)
+      return out
     check(lib.rk_loss_reduce(ptr(self.loss_part), n_part, float(denom_rows), ptr(out), stream),
           "rk_loss_reduce")
     return out
@@ -442,19 +459,28 @@ class FusedEngine:
     else:
       users = blk.users[row_off:row_off + B]
       z = self._mf_forward(users, B, keep_drop, True, stream)
-    loss = self._loss(z, B, tb, row_off, rows, stream, out, ip=ip)
+    # single process: nothing has to exist as an array of its own for an exchange, so the small
+    # reductions of the step ride on its Adam launch as they do in rk_ae_train_step -- the loss
+    # partials, the decode epilogue's row-tile column sums (decoder bias gradient) and the K slabs
+    # of the bf16-pipe dW (three launches less)
+    tied = self.kind == "ae" and bool(m.is_constrained)
+    lazy = ip is None and self.allreduce is None
+    loss = self._loss(z, B, tb, row_off, rows, stream, out, ip=ip, defer=lazy)
     self._loss_target = loss
 
     # ---- dW = dO^T . z  (+ decoder bias gradient) ----
+    keep_slabs = lazy and not tied and self.split16 and self.ws_dw is not None
     if self.loss_id == LOSS_MNLL:
       # dO was produced by rk_mnll_finish: column sums need a pass over dO
-      self._dw(z, B, tb, self.gb_de, stream)
+      self._dw(z, B, tb, self.gb_de, stream, keep_slabs)
     else:
       # the loss epilogue already reduced dO per row tile: sum those few rows
-      check(lib.rk_colsum(ptr(self.gb_part), cdiv(B, self.row_tile), tb.n_cap, 0, ptr(tb.counts),
-                          ptr(self.gb_de), stream), "rk_colsum")
-      self._dw(z, B, tb, None, stream)
-    tied = self.kind == "ae" and bool(m.is_constrained)
+      if lazy:
+        self._gb_lazy = (cdiv(B, self.row_tile), tb)
+      else:
+        check(lib.rk_colsum(ptr(self.gb_part), cdiv(B, self.row_tile), tb.n_cap, 0, ptr(tb.counts),
+                            ptr(self.gb_de), stream), "rk_colsum")
+      self._dw(z, B, tb, None, stream, keep_slabs)
     n_b_host = self.allreduce.n_b(blk) if self.allreduce is not None else None
 
     # ---- dZ = dO . W_de[T] and everything upstream of it ----
@@ -526,12 +552,20 @@ class FusedEngine:
     self._apply_updates(blk, row_off, B, stream, "all", tgt=tb)
     return loss
 
-  def _dw(self, z, B, blk, gb_de, stream):
+  def _dw(self, z, B, blk, gb_de, stream, keep_slabs=False):
     """G_de = dO^T . z (+ gb_de = colsum(dO) if asked): the bf16-pipe kernel (csrc/dw3.hip) unless
-    RK_GEMM_PREC=f32 keeps the contractions on the fp32 MFMA."""
+    RK_GEMM_PREC=f32 keeps the contractions on the fp32 MFMA.  keep_slabs: leave the K slabs
+    unsummed in the dW workspace of its own (the dZ product that follows reuses `ws`) for the Adam
+    sweep to add up."""
     h0 = self.h[0]
     self._dw_slabs = None
-    if self.split16:
+    self._ws_dw_live = False
+    if self.split16 and keep_slabs:
+      check(self.lib.rk_decode_bwd_dw3(ptr(self.dO), ptr(z), B, h0, blk.ref, None, ptr(gb_de),
+                                       ptr(self.ws_dw), None, stream), "rk_decode_bwd_dw3")
+      self._dw_slabs = (blk, B)
+      self._ws_dw_live = True
+    elif self.split16:
       check(self.lib.rk_decode_bwd_dw3(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(self.G_de), ptr(gb_de),
                                        ptr(self.ws), None, stream), "rk_decode_bwd_dw3")
     else:
@@ -795,13 +829,21 @@ class FusedEngine:
     dec = part in ("all", "decoder")
     enc = part in ("all", "encoder")
 
-    def table(name, G, b=None):
+    def table(name, G, b=None, parts=None):
       b = blk if b is None else b
       s = S[name]
       if s.sparse:
-        self._adam_rows(s, b.items, None, b.counts, b.n_cap, G, h0, stream)
+        self._adam_rows(s, b.items, None, b.counts, b.n_cap, G, h0, stream, parts=parts)
       else:
-        self._adam_table(s, b.pos, G, h0, n_items, stream)
+        self._adam_table(s, b.pos, G, h0, n_items, stream, parts=parts)
+
+    # gradients the step left as partial arrays (train_step, single process)
+    dw_parts = gb_parts = None
+    if dec and self._dw_slabs is not None and self._dw_slabs[0] is tb:
+      dw_parts = (self.lib.rk_dw3_slabs(ptr(self.ws_dw), self._dw_slabs[1], h0), self.lib.rk_dw3_max_splits(),
+                  tb.n_cap * h0, None, tb.counts.data_ptr() + 4 * 4)
+    if dec and self._gb_lazy is not None and self._gb_lazy[1] is tb:
+      gb_parts = (ptr(self.gb_part), self._gb_lazy[0], 0, tb.counts.data_ptr() + 2 * 4, None)
 
     if self.kind == "ae":
       en_w = "en_embedding_layer.weight"
@@ -812,7 +854,7 @@ class FusedEngine:
         if enc:
           table(en_w, self.G_en)
         if dec:
-          table("de_embedding_layer.weight", self.G_de, tb)
+          table("de_embedding_layer.weight", self.G_de, tb, dw_parts)
       if enc:
         self._adam_dense(S["_DynamicAutoencoder__en_linear_embedding_layer.bias"], self.gb_en, stream)
         for i in range(self.nl):
@@ -824,7 +866,7 @@ class FusedEngine:
       if dec:
         # decoder bias: a dense [n_items] gradient (index_select backward), wd = 0
         self._adam_table(S["_DynamicAutoencoder__de_linear_embedding_layer.bias"], tb.pos,
-                         self.gb_de, 1, n_items, stream)
+                         self.gb_de, 1, n_items, stream, parts=gb_parts)
     else:
       lib = self.lib
       if enc:
@@ -836,14 +878,14 @@ class FusedEngine:
           check(lib.rk_scatter_pos(ptr(self.pos_u), ptr(users), B, 0, stream), "rk_scatter_pos")
           self._adam_table(su, self.pos_u, self.dbott, h0, m.num_users, stream)
           if dec:
-            table("item_embedding_layer.weight", self.G_de, tb)
-            self._adam_table(S["bias"], tb.pos, self.gb_de, 1, n_items, stream)
+            table("item_embedding_layer.weight", self.G_de, tb, dw_parts)
+            self._adam_table(S["bias"], tb.pos, self.gb_de, 1, n_items, stream, parts=gb_parts)
             dec = False
           self._flush_jobs(stream)       # before the user-row map is cleared again
           check(lib.rk_scatter_pos(ptr(self.pos_u), ptr(users), B, 1, stream), "rk_scatter_pos")
       if dec:
-        table("item_embedding_layer.weight", self.G_de, tb)
-        self._adam_table(S["bias"], tb.pos, self.gb_de, 1, n_items, stream)
+        table("item_embedding_layer.weight", self.G_de, tb, dw_parts)
+        self._adam_table(S["bias"], tb.pos, self.gb_de, 1, n_items, stream, parts=gb_parts)
     self._flush_jobs(stream)
 
   # ------------------------------------------------------------- inference
