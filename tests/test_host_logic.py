@@ -146,3 +146,23 @@ def test_batch_metrics_equal_the_per_user_functions():
   assert M.batch_metrics(recs.tolist(), tm, [M.Recall(5), Mine("mine")]) is None
   ragged = [list(r[:K - (i % 2)]) for i, r in enumerate(recs)]
   assert M.batch_metrics(ragged, tm, [M.Recall(5)]) is None
+
+
+def test_epoch_order_is_drawn_on_one_thread_and_unchanged_by_it():
+  """The permutation of an epoch is torch.randperm under a private generator (reference
+  data.py:124-136); ours runs it with torch's intra-op team reduced to the calling thread (the
+  team, sized by the host's cores, gets the whole process throttled inside a CPU-quota container)
+  and must restore the setting and draw the same permutation."""
+  import torch
+  from recoder_amd.data import epoch_user_order
+  n0 = torch.get_num_threads()
+  torch.manual_seed(11)
+  got = epoch_user_order(50000)
+  assert torch.get_num_threads() == n0
+  torch.manual_seed(11)
+  torch.empty((), dtype=torch.int64).random_()
+  seed = int(torch.empty((), dtype=torch.int64).random_().item())
+  g = torch.Generator()
+  g.manual_seed(seed)
+  want = torch.randperm(50000, generator=g).numpy()
+  assert np.array_equal(got, want)

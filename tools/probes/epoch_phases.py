@@ -27,10 +27,10 @@ timed(M.Recoder, "_run_epoch_graph")
 timed(M.Recoder, "_sync_ranges")
 csr = synthetic.ml20m_like(seed=0)
 torch.manual_seed(0)
-rec = Recoder(model=DynamicAutoencoder([200], activation_type="tanh", noise_prob=0.5), use_cuda=True,
+rec = Recoder(model=DynamicAutoencoder([200], activation_type="tanh", noise_prob=0.5, sparse=os.environ.get("SPARSE") == "1"), use_cuda=True,
               optimizer_type="adam", loss="mse")
 ds = RecommendationDataset(csr)
-kw = dict(batch_size=500, lr=1e-3, weight_decay=2e-5, negative_sampling=True)
+kw = dict(batch_size=500, lr=1e-3, weight_decay=0.0 if os.environ.get("SPARSE") == "1" else 2e-5, negative_sampling=True)
 rec.train(ds, num_epochs=2, **kw)
 torch.cuda.synchronize(); T.clear()
 t0 = time.perf_counter()
