@@ -840,7 +840,8 @@ class FusedEngine:
     # gradients the step left as partial arrays (train_step, single process)
     dw_parts = gb_parts = None
     if dec and self._dw_slabs is not None and self._dw_slabs[0] is tb:
-      dw_parts = (self.lib.rk_dw3_slabs(ptr(self.ws_dw), self._dw_slabs[1], h0), self.lib.rk_dw3_max_splits(),
+      ws = self.ws_dw if self._ws_dw_live else self.ws
+      dw_parts = (self.lib.rk_dw3_slabs(ptr(ws), self._dw_slabs[1], h0), self.lib.rk_dw3_max_splits(),
                   tb.n_cap * h0, None, tb.counts.data_ptr() + 4 * 4)
     if dec and self._gb_lazy is not None and self._gb_lazy[1] is tb:
       gb_parts = (ptr(self.gb_part), self._gb_lazy[0], 0, tb.counts.data_ptr() + 2 * 4, None)
