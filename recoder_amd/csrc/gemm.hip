@@ -800,6 +800,9 @@ __global__ __launch_bounds__(RED_W * 64) void splitk_reduce_kernel(
   const int per = (ns + RED_W - 1) / RED_W;
   const int z1 = min(ns, (q + 1) * per);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  // (the activation values of the fused act' are fetched with the slabs, not behind the barrier)
+  float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (Zact && q == 0 && i < tot4) y = reinterpret_cast<const float4 *>(Zact)[i];
   if (i < tot4) {
     int z = q * per;
     for (; z + 8 <= z1; z += 8) {
@@ -823,7 +826,6 @@ __global__ __launch_bounds__(RED_W * 64) void splitk_reduce_kernel(
       s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
     }
     if (Zact) {
-      const float4 y = reinterpret_cast<const float4 *>(Zact)[i];
       s.x *= rk_act_dy(y.x, act); s.y *= rk_act_dy(y.y, act);
       s.z *= rk_act_dy(y.z, act); s.w *= rk_act_dy(y.w, act);
     }
