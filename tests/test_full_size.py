@@ -356,3 +356,40 @@ def test_c5_rank_shard_resident_generated_on_device():
   b = orc.collate(sub, users, 500, True)[0]
   want = o.train_step(b)
   assert abs(losses[0] - want) / abs(want) < 1e-5, (losses[0], want)
+
+
+def test_c5_batch_4096_equals_its_512_row_blocks():
+  """SURVEY 8d's second C5 batch size: B = 4096 over the 1 M-item catalogue (~336 k sampled items,
+  a 5.5 GB logit block).  No CPU oracle finishes that in seconds, so the size-independent property:
+  one batch of 4096 rows IS eight row blocks of 512 over the same item set (the reference's
+  num_sampling_users mechanism, data.py:216-249) -- the 4096-row kernels must give the mean of the
+  eight 512-row losses, and the first training step of batch_size 4096 that very loss."""
+  from recoder_amd import synthetic
+  from recoder_amd.device import Block, DeviceCSR
+  csr = synthetic.uniform(40000, 1000000, 100, seed=3)
+  cfg = dict(kind="ae", hidden_layers=[512], loss="mse", noise_prob=0.0, sparse=True, wd=0.0)
+  order = np.random.RandomState(9).permutation(csr.shape[0]).astype(np.int64)
+  rec, model, init, losses = _train(csr, cfg, 3, order, B=4096)
+  assert len(losses) == 3 and np.all(np.isfinite(losses))
+  # the same first batch through the evaluation-mode loss of a model at the initial weights
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder
+  m = DynamicAutoencoder(hidden_layers=[512], activation_type="tanh", noise_prob=0.0, sparse=True)
+  r = Recoder(model=m, use_cuda=True, optimizer_type="adam", loss="mse")
+  from recoder_amd.data import RecommendationDataset
+  r._Recoder__init_training(RecommendationDataset(csr), 1e-3, 0.0)
+  with torch.no_grad():
+    for k, v in m.named_parameters():
+      v.copy_(init[k].to(v.device))
+  m.eval()
+  eng = r._engine()
+  dcsr = DeviceCSR(csr)
+  users = order[:4096]
+  blk = Block(4096, int(np.diff(csr.indptr)[users].sum()), csr.shape[1])
+  blk.collate(dcsr, torch.from_numpy(users).to(dev()))
+  n_b = blk.host_n_b()
+  assert n_b == len(np.unique(csr[users].indices)) and n_b > 300000
+  whole = float(eng.compute_loss(blk, 0, 4096).item())
+  parts = [float(eng.compute_loss(blk, i * 512, 512).item()) for i in range(8)]
+  assert abs(whole - np.mean(parts)) / abs(whole) < 1e-5, (whole, parts)
+  assert abs(losses[0] - whole) / abs(whole) < 1e-5, (losses[0], whole)

@@ -32,6 +32,9 @@ CONFIGS = {
   "c5u": dict(data=lambda: synthetic.uniform(100000, 1000000, 100, seed=3),
               model=lambda: DynamicAutoencoder([512], activation_type="tanh", noise_prob=0.0, sparse=True),
               loss="mse", wd=0.0, note="C5-shaped 1M items (100k-user shard) AE[512] SparseAdam"),
+  "c5u4k": dict(data=lambda: synthetic.uniform(100000, 1000000, 100, seed=3), B=4096,
+                model=lambda: DynamicAutoencoder([512], activation_type="tanh", noise_prob=0.0, sparse=True),
+                loss="mse", wd=0.0, note="the same at B = 4096 (SURVEY 8d's second C5 batch size)"),
 }
 
 
@@ -42,6 +45,7 @@ def run(name, B=500):
   the start-up were what round 2 first reported: 70 ms that the container's CPU throttling (set off
   by the start-up's OpenMP teams) hit or missed at random."""
   c = CONFIGS[name]
+  B = c.get("B", B)
   csr = c["data"]()
   torch.manual_seed(0)
   rec = Recoder(model=c["model"](), use_cuda=True, optimizer_type="adam", loss=c["loss"])
