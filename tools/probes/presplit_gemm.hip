@@ -3,7 +3,7 @@
 // accumulated in fp32 on v_mfma_f32_32x32x16_f16 -- the arithmetic of gemm.hip's PREC_H3, without
 // the fp32 -> fp16-pair split in the k-loop (~150 VALU instructions per wave and k-tile there).
 // 128 x 128 tiles, 4 waves of 64 x 64 (8 LDS reads for 12 MFMAs per 16-deep k-step), BK = 32, register
-// prefetch of the next k-tile, plain fp32 store of C.  Sizes: the C5 shape at B = 4096 by default.
+// prefetch of the next k-tile into a second LDS stage (one barrier per tile), plain fp32 store of C.  Sizes: the C5 shape at B = 4096 by default.
 //   hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form -o /tmp/psg tools/probes/presplit_gemm.hip && /tmp/psg [M N K]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -20,8 +20,8 @@ constexpr int ROWB = 144;                 // LDS row: 64 B hi | 64 B lo | 16 B p
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void presplit_gemm(const _Float16 *__restrict__ Ah, const _Float16 *__restrict__ Al,
                                                      const _Float16 *__restrict__ Bh, const _Float16 *__restrict__ Bl,
                                                      float *__restrict__ C, int M, int N, int K, int tiles_n) {
-  __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * ROWB];
-  char *As = smem, *Bs = smem + BM * ROWB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // two stages of (BM + BN) rows
+  constexpr int STAGE = (BM + BN) * ROWB;
   // XCD-aware order as in gemm.hip: workgroup L runs on XCD L % 8; give each XCD a contiguous chunk
   const int total = gridDim.x, chunk = (total + 7) >> 3;
   const int t = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
@@ -58,41 +58,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     ra[i] = *reinterpret_cast<const uint4 *>(srcA[i] + (k0));          \
     rb[i] = *reinterpret_cast<const uint4 *>(srcB[i] + (k0));          \
   }
+#define SSTORE(buf)                                                                  \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                    \
+    *reinterpret_cast<uint4 *>(smem + (buf) * STAGE + dst[i]) = ra[i];               \
+    *reinterpret_cast<uint4 *>(smem + (buf) * STAGE + BM * ROWB + dst[i]) = rb[i];   \
+  }
   GLOAD(0);
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    __syncthreads();
+  SSTORE(0);
+  __syncthreads();
+  const int a_off = (wm * 64 + l31) * ROWB + lh * 16, b_off = BM * ROWB + (wn * 64 + l31) * ROWB + lh * 16;
+  int buf = 0;
+  for (int k0 = 0; k0 < K; k0 += BK, buf ^= 1) {
+    GLOAD(min(k0 + BK, K - BK));                 // the next tile, in flight under this one's MFMAs
+    const char *S = smem + buf * STAGE;
+    f16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];          // [k-step][tile]: all LDS reads of the tile up front
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<uint4 *>(As + dst[i]) = ra[i];
-      *reinterpret_cast<uint4 *>(Bs + dst[i]) = rb[i];
-    }
-    __syncthreads();
-    GLOAD(min(k0 + BK, K - BK));
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      f16x8 ah[2], al[2], bh[2], bl[2];
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const char *q = As + (wm * 64 + i * 32 + l31) * ROWB + ks * 32 + lh * 16;
-        ah[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q));
-        al[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q + 64));
-        const char *p = Bs + (wn * 64 + i * 32 + l31) * ROWB + ks * 32 + lh * 16;
-        bh[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(p));
-        bl[i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(p + 64));
+        const char *q = S + a_off + i * 32 * ROWB + ks * 32;
+        ah[ks][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q));
+        al[ks][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q + 64));
+        const char *p = S + b_off + i * 32 * ROWB + ks * 32;
+        bh[ks][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(p));
+        bl[ks][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(p + 64));
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+    for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
     }
+    SSTORE(buf ^ 1);                             // (last read in the previous iteration: one barrier per tile)
+    __syncthreads();
   }
   // plain store: lane (l31, lh) holds rows (r & 3) + 8 (r >> 2) + 4 lh of column l31 of each 32 x 32 tile
 #pragma unroll
@@ -127,13 +134,14 @@ int main(int argc, char **argv) {
   fill<<<2048, 256>>>(Bh, (size_t)N * K, 3, 1.0f / 512); fill<<<2048, 256>>>(Bl, (size_t)N * K, 4, 1.0f / (512 * 2048));
   const int tiles_n = (N + BN - 1) / BN, tiles = ((M + BM - 1) / BM) * tiles_n;
   const int grid = ((tiles + 7) / 8) * 8;
+  hipFuncSetAttribute((const void *)presplit_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + BN) * ROWB);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int it = 0; it < 2; ++it) presplit_gemm<<<grid, 256>>>(Ah, Al, Bh, Bl, C, M, N, K, tiles_n);
+  for (int it = 0; it < 2; ++it) presplit_gemm<<<grid, 256, 2 * (BM + BN) * ROWB>>>(Ah, Al, Bh, Bl, C, M, N, K, tiles_n);
   hipDeviceSynchronize();
   const int reps = 5;
   hipEventRecord(e0);
-  for (int it = 0; it < reps; ++it) presplit_gemm<<<grid, 256>>>(Ah, Al, Bh, Bl, C, M, N, K, tiles_n);
+  for (int it = 0; it < reps; ++it) presplit_gemm<<<grid, 256, 2 * (BM + BN) * ROWB>>>(Ah, Al, Bh, Bl, C, M, N, K, tiles_n);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
