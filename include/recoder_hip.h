@@ -291,6 +291,47 @@ int32_t rk_gemm_split16(void);
 int32_t rk_encode_bwd_segments(int32_t B);
 
 /*
+ * Pre-split operand planes of the decoder contractions (csrc/planes.h, csrc/decode16.hip).
+ * rk_decode_loss / rk_decode_bwd_dz cut every fp32 operand into an fp16 pair (s.x = hi + lo) while
+ * they stage it -- each W_de row once per row tile, Z once per column tile.  The *_planes entry
+ * points take the operands ALREADY split, once per step, as compact plane images (one 128-byte
+ * line = 32 hi + 32 lo values of one row's k-tile) and run the same arithmetic (lo.hi + hi.lo +
+ * hi.hi in fp32 on v_mfma_f32_32x32x16_f16, same k order: bit-identical results for equal tile
+ * shapes) with a copy -> LDS -> MFMA k-loop:
+ *   z  : image of Z [B, h]                (rk_split_z, or the encoder forward of rk_ae_train_step)
+ *   w  : image of W_de[items[c]] [n_b, h] (rk_split_w)           -- B operand of the decode
+ *   wt : image of its transpose [h, n_b]  (rk_split_w)           -- B operand of dZ
+ * rk_planes_layout carves the three images + 4 scale slots out of ONE caller-allocated, ZEROED,
+ * 256-byte aligned buffer of rk_planes_bytes(B_cap, h, n_cap) bytes (the K padding is never
+ * written and must read as zero).
+ */
+typedef struct rk_planes {
+  float *scales;      /* [4] dev: [0] split scale of Z, [1] of W_de (written by the split passes) */
+  void *z, *w, *wt;
+  int32_t h, B_cap, n_cap, n_ld;   /* n_ld = round_up(n_cap, 32) */
+} rk_planes_t;
+int64_t rk_planes_bytes(int32_t B_cap, int32_t h, int32_t n_cap);
+/* tuning / test hook: rows of a decode tile, 128 or 64 (the tile shape of rk_decode_loss); 0 = by
+ * the problem's size (default) */
+void rk_planes_tile(int32_t rows);
+int rk_planes_layout(void *buffer, int32_t B_cap, int32_t h, int32_t n_cap, rk_planes_t *out);
+/* W_de[tgt->items[0 .. n_b)] -> pl->w and pl->wt; the scale from ranges[64..127] (rk_amax notes) */
+int rk_split_w(const float *W_de, int32_t h, const rk_block_t *tgt, const int32_t *ranges,
+               const rk_planes_t *pl, void *stream);
+/* Z[B, h] -> pl->z; the scale from ranges[0..63] */
+int rk_split_z(const float *Z, int32_t B, int32_t h, const int32_t *ranges, const rk_planes_t *pl,
+               void *stream);
+/* rk_decode_loss on pl->z x pl->w (arguments as there).  MSE / BCE: the padding columns
+ * [n_t, ld) of every dO row are written as zeros. */
+int rk_decode_loss_planes(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off,
+                          const float *b_de, int32_t loss_kind, float confidence, float inv_B,
+                          float *dO, int32_t ld_out, float *loss_part, float *gb_part, void *stream);
+/* rk_decode_bwd_dz on dO x pl->wt (arguments as there; dO rows are ld = counts[2] apart). */
+int rk_decode_bwd_dz_planes(const float *dO, int32_t B, const rk_planes_t *pl, const rk_block_t *tgt,
+                            const float *Zact /* nullable */, int32_t act, float *dZ,
+                            float *workspace, void *stream);
+
+/*
  * Hidden nn.Linear stack (nn.py:242-249): Y = act(X W^T + b), and backward.
  *   rk_linear_fwd : Y[B,N] = act(X[B,K] . W[N,K]^T + b)      (wT: W is [K,N])
  *   rk_linear_bwd : dYpre = dY * act'(Y) (in place), dX = dYpre . W,
@@ -455,6 +496,10 @@ typedef struct rk_ae_step {
    * (rk_dw3_workspace_bytes).  All NULL: dW runs in line on `stream`, in `ws`. */
   float *ws_dw;
   void *dw_stream, *dw_fork, *dw_join;
+  /* nullable: operand planes (rk_planes_layout) -- the step then splits W_de[items] inside its
+   * encoder-forward launch, Z in that kernel's epilogue (unbounded activations: rk_amax +
+   * rk_split_z), and runs the decode and dZ through the *_planes kernels */
+  const rk_planes_t *planes;
 } rk_ae_step_t;
 
 void *rk_event_create(void);          /* ordering-only (no timing, device-scope fence) */

@@ -72,7 +72,14 @@ class RkAeStep(Structure):
     ("cursor_next", c_void_p),
     ("time_all", POINTER(c_void_p)),
     ("ws_dw", c_void_p), ("dw_stream", c_void_p), ("dw_fork", c_void_p), ("dw_join", c_void_p),
+    ("planes", c_void_p),
   ]
+
+
+class RkPlanes(Structure):
+  """mirror of rk_planes_t"""
+  _fields_ = [("scales", c_void_p), ("z", c_void_p), ("w", c_void_p), ("wt", c_void_p),
+              ("h", c_int32), ("B_cap", c_int32), ("n_cap", c_int32), ("n_ld", c_int32)]
 
 
 class RkAdamJob(Structure):
@@ -113,6 +120,14 @@ SIGNATURES = {
   "rk_decode_loss": (c_int32, [_P, c_int32, c_int32, _BLK, c_int32, _P, _P, c_int32, c_float,
                                c_float, _P, c_int32, _P, _P, _P, _P]),
   "rk_amax": (c_int32, [_P, c_int64, _P, _P]),
+  "rk_planes_bytes": (c_int64, [c_int32, c_int32, c_int32]),
+  "rk_planes_tile": (None, [c_int32]),
+  "rk_planes_layout": (c_int32, [_P, c_int32, c_int32, c_int32, POINTER(RkPlanes)]),
+  "rk_split_w": (c_int32, [_P, c_int32, _BLK, _P, POINTER(RkPlanes), _P]),
+  "rk_split_z": (c_int32, [_P, c_int32, c_int32, _P, POINTER(RkPlanes), _P]),
+  "rk_decode_loss_planes": (c_int32, [POINTER(RkPlanes), c_int32, _BLK, c_int32, _P, c_int32, c_float,
+                                      c_float, _P, c_int32, _P, _P, _P]),
+  "rk_decode_bwd_dz_planes": (c_int32, [_P, c_int32, POINTER(RkPlanes), _BLK, _P, c_int32, _P, _P, _P]),
   "rk_mnll_finish": (c_int32, [_P, c_int32, _BLK, c_int32, c_float, _P, _P]),
   "rk_mnll_row_stats": (c_int32, [_P, c_int32, _BLK, _P, _P]),
   "rk_mnll_finish_ext": (c_int32, [_P, c_int32, _BLK, c_int32, c_float, _P, _P, _P, _P, _P]),

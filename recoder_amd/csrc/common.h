@@ -31,10 +31,17 @@ void rk_set_error(const char *fmt, ...);
 static inline int rk_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // internal entry points shared between translation units (not part of the C ABI)
+// (es: nullable, planes.h -- split jobs riding on the launch; rng_step is used when cursor == null)
+struct rk_enc_split_t;
 int rk_ae_encode_fwd_at(const rk_block_t *blk, int32_t row_off, int32_t B, const float *W_en,
                         const float *b_en, int32_t h, const uint8_t *keep, float p, uint64_t seed,
                         const int64_t *cursor, int32_t cursor_off, const int64_t *users, int32_t act,
-                        float *Z0, void *zt_planes, void *stream);
+                        float *Z0, void *zt_planes, void *stream, const rk_enc_split_t *es,
+                        uint64_t rng_step);
+// gemm.hip: the split-K reduce (ws[split][M][N] -> out, * act'(Zact) if given) and the split-K factor
+int rk_splitk_reduce(const float *ws, int M, int N, const int32_t *Kdev, int splits, const float *Zact,
+                     int act, float *out, void *stream);
+int rk_dz_splits(int B);
 int rk_adam_multi_at(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part, int32_t n_part,
                      float denom, float *loss_out, const int64_t *cursor, int32_t cursor_off,
                      const void *table, int32_t tab_stride, const int32_t *tab_slots,

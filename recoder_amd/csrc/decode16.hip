@@ -1,0 +1,699 @@
+// Decoder contractions on PRE-SPLIT operand planes (csrc/planes.h) -- the round-3 replacement of
+// gemm.hip's PREC_H3 kernels on the hot path:
+//
+//   decode + loss : O[B,n_b] = Z . W_de[T]^T + b_de[T]  (reference nn.py:271-280) + the fused loss /
+//                   dLoss/dLogits epilogue (losses.py:43-47, BCEWithLogits) -- both operands arrive
+//                   as fp16 hi / lo planes, the k-loop is copy -> LDS -> MFMA: no VALU split at all
+//   bwd dZ        : dZ[B,h] = dO[B,n_b] . W_de[T]  (autograd of F.linear) -- the B operand is the
+//                   W^T plane image; dO (fp32, read exactly once per column tile) goes global ->
+//                   registers of the one wave that owns its 32 rows, split there (no LDS round trip)
+//
+// Arithmetic identical to gemm.hip PREC_H3: s.x = hi + lo (fp16), a.b = lo.hi + hi.lo + hi.hi
+// accumulated in fp32 on v_mfma_f32_32x32x16_f16 in the same k order -- with equal tile shapes the
+// two paths agree BIT FOR BIT (tests/test_planes.py).
+#include <stdlib.h>
+
+#include "common.h"
+#include "planes.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int ROWB = 144;            // LDS row: 64 B hi | 64 B lo | 16 B pad (odd number of 16-B slots)
+constexpr float SCALE_DO = 1024.0f;  // dO without a published maximum (as gemm.hip)
+
+enum { EPI_STORE = 0, EPI_LOSS_MSE = 1, EPI_LOSS_BCE = 3 };
+
+__device__ __forceinline__ void publish_amax(int32_t *counts, int slot, float v) {
+  atomicMax(reinterpret_cast<unsigned int *>(counts) + 8 + (slot & 63), __float_as_uint(v));
+}
+
+struct DecP {
+  const char *zp, *wp;        // A / B plane images (row pitch KT * 128 bytes)
+  const float *scales;        // [0] scale of Z, [1] scale of W
+  int KT;
+  int M;                      // rows (B)
+  int n_cap;
+  const int32_t *Ndev;        // n_t on the device
+  // store epilogue
+  float *C;
+  int ldc;                    // <= 0: read from ld_dev
+  const int32_t *ld_dev;
+  const float *bias;
+  const int32_t *bidx;        // bias index = bidx[n] (gathered decoder bias)
+  // loss epilogue
+  rk_block_t blk;
+  int row_off;
+  float confidence, inv_B;
+  float *loss_part;
+  float *gb_part;
+};
+
+// 4 waves as 2 x 2, wave tile (TM*32) x (TN*32): BM = 64*TM, BN = 64*TN.  BK = 32, two LDS stages,
+// register prefetch of the next k-tile, ONE barrier per k-tile, every LDS read of a tile ahead of
+// its MFMAs (tools/probes/presplit_gemm.hip: 15 us at the C2 shape against 24 for the in-loop split).
+template <int TM, int TN, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+void decode_planes_kernel(DecP p) {
+  constexpr int BM = 64 * TM, BN = 64 * TN;
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int A_PT = BM / 32, B_PT = BN / 32;          // 16-byte pieces per thread and k-tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int L = blockIdx.x;
+  const int M = p.M, N = *p.Ndev;
+  // XCD-aware tile order (gemm.hip): workgroup L runs on XCD L % 8 and takes a contiguous chunk of
+  // the LIVE tile list; consecutive tiles share the W panel (mt fastest)
+  const int tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+  const int total = tm * tn;
+  const int chunk = (total + 7) >> 3;
+  const int t = (L & 7) * chunk + (L >> 3);
+  if ((L >> 3) >= chunk || t >= total) return;
+  const int mt = t % tm, nt = t / tm;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int64_t pitch = (int64_t)p.KT * rkp::LINE;
+  const char *srcA[A_PT], *srcB[B_PT];
+  int dstA[A_PT], dstB[B_PT];
+#pragma unroll
+  for (int i = 0; i < A_PT; ++i) {
+    const int idx = tid + 256 * i, row = idx >> 3, piece = idx & 7;
+    srcA[i] = p.zp + (int64_t)min(m0 + row, M - 1) * pitch + piece * 16;
+    dstA[i] = row * ROWB + piece * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < B_PT; ++i) {
+    const int idx = tid + 256 * i, row = idx >> 3, piece = idx & 7;
+    srcB[i] = p.wp + (int64_t)min(n0 + row, N - 1) * pitch + piece * 16;
+    dstB[i] = BM * ROWB + row * ROWB + piece * 16;
+  }
+  uint4 ra[A_PT], rb[B_PT];
+  // (macros, not lambdas capturing the arrays: hipcc put them into scratch memory then)
+#define GLOAD(kt)                                                                  \
+  _Pragma("unroll") for (int i = 0; i < A_PT; ++i)                                 \
+    ra[i] = *reinterpret_cast<const uint4 *>(srcA[i] + (int64_t)(kt) * rkp::LINE); \
+  _Pragma("unroll") for (int i = 0; i < B_PT; ++i)                                 \
+    rb[i] = *reinterpret_cast<const uint4 *>(srcB[i] + (int64_t)(kt) * rkp::LINE);
+#define SSTORE(buf)                                                                \
+  _Pragma("unroll") for (int i = 0; i < A_PT; ++i)                                 \
+    *reinterpret_cast<uint4 *>(smem + (buf) * STAGE + dstA[i]) = ra[i];            \
+  _Pragma("unroll") for (int i = 0; i < B_PT; ++i)                                 \
+    *reinterpret_cast<uint4 *>(smem + (buf) * STAGE + dstB[i]) = rb[i];
+
+  // Loss epilogue operands (gathered bias, bitmap words) are fetched NOW so that their dependent
+  // round trips overlap the k-loop instead of the epilogue.
+  constexpr bool LOSS = (EPI != EPI_STORE);
+  float pre_bv[LOSS ? TN : 1][4];
+  uint32_t pre_w[LOSS ? TM : 1][LOSS ? TN : 1][4];
+  if (LOSS) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nb = n0 + (wn * TN + j) * 32;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int nc = min(nb + (lane & 7) * 4 + e, N - 1);
+        pre_bv[j][e] = p.bias[p.bidx ? p.bidx[nc] : nc];
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int m = m0 + (wm * TM + i) * 32 + (lane >> 3) + 8 * it;
+          const int row = p.row_off + min(m, M - 1);
+          pre_w[i][j][it] = p.blk.bits_rc[(int64_t)row * p.blk.ldw_rc + min(nb >> 5, p.blk.ldw_rc - 1)];
+        }
+    }
+  }
+
+  GLOAD(0);
+  SSTORE(0);
+  __syncthreads();
+  const int a_off = ((wm * TM) * 32 + l31) * ROWB + lh * 16;
+  const int b_off = BM * ROWB + ((wn * TN) * 32 + l31) * ROWB + lh * 16;
+  const int KT = p.KT;
+  int buf = 0;
+  for (int kt = 0; kt < KT; ++kt, buf ^= 1) {
+    GLOAD(min(kt + 1, KT - 1));                 // the next tile, in flight under this one's MFMAs
+    const char *S = smem + buf * STAGE;
+    f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const char *q = S + a_off + i * 32 * ROWB + ks * 32;
+        ah[ks][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q));
+        al[ks][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q + 64));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const char *q = S + b_off + j * 32 * ROWB + ks * 32;
+        bh[ks][j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q));
+        bl[ks][j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q + 64));
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      // small terms first (the order of gemm.hip: bit-identical accumulators)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+    }
+    SSTORE(buf ^ 1);                            // (last read in the previous iteration)
+    __syncthreads();
+  }
+#undef GLOAD
+#undef SSTORE
+
+  // ------------------------------------------------------------- epilogues (as gemm.hip)
+  {
+    const float inv = 1.0f / (p.scales[0] * p.scales[1]);       // exact: powers of two
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
+  }
+  constexpr int TLD = 36;
+  float *fsm = reinterpret_cast<float *>(smem);
+  float *wlds = fsm + wid * (32 * TLD);                     // private to this wave
+  const int rr0 = lane >> 3, c4 = lane & 7;                 // row-major role of the lane
+  auto transpose_tile = [&](const f32x16 &a, float4 (&v)[4]) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wlds[((r & 3) + 8 * (r >> 2) + 4 * lh) * TLD + l31] = a[r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      v[it] = *reinterpret_cast<const float4 *>(wlds + (rr0 + 8 * it) * TLD + c4 * 4);
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  if (EPI == EPI_STORE) {
+    const int ldc = p.ldc > 0 ? p.ldc : *p.ld_dev;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        float4 v[4];
+        transpose_tile(acc[i][j], v);
+        const int n = n0 + (wn * TN + j) * 32 + c4 * 4;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int nc = min(n + e, N - 1);
+            bv[e] = p.bias[p.bidx ? p.bidx[nc] : nc];
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int m = m0 + (wm * TM + i) * 32 + rr0 + 8 * it;
+          if (m < M && n < N) {
+            const float o[4] = {v[it].x + bv[0], v[it].y + bv[1], v[it].z + bv[2], v[it].w + bv[3]};
+            float *dst = p.C + (int64_t)m * ldc + n;
+            if (n + 3 < N && (ldc & 3) == 0) {
+              *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n + e < N) dst[e] = o[e];
+            }
+          }
+        }
+      }
+  } else {
+    float *lred = fsm + 4 * (32 * TLD);           // after the 4 per-wave transpose areas
+    float *cpart = lred + 8;                      // [2][BN] column partial sums (one row per 64 rows)
+    const int ldc = *p.ld_dev;
+    const rk_block_t &b = p.blk;
+    const bool implicit = b.implicit != 0;
+    float lsum = 0.f, gmax = 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nb = n0 + (wn * TN + j) * 32;     // multiple of 32: one bitmap word per row
+      const int n = nb + c4 * 4;
+      float bv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bv[e] = pre_bv[LOSS ? j : 0][e];
+      float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float4 v[4];
+        transpose_tile(acc[i][j], v);
+        uint32_t w[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) w[it] = pre_w[LOSS ? i : 0][LOSS ? j : 0][it];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int m = m0 + (wm * TM + i) * 32 + rr0 + 8 * it;
+          const float ov[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+          float g[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool ok = (m < M) && (n + e < N);
+            const float o = ov[e] + bv[e];
+            float tv = 0.f;
+            if (ok && ((w[it] >> (c4 * 4 + e)) & 1u)) {
+              tv = 1.0f;
+              if (!implicit) tv = b.vals[rk_entry_index(b, p.row_off + m, n + e, w[it])];
+            }
+            float l;
+            if (EPI == EPI_LOSS_MSE) {
+              const float wgt = (tv > 0.f) ? (1.0f + p.confidence) : 1.0f;
+              const float d = o - tv;
+              l = wgt * (d * d);
+              g[e] = (2.0f * d) * (wgt * p.inv_B);
+            } else {  // BCE with logits: (1-t)*o - logsigmoid(o)
+              const float ls = fminf(o, 0.f) - log1pf(expf(-fabsf(o)));
+              l = (1.0f - tv) * o - ls;
+              const float sg = 1.0f / (1.0f + expf(-o));
+              g[e] = (sg - tv) * p.inv_B;
+            }
+            if (ok) { lsum += l; cs[e] += g[e]; gmax = fmaxf(gmax, fabsf(g[e])); }
+            else g[e] = 0.f;     // padding columns [N, ld) of the dO row are ZEROS (rk_decode_bwd_dz_planes)
+          }
+          // (the tiles cover [0, ld): ld = round_up(N, 32) and BN is a multiple of 32)
+          if (m < M && n < ldc)
+            *reinterpret_cast<float4 *>(p.C + (int64_t)m * ldc + n) = make_float4(g[0], g[1], g[2], g[3]);
+        }
+      }
+      // column sums over this wave's rows: lanes with equal c4 hold different rows
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        cs[e] += __shfl_xor(cs[e], 8, 64);
+        cs[e] += __shfl_xor(cs[e], 16, 64);
+        cs[e] += __shfl_xor(cs[e], 32, 64);
+      }
+      if (rr0 == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cpart[wm * BN + (wn * TN + j) * 32 + c4 * 4 + e] = cs[e];
+      }
+    }
+    lsum = rk_wave_sum(lsum);
+    gmax = rk_wave_max(gmax);
+    if (lane == 0) { lred[wid] = lsum; lred[4 + wid] = gmax; }
+    __syncthreads();
+    if (tid == 0) {
+      p.loss_part[t] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
+      const float gm = fmaxf(fmaxf(lred[4], lred[5]), fmaxf(lred[6], lred[7]));
+      publish_amax(b.counts, L, gm);
+    }
+    if (p.gb_part && tid < BN) {
+      // one gb_part row per 64 rows of dO (rk_decode_row_tile): TM = 1: the two waves along M hold
+      // 32 rows each of ONE row group; TM = 2: each of them holds a whole group
+      const int n = n0 + tid;
+      if (n < N) {
+        if (TM == 1) {
+          if (m0 < M) p.gb_part[(int64_t)mt * ldc + n] = cpart[tid] + cpart[BN + tid];
+        } else {
+#pragma unroll
+          for (int g = 0; g < 2; ++g)
+            if (m0 + g * 64 < M) p.gb_part[(int64_t)(mt * 2 + g) * ldc + n] = cpart[g * BN + tid];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ dZ
+struct DzP {
+  const float *dO;            // [M][ld] fp32 (columns [n_t, ld): anything, masked in the kernel)
+  const char *wtp;            // W^T image: row j = hidden unit, pitch (n_ld / 32) lines
+  const float *scales;        // [1] scale of W
+  const uint32_t *a_amax;     // 64 slots: running max |dO| (counts + 8)
+  const int32_t *counts;      // [0] n_t (= K), [2] ld
+  int n_ld;
+  int M, N;                   // rows (B), h
+  int tiles_n;
+  float *ws;                  // [split][M][N] slabs
+};
+
+// Workgroup = 4 waves x 32 rows (BM = 128) x BN = 32 * TN columns.  B (the W^T image, shared by the
+// four waves) goes through LDS as in the decode; A (dO) belongs to ONE wave per row, so its
+// fragments go global -> registers directly (a lane: 8 consecutive k of its row per k-step = two
+// 16-byte loads) and are split there -- with one column tile (h <= 32 * TN) every dO element is
+// split exactly once on the whole chip.
+template <int TN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+void dz_planes_kernel(DzP p) {
+  constexpr int BM = 128, BN = 32 * TN;
+  constexpr int STAGE = BN * ROWB;
+  constexpr int B_PT = (BN * 8 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nsplit = gridDim.y;
+  const int L = blockIdx.y * gridDim.x + blockIdx.x;
+  const int M = p.M, N = p.N, K = p.counts[0], lda = p.counts[2];
+  const float a_scale = rkp::scale_from(p.a_amax, SCALE_DO);
+  const float b_scale = p.scales[1];
+  const int tm = (M + BM - 1) / BM, tn = p.tiles_n;
+  const int per_split = tm * tn;
+  const int total = per_split * nsplit;
+  const int chunk = (total + 7) >> 3;
+  const int t = (L & 7) * chunk + (L >> 3);
+  if ((L >> 3) >= chunk || t >= total) return;
+  const int split = t / per_split, rt = t % per_split;
+  const int mt = rt % tm, nt = rt / tm;
+  const int m0 = mt * BM, n0 = nt * BN;
+  // split-K: the chunk follows the device-resident K so that every split is live (as gemm.hip)
+  const int kchunk = ((K + nsplit - 1) / nsplit + 31) & ~31;
+  const int kbeg = split * kchunk;
+  const int kend = min(K, kbeg + kchunk);
+  if (kbeg >= kend) return;
+  const int nk = (kend - kbeg + 31) >> 5;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // A: this lane's row, 8 consecutive k per k-step (kbeg is a multiple of 32, lda of 32: 16-byte
+  // aligned; the tile never reaches past column ld, whose tail [n_t, ld) holds zeros)
+  const float *a_src = p.dO + (int64_t)min(m0 + wid * 32 + l31, M - 1) * lda + kbeg + lh * 8;
+  // B: rows n0 .. n0 + BN - 1 of the W^T image, k-tile (kbeg >> 5) + kt
+  const char *srcB[B_PT];
+  int dstB[B_PT];
+#pragma unroll
+  for (int i = 0; i < B_PT; ++i) {
+    const int idx = min(tid + 256 * i, BN * 8 - 1), row = idx >> 3, piece = idx & 7;
+    // (the image has round_up(h, 32) rows; a tile may be wider: clamp -- those columns are never stored)
+    srcB[i] = p.wtp + ((int64_t)min(n0 + row, rkp::kp_of(N) - 1) * (p.n_ld >> 5) + (kbeg >> 5)) * rkp::LINE + piece * 16;
+    dstB[i] = row * ROWB + piece * 16;
+  }
+  uint4 rb[B_PT];
+  float4 an[4], ac[4];
+#define GLOADB(kt)                                                                 \
+  _Pragma("unroll") for (int i = 0; i < B_PT; ++i)                                 \
+    rb[i] = *reinterpret_cast<const uint4 *>(srcB[i] + (int64_t)(kt) * rkp::LINE);
+#define GLOADA(dst, kt)                                                            \
+  _Pragma("unroll") for (int u = 0; u < 4; ++u)                                    \
+    dst[u] = *reinterpret_cast<const float4 *>(a_src + (kt) * 32 + (u >> 1) * 16 + (u & 1) * 4);
+#define SSTOREB(buf)                                                               \
+  _Pragma("unroll") for (int i = 0; i < B_PT; ++i)                                 \
+    if ((BN * 8) % 256 == 0 || tid + 256 * i < BN * 8)                             \
+      *reinterpret_cast<uint4 *>(smem + (buf) * STAGE + dstB[i]) = rb[i];
+
+  GLOADB(0);
+  GLOADA(ac, 0);
+  SSTOREB(0);
+  __syncthreads();
+  const int b_off = l31 * ROWB + lh * 16;
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt, buf ^= 1) {
+    const int kn = min(kt + 1, nk - 1);
+    GLOADB(kn);
+    GLOADA(an, kn);
+    const char *S = smem + buf * STAGE;
+    // K tail: the columns [K, ld) of dO may hold anything (stale values of an earlier, wider block:
+    // scaled by THIS block's split scale they can overflow fp16, and inf x 0 = nan) -- zeroed here,
+    // in the last k-tile of the last split only (uniform branch, behind the loads' wait)
+    if (kt == nk - 1 && kbeg + nk * 32 > kend) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = kbeg + kt * 32 + (u >> 1) * 16 + lh * 8 + (u & 1) * 4;
+        ac[u].x = k + 0 < kend ? ac[u].x : 0.f;
+        ac[u].y = k + 1 < kend ? ac[u].y : 0.f;
+        ac[u].z = k + 2 < kend ? ac[u].z : 0.f;
+        ac[u].w = k + 3 < kend ? ac[u].w : 0.f;
+      }
+    }
+    f16x8 ah[2], al[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint2 h0, l0, h1, l1;
+      rkp::split4(ac[2 * ks], a_scale, h0, l0);
+      rkp::split4(ac[2 * ks + 1], a_scale, h1, l1);
+      ah[ks] = __builtin_bit_cast(f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+      al[ks] = __builtin_bit_cast(f16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 bh[TN], bl[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const char *q = S + b_off + j * 32 * ROWB + ks * 32;
+        bh[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q));
+        bl[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q + 64));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh[j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl[j], acc[j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh[j], acc[j], 0, 0, 0);
+    }
+    SSTOREB(buf ^ 1);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ac[u] = an[u];
+  }
+#undef GLOADB
+#undef GLOADA
+#undef SSTOREB
+
+  const float inv = 1.0f / (a_scale * b_scale);
+  // slab store: a lane holds 16 rows of ONE column; through the per-wave LDS transpose a lane owns
+  // 4 x (one row, 4 consecutive columns) and stores 16 bytes at a time
+  constexpr int TLD = 36;
+  float *wlds = reinterpret_cast<float *>(smem) + wid * (32 * TLD);
+  const int rr0 = lane >> 3, c4 = lane & 7;
+  float *ws = p.ws + (int64_t)split * M * N;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wlds[((r & 3) + 8 * (r >> 2) + 4 * lh) * TLD + l31] = acc[j][r] * inv;
+    __builtin_amdgcn_wave_barrier();
+    const int n = n0 + j * 32 + c4 * 4;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const float4 v = *reinterpret_cast<const float4 *>(wlds + (rr0 + 8 * it) * TLD + c4 * 4);
+      const int m = m0 + wid * 32 + rr0 + 8 * it;
+      if (m < M && n < N) *reinterpret_cast<float4 *>(ws + (int64_t)m * N + n) = v;   // (N % 4 == 0)
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------- stand-alone split passes
+__global__ __launch_bounds__(256) void split_w_kernel(rkp::SplitW p) {
+  __shared__ __attribute__((aligned(16))) char sm[rkp::SPLIT_W_LDS];
+  rkp::split_w_job<256>(p, (int)blockIdx.x, sm);
+}
+
+// X[rows, K] fp32 (leading dimension ld) -> its plane image; scale from `amax` (64 slots, nullable)
+// or the static default; scales[slot] <- the scale used
+__global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ X, int rows, int K,
+                                                         int ld, const uint32_t *amax, float dflt,
+                                                         char *img, int KT, float *scales, int slot) {
+  const float s = rkp::scale_from(amax, dflt);
+  if (blockIdx.x == 0 && threadIdx.x == 0) scales[slot] = s;
+  const int q4 = KT * 8;                          // float4 per image row
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)rows * q4) return;
+  const int r = (int)(i / q4), k = (int)(i % q4) * 4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (k < K) v = *reinterpret_cast<const float4 *>(X + (int64_t)r * ld + k);     // (K % 4 == 0)
+  rkp::store_split4(img + (int64_t)r * KT * rkp::LINE, k, v, s);
+}
+
+inline bool aligned16(const void *q) { return ((uintptr_t)q & 15) == 0; }
+
+template <typename Kern>
+int set_lds(Kern k, int bytes) {
+  // More than 64 KB of LDS per workgroup has to be asked for -- ONCE per kernel and process, for
+  // the most any launch will use (160 KB): calling hipFuncSetAttribute next to another thread's
+  // launch of the same kernel faulted the GPU (two virtual ranks in one process).
+  static const int rc = [k] {
+    return hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess ? 0 : -1;
+  }();
+  (void)bytes;
+  return rc;
+}
+
+// decode tile shape: by the problem's size unless RK_DEC_TILE / rk_planes_tile force 64 (64 x 128,
+// the tile shape of gemm.hip's decode: bit-identical results) or 128 (128 x 128)
+int g_dec_tm = -1;     // -1: not read yet; 0: by shape; 1 / 2: forced (RK_DEC_TILE, rk_planes_tile)
+inline int dec_tm(int B, int n_cap) {
+  if (g_dec_tm < 0) {
+    const char *e = getenv("RK_DEC_TILE");
+    g_dec_tm = e ? (atoi(e) == 64 ? 1 : (atoi(e) == 128 ? 2 : 0)) : 0;
+  }
+  if (g_dec_tm > 0) return g_dec_tm;
+  // 128 x 128 tiles (one workgroup per CU, 512 VGPRs each) once they fill the chip twice over;
+  // below that 64 x 128 (two per CU): C2 (B = 500, n_b ~ 7.9 k) 21.3 vs 25.5 us
+  return rk_cdiv(B, 128) * rk_cdiv(n_cap, 128) >= 512 ? 2 : 1;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------- C ABI
+static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+extern "C" void rk_planes_tile(int32_t rows) { g_dec_tm = rows == 64 ? 1 : (rows == 128 ? 2 : 0); }
+
+extern "C" int64_t rk_planes_bytes(int32_t B_cap, int32_t h, int32_t n_cap) {
+  const int64_t KT = rkp::kp_of(h) / 32, n_ld = rkp::kp_of(n_cap);
+  return 256 + align256((int64_t)B_cap * KT * rkp::LINE) + align256((int64_t)n_cap * KT * rkp::LINE) +
+         align256((int64_t)rkp::kp_of(h) * (n_ld / 32) * rkp::LINE);
+}
+
+extern "C" int rk_planes_layout(void *buffer, int32_t B_cap, int32_t h, int32_t n_cap, rk_planes_t *out) {
+  RK_REQUIRE(buffer != nullptr && out != nullptr && (((uintptr_t)buffer) & 255) == 0, "buffer: 256-byte aligned");
+  RK_REQUIRE(h > 0 && h % 4 == 0, "h must be a multiple of 4");
+  const int64_t KT = rkp::kp_of(h) / 32, n_ld = rkp::kp_of(n_cap);
+  char *b = (char *)buffer;
+  out->scales = (float *)b;
+  out->z = b + 256;
+  out->w = (char *)out->z + align256((int64_t)B_cap * KT * rkp::LINE);
+  out->wt = (char *)out->w + align256((int64_t)n_cap * KT * rkp::LINE);
+  out->h = h; out->B_cap = B_cap; out->n_cap = n_cap; out->n_ld = (int32_t)n_ld;
+  return 0;
+}
+
+static rkp::SplitW split_w_args(const float *W_de, const rk_block_t *tgt, const int32_t *ranges,
+                                const rk_planes_t *pl) {
+  rkp::SplitW s = {};
+  s.W = W_de; s.items = tgt->items; s.counts = tgt->counts;
+  s.amax = ranges ? reinterpret_cast<const uint32_t *>(ranges) + 64 : nullptr;
+  s.wp = (char *)pl->w; s.wtp = (char *)pl->wt; s.scales = pl->scales;
+  s.h = pl->h; s.KT = rkp::kp_of(pl->h) / 32; s.n_ld = pl->n_ld;
+  return s;
+}
+
+rkp::SplitW rk_split_w_args(const float *W_de, const rk_block_t *tgt, const int32_t *ranges,
+                            const rk_planes_t *pl) {
+  return split_w_args(W_de, tgt, ranges, pl);
+}
+
+extern "C" int rk_split_w(const float *W_de, int32_t h, const rk_block_t *tgt, const int32_t *ranges,
+                          const rk_planes_t *pl, void *stream_) {
+  RK_REQUIRE(pl && pl->h == h && tgt->n_cap <= pl->n_cap, "planes were laid out for another shape");
+  RK_REQUIRE(aligned16(W_de), "W_de must be 16-byte aligned");
+  const rkp::SplitW s = split_w_args(W_de, tgt, ranges, pl);
+  RK_LAUNCH(split_w_kernel, dim3(rk_cdiv(tgt->n_cap, 32)), dim3(256), 0, (hipStream_t)stream_, s);
+  RK_CHECK_LAUNCH("split_w");
+  return 0;
+}
+
+extern "C" int rk_split_z(const float *Z, int32_t B, int32_t h, const int32_t *ranges,
+                          const rk_planes_t *pl, void *stream_) {
+  RK_REQUIRE(pl && pl->h == h && B <= pl->B_cap, "planes were laid out for another shape");
+  RK_REQUIRE(aligned16(Z), "Z must be 16-byte aligned");
+  if (B == 0) return 0;
+  const int KT = rkp::kp_of(h) / 32;
+  RK_LAUNCH(split_rows_kernel, dim3(rk_cdiv((int64_t)B * KT * 8, 256)), dim3(256), 0, (hipStream_t)stream_,
+            Z, B, h, h, reinterpret_cast<const uint32_t *>(ranges), rkp::SCALE_Z, (char *)pl->z, KT,
+            pl->scales, 0);
+  RK_CHECK_LAUNCH("split_z");
+  return 0;
+}
+
+extern "C" int rk_decode_loss_planes(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt,
+                                     int32_t row_off, const float *b_de, int32_t loss_kind,
+                                     float confidence, float inv_B, float *dO, int32_t ld_out,
+                                     float *loss_part, float *gb_part, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(pl && B <= pl->B_cap && tgt->n_cap <= pl->n_cap, "planes were laid out for another shape");
+  RK_REQUIRE(row_off >= 0 && row_off + B <= tgt->S_cap, "row slice out of range");
+  if (B == 0) return 0;
+  DecP p = {};
+  p.zp = (const char *)pl->z; p.wp = (const char *)pl->w; p.scales = pl->scales;
+  p.KT = rkp::kp_of(pl->h) / 32;
+  p.M = B; p.n_cap = tgt->n_cap; p.Ndev = tgt->counts;
+  p.C = dO; p.bias = b_de; p.bidx = tgt->items;
+  p.blk = *tgt; p.row_off = row_off; p.confidence = confidence; p.inv_B = inv_B;
+  p.loss_part = loss_part; p.gb_part = gb_part;
+  const bool loss = loss_kind == RK_LOSS_MSE || loss_kind == RK_LOSS_BCE;
+  if (loss) {
+    RK_REQUIRE(tgt->implicit || tgt->pref_rc != nullptr, "explicit values need pref_rc");
+    p.ld_dev = tgt->counts + 2;
+  } else if (loss_kind == RK_LOSS_MNLL) {
+    p.ldc = 0; p.ld_dev = tgt->counts + 2;
+  } else {
+    RK_REQUIRE(ld_out > 0, "ld_out");
+    p.ldc = ld_out;
+  }
+  const int tm = dec_tm(B, tgt->n_cap);
+  const int BM = 64 * tm, BN = 128;
+  const int grid = rk_cdiv(rk_cdiv(B, BM) * rk_cdiv(tgt->n_cap, BN), 8) * 8;
+  const int lds = 2 * (BM + BN) * ROWB;
+#define LAUNCH(TM, EPI)                                                                        \
+  do {                                                                                         \
+    if (set_lds(decode_planes_kernel<TM, 2, EPI>, lds)) { rk_set_error("LDS attribute"); return -1; } \
+    RK_LAUNCH((decode_planes_kernel<TM, 2, EPI>), dim3(grid), dim3(256), lds, stream, p);      \
+  } while (0)
+  if (tm == 2) {
+    if (loss_kind == RK_LOSS_MSE) LAUNCH(2, EPI_LOSS_MSE);
+    else if (loss_kind == RK_LOSS_BCE) LAUNCH(2, EPI_LOSS_BCE);
+    else LAUNCH(2, EPI_STORE);
+  } else {
+    if (loss_kind == RK_LOSS_MSE) LAUNCH(1, EPI_LOSS_MSE);
+    else if (loss_kind == RK_LOSS_BCE) LAUNCH(1, EPI_LOSS_BCE);
+    else LAUNCH(1, EPI_STORE);
+  }
+#undef LAUNCH
+  RK_CHECK_LAUNCH("decode_loss_planes");
+  return 0;
+}
+
+// the split-K reduce of gemm.hip (ws[split][M][N] -> out, * act'(Zact) if given)
+int rk_splitk_reduce(const float *ws, int M, int N, const int32_t *Kdev, int splits, const float *Zact,
+                     int act, float *out, void *stream);
+int rk_dz_splits(int B);
+
+extern "C" int rk_decode_bwd_dz_planes(const float *dO, int32_t B, const rk_planes_t *pl,
+                                       const rk_block_t *tgt, const float *Zact, int32_t act, float *dZ,
+                                       float *workspace, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(pl && tgt->n_cap <= pl->n_cap, "planes were laid out for another shape");
+  RK_REQUIRE(aligned16(dO) && aligned16(workspace) && aligned16(dZ), "operands must be 16-byte aligned");
+  if (B == 0) return 0;
+  const int h = pl->h;
+  DzP p = {};
+  p.dO = dO; p.wtp = (const char *)pl->wt; p.scales = pl->scales;
+  p.a_amax = reinterpret_cast<const uint32_t *>(tgt->counts) + 8;
+  p.counts = tgt->counts; p.n_ld = pl->n_ld;
+  p.M = B; p.N = h; p.ws = workspace;
+  const int splits = rk_dz_splits(B);
+  // one column tile up to h = 256 (7 x 32 covers h = 200: dO is read and split once), else 256-wide tiles
+  const int tn = h <= 64 ? 2 : (h <= 128 ? 4 : (h <= 224 ? 7 : 8));
+  p.tiles_n = rk_cdiv(h, 32 * tn);
+  const int tiles = rk_cdiv(B, 128) * p.tiles_n;
+  const int lds = 2 * 32 * tn * ROWB;
+#define LAUNCH(TN)                                                                             \
+  do {                                                                                         \
+    if (set_lds(dz_planes_kernel<TN>, lds)) { rk_set_error("LDS attribute"); return -1; }      \
+    RK_LAUNCH((dz_planes_kernel<TN>), dim3(tiles, splits), dim3(256), lds, stream, p);         \
+  } while (0)
+  if (tn == 2) LAUNCH(2); else if (tn == 4) LAUNCH(4); else if (tn == 7) LAUNCH(7); else LAUNCH(8);
+#undef LAUNCH
+  RK_CHECK_LAUNCH("decode_bwd_dz_planes");
+  return rk_splitk_reduce(workspace, B, h, tgt->counts, splits, Zact, act, dZ, stream_);
+}

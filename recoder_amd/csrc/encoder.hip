@@ -13,6 +13,7 @@
 // the transposed bitmap so the fp32 sum is order-deterministic (no atomics).
 #include "common.h"
 #include "encoder_bwd.h"
+#include "planes.h"
 
 namespace {
 
@@ -26,14 +27,24 @@ __global__ __launch_bounds__(FW * 64) void ae_encode_fwd_kernel(
     int h, const uint8_t *__restrict__ keep, float p, float scale, uint64_t seed,
     uint64_t rng_step, const int64_t *__restrict__ users, const float *__restrict__ user_norm,
     int act, float *__restrict__ Z0, uint16_t *__restrict__ planes, int64_t plane_stride,
-    int cols_pad, rk_cur_t cur) {
+    int cols_pad, rk_cur_t cur, rkp::SplitW sw, int n_split, char *__restrict__ zimg, int z_kt) {
   __shared__ float red[FW];
+  constexpr int PART_B = (FW - 1) * HV * 256 * 4;
+  __shared__ __attribute__((aligned(16))) char sm_raw[PART_B > rkp::SPLIT_W_LDS ? PART_B : rkp::SPLIT_W_LDS];
+  // The first n_split workgroups split the decoder rows of the block's items into the fp16 plane
+  // images of the decoder contractions (planes.h).  The pass touches neither the encoder table's
+  // output nor anything this launch writes, and the decode that needs it is the NEXT launch: it
+  // rides here off the chain (first in the grid: uniform work, never the launch's tail).
+  if ((int)blockIdx.x < n_split) {
+    rkp::split_w_job<FW * 64>(sw, (int)blockIdx.x, sm_raw);
+    return;
+  }
   if (cur.cursor) {          // graph replay (common.h): the step's RNG index and user ids
     rng_step = (uint64_t)(rk_cur_global(cur) + 1);
     if (users) users += rk_cur_local(cur) * B;       // (replayed steps are whole batches: S == B)
   }
-  __shared__ __attribute__((aligned(16))) float part[FW - 1][HV * 256];
-  const int r = blockIdx.x;            // row within the slice
+  float (*part)[HV * 256] = reinterpret_cast<float (*)[HV * 256]>(sm_raw);
+  const int r = (int)blockIdx.x - n_split;            // row within the slice
   if (r >= B) {
     // planes != null: the grid covers the rows up to the next multiple of 64; the padding rows
     // of the Z^T planes are (re)written as zeros (the dW kernel's K padding relies on it)
@@ -165,6 +176,12 @@ __global__ __launch_bounds__(FW * 64) void ae_encode_fwd_kernel(
         y.z = rk_act(a.z + bb.z, act);
         y.w = rk_act(a.w + bb.w, act);
         *reinterpret_cast<float4 *>(Z0 + (int64_t)r * h + hh) = y;
+        // Z as fp16 hi / lo plane image for the decode (planes.h), with the value still in registers
+        // (bounded activations only: their split scale is static)
+        if (zimg) {
+          rkp::store_split4(zimg + (int64_t)r * z_kt * rkp::LINE, hh, y, rkp::SCALE_Z);
+          if (r == 0 && tid == 0) sw.scales[0] = rkp::SCALE_Z;     // (consumers read the scale from there)
+        }
         if (planes) {
           // Z^T as three bf16 planes in the fragment order of the dW kernel (csrc/dw3.hip):
           // element (k = r, n) at ((k/8)*cols_pad + n)*8 + k%8 -- written here, with the value
@@ -391,7 +408,8 @@ static int encode_fwd_launch(const rk_block_t *blk, int32_t row_off, int32_t B, 
                              const float *b_en, int32_t h, const uint8_t *keep, float p,
                              uint64_t seed, uint64_t rng_step, const int64_t *users,
                              const float *user_norm, int32_t act, float *Z0, void *stream_,
-                             void *zt_planes = nullptr, rk_cur_t cur = {nullptr, 0}) {
+                             void *zt_planes = nullptr, rk_cur_t cur = {nullptr, 0},
+                             const rk_enc_split_t *es = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(h > 0 && h % 4 == 0 && h <= 1024, "h must be a multiple of 4, <= 1024");
   RK_REQUIRE(p >= 0.f && p < 1.f, "noise_prob must be in [0,1)");
@@ -404,10 +422,16 @@ static int encode_fwd_launch(const rk_block_t *blk, int32_t row_off, int32_t B, 
   const int rows = zt_planes ? rk_dw3_rows_pad(B) : B;
   const int cols_pad = rk_dw3_cols_pad(h);
   const int64_t plane_stride = (int64_t)rk_dw3_rows_pad(B) * cols_pad;
+  rkp::SplitW sw = {};
+  int n_split = 0, z_kt = 0;
+  char *zimg = nullptr;
+  if (es) {
+    sw = es->sw; n_split = es->n_split; zimg = es->zimg; z_kt = es->z_kt;
+  }
 #define LAUNCH(HV)                                                                         \
-  RK_LAUNCH(ae_encode_fwd_kernel<HV>, dim3(rows), dim3(FW * 64), 0, stream, *blk, row_off, \
+  RK_LAUNCH(ae_encode_fwd_kernel<HV>, dim3(n_split + rows), dim3(FW * 64), 0, stream, *blk, row_off, \
                      B, W_en, b_en, h, keep, p, scale, seed, rng_step, users, user_norm, act, Z0, \
-                     (uint16_t *)zt_planes, plane_stride, cols_pad, cur)
+                     (uint16_t *)zt_planes, plane_stride, cols_pad, cur, sw, n_split, zimg, z_kt)
   if (hv == 1) LAUNCH(1); else if (hv == 2) LAUNCH(2); else LAUNCH(4);
 #undef LAUNCH
   RK_CHECK_LAUNCH("ae_encode_fwd");
@@ -439,10 +463,11 @@ extern "C" int rk_ae_encode_fwd_planes(const rk_block_t *blk, int32_t row_off, i
 int rk_ae_encode_fwd_at(const rk_block_t *blk, int32_t row_off, int32_t B, const float *W_en,
                         const float *b_en, int32_t h, const uint8_t *keep, float p, uint64_t seed,
                         const int64_t *cursor, int32_t cursor_off, const int64_t *users, int32_t act,
-                        float *Z0, void *zt_planes, void *stream_) {
+                        float *Z0, void *zt_planes, void *stream_, const rk_enc_split_t *es,
+                        uint64_t rng_step) {
   const rk_cur_t cur = {cursor, cursor_off};
-  return encode_fwd_launch(blk, row_off, B, W_en, b_en, h, keep, p, seed, 0, users, nullptr, act, Z0,
-                           stream_, zt_planes, cur);
+  return encode_fwd_launch(blk, row_off, B, W_en, b_en, h, keep, p, seed, rng_step, users, nullptr, act,
+                           Z0, stream_, zt_planes, cur, es);
 }
 
 extern "C" int rk_ae_encode_fwd_partial(const rk_block_t *blk, int32_t row_off, int32_t B,

@@ -1066,6 +1066,17 @@ extern "C" int rk_amax(const float *x, int64_t n, int32_t *slots, void *stream_)
   return 0;
 }
 
+int rk_dz_splits(int B) { return dz_splits(B); }
+
+int rk_splitk_reduce(const float *ws, int M, int N, const int32_t *Kdev, int splits, const float *Zact,
+                     int act, float *out, void *stream_) {
+  const int grid = rk_cdiv((int64_t)M * N / 4, 64);
+  RK_LAUNCH(splitk_reduce_kernel, dim3(grid), dim3(RED_W * 64), 0, (hipStream_t)stream_, ws, M, N, Kdev, 0,
+            splits, Zact, act, out);
+  RK_CHECK_LAUNCH("splitk_reduce");
+  return 0;
+}
+
 extern "C" void rk_gemm_probe(unsigned long long *buffer) { g_gemm_probe = buffer; }
 
 extern "C" int32_t rk_gemm_split16(void) { return use_h3() ? 1 : 0; }

@@ -1,0 +1,143 @@
+// Pre-split operand planes of the decoder contractions (decode16.hip).
+//
+// gemm.hip's PREC_H3 kernels split every fp32 operand into an fp16 pair  s.x = hi + lo  while they
+// stage it into LDS -- every W_de row once per ROW tile (8x in the decode, 4x in dZ), Z once per
+// column tile (62x): 30 VALU instructions per MFMA (profiles/r02_b_gemm_sq_counters_b500.txt).  Here
+// each operand is split ONCE per step into a compact "plane image" that the contraction kernels copy
+// into LDS as it is:
+//
+//   image of X[rows, K] (K = contraction index, padded to Kp = round_up(K, 32) with zeros):
+//     row r = KT = Kp / 32 k-tiles of 128 bytes:  [ 32 x fp16 hi | 32 x fp16 lo ]
+//     element (r, k): hi at  r * KT * 128 + (k >> 5) * 128 + (k & 31) * 2,  lo 64 bytes further.
+//   One 128-byte line = one row's share of a 32-deep k-tile (hi and lo together), so staging a tile
+//   is a plain copy of full cache lines, and in LDS (row stride 144 B, an odd number of 16-byte
+//   slots) a lane's MFMA fragment (8 consecutive k of one row) is one conflict-free ds_read_b128.
+//
+//   Z  image  [B rows][KT(h)]        written by the encoder forward with the value in registers
+//   W  image  [n_b rows][KT(h)]      the gathered decoder rows W_de[items[c]] (decode: B operand)
+//   W^T image [Hp rows][KT(n_ld)]    row j = hidden unit, k = compact item index (dZ: B operand);
+//                                     items in [n_b, round_up(n_b, 32)) are written as ZEROS (the K tail)
+//   scales[0] / [1]: the power-of-two split scales used for Z / W (read by the consumers).
+#pragma once
+#include "common.h"
+
+namespace rkp {
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int LINE = 128;                 // bytes of one row's 32-deep k-tile (hi | lo)
+constexpr float SCALE_W = 128.0f;         // static ranges when no bound is published (as gemm.hip)
+constexpr float SCALE_Z = 32.0f;
+
+__host__ __device__ inline int kp_of(int K) { return (K + 31) & ~31; }
+
+// 4 consecutive-k fp32 values -> 4 fp16 "hi" + 4 fp16 "lo" of s.x  (identical to gemm.hip split4:
+// the two paths produce the same pieces, so their contractions agree bit for bit)
+__device__ __forceinline__ void split4(const float4 v, const float s, uint2 &hi, uint2 &lo) {
+  const f32x2 a = {v.x * s, v.y * s}, b = {v.z * s, v.w * s};
+  const f16x2 ha = __builtin_convertvector(a, f16x2), hb = __builtin_convertvector(b, f16x2);
+  const f32x2 la = a - __builtin_convertvector(ha, f32x2), lb = b - __builtin_convertvector(hb, f32x2);
+  const f16x2 qa = __builtin_convertvector(la, f16x2), qb = __builtin_convertvector(lb, f16x2);
+  hi.x = __builtin_bit_cast(uint32_t, ha); hi.y = __builtin_bit_cast(uint32_t, hb);
+  lo.x = __builtin_bit_cast(uint32_t, qa); lo.y = __builtin_bit_cast(uint32_t, qb);
+}
+
+// scale of an operand from its published maximum (64 slots of fp32 bit patterns, gemm.hip
+// scale_from): max . s in [2^13, 2^14); all slots zero / no slots: the static default.
+// Must be called by a whole wave (it shuffles).
+__device__ __forceinline__ float scale_from(const uint32_t *slots, float dflt) {
+  if (slots == nullptr) return dflt;
+  uint32_t m = slots[threadIdx.x & 63];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+  if (m == 0) return dflt;
+  const int e = min(max((int)(m >> 23) - 127, -100), 100);
+  return __uint_as_float((uint32_t)(13 - e + 127) << 23);
+}
+
+// store the split of 4 consecutive k (k % 4 == 0) of one image row
+__device__ __forceinline__ void store_split4(char *row_base, int k, const float4 v, const float s) {
+  uint2 hi, lo;
+  split4(v, s, hi, lo);
+  char *d = row_base + (k >> 5) * LINE + (k & 31) * 2;
+  *reinterpret_cast<uint2 *>(d) = hi;
+  *reinterpret_cast<uint2 *>(d + 64) = lo;
+}
+
+struct SplitW {
+  const float *W;            // [n_items, h] table the decoder reads
+  const int32_t *items;      // compact column -> table row
+  const int32_t *counts;     // [0] = n_b (device)
+  const uint32_t *amax;      // 64 slots: bound of |W| (nullable)
+  char *wp;                  // W image   [n rows][KT]
+  char *wtp;                 // W^T image [Hp rows][n_ld / 32]
+  float *scales;             // [1] <- the scale used
+  int h, KT;                 // KT = kp_of(h) / 32
+  int n_ld;                  // items padded (multiple of 32): row pitch of the W^T image = n_ld / 32 lines
+};
+
+// One workgroup (NT threads, NT = 256 or 512) splits the 32 gathered rows of item tile `tile`:
+// W image rows by direct 8-byte stores, the W^T image through an LDS transposition, 64 hidden units
+// at a time.  smem: 2 * 32 * 66 * 2 bytes (8448).
+constexpr int SPLIT_W_LDS = 2 * 32 * 66 * 2;
+template <int NT>
+__device__ __forceinline__ void split_w_job(const SplitW &p, const int tile, char *smem) {
+  const int n_b = p.counts[0];
+  const int k0 = tile * 32;
+  if (k0 >= n_b) return;
+  const float s = scale_from(p.amax, SCALE_W);
+  if (tile == 0 && threadIdx.x == 0) p.scales[1] = s;
+  const int tid = threadIdx.x;
+  const int Kp = p.KT * 32;
+  uint16_t *sh = reinterpret_cast<uint16_t *>(smem);          // [plane][item 32][66]
+  for (int j0 = 0; j0 < Kp; j0 += 64) {
+    // phase 1: item rows -> split -> W image + LDS (row-major)
+    for (int u = tid; u < 32 * 16; u += NT) {
+      const int it = u >> 4, q = u & 15;
+      const int j = j0 + q * 4;
+      const int c = k0 + it;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < n_b && j < p.h) v = *reinterpret_cast<const float4 *>(p.W + (int64_t)p.items[c] * p.h + j);
+      uint2 hi, lo;
+      split4(v, s, hi, lo);
+      if (c < n_b && j < Kp) {
+        char *d = p.wp + (int64_t)c * p.KT * LINE + (j >> 5) * LINE + (j & 31) * 2;
+        *reinterpret_cast<uint2 *>(d) = hi;
+        *reinterpret_cast<uint2 *>(d + 64) = lo;
+      }
+      uint32_t *dh = reinterpret_cast<uint32_t *>(sh + it * 66 + q * 4);
+      uint32_t *dl = reinterpret_cast<uint32_t *>(sh + 32 * 66 + it * 66 + q * 4);
+      dh[0] = hi.x; dh[1] = hi.y;
+      dl[0] = lo.x; dl[1] = lo.y;
+    }
+    __syncthreads();
+    // phase 2: (hidden unit j, 16-byte piece pc): 8 items of one plane -> one piece of the W^T line
+    for (int u = tid; u < 64 * 8; u += NT) {
+      const int jj = u >> 3, pc = u & 7;
+      const int j = j0 + jj;
+      if (j < Kp) {
+        const uint16_t *src = sh + (pc >> 2) * 32 * 66 + ((pc & 3) * 8) * 66 + jj;
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          w[e] = (uint32_t)src[(2 * e) * 66] | ((uint32_t)src[(2 * e + 1) * 66] << 16);
+        char *d = p.wtp + ((int64_t)j * (p.n_ld >> 5) + tile) * LINE + pc * 16;
+        *reinterpret_cast<uint4 *>(d) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace rkp
+
+// split jobs riding on the encoder-forward launch (rk_ae_encode_fwd_at)
+struct rk_enc_split_t {
+  rkp::SplitW sw;       // the W split (n_split workgroups, first in the grid); sw.scales is also
+  int n_split;          // where the Z image's scale goes
+  char *zimg;           // nullable: Z image written by the kernel's epilogue (static scale)
+  int z_kt;
+};
+rkp::SplitW rk_split_w_args(const float *W_de, const rk_block_t *tgt, const int32_t *ranges,
+                            const rk_planes_t *pl);

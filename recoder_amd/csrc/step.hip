@@ -6,6 +6,7 @@
 // Python->ctypes transitions per step (the host enqueue time was approaching the
 // GPU time of the step).
 #include "common.h"
+#include "planes.h"
 
 extern "C" void *rk_event_create(void) {
   // ordering-only events between streams of ONE device: no timing, and no
@@ -276,13 +277,27 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   const bool dw_branch = dw3 && a->dw_stream != nullptr;
   RK_REQUIRE(!dw_branch || (a->ws_dw && a->dw_fork && a->dw_join), "dw_stream needs ws_dw, dw_fork, dw_join");
 
+  // pre-split operand planes (decode16.hip): W_de[items] is split by extra workgroups of the
+  // encoder-forward launch, Z by that kernel's epilogue; decode and dZ copy the images into LDS
+  const bool pl = a->planes != nullptr && rk_gemm_split16() != 0;
   if (phase & RK_STEP_FWD_DW) {
     {
       Timer t(a, RK_ENTRY_ENCODE_FWD, sm);
-      if (a->cursor)
+      if (pl) {
+        rk_enc_split_t es = {};
+        es.sw = rk_split_w_args(W_de, blk, a->ranges, a->planes);
+        es.n_split = rk_cdiv(blk->n_cap, 32);
+        es.zimg = act_bounded(a->act) ? (char *)a->planes->z : nullptr;
+        es.z_kt = rkp::kp_of(h) / 32;
+        RK_REQUIRE(a->planes->h == h && B <= a->planes->B_cap && blk->n_cap <= a->planes->n_cap,
+                   "planes were laid out for another shape");
         RK_TRY(rk_ae_encode_fwd_at(blk, a->row_off, B, a->par[RK_PAR_W_EN].p, a->par[RK_PAR_B_EN].p, h,
                                    a->keep, a->noise_p, a->seed, a->cursor, a->cursor_off, a->users,
-                                   a->act, a->Z0, planes ? a->zt_planes : nullptr, sm));
+                                   a->act, a->Z0, planes ? a->zt_planes : nullptr, sm, &es, a->rng_step));
+      } else if (a->cursor)
+        RK_TRY(rk_ae_encode_fwd_at(blk, a->row_off, B, a->par[RK_PAR_W_EN].p, a->par[RK_PAR_B_EN].p, h,
+                                   a->keep, a->noise_p, a->seed, a->cursor, a->cursor_off, a->users,
+                                   a->act, a->Z0, planes ? a->zt_planes : nullptr, sm, nullptr, 0));
       else if (planes)
         RK_TRY(rk_ae_encode_fwd_planes(blk, a->row_off, B, a->par[RK_PAR_W_EN].p, a->par[RK_PAR_B_EN].p,
                                        h, a->keep, a->noise_p, a->seed, a->rng_step, a->users, a->act,
@@ -294,8 +309,15 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     {
       Timer t(a, RK_ENTRY_DECODE_LOSS, sm);
       if (a->ranges && !act_bounded(a->act)) RK_TRY(rk_amax(a->Z0, (int64_t)B * h, a->ranges, sm));
-      RK_TRY(rk_decode_loss(a->Z0, B, h, blk, a->row_off, W_de, a->par[RK_PAR_B_DE].p, a->loss_kind,
-                            a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, a->ranges, sm));
+      if (pl) {
+        // (unbounded activations: the split scale of Z needs its maximum first)
+        if (!act_bounded(a->act)) RK_TRY(rk_split_z(a->Z0, B, h, a->ranges, a->planes, sm));
+        RK_TRY(rk_decode_loss_planes(a->planes, B, blk, a->row_off, a->par[RK_PAR_B_DE].p, a->loss_kind,
+                                     a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, sm));
+      } else {
+        RK_TRY(rk_decode_loss(a->Z0, B, h, blk, a->row_off, W_de, a->par[RK_PAR_B_DE].p, a->loss_kind,
+                              a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, a->ranges, sm));
+      }
       if (mnll) RK_TRY(rk_mnll_finish(a->dO, B, blk, a->row_off, a->inv_B, a->loss_part, sm));
     }
     if (dw_branch) RK_TRY(rk_event_record(a->dw_fork, sm));      // dO and the Z^T planes are ready
@@ -315,7 +337,10 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   if (phase & RK_STEP_DZ_ENC) {
     {
       Timer t(a, RK_ENTRY_DECODE_BWD_DZ, sm);
-      RK_TRY(rk_decode_bwd_dz(a->dO, B, h, blk, W_de, a->Z0, a->act, a->dZ0, a->ws, a->ranges, sm));
+      if (pl)
+        RK_TRY(rk_decode_bwd_dz_planes(a->dO, B, a->planes, blk, a->Z0, a->act, a->dZ0, a->ws, sm));
+      else
+        RK_TRY(rk_decode_bwd_dz(a->dO, B, h, blk, W_de, a->Z0, a->act, a->dZ0, a->ws, a->ranges, sm));
     }
     if (a->tied || mnll || !whole) {
       Timer t(a, RK_ENTRY_ENCODE_BWD, sm);

@@ -49,6 +49,7 @@ class TimedLib:
     if not name.startswith("rk_") or name in ("rk_dz_workspace_bytes", "rk_dw_workspace_bytes", "rk_dw_splits", "rk_encode_bwd_segments", "rk_loss_partials", "rk_decode_row_tile",
                                               "rk_dw3_workspace_bytes", "rk_dw3_max_splits", "rk_dw3_slabs", "rk_gemm_split16",
                                               "rk_dw3_planes_bytes", "rk_dw3_rows_pad", "rk_dw3_cols_pad",
+                                              "rk_planes_bytes", "rk_planes_layout",
                                               "rk_last_error", "rk_version"):
       return fn
 
@@ -145,7 +146,9 @@ class FusedEngine:
     h0 = self.h[0]
     ld_cap = cdiv(n_cap, 32) * 32
     self.B_cap, self.n_cap, self.ld_cap = B_cap, n_cap, ld_cap
-    self.dO = torch.empty(B_cap * ld_cap, **f)
+    # (zeroed: the padding columns [n_b, ld) of its rows meet the zeros of the W^T plane image in the
+    # dZ contraction and must be finite)
+    self.dO = torch.zeros(B_cap * ld_cap, **f)
     self.G_de = torch.empty(n_cap * h0, **f)
     # the fused dW + encoder-backward launch writes G_en in row segments (long item columns)
     self.G_en = torch.empty(n_cap * h0 * self.lib.rk_encode_bwd_segments(B_cap), **f)
@@ -173,6 +176,15 @@ class FusedEngine:
     # Z^T as bf16 planes for the dW kernel, written by the encoder forward of the one-call step
     # (zeroed once: the padding columns are never written)
     self.zt_planes = torch.zeros(self.lib.rk_dw3_planes_bytes(B_cap, h0) // 4 + 16, **f)
+    # pre-split operand planes of the decoder contractions (csrc/planes.h); RK_PLANES=0: the
+    # in-loop split of round 2
+    self.planes = None
+    if self.split16 and os.environ.get("RK_PLANES", "1") != "0":
+      from ._lib import RkPlanes
+      self.planes_buf = torch.zeros(self.lib.rk_planes_bytes(B_cap, h0, n_cap) // 4 + 64, **f)
+      self.planes = RkPlanes()
+      check(self.lib.rk_planes_layout(ptr(self.planes_buf), B_cap, h0, n_cap, ctypes.byref(self.planes)),
+            "rk_planes_layout")
     self.n_part = self.lib.rk_loss_partials(B_cap, n_cap)
     self.loss_part = torch.zeros(self.n_part, **f)
     self.loss_out = torch.zeros(1, **f)
@@ -629,6 +641,8 @@ class FusedEngine:
     st.G_de, st.G_en, st.gb_de = ptr(self.G_de), ptr(self.G_en), ptr(self.gb_de)
     st.gb_part, st.ws = ptr(self.gb_part), ptr(self.ws)
     st.zt_planes = ptr(self.zt_planes)
+    st.planes = (ctypes.addressof(self.planes)
+                 if self.planes is not None and self.item_parallel is None else None)
     self._check_weight_range()
     st.ranges = ptr(self.ranges)
     plain = dp is None and not m.is_constrained and self.loss_id != LOSS_MNLL
