@@ -314,6 +314,9 @@ int64_t rk_planes_bytes(int32_t B_cap, int32_t h, int32_t n_cap);
 /* tuning / test hook: rows of a decode tile, 128 or 64 (the tile shape of rk_decode_loss); 0 = by
  * the problem's size (default) */
 void rk_planes_tile(int32_t rows);
+/* tuning probe (tools/probes/planes_phase_probe.py): device buffer of 8 uint64 per workgroup of the
+ * largest grid, or NULL (default) to switch it off */
+void rk_planes_probe(unsigned long long *buffer);
 int rk_planes_layout(void *buffer, int32_t B_cap, int32_t h, int32_t n_cap, rk_planes_t *out);
 /* W_de[tgt->items[0 .. n_b)] -> pl->w and pl->wt; the scale from ranges[64..127] (rk_amax notes) */
 int rk_split_w(const float *W_de, int32_t h, const rk_block_t *tgt, const int32_t *ranges,

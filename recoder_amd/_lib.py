@@ -122,6 +122,7 @@ SIGNATURES = {
   "rk_amax": (c_int32, [_P, c_int64, _P, _P]),
   "rk_planes_bytes": (c_int64, [c_int32, c_int32, c_int32]),
   "rk_planes_tile": (None, [c_int32]),
+  "rk_planes_probe": (None, [_P]),
   "rk_planes_layout": (c_int32, [_P, c_int32, c_int32, c_int32, POINTER(RkPlanes)]),
   "rk_split_w": (c_int32, [_P, c_int32, _BLK, _P, POINTER(RkPlanes), _P]),
   "rk_split_z": (c_int32, [_P, c_int32, c_int32, _P, POINTER(RkPlanes), _P]),

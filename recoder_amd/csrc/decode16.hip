@@ -20,6 +20,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // (a first-class vector: HIP's uint4 is a struct)
 
 constexpr int ROWB = 144;            // LDS row: 64 B hi | 64 B lo | 16 B pad (odd number of 16-B slots)
 constexpr float SCALE_DO = 1024.0f;  // dO without a published maximum (as gemm.hip)
@@ -30,7 +32,42 @@ __device__ __forceinline__ void publish_amax(int32_t *counts, int slot, float v)
   atomicMax(reinterpret_cast<unsigned int *>(counts) + 8 + (slot & 63), __float_as_uint(v));
 }
 
+// (force-inlined helpers with compile-time trip counts: a _Pragma("unroll") loop inside a macro that
+// is expanded inside ANOTHER macro was not unrolled, and the register ring went to scratch memory)
+template <int N>
+__device__ __forceinline__ void ld_pieces(u32x4 (&r)[N], const char *const (&src)[N], const int64_t off) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) r[i] = *reinterpret_cast<const u32x4 *>(src[i] + off);
+}
+template <int N>
+__device__ __forceinline__ void st_pieces(char *base, const int (&dst)[N], const u32x4 (&r)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) *reinterpret_cast<u32x4 *>(base + dst[i]) = r[i];
+}
+
+template <int TOTAL, int N>
+__device__ __forceinline__ void st_pieces_n(char *base, const int (&dst)[N], const u32x4 (&r)[N], const int tid) {
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (TOTAL % 256 == 0 || tid + 256 * i < TOTAL) *reinterpret_cast<u32x4 *>(base + dst[i]) = r[i];
+}
+// this lane's A fragments of one 32-deep k-tile: 8 consecutive k per k-step = 2 x 16 bytes
+__device__ __forceinline__ void ld_a4(f32x4 (&r)[4], const float *src) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const f32x4 *>(src + (u >> 1) * 16 + (u & 1) * 4);
+}
+
+// rk_planes_probe(buffer): every workgroup of the two contraction kernels records wall_clock64() at
+// entry, after the prologue (first tile staged), after the k-loop and after the epilogue, plus its
+// tile index (tools/probes/planes_phase_probe.py).  One uniform branch per stamp.
+unsigned long long *g_probe = nullptr;
+#define RK_STAMP(k)                                                                  \
+  do {                                                                               \
+    if (p.probe && threadIdx.x == 0) p.probe[(size_t)L * 8 + (k)] = wall_clock64();  \
+  } while (0)
+
 struct DecP {
+  unsigned long long *probe;
   const char *zp, *wp;        // A / B plane images (row pitch KT * 128 bytes)
   const float *scales;        // [0] scale of Z, [1] scale of W
   int KT;
@@ -54,7 +91,7 @@ struct DecP {
 // 4 waves as 2 x 2, wave tile (TM*32) x (TN*32): BM = 64*TM, BN = 64*TN.  BK = 32, two LDS stages,
 // register prefetch of the next k-tile, ONE barrier per k-tile, every LDS read of a tile ahead of
 // its MFMAs (tools/probes/presplit_gemm.hip: 15 us at the C2 shape against 24 for the in-loop split).
-template <int TM, int TN, int EPI>
+template <int TM, int TN, int EPI, int RD = 3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 void decode_planes_kernel(DecP p) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -74,6 +111,7 @@ void decode_planes_kernel(DecP p) {
   const int m0 = mt * BM, n0 = nt * BN;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1, l31 = lane & 31, lh = lane >> 5;
+  RK_STAMP(0);
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -98,33 +136,37 @@ void decode_planes_kernel(DecP p) {
     srcB[i] = p.wp + (int64_t)min(n0 + row, N - 1) * pitch + piece * 16;
     dstB[i] = BM * ROWB + row * ROWB + piece * 16;
   }
-  uint4 ra[A_PT], rb[B_PT];
-  // (macros, not lambdas capturing the arrays: hipcc put them into scratch memory then)
-#define GLOAD(kt)                                                                  \
-  _Pragma("unroll") for (int i = 0; i < A_PT; ++i)                                 \
-    ra[i] = *reinterpret_cast<const uint4 *>(srcA[i] + (int64_t)(kt) * rkp::LINE); \
-  _Pragma("unroll") for (int i = 0; i < B_PT; ++i)                                 \
-    rb[i] = *reinterpret_cast<const uint4 *>(srcB[i] + (int64_t)(kt) * rkp::LINE);
-#define SSTORE(buf)                                                                \
-  _Pragma("unroll") for (int i = 0; i < A_PT; ++i)                                 \
-    *reinterpret_cast<uint4 *>(smem + (buf) * STAGE + dstA[i]) = ra[i];            \
-  _Pragma("unroll") for (int i = 0; i < B_PT; ++i)                                 \
-    *reinterpret_cast<uint4 *>(smem + (buf) * STAGE + dstB[i]) = rb[i];
+  // register ring, RD k-tiles deep: K = h is SHORT (7 k-tiles at h = 200) and a tile's loads take
+  // 1-2 us to come back from L2 -- with one tile in flight the k-loop was 7 round trips long
+  u32x4 ra0[A_PT], ra1[A_PT], ra2[A_PT], rb0[B_PT], rb1[B_PT], rb2[B_PT];
+#define GLOAD(slot, kt)                                                                  \
+  ld_pieces(ra##slot, srcA, (int64_t)(kt) * rkp::LINE);                                  \
+  ld_pieces(rb##slot, srcB, (int64_t)(kt) * rkp::LINE);
+#define SSTORE(buf, slot)                                                                \
+  st_pieces(smem + (buf) * STAGE, dstA, ra##slot);                                       \
+  st_pieces(smem + (buf) * STAGE, dstB, rb##slot);
 
-  // Loss epilogue operands (gathered bias, bitmap words) are fetched NOW so that their dependent
-  // round trips overlap the k-loop instead of the epilogue.
+  const int KT = p.KT;
+  GLOAD(0, 0);
+  GLOAD(1, min(1, KT - 1));
+  GLOAD(2, min(2, KT - 1));
+  // Loss epilogue operands (gathered bias, bitmap words) are fetched NOW, behind the first tiles'
+  // loads, so that their dependent round trips overlap the k-loop instead of the epilogue.  All
+  // gather indices first, then all values: independent loads (a `bidx ? bidx[n] : n` select per
+  // element made hipcc branch and wait vmcnt(0) for every one of them: 16 serial round trips).
   constexpr bool LOSS = (EPI != EPI_STORE);
   float pre_bv[LOSS ? TN : 1][4];
   uint32_t pre_w[LOSS ? TM : 1][LOSS ? TN : 1][4];
   if (LOSS) {
+    int gi[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        gi[j][e] = p.bidx[min(n0 + (wn * TN + j) * 32 + (lane & 7) * 4 + e, N - 1)];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int nb = n0 + (wn * TN + j) * 32;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int nc = min(nb + (lane & 7) * 4 + e, N - 1);
-        pre_bv[j][e] = p.bias[p.bidx ? p.bidx[nc] : nc];
-      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -134,59 +176,71 @@ void decode_planes_kernel(DecP p) {
           pre_w[i][j][it] = p.blk.bits_rc[(int64_t)row * p.blk.ldw_rc + min(nb >> 5, p.blk.ldw_rc - 1)];
         }
     }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pre_bv[j][e] = p.bias[gi[j][e]];
   }
-
-  GLOAD(0);
-  SSTORE(0);
+  SSTORE(0, 0);
   __syncthreads();
+  RK_STAMP(1);
   const int a_off = ((wm * TM) * 32 + l31) * ROWB + lh * 16;
   const int b_off = BM * ROWB + ((wn * TN) * 32 + l31) * ROWB + lh * 16;
-  const int KT = p.KT;
-  int buf = 0;
-  for (int kt = 0; kt < KT; ++kt, buf ^= 1) {
-    GLOAD(min(kt + 1, KT - 1));                 // the next tile, in flight under this one's MFMAs
-    const char *S = smem + buf * STAGE;
-    f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const char *q = S + a_off + i * 32 * ROWB + ks * 32;
-        ah[ks][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q));
-        al[ks][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q + 64));
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const char *q = S + b_off + j * 32 * ROWB + ks * 32;
-        bh[ks][j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q));
-        bl[ks][j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q + 64));
-      }
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      // small terms first (the order of gemm.hip: bit-identical accumulators)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
-    }
-    SSTORE(buf ^ 1);                            // (last read in the previous iteration)
-    __syncthreads();
+  // tile kt sits in ring slot kt % RD until it is stored into LDS stage kt & 1 (at the end of
+  // iteration kt - 1); iteration kt refills that slot with tile kt + RD (clamped: never stored)
+  static_assert(RD == 3, "the k-loop below is unrolled by hand for a ring of 3");
+#define KTILE(U, UN)                                                                    \
+  if (kt0 + (U) < KT) {                                                                  \
+    const int kt = kt0 + (U);                                                            \
+    GLOAD(U, min(kt + RD, KT - 1));                                                     \
+    const char *S = smem + (kt & 1) * STAGE;                                            \
+    f16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];                                   \
+    _Pragma("unroll")                                                                   \
+    for (int ks = 0; ks < 2; ++ks) {                                                    \
+    _Pragma("unroll")                                                                   \
+      for (int i = 0; i < TM; ++i) {                                                    \
+        const char *q = S + a_off + i * 32 * ROWB + ks * 32;                            \
+        ah[ks][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q));     \
+        al[ks][i] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q + 64)); \
+      }                                                                                 \
+    _Pragma("unroll")                                                                   \
+      for (int j = 0; j < TN; ++j) {                                                    \
+        const char *q = S + b_off + j * 32 * ROWB + ks * 32;                            \
+        bh[ks][j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q));     \
+        bl[ks][j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q + 64)); \
+      }                                                                                 \
+    }                                                                                   \
+    _Pragma("unroll")                                                                   \
+    for (int ks = 0; ks < 2; ++ks) {                                                    \
+    _Pragma("unroll")                                                                   \
+      for (int i = 0; i < TM; ++i)                                                      \
+    _Pragma("unroll")                                                                   \
+        for (int j = 0; j < TN; ++j)                                                    \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][i], bh[ks][j], acc[i][j], 0, 0, 0); \
+    _Pragma("unroll")                                                                   \
+      for (int i = 0; i < TM; ++i)                                                      \
+    _Pragma("unroll")                                                                   \
+        for (int j = 0; j < TN; ++j)                                                    \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bl[ks][j], acc[i][j], 0, 0, 0); \
+    _Pragma("unroll")                                                                   \
+      for (int i = 0; i < TM; ++i)                                                      \
+    _Pragma("unroll")                                                                   \
+        for (int j = 0; j < TN; ++j)                                                    \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0); \
+    }                                                                                   \
+    SSTORE((kt + 1) & 1, UN);                                                           \
+    __syncthreads();                                                                    \
   }
+  for (int kt0 = 0; kt0 < KT; kt0 += RD) {
+    KTILE(0, 1)
+    KTILE(1, 2)
+    KTILE(2, 0)
+  }
+#undef KTILE
 #undef GLOAD
 #undef SSTORE
 
+  RK_STAMP(2);
   // ------------------------------------------------------------- epilogues (as gemm.hip)
   {
     const float inv = 1.0f / (p.scales[0] * p.scales[1]);       // exact: powers of two
@@ -223,11 +277,11 @@ void decode_planes_kernel(DecP p) {
         const int n = n0 + (wn * TN + j) * 32 + c4 * 4;
         float bv[4] = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) {
+          int gi[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int nc = min(n + e, N - 1);
-            bv[e] = p.bias[p.bidx ? p.bidx[nc] : nc];
-          }
+          for (int e = 0; e < 4; ++e) gi[e] = p.bidx[min(n + e, N - 1)];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bv[e] = p.bias[gi[e]];
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -337,10 +391,13 @@ void decode_planes_kernel(DecP p) {
       }
     }
   }
+  RK_STAMP(3);
+  if (p.probe && threadIdx.x == 0) p.probe[(size_t)L * 8 + 4] = (unsigned long long)t + 1;
 }
 
 // ------------------------------------------------------------------------------------ dZ
 struct DzP {
+  unsigned long long *probe;
   const float *dO;            // [M][ld] fp32 (columns [n_t, ld): anything, masked in the kernel)
   const char *wtp;            // W^T image: row j = hidden unit, pitch (n_ld / 32) lines
   const float *scales;        // [1] scale of W
@@ -387,6 +444,7 @@ void dz_planes_kernel(DzP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
+  RK_STAMP(0);
   f32x16 acc[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j)
@@ -406,77 +464,75 @@ void dz_planes_kernel(DzP p) {
     srcB[i] = p.wtp + ((int64_t)min(n0 + row, rkp::kp_of(N) - 1) * (p.n_ld >> 5) + (kbeg >> 5)) * rkp::LINE + piece * 16;
     dstB[i] = row * ROWB + piece * 16;
   }
-  uint4 rb[B_PT];
-  float4 an[4], ac[4];
-#define GLOADB(kt)                                                                 \
-  _Pragma("unroll") for (int i = 0; i < B_PT; ++i)                                 \
-    rb[i] = *reinterpret_cast<const uint4 *>(srcB[i] + (int64_t)(kt) * rkp::LINE);
-#define GLOADA(dst, kt)                                                            \
-  _Pragma("unroll") for (int u = 0; u < 4; ++u)                                    \
-    dst[u] = *reinterpret_cast<const float4 *>(a_src + (kt) * 32 + (u >> 1) * 16 + (u & 1) * 4);
-#define SSTOREB(buf)                                                               \
-  _Pragma("unroll") for (int i = 0; i < B_PT; ++i)                                 \
-    if ((BN * 8) % 256 == 0 || tid + 256 * i < BN * 8)                             \
-      *reinterpret_cast<uint4 *>(smem + (buf) * STAGE + dstB[i]) = rb[i];
-
-  GLOADB(0);
-  GLOADA(ac, 0);
-  SSTOREB(0);
+  // register ring, 3 k-tiles deep, for both operands (a split of the C2 shape holds 4 k-tiles: nearly
+  // all of its loads are in flight at once); B goes on through two LDS stages, A stays in registers
+  u32x4 rb0[B_PT], rb1[B_PT], rb2[B_PT];
+  f32x4 ra0[4], ra1[4], ra2[4];
+#define GLOAD(slot, kt)                                                            \
+  ld_pieces(rb##slot, srcB, (int64_t)(kt) * rkp::LINE);                            \
+  ld_a4(ra##slot, a_src + (kt) * 32);
+#define SSTOREB(buf, slot) st_pieces_n<BN * 8>(smem + (buf) * STAGE, dstB, rb##slot, tid);
+  GLOAD(0, 0);
+  GLOAD(1, min(1, nk - 1));
+  GLOAD(2, min(2, nk - 1));
+  SSTOREB(0, 0);
   __syncthreads();
+  RK_STAMP(1);
   const int b_off = l31 * ROWB + lh * 16;
-  int buf = 0;
-  for (int kt = 0; kt < nk; ++kt, buf ^= 1) {
-    const int kn = min(kt + 1, nk - 1);
-    GLOADB(kn);
-    GLOADA(an, kn);
-    const char *S = smem + buf * STAGE;
-    // K tail: the columns [K, ld) of dO may hold anything (stale values of an earlier, wider block:
-    // scaled by THIS block's split scale they can overflow fp16, and inf x 0 = nan) -- zeroed here,
-    // in the last k-tile of the last split only (uniform branch, behind the loads' wait)
-    if (kt == nk - 1 && kbeg + nk * 32 > kend) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int k = kbeg + kt * 32 + (u >> 1) * 16 + lh * 8 + (u & 1) * 4;
-        ac[u].x = k + 0 < kend ? ac[u].x : 0.f;
-        ac[u].y = k + 1 < kend ? ac[u].y : 0.f;
-        ac[u].z = k + 2 < kend ? ac[u].z : 0.f;
-        ac[u].w = k + 3 < kend ? ac[u].w : 0.f;
-      }
-    }
-    f16x8 ah[2], al[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      uint2 h0, l0, h1, l1;
-      rkp::split4(ac[2 * ks], a_scale, h0, l0);
-      rkp::split4(ac[2 * ks + 1], a_scale, h1, l1);
-      ah[ks] = __builtin_bit_cast(f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
-      al[ks] = __builtin_bit_cast(f16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      f16x8 bh[TN], bl[TN];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const char *q = S + b_off + j * 32 * ROWB + ks * 32;
-        bh[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q));
-        bl[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q + 64));
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh[j], acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl[j], acc[j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh[j], acc[j], 0, 0, 0);
-    }
-    SSTOREB(buf ^ 1);
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 4; ++u) ac[u] = an[u];
+#define KTILE(U, UN)                                                                                \
+  if (kt0 + (U) < nk) {                                                                             \
+    const int kt = kt0 + (U);                                                                       \
+    f32x4 ac[4];                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) ac[u] = ra##U[u];                                 \
+    /* K tail: the columns [K, ld) of dO may hold anything (stale values of an earlier, wider */   \
+    /* block: scaled by THIS block's split scale they can overflow fp16, and inf x 0 = nan) -- */  \
+    /* zeroed here, in the last k-tile of the last split only (uniform branch) */                   \
+    if (kt == nk - 1 && kbeg + nk * 32 > kend) {                                                    \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                               \
+        const int k = kbeg + kt * 32 + (u >> 1) * 16 + lh * 8 + (u & 1) * 4;                        \
+        ac[u].x = k + 0 < kend ? ac[u].x : 0.f;                                                     \
+        ac[u].y = k + 1 < kend ? ac[u].y : 0.f;                                                     \
+        ac[u].z = k + 2 < kend ? ac[u].z : 0.f;                                                     \
+        ac[u].w = k + 3 < kend ? ac[u].w : 0.f;                                                     \
+      }                                                                                             \
+    }                                                                                               \
+    f16x8 ah[2], al[2];                                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                              \
+      uint2 h0, l0, h1, l1;                                                                         \
+      rkp::split4(make_float4(ac[2 * ks].x, ac[2 * ks].y, ac[2 * ks].z, ac[2 * ks].w), a_scale, h0, l0); \
+      rkp::split4(make_float4(ac[2 * ks + 1].x, ac[2 * ks + 1].y, ac[2 * ks + 1].z, ac[2 * ks + 1].w), a_scale, h1, l1); \
+      ah[ks] = __builtin_bit_cast(f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));                       \
+      al[ks] = __builtin_bit_cast(f16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));                       \
+    }                                                                                               \
+    GLOAD(U, min(kt + 3, nk - 1));                                                                  \
+    const char *S = smem + (kt & 1) * STAGE;                                                        \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                              \
+      f16x8 bh[TN], bl[TN];                                                                         \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                              \
+        const char *q = S + b_off + j * 32 * ROWB + ks * 32;                                        \
+        bh[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q));                     \
+        bl[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q + 64));                \
+      }                                                                                             \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                \
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh[j], acc[j], 0, 0, 0);            \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                \
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl[j], acc[j], 0, 0, 0);            \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                \
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh[j], acc[j], 0, 0, 0);            \
+    }                                                                                               \
+    SSTOREB((kt + 1) & 1, UN);                                                                      \
+    __syncthreads();                                                                                \
   }
-#undef GLOADB
-#undef GLOADA
+  for (int kt0 = 0; kt0 < nk; kt0 += 3) {
+    KTILE(0, 1)
+    KTILE(1, 2)
+    KTILE(2, 0)
+  }
+#undef KTILE
+#undef GLOAD
 #undef SSTOREB
 
+  RK_STAMP(2);
   const float inv = 1.0f / (a_scale * b_scale);
   // slab store: a lane holds 16 rows of ONE column; through the per-wave LDS transpose a lane owns
   // 4 x (one row, 4 consecutive columns) and stores 16 bytes at a time
@@ -499,6 +555,8 @@ void dz_planes_kernel(DzP p) {
     }
     __builtin_amdgcn_wave_barrier();
   }
+  RK_STAMP(3);
+  if (p.probe && threadIdx.x == 0) p.probe[(size_t)L * 8 + 4] = (unsigned long long)t + 1;
 }
 
 // ---------------------------------------------------------------- stand-alone split passes
@@ -546,15 +604,18 @@ inline int dec_tm(int B, int n_cap) {
     g_dec_tm = e ? (atoi(e) == 64 ? 1 : (atoi(e) == 128 ? 2 : 0)) : 0;
   }
   if (g_dec_tm > 0) return g_dec_tm;
-  // 128 x 128 tiles (one workgroup per CU, 512 VGPRs each) once they fill the chip twice over;
-  // below that 64 x 128 (two per CU): C2 (B = 500, n_b ~ 7.9 k) 21.3 vs 25.5 us
-  return rk_cdiv(B, 128) * rk_cdiv(n_cap, 128) >= 512 ? 2 : 1;
+  // 128 x 128 tiles for large batches; below that 64 x 128 (two workgroups per CU): C2 (B = 500,
+  // n_b ~ 7.9 k: one wave of either tiling) 20.4 vs 22.4 us.  (n_b only exists on the device.)
+  (void)n_cap;
+  return B >= 1024 ? 2 : 1;
 }
 
 }  // namespace
 
 // ------------------------------------------------------------------------------- C ABI
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+extern "C" void rk_planes_probe(unsigned long long *buffer) { g_probe = buffer; }
 
 extern "C" void rk_planes_tile(int32_t rows) { g_dec_tm = rows == 64 ? 1 : (rows == 128 ? 2 : 0); }
 
@@ -624,6 +685,7 @@ extern "C" int rk_decode_loss_planes(const rk_planes_t *pl, int32_t B, const rk_
   RK_REQUIRE(row_off >= 0 && row_off + B <= tgt->S_cap, "row slice out of range");
   if (B == 0) return 0;
   DecP p = {};
+  p.probe = g_probe;
   p.zp = (const char *)pl->z; p.wp = (const char *)pl->w; p.scales = pl->scales;
   p.KT = rkp::kp_of(pl->h) / 32;
   p.M = B; p.n_cap = tgt->n_cap; p.Ndev = tgt->counts;
@@ -677,6 +739,7 @@ extern "C" int rk_decode_bwd_dz_planes(const float *dO, int32_t B, const rk_plan
   if (B == 0) return 0;
   const int h = pl->h;
   DzP p = {};
+  p.probe = g_probe;
   p.dO = dO; p.wtp = (const char *)pl->wt; p.scales = pl->scales;
   p.a_amax = reinterpret_cast<const uint32_t *>(tgt->counts) + 8;
   p.counts = tgt->counts; p.n_ld = pl->n_ld;
