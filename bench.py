@@ -151,6 +151,42 @@ def cpu_baseline(cfg, csr, steps, warmup=4):
                      % (done // B, B, warmup, dt, max_seconds))
 
 
+def recall_check(rec, model, cfg, csr, n_held=1000, k=20):
+  """Recall@20 (BASELINE.json's metric names it next to the throughput) of the state the timed run
+  left behind: the product's Recoder.evaluate (strip decode + rk_topk_masked_strip on the GPU)
+  against the oracle's evaluate (reference model.py:513-544, metrics.py:23-29 on the CPU) on the SAME
+  parameters and the same users -- 80 % of each user's items as input, the other 20 % as the
+  relevant set.  Outside the timed region."""
+  import scipy.sparse as sp
+  from oracle import recoder_oracle as orc
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.metrics import Recall
+  rng = np.random.RandomState(123)
+  held = np.sort(rng.choice(csr.shape[0], size=min(n_held, csr.shape[0]), replace=False))
+  rows = csr[held].tocoo()
+  to_target = rng.rand(rows.nnz) < 0.2
+  mk = lambda m: sp.csr_matrix((rows.data[m], (rows.row[m], rows.col[m])), shape=(len(held), csr.shape[1]))
+  csr_in, csr_te = mk(~to_target), mk(to_target)
+  ok = (np.diff(csr_in.indptr) > 0) & (np.diff(csr_te.indptr) > 0)
+  csr_in, csr_te = csr_in[ok], csr_te[ok]
+  got = rec.evaluate(RecommendationDataset(csr_in, csr_te), num_recommendations=k, metrics=[Recall(k)],
+                     batch_size=500)
+  got = float(np.mean(list(got.values())[0]))
+  state = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+  kind = cfg.get("kind", "ae")
+  if kind == "ae":
+    o = orc.OracleRecoder("ae", state, hidden_layers=cfg["hidden_layers"],
+                          activation_type=cfg["activation_type"], loss=cfg["loss"])
+  else:
+    o = orc.OracleRecoder("mf", state, activation_type=cfg["activation_type"], loss=cfg["loss"])
+  want = o.evaluate(csr_in, csr_te, k, 500, [("recall", k)])[("recall", k)]
+  return dict(value=got, oracle=float(want), users=int(csr_in.shape[0]), k=k,
+              match_4dp=bool(round(got, 4) == round(want, 4)),
+              protocol="Recall@%d of %d users after the timed steps: 80 %% of a user's items as input, 20 %% "
+                       "as relevant set (seed 123); product = Recoder.evaluate on the GPU, oracle = "
+                       "oracle/recoder_oracle.py evaluate on the same parameters" % (k, csr_in.shape[0]))
+
+
 def alt_item_parallel(cfg, csr, B, W, K, world, rank, device, sync_all):
   """The same workload with the ITEM dimension sharded (RK_PARALLEL=items): W warm-up + K timed steps
   of B users per rank through Recoder.train, timed like the main run (barrier + synchronize on both
@@ -207,6 +243,7 @@ def main():
   ap.add_argument("--config", default="c2")
   ap.add_argument("--cpu-steps", type=int, default=1000)   # bounded by RK_CPU_SECONDS (20 s)
   ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-recall", action="store_true")
   args = ap.parse_args()
   cfg = CONFIGS[args.config]
 
@@ -403,7 +440,7 @@ def main():
     dominant = dom["name"]
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload
     # (profiles/r*_pmc_traffic.json, tools/pmc_traffic.py); null for other configs
-    traffic = None
+    traffic = traffic_source = None
     if args.config == "c2" and not multi:
       import glob
       files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
@@ -411,6 +448,9 @@ def main():
         ent = json.load(open(files[-1]))["entries"].get(dominant)
         if ent:
           traffic = ent["hbm_bytes_per_launch"]
+          traffic_source = ("%s: committed rocprofv3 PMC passes of this command (FETCH_SIZE / WRITE_SIZE in "
+                            "separate runs, tools/profile_round.sh) -- NOT collected in this run"
+                            % os.path.relpath(files[-1], ROOT))
     # the dW launch group runs on the side stream NEXT to dZ -> encoder backward
     # (rk_ae_step_t.dw_stream): it is not a link of the step's chain then
     side = ["rk_decode_bwd_dw"] if (getattr(eng, "ws_dw", None) is not None and not multi) else []
@@ -420,7 +460,8 @@ def main():
     chain_us = sum(k["avg_us"] for k in kernels if k["name"] not in side)
     ideal_us = sum(k["ideal_us"] for k in kernels)
     roofline = dict(bound=dom["bound"], achieved=dom["achieved"], peak=dom["peak"], unit=dom["unit"],
-                    frac=dom["frac"], traffic=traffic, kernel=dominant, kernel_names=dom["kernels"],
+                    frac=dom["frac"], traffic=traffic, traffic_source=traffic_source, kernel=dominant,
+                    kernel_names=dom["kernels"],
                     avg_launch_ms=dom["avg_us"] / 1e3, samples=dom["samples"],
                     event_pair_overhead_ms=ev_over, kernels=kernels,
                     step=dict(ideal_us=ideal_us, kernel_chain_us=chain_us,
@@ -449,6 +490,14 @@ def main():
     }
     if same_dev:
       out["INVALID"] = "RK_BENCH_ONE_GPU_GLOO: all ranks share one GPU, gloo collectives (a code-path test)"
+    if world == 1 and not multi and not args.no_recall:
+      # Recall@20 of the trained state, product vs oracle (outside the timed region)
+      try:
+        rc = recall_check(rec, model, cfg, csr)
+        out["recall_at_20"], out["recall_match_4dp"], out["recall"] = rc["value"], rc["match_4dp"], rc
+      except Exception as e:          # noqa: BLE001 -- never lose the line
+        out["recall_at_20"], out["recall_match_4dp"] = None, None
+        out["recall"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if world == 1 and not multi and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline(cfg, csr, args.cpu_steps)
   if want_alt:

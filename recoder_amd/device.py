@@ -85,9 +85,17 @@ class DeviceCSR:
     as_t = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.ascontiguousarray(a))
     self = cls.__new__(cls)
     self._init_arrays(shape, as_t(indptr), as_t(indices), None if data is None else as_t(data), device)
-    if check and self.nnz:
-      if int(self.indptr[0].item()) != 0 or self.indptr.numel() != self.shape[0] + 1:
+    if check:
+      # (also for an empty matrix: the collation kernels index indices / data through indptr)
+      ip = self.indptr
+      if ip.numel() != self.shape[0] + 1 or int(ip[0].item()) != 0:
         raise ValueError("indptr must start at 0 and have n_rows + 1 entries")
+      if ip.numel() > 1 and bool((ip[1:] < ip[:-1]).any().item()):
+        raise ValueError("indptr must be non-decreasing")
+      n_idx = int(as_t(indices).numel())
+      if int(ip[-1].item()) > n_idx or (data is not None and int(as_t(data).numel()) < int(ip[-1].item())):
+        raise ValueError("indptr[-1] exceeds len(indices) (or len(data))")
+    if check and self.nnz:
       idx = self.indices[:self.nnz].to(torch.int64)
       if int(idx.min().item()) < 0 or int(idx.max().item()) >= self.shape[1]:
         raise ValueError("column index out of range")

@@ -454,10 +454,12 @@ class FusedEngine:
     main_s = torch.cuda.current_stream()
     ip = self.item_parallel
     if tgt is not None:
+      # (never reached through Recoder.train: it routes these to the generic engine / replicated
+      # training -- model.Recoder._pick_engine_for, _setup_data_parallel)
       if self.kind == "ae" and bool(m.is_constrained):
-        raise NotImplementedError("tied weights with a separate target matrix in training")
+        raise RuntimeError("FusedEngine: tied weights with a separate target matrix belong to the generic engine")
       if ip is not None or self.allreduce is not None:
-        raise NotImplementedError("multi-GPU training with a separate target matrix")
+        raise RuntimeError("FusedEngine: a separate target matrix has no sharded formulation")
     if self.c_step_eligible() and tgt is None and not (ip is not None and self.loss_id == LOSS_MNLL):
       return self._c_train_step(blk, row_off, B, keep_noise, out, global_rows, main_s)
     self._gb_lazy = None

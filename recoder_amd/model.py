@@ -107,6 +107,8 @@ class Recoder(object):
     FactorizationModel subclasses, arbitrary nn.Module losses, sgd/adagrad/rmsprop."""
     if self._fused_kind() is None or self.optimizer_type != "adam":
       return True
+    if getattr(self, "_force_generic", None):
+      return True
     from .nn import fused_supported
     if not fused_supported(self.model):
       if not getattr(self, "_warned_generic", False):
@@ -116,7 +118,14 @@ class Recoder(object):
                     "torch autograd on the GPU instead", self.model.activation_type)
       return True
     if isinstance(self.loss, str):
-      return False
+      # named losses are built as <Loss>(reduction='sum', **loss_params) (model.py:87-99): the fused
+      # epilogues implement the MSE confidence weight and nothing else a module can be given
+      extra = set(self.loss_params) - ({"confidence"} if self.loss == "mse" else set())
+      if extra and not getattr(self, "_warned_loss_params", False):
+        self._warned_loss_params = True
+        log.warning("loss_params %s are outside the fused loss epilogues: training through torch "
+                    "autograd on the GPU instead", sorted(extra))
+      return bool(extra)
     # loss MODULES: the fused epilogues compute the plain summed loss -- anything else a module
     # can be configured with (mean / none reduction, element or class weights) goes through torch
     if isinstance(self.loss, (MSELoss, MultinomialNLLLoss)):
@@ -208,6 +217,14 @@ class Recoder(object):
     if hasattr(eng, "refresh_weight_range"):
       eng.refresh_weight_range()
 
+  def _check_ranges(self):
+    """The same bound, recomputed only when the table changed since it was last taken (its torch
+    version counter / address: predict and recommend are called once per evaluation batch, and a
+    full-table norm is ~800 MB of reads at 1 M items)."""
+    eng = self._engine()
+    if hasattr(eng, "_check_weight_range"):
+      eng._check_weight_range()
+
   def _engine(self):
     if self.__engine is None:
       self.__init_loss_module()
@@ -265,14 +282,9 @@ class Recoder(object):
     if type(self.loss) is str:
       current_state["loss"] = self.loss
       current_state["loss_params"] = self.loss_params
-    # multi-GPU: the replicas are identical; one writer (concurrent writers of one path can
-    # truncate each other on a shared filesystem), the others wait for the file
-    import torch.distributed as dist
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    if not multi or dist.get_rank() == 0:
-      torch.save(current_state, checkpoint_file)
-    if multi:
-      dist.barrier()
+    # (no collective in here: a caller may save from one rank only.  The checkpoint train() writes
+    # under data / item parallelism has one writer and a barrier -- see _epoch_end)
+    torch.save(current_state, checkpoint_file)
     return checkpoint_file
 
   # --------------------------------------------------------------- training
@@ -323,6 +335,7 @@ class Recoder(object):
     assert num_sampling_users >= batch_size and num_sampling_users % batch_size == 0, \
       "number of sampling users should be a multiple of the batch size"
 
+    self._pick_engine_for(train_dataset)
     self.__init_training(train_dataset=train_dataset, lr=lr, weight_decay=weight_decay)
     train_dataset = self._setup_data_parallel(train_dataset, negative_sampling)
     if getattr(self, "_ip", None) is not None:
@@ -361,6 +374,24 @@ class Recoder(object):
                 iters_per_epoch=iters_per_epoch, eval_num_users=eval_num_users,
                 eval_batch_size=eval_batch_size)
     self._sync_user_rows()
+
+  def _pick_engine_for(self, train_dataset):
+    """Combinations the fused step does not cover train through the generic engine (torch autograd
+    on the GPU, recoder_amd/generic.py) instead of raising -- the reference trains all of them
+    (model.py:464-476, nn.py:191-202): tied weights with a separate target matrix."""
+    has_target = getattr(train_dataset, "target_interactions_matrix", None) is not None or \
+        (hasattr(train_dataset, "device_target_csr") and train_dataset.device_target_csr() is not None)
+    tied = self._fused_kind() == "ae" and bool(getattr(self.model, "is_constrained", False))
+    force = "tied weights with a separate target matrix" if (has_target and tied) else None
+    if force != getattr(self, "_force_generic", None):
+      self._force_generic = force
+      if self.__engine is not None:
+        # the engine is rebuilt for this call; the optimizers (and their state) stay
+        if hasattr(self.__engine, "sync_optimizer_steps"):
+          self.__engine.sync_optimizer_steps()
+        self.__engine = None
+      if force:
+        log.warning("%s has no fused HIP step: training through torch autograd on the GPU", force)
 
   def _sync_user_rows(self):
     """Bring every replica up to date with the rows other ranks own -- parameters and
@@ -418,11 +449,13 @@ class Recoder(object):
         return train_dataset
       if dist.get_world_size() == 1 and os.environ.get("RK_FORCE_DP") != "1":
         return train_dataset
-    if self._use_generic():
-      raise NotImplementedError("multi-GPU training is implemented for the fused "
-                                "DynamicAutoencoder / MatrixFactorization paths")
-    if train_dataset.device_target_csr() is not None:
-      raise NotImplementedError("multi-GPU training with a separate target matrix")
+    if self._use_generic() or train_dataset.device_target_csr() is not None:
+      # no sharded formulation for these: every rank trains the same replica on the whole data
+      # (identical results on every rank, no speed-up) instead of refusing to run
+      log.warning("multi-GPU training covers the fused DynamicAutoencoder / MatrixFactorization step "
+                  "without a separate target matrix: running this configuration replicated on "
+                  "every rank")
+      return train_dataset
     if dp is None:
       for p_ in self.model.parameters():          # identical replicas: rank 0's initial weights
         dist.broadcast(p_.data, src=0)
@@ -470,7 +503,15 @@ class Recoder(object):
     nnz_cap = max(1, _top_sum(dcsr.degrees, S))
     n_cap = nnz_cap
     if train and getattr(self, "_dp", None) is not None:
-      n_cap = nnz_cap * self._dp.world      # the union item set can exceed one rank's nnz bound
+      # the union item set can exceed one rank's nnz bound; the SAME capacity on every rank (a
+      # rank with lighter users would otherwise clamp n_b on its own and the gradient exchange
+      # would disagree on its sizes): MAX over the ranks, once per (matrix, group size)
+      cache = self.__dict__.setdefault("_dp_nnz_cap", {})
+      key = (id(dcsr), int(S))
+      if key not in cache:
+        t = torch.tensor([nnz_cap], dtype=torch.int32, device=self.device)
+        cache[key] = int(self._dp.union_marks(t).max().item())
+      n_cap = min(dcsr.n_items, cache[key] * self._dp.world)
     if train and getattr(self, "_ip", None) is not None and negative_sampling:
       n_cap = min(nnz_cap, -(-dcsr.n_items // self._ip.world))   # at most the owned items
     return Block(S, nnz_cap, dcsr.n_items, self.device, negative_sampling=negative_sampling,
@@ -513,6 +554,10 @@ class Recoder(object):
       order = self.user_order_hook(self.current_epoch, n)
     if order is None:
       order = epoch_user_order(n)
+    if np.shape(order) != (n,):
+      # (the contract of the hook, in the graph-replay path as well: one entry per user)
+      raise ValueError("user_order_hook must return one entry per user of the dataset (%d), got %s"
+                       % (n, np.shape(order)))
     if getattr(self, "_ip", None) is not None:
       o = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int64)).to(self.device)
       order = self._ip.broadcast(o).cpu().numpy()   # one user order for all item shards
@@ -663,7 +708,17 @@ class Recoder(object):
     if model_checkpoint_prefix and \
         ((checkpoint_freq > 0 and epoch % checkpoint_freq == 0) or epoch == num_epochs):
       self._sync_user_rows()
-      self.save_state(model_checkpoint_prefix)
+      # multi-GPU training (every rank is here): the replicas are identical -- one writer
+      # (concurrent writers of one path can truncate each other on a shared filesystem), the
+      # others wait for the file
+      import torch.distributed as dist
+      multi = (getattr(self, "_dp", None) is not None or getattr(self, "_ip", None) is not None) and \
+          getattr(self, "_dp_override", None) is None and getattr(self, "_ip_override", None) is None and \
+          dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+      if not multi or dist.get_rank() == 0:
+        self.save_state(model_checkpoint_prefix)
+      if multi:
+        dist.barrier()
 
   # ------------------------------------------------------------ graph replay
   def _graph_ok(self, dataloader, iters_per_epoch, num_batches):
@@ -793,7 +848,7 @@ class Recoder(object):
     if self.model is None:
       raise Exception("Model not initialized.")
     self.model.eval()
-    self._sync_ranges()
+    self._check_ranges()
     out, blk, B = self._predict_scores(users_interactions)
     if return_input:
       m = users_interactions.interactions_matrix
@@ -861,7 +916,7 @@ class Recoder(object):
     (``rk_topk_masked_strip``) and the per-strip winners are merged with one more top-k pass --
     ties resolve to the lower item id at both levels, as torch.topk on the full row would."""
     self.model.eval()
-    self._sync_ranges()
+    self._check_ranges()
     k = int(num_recommendations)
     from . import _lib
     from .device import current_stream

@@ -156,6 +156,12 @@ TARGET_CONFIGS = {
                      loss="logistic", train=dict(batch_size=32, lr=1e-3, weight_decay=0.0, num_epochs=2,
                                                  negative_sampling=True),
                      data=dict(n_users=130, n_items=110, mean_deg=9, seed=52)),
+  # tied weights (nn.py:191-202, 224-226): the decoder reads the ENCODER table at the target items
+  "ae_tied": dict(kind="ae", model=dict(hidden_layers=[20], activation_type="tanh", sparse=False,
+                                        is_constrained=True),
+                  loss="logistic", train=dict(batch_size=32, lr=1e-3, weight_decay=2e-5, num_epochs=2,
+                                              negative_sampling=True),
+                  data=dict(n_users=130, n_items=110, mean_deg=9, seed=54)),
   "mf": dict(kind="mf", model=dict(embedding_size=12, activation_type="tanh", sparse=False),
              loss="logloss", train=dict(batch_size=32, lr=1e-3, weight_decay=1e-5, num_epochs=2,
                                         negative_sampling=True),
@@ -213,8 +219,12 @@ if __name__ == "__main__":
   import functools
   _load = torch.load
   torch.load = functools.partial(_load, weights_only=False)
-  make_dataframe_fixture()
+  only = sys.argv[1:]            # e.g. `target:ae_tied`: regenerate just that fixture
+  if not only:
+    make_dataframe_fixture()
   for name, cfg in CKPT_CONFIGS.items():
-    make_checkpoint_fixture(name, cfg)
+    if not only or "ckpt:" + name in only:
+      make_checkpoint_fixture(name, cfg)
   for name, cfg in TARGET_CONFIGS.items():
-    make_target_fixture(name, cfg)
+    if not only or "target:" + name in only:
+      make_target_fixture(name, cfg)

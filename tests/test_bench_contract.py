@@ -43,6 +43,10 @@ def test_single_gpu_line():
   c = d["cpu_baseline"]
   assert c["kind"] == "port" and c["cores"] >= 1 and c["host_cores"] >= c["cores"] and c["value"] > 0
   assert d["config"]["api"] == "Recoder.train" and d["config"]["graph_replay"] is True
+  # Recall@20 of the trained state next to the throughput it qualifies: product == oracle to 4 decimals
+  assert d["recall_match_4dp"] is True and 0.0 <= d["recall_at_20"] <= 1.0, d.get("recall")
+  assert abs(d["recall"]["value"] - d["recall"]["oracle"]) < 5e-5
+  assert d["roofline"]["traffic"] is None or "NOT collected in this run" in d["roofline"]["traffic_source"]
 
 
 @pytest.mark.parametrize("abandon_alt", [False, True])

@@ -166,3 +166,31 @@ def test_epoch_order_is_drawn_on_one_thread_and_unchanged_by_it():
   g.manual_seed(seed)
   want = torch.randperm(50000, generator=g).numpy()
   assert np.array_equal(got, want)
+
+
+def test_engine_choice_by_dataset_and_loss_params():
+  """Combinations without a fused HIP step are routed to the generic (torch autograd, GPU) engine
+  instead of raising: tied weights with a separate target matrix (reference model.py:464-476,
+  nn.py:191-202), and named losses whose loss_params go beyond what the fused epilogues implement
+  (model.py:87-99 builds BCEWithLogitsLoss(reduction='sum', **loss_params))."""
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder
+  m = sp.random(30, 20, density=0.2, format="csr", random_state=0, dtype=np.float32)
+  m.data[:] = 1.0
+  tied = DynamicAutoencoder(hidden_layers=[8], is_constrained=True)
+  rec = Recoder(model=tied, use_cuda=True, optimizer_type="adam", loss="mse")
+  assert not rec._use_generic()
+  rec._pick_engine_for(RecommendationDataset(m, m))
+  assert rec._use_generic() and "target matrix" in rec._force_generic
+  rec._pick_engine_for(RecommendationDataset(m))          # back to the fused engine
+  assert not rec._use_generic()
+  plain = DynamicAutoencoder(hidden_layers=[8])
+  rec2 = Recoder(model=plain, use_cuda=True, optimizer_type="adam", loss="mse")
+  rec2._pick_engine_for(RecommendationDataset(m, m))      # untied + target: fused
+  assert not rec2._use_generic()
+  assert not Recoder(model=plain, optimizer_type="adam", loss="mse", loss_params={"confidence": 2})._use_generic()
+  assert Recoder(model=plain, optimizer_type="adam", loss="logistic",
+                 loss_params={"pos_weight": torch.ones(20)})._use_generic()
+  assert Recoder(model=plain, optimizer_type="adam", loss="logistic",
+                 loss_params={"weight": torch.ones(20)})._use_generic()

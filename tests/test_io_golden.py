@@ -232,11 +232,12 @@ def test_train_from_device_dataset_equals_host_dataset():
 
 # ------------------------------------------------- training on a dataset WITH a target matrix
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["ae", "ae2_sparse", "mf"])
+@pytest.mark.parametrize("name", ["ae", "ae2_sparse", "ae_tied", "mf"])
 def test_training_with_target_matrix_replays_reference(name):
   """reference data.py:60-62 + model.py:464-472: (input, target) batches in the hot loop -- decode,
   loss, dW and the decoder-side updates over the TARGET batch's item set, the encoder side over the
-  input's.  Golden losses / final parameters from the reference itself."""
+  input's.  Golden losses / final parameters from the reference itself.  (ae_tied: tied weights with
+  a target matrix have no fused step and train through the generic engine, nn.py:191-202.)"""
   from recoder_amd.data import RecommendationDataset
   from recoder_amd.model import Recoder
   from recoder_amd.nn import DynamicAutoencoder, MatrixFactorization
