@@ -331,6 +331,12 @@ def main():
     sync_all()
     T["warm"] = eng.timed_samples_ms()
     eng.time_plan = plan_timed
+    # the bracketed group of the timed region as a graph of its own (timing events as event-record
+    # nodes), captured HERE, in front of the clock: the timed region is graph replay throughout
+    gs = getattr(rec, "_graph_stepper", None)
+    T["timed_graph"] = False
+    if gs is not None and not SAMPLE_POST and K >= 2 * G:
+      T["timed_graph"] = bool(gs.prepare_timed(gs.global_step + ((K // G) - 1) * G))
     sync_all()
     T["t0"] = time.perf_counter()
     return False
@@ -485,7 +491,8 @@ def main():
                  "first_loss": float(losses[0]), "last_loss": float(losses[-1]),
                  "host_enqueue_ms_per_step": T["enqueue"] / K * 1e3,
                  "graph_replay": bool(getattr(rec, "_graph_stepper", None) is not None),
-                 "steps_per_graph": G, "alt_item_parallel": None},
+                 "steps_per_graph": G, "bracketed_group_is_graph": bool(T.get("timed_graph")),
+                 "alt_item_parallel": None},
       "roofline": roofline,
     }
     if same_dev:

@@ -523,6 +523,13 @@ int rk_ae_train_step(const rk_ae_step_t *step);
 int rk_collate_at(const int64_t *ds_indptr, const int32_t *ds_indices, const float *ds_data,
                   const int64_t *users_base, int32_t S, int32_t negative_sampling,
                   const int64_t *cursor, int32_t off, const rk_block_t *blk, void *stream);
+/* the same for n_blk <= RK_COLLATE_MULTI equally shaped blocks in ONE set of launches; block g
+ * takes cursor offset off0 + g */
+#define RK_COLLATE_MULTI 8
+int rk_collate_at_multi(const int64_t *ds_indptr, const int32_t *ds_indices, const float *ds_data,
+                        const int64_t *users_base, int32_t S, int32_t negative_sampling,
+                        const int64_t *cursor, int32_t off0, const rk_block_t *const *blks,
+                        int32_t n_blk, void *stream);
 int rk_cursor_set(int64_t *cursor, int64_t step, int64_t epoch_base, void *stream);
 int rk_cursor_advance(int64_t *cursor, int64_t n, void *stream);
 int rk_adam_consts(double lr, double beta1, double beta2, double eps, double weight_decay,
@@ -531,6 +538,9 @@ int rk_adam_consts(double lr, double beta1, double beta2, double eps, double wei
 int rk_graph_begin(void *stream);
 void *rk_graph_end(void *stream);              /* -> executable graph handle, NULL on error */
 int rk_graph_launch(void *graph_exec, void *stream);
+/* != 0: rk_ae_train_step's timing events (time_ev0 / time_all) may be used INSIDE a capture -- they
+ * become event-record nodes that every replay re-records.  Depends on the HIP runtime in the process. */
+int32_t rk_graph_timing_supported(void);
 void rk_graph_destroy(void *graph_exec);
 /* cross-stream edges inside a capture (fork / join): event from rk_event_create */
 int rk_event_record(void *event, void *stream);

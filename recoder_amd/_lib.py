@@ -174,6 +174,7 @@ SIGNATURES = {
   "rk_event_elapsed_ms": (c_float, [c_void_p, c_void_p]),
   "rk_ae_train_step": (c_int32, [POINTER(RkAeStep)]),
   "rk_collate_at": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, c_int32, _BLK, _P]),
+  "rk_collate_at_multi": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, c_int32, POINTER(_BLK), c_int32, _P]),
   "rk_cursor_set": (c_int32, [_P, c_int64, c_int64, _P]),
   "rk_cursor_advance": (c_int32, [_P, c_int64, _P]),
   "rk_adam_consts": (c_int32, [c_double, c_double, c_double, c_double, c_double, c_int32, c_int32,
@@ -181,6 +182,7 @@ SIGNATURES = {
   "rk_graph_begin": (c_int32, [_P]),
   "rk_graph_end": (c_void_p, [_P]),
   "rk_graph_launch": (c_int32, [_P, _P]),
+  "rk_graph_timing_supported": (c_int32, []),
   "rk_graph_destroy": (None, [_P]),
   "rk_event_record": (c_int32, [_P, _P]),
   "rk_stream_wait_event": (c_int32, [_P, _P]),

@@ -26,9 +26,15 @@ constexpr int SEG_WORDS = 2048;           // bitmap words a wave builds in LDS a
 //        [0, nrow_blk)            one wave per sampled row: mark[item] = stamp
 //        nrow_blk                 block CSR row pointers (exclusive scan of degrees)
 //        (nrow_blk, gridDim.x)    zero bits_cr (capacity-sized, no dependency on n_b)
-__global__ __launch_bounds__(256) void collate_phase1_kernel(
+// up to RK_COLLATE_MULTI blocks collated by ONE set of launches (rk_collate_at_multi): block g =
+// blockIdx.y, cursor offset off0 + g
+struct MultiBlk {
+  rk_block_t b[RK_COLLATE_MULTI];
+};
+
+__device__ __forceinline__ void collate_phase1_body(
     const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
-    const int64_t *__restrict__ users, int S, int32_t stamp, int all, int nrow_blk, rk_block_t b,
+    const int64_t *__restrict__ users, int S, int32_t stamp, int all, int nrow_blk, const rk_block_t &b,
     rk_cur_t cur) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   if (cur.cursor) { users += rk_cur_local(cur) * S; stamp = rk_cur_stamp(cur); }
@@ -91,8 +97,21 @@ __global__ __launch_bounds__(256) void collate_phase1_kernel(
   }
 }
 
+__global__ __launch_bounds__(256) void collate_phase1_kernel(
+    const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
+    const int64_t *__restrict__ users, int S, int32_t stamp, int all, int nrow_blk, rk_block_t b,
+    rk_cur_t cur) {
+  collate_phase1_body(ds_indptr, ds_indices, users, S, stamp, all, nrow_blk, b, cur);
+}
+__global__ __launch_bounds__(256) void collate_phase1_multi_kernel(
+    const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
+    const int64_t *__restrict__ users, int S, int all, int nrow_blk, MultiBlk mb, rk_cur_t cur) {
+  cur.off += (int)blockIdx.y;
+  collate_phase1_body(ds_indptr, ds_indices, users, S, 1, all, nrow_blk, mb.b[blockIdx.y], cur);
+}
+
 // ---- count: marked items per chunk (large catalogues) ----
-__global__ __launch_bounds__(256) void collate_count_kernel(
+__device__ __forceinline__ void collate_count_body(
     const int32_t *__restrict__ mark, int n_items, int32_t stamp, int all,
     int32_t *__restrict__ scan_tmp, rk_cur_t cur) {
   __shared__ int32_t ws[4];
@@ -109,9 +128,19 @@ __global__ __launch_bounds__(256) void collate_count_kernel(
   __syncthreads();
   if (threadIdx.x == 0) scan_tmp[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
+__global__ __launch_bounds__(256) void collate_count_kernel(
+    const int32_t *__restrict__ mark, int n_items, int32_t stamp, int all,
+    int32_t *__restrict__ scan_tmp, rk_cur_t cur) {
+  collate_count_body(mark, n_items, stamp, all, scan_tmp, cur);
+}
+__global__ __launch_bounds__(256) void collate_count_multi_kernel(int all, MultiBlk mb, rk_cur_t cur) {
+  cur.off += (int)blockIdx.y;
+  const rk_block_t &b = mb.b[blockIdx.y];
+  collate_count_body(b.mark, b.n_items, 1, all, b.scan_tmp, cur);
+}
 
 // ---- assign: pos[] / items[] in ascending item order (large catalogues) ----
-__global__ __launch_bounds__(256) void collate_assign_kernel(
+__device__ __forceinline__ void collate_assign_body(
     const int32_t *__restrict__ mark, int n_items, int32_t stamp, int all,
     const int32_t *__restrict__ scan_tmp, int n_chunks, int32_t *__restrict__ pos,
     int32_t *__restrict__ items, int32_t *__restrict__ counts, int n_cap, int nnz_cap, rk_cur_t cur) {
@@ -168,9 +197,21 @@ __global__ __launch_bounds__(256) void collate_assign_kernel(
     }
   }
 }
+__global__ __launch_bounds__(256) void collate_assign_kernel(
+    const int32_t *__restrict__ mark, int n_items, int32_t stamp, int all,
+    const int32_t *__restrict__ scan_tmp, int n_chunks, int32_t *__restrict__ pos,
+    int32_t *__restrict__ items, int32_t *__restrict__ counts, int n_cap, int nnz_cap, rk_cur_t cur) {
+  collate_assign_body(mark, n_items, stamp, all, scan_tmp, n_chunks, pos, items, counts, n_cap, nnz_cap, cur);
+}
+__global__ __launch_bounds__(256) void collate_assign_multi_kernel(int all, MultiBlk mb, rk_cur_t cur) {
+  cur.off += (int)blockIdx.y;
+  const rk_block_t &b = mb.b[blockIdx.y];
+  collate_assign_body(b.mark, b.n_items, 1, all, b.scan_tmp, b.n_chunks, b.pos, b.items, b.counts, b.n_cap,
+                      b.nnz_cap, cur);
+}
 
 // ---- scan (small catalogues): ONE workgroup does count + assign in one launch ----
-__global__ __launch_bounds__(1024) void collate_scan_small_kernel(
+__device__ __forceinline__ void collate_scan_small_body(
     const int32_t *__restrict__ mark, int n_items, int32_t stamp, int all,
     int32_t *__restrict__ pos, int32_t *__restrict__ items, int32_t *__restrict__ counts,
     int n_cap, int nnz_cap, rk_cur_t cur) {
@@ -225,13 +266,24 @@ __global__ __launch_bounds__(1024) void collate_scan_small_kernel(
     counts[5] = carry_s > n_cap ? carry_s : 0;
   }
 }
+__global__ __launch_bounds__(1024) void collate_scan_small_kernel(
+    const int32_t *__restrict__ mark, int n_items, int32_t stamp, int all,
+    int32_t *__restrict__ pos, int32_t *__restrict__ items, int32_t *__restrict__ counts,
+    int n_cap, int nnz_cap, rk_cur_t cur) {
+  collate_scan_small_body(mark, n_items, stamp, all, pos, items, counts, n_cap, nnz_cap, cur);
+}
+__global__ __launch_bounds__(1024) void collate_scan_small_multi_kernel(int all, MultiBlk mb, rk_cur_t cur) {
+  cur.off += (int)blockIdx.x;
+  const rk_block_t &b = mb.b[blockIdx.x];
+  collate_scan_small_body(b.mark, b.n_items, 1, all, b.pos, b.items, b.counts, b.n_cap, b.nnz_cap, cur);
+}
 
 // ---- build: one wave per sampled row -- relabelled columns, values, the row's
 //      bitmap words + their exclusive prefix popcounts (assembled in LDS and
 //      written out whole: bits_rc needs no clearing), transposed-bitmap bits ----
-__global__ __launch_bounds__(256) void collate_build_kernel(
+__device__ __forceinline__ void collate_build_body(
     const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
-    const float *__restrict__ ds_data, const int64_t *__restrict__ users, int S, rk_block_t b,
+    const float *__restrict__ ds_data, const int64_t *__restrict__ users, int S, const rk_block_t &b,
     rk_cur_t cur) {
   __shared__ uint32_t wbits[4][SEG_WORDS];
   if (cur.cursor) users += rk_cur_local(cur) * S;
@@ -284,6 +336,19 @@ __global__ __launch_bounds__(256) void collate_build_kernel(
     }
     __builtin_amdgcn_wave_barrier();
   }
+}
+__global__ __launch_bounds__(256) void collate_build_kernel(
+    const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
+    const float *__restrict__ ds_data, const int64_t *__restrict__ users, int S, rk_block_t b,
+    rk_cur_t cur) {
+  collate_build_body(ds_indptr, ds_indices, ds_data, users, S, b, cur);
+}
+__global__ __launch_bounds__(256) void collate_build_multi_kernel(
+    const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
+    const float *__restrict__ ds_data, const int64_t *__restrict__ users, int S, MultiBlk mb,
+    rk_cur_t cur) {
+  cur.off += (int)blockIdx.y;
+  collate_build_body(ds_indptr, ds_indices, ds_data, users, S, mb.b[blockIdx.y], cur);
 }
 
 }  // namespace
@@ -377,6 +442,56 @@ extern "C" int rk_collate_at(const int64_t *ds_indptr, const int32_t *ds_indices
   const rk_cur_t cur = {cursor, off};
   return collate_impl(ds_indptr, ds_indices, ds_data, users_base, S, negative_sampling, 1, 0, blk, cur,
                       stream_);
+}
+
+// rk_collate_at for n_blk blocks in ONE set of launches (block g: cursor offset off0 + g): the G
+// look-ahead blocks of a replayed group, or the G blocks behind a cut, cost 3 launches on one queue
+// instead of 3 G on G queues (a 4-branch graph took 140 us to start them under the profiler)
+extern "C" int rk_collate_at_multi(const int64_t *ds_indptr, const int32_t *ds_indices,
+                                   const float *ds_data, const int64_t *users_base, int32_t S,
+                                   int32_t negative_sampling, const int64_t *cursor, int32_t off0,
+                                   const rk_block_t *const *blks, int32_t n_blk, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(cursor != nullptr && blks != nullptr, "null cursor / blocks");
+  RK_REQUIRE(n_blk >= 1 && n_blk <= RK_COLLATE_MULTI, "1 .. RK_COLLATE_MULTI blocks");
+  MultiBlk mb = {};
+  const rk_block_t *b0 = blks[0];
+  for (int g = 0; g < n_blk; ++g) {
+    const rk_block_t *blk = blks[g];
+    RK_REQUIRE(blk != nullptr, "null block");
+    RK_REQUIRE(S >= 0 && S <= blk->S_cap, "S exceeds block capacity");
+    RK_REQUIRE(blk->n_chunks == rk_cdiv(blk->n_items, RK_SCAN_CHUNK), "n_chunks mismatch");
+    RK_REQUIRE(blk->ldw_rc * 32 >= blk->n_cap && blk->ldw_cr * 32 >= blk->S_cap, "bitmap ld");
+    RK_REQUIRE(blk->n_items == b0->n_items && blk->n_cap == b0->n_cap && blk->ldw_cr == b0->ldw_cr &&
+               (blk->bits_cr != nullptr) == (b0->bits_cr != nullptr), "the blocks must have one shape");
+    mb.b[g] = *blk;
+  }
+  if (S == 0) return 0;
+  const rk_cur_t cur = {cursor, off0};
+  const int all = negative_sampling ? 0 : 1;
+  const int nrow_blk = rk_cdiv(S, 4);
+  int nzero = 0;
+  if (b0->bits_cr) {
+    nzero = rk_cdiv((int64_t)b0->n_cap * b0->ldw_cr, 4 * 256 * 8);
+    if (nzero < 1) nzero = 1;
+    if (nzero > 512) nzero = 512;
+  }
+  RK_LAUNCH(collate_phase1_multi_kernel, dim3(nrow_blk + 1 + nzero, n_blk), dim3(256), 0, stream, ds_indptr,
+            ds_indices, users_base, S, all, nrow_blk, mb, cur);
+  RK_CHECK_LAUNCH("collate_phase1_multi");
+  if (b0->n_items <= SMALL_SCAN_MAX) {
+    RK_LAUNCH(collate_scan_small_multi_kernel, dim3(n_blk), dim3(1024), 0, stream, all, mb, cur);
+    RK_CHECK_LAUNCH("collate_scan_small_multi");
+  } else {
+    RK_LAUNCH(collate_count_multi_kernel, dim3(b0->n_chunks, n_blk), dim3(256), 0, stream, all, mb, cur);
+    RK_CHECK_LAUNCH("collate_count_multi");
+    RK_LAUNCH(collate_assign_multi_kernel, dim3(b0->n_chunks, n_blk), dim3(256), 0, stream, all, mb, cur);
+    RK_CHECK_LAUNCH("collate_assign_multi");
+  }
+  RK_LAUNCH(collate_build_multi_kernel, dim3(rk_cdiv(S, 4), n_blk), dim3(256), 0, stream, ds_indptr,
+            ds_indices, ds_data, users_base, S, mb, cur);
+  RK_CHECK_LAUNCH("collate_build_multi");
+  return 0;
 }
 
 namespace {

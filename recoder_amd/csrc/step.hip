@@ -5,6 +5,8 @@
 // caller-provided HIP streams; keeping the sequencing in C removes ~35
 // Python->ctypes transitions per step (the host enqueue time was approaching the
 // GPU time of the step).
+#include <stdlib.h>
+
 #include "common.h"
 #include "planes.h"
 
@@ -88,6 +90,30 @@ extern "C" void *rk_graph_end(void *stream) {
   return (void *)exec;
 }
 
+// Can a timing event be recorded as an event-record NODE of a stream capture
+// (hipEventRecordWithFlags(..., hipEventRecordExternal))?  Works on the ROCm 7.2 runtime
+// (tools/probes/graph_event_probe.hip), returns "invalid argument" on the 7.0 runtime PyTorch
+// bundles: probed once on a scratch stream, so that callers can fall back to eager brackets.
+extern "C" int32_t rk_graph_timing_supported(void) {
+  static const int ok = [] {
+    hipStream_t s = nullptr;
+    hipEvent_t e = nullptr;
+    hipGraph_t g = nullptr;
+    int good = 0;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&e) == hipSuccess &&
+        hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
+      good = hipEventRecordWithFlags(e, s, hipEventRecordExternal) == hipSuccess;
+      (void)hipStreamEndCapture(s, &g);
+    }
+    if (g) (void)hipGraphDestroy(g);
+    if (e) (void)hipEventDestroy(e);
+    if (s) (void)hipStreamDestroy(s);
+    (void)hipGetLastError();
+    return good;
+  }();
+  return ok;
+}
+
 extern "C" int rk_graph_launch(void *graph_exec, void *stream) {
   const hipError_t e = hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream);
   if (e != hipSuccess) {
@@ -103,6 +129,21 @@ extern "C" void rk_graph_destroy(void *graph_exec) {
 
 namespace {
 
+// A timing event recorded while its stream is being CAPTURED becomes an event-record NODE of the
+// graph (hipEventRecordExternal): every replay re-records it, and hipEventElapsedTime between two
+// of them reads the interval inside the replayed graph (tools/probes/graph_event_probe.hip) -- so a
+// bracketed group of steps can be a graph replay like every other one.
+inline void timer_record(hipEvent_t e, hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  hipError_t rc;
+  if (hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive)
+    rc = hipEventRecordWithFlags(e, s, hipEventRecordExternal);
+  else
+    rc = hipEventRecord(e, s);
+  if (rc != hipSuccess && getenv("RK_DEBUG_TIMER"))
+    fprintf(stderr, "timer_record(%p, %p) capture=%d -> %s\n", (void *)e, (void *)s, (int)st, hipGetErrorString(rc));
+}
+
 struct Timer {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   hipStream_t s;
@@ -112,10 +153,10 @@ struct Timer {
     } else if (a->time_entry == RK_ENTRY_ALL && a->time_all) {
       e0 = (hipEvent_t)a->time_all[2 * id]; e1 = (hipEvent_t)a->time_all[2 * id + 1];
     }
-    if (e0) (void)hipEventRecord(e0, s);
+    if (e0) timer_record(e0, s);
   }
   ~Timer() {
-    if (e1) (void)hipEventRecord(e1, s);
+    if (e1) timer_record(e1, s);
   }
 };
 

@@ -688,12 +688,12 @@ class FusedEngine:
       n_ent = max(ENTRY.values()) + 1
       evs = (ctypes.c_void_p * (2 * n_ent))()
       for ename, eid in ENTRY.items():
-        evs[2 * eid], evs[2 * eid + 1] = raw.rk_timing_event_create(), raw.rk_timing_event_create()
+        evs[2 * eid], evs[2 * eid + 1] = self._new_timing_event(raw), self._new_timing_event(raw)
         self._time_samples.append((ename, evs[2 * eid], evs[2 * eid + 1]))
       self._time_keep.append(evs)          # (the array must outlive the call)
       st.time_entry, st.time_all = ENTRY_ALL, evs
     elif name is not None:
-      e0, e1 = raw.rk_timing_event_create(), raw.rk_timing_event_create()
+      e0, e1 = self._new_timing_event(raw), self._new_timing_event(raw)
       self._time_samples.append((name, e0, e1))
       st.time_entry, st.time_ev0, st.time_ev1 = ENTRY[name], e0, e1
     else:
@@ -741,6 +741,21 @@ class FusedEngine:
       check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
     self._loss_target = out
     return out
+
+  def _new_timing_event(self, raw):
+    """A timing event -- from the pool graph.GraphStepper.prepare_timed filled BEFORE its capture
+    began when there is one (an event created while a stream capture is active cannot be recorded
+    as an event-record node: hipEventRecordWithFlags returns invalid argument)."""
+    pool = getattr(self, "_event_pool", None)
+    if pool:
+      return pool.pop()
+    return raw.rk_timing_event_create()
+
+  def reserve_timing_events(self, n):
+    raw = _lib.load()
+    pool = self.__dict__.setdefault("_event_pool", [])
+    while len(pool) < n:
+      pool.append(raw.rk_timing_event_create())
 
   def decoder_bias_grad(self, n_b):
     """gb_de[:n_b] of the last training step (tests).  The one-call step consumes the

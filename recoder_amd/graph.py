@@ -17,6 +17,7 @@ per-step loss.  The captured kernels are the same C-ABI entry points the eager p
 the ragged last batch, groups bench.py brackets with timing events) run eagerly through them.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -31,10 +32,13 @@ _PAR_NAMES = {PAR_W_EN: "en_embedding_layer.weight",
 
 
 class GraphStepper:
+  MULTI_MAX = 8          # RK_COLLATE_MULTI (include/recoder_hip.h)
+
   def __init__(self, engine, dcsr, make_block, B, negative_sampling, group, n_users, device):
     self.lib = _lib.load()
     self.eng, self.dcsr, self.B, self.ns, self.G = engine, dcsr, int(B), bool(negative_sampling), int(group)
     self.device = device
+    self.multi = os.environ.get("RK_COLLATE_MULTI", "1") != "0"    # batched collation launches
     self.blocks = [[make_block() for _ in range(self.G)] for _ in range(2)]
     self.tail_blk = make_block()            # ragged last batch: eager, host-provided arguments
     engine.ensure_capacity(self.B, self.blocks[0][0].n_cap)
@@ -63,6 +67,7 @@ class GraphStepper:
     self.exec = [None, None]
     self._la_slot = 1                      # slot holding the newest look-ahead blocks
     self.exec_first = [None, None]         # the group right behind a cut: its collation + its steps, per slot
+    self.exec_timed = {}                   # (slot, first global index) -> a group captured WITH timing events
     self.warmed = False
     self.global_step = 0                   # steps this stepper's cursor has seen
     self.epoch_base = 0
@@ -76,6 +81,9 @@ class GraphStepper:
       if e:
         self.lib.rk_graph_destroy(e)
     self.exec_first = [None, None]
+    for e in self.exec_timed.values():
+      self.lib.rk_graph_destroy(e)
+    self.exec_timed = {}
     self.warmed = False
 
   def close(self):
@@ -97,6 +105,19 @@ class GraphStepper:
     check(self.lib.rk_collate_at(ptr(d.indptr), ptr(d.indices), ptr(d.data), ptr(self.order), self.B,
                                  1 if self.ns else 0, self._cur(slot), off, blk.ref, self._h(stream)),
           "rk_collate_at")
+
+  def _collate_many(self, blks, off0, stream, slot):
+    """rk_collate_at for several blocks (cursor offsets off0, off0 + 1, ...) in ONE set of launches."""
+    d = self.dcsr
+    n = len(blks)
+    arr = (ctypes.POINTER(_lib.RkBlock) * n)()
+    for g, blk in enumerate(blks):
+      blk.c.implicit = 1 if d.data is None else 0
+      blk.S = self.B
+      arr[g] = ctypes.pointer(blk.c)
+    check(self.lib.rk_collate_at_multi(ptr(d.indptr), ptr(d.indices), ptr(d.data), ptr(self.order), self.B,
+                                       1 if self.ns else 0, self._cur(slot), off0, arr, n,
+                                       self._h(stream)), "rk_collate_at_multi")
 
   def _step(self, slot, g, index=None, advance=None):
     """Enqueue the training step of block [slot][g] (cursor offset g) on the main stream; index
@@ -124,11 +145,17 @@ class GraphStepper:
     # graph keeps on the launching stream's queue: with step 0 captured first the training chain
     # stays on one hardware queue from launch to launch (11 us between groups; with the collation
     # first it moved to another queue every launch, 28-31 us).
+    multi = G <= self.MULTI_MAX and self.multi
     for g in range(max(n_steps, G)):
       if g < n_steps:
         self._step(slot, g, None if first_index is None else first_index + g,
                    advance=n_steps if g == n_steps - 1 else None)
-      if g < G and lookahead:
+      if lookahead and multi:
+        # the G look-ahead blocks in ONE set of launches, behind the dW kernel of step 0 (which the
+        # Adam sweep of step 0 waits for; nothing needs the blocks before the end of the group)
+        if g == 0:
+          self._collate_many(self.blocks[1 - slot], n_steps, self.side, slot)
+      elif g < G and lookahead:
         self._collate(self.blocks[1 - slot][g], n_steps + g, self.side, slot)
     check(lib.rk_event_record(self.ev_join, self._h(self.side)), "rk_event_record")
     check(lib.rk_stream_wait_event(self._h(self.main), self.ev_join), "rk_stream_wait_event")
@@ -137,6 +164,11 @@ class GraphStepper:
     """Collate blocks[slot][0..n0) side by side: block 0 on the main stream, the others on streams
     of their own, joined back.  Called inside a capture or eagerly."""
     lib = self.lib
+    if n0 <= self.MULTI_MAX and self.multi:
+      # one set of launches on the main stream for all of them (4 parallel branches of a graph took
+      # ~140 us to get going; three launches of 4x the workgroups take one collation's time)
+      self._collate_many(self.blocks[slot][:n0], 0, self.main, slot)
+      return
     if n0 > 1:
       check(lib.rk_event_record(self.ev_fork, self._h(self.main)), "rk_event_record")
     self._collate(self.blocks[slot][0], 0, self.main, slot)
@@ -227,7 +259,12 @@ class GraphStepper:
         # object loaded) before it is captured -- graphs captured cold replayed ~8x slower on the
         # host -- and the graphs are captured right behind it (capturing enqueues nothing), i.e.
         # in the warm-up of a benchmark, never inside its timed region
-        if eager or not self.warmed:
+        timed = self.exec_timed.get((slot, idx0)) if (eager and self.warmed and not need_pre and
+                                                      left == G) else None
+        if timed is not None:
+          la = False                       # a bracketed group, captured with its events (prepare_timed)
+          check(lib.rk_graph_launch(timed, self._h(self.main)), "rk_graph_launch")
+        elif eager or not self.warmed:
           if need_pre:
             self._pre_collate(G, slot)
           la = left > G                    # (run() ends with this group: a cut or the epoch's end
@@ -254,6 +291,23 @@ class GraphStepper:
     self._collated = slot if la else None
     if la:
       self._la_slot = slot               # (remembered across cuts / epochs: see the restart above)
+
+  def prepare_timed(self, first_index):
+    """Capture, for both slots, the group of G steps starting at global step `first_index` WITH the
+    timing events the engine's time plan asks for (event-record nodes: csrc/step.hip timer_record),
+    without the look-ahead collation (run() ends with that group).  bench.py calls this in front of
+    its timed region; run() then replays it instead of enqueueing the bracketed group eagerly."""
+    if not self.warmed or os.environ.get("RK_TIMED_GRAPH", "1") == "0" or \
+        not self.lib.rk_graph_timing_supported():
+      return False
+    from ._lib import ENTRY
+    self.eng.reserve_timing_events(2 * self.G * 2 * (max(ENTRY.values()) + 1))   # (created outside the capture)
+    for v in (0, 1):
+      key = (v, int(first_index))
+      if key not in self.exec_timed:
+        self.exec_timed[key] = self._capture(
+            lambda v=v: self._group(v, self.G, first_index=int(first_index), lookahead=False))
+    return True
 
   def _warm_capture(self):
     """Capture the graphs once every kernel has been launched eagerly (the first steps run)."""

@@ -549,15 +549,11 @@ class Recoder(object):
       self._train_pf = pf
     pf.reset()
     n = len(ds)
-    order = None
-    if self.user_order_hook is not None:
+    order, self._pending_order = getattr(self, "_pending_order", None), None
+    if order is None and self.user_order_hook is not None:
       order = self.user_order_hook(self.current_epoch, n)
     if order is None:
       order = epoch_user_order(n)
-    if np.shape(order) != (n,):
-      # (the contract of the hook, in the graph-replay path as well: one entry per user)
-      raise ValueError("user_order_hook must return one entry per user of the dataset (%d), got %s"
-                       % (n, np.shape(order)))
     if getattr(self, "_ip", None) is not None:
       o = torch.from_numpy(np.ascontiguousarray(order, dtype=np.int64)).to(self.device)
       order = self._ip.broadcast(o).cpu().numpy()   # one user order for all item shards
@@ -653,11 +649,16 @@ class Recoder(object):
         # this is the last epoch: the SEQUENCE of draws stays the reference's
         ahead = (epoch < num_epochs and self.user_order_hook is None and
                  not (eval_freq > 0 and epoch % eval_freq == 0 and val_dataloader is not None))
-        self.last_epoch_losses = self._train_epoch_graph(train_dataloader, draw_next_order=ahead)
-        self._epoch_end(epoch, num_epochs, len(self.last_epoch_losses), val_dataloader, eval_freq,
-                        metrics, eval_num_recommendations, eval_batch_size, eval_num_users,
-                        model_checkpoint_prefix, checkpoint_freq)
-        continue
+        losses = self._train_epoch_graph(train_dataloader, draw_next_order=ahead)
+        if losses is not None:
+          self.last_epoch_losses = losses
+          self._epoch_end(epoch, num_epochs, len(self.last_epoch_losses), val_dataloader, eval_freq,
+                          metrics, eval_num_recommendations, eval_batch_size, eval_num_users,
+                          model_checkpoint_prefix, checkpoint_freq)
+          continue
+        # (the hook's order is not one pass over the users: eagerly sequenced steps below)
+        iterator = enumerate(self._step_generator(train_dataloader), 1)
+        iters_to_process = num_batches
 
       n_done = 0
       for batch_itr, (blk, row_off, rows, keep_noise, keep_drop, tgt_blk) in iterator:
@@ -760,8 +761,11 @@ class Recoder(object):
       order = epoch_user_order(n)
     order = np.ascontiguousarray(order, dtype=np.int64)
     if order.shape != (n,):
-      raise ValueError("user_order_hook must return one entry per user of the dataset (%d), got %s"
-                       % (n, order.shape))
+      # a hook may hand over any list of users (a subset, repeats): the replayed graphs are laid out
+      # for one pass over the n users -- this epoch takes the eagerly sequenced path with the SAME
+      # order (the hook is not asked twice)
+      self._pending_order = order
+      return None
     caller = torch.cuda.current_stream()
     gs.main.wait_stream(caller)
     with torch.cuda.stream(gs.main):

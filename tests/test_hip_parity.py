@@ -7,6 +7,8 @@ Bars: integer / index work (collation) is bit-exact; floating point is within
 compared with rtol 1e-4 + a small atol because the reference accumulates in a
 different (MKL) order.
 """
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -172,6 +174,19 @@ def make_oracle(c, state):
       lr=c["lr"], weight_decay=c["weight_decay"])
 
 
+# Post-step parameters against the reference's: Adam turns a gradient g into a step of size
+# lr * m / (sqrt(v) + eps) ~ lr * sign(g) -- for the handful of elements whose gradient is near
+# zero (|g| ~ eps) a 1e-7 relative difference of the GEMM output moves m / sqrt(v) by O(1), i.e.
+# the parameter by up to lr = 1e-3 ABSOLUTE, whatever its size; everywhere else the parameters
+# agree to rounding.  So: all but TIGHT_FRAC of the elements within 1e-5 relative (+2e-7), and
+# the worst relative error of the elements with |w| > 1e-3 bounded by TIGHT_REL.
+# Measured over the eight golden replays (round 3): every bias, hidden layer, MF table and most
+# embedding tables: ALL elements within 1e-5 (worst 3.3e-6 relative where |w| > 1e-3); two embedding
+# tables have 3.5e-4 / 6.9e-4 of their elements beyond it, worst 1.6e-5 / 5.2e-5 relative.
+TIGHT_FRAC = float(os.environ.get("RK_TIGHT_FRAC", "1e-3"))
+TIGHT_REL = float(os.environ.get("RK_TIGHT_REL", "1e-4"))
+
+
 def close_stats(a, b, rtol, atol):
   a = np.asarray(a, dtype=np.float64)
   b = np.asarray(b, dtype=np.float64)
@@ -179,6 +194,18 @@ def close_stats(a, b, rtol, atol):
   tol = atol + rtol * np.abs(b)
   bad = err > tol
   return float(bad.mean()), float(err.max()), float(np.abs(b).max())
+
+
+def tight_stats(a, b):
+  """north_star's "1e-5 relative" applied to post-step PARAMETERS: (fraction of elements beyond
+  1e-5 relative + 2e-7 absolute, max relative error over the elements with |w| > 1e-3)."""
+  a = np.asarray(a, dtype=np.float64)
+  b = np.asarray(b, dtype=np.float64)
+  err = np.abs(a - b)
+  bad = err > 2e-7 + 1e-5 * np.abs(b)
+  big = np.abs(b) > 1e-3
+  mx_rel = float((err[big] / np.abs(b[big])).max()) if big.any() else 0.0
+  return float(bad.mean()), mx_rel
 
 
 # --------------------------------------------------------------------------
@@ -228,9 +255,14 @@ def test_train_replays_reference_golden(name):
   sd = {k: v.detach().cpu() for k, v in model.named_parameters()}
   for k, v in final.items():
     frac, mx, scale = close_stats(sd[k].numpy(), v.numpy(), 1e-4, 2e-6)
-    print("  ", k, "bad frac %.2e max err %.3e (scale %.3e)" % (frac, mx, scale))
+    tfrac, trel = tight_stats(sd[k].numpy(), v.numpy())
+    print("  ", k, "bad frac %.2e max err %.3e (scale %.3e) | beyond 1e-5 rel: %.2e of elements, "
+          "max rel err where |w| > 1e-3: %.2e" % (frac, mx, scale, tfrac, trel))
     assert frac < 2e-3, (k, frac, mx)
     assert mx < 5e-3 * max(1.0, scale), (k, mx)
+    # north_star's tolerance on the parameters themselves (TIGHT_FRAC / TIGHT_REL: see the note there)
+    assert tfrac < TIGHT_FRAC, (k, tfrac)
+    assert trel < TIGHT_REL, (k, trel)
 
 
 def test_model_init_matches_reference_golden():
@@ -1461,3 +1493,29 @@ def test_linear_layer_entry_points_match_torch(B, N, K, wt, act, acc):
   got_dW = dWd.cpu().double()
   assert torch.allclose(got_dW.t() if wt else got_dW, want_dW, **tol)
   assert torch.allclose(db.cpu().double(), gpre.sum(0), **tol)
+
+
+def test_hook_order_that_is_not_one_pass_takes_the_eager_path(monkeypatch):
+  """A user_order_hook may return any list of users (here: a subset with a ragged tail).  The
+  replayed graphs are laid out for one pass over the dataset, so such an epoch is sequenced eagerly
+  with the same order -- same losses as with graph replay switched off, the hook asked once per
+  epoch."""
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder
+  csr = synth_csr(700, 400, 12, seed=77)
+  sub = np.random.RandomState(3).permutation(700)[:300].astype(np.int64)
+
+  def run(graph):
+    monkeypatch.setenv("RK_GRAPH", "1" if graph else "0")
+    torch.manual_seed(5)
+    model = DynamicAutoencoder([32], activation_type="tanh", noise_prob=0.0, sparse=False)
+    rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss="mse")
+    calls = []
+    rec.user_order_hook = lambda epoch, n: calls.append(epoch) or sub
+    rec.train(RecommendationDataset(csr), batch_size=128, lr=1e-3, weight_decay=1e-5, num_epochs=2,
+              negative_sampling=True)
+    assert calls == [1, 2]
+    return np.concatenate(rec.loss_history)
+  a, b = run(False), run(True)
+  assert len(a) == 2 * 3 and np.array_equal(a, b)

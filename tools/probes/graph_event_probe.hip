@@ -13,12 +13,20 @@ __global__ void spin(float *x, int n) {
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-int main() {
+int main(int argc, char **argv) {
   float *d;
   CK(hipMalloc(&d, 4096));
   CK(hipMemset(d, 0, 4096));
-  hipStream_t s;
-  CK(hipStreamCreate(&s));
+  hipStream_t s, side;
+  const char *mode = argc > 1 ? argv[1] : "plain";
+  if (mode[0] == 'n') { CK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, 0)); }
+  else { CK(hipStreamCreate(&s)); }
+  CK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, 0));
+  hipEvent_t fork, join;
+  CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+  CK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+  const bool forked = argc > 2;
+  printf("stream: %s, forked side stream in the capture: %d\n", mode, (int)forked);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
@@ -26,10 +34,19 @@ int main() {
   CK(hipStreamSynchronize(s));
   CK(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
   spin<<<1, 256, 0, s>>>(d, 20000);
+  if (forked) {
+    CK(hipEventRecord(fork, s));
+    CK(hipStreamWaitEvent(side, fork, 0));
+    spin<<<1, 256, 0, side>>>(d + 512, 20000);
+  }
   CK(hipEventRecordWithFlags(e0, s, hipEventRecordExternal));
   spin<<<1, 256, 0, s>>>(d, 200000);
   CK(hipEventRecordWithFlags(e1, s, hipEventRecordExternal));
   spin<<<1, 256, 0, s>>>(d, 20000);
+  if (forked) {
+    CK(hipEventRecord(join, side));
+    CK(hipStreamWaitEvent(s, join, 0));
+  }
   hipGraph_t g;
   CK(hipStreamEndCapture(s, &g));
   size_t nn = 0;
