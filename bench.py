@@ -44,13 +44,13 @@ PEAK_MFMA_16_TF = 2500.0       # v_mfma_f32_32x32x16_{f16,bf16} dense peak (no s
 GEMM_F32 = os.environ.get("RK_GEMM_PREC", "")[:1].lower() == "f"
 # MFMA flops the 16-bit pipe spends per algorithmic flop: decode / dZ multiply fp16 hi+lo pairs
 # (3 products), dW bf16 triples (6 products) -- the ceiling on ALGORITHMIC flops is peak / this
-PRODUCTS = {"rk_decode_loss": 3, "rk_decode_bwd_dz": 3, "rk_decode_bwd_dw": 6}
+PRODUCTS = {"rk_decode_loss": 3, "rk_decode_bwd_dz": 3, "rk_decode_bwd_dw": 6, "rk_decode_bwd_dw3": 6}
 ENTRIES = ["rk_ae_encode_fwd", "rk_decode_loss", "rk_decode_bwd_dz", "rk_decode_bwd_dw",
            "rk_ae_encode_bwd", "rk_adam_multi"]
 # the kernels each bracketed entry launches (names as rocprofv3 --kernel-trace prints them)
-KERNELS = {"rk_ae_encode_fwd": ["ae_encode_fwd_kernel"],
-           "rk_decode_loss": ["gemm_kernel<2,2,1,2,0,0,EPI_LOSS,..,PREC_H3>"],
-           "rk_decode_bwd_dz": ["gemm_kernel<4,1,1,4,0,1,EPI_SPLITK,..,PREC_H3>", "splitk_reduce_kernel"],
+KERNELS = {"rk_ae_encode_fwd": ["ae_encode_fwd_kernel (+ the W_de[items] split workgroups)"],
+           "rk_decode_loss": ["decode_planes_kernel<TM,2,EPI>"],
+           "rk_decode_bwd_dz": ["dz_planes_kernel<TN>", "splitk_reduce_kernel"],
            "rk_decode_bwd_dw": ["split_planes_t_kernel", "dw3_kernel"],
            "rk_ae_encode_bwd": ["ae_encode_bwd_cols_kernel", "ae_encode_bwd_kernel"],
            "rk_adam_multi": ["adam_multi_kernel"]}
@@ -65,6 +65,23 @@ CONFIGS = {
   "c2s": dict(workload="C2 with sparse=True (SparseAdam on the two tables)",
               data="ml20m", kind="ae", hidden_layers=[200], activation_type="tanh", noise_prob=0.5,
               sparse=True, loss="mse", batch_size=500, lr=1e-3, weight_decay=2e-5),
+  # the other BASELINE.json configurations at their 1-GPU shapes (parity-test cases; these lines are
+  # extra data points, `python bench.py --config c3|c4|c5u` -- the graded line is c2)
+  "c3": dict(workload="C3 MSD-like synthetic CSR 200000x41140 (200k of the 471k users; lognormal degree "
+                      "mean 59, Zipf(1) items, seed 1); DynamicAutoencoder hidden=[200,200] tanh noise 0.5, "
+                      "multinomial NLL, dense Adam lr 1e-3 wd 2e-5, negative sampling",
+             data="msd200k", kind="ae", hidden_layers=[200, 200], activation_type="tanh", noise_prob=0.5,
+             sparse=False, loss="logloss", batch_size=500, lr=1e-3, weight_decay=2e-5),
+  "c4": dict(workload="C4 MSD-big stand-in, synthetic CSR 300000x250000 (lognormal degree mean 50, Zipf(1) "
+                      "items, seed 2); MatrixFactorization embedding_size=128, MSE, SparseAdam lr 1e-3, "
+                      "negative sampling (1-GPU shape of the 8-GPU data-parallel configuration)",
+             data="msdbig", kind="mf", embedding_size=128, activation_type="none", sparse=True,
+             loss="mse", batch_size=500, lr=1e-3, weight_decay=0.0),
+  "c5u": dict(workload="C5-shaped: synthetic CSR 100000x1000000 uniform, 100 interactions per user (one "
+                       "rank's slice of the 10M x 1M matrix), seed 3; DynamicAutoencoder hidden=[512] tanh, "
+                       "MSE, SparseAdam lr 1e-3, negative sampling",
+              data="c5u", kind="ae", hidden_layers=[512], activation_type="tanh", noise_prob=0.0,
+              sparse=True, loss="mse", batch_size=500, lr=1e-3, weight_decay=0.0),
   "small": dict(workload="smoke-size synthetic 5000x3000", data="small", kind="ae",
                 hidden_layers=[200], activation_type="tanh", noise_prob=0.5, sparse=False,
                 loss="mse", batch_size=500, lr=1e-3, weight_decay=2e-5),
@@ -77,6 +94,12 @@ def make_csr(cfg):
     return synthetic.ml20m_like(seed=0)
   if cfg["data"] == "small":
     return synthetic.lognormal_zipf(5000, 3000, 40, seed=0)
+  if cfg["data"] == "msd200k":
+    return synthetic.lognormal_zipf(200000, 41140, 59, seed=1)
+  if cfg["data"] == "msdbig":
+    return synthetic.lognormal_zipf(300000, 250000, 50, seed=2)
+  if cfg["data"] == "c5u":
+    return synthetic.uniform(100000, 1000000, 100, seed=3)
   raise ValueError(cfg["data"])
 
 
@@ -104,7 +127,25 @@ def algorithmic_work(entry, B, h0, n_b, nnz, n_items, cfg_sparse=False):
   return "hbm", 0.0, "GB/s"
 
 
+def entry_work(entry, B, h0, n_b, nnz, n_items, cfg):
+  """algorithmic_work extended to the entries of the per-entry sequencing (hidden stacks, MF,
+  multinomial loss); (None, ...) for the small launches that have no meaningful roofline."""
+  if entry in ENTRIES:
+    return algorithmic_work(entry, B, h0, n_b, nnz, n_items, bool(cfg["sparse"]))
+  if entry in ("rk_decode_bwd_dw3",):
+    return "mfma", 2.0 * B * h0 * n_b / 1e12, "TFLOP/s"
+  if entry == "rk_mnll_finish":                 # two passes over the B x n_b logits, one write
+    return "hbm", 3.0 * B * n_b * 4 / 1e9, "GB/s"
+  if entry in ("rk_linear_fwd", "rk_linear_bwd") and cfg["kind"] == "ae" and len(cfg["hidden_layers"]) > 1:
+    hh = cfg["hidden_layers"]
+    fl = 2.0 * B * hh[0] * hh[1] * (1 if entry == "rk_linear_fwd" else 2)
+    return "mfma_f32", fl / 1e12, "TFLOP/s"
+  return None, 0.0, ""
+
+
 def peak_of(entry, bound):
+  if bound == "mfma_f32":
+    return PEAK_MFMA_F32_TF
   if bound != "mfma":
     return PEAK_HBM_GBS
   if GEMM_F32:
@@ -275,12 +316,18 @@ def main():
 
   csr = make_csr(cfg)                       # every rank builds the same seeded matrix
   n_users, n_items = csr.shape
-  B, h0 = cfg["batch_size"], cfg["hidden_layers"][0]
+  B = cfg["batch_size"]
+  h0 = cfg["hidden_layers"][0] if cfg["kind"] == "ae" else cfg["embedding_size"]
   W, K = args.warmup, args.steps
 
   torch.manual_seed(0)       # same initial weights on every rank
-  model = DynamicAutoencoder(hidden_layers=cfg["hidden_layers"], activation_type=cfg["activation_type"],
-                             noise_prob=cfg["noise_prob"], sparse=cfg["sparse"])
+  if cfg["kind"] == "mf":
+    from recoder_amd.nn import MatrixFactorization
+    model = MatrixFactorization(cfg["embedding_size"], activation_type=cfg["activation_type"],
+                                sparse=cfg["sparse"])
+  else:
+    model = DynamicAutoencoder(hidden_layers=cfg["hidden_layers"], activation_type=cfg["activation_type"],
+                               noise_prob=cfg["noise_prob"], sparse=cfg["sparse"])
   rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss=cfg["loss"],
                 num_items=n_items, num_users=n_users)
   orders = {}
@@ -345,13 +392,29 @@ def main():
     T["enqueue"] = time.perf_counter() - T["t0"]     # host time to enqueue the timed steps
     sync_all()
     T["dt"] = time.perf_counter() - T["t0"]
+    lib_t = rec._engine().lib
+    if getattr(lib_t, "enabled", False):
+      lib_t.enabled = False
+      T["entries"] = lib_t.summary()
     return not SAMPLE_POST                           # end the training here
 
   def install():
     rec._engine().time_plan = plan_warm
     return False
 
+  # configurations outside the one-call step (hidden stacks, MF) are sequenced entry by entry from
+  # Python: there every C-ABI call of the last few timed steps is bracketed by engine.TimedLib
+  n_sample = max(1, K // 20)
+
+  def sample_on():
+    eng = rec._engine()
+    if not eng.c_step_eligible():
+      eng.lib.reset()
+      eng.lib.enabled = True
+    return False
   rec.step_marks = {0: install, W: start, W + K: stop}
+  if cfg["kind"] != "ae" or len(cfg["hidden_layers"]) > 1:
+    rec.step_marks[W + K - n_sample] = sample_on
   if SAMPLE_POST:
     rec.step_marks[W + K + G] = lambda: True
   prewarm = float(os.environ.get("RK_BENCH_PREWARM", "0"))
@@ -437,6 +500,30 @@ def main():
         kernels.append(line(e, timed[e], "timed region"))
       elif T["warm"].get(e):
         kernels.append(line(e, T["warm"][e], "warm-up"))
+    small = []
+    if T.get("entries"):
+      # per-entry sequencing: {C-ABI entry: (calls, mean ms)} of the last n_sample timed steps
+      kernels = []
+      for e, (calls, ms) in sorted(T["entries"].items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+        per_step = calls / float(n_sample)
+        bound, work, unit = entry_work(e, B, h0, n_b, nnz, n_items, cfg)
+        if e == "rk_adam_multi":
+          # the per-entry sequencing issues the step's updates in launches of <= 6 tensors: the
+          # formula is the whole step's traffic (the two tables dominate), spread over them;
+          # MatrixFactorization: the item table + its bias only (the user rows go through rk_adam_rows)
+          if cfg["kind"] == "mf":
+            work = (n_b * h0 * 28 * (1 if cfg["sparse"] else 0) + n_items * 28 + n_b * 32) / 1e9 \
+                if cfg["sparse"] else (n_items * h0 * 24 + n_b * h0 * 4 + n_items * 32) / 1e9
+          work /= max(per_step, 1.0)
+        if bound is None or work <= 0:
+          small.append(dict(name=e, launches_per_step=per_step, avg_us=ms * 1e3))
+          continue
+        peak = peak_of(e, bound)
+        ach = work / (ms * 1e-3)
+        kernels.append(dict(name=e, kernels=KERNELS.get(e, []), avg_us=ms * 1e3, samples=calls,
+                            launches_per_step=per_step, sampled="timed region (last %d steps)" % n_sample,
+                            bound="mfma" if bound.startswith("mfma") else bound, achieved=ach, peak=peak,
+                            unit=unit, frac=ach / peak, ideal_us=work / peak * 1e6))
     if not kernels:
       # (no launch group was bracketed: a run too short for the sampling plan -- never lose the line)
       kernels = [dict(name="rk_adam_multi", kernels=KERNELS.get("rk_adam_multi", []), avg_us=float("nan"),
@@ -463,13 +550,14 @@ def main():
     for k in kernels:
       if k["name"] in side:
         k["concurrent_with"] = ["rk_decode_bwd_dz", "rk_ae_encode_bwd"]
-    chain_us = sum(k["avg_us"] for k in kernels if k["name"] not in side)
-    ideal_us = sum(k["ideal_us"] for k in kernels)
+    chain_us = sum(k["avg_us"] * k.get("launches_per_step", 1) for k in kernels if k["name"] not in side) + \
+        sum(k["avg_us"] * k["launches_per_step"] for k in small)
+    ideal_us = sum(k["ideal_us"] * k.get("launches_per_step", 1) for k in kernels)
     roofline = dict(bound=dom["bound"], achieved=dom["achieved"], peak=dom["peak"], unit=dom["unit"],
                     frac=dom["frac"], traffic=traffic, traffic_source=traffic_source, kernel=dominant,
                     kernel_names=dom["kernels"],
                     avg_launch_ms=dom["avg_us"] / 1e3, samples=dom["samples"],
-                    event_pair_overhead_ms=ev_over, kernels=kernels,
+                    event_pair_overhead_ms=ev_over, kernels=kernels, small_launches=small,
                     step=dict(ideal_us=ideal_us, kernel_chain_us=chain_us,
                               measured_us=dt / K * 1e6, frac=ideal_us / (dt / K * 1e6)))
     out = {
@@ -500,7 +588,7 @@ def main():
     if world == 1 and not multi and not args.no_recall:
       # Recall@20 of the trained state, product vs oracle (outside the timed region)
       try:
-        rc = recall_check(rec, model, cfg, csr)
+        rc = recall_check(rec, model, cfg, csr, n_held=1000 if n_items <= 100000 else 300)
         out["recall_at_20"], out["recall_match_4dp"], out["recall"] = rc["value"], rc["match_4dp"], rc
       except Exception as e:          # noqa: BLE001 -- never lose the line
         out["recall_at_20"], out["recall_match_4dp"] = None, None

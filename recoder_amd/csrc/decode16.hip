@@ -399,7 +399,7 @@ void decode_planes_kernel(DecP p) {
 struct DzP {
   unsigned long long *probe;
   const float *dO;            // [M][ld] fp32 (columns [n_t, ld): anything, masked in the kernel)
-  const char *wtp;            // W^T image: row j = hidden unit, pitch (n_ld / 32) lines
+  const char *wtp;            // W^T image, k-tile major: line (kt, j) at (kt * Hp + j) * 128
   const float *scales;        // [1] scale of W
   const uint32_t *a_amax;     // 64 slots: running max |dO| (counts + 8)
   const int32_t *counts;      // [0] n_t (= K), [2] ld
@@ -414,7 +414,10 @@ struct DzP {
 // fragments go global -> registers directly (a lane: 8 consecutive k of its row per k-step = two
 // 16-byte loads) and are split there -- with one column tile (h <= 32 * TN) every dO element is
 // split exactly once on the whole chip.
-template <int TN>
+// RD: k-tiles of register prefetch.  1 by default: next to the dW kernel on the side stream a 3-deep
+// ring gained dZ 0.5 us and cost dW 11 (22 -> 33 us: it waits on the same L2 fetch path, and the
+// Adam sweep waits for dW); 3 where dZ runs alone.
+template <int TN, int RD = 1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 void dz_planes_kernel(DzP p) {
   constexpr int BM = 128, BN = 32 * TN;
@@ -461,25 +464,27 @@ void dz_planes_kernel(DzP p) {
   for (int i = 0; i < B_PT; ++i) {
     const int idx = min(tid + 256 * i, BN * 8 - 1), row = idx >> 3, piece = idx & 7;
     // (the image has round_up(h, 32) rows; a tile may be wider: clamp -- those columns are never stored)
-    srcB[i] = p.wtp + ((int64_t)min(n0 + row, rkp::kp_of(N) - 1) * (p.n_ld >> 5) + (kbeg >> 5)) * rkp::LINE + piece * 16;
+    srcB[i] = p.wtp + ((int64_t)(kbeg >> 5) * rkp::kp_of(N) + min(n0 + row, rkp::kp_of(N) - 1)) * rkp::LINE + piece * 16;
     dstB[i] = row * ROWB + piece * 16;
   }
-  // register ring, 3 k-tiles deep, for both operands (a split of the C2 shape holds 4 k-tiles: nearly
-  // all of its loads are in flight at once); B goes on through two LDS stages, A stays in registers
+  // register ring (RD k-tiles) for both operands; B goes on through two LDS stages, A stays in registers
   u32x4 rb0[B_PT], rb1[B_PT], rb2[B_PT];
   f32x4 ra0[4], ra1[4], ra2[4];
+  const int64_t b_step = (int64_t)rkp::kp_of(N) * rkp::LINE;      // one k-tile of the image
 #define GLOAD(slot, kt)                                                            \
-  ld_pieces(rb##slot, srcB, (int64_t)(kt) * rkp::LINE);                            \
+  ld_pieces(rb##slot, srcB, (int64_t)(kt) * b_step);                               \
   ld_a4(ra##slot, a_src + (kt) * 32);
 #define SSTOREB(buf, slot) st_pieces_n<BN * 8>(smem + (buf) * STAGE, dstB, rb##slot, tid);
   GLOAD(0, 0);
-  GLOAD(1, min(1, nk - 1));
-  GLOAD(2, min(2, nk - 1));
+  if (RD == 3) {
+    GLOAD(1, min(1, nk - 1));
+    GLOAD(2, min(2, nk - 1));
+  }
   SSTOREB(0, 0);
   __syncthreads();
   RK_STAMP(1);
   const int b_off = l31 * ROWB + lh * 16;
-#define KTILE(U, UN)                                                                                \
+#define KTILE(U, UN, D)                                                                              \
   if (kt0 + (U) < nk) {                                                                             \
     const int kt = kt0 + (U);                                                                       \
     f32x4 ac[4];                                                                                    \
@@ -504,7 +509,7 @@ void dz_planes_kernel(DzP p) {
       ah[ks] = __builtin_bit_cast(f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));                       \
       al[ks] = __builtin_bit_cast(f16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));                       \
     }                                                                                               \
-    GLOAD(U, min(kt + 3, nk - 1));                                                                  \
+    GLOAD(U, min(kt + (D), nk - 1));                                                                  \
     const char *S = smem + (kt & 1) * STAGE;                                                        \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                              \
       f16x8 bh[TN], bl[TN];                                                                         \
@@ -523,10 +528,16 @@ void dz_planes_kernel(DzP p) {
     SSTOREB((kt + 1) & 1, UN);                                                                      \
     __syncthreads();                                                                                \
   }
-  for (int kt0 = 0; kt0 < nk; kt0 += 3) {
-    KTILE(0, 1)
-    KTILE(1, 2)
-    KTILE(2, 0)
+  if (RD == 3) {
+    for (int kt0 = 0; kt0 < nk; kt0 += 3) {
+      KTILE(0, 1, 3)
+      KTILE(1, 2, 3)
+      KTILE(2, 0, 3)
+    }
+  } else {
+    for (int kt0 = 0; kt0 < nk; ++kt0) {
+      KTILE(0, 0, 1)
+    }
   }
 #undef KTILE
 #undef GLOAD
@@ -606,8 +617,9 @@ inline int dec_tm(int B, int n_cap) {
   if (g_dec_tm > 0) return g_dec_tm;
   // 128 x 128 tiles for large batches; below that 64 x 128 (two workgroups per CU): C2 (B = 500,
   // n_b ~ 7.9 k: one wave of either tiling) 20.4 vs 22.4 us.  (n_b only exists on the device.)
-  (void)n_cap;
-  return B >= 1024 ? 2 : 1;
+  // (long item sets -- C5: 48.8 k sampled items of 1 M -- take the 128 x 128 tile at any batch size:
+  // 122 vs 154 us, its W panel is re-read half as often)
+  return (B >= 1024 || n_cap >= 32768) ? 2 : 1;
 }
 
 }  // namespace
@@ -745,8 +757,13 @@ extern "C" int rk_decode_bwd_dz_planes(const float *dO, int32_t B, const rk_plan
   p.counts = tgt->counts; p.n_ld = pl->n_ld;
   p.M = B; p.N = h; p.ws = workspace;
   const int splits = rk_dz_splits(B);
-  // one column tile up to h = 256 (7 x 32 covers h = 200: dO is read and split once), else 256-wide tiles
-  const int tn = h <= 64 ? 2 : (h <= 128 ? 4 : (h <= 224 ? 7 : 8));
+  // one column tile up to h = 224 (dO read and split once); wider h: 128-column tiles with two
+  // resident workgroups per CU (C5, h = 512: 190 vs 282 us for 256-column tiles with one)
+  int tn = h <= 64 ? 2 : (h <= 128 ? 4 : (h <= 224 ? 7 : 4));
+  {
+    static const int tn_env = [] { const char *e = getenv("RK_DZ_TN"); return e ? atoi(e) : 0; }();   // (tuning)
+    if (tn_env == 2 || tn_env == 4 || tn_env == 7 || tn_env == 8) tn = tn_env;
+  }
   p.tiles_n = rk_cdiv(h, 32 * tn);
   const int tiles = rk_cdiv(B, 128) * p.tiles_n;
   const int lds = 2 * 32 * tn * ROWB;

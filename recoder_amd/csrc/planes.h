@@ -15,7 +15,12 @@
 //
 //   Z  image  [B rows][KT(h)]        written by the encoder forward with the value in registers
 //   W  image  [n_b rows][KT(h)]      the gathered decoder rows W_de[items[c]] (decode: B operand)
-//   W^T image [Hp rows][KT(n_ld)]    row j = hidden unit, k = compact item index (dZ: B operand);
+//   W^T image [KT(n_ld)][Hp rows]    K-TILE MAJOR: line (kt, j) = hidden unit j, the 32 compact items of
+//                                     k-tile kt (dZ: B operand) at (kt * Hp + j) * 128 -- a k-tile of the
+//                                     whole image is ONE contiguous block (Hp * 128 bytes), so the dZ
+//                                     kernel streams and the split pass writes contiguously (row-major
+//                                     [Hp][KT] put consecutive rows 195 KB apart at C5's 48.8 k items:
+//                                     dZ ran 9x off its MFMA time);
 //                                     items in [n_b, round_up(n_b, 32)) are written as ZEROS (the K tail)
 //   scales[0] / [1]: the power-of-two split scales used for Z / W (read by the consumers).
 #pragma once
@@ -71,7 +76,7 @@ struct SplitW {
   const int32_t *counts;     // [0] = n_b (device)
   const uint32_t *amax;      // 64 slots: bound of |W| (nullable)
   char *wp;                  // W image   [n rows][KT]
-  char *wtp;                 // W^T image [Hp rows][n_ld / 32]
+  char *wtp;                 // W^T image [n_ld / 32 k-tiles][Hp rows]
   float *scales;             // [1] <- the scale used
   int h, KT;                 // KT = kp_of(h) / 32
   int n_ld;                  // items padded (multiple of 32): row pitch of the W^T image = n_ld / 32 lines
@@ -122,7 +127,7 @@ __device__ __forceinline__ void split_w_job(const SplitW &p, const int tile, cha
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           w[e] = (uint32_t)src[(2 * e) * 66] | ((uint32_t)src[(2 * e + 1) * 66] << 16);
-        char *d = p.wtp + ((int64_t)j * (p.n_ld >> 5) + tile) * LINE + pc * 16;
+        char *d = p.wtp + ((int64_t)tile * Kp + j) * LINE + pc * 16;
         *reinterpret_cast<uint4 *>(d) = make_uint4(w[0], w[1], w[2], w[3]);
       }
     }

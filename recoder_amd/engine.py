@@ -729,13 +729,23 @@ class FusedEngine:
       h0 = self.h[0]
       tied = bool(m.is_constrained)
       n_b = dp.n_b(blk)
-      st.phase = STEP_FWD_DW | STEP_DZ_ENC
-      check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
       G_enc = self.G_de if tied else self.G_en
-      views = [G_enc[:n_b * h0], self.small[:self.small_off + n_b]]
-      if not tied:
-        views.insert(0, self.G_de[:n_b * h0])
-      dp.reduce(views)
+      if tied:
+        # tied weights: the encoder backward accumulates onto dW's rows -- nothing may leave before it
+        st.phase = STEP_FWD_DW | STEP_DZ_ENC
+        check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
+        dp.reduce([G_enc[:n_b * h0], self.small[:self.small_off + n_b]])
+      else:
+        # the decoder-side gradients (dW rows, loss, gathered-bias gradient) travel on the
+        # communication stream while this stream runs dZ -> encoder backward; the encoder side
+        # (gradient rows, encoder bias) follows behind them; the Adam sweep waits for both
+        st.phase = STEP_FWD_DW
+        check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
+        dp.reduce_async([self.G_de[:n_b * h0], self.small[h0:self.small_off + n_b]], main_s)
+        st.phase = STEP_DZ_ENC
+        check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
+        dp.reduce_async([G_enc[:n_b * h0], self.small[:h0]], main_s)
+        dp.join_async(main_s)
       out.copy_(self.loss_dp)
       st.phase = STEP_UPDATE
       check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")

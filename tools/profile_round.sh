@@ -14,5 +14,10 @@ python tools/rocpd_stats.py $(find $out -name 'stats_results.db') > $out/kernel_
 python tools/pmc_traffic.py $(find $out -name 'fetch_results.db') $(find $out -name 'write_results.db') > $out/pmc_traffic.json
 python tools/rocpd_gaps.py $(find $out -name 'stats_results.db') 60 120 > $out/timeline.txt
 grep metric $out/stats.log > $out/bench_profiled.json
+# SQ counters of the contraction kernels (one more pass, its own run)
+RK_GRAPH=0 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format rocpd -d $out -o sq -- $B > $out/sq.log 2>&1
+python tools/rocpd_pmc.py $(find $out -name 'sq_results.db') > $out/sq_counters.txt 2>&1
 $B > $out/bench.json 2> $out/bench.err
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_steps20.json 2>> $out/bench.err
+rm -f $(find $out -name '*.db')
 cat $out/kernel_stats.md | head -20; cat $out/pmc_traffic.json; cat $out/timeline.txt
