@@ -535,6 +535,36 @@ int rk_cursor_advance(int64_t *cursor, int64_t n, void *stream);
 int rk_adam_consts(double lr, double beta1, double beta2, double eps, double weight_decay,
                    int32_t step, int32_t n_steps, int32_t stride_floats, float *out_host);
 /* (entries of steps step .. step + n_steps - 1, 8 floats each, stride_floats apart) */
+/*
+ * Graph replay of steps that are sequenced ENTRY BY ENTRY from the host (hidden stacks, bottleneck
+ * dropout, MatrixFactorization: everything outside rk_ae_train_step).  Between rk_replay_set and
+ * rk_replay_clear (thread-local) the entry points below take what changes from step to step from
+ * the device-resident cursor instead of their host arguments, so that a captured sequence of them
+ * can be replayed:
+ *   rk_ae_encode_fwd                       rng_step = cursor[0] + off + 1; users = users_base + local * B
+ *   rk_dropout                             rng_step = cursor[0] + off + 1
+ *   rk_gather_rows / rk_scatter_pos /      rows / idx64 = users_base + local * B  (the pointer argument
+ *   rk_adam_rows (idx64)                   is ignored)
+ *   rk_adam_rows / rk_adam_multi           Adam constants = adam_table[local * tab_stride + slot]
+ *                                          (slot: the call's `step` argument / rk_adam_job_t.par.step
+ *                                          are read as the parameter's SLOT, >= 1 -> slot = value - 1);
+ *                                          rk_adam_multi: loss_out is the BASE of the epoch's loss
+ *                                          buffer (slot `local`), and the launch carrying the loss
+ *                                          publishes cursor_next = {cursor[0] + advance, cursor[1]}
+ * with local = cursor[0] - cursor[1] + off (the step's index in its epoch).
+ */
+typedef struct rk_replay {
+  const int64_t *cursor;
+  int32_t off;
+  int32_t B;                 /* rows of a step (whole batches only) */
+  const int64_t *users_base; /* the epoch's user order */
+  const void *adam_table;    /* [steps][tab_stride] entries of 8 floats (rk_adam_consts) */
+  int32_t tab_stride;
+  int32_t advance;           /* with cursor_next */
+  int64_t *cursor_next;      /* nullable */
+} rk_replay_t;
+void rk_replay_set(const rk_replay_t *ctx);
+void rk_replay_clear(void);
 int rk_graph_begin(void *stream);
 void *rk_graph_end(void *stream);              /* -> executable graph handle, NULL on error */
 int rk_graph_launch(void *graph_exec, void *stream);

@@ -76,6 +76,13 @@ class RkAeStep(Structure):
   ]
 
 
+class RkReplay(Structure):
+  """mirror of rk_replay_t"""
+  _fields_ = [("cursor", c_void_p), ("off", c_int32), ("B", c_int32), ("users_base", c_void_p),
+              ("adam_table", c_void_p), ("tab_stride", c_int32), ("advance", c_int32),
+              ("cursor_next", c_void_p)]
+
+
 class RkPlanes(Structure):
   """mirror of rk_planes_t"""
   _fields_ = [("scales", c_void_p), ("z", c_void_p), ("w", c_void_p), ("wt", c_void_p),
@@ -179,6 +186,8 @@ SIGNATURES = {
   "rk_cursor_advance": (c_int32, [_P, c_int64, _P]),
   "rk_adam_consts": (c_int32, [c_double, c_double, c_double, c_double, c_double, c_int32, c_int32,
                                c_int32, _P]),
+  "rk_replay_set": (None, [POINTER(RkReplay)]),
+  "rk_replay_clear": (None, []),
   "rk_graph_begin": (c_int32, [_P]),
   "rk_graph_end": (c_void_p, [_P]),
   "rk_graph_launch": (c_int32, [_P, _P]),

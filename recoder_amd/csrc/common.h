@@ -38,6 +38,9 @@ int rk_ae_encode_fwd_at(const rk_block_t *blk, int32_t row_off, int32_t B, const
                         const int64_t *cursor, int32_t cursor_off, const int64_t *users, int32_t act,
                         float *Z0, void *zt_planes, void *stream, const rk_enc_split_t *es,
                         uint64_t rng_step);
+// The replay context of the per-entry sequencing (rk_replay_set, capi.hip): thread-local, null outside
+// a bracketed step
+const rk_replay_t *rk_replay_get(void);
 // gemm.hip: the split-K reduce (ws[split][M][N] -> out, * act'(Zact) if given) and the split-K factor
 int rk_splitk_reduce(const float *ws, int M, int N, const int32_t *Kdev, int splits, const float *Zact,
                      int act, float *out, void *stream);

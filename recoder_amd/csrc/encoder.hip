@@ -443,6 +443,11 @@ extern "C" int rk_ae_encode_fwd(const rk_block_t *blk, int32_t row_off, int32_t 
                                 const uint8_t *keep, float p, uint64_t seed, uint64_t rng_step,
                                 const int64_t *users, int32_t act, float *Z0, void *stream_) {
   RK_REQUIRE(b_en != nullptr, "b_en is required");
+  if (const rk_replay_t *rp = rk_replay_get()) {     // replayed per-entry step: cursor-derived
+    const rk_cur_t cur = {rp->cursor, rp->off};
+    return encode_fwd_launch(blk, row_off, B, W_en, b_en, h, keep, p, seed, 0, rp->users_base, nullptr,
+                             act, Z0, stream_, nullptr, cur);
+  }
   return encode_fwd_launch(blk, row_off, B, W_en, b_en, h, keep, p, seed, rng_step, users, nullptr,
                            act, Z0, stream_);
 }

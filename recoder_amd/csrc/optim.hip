@@ -94,7 +94,12 @@ __global__ __launch_bounds__(256) void adam_table_scalar_kernel(float *W, float 
 __global__ __launch_bounds__(256) void adam_rows_kernel(float *W, float *m, float *v, int h,
                                                         const int32_t *idx32, const int64_t *idx64,
                                                         const int32_t *n_dev, int n_host,
-                                                        const float *G, AdamC c) {
+                                                        const float *G, AdamC c, rk_cur_t cur,
+                                                        const AdamC *ctab, int tab_stride, int tab_slot) {
+  if (cur.cursor) {            // replayed step: this step's users and constants
+    if (idx64) idx64 += rk_cur_local(cur) * n_host;
+    if (ctab) c = ctab[rk_cur_local(cur) * tab_stride + tab_slot];
+  }
   const int n = n_dev ? *n_dev : n_host;
   const int64_t tot = (int64_t)n * h;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
@@ -122,7 +127,8 @@ __global__ __launch_bounds__(256) void act_grad_kernel(float *dY, const float *Y
 
 __global__ __launch_bounds__(256) void dropout_kernel(float *X, const uint8_t *keep, int64_t n,
                                                       int ncols, float p, float scale,
-                                                      uint64_t seed, uint64_t step) {
+                                                      uint64_t seed, uint64_t step, rk_cur_t cur) {
+  if (cur.cursor) step = (uint64_t)(rk_cur_global(cur) + 1);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const bool k = keep ? (keep[i] != 0)
                         : rk_keep_draw(seed, step, (uint64_t)(i / ncols) + 0x51ed270b1ULL,
@@ -167,7 +173,8 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float *X, int rows, 
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float *E, const int64_t *rows, int B,
-                                                          int d, int act, float *out) {
+                                                          int d, int act, float *out, rk_cur_t cur) {
+  if (cur.cursor) rows += rk_cur_local(cur) * B;
   const int64_t tot = (int64_t)B * d;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
     const int r = (int)(i / d), q = (int)(i % d);
@@ -176,7 +183,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *E, const 
 }
 
 __global__ __launch_bounds__(256) void scatter_pos_kernel(int32_t *pos, const int64_t *rows, int B,
-                                                          int clear) {
+                                                          int clear, rk_cur_t cur) {
+  if (cur.cursor) rows += rk_cur_local(cur) * B;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < B) pos[rows[i]] = clear ? -1 : i;
 }
@@ -441,8 +449,16 @@ extern "C" int rk_adam_rows(float *W, float *m, float *v, int32_t h, const int32
   RK_REQUIRE((idx32 != nullptr) != (idx64 != nullptr), "exactly one index array");
   if (n_cap == 0) return 0;
   const AdamC c = make_consts(lr, beta1, beta2, eps, 0.0, step);
+  rk_cur_t cur = {nullptr, 0};
+  const AdamC *ctab = nullptr;
+  int tab_stride = 0, tab_slot = 0;
+  if (const rk_replay_t *rp = rk_replay_get()) {     // replayed step: `step` is the parameter's slot + 1
+    cur = {rp->cursor, rp->off};
+    ctab = (const AdamC *)rp->adam_table; tab_stride = rp->tab_stride; tab_slot = step - 1;
+    if (idx64) { idx64 = rp->users_base; RK_REQUIRE(n_cap == rp->B, "replay: idx64 covers one batch"); }
+  }
   RK_LAUNCH(adam_rows_kernel, dim3(grid_for((int64_t)n_cap * h)), dim3(256), 0, stream, W,
-                     m, v, h, idx32, idx64, n_dev, n_cap, G, c);
+                     m, v, h, idx32, idx64, n_dev, n_cap, G, c, cur, ctab, tab_stride, tab_slot);
   RK_CHECK_LAUNCH("adam_rows");
   return 0;
 }
@@ -526,6 +542,16 @@ int rk_adam_multi_at(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part
 
 extern "C" int rk_adam_multi(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part,
                              int32_t n_part, float denom, float *loss_out, void *stream_) {
+  if (const rk_replay_t *rp = rk_replay_get()) {
+    // replayed per-entry step: par.step of every job is its parameter's slot + 1 in the constants table
+    int32_t slots[RK_ADAM_MULTI_MAX];
+    rk_adam_job_t tmp[RK_ADAM_MULTI_MAX];
+    RK_REQUIRE(n_jobs >= 0 && n_jobs <= RK_ADAM_MULTI_MAX, "too many jobs for one launch");
+    for (int j = 0; j < n_jobs; ++j) { tmp[j] = jobs[j]; slots[j] = jobs[j].par.step - 1; tmp[j].par.step = 1; }
+    return rk_adam_multi_at(tmp, n_jobs, loss_part, n_part, denom, loss_out, rp->cursor, rp->off,
+                            rp->adam_table, rp->tab_stride, slots,
+                            loss_part ? rp->cursor_next : nullptr, rp->advance, stream_);
+  }
   return rk_adam_multi_at(jobs, n_jobs, loss_part, n_part, denom, loss_out, nullptr, 0, nullptr, 0,
                           nullptr, nullptr, 0, stream_);
 }
@@ -548,8 +574,10 @@ extern "C" int rk_scatter_pos(int32_t *pos, const int64_t *rows, int32_t B, int3
                               void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B == 0) return 0;
+  rk_cur_t cur = {nullptr, 0};
+  if (const rk_replay_t *rp = rk_replay_get()) { cur = {rp->cursor, rp->off}; rows = rp->users_base; }
   RK_LAUNCH(scatter_pos_kernel, dim3(rk_cdiv(B, 256)), dim3(256), 0, stream, pos, rows, B,
-                     clear);
+                     clear, cur);
   RK_CHECK_LAUNCH("scatter_pos");
   return 0;
 }
@@ -578,8 +606,10 @@ extern "C" int rk_dropout(float *X, const uint8_t *keep, int64_t n, int32_t ncol
   RK_REQUIRE(p >= 0.f && p < 1.f, "dropout prob must be in [0,1)");
   if (n == 0 || p == 0.f) return 0;
   const float scale = 1.0f / (float)(1.0 - (double)p);
+  rk_cur_t cur = {nullptr, 0};
+  if (const rk_replay_t *rp = rk_replay_get()) cur = {rp->cursor, rp->off};
   RK_LAUNCH(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, stream, X, keep, n, ncols, p,
-                     scale, seed, rng_step);
+                     scale, seed, rng_step, cur);
   RK_CHECK_LAUNCH("dropout");
   return 0;
 }
@@ -598,8 +628,10 @@ extern "C" int rk_gather_rows(const float *E, const int64_t *rows, int32_t B, in
                               int32_t act, float *out, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B == 0) return 0;
+  rk_cur_t cur = {nullptr, 0};
+  if (const rk_replay_t *rp = rk_replay_get()) { cur = {rp->cursor, rp->off}; rows = rp->users_base; }
   RK_LAUNCH(gather_rows_kernel, dim3(grid_for((int64_t)B * d)), dim3(256), 0, stream, E,
-                     rows, B, d, act, out);
+                     rows, B, d, act, out, cur);
   RK_CHECK_LAUNCH("gather_rows");
   return 0;
 }

@@ -253,13 +253,17 @@ class FusedEngine:
     """parts = (pointer, g_parts, g_stride, gstride_dev, gparts_dev): the gradient is the sum, in
     order, of that many partial arrays (rk_adam_job_t) instead of the single array `g`."""
     from ._lib import RkAdamJob
-    s.step += 1
+    rp = getattr(self, "_replay", None)
+    if rp is None:
+      s.step += 1
     lr, b1, b2, eps = self._adam_args(s)
     j = RkAdamJob()
     a = j.par
     a.p, a.m, a.v = ptr(s.p), ptr(s.m), ptr(s.v)
     a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = lr, b1, b2, eps, float(s.wd)
-    a.step, a.sparse = s.step, 1 if rows is not None else 0
+    # (replay: `step` carries the parameter's slot + 1 in the per-epoch constants table, rk_replay_t)
+    a.step = s.step if rp is None else rp["slots"][s.name] + 1
+    a.sparse = 1 if rows is not None else 0
     j.n_rows, j.h, j.g, j.g_parts = n_rows, h, ptr(g), 1
     j.pos, j.rows, j.n_dev, j.n_cap = ptr(pos), ptr(rows), ptr(n_dev), n_cap
     if parts is not None:
@@ -292,10 +296,13 @@ class FusedEngine:
       self._job(s, 0, h, G, rows=idx32, n_dev=n_dev, n_cap=n_cap, parts=parts)
       return
     assert parts is None
-    s.step += 1
+    rp = getattr(self, "_replay", None)
+    if rp is None:
+      s.step += 1
     lr, b1, b2, eps = self._adam_args(s)
     check(self.lib.rk_adam_rows(ptr(s.p), ptr(s.m), ptr(s.v), h, ptr(idx32), ptr(idx64), ptr(n_dev),
-                                n_cap, ptr(G), lr, b1, b2, eps, s.step, stream), "rk_adam_rows")
+                                n_cap, ptr(G), lr, b1, b2, eps,
+                                s.step if rp is None else rp["slots"][s.name] + 1, stream), "rk_adam_rows")
 
   def _adam_dense(self, s, g, stream):
     self._job(s, 1, s.p.numel(), g)
@@ -437,7 +444,7 @@ class FusedEngine:
     return self._loss(z, B, tgt if tgt is not None else blk, row_off, B, stream, out)
 
   def train_step(self, blk, row_off, B, keep_noise=None, keep_drop=None, out=None,
-                 global_rows=None, tgt=None):
+                 global_rows=None, tgt=None, replay=None):
     """One optimisation step on rows [row_off, row_off+B) of the collated
     block (model.py:383-404).  ``global_rows`` = rows summed over all ranks
     (data parallel); the loss/gradients are normalised by it.
@@ -461,17 +468,45 @@ class FusedEngine:
       if ip is not None or self.allreduce is not None:
         raise RuntimeError("FusedEngine: a separate target matrix has no sharded formulation")
     if self.c_step_eligible() and tgt is None and not (ip is not None and self.loss_id == LOSS_MNLL):
-      return self._c_train_step(blk, row_off, B, keep_noise, out, global_rows, main_s)
+      return self._c_train_step(blk, row_off, B, keep_noise, out, global_rows, main_s, replay=replay)
+    if replay is not None:
+      # graph replay of the per-entry sequencing (graph.GraphStepper): what changes per step comes
+      # from the device-resident cursor (include/recoder_hip.h rk_replay_t); the host counters are
+      # advanced by the stepper, `out` is the base of the epoch's loss buffer
+      from ._lib import RkReplay
+      ctx = RkReplay()
+      ctx.cursor, ctx.off, ctx.B = replay["cursor"], replay["off"], B
+      ctx.users_base, ctx.adam_table, ctx.tab_stride = replay["users"], replay["table"], replay["tab_stride"]
+      ctx.cursor_next, ctx.advance = replay["next"] if replay.get("next") is not None else (None, 0)
+      raw_lib = _lib.load()
+      raw_lib.rk_replay_set(ctypes.byref(ctx))
+      self._replay = replay
+      try:
+        return self._entry_train_step(blk, row_off, B, keep_noise, keep_drop, out, global_rows, tgt, main_s)
+      finally:
+        self._replay = None
+        raw_lib.rk_replay_clear()
+    return self._entry_train_step(blk, row_off, B, keep_noise, keep_drop, out, global_rows, tgt, main_s)
+
+  def _entry_train_step(self, blk, row_off, B, keep_noise, keep_drop, out, global_rows, tgt, main_s):
+    """The step sequenced entry by entry from here (hidden stacks, bottleneck dropout,
+    MatrixFactorization, separate target blocks, the multi-GPU variants)."""
+    lib, m = self.lib, self.model
+    ip = self.item_parallel
+    tb = blk if tgt is None else tgt
     self._gb_lazy = None
     self._gb_en_segs = 0
     stream = ctypes.c_void_p(main_s.cuda_stream)
-    self.rng_step += 1
+    if getattr(self, "_replay", None) is None:
+      self.rng_step += 1
     h0 = self.h[0]
     rows = B if global_rows is None else global_rows
     if self.kind == "ae":
       z = self._ae_forward(blk, row_off, B, keep_noise, keep_drop, True, stream)
     else:
-      users = blk.users[row_off:row_off + B]
+      rp = getattr(self, "_replay", None)
+      # (replay: the C entry points take the step's users from the cursor; the pointer is a placeholder)
+      users = blk.users[row_off:row_off + B] if rp is None else rp["users_t"]
       z = self._mf_forward(users, B, keep_drop, True, stream)
     # single process: nothing has to exist as an array of its own for an exchange, so the small
     # reductions of the step ride on its Adam launch as they do in rk_ae_train_step -- the loss
@@ -484,9 +519,24 @@ class FusedEngine:
 
     # ---- dW = dO^T . z  (+ decoder bias gradient) ----
     keep_slabs = lazy and not tied and self.split16 and self.ws_dw is not None
+    # replayed steps: dW (it needs dO and z only) as a branch on the stepper's side stream next to
+    # dZ -> hidden stacks -> encoder backward, joined in front of the Adam sweeps -- as the one-call
+    # step does (rk_ae_step_t.dw_stream); its K slabs live in a workspace of their own
+    rp = getattr(self, "_replay", None)
+    # (off by default: with a dozen more launches on the chain the two cross-queue edges cost more
+    # than the overlap buys -- C3 0.307 vs 0.300 ms, C4 0.150 vs 0.147 ms per step; RK_DW_BRANCH_ENTRY=1)
+    dw_side = rp.get("dw_stream") if (rp is not None and keep_slabs and self.dw_branch and
+                                      os.environ.get("RK_DW_BRANCH_ENTRY") == "1") else None
+    dw_stream = stream
+    if dw_side is not None:
+      if getattr(self, "_dw_ev", None) is None:
+        self._dw_ev = (torch.cuda.Event(), torch.cuda.Event())
+      self._dw_ev[0].record(main_s)
+      dw_side.wait_event(self._dw_ev[0])
+      dw_stream = ctypes.c_void_p(dw_side.cuda_stream)
     if self.loss_id == LOSS_MNLL:
       # dO was produced by rk_mnll_finish: column sums need a pass over dO
-      self._dw(z, B, tb, self.gb_de, stream, keep_slabs)
+      self._dw(z, B, tb, self.gb_de, dw_stream, keep_slabs)
     else:
       # the loss epilogue already reduced dO per row tile: sum those few rows
       if lazy:
@@ -494,7 +544,9 @@ class FusedEngine:
       else:
         check(lib.rk_colsum(ptr(self.gb_part), cdiv(B, self.row_tile), tb.n_cap, 0, ptr(tb.counts),
                             ptr(self.gb_de), stream), "rk_colsum")
-      self._dw(z, B, tb, None, stream, keep_slabs)
+      self._dw(z, B, tb, None, dw_stream, keep_slabs)
+    if dw_side is not None:
+      self._dw_ev[1].record(dw_side)
     n_b_host = self.allreduce.n_b(blk) if self.allreduce is not None else None
 
     # ---- dZ = dO . W_de[T] and everything upstream of it ----
@@ -563,6 +615,8 @@ class FusedEngine:
       # data parallel over users: every gradient of the step (live rows of both tables, gathered
       # bias, dense layers, loss) is SUM all-reduced as one in-order RCCL group on this stream
       self.allreduce.reduce(self.grad_views(n_b_host, "all"))
+    if dw_side is not None:
+      main_s.wait_event(self._dw_ev[1])
     self._apply_updates(blk, row_off, B, stream, "all", tgt=tb)
     return loss
 
@@ -912,7 +966,8 @@ class FusedEngine:
     else:
       lib = self.lib
       if enc:
-        users = blk.users[row_off:row_off + B]
+        rp = getattr(self, "_replay", None)
+        users = blk.users[row_off:row_off + B] if rp is None else rp["users_t"]
         su = S["user_embedding_layer.weight"]
         if su.sparse:
           self._adam_rows(su, None, users, None, B, self.dbott, h0, stream)

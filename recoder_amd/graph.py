@@ -50,8 +50,13 @@ class GraphStepper:
     # one reads valid user ids (its blocks are never trained on)
     self.order = torch.zeros((self.steps_cap + 2 * self.G) * self.B, dtype=torch.int64, device=device)
     self.loss_buf = torch.zeros(self.steps_cap + self.G, dtype=torch.float32, device=device)
-    self.table = torch.zeros((self.steps_cap + self.G) * 4 * 8, dtype=torch.float32, device=device)
-    self.table_host = torch.zeros((self.steps_cap + self.G) * 4 * 8, dtype=torch.float32).pin_memory()
+    # per-epoch table of Adam constants: one 8-float entry per (step, parameter slot).  The one-call
+    # step has its four parameters (slots = RK_PAR_*); the entry-by-entry sequencing one per state
+    self.c_step = engine.c_step_eligible()
+    self.slots = None if self.c_step else {name: i for i, name in enumerate(engine.states)}
+    self.tab_stride = 4 if self.c_step else max(1, len(engine.states))
+    self.table = torch.zeros((self.steps_cap + self.G) * self.tab_stride * 8, dtype=torch.float32, device=device)
+    self.table_host = torch.zeros((self.steps_cap + self.G) * self.tab_stride * 8, dtype=torch.float32).pin_memory()
     # stream capture needs a stream of its own (not the default stream torch work runs on)
     self.main = torch.cuda.Stream(device=device)
     self.side = torch.cuda.Stream(device=device)
@@ -126,8 +131,14 @@ class GraphStepper:
     replay = dict(st=self.st[slot][g], cursor=self._cur(slot), off=g, table=ptr(self.table),
                   users=ptr(self.order), timed=index is not None, index=index, dw_stream=self.side,
                   next=None if advance is None else (self._cur(1 - slot), advance))
-    self.eng._c_train_step(self.blocks[slot][g], 0, self.B, None, self.loss_buf, None, self.main,
-                           replay=replay)
+    if self.c_step:
+      self.eng._c_train_step(self.blocks[slot][g], 0, self.B, None, self.loss_buf, None, self.main,
+                             replay=replay)
+    else:
+      # entry-by-entry sequencing (hidden stacks, dropout, MatrixFactorization) under the replay
+      # context: every state's Adam constants have a slot of their own in the table
+      replay.update(tab_stride=self.tab_stride, slots=self.slots, users_t=self.order)
+      self.eng.train_step(self.blocks[slot][g], 0, self.B, out=self.loss_buf, replay=replay)
 
   def _group(self, slot, n_steps=None, first_index=None, lookahead=True):
     """One group on slot `slot`: its steps on the main stream, the collation of the NEXT group's
@@ -208,15 +219,12 @@ class GraphStepper:
     # Adam constants of every step of the epoch (exactly what rk_adam_multi derives itself)
     th = self.table_host
     S = self.eng.states
-    tied = bool(self.eng.model.is_constrained)
-    for k, name in _PAR_NAMES.items():
-      if k == PAR_W_DE and tied:
-        continue
+    for k, name in self._slot_items():
       s = S[name]
       lr, b1, b2, eps = self.eng._adam_args(s)
       wd = 0.0 if s.sparse else float(s.wd)
-      # entry (step i of the epoch, parameter k) at float offset (i * 4 + k) * 8
-      check(self.lib.rk_adam_consts(lr, b1, b2, eps, wd, s.step + 1, n_full + self.G, 4 * 8,
+      # entry (step i of the epoch, slot k) at float offset (i * tab_stride + k) * 8
+      check(self.lib.rk_adam_consts(lr, b1, b2, eps, wd, s.step + 1, n_full + self.G, self.tab_stride * 8,
                                     th.data_ptr() + k * 8 * 4), "rk_adam_consts")
     self.table.copy_(th, non_blocking=False)
     self.global_step = int(global_step)
@@ -327,13 +335,17 @@ class GraphStepper:
     """Forget the look-ahead blocks (a step mark / an eager ragged step follows)."""
     self._collated = None
 
+  def _slot_items(self):
+    """(table slot, state name) of every parameter the replayed steps update."""
+    if not self.c_step:
+      return [(i, name) for name, i in self.slots.items()]
+    tied = bool(self.eng.model.is_constrained)
+    return [(k, name) for k, name in _PAR_NAMES.items() if not (k == PAR_W_DE and tied)]
+
   def _advance_host(self, k):
     self.global_step += k
     S = self.eng.states
-    tied = bool(self.eng.model.is_constrained)
-    for key, name in _PAR_NAMES.items():
-      if key == PAR_W_DE and tied:
-        continue
+    for _, name in self._slot_items():
       S[name].step += k
     self.eng.rng_step += k
 

@@ -726,8 +726,10 @@ class Recoder(object):
     if os.environ.get("RK_GRAPH", "1") == "0":
       return False
     eng = self._engine()
-    if getattr(eng, "generic", False) or not eng.c_step_eligible():
+    if getattr(eng, "generic", False):
       return False
+    if not eng.c_step_eligible() and os.environ.get("RK_GRAPH_ENTRY", "1") == "0":
+      return False                       # (entry-by-entry sequenced steps: replayed too by default)
     if getattr(self, "_dp", None) is not None or getattr(self, "_ip", None) is not None:
       return False
     ds = dataloader.dataset
@@ -745,7 +747,8 @@ class Recoder(object):
     B, ns, n = dataloader.batch_size, dataloader.negative_sampling, len(ds)
     gs = getattr(self, "_graph_stepper", None)
     G = max(1, min(self.graph_group, n // B))
-    if gs is None or gs.dcsr is not dcsr or gs.B != B or gs.ns != ns or gs.G != G:
+    if gs is None or gs.eng is not eng or gs.dcsr is not dcsr or gs.B != B or gs.ns != ns or gs.G != G or \
+        (not gs.c_step and set(gs.slots) != set(eng.states)):
       if gs is not None:
         gs.close()
       gs = GraphStepper(eng, dcsr, lambda: self._make_block(dcsr, B, ns, train=True), B, ns, G, n,

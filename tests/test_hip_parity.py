@@ -1128,7 +1128,8 @@ def test_data_parallel_virtual_ranks_random_shapes(seed):
 
 
 @pytest.mark.parametrize("case", ["dense_noise", "sparse_tied_bce", "logloss", "ratings_all_items",
-                                  "ratings_relu_conf"])
+                                  "ratings_relu_conf", "stack_dropout", "stack_logloss_tied", "mf_sparse",
+                                  "mf_dense_dropout"])
 def test_graph_replay_is_bitwise_equal_to_eager_steps(case, monkeypatch):
   """recoder_amd/graph.py: groups of steps replayed as HIP graphs (users, stamps, RNG step, Adam
   constants and loss slot derived on the device from a cursor) must reproduce the eagerly
@@ -1152,6 +1153,24 @@ def test_graph_replay_is_bitwise_equal_to_eager_steps(case, monkeypatch):
     mk = lambda: DynamicAutoencoder([32], activation_type="sigmoid", noise_prob=0.0, sparse=True,
                                     is_constrained=True)
     loss, wd = "logistic", 0.0
+  elif case == "stack_dropout":
+    # hidden stack + both dropouts: the entry-by-entry sequencing under the replay context
+    # (rk_replay_t: RNG steps, users, Adam constants and the loss slot from the cursor)
+    mk = lambda: DynamicAutoencoder([48, 24], activation_type="tanh", noise_prob=0.2, dropout_prob=0.3,
+                                    sparse=False)
+    loss, wd = "mse", 1e-5
+  elif case == "stack_logloss_tied":
+    mk = lambda: DynamicAutoencoder([32, 16], activation_type="sigmoid", noise_prob=0.0, sparse=True,
+                                    is_constrained=True)
+    loss, wd = "logloss", 0.0
+  elif case == "mf_sparse":
+    from recoder_amd.nn import MatrixFactorization
+    mk = lambda: MatrixFactorization(24, activation_type="none", sparse=True)
+    loss, wd = "mse", 0.0
+  elif case == "mf_dense_dropout":
+    from recoder_amd.nn import MatrixFactorization
+    mk = lambda: MatrixFactorization(16, activation_type="tanh", dropout_prob=0.25, sparse=False)
+    loss, wd = "logistic", 2e-5
   else:
     mk = lambda: DynamicAutoencoder([32], activation_type="tanh", noise_prob=0.3, sparse=False)
     loss, wd = "logloss", 1e-5
