@@ -211,59 +211,104 @@ __global__ __launch_bounds__(256) void collate_assign_multi_kernel(int all, Mult
 }
 
 // ---- scan (small catalogues): ONE workgroup does count + assign in one launch ----
+// ONE pass: every thread loads its 4 items of EVERY 4096-item round up front (independent 16-byte
+// loads: one round trip instead of one per round -- the five dependent rounds of a 20 k-item
+// catalogue took 33 us), counts them, a wave scan per round, then one exclusive scan over the
+// (round, wave) totals in LDS gives every thread its output offsets.
 __device__ __forceinline__ void collate_scan_small_body(
     const int32_t *__restrict__ mark, int n_items, int32_t stamp, int all,
     int32_t *__restrict__ pos, int32_t *__restrict__ items, int32_t *__restrict__ counts,
     int n_cap, int nnz_cap, rk_cur_t cur) {
-  __shared__ int32_t wsum[16];
-  __shared__ int32_t carry_s;
+  constexpr int R = SMALL_SCAN_MAX / 4096;          // 16 rounds at most
+  __shared__ int32_t wsum[R * 16];                  // [round][wave]: marked items
+  __shared__ int32_t wtot[4];
+  __shared__ int32_t total_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   if (cur.cursor) stamp = rk_cur_stamp(cur);
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < n_items; base += 4096) {
-    const int it0 = base + tid * 4;
-    int32_t f[4];
-    int32_t local = 0;
+  const int rounds = (n_items + 4095) >> 12;
+  int4 m[R];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int it = it0 + k;
-      f[k] = (it < n_items && (all || mark[it] == stamp)) ? 1 : 0;
-      local += f[k];
+  for (int r = 0; r < R; ++r) {
+    const int it0 = r * 4096 + tid * 4;
+    m[r] = make_int4(0, 0, 0, 0);
+    if (r < rounds) {
+      if (it0 + 3 < n_items) {
+        m[r] = *reinterpret_cast<const int4 *>(mark + it0);
+      } else {
+        if (it0 + 0 < n_items) m[r].x = mark[it0 + 0];
+        if (it0 + 1 < n_items) m[r].y = mark[it0 + 1];
+        if (it0 + 2 < n_items) m[r].z = mark[it0 + 2];
+      }
     }
-    int32_t x = local;
+  }
+  uint32_t fl[R];                                   // 4 flag bits per round
+  int32_t incl[R];                                  // inclusive wave scan of the per-thread counts
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int it0 = r * 4096 + tid * 4;
+    uint32_t f = 0;
+    if (r < rounds) {
+      if (it0 + 0 < n_items && (all || m[r].x == stamp)) f |= 1u;
+      if (it0 + 1 < n_items && (all || m[r].y == stamp)) f |= 2u;
+      if (it0 + 2 < n_items && (all || m[r].z == stamp)) f |= 4u;
+      if (it0 + 3 < n_items && (all || m[r].w == stamp)) f |= 8u;
+    }
+    fl[r] = f;
+    int32_t x = __popc(f);
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-      int32_t y = __shfl_up(x, off, 64);
+      const int32_t y = __shfl_up(x, off, 64);
       if (lane >= off) x += y;
     }
-    if (lane == 63) wsum[wid] = x;
-    __syncthreads();
-    int32_t woff = 0;
-    for (int w = 0; w < wid; ++w) woff += wsum[w];
-    const int32_t carry = carry_s;
-    int32_t p = carry + woff + x - local;
+    incl[r] = x;
+    if (lane == 63) wsum[r * 16 + wid] = x;
+  }
+  __syncthreads();
+  // exclusive scan of the R * 16 (round, wave) totals, in item order, by the first 4 waves
+  int32_t v = 0, vin = 0;
+  if (tid < R * 16) {
+    v = (tid >> 4) < rounds ? wsum[tid] : 0;
+    vin = v;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int it = it0 + k;
-      if (it < n_items) {
-        if (f[k]) {
-          if (p < n_cap) { pos[it] = p; items[p] = it; } else { pos[it] = -1; }
-          ++p;
-        } else {
-          pos[it] = -1;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int32_t y = __shfl_up(vin, off, 64);
+      if (lane >= off) vin += y;
+    }
+    if (lane == 63) wtot[wid] = vin;
+  }
+  __syncthreads();
+  if (tid < R * 16) {
+    int32_t before = 0;
+    for (int w = 0; w < wid; ++w) before += wtot[w];
+    wsum[tid] = before + vin - v;                   // exclusive offset of (round, wave)
+    if (tid == R * 16 - 1) total_s = before + vin;
+  }
+  __syncthreads();
+  const int32_t total = total_s;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (r < rounds) {
+      const int it0 = r * 4096 + tid * 4;
+      int32_t p = wsum[r * 16 + wid] + incl[r] - __popc(fl[r]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int it = it0 + k;
+        if (it < n_items) {
+          if ((fl[r] >> k) & 1u) {
+            if (p < n_cap) { pos[it] = p; items[p] = it; } else { pos[it] = -1; }
+            ++p;
+          } else {
+            pos[it] = -1;
+          }
         }
       }
     }
-    __syncthreads();
-    if (tid == 1023) carry_s = carry + woff + x;
-    __syncthreads();
   }
   if (tid == 0) {
-    const int32_t n_b = min(carry_s, n_cap);        // (see collate_assign_kernel)
+    const int32_t n_b = min(total, n_cap);          // (see collate_assign_kernel)
     counts[0] = n_b;
     counts[2] = (n_b + 31) & ~31;
-    counts[5] = carry_s > n_cap ? carry_s : 0;
+    counts[5] = total > n_cap ? total : 0;
   }
 }
 __global__ __launch_bounds__(1024) void collate_scan_small_kernel(

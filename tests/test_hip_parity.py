@@ -695,10 +695,12 @@ def test_dataframe_to_csr_matrix_contract():
   assert m2.shape == m.shape
 
 
-@pytest.mark.parametrize("kind", ["ae", "ae_items", "mf", "mf_sparse"])
+@pytest.mark.parametrize("kind", ["ae", "ae_overlap", "ae_items", "mf", "mf_sparse"])
 def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind):
   """Recoder.train under an initialised torch.distributed group (RCCL, 1 rank):
-  two-phase collation + all-reduced gradients must reproduce the plain run."""
+  two-phase collation + all-reduced gradients must reproduce the plain run.  ae_overlap: the
+  two-group exchange of a multi-rank run (decoder-side gradients on the communication stream while
+  the step stream runs dZ -> encoder backward), forced on although one rank has nothing to hide."""
   import torch.distributed as dist
   from recoder_amd.data import RecommendationDataset
   from recoder_amd.model import Recoder
@@ -706,7 +708,10 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
   # "ae" = users sharded (gradient all-reduce), "ae_items" = items sharded (parallel.ItemParallel)
   monkeypatch.setenv("RK_PARALLEL", "items" if kind == "ae_items" else "users")
   items_mode = kind == "ae_items"
-  kind = "ae" if items_mode else kind
+  overlap = kind == "ae_overlap"
+  if overlap:
+    monkeypatch.setenv("RK_DP_OVERLAP", "1")
+  kind = "ae" if (items_mode or overlap) else kind
   c = STEP_CASES[0][1] if kind == "ae" else dict(kind="mf", embedding_size=32,
                                                  activation_type="tanh", sparse=(kind == "mf_sparse"))
 
@@ -724,7 +729,8 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
   base_l, base_p = run(False)
   monkeypatch.setenv("RK_FORCE_DP", "1")
   monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
-  monkeypatch.setenv("MASTER_PORT", str(29577 + ["ae", "mf", "mf_sparse"].index(kind) + 5 * items_mode))
+  monkeypatch.setenv("MASTER_PORT", str(29577 + ["ae", "mf", "mf_sparse"].index(kind) + 5 * items_mode +
+                                        20 * overlap))
   dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
   try:
     dp_l, dp_p = run(True)
