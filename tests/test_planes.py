@@ -1,0 +1,175 @@
+"""GPU: the pre-split operand planes (csrc/planes.h, csrc/decode16.hip) against the in-loop split
+kernels of csrc/gemm.hip -- the same arithmetic (s.x = hi + lo in fp16, lo.hi + hi.lo + hi.hi in
+fp32, same k order), so with equal tile shapes every output must agree BIT FOR BIT; the 128 x 128
+decode tile only regroups the loss / bias partial sums.  Plus the batched collation against the
+per-block one."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from recoder_amd import _lib
+from recoder_amd._lib import LOSS_BCE, LOSS_MSE, LOSS_NONE, RkBlock, RkPlanes, check, ptr
+from recoder_amd.device import Block, DeviceCSR, current_stream
+from tests.test_hip_parity import synth_csr
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(B, h, n_users, n_items, deg, seed, ratings=False):
+  lib = _lib.load()
+  dev = torch.device("cuda")
+  csr = synth_csr(n_users, n_items, deg, seed=seed, ratings=ratings)
+  dcsr = DeviceCSR(csr)
+  f = dict(dtype=torch.float32, device=dev)
+  g = torch.Generator(device=dev)
+  g.manual_seed(seed)
+  W = torch.randn(n_items, h, generator=g, **f) * 0.07
+  bias = torch.randn(n_items, generator=g, **f) * 0.02
+  users = torch.arange(B, dtype=torch.int64, device=dev)
+  blk = Block(B, int(np.sort(dcsr.degrees)[-B:].sum()), n_items, dev)
+  blk.collate(dcsr, users)
+  Z = torch.tanh(torch.randn(B, h, generator=g, **f))
+  ranges = torch.zeros(128, dtype=torch.int32, device=dev)
+  ranges[64:65].copy_(W.abs().max().reshape(1).view(torch.int32))
+  buf = torch.zeros(lib.rk_planes_bytes(B, h, blk.n_cap) // 4 + 64, **f)
+  pl = RkPlanes()
+  check(lib.rk_planes_layout(ptr(buf), B, h, blk.n_cap, ctypes.byref(pl)))
+  return lib, blk, W, bias, Z, ranges, pl, buf
+
+
+@pytest.mark.parametrize("B,h,n_items,loss", [(500, 200, 3000, LOSS_MSE), (37, 20, 400, LOSS_BCE),
+                                              (1, 8, 97, LOSS_MSE), (130, 64, 900, LOSS_NONE),
+                                              (300, 512, 2000, LOSS_MSE), (64, 36, 333, LOSS_BCE)])
+def test_decode_and_dz_on_planes_equal_the_in_loop_split_bit_for_bit(B, h, n_items, loss):
+  lib, blk, W, bias, Z, ranges, pl, buf = _setup(B, h, max(B, 600), n_items, 14, seed=B + h,
+                                                 ratings=(loss == LOSS_MSE and h == 200))
+  st = current_stream()
+  f = dict(dtype=torch.float32, device=Z.device)
+  n_b, nnz, ld, S = blk.counts_host()
+  npart = lib.rk_loss_partials(B, blk.n_cap)
+  ntile = -(-B // lib.rk_decode_row_tile())
+
+  def decode(planes, tile=0):
+    dO = torch.zeros(B * blk.ld_cap, **f)
+    part = torch.zeros(npart, **f)
+    gbp = torch.zeros(ntile * blk.ld_cap, **f)
+    blk.counts[8:72].zero_()
+    if planes:
+      lib.rk_planes_tile(tile)
+      check(lib.rk_split_w(ptr(W), h, blk.ref, ptr(ranges), ctypes.byref(pl), st))
+      check(lib.rk_split_z(ptr(Z), B, h, ptr(ranges), ctypes.byref(pl), st))
+      check(lib.rk_decode_loss_planes(ctypes.byref(pl), B, blk.ref, 0, ptr(bias), loss, 0.5, 1.0 / B,
+                                      ptr(dO), blk.ld_cap, ptr(part), ptr(gbp), st))
+      lib.rk_planes_tile(0)
+    else:
+      check(lib.rk_decode_loss(ptr(Z), B, h, blk.ref, 0, ptr(W), ptr(bias), loss, 0.5, 1.0 / B, ptr(dO),
+                               blk.ld_cap, ptr(part), ptr(gbp), ptr(ranges), st))
+    ldo = blk.ld_cap if loss == LOSS_NONE else ld
+    return (dO[:B * ldo].view(B, ldo)[:, :n_b].clone(), part.clone(),
+            gbp[:ntile * ld].view(ntile, ld)[:, :n_b].clone(), blk.counts[8:72].clone())
+
+  o = decode(False)
+  n64 = decode(True, 64)
+  n128 = decode(True, 128)
+  assert torch.equal(o[0], n64[0]) and torch.equal(o[0], n128[0])            # logits / dLoss/dLogits
+  if loss != LOSS_NONE:
+    assert torch.equal(o[1], n64[1]) and torch.equal(o[2], n64[2])           # loss and bias partials
+    assert abs(o[1].double().sum().item() - n128[1].double().sum().item()) <= 1e-6 * abs(o[1].double().sum().item())
+    assert torch.allclose(o[2].sum(0), n128[2].sum(0), rtol=1e-5, atol=1e-7)
+    assert o[3].view(torch.float32).max() == n64[3].view(torch.float32).max() == n128[3].view(torch.float32).max()
+    # the padding columns of every dO row are zeros (the dZ contraction's K tail)
+    if ld > n_b:
+      dO = torch.zeros(B * blk.ld_cap, **f).fill_(7.0)
+      part = torch.zeros(npart, **f)
+      check(lib.rk_decode_loss_planes(ctypes.byref(pl), B, blk.ref, 0, ptr(bias), loss, 0.5, 1.0 / B,
+                                      ptr(dO), blk.ld_cap, ptr(part), None, st))
+      assert float(dO[:B * ld].view(B, ld)[:, n_b:].abs().max()) == 0.0
+    # dZ: planes == in-loop split, also with garbage in dO's padding columns (masked in the kernel)
+    dO = torch.zeros(B * blk.ld_cap, **f)
+    part = torch.zeros(npart, **f)
+    blk.counts[8:72].zero_()
+    check(lib.rk_decode_loss(ptr(Z), B, h, blk.ref, 0, ptr(W), ptr(bias), loss, 0.5, 1.0 / B, ptr(dO),
+                             blk.ld_cap, ptr(part), None, ptr(ranges), st))
+    ws = torch.zeros(lib.rk_dz_workspace_bytes(B, h) // 4 + 64, **f)
+    dz0 = torch.zeros(B, h, **f)
+    dz1 = torch.zeros(B, h, **f)
+    check(lib.rk_decode_bwd_dz(ptr(dO), B, h, blk.ref, ptr(W), ptr(Z), 1, ptr(dz0), ptr(ws), ptr(ranges), st))
+    if ld > n_b:
+      dO[:B * ld].view(B, ld)[:, n_b:] = 3.0e30          # would overflow the fp16 split: must be masked
+    ws.zero_()
+    check(lib.rk_decode_bwd_dz_planes(ptr(dO), B, ctypes.byref(pl), blk.ref, ptr(Z), 1, ptr(dz1), ptr(ws), st))
+    assert torch.equal(dz0, dz1)
+    ref = (dO[:B * ld].view(B, ld)[:, :n_b].double() @ W[blk.items[:n_b].long()].double()) * (1 - Z.double() ** 2)
+    assert (dz1.double() - ref).abs().max().item() <= 2e-6 * max(ref.abs().max().item(), 1e-30)
+
+
+def test_plane_images_hold_the_split_operands():
+  """hi + lo of every image entry reproduces s.x to 2^-22 (fp16 pair), the K padding is zero, the W^T
+  image is the transpose of the W image (k-tile major) with zeros behind the live items."""
+  B, h, n_items = 70, 40, 500
+  lib, blk, W, bias, Z, ranges, pl, buf = _setup(B, h, 600, n_items, 12, seed=5)
+  st = current_stream()
+  check(lib.rk_split_w(ptr(W), h, blk.ref, ptr(ranges), ctypes.byref(pl), st))
+  check(lib.rk_split_z(ptr(Z), B, h, ptr(ranges), ctypes.byref(pl), st))
+  torch.cuda.synchronize()
+  n_b = blk.counts_host()[0]
+  KT = -(-h // 32)
+  raw = buf.view(torch.uint8)
+  base = buf.data_ptr()
+  sc = buf[:4].cpu().numpy()
+
+  def image(p, rows, kt):
+    off = p - base
+    x = raw[off:off + rows * kt * 128].view(torch.float16).view(rows, kt, 2, 32).float()
+    return x[:, :, 0, :].reshape(rows, kt * 32), x[:, :, 1, :].reshape(rows, kt * 32)
+  zh, zl = image(pl.z, B, KT)
+  assert torch.allclose((zh + zl)[:, :h] / float(sc[0]), Z, rtol=3e-7, atol=1e-9)
+  assert float((zh + zl)[:, h:].abs().max()) == 0.0
+  wh, wl = image(pl.w, n_b, KT)
+  Wg = W[blk.items[:n_b].long()]
+  assert torch.allclose((wh + wl)[:, :h] / float(sc[1]), Wg, rtol=3e-7, atol=1e-9)
+  Hp = KT * 32
+  nkt = -(-n_b // 32)
+  off = pl.wt - base
+  t = raw[off:off + nkt * Hp * 128].view(torch.float16).view(nkt, Hp, 2, 32).float()
+  wt = (t[:, :, 0, :] + t[:, :, 1, :]).permute(1, 0, 2).reshape(Hp, nkt * 32)      # [j][item]
+  assert torch.allclose(wt[:h, :n_b] / float(sc[1]), Wg.t(), rtol=3e-7, atol=1e-9)
+  assert float(wt[:, n_b:].abs().max()) == 0.0 and float(wt[h:].abs().max()) == 0.0
+
+
+def test_batched_collation_equals_per_block_collation():
+  """rk_collate_at_multi (the G blocks of a group in one set of launches) against rk_collate_at per
+  block: every array of every block bit-equal."""
+  lib = _lib.load()
+  dev = torch.device("cuda")
+  csr = synth_csr(900, 700, 15, seed=3, ratings=True)
+  dcsr = DeviceCSR(csr)
+  S, G = 100, 4
+  order = torch.from_numpy(np.random.RandomState(1).permutation(900).astype(np.int64)).to(dev)
+  cursor = torch.tensor([3, 0], dtype=torch.int64, device=dev)      # step 3 of the epoch
+  st = current_stream()
+  cap = int(np.sort(dcsr.degrees)[-S:].sum())
+  a = [Block(S, cap, 700, dev) for _ in range(G)]
+  b = [Block(S, cap, 700, dev) for _ in range(G)]
+  for g, blk in enumerate(a):
+    blk.c.implicit = 0
+    check(lib.rk_collate_at(ptr(dcsr.indptr), ptr(dcsr.indices), ptr(dcsr.data), ptr(order), S, 1,
+                            ptr(cursor), g, blk.ref, st))
+  arr = (ctypes.POINTER(RkBlock) * G)()
+  for g, blk in enumerate(b):
+    blk.c.implicit = 0
+    arr[g] = ctypes.pointer(blk.c)
+  check(lib.rk_collate_at_multi(ptr(dcsr.indptr), ptr(dcsr.indices), ptr(dcsr.data), ptr(order), S, 1,
+                                ptr(cursor), 0, arr, G, st))
+  torch.cuda.synchronize()
+  for x, y in zip(a, b):
+    n_b, nnz = int(x.counts[0]), int(x.counts[1])
+    assert torch.equal(x.counts[:8], y.counts[:8]) and n_b > 0
+    assert torch.equal(x.items[:n_b], y.items[:n_b]) and torch.equal(x.pos, y.pos)
+    assert torch.equal(x.indptr[:S + 1], y.indptr[:S + 1])
+    assert torch.equal(x.cols[:nnz], y.cols[:nnz]) and torch.equal(x.vals[:nnz], y.vals[:nnz])
+    wr = (n_b + 31) // 32
+    assert torch.equal(x.bits_rc.view(S, -1)[:, :wr], y.bits_rc.view(S, -1)[:, :wr])
+    assert torch.equal(x.bits_cr.view(x.n_cap, -1)[:n_b], y.bits_cr.view(y.n_cap, -1)[:n_b])
