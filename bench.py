@@ -42,6 +42,9 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_MFMA_F32_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
 PEAK_MFMA_16_TF = 2500.0       # v_mfma_f32_32x32x16_{f16,bf16} dense peak (no sparsity)
 GEMM_F32 = os.environ.get("RK_GEMM_PREC", "")[:1].lower() == "f"
+# RK_GEMM_PREC=bf16: the decoder contractions of the one-call step on PLAIN bf16 operands (one product,
+# fp32 accumulate) -- BASELINE configs[1] says "bf16"; a separate data point, never the graded line
+GEMM_BF16 = os.environ.get("RK_GEMM_PREC", "")[:1].lower() == "b"
 # MFMA flops the 16-bit pipe spends per algorithmic flop: decode / dZ multiply fp16 hi+lo pairs
 # (3 products), dW bf16 triples (6 products) -- the ceiling on ALGORITHMIC flops is peak / this
 PRODUCTS = {"rk_decode_loss": 3, "rk_decode_bwd_dz": 3, "rk_decode_bwd_dw": 6, "rk_decode_bwd_dw3": 6}
@@ -150,7 +153,7 @@ def peak_of(entry, bound):
     return PEAK_HBM_GBS
   if GEMM_F32:
     return PEAK_MFMA_F32_TF
-  return PEAK_MFMA_16_TF / PRODUCTS[entry]
+  return PEAK_MFMA_16_TF / (1 if GEMM_BF16 else PRODUCTS[entry])
 
 
 def cpu_baseline(cfg, csr, steps, warmup=4):
@@ -504,8 +507,11 @@ def main():
     if T.get("entries"):
       # per-entry sequencing: {C-ABI entry: (calls, mean ms)} of the last n_sample timed steps
       kernels = []
+      # (the steps that really went through the bracketed calls: with graph replay only the eagerly
+      # sequenced ones behind the sampling mark do; the decode runs exactly once per step)
+      n_sampled = max(1, T["entries"].get("rk_decode_loss", (n_sample, 0.0))[0])
       for e, (calls, ms) in sorted(T["entries"].items(), key=lambda kv: -kv[1][0] * kv[1][1]):
-        per_step = calls / float(n_sample)
+        per_step = calls / float(n_sampled)
         bound, work, unit = entry_work(e, B, h0, n_b, nnz, n_items, cfg)
         if e == "rk_adam_multi":
           # the per-entry sequencing issues the step's updates in launches of <= 6 tensors: the
@@ -521,7 +527,7 @@ def main():
         peak = peak_of(e, bound)
         ach = work / (ms * 1e-3)
         kernels.append(dict(name=e, kernels=KERNELS.get(e, []), avg_us=ms * 1e3, samples=calls,
-                            launches_per_step=per_step, sampled="timed region (last %d steps)" % n_sample,
+                            launches_per_step=per_step, sampled="timed region (%d eagerly sequenced steps)" % n_sampled,
                             bound="mfma" if bound.startswith("mfma") else bound, achieved=ach, peak=peak,
                             unit=unit, frac=ach / peak, ideal_us=work / peak * 1e6))
     if not kernels:
@@ -569,7 +575,9 @@ def main():
       # MFMA, fp32 accumulate.  BASELINE configs[1] says "bf16": plain bf16 operands miss the 1e-5
       # parity bar north_star sets (measured), so they are not used.
       "vs_baseline": None,
-      "dtype": "f32" if GEMM_F32 else "f32 (decoder GEMMs: split 16-bit operands, f32 accumulate)",
+      "dtype": "f32" if GEMM_F32 else
+               ("bf16 operands in the decoder GEMMs (f32 accumulate), f32 elsewhere" if GEMM_BF16 else
+                "f32 (decoder GEMMs: split 16-bit operands, f32 accumulate)"),
       "data": "synthetic",
       "config": {"workload": cfg["workload"], "api": "Recoder.train", "batch_size_per_gpu": B,
                  "global_batch": global_rows,
@@ -583,6 +591,10 @@ def main():
                  "alt_item_parallel": None},
       "roofline": roofline,
     }
+    if GEMM_BF16:
+      out["variant"] = ("RK_GEMM_PREC=bf16: plain bf16 operands -- the dtype BASELINE configs[1] names; a SEPARATE "
+                        "data point that misses the 1e-5 parity bar (see `recall`: product vs the fp32 oracle); "
+                        "the graded line is the default run")
     if same_dev:
       out["INVALID"] = "RK_BENCH_ONE_GPU_GLOO: all ranks share one GPU, gloo collectives (a code-path test)"
     if world == 1 and not multi and not args.no_recall:

@@ -284,6 +284,10 @@ int rk_split_planes_t(const float *X, int32_t rows, int32_t cols, int32_t ld,
 /* != 0: the decoder contractions run on the 16-bit matrix pipe (default); RK_GEMM_PREC=f32 in
  * the environment keeps all of them on the fp32 MFMA */
 int32_t rk_gemm_split16(void);
+/* != 0 (RK_GEMM_PREC=bf16): the *_planes contractions and rk_decode_bwd_dw3 multiply PLAIN bf16
+ * operands (one product, fp32 accumulate) -- BASELINE configs[1]'s dtype as a separate data point;
+ * it does not meet the 1e-5 parity bar and is never the default */
+int32_t rk_gemm_plain_bf16(void);
 /* The fused call writes G_en as rk_encode_bwd_segments(B) partial arrays of n_cap*h floats
  * each (row segments of long item columns; 1 below 513 rows) and gb_en as as many partial
  * vectors of h floats: the gradients are their sums in segment order -- rk_adam_multi

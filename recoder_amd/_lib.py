@@ -157,6 +157,7 @@ SIGNATURES = {
                                         c_uint64, _P, c_int32, _P, _P, _P]),
   "rk_split_planes_t": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
   "rk_gemm_split16": (c_int32, []),
+  "rk_gemm_plain_bf16": (c_int32, []),
   "rk_gemm_probe": (None, [_P]),
   "rk_encode_bwd_segments": (c_int32, [c_int32]),
   "rk_dw_splits": (c_int32, [c_int32]),

@@ -20,6 +20,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // (a first-class vector: HIP's uint4 is a struct)
 
@@ -91,7 +92,8 @@ struct DecP {
 // 4 waves as 2 x 2, wave tile (TM*32) x (TN*32): BM = 64*TM, BN = 64*TN.  BK = 32, two LDS stages,
 // register prefetch of the next k-tile, ONE barrier per k-tile, every LDS read of a tile ahead of
 // its MFMAs (tools/probes/presplit_gemm.hip: 15 us at the C2 shape against 24 for the in-loop split).
-template <int TM, int TN, int EPI, int RD = 3>
+// PLAIN: bf16 images, ONE product (RK_GEMM_PREC=bf16: the separate bf16 data point)
+template <int TM, int TN, int EPI, int RD = 3, bool PLAIN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 void decode_planes_kernel(DecP p) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -210,6 +212,13 @@ void decode_planes_kernel(DecP p) {
         bl[ks][j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q + 64)); \
       }                                                                                 \
     }                                                                                   \
+    if (PLAIN) {                                                                        \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                  \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j)                                \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                        \
+                __builtin_bit_cast(bf16x8, ah[ks][i]), __builtin_bit_cast(bf16x8, bh[ks][j]), acc[i][j], 0, 0, 0); \
+    } else {                                                                            \
     _Pragma("unroll")                                                                   \
     for (int ks = 0; ks < 2; ++ks) {                                                    \
     _Pragma("unroll")                                                                   \
@@ -227,6 +236,7 @@ void decode_planes_kernel(DecP p) {
     _Pragma("unroll")                                                                   \
         for (int j = 0; j < TN; ++j)                                                    \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0); \
+    }                                                                                   \
     }                                                                                   \
     SSTORE((kt + 1) & 1, UN);                                                           \
     __syncthreads();                                                                    \
@@ -417,7 +427,7 @@ struct DzP {
 // RD: k-tiles of register prefetch.  1 by default: next to the dW kernel on the side stream a 3-deep
 // ring gained dZ 0.5 us and cost dW 11 (22 -> 33 us: it waits on the same L2 fetch path, and the
 // Adam sweep waits for dW); 3 where dZ runs alone.
-template <int TN, int RD = 1>
+template <int TN, int RD = 1, bool PLAIN = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 void dz_planes_kernel(DzP p) {
   constexpr int BM = 128, BN = 32 * TN;
@@ -427,7 +437,7 @@ void dz_planes_kernel(DzP p) {
   const int nsplit = gridDim.y;
   const int L = blockIdx.y * gridDim.x + blockIdx.x;
   const int M = p.M, N = p.N, K = p.counts[0], lda = p.counts[2];
-  const float a_scale = rkp::scale_from(p.a_amax, SCALE_DO);
+  const float a_scale = PLAIN ? 1.0f : rkp::scale_from(p.a_amax, SCALE_DO);
   const float b_scale = p.scales[1];
   const int tm = (M + BM - 1) / BM, tn = p.tiles_n;
   const int per_split = tm * tn;
@@ -504,8 +514,13 @@ void dz_planes_kernel(DzP p) {
     f16x8 ah[2], al[2];                                                                             \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                              \
       uint2 h0, l0, h1, l1;                                                                         \
+      if (PLAIN) {                                                                                  \
+        rkp::plain4(make_float4(ac[2 * ks].x, ac[2 * ks].y, ac[2 * ks].z, ac[2 * ks].w), h0, l0);   \
+        rkp::plain4(make_float4(ac[2 * ks + 1].x, ac[2 * ks + 1].y, ac[2 * ks + 1].z, ac[2 * ks + 1].w), h1, l1); \
+      } else {                                                                                      \
       rkp::split4(make_float4(ac[2 * ks].x, ac[2 * ks].y, ac[2 * ks].z, ac[2 * ks].w), a_scale, h0, l0); \
       rkp::split4(make_float4(ac[2 * ks + 1].x, ac[2 * ks + 1].y, ac[2 * ks + 1].z, ac[2 * ks + 1].w), a_scale, h1, l1); \
+      }                                                                                             \
       ah[ks] = __builtin_bit_cast(f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));                       \
       al[ks] = __builtin_bit_cast(f16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));                       \
     }                                                                                               \
@@ -518,12 +533,18 @@ void dz_planes_kernel(DzP p) {
         bh[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q));                     \
         bl[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q + 64));                \
       }                                                                                             \
+      if (PLAIN) {                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                              \
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[ks]),      \
+                                                           __builtin_bit_cast(bf16x8, bh[j]), acc[j], 0, 0, 0); \
+      } else {                                                                                      \
       _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                \
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh[j], acc[j], 0, 0, 0);            \
       _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                \
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl[j], acc[j], 0, 0, 0);            \
       _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                \
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh[j], acc[j], 0, 0, 0);            \
+      }                                                                                             \
     }                                                                                               \
     SSTOREB((kt + 1) & 1, UN);                                                                      \
     __syncthreads();                                                                                \
@@ -580,8 +601,9 @@ __global__ __launch_bounds__(256) void split_w_kernel(rkp::SplitW p) {
 // or the static default; scales[slot] <- the scale used
 __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ X, int rows, int K,
                                                          int ld, const uint32_t *amax, float dflt,
-                                                         char *img, int KT, float *scales, int slot) {
-  const float s = rkp::scale_from(amax, dflt);
+                                                         char *img, int KT, float *scales, int slot,
+                                                         int plain) {
+  const float s = plain ? 1.0f : rkp::scale_from(amax, dflt);
   if (blockIdx.x == 0 && threadIdx.x == 0) scales[slot] = s;
   const int q4 = KT * 8;                          // float4 per image row
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -589,7 +611,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
   const int r = (int)(i / q4), k = (int)(i % q4) * 4;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (k < K) v = *reinterpret_cast<const float4 *>(X + (int64_t)r * ld + k);     // (K % 4 == 0)
-  rkp::store_split4(img + (int64_t)r * KT * rkp::LINE, k, v, s);
+  rkp::store_split4(img + (int64_t)r * KT * rkp::LINE, k, v, s, plain != 0);
 }
 
 inline bool aligned16(const void *q) { return ((uintptr_t)q & 15) == 0; }
@@ -657,6 +679,7 @@ static rkp::SplitW split_w_args(const float *W_de, const rk_block_t *tgt, const 
   s.amax = ranges ? reinterpret_cast<const uint32_t *>(ranges) + 64 : nullptr;
   s.wp = (char *)pl->w; s.wtp = (char *)pl->wt; s.scales = pl->scales;
   s.h = pl->h; s.KT = rkp::kp_of(pl->h) / 32; s.n_ld = pl->n_ld;
+  s.plain = rk_gemm_plain_bf16();
   return s;
 }
 
@@ -683,7 +706,7 @@ extern "C" int rk_split_z(const float *Z, int32_t B, int32_t h, const int32_t *r
   const int KT = rkp::kp_of(h) / 32;
   RK_LAUNCH(split_rows_kernel, dim3(rk_cdiv((int64_t)B * KT * 8, 256)), dim3(256), 0, (hipStream_t)stream_,
             Z, B, h, h, reinterpret_cast<const uint32_t *>(ranges), rkp::SCALE_Z, (char *)pl->z, KT,
-            pl->scales, 0);
+            pl->scales, 0, (int)rk_gemm_plain_bf16());
   RK_CHECK_LAUNCH("split_z");
   return 0;
 }
@@ -720,8 +743,13 @@ extern "C" int rk_decode_loss_planes(const rk_planes_t *pl, int32_t B, const rk_
   const int lds = 2 * (BM + BN) * ROWB;
 #define LAUNCH(TM, EPI)                                                                        \
   do {                                                                                         \
-    if (set_lds(decode_planes_kernel<TM, 2, EPI>, lds)) { rk_set_error("LDS attribute"); return -1; } \
-    RK_LAUNCH((decode_planes_kernel<TM, 2, EPI>), dim3(grid), dim3(256), lds, stream, p);      \
+    if (rk_gemm_plain_bf16()) {                                                                \
+      if (set_lds(decode_planes_kernel<TM, 2, EPI, 3, true>, lds)) { rk_set_error("LDS attribute"); return -1; } \
+      RK_LAUNCH((decode_planes_kernel<TM, 2, EPI, 3, true>), dim3(grid), dim3(256), lds, stream, p); \
+    } else {                                                                                   \
+      if (set_lds(decode_planes_kernel<TM, 2, EPI>, lds)) { rk_set_error("LDS attribute"); return -1; } \
+      RK_LAUNCH((decode_planes_kernel<TM, 2, EPI>), dim3(grid), dim3(256), lds, stream, p);    \
+    }                                                                                          \
   } while (0)
   if (tm == 2) {
     if (loss_kind == RK_LOSS_MSE) LAUNCH(2, EPI_LOSS_MSE);
@@ -769,8 +797,13 @@ extern "C" int rk_decode_bwd_dz_planes(const float *dO, int32_t B, const rk_plan
   const int lds = 2 * 32 * tn * ROWB;
 #define LAUNCH(TN)                                                                             \
   do {                                                                                         \
-    if (set_lds(dz_planes_kernel<TN>, lds)) { rk_set_error("LDS attribute"); return -1; }      \
-    RK_LAUNCH((dz_planes_kernel<TN>), dim3(tiles, splits), dim3(256), lds, stream, p);         \
+    if (rk_gemm_plain_bf16()) {                                                                \
+      if (set_lds(dz_planes_kernel<TN, 1, true>, lds)) { rk_set_error("LDS attribute"); return -1; } \
+      RK_LAUNCH((dz_planes_kernel<TN, 1, true>), dim3(tiles, splits), dim3(256), lds, stream, p); \
+    } else {                                                                                   \
+      if (set_lds(dz_planes_kernel<TN>, lds)) { rk_set_error("LDS attribute"); return -1; }    \
+      RK_LAUNCH((dz_planes_kernel<TN>), dim3(tiles, splits), dim3(256), lds, stream, p);       \
+    }                                                                                          \
   } while (0)
   if (tn == 2) LAUNCH(2); else if (tn == 4) LAUNCH(4); else if (tn == 7) LAUNCH(7); else LAUNCH(8);
 #undef LAUNCH

@@ -78,6 +78,7 @@ struct Dw3P {
   float *slabs;               // [max_splits][slab_stride]
   int64_t slab_stride;        // floats
   unsigned long long *probe;  // tuning probe (null in production): 16 wall-clock stamps per workgroup
+  int plain;                  // != 0 (RK_GEMM_PREC=bf16): only the hi . hi product -- plain bf16 operands
 };
 
 unsigned long long *g_dw3_probe = nullptr;
@@ -118,7 +119,10 @@ namespace {
 //     enters the CU once.  (An LDS-DMA ring for B measured ~33 GB/s per CU whatever its depth.)
 //   One barrier per 32-deep stage: MFMAs of stage s, conversion of stage s+1 and the raw store of
 //   stage s+2 touch three different buffers.
-template <int BN>
+// PLAIN (RK_GEMM_PREC=bf16): only the hi . hi product.  A template parameter, not a run-time branch: a
+// uniform `if (p.plain)` in front of the six products cost the default kernel 10 us (22 -> 33: the
+// MFMA / load interleave the scheduling barriers pin was gone).
+template <int BN, bool PLAIN = false>
 __global__ __launch_bounds__(512) void dw3_kernel(Dw3P p) {
   constexpr int BM = 64, R = 4, P = R - 1;              // B: k-steps of 16, P of them prefetched
   constexpr int BKA = 32;                               // A: LDS stages of two k-steps
@@ -215,6 +219,11 @@ __global__ __launch_bounds__(512) void dw3_kernel(Dw3P p) {
     }
     // small terms first; the accumulators alternate so that no MFMA waits on the one before it
     // (an instruction slipping between two MFMAs on the SAME accumulator costs ~40 cycles)
+    if (PLAIN) {
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[t], Bh, acc[t], 0, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al[t], Bh, acc[t], 0, 0, 0);
 #pragma unroll
@@ -367,12 +376,18 @@ extern "C" int rk_decode_bwd_dw3(const float *dO, const float *Z, int32_t B, int
   p.G = G_de; p.slabs = (float *)((char *)workspace + planes_b);
   p.slab_stride = (int64_t)tgt->n_cap * h;
   p.probe = g_dw3_probe;
+  p.plain = rk_gemm_plain_bf16();
   const int tiles_cap = rk_cdiv(tgt->n_cap, 64) * p.tiles_n;
   p.wg_slots = 256;       // one 8-wave workgroup per CU is what the split-K sizing aims at
   // the live workgroups are the first tiles_m(n_t) * tiles_n * ns of the grid; ns * tiles never
   // exceeds max(wg_slots, tiles), so the capacity grid is bounded by that
   const int64_t grid = std::max<int64_t>((int64_t)tiles_cap, std::min<int64_t>((int64_t)tiles_cap * DW3_MAX_SPLITS, p.wg_slots));
-  if (bn == 128)
+  if (p.plain) {
+    if (bn == 128)
+      RK_LAUNCH((dw3_kernel<128, true>), dim3((unsigned)grid), dim3(512), 0, stream, p);
+    else
+      RK_LAUNCH((dw3_kernel<256, true>), dim3((unsigned)grid), dim3(512), 0, stream, p);
+  } else if (bn == 128)
     RK_LAUNCH((dw3_kernel<128>), dim3((unsigned)grid), dim3(512), 0, stream, p);
   else
     RK_LAUNCH((dw3_kernel<256>), dim3((unsigned)grid), dim3(512), 0, stream, p);

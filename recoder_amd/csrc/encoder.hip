@@ -179,8 +179,9 @@ __global__ __launch_bounds__(FW * 64) void ae_encode_fwd_kernel(
         // Z as fp16 hi / lo plane image for the decode (planes.h), with the value still in registers
         // (bounded activations only: their split scale is static)
         if (zimg) {
-          rkp::store_split4(zimg + (int64_t)r * z_kt * rkp::LINE, hh, y, rkp::SCALE_Z);
-          if (r == 0 && tid == 0) sw.scales[0] = rkp::SCALE_Z;     // (consumers read the scale from there)
+          const float sz = sw.plain ? 1.0f : rkp::SCALE_Z;
+          rkp::store_split4(zimg + (int64_t)r * z_kt * rkp::LINE, hh, y, sz, sw.plain != 0);
+          if (r == 0 && tid == 0) sw.scales[0] = sz;     // (consumers read the scale from there)
         }
         if (planes) {
           // Z^T as three bf16 planes in the fragment order of the dW kernel (csrc/dw3.hip):

@@ -61,10 +61,19 @@ __device__ __forceinline__ float scale_from(const uint32_t *slots, float dflt) {
   return __uint_as_float((uint32_t)(13 - e + 127) << 23);
 }
 
+// plain bf16 operands (RK_GEMM_PREC=bf16): hi = bf16(x), no scale, lo unused (zero)
+__device__ __forceinline__ void plain4(const float4 v, uint2 &hi, uint2 &lo) {
+  uint32_t m, l;
+  rk_split_bf16_pair(v.x, v.y, hi.x, m, l);
+  rk_split_bf16_pair(v.z, v.w, hi.y, m, l);
+  lo = make_uint2(0u, 0u);
+}
+
 // store the split of 4 consecutive k (k % 4 == 0) of one image row
-__device__ __forceinline__ void store_split4(char *row_base, int k, const float4 v, const float s) {
+__device__ __forceinline__ void store_split4(char *row_base, int k, const float4 v, const float s,
+                                             const bool plain = false) {
   uint2 hi, lo;
-  split4(v, s, hi, lo);
+  if (plain) plain4(v, hi, lo); else split4(v, s, hi, lo);
   char *d = row_base + (k >> 5) * LINE + (k & 31) * 2;
   *reinterpret_cast<uint2 *>(d) = hi;
   *reinterpret_cast<uint2 *>(d + 64) = lo;
@@ -80,6 +89,7 @@ struct SplitW {
   float *scales;             // [1] <- the scale used
   int h, KT;                 // KT = kp_of(h) / 32
   int n_ld;                  // items padded (multiple of 32): row pitch of the W^T image = n_ld / 32 lines
+  int plain;                 // != 0: plain bf16 images (RK_GEMM_PREC=bf16), scale 1
 };
 
 // One workgroup (NT threads, NT = 256 or 512) splits the 32 gathered rows of item tile `tile`:
@@ -91,7 +101,7 @@ __device__ __forceinline__ void split_w_job(const SplitW &p, const int tile, cha
   const int n_b = p.counts[0];
   const int k0 = tile * 32;
   if (k0 >= n_b) return;
-  const float s = scale_from(p.amax, SCALE_W);
+  const float s = p.plain ? 1.0f : scale_from(p.amax, SCALE_W);
   if (tile == 0 && threadIdx.x == 0) p.scales[1] = s;
   const int tid = threadIdx.x;
   const int Kp = p.KT * 32;
@@ -105,7 +115,7 @@ __device__ __forceinline__ void split_w_job(const SplitW &p, const int tile, cha
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c < n_b && j < p.h) v = *reinterpret_cast<const float4 *>(p.W + (int64_t)p.items[c] * p.h + j);
       uint2 hi, lo;
-      split4(v, s, hi, lo);
+      if (p.plain) plain4(v, hi, lo); else split4(v, s, hi, lo);
       if (c < n_b && j < Kp) {
         char *d = p.wp + (int64_t)c * p.KT * LINE + (j >> 5) * LINE + (j & 31) * 2;
         *reinterpret_cast<uint2 *>(d) = hi;

@@ -173,3 +173,18 @@ def test_batched_collation_equals_per_block_collation():
     wr = (n_b + 31) // 32
     assert torch.equal(x.bits_rc.view(S, -1)[:, :wr], y.bits_rc.view(S, -1)[:, :wr])
     assert torch.equal(x.bits_cr.view(x.n_cap, -1)[:n_b], y.bits_cr.view(y.n_cap, -1)[:n_b])
+
+
+def test_device_csr_from_arrays_rejects_inconsistent_indptr():
+  """a malformed CSR (indptr decreasing, or pointing past the index array) must be
+  refused before the collation kernels index through it."""
+  dev = torch.device("cuda")
+  indptr = np.array([0, 2, 4, 6], dtype=np.int64)
+  indices = np.array([0, 1, 0, 2, 1, 3], dtype=np.int32)
+  DeviceCSR.from_arrays((3, 4), indptr, indices, None, dev)          # well formed
+  with pytest.raises(ValueError, match="non-decreasing"):
+    DeviceCSR.from_arrays((3, 4), np.array([0, 4, 2, 6], dtype=np.int64), indices, None, dev)
+  with pytest.raises(ValueError, match="exceeds"):
+    DeviceCSR.from_arrays((3, 4), np.array([0, 2, 4, 9], dtype=np.int64), indices, None, dev)
+  with pytest.raises(ValueError, match="exceeds"):
+    DeviceCSR.from_arrays((3, 4), indptr, indices, np.ones(4, dtype=np.float32), dev)
