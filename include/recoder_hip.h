@@ -263,6 +263,21 @@ int rk_decode_bwd_dw3(const float *dO, const float *Z, int32_t B, int32_t h,
                       const rk_block_t *tgt, float *G_de, float *gb_de, void *workspace,
                       const void *zt_planes /* nullable: made from Z into workspace */,
                       void *stream);
+/*
+ * rk_decode_bwd_dw2 -- the same contraction with the operands cut into fp16 PAIRS (s.x = hi + lo,
+ * three products lo.hi + hi.lo + hi.hi on v_mfma_f32_32x32x16_f16: half the MFMAs of the bf16
+ * triples, two planes instead of three) -- the arithmetic of rk_decode_loss / rk_decode_bwd_dz.
+ * Power-of-two scales from published maxima: dO from tgt->counts[8..71] (the loss kernels), Z from
+ * ranges[0..63] (rk_amax notes) when the planes are made here; a caller-provided zt_planes holds
+ * pairs written with the static scale (rk_ae_train_step: bounded activations).  Workspace and
+ * slab conventions as rk_decode_bwd_dw3.  rk_dw_pairs() != 0: the training step uses this entry
+ * (default; RK_DW_PREC=bf16x3 keeps the triples).
+ */
+int rk_decode_bwd_dw2(const float *dO, const float *Z, int32_t B, int32_t h,
+                      const rk_block_t *tgt, float *G_de, float *gb_de, void *workspace,
+                      const void *zt_planes /* nullable */, const int32_t *ranges /* nullable */,
+                      void *stream);
+int32_t rk_dw_pairs(void);
 /* The Z^T planes of rk_decode_bwd_dw3 can be written by the kernel that produces Z:
  * rk_ae_encode_fwd_planes = rk_ae_encode_fwd + the three bf16 planes of its output, into a
  * buffer of rk_dw3_planes_bytes(B, h) bytes that the caller allocated ZEROED (16-byte aligned;

@@ -150,6 +150,8 @@ SIGNATURES = {
   "rk_dw3_probe": (None, [_P]),
   "rk_dw3_slabs": (c_void_p, [_P, c_int32, c_int32]),
   "rk_decode_bwd_dw3": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, _P, _P]),
+  "rk_decode_bwd_dw2": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, _P, _P, _P]),
+  "rk_dw_pairs": (c_int32, []),
   "rk_dw3_planes_bytes": (c_int64, [c_int32, c_int32]),
   "rk_dw3_rows_pad": (c_int32, [c_int32]),
   "rk_dw3_cols_pad": (c_int32, [c_int32]),

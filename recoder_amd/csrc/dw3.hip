@@ -22,13 +22,17 @@
 //     all-padding columns.
 //   * split-K sized ON THE DEVICE from the live item count (counts[0]); the slabs are consumed by
 //     rk_adam_multi (g_parts read from counts[4]) or summed by slab_sum3.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "common.h"
+#include "planes.h"
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -39,9 +43,15 @@ __device__ __forceinline__ void split_pair(float a, float b, uint32_t &h, uint32
 // X[rows, cols] fp32 (row-major, ld) -> bf16 planes [3][rows_pad/8][cols_pad][8] of X^T's
 // k-contiguous image: element (k = row, n = col) of plane p sits at ((k/8)*cols_pad + n)*8 + k%8.
 // Rows >= rows and columns >= cols are written as zeros (the GEMM relies on it).
+// pairs != 0: TWO fp16 planes hi / lo of s.x (s from `amax`: 64 slots, nullable -> the static scale of
+// planes.h; *scale_out <- s) instead of three bf16 ones
 __global__ __launch_bounds__(256) void split_planes_t_kernel(const float *__restrict__ X, int rows,
                                                              int cols, int ld, int rows_pad,
-                                                             int cols_pad, uint16_t *__restrict__ P) {
+                                                             int cols_pad, uint16_t *__restrict__ P,
+                                                             int pairs, const uint32_t *amax,
+                                                             float *scale_out) {
+  const float s = pairs ? rkp::scale_from(amax, rkp::SCALE_Z) : 1.0f;
+  if (pairs && scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (chunk, n)
   const int64_t tot = (int64_t)(rows_pad >> 3) * cols_pad;
   if (i >= tot) return;
@@ -52,13 +62,21 @@ __global__ __launch_bounds__(256) void split_planes_t_kernel(const float *__rest
     const int r = c8 * 8 + j;
     x[j] = (r < rows && n < cols) ? X[(int64_t)r * ld + n] : 0.f;
   }
+  const int64_t plane = (int64_t)rows_pad * cols_pad;               // 16-bit elements
+  uint16_t *d = P + i * 8;
+  if (pairs) {
+    uint2 h0, l0, h1, l1;
+    rkp::split4(make_float4(x[0], x[1], x[2], x[3]), s, h0, l0);
+    rkp::split4(make_float4(x[4], x[5], x[6], x[7]), s, h1, l1);
+    *reinterpret_cast<uint4 *>(d) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    *reinterpret_cast<uint4 *>(d + plane) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    return;
+  }
   uint4 h, m, l;
   split_pair(x[0], x[1], h.x, m.x, l.x);
   split_pair(x[2], x[3], h.y, m.y, l.y);
   split_pair(x[4], x[5], h.z, m.z, l.z);
   split_pair(x[6], x[7], h.w, m.w, l.w);
-  const int64_t plane = (int64_t)rows_pad * cols_pad;               // bf16 elements
-  uint16_t *d = P + i * 8;
   *reinterpret_cast<uint4 *>(d) = h;
   *reinterpret_cast<uint4 *>(d + plane) = m;
   *reinterpret_cast<uint4 *>(d + 2 * plane) = l;
@@ -79,6 +97,10 @@ struct Dw3P {
   int64_t slab_stride;        // floats
   unsigned long long *probe;  // tuning probe (null in production): 16 wall-clock stamps per workgroup
   int plain;                  // != 0 (RK_GEMM_PREC=bf16): only the hi . hi product -- plain bf16 operands
+  // fp16-pair mode (rk_decode_bwd_dw2): power-of-two split scales
+  const uint32_t *a_amax;     // 64 slots: running max |dO| (counts + 8)
+  const float *z_scale_dev;   // scale the Z^T planes were written with (device), or null:
+  float z_scale;              //   this host value
 };
 
 unsigned long long *g_dw3_probe = nullptr;
@@ -122,18 +144,26 @@ namespace {
 // PLAIN (RK_GEMM_PREC=bf16): only the hi . hi product.  A template parameter, not a run-time branch: a
 // uniform `if (p.plain)` in front of the six products cost the default kernel 10 us (22 -> 33: the
 // MFMA / load interleave the scheduling barriers pin was gone).
-template <int BN, bool PLAIN = false>
+// PAIRS (rk_decode_bwd_dw2, the default of the training step since round 3): the operands are cut into
+// fp16 PAIRS s.x = hi + lo like the decode / dZ contractions (scales: dO from the maximum the loss
+// kernels publish, Z static or from rk_amax) and THREE products lo.hi + hi.lo + hi.hi are accumulated
+// on v_mfma_f32_32x32x16_f16 instead of six bf16 ones: half the MFMAs, two planes instead of three
+// to fetch and to convert.
+template <int BN, bool PLAIN = false, bool PAIRS = false>
 __global__ __launch_bounds__(512) void dw3_kernel(Dw3P p) {
   constexpr int BM = 64, R = 4, P = R - 1;              // B: k-steps of 16, P of them prefetched
   constexpr int BKA = 32;                               // A: LDS stages of two k-steps
   constexpr int WN = BN / 32, WM = 8 / WN, MT = 2 / WM;
   constexpr int RAW_F = BKA * BM;                       // floats per raw stage
-  constexpr int FRAG_B = 4 * 3 * 64 * 16;               // bytes per fragment stage: 4 jobs x 3 planes
+  constexpr int NP = PAIRS ? 2 : 3;                     // planes
+  constexpr int FRAG_B = 4 * NP * 64 * 16;              // bytes per fragment stage: 4 jobs x NP planes
   __shared__ __attribute__((aligned(16))) char smem[2 * RAW_F * 4 + 2 * FRAG_B];
   float *raw = reinterpret_cast<float *>(smem);
   char *frag = smem + 2 * RAW_F * 4;
 
   const int n_t = p.counts[0], ld = p.counts[2];
+  const float a_scale = PAIRS ? rkp::scale_from(p.a_amax, 1024.0f) : 1.0f;
+  const float z_scale = PAIRS ? (p.z_scale_dev ? *p.z_scale_dev : p.z_scale) : 1.0f;
   int kc;
   const int ns = dw3_splits(n_t, p.tiles_n, p.Bp, p.max_splits, p.wg_slots, &kc);
   const int L = blockIdx.x;
@@ -182,13 +212,20 @@ __global__ __launch_bounds__(512) void dw3_kernel(Dw3P p) {
   auto convert = [&](int buf) {
     const float *r = raw + buf * RAW_F + (((cj & 1) * 16 + lh * 8 + chf * 4) * BM + (cj >> 1) * 32 + l31);
     const float x0 = r[0], x1 = r[BM], x2 = r[2 * BM], x3 = r[3 * BM];
-    uint2 h, m, l;
-    split_pair(x0, x1, h.x, m.x, l.x);
-    split_pair(x2, x3, h.y, m.y, l.y);
-    char *d = frag + buf * FRAG_B + (cj * 3 * 64 + lane) * 16 + chf * 8;
-    *reinterpret_cast<uint2 *>(d) = h;
-    *reinterpret_cast<uint2 *>(d + 64 * 16) = m;
-    *reinterpret_cast<uint2 *>(d + 2 * 64 * 16) = l;
+    char *d = frag + buf * FRAG_B + (cj * NP * 64 + lane) * 16 + chf * 8;
+    if (PAIRS) {
+      uint2 h, l;
+      rkp::split4(make_float4(x0, x1, x2, x3), a_scale, h, l);
+      *reinterpret_cast<uint2 *>(d) = h;
+      *reinterpret_cast<uint2 *>(d + 64 * 16) = l;
+    } else {
+      uint2 h, m, l;
+      split_pair(x0, x1, h.x, m.x, l.x);
+      split_pair(x2, x3, h.y, m.y, l.y);
+      *reinterpret_cast<uint2 *>(d) = h;
+      *reinterpret_cast<uint2 *>(d + 64 * 16) = m;
+      *reinterpret_cast<uint2 *>(d + 2 * 64 * 16) = l;
+    }
   };
   // B fragments: plane pl, k-step kt -> 8 k-values (chunk 2*kt + lh) of column n0 + wn*32 + l31
   const int nk = 2 * na;
@@ -197,25 +234,43 @@ __global__ __launch_bounds__(512) void dw3_kernel(Dw3P p) {
   // (a wave whose 32 columns all lie past h -- h = 200: the last of the eight -- neither loads
   // nor multiplies: the fetch rate is what bounds the kernel)
   const bool wave_live = n0 + wn * 32 < p.h;
-  auto loadB = [&](uint4 (&dst)[3], int kt) {
+  auto loadB = [&](uint4 (&dst)[NP], int kt) {
     const uint16_t *q = b_src + (int64_t)(2 * stage_of(kt >> 1) + (kt & 1)) * b_step;
     if (wave_live) {
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) dst[pl] = *reinterpret_cast<const uint4 *>(q + pl * p.plane_stride);
+      for (int pl = 0; pl < NP; ++pl) dst[pl] = *reinterpret_cast<const uint4 *>(q + pl * p.plane_stride);
     }
   };
 
-  auto compute = [&](int buf, int ks, const uint4 (&b)[3]) {
-    const bf16x8 Bh = __builtin_bit_cast(bf16x8, b[0]), Bm = __builtin_bit_cast(bf16x8, b[1]),
-                 Bl = __builtin_bit_cast(bf16x8, b[2]);
+  auto compute = [&](int buf, int ks, const uint4 (&b)[NP]) {
     if (!wave_live) return;
+    if (PAIRS) {
+      const f16x8 Bh = __builtin_bit_cast(f16x8, b[0]), Bl = __builtin_bit_cast(f16x8, b[1]);
+      f16x8 Ah[MT], Al[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const char *q = frag + buf * FRAG_B + ((((wm * MT + t) * 2 + ks) * NP) * 64 + lane) * 16;
+        Ah[t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q));
+        Al[t] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q + 64 * 16));
+      }
+      // small terms first, as the decode / dZ contractions
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[t], Bh, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[t], Bl, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[t], Bh, acc[t], 0, 0, 0);
+      return;
+    }
+    const bf16x8 Bh = __builtin_bit_cast(bf16x8, b[0]), Bm = __builtin_bit_cast(bf16x8, b[1]),
+                 Bl = __builtin_bit_cast(bf16x8, b[NP - 1]);
     bf16x8 Ah[MT], Am[MT], Al[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-      const char *q = frag + buf * FRAG_B + ((((wm * MT + t) * 2 + ks) * 3) * 64 + lane) * 16;
+      const char *q = frag + buf * FRAG_B + ((((wm * MT + t) * 2 + ks) * NP) * 64 + lane) * 16;
       Ah[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(q));
       Am[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(q + 64 * 16));
-      Al[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(q + 2 * 64 * 16));
+      Al[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(q + (NP - 1) * 64 * 16));
     }
     // small terms first; the accumulators alternate so that no MFMA waits on the one before it
     // (an instruction slipping between two MFMAs on the SAME accumulator costs ~40 cycles)
@@ -238,7 +293,7 @@ __global__ __launch_bounds__(512) void dw3_kernel(Dw3P p) {
     for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah[t], Bh, acc[t], 0, 0, 0);
   };
 
-  uint4 breg[R][3];
+  uint4 breg[R][NP];
   if (na > 0) {
 #pragma unroll
     for (int r = 0; r < P; ++r) loadB(breg[r], r);
@@ -277,12 +332,13 @@ __global__ __launch_bounds__(512) void dw3_kernel(Dw3P p) {
   // ---- epilogue: a lane holds 16 items (rows) of ONE column; 32 lanes = 128 contiguous bytes ----
   float *C = (ns == 1 && p.G) ? p.G : p.slabs + (int64_t)split * p.slab_stride;
   const int n = n0 + wn * 32 + l31;
+  const float inv = PAIRS ? 1.0f / (a_scale * z_scale) : 1.0f;       // exact: powers of two
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int item = m0 + (wm * MT + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (item < n_t && n < p.h) C[(int64_t)item * p.h + n] = acc[t][r];
+      if (item < n_t && n < p.h) C[(int64_t)item * p.h + n] = PAIRS ? acc[t][r] * inv : acc[t][r];
     }
   }
   if (probing) {
@@ -331,15 +387,25 @@ extern "C" int32_t rk_dw3_max_splits(void) { return DW3_MAX_SPLITS; }
 
 extern "C" void rk_dw3_probe(unsigned long long *buffer) { g_dw3_probe = buffer; }
 
+static int split_planes_t_launch(const float *X, int32_t rows, int32_t cols, int32_t ld, int32_t rows_pad,
+                                 int32_t cols_pad, void *planes, int pairs, const uint32_t *amax,
+                                 float *scale_out, void *stream_);
+
 extern "C" int rk_split_planes_t(const float *X, int32_t rows, int32_t cols, int32_t ld,
                                  int32_t rows_pad, int32_t cols_pad, void *planes, void *stream_) {
+  return split_planes_t_launch(X, rows, cols, ld, rows_pad, cols_pad, planes, 0, nullptr, nullptr, stream_);
+}
+
+static int split_planes_t_launch(const float *X, int32_t rows, int32_t cols, int32_t ld, int32_t rows_pad,
+                                 int32_t cols_pad, void *planes, int pairs, const uint32_t *amax,
+                                 float *scale_out, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(rows_pad % 8 == 0 && rows_pad >= rows && cols_pad >= cols, "bad padding");
   RK_REQUIRE((((uintptr_t)planes) & 15) == 0, "planes must be 16-byte aligned");
   const int64_t tot = (int64_t)(rows_pad >> 3) * cols_pad;
   if (tot == 0) return 0;
   RK_LAUNCH(split_planes_t_kernel, dim3(rk_cdiv(tot, 256)), dim3(256), 0, stream, X, rows, cols, ld,
-            rows_pad, cols_pad, (uint16_t *)planes);
+            rows_pad, cols_pad, (uint16_t *)planes, pairs, amax, scale_out);
   RK_CHECK_LAUNCH("split_planes_t");
   return 0;
 }
@@ -349,9 +415,9 @@ extern "C" int64_t rk_dw3_planes_bytes(int32_t B, int32_t h) { return dw3_plane_
 extern "C" int32_t rk_dw3_cols_pad(int32_t h) { return dw3_cols_pad(h); }
 extern "C" int32_t rk_dw3_rows_pad(int32_t B) { return dw3_rows_pad(B); }
 
-extern "C" int rk_decode_bwd_dw3(const float *dO, const float *Z, int32_t B, int32_t h,
-                                 const rk_block_t *tgt, float *G_de, float *gb_de, void *workspace,
-                                 const void *zt_planes, void *stream_) {
+static int dw_impl(const float *dO, const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
+                   float *G_de, float *gb_de, void *workspace, const void *zt_planes, bool pairs,
+                   const int32_t *ranges, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(h > 0 && h % 4 == 0, "h must be a multiple of 4");
   RK_REQUIRE(workspace != nullptr && (((uintptr_t)workspace) & 255) == 0, "workspace: 256-byte aligned");
@@ -360,15 +426,23 @@ extern "C" int rk_decode_bwd_dw3(const float *dO, const float *Z, int32_t B, int
   const int bn = dw3_bn(h);
   const int cols_pad = dw3_cols_pad(h), Bp = dw3_rows_pad(B);
   const int64_t planes_b = (dw3_plane_bytes(B, h) + 255) & ~(int64_t)255;
-  // Z^T planes: the caller's (rk_ae_encode_fwd_planes wrote them with Z) or made here
+  if (rk_gemm_plain_bf16()) pairs = false;       // (the plain-bf16 data point rides on the bf16 planes)
+  Dw3P p = {};
+  // Z^T planes: the caller's (the encoder forward wrote them with Z) or made here.  Pairs made here:
+  // the scale from ranges[0..63] (a bound of |Z|; all zero / NULL: the static one), kept in the
+  // unused third plane's space for the kernel
+  p.z_scale = rkp::SCALE_Z;
   if (zt_planes == nullptr) {
     RK_REQUIRE(Z != nullptr, "Z or zt_planes");
-    int rc = rk_split_planes_t(Z, B, h, h, Bp, cols_pad, workspace, stream_);
+    float *sc = pairs ? reinterpret_cast<float *>((char *)workspace + (int64_t)2 * Bp * cols_pad * 2) : nullptr;
+    int rc = split_planes_t_launch(Z, B, h, h, Bp, cols_pad, workspace, pairs ? 1 : 0,
+                                   reinterpret_cast<const uint32_t *>(ranges), sc, stream_);
     if (rc) return rc;
     zt_planes = workspace;
+    p.z_scale_dev = sc;
   }
   RK_REQUIRE((((uintptr_t)zt_planes) & 15) == 0, "zt_planes must be 16-byte aligned");
-  Dw3P p = {};
+  p.a_amax = reinterpret_cast<const uint32_t *>(tgt->counts) + 8;
   p.dO = dO; p.counts = tgt->counts;
   p.planes = (const uint16_t *)zt_planes; p.plane_stride = (int64_t)Bp * cols_pad;
   p.cols_pad = cols_pad; p.B = B; p.Bp = Bp; p.h = h;
@@ -382,7 +456,12 @@ extern "C" int rk_decode_bwd_dw3(const float *dO, const float *Z, int32_t B, int
   // the live workgroups are the first tiles_m(n_t) * tiles_n * ns of the grid; ns * tiles never
   // exceeds max(wg_slots, tiles), so the capacity grid is bounded by that
   const int64_t grid = std::max<int64_t>((int64_t)tiles_cap, std::min<int64_t>((int64_t)tiles_cap * DW3_MAX_SPLITS, p.wg_slots));
-  if (p.plain) {
+  if (pairs) {
+    if (bn == 128)
+      RK_LAUNCH((dw3_kernel<128, false, true>), dim3((unsigned)grid), dim3(512), 0, stream, p);
+    else
+      RK_LAUNCH((dw3_kernel<256, false, true>), dim3((unsigned)grid), dim3(512), 0, stream, p);
+  } else if (p.plain) {
     if (bn == 128)
       RK_LAUNCH((dw3_kernel<128, true>), dim3((unsigned)grid), dim3(512), 0, stream, p);
     else
@@ -400,6 +479,31 @@ extern "C" int rk_decode_bwd_dw3(const float *dO, const float *Z, int32_t B, int
   }
   if (gb_de) return rk_colsum(dO, B, tgt->n_cap, 0, tgt->counts, gb_de, stream_);
   return 0;
+}
+
+extern "C" int rk_decode_bwd_dw3(const float *dO, const float *Z, int32_t B, int32_t h,
+                                 const rk_block_t *tgt, float *G_de, float *gb_de, void *workspace,
+                                 const void *zt_planes, void *stream_) {
+  return dw_impl(dO, Z, B, h, tgt, G_de, gb_de, workspace, zt_planes, false, nullptr, stream_);
+}
+
+// The same contraction with fp16 PAIRS (three products): see dw3_kernel.  dO's split scale comes from
+// the maximum the loss kernels publish in tgt->counts[8..71] (as rk_decode_bwd_dz), Z's from
+// ranges[0..63] when the planes are made here (zt_planes == NULL), else the static one the encoder
+// forward wrote them with (bounded activations only: rk_dw_pairs_planes_ok).
+extern "C" int rk_decode_bwd_dw2(const float *dO, const float *Z, int32_t B, int32_t h,
+                                 const rk_block_t *tgt, float *G_de, float *gb_de, void *workspace,
+                                 const void *zt_planes, const int32_t *ranges, void *stream_) {
+  return dw_impl(dO, Z, B, h, tgt, G_de, gb_de, workspace, zt_planes, true, ranges, stream_);
+}
+
+// RK_DW_PREC=bf16x3 keeps dW on the bf16 triples (no operand range at all) in the training step
+extern "C" int32_t rk_dw_pairs(void) {
+  static const int v = [] {
+    const char *e = getenv("RK_DW_PREC");
+    return (e && e[0] == 'b') ? 0 : 1;
+  }();
+  return (v && !rk_gemm_plain_bf16()) ? 1 : 0;
 }
 
 extern "C" const float *rk_dw3_slabs(const void *workspace, int32_t B, int32_t h) {

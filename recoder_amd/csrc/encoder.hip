@@ -27,7 +27,8 @@ __global__ __launch_bounds__(FW * 64) void ae_encode_fwd_kernel(
     int h, const uint8_t *__restrict__ keep, float p, float scale, uint64_t seed,
     uint64_t rng_step, const int64_t *__restrict__ users, const float *__restrict__ user_norm,
     int act, float *__restrict__ Z0, uint16_t *__restrict__ planes, int64_t plane_stride,
-    int cols_pad, rk_cur_t cur, rkp::SplitW sw, int n_split, char *__restrict__ zimg, int z_kt) {
+    int cols_pad, rk_cur_t cur, rkp::SplitW sw, int n_split, char *__restrict__ zimg, int z_kt,
+    int zt_pairs) {
   __shared__ float red[FW];
   constexpr int PART_B = (FW - 1) * HV * 256 * 4;
   __shared__ __attribute__((aligned(16))) char sm_raw[PART_B > rkp::SPLIT_W_LDS ? PART_B : rkp::SPLIT_W_LDS];
@@ -188,8 +189,15 @@ __global__ __launch_bounds__(FW * 64) void ae_encode_fwd_kernel(
           // element (k = r, n) at ((k/8)*cols_pad + n)*8 + k%8 -- written here, with the value
           // still in registers, instead of by a pass of its own
           uint32_t hp[2], mp[2], lp[2];
+          if (zt_pairs) {
+            // fp16 pairs for rk_decode_bwd_dw2 (static scale: bounded activations): planes 0 / 1
+            uint2 hh2, ll2;
+            rkp::split4(y, rkp::SCALE_Z, hh2, ll2);
+            hp[0] = hh2.x; hp[1] = hh2.y; mp[0] = ll2.x; mp[1] = ll2.y; lp[0] = lp[1] = 0u;
+          } else {
           rk_split_bf16_pair(y.x, y.y, hp[0], mp[0], lp[0]);
           rk_split_bf16_pair(y.z, y.w, hp[1], mp[1], lp[1]);
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int64_t o = ((int64_t)(r >> 3) * cols_pad + hh + e) * 8 + (r & 7);
@@ -410,7 +418,7 @@ static int encode_fwd_launch(const rk_block_t *blk, int32_t row_off, int32_t B, 
                              uint64_t seed, uint64_t rng_step, const int64_t *users,
                              const float *user_norm, int32_t act, float *Z0, void *stream_,
                              void *zt_planes = nullptr, rk_cur_t cur = {nullptr, 0},
-                             const rk_enc_split_t *es = nullptr) {
+                             const rk_enc_split_t *es = nullptr, int zt_pairs = 0) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(h > 0 && h % 4 == 0 && h <= 1024, "h must be a multiple of 4, <= 1024");
   RK_REQUIRE(p >= 0.f && p < 1.f, "noise_prob must be in [0,1)");
@@ -432,7 +440,7 @@ static int encode_fwd_launch(const rk_block_t *blk, int32_t row_off, int32_t B, 
 #define LAUNCH(HV)                                                                         \
   RK_LAUNCH(ae_encode_fwd_kernel<HV>, dim3(n_split + rows), dim3(FW * 64), 0, stream, *blk, row_off, \
                      B, W_en, b_en, h, keep, p, scale, seed, rng_step, users, user_norm, act, Z0, \
-                     (uint16_t *)zt_planes, plane_stride, cols_pad, cur, sw, n_split, zimg, z_kt)
+                     (uint16_t *)zt_planes, plane_stride, cols_pad, cur, sw, n_split, zimg, z_kt, zt_pairs)
   if (hv == 1) LAUNCH(1); else if (hv == 2) LAUNCH(2); else LAUNCH(4);
 #undef LAUNCH
   RK_CHECK_LAUNCH("ae_encode_fwd");
@@ -472,8 +480,9 @@ int rk_ae_encode_fwd_at(const rk_block_t *blk, int32_t row_off, int32_t B, const
                         float *Z0, void *zt_planes, void *stream_, const rk_enc_split_t *es,
                         uint64_t rng_step) {
   const rk_cur_t cur = {cursor, cursor_off};
+  // (the Z^T planes the step's dW kernel reads: fp16 pairs for rk_decode_bwd_dw2, bf16 triples else)
   return encode_fwd_launch(blk, row_off, B, W_en, b_en, h, keep, p, seed, rng_step, users, nullptr, act,
-                           Z0, stream_, zt_planes, cur, es);
+                           Z0, stream_, zt_planes, cur, es, zt_planes != nullptr && rk_dw_pairs() ? 1 : 0);
 }
 
 extern "C" int rk_ae_encode_fwd_partial(const rk_block_t *blk, int32_t row_off, int32_t B,

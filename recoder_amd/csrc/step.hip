@@ -186,9 +186,16 @@ int dw_call(const rk_ae_step_t *a, float *G_de, float *gb_de, bool have_planes,
             float *ws = nullptr, void *stream = nullptr) {
   ws = ws ? ws : a->ws;
   stream = stream ? stream : a->stream;
-  if (rk_gemm_split16() && ws)
+  if (rk_gemm_split16() && ws) {
+    // fp16 pairs (three products) by default; the Z^T planes come from the encoder forward when it
+    // could write them (bounded activation: static scale), else they are made from Z with the
+    // bound rk_amax left in ranges
+    if (rk_dw_pairs())
+      return rk_decode_bwd_dw2(a->dO, a->Z0, a->B, a->h, a->blk, G_de, gb_de, ws,
+                               have_planes ? a->zt_planes : nullptr, a->ranges, stream);
     return rk_decode_bwd_dw3(a->dO, a->Z0, a->B, a->h, a->blk, G_de, gb_de, ws,
                              have_planes ? a->zt_planes : nullptr, stream);
+  }
   return rk_decode_bwd_dw(a->dO, a->Z0, a->B, a->h, a->blk, G_de, gb_de, stream);
 }
 
@@ -313,7 +320,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   const bool dw3 = whole && !(a->tied || mnll) && rk_gemm_split16() && a->ws != nullptr;
   // the encoder forward writes the Z^T planes of the bf16-pipe dW kernel along with Z
   const bool planes = rk_gemm_split16() && a->ws != nullptr && a->zt_planes != nullptr &&
-                      (phase & RK_STEP_FWD_DW) != 0;
+                      (phase & RK_STEP_FWD_DW) != 0 && (!rk_dw_pairs() || act_bounded(a->act));
   // dW on a stream of its own next to the dZ -> encoder-backward chain (rk_ae_step_t.dw_stream)
   const bool dw_branch = dw3 && a->dw_stream != nullptr;
   RK_REQUIRE(!dw_branch || (a->ws_dw && a->dw_fork && a->dw_join), "dw_stream needs ws_dw, dw_fork, dw_join");

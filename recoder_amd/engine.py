@@ -47,7 +47,7 @@ class TimedLib:
   def __getattr__(self, name):
     fn = getattr(self._lib, name)
     if not name.startswith("rk_") or name in ("rk_dz_workspace_bytes", "rk_dw_workspace_bytes", "rk_dw_splits", "rk_encode_bwd_segments", "rk_loss_partials", "rk_decode_row_tile",
-                                              "rk_dw3_workspace_bytes", "rk_dw3_max_splits", "rk_dw3_slabs", "rk_gemm_split16",
+                                              "rk_dw3_workspace_bytes", "rk_dw3_max_splits", "rk_dw3_slabs", "rk_gemm_split16", "rk_dw_pairs",
                                               "rk_dw3_planes_bytes", "rk_dw3_rows_pad", "rk_dw3_cols_pad",
                                               "rk_planes_bytes", "rk_planes_layout",
                                               "rk_last_error", "rk_version"):
@@ -628,14 +628,19 @@ class FusedEngine:
     h0 = self.h[0]
     self._dw_slabs = None
     self._ws_dw_live = False
-    if self.split16 and keep_slabs:
-      check(self.lib.rk_decode_bwd_dw3(ptr(self.dO), ptr(z), B, h0, blk.ref, None, ptr(gb_de),
-                                       ptr(self.ws_dw), None, stream), "rk_decode_bwd_dw3")
-      self._dw_slabs = (blk, B)
-      self._ws_dw_live = True
-    elif self.split16:
-      check(self.lib.rk_decode_bwd_dw3(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(self.G_de), ptr(gb_de),
-                                       ptr(self.ws), None, stream), "rk_decode_bwd_dw3")
+    if self.split16:
+      # fp16 pairs (rk_decode_bwd_dw2: three products, the scale of z from self.ranges -- the bound
+      # rk_amax left there for this z when the activation is unbounded) unless RK_DW_PREC=bf16x3
+      G, ws = (None, self.ws_dw) if keep_slabs else (self.G_de, self.ws)
+      if self.lib.rk_dw_pairs():
+        check(self.lib.rk_decode_bwd_dw2(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(G), ptr(gb_de), ptr(ws),
+                                         None, ptr(self.ranges), stream), "rk_decode_bwd_dw2")
+      else:
+        check(self.lib.rk_decode_bwd_dw3(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(G), ptr(gb_de), ptr(ws),
+                                         None, stream), "rk_decode_bwd_dw3")
+      if keep_slabs:
+        self._dw_slabs = (blk, B)
+        self._ws_dw_live = True
     else:
       check(self.lib.rk_decode_bwd_dw(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(self.G_de), ptr(gb_de),
                                       stream), "rk_decode_bwd_dw")

@@ -280,8 +280,15 @@ class GraphStepper:
           self._warm_capture()
         else:
           la = True
-          check(lib.rk_graph_launch(self.exec_first[slot] if need_pre else self.exec[slot],
-                                    self._h(self.main)), "rk_graph_launch")
+          if need_pre and self.multi and G <= self.MULTI_MAX:
+            # behind a cut: the group's blocks are collated by ONE eagerly enqueued set of launches --
+            # the GPU starts on them a few us later, and the ~50 us it takes a graph launch to reach
+            # the GPU hide behind them -- then the ordinary group graph
+            self._pre_collate(G, slot)
+            check(lib.rk_graph_launch(self.exec[slot], self._h(self.main)), "rk_graph_launch")
+          else:
+            check(lib.rk_graph_launch(self.exec_first[slot] if need_pre else self.exec[slot],
+                                      self._h(self.main)), "rk_graph_launch")
         k = G
       else:
         if need_pre:

@@ -189,7 +189,7 @@ def test_dw_slabs_contract():
 # ---------------------------------------------------------------------------------------------
 # bf16-pipe dW (csrc/dw3.hip): three bf16 pieces per fp32 operand, six products, no operand range
 # ---------------------------------------------------------------------------------------------
-def _dw3_case(B, h, n_t, gtop, ztop, give_G, seed=5, n_items=None):
+def _dw3_case(B, h, n_t, gtop, ztop, give_G, seed=5, n_items=None, pairs=False):
   from recoder_amd import _lib
   from recoder_amd._lib import check, ptr
   from recoder_amd.device import current_stream
@@ -215,8 +215,18 @@ def _dw3_case(B, h, n_t, gtop, ztop, give_G, seed=5, n_items=None):
   nbytes = lib.rk_dw3_workspace_bytes(B, h, blk.n_cap)
   ws = torch.full((nbytes // 4 + 64,), float("nan"), device=dev)
   G = torch.full((blk.n_cap * h,), float("nan"), device=dev) if give_G else None
-  check(lib.rk_decode_bwd_dw3(ptr(dO_dev), ptr(Zd), B, h, blk.ref, ptr(G), None, ptr(ws), None,
-                              current_stream()), "rk_decode_bwd_dw3")
+  if pairs:
+    # fp16 pairs (rk_decode_bwd_dw2): the operand maxima are published the way the training step
+    # does it -- max |dO| in counts[8..71] (the loss kernels), a bound of |Z| in ranges[0..63] (rk_amax)
+    blk.counts[8:72].zero_()
+    blk.counts[8:9].copy_(dO.abs().max().reshape(1).to(dev).view(torch.int32))
+    ranges = torch.zeros(128, dtype=torch.int32, device=dev)
+    check(lib.rk_amax(ptr(Zd), B * h, ptr(ranges), current_stream()), "rk_amax")
+    check(lib.rk_decode_bwd_dw2(ptr(dO_dev), ptr(Zd), B, h, blk.ref, ptr(G), None, ptr(ws), None, ptr(ranges),
+                                current_stream()), "rk_decode_bwd_dw2")
+  else:
+    check(lib.rk_decode_bwd_dw3(ptr(dO_dev), ptr(Zd), B, h, blk.ref, ptr(G), None, ptr(ws), None,
+                                current_stream()), "rk_decode_bwd_dw3")
   torch.cuda.synchronize()
   ns = int(blk.counts[4].item())
   assert 1 <= ns <= lib.rk_dw3_max_splits()
@@ -243,6 +253,26 @@ def test_dw3_matches_float64(B, h, n_t, give_G):
   err, err32, ns = _dw3_case(B, h, n_t, 2e-3, 1.0, give_G)
   print("B %d h %d n_t %d slabs %d: bf16x3 %.2e   fp32 matmul %.2e" % (B, h, n_t, ns, err, err32))
   # error / sum |products|: an fp32 matmul of the same operands sits at 2-6e-7 on this data
+  assert err < max(5e-7, 1.05 * err32), (err, err32)
+
+
+@pytest.mark.parametrize("B,h,n_t", [(500, 200, 7842), (96, 64, 333), (37, 200, 65), (512, 512, 3000),
+                                     (1000, 128, 129), (64, 256, 4097), (300, 20, 1000)])
+@pytest.mark.parametrize("give_G", [True, False])
+def test_dw2_fp16_pairs_match_float64(B, h, n_t, give_G):
+  """rk_decode_bwd_dw2 (the training step's default since round 3): fp16 pairs, three products --
+  the accuracy of an fp32 matmul of the same operands, as the bf16 triples."""
+  err, err32, ns = _dw3_case(B, h, n_t, 2e-3, 1.0, give_G, pairs=True)
+  print("B %d h %d n_t %d slabs %d: fp16x2 %.2e   fp32 matmul %.2e" % (B, h, n_t, ns, err, err32))
+  assert err < max(5e-7, 1.05 * err32), (err, err32)
+
+
+@pytest.mark.parametrize("gtop,ztop", [(1e-7, 1.0), (40.0, 1e4), (3e4, 3e4), (1e-12, 1e-3), (1e15, 1e15)])
+def test_dw2_scales_follow_the_published_maxima(gtop, ztop):
+  """The pair split takes its power-of-two scales from the published maxima of BOTH operands:
+  magnitudes from 1e-12 to 1e15 come out with the same relative accuracy."""
+  err, err32, ns = _dw3_case(200, 200, 1500, gtop, ztop, True, seed=9, pairs=True)
+  print("gtop %g ztop %g: fp16x2 %.2e   fp32 matmul %.2e" % (gtop, ztop, err, err32))
   assert err < max(5e-7, 1.05 * err32), (err, err32)
 
 

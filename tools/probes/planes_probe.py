@@ -145,6 +145,11 @@ def main():
         ptr(dO), B, h, blk.ref, ptr(W), ptr(Z), act, ptr(dz_old), ptr(ws), ptr(ranges), st)))
     r["dz_new"] = timeit(lambda: check(lib.rk_decode_bwd_dz_planes(
         ptr(dO), B, ctypes.byref(pl), blk.ref, ptr(Z), act, ptr(dz_new), ptr(ws), st)))
+    ws3 = torch.zeros(lib.rk_dw3_workspace_bytes(B, h, blk.n_cap) // 4 + 64, **f)
+    r["dw_bf16x3"] = timeit(lambda: check(lib.rk_decode_bwd_dw3(
+        ptr(dO), ptr(Z), B, h, blk.ref, None, None, ptr(ws3), None, st)), n=10, warm=2)
+    r["dw_fp16x2"] = timeit(lambda: check(lib.rk_decode_bwd_dw2(
+        ptr(dO), ptr(Z), B, h, blk.ref, None, None, ptr(ws3), None, ptr(ranges), st)), n=10, warm=2)
     gf = 2.0 * B * h * n_b / 1e9
     print("B=%5d n_b=%6d h=%d | " % (B, n_b, h) + " ".join("%s %.1fus" % kv for kv in r.items()) +
           " | GEMM %.2f GF" % gf, flush=True)
