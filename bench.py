@@ -45,16 +45,19 @@ GEMM_F32 = os.environ.get("RK_GEMM_PREC", "")[:1].lower() == "f"
 # RK_GEMM_PREC=bf16: the decoder contractions of the one-call step on PLAIN bf16 operands (one product,
 # fp32 accumulate) -- BASELINE configs[1] says "bf16"; a separate data point, never the graded line
 GEMM_BF16 = os.environ.get("RK_GEMM_PREC", "")[:1].lower() == "b"
-# MFMA flops the 16-bit pipe spends per algorithmic flop: decode / dZ multiply fp16 hi+lo pairs
-# (3 products), dW bf16 triples (6 products) -- the ceiling on ALGORITHMIC flops is peak / this
-PRODUCTS = {"rk_decode_loss": 3, "rk_decode_bwd_dz": 3, "rk_decode_bwd_dw": 6, "rk_decode_bwd_dw3": 6}
+# MFMA flops the 16-bit pipe spends per algorithmic flop: the three decoder contractions multiply
+# fp16 hi+lo pairs (3 products; dW on bf16 triples -- RK_DW_PREC=bf16x3 -- 6) -- the ceiling on
+# ALGORITHMIC flops is peak / this
+DW_BF16X3 = os.environ.get("RK_DW_PREC", "").lower().startswith("bf16x3")
+PRODUCTS = {"rk_decode_loss": 3, "rk_decode_bwd_dz": 3, "rk_decode_bwd_dw": 6 if DW_BF16X3 else 3,
+            "rk_decode_bwd_dw3": 6}
 ENTRIES = ["rk_ae_encode_fwd", "rk_decode_loss", "rk_decode_bwd_dz", "rk_decode_bwd_dw",
            "rk_ae_encode_bwd", "rk_adam_multi"]
 # the kernels each bracketed entry launches (names as rocprofv3 --kernel-trace prints them)
 KERNELS = {"rk_ae_encode_fwd": ["ae_encode_fwd_kernel (+ the W_de[items] split workgroups)"],
            "rk_decode_loss": ["decode_planes_kernel<TM,2,EPI>"],
            "rk_decode_bwd_dz": ["dz_planes_kernel<TN>", "splitk_reduce_kernel"],
-           "rk_decode_bwd_dw": ["split_planes_t_kernel", "dw3_kernel"],
+           "rk_decode_bwd_dw": ["dw3_kernel<BN,PLAIN,PAIRS> (+ split_planes_t_kernel when the encoder did not write Z^T)"],
            "rk_ae_encode_bwd": ["ae_encode_bwd_cols_kernel", "ae_encode_bwd_kernel"],
            "rk_adam_multi": ["adam_multi_kernel"]}
 
@@ -570,9 +573,8 @@ def main():
       "metric": "train_users_per_sec", "value": value, "unit": "users/s",
       "n_gpus": world, "steps": K, "warmup": W,
       "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
-      # fp32 storage, accumulation and element-wise math everywhere; decode / dZ multiply fp16
-      # hi+lo pairs (3 products), dW bf16 triples (6 products) of the fp32 operands on the 16-bit
-      # MFMA, fp32 accumulate.  BASELINE configs[1] says "bf16": plain bf16 operands miss the 1e-5
+      # fp32 storage, accumulation and element-wise math everywhere; decode / dZ / dW multiply fp16
+      # hi+lo pairs (3 products) of the fp32 operands on the 16-bit MFMA, fp32 accumulate.  BASELINE configs[1] says "bf16": plain bf16 operands miss the 1e-5
       # parity bar north_star sets (measured), so they are not used.
       "vs_baseline": None,
       "dtype": "f32" if GEMM_F32 else

@@ -495,7 +495,11 @@ typedef struct rk_ae_step {
    * global index of the epoch's first step} (device memory) and this launch's offset in the
    * replayed group: rng_step = cursor[0] + off + 1, Adam constants = adam_table[(cursor[0] -
    * cursor[1] + off) * RK_PAR_COUNT + par] (8 floats each, rk_adam_consts), the loss goes to
-   * loss_out[cursor[0] - cursor[1] + off].  cursor == NULL: the host values above are used. */
+   * loss_out[cursor[0] - cursor[1] + off].  cursor == NULL: the host values above are used.
+   * Phased (data-parallel) steps replay too: FWD_DW leaves the local loss in loss_out[0] as ever
+   * (the caller points it at a scalar of its own and all-reduces it with the gradients); for the
+   * UPDATE call the caller sets loss_part = that scalar and loss_out = the epoch's loss buffer --
+   * the Adam launch files loss_part[0] under the step's slot and publishes cursor_next. */
   int32_t *ranges;           /* nullable: 128 slots, operand ranges of the decoder contractions
                                 (rk_decode_loss): the step keeps [64..127] up to date from its Adam
                                 sweep of the decoder table and fills [0..63] with rk_amax(Z) when
@@ -549,6 +553,12 @@ int rk_collate_at_multi(const int64_t *ds_indptr, const int32_t *ds_indices, con
                         const int64_t *users_base, int32_t S, int32_t negative_sampling,
                         const int64_t *cursor, int32_t off0, const rk_block_t *const *blks,
                         int32_t n_blk, void *stream);
+/* phase as rk_collate (1: row pointers + item marking; 2: the rest): data-parallel replay puts the
+ * MAX all-reduce of the blocks' mark arrays between the two, inside the capture */
+int rk_collate_at_multi_phase(const int64_t *ds_indptr, const int32_t *ds_indices, const float *ds_data,
+                              const int64_t *users_base, int32_t S, int32_t negative_sampling,
+                              const int64_t *cursor, int32_t off0, const rk_block_t *const *blks,
+                              int32_t n_blk, int32_t phase, void *stream);
 int rk_cursor_set(int64_t *cursor, int64_t step, int64_t epoch_base, void *stream);
 int rk_cursor_advance(int64_t *cursor, int64_t n, void *stream);
 int rk_adam_consts(double lr, double beta1, double beta2, double eps, double weight_decay,

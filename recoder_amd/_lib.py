@@ -185,6 +185,8 @@ SIGNATURES = {
   "rk_ae_train_step": (c_int32, [POINTER(RkAeStep)]),
   "rk_collate_at": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, c_int32, _BLK, _P]),
   "rk_collate_at_multi": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, c_int32, POINTER(_BLK), c_int32, _P]),
+  "rk_collate_at_multi_phase": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, c_int32, POINTER(_BLK), c_int32,
+                                          c_int32, _P]),
   "rk_cursor_set": (c_int32, [_P, c_int64, c_int64, _P]),
   "rk_cursor_advance": (c_int32, [_P, c_int64, _P]),
   "rk_adam_consts": (c_int32, [c_double, c_double, c_double, c_double, c_double, c_int32, c_int32,

@@ -496,7 +496,19 @@ extern "C" int rk_collate_at_multi(const int64_t *ds_indptr, const int32_t *ds_i
                                    const float *ds_data, const int64_t *users_base, int32_t S,
                                    int32_t negative_sampling, const int64_t *cursor, int32_t off0,
                                    const rk_block_t *const *blks, int32_t n_blk, void *stream_) {
+  return rk_collate_at_multi_phase(ds_indptr, ds_indices, ds_data, users_base, S, negative_sampling,
+                                   cursor, off0, blks, n_blk, 0, stream_);
+}
+
+// phase as rk_collate: 1 = row pointers + item marking, 2 = the rest (data-parallel replay: the
+// MAX all-reduce of the n_blk mark arrays goes between them, captured with the launches)
+extern "C" int rk_collate_at_multi_phase(const int64_t *ds_indptr, const int32_t *ds_indices,
+                                         const float *ds_data, const int64_t *users_base, int32_t S,
+                                         int32_t negative_sampling, const int64_t *cursor, int32_t off0,
+                                         const rk_block_t *const *blks, int32_t n_blk, int32_t phase,
+                                         void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(phase >= 0 && phase <= 2, "phase must be 0, 1 or 2");
   RK_REQUIRE(cursor != nullptr && blks != nullptr, "null cursor / blocks");
   RK_REQUIRE(n_blk >= 1 && n_blk <= RK_COLLATE_MULTI, "1 .. RK_COLLATE_MULTI blocks");
   MultiBlk mb = {};
@@ -521,9 +533,12 @@ extern "C" int rk_collate_at_multi(const int64_t *ds_indptr, const int32_t *ds_i
     if (nzero < 1) nzero = 1;
     if (nzero > 512) nzero = 512;
   }
-  RK_LAUNCH(collate_phase1_multi_kernel, dim3(nrow_blk + 1 + nzero, n_blk), dim3(256), 0, stream, ds_indptr,
-            ds_indices, users_base, S, all, nrow_blk, mb, cur);
-  RK_CHECK_LAUNCH("collate_phase1_multi");
+  if (phase != 2) {
+    RK_LAUNCH(collate_phase1_multi_kernel, dim3(nrow_blk + 1 + nzero, n_blk), dim3(256), 0, stream, ds_indptr,
+              ds_indices, users_base, S, all, nrow_blk, mb, cur);
+    RK_CHECK_LAUNCH("collate_phase1_multi");
+  }
+  if (phase == 1) return 0;
   if (b0->n_items <= SMALL_SCAN_MAX) {
     RK_LAUNCH(collate_scan_small_multi_kernel, dim3(n_blk), dim3(1024), 0, stream, all, mb, cur);
     RK_CHECK_LAUNCH("collate_scan_small_multi");

@@ -1017,8 +1017,10 @@ inline int dw_splits(int B) {
 
 inline int dz_splits(int B) {
   const int tiles_m = rk_cdiv(B, 128);
+  static const int cap = [] { const char *e = getenv("RK_DZ_SPLITS"); const int v = e ? atoi(e) : 0;
+                              return (v >= 8 && v <= DZ_SPLITS) ? (v & ~7) : DZ_SPLITS; }();
   int s = (512 / tiles_m) & ~7;
-  return s < 8 ? 8 : (s > DZ_SPLITS ? DZ_SPLITS : s);
+  return s < 8 ? 8 : (s > cap ? cap : s);
 }
 constexpr int DEC_BM = 64;          // rows per decode tile (rk_loss_partials, gb_part rows)
 

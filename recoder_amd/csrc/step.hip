@@ -454,8 +454,12 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       jobs[n].g_parts = rk_encode_bwd_segments(B); jobs[n].g_stride = h;
     }
     ++n;
-    RK_REQUIRE(a->cursor == nullptr || (whole && a->adam_table != nullptr),
-               "graph replay covers whole steps and needs the Adam constants table");
+    RK_REQUIRE(a->cursor == nullptr || a->adam_table != nullptr,
+               "graph replay needs the Adam constants table");
+    // replayed PHASED steps (data parallel): the caller's exchange has left the global loss in a
+    // scalar of its own; the update phase gets it as loss_part[0] (denom 1) and this launch's loss
+    // block files it under the step's slot of loss_out and publishes the next cursor
+    const bool with_loss = whole || a->cursor != nullptr;
     // the two bias jobs go FIRST in the grid (the launch dispatches its workgroups in order): a few
     // dozen workgroups with a long chain of dependent loads (pos -> 8 partial gradient rows), which
     // as the LAST ones dispatched were the tail of the whole sweep (43 vs 37 us in isolation)
@@ -468,8 +472,9 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       for (int k = 0; k < n; ++k) { jobs[k] = j2[k]; slots[k] = s2[k]; }
     }
     Timer t(a, RK_ENTRY_ADAM_MULTI, sm);
-    RK_TRY(rk_adam_multi_at(jobs, n, whole ? a->loss_part : nullptr, n_part, a->denom,
-                            whole ? a->loss_out : nullptr, a->cursor, a->cursor_off, a->adam_table,
+    RK_TRY(rk_adam_multi_at(jobs, n, with_loss ? a->loss_part : nullptr, whole ? n_part : 1,
+                            whole ? a->denom : 1.0f, with_loss ? a->loss_out : nullptr, a->cursor,
+                            a->cursor_off, a->adam_table,
                             RK_PAR_COUNT, slots, a->cursor_next, a->cursor_advance, sm));
   }
   return 0;

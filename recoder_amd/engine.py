@@ -787,7 +787,10 @@ class FusedEngine:
       # as ONE in-order RCCL group on this stream, then the identical Adam on every replica
       h0 = self.h[0]
       tied = bool(m.is_constrained)
-      n_b = dp.n_b(blk)
+      # replayed (graph.GraphStepper): a captured collective has a fixed size -- the exchange covers
+      # the blocks' whole capacity (rows past n_b are never read by the update) instead of the live
+      # rows, and nothing of the step is read on the host
+      n_b = dp.n_b(blk) if replay is None else blk.n_cap
       G_enc = self.G_de if tied else self.G_en
       if tied:
         # tied weights: the encoder backward accumulates onto dW's rows -- nothing may leave before it
@@ -805,7 +808,11 @@ class FusedEngine:
         check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
         dp.reduce_async([G_enc[:n_b * h0], self.small[:h0]], main_s)
         dp.join_async(main_s)
-      out.copy_(self.loss_dp)
+      if replay is None:
+        out.copy_(self.loss_dp)
+      else:
+        # the Adam launch files the exchanged loss under the step's slot of the epoch's buffer
+        st.loss_part, st.loss_out = ptr(self.loss_dp), ptr(out)
       st.phase = STEP_UPDATE
       check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
     self._loss_target = out

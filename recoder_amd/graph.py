@@ -39,6 +39,12 @@ class GraphStepper:
     self.eng, self.dcsr, self.B, self.ns, self.G = engine, dcsr, int(B), bool(negative_sampling), int(group)
     self.device = device
     self.multi = os.environ.get("RK_COLLATE_MULTI", "1") != "0"    # batched collation launches
+    # data parallel over users (parallel.DataParallel attached to the engine): every block's item
+    # set is the union over the ranks -- the MAX all-reduce of the blocks' stamp arrays sits between
+    # the two collation phases, captured with them -- and the step's two gradient exchanges are
+    # captured between its phases (engine._c_train_step); all of fixed size
+    self.dp = getattr(engine, "allreduce", None)
+    assert self.dp is None or (self.multi and self.G <= self.MULTI_MAX and engine.c_step_eligible())
     self.blocks = [[make_block() for _ in range(self.G)] for _ in range(2)]
     self.tail_blk = make_block()            # ragged last batch: eager, host-provided arguments
     engine.ensure_capacity(self.B, self.blocks[0][0].n_cap)
@@ -49,6 +55,8 @@ class GraphStepper:
     # the epoch's user order, padded so that the look-ahead collation of the group after the last
     # one reads valid user ids (its blocks are never trained on)
     self.order = torch.zeros((self.steps_cap + 2 * self.G) * self.B, dtype=torch.int64, device=device)
+    # (data parallel: `order` holds rows of this rank's shard; the dropout RNG is keyed on GLOBAL ids)
+    self.order_global = self.order if self.dp is None else torch.zeros_like(self.order)
     self.loss_buf = torch.zeros(self.steps_cap + self.G, dtype=torch.float32, device=device)
     # per-epoch table of Adam constants: one 8-float entry per (step, parameter slot).  The one-call
     # step has its four parameters (slots = RK_PAR_*); the entry-by-entry sequencing one per state
@@ -120,20 +128,26 @@ class GraphStepper:
       blk.c.implicit = 1 if d.data is None else 0
       blk.S = self.B
       arr[g] = ctypes.pointer(blk.c)
-    check(self.lib.rk_collate_at_multi(ptr(d.indptr), ptr(d.indices), ptr(d.data), ptr(self.order), self.B,
-                                       1 if self.ns else 0, self._cur(slot), off0, arr, n,
-                                       self._h(stream)), "rk_collate_at_multi")
+    args = (ptr(d.indptr), ptr(d.indices), ptr(d.data), ptr(self.order), self.B, 1 if self.ns else 0,
+            self._cur(slot), off0, arr, n)
+    if self.dp is None:
+      check(self.lib.rk_collate_at_multi(*args, self._h(stream)), "rk_collate_at_multi")
+      return
+    check(self.lib.rk_collate_at_multi_phase(*args, 1, self._h(stream)), "rk_collate_at_multi_phase")
+    with torch.cuda.stream(stream):
+      self.dp.union_marks_many([blk.mark for blk in blks])
+    check(self.lib.rk_collate_at_multi_phase(*args, 2, self._h(stream)), "rk_collate_at_multi_phase")
 
   def _step(self, slot, g, index=None, advance=None):
     """Enqueue the training step of block [slot][g] (cursor offset g) on the main stream; index
     != None: an eager step that bench.py's time plan may bracket; advance: the group's last step
     publishes the other slot's cursor."""
     replay = dict(st=self.st[slot][g], cursor=self._cur(slot), off=g, table=ptr(self.table),
-                  users=ptr(self.order), timed=index is not None, index=index, dw_stream=self.side,
+                  users=ptr(self.order_global), timed=index is not None, index=index, dw_stream=self.side,
                   next=None if advance is None else (self._cur(1 - slot), advance))
     if self.c_step:
-      self.eng._c_train_step(self.blocks[slot][g], 0, self.B, None, self.loss_buf, None, self.main,
-                             replay=replay)
+      self.eng._c_train_step(self.blocks[slot][g], 0, self.B, None, self.loss_buf,
+                             None if self.dp is None else self.B * self.dp.world, self.main, replay=replay)
     else:
       # entry-by-entry sequencing (hidden stacks, dropout, MatrixFactorization) under the replay
       # context: every state's Adam constants have a slot of their own in the table
@@ -216,6 +230,8 @@ class GraphStepper:
     order_np = np.ascontiguousarray(order_np, dtype=np.int64)
     self.order.copy_(torch.from_numpy(np.concatenate([order_np, np.resize(order_np, pad)])),
                      non_blocking=False)
+    if self.dp is not None:
+      torch.add(self.order, int(self.dp.user_offset), out=self.order_global)
     # Adam constants of every step of the epoch (exactly what rk_adam_multi derives itself)
     th = self.table_host
     S = self.eng.states

@@ -730,8 +730,16 @@ class Recoder(object):
       return False
     if not eng.c_step_eligible() and os.environ.get("RK_GRAPH_ENTRY", "1") == "0":
       return False                       # (entry-by-entry sequenced steps: replayed too by default)
-    if getattr(self, "_dp", None) is not None or getattr(self, "_ip", None) is not None:
+    if getattr(self, "_ip", None) is not None:
       return False
+    dp = getattr(self, "_dp", None)
+    if dp is not None:
+      # users-DP replays too when its collectives are our own in-order RCCL calls (capturable) and
+      # the step is the one-call autoencoder step; injected collectives (virtual ranks in tests),
+      # torch.distributed / gloo and the entry-by-entry engines keep the eager sequencing
+      if not (dp.direct and not dp.virtual and eng.c_step_eligible() and
+              os.environ.get("RK_GRAPH_DP", "1") != "0" and self.graph_group <= 8):
+        return False
     ds = dataloader.dataset
     return (self.mask_hook is None and dataloader.num_sampling_users == dataloader.batch_size and
             ds.device_target_csr() is None and iters_per_epoch == num_batches and
@@ -748,6 +756,7 @@ class Recoder(object):
     gs = getattr(self, "_graph_stepper", None)
     G = max(1, min(self.graph_group, n // B))
     if gs is None or gs.eng is not eng or gs.dcsr is not dcsr or gs.B != B or gs.ns != ns or gs.G != G or \
+        gs.dp is not getattr(eng, "allreduce", None) or \
         (not gs.c_step and set(gs.slots) != set(eng.states)):
       if gs is not None:
         gs.close()
@@ -763,6 +772,10 @@ class Recoder(object):
     if order is None:
       order = epoch_user_order(n)
     order = np.ascontiguousarray(order, dtype=np.int64)
+    n_draw = n
+    if getattr(self, "_dp", None) is not None and order.shape == (n,):
+      n = self._dp_users_per_epoch         # equal step counts on every rank (as _step_generator)
+      order = np.ascontiguousarray(order[:n])
     if order.shape != (n,):
       # a hook may hand over any list of users (a subset, repeats): the replayed graphs are laid out
       # for one pass over the n users -- this epoch takes the eagerly sequenced path with the SAME
@@ -772,11 +785,11 @@ class Recoder(object):
     caller = torch.cuda.current_stream()
     gs.main.wait_stream(caller)
     with torch.cuda.stream(gs.main):
-      losses = self._run_epoch_graph(gs, eng, dcsr, order, n, B, draw_next_order)
+      losses = self._run_epoch_graph(gs, eng, dcsr, order, n, B, draw_next_order, n_draw)
     caller.wait_stream(gs.main)
     return losses
 
-  def _run_epoch_graph(self, gs, eng, dcsr, order, n, B, draw_next_order=False):
+  def _run_epoch_graph(self, gs, eng, dcsr, order, n, B, draw_next_order=False, n_draw=None):
     n_full = gs.begin_epoch(order, eng.rng_step)
     n_total = n_full + (1 if n % B else 0)
     g0 = self._global_step
@@ -802,13 +815,20 @@ class Recoder(object):
     if not stopped and n % B:
       # the ragged last batch: eager, host-provided arguments (its own block)
       users = torch.from_numpy(order[n_full * B:]).to(self.device)
-      gs.tail_blk.collate(dcsr, users)
+      dp = getattr(self, "_dp", None)
       out = torch.zeros(1, dtype=torch.float32, device=self.device)
-      eng.train_step(gs.tail_blk, 0, int(users.numel()), out=out)
+      if dp is not None:
+        dp.collate(gs.tail_blk, dcsr, users)
+        eng.train_step(gs.tail_blk, 0, int(users.numel()), out=out,
+                       global_rows=int(users.numel()) * dp.world)
+      else:
+        gs.tail_blk.collate(dcsr, users)
+        eng.train_step(gs.tail_blk, 0, int(users.numel()), out=out)
       self._global_step += 1
       losses = torch.cat([losses, out])
     if draw_next_order and not self._stop_training:
-      self._order_ahead = (n, epoch_user_order(n))      # (everything of this epoch is enqueued)
+      n_draw = n if n_draw is None else n_draw
+      self._order_ahead = (n_draw, epoch_user_order(n_draw))      # (everything of this epoch is enqueued)
     return losses.cpu().numpy().copy()
 
   def _validate(self, val_dataloader):

@@ -144,6 +144,16 @@ class DataParallel:
       return self._mark_comm.all_reduce(mark, op=ncclMax)
     return union_marks(mark, self.group)
 
+  def union_marks_many(self, marks):
+    """The MAX all-reduces of several blocks' stamp arrays, in order on the current stream (one
+    RCCL group on the direct communicator: a replayed group's look-ahead blocks)."""
+    if self._max_fn is None and self._mark_comm is not None and all(m.is_cuda for m in marks):
+      from .rccl import ncclMax
+      self._mark_comm.all_reduce_many(marks, op=ncclMax)
+      return
+    for m in marks:
+      self.union_marks(m)
+
   def collate(self, blk, dcsr, users_dev):
     """Two-phase collation with the union item set.  ``users_dev`` are rows of this
     rank's shard; the block carries their GLOBAL ids (MatrixFactorization looks its

@@ -695,12 +695,14 @@ def test_dataframe_to_csr_matrix_contract():
   assert m2.shape == m.shape
 
 
-@pytest.mark.parametrize("kind", ["ae", "ae_overlap", "ae_items", "mf", "mf_sparse"])
+@pytest.mark.parametrize("kind", ["ae", "ae_overlap", "ae_eager", "ae_items", "mf", "mf_sparse"])
 def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind):
   """Recoder.train under an initialised torch.distributed group (RCCL, 1 rank):
   two-phase collation + all-reduced gradients must reproduce the plain run.  ae_overlap: the
   two-group exchange of a multi-rank run (decoder-side gradients on the communication stream while
-  the step stream runs dZ -> encoder backward), forced on although one rank has nothing to hide."""
+  the step stream runs dZ -> encoder backward), forced on although one rank has nothing to hide.
+  ae / ae_overlap replay the phased step, its collectives included, as HIP graphs
+  (graph.GraphStepper with a DataParallel); ae_eager (RK_GRAPH_DP=0) sequences it from the host."""
   import torch.distributed as dist
   from recoder_amd.data import RecommendationDataset
   from recoder_amd.model import Recoder
@@ -709,9 +711,13 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
   monkeypatch.setenv("RK_PARALLEL", "items" if kind == "ae_items" else "users")
   items_mode = kind == "ae_items"
   overlap = kind == "ae_overlap"
+  eager_dp = kind == "ae_eager"
   if overlap:
     monkeypatch.setenv("RK_DP_OVERLAP", "1")
-  kind = "ae" if (items_mode or overlap) else kind
+  if eager_dp:
+    monkeypatch.setenv("RK_GRAPH_DP", "0")
+  graph_dp = kind in ("ae", "ae_overlap")
+  kind = "ae" if (items_mode or overlap or eager_dp) else kind
   c = STEP_CASES[0][1] if kind == "ae" else dict(kind="mf", embedding_size=32,
                                                  activation_type="tanh", sparse=(kind == "mf_sparse"))
 
@@ -724,13 +730,16 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
     rec.train(RecommendationDataset(csr), batch_size=300, lr=1e-3, weight_decay=2e-5, num_epochs=2,
               negative_sampling=True)
     assert ((rec._ip if items_mode else rec._dp) is not None) == dp
+    gs = getattr(rec, "_graph_stepper", None)
+    if dp:
+      assert (gs is not None and gs.dp is rec._dp and gs.warmed) == graph_dp
     return np.concatenate(rec.loss_history), {k: v.detach().cpu().clone() for k, v in model.named_parameters()}
 
   base_l, base_p = run(False)
   monkeypatch.setenv("RK_FORCE_DP", "1")
   monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
   monkeypatch.setenv("MASTER_PORT", str(29577 + ["ae", "mf", "mf_sparse"].index(kind) + 5 * items_mode +
-                                        20 * overlap))
+                                        20 * overlap + 30 * eager_dp))
   dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
   try:
     dp_l, dp_p = run(True)
