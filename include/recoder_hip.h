@@ -622,6 +622,32 @@ int rk_topk_masked_strip(const float *scores, int32_t B, int32_t n, int32_t ld,
                          const rk_block_t *seen, int32_t row_off, int32_t k, int32_t col_off,
                          int64_t *out_idx, float *out_val, int32_t out_ld, void *stream);
 int32_t rk_topk_max_k(void);
+/*
+ * The fused form (catalogues of more than one strip): no score matrix at all.
+ *   1. rk_topk_masked_strided on the scores of a STRIDED SAMPLE of the catalogue (score column c is
+ *      item col_off + c * col_stride): the k-th best sampled score of a row is a lower bound of the
+ *      k-th best score of its whole row;
+ *   2. rk_decode_filter_planes: the decode over the whole catalogue from plane images (rk_split_image
+ *      of the encoder output and -- once per evaluation -- of the decoder table), whose epilogue
+ *      keeps only the unseen entries that reach their row's bound: (score, item id) pairs appended
+ *      to the row's candidate list (cand_cnt[r] counts them, also past cand_cap);
+ *   3. rk_topk_pairs: the k best pairs of every row by (score descending, id ascending) -- exactly
+ *      torch.topk's choice on the masked full row.  status |= 1: a list overflowed, |= 2: a row has
+ *      fewer than k candidates (k above its unseen items); the caller falls back to the strips.
+ */
+int rk_split_image(const float *X, int64_t rows, int32_t K, int64_t ld, const int32_t *amax /* nullable */,
+                   float dflt_scale, void *image, float *scales, int32_t slot, void *stream);
+int rk_topk_masked_strided(const float *scores, int32_t B, int32_t n, int32_t ld, const rk_block_t *seen,
+                           int32_t row_off, int32_t k, int32_t col_off, int32_t col_stride,
+                           int64_t *out_idx, float *out_val, int32_t out_ld, void *stream);
+int rk_decode_filter_planes(const void *zimg, const void *wimg, const float *scales, int32_t h, int32_t B,
+                            int32_t n, int32_t col_off, const float *b_de /* nullable */,
+                            const rk_block_t *seen /* nullable */, int32_t row_off, const float *thr,
+                            float *cand_val, int32_t *cand_idx, int32_t *cand_cnt, int32_t cand_cap,
+                            const int32_t *n_dev, void *stream);
+int rk_topk_pairs(const float *val, const int32_t *idx, const int32_t *cnt, int32_t B, int32_t cap,
+                  int32_t k, int64_t *out_idx, int32_t out_ld, int32_t *status, void *stream);
+int32_t rk_topk_pairs_max_cap(void);
 
 #ifdef __cplusplus
 }

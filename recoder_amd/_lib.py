@@ -204,6 +204,13 @@ SIGNATURES = {
   "rk_topk_masked_strip": (c_int32, [_P, c_int32, c_int32, c_int32, _BLK, c_int32, c_int32, c_int32, _P, _P,
                                      c_int32, _P]),
   "rk_topk_max_k": (c_int32, []),
+  "rk_split_image": (c_int32, [_P, c_int64, c_int32, c_int64, _P, c_float, _P, _P, c_int32, _P]),
+  "rk_topk_masked_strided": (c_int32, [_P, c_int32, c_int32, c_int32, _BLK, c_int32, c_int32, c_int32, c_int32,
+                                       _P, _P, c_int32, _P]),
+  "rk_decode_filter_planes": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _BLK, c_int32, _P,
+                                        _P, _P, _P, c_int32, _P, _P]),
+  "rk_topk_pairs": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, _P, c_int32, _P, _P]),
+  "rk_topk_pairs_max_cap": (c_int32, []),
 }
 
 _lib = None

@@ -27,7 +27,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));      // (a first-cla
 constexpr int ROWB = 144;            // LDS row: 64 B hi | 64 B lo | 16 B pad (odd number of 16-B slots)
 constexpr float SCALE_DO = 1024.0f;  // dO without a published maximum (as gemm.hip)
 
-enum { EPI_STORE = 0, EPI_LOSS_MSE = 1, EPI_LOSS_BCE = 3 };
+// EPI_FILTER (Recoder.recommend): nothing of the score tile is stored -- an entry survives only if it
+// reaches its row's threshold (a lower bound of the row's k-th best score, from a strided sample of
+// the catalogue) and is not a seen item; survivors are appended to the row's candidate list
+enum { EPI_STORE = 0, EPI_LOSS_MSE = 1, EPI_LOSS_BCE = 3, EPI_FILTER = 4 };
 
 __device__ __forceinline__ void publish_amax(int32_t *counts, int slot, float v) {
   atomicMax(reinterpret_cast<unsigned int *>(counts) + 8 + (slot & 63), __float_as_uint(v));
@@ -87,6 +90,13 @@ struct DecP {
   float confidence, inv_B;
   float *loss_part;
   float *gb_part;
+  // filter epilogue: column n is item col_off + n; blk = the users' INPUT block over the whole
+  // catalogue (seen items), has_seen == 0: nothing is masked
+  const float *thr;           // [M]
+  float *cand_val;            // [M][cand_cap]
+  int32_t *cand_idx;          // [M][cand_cap] item ids
+  int32_t *cand_cnt;          // [M] survivors seen (may exceed cand_cap: the caller checks)
+  int cand_cap, col_off, has_seen;
 };
 
 // 4 waves as 2 x 2, wave tile (TM*32) x (TN*32): BM = 64*TM, BN = 64*TN.  BK = 32, two LDS stages,
@@ -156,7 +166,7 @@ void decode_planes_kernel(DecP p) {
   // loads, so that their dependent round trips overlap the k-loop instead of the epilogue.  All
   // gather indices first, then all values: independent loads (a `bidx ? bidx[n] : n` select per
   // element made hipcc branch and wait vmcnt(0) for every one of them: 16 serial round trips).
-  constexpr bool LOSS = (EPI != EPI_STORE);
+  constexpr bool LOSS = (EPI == EPI_LOSS_MSE || EPI == EPI_LOSS_BCE);
   float pre_bv[LOSS ? TN : 1][4];
   uint32_t pre_w[LOSS ? TM : 1][LOSS ? TN : 1][4];
   if (LOSS) {
@@ -309,6 +319,55 @@ void decode_planes_kernel(DecP p) {
           }
         }
       }
+  } else if (EPI == EPI_FILTER) {
+    const rk_block_t &b = p.blk;
+    const bool implicit = b.implicit != 0;
+    float th[TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+        th[i][it] = p.thr[min(m0 + (wm * TM + i) * 32 + rr0 + 8 * it, M - 1)];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + c4 * 4;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[e] = p.bias[min(n + e, N - 1)];
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float4 v[4];
+        transpose_tile(acc[i][j], v);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int m = m0 + (wm * TM + i) * 32 + rr0 + 8 * it;
+          const float ov[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float o = ov[e] + bv[e];
+            if (m < M && n + e < N && o >= th[i][it]) {        // (rare: a few hundred per row in all)
+              const int gc = p.col_off + n + e;
+              bool seen = false;
+              if (p.has_seen) {
+                const int row = p.row_off + m;
+                const uint32_t word = b.bits_rc[(int64_t)row * b.ldw_rc + (gc >> 5)];
+                if ((word >> (gc & 31)) & 1u)
+                  seen = implicit ? true : (b.vals[rk_entry_index(b, row, gc, word)] > 0.f);
+              }
+              if (!seen) {
+                const int slot = atomicAdd(p.cand_cnt + m, 1);
+                if (slot < p.cand_cap) {
+                  p.cand_val[(int64_t)m * p.cand_cap + slot] = o;
+                  p.cand_idx[(int64_t)m * p.cand_cap + slot] = gc;
+                }
+              }
+            }
+          }
+        }
+      }
+    }
   } else {
     float *lred = fsm + 4 * (32 * TLD);           // after the 4 per-wave transpose areas
     float *cpart = lred + 8;                      // [2][BN] column partial sums (one row per 64 rows)
@@ -599,8 +658,8 @@ __global__ __launch_bounds__(256) void split_w_kernel(rkp::SplitW p) {
 
 // X[rows, K] fp32 (leading dimension ld) -> its plane image; scale from `amax` (64 slots, nullable)
 // or the static default; scales[slot] <- the scale used
-__global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ X, int rows, int K,
-                                                         int ld, const uint32_t *amax, float dflt,
+__global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ X, int64_t rows, int K,
+                                                         int64_t ld, const uint32_t *amax, float dflt,
                                                          char *img, int KT, float *scales, int slot,
                                                          int plain) {
   const float s = plain ? 1.0f : rkp::scale_from(amax, dflt);
@@ -608,10 +667,11 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
   const int q4 = KT * 8;                          // float4 per image row
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)rows * q4) return;
-  const int r = (int)(i / q4), k = (int)(i % q4) * 4;
+  const int64_t r = i / q4;
+  const int k = (int)(i % q4) * 4;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (k < K) v = *reinterpret_cast<const float4 *>(X + (int64_t)r * ld + k);     // (K % 4 == 0)
-  rkp::store_split4(img + (int64_t)r * KT * rkp::LINE, k, v, s, plain != 0);
+  if (k < K) v = *reinterpret_cast<const float4 *>(X + r * ld + k);     // (K % 4 == 0)
+  rkp::store_split4(img + r * KT * rkp::LINE, k, v, s, plain != 0);
 }
 
 inline bool aligned16(const void *q) { return ((uintptr_t)q & 15) == 0; }
@@ -762,6 +822,60 @@ extern "C" int rk_decode_loss_planes(const rk_planes_t *pl, int32_t B, const rk_
   }
 #undef LAUNCH
   RK_CHECK_LAUNCH("decode_loss_planes");
+  return 0;
+}
+
+// X[rows, K] fp32 (leading dimension ld) -> its plane image [rows][kp_of(K) / 32 lines]; the scale from
+// `amax` (64 slots of fp32 bit patterns, nullable: dflt_scale), published in scales[slot]
+extern "C" int rk_split_image(const float *X, int64_t rows, int32_t K, int64_t ld, const int32_t *amax,
+                              float dflt_scale, void *image, float *scales, int32_t slot, void *stream_) {
+  RK_REQUIRE(aligned16(X) && aligned16(image) && K % 4 == 0 && ld % 4 == 0, "16-byte aligned operands, K % 4 == 0");
+  RK_REQUIRE(slot == 0 || slot == 1, "slot is 0 (Z) or 1 (W)");
+  RK_REQUIRE(rows * (int64_t)(rkp::kp_of(K) / 32) * 8 < ((int64_t)1 << 31) * 256, "image too large for one launch");
+  if (rows == 0) return 0;
+  const int KT = rkp::kp_of(K) / 32;
+  RK_LAUNCH(split_rows_kernel, dim3((unsigned)rk_cdiv(rows * KT * 8, 256)), dim3(256), 0, (hipStream_t)stream_,
+            X, rows, K, ld, reinterpret_cast<const uint32_t *>(amax), dflt_scale, (char *)image, KT, scales,
+            slot, (int)rk_gemm_plain_bf16());
+  RK_CHECK_LAUNCH("split_image");
+  return 0;
+}
+
+// Recoder.recommend's decode over a strip of the catalogue with the top-k FILTER fused (EPI_FILTER):
+// zimg [B][KT], wimg [n][KT] (rows = items col_off .. col_off + n), scales {Z, W}
+extern "C" int rk_decode_filter_planes(const void *zimg, const void *wimg, const float *scales, int32_t h,
+                                       int32_t B, int32_t n, int32_t col_off, const float *b_de,
+                                       const rk_block_t *seen, int32_t row_off, const float *thr,
+                                       float *cand_val, int32_t *cand_idx, int32_t *cand_cnt,
+                                       int32_t cand_cap, const int32_t *n_dev, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(zimg && wimg && scales && thr && cand_val && cand_idx && cand_cnt && n_dev, "null argument");
+  RK_REQUIRE(seen == nullptr || (row_off >= 0 && row_off + B <= seen->S_cap && seen->bits_rc != nullptr &&
+                                 (seen->implicit || seen->pref_rc != nullptr) &&
+                                 (int64_t)seen->ldw_rc * 32 >= col_off + n),
+             "seen block: rows / bitmap do not cover the strip");
+  if (B == 0 || n == 0) return 0;
+  DecP p = {};
+  p.zp = (const char *)zimg; p.wp = (const char *)wimg; p.scales = scales;
+  p.KT = rkp::kp_of(h) / 32;
+  p.M = B; p.n_cap = n; p.Ndev = n_dev;
+  p.bias = b_de ? b_de + col_off : nullptr;
+  if (seen) { p.blk = *seen; p.has_seen = 1; }
+  p.row_off = row_off;
+  p.thr = thr; p.cand_val = cand_val; p.cand_idx = cand_idx; p.cand_cnt = cand_cnt;
+  p.cand_cap = cand_cap; p.col_off = col_off;
+  const int tm = dec_tm(B, n);
+  const int BM = 64 * tm, BN = 128;
+  const int grid = rk_cdiv(rk_cdiv(B, BM) * rk_cdiv(n, BN), 8) * 8;
+  const int lds = 2 * (BM + BN) * ROWB;
+  if (tm == 2) {
+    if (set_lds(decode_planes_kernel<2, 2, EPI_FILTER>, lds)) { rk_set_error("LDS attribute"); return -1; }
+    RK_LAUNCH((decode_planes_kernel<2, 2, EPI_FILTER>), dim3(grid), dim3(256), lds, stream, p);
+  } else {
+    if (set_lds(decode_planes_kernel<1, 2, EPI_FILTER>, lds)) { rk_set_error("LDS attribute"); return -1; }
+    RK_LAUNCH((decode_planes_kernel<1, 2, EPI_FILTER>), dim3(grid), dim3(256), lds, stream, p);
+  }
+  RK_CHECK_LAUNCH("decode_filter_planes");
   return 0;
 }
 

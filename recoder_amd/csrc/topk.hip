@@ -22,7 +22,8 @@ __device__ __forceinline__ float key2f(uint32_t k) {
 __global__ __launch_bounds__(256) void topk_masked_kernel(const float *scores, int n, int ld,
                                                           rk_block_t seen, int has_seen,
                                                           int row_off, int k, int64_t *out_idx,
-                                                          float *out_val, int col_off, int out_ld) {
+                                                          float *out_val, int col_off, int out_ld,
+                                                          int col_stride) {
   __shared__ uint32_t hist[256];
   __shared__ unsigned long long cand[KMAX];
   __shared__ uint32_t s_prefix, s_need, s_cnt, s_tie;
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void topk_masked_kernel(const float *scores, i
   auto key_at = [&](int c) -> uint32_t {
     float f = srow[c];
     if (bits) {
-      const int gc = col_off + c;
+      const int gc = col_off + c * col_stride;
       const uint32_t word = bits[gc >> 5];
       if ((word >> (gc & 31)) & 1u) {
         const float v = implicit ? 1.0f : seen.vals[rk_entry_index(seen, row, gc, word)];
@@ -129,28 +130,93 @@ __global__ __launch_bounds__(256) void topk_masked_kernel(const float *scores, i
   for (int i = tid; i < k; i += 256) {
     const unsigned long long e = cand[i];
     const uint32_t c = ~(uint32_t)(e & 0xffffffffull);
-    out_idx[(int64_t)r * out_ld + i] = (int64_t)c + col_off;
+    out_idx[(int64_t)r * out_ld + i] = (int64_t)c * col_stride + col_off;
     if (out_val) out_val[(int64_t)r * out_ld + i] = key2f((uint32_t)(e >> 32));
   }
 }
 
+// Final pass of the fused-filter recommend: row r holds cnt[r] (<= cap) candidate (score, item id)
+// pairs in ANY order; its k best by (score descending, id ascending) -> out_idx[r][0..k).  One
+// workgroup per row: bitonic sort of the composite keys in LDS.  status[0] |= 1 if a row overflowed
+// its list (cnt > cap), |= 2 if it has fewer than k candidates: the caller then takes the strip path.
+constexpr int PAIRS_CAP = 8192;
+__global__ __launch_bounds__(256) void topk_pairs_kernel(const float *__restrict__ val,
+                                                         const int32_t *__restrict__ idx,
+                                                         const int32_t *__restrict__ cnt, int cap, int k,
+                                                         int64_t *out_idx, int out_ld, int32_t *status) {
+  extern __shared__ unsigned long long keys[];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const int c0 = cnt[r];
+  if (c0 > cap || c0 < k) {
+    if (tid == 0) atomicOr(status, c0 > cap ? 1 : 2);
+    return;
+  }
+  int P = 1;
+  while (P < c0) P <<= 1;
+  for (int i = tid; i < P; i += 256) {
+    unsigned long long e = 0ull;
+    if (i < c0) e = ((unsigned long long)f2key(val[(int64_t)r * cap + i]) << 32) |
+                    (uint32_t)(~(uint32_t)idx[(int64_t)r * cap + i]);
+    keys[i] = e;
+  }
+  __syncthreads();
+  for (int size = 2; size <= P; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = tid; i < P; i += 256) {
+        const int j = i ^ stride;
+        if (j > i) {
+          const bool desc = ((i & size) == 0);
+          const unsigned long long a = keys[i], b = keys[j];
+          if ((a < b) == desc) { keys[i] = b; keys[j] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < k; i += 256)
+    out_idx[(int64_t)r * out_ld + i] = (int64_t)(~(uint32_t)(keys[i] & 0xffffffffull));
+}
+
 }  // namespace
+
+extern "C" int rk_topk_pairs(const float *val, const int32_t *idx, const int32_t *cnt, int32_t B,
+                             int32_t cap, int32_t k, int64_t *out_idx, int32_t out_ld, int32_t *status,
+                             void *stream_) {
+  RK_REQUIRE(cap >= 1 && cap <= PAIRS_CAP && (cap & (cap - 1)) == 0, "cap: a power of two <= 8192");
+  RK_REQUIRE(k >= 1 && k <= cap && out_ld >= k, "k / out_ld");
+  if (B == 0) return 0;
+  RK_LAUNCH(topk_pairs_kernel, dim3(B), dim3(256), cap * 8, (hipStream_t)stream_, val, idx, cnt, cap, k,
+            out_idx, out_ld, status);
+  RK_CHECK_LAUNCH("topk_pairs");
+  return 0;
+}
+
+extern "C" int32_t rk_topk_pairs_max_cap(void) { return PAIRS_CAP; }
+
+extern "C" int rk_topk_masked_strided(const float *scores, int32_t B, int32_t n, int32_t ld,
+                                      const rk_block_t *seen, int32_t row_off, int32_t k,
+                                      int32_t col_off, int32_t col_stride, int64_t *out_idx,
+                                      float *out_val, int32_t out_ld, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(k >= 1 && k <= KMAX, "k must be in [1, 1024]");
+  RK_REQUIRE(k <= n, "k larger than the number of score columns");
+  RK_REQUIRE(out_ld >= k && col_off >= 0 && col_stride >= 1, "bad output layout");
+  RK_REQUIRE(seen == nullptr || seen->implicit || seen->pref_rc != nullptr, "explicit values need pref_rc");
+  if (B == 0) return 0;
+  rk_block_t dummy = {};
+  RK_LAUNCH(topk_masked_kernel, dim3(B), dim3(256), 0, stream, scores, n, ld,
+                     seen ? *seen : dummy, seen ? 1 : 0, row_off, k, out_idx, out_val, col_off, out_ld,
+                     col_stride);
+  RK_CHECK_LAUNCH("topk_masked");
+  return 0;
+}
 
 extern "C" int rk_topk_masked_strip(const float *scores, int32_t B, int32_t n, int32_t ld,
                                     const rk_block_t *seen, int32_t row_off, int32_t k,
                                     int32_t col_off, int64_t *out_idx, float *out_val,
                                     int32_t out_ld, void *stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  RK_REQUIRE(k >= 1 && k <= KMAX, "k must be in [1, 1024]");
-  RK_REQUIRE(k <= n, "k larger than the number of score columns");
-  RK_REQUIRE(out_ld >= k && col_off >= 0, "bad output layout");
-  RK_REQUIRE(seen == nullptr || seen->implicit || seen->pref_rc != nullptr, "explicit values need pref_rc");
-  if (B == 0) return 0;
-  rk_block_t dummy = {};
-  RK_LAUNCH(topk_masked_kernel, dim3(B), dim3(256), 0, stream, scores, n, ld,
-                     seen ? *seen : dummy, seen ? 1 : 0, row_off, k, out_idx, out_val, col_off, out_ld);
-  RK_CHECK_LAUNCH("topk_masked");
-  return 0;
+  return rk_topk_masked_strided(scores, B, n, ld, seen, row_off, k, col_off, 1, out_idx, out_val, out_ld,
+                                stream_);
 }
 
 extern "C" int rk_topk_masked(const float *scores, int32_t B, int32_t n, int32_t ld,

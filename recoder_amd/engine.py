@@ -1016,6 +1016,101 @@ class FusedEngine:
                                   self._ranges(z, B * self.h[0], stream), stream), "rk_decode_loss")
     return out
 
+  # ---- Recoder.recommend without a score matrix (include/recoder_hip.h "The fused form") ----
+  EVAL_CAND_CAP = 4096          # candidate pairs per row (a power of two <= rk_topk_pairs_max_cap)
+  EVAL_SAMPLE_MIN = 16384       # least number of sampled items
+
+  def _eval_images(self, n_items, stride):
+    """Plane images of the decoder table (all items) and of its strided sample, split once per
+    state of the weights (the Adam step counts / torch's version counter change when they do)."""
+    W, _ = self._decoder_params()
+    h = self.h[0]
+    key = (W.data_ptr(), W._version, n_items, stride, tuple(s.step for s in self.states.values()),
+           bool(self.lib.rk_gemm_plain_bf16()))
+    ev = getattr(self, "_eval_img", None)
+    if ev is not None and ev["key"] == key:
+      return ev
+    self._check_weight_range()
+    KT = -(-h // 32)
+    m = -(-n_items // stride)
+    stream = current_stream()
+    ev = dict(key=key, m=m,
+              scales=torch.zeros(64, dtype=torch.float32, device=self.device),
+              w=torch.empty(n_items * KT * 32, dtype=torch.float32, device=self.device),
+              ws=torch.empty(m * KT * 32, dtype=torch.float32, device=self.device),
+              n_dev=torch.tensor([n_items], dtype=torch.int32, device=self.device))
+    amax_w = self.ranges.data_ptr() + 64 * 4
+    check(self.lib.rk_split_image(ptr(W), n_items, h, h, amax_w, 128.0, ptr(ev["w"]), ptr(ev["scales"]), 1,
+                                  stream), "rk_split_image")
+    check(self.lib.rk_split_image(ptr(W), m, h, h * stride, amax_w, 128.0, ptr(ev["ws"]), ptr(ev["scales"]), 1,
+                                  stream), "rk_split_image")
+    sblk = Block(1, 1, n_items, self.device, negative_sampling=True, need_bits_cr=False, n_cap=m)
+    sblk.set_items(torch.arange(0, n_items, stride, dtype=torch.int32, device=self.device), m, 1)
+    ev["sblk"] = sblk
+    self._eval_img = ev
+    return ev
+
+  def recommend_fused(self, blk, B, k, n_items):
+    """Top-k item ids [B, k] (int64, device) of the users collated in `blk` (the whole catalogue as
+    columns), or None when a candidate list overflowed / a row has fewer than k unseen items (the
+    caller then decodes strip by strip)."""
+    from ._lib import RkPlanes
+    lib, h, cap = self.lib, self.h[0], self.EVAL_CAND_CAP
+    if not (self.split16 and k <= cap // 8 and h % 4 == 0):
+      return None
+    # sample size: the expected number of survivors per row is n_items * k / m -- a quarter of the list
+    m_target = max(self.EVAL_SAMPLE_MIN, -(-4 * n_items * k // cap))
+    stride = max(1, n_items // m_target)
+    ev = self._eval_images(n_items, stride)
+    m = ev["m"]
+    if m < k:
+      return None
+    stream = current_stream()
+    z = self.encode_eval(blk, 0, B)
+    KT = -(-h // 32)
+    ws = self.__dict__.setdefault("_eval_buf", {})
+    if ws.get("B", 0) < B or ws.get("m") != m or ws.get("k") != k:
+      f = dict(dtype=torch.float32, device=self.device)
+      ws.update(B=B, m=m, k=k, zimg=torch.empty(B * KT * 32, **f),
+                scores=torch.empty(B * (-(-m // 32) * 32), **f),
+                s_idx=torch.empty(B, k, dtype=torch.int64, device=self.device), s_val=torch.empty(B, k, **f),
+                thr=torch.empty(B, **f), c_val=torch.empty(B * cap, **f),
+                c_idx=torch.empty(B * cap, dtype=torch.int32, device=self.device),
+                c_cnt=torch.zeros(B + 1, dtype=torch.int32, device=self.device),
+                out=torch.empty(B, k, dtype=torch.int64, device=self.device))
+    # Z image (scale slot 0): the bound of |z| for unbounded activations, else the static scale
+    amax_z = None
+    if not self.act_bounded:
+      check(lib.rk_amax(ptr(z), B * h, ptr(self.ranges), stream), "rk_amax")
+      amax_z = ptr(self.ranges)
+    check(lib.rk_split_image(ptr(z), B, h, h, amax_z, 32.0, ptr(ws["zimg"]), ptr(ev["scales"]), 0, stream),
+          "rk_split_image")
+    _, b = self._decoder_params()
+    # 1. the strided sample: scores -> masked top k -> the k-th best is the row's bound
+    pl = RkPlanes()
+    pl.scales, pl.z, pl.w, pl.wt = ptr(ev["scales"]), ptr(ws["zimg"]), ptr(ev["ws"]), None
+    pl.h, pl.B_cap, pl.n_cap, pl.n_ld = h, B, m, -(-m // 32) * 32
+    ld = -(-m // 32) * 32
+    sblk = ev["sblk"]
+    sblk.c.S_cap = max(sblk.c.S_cap, B)        # (an item set without rows: any B)
+    check(lib.rk_decode_loss_planes(ctypes.byref(pl), B, sblk.ref, 0, ptr(b), LOSS_NONE, 0.0, 1.0,
+                                    ptr(ws["scores"]), ld, None, None, stream), "rk_decode_loss_planes")
+    stride_ = ev["key"][3]
+    check(lib.rk_topk_masked_strided(ptr(ws["scores"]), B, m, ld, blk.ref, 0, k, 0, stride_,
+                                     ptr(ws["s_idx"]), ptr(ws["s_val"]), k, stream), "rk_topk_masked_strided")
+    ws["thr"][:B].copy_(ws["s_val"][:B, k - 1])
+    # 2. the whole catalogue with the filter in the decode's epilogue
+    ws["c_cnt"].zero_()
+    status = ws["c_cnt"][-1:]                  # (behind the rows' counters)
+    check(lib.rk_decode_filter_planes(ptr(ws["zimg"]), ptr(ev["w"]), ptr(ev["scales"]), h, B, n_items, 0,
+                                      ptr(b), blk.ref, 0, ptr(ws["thr"]), ptr(ws["c_val"]), ptr(ws["c_idx"]),
+                                      ptr(ws["c_cnt"]), cap, ptr(ev["n_dev"]), stream),
+          "rk_decode_filter_planes")
+    # 3. the k best candidates of every row
+    check(lib.rk_topk_pairs(ptr(ws["c_val"]), ptr(ws["c_idx"]), ptr(ws["c_cnt"]), B, cap, k, ptr(ws["out"]),
+                            k, ptr(status), stream), "rk_topk_pairs")
+    return ws["out"][:B], status
+
   def predict_scores(self, blk, row_off, B, out, ld_out, tgt_items_blk):
     """Logits for rows of ``blk`` against the item set of ``tgt_items_blk``
     (model.py:487-511 with input_items=None: the whole catalogue)."""

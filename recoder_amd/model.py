@@ -960,6 +960,19 @@ class Recoder(object):
       lo0 = bounds[-2][0]                                         # merge it into the one before
       bounds = bounds[:-2] + [(lo0, n_items)]
     ns = len(bounds)
+    if ns > 1 and os.environ.get("RK_EVAL_FUSED", "1") != "0" and hasattr(engine, "recommend_fused"):
+      # catalogues of more than one strip: the top-k filter rides in the decode's epilogue (no score
+      # matrix, no passes over it): a strided sample of the catalogue bounds every row's k-th best
+      # score from below, the decode over all items keeps only what reaches the bound
+      # (engine.recommend_fused / include/recoder_hip.h "The fused form") -- the same ids, ties included
+      res = engine.recommend_fused(blk, B, k, n_items)
+      if res is not None:
+        out, status = res
+        host = torch.cat([out.reshape(-1), status.to(torch.int64)]).cpu().numpy()
+        if host[-1] == 0:
+          self.eval_fused_batches = getattr(self, "eval_fused_batches", 0) + 1
+          return host[:-1].reshape(B, k).copy()
+        # (a candidate list overflowed, or a row has fewer than k unseen items: strip by strip)
     width = max(hi - lo for lo, hi in bounds)
     ld = -(-width // 32) * 32
     if ws["scores"] is None or ws["scores"].numel() < B * ld:

@@ -1430,6 +1430,58 @@ def test_recommend_strips_equal_dense_topk_random_shapes(seed, monkeypatch):
   assert not np.take_along_axis(seen, got, axis=1).any()           # nothing already seen is recommended
 
 
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_recommend_fused_filter_equals_the_strips(seed, monkeypatch):
+  """Recoder.recommend with the top-k filter in the decode's epilogue (a strided sample bounds every
+  row's k-th best score; only what reaches the bound leaves the kernel; rk_topk_pairs picks the k best
+  by (score, lower id)) against the strip-by-strip path: the SAME ids, ties included (duplicated
+  decoder rows), seen items never returned; small candidate lists force the overflow fallback."""
+  from recoder_amd.data import RecommendationDataset, UsersInteractions
+  from recoder_amd.engine import FusedEngine
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder, MatrixFactorization
+  rng = np.random.RandomState(3100 + seed)
+  n_items = int(rng.choice([700, 2049, 6000]))
+  n_users = 150
+  k = int(rng.choice([1, 5, 20]))
+  strip = int(rng.choice([128, 500, 1024]))
+  B = int(rng.choice([3, 64, 130]))
+  kind = "mf" if seed % 5 == 4 else "ae"
+  act = "tanh" if seed % 2 == 0 else "relu"          # (unbounded: the Z image takes its scale from rk_amax)
+  csr = synth_csr(n_users, n_items, 12, seed=700 + seed, ratings=bool(rng.rand() < 0.5))
+  torch.manual_seed(60 + seed)
+  if kind == "ae":
+    model = DynamicAutoencoder([int(rng.choice([8, 36, 64]))], activation_type=act, sparse=False)
+  else:
+    model = MatrixFactorization(16, activation_type="none", sparse=False)
+  rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss="mse")
+  rec.train(RecommendationDataset(csr), batch_size=50, lr=1e-2, weight_decay=0.0, num_epochs=1,
+            negative_sampling=True)
+  if seed % 3 == 0:
+    # exact ties: a run of items shares one decoder row and bias
+    W, b = rec._engine()._decoder_params()
+    with torch.no_grad():
+      W[100:140] = W[100:101]
+      b[100:140] = b[100]
+  cap = int(rng.choice([64, 256, 4096])) if k <= 5 else 4096
+  monkeypatch.setattr(FusedEngine, "EVAL_CAND_CAP", cap)
+  monkeypatch.setattr(FusedEngine, "EVAL_SAMPLE_MIN", int(rng.choice([64, 200, 512])))
+  monkeypatch.setattr(type(rec), "eval_strip_items", strip, raising=False)
+  users = rng.permutation(n_users)[:B]
+  ui = UsersInteractions(users=users, interactions_matrix=csr[users])
+  rec.eval_fused_batches = 0
+  got = rec.recommend_array(ui, k)
+  fused = rec.eval_fused_batches
+  monkeypatch.setenv("RK_EVAL_FUSED", "0")
+  want = rec.recommend_array(ui, k)
+  assert rec.eval_fused_batches == fused
+  assert np.array_equal(got, want), dict(n_items=n_items, k=k, B=B, kind=kind, cap=cap, fused=fused)
+  if cap == 4096:
+    assert fused == 1                                  # (the filter really ran)
+  seen = csr[users].toarray() > 0
+  assert not np.take_along_axis(seen, got, axis=1).any()
+
+
 def test_topk_tie_rule_and_strip_merge():
   """rk_topk_masked: exact ties resolve to the LOWER item id; only POSITIVE stored interactions are
   masked (model.py:537); the strip-wise top-k + merge equals the one-pass top-k."""
