@@ -366,14 +366,25 @@ def main():
 
   SAMPLE_POST = os.environ.get("RK_BENCH_SAMPLE", "timed") == "post"
 
+  def bracket_first(K):
+    # the whole group of the timed region that is enqueued eagerly with its launch groups bracketed
+    # (HIP events cannot sit inside a replayed graph on this runtime): the SECOND one when there are
+    # three or more -- the host needs ~4x longer to enqueue a group launch by launch than to replay
+    # it, which behind a queued group and in front of cheap replays costs the GPU nothing, while as
+    # the LAST group (rounds 1-3) it set the end of the timed region -- else the last one
+    n_groups = K // G
+    if n_groups >= 3:
+      return W + G
+    return W + (n_groups - 1) * G if n_groups >= 2 else W + K
+
   def plan_timed(i):
-    # timed region: the LAST whole group is enqueued eagerly with every launch group bracketed
-    # (HIP events cannot sit inside a replayed graph); everything else is graph replay
+    # timed region: ONE whole group is enqueued eagerly with every launch group bracketed;
+    # everything else is graph replay
     if SAMPLE_POST:
       return "all" if W + K <= i < W + K + G else None
     # -- and of that group only as many steps as a 5 % sample of K (every bracket costs two event
     # records = two barrier packets in the queue)
-    last = W + ((K // G) - 1) * G if K >= 2 * G else W + K
+    last = bracket_first(K)
     n_br = min(G, max(1, K // 20))
     # (the group's other steps bracket the dominant launch only: more samples of the kernel the
     # roofline is quoted on for one event pair each)
@@ -389,7 +400,8 @@ def main():
     gs = getattr(rec, "_graph_stepper", None)
     T["timed_graph"] = False
     if gs is not None and not SAMPLE_POST and K >= 2 * G:
-      T["timed_graph"] = bool(gs.prepare_timed(gs.global_step + ((K // G) - 1) * G))
+      first = bracket_first(K) - W
+      T["timed_graph"] = bool(gs.prepare_timed(gs.global_step + first, lookahead=(K - first) > G))
     sync_all()
     T["t0"] = time.perf_counter()
     return False

@@ -123,11 +123,16 @@ class GraphStepper:
     """rk_collate_at for several blocks (cursor offsets off0, off0 + 1, ...) in ONE set of launches."""
     d = self.dcsr
     n = len(blks)
-    arr = (ctypes.POINTER(_lib.RkBlock) * n)()
-    for g, blk in enumerate(blks):
-      blk.c.implicit = 1 if d.data is None else 0
-      blk.S = self.B
-      arr[g] = ctypes.pointer(blk.c)
+    cache = self.__dict__.setdefault("_blk_arrays", {})
+    key = tuple(id(blk) for blk in blks)
+    arr = cache.get(key)
+    if arr is None:                       # (built once per block list: this sits on the restart path)
+      arr = (ctypes.POINTER(_lib.RkBlock) * n)()
+      for g, blk in enumerate(blks):
+        blk.c.implicit = 1 if d.data is None else 0
+        blk.S = self.B
+        arr[g] = ctypes.pointer(blk.c)
+      cache[key] = arr
     args = (ptr(d.indptr), ptr(d.indices), ptr(d.data), ptr(self.order), self.B, 1 if self.ns else 0,
             self._cur(slot), off0, arr, n)
     if self.dp is None:
@@ -245,6 +250,7 @@ class GraphStepper:
     self.table.copy_(th, non_blocking=False)
     self.global_step = int(global_step)
     self.epoch_base = int(global_step)
+    self._cursor_at = None
     self._collated = None                # slot whose blocks hold the steps at the cursor
     return n_full
 
@@ -269,8 +275,7 @@ class GraphStepper:
       # stamps (rk_cur_stamp) -- but possibly other users (the padding behind an epoch's last
       # step), and a block collated twice in a row with one stamp keeps the first set's items.
       slot = 1 - self._la_slot
-      check(lib.rk_cursor_set(self._cur(slot), self.global_step, self.epoch_base, self._h(self.main)),
-            "rk_cursor_set")
+      self._set_cursor(slot)
     else:
       slot = self._collated
     done = 0
@@ -283,10 +288,10 @@ class GraphStepper:
         # object loaded) before it is captured -- graphs captured cold replayed ~8x slower on the
         # host -- and the graphs are captured right behind it (capturing enqueues nothing), i.e.
         # in the warm-up of a benchmark, never inside its timed region
-        timed = self.exec_timed.get((slot, idx0)) if (eager and self.warmed and not need_pre and
-                                                      left == G) else None
+        timed = self.exec_timed.get((slot, idx0, left > G)) if (eager and self.warmed and
+                                                                not need_pre) else None
         if timed is not None:
-          la = False                       # a bracketed group, captured with its events (prepare_timed)
+          la = left > G                    # a bracketed group, captured with its events (prepare_timed)
           check(lib.rk_graph_launch(timed, self._h(self.main)), "rk_graph_launch")
         elif eager or not self.warmed:
           if need_pre:
@@ -323,21 +328,22 @@ class GraphStepper:
     if la:
       self._la_slot = slot               # (remembered across cuts / epochs: see the restart above)
 
-  def prepare_timed(self, first_index):
+  def prepare_timed(self, first_index, lookahead=False):
     """Capture, for both slots, the group of G steps starting at global step `first_index` WITH the
     timing events the engine's time plan asks for (event-record nodes: csrc/step.hip timer_record),
-    without the look-ahead collation (run() ends with that group).  bench.py calls this in front of
-    its timed region; run() then replays it instead of enqueueing the bracketed group eagerly."""
+    with or without the look-ahead collation (without: run() ends with that group).  bench.py calls
+    this in front of its timed region; run() then replays it instead of enqueueing the bracketed
+    group eagerly."""
     if not self.warmed or os.environ.get("RK_TIMED_GRAPH", "1") == "0" or \
         not self.lib.rk_graph_timing_supported():
       return False
     from ._lib import ENTRY
     self.eng.reserve_timing_events(2 * self.G * 2 * (max(ENTRY.values()) + 1))   # (created outside the capture)
     for v in (0, 1):
-      key = (v, int(first_index))
+      key = (v, int(first_index), bool(lookahead))
       if key not in self.exec_timed:
         self.exec_timed[key] = self._capture(
-            lambda v=v: self._group(v, self.G, first_index=int(first_index), lookahead=False))
+            lambda v=v: self._group(v, self.G, first_index=int(first_index), lookahead=bool(lookahead)))
     return True
 
   def _warm_capture(self):
@@ -355,8 +361,20 @@ class GraphStepper:
         self.exec_first[v] = self._capture(lambda v=v: (self._pre_collate(G, v), self._group(v)))
 
   def cut(self):
-    """Forget the look-ahead blocks (a step mark / an eager ragged step follows)."""
+    """Forget the look-ahead blocks (a step mark / an eager ragged step follows).  The cursor of the
+    slot the next run() restarts on is pointed at the next step HERE (a one-thread launch that knows
+    nothing of the steps to come: it need not sit between a caller's mark and its first step)."""
     self._collated = None
+    if self.warmed:
+      self._set_cursor(1 - self._la_slot)
+
+  def _set_cursor(self, slot):
+    key = (slot, self.global_step, self.epoch_base)
+    if getattr(self, "_cursor_at", None) == key:
+      return
+    check(self.lib.rk_cursor_set(self._cur(slot), self.global_step, self.epoch_base, self._h(self.main)),
+          "rk_cursor_set")
+    self._cursor_at = key
 
   def _slot_items(self):
     """(table slot, state name) of every parameter the replayed steps update."""
@@ -366,6 +384,7 @@ class GraphStepper:
     return [(k, name) for k, name in _PAR_NAMES.items() if not (k == PAR_W_DE and tied)]
 
   def _advance_host(self, k):
+    self._cursor_at = None               # (the group's last Adam launch moved the cursors)
     self.global_step += k
     S = self.eng.states
     for _, name in self._slot_items():
