@@ -369,9 +369,11 @@ def main():
   def bracket_first(K):
     # the whole group of the timed region that is enqueued eagerly with its launch groups bracketed
     # (HIP events cannot sit inside a replayed graph on this runtime): the SECOND one when there are
-    # three or more -- the host needs ~4x longer to enqueue a group launch by launch than to replay
-    # it, which behind a queued group and in front of cheap replays costs the GPU nothing, while as
-    # the LAST group (rounds 1-3) it set the end of the timed region -- else the last one
+    # three or more -- the host needs ~0.55 ms to enqueue a group launch by launch against 0.03 ms to
+    # replay it, which behind a queued group and in front of cheap replays costs the GPU less than as
+    # the LAST group (rounds 1-3), where it set the end of the timed region (20 steps: 0.137-0.138 vs
+    # 0.142-0.145 ms; the third group instead: 0.139-0.140 -- the event records themselves, barrier
+    # packets between the launches, keep ~12 us per bracketed step) -- else the last one
     n_groups = K // G
     if n_groups >= 3:
       return W + G
