@@ -598,8 +598,14 @@ int rk_graph_begin(void *stream);
 void *rk_graph_end(void *stream);              /* -> executable graph handle, NULL on error */
 int rk_graph_launch(void *graph_exec, void *stream);
 /* != 0: rk_ae_train_step's timing events (time_ev0 / time_all) may be used INSIDE a capture -- they
- * become event-record nodes that every replay re-records.  Depends on the HIP runtime in the process. */
+ * become event-record nodes that every replay re-records.  Depends on the HIP runtime in the process:
+ * hipEventRecordWithFlags(hipEventRecordExternal) where it is accepted (ROCm 7.2); with
+ * RK_GRAPH_EVENT_NODES=1 also nodes added with hipGraphAddEventRecordNode at the capture's current
+ * dependencies (works on the 7.0 runtime PyTorch bundles; off by default: no faster than the eager
+ * brackets there and its intervals read longer); rk_graph_event_node_probe runs that route once on a scratch stream and returns the
+ * interval (ms) it read between two such nodes, or a negative code. */
 int32_t rk_graph_timing_supported(void);
+float rk_graph_event_node_probe(void);
 void rk_graph_destroy(void *graph_exec);
 /* cross-stream edges inside a capture (fork / join): event from rk_event_create */
 int rk_event_record(void *event, void *stream);

@@ -197,6 +197,7 @@ SIGNATURES = {
   "rk_graph_end": (c_void_p, [_P]),
   "rk_graph_launch": (c_int32, [_P, _P]),
   "rk_graph_timing_supported": (c_int32, []),
+  "rk_graph_event_node_probe": (c_float, []),
   "rk_graph_destroy": (None, [_P]),
   "rk_event_record": (c_int32, [_P, _P]),
   "rk_stream_wait_event": (c_int32, [_P, _P]),
