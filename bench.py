@@ -52,14 +52,18 @@ DW_BF16X3 = os.environ.get("RK_DW_PREC", "").lower().startswith("bf16x3")
 PRODUCTS = {"rk_decode_loss": 3, "rk_decode_bwd_dz": 3, "rk_decode_bwd_dw": 6 if DW_BF16X3 else 3,
             "rk_decode_bwd_dw3": 6}
 ENTRIES = ["rk_ae_encode_fwd", "rk_decode_loss", "rk_decode_bwd_dz", "rk_decode_bwd_dw",
-           "rk_ae_encode_bwd", "rk_adam_multi"]
+           "rk_ae_encode_bwd", "rk_adam_multi", "rk_adam_de"]
+# rk_adam_de_side() (csrc/step.hip): the decoder table's Adam sweep is a launch of its own on the dW
+# stream ("rk_adam_de"), the step's update launch ("rk_adam_multi") covers the rest -- the SAME kernel
+# twice per step; set in main() from the library
+ADAM_DE_SIDE = False
 # the kernels each bracketed entry launches (names as rocprofv3 --kernel-trace prints them)
 KERNELS = {"rk_ae_encode_fwd": ["ae_encode_fwd_kernel (+ the W_de[items] split workgroups)"],
            "rk_decode_loss": ["decode_planes_kernel<TM,2,EPI>"],
            "rk_decode_bwd_dz": ["dz_planes_kernel<TN>", "splitk_reduce_kernel"],
            "rk_decode_bwd_dw": ["dw3_kernel<BN,PLAIN,PAIRS> (+ split_planes_t_kernel when the encoder did not write Z^T)"],
            "rk_ae_encode_bwd": ["ae_encode_bwd_cols_kernel", "ae_encode_bwd_kernel"],
-           "rk_adam_multi": ["adam_multi_kernel"]}
+           "rk_adam_multi": ["adam_multi_kernel"], "rk_adam_de": ["adam_multi_kernel"]}
 
 CONFIGS = {
   # C2 of BASELINE.json: ML-20M autoencoder, hidden [200], MSE, 1 x MI355X
@@ -127,9 +131,17 @@ def algorithmic_work(entry, B, h0, n_b, nnz, n_items, cfg_sparse=False):
     slabs = 1 if GEMM_F32 else max(1, min(256 // max(tiles, 1), 4, (-(-B // 64) * 64) // 64))
     extra = (slabs - 1) * n_b * h0 * 4
     if cfg_sparse:
-      return "hbm", (2 * n_b * h0 * 28 + extra + n_items * 28 + n_b * 32) / 1e9, "GB/s"
-    return "hbm", (2 * (n_items * h0 * 24 + n_b * h0 * 4 + n_items * 4) + extra
-                   + n_items * 28 + n_b * 32 + h0 * 28) / 1e9, "GB/s"
+      table, rest = n_b * h0 * 28, n_items * 28 + n_b * 32
+    else:
+      table, rest = n_items * h0 * 24 + n_b * h0 * 4 + n_items * 4, n_items * 28 + n_b * 32 + h0 * 28
+    if ADAM_DE_SIDE:        # this launch: the encoder table + the small tensors
+      return "hbm", (table + rest) / 1e9, "GB/s"
+    return "hbm", (2 * table + extra + rest) / 1e9, "GB/s"
+  if entry == "rk_adam_de":  # the decoder table behind dW (its gradient arrives as K slabs, summed here)
+    tiles = -(-int(n_b) // 64) * -(-h0 // (128 if h0 <= 128 else 256))
+    slabs = 1 if GEMM_F32 else max(1, min(256 // max(tiles, 1), 4, (-(-B // 64) * 64) // 64))
+    table = n_b * h0 * 28 if cfg_sparse else n_items * h0 * 24 + n_b * h0 * 4 + n_items * 4
+    return "hbm", (table + (slabs - 1) * n_b * h0 * 4) / 1e9, "GB/s"
   return "hbm", 0.0, "GB/s"
 
 
@@ -500,6 +512,10 @@ def main():
     n_b, nnz = float(np.mean(nbs)), float(np.mean(nnzs))
     ev_over = eng.event_pair_overhead_ms()
     timed = eng.timed_samples_ms()
+    global ADAM_DE_SIDE
+    from recoder_amd import _lib as _rk_lib
+    ADAM_DE_SIDE = bool(_rk_lib.load().rk_adam_de_side()) and getattr(eng, "ws_dw", None) is not None and \
+        not multi and bool(timed.get("rk_adam_de") or T["warm"].get("rk_adam_de"))
 
     def line(entry, ms_list, where):
       # median of the bracketed launches (the first bracketed call of a kernel includes its
@@ -552,7 +568,24 @@ def main():
       kernels = [dict(name="rk_adam_multi", kernels=KERNELS.get("rk_adam_multi", []), avg_us=float("nan"),
                       samples=0, sampled="none", bound="hbm", achieved=float("nan"), peak=PEAK_HBM_GBS,
                       unit="GB/s", frac=float("nan"), ideal_us=float("nan"))]
-    dom = max(kernels, key=lambda k: (k["avg_us"] if k["avg_us"] == k["avg_us"] else -1.0))
+    # the dominant KERNEL: the one the step spends most time in, over all its launches (the Adam sweep
+    # runs as two launches of adam_multi_kernel when the decoder table's half sits on the dW stream)
+    by_kernel = {}
+    for k in kernels:
+      if k["avg_us"] == k["avg_us"]:
+        key = tuple(k["kernels"]) if k["name"] in ("rk_adam_multi", "rk_adam_de") else (k["name"],)
+        by_kernel.setdefault(key, []).append(k)
+    group = max(by_kernel.values(), key=lambda ks: sum(k["avg_us"] * k.get("launches_per_step", 1) for k in ks)) \
+        if by_kernel else [kernels[0]]
+    dom = group[0]
+    if len(group) > 1:
+      # several launches of one kernel per step: bytes of all of them over the time of all of them,
+      # the average launch duration (what rocprofv3 --stats reports for the kernel)
+      tot_us = sum(k["avg_us"] for k in group)
+      work = sum(k["achieved"] * k["avg_us"] for k in group)          # (GB/s * us: bytes up to a constant)
+      dom = dict(group[0], name="+".join(k["name"] for k in group), avg_us=tot_us / len(group),
+                 achieved=work / tot_us, frac=work / tot_us / group[0]["peak"],
+                 samples=min(k["samples"] for k in group), launches_per_step=len(group))
     dominant = dom["name"]
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload
     # (profiles/r*_pmc_traffic.json, tools/pmc_traffic.py); null for other configs
@@ -561,7 +594,7 @@ def main():
       import glob
       files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
       if files:
-        ent = json.load(open(files[-1]))["entries"].get(dominant)
+        ent = json.load(open(files[-1]))["entries"].get(dominant.split("+")[0])
         if ent:
           traffic = ent["hbm_bytes_per_launch"]
           traffic_source = ("%s: committed rocprofv3 PMC passes of this command (FETCH_SIZE / WRITE_SIZE in "
@@ -569,7 +602,7 @@ def main():
                             % os.path.relpath(files[-1], ROOT))
     # the dW launch group runs on the side stream NEXT to dZ -> encoder backward
     # (rk_ae_step_t.dw_stream): it is not a link of the step's chain then
-    side = ["rk_decode_bwd_dw"] if (getattr(eng, "ws_dw", None) is not None and not multi) else []
+    side = ["rk_decode_bwd_dw", "rk_adam_de"] if (getattr(eng, "ws_dw", None) is not None and not multi) else []
     for k in kernels:
       if k["name"] in side:
         k["concurrent_with"] = ["rk_decode_bwd_dz", "rk_ae_encode_bwd"]

@@ -278,6 +278,13 @@ int rk_decode_bwd_dw2(const float *dO, const float *Z, int32_t B, int32_t h,
                       const void *zt_planes /* nullable */, const int32_t *ranges /* nullable */,
                       void *stream);
 int32_t rk_dw_pairs(void);
+/* != 0 (RK_ADAM_DE_SIDE=1; off by default): whole steps with a dw_stream run the decoder table's
+ * Adam sweep as a launch of its own right behind the dW kernel ON dw_stream -- it needs nothing else
+ * of the step -- next to the split-K reduce and the encoder backward of the chain (both
+ * latency-bound); the update on the chain covers the encoder table, the biases and the loss.  Same
+ * jobs, same arithmetic: bit-identical.  C2: 0.1219 vs 0.1234 ms per step, the two sweeps then read
+ * 0.52 of the HBM peak (they share the chip) instead of 0.68 for the one. */
+int32_t rk_adam_de_side(void);
 /* The Z^T planes of rk_decode_bwd_dw3 can be written by the kernel that produces Z:
  * rk_ae_encode_fwd_planes = rk_ae_encode_fwd + the three bf16 planes of its output, into a
  * buffer of rk_dw3_planes_bytes(B, h) bytes that the caller allocated ZEROED (16-byte aligned;
@@ -418,7 +425,10 @@ int rk_scatter_pos(int32_t *pos, const int64_t *rows, int32_t B, int32_t clear,
 enum { RK_PAR_W_EN = 0, RK_PAR_B_EN = 1, RK_PAR_W_DE = 2, RK_PAR_B_DE = 3, RK_PAR_COUNT = 4 };
 enum { RK_ENTRY_NONE = 0, RK_ENTRY_ENCODE_FWD = 1, RK_ENTRY_DECODE_LOSS = 2,
        RK_ENTRY_DECODE_BWD_DZ = 3, RK_ENTRY_DECODE_BWD_DW = 4, RK_ENTRY_ENCODE_BWD = 5,
-       RK_ENTRY_ADAM_MULTI = 6, RK_ENTRY_COUNT = 7,
+       RK_ENTRY_ADAM_MULTI = 6,
+       RK_ENTRY_ADAM_DE = 7 /* the decoder table's Adam sweep when it runs behind dW on dw_stream
+                               (rk_adam_de_side): the same kernel as ADAM_MULTI, a launch of its own */,
+       RK_ENTRY_COUNT = 8,
        RK_ENTRY_ALL = -1 /* bracket every entry: rk_ae_step_t.time_all */ };
 /* rk_ae_step_t.phase: which part of the step to enqueue (0 = all).  Data parallel
  * callers run FWD_DW, all-reduce the decoder-side gradients, DZ_ENC, all-reduce the

@@ -46,7 +46,7 @@ class RkAdamParam(Structure):
 PAR_W_EN, PAR_B_EN, PAR_W_DE, PAR_B_DE = 0, 1, 2, 3
 ENTRY_ALL = -1
 ENTRY = {"rk_ae_encode_fwd": 1, "rk_decode_loss": 2, "rk_decode_bwd_dz": 3, "rk_decode_bwd_dw": 4,
-         "rk_ae_encode_bwd": 5, "rk_adam_multi": 6}
+         "rk_ae_encode_bwd": 5, "rk_adam_multi": 6, "rk_adam_de": 7}
 
 
 class RkAeStep(Structure):
@@ -152,6 +152,7 @@ SIGNATURES = {
   "rk_decode_bwd_dw3": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, _P, _P]),
   "rk_decode_bwd_dw2": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, _P, _P, _P]),
   "rk_dw_pairs": (c_int32, []),
+  "rk_adam_de_side": (c_int32, []),
   "rk_dw3_planes_bytes": (c_int64, [c_int32, c_int32]),
   "rk_dw3_rows_pad": (c_int32, [c_int32]),
   "rk_dw3_cols_pad": (c_int32, [c_int32]),

@@ -11,6 +11,7 @@
 // SparseAdam: torch.optim.SparseAdam (`_functional.sparse_adam`) on the touched
 //            rows only (model.py:138,401-402): no weight decay, eps added to
 //            the raw sqrt, bias correction folded into the step size.
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -538,6 +539,14 @@ int rk_adam_multi_at(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part
   RK_LAUNCH(adam_multi_kernel, dim3(blocks), dim3(256), 0, stream, a);
   RK_CHECK_LAUNCH("adam_multi");
   return 0;
+}
+
+// RK_ADAM_DE_SIDE=1: the decoder table's sweep as a launch of its own behind dW on dw_stream (off by
+// default: +1.2 % throughput at C2, but the sweep then shares the chip with the encoder backward and
+// reads 0.52 of the HBM peak instead of 0.68 -- DESIGN.md section 4)
+extern "C" int32_t rk_adam_de_side(void) {
+  static const int on = [] { const char *e = getenv("RK_ADAM_DE_SIDE"); return (e && atoi(e) == 1) ? 1 : 0; }();
+  return on;
 }
 
 extern "C" int rk_adam_multi(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part,

@@ -414,6 +414,10 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   // dW on a stream of its own next to the dZ -> encoder-backward chain (rk_ae_step_t.dw_stream)
   const bool dw_branch = dw3 && a->dw_stream != nullptr;
   RK_REQUIRE(!dw_branch || (a->ws_dw && a->dw_fork && a->dw_join), "dw_stream needs ws_dw, dw_fork, dw_join");
+  // the decoder table's Adam sweep right behind the dW kernel ON dw_stream (it needs nothing else),
+  // next to the reduce / encoder backward of the chain; the update on the chain then covers the
+  // encoder table, the biases and the loss (rk_adam_de_side; RK_ADAM_DE_SIDE=0: one launch)
+  const bool de_side = dw_branch && phase == RK_STEP_ALL && rk_adam_de_side() != 0;
 
   // pre-split operand planes (decode16.hip): W_de[items] is split by extra workgroups of the
   // encoder-forward launch, Z by that kernel's epilogue; decode and dZ copy the images into LDS
@@ -494,8 +498,10 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
         Timer t(a, RK_ENTRY_DECODE_BWD_DW, a->dw_stream);
         RK_TRY(dw_call(a, nullptr, nullptr, planes, a->ws_dw, a->dw_stream));
       }
-      RK_TRY(rk_event_record(a->dw_join, a->dw_stream));
-      RK_TRY(rk_stream_wait_event(sm, a->dw_join));
+      if (!de_side) {
+        RK_TRY(rk_event_record(a->dw_join, a->dw_stream));
+        RK_TRY(rk_stream_wait_event(sm, a->dw_join));
+      }
     } else if (dw3) {
       // the dZ slabs in the workspace are consumed: the bf16-pipe dW takes it over (Z^T planes +
       // its own K slabs, which rk_adam_multi sums while it reads the gradient)
@@ -529,7 +535,18 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
         jobs[n].g_stride = blk->n_cap * h; jobs[n].gparts_dev = blk->counts + 4;
       }
       slots[n] = RK_PAR_W_DE;
-      ++n;
+      if (de_side) {
+        const int32_t sl = RK_PAR_W_DE;
+        {
+          Timer t(a, RK_ENTRY_ADAM_DE, a->dw_stream);
+          RK_TRY(rk_adam_multi_at(&jobs[n], 1, nullptr, 0, a->denom, nullptr, a->cursor, a->cursor_off,
+                                  a->adam_table, RK_PAR_COUNT, &sl, nullptr, 0, a->dw_stream));
+        }
+        RK_TRY(rk_event_record(a->dw_join, a->dw_stream));
+        RK_TRY(rk_stream_wait_event(sm, a->dw_join));
+      } else {
+        ++n;
+      }
     }
     slots[n] = RK_PAR_B_DE;
     jobs[n] = table_job(a->par[RK_PAR_B_DE], blk, n_items, 1, a->gb_de, true);
