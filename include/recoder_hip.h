@@ -278,6 +278,19 @@ int rk_decode_bwd_dw2(const float *dO, const float *Z, int32_t B, int32_t h,
                       const void *zt_planes /* nullable */, const int32_t *ranges /* nullable */,
                       void *stream);
 int32_t rk_dw_pairs(void);
+/*
+ * rk_decode_bwd_dw2 (the K slabs stay in the workspace, as with G_de == NULL) and rk_ae_encode_bwd in
+ * ONE launch: its first workgroups run the dW tiles, the others the encoder backward's columns.  Both
+ * depend only on what is in front of them in the step and write disjoint outputs; as two launches
+ * they cost the chain 16 + 14 us in line, or a side stream's two cross-queue edges.  Domain:
+ * rk_dw_encode_bwd_fused_ok (fp16-pair dW, row window of <= 64 bitmap words; RK_DW_ENC_FUSED=0: off).
+ */
+int32_t rk_dw_encode_bwd_fused_ok(int32_t row_off, int32_t B);
+int rk_decode_bwd_dw2_encode_bwd(const float *dO, const float *Z /* nullable with zt_planes */, int32_t B,
+                                 int32_t h, const rk_block_t *tgt, void *workspace,
+                                 const void *zt_planes /* nullable */, const int32_t *ranges /* nullable */,
+                                 int32_t row_off, const float *dZ0pre, float *G_en,
+                                 float *gb_en /* nullable */, void *stream);
 /* != 0 (RK_ADAM_DE_SIDE=1; off by default): whole steps with a dw_stream run the decoder table's
  * Adam sweep as a launch of its own right behind the dW kernel ON dw_stream -- it needs nothing else
  * of the step -- next to the split-K reduce and the encoder backward of the chain (both
@@ -340,6 +353,24 @@ int64_t rk_planes_bytes(int32_t B_cap, int32_t h, int32_t n_cap);
 /* tuning / test hook: rows of a decode tile, 128 or 64 (the tile shape of rk_decode_loss); 0 = by
  * the problem's size (default) */
 void rk_planes_tile(int32_t rows);
+/*
+ * The decode + loss of rk_decode_loss_planes (MSE / BCE, 64 x 128 tiles) with dZ FUSED: every workgroup
+ * multiplies the dO tile it has just computed (kept in LDS, cut into fp16 pairs with the TILE's own
+ * power-of-two scale) with its 128 items of the W^T image and writes the partial dZ[64 rows, h] into
+ * slab (column tile) of dz_workspace [ceil(n_cap / 128)][B][h]; rk_decode_dz_reduce sums the live
+ * slabs (* act'(Zact) if given) into dZ.  Replaces rk_decode_loss_planes + rk_decode_bwd_dz_planes
+ * (one launch, one pass over dO and one cross-queue edge less); same mathematics, other split scales
+ * and summation grouping than the stand-alone kernel (agreement ~1e-7 relative).  Shapes / losses:
+ * rk_decode_dz_fused_ok (h <= 256, B < 1024 and n_cap < 32768: the 64-row tile's domain; RK_DZ_FUSED=0
+ * turns it off).
+ */
+int32_t rk_decode_dz_fused_ok(int32_t B, int32_t h, int32_t n_cap, int32_t loss_kind);
+int64_t rk_dz_fused_workspace_bytes(int32_t B, int32_t h, int32_t n_cap);
+int rk_decode_loss_dz_planes(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off,
+                             const float *b_de, int32_t loss_kind, float confidence, float inv_B, float *dO,
+                             float *loss_part, float *gb_part, float *dz_workspace, void *stream);
+int rk_decode_dz_reduce(const float *dz_workspace, int32_t B, int32_t h, const rk_block_t *tgt,
+                        const float *Zact /* nullable */, int32_t act, float *dZ, void *stream);
 /* tuning probe (tools/probes/planes_phase_probe.py): device buffer of 8 uint64 per workgroup of the
  * largest grid, or NULL (default) to switch it off */
 void rk_planes_probe(unsigned long long *buffer);

@@ -153,6 +153,13 @@ SIGNATURES = {
   "rk_decode_bwd_dw2": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, _P, _P, _P]),
   "rk_dw_pairs": (c_int32, []),
   "rk_adam_de_side": (c_int32, []),
+  "rk_dw_encode_bwd_fused_ok": (c_int32, [c_int32, c_int32]),
+  "rk_decode_bwd_dw2_encode_bwd": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, c_int32, _P, _P, _P, _P]),
+  "rk_decode_dz_fused_ok": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
+  "rk_dz_fused_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
+  "rk_decode_loss_dz_planes": (c_int32, [_P, c_int32, _BLK, c_int32, _P, c_int32, c_float, c_float, _P, _P, _P,
+                                         _P, _P]),
+  "rk_decode_dz_reduce": (c_int32, [_P, c_int32, c_int32, _BLK, _P, c_int32, _P, _P]),
   "rk_dw3_planes_bytes": (c_int64, [c_int32, c_int32]),
   "rk_dw3_rows_pad": (c_int32, [c_int32]),
   "rk_dw3_cols_pad": (c_int32, [c_int32]),

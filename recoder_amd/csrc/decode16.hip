@@ -90,6 +90,10 @@ struct DecP {
   float confidence, inv_B;
   float *loss_part;
   float *gb_part;
+  // fused dZ (DZT > 0): the W^T image, the slabs [column tile][M][h] and h
+  const char *wtp;
+  float *dz_ws;
+  int h;
   // filter epilogue: column n is item col_off + n; blk = the users' INPUT block over the whole
   // catalogue (seen items), has_seen == 0: nothing is masked
   const float *thr;           // [M]
@@ -103,10 +107,22 @@ struct DecP {
 // register prefetch of the next k-tile, ONE barrier per k-tile, every LDS read of a tile ahead of
 // its MFMAs (tools/probes/presplit_gemm.hip: 15 us at the C2 shape against 24 for the in-loop split).
 // PLAIN: bf16 images, ONE product (RK_GEMM_PREC=bf16: the separate bf16 data point)
-template <int TM, int TN, int EPI, int RD = 3, bool PLAIN = false>
+// DZT > 0 (64 x 128 tiles, loss epilogues): dZ FUSED -- the workgroup keeps its dO tile (fp32, in LDS),
+// cuts it into fp16 pairs with the TILE's own power-of-two scale (its maximum is known here; the
+// stand-alone dZ kernel has to take the launch-wide one the loss epilogues publish) and multiplies it
+// with the tile's 128 items of the W^T image: dZ partial [64 rows, h] of column tile nt -> slab nt of
+// the split-K workspace, summed by rk_splitk_reduce like the stand-alone kernel's K slabs (62 against
+// 64 at C2).  One launch, one pass over dO and one cross-queue edge less.  DZT = ceil(h / 32) <= 8.
+template <int TM, int TN, int EPI, int RD = 3, bool PLAIN = false, int DZT = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 void decode_planes_kernel(DecP p) {
   constexpr int BM = 64 * TM, BN = 64 * TN;
+  static_assert(DZT == 0 || (TM == 1 && TN == 2 && !PLAIN && (EPI == EPI_LOSS_MSE || EPI == EPI_LOSS_BCE)),
+                "the fused dZ rides on the 64 x 128 loss tiles");
+  constexpr int DT_LD = 132;                              // floats per row of the dO tile in LDS
+  constexpr int DT_OFF = 256 * ROWB;                      // its byte offset (behind the W^T stage: <= 256 rows)
+  constexpr int B2_ROWS = 32 * (DZT > 0 ? DZT : 1);       // rows of a W^T k-tile staged (>= kp_of(h))
+  constexpr int B2_PT = (B2_ROWS * 8 + 255) / 256;
   constexpr int STAGE = (BM + BN) * ROWB;
   constexpr int A_PT = BM / 32, B_PT = BN / 32;          // 16-byte pieces per thread and k-tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -261,6 +277,21 @@ void decode_planes_kernel(DecP p) {
 #undef SSTORE
 
   RK_STAMP(2);
+  // fused dZ: the first k-tile of the W^T image (the tile's first 32 items, every hidden unit) is
+  // fetched NOW, under the epilogue
+  const char *srcB2[B2_PT];
+  int dstB2[B2_PT];
+  u32x4 rw2[B2_PT];
+  const int Hp2 = rkp::kp_of(p.h);
+  if (DZT > 0) {
+#pragma unroll
+    for (int i = 0; i < B2_PT; ++i) {
+      const int idx = min(tid + 256 * i, B2_ROWS * 8 - 1), row = idx >> 3, piece = idx & 7;
+      srcB2[i] = p.wtp + ((int64_t)(n0 >> 5) * Hp2 + min(row, Hp2 - 1)) * rkp::LINE + piece * 16;
+      dstB2[i] = row * ROWB + piece * 16;
+    }
+    ld_pieces(rw2, srcB2, 0);
+  }
   // ------------------------------------------------------------- epilogues (as gemm.hip)
   {
     const float inv = 1.0f / (p.scales[0] * p.scales[1]);       // exact: powers of two
@@ -422,6 +453,10 @@ void decode_planes_kernel(DecP p) {
           // (the tiles cover [0, ld): ld = round_up(N, 32) and BN is a multiple of 32)
           if (m < M && n < ldc)
             *reinterpret_cast<float4 *>(p.C + (int64_t)m * ldc + n) = make_float4(g[0], g[1], g[2], g[3]);
+          if (DZT > 0)      // (rows past M / columns past N hold zeros: g was zeroed above)
+            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(smem + DT_OFF) +
+                                        ((wm * TM + i) * 32 + rr0 + 8 * it) * DT_LD + (wn * TN + j) * 32 + c4 * 4) =
+                make_float4(g[0], g[1], g[2], g[3]);
         }
       }
       // column sums over this wave's rows: lanes with equal c4 hold different rows
@@ -458,6 +493,79 @@ void decode_planes_kernel(DecP p) {
             if (m0 + g * 64 < M) p.gb_part[(int64_t)(mt * 2 + g) * ldc + n] = cpart[g * BN + tid];
         }
       }
+    }
+  }
+  if (DZT > 0) {
+    // ---------------------------------------------------------------- fused dZ partial of this tile
+    constexpr int T2A = DZT > 0 ? (DZT + 1) / 2 : 1;     // column tiles (32 hidden units) per wave
+    float *lred2 = fsm + 4 * (32 * TLD);
+    const float gm = fmaxf(fmaxf(lred2[4], lred2[5]), fmaxf(lred2[6], lred2[7]));   // the tile's max |dO|
+    float s_do = 1.0f;
+    if (gm > 0.f) {
+      const int e = min(max((int)(__float_as_uint(gm) >> 23) - 127, -100), 100);
+      s_do = __uint_as_float((uint32_t)(13 - e + 127) << 23);
+    }
+    const int nk2 = min(BN / 32, (N - n0 + 31) >> 5);    // live k-tiles (32 items each) of this tile
+    const int j0 = wn * T2A, nj = wn == 0 ? T2A : DZT - T2A;
+    f32x16 acc2[T2A];
+#pragma unroll
+    for (int j = 0; j < T2A; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
+    __syncthreads();                                     // the epilogue's LDS (transposes, sums) is free
+    st_pieces_n<B2_ROWS * 8>(smem, dstB2, rw2, tid);
+    __syncthreads();
+    const float *drow = reinterpret_cast<const float *>(smem + DT_OFF) + (wm * 32 + l31) * DT_LD + lh * 8;
+    const int b2_off = l31 * ROWB + lh * 16;
+    const int64_t b2_step = (int64_t)Hp2 * rkp::LINE;
+    for (int kt = 0; kt < nk2; ++kt) {
+      if (kt + 1 < nk2) ld_pieces(rw2, srcB2, (int64_t)(kt + 1) * b2_step);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(drow + kt * 32 + ks * 16);
+        const float4 a1 = *reinterpret_cast<const float4 *>(drow + kt * 32 + ks * 16 + 4);
+        uint2 h0, l0, h1, l1;
+        rkp::split4(a0, s_do, h0, l0);
+        rkp::split4(a1, s_do, h1, l1);
+        const f16x8 ah = __builtin_bit_cast(f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+        const f16x8 al = __builtin_bit_cast(f16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+        f16x8 bh[T2A], bl[T2A];
+#pragma unroll
+        for (int j = 0; j < T2A; ++j) {
+          const char *q = smem + b2_off + min(j0 + j, DZT - 1) * 32 * ROWB + ks * 32;
+          bh[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q));
+          bl[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q + 64));
+        }
+#pragma unroll
+        for (int j = 0; j < T2A; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[j], acc2[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < T2A; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[j], acc2[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < T2A; ++j) acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[j], acc2[j], 0, 0, 0);
+      }
+      __syncthreads();
+      if (kt + 1 < nk2) {
+        st_pieces_n<B2_ROWS * 8>(smem, dstB2, rw2, tid);
+        __syncthreads();
+      }
+    }
+    // slab store (as dz_planes_kernel): per-wave LDS transpose, 16 bytes per lane
+    const float inv2 = 1.0f / (s_do * p.scales[1]);
+    float *ws = p.dz_ws + (int64_t)nt * M * p.h;
+#pragma unroll
+    for (int j = 0; j < T2A; ++j) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) wlds[((r & 3) + 8 * (r >> 2) + 4 * lh) * TLD + l31] = acc2[j][r] * inv2;
+      __builtin_amdgcn_wave_barrier();
+      const int n = (j0 + j) * 32 + c4 * 4;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const float4 v = *reinterpret_cast<const float4 *>(wlds + (rr0 + 8 * it) * TLD + c4 * 4);
+        const int m = m0 + wm * 32 + rr0 + 8 * it;
+        if (j < nj && m < M && n < p.h) *reinterpret_cast<float4 *>(ws + (int64_t)m * p.h + n) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   }
   RK_STAMP(3);
@@ -877,6 +985,76 @@ extern "C" int rk_decode_filter_planes(const void *zimg, const void *wimg, const
   }
   RK_CHECK_LAUNCH("decode_filter_planes");
   return 0;
+}
+
+// ---- decode + loss with the dZ partials of every 128-item column tile fused in (DZT > 0 above) ----
+int rk_splitk_reduce_tiles(const float *ws, int M, int N, const int32_t *Kdev, int max_splits, int tile_k,
+                           const float *Zact, int act, float *out, void *stream);
+
+// RK_DZ_FUSED=0: the stand-alone dZ kernel everywhere (A/B switch)
+static int dz_fused_on() {
+  static const int on = [] { const char *e = getenv("RK_DZ_FUSED"); return (e && atoi(e) == 0) ? 0 : 1; }();
+  return on;
+}
+
+extern "C" int32_t rk_decode_dz_fused_ok(int32_t B, int32_t h, int32_t n_cap, int32_t loss_kind) {
+  return dz_fused_on() && !rk_gemm_plain_bf16() && (loss_kind == RK_LOSS_MSE || loss_kind == RK_LOSS_BCE) &&
+         h % 4 == 0 && h <= 256 && dec_tm(B, n_cap) == 1 ? 1 : 0;
+}
+
+extern "C" int64_t rk_dz_fused_workspace_bytes(int32_t B, int32_t h, int32_t n_cap) {
+  return (int64_t)rk_cdiv(n_cap, 128) * B * h * sizeof(float);
+}
+
+extern "C" int rk_decode_loss_dz_planes(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt,
+                                        int32_t row_off, const float *b_de, int32_t loss_kind,
+                                        float confidence, float inv_B, float *dO, float *loss_part,
+                                        float *gb_part, float *dz_workspace, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(pl && B <= pl->B_cap && tgt->n_cap <= pl->n_cap, "planes were laid out for another shape");
+  RK_REQUIRE(row_off >= 0 && row_off + B <= tgt->S_cap, "row slice out of range");
+  RK_REQUIRE(rk_decode_dz_fused_ok(B, pl->h, tgt->n_cap, loss_kind), "shape / loss outside the fused dZ (rk_decode_dz_fused_ok)");
+  RK_REQUIRE(tgt->implicit || tgt->pref_rc != nullptr, "explicit values need pref_rc");
+  RK_REQUIRE(aligned16(dz_workspace), "workspace must be 16-byte aligned");
+  if (B == 0) return 0;
+  DecP p = {};
+  p.probe = g_probe;
+  p.zp = (const char *)pl->z; p.wp = (const char *)pl->w; p.scales = pl->scales;
+  p.KT = rkp::kp_of(pl->h) / 32;
+  p.M = B; p.n_cap = tgt->n_cap; p.Ndev = tgt->counts;
+  p.C = dO; p.bias = b_de; p.bidx = tgt->items;
+  p.blk = *tgt; p.row_off = row_off; p.confidence = confidence; p.inv_B = inv_B;
+  p.loss_part = loss_part; p.gb_part = gb_part;
+  p.ld_dev = tgt->counts + 2;
+  p.wtp = (const char *)pl->wt; p.dz_ws = dz_workspace; p.h = pl->h;
+  const int BM = 64, BN = 128;
+  const int grid = rk_cdiv(rk_cdiv(B, BM) * rk_cdiv(tgt->n_cap, BN), 8) * 8;
+  const int lds = 256 * ROWB + 64 * 132 * 4;            // W^T stage | dO tile (the k-loop's stages fit below)
+  const int dzt = rk_cdiv(pl->h, 32);
+#define LAUNCH(EPI, DZT)                                                                          \
+  do {                                                                                            \
+    if (set_lds(decode_planes_kernel<1, 2, EPI, 3, false, DZT>, lds)) { rk_set_error("LDS attribute"); return -1; } \
+    RK_LAUNCH((decode_planes_kernel<1, 2, EPI, 3, false, DZT>), dim3(grid), dim3(256), lds, stream, p); \
+  } while (0)
+#define BY_H(EPI)                                                                                 \
+  do {                                                                                            \
+    if (dzt <= 2) LAUNCH(EPI, 2); else if (dzt <= 4) LAUNCH(EPI, 4); else if (dzt <= 7) LAUNCH(EPI, 7); \
+    else LAUNCH(EPI, 8);                                                                          \
+  } while (0)
+  if (loss_kind == RK_LOSS_MSE) BY_H(EPI_LOSS_MSE); else BY_H(EPI_LOSS_BCE);
+#undef BY_H
+#undef LAUNCH
+  RK_CHECK_LAUNCH("decode_loss_dz_planes");
+  return 0;
+}
+
+// dZ = sum of the column-tile slabs rk_decode_loss_dz_planes wrote (* act'(Zact) if given)
+extern "C" int rk_decode_dz_reduce(const float *dz_workspace, int32_t B, int32_t h, const rk_block_t *tgt,
+                                   const float *Zact, int32_t act, float *dZ, void *stream_) {
+  RK_REQUIRE(aligned16(dz_workspace) && aligned16(dZ), "operands must be 16-byte aligned");
+  if (B == 0) return 0;
+  return rk_splitk_reduce_tiles(dz_workspace, B, h, tgt->counts, rk_cdiv(tgt->n_cap, 128), 128, Zact, act, dZ,
+                                stream_);
 }
 
 // the split-K reduce of gemm.hip (ws[split][M][N] -> out, * act'(Zact) if given)

@@ -27,6 +27,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "encoder_bwd.h"
 #include "planes.h"
 
 namespace {
@@ -149,8 +150,8 @@ namespace {
 // kernels publish, Z static or from rk_amax) and THREE products lo.hi + hi.lo + hi.hi are accumulated
 // on v_mfma_f32_32x32x16_f16 instead of six bf16 ones: half the MFMAs, two planes instead of three
 // to fetch and to convert.
-template <int BN, bool PLAIN = false, bool PAIRS = false>
-__global__ __launch_bounds__(512) void dw3_kernel(Dw3P p) {
+template <int BN, bool PLAIN, bool PAIRS>
+__device__ __forceinline__ void dw3_body(const Dw3P &p, const int L) {
   constexpr int BM = 64, R = 4, P = R - 1;              // B: k-steps of 16, P of them prefetched
   constexpr int BKA = 32;                               // A: LDS stages of two k-steps
   constexpr int WN = BN / 32, WM = 8 / WN, MT = 2 / WM;
@@ -166,7 +167,6 @@ __global__ __launch_bounds__(512) void dw3_kernel(Dw3P p) {
   const float z_scale = PAIRS ? (p.z_scale_dev ? *p.z_scale_dev : p.z_scale) : 1.0f;
   int kc;
   const int ns = dw3_splits(n_t, p.tiles_n, p.Bp, p.max_splits, p.wg_slots, &kc);
-  const int L = blockIdx.x;
   if (L == 0 && threadIdx.x == 0) p.counts[4] = ns;
   const int tiles_m = (n_t + BM - 1) / BM;
   if (L >= tiles_m * p.tiles_n * ns) return;
@@ -347,6 +347,35 @@ __global__ __launch_bounds__(512) void dw3_kernel(Dw3P p) {
   }
 }
 
+template <int BN, bool PLAIN = false, bool PAIRS = false>
+__global__ __launch_bounds__(512) void dw3_kernel(Dw3P p) {
+  dw3_body<BN, PLAIN, PAIRS>(p, (int)blockIdx.x);
+}
+
+// dW (fp16 pairs) || encoder backward in ONE launch: the first n_dw workgroups run the dW tiles, the
+// others the encoder backward's columns (encoder_bwd.h: a wave per column, 4 per workgroup -- waves
+// 4 .. 7 of those workgroups leave at once).  Both need only what the launches in front of them left
+// (dO and the Z^T planes; dZ0 and the block) and write disjoint outputs: as two launches they cost the
+// chain 16 + 14 us in line or two cross-queue edges (12 us fork + 6-11 us join) on a side stream.
+struct EncBwdP {
+  rk_block_t b;
+  int row_off, B;
+  const float *dZ;
+  int h;
+  float *G;
+  float *gb;
+  int n_gb;
+};
+template <int BN, int HV>
+__global__ __launch_bounds__(512) void dw_encbwd_kernel(Dw3P p, EncBwdP e, int n_dw) {
+  if ((int)blockIdx.x < n_dw) {
+    dw3_body<BN, false, true>(p, (int)blockIdx.x);
+    return;
+  }
+  if (threadIdx.x >= 256) return;
+  ae_encode_bwd_cols_body<HV>(e.b, e.row_off, e.B, e.dZ, e.h, e.G, 0, e.gb, e.n_gb, (int)blockIdx.x - n_dw);
+}
+
 // G = sum of the ns slabs the kernel above wrote (ns = counts[4]; nothing to do for ns == 1:
 // the kernel wrote G itself)
 __global__ __launch_bounds__(256) void slab_sum3_kernel(const float *__restrict__ slabs,
@@ -415,9 +444,15 @@ extern "C" int64_t rk_dw3_planes_bytes(int32_t B, int32_t h) { return dw3_plane_
 extern "C" int32_t rk_dw3_cols_pad(int32_t h) { return dw3_cols_pad(h); }
 extern "C" int32_t rk_dw3_rows_pad(int32_t B) { return dw3_rows_pad(B); }
 
+struct EncBwdArgs {          // the encoder backward riding on the dW launch (rk_decode_bwd_dw2_encode_bwd)
+  int32_t row_off;
+  const float *dZ0pre;
+  float *G_en, *gb_en;
+};
+
 static int dw_impl(const float *dO, const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
                    float *G_de, float *gb_de, void *workspace, const void *zt_planes, bool pairs,
-                   const int32_t *ranges, void *stream_) {
+                   const int32_t *ranges, void *stream_, const EncBwdArgs *enc = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(h > 0 && h % 4 == 0, "h must be a multiple of 4");
   RK_REQUIRE(workspace != nullptr && (((uintptr_t)workspace) & 255) == 0, "workspace: 256-byte aligned");
@@ -456,7 +491,18 @@ static int dw_impl(const float *dO, const float *Z, int32_t B, int32_t h, const 
   // the live workgroups are the first tiles_m(n_t) * tiles_n * ns of the grid; ns * tiles never
   // exceeds max(wg_slots, tiles), so the capacity grid is bounded by that
   const int64_t grid = std::max<int64_t>((int64_t)tiles_cap, std::min<int64_t>((int64_t)tiles_cap * DW3_MAX_SPLITS, p.wg_slots));
-  if (pairs) {
+  if (enc) {
+    RK_REQUIRE(pairs, "the fused encoder backward rides on the fp16-pair dW");
+    EncBwdP e = {};
+    e.b = *tgt; e.row_off = enc->row_off; e.B = B; e.dZ = enc->dZ0pre; e.h = h; e.G = enc->G_en;
+    e.gb = enc->gb_en; e.n_gb = enc->gb_en ? rk_cdiv(h, 64) : 0;
+    const int n_enc = rk_cdiv(tgt->n_cap, 4) + e.n_gb;
+    const int hv = rk_cdiv(h, 256);
+#define LAUNCH(BN, HV) RK_LAUNCH((dw_encbwd_kernel<BN, HV>), dim3((unsigned)grid + n_enc), dim3(512), 0, stream, p, e, (int)grid)
+    if (bn == 128) { if (hv == 1) LAUNCH(128, 1); else if (hv == 2) LAUNCH(128, 2); else LAUNCH(128, 4); }
+    else { if (hv == 1) LAUNCH(256, 1); else if (hv == 2) LAUNCH(256, 2); else LAUNCH(256, 4); }
+#undef LAUNCH
+  } else if (pairs) {
     if (bn == 128)
       RK_LAUNCH((dw3_kernel<128, false, true>), dim3((unsigned)grid), dim3(512), 0, stream, p);
     else
@@ -495,6 +541,26 @@ extern "C" int rk_decode_bwd_dw2(const float *dO, const float *Z, int32_t B, int
                                  const rk_block_t *tgt, float *G_de, float *gb_de, void *workspace,
                                  const void *zt_planes, const int32_t *ranges, void *stream_) {
   return dw_impl(dO, Z, B, h, tgt, G_de, gb_de, workspace, zt_planes, true, ranges, stream_);
+}
+
+// rk_decode_bwd_dw2 (slabs stay in the workspace: G_de == NULL semantics) and rk_ae_encode_bwd (one
+// bitmap word per lane: the row window spans <= 64 words) in ONE launch -- see dw_encbwd_kernel
+extern "C" int32_t rk_dw_encode_bwd_fused_ok(int32_t row_off, int32_t B) {
+  static const int on = [] { const char *e = getenv("RK_DW_ENC_FUSED"); return (e && atoi(e) == 0) ? 0 : 1; }();
+  return on && rk_dw_pairs() && (((row_off + B + 31) >> 5) - (row_off >> 5) <= 64) ? 1 : 0;
+}
+
+extern "C" int rk_decode_bwd_dw2_encode_bwd(const float *dO, const float *Z, int32_t B, int32_t h,
+                                            const rk_block_t *tgt, void *workspace, const void *zt_planes,
+                                            const int32_t *ranges, int32_t row_off, const float *dZ0pre,
+                                            float *G_en, float *gb_en, void *stream_) {
+  RK_REQUIRE(rk_dw_encode_bwd_fused_ok(row_off, B), "outside the fused launch's domain (rk_dw_encode_bwd_fused_ok)");
+  RK_REQUIRE(h > 0 && h % 4 == 0 && h <= 1024, "h must be a multiple of 4, <= 1024");
+  RK_REQUIRE(row_off >= 0 && B >= 0 && row_off + B <= tgt->S_cap, "row slice out of range");
+  RK_REQUIRE(tgt->bits_cr != nullptr && tgt->pref_rc != nullptr,
+             "block was built without the transposed bitmap / prefix index");
+  const EncBwdArgs enc = {row_off, dZ0pre, G_en, gb_en};
+  return dw_impl(dO, Z, B, h, tgt, nullptr, nullptr, workspace, zt_planes, true, ranges, stream_, &enc);
 }
 
 // RK_DW_PREC=bf16x3 keeps dW on the bf16 triples (no operand range at all) in the training step

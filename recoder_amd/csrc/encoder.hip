@@ -227,196 +227,13 @@ __global__ __launch_bounds__(256) void ae_encode_bwd_kernel(
   ae_encode_bwd_body<HV>(b, row_off, B, dZ, h, G, accumulate, gb, n_gb, (int)blockIdx.x);
 }
 
-// Encoder backward, one WAVE per sampled item column (4 columns per workgroup).  A C2 batch holds
-// 3.4 stored entries per column on average (99 % of the columns hold <= 41, 20 of ~7 900 more than
-// 128): a workgroup per column spent the launch on dispatch and on a chain of dependent loads per
-// 64-row group.  Here a wave reads the column's whole bitmap row at once (one word per lane: B <=
-// 2048), lists its rows in ascending order, fetches their values in parallel and then streams the
-// dZ rows, 8 loads in flight.  Columns with more than 64 entries are done afterwards by the 4 waves
-// of the workgroup together (64-row groups round-robin, combined in fixed order).
+// (the workgroup body lives in encoder_bwd.h: the fused dW || encoder-backward launch of dw3.hip
+// runs it next to the dW tiles)
 template <int HV>
 __global__ __launch_bounds__(256) void ae_encode_bwd_cols_kernel(
     rk_block_t b, int row_off, int B, const float *__restrict__ dZ, int h,
     float *__restrict__ G, int accumulate, float *__restrict__ gb, int n_gb) {
-  const int bid = (int)blockIdx.x;
-  if (bid < n_gb) {                 // encoder-bias gradient: the shared body's first branch
-    ae_encode_bwd_body<HV>(b, row_off, B, dZ, h, G, accumulate, gb, n_gb, bid);
-    return;
-  }
-  __shared__ __attribute__((aligned(16))) float part[3][HV * 256];
-  __shared__ uint16_t rows_l[4][64];
-  __shared__ uint16_t rows_h[2048 + 64];
-  __shared__ int heavy_l[4];          // entries of wave w's column if it is a heavy one, else 0
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int n_b = b.counts[0];
-  // wave w of workgroup i takes column i + w * Q, Q = ceil(n_b / 4): columns that are neighbours
-  // by item id land in different workgroups (a catalogue sorted by popularity would otherwise put
-  // all its heavy columns into the first few workgroups, one after the other)
-  const int Q = (n_b + 3) >> 2;
-  const int c0 = bid - n_gb;
-  if (c0 >= Q) return;
-  const int c = c0 + wid * Q;
-  const bool live = c < n_b;
-  const int w0 = row_off >> 5, rend = row_off + B;
-  const int nw = ((rend + 31) >> 5) - w0;              // <= 64 (host-checked)
-  uint32_t m = 0;
-  if (live && lane < nw) {
-    m = b.bits_cr[(int64_t)c * b.ldw_cr + w0 + lane];
-    const int base = (w0 + lane) << 5;
-    if (base < row_off) m &= ~0u << (row_off - base);
-    if (base + 32 > rend) m &= (1u << (rend - base)) - 1u;     // (rend - base is in 1..31 here)
-  }
-  const int cnt = __popc(m);
-  int incl = cnt;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int t = __shfl_up(incl, d, 64);
-    if (lane >= d) incl += t;
-  }
-  const int total = __shfl(incl, 63, 64);
-  const bool heavy = total > 64;
-  if (lane == 0) heavy_l[wid] = heavy ? total : 0;
-  if (!heavy) {
-    int o = incl - cnt;
-    while (m) {
-      const int k = __builtin_ctz(m);
-      m &= m - 1;
-      rows_l[wid][o++] = (uint16_t)(((w0 + lane) << 5) + k - row_off);    // (relative: < 2048 + 32)
-    }
-  }
-  __syncthreads();
-  float4 acc[HV];
-#pragma unroll
-  for (int k = 0; k < HV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (live && !heavy && total > 0) {
-    int row = row_off;
-    float sv = 0.f;
-    if (lane < total) {
-      row = row_off + rows_l[wid][lane];
-      const uint32_t word = b.bits_rc[(int64_t)row * b.ldw_rc + (c >> 5)];
-      sv = b.svals[rk_entry_index(b, row, c, word)];
-    }
-    for (int k = 0; k < total; k += 8) {
-      int kk[8];
-      float s8[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {       // (lanes past `total` carry row_off / 0: exact zeros)
-        kk[u] = __shfl(row, (k + u) & 63, 64) - row_off;
-        s8[u] = (k + u < 64) ? __shfl(sv, (k + u) & 63, 64) : 0.f;
-      }
-#pragma unroll
-      for (int v = 0; v < HV; ++v) {
-        const int hh = min((v * 64 + lane) * 4, h - 4);
-        float4 d4[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          d4[u] = *reinterpret_cast<const float4 *>(dZ + (int64_t)kk[u] * h + hh);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          acc[v].x = fmaf(s8[u], d4[u].x, acc[v].x);
-          acc[v].y = fmaf(s8[u], d4[u].y, acc[v].y);
-          acc[v].z = fmaf(s8[u], d4[u].z, acc[v].z);
-          acc[v].w = fmaf(s8[u], d4[u].w, acc[v].w);
-        }
-      }
-    }
-  }
-  if (live && !heavy) {
-    float *grow = G + (int64_t)c * h;
-#pragma unroll
-    for (int v = 0; v < HV; ++v) {
-      const int hh = (v * 64 + lane) * 4;
-      if (hh < h) {
-        float4 a = acc[v];
-        if (accumulate) {
-          const float4 o = *reinterpret_cast<const float4 *>(grow + hh);
-          a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
-        }
-        *reinterpret_cast<float4 *>(grow + hh) = a;
-      }
-    }
-  }
-  // ---- the workgroup's heavy columns, one after the other, all 4 waves each: the owner wave
-  // lists the column's rows in LDS, every wave takes a contiguous quarter of the ENTRIES (balanced
-  // whatever the rows are), fetches their values 64 at a time and streams the dZ rows 16 loads deep
-  for (int j = 0; j < 4; ++j) {
-    const int tot_j = heavy_l[j];                   // (uniform: read from LDS behind a barrier)
-    if (tot_j == 0) continue;
-    const int cj = c0 + j * Q;
-    if (wid == j) {
-      int o = incl - cnt;
-      while (m) {
-        const int k = __builtin_ctz(m);
-        m &= m - 1;
-        rows_h[o++] = (uint16_t)(((w0 + lane) << 5) + k - row_off);
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < HV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int per = (tot_j + 3) >> 2;
-    const int e1 = min(tot_j, (wid + 1) * per);
-    for (int e0 = wid * per; e0 < e1; e0 += 64) {
-      const int ne = min(64, e1 - e0);
-      int row = row_off;
-      float sv = 0.f;
-      if (lane < ne) {
-        row = row_off + rows_h[e0 + lane];
-        const uint32_t word = b.bits_rc[(int64_t)row * b.ldw_rc + (cj >> 5)];
-        sv = b.svals[rk_entry_index(b, row, cj, word)];
-      }
-      for (int k = 0; k < ne; k += 16) {
-        int kk[16];
-        float s16[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {    // (lanes past `ne` carry row_off / 0: exact zeros)
-          kk[u] = __shfl(row, (k + u) & 63, 64) - row_off;
-          s16[u] = (k + u < 64) ? __shfl(sv, (k + u) & 63, 64) : 0.f;
-        }
-#pragma unroll
-        for (int v = 0; v < HV; ++v) {
-          const int hh = min((v * 64 + lane) * 4, h - 4);
-          float4 d4[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u)
-            d4[u] = *reinterpret_cast<const float4 *>(dZ + (int64_t)kk[u] * h + hh);
-#pragma unroll
-          for (int u = 0; u < 16; ++u) {
-            acc[v].x = fmaf(s16[u], d4[u].x, acc[v].x);
-            acc[v].y = fmaf(s16[u], d4[u].y, acc[v].y);
-            acc[v].z = fmaf(s16[u], d4[u].z, acc[v].z);
-            acc[v].w = fmaf(s16[u], d4[u].w, acc[v].w);
-          }
-        }
-      }
-    }
-    if (wid > 0) {
-#pragma unroll
-      for (int v = 0; v < HV; ++v)
-        *reinterpret_cast<float4 *>(&part[wid - 1][(v * 64 + lane) * 4]) = acc[v];
-    }
-    __syncthreads();
-    if (wid == 0) {
-      float *grow = G + (int64_t)cj * h;
-#pragma unroll
-      for (int v = 0; v < HV; ++v) {
-        const int hh = (v * 64 + lane) * 4;
-        if (hh < h) {
-          float4 a = acc[v];
-          for (int w = 0; w < 3; ++w) {
-            const float4 o = *reinterpret_cast<const float4 *>(&part[w][hh]);
-            a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
-          }
-          if (accumulate) {
-            const float4 o = *reinterpret_cast<const float4 *>(grow + hh);
-            a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
-          }
-          *reinterpret_cast<float4 *>(grow + hh) = a;
-        }
-      }
-    }
-    __syncthreads();                                // (part / rows_h are reused by the next one)
-  }
+  ae_encode_bwd_cols_body<HV>(b, row_off, B, dZ, h, G, accumulate, gb, n_gb, (int)blockIdx.x);
 }
 
 }  // namespace

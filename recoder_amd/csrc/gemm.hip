@@ -783,14 +783,15 @@ __global__ __launch_bounds__(256) void dw_encode_bwd_kernel(
 // ws[split][M][N] -> out[M][N] (fixed split order), optional * act'(Zact)
 constexpr int RED_W = 8;       // waves per workgroup: each sums 1/RED_W of the splits
 __global__ __launch_bounds__(RED_W * 64) void splitk_reduce_kernel(
-    const float *__restrict__ ws, int M, int N, const int32_t *__restrict__ Kdev, int unused,
+    const float *__restrict__ ws, int M, int N, const int32_t *__restrict__ Kdev, int tile_k,
     int max_splits, const float *__restrict__ Zact, int act, float *__restrict__ out) {
   // 64 float4 outputs per workgroup; the waves each sum a contiguous share of the splits (all of
   // its loads in flight at once: the slabs come from the Infinity Cache / HBM, and the launch is as
   // long as one wave's chain of load batches), combined in fixed order through LDS
   __shared__ float4 part[RED_W - 1][64];
   const int K = *Kdev;
-  const int kchunk = ((K + max_splits - 1) / max_splits + 31) & ~31;   // as the GEMM derives it
+  // (tile_k > 0: one slab per tile_k-wide column tile of the decode -- the fused dZ of decode16.hip)
+  const int kchunk = tile_k > 0 ? tile_k : ((K + max_splits - 1) / max_splits + 31) & ~31;   // as the GEMM derives it
   int ns = (K + kchunk - 1) / kchunk;
   if (ns > max_splits) ns = max_splits;
   const int64_t tot4 = ((int64_t)M * N) >> 2;      // M*N is a multiple of 4 (N = h)
@@ -1075,6 +1076,15 @@ int rk_splitk_reduce(const float *ws, int M, int N, const int32_t *Kdev, int spl
   const int grid = rk_cdiv((int64_t)M * N / 4, 64);
   RK_LAUNCH(splitk_reduce_kernel, dim3(grid), dim3(RED_W * 64), 0, (hipStream_t)stream_, ws, M, N, Kdev, 0,
             splits, Zact, act, out);
+  RK_CHECK_LAUNCH("splitk_reduce");
+  return 0;
+}
+
+int rk_splitk_reduce_tiles(const float *ws, int M, int N, const int32_t *Kdev, int max_splits, int tile_k,
+                           const float *Zact, int act, float *out, void *stream_) {
+  const int grid = rk_cdiv((int64_t)M * N / 4, 64);
+  RK_LAUNCH(splitk_reduce_kernel, dim3(grid), dim3(RED_W * 64), 0, (hipStream_t)stream_, ws, M, N, Kdev, tile_k,
+            max_splits, Zact, act, out);
   RK_CHECK_LAUNCH("splitk_reduce");
   return 0;
 }

@@ -417,11 +417,18 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   // the decoder table's Adam sweep right behind the dW kernel ON dw_stream (it needs nothing else),
   // next to the reduce / encoder backward of the chain; the update on the chain then covers the
   // encoder table, the biases and the loss (rk_adam_de_side; RK_ADAM_DE_SIDE=0: one launch)
-  const bool de_side = dw_branch && phase == RK_STEP_ALL && rk_adam_de_side() != 0;
+  // dW and the encoder backward as ONE launch on the chain instead of a side-stream branch
+  const bool dw_enc_fused = dw3 && rk_dw_encode_bwd_fused_ok(a->row_off, B) != 0;
+  const bool de_side = dw_branch && !dw_enc_fused && phase == RK_STEP_ALL && rk_adam_de_side() != 0;
 
   // pre-split operand planes (decode16.hip): W_de[items] is split by extra workgroups of the
   // encoder-forward launch, Z by that kernel's epilogue; decode and dZ copy the images into LDS
   const bool pl = a->planes != nullptr && rk_gemm_split16() != 0;
+  // dZ fused into the decode launch (decode16.hip DZT): the phases that hold both halves and leave the
+  // dZ workspace alone in between -- the untied MSE / BCE step whose dW has a workspace of its own
+  const bool dz_fused = pl && (phase & RK_STEP_FWD_DW) && (phase & RK_STEP_DZ_ENC) && !a->tied && !mnll &&
+                        a->ws != nullptr &&
+                        rk_decode_dz_fused_ok(B, h, blk->n_cap, a->loss_kind) != 0;
   if (phase & RK_STEP_FWD_DW) {
     {
       Timer t(a, RK_ENTRY_ENCODE_FWD, sm);
@@ -454,15 +461,22 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       if (pl) {
         // (unbounded activations: the split scale of Z needs its maximum first)
         if (!act_bounded(a->act)) RK_TRY(rk_split_z(a->Z0, B, h, a->ranges, a->planes, sm));
-        RK_TRY(rk_decode_loss_planes(a->planes, B, blk, a->row_off, a->par[RK_PAR_B_DE].p, a->loss_kind,
-                                     a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, sm));
+        if (dz_fused)
+          RK_TRY(rk_decode_loss_dz_planes(a->planes, B, blk, a->row_off, a->par[RK_PAR_B_DE].p, a->loss_kind,
+                                          a->confidence, a->inv_B, a->dO, a->loss_part, a->gb_part, a->ws, sm));
+        else
+          RK_TRY(rk_decode_loss_planes(a->planes, B, blk, a->row_off, a->par[RK_PAR_B_DE].p, a->loss_kind,
+                                       a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, sm));
       } else {
         RK_TRY(rk_decode_loss(a->Z0, B, h, blk, a->row_off, W_de, a->par[RK_PAR_B_DE].p, a->loss_kind,
                               a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, a->ranges, sm));
       }
       if (mnll) RK_TRY(rk_mnll_finish(a->dO, B, blk, a->row_off, a->inv_B, a->loss_part, sm));
     }
-    if (dw_branch) RK_TRY(rk_event_record(a->dw_fork, sm));      // dO and the Z^T planes are ready
+    // dO and the Z^T planes are ready: the dW branch starts here -- and so does whatever else the
+    // caller queues behind this event (graph.GraphStepper: the look-ahead collation, which must not
+    // run next to the decode: its workgroups do not fit into the LDS the fused decode leaves)
+    if (dw_branch) RK_TRY(rk_event_record(a->dw_fork, sm));
     // dW: on its own (tied weights: the encoder backward accumulates onto its rows;
     // MNLL: + column sums of dO; data parallel: G_de must travel early), otherwise
     // fused with the encoder backward below
@@ -479,7 +493,9 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   if (phase & RK_STEP_DZ_ENC) {
     {
       Timer t(a, RK_ENTRY_DECODE_BWD_DZ, sm);
-      if (pl)
+      if (dz_fused)        // (the decode launch left the column tiles' partials in the workspace)
+        RK_TRY(rk_decode_dz_reduce(a->ws, B, h, blk, a->Z0, a->act, a->dZ0, sm));
+      else if (pl)
         RK_TRY(rk_decode_bwd_dz_planes(a->dO, B, a->planes, blk, a->Z0, a->act, a->dZ0, a->ws, sm));
       else
         RK_TRY(rk_decode_bwd_dz(a->dO, B, h, blk, W_de, a->Z0, a->act, a->dZ0, a->ws, a->ranges, sm));
@@ -487,6 +503,12 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     if (a->tied || mnll || !whole) {
       Timer t(a, RK_ENTRY_ENCODE_BWD, sm);
       RK_TRY(rk_ae_encode_bwd(blk, a->row_off, B, a->dZ0, h, G_en, a->tied ? 1 : 0, a->gb_en, sm));
+    } else if (dw_enc_fused) {
+      // dW || encoder backward in ONE launch on the chain (dw3.hip dw_encbwd_kernel): no side stream
+      Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
+      RK_TRY(rk_decode_bwd_dw2_encode_bwd(a->dO, a->Z0, B, h, blk, dw_branch ? a->ws_dw : a->ws,
+                                          planes ? a->zt_planes : nullptr, a->ranges, a->row_off, a->dZ0,
+                                          G_en, a->gb_en, sm));
     } else if (dw_branch) {
       {
         Timer t(a, RK_ENTRY_ENCODE_BWD, sm);

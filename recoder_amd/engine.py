@@ -46,7 +46,7 @@ class TimedLib:
 
   def __getattr__(self, name):
     fn = getattr(self._lib, name)
-    if not name.startswith("rk_") or name in ("rk_dz_workspace_bytes", "rk_dw_workspace_bytes", "rk_dw_splits", "rk_encode_bwd_segments", "rk_loss_partials", "rk_decode_row_tile",
+    if not name.startswith("rk_") or name in ("rk_dz_workspace_bytes", "rk_dz_fused_workspace_bytes", "rk_decode_dz_fused_ok", "rk_dw_workspace_bytes", "rk_dw_splits", "rk_encode_bwd_segments", "rk_loss_partials", "rk_decode_row_tile",
                                               "rk_dw3_workspace_bytes", "rk_dw3_max_splits", "rk_dw3_slabs", "rk_gemm_split16", "rk_dw_pairs",
                                               "rk_dw3_planes_bytes", "rk_dw3_rows_pad", "rk_dw3_cols_pad",
                                               "rk_planes_bytes", "rk_planes_layout",
@@ -166,6 +166,7 @@ class FusedEngine:
     # one workspace, used in turn by the dZ split-K slabs, then by dW (bf16-pipe kernel: Z^T
     # planes + K slabs, which stay live until the Adam sweep has read them)
     self.ws = torch.zeros(max(self.lib.rk_dz_workspace_bytes(B_cap, h0),
+                              self.lib.rk_dz_fused_workspace_bytes(B_cap, h0, n_cap),
                               self.lib.rk_dw_workspace_bytes(B_cap, h0, n_cap),
                               self.lib.rk_dw3_workspace_bytes(B_cap, h0, n_cap)) // 4 + 64, **f)
     self.split16 = bool(self.lib.rk_gemm_split16())

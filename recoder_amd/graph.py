@@ -184,6 +184,11 @@ class GraphStepper:
         # the G look-ahead blocks in ONE set of launches, behind the dW kernel of step 0 (which the
         # Adam sweep of step 0 waits for; nothing needs the blocks before the end of the group)
         if g == 0:
+          # (released by the event the step records behind its decode: the collation's workgroups
+          # beside the fused decode + dZ launch doubled it, 26 -> 47 us)
+          ev = getattr(self.eng, "_dw_objs", None)
+          if self.c_step and ev is not None and self.eng._ws_dw_live:
+            check(lib.rk_stream_wait_event(self._h(self.side), ev[1]), "rk_stream_wait_event")
           self._collate_many(self.blocks[1 - slot], n_steps, self.side, slot)
       elif g < G and lookahead:
         self._collate(self.blocks[1 - slot][g], n_steps + g, self.side, slot)

@@ -105,6 +105,55 @@ def test_decode_and_dz_on_planes_equal_the_in_loop_split_bit_for_bit(B, h, n_ite
     assert (dz1.double() - ref).abs().max().item() <= 2e-6 * max(ref.abs().max().item(), 1e-30)
 
 
+@pytest.mark.parametrize("B,h,n_items,loss", [(500, 200, 3000, LOSS_MSE), (37, 20, 400, LOSS_BCE),
+                                              (1, 8, 97, LOSS_MSE), (130, 64, 900, LOSS_BCE),
+                                              (300, 256, 2000, LOSS_MSE), (64, 36, 333, LOSS_BCE)])
+def test_decode_with_fused_dz_equals_the_two_launches(B, h, n_items, loss):
+  """rk_decode_loss_dz_planes + rk_decode_dz_reduce against rk_decode_loss_planes +
+  rk_decode_bwd_dz_planes: dO, loss and bias partials, published maxima bit for bit (the same decode
+  tiles and epilogue); dZ to 1e-6 of its maximum (the fused form cuts every dO tile with the tile's
+  own scale and sums per 128-item tile instead of per K chunk) and against a float64 product."""
+  lib, blk, W, bias, Z, ranges, pl, buf = _setup(B, h, max(B, 600), n_items, 14, seed=B + h,
+                                                 ratings=(loss == LOSS_MSE and h == 200))
+  assert lib.rk_decode_dz_fused_ok(B, h, blk.n_cap, loss) == 1
+  st = current_stream()
+  f = dict(dtype=torch.float32, device=Z.device)
+  n_b, nnz, ld, S = blk.counts_host()
+  npart = lib.rk_loss_partials(B, blk.n_cap)
+  ntile = -(-B // lib.rk_decode_row_tile())
+  check(lib.rk_split_w(ptr(W), h, blk.ref, ptr(ranges), ctypes.byref(pl), st))
+  check(lib.rk_split_z(ptr(Z), B, h, ptr(ranges), ctypes.byref(pl), st))
+  lib.rk_planes_tile(64)
+
+  def run(fused):
+    dO = torch.full((B * blk.ld_cap,), 5.0, **f)
+    part = torch.zeros(npart, **f)
+    gbp = torch.zeros(ntile * blk.ld_cap, **f)
+    dz = torch.zeros(B, h, **f)
+    blk.counts[8:72].zero_()
+    if fused:
+      ws = torch.full((lib.rk_dz_fused_workspace_bytes(B, h, blk.n_cap) // 4 + 64,), float("nan"), **f)
+      check(lib.rk_decode_loss_dz_planes(ctypes.byref(pl), B, blk.ref, 0, ptr(bias), loss, 0.5, 1.0 / B, ptr(dO),
+                                         ptr(part), ptr(gbp), ptr(ws), st))
+      check(lib.rk_decode_dz_reduce(ptr(ws), B, h, blk.ref, ptr(Z), 1, ptr(dz), st))
+    else:
+      ws = torch.zeros(lib.rk_dz_workspace_bytes(B, h) // 4 + 64, **f)
+      check(lib.rk_decode_loss_planes(ctypes.byref(pl), B, blk.ref, 0, ptr(bias), loss, 0.5, 1.0 / B, ptr(dO),
+                                      blk.ld_cap, ptr(part), ptr(gbp), st))
+      check(lib.rk_decode_bwd_dz_planes(ptr(dO), B, ctypes.byref(pl), blk.ref, ptr(Z), 1, ptr(dz), ptr(ws), st))
+    torch.cuda.synchronize()
+    return dO[:B * ld].view(B, ld).clone(), part.clone(), gbp.clone(), blk.counts[8:72].clone(), dz
+  a, b = run(False), run(True)
+  lib.rk_planes_tile(0)
+  for x, y in zip(a[:4], b[:4]):
+    assert torch.equal(x, y)
+  ref = (a[0][:, :n_b].double() @ W[blk.items[:n_b].long()].double()) * (1 - Z.double() ** 2)
+  top = max(ref.abs().max().item(), 1e-30)
+  assert (b[4].double() - ref).abs().max().item() <= 2e-6 * top
+  assert (b[4].double() - a[4].double()).abs().max().item() <= 2e-6 * top
+  assert bool(torch.isfinite(b[4]).all())
+
+
 def test_plane_images_hold_the_split_operands():
   """hi + lo of every image entry reproduces s.x to 2^-22 (fp16 pair), the K padding is zero, the W^T
   image is the transpose of the W image (k-tile major) with zeros behind the live items."""
