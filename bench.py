@@ -57,6 +57,12 @@ ENTRIES = ["rk_ae_encode_fwd", "rk_decode_loss", "rk_decode_bwd_dz", "rk_decode_
 # stream ("rk_adam_de"), the step's update launch ("rk_adam_multi") covers the rest -- the SAME kernel
 # twice per step; set in main() from the library
 ADAM_DE_SIDE = False
+# the one-call step's launch structure (set in main() from the library): dZ fused into the decode
+# launch (decode16.hip DZT: "rk_decode_loss" then carries both contractions, "rk_decode_bwd_dz" is the
+# slab reduce alone) and dW || encoder backward as one launch (dw3.hip dw_encbwd_kernel: bracketed as
+# "rk_decode_bwd_dw", no "rk_ae_encode_bwd" launch)
+FUSED_DZ = False
+FUSED_DW_ENC = False
 # the kernels each bracketed entry launches (names as rocprofv3 --kernel-trace prints them)
 KERNELS = {"rk_ae_encode_fwd": ["ae_encode_fwd_kernel (+ the W_de[items] split workgroups)"],
            "rk_decode_loss": ["decode_planes_kernel<TM,2,EPI>"],
@@ -116,6 +122,10 @@ def make_csr(cfg):
 def algorithmic_work(entry, B, h0, n_b, nnz, n_items, cfg_sparse=False):
   """(bound, work per launch group [TFLOP or GB], unit) of one C-ABI entry."""
   gemm = 2.0 * B * h0 * n_b
+  if entry == "rk_decode_loss" and FUSED_DZ:
+    return "mfma", 2 * gemm / 1e12, "TFLOP/s"      # decode + the dZ partials of every column tile
+  if entry == "rk_decode_bwd_dz" and FUSED_DZ:     # the reduce of the column-tile slabs alone
+    return "hbm", (-(-int(n_b) // 128) * B * h0 * 4 + 2 * B * h0 * 4) / 1e9, "GB/s"
   if entry in ("rk_decode_loss", "rk_decode_bwd_dz", "rk_decode_bwd_dw"):
     return "mfma", gemm / 1e12, "TFLOP/s"          # algorithmic flops of the contraction
   if entry == "rk_ae_encode_fwd":
@@ -512,8 +522,19 @@ def main():
     n_b, nnz = float(np.mean(nbs)), float(np.mean(nnzs))
     ev_over = eng.event_pair_overhead_ms()
     timed = eng.timed_samples_ms()
-    global ADAM_DE_SIDE
+    global ADAM_DE_SIDE, FUSED_DZ, FUSED_DW_ENC
     from recoder_amd import _lib as _rk_lib
+    one_call = cfg["kind"] == "ae" and len(cfg["hidden_layers"]) == 1 and cfg["loss"] in ("mse", "logistic") \
+        and getattr(eng, "ws_dw", None) is not None and not multi and getattr(eng, "planes", None) is not None
+    if one_call:
+      lk = 0 if cfg["loss"] == "mse" else 1
+      FUSED_DZ = bool(_rk_lib.load().rk_decode_dz_fused_ok(B, h0, eng.n_cap_last, lk))
+      FUSED_DW_ENC = bool(_rk_lib.load().rk_dw_encode_bwd_fused_ok(0, B))
+      if FUSED_DZ:
+        KERNELS["rk_decode_loss"] = ["decode_planes_kernel<1,2,EPI,3,false,DZT> (decode + loss + dZ partials per column tile)"]
+        KERNELS["rk_decode_bwd_dz"] = ["splitk_reduce_kernel"]
+      if FUSED_DW_ENC:
+        KERNELS["rk_decode_bwd_dw"] = ["dw_encbwd_kernel<BN,HV> (dW tiles || encoder-backward columns)"]
     ADAM_DE_SIDE = bool(_rk_lib.load().rk_adam_de_side()) and getattr(eng, "ws_dw", None) is not None and \
         not multi and bool(timed.get("rk_adam_de") or T["warm"].get("rk_adam_de"))
 
@@ -602,7 +623,8 @@ def main():
                             % os.path.relpath(files[-1], ROOT))
     # the dW launch group runs on the side stream NEXT to dZ -> encoder backward
     # (rk_ae_step_t.dw_stream): it is not a link of the step's chain then
-    side = ["rk_decode_bwd_dw", "rk_adam_de"] if (getattr(eng, "ws_dw", None) is not None and not multi) else []
+    side = ["rk_decode_bwd_dw", "rk_adam_de"] if (getattr(eng, "ws_dw", None) is not None and not multi and
+                                                  not FUSED_DW_ENC) else []
     for k in kernels:
       if k["name"] in side:
         k["concurrent_with"] = ["rk_decode_bwd_dz", "rk_ae_encode_bwd"]
