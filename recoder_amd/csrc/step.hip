@@ -414,12 +414,6 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   // dW on a stream of its own next to the dZ -> encoder-backward chain (rk_ae_step_t.dw_stream)
   const bool dw_branch = dw3 && a->dw_stream != nullptr;
   RK_REQUIRE(!dw_branch || (a->ws_dw && a->dw_fork && a->dw_join), "dw_stream needs ws_dw, dw_fork, dw_join");
-  // the decoder table's Adam sweep right behind the dW kernel ON dw_stream (it needs nothing else),
-  // next to the reduce / encoder backward of the chain; the update on the chain then covers the
-  // encoder table, the biases and the loss (rk_adam_de_side; RK_ADAM_DE_SIDE=0: one launch)
-  // dW and the encoder backward as ONE launch on the chain instead of a side-stream branch
-  const bool dw_enc_fused = dw3 && rk_dw_encode_bwd_fused_ok(a->row_off, B) != 0;
-  const bool de_side = dw_branch && !dw_enc_fused && phase == RK_STEP_ALL && rk_adam_de_side() != 0;
 
   // pre-split operand planes (decode16.hip): W_de[items] is split by extra workgroups of the
   // encoder-forward launch, Z by that kernel's epilogue; decode and dZ copy the images into LDS
@@ -429,6 +423,13 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   const bool dz_fused = pl && (phase & RK_STEP_FWD_DW) && (phase & RK_STEP_DZ_ENC) && !a->tied && !mnll &&
                         a->ws != nullptr &&
                         rk_decode_dz_fused_ok(B, h, blk->n_cap, a->loss_kind) != 0;
+  // dW and the encoder backward as ONE launch on the chain instead of a side-stream branch
+  // (in the small-shape domain of the fused decode only: at C5's sizes -- dW 100+ us -- the side-stream
+  // branch next to dZ -> encoder backward is worth more than its two edges: 0.75 vs 0.83 ms per step)
+  const bool dw_enc_fused = dw3 && dz_fused && rk_dw_encode_bwd_fused_ok(a->row_off, B) != 0;
+  // opt-in (rk_adam_de_side): the decoder table's Adam sweep right behind the dW kernel ON dw_stream,
+  // next to the reduce / encoder backward; the update on the chain then covers the rest
+  const bool de_side = dw_branch && !dw_enc_fused && phase == RK_STEP_ALL && rk_adam_de_side() != 0;
   if (phase & RK_STEP_FWD_DW) {
     {
       Timer t(a, RK_ENTRY_ENCODE_FWD, sm);

@@ -19,7 +19,7 @@ ENTRY_KERNELS = {
   "rk_adam_multi": ["adam_multi_kernel"],
   "rk_decode_loss": ["decode_planes_kernel", "gemm_kernel<2, 2, 1, 2, 0, 0, 1"],
   "rk_decode_bwd_dz": ["dz_planes_kernel", "gemm_kernel<4, 1, 1, 4, 0, 1, 2", "splitk_reduce_kernel"],
-  "rk_decode_bwd_dw": ["dw3_kernel"],                    # bf16-pipe dW (csrc/dw3.hip)
+  "rk_decode_bwd_dw": ["dw3_kernel", "dw_encbwd_kernel"],   # dW (csrc/dw3.hip), alone or || encoder backward
   "rk_ae_encode_bwd": ["ae_encode_bwd_cols_kernel", "ae_encode_bwd_kernel"],
   "rk_ae_encode_fwd": ["ae_encode_fwd_kernel"],
 }
