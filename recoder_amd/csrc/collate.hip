@@ -19,7 +19,14 @@
 namespace {
 
 constexpr int SMALL_SCAN_MAX = 1 << 16;   // catalogues up to 64k items: single-workgroup scan
-constexpr int SEG_WORDS = 2048;           // bitmap words a wave builds in LDS at a time
+constexpr int SEG_WORDS = 2048;           // bitmap words a wave builds in LDS at a time, at most
+// (the launch asks for what the block's capacity needs: 629 words per wave at ML-20M's 20 k items = 10 KB
+// per workgroup instead of 32 -- the look-ahead collation runs beside the fused decode launch, which
+// leaves 22 KB of a CU's LDS)
+inline int seg_words_for(int n_cap) {
+  const int w = ((n_cap + 31) / 32 + 63) & ~63;
+  return w < 64 ? 64 : (w > SEG_WORDS ? SEG_WORDS : w);
+}
 
 // ---- phase 1 (one launch): mark the touched items, scan the row degrees, clear
 //      the transposed bitmap.  Roles by block index:
@@ -329,8 +336,8 @@ __global__ __launch_bounds__(1024) void collate_scan_small_multi_kernel(int all,
 __device__ __forceinline__ void collate_build_body(
     const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
     const float *__restrict__ ds_data, const int64_t *__restrict__ users, int S, const rk_block_t &b,
-    rk_cur_t cur) {
-  __shared__ uint32_t wbits[4][SEG_WORDS];
+    rk_cur_t cur, const int seg) {
+  extern __shared__ uint32_t wbits[];               // [4 waves][seg words]
   if (cur.cursor) users += rk_cur_local(cur) * S;
   const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + wid;
@@ -349,12 +356,12 @@ __device__ __forceinline__ void collate_build_body(
     b.vals[out0 + k] = c < 0 ? 0.0f : (ds_data ? ds_data[beg + k] : 1.0f);
     if (b.bits_cr && c >= 0) atomicOr(&b.bits_cr[(int64_t)c * b.ldw_cr + (row >> 5)], 1u << (row & 31));
   }
-  uint32_t *wb = wbits[wid];
+  uint32_t *wb = wbits + wid * seg;
   uint32_t *bits = b.bits_rc + (int64_t)row * b.ldw_rc;
   int32_t *pref = b.pref_rc ? b.pref_rc + (int64_t)row * b.ldw_rc : nullptr;
   int32_t carry = 0;
-  for (int w0 = 0; w0 < wr; w0 += SEG_WORDS) {
-    const int nw = min(SEG_WORDS, wr - w0);
+  for (int w0 = 0; w0 < wr; w0 += seg) {
+    const int nw = min(seg, wr - w0);
     for (int w = lane; w < nw; w += 64) wb[w] = 0u;
     __builtin_amdgcn_wave_barrier();
     for (int k = lane; k < n; k += 64) {
@@ -385,15 +392,15 @@ __device__ __forceinline__ void collate_build_body(
 __global__ __launch_bounds__(256) void collate_build_kernel(
     const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
     const float *__restrict__ ds_data, const int64_t *__restrict__ users, int S, rk_block_t b,
-    rk_cur_t cur) {
-  collate_build_body(ds_indptr, ds_indices, ds_data, users, S, b, cur);
+    rk_cur_t cur, int seg) {
+  collate_build_body(ds_indptr, ds_indices, ds_data, users, S, b, cur, seg);
 }
 __global__ __launch_bounds__(256) void collate_build_multi_kernel(
     const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
     const float *__restrict__ ds_data, const int64_t *__restrict__ users, int S, MultiBlk mb,
-    rk_cur_t cur) {
+    rk_cur_t cur, int seg) {
   cur.off += (int)blockIdx.y;
-  collate_build_body(ds_indptr, ds_indices, ds_data, users, S, mb.b[blockIdx.y], cur);
+  collate_build_body(ds_indptr, ds_indices, ds_data, users, S, mb.b[blockIdx.y], cur, seg);
 }
 
 }  // namespace
@@ -464,8 +471,9 @@ static int collate_impl(const int64_t *ds_indptr, const int32_t *ds_indices,
                        blk->pos, blk->items, blk->counts, blk->n_cap, blk->nnz_cap, cur);
     RK_CHECK_LAUNCH("collate_assign");
   }
-  RK_LAUNCH(collate_build_kernel, dim3(rk_cdiv(S, 4)), dim3(256), 0, stream,
-                     ds_indptr, ds_indices, ds_data, users, S, *blk, cur);
+  const int seg = seg_words_for(blk->n_cap);
+  RK_LAUNCH(collate_build_kernel, dim3(rk_cdiv(S, 4)), dim3(256), 4 * seg * sizeof(uint32_t), stream,
+                     ds_indptr, ds_indices, ds_data, users, S, *blk, cur, seg);
   RK_CHECK_LAUNCH("collate_build");
   return 0;
 }
@@ -548,8 +556,9 @@ extern "C" int rk_collate_at_multi_phase(const int64_t *ds_indptr, const int32_t
     RK_LAUNCH(collate_assign_multi_kernel, dim3(b0->n_chunks, n_blk), dim3(256), 0, stream, all, mb, cur);
     RK_CHECK_LAUNCH("collate_assign_multi");
   }
-  RK_LAUNCH(collate_build_multi_kernel, dim3(rk_cdiv(S, 4), n_blk), dim3(256), 0, stream, ds_indptr,
-            ds_indices, ds_data, users_base, S, mb, cur);
+  const int seg = seg_words_for(b0->n_cap);
+  RK_LAUNCH(collate_build_multi_kernel, dim3(rk_cdiv(S, 4), n_blk), dim3(256), 4 * seg * sizeof(uint32_t), stream,
+            ds_indptr, ds_indices, ds_data, users_base, S, mb, cur, seg);
   RK_CHECK_LAUNCH("collate_build_multi");
   return 0;
 }
