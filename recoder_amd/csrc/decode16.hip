@@ -497,6 +497,7 @@ void decode_planes_kernel(DecP p) {
   }
   if (DZT > 0) {
     // ---------------------------------------------------------------- fused dZ partial of this tile
+    RK_STAMP(5);
     constexpr int T2A = DZT > 0 ? (DZT + 1) / 2 : 1;     // column tiles (32 hidden units) per wave
     float *lred2 = fsm + 4 * (32 * TLD);
     const float gm = fmaxf(fmaxf(lred2[4], lred2[5]), fmaxf(lred2[6], lred2[7]));   // the tile's max |dO|

@@ -25,6 +25,10 @@ def report(name, buf, tick_us=0.01):
   print("%s: %d live workgroups, last end %.1f us" % (name, len(live), rel[:, 3].max()))
   for lab, x in (("start", start), ("prologue", pro), ("k-loop", loop), ("epilogue", epi)):
     print("   %-9s %s" % (lab, q(x)))
+  if (live[:, 5] > 0).all():          # the fused decode + dZ launch: where its dZ part starts
+    mid = (live[:, 5].astype(np.float64) - t0) * tick_us
+    print("   %-9s %s" % ("  loss ep.", q(mid - rel[:, 2])))
+    print("   %-9s %s" % ("  dZ part", q(rel[:, 3] - mid)))
 
 
 def main():
@@ -64,6 +68,9 @@ def main():
   for tile in (64, 128):
     calls.append(("decode+mse tile %d" % tile, tile, dec(LOSS_MSE)))
     calls.append(("decode store tile %d" % tile, tile, dec(LOSS_NONE)))
+  wsf = torch.empty(lib.rk_dz_fused_workspace_bytes(B, h, blk.n_cap) // 4 + 64, **f)
+  calls.append(("decode+mse+dZ partials (fused) tile 64", 64, lambda: lib.rk_decode_loss_dz_planes(
+      ctypes.byref(pl), B, blk.ref, 0, ptr(bias), LOSS_MSE, 0.0, 1.0 / B, ptr(dO), ptr(part), ptr(gbp), ptr(wsf), st)))
   calls.append(("dz (GEMM + reduce)", 64, lambda: lib.rk_decode_bwd_dz_planes(
       ptr(dO), B, ctypes.byref(pl), blk.ref, None, 0, ptr(dZ), ptr(ws), st)))
   for name, tile, fn in calls:
