@@ -420,8 +420,11 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   const bool pl = a->planes != nullptr && rk_gemm_split16() != 0;
   // dZ fused into the decode launch (decode16.hip DZT): the phases that hold both halves and leave the
   // dZ workspace alone in between -- the untied MSE / BCE step whose dW has a workspace of its own
-  const bool dz_fused = pl && (phase & RK_STEP_FWD_DW) && (phase & RK_STEP_DZ_ENC) && !a->tied && !mnll &&
-                        a->ws != nullptr &&
+  // Phased (data-parallel) steps: the slabs must survive from the FWD_DW call to the DZ_ENC call, so
+  // the in-line dW of the first takes the workspace of its own (ws_dw) -- the same predicate in both calls.
+  const bool both = (phase & RK_STEP_FWD_DW) && (phase & RK_STEP_DZ_ENC);
+  const bool dz_fused = pl && !a->tied && !mnll && a->ws != nullptr && (both ? whole : a->ws_dw != nullptr) &&
+                        (phase & (RK_STEP_FWD_DW | RK_STEP_DZ_ENC)) != 0 &&
                         rk_decode_dz_fused_ok(B, h, blk->n_cap, a->loss_kind) != 0;
   // dW and the encoder backward as ONE launch on the chain instead of a side-stream branch
   // (in the small-shape domain of the fused decode only: at C5's sizes -- dW 100+ us -- the side-stream
@@ -483,7 +486,8 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     // fused with the encoder backward below
     if (a->tied || mnll || !whole) {
       Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
-      RK_TRY(dw_call(a, a->G_de, mnll ? a->gb_de : nullptr, planes));
+      // (the fused decode's dZ slabs sit in a->ws until the DZ_ENC call: dW works in ws_dw then)
+      RK_TRY(dw_call(a, a->G_de, mnll ? a->gb_de : nullptr, planes, dz_fused ? a->ws_dw : nullptr));
     }
     if (!whole) {
       // the data-parallel exchange needs gb_de and the loss scalar as arrays of their own

@@ -720,6 +720,8 @@ class FusedEngine:
     st.stream = main_s.cuda_stream
     st.cursor, st.cursor_off, st.adam_table, st.cursor_next, st.cursor_advance = None, 0, None, None, 0
     st.ws_dw = st.dw_stream = st.dw_fork = st.dw_join = None
+    if dp is not None and self.ws_dw is not None and not m.is_constrained:
+      st.ws_dw = ptr(self.ws_dw)        # (phased steps: dW's own workspace lets the decode launch keep its dZ slabs)
     self._ws_dw_live = False
     if dw3 and self.ws_dw is not None:
       if self._dw_objs is None:
