@@ -115,7 +115,8 @@ def test_decode_with_fused_dz_equals_the_two_launches(B, h, n_items, loss):
   own scale and sums per 128-item tile instead of per K chunk) and against a float64 product."""
   lib, blk, W, bias, Z, ranges, pl, buf = _setup(B, h, max(B, 600), n_items, 14, seed=B + h,
                                                  ratings=(loss == LOSS_MSE and h == 200))
-  assert lib.rk_decode_dz_fused_ok(B, h, blk.n_cap, loss) == 1
+  if lib.rk_decode_dz_fused_ok(B, h, blk.n_cap, loss) != 1:
+    pytest.skip("the fused decode + dZ launch is switched off (RK_DZ_FUSED=0 / plain bf16 operands)")
   st = current_stream()
   f = dict(dtype=torch.float32, device=Z.device)
   n_b, nnz, ld, S = blk.counts_host()
