@@ -396,7 +396,7 @@ class FusedEngine:
     check(self.lib.rk_amax(ptr(z), n, ptr(self.ranges), stream), "rk_amax")
     return ptr(self.ranges)
 
-  def _loss(self, z, B, tgt, row_off, denom_rows, stream, out=None, ip=None, defer=False):
+  def _loss(self, z, B, tgt, row_off, denom_rows, stream, out=None, ip=None, defer=False, fuse_dz=False):
     """decode + loss; leaves dLoss/dLogits in self.dO. Returns device scalar.  ip: the
     block holds an item shard (parallel.ItemParallel) -- only the multinomial loss needs to
     know: its softmax statistics are combined over the ranks."""
@@ -404,10 +404,27 @@ class FusedEngine:
     W, b = self._decoder_params()
     inv_B = _f32(np.float32(1.0) / np.float32(denom_rows))
     out = self.loss_out if out is None else out
-    check(lib.rk_decode_loss(ptr(z), B, self.h[0], tgt.ref, row_off, ptr(W), ptr(b), self.loss_id,
-                             self.confidence, inv_B, ptr(self.dO), 0, ptr(self.loss_part),
-                             ptr(self.gb_part), self._ranges(z, B * self.h[0], stream), stream),
-          "rk_decode_loss")
+    self._dz_in_ws = False
+    if fuse_dz and ip is None and self.planes is not None and self.split16 and self.ws_dw is not None and \
+        self.item_parallel is None and lib.rk_decode_dz_fused_ok(B, self.h[0], tgt.n_cap, self.loss_id):
+      # training steps sequenced entry by entry (hidden stacks, bottleneck dropout, MatrixFactorization):
+      # the operands are split once (two launches) and the decode launch leaves the dZ partials of its
+      # column tiles in self.ws (rk_decode_loss_dz_planes) -- the dZ launch, its pass over dO and the
+      # in-loop operand splits go; rk_decode_dz_reduce follows where rk_decode_bwd_dz stood, dW works
+      # in its own workspace in between
+      h0 = self.h[0]
+      rg = self._ranges(z, B * h0, stream)
+      check(lib.rk_split_w(ptr(W), h0, tgt.ref, rg, ctypes.byref(self.planes), stream), "rk_split_w")
+      check(lib.rk_split_z(ptr(z), B, h0, rg, ctypes.byref(self.planes), stream), "rk_split_z")
+      check(lib.rk_decode_loss_dz_planes(ctypes.byref(self.planes), B, tgt.ref, row_off, ptr(b), self.loss_id,
+                                         self.confidence, inv_B, ptr(self.dO), ptr(self.loss_part),
+                                         ptr(self.gb_part), ptr(self.ws), stream), "rk_decode_loss_dz_planes")
+      self._dz_in_ws = True
+    else:
+      check(lib.rk_decode_loss(ptr(z), B, self.h[0], tgt.ref, row_off, ptr(W), ptr(b), self.loss_id,
+                               self.confidence, inv_B, ptr(self.dO), 0, ptr(self.loss_part),
+                               ptr(self.gb_part), self._ranges(z, B * self.h[0], stream), stream),
+            "rk_decode_loss")
     if self.loss_id == LOSS_MNLL and ip is not None:
       # per-row {max, sum exp} of the local logits -> all ranks' pairs -> global log-sum-exp
       stats = torch.empty(B, 2, dtype=torch.float32, device=self.device)
@@ -515,7 +532,8 @@ class FusedEngine:
     # of the bf16-pipe dW (three launches less)
     tied = self.kind == "ae" and bool(m.is_constrained)
     lazy = ip is None and self.allreduce is None
-    loss = self._loss(z, B, tb, row_off, rows, stream, out, ip=ip, defer=lazy)
+    loss = self._loss(z, B, tb, row_off, rows, stream, out, ip=ip, defer=lazy,
+                      fuse_dz=os.environ.get("RK_ENTRY_DZ_FUSED", "1") != "0")
     self._loss_target = loss
 
     # ---- dW = dO^T . z  (+ decoder bias gradient) ----
@@ -560,9 +578,14 @@ class FusedEngine:
     if self.kind == "ae" and self.nl > 0:
       dz = self.ddec[self.nl - 1]
     fuse_act = simple and ip is None        # act' folded into the split-K reduce
-    check(lib.rk_decode_bwd_dz(ptr(self.dO), B, h0, tb.ref, ptr(W_de),
-                               ptr(self.enc[0]) if fuse_act else None, self.act, ptr(dz),
-                               ptr(self.ws), ptr(self.ranges), stream), "rk_decode_bwd_dz")
+    if getattr(self, "_dz_in_ws", False):
+      check(lib.rk_decode_dz_reduce(ptr(self.ws), B, h0, tb.ref, ptr(self.enc[0]) if fuse_act else None,
+                                    self.act, ptr(dz), stream), "rk_decode_dz_reduce")
+      self._dz_in_ws = False
+    else:
+      check(lib.rk_decode_bwd_dz(ptr(self.dO), B, h0, tb.ref, ptr(W_de),
+                                 ptr(self.enc[0]) if fuse_act else None, self.act, ptr(dz),
+                                 ptr(self.ws), ptr(self.ranges), stream), "rk_decode_bwd_dz")
     if ip is not None:
       # item parallel: dLoss/d(decoder input) summed over the ranks' item shards; everything
       # upstream (hidden stacks, user rows) is replicated and sees identical inputs
@@ -633,6 +656,8 @@ class FusedEngine:
       # fp16 pairs (rk_decode_bwd_dw2: three products, the scale of z from self.ranges -- the bound
       # rk_amax left there for this z when the activation is unbounded) unless RK_DW_PREC=bf16x3
       G, ws = (None, self.ws_dw) if keep_slabs else (self.G_de, self.ws)
+      if getattr(self, "_dz_in_ws", False):
+        ws = self.ws_dw                  # (self.ws holds the decode launch's dZ partials until the reduce)
       if self.lib.rk_dw_pairs():
         check(self.lib.rk_decode_bwd_dw2(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(G), ptr(gb_de), ptr(ws),
                                          None, ptr(self.ranges), stream), "rk_decode_bwd_dw2")
