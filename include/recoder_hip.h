@@ -361,7 +361,7 @@ void rk_planes_tile(int32_t rows);
  * slabs (* act'(Zact) if given) into dZ.  Replaces rk_decode_loss_planes + rk_decode_bwd_dz_planes
  * (one launch, one pass over dO and one cross-queue edge less); same mathematics, other split scales
  * and summation grouping than the stand-alone kernel (agreement ~1e-7 relative).  Shapes / losses:
- * rk_decode_dz_fused_ok (h <= 256, B < 1024 and n_cap < 32768: the 64-row tile's domain; RK_DZ_FUSED=0
+ * rk_decode_dz_fused_ok (h <= 256, B < 1024, slab workspace <= 4 GB; always 64-row tiles; RK_DZ_FUSED=0
  * turns it off).
  */
 int32_t rk_decode_dz_fused_ok(int32_t B, int32_t h, int32_t n_cap, int32_t loss_kind);

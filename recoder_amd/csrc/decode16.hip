@@ -998,13 +998,21 @@ static int dz_fused_on() {
   return on;
 }
 
-extern "C" int32_t rk_decode_dz_fused_ok(int32_t B, int32_t h, int32_t n_cap, int32_t loss_kind) {
-  return dz_fused_on() && !rk_gemm_plain_bf16() && (loss_kind == RK_LOSS_MSE || loss_kind == RK_LOSS_BCE) &&
-         h % 4 == 0 && h <= 256 && dec_tm(B, n_cap) == 1 ? 1 : 0;
+// The fused launch always runs 64 x 128 tiles, whatever the block's CAPACITY: the 128-row tile rule of
+// the plain decode (dec_tm: n_cap >= 32768) looks at the capacity because the live item count only
+// exists on the device, and sent the MSD-big stand-in (250 k items, 10 k of them live per batch) to
+// the two-launch form -- 0.138 vs 0.122 ms per step.  Not with a forced 128-row tile (tests), and not
+// when the slab workspace (one slab per 128 items of CAPACITY) would pass 4 GB.
+extern "C" int64_t rk_dz_fused_workspace_bytes(int32_t B, int32_t h, int32_t n_cap) {
+  if (h > 256 || B >= 1024) return 0;                      // never in the fused launch's domain
+  return (int64_t)rk_cdiv(n_cap, 128) * B * h * sizeof(float);
 }
 
-extern "C" int64_t rk_dz_fused_workspace_bytes(int32_t B, int32_t h, int32_t n_cap) {
-  return (int64_t)rk_cdiv(n_cap, 128) * B * h * sizeof(float);
+extern "C" int32_t rk_decode_dz_fused_ok(int32_t B, int32_t h, int32_t n_cap, int32_t loss_kind) {
+  (void)dec_tm(B, n_cap);                                  // (reads RK_DEC_TILE once)
+  return dz_fused_on() && !rk_gemm_plain_bf16() && (loss_kind == RK_LOSS_MSE || loss_kind == RK_LOSS_BCE) &&
+         h % 4 == 0 && h <= 256 && B < 1024 && g_dec_tm != 2 &&
+         rk_dz_fused_workspace_bytes(B, h, n_cap) <= ((int64_t)4 << 30) ? 1 : 0;
 }
 
 extern "C" int rk_decode_loss_dz_planes(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt,
