@@ -69,7 +69,10 @@ KERNELS = {"rk_ae_encode_fwd": ["ae_encode_fwd_kernel (+ the W_de[items] split w
            "rk_decode_bwd_dz": ["dz_planes_kernel<TN>", "splitk_reduce_kernel"],
            "rk_decode_bwd_dw": ["dw3_kernel<BN,PLAIN,PAIRS> (+ split_planes_t_kernel when the encoder did not write Z^T)"],
            "rk_ae_encode_bwd": ["ae_encode_bwd_cols_kernel", "ae_encode_bwd_kernel"],
-           "rk_adam_multi": ["adam_multi_kernel"], "rk_adam_de": ["adam_multi_kernel"]}
+           "rk_adam_multi": ["adam_multi_kernel"], "rk_adam_de": ["adam_multi_kernel"],
+           "rk_decode_loss_dz_planes": ["decode_planes_kernel<1,2,EPI,3,false,DZT> (decode + loss + dZ partials)"],
+           "rk_decode_dz_reduce": ["splitk_reduce_kernel"], "rk_split_w": ["split_w_kernel"],
+           "rk_decode_bwd_dw2": ["dw3_kernel<BN,false,true>"]}
 
 CONFIGS = {
   # C2 of BASELINE.json: ML-20M autoencoder, hidden [200], MSE, 1 x MI355X
@@ -160,8 +163,14 @@ def entry_work(entry, B, h0, n_b, nnz, n_items, cfg):
   multinomial loss); (None, ...) for the small launches that have no meaningful roofline."""
   if entry in ENTRIES:
     return algorithmic_work(entry, B, h0, n_b, nnz, n_items, bool(cfg["sparse"]))
-  if entry in ("rk_decode_bwd_dw3",):
+  if entry in ("rk_decode_bwd_dw3", "rk_decode_bwd_dw2"):
     return "mfma", 2.0 * B * h0 * n_b / 1e12, "TFLOP/s"
+  if entry == "rk_decode_loss_dz_planes":       # decode + loss + the dZ partials of every column tile
+    return "mfma", 4.0 * B * h0 * n_b / 1e12, "TFLOP/s"
+  if entry == "rk_decode_dz_reduce":            # the column-tile slabs summed
+    return "hbm", (-(-int(n_b) // 128) * B * h0 * 4 + 2 * B * h0 * 4) / 1e9, "GB/s"
+  if entry == "rk_split_w":                     # gathered decoder rows -> W and W^T plane images
+    return "hbm", 3.0 * n_b * h0 * 4 / 1e9, "GB/s"
   if entry == "rk_mnll_finish":                 # two passes over the B x n_b logits, one write
     return "hbm", 3.0 * B * n_b * 4 / 1e9, "GB/s"
   if entry in ("rk_linear_fwd", "rk_linear_bwd") and cfg["kind"] == "ae" and len(cfg["hidden_layers"]) > 1:
@@ -178,7 +187,7 @@ def peak_of(entry, bound):
     return PEAK_HBM_GBS
   if GEMM_F32:
     return PEAK_MFMA_F32_TF
-  return PEAK_MFMA_16_TF / (1 if GEMM_BF16 else PRODUCTS[entry])
+  return PEAK_MFMA_16_TF / (1 if GEMM_BF16 else PRODUCTS.get(entry, 3))
 
 
 def cpu_baseline(cfg, csr, steps, warmup=4):
@@ -563,7 +572,8 @@ def main():
       kernels = []
       # (the steps that really went through the bracketed calls: with graph replay only the eagerly
       # sequenced ones behind the sampling mark do; the decode runs exactly once per step)
-      n_sampled = max(1, T["entries"].get("rk_decode_loss", (n_sample, 0.0))[0])
+      n_sampled = max(1, T["entries"].get("rk_decode_loss", T["entries"].get("rk_decode_loss_dz_planes",
+                                                                             (n_sample, 0.0)))[0])
       for e, (calls, ms) in sorted(T["entries"].items(), key=lambda kv: -kv[1][0] * kv[1][1]):
         per_step = calls / float(n_sampled)
         bound, work, unit = entry_work(e, B, h0, n_b, nnz, n_items, cfg)
