@@ -72,7 +72,8 @@ KERNELS = {"rk_ae_encode_fwd": ["ae_encode_fwd_kernel (+ the W_de[items] split w
            "rk_adam_multi": ["adam_multi_kernel"], "rk_adam_de": ["adam_multi_kernel"],
            "rk_decode_loss_dz_planes": ["decode_planes_kernel<1,2,EPI,3,false,DZT> (decode + loss + dZ partials)"],
            "rk_decode_dz_reduce": ["splitk_reduce_kernel"], "rk_split_w": ["split_w_kernel"],
-           "rk_decode_bwd_dw2": ["dw3_kernel<BN,false,true>"]}
+           "rk_decode_bwd_dw2": ["dw3_kernel<BN,false,true>"],
+           "rk_decode_bwd_dw2_encode_bwd": ["dw_encbwd_kernel<BN,HV> (dW tiles || encoder-backward columns)"]}
 
 CONFIGS = {
   # C2 of BASELINE.json: ML-20M autoencoder, hidden [200], MSE, 1 x MI355X
@@ -163,7 +164,7 @@ def entry_work(entry, B, h0, n_b, nnz, n_items, cfg):
   multinomial loss); (None, ...) for the small launches that have no meaningful roofline."""
   if entry in ENTRIES:
     return algorithmic_work(entry, B, h0, n_b, nnz, n_items, bool(cfg["sparse"]))
-  if entry in ("rk_decode_bwd_dw3", "rk_decode_bwd_dw2"):
+  if entry in ("rk_decode_bwd_dw3", "rk_decode_bwd_dw2", "rk_decode_bwd_dw2_encode_bwd"):
     return "mfma", 2.0 * B * h0 * n_b / 1e12, "TFLOP/s"
   if entry == "rk_decode_loss_dz_planes":       # decode + loss + the dZ partials of every column tile
     return "mfma", 4.0 * B * h0 * n_b / 1e12, "TFLOP/s"

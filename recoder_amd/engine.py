@@ -46,7 +46,8 @@ class TimedLib:
 
   def __getattr__(self, name):
     fn = getattr(self._lib, name)
-    if not name.startswith("rk_") or name in ("rk_dz_workspace_bytes", "rk_dz_fused_workspace_bytes", "rk_decode_dz_fused_ok", "rk_dw_workspace_bytes", "rk_dw_splits", "rk_encode_bwd_segments", "rk_loss_partials", "rk_decode_row_tile",
+    if not name.startswith("rk_") or name in ("rk_dz_workspace_bytes", "rk_dz_fused_workspace_bytes", "rk_decode_dz_fused_ok",
+                                              "rk_dw_encode_bwd_fused_ok", "rk_dw_workspace_bytes", "rk_dw_splits", "rk_encode_bwd_segments", "rk_loss_partials", "rk_decode_row_tile",
                                               "rk_dw3_workspace_bytes", "rk_dw3_max_splits", "rk_dw3_slabs", "rk_gemm_split16", "rk_dw_pairs",
                                               "rk_dw3_planes_bytes", "rk_dw3_rows_pad", "rk_dw3_cols_pad",
                                               "rk_planes_bytes", "rk_planes_layout",
@@ -553,7 +554,23 @@ class FusedEngine:
       self._dw_ev[0].record(main_s)
       dw_side.wait_event(self._dw_ev[0])
       dw_stream = ctypes.c_void_p(dw_side.cuda_stream)
-    if self.loss_id == LOSS_MNLL:
+    # dW (it needs dO and z only) can wait for the encoder backward and share its launch
+    # (rk_decode_bwd_dw2_encode_bwd: one launch less on the chain) when both work on ONE block, the K
+    # slabs stay in the dW workspace for the Adam sweep and no side stream is in play
+    defer_dw = (keep_slabs and dw_side is None and self.kind == "ae" and tb is blk and
+                os.environ.get("RK_ENTRY_DW_ENC_FUSED", "1") != "0" and
+                bool(lib.rk_dw_encode_bwd_fused_ok(row_off, B)))
+    self._dw_deferred = None
+    if defer_dw:
+      if self.loss_id == LOSS_MNLL:
+        check(lib.rk_colsum(ptr(self.dO), B, tb.n_cap, 0, ptr(tb.counts), ptr(self.gb_de), stream), "rk_colsum")
+      elif lazy:
+        self._gb_lazy = (cdiv(B, self.row_tile), tb)
+      else:
+        check(lib.rk_colsum(ptr(self.gb_part), cdiv(B, self.row_tile), tb.n_cap, 0, ptr(tb.counts),
+                            ptr(self.gb_de), stream), "rk_colsum")
+      self._dw_deferred = z
+    elif self.loss_id == LOSS_MNLL:
       # dO was produced by rk_mnll_finish: column sums need a pass over dO
       self._dw(z, B, tb, self.gb_de, dw_stream, keep_slabs)
     else:
@@ -625,8 +642,16 @@ class FusedEngine:
         check(lib.rk_act_grad(ptr(self.denc[0]), ptr(self.enc[0]), B * h0, self.act, stream),
               "rk_act_grad")
       G_en = self.G_de if tied else self.G_en      # tied: accumulates on top of dW's rows
-      check(lib.rk_ae_encode_bwd(blk.ref, row_off, B, ptr(self.denc[0]), h0, ptr(G_en),
-                                 1 if tied else 0, ptr(self.gb_en), stream), "rk_ae_encode_bwd")
+      if getattr(self, "_dw_deferred", None) is not None:
+        zz, self._dw_deferred = self._dw_deferred, None
+        check(lib.rk_decode_bwd_dw2_encode_bwd(ptr(self.dO), ptr(zz), B, h0, blk.ref, ptr(self.ws_dw), None,
+                                               ptr(self.ranges), row_off, ptr(self.denc[0]), ptr(G_en),
+                                               ptr(self.gb_en), stream), "rk_decode_bwd_dw2_encode_bwd")
+        self._dw_slabs = (blk, B)
+        self._ws_dw_live = True
+      else:
+        check(lib.rk_ae_encode_bwd(blk.ref, row_off, B, ptr(self.denc[0]), h0, ptr(G_en),
+                                   1 if tied else 0, ptr(self.gb_en), stream), "rk_ae_encode_bwd")
     else:
       # MF: gradient of the gathered user rows = dU * act'(U) (after dropout)
       n = B * h0
