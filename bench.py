@@ -12,15 +12,17 @@ second one fires after the last timed step was enqueued, synchronizes, barriers 
 (rk_collate) + encoder SpMM + decoder GEMM with fused loss + backward + fused Adam.  The CSR is
 resident in HBM when the timed region starts.  N > 1 is launched by torch.distributed.run, one
 rank per GPU; the USERS are sharded over the ranks (north_star's partitioning; weak scaling:
-B users per rank per step) with one in-order RCCL group of gradient all-reduces per step.
+B users per rank per step) with two in-order RCCL groups of gradient all-reduces per step (decoder
+side, then encoder side), captured with the step's kernels in the replayed graphs.
 
 Also reported:
   roofline     -- every launch group of the production step (rk_ae_train_step) bracketed with HIP
-                  events on the step's stream, in the first (eager) group of the warm-up and in the
-                  LAST whole group of the timed region (enqueued eagerly: events cannot sit inside
-                  a replayed graph; all other groups are graph replays), against its algorithmic
-                  flops / bytes; the slowest one is reported as the dominant
-                  kernel.
+                  events on the step's stream, in the first (eager) group of the warm-up and in ONE
+                  whole group of the timed region (the second one; enqueued eagerly: on the HIP
+                  runtime PyTorch bundles events cannot sit inside a replayed graph; all other
+                  groups are graph replays), against its algorithmic flops / bytes (DESIGN.md
+                  section 4); the kernel the step spends most time in is reported as the dominant one.
+  recall_at_20 -- Recall@20 of the state the run left behind, product vs oracle, outside the clock.
   cpu_baseline -- oracle/recoder_oracle.py (the pinned CPU restatement of the
                   reference op sequence, PyTorch-CPU eager) timed on this host's
                   cores on a bounded sample of the same workload (rank 0, N=1).
