@@ -1003,8 +1003,13 @@ static int dz_fused_on() {
 // exists on the device, and sent the MSD-big stand-in (250 k items, 10 k of them live per batch) to
 // the two-launch form -- 0.138 vs 0.122 ms per step.  Not with a forced 128-row tile (tests), and not
 // when the slab workspace (one slab per 128 items of CAPACITY) would pass 4 GB.
+// (decided by the capacity and h alone -- priced at the domain's largest batch -- so that every batch
+// size of one engine, its ragged last batch included, takes the same form and finds its workspace)
+static inline bool dz_fused_slabs_ok(int h, int n_cap) {
+  return (int64_t)rk_cdiv(n_cap, 128) * 1023 * h * (int64_t)sizeof(float) <= ((int64_t)4 << 30);
+}
 extern "C" int64_t rk_dz_fused_workspace_bytes(int32_t B, int32_t h, int32_t n_cap) {
-  if (h > 256 || B >= 1024) return 0;                      // never in the fused launch's domain
+  if (h > 256 || B >= 1024 || !dz_fused_slabs_ok(h, n_cap)) return 0;    // the two-launch form: no workspace
   return (int64_t)rk_cdiv(n_cap, 128) * B * h * sizeof(float);
 }
 
@@ -1012,7 +1017,7 @@ extern "C" int32_t rk_decode_dz_fused_ok(int32_t B, int32_t h, int32_t n_cap, in
   (void)dec_tm(B, n_cap);                                  // (reads RK_DEC_TILE once)
   return dz_fused_on() && !rk_gemm_plain_bf16() && (loss_kind == RK_LOSS_MSE || loss_kind == RK_LOSS_BCE) &&
          h % 4 == 0 && h <= 256 && B < 1024 && g_dec_tm != 2 &&
-         rk_dz_fused_workspace_bytes(B, h, n_cap) <= ((int64_t)4 << 30) ? 1 : 0;
+         dz_fused_slabs_ok(h, n_cap) ? 1 : 0;
 }
 
 extern "C" int rk_decode_loss_dz_planes(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt,

@@ -167,7 +167,8 @@ class FusedEngine:
     # one workspace, used in turn by the dZ split-K slabs, then by dW (bf16-pipe kernel: Z^T
     # planes + K slabs, which stay live until the Adam sweep has read them)
     self.ws = torch.zeros(max(self.lib.rk_dz_workspace_bytes(B_cap, h0),
-                              self.lib.rk_dz_fused_workspace_bytes(B_cap, h0, n_cap),
+                              # (any batch below 1024 rows -- a ragged last one too -- may take the fused form)
+                              self.lib.rk_dz_fused_workspace_bytes(min(B_cap, 1023), h0, n_cap),
                               self.lib.rk_dw_workspace_bytes(B_cap, h0, n_cap),
                               self.lib.rk_dw3_workspace_bytes(B_cap, h0, n_cap)) // 4 + 64, **f)
     self.split16 = bool(self.lib.rk_gemm_split16())
