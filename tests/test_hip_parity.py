@@ -391,6 +391,14 @@ STEP_CASES = [
   ("edge_b1_mf4", dict(kind="mf", embedding_size=4, activation_type="tanh", sparse=False,
                        loss="mse", loss_params=None, lr=1e-3, weight_decay=2e-5),
    (9, 33, 3), 1, 1),
+  # a batch of >= 1024 rows (128-row decode tiles, stand-alone dZ kernel) followed by a ragged last one
+  # below 1024 (the fused decode + dZ launch, in the workspace the engine sized for the big batch)
+  ("big_then_ragged_ae64", dict(kind="ae", hidden_layers=[64], activation_type="tanh", noise_prob=0.3,
+                                sparse=False, loss="mse", loss_params=None, lr=1e-3, weight_decay=2e-5),
+   (1400, 900, 12), 1100, 1100),
+  ("big_then_ragged_mf16", dict(kind="mf", embedding_size=16, activation_type="none", sparse=True,
+                                loss="logistic", loss_params=None, lr=1e-3, weight_decay=0.0),
+   (1300, 700, 10), 1030, 1030),
 ]
 
 
