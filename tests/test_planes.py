@@ -238,3 +238,50 @@ def test_device_csr_from_arrays_rejects_inconsistent_indptr():
     DeviceCSR.from_arrays((3, 4), np.array([0, 2, 4, 9], dtype=np.int64), indices, None, dev)
   with pytest.raises(ValueError, match="exceeds"):
     DeviceCSR.from_arrays((3, 4), indptr, indices, np.ones(4, dtype=np.float32), dev)
+
+
+@pytest.mark.parametrize("B,h,n_items,row_off", [(500, 200, 3000, 0), (130, 64, 900, 0), (33, 20, 400, 0),
+                                                 (300, 260, 2000, 0), (200, 128, 1500, 56)])
+def test_dw_and_encoder_backward_in_one_launch_equal_the_two_launches(B, h, n_items, row_off):
+  """rk_decode_bwd_dw2_encode_bwd (dw3.hip dw_encbwd_kernel: dW tiles || encoder-backward columns)
+  against rk_decode_bwd_dw2 + rk_ae_encode_bwd: the same workgroup bodies, so the K slabs of dW, their
+  count, G_en and the encoder-bias gradient agree bit for bit."""
+  S = B + row_off
+  lib, blk, W, bias, Z, ranges, pl, buf = _setup(S, h, max(S, 600), n_items, 14, seed=B + h + 1)
+  if lib.rk_dw_encode_bwd_fused_ok(row_off, B) != 1:
+    pytest.skip("the fused dW || encoder-backward launch is switched off")
+  st = current_stream()
+  f = dict(dtype=torch.float32, device=Z.device)
+  n_b, nnz, ld, _ = blk.counts_host()
+  g = torch.Generator(device=Z.device)
+  g.manual_seed(B)
+  dO = torch.zeros(B * blk.ld_cap, **f)
+  dO[:B * ld].view(B, ld)[:, :n_b] = torch.randn(B, n_b, generator=g, **f) * 1e-3
+  blk.counts[8:72].zero_()
+  blk.counts[8:9].copy_(dO.abs().max().reshape(1).view(torch.int32))
+  Zb = Z[:B].contiguous()
+  dZ0 = torch.randn(B, h, generator=g, **f) * 1e-2
+  # svals: what the encoder forward leaves (any values do for the comparison)
+  blk.svals[:nnz].copy_(torch.rand(nnz, generator=g, **f))
+  wsz = lib.rk_dw3_workspace_bytes(B, h, blk.n_cap) // 4 + 64
+
+  def run(fused):
+    ws = torch.zeros(wsz, **f)
+    G_en = torch.full((blk.n_cap * h,), 3.0, **f)
+    gb = torch.full((h * 8,), 3.0, **f)
+    blk.counts[4:5].zero_()
+    if fused:
+      check(lib.rk_decode_bwd_dw2_encode_bwd(ptr(dO), ptr(Zb), B, h, blk.ref, ptr(ws), None, ptr(ranges),
+                                             row_off, ptr(dZ0), ptr(G_en), ptr(gb), st))
+    else:
+      check(lib.rk_decode_bwd_dw2(ptr(dO), ptr(Zb), B, h, blk.ref, None, None, ptr(ws), None, ptr(ranges), st))
+      check(lib.rk_ae_encode_bwd(blk.ref, row_off, B, ptr(dZ0), h, ptr(G_en), 0, ptr(gb), st))
+    torch.cuda.synchronize()
+    ns = int(blk.counts[4].item())
+    off = (lib.rk_dw3_planes_bytes(B, h) + 255) // 256 * 256 // 4
+    slabs = ws[off:off + ns * blk.n_cap * h].view(ns, blk.n_cap, h)[:, :n_b].clone()
+    return ns, slabs, G_en[:n_b * h].clone(), gb[:h].clone()
+  a, b = run(False), run(True)
+  assert a[0] == b[0] and a[0] >= 1
+  assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+  assert float(a[1].abs().max()) > 0 and float(a[2].abs().max()) > 0
