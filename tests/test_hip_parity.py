@@ -762,6 +762,40 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
     assert frac < 2e-3, (k, frac, mx, scale)
 
 
+def test_data_parallel_graph_replay_is_bitwise_equal_to_host_sequencing(monkeypatch):
+  """Users-DP under one RCCL rank: the phased step replayed as HIP graphs (collectives inside, exchange
+  over the blocks' capacity) against the same step sequenced from the host (exchange over the live
+  rows): same losses, same parameters, to the bit."""
+  import torch.distributed as dist
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.model import Recoder
+  csr = synth_csr(1300, 2500, 25, seed=19)
+  c = STEP_CASES[0][1]
+  monkeypatch.setenv("RK_PARALLEL", "users")
+  monkeypatch.setenv("RK_FORCE_DP", "1")
+  monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+  monkeypatch.setenv("MASTER_PORT", "29643")
+  dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+  try:
+    out = {}
+    for mode in ("1", "0"):
+      monkeypatch.setenv("RK_GRAPH_DP", mode)
+      torch.manual_seed(13)
+      model = make_model(c)
+      rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss="mse")
+      rec.user_order_hook = lambda epoch, n: np.random.RandomState(epoch).permutation(n)
+      rec.train(RecommendationDataset(csr), batch_size=250, lr=1e-3, weight_decay=2e-5, num_epochs=2,
+                negative_sampling=True)
+      gs = getattr(rec, "_graph_stepper", None)
+      assert (gs is not None and gs.dp is rec._dp and gs.warmed) == (mode == "1")
+      out[mode] = (np.concatenate(rec.loss_history), {k: v.detach().cpu().clone() for k, v in model.named_parameters()})
+  finally:
+    dist.destroy_process_group()
+  assert np.array_equal(out["1"][0], out["0"][0])
+  for k in out["1"][1]:
+    assert torch.equal(out["1"][1][k], out["0"][1][k]), k
+
+
 class _VirtualRanks:
   """In-process stand-in for the collectives of parallel.ItemParallel: `world` threads,
   one virtual rank each, on ONE GPU."""
