@@ -106,42 +106,70 @@ __device__ __forceinline__ void split_w_job(const SplitW &p, const int tile, cha
   const int tid = threadIdx.x;
   const int Kp = p.KT * 32;
   uint16_t *sh = reinterpret_cast<uint16_t *>(smem);          // [plane][item 32][66]
-  for (int j0 = 0; j0 < Kp; j0 += 64) {
-    // phase 1: item rows -> split -> W image + LDS (row-major)
-    for (int u = tid; u < 32 * 16; u += NT) {
-      const int it = u >> 4, q = u & 15;
-      const int j = j0 + q * 4;
-      const int c = k0 + it;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < n_b && j < p.h) v = *reinterpret_cast<const float4 *>(p.W + (int64_t)p.items[c] * p.h + j);
-      uint2 hi, lo;
-      if (p.plain) plain4(v, hi, lo); else split4(v, s, hi, lo);
-      if (c < n_b && j < Kp) {
-        char *d = p.wp + (int64_t)c * p.KT * LINE + (j >> 5) * LINE + (j & 31) * 2;
-        *reinterpret_cast<uint2 *>(d) = hi;
-        *reinterpret_cast<uint2 *>(d + 64) = lo;
-      }
-      uint32_t *dh = reinterpret_cast<uint32_t *>(sh + it * 66 + q * 4);
-      uint32_t *dl = reinterpret_cast<uint32_t *>(sh + 32 * 66 + it * 66 + q * 4);
-      dh[0] = hi.x; dh[1] = hi.y;
-      dl[0] = lo.x; dl[1] = lo.y;
-    }
-    __syncthreads();
-    // phase 2: (hidden unit j, 16-byte piece pc): 8 items of one plane -> one piece of the W^T line
-    for (int u = tid; u < 64 * 8; u += NT) {
-      const int jj = u >> 3, pc = u & 7;
-      const int j = j0 + jj;
-      if (j < Kp) {
-        const uint16_t *src = sh + (pc >> 2) * 32 * 66 + ((pc & 3) * 8) * 66 + jj;
-        uint32_t w[4];
+  // The table rows of FOUR 64-unit chunks are fetched at once (h = 200: all of them): chunk by chunk
+  // the job was a chain of as many dependent round trips, and these workgroups, not the user rows,
+  // were what the encoder-forward launch waited for.
+  constexpr int PER = (32 * 16 + NT - 1) / NT;           // (item, float4) pairs per thread and chunk
+  int my_c[PER];
+  int64_t my_row[PER];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          w[e] = (uint32_t)src[(2 * e) * 66] | ((uint32_t)src[(2 * e + 1) * 66] << 16);
-        char *d = p.wtp + ((int64_t)tile * Kp + j) * LINE + pc * 16;
-        *reinterpret_cast<uint4 *>(d) = make_uint4(w[0], w[1], w[2], w[3]);
+  for (int e = 0; e < PER; ++e) {
+    const int u = tid + e * NT;
+    my_c[e] = k0 + (u >> 4);
+    my_row[e] = (u < 32 * 16 && my_c[e] < n_b) ? (int64_t)p.items[my_c[e]] * p.h : -1;
+  }
+  for (int jg = 0; jg < Kp; jg += 256) {
+    float4 pre[4][PER];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int e = 0; e < PER; ++e) {
+        const int j = jg + g * 64 + ((tid + e * NT) & 15) * 4;
+        pre[g][e] = (my_row[e] >= 0 && j < p.h) ? *reinterpret_cast<const float4 *>(p.W + my_row[e] + j)
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
       }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int j0 = jg + g * 64;
+      if (j0 >= Kp) break;
+      // phase 1: item rows -> split -> W image + LDS (row-major)
+#pragma unroll
+      for (int e = 0; e < PER; ++e) {
+        const int u = tid + e * NT;
+        if (u < 32 * 16) {
+          const int it = u >> 4, q = u & 15;
+          const int j = j0 + q * 4;
+          const int c = my_c[e];
+          uint2 hi, lo;
+          if (p.plain) plain4(pre[g][e], hi, lo); else split4(pre[g][e], s, hi, lo);
+          if (c < n_b && j < Kp) {
+            char *d = p.wp + (int64_t)c * p.KT * LINE + (j >> 5) * LINE + (j & 31) * 2;
+            *reinterpret_cast<uint2 *>(d) = hi;
+            *reinterpret_cast<uint2 *>(d + 64) = lo;
+          }
+          uint32_t *dh = reinterpret_cast<uint32_t *>(sh + it * 66 + q * 4);
+          uint32_t *dl = reinterpret_cast<uint32_t *>(sh + 32 * 66 + it * 66 + q * 4);
+          dh[0] = hi.x; dh[1] = hi.y;
+          dl[0] = lo.x; dl[1] = lo.y;
+        }
+      }
+      __syncthreads();
+      // phase 2: (hidden unit j, 16-byte piece pc): 8 items of one plane -> one piece of the W^T line
+      for (int u = tid; u < 64 * 8; u += NT) {
+        const int jj = u >> 3, pc = u & 7;
+        const int j = j0 + jj;
+        if (j < Kp) {
+          const uint16_t *src = sh + (pc >> 2) * 32 * 66 + ((pc & 3) * 8) * 66 + jj;
+          uint32_t w[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            w[e] = (uint32_t)src[(2 * e) * 66] | ((uint32_t)src[(2 * e + 1) * 66] << 16);
+          char *d = p.wtp + ((int64_t)tile * Kp + j) * LINE + pc * 16;
+          *reinterpret_cast<uint4 *>(d) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
 }
 
