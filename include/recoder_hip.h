@@ -371,6 +371,9 @@ int rk_decode_loss_dz_planes(const rk_planes_t *pl, int32_t B, const rk_block_t 
                              float *loss_part, float *gb_part, float *dz_workspace, void *stream);
 int rk_decode_dz_reduce(const float *dz_workspace, int32_t B, int32_t h, const rk_block_t *tgt,
                         const float *Zact /* nullable */, int32_t act, float *dZ, void *stream);
+/* tuning probe (tools/probes/enc_phase_probe.py): device buffer of 8 uint64 per user row of the
+ * encoder forward (entry, first entries loaded, gather done, end); NULL (default): off */
+void rk_enc_probe(unsigned long long *buffer);
 /* tuning probe (tools/probes/planes_phase_probe.py): device buffer of 8 uint64 per workgroup of the
  * largest grid, or NULL (default) to switch it off */
 void rk_planes_probe(unsigned long long *buffer);

@@ -21,14 +21,18 @@ namespace {
 // long as its LONGEST row (a C2 batch: mean 55 stored interactions, maximum 430-900), so the row is
 // cut into as many pieces as the register budget allows at two workgroups per CU
 constexpr int FW = 8;
-template <int HV>
+// rk_enc_probe(buffer): every row workgroup of the encoder forward records wall_clock64() at entry,
+// with its first entries loaded, after the gather and at the end (tools/probes/enc_phase_probe.py)
+unsigned long long *g_enc_probe = nullptr;
+#define ESTAMP(k) do { if (probe && threadIdx.x == 0) probe[(size_t)(blockIdx.x - n_split) * 8 + (k)] = wall_clock64(); } while (0)
+template <int HV, int UB>
 __global__ __launch_bounds__(FW * 64) void ae_encode_fwd_kernel(
     rk_block_t b, int row_off, int B, const float *__restrict__ W, const float *__restrict__ bias,
     int h, const uint8_t *__restrict__ keep, float p, float scale, uint64_t seed,
     uint64_t rng_step, const int64_t *__restrict__ users, const float *__restrict__ user_norm,
     int act, float *__restrict__ Z0, uint16_t *__restrict__ planes, int64_t plane_stride,
     int cols_pad, rk_cur_t cur, rkp::SplitW sw, int n_split, char *__restrict__ zimg, int z_kt,
-    int zt_pairs) {
+    int zt_pairs, unsigned long long *probe) {
   __shared__ float red[FW];
   constexpr int PART_B = (FW - 1) * HV * 256 * 4;
   __shared__ __attribute__((aligned(16))) char sm_raw[PART_B > rkp::SPLIT_W_LDS ? PART_B : rkp::SPLIT_W_LDS];
@@ -59,6 +63,7 @@ __global__ __launch_bounds__(FW * 64) void ae_encode_fwd_kernel(
   }
   const int row = row_off + r;         // row within the block
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  ESTAMP(0);
   const int beg = b.indptr[row], end = b.indptr[row + 1];
   const int n = end - beg;
   const bool implicit = b.implicit != 0;
@@ -100,6 +105,7 @@ __global__ __launch_bounds__(FW * 64) void ae_encode_fwd_kernel(
     nrm = fmaxf(sqrtf(tot), 1e-12f);
   }
 
+  if (probe) { if (item0 == 0x7fffffff && v0 == 1e30f) return; ESTAMP(1); }     // (stamp behind the loads)
   float4 acc[HV];
 #pragma unroll
   for (int k = 0; k < HV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -137,23 +143,26 @@ __global__ __launch_bounds__(FW * 64) void ae_encode_fwd_kernel(
     // loads of consecutive entries are independent and stay in flight together
     // (lanes past the wave's range carry item 0 / s 0, so rounding cnt up to a
     // multiple of 8 only adds exact zeros)
-    for (int k = 0; k < cnt; k += 8) {
-      int it[8];
-      float sv[8];
+    // UB row loads in flight per lane.  (16 instead of 8 does not shorten a heavy row -- 7.4 vs 7.7 us for
+    // 599 entries: the row is bound by what ONE CU fetches, ~560 cache lines per us -- and costs the
+    // light rows occupancy: 17.3-18.3 vs 15.8 us for the launch inside the step)
+    for (int k = 0; k < cnt; k += UB) {
+      int it[UB];
+      float sv[UB];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < UB; ++u) {
         it[u] = __shfl(item, (k + u) & 63, 64);
         sv[u] = (k + u < 64) ? __shfl(s, (k + u) & 63, 64) : 0.f;
       }
 #pragma unroll
       for (int v = 0; v < HV; ++v) {
         const int hh = min((v * 64 + lane) * 4, h - 4);
-        float4 w4[8];
+        float4 w4[UB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < UB; ++u)
           w4[u] = *reinterpret_cast<const float4 *>(W + (int64_t)it[u] * h + hh);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < UB; ++u) {
           acc[v].x = fmaf(sv[u], w4[u].x, acc[v].x);
           acc[v].y = fmaf(sv[u], w4[u].y, acc[v].y);
           acc[v].z = fmaf(sv[u], w4[u].z, acc[v].z);
@@ -162,6 +171,7 @@ __global__ __launch_bounds__(FW * 64) void ae_encode_fwd_kernel(
       }
     }
   }
+  if (probe) { if (acc[0].x == 1.2345e30f) return; ESTAMP(2); }
   // ---- combine the 4 partial sums in fixed order, bias, activation ----
   if (wid > 0) {
 #pragma unroll
@@ -218,6 +228,7 @@ __global__ __launch_bounds__(FW * 64) void ae_encode_fwd_kernel(
       }
     }
   }
+  ESTAMP(3);
 }
 
 template <int HV>
@@ -263,14 +274,16 @@ static int encode_fwd_launch(const rk_block_t *blk, int32_t row_off, int32_t B, 
     sw = es->sw; n_split = es->n_split; zimg = es->zimg; z_kt = es->z_kt;
   }
 #define LAUNCH(HV)                                                                         \
-  RK_LAUNCH(ae_encode_fwd_kernel<HV>, dim3(n_split + rows), dim3(FW * 64), 0, stream, *blk, row_off, \
+  RK_LAUNCH((ae_encode_fwd_kernel<HV, 8>), dim3(n_split + rows), dim3(FW * 64), 0, stream, *blk, row_off, \
                      B, W_en, b_en, h, keep, p, scale, seed, rng_step, users, user_norm, act, Z0, \
-                     (uint16_t *)zt_planes, plane_stride, cols_pad, cur, sw, n_split, zimg, z_kt, zt_pairs)
+                     (uint16_t *)zt_planes, plane_stride, cols_pad, cur, sw, n_split, zimg, z_kt, zt_pairs, g_enc_probe)
   if (hv == 1) LAUNCH(1); else if (hv == 2) LAUNCH(2); else LAUNCH(4);
 #undef LAUNCH
   RK_CHECK_LAUNCH("ae_encode_fwd");
   return 0;
 }
+
+extern "C" void rk_enc_probe(unsigned long long *buffer) { g_enc_probe = buffer; }
 
 extern "C" int rk_ae_encode_fwd(const rk_block_t *blk, int32_t row_off, int32_t B,
                                 const float *W_en, const float *b_en, int32_t h,

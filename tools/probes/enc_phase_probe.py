@@ -1,10 +1,13 @@
+"""Per-row phase stamps of the encoder forward (rk_enc_probe): when each row workgroup starts, how long it
+waits for its row pointer + first entries, its gather and its epilogue; the five longest rows.
+    python tools/probes/enc_phase_probe.py"""
 import ctypes, os, sys
 import numpy as np, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, ROOT)
 from recoder_amd import _lib, synthetic
 from recoder_amd._lib import check, ptr
 from recoder_amd.device import Block, DeviceCSR, current_stream
-lib = _lib.load(); raw = ctypes.CDLL(os.path.join(ROOT, "recoder_amd", "csrc", "librecoder_hip.so"))
+lib = _lib.load(); raw = lib
 dev = torch.device("cuda"); B, h = 500, 200
 csr = synthetic.ml20m_like(seed=0, n_users=20000); dcsr = DeviceCSR(csr); n_items = csr.shape[1]
 f = dict(dtype=torch.float32, device=dev)
@@ -16,7 +19,7 @@ fn = lambda: check(lib.rk_ae_encode_fwd(blk.ref, 0, B, ptr(W), ptr(bias), h, Non
 for _ in range(5): fn()
 torch.cuda.synchronize()
 probe = torch.zeros(8 * 4096, dtype=torch.int64, device=dev)
-raw.rk_enc_probe(ctypes.c_void_p(probe.data_ptr()))
+raw.rk_enc_probe(probe.data_ptr())
 big = torch.empty(64 << 20, dtype=torch.float32, device=dev); big.fill_(1.0)   # flush caches
 torch.cuda.synchronize()
 fn(); torch.cuda.synchronize()
