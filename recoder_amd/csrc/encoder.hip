@@ -151,8 +151,10 @@ __global__ __launch_bounds__(FW * 64) void ae_encode_fwd_kernel(
       float sv[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        it[u] = __shfl(item, (k + u) & 63, 64);
-        sv[u] = (k + u < 64) ? __shfl(s, (k + u) & 63, 64) : 0.f;
+        // (the lane index is wave-uniform: v_readlane into a scalar register instead of a ds_bpermute
+        // through the LDS crossbar; 16 VGPRs less, same speed)
+        it[u] = __builtin_amdgcn_readlane(item, (k + u) & 63);
+        sv[u] = (k + u < 64) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), (k + u) & 63)) : 0.f;
       }
 #pragma unroll
       for (int v = 0; v < HV; ++v) {
