@@ -74,6 +74,7 @@ KERNELS = {"rk_ae_encode_fwd": ["ae_encode_fwd_kernel (+ the W_de[items] split w
            "rk_adam_multi": ["adam_multi_kernel"], "rk_adam_de": ["adam_multi_kernel"],
            "rk_decode_loss_dz_planes": ["decode_planes_kernel<1,2,EPI,3,false,DZT> (decode + loss + dZ partials)"],
            "rk_decode_dz_reduce": ["splitk_reduce_kernel"], "rk_split_w": ["split_w_kernel"],
+           "rk_split_wz": ["split_wz_kernel (W_de[items] and Z plane images, one launch)"],
            "rk_decode_bwd_dw2": ["dw3_kernel<BN,false,true>"],
            "rk_decode_bwd_dw2_encode_bwd": ["dw_encbwd_kernel<BN,HV> (dW tiles || encoder-backward columns)"]}
 
@@ -174,6 +175,8 @@ def entry_work(entry, B, h0, n_b, nnz, n_items, cfg):
     return "hbm", (-(-int(n_b) // 128) * B * h0 * 4 + 2 * B * h0 * 4) / 1e9, "GB/s"
   if entry == "rk_split_w":                     # gathered decoder rows -> W and W^T plane images
     return "hbm", 3.0 * n_b * h0 * 4 / 1e9, "GB/s"
+  if entry == "rk_split_wz":                    # ... and Z -> its image, in the same launch
+    return "hbm", (3.0 * n_b + 2.0 * B) * h0 * 4 / 1e9, "GB/s"
   if entry == "rk_mnll_finish":                 # two passes over the B x n_b logits, one write
     return "hbm", 3.0 * B * n_b * 4 / 1e9, "GB/s"
   if entry in ("rk_linear_fwd", "rk_linear_bwd") and cfg["kind"] == "ae" and len(cfg["hidden_layers"]) > 1:

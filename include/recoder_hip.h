@@ -381,6 +381,10 @@ int rk_planes_layout(void *buffer, int32_t B_cap, int32_t h, int32_t n_cap, rk_p
 /* W_de[tgt->items[0 .. n_b)] -> pl->w and pl->wt; the scale from ranges[64..127] (rk_amax notes) */
 int rk_split_w(const float *W_de, int32_t h, const rk_block_t *tgt, const int32_t *ranges,
                const rk_planes_t *pl, void *stream);
+/* rk_split_w + rk_split_z as ONE launch (entry-by-entry sequenced steps: MatrixFactorization, hidden
+ * stacks -- one launch less in front of every decode; same images, bit for bit) */
+int rk_split_wz(const float *W_de, const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
+                const int32_t *ranges, const rk_planes_t *pl, void *stream);
 /* Z[B, h] -> pl->z; the scale from ranges[0..63] */
 int rk_split_z(const float *Z, int32_t B, int32_t h, const int32_t *ranges, const rk_planes_t *pl,
                void *stream);
@@ -419,6 +423,11 @@ int rk_colsum(const float *X, int32_t rows, int32_t cols, int32_t ld,
               void *stream);
 int rk_gather_rows(const float *E, const int64_t *rows, int32_t B, int32_t d,
                    int32_t act, float *out, void *stream);
+/* the same gather (nn.py:344-362: MatrixFactorization's user rows) that also publishes max |out| in
+ * slots[0..63] the way rk_amax does (64 workgroups, one slot each): gather + rk_amax in one launch
+ * for unbounded activations */
+int rk_gather_rows_amax(const float *E, const int64_t *rows, int32_t B, int32_t d,
+                        int32_t act, float *out, int32_t *slots, void *stream);
 
 /*
  * Optimisers (exact formulas of torch.optim.Adam `_single_tensor_adam` and

@@ -133,6 +133,7 @@ SIGNATURES = {
   "rk_planes_layout": (c_int32, [_P, c_int32, c_int32, c_int32, POINTER(RkPlanes)]),
   "rk_split_w": (c_int32, [_P, c_int32, _BLK, _P, POINTER(RkPlanes), _P]),
   "rk_split_z": (c_int32, [_P, c_int32, c_int32, _P, POINTER(RkPlanes), _P]),
+  "rk_split_wz": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, POINTER(RkPlanes), _P]),
   "rk_decode_loss_planes": (c_int32, [POINTER(RkPlanes), c_int32, _BLK, c_int32, _P, c_int32, c_float,
                                       c_float, _P, c_int32, _P, _P, _P]),
   "rk_decode_bwd_dz_planes": (c_int32, [_P, c_int32, POINTER(RkPlanes), _BLK, _P, c_int32, _P, _P, _P]),
@@ -179,6 +180,7 @@ SIGNATURES = {
   "rk_dropout": (c_int32, [_P, _P, c_int64, c_int32, c_float, c_uint64, c_uint64, _P]),
   "rk_colsum": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P, _P]),
   "rk_gather_rows": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P]),
+  "rk_gather_rows_amax": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P]),
   "rk_adam_table": (c_int32, [_P, _P, _P, c_int32, c_int32, _P, _P, c_double, c_double, c_double,
                               c_double, c_double, c_int32, _P]),
   "rk_adam_rows": (c_int32, [_P, _P, _P, c_int32, _P, _P, _P, c_int32, _P, c_double, c_double,

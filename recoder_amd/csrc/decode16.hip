@@ -767,20 +767,39 @@ __global__ __launch_bounds__(256) void split_w_kernel(rkp::SplitW p) {
 
 // X[rows, K] fp32 (leading dimension ld) -> its plane image; scale from `amax` (64 slots, nullable)
 // or the static default; scales[slot] <- the scale used
-__global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ X, int64_t rows, int K,
-                                                         int64_t ld, const uint32_t *amax, float dflt,
-                                                         char *img, int KT, float *scales, int slot,
-                                                         int plain) {
+__device__ __forceinline__ void split_rows_job(const int block, const float *__restrict__ X, int64_t rows,
+                                               int K, int64_t ld, const uint32_t *amax, float dflt,
+                                               char *img, int KT, float *scales, int slot, int plain) {
   const float s = plain ? 1.0f : rkp::scale_from(amax, dflt);
-  if (blockIdx.x == 0 && threadIdx.x == 0) scales[slot] = s;
+  if (block == 0 && threadIdx.x == 0) scales[slot] = s;
   const int q4 = KT * 8;                          // float4 per image row
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = (int64_t)block * 256 + threadIdx.x;
   if (i >= (int64_t)rows * q4) return;
   const int64_t r = i / q4;
   const int k = (int)(i % q4) * 4;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (k < K) v = *reinterpret_cast<const float4 *>(X + r * ld + k);     // (K % 4 == 0)
   rkp::store_split4(img + r * KT * rkp::LINE, k, v, s, plain != 0);
+}
+
+__global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ X, int64_t rows, int K,
+                                                         int64_t ld, const uint32_t *amax, float dflt,
+                                                         char *img, int KT, float *scales, int slot,
+                                                         int plain) {
+  split_rows_job((int)blockIdx.x, X, rows, K, ld, amax, dflt, img, KT, scales, slot, plain);
+}
+
+// rk_split_wz: both operand splits of an entry-by-entry sequenced decode in ONE launch (the one-call
+// step lets them ride on its encoder forward): workgroups [0, w_tiles) cut W_de[items], the rest Z
+__global__ __launch_bounds__(256) void split_wz_kernel(rkp::SplitW p, int w_tiles, const float *__restrict__ Z,
+                                                       int B, const uint32_t *zmax, char *zimg) {
+  __shared__ __attribute__((aligned(16))) char sm[rkp::SPLIT_W_LDS];
+  if ((int)blockIdx.x < w_tiles) {
+    rkp::split_w_job<256>(p, (int)blockIdx.x, sm);
+    return;
+  }
+  split_rows_job((int)blockIdx.x - w_tiles, Z, B, p.h, p.h, zmax, rkp::SCALE_Z, zimg, p.KT, p.scales, 0,
+                 p.plain);
 }
 
 inline bool aligned16(const void *q) { return ((uintptr_t)q & 15) == 0; }
@@ -864,6 +883,21 @@ extern "C" int rk_split_w(const float *W_de, int32_t h, const rk_block_t *tgt, c
   const rkp::SplitW s = split_w_args(W_de, tgt, ranges, pl);
   RK_LAUNCH(split_w_kernel, dim3(rk_cdiv(tgt->n_cap, 32)), dim3(256), 0, (hipStream_t)stream_, s);
   RK_CHECK_LAUNCH("split_w");
+  return 0;
+}
+
+extern "C" int rk_split_wz(const float *W_de, const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
+                           const int32_t *ranges, const rk_planes_t *pl, void *stream_) {
+  RK_REQUIRE(pl && pl->h == h && tgt->n_cap <= pl->n_cap && B <= pl->B_cap,
+             "planes were laid out for another shape");
+  RK_REQUIRE(aligned16(W_de) && aligned16(Z), "W_de and Z must be 16-byte aligned");
+  if (B == 0) return rk_split_w(W_de, h, tgt, ranges, pl, stream_);
+  const rkp::SplitW s = split_w_args(W_de, tgt, ranges, pl);
+  const int w_tiles = rk_cdiv(tgt->n_cap, 32);
+  const int z_blocks = rk_cdiv((int64_t)B * s.KT * 8, 256);
+  RK_LAUNCH(split_wz_kernel, dim3(w_tiles + z_blocks), dim3(256), 0, (hipStream_t)stream_, s, w_tiles, Z,
+            B, reinterpret_cast<const uint32_t *>(ranges), (char *)pl->z);
+  RK_CHECK_LAUNCH("split_wz");
   return 0;
 }
 

@@ -183,6 +183,29 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *E, const 
   }
 }
 
+// the same gather with max |out| published for the split contractions (rk_amax's contract: the
+// maximum over the 64 slots is what the kernels use): 64 workgroups, workgroup b files ITS maximum
+// under slots[b] -- no atomics, no zeroing pass, one launch instead of two in front of an MF decode
+__global__ __launch_bounds__(256) void gather_rows_amax_kernel(const float *E, const int64_t *rows, int B,
+                                                               int d, int act, float *out,
+                                                               uint32_t *__restrict__ slots, rk_cur_t cur) {
+  __shared__ float red[4];
+  if (cur.cursor) rows += rk_cur_local(cur) * B;
+  const int64_t tot = (int64_t)B * d;
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / d), q = (int)(i % d);
+    const float v = rk_act(E[rows[r] * d + q], act);
+    out[i] = v;
+    m = fmaxf(m, fabsf(v));
+  }
+  m = rk_wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    slots[blockIdx.x] = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
 __global__ __launch_bounds__(256) void scatter_pos_kernel(int32_t *pos, const int64_t *rows, int B,
                                                           int clear, rk_cur_t cur) {
   if (cur.cursor) rows += rk_cur_local(cur) * B;
@@ -630,6 +653,18 @@ extern "C" int rk_colsum(const float *X, int32_t rows, int32_t cols, int32_t ld,
   RK_LAUNCH(colsum_kernel, dim3(rk_cdiv(cols, 64)), dim3(1024), 0, stream, X, rows, cols, ld,
                      counts_dev, out);
   RK_CHECK_LAUNCH("colsum");
+  return 0;
+}
+
+extern "C" int rk_gather_rows_amax(const float *E, const int64_t *rows, int32_t B, int32_t d,
+                                   int32_t act, float *out, int32_t *slots, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(slots != nullptr && B > 0, "slots, B > 0");
+  rk_cur_t cur = {nullptr, 0};
+  if (const rk_replay_t *rp = rk_replay_get()) { cur = {rp->cursor, rp->off}; rows = rp->users_base; }
+  RK_LAUNCH(gather_rows_amax_kernel, dim3(64), dim3(256), 0, stream, E, rows, B, d, act, out,
+            reinterpret_cast<uint32_t *>(slots), cur);
+  RK_CHECK_LAUNCH("gather_rows_amax");
   return 0;
 }
 

@@ -355,10 +355,18 @@ class FusedEngine:
   def _mf_forward(self, users, B, keep_drop, train, stream):
     m, lib = self.model, self.lib
     d = self.h[0]
-    check(lib.rk_gather_rows(ptr(m.user_embedding_layer.weight), ptr(users), B, d, self.act,
-                             ptr(self.enc[0]), stream), "rk_gather_rows")
-    z = self.enc[0]
     self.drop_active = bool(train and m.dropout_prob > 0)
+    self._amax_of = None
+    if not self.act_bounded and not self.drop_active and self.split16 and B > 0:
+      # unbounded activation: the split contractions need max |z| -- the gather publishes it
+      # (64 slots, one per workgroup) instead of an rk_amax launch behind it
+      check(lib.rk_gather_rows_amax(ptr(m.user_embedding_layer.weight), ptr(users), B, d, self.act,
+                                    ptr(self.enc[0]), ptr(self.ranges), stream), "rk_gather_rows_amax")
+      self._amax_of = (self.enc[0].data_ptr(), B * d)
+    else:
+      check(lib.rk_gather_rows(ptr(m.user_embedding_layer.weight), ptr(users), B, d, self.act,
+                               ptr(self.enc[0]), stream), "rk_gather_rows")
+    z = self.enc[0]
     if self.drop_active:
       n = B * d
       self.bott[:n].copy_(z[:n])
@@ -395,6 +403,8 @@ class FusedEngine:
     self._check_weight_range()
     if self.act_bounded:
       return ptr(self.ranges)         # |Z| <= 1 (tanh / sigmoid): the static scale of Z is exact
+    if getattr(self, "_amax_of", None) == (z.data_ptr(), n):
+      return ptr(self.ranges)         # (rk_gather_rows_amax of this forward left it there)
     check(self.lib.rk_amax(ptr(z), n, ptr(self.ranges), stream), "rk_amax")
     return ptr(self.ranges)
 
@@ -416,8 +426,8 @@ class FusedEngine:
       # in its own workspace in between
       h0 = self.h[0]
       rg = self._ranges(z, B * h0, stream)
-      check(lib.rk_split_w(ptr(W), h0, tgt.ref, rg, ctypes.byref(self.planes), stream), "rk_split_w")
-      check(lib.rk_split_z(ptr(z), B, h0, rg, ctypes.byref(self.planes), stream), "rk_split_z")
+      check(lib.rk_split_wz(ptr(W), ptr(z), B, h0, tgt.ref, rg, ctypes.byref(self.planes), stream),
+            "rk_split_wz")
       check(lib.rk_decode_loss_dz_planes(ctypes.byref(self.planes), B, tgt.ref, row_off, ptr(b), self.loss_id,
                                          self.confidence, inv_B, ptr(self.dO), ptr(self.loss_part),
                                          ptr(self.gb_part), ptr(self.ws), stream), "rk_decode_loss_dz_planes")
@@ -595,7 +605,8 @@ class FusedEngine:
     dz = bott_grad
     if self.kind == "ae" and self.nl > 0:
       dz = self.ddec[self.nl - 1]
-    fuse_act = simple and ip is None        # act' folded into the split-K reduce
+    # act' folded into the split-K reduce (MF without dropout: the gathered rows ARE the decoder's input)
+    fuse_act = (simple or (self.kind != "ae" and not self.drop_active)) and ip is None
     if getattr(self, "_dz_in_ws", False):
       check(lib.rk_decode_dz_reduce(ptr(self.ws), B, h0, tb.ref, ptr(self.enc[0]) if fuse_act else None,
                                     self.act, ptr(dz), stream), "rk_decode_dz_reduce")
@@ -659,7 +670,8 @@ class FusedEngine:
       if self.drop_active:
         check(lib.rk_dropout(ptr(self.dbott), ptr(keep_drop), n, h0, float(m.dropout_prob),
                              self.seed ^ 0xd0d0, self.rng_step, stream), "rk_dropout")
-      check(lib.rk_act_grad(ptr(self.dbott), ptr(self.enc[0]), n, self.act, stream), "rk_act_grad")
+      if not fuse_act:
+        check(lib.rk_act_grad(ptr(self.dbott), ptr(self.enc[0]), n, self.act, stream), "rk_act_grad")
 
     if self.allreduce is not None:
       # data parallel over users: every gradient of the step (live rows of both tables, gathered

@@ -481,6 +481,11 @@ class Recoder(object):
     self._dp_n_users = n
     if hasattr(train_dataset, "row_shard"):           # data.DeviceDataset: sliced in HBM
       shard = train_dataset.row_shard(lo, hi)
+    elif getattr(train_dataset, "_dev", None) is not None:
+      # a host dataset whose matrix is already resident (dataset.device_csr() was called): this
+      # rank's rows are a device-side slice of it -- no host slicing, no second upload
+      from .data import DeviceDataset
+      shard = DeviceDataset(train_dataset._dev.row_slice(lo, hi))
     else:
       shard = RecommendationDataset(train_dataset.interactions_matrix[lo:hi])
     # every rank runs the same number of equally sized steps (collectives in lockstep)

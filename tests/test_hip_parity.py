@@ -1159,7 +1159,12 @@ def test_data_parallel_virtual_ranks_random_shapes(seed):
   def run(r):
     try:
       torch.cuda.set_device(0)
-      reps[r][1].train(RecommendationDataset(csr), batch_size=B, **kw)
+      ds_r = RecommendationDataset(csr)
+      if seed % 2:
+        # a host dataset that is already resident in HBM: the rank's rows are a device-side slice
+        # (model.Recoder._setup_data_parallel) -- same training as the host-sliced shard
+        ds_r.device_csr()
+      reps[r][1].train(ds_r, batch_size=B, **kw)
     except BaseException as e:       # noqa: B036 -- release the other threads
       errs.append(e)
       vr.barrier.abort()

@@ -285,3 +285,46 @@ def test_dw_and_encoder_backward_in_one_launch_equal_the_two_launches(B, h, n_it
   assert a[0] == b[0] and a[0] >= 1
   assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
   assert float(a[1].abs().max()) > 0 and float(a[2].abs().max()) > 0
+
+
+@pytest.mark.parametrize("B,h,n_items", [(500, 128, 3000), (37, 20, 400), (1, 8, 97), (300, 512, 2000)])
+def test_split_wz_is_the_two_split_launches(B, h, n_items):
+  """rk_split_wz (one launch) leaves the images rk_split_w + rk_split_z leave, byte for byte, also with
+  a published (non-static) range of Z."""
+  lib, blk, W, bias, Z, ranges, pl, buf = _setup(B, h, max(B, 600), n_items, 14, seed=7 * B + h)
+  st = current_stream()
+  Zu = Z * 37.5                                   # unbounded activation: the range comes from rk_amax
+  check(lib.rk_amax(ptr(Zu), B * h, ptr(ranges), st))
+  buf.zero_()
+  check(lib.rk_split_w(ptr(W), h, blk.ref, ptr(ranges), ctypes.byref(pl), st))
+  check(lib.rk_split_z(ptr(Zu), B, h, ptr(ranges), ctypes.byref(pl), st))
+  torch.cuda.synchronize()
+  two = buf.clone()
+  buf.zero_()
+  check(lib.rk_split_wz(ptr(W), ptr(Zu), B, h, blk.ref, ptr(ranges), ctypes.byref(pl), st))
+  torch.cuda.synchronize()
+  assert torch.equal(two.view(torch.int32), buf.view(torch.int32))
+
+
+@pytest.mark.parametrize("B,d,act", [(500, 128, 0), (37, 20, 3), (1, 8, 4), (1000, 64, 1)])
+def test_gather_rows_amax_is_gather_plus_amax(B, d, act):
+  """rk_gather_rows_amax == rk_gather_rows followed by rk_amax: the same rows, and the maximum over the
+  64 published slots (what the split kernels use) is max |out| exactly."""
+  lib = _lib.load()
+  dev = torch.device("cuda")
+  g = torch.Generator(device=dev)
+  g.manual_seed(B + d)
+  E = torch.randn(5000, d, generator=g, device=dev) * 3.0
+  rows = torch.randint(0, 5000, (B,), generator=g, device=dev, dtype=torch.int64)
+  st = current_stream()
+  out0 = torch.empty(B * d, device=dev)
+  out1 = torch.empty(B * d, device=dev)
+  r0 = torch.full((128,), 7, dtype=torch.int32, device=dev)
+  r1 = torch.full((128,), 7, dtype=torch.int32, device=dev)
+  check(lib.rk_gather_rows(ptr(E), ptr(rows), B, d, act, ptr(out0), st))
+  check(lib.rk_amax(ptr(out0), B * d, ptr(r0), st))
+  check(lib.rk_gather_rows_amax(ptr(E), ptr(rows), B, d, act, ptr(out1), ptr(r1), st))
+  torch.cuda.synchronize()
+  assert torch.equal(out0, out1)
+  assert int(r0[:64].max()) == int(r1[:64].max()) == int(out0.abs().max().view(torch.int32))
+  assert torch.equal(r0[64:], r1[64:])            # the W half is not touched
