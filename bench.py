@@ -76,7 +76,9 @@ KERNELS = {"rk_ae_encode_fwd": ["ae_encode_fwd_kernel (+ the W_de[items] split w
            "rk_decode_dz_reduce": ["splitk_reduce_kernel"], "rk_split_w": ["split_w_kernel"],
            "rk_split_wz": ["split_wz_kernel (W_de[items] and Z plane images, one launch)"],
            "rk_decode_bwd_dw2": ["dw3_kernel<BN,false,true>"],
-           "rk_decode_bwd_dw2_encode_bwd": ["dw_encbwd_kernel<BN,HV> (dW tiles || encoder-backward columns)"]}
+           "rk_decode_bwd_dw2_encode_bwd": ["dw_encbwd_kernel<BN,HV> (dW tiles || encoder-backward columns)"],
+           "rk_decode_bwd_dw2_encode_bwd_colsum": ["dw_encbwd_kernel<BN,HV> (dW tiles || dO column sums || "
+                                                   "encoder-backward columns)"]}
 
 CONFIGS = {
   # C2 of BASELINE.json: ML-20M autoencoder, hidden [200], MSE, 1 x MI355X
@@ -167,7 +169,8 @@ def entry_work(entry, B, h0, n_b, nnz, n_items, cfg):
   multinomial loss); (None, ...) for the small launches that have no meaningful roofline."""
   if entry in ENTRIES:
     return algorithmic_work(entry, B, h0, n_b, nnz, n_items, bool(cfg["sparse"]))
-  if entry in ("rk_decode_bwd_dw3", "rk_decode_bwd_dw2", "rk_decode_bwd_dw2_encode_bwd"):
+  if entry in ("rk_decode_bwd_dw3", "rk_decode_bwd_dw2", "rk_decode_bwd_dw2_encode_bwd",
+               "rk_decode_bwd_dw2_encode_bwd_colsum"):
     return "mfma", 2.0 * B * h0 * n_b / 1e12, "TFLOP/s"
   if entry == "rk_decode_loss_dz_planes":       # decode + loss + the dZ partials of every column tile
     return "mfma", 4.0 * B * h0 * n_b / 1e12, "TFLOP/s"
@@ -179,7 +182,8 @@ def entry_work(entry, B, h0, n_b, nnz, n_items, cfg):
     return "hbm", (3.0 * n_b + 2.0 * B) * h0 * 4 / 1e9, "GB/s"
   if entry == "rk_mnll_finish":                 # two passes over the B x n_b logits, one write
     return "hbm", 3.0 * B * n_b * 4 / 1e9, "GB/s"
-  if entry in ("rk_linear_fwd", "rk_linear_bwd") and cfg["kind"] == "ae" and len(cfg["hidden_layers"]) > 1:
+  if entry in ("rk_linear_fwd", "rk_linear_bwd", "rk_linear_bwd_dact") and cfg["kind"] == "ae" and \
+      len(cfg["hidden_layers"]) > 1:
     hh = cfg["hidden_layers"]
     fl = 2.0 * B * hh[0] * hh[1] * (1 if entry == "rk_linear_fwd" else 2)
     return "mfma_f32", fl / 1e12, "TFLOP/s"

@@ -291,6 +291,14 @@ int rk_decode_bwd_dw2_encode_bwd(const float *dO, const float *Z /* nullable wit
                                  const void *zt_planes /* nullable */, const int32_t *ranges /* nullable */,
                                  int32_t row_off, const float *dZ0pre, float *G_en,
                                  float *gb_en /* nullable */, void *stream);
+/* the same launch with the decoder bias gradient gb_de[c] = sum_r dO[r][c] as a third workgroup range
+ * (multinomial loss: dO comes from rk_mnll_finish, no decode epilogue has summed its columns) --
+ * the rk_colsum launch of those steps */
+int rk_decode_bwd_dw2_encode_bwd_colsum(const float *dO, const float *Z /* nullable with zt_planes */,
+                                        int32_t B, int32_t h, const rk_block_t *tgt, void *workspace,
+                                        const void *zt_planes, const int32_t *ranges, int32_t row_off,
+                                        const float *dZ0pre, float *G_en, float *gb_en, float *gb_de,
+                                        void *stream);
 /* != 0 (RK_ADAM_DE_SIDE=1; off by default): whole steps with a dw_stream run the decoder table's
  * Adam sweep as a launch of its own right behind the dW kernel ON dw_stream -- it needs nothing else
  * of the step -- next to the split-K reduce and the encoder backward of the chain (both
@@ -411,6 +419,15 @@ int rk_linear_bwd(float *dY, const float *Y, const float *X, const float *W,
                   int32_t B, int32_t N, int32_t K, int32_t w_transposed,
                   int32_t act, float *dX /* nullable */, float *dW,
                   int32_t dw_accumulate, float *db, void *stream);
+/* tuning switch (default off, RK_LINEAR_PAIR=1): rk_linear_bwd's dX and dW products as ONE launch */
+void rk_linear_pair(int32_t on);
+/* rk_linear_bwd whose dX leaves multiplied by act'(dx_act_y[B,K]) (nullable): the backward of a
+ * stack's FIRST Linear layer hands its gradient to the embedding layer's activation -- the
+ * rk_act_grad launch that followed, folded into the dX epilogue (same product, same bits). */
+int rk_linear_bwd_dact(float *dY, const float *Y, const float *X, const float *W,
+                       int32_t B, int32_t N, int32_t K, int32_t w_transposed, int32_t act,
+                       float *dX, float *dW, int32_t dw_accumulate, float *db,
+                       const float *dx_act_y, void *stream);
 
 /* elementwise helpers */
 int rk_act_grad(float *dY, const float *Y, int64_t n, int32_t act, void *stream);

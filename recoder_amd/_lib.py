@@ -157,6 +157,8 @@ SIGNATURES = {
   "rk_enc_probe": (None, [_P]),
   "rk_dw_encode_bwd_fused_ok": (c_int32, [c_int32, c_int32]),
   "rk_decode_bwd_dw2_encode_bwd": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, c_int32, _P, _P, _P, _P]),
+  "rk_decode_bwd_dw2_encode_bwd_colsum": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, c_int32, _P, _P,
+                                                    _P, _P, _P]),
   "rk_decode_dz_fused_ok": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
   "rk_dz_fused_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
   "rk_decode_loss_dz_planes": (c_int32, [_P, c_int32, _BLK, c_int32, _P, c_int32, c_float, c_float, _P, _P, _P,
@@ -176,6 +178,9 @@ SIGNATURES = {
   "rk_linear_fwd": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
   "rk_linear_bwd": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P,
                               c_int32, _P, _P]),
+  "rk_linear_pair": (None, [c_int32]),
+  "rk_linear_bwd_dact": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P,
+                                   c_int32, _P, _P, _P]),
   "rk_act_grad": (c_int32, [_P, _P, c_int64, c_int32, _P]),
   "rk_dropout": (c_int32, [_P, _P, c_int64, c_int32, c_float, c_uint64, c_uint64, _P]),
   "rk_colsum": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P, _P]),

@@ -64,9 +64,12 @@ struct rk_small_gemm_t {
   float *C; int ldc;
   const float *bias;          // per output column, nullable
   int act, accumulate;        // C = act(...) (+ C if accumulate)
+  const float *dact_y;        // nullable: C = (...) * act'(dact_y[m * ldc + n]) (derivative `dact`)
+  int dact;
 };
 bool rk_small_gemm_fits(int M, int N, int K);
 int rk_small_gemm(const rk_small_gemm_t *g, void *stream);
+int rk_small_gemm_pair(const rk_small_gemm_t *g1, const rk_small_gemm_t *g2, void *stream);
 // dY <- dY * act'(Y) in place, db[c] = column sums of the result ([rows, cols] row-major)
 int rk_act_grad_colsum(float *dY, const float *Y, int rows, int cols, int act, float *db, void *stream);
 

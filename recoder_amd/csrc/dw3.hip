@@ -366,14 +366,57 @@ struct EncBwdP {
   float *gb;
   int n_gb;
 };
+// (multinomial loss: dO comes from rk_mnll_finish, no epilogue has summed its columns) the decoder
+// bias gradient out[c] = sum_r dO[r][c] as a third workgroup range of the same launch: 64 columns x
+// 8 row slices per workgroup, 4 accumulators per thread, combined in a fixed order
+struct ColsumP {
+  const float *X;
+  int rows;
+  const int32_t *counts;      // [0] live columns, [2] ld
+  float *out;
+};
+__device__ __forceinline__ void colsum_body_512(const ColsumP &c, const int block) {
+  __shared__ float part[8][64];
+  const int cols = c.counts[0], ld = c.counts[2];
+  const int lc = threadIdx.x & 63, s = threadIdx.x >> 6;
+  const int col = block * 64 + lc;
+  const int per = (c.rows + 7) >> 3;
+  const int r0 = s * per, r1 = min(c.rows, r0 + per);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (col < cols) {
+    const float *x = c.X + col;
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {
+      a0 += x[(int64_t)r * ld];
+      a1 += x[(int64_t)(r + 1) * ld];
+      a2 += x[(int64_t)(r + 2) * ld];
+      a3 += x[(int64_t)(r + 3) * ld];
+    }
+    for (; r < r1; ++r) a0 += x[(int64_t)r * ld];
+  }
+  part[s][lc] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (s == 0 && col < cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += part[k][lc];
+    c.out[col] = t;
+  }
+}
+
 template <int BN, int HV>
-__global__ __launch_bounds__(512) void dw_encbwd_kernel(Dw3P p, EncBwdP e, int n_dw) {
+__global__ __launch_bounds__(512) void dw_encbwd_kernel(Dw3P p, EncBwdP e, int n_dw, ColsumP cs, int n_cs) {
   if ((int)blockIdx.x < n_dw) {
     dw3_body<BN, false, true>(p, (int)blockIdx.x);
     return;
   }
+  if ((int)blockIdx.x < n_dw + n_cs) {
+    colsum_body_512(cs, (int)blockIdx.x - n_dw);
+    return;
+  }
   if (threadIdx.x >= 256) return;
-  ae_encode_bwd_cols_body<HV>(e.b, e.row_off, e.B, e.dZ, e.h, e.G, 0, e.gb, e.n_gb, (int)blockIdx.x - n_dw);
+  ae_encode_bwd_cols_body<HV>(e.b, e.row_off, e.B, e.dZ, e.h, e.G, 0, e.gb, e.n_gb,
+                              (int)blockIdx.x - n_dw - n_cs);
 }
 
 // G = sum of the ns slabs the kernel above wrote (ns = counts[4]; nothing to do for ns == 1:
@@ -498,7 +541,14 @@ static int dw_impl(const float *dO, const float *Z, int32_t B, int32_t h, const 
     e.gb = enc->gb_en; e.n_gb = enc->gb_en ? rk_cdiv(h, 64) : 0;
     const int n_enc = rk_cdiv(tgt->n_cap, 4) + e.n_gb;
     const int hv = rk_cdiv(h, 256);
-#define LAUNCH(BN, HV) RK_LAUNCH((dw_encbwd_kernel<BN, HV>), dim3((unsigned)grid + n_enc), dim3(512), 0, stream, p, e, (int)grid)
+    ColsumP cs = {};
+    int n_cs = 0;
+    if (gb_de) {            // column sums of dO ride on this launch too
+      cs.X = dO; cs.rows = B; cs.counts = tgt->counts; cs.out = gb_de;
+      n_cs = rk_cdiv(tgt->n_cap, 64);
+      gb_de = nullptr;
+    }
+#define LAUNCH(BN, HV) RK_LAUNCH((dw_encbwd_kernel<BN, HV>), dim3((unsigned)grid + n_cs + n_enc), dim3(512), 0, stream, p, e, (int)grid, cs, n_cs)
     if (bn == 128) { if (hv == 1) LAUNCH(128, 1); else if (hv == 2) LAUNCH(128, 2); else LAUNCH(128, 4); }
     else { if (hv == 1) LAUNCH(256, 1); else if (hv == 2) LAUNCH(256, 2); else LAUNCH(256, 4); }
 #undef LAUNCH
@@ -561,6 +611,22 @@ extern "C" int rk_decode_bwd_dw2_encode_bwd(const float *dO, const float *Z, int
              "block was built without the transposed bitmap / prefix index");
   const EncBwdArgs enc = {row_off, dZ0pre, G_en, gb_en};
   return dw_impl(dO, Z, B, h, tgt, nullptr, nullptr, workspace, zt_planes, true, ranges, stream_, &enc);
+}
+
+// ... and the decoder bias gradient gb_de[c] = sum_r dO[r][c] (multinomial loss) as a third
+// workgroup range of that launch
+extern "C" int rk_decode_bwd_dw2_encode_bwd_colsum(const float *dO, const float *Z, int32_t B, int32_t h,
+                                                   const rk_block_t *tgt, void *workspace,
+                                                   const void *zt_planes, const int32_t *ranges,
+                                                   int32_t row_off, const float *dZ0pre, float *G_en,
+                                                   float *gb_en, float *gb_de, void *stream_) {
+  RK_REQUIRE(rk_dw_encode_bwd_fused_ok(row_off, B), "outside the fused launch's domain (rk_dw_encode_bwd_fused_ok)");
+  RK_REQUIRE(h > 0 && h % 4 == 0 && h <= 1024, "h must be a multiple of 4, <= 1024");
+  RK_REQUIRE(row_off >= 0 && B >= 0 && row_off + B <= tgt->S_cap, "row slice out of range");
+  RK_REQUIRE(tgt->bits_cr != nullptr && tgt->pref_rc != nullptr,
+             "block was built without the transposed bitmap / prefix index");
+  const EncBwdArgs enc = {row_off, dZ0pre, G_en, gb_en};
+  return dw_impl(dO, Z, B, h, tgt, nullptr, gb_de, workspace, zt_planes, true, ranges, stream_, &enc);
 }
 
 // RK_DW_PREC=bf16x3 keeps dW on the bf16 triples (no operand range at all) in the training step

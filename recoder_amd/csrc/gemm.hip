@@ -1233,7 +1233,7 @@ extern "C" int rk_mnll_finish(float *dO, int32_t B, const rk_block_t *tgt, int32
   if (B == 0) return 0;
   RK_REQUIRE(tgt->implicit || tgt->pref_rc != nullptr, "explicit values need pref_rc");
   RK_LAUNCH(mnll_finish_kernel, dim3(B), dim3(256), 0, stream, dO, *tgt, row_off, inv_B,
-                     loss_part, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr);
+            loss_part, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr);
   RK_CHECK_LAUNCH("mnll_finish");
   return 0;
 }
@@ -1444,9 +1444,30 @@ extern "C" int rk_linear_fwd(const float *X, const float *W, const float *b, int
   return 0;
 }
 
+static int linear_bwd_impl(float *dY, const float *Y, const float *X, const float *W, int32_t B,
+                           int32_t N, int32_t K, int32_t w_transposed, int32_t act, float *dX,
+                           float *dW, int32_t dw_accumulate, float *db, const float *dx_act_y, void *stream_);
+
+static int g_linear_pair = -1;     // -1: RK_LINEAR_PAIR not read yet
+extern "C" void rk_linear_pair(int32_t on) { g_linear_pair = on ? 1 : 0; }
+
 extern "C" int rk_linear_bwd(float *dY, const float *Y, const float *X, const float *W, int32_t B,
                              int32_t N, int32_t K, int32_t w_transposed, int32_t act, float *dX,
                              float *dW, int32_t dw_accumulate, float *db, void *stream_) {
+  return linear_bwd_impl(dY, Y, X, W, B, N, K, w_transposed, act, dX, dW, dw_accumulate, db, nullptr, stream_);
+}
+
+extern "C" int rk_linear_bwd_dact(float *dY, const float *Y, const float *X, const float *W, int32_t B,
+                                  int32_t N, int32_t K, int32_t w_transposed, int32_t act, float *dX,
+                                  float *dW, int32_t dw_accumulate, float *db, const float *dx_act_y,
+                                  void *stream_) {
+  RK_REQUIRE(dX != nullptr || dx_act_y == nullptr, "dx_act_y needs dX");
+  return linear_bwd_impl(dY, Y, X, W, B, N, K, w_transposed, act, dX, dW, dw_accumulate, db, dx_act_y, stream_);
+}
+
+static int linear_bwd_impl(float *dY, const float *Y, const float *X, const float *W, int32_t B,
+                           int32_t N, int32_t K, int32_t w_transposed, int32_t act, float *dX,
+                           float *dW, int32_t dw_accumulate, float *db, const float *dx_act_y, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B == 0) return 0;
   int rc = db ? rk_act_grad_colsum(dY, Y, B, N, act, db, stream_)
@@ -1456,22 +1477,26 @@ extern "C" int rk_linear_bwd(float *dY, const float *Y, const float *X, const fl
   const bool small = g_gemm_probe == nullptr && rk_small_gemm_fits(B, K, N) &&
                      rk_small_gemm_fits(w_transposed ? K : N, w_transposed ? N : K, B);
   if (small) {
+    rk_small_gemm_t gx = {}, gw = {};
     if (dX) {  // dX[B,K] = dY[B,N] . Weff[N,K]: reduction over N
-      rk_small_gemm_t g = {};
-      g.A = dY; g.lda = N; g.amode = 0;
-      g.B = W; g.ldb = ldw; g.bmode = w_transposed ? 0 : 1;   // W[N,K]: k-major; Wst[K,N]: N contiguous
-      g.M = B; g.N = K; g.K = N; g.C = dX; g.ldc = K; g.act = RK_ACT_NONE;
-      rc = rk_small_gemm(&g, stream_);
-      if (rc) return rc;
+      gx.A = dY; gx.lda = N; gx.amode = 0;
+      gx.B = W; gx.ldb = ldw; gx.bmode = w_transposed ? 0 : 1;   // W[N,K]: k-major; Wst[K,N]: N contiguous
+      gx.M = B; gx.N = K; gx.K = N; gx.C = dX; gx.ldc = K; gx.act = RK_ACT_NONE;
+      gx.dact_y = dx_act_y; gx.dact = act;
     }
     if (dW) {  // reduction over the B rows: both operands k-major
-      rk_small_gemm_t g = {};
+      rk_small_gemm_t &g = gw;
       g.amode = 1; g.bmode = 1; g.K = B; g.act = RK_ACT_NONE; g.accumulate = dw_accumulate; g.C = dW;
       if (!w_transposed) { g.A = dY; g.lda = N; g.B = X; g.ldb = K; g.M = N; g.N = K; g.ldc = K; }   // dW[N,K] = dY^T . X
       else               { g.A = X; g.lda = K; g.B = dY; g.ldb = N; g.M = K; g.N = N; g.ldc = N; }   // dWst[K,N] = X^T . dY
-      rc = rk_small_gemm(&g, stream_);
-      if (rc) return rc;
     }
+    // both read dYpre only and write disjoint outputs, but as ONE launch (rk_small_gemm_pair,
+    // RK_LINEAR_PAIR=1) they take 15.5 us against 5.3 + 7.4 one behind the other at 500 x 200 x 200
+    // (tools/probes/linear_bwd_probe.py: 21.1 vs 17.7 us per call; C3 0.292 vs 0.274 ms per step)
+    if (g_linear_pair < 0) { const char *e = getenv("RK_LINEAR_PAIR"); g_linear_pair = (e && atoi(e) == 1) ? 1 : 0; }
+    if (dX && dW && g_linear_pair) return rk_small_gemm_pair(&gx, &gw, stream_);
+    if (dX) { rc = rk_small_gemm(&gx, stream_); if (rc) return rc; }
+    if (dW) { rc = rk_small_gemm(&gw, stream_); if (rc) return rc; }
     return 0;
   }
   if (dX) {  // dX[B,K] = dY[B,N] . Weff[N,K]
@@ -1487,6 +1512,10 @@ extern "C" int rk_linear_bwd(float *dY, const float *Y, const float *X, const fl
     if (!w_transposed) launch_small<0, 1>(p, tiles, vec, stream);   // W[N,K]: k-major
     else launch_small<0, 0>(p, tiles, vec, stream);                 // Wst[K,N]: reduction contiguous
     RK_CHECK_LAUNCH("linear_bwd_dx");
+    if (dx_act_y) {
+      rc = rk_act_grad(dX, dx_act_y, (int64_t)B * K, act, stream_);
+      if (rc) return rc;
+    }
   }
   if (dW) {
     GemmP p = {};

@@ -70,16 +70,21 @@ __device__ __forceinline__ void direct_load(const float *__restrict__ X, int64_t
     }
 }
 
+constexpr int SG_PANEL = 32 * SG_LD;
 template <int AMODE, int BMODE>
-__global__ __launch_bounds__(256) void small_gemm_kernel(rk_small_gemm_t g, int tiles_n, int vec_a,
-                                                         int vec_b) {
+constexpr int sg_smem_floats() {
   // staging panels of the K-contiguous operands; the cross-wave reduction reuses the space
-  constexpr int PANEL = 32 * SG_LD;
   constexpr int N_PANEL = (AMODE == 0 ? 1 : 0) + (BMODE == 0 ? 1 : 0);
-  constexpr int SM = (N_PANEL * PANEL > 4 * 16 * 64) ? N_PANEL * PANEL : 4 * 16 * 64;
-  __shared__ __attribute__((aligned(16))) float smem[SM];
+  return (N_PANEL * SG_PANEL > 4 * 16 * 64) ? N_PANEL * SG_PANEL : 4 * 16 * 64;
+}
+
+// one 32 x 32 output tile (number `tile` of g's tile grid) by the calling workgroup
+template <int AMODE, int BMODE>
+__device__ __forceinline__ void small_gemm_tile(const rk_small_gemm_t &g, const int tile, const int tiles_n,
+                                                const int vec_a, const int vec_b, float *smem) {
+  constexpr int PANEL = SG_PANEL;
   float *As = smem, *Bs = smem + (AMODE == 0 ? PANEL : 0);
-  const int mt = blockIdx.x / tiles_n, nt = blockIdx.x % tiles_n;
+  const int mt = tile / tiles_n, nt = tile % tiles_n;
   const int m0 = mt * 32, n0 = nt * 32;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
@@ -154,10 +159,32 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(rk_small_gemm_t g, int 
     const int m = m0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
     if (m < g.M && col < g.N) {
       float *dst = g.C + (int64_t)m * g.ldc + col;
-      const float o = rk_act(s + bv, g.act);
+      float o = rk_act(s + bv, g.act);
+      // (backward of a stack's first layer: the gradient leaves multiplied by act'(the layer's
+      // input activation) -- the rk_act_grad pass that followed, same product)
+      if (g.dact_y) o = o * rk_act_dy(g.dact_y[(int64_t)m * g.ldc + col], g.dact);
       *dst = g.accumulate ? (o + *dst) : o;
     }
   }
+}
+
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void small_gemm_kernel(rk_small_gemm_t g, int tiles_n, int vec_a,
+                                                         int vec_b) {
+  __shared__ __attribute__((aligned(16))) float smem[sg_smem_floats<AMODE, BMODE>()];
+  small_gemm_tile<AMODE, BMODE>(g, (int)blockIdx.x, tiles_n, vec_a, vec_b, smem);
+}
+
+// TWO independent contractions in one launch (rk_linear_bwd: dX and dW both need dYpre only):
+// workgroups [0, tiles1) take g1's tiles, the rest g2's (both operands k-major: <1, 1>)
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void small_gemm_pair_kernel(rk_small_gemm_t g1, int tiles_n1, int vec_a1,
+                                                              int vec_b1, int tiles1, rk_small_gemm_t g2,
+                                                              int tiles_n2) {
+  constexpr int SM1 = sg_smem_floats<AMODE, BMODE>(), SM2 = sg_smem_floats<1, 1>();
+  __shared__ __attribute__((aligned(16))) float smem[SM1 > SM2 ? SM1 : SM2];
+  if ((int)blockIdx.x < tiles1) small_gemm_tile<AMODE, BMODE>(g1, (int)blockIdx.x, tiles_n1, vec_a1, vec_b1, smem);
+  else small_gemm_tile<1, 1>(g2, (int)blockIdx.x - tiles1, tiles_n2, 0, 0, smem);
 }
 
 // dY <- dY * act'(Y) in place and db[c] = sum_r dY[r][c] of the result, in one pass: block = 32
@@ -227,6 +254,23 @@ int rk_small_gemm(const rk_small_gemm_t *g, void *stream_) {
   else               { if (g->bmode == 0) SG(1, 0); else SG(1, 1); }
 #undef SG
   RK_CHECK_LAUNCH("small_gemm");
+  return 0;
+}
+
+// g1 (amode 0) and g2 (amode 1, bmode 1) as one launch; results identical to two rk_small_gemm calls
+int rk_small_gemm_pair(const rk_small_gemm_t *g1, const rk_small_gemm_t *g2, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(g1->amode == 0 && g2->amode == 1 && g2->bmode == 1, "pair: dX-shaped and dW-shaped operands");
+  RK_REQUIRE(g1->M > 0 && g1->N > 0 && g1->K > 0 && g2->M > 0 && g2->N > 0 && g2->K > 0, "pair: empty problem");
+  const int tn1 = rk_cdiv(g1->N, 32), tn2 = rk_cdiv(g2->N, 32);
+  const int t1 = rk_cdiv(g1->M, 32) * tn1, t2 = rk_cdiv(g2->M, 32) * tn2;
+  const int va = (al16(g1->A) && g1->lda % 4 == 0 && g1->K % 4 == 0) ? 1 : 0;
+  const int vb = (g1->bmode == 0 && al16(g1->B) && g1->ldb % 4 == 0 && g1->K % 4 == 0) ? 1 : 0;
+  if (g1->bmode == 0)
+    RK_LAUNCH((small_gemm_pair_kernel<0, 0>), dim3(t1 + t2), dim3(256), 0, stream, *g1, tn1, va, vb, t1, *g2, tn2);
+  else
+    RK_LAUNCH((small_gemm_pair_kernel<0, 1>), dim3(t1 + t2), dim3(256), 0, stream, *g1, tn1, va, vb, t1, *g2, tn2);
+  RK_CHECK_LAUNCH("small_gemm_pair");
   return 0;
 }
 

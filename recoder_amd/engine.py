@@ -572,9 +572,12 @@ class FusedEngine:
                 os.environ.get("RK_ENTRY_DW_ENC_FUSED", "1") != "0" and
                 bool(lib.rk_dw_encode_bwd_fused_ok(row_off, B)))
     self._dw_deferred = None
+    self._dw_colsum = False
     if defer_dw:
       if self.loss_id == LOSS_MNLL:
-        check(lib.rk_colsum(ptr(self.dO), B, tb.n_cap, 0, ptr(tb.counts), ptr(self.gb_de), stream), "rk_colsum")
+        # (dO comes from rk_mnll_finish: its column sums -- the decoder bias gradient -- are taken by
+        # extra workgroups of the dW || encoder-backward launch)
+        self._dw_colsum = True
       elif lazy:
         self._gb_lazy = (cdiv(B, self.row_tile), tb)
       else:
@@ -645,20 +648,32 @@ class FusedEngine:
       # encoder Linear stack, last to first
       for i in range(self.nl - 1, -1, -1):
         layer = m.encoding_layers[i]
-        check(lib.rk_linear_bwd(ptr(self.denc[i + 1]), ptr(self.enc[i + 1]), ptr(self.enc[i]),
-                                ptr(layer.weight), B, self.h[i + 1], self.h[i], 0, self.act,
-                                ptr(self.denc[i]), ptr(self.g_enc_w[i]),
-                                1 if m.is_constrained else 0, ptr(self.g_enc_b[i]), stream),
+        # (the stack's first layer: its dX is the embedding layer's gradient -- act'(enc[0]) is
+        # folded into that product's epilogue instead of an rk_act_grad launch behind it)
+        last = i == 0 and not fuse_act
+        check(lib.rk_linear_bwd_dact(ptr(self.denc[i + 1]), ptr(self.enc[i + 1]), ptr(self.enc[i]),
+                                     ptr(layer.weight), B, self.h[i + 1], self.h[i], 0, self.act,
+                                     ptr(self.denc[i]), ptr(self.g_enc_w[i]),
+                                     1 if m.is_constrained else 0, ptr(self.g_enc_b[i]),
+                                     ptr(self.enc[0]) if last else None, stream),
               "rk_linear_bwd")
+        if last:
+          fuse_act = True
       if not fuse_act:
         check(lib.rk_act_grad(ptr(self.denc[0]), ptr(self.enc[0]), B * h0, self.act, stream),
               "rk_act_grad")
       G_en = self.G_de if tied else self.G_en      # tied: accumulates on top of dW's rows
       if getattr(self, "_dw_deferred", None) is not None:
         zz, self._dw_deferred = self._dw_deferred, None
-        check(lib.rk_decode_bwd_dw2_encode_bwd(ptr(self.dO), ptr(zz), B, h0, blk.ref, ptr(self.ws_dw), None,
-                                               ptr(self.ranges), row_off, ptr(self.denc[0]), ptr(G_en),
-                                               ptr(self.gb_en), stream), "rk_decode_bwd_dw2_encode_bwd")
+        if self._dw_colsum:
+          check(lib.rk_decode_bwd_dw2_encode_bwd_colsum(ptr(self.dO), ptr(zz), B, h0, blk.ref, ptr(self.ws_dw),
+                                                        None, ptr(self.ranges), row_off, ptr(self.denc[0]),
+                                                        ptr(G_en), ptr(self.gb_en), ptr(self.gb_de), stream),
+                "rk_decode_bwd_dw2_encode_bwd_colsum")
+        else:
+          check(lib.rk_decode_bwd_dw2_encode_bwd(ptr(self.dO), ptr(zz), B, h0, blk.ref, ptr(self.ws_dw), None,
+                                                 ptr(self.ranges), row_off, ptr(self.denc[0]), ptr(G_en),
+                                                 ptr(self.gb_en), stream), "rk_decode_bwd_dw2_encode_bwd")
         self._dw_slabs = (blk, B)
         self._ws_dw_live = True
       else:

@@ -1589,11 +1589,13 @@ def test_topk_tie_rule_and_strip_merge():
   (1, 8, 4, 0, "none", 0), (64, 32, 600, 0, "selu", 0), (300, 50, 30, 1, "elu", 0),
   (33, 1100, 40, 0, "tanh", 0), (33, 40, 1100, 1, "tanh", 1),         # past the small kernel: LDS-tiled path
 ])
-def test_linear_layer_entry_points_match_torch(B, N, K, wt, act, acc):
+@pytest.mark.parametrize("pair", [0, 1])
+def test_linear_layer_entry_points_match_torch(B, N, K, wt, act, acc, pair):
   from recoder_amd import _lib
   from recoder_amd._lib import ACT, check, ptr
   from recoder_amd.device import current_stream
   lib = _lib.load()
+  lib.rk_linear_pair(pair)       # dX and dW as one launch (opt-in) or two: the same tiles either way
   g = torch.Generator(device="cpu").manual_seed(B * 7 + N * 3 + K)
   f = lambda *s: torch.randn(*s, generator=g, dtype=torch.float32)
   X, W, b, dY0, dW0 = f(B, K), f(N, K) * 0.2, f(N) * 0.1, f(B, N), f(N, K)
@@ -1626,6 +1628,20 @@ def test_linear_layer_entry_points_match_torch(B, N, K, wt, act, acc):
   got_dW = dWd.cpu().double()
   assert torch.allclose(got_dW.t() if wt else got_dW, want_dW, **tol)
   assert torch.allclose(db.cpu().double(), gpre.sum(0), **tol)
+  # rk_linear_bwd_dact: the same call with act'(Xact) folded into dX's epilogue == the call above
+  # followed by rk_act_grad, bit for bit (dW, db and dYpre unchanged)
+  Xact = fn(f(B, K)).to(dev())
+  dY2 = dY0.to(dev()).clone()
+  dX2 = torch.empty(B, K, device=dev())
+  dW2 = ((dW0.t().contiguous() if wt else dW0).to(dev()).clone() if acc
+         else torch.empty(K, N, device=dev()) if wt else torch.empty(N, K, device=dev()))
+  db2 = torch.empty(N, device=dev())
+  check(lib.rk_linear_bwd_dact(ptr(dY2), ptr(Y), ptr(Xd), ptr(Wd), B, N, K, wt, a, ptr(dX2), ptr(dW2), acc,
+                               ptr(db2), ptr(Xact), st), "rk_linear_bwd_dact")
+  check(lib.rk_act_grad(ptr(dX), ptr(Xact), B * K, a, st), "rk_act_grad")
+  torch.cuda.synchronize()
+  lib.rk_linear_pair(0)
+  assert torch.equal(dX2, dX) and torch.equal(dW2, dWd) and torch.equal(db2, db) and torch.equal(dY2, dY)
 
 
 def test_hook_order_that_is_not_one_pass_takes_the_eager_path(monkeypatch):

@@ -285,6 +285,26 @@ def test_dw_and_encoder_backward_in_one_launch_equal_the_two_launches(B, h, n_it
   assert a[0] == b[0] and a[0] >= 1
   assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
   assert float(a[1].abs().max()) > 0 and float(a[2].abs().max()) > 0
+  # ... and with dO's column sums (the multinomial loss's decoder bias gradient) as a third workgroup
+  # range: everything else unchanged, the sums equal to rk_colsum's up to the order of 8 row slices
+  ws = torch.zeros(wsz, **f)
+  G_en = torch.full((blk.n_cap * h,), 3.0, **f)
+  gb = torch.full((h * 8,), 3.0, **f)
+  gb_de = torch.full((blk.ld_cap,), 7.0, **f)
+  want = torch.empty(blk.ld_cap, **f)
+  blk.counts[4:5].zero_()
+  check(lib.rk_decode_bwd_dw2_encode_bwd_colsum(ptr(dO), ptr(Zb), B, h, blk.ref, ptr(ws), None, ptr(ranges),
+                                                row_off, ptr(dZ0), ptr(G_en), ptr(gb), ptr(gb_de), st))
+  check(lib.rk_colsum(ptr(dO), B, blk.n_cap, 0, ptr(blk.counts), ptr(want), st))
+  torch.cuda.synchronize()
+  off = (lib.rk_dw3_planes_bytes(B, h) + 255) // 256 * 256 // 4
+  assert int(blk.counts[4].item()) == b[0]
+  assert torch.equal(ws[off:off + b[0] * blk.n_cap * h].view(b[0], blk.n_cap, h)[:, :n_b], b[1])
+  assert torch.equal(G_en[:n_b * h], b[2]) and torch.equal(gb[:h], b[3])
+  ref64 = dO[:B * ld].view(B, ld)[:, :n_b].double().sum(0)
+  assert torch.allclose(gb_de[:n_b].double(), ref64, rtol=1e-5, atol=1e-8)
+  assert torch.allclose(gb_de[:n_b], want[:n_b], rtol=1e-5, atol=1e-8)
+  assert bool((gb_de[n_b:] == 7.0).all())          # nothing past the live columns is written
 
 
 @pytest.mark.parametrize("B,h,n_items", [(500, 128, 3000), (37, 20, 400), (1, 8, 97), (300, 512, 2000)])
