@@ -73,6 +73,8 @@ KERNELS = {"rk_ae_encode_fwd": ["ae_encode_fwd_kernel (+ the W_de[items] split w
            "rk_ae_encode_bwd": ["ae_encode_bwd_cols_kernel", "ae_encode_bwd_kernel"],
            "rk_adam_multi": ["adam_multi_kernel"], "rk_adam_de": ["adam_multi_kernel"],
            "rk_decode_loss_dz_planes": ["decode_planes_kernel<1,2,EPI,3,false,DZT> (decode + loss + dZ partials)"],
+           "rk_decode_loss_planes": ["decode_planes_kernel<TM,2,EPI>"],
+           "rk_decode_bwd_dz_planes": ["dz_planes_kernel<TN>", "splitk_reduce_kernel"],
            "rk_decode_dz_reduce": ["splitk_reduce_kernel"], "rk_split_w": ["split_w_kernel"],
            "rk_split_wz": ["split_wz_kernel (W_de[items] and Z plane images, one launch)"],
            "rk_decode_bwd_dw2": ["dw3_kernel<BN,false,true>"],
@@ -171,6 +173,8 @@ def entry_work(entry, B, h0, n_b, nnz, n_items, cfg):
     return algorithmic_work(entry, B, h0, n_b, nnz, n_items, bool(cfg["sparse"]))
   if entry in ("rk_decode_bwd_dw3", "rk_decode_bwd_dw2", "rk_decode_bwd_dw2_encode_bwd",
                "rk_decode_bwd_dw2_encode_bwd_colsum"):
+    return "mfma", 2.0 * B * h0 * n_b / 1e12, "TFLOP/s"
+  if entry in ("rk_decode_loss_planes", "rk_decode_bwd_dz_planes"):    # the plane kernels outside the fused form
     return "mfma", 2.0 * B * h0 * n_b / 1e12, "TFLOP/s"
   if entry == "rk_decode_loss_dz_planes":       # decode + loss + the dZ partials of every column tile
     return "mfma", 4.0 * B * h0 * n_b / 1e12, "TFLOP/s"

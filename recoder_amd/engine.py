@@ -417,6 +417,7 @@ class FusedEngine:
     inv_B = _f32(np.float32(1.0) / np.float32(denom_rows))
     out = self.loss_out if out is None else out
     self._dz_in_ws = False
+    self._dz_on_planes = False
     if fuse_dz and ip is None and self.planes is not None and self.split16 and self.ws_dw is not None and \
         self.item_parallel is None and lib.rk_decode_dz_fused_ok(B, self.h[0], tgt.n_cap, self.loss_id):
       # training steps sequenced entry by entry (hidden stacks, bottleneck dropout, MatrixFactorization):
@@ -432,6 +433,19 @@ class FusedEngine:
                                          self.confidence, inv_B, ptr(self.dO), ptr(self.loss_part),
                                          ptr(self.gb_part), ptr(self.ws), stream), "rk_decode_loss_dz_planes")
       self._dz_in_ws = True
+    elif fuse_dz and ip is None and self.planes is not None and self.split16 and self.item_parallel is None \
+        and os.environ.get("RK_ENTRY_PLANES", "1") != "0":
+      # outside the fused launch's domain (multinomial loss, h > 256, >= 1024 rows): still the plane
+      # kernels -- ONE split launch, then the copy -> LDS -> MFMA decode; the dZ product follows on the
+      # W^T image (rk_decode_bwd_dz_planes) where rk_decode_bwd_dz would split W_de in its k-loop again
+      h0 = self.h[0]
+      rg = self._ranges(z, B * h0, stream)
+      check(lib.rk_split_wz(ptr(W), ptr(z), B, h0, tgt.ref, rg, ctypes.byref(self.planes), stream),
+            "rk_split_wz")
+      check(lib.rk_decode_loss_planes(ctypes.byref(self.planes), B, tgt.ref, row_off, ptr(b), self.loss_id,
+                                      self.confidence, inv_B, ptr(self.dO), 0, ptr(self.loss_part),
+                                      ptr(self.gb_part), stream), "rk_decode_loss_planes")
+      self._dz_on_planes = True
     else:
       check(lib.rk_decode_loss(ptr(z), B, self.h[0], tgt.ref, row_off, ptr(W), ptr(b), self.loss_id,
                                self.confidence, inv_B, ptr(self.dO), 0, ptr(self.loss_part),
@@ -614,6 +628,11 @@ class FusedEngine:
       check(lib.rk_decode_dz_reduce(ptr(self.ws), B, h0, tb.ref, ptr(self.enc[0]) if fuse_act else None,
                                     self.act, ptr(dz), stream), "rk_decode_dz_reduce")
       self._dz_in_ws = False
+    elif getattr(self, "_dz_on_planes", False):
+      check(lib.rk_decode_bwd_dz_planes(ptr(self.dO), B, ctypes.byref(self.planes), tb.ref,
+                                        ptr(self.enc[0]) if fuse_act else None, self.act, ptr(dz),
+                                        ptr(self.ws), stream), "rk_decode_bwd_dz_planes")
+      self._dz_on_planes = False
     else:
       check(lib.rk_decode_bwd_dz(ptr(self.dO), B, h0, tb.ref, ptr(W_de),
                                  ptr(self.enc[0]) if fuse_act else None, self.act, ptr(dz),
