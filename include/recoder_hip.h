@@ -440,11 +440,15 @@ int rk_colsum(const float *X, int32_t rows, int32_t cols, int32_t ld,
               void *stream);
 int rk_gather_rows(const float *E, const int64_t *rows, int32_t B, int32_t d,
                    int32_t act, float *out, void *stream);
-/* the same gather (nn.py:344-362: MatrixFactorization's user rows) that also publishes max |out| in
- * slots[0..63] the way rk_amax does (64 workgroups, one slot each): gather + rk_amax in one launch
- * for unbounded activations */
+/* the same gather (nn.py:344-362: MatrixFactorization's user rows) that also
+ *   slots  (nullable): publishes max |out| in slots[0..63] the way rk_amax does (64 workgroups, one
+ *                      slot each): gather + rk_amax in one launch for unbounded activations;
+ *   rows32 (nullable, B + 1 ints): rows32[0] <- B, rows32[1 + r] <- rows[r] -- the index array and
+ *                      device-resident count of a SparseAdam job (rk_adam_job_t.rows / n_dev): the
+ *                      user table's update then rides on the step's rk_adam_multi launch instead
+ *                      of an rk_adam_rows launch of its own */
 int rk_gather_rows_amax(const float *E, const int64_t *rows, int32_t B, int32_t d,
-                        int32_t act, float *out, int32_t *slots, void *stream);
+                        int32_t act, float *out, int32_t *slots, int32_t *rows32, void *stream);
 
 /*
  * Optimisers (exact formulas of torch.optim.Adam `_single_tensor_adam` and

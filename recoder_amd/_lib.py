@@ -185,7 +185,7 @@ SIGNATURES = {
   "rk_dropout": (c_int32, [_P, _P, c_int64, c_int32, c_float, c_uint64, c_uint64, _P]),
   "rk_colsum": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P, _P]),
   "rk_gather_rows": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P]),
-  "rk_gather_rows_amax": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P]),
+  "rk_gather_rows_amax": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P]),
   "rk_adam_table": (c_int32, [_P, _P, _P, c_int32, c_int32, _P, _P, c_double, c_double, c_double,
                               c_double, c_double, c_int32, _P]),
   "rk_adam_rows": (c_int32, [_P, _P, _P, c_int32, _P, _P, _P, c_int32, _P, c_double, c_double,

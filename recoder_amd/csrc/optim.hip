@@ -186,11 +186,19 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *E, const 
 // the same gather with max |out| published for the split contractions (rk_amax's contract: the
 // maximum over the 64 slots is what the kernels use): 64 workgroups, workgroup b files ITS maximum
 // under slots[b] -- no atomics, no zeroing pass, one launch instead of two in front of an MF decode
+// rows32 (nullable): rows32[0] <- B, rows32[1 + r] <- rows[r] -- the step's user rows as the int32
+// index array (+ device-resident count) a SparseAdam job of rk_adam_multi takes, so that the user
+// table's update rides on the step's one Adam launch (replayed steps: these ARE the cursor's users)
 __global__ __launch_bounds__(256) void gather_rows_amax_kernel(const float *E, const int64_t *rows, int B,
                                                                int d, int act, float *out,
-                                                               uint32_t *__restrict__ slots, rk_cur_t cur) {
+                                                               uint32_t *__restrict__ slots,
+                                                               int32_t *__restrict__ rows32, rk_cur_t cur) {
   __shared__ float red[4];
   if (cur.cursor) rows += rk_cur_local(cur) * B;
+  if (rows32 && blockIdx.x == 0) {
+    if (threadIdx.x == 0) rows32[0] = B;
+    for (int r = threadIdx.x; r < B; r += 256) rows32[1 + r] = (int32_t)rows[r];
+  }
   const int64_t tot = (int64_t)B * d;
   float m = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256) void gather_rows_amax_kernel(const float *E, c
   m = rk_wave_max(m);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0)
+  if (threadIdx.x == 0 && slots)
     slots[blockIdx.x] = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
@@ -657,13 +665,14 @@ extern "C" int rk_colsum(const float *X, int32_t rows, int32_t cols, int32_t ld,
 }
 
 extern "C" int rk_gather_rows_amax(const float *E, const int64_t *rows, int32_t B, int32_t d,
-                                   int32_t act, float *out, int32_t *slots, void *stream_) {
+                                   int32_t act, float *out, int32_t *slots, int32_t *rows32,
+                                   void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  RK_REQUIRE(slots != nullptr && B > 0, "slots, B > 0");
+  RK_REQUIRE(B > 0, "B > 0");
   rk_cur_t cur = {nullptr, 0};
   if (const rk_replay_t *rp = rk_replay_get()) { cur = {rp->cursor, rp->off}; rows = rp->users_base; }
   RK_LAUNCH(gather_rows_amax_kernel, dim3(64), dim3(256), 0, stream, E, rows, B, d, act, out,
-            reinterpret_cast<uint32_t *>(slots), cur);
+            reinterpret_cast<uint32_t *>(slots), rows32, cur);
   RK_CHECK_LAUNCH("gather_rows_amax");
   return 0;
 }

@@ -357,12 +357,25 @@ class FusedEngine:
     d = self.h[0]
     self.drop_active = bool(train and m.dropout_prob > 0)
     self._amax_of = None
-    if not self.act_bounded and not self.drop_active and self.split16 and B > 0:
+    self._users32 = None
+    want_amax = not self.act_bounded and not self.drop_active and self.split16
+    # SparseAdam on the user table: the gather leaves the step's users as an int32 index array (+
+    # count) so that the update is a job of the step's rk_adam_multi launch, not an rk_adam_rows launch
+    su = self.states.get("user_embedding_layer.weight") if train else None
+    want_rows = su is not None and su.sparse and self.allreduce is None and self.item_parallel is None
+    if (want_amax or want_rows) and B > 0:
       # unbounded activation: the split contractions need max |z| -- the gather publishes it
       # (64 slots, one per workgroup) instead of an rk_amax launch behind it
+      if want_rows and (getattr(self, "_users32_buf", None) is None or self._users32_buf.numel() < B + 1):
+        self._users32_buf = torch.zeros(max(B, self.B_cap) + 1, dtype=torch.int32, device=self.device)
       check(lib.rk_gather_rows_amax(ptr(m.user_embedding_layer.weight), ptr(users), B, d, self.act,
-                                    ptr(self.enc[0]), ptr(self.ranges), stream), "rk_gather_rows_amax")
-      self._amax_of = (self.enc[0].data_ptr(), B * d)
+                                    ptr(self.enc[0]), ptr(self.ranges) if want_amax else None,
+                                    ptr(self._users32_buf) if want_rows else None, stream),
+            "rk_gather_rows_amax")
+      if want_amax:
+        self._amax_of = (self.enc[0].data_ptr(), B * d)
+      if want_rows:
+        self._users32 = self._users32_buf
     else:
       check(lib.rk_gather_rows(ptr(m.user_embedding_layer.weight), ptr(users), B, d, self.act,
                                ptr(self.enc[0]), stream), "rk_gather_rows")
@@ -1081,7 +1094,11 @@ class FusedEngine:
         rp = getattr(self, "_replay", None)
         users = blk.users[row_off:row_off + B] if rp is None else rp["users_t"]
         su = S["user_embedding_layer.weight"]
-        if su.sparse:
+        if su.sparse and getattr(self, "_users32", None) is not None:
+          # (the forward's gather left the users as int32 rows + count: a job of the one Adam launch)
+          u32 = self._users32
+          self._adam_rows(su, u32[1:], None, u32[:1], B, self.dbott, h0, stream)
+        elif su.sparse:
           self._adam_rows(su, None, users, None, B, self.dbott, h0, stream)
         else:
           check(lib.rk_scatter_pos(ptr(self.pos_u), ptr(users), B, 0, stream), "rk_scatter_pos")

@@ -343,8 +343,13 @@ def test_gather_rows_amax_is_gather_plus_amax(B, d, act):
   r1 = torch.full((128,), 7, dtype=torch.int32, device=dev)
   check(lib.rk_gather_rows(ptr(E), ptr(rows), B, d, act, ptr(out0), st))
   check(lib.rk_amax(ptr(out0), B * d, ptr(r0), st))
-  check(lib.rk_gather_rows_amax(ptr(E), ptr(rows), B, d, act, ptr(out1), ptr(r1), st))
+  r32 = torch.full((B + 3,), -5, dtype=torch.int32, device=dev)
+  check(lib.rk_gather_rows_amax(ptr(E), ptr(rows), B, d, act, ptr(out1), ptr(r1), ptr(r32), st))
+  out2 = torch.empty(B * d, device=dev)
+  check(lib.rk_gather_rows_amax(ptr(E), ptr(rows), B, d, act, ptr(out2), None, None, st))   # plain gather
   torch.cuda.synchronize()
-  assert torch.equal(out0, out1)
+  assert torch.equal(out0, out1) and torch.equal(out0, out2)
+  # the rows as an int32 index array behind their count (a SparseAdam job's rows / n_dev)
+  assert int(r32[0]) == B and torch.equal(r32[1:B + 1].long(), rows) and bool((r32[B + 1:] == -5).all())
   assert int(r0[:64].max()) == int(r1[:64].max()) == int(out0.abs().max().view(torch.int32))
   assert torch.equal(r0[64:], r1[64:])            # the W half is not touched
