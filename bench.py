@@ -586,17 +586,19 @@ def main():
       kernels = []
       # (the steps that really went through the bracketed calls: with graph replay only the eagerly
       # sequenced ones behind the sampling mark do; the decode runs exactly once per step)
-      n_sampled = max(1, T["entries"].get("rk_decode_loss", T["entries"].get("rk_decode_loss_dz_planes",
-                                                                             (n_sample, 0.0)))[0])
+      n_sampled = max(1, next((T["entries"][e][0] for e in ("rk_decode_loss", "rk_decode_loss_dz_planes",
+                                                            "rk_decode_loss_planes") if e in T["entries"]),
+                              n_sample))
       for e, (calls, ms) in sorted(T["entries"].items(), key=lambda kv: -kv[1][0] * kv[1][1]):
         per_step = calls / float(n_sampled)
         bound, work, unit = entry_work(e, B, h0, n_b, nnz, n_items, cfg)
         if e == "rk_adam_multi":
           # the per-entry sequencing issues the step's updates in launches of <= 6 tensors: the
           # formula is the whole step's traffic (the two tables dominate), spread over them;
-          # MatrixFactorization: the item table + its bias only (the user rows go through rk_adam_rows)
+          # MatrixFactorization: the item table + its bias, and under SparseAdam the step's B user rows
+          # (a job of the same launch: the gather leaves them as an int32 index array)
           if cfg["kind"] == "mf":
-            work = (n_b * h0 * 28 * (1 if cfg["sparse"] else 0) + n_items * 28 + n_b * 32) / 1e9 \
+            work = ((n_b + B) * h0 * 28 + n_items * 28 + n_b * 32) / 1e9 \
                 if cfg["sparse"] else (n_items * h0 * 24 + n_b * h0 * 4 + n_items * 32) / 1e9
           work /= max(per_step, 1.0)
         if bound is None or work <= 0:

@@ -393,6 +393,14 @@ int rk_split_w(const float *W_de, int32_t h, const rk_block_t *tgt, const int32_
  * stacks -- one launch less in front of every decode; same images, bit for bit) */
 int rk_split_wz(const float *W_de, const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
                 const int32_t *ranges, const rk_planes_t *pl, void *stream);
+/* rk_split_wz that ALSO writes Z^T as the fp16 pair planes (+ their scale) of the dW kernel at the head
+ * of dw_workspace -- where rk_decode_bwd_dw2 makes them in a launch of its own when it is called
+ * with zt_planes == NULL; call it with zt_planes == workspace == dw_workspace afterwards (the kernel then
+ * reads the scale the planes were written with).  dw_workspace NULL: rk_split_wz.  Only where
+ * rk_split_zt_ok() (dW on fp16 pairs, not the plain-bf16 data point). */
+int32_t rk_split_zt_ok(void);
+int rk_split_wz_zt(const float *W_de, const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
+                   const int32_t *ranges, const rk_planes_t *pl, void *dw_workspace, void *stream);
 /* Z[B, h] -> pl->z; the scale from ranges[0..63] */
 int rk_split_z(const float *Z, int32_t B, int32_t h, const int32_t *ranges, const rk_planes_t *pl,
                void *stream);

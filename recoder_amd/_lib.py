@@ -134,6 +134,8 @@ SIGNATURES = {
   "rk_split_w": (c_int32, [_P, c_int32, _BLK, _P, POINTER(RkPlanes), _P]),
   "rk_split_z": (c_int32, [_P, c_int32, c_int32, _P, POINTER(RkPlanes), _P]),
   "rk_split_wz": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, POINTER(RkPlanes), _P]),
+  "rk_split_wz_zt": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, POINTER(RkPlanes), _P, _P]),
+  "rk_split_zt_ok": (c_int32, []),
   "rk_decode_loss_planes": (c_int32, [POINTER(RkPlanes), c_int32, _BLK, c_int32, _P, c_int32, c_float,
                                       c_float, _P, c_int32, _P, _P, _P]),
   "rk_decode_bwd_dz_planes": (c_int32, [_P, c_int32, POINTER(RkPlanes), _BLK, _P, c_int32, _P, _P, _P]),

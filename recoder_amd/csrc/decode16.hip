@@ -791,15 +791,28 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
 
 // rk_split_wz: both operand splits of an entry-by-entry sequenced decode in ONE launch (the one-call
 // step lets them ride on its encoder forward): workgroups [0, w_tiles) cut W_de[items], the rest Z
+// ... and behind them (zt_blocks > 0) Z^T as the fp16 pair planes the dW kernel reads, written where
+// rk_decode_bwd_dw2 would make them in a launch of its own: at the head of ITS workspace
+struct SplitZt {
+  uint16_t *P;
+  float *scale_out;
+  int rows_pad, cols_pad;
+};
 __global__ __launch_bounds__(256) void split_wz_kernel(rkp::SplitW p, int w_tiles, const float *__restrict__ Z,
-                                                       int B, const uint32_t *zmax, char *zimg) {
+                                                       int B, const uint32_t *zmax, char *zimg, int z_blocks,
+                                                       SplitZt zt) {
   __shared__ __attribute__((aligned(16))) char sm[rkp::SPLIT_W_LDS];
-  if ((int)blockIdx.x < w_tiles) {
-    rkp::split_w_job<256>(p, (int)blockIdx.x, sm);
+  const int blk = (int)blockIdx.x;
+  if (blk < w_tiles) {
+    rkp::split_w_job<256>(p, blk, sm);
     return;
   }
-  split_rows_job((int)blockIdx.x - w_tiles, Z, B, p.h, p.h, zmax, rkp::SCALE_Z, zimg, p.KT, p.scales, 0,
-                 p.plain);
+  if (blk < w_tiles + z_blocks) {
+    split_rows_job(blk - w_tiles, Z, B, p.h, p.h, zmax, rkp::SCALE_Z, zimg, p.KT, p.scales, 0, p.plain);
+    return;
+  }
+  rkp::split_zt_pairs_job(blk - w_tiles - z_blocks, Z, B, p.h, p.h, zt.rows_pad, zt.cols_pad, zt.P, zmax,
+                          zt.scale_out);
 }
 
 inline bool aligned16(const void *q) { return ((uintptr_t)q & 15) == 0; }
@@ -886,19 +899,37 @@ extern "C" int rk_split_w(const float *W_de, int32_t h, const rk_block_t *tgt, c
   return 0;
 }
 
-extern "C" int rk_split_wz(const float *W_de, const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
-                           const int32_t *ranges, const rk_planes_t *pl, void *stream_) {
+extern "C" int32_t rk_split_zt_ok(void) { return (rk_dw_pairs() && !rk_gemm_plain_bf16()) ? 1 : 0; }
+
+extern "C" int rk_split_wz_zt(const float *W_de, const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
+                              const int32_t *ranges, const rk_planes_t *pl, void *dw_workspace,
+                              void *stream_) {
   RK_REQUIRE(pl && pl->h == h && tgt->n_cap <= pl->n_cap && B <= pl->B_cap,
              "planes were laid out for another shape");
   RK_REQUIRE(aligned16(W_de) && aligned16(Z), "W_de and Z must be 16-byte aligned");
+  RK_REQUIRE(dw_workspace == nullptr || (rk_split_zt_ok() && (((uintptr_t)dw_workspace) & 255) == 0),
+             "Z^T pair planes: fp16-pair dW only (rk_split_zt_ok), 256-byte aligned workspace");
   if (B == 0) return rk_split_w(W_de, h, tgt, ranges, pl, stream_);
   const rkp::SplitW s = split_w_args(W_de, tgt, ranges, pl);
   const int w_tiles = rk_cdiv(tgt->n_cap, 32);
   const int z_blocks = rk_cdiv((int64_t)B * s.KT * 8, 256);
-  RK_LAUNCH(split_wz_kernel, dim3(w_tiles + z_blocks), dim3(256), 0, (hipStream_t)stream_, s, w_tiles, Z,
-            B, reinterpret_cast<const uint32_t *>(ranges), (char *)pl->z);
+  SplitZt zt = {};
+  int zt_blocks = 0;
+  if (dw_workspace) {
+    zt.rows_pad = rk_dw3_rows_pad(B); zt.cols_pad = rk_dw3_cols_pad(h);
+    zt.P = (uint16_t *)dw_workspace;
+    zt.scale_out = reinterpret_cast<float *>((char *)dw_workspace + (int64_t)2 * zt.rows_pad * zt.cols_pad * 2);
+    zt_blocks = rk_cdiv((int64_t)(zt.rows_pad >> 3) * zt.cols_pad, 256);
+  }
+  RK_LAUNCH(split_wz_kernel, dim3(w_tiles + z_blocks + zt_blocks), dim3(256), 0, (hipStream_t)stream_, s,
+            w_tiles, Z, B, reinterpret_cast<const uint32_t *>(ranges), (char *)pl->z, z_blocks, zt);
   RK_CHECK_LAUNCH("split_wz");
   return 0;
+}
+
+extern "C" int rk_split_wz(const float *W_de, const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
+                           const int32_t *ranges, const rk_planes_t *pl, void *stream_) {
+  return rk_split_wz_zt(W_de, Z, B, h, tgt, ranges, pl, nullptr, stream_);
 }
 
 extern "C" int rk_split_z(const float *Z, int32_t B, int32_t h, const int32_t *ranges,

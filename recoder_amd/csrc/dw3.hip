@@ -51,8 +51,10 @@ __global__ __launch_bounds__(256) void split_planes_t_kernel(const float *__rest
                                                              int cols_pad, uint16_t *__restrict__ P,
                                                              int pairs, const uint32_t *amax,
                                                              float *scale_out) {
-  const float s = pairs ? rkp::scale_from(amax, rkp::SCALE_Z) : 1.0f;
-  if (pairs && scale_out && blockIdx.x == 0 && threadIdx.x == 0) *scale_out = s;
+  if (pairs) {
+    rkp::split_zt_pairs_job((int)blockIdx.x, X, rows, cols, ld, rows_pad, cols_pad, P, amax, scale_out);
+    return;
+  }
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (chunk, n)
   const int64_t tot = (int64_t)(rows_pad >> 3) * cols_pad;
   if (i >= tot) return;
@@ -65,14 +67,6 @@ __global__ __launch_bounds__(256) void split_planes_t_kernel(const float *__rest
   }
   const int64_t plane = (int64_t)rows_pad * cols_pad;               // 16-bit elements
   uint16_t *d = P + i * 8;
-  if (pairs) {
-    uint2 h0, l0, h1, l1;
-    rkp::split4(make_float4(x[0], x[1], x[2], x[3]), s, h0, l0);
-    rkp::split4(make_float4(x[4], x[5], x[6], x[7]), s, h1, l1);
-    *reinterpret_cast<uint4 *>(d) = make_uint4(h0.x, h0.y, h1.x, h1.y);
-    *reinterpret_cast<uint4 *>(d + plane) = make_uint4(l0.x, l0.y, l1.x, l1.y);
-    return;
-  }
   uint4 h, m, l;
   split_pair(x[0], x[1], h.x, m.x, l.x);
   split_pair(x[2], x[3], h.y, m.y, l.y);
@@ -518,6 +512,10 @@ static int dw_impl(const float *dO, const float *Z, int32_t B, int32_t h, const 
     if (rc) return rc;
     zt_planes = workspace;
     p.z_scale_dev = sc;
+  } else if (zt_planes == workspace && pairs) {
+    // the pair planes AND their scale were made in place, at the head of this workspace, by an earlier
+    // launch (rk_split_wz_zt: the operand splits of the step's decode)
+    p.z_scale_dev = reinterpret_cast<float *>((char *)workspace + (int64_t)2 * Bp * cols_pad * 2);
   }
   RK_REQUIRE((((uintptr_t)zt_planes) & 15) == 0, "zt_planes must be 16-byte aligned");
   p.a_amax = reinterpret_cast<const uint32_t *>(tgt->counts) + 8;

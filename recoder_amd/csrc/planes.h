@@ -79,6 +79,34 @@ __device__ __forceinline__ void store_split4(char *row_base, int k, const float4
   *reinterpret_cast<uint2 *>(d + 64) = lo;
 }
 
+// Z^T as TWO fp16 planes hi / lo of s.x in the dW kernels' layout (dw3.hip: plane p element (k = row,
+// n = col) at ((k/8)*cols_pad + n)*8 + k%8; rows >= rows and columns >= cols are zeros); s from `amax`
+// (64 slots, nullable -> SCALE_Z), *scale_out <- s.  Thread i of the job grid: (chunk of 8 rows, n).
+__device__ __forceinline__ void split_zt_pairs_job(const int block, const float *__restrict__ X, int rows,
+                                                   int cols, int ld, int rows_pad, int cols_pad,
+                                                   uint16_t *__restrict__ P, const uint32_t *amax,
+                                                   float *scale_out) {
+  const float s = scale_from(amax, SCALE_Z);
+  if (scale_out && block == 0 && threadIdx.x == 0) *scale_out = s;
+  const int64_t i = (int64_t)block * 256 + threadIdx.x;
+  const int64_t tot = (int64_t)(rows_pad >> 3) * cols_pad;
+  if (i >= tot) return;
+  const int c8 = (int)(i / cols_pad), n = (int)(i % cols_pad);
+  float x[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int r = c8 * 8 + j;
+    x[j] = (r < rows && n < cols) ? X[(int64_t)r * ld + n] : 0.f;
+  }
+  const int64_t plane = (int64_t)rows_pad * cols_pad;               // 16-bit elements
+  uint16_t *d = P + i * 8;
+  uint2 h0, l0, h1, l1;
+  split4(make_float4(x[0], x[1], x[2], x[3]), s, h0, l0);
+  split4(make_float4(x[4], x[5], x[6], x[7]), s, h1, l1);
+  *reinterpret_cast<uint4 *>(d) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+  *reinterpret_cast<uint4 *>(d + plane) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+}
+
 struct SplitW {
   const float *W;            // [n_items, h] table the decoder reads
   const int32_t *items;      // compact column -> table row

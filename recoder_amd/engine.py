@@ -50,7 +50,7 @@ class TimedLib:
                                               "rk_dw_encode_bwd_fused_ok", "rk_dw_workspace_bytes", "rk_dw_splits", "rk_encode_bwd_segments", "rk_loss_partials", "rk_decode_row_tile",
                                               "rk_dw3_workspace_bytes", "rk_dw3_max_splits", "rk_dw3_slabs", "rk_gemm_split16", "rk_dw_pairs",
                                               "rk_dw3_planes_bytes", "rk_dw3_rows_pad", "rk_dw3_cols_pad",
-                                              "rk_planes_bytes", "rk_planes_layout",
+                                              "rk_planes_bytes", "rk_planes_layout", "rk_split_zt_ok",
                                               "rk_last_error", "rk_version"):
       return fn
 
@@ -421,7 +421,8 @@ class FusedEngine:
     check(self.lib.rk_amax(ptr(z), n, ptr(self.ranges), stream), "rk_amax")
     return ptr(self.ranges)
 
-  def _loss(self, z, B, tgt, row_off, denom_rows, stream, out=None, ip=None, defer=False, fuse_dz=False):
+  def _loss(self, z, B, tgt, row_off, denom_rows, stream, out=None, ip=None, defer=False, fuse_dz=False,
+            zt_ws=None):
     """decode + loss; leaves dLoss/dLogits in self.dO. Returns device scalar.  ip: the
     block holds an item shard (parallel.ItemParallel) -- only the multinomial loss needs to
     know: its softmax statistics are combined over the ranks."""
@@ -431,6 +432,11 @@ class FusedEngine:
     out = self.loss_out if out is None else out
     self._dz_in_ws = False
     self._dz_on_planes = False
+    # zt_ws: the workspace the step's dW launch will use -- the split launch then writes Z^T as that
+    # kernel's fp16 pair planes at its head (one launch less inside rk_decode_bwd_dw2)
+    self._zt_ready = None
+    if zt_ws is not None and not self.lib.rk_split_zt_ok():
+      zt_ws = None
     if fuse_dz and ip is None and self.planes is not None and self.split16 and self.ws_dw is not None and \
         self.item_parallel is None and lib.rk_decode_dz_fused_ok(B, self.h[0], tgt.n_cap, self.loss_id):
       # training steps sequenced entry by entry (hidden stacks, bottleneck dropout, MatrixFactorization):
@@ -440,8 +446,9 @@ class FusedEngine:
       # in its own workspace in between
       h0 = self.h[0]
       rg = self._ranges(z, B * h0, stream)
-      check(lib.rk_split_wz(ptr(W), ptr(z), B, h0, tgt.ref, rg, ctypes.byref(self.planes), stream),
-            "rk_split_wz")
+      check(lib.rk_split_wz_zt(ptr(W), ptr(z), B, h0, tgt.ref, rg, ctypes.byref(self.planes), ptr(zt_ws),
+                               stream), "rk_split_wz")
+      self._zt_ready = None if zt_ws is None else zt_ws.data_ptr()
       check(lib.rk_decode_loss_dz_planes(ctypes.byref(self.planes), B, tgt.ref, row_off, ptr(b), self.loss_id,
                                          self.confidence, inv_B, ptr(self.dO), ptr(self.loss_part),
                                          ptr(self.gb_part), ptr(self.ws), stream), "rk_decode_loss_dz_planes")
@@ -453,8 +460,9 @@ class FusedEngine:
       # W^T image (rk_decode_bwd_dz_planes) where rk_decode_bwd_dz would split W_de in its k-loop again
       h0 = self.h[0]
       rg = self._ranges(z, B * h0, stream)
-      check(lib.rk_split_wz(ptr(W), ptr(z), B, h0, tgt.ref, rg, ctypes.byref(self.planes), stream),
-            "rk_split_wz")
+      check(lib.rk_split_wz_zt(ptr(W), ptr(z), B, h0, tgt.ref, rg, ctypes.byref(self.planes), ptr(zt_ws),
+                               stream), "rk_split_wz")
+      self._zt_ready = None if zt_ws is None else zt_ws.data_ptr()
       check(lib.rk_decode_loss_planes(ctypes.byref(self.planes), B, tgt.ref, row_off, ptr(b), self.loss_id,
                                       self.confidence, inv_B, ptr(self.dO), 0, ptr(self.loss_part),
                                       ptr(self.gb_part), stream), "rk_decode_loss_planes")
@@ -571,8 +579,11 @@ class FusedEngine:
     # of the bf16-pipe dW (three launches less)
     tied = self.kind == "ae" and bool(m.is_constrained)
     lazy = ip is None and self.allreduce is None
+    # (dW will work in ws_dw with its K slabs kept for the Adam sweep: see keep_slabs below)
+    zt_ws = self.ws_dw if (lazy and not tied and self.split16 and self.ws_dw is not None and
+                           os.environ.get("RK_ENTRY_ZT_SPLIT", "1") != "0") else None
     loss = self._loss(z, B, tb, row_off, rows, stream, out, ip=ip, defer=lazy,
-                      fuse_dz=os.environ.get("RK_ENTRY_DZ_FUSED", "1") != "0")
+                      fuse_dz=os.environ.get("RK_ENTRY_DZ_FUSED", "1") != "0", zt_ws=zt_ws)
     self._loss_target = loss
 
     # ---- dW = dO^T . z  (+ decoder bias gradient) ----
@@ -697,13 +708,14 @@ class FusedEngine:
       G_en = self.G_de if tied else self.G_en      # tied: accumulates on top of dW's rows
       if getattr(self, "_dw_deferred", None) is not None:
         zz, self._dw_deferred = self._dw_deferred, None
+        zt = ptr(self.ws_dw) if getattr(self, "_zt_ready", None) == self.ws_dw.data_ptr() else None
         if self._dw_colsum:
           check(lib.rk_decode_bwd_dw2_encode_bwd_colsum(ptr(self.dO), ptr(zz), B, h0, blk.ref, ptr(self.ws_dw),
-                                                        None, ptr(self.ranges), row_off, ptr(self.denc[0]),
+                                                        zt, ptr(self.ranges), row_off, ptr(self.denc[0]),
                                                         ptr(G_en), ptr(self.gb_en), ptr(self.gb_de), stream),
                 "rk_decode_bwd_dw2_encode_bwd_colsum")
         else:
-          check(lib.rk_decode_bwd_dw2_encode_bwd(ptr(self.dO), ptr(zz), B, h0, blk.ref, ptr(self.ws_dw), None,
+          check(lib.rk_decode_bwd_dw2_encode_bwd(ptr(self.dO), ptr(zz), B, h0, blk.ref, ptr(self.ws_dw), zt,
                                                  ptr(self.ranges), row_off, ptr(self.denc[0]), ptr(G_en),
                                                  ptr(self.gb_en), stream), "rk_decode_bwd_dw2_encode_bwd")
         self._dw_slabs = (blk, B)
@@ -744,8 +756,10 @@ class FusedEngine:
       if getattr(self, "_dz_in_ws", False):
         ws = self.ws_dw                  # (self.ws holds the decode launch's dZ partials until the reduce)
       if self.lib.rk_dw_pairs():
+        # (Z^T pair planes already at the head of this workspace: rk_split_wz_zt of this step's decode)
+        zt = ptr(ws) if getattr(self, "_zt_ready", None) == ws.data_ptr() else None
         check(self.lib.rk_decode_bwd_dw2(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(G), ptr(gb_de), ptr(ws),
-                                         None, ptr(self.ranges), stream), "rk_decode_bwd_dw2")
+                                         zt, ptr(self.ranges), stream), "rk_decode_bwd_dw2")
       else:
         check(self.lib.rk_decode_bwd_dw3(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(G), ptr(gb_de), ptr(ws),
                                          None, stream), "rk_decode_bwd_dw3")

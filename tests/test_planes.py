@@ -353,3 +353,45 @@ def test_gather_rows_amax_is_gather_plus_amax(B, d, act):
   assert int(r32[0]) == B and torch.equal(r32[1:B + 1].long(), rows) and bool((r32[B + 1:] == -5).all())
   assert int(r0[:64].max()) == int(r1[:64].max()) == int(out0.abs().max().view(torch.int32))
   assert torch.equal(r0[64:], r1[64:])            # the W half is not touched
+
+
+@pytest.mark.parametrize("B,h,n_items,scale", [(500, 128, 3000, 37.5), (130, 64, 900, 1.0), (33, 20, 400, 1e-3),
+                                               (300, 260, 2000, 5.0)])
+def test_split_wz_zt_leaves_the_planes_dw2_would_make(B, h, n_items, scale):
+  """rk_split_wz_zt writes Z^T as the dW kernel's fp16 pair planes (+ their scale) at the head of the dW
+  workspace: rk_decode_bwd_dw2 called with zt_planes == workspace then produces the K slabs it produces
+  when it makes the planes itself (zt_planes == NULL), bit for bit -- bounded and unbounded ranges of Z."""
+  lib, blk, W, bias, Z, ranges, pl, buf = _setup(B, h, max(B, 600), n_items, 14, seed=3 * B + h)
+  if lib.rk_split_zt_ok() != 1:
+    pytest.skip("dW is not on fp16 pairs")
+  st = current_stream()
+  f = dict(dtype=torch.float32, device=Z.device)
+  n_b, nnz, ld, _ = blk.counts_host()
+  g = torch.Generator(device=Z.device)
+  g.manual_seed(B)
+  dO = torch.zeros(B * blk.ld_cap, **f)
+  dO[:B * ld].view(B, ld)[:, :n_b] = torch.randn(B, n_b, generator=g, **f) * 1e-3
+  blk.counts[8:72].zero_()
+  blk.counts[8:9].copy_(dO.abs().max().reshape(1).view(torch.int32))
+  Zu = (Z * scale).contiguous()
+  if scale != 1.0:
+    check(lib.rk_amax(ptr(Zu), B * h, ptr(ranges), st))       # (scale == 1: |Z| <= 1, the static range)
+  wsz = lib.rk_dw3_workspace_bytes(B, h, blk.n_cap) // 4 + 64
+  off = (lib.rk_dw3_planes_bytes(B, h) + 255) // 256 * 256 // 4
+
+  def run(pre):
+    ws = torch.full((wsz,), 3.0, **f)
+    blk.counts[4:5].zero_()
+    if pre:
+      check(lib.rk_split_wz_zt(ptr(W), ptr(Zu), B, h, blk.ref, ptr(ranges), ctypes.byref(pl), ptr(ws), st))
+    check(lib.rk_decode_bwd_dw2(ptr(dO), ptr(Zu), B, h, blk.ref, None, None, ptr(ws), ptr(ws) if pre else None,
+                                ptr(ranges), st))
+    torch.cuda.synchronize()
+    ns = int(blk.counts[4].item())
+    return ns, ws[:off].clone(), ws[off:off + ns * blk.n_cap * h].view(ns, blk.n_cap, h)[:, :n_b].clone()
+  a, b = run(False), run(True)
+  rp, cp = lib.rk_dw3_rows_pad(B), lib.rk_dw3_cols_pad(h)
+  used = 2 * rp * cp * 2 // 4 + 1                     # two 16-bit planes + the scale
+  assert a[0] == b[0] >= 1
+  assert torch.equal(a[1][:used].view(torch.int32), b[1][:used].view(torch.int32))
+  assert torch.equal(a[2], b[2]) and float(a[2].abs().max()) > 0
