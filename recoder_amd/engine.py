@@ -151,6 +151,9 @@ class FusedEngine:
     # dZ contraction and must be finite)
     self.dO = torch.zeros(B_cap * ld_cap, **f)
     self.G_de = torch.empty(n_cap * h0, **f)
+    # MF: [B | the step's user rows as int32] left by the forward's gather for the SparseAdam job of
+    # the user table (rk_gather_rows_amax)
+    self._users32_buf = torch.zeros(B_cap + 1, dtype=torch.int32, device=dev) if self.kind == "mf" else None
     # the fused dW + encoder-backward launch writes G_en in row segments (long item columns)
     self.G_en = torch.empty(n_cap * h0 * self.lib.rk_encode_bwd_segments(B_cap), **f)
     # small gradients in ONE buffer [gb_en (h0) | loss | pad | gb_de (n_cap)] so that a
@@ -367,7 +370,7 @@ class FusedEngine:
       # unbounded activation: the split contractions need max |z| -- the gather publishes it
       # (64 slots, one per workgroup) instead of an rk_amax launch behind it
       if want_rows and (getattr(self, "_users32_buf", None) is None or self._users32_buf.numel() < B + 1):
-        self._users32_buf = torch.zeros(max(B, self.B_cap) + 1, dtype=torch.int32, device=self.device)
+        want_rows = False        # (ensure_capacity has not run for this batch size yet: the plain update)
       check(lib.rk_gather_rows_amax(ptr(m.user_embedding_layer.weight), ptr(users), B, d, self.act,
                                     ptr(self.enc[0]), ptr(self.ranges) if want_amax else None,
                                     ptr(self._users32_buf) if want_rows else None, stream),
