@@ -79,6 +79,7 @@ KERNELS = {"rk_ae_encode_fwd": ["ae_encode_fwd_kernel (+ the W_de[items] split w
            "rk_split_wz": ["split_wz_kernel (W_de[items] and Z plane images, one launch)"],
            "rk_decode_bwd_dw2": ["dw3_kernel<BN,false,true>"],
            "rk_decode_bwd_dw2_encode_bwd": ["dw_encbwd_kernel<BN,HV> (dW tiles || encoder-backward columns)"],
+           "rk_decode_bwd_dw2_dz_reduce": ["dw_reduce_kernel<BN> (dW tiles || the dZ slab reduce)"],
            "rk_decode_bwd_dw2_encode_bwd_colsum": ["dw_encbwd_kernel<BN,HV> (dW tiles || dO column sums || "
                                                    "encoder-backward columns)"]}
 
@@ -172,7 +173,7 @@ def entry_work(entry, B, h0, n_b, nnz, n_items, cfg):
   if entry in ENTRIES:
     return algorithmic_work(entry, B, h0, n_b, nnz, n_items, bool(cfg["sparse"]))
   if entry in ("rk_decode_bwd_dw3", "rk_decode_bwd_dw2", "rk_decode_bwd_dw2_encode_bwd",
-               "rk_decode_bwd_dw2_encode_bwd_colsum"):
+               "rk_decode_bwd_dw2_encode_bwd_colsum", "rk_decode_bwd_dw2_dz_reduce"):
     return "mfma", 2.0 * B * h0 * n_b / 1e12, "TFLOP/s"
   if entry in ("rk_decode_loss_planes", "rk_decode_bwd_dz_planes"):    # the plane kernels outside the fused form
     return "mfma", 2.0 * B * h0 * n_b / 1e12, "TFLOP/s"

@@ -291,6 +291,15 @@ int rk_decode_bwd_dw2_encode_bwd(const float *dO, const float *Z /* nullable wit
                                  const void *zt_planes /* nullable */, const int32_t *ranges /* nullable */,
                                  int32_t row_off, const float *dZ0pre, float *G_en,
                                  float *gb_en /* nullable */, void *stream);
+/* rk_decode_bwd_dw2 (G_de == NULL: the K slabs stay in `workspace`) and rk_decode_dz_reduce (the column-
+ * tile slabs rk_decode_loss_dz_planes left in dz_workspace -> dZ, * act'(Zact) if given) in ONE launch:
+ * MatrixFactorization steps, where nothing between the decode and the Adam sweep reads dZ
+ * (nn.py:344-362: the user rows' gradient goes straight to the optimizer). */
+int rk_decode_bwd_dw2_dz_reduce(const float *dO, const float *Z /* nullable with zt_planes */, int32_t B,
+                                int32_t h, const rk_block_t *tgt, void *workspace,
+                                const void *zt_planes /* nullable */, const int32_t *ranges /* nullable */,
+                                const float *dz_workspace, const float *Zact /* nullable */, int32_t act,
+                                float *dZ, void *stream);
 /* the same launch with the decoder bias gradient gb_de[c] = sum_r dO[r][c] as a third workgroup range
  * (multinomial loss: dO comes from rk_mnll_finish, no decode epilogue has summed its columns) --
  * the rk_colsum launch of those steps */

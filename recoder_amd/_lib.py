@@ -159,6 +159,7 @@ SIGNATURES = {
   "rk_enc_probe": (None, [_P]),
   "rk_dw_encode_bwd_fused_ok": (c_int32, [c_int32, c_int32]),
   "rk_decode_bwd_dw2_encode_bwd": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, c_int32, _P, _P, _P, _P]),
+  "rk_decode_bwd_dw2_dz_reduce": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, _P, _P, c_int32, _P, _P]),
   "rk_decode_bwd_dw2_encode_bwd_colsum": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, c_int32, _P, _P,
                                                     _P, _P, _P]),
   "rk_decode_dz_fused_ok": (c_int32, [c_int32, c_int32, c_int32, c_int32]),

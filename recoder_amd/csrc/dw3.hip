@@ -29,6 +29,7 @@
 #include "common.h"
 #include "encoder_bwd.h"
 #include "planes.h"
+#include "splitk_reduce.h"
 
 namespace {
 
@@ -346,6 +347,19 @@ __global__ __launch_bounds__(512) void dw3_kernel(Dw3P p) {
   dw3_body<BN, PLAIN, PAIRS>(p, (int)blockIdx.x);
 }
 
+// dW (fp16 pairs) || the dZ slab reduce in ONE launch (MatrixFactorization steps: nothing between the
+// decode and the Adam sweep reads dZ, so its reduce need not be a link of the chain): the first n_dw
+// workgroups run the dW tiles, the others rkred::body (512 threads either way)
+template <int BN>
+__global__ __launch_bounds__(512) void dw_reduce_kernel(Dw3P p, int n_dw, rkred::Args r) {
+  if ((int)blockIdx.x < n_dw) {
+    dw3_body<BN, false, true>(p, (int)blockIdx.x);
+    return;
+  }
+  __shared__ float4 part[rkred::RED_W - 1][64];
+  rkred::body(r, (int)blockIdx.x - n_dw, part);
+}
+
 // dW (fp16 pairs) || encoder backward in ONE launch: the first n_dw workgroups run the dW tiles, the
 // others the encoder backward's columns (encoder_bwd.h: a wave per column, 4 per workgroup -- waves
 // 4 .. 7 of those workgroups leave at once).  Both need only what the launches in front of them left
@@ -489,7 +503,8 @@ struct EncBwdArgs {          // the encoder backward riding on the dW launch (rk
 
 static int dw_impl(const float *dO, const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
                    float *G_de, float *gb_de, void *workspace, const void *zt_planes, bool pairs,
-                   const int32_t *ranges, void *stream_, const EncBwdArgs *enc = nullptr) {
+                   const int32_t *ranges, void *stream_, const EncBwdArgs *enc = nullptr,
+                   const rkred::Args *red = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(h > 0 && h % 4 == 0, "h must be a multiple of 4");
   RK_REQUIRE(workspace != nullptr && (((uintptr_t)workspace) & 255) == 0, "workspace: 256-byte aligned");
@@ -550,6 +565,12 @@ static int dw_impl(const float *dO, const float *Z, int32_t B, int32_t h, const 
     if (bn == 128) { if (hv == 1) LAUNCH(128, 1); else if (hv == 2) LAUNCH(128, 2); else LAUNCH(128, 4); }
     else { if (hv == 1) LAUNCH(256, 1); else if (hv == 2) LAUNCH(256, 2); else LAUNCH(256, 4); }
 #undef LAUNCH
+  } else if (pairs && red) {
+    const int n_red = rkred::blocks(red->M, red->N);
+    if (bn == 128)
+      RK_LAUNCH((dw_reduce_kernel<128>), dim3((unsigned)grid + n_red), dim3(512), 0, stream, p, (int)grid, *red);
+    else
+      RK_LAUNCH((dw_reduce_kernel<256>), dim3((unsigned)grid + n_red), dim3(512), 0, stream, p, (int)grid, *red);
   } else if (pairs) {
     if (bn == 128)
       RK_LAUNCH((dw3_kernel<128, false, true>), dim3((unsigned)grid), dim3(512), 0, stream, p);
@@ -609,6 +630,19 @@ extern "C" int rk_decode_bwd_dw2_encode_bwd(const float *dO, const float *Z, int
              "block was built without the transposed bitmap / prefix index");
   const EncBwdArgs enc = {row_off, dZ0pre, G_en, gb_en};
   return dw_impl(dO, Z, B, h, tgt, nullptr, nullptr, workspace, zt_planes, true, ranges, stream_, &enc);
+}
+
+// rk_decode_bwd_dw2 (slabs stay in the workspace) || rk_decode_dz_reduce in ONE launch
+extern "C" int rk_decode_bwd_dw2_dz_reduce(const float *dO, const float *Z, int32_t B, int32_t h,
+                                           const rk_block_t *tgt, void *workspace, const void *zt_planes,
+                                           const int32_t *ranges, const float *dz_workspace,
+                                           const float *Zact, int32_t act, float *dZ, void *stream_) {
+  RK_REQUIRE(rk_dw_pairs() && !rk_gemm_plain_bf16(), "the fused reduce rides on the fp16-pair dW");
+  RK_REQUIRE(dz_workspace != nullptr && dZ != nullptr &&
+             ((((uintptr_t)dz_workspace) | ((uintptr_t)dZ)) & 15) == 0, "dz_workspace, dZ: 16-byte aligned");
+  if (B == 0) return 0;
+  const rkred::Args red = {dz_workspace, B, h, tgt->counts, 128, rk_cdiv(tgt->n_cap, 128), Zact, act, dZ};
+  return dw_impl(dO, Z, B, h, tgt, nullptr, nullptr, workspace, zt_planes, true, ranges, stream_, nullptr, &red);
 }
 
 // ... and the decoder bias gradient gb_de[c] = sum_r dO[r][c] (multinomial loss) as a third

@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "splitk_reduce.h"
 #include "encoder_bwd.h"
 
 // rk_gemm_probe(buffer): when set, every GEMM workgroup records wall_clock64() at entry, after
@@ -780,58 +781,14 @@ __global__ __launch_bounds__(256) void dw_encode_bwd_kernel(
                            seg_stride);
 }
 
-// ws[split][M][N] -> out[M][N] (fixed split order), optional * act'(Zact)
-constexpr int RED_W = 8;       // waves per workgroup: each sums 1/RED_W of the splits
+// ws[split][M][N] -> out[M][N] (fixed split order), optional * act'(Zact): body in splitk_reduce.h
+constexpr int RED_W = rkred::RED_W;
 __global__ __launch_bounds__(RED_W * 64) void splitk_reduce_kernel(
     const float *__restrict__ ws, int M, int N, const int32_t *__restrict__ Kdev, int tile_k,
     int max_splits, const float *__restrict__ Zact, int act, float *__restrict__ out) {
-  // 64 float4 outputs per workgroup; the waves each sum a contiguous share of the splits (all of
-  // its loads in flight at once: the slabs come from the Infinity Cache / HBM, and the launch is as
-  // long as one wave's chain of load batches), combined in fixed order through LDS
   __shared__ float4 part[RED_W - 1][64];
-  const int K = *Kdev;
-  // (tile_k > 0: one slab per tile_k-wide column tile of the decode -- the fused dZ of decode16.hip)
-  const int kchunk = tile_k > 0 ? tile_k : ((K + max_splits - 1) / max_splits + 31) & ~31;   // as the GEMM derives it
-  int ns = (K + kchunk - 1) / kchunk;
-  if (ns > max_splits) ns = max_splits;
-  const int64_t tot4 = ((int64_t)M * N) >> 2;      // M*N is a multiple of 4 (N = h)
-  const float4 *ws4 = reinterpret_cast<const float4 *>(ws);
-  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
-  const int per = (ns + RED_W - 1) / RED_W;
-  const int z1 = min(ns, (q + 1) * per);
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  // (the activation values of the fused act' are fetched with the slabs, not behind the barrier)
-  float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (Zact && q == 0 && i < tot4) y = reinterpret_cast<const float4 *>(Zact)[i];
-  if (i < tot4) {
-    int z = q * per;
-    for (; z + 8 <= z1; z += 8) {
-      float4 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = ws4[(int64_t)(z + u) * tot4 + i];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
-    }
-    for (; z < z1; ++z) {
-      const float4 v = ws4[(int64_t)z * tot4 + i];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-  }
-  if (q > 0) part[q - 1][lane] = s;
-  __syncthreads();
-  if (q == 0 && i < tot4) {
-#pragma unroll
-    for (int w = 0; w < RED_W - 1; ++w) {
-      const float4 a = part[w][lane];
-      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
-    }
-    if (Zact) {
-      s.x *= rk_act_dy(y.x, act); s.y *= rk_act_dy(y.y, act);
-      s.z *= rk_act_dy(y.z, act); s.w *= rk_act_dy(y.w, act);
-    }
-    reinterpret_cast<float4 *>(out)[i] = s;
-  }
+  const rkred::Args a = {ws, M, N, Kdev, tile_k, max_splits, Zact, act, out};
+  rkred::body(a, (int)blockIdx.x, part);
 }
 
 // out[i] = sum_z ws[z][i] over the live rows of a [splits][M_cap][N] slab stack (dW split-K)

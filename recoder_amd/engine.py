@@ -635,7 +635,16 @@ class FusedEngine:
       else:
         check(lib.rk_colsum(ptr(self.gb_part), cdiv(B, self.row_tile), tb.n_cap, 0, ptr(tb.counts),
                             ptr(self.gb_de), stream), "rk_colsum")
-      self._dw(z, B, tb, None, dw_stream, keep_slabs)
+      # MatrixFactorization: nothing between the decode and the Adam sweep reads dZ (the user rows'
+      # gradient), so the reduce of the decode launch's dZ partials rides on the dW launch
+      red = None
+      if (self.kind != "ae" and getattr(self, "_dz_in_ws", False) and keep_slabs and dw_side is None and
+          ip is None and self.lib.rk_dw_pairs() and os.environ.get("RK_ENTRY_DW_REDUCE", "1") != "0"):
+        red = (self.ws, None if self.drop_active else self.enc[0], self.dbott)
+      self._dw(z, B, tb, None, dw_stream, keep_slabs, red=red)
+      if red is not None:
+        self._dz_in_ws = False
+        self._dz_done = True
     if dw_side is not None:
       self._dw_ev[1].record(dw_side)
     n_b_host = self.allreduce.n_b(blk) if self.allreduce is not None else None
@@ -651,7 +660,9 @@ class FusedEngine:
       dz = self.ddec[self.nl - 1]
     # act' folded into the split-K reduce (MF without dropout: the gathered rows ARE the decoder's input)
     fuse_act = (simple or (self.kind != "ae" and not self.drop_active)) and ip is None
-    if getattr(self, "_dz_in_ws", False):
+    if getattr(self, "_dz_done", False):
+      self._dz_done = False            # (summed by the dW launch: rk_decode_bwd_dw2_dz_reduce)
+    elif getattr(self, "_dz_in_ws", False):
       check(lib.rk_decode_dz_reduce(ptr(self.ws), B, h0, tb.ref, ptr(self.enc[0]) if fuse_act else None,
                                     self.act, ptr(dz), stream), "rk_decode_dz_reduce")
       self._dz_in_ws = False
@@ -744,7 +755,7 @@ class FusedEngine:
     self._apply_updates(blk, row_off, B, stream, "all", tgt=tb)
     return loss
 
-  def _dw(self, z, B, blk, gb_de, stream, keep_slabs=False):
+  def _dw(self, z, B, blk, gb_de, stream, keep_slabs=False, red=None):
     """G_de = dO^T . z (+ gb_de = colsum(dO) if asked): the bf16-pipe kernel (csrc/dw3.hip) unless
     RK_GEMM_PREC=f32 keeps the contractions on the fp32 MFMA.  keep_slabs: leave the K slabs
     unsummed in the dW workspace of its own (the dZ product that follows reuses `ws`) for the Adam
@@ -761,8 +772,15 @@ class FusedEngine:
       if self.lib.rk_dw_pairs():
         # (Z^T pair planes already at the head of this workspace: rk_split_wz_zt of this step's decode)
         zt = ptr(ws) if getattr(self, "_zt_ready", None) == ws.data_ptr() else None
-        check(self.lib.rk_decode_bwd_dw2(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(G), ptr(gb_de), ptr(ws),
-                                         zt, ptr(self.ranges), stream), "rk_decode_bwd_dw2")
+        if red is not None:
+          # red = (the decode launch's dZ partials, Zact or None, dZ): summed by extra workgroups here
+          assert G is None and gb_de is None
+          check(self.lib.rk_decode_bwd_dw2_dz_reduce(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(ws), zt,
+                                                     ptr(self.ranges), ptr(red[0]), ptr(red[1]), self.act,
+                                                     ptr(red[2]), stream), "rk_decode_bwd_dw2_dz_reduce")
+        else:
+          check(self.lib.rk_decode_bwd_dw2(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(G), ptr(gb_de), ptr(ws),
+                                           zt, ptr(self.ranges), stream), "rk_decode_bwd_dw2")
       else:
         check(self.lib.rk_decode_bwd_dw3(ptr(self.dO), ptr(z), B, h0, blk.ref, ptr(G), ptr(gb_de), ptr(ws),
                                          None, stream), "rk_decode_bwd_dw3")

@@ -395,3 +395,49 @@ def test_split_wz_zt_leaves_the_planes_dw2_would_make(B, h, n_items, scale):
   assert a[0] == b[0] >= 1
   assert torch.equal(a[1][:used].view(torch.int32), b[1][:used].view(torch.int32))
   assert torch.equal(a[2], b[2]) and float(a[2].abs().max()) > 0
+
+
+@pytest.mark.parametrize("B,h,n_items,act", [(500, 128, 3000, 0), (130, 64, 900, 1), (33, 20, 400, 3)])
+def test_dw_and_dz_reduce_in_one_launch_equal_the_two_launches(B, h, n_items, act):
+  """rk_decode_bwd_dw2_dz_reduce (dw3.hip dw_reduce_kernel: dW tiles || the slab reduce of the fused
+  decode's dZ partials) against rk_decode_bwd_dw2 + rk_decode_dz_reduce: the same workgroup bodies, so
+  the K slabs of dW and dZ agree bit for bit (with and without act' folded in)."""
+  lib, blk, W, bias, Z, ranges, pl, buf = _setup(B, h, max(B, 600), n_items, 14, seed=5 * B + h)
+  if lib.rk_split_zt_ok() != 1:
+    pytest.skip("dW is not on fp16 pairs")
+  st = current_stream()
+  f = dict(dtype=torch.float32, device=Z.device)
+  n_b, nnz, ld, _ = blk.counts_host()
+  g = torch.Generator(device=Z.device)
+  g.manual_seed(B + 1)
+  dO = torch.zeros(B * blk.ld_cap, **f)
+  dO[:B * ld].view(B, ld)[:, :n_b] = torch.randn(B, n_b, generator=g, **f) * 1e-3
+  blk.counts[8:72].zero_()
+  blk.counts[8:9].copy_(dO.abs().max().reshape(1).view(torch.int32))
+  Zb = Z[:B].contiguous()
+  n_tiles = -(-blk.n_cap // 128)
+  dz_ws = torch.randn(n_tiles * B * h, generator=g, **f)          # one slab per 128-item column tile
+  wsz = lib.rk_dw3_workspace_bytes(B, h, blk.n_cap) // 4 + 64
+  off = (lib.rk_dw3_planes_bytes(B, h) + 255) // 256 * 256 // 4
+
+  def run(fused, zact):
+    ws = torch.zeros(wsz, **f)
+    dZ = torch.full((B * h,), 9.0, **f)
+    blk.counts[4:5].zero_()
+    if fused:
+      check(lib.rk_decode_bwd_dw2_dz_reduce(ptr(dO), ptr(Zb), B, h, blk.ref, ptr(ws), None, ptr(ranges),
+                                            ptr(dz_ws), ptr(Zb) if zact else None, act, ptr(dZ), st))
+    else:
+      check(lib.rk_decode_bwd_dw2(ptr(dO), ptr(Zb), B, h, blk.ref, None, None, ptr(ws), None, ptr(ranges), st))
+      check(lib.rk_decode_dz_reduce(ptr(dz_ws), B, h, blk.ref, ptr(Zb) if zact else None, act, ptr(dZ), st))
+    torch.cuda.synchronize()
+    ns = int(blk.counts[4].item())
+    return ns, ws[off:off + ns * blk.n_cap * h].view(ns, blk.n_cap, h)[:, :n_b].clone(), dZ
+  for zact in (False, True):
+    a, b = run(False, zact), run(True, zact)
+    assert a[0] == b[0] >= 1
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    live = -(-n_b // 128)
+    want = dz_ws.view(n_tiles, B * h)[:live].double().sum(0)
+    if not zact:
+      assert torch.allclose(a[2].double(), want, rtol=1e-5, atol=1e-5)
