@@ -495,11 +495,22 @@ class Recoder(object):
   def _enable_item_parallel(self, ip, train_dataset):
     from .parallel import ItemParallel
     full = train_dataset.interactions_matrix
-    ip.user_norm_dev = torch.from_numpy(ItemParallel.user_norms(full)).to(self.device)
-    ip.user_tsum_dev = torch.from_numpy(ItemParallel.user_target_sums(full)).to(self.device)
+    dev = getattr(train_dataset, "_dev", None)
+    on_device = dev is not None and (full is None or dev.implicit)
+    if on_device:
+      # the matrix is resident in HBM (a DeviceDataset has no host copy at all): the row statistics
+      # and this rank's column shard are taken there (implicit feedback: exactly the host's numbers)
+      ip.user_norm_dev = ItemParallel.user_norms_dev(dev)
+      ip.user_tsum_dev = ItemParallel.user_target_sums_dev(dev)
+    else:
+      ip.user_norm_dev = torch.from_numpy(ItemParallel.user_norms(full)).to(self.device)
+      ip.user_tsum_dev = torch.from_numpy(ItemParallel.user_target_sums(full)).to(self.device)
     ip.prepare(self.device)
     self._engine().item_parallel = ip
     self._ip = ip
+    if on_device:
+      from .data import DeviceDataset
+      return DeviceDataset(ip.shard_device_csr(dev))
     return RecommendationDataset(ip.shard_csr(full))
 
   def _make_block(self, dcsr, S, negative_sampling, train=False):

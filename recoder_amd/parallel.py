@@ -262,6 +262,43 @@ class ItemParallel:
     np.cumsum(counts, out=indptr[1:])
     return sp.csr_matrix((csr.data[keep], csr.indices[keep], indptr), shape=csr.shape)
 
+  # ---- the same three for a matrix that is resident in HBM (data.DeviceDataset, or a host dataset
+  # after dataset.device_csr()): torch ops on the device arrays, no host pass over the matrix
+  @staticmethod
+  def _row_ids(dcsr):
+    n = dcsr.shape[0]
+    return torch.repeat_interleave(torch.arange(n, device=dcsr.device), dcsr.indptr[1:] - dcsr.indptr[:-1])
+
+  def shard_device_csr(self, dcsr):
+    """shard_csr on the device: every row, only the owned columns (global ids, same shape)."""
+    from .device import DeviceCSR
+    n, nnz = dcsr.shape[0], dcsr.nnz
+    idx = dcsr.indices[:nnz]
+    keep = (idx % self.world) == self.rank
+    counts = torch.bincount(self._row_ids(dcsr)[keep], minlength=n)
+    indptr = torch.zeros(n + 1, dtype=torch.int64, device=dcsr.device)
+    torch.cumsum(counts, 0, out=indptr[1:])
+    data = None if dcsr.data is None else dcsr.data[:nnz][keep]
+    return DeviceCSR.from_arrays(dcsr.shape, indptr, idx[keep], data, dcsr.device, check=False)
+
+  @staticmethod
+  def _row_sums_dev(dcsr, square):
+    deg = (dcsr.indptr[1:] - dcsr.indptr[:-1]).to(torch.float64)
+    if dcsr.data is None:                      # implicit feedback: every stored value is 1.0
+      return deg
+    v = dcsr.data[:dcsr.nnz].to(torch.float64)
+    out = torch.zeros(dcsr.shape[0], dtype=torch.float64, device=dcsr.device)
+    return out.index_add_(0, ItemParallel._row_ids(dcsr), v * v if square else v)
+
+  @staticmethod
+  def user_norms_dev(dcsr):
+    """user_norms on the device (fp64 accumulation, fp32 result)."""
+    return ItemParallel._row_sums_dev(dcsr, True).sqrt().to(torch.float32)
+
+  @staticmethod
+  def user_target_sums_dev(dcsr):
+    return ItemParallel._row_sums_dev(dcsr, False).to(torch.float32)
+
   @staticmethod
   def user_norms(csr):
     """L2 norm of every user's WHOLE row (F.normalize's denominator, nn.py:235), fp32."""

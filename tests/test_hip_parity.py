@@ -987,7 +987,14 @@ def test_item_parallel_virtual_ranks_random_shapes(seed):
   def run(r):
     try:
       torch.cuda.set_device(0)
-      reps[r][1].train(RecommendationDataset(csr), batch_size=b, **kw)
+      ds_r = RecommendationDataset(csr)
+      if seed % 3 == 1:
+        # the matrix only exists in HBM: row statistics and the column shard are taken on the device
+        from recoder_amd.data import DeviceDataset
+        ds_r = DeviceDataset(ds_r.device_csr())
+      elif seed % 3 == 2:
+        ds_r.device_csr()              # host dataset, already resident
+      reps[r][1].train(ds_r, batch_size=b, **kw)
     except BaseException as e:       # noqa: B036 -- release the other threads
       errs.append(e)
       vr.barrier.abort()
