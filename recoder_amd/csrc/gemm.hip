@@ -815,7 +815,7 @@ __global__ __launch_bounds__(256) void mnll_finish_kernel(float *dO, rk_block_t 
                                                           const float *ext_max, const float *ext_logsum,
                                                           const float *ext_tsum) {
   __shared__ float red[4];
-  __shared__ float bc[2];
+  __shared__ float red2[8];
   const int r = blockIdx.x, row = row_off + r;
   const int n = b.counts[0], ld = b.counts[2];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -825,6 +825,15 @@ __global__ __launch_bounds__(256) void mnll_finish_kernel(float *dO, rk_block_t 
   // 4 columns lie in one bitmap word.  Columns >= n of the last quad are padding: masked.
   const float4 *orow4 = reinterpret_cast<const float4 *>(orow);
   const int n4 = (n + 3) >> 2;
+  // the sparse part's operands of this thread's FIRST stored entry (rows of up to 256 entries need no
+  // more) are fetched now, in front of the statistics pass: indptr -> column -> logit are three
+  // dependent round trips that used to start behind it
+  const int beg = b.indptr[row], end = b.indptr[row + 1];
+  float t0 = 0.f, x0 = 0.f;
+  if (beg + tid < end) {
+    t0 = implicit ? 1.0f : b.vals[beg + tid];
+    x0 = orow[b.cols[beg + tid]];
+  }
   float mx = -INFINITY, lsum;
   if (ext_max) {
     mx = ext_max[r];
@@ -856,9 +865,13 @@ __global__ __launch_bounds__(256) void mnll_finish_kernel(float *dO, rk_block_t 
     __syncthreads();
   }
   // sparse part: loss = -sum_t t*lsm ; sum_g = sum_t (-t*inv_B)
-  const int beg = b.indptr[row], end = b.indptr[row + 1];
   float lp = 0.f, sg = 0.f;
-  for (int j = beg + tid; j < end; j += 256) {
+  if (beg + tid < end) {
+    const float lsm = (x0 - mx) - lsum;
+    lp += -t0 * lsm;
+    sg += -t0 * inv_B;
+  }
+  for (int j = beg + tid + 256; j < end; j += 256) {
     const float t = implicit ? 1.0f : b.vals[j];
     const float lsm = (orow[b.cols[j]] - mx) - lsum;
     lp += -t * lsm;
@@ -866,15 +879,11 @@ __global__ __launch_bounds__(256) void mnll_finish_kernel(float *dO, rk_block_t 
   }
   lp = rk_wave_sum(lp);
   sg = rk_wave_sum(sg);
-  if (lane == 0) red[wid] = lp;
+  // (both block sums through one barrier pair: red2 = 8 floats)
+  if (lane == 0) { red2[wid] = lp; red2[4 + wid] = sg; }
   __syncthreads();
-  if (tid == 0) loss_part[r] = (red[0] + red[1]) + (red[2] + red[3]);
-  __syncthreads();
-  if (lane == 0) red[wid] = sg;
-  __syncthreads();
-  if (tid == 0) bc[0] = (red[0] + red[1]) + (red[2] + red[3]);
-  __syncthreads();
-  const float sum_g = ext_tsum ? -ext_tsum[r] * inv_B : bc[0];
+  if (tid == 0) loss_part[r] = (red2[0] + red2[1]) + (red2[2] + red2[3]);
+  const float sum_g = ext_tsum ? -ext_tsum[r] * inv_B : (red2[4] + red2[5]) + (red2[6] + red2[7]);
   float gmax = 0.f;
   // dense part: dO = g - softmax * sum_g,  g = -t*inv_B at stored positions
   const uint32_t *brow = b.bits_rc + (int64_t)row * b.ldw_rc;
