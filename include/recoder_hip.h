@@ -436,7 +436,8 @@ int rk_linear_bwd(float *dY, const float *Y, const float *X, const float *W,
                   int32_t B, int32_t N, int32_t K, int32_t w_transposed,
                   int32_t act, float *dX /* nullable */, float *dW,
                   int32_t dw_accumulate, float *db, void *stream);
-/* tuning switch (default off, RK_LINEAR_PAIR=1): rk_linear_bwd's dX and dW products as ONE launch */
+/* tuning switch (default on, RK_LINEAR_PAIR=0 / rk_linear_pair(0): off): rk_linear_bwd's dX and dW
+ * products as ONE launch of two workgroup ranges (same tiles, same sums as the two launches) */
 void rk_linear_pair(int32_t on);
 /* rk_linear_bwd whose dX leaves multiplied by act'(dx_act_y[B,K]) (nullable): the backward of a
  * stack's FIRST Linear layer hands its gradient to the embedding layer's activation -- the

@@ -1456,10 +1456,11 @@ static int linear_bwd_impl(float *dY, const float *Y, const float *X, const floa
       if (!w_transposed) { g.A = dY; g.lda = N; g.B = X; g.ldb = K; g.M = N; g.N = K; g.ldc = K; }   // dW[N,K] = dY^T . X
       else               { g.A = X; g.lda = K; g.B = dY; g.ldb = N; g.M = K; g.N = N; g.ldc = N; }   // dWst[K,N] = X^T . dY
     }
-    // both read dYpre only and write disjoint outputs, but as ONE launch (rk_small_gemm_pair,
-    // RK_LINEAR_PAIR=1) they take 15.5 us against 5.3 + 7.4 one behind the other at 500 x 200 x 200
-    // (tools/probes/linear_bwd_probe.py: 21.1 vs 17.7 us per call; C3 0.292 vs 0.274 ms per step)
-    if (g_linear_pair < 0) { const char *e = getenv("RK_LINEAR_PAIR"); g_linear_pair = (e && atoi(e) == 1) ? 1 : 0; }
+    // both read dYpre only and write disjoint outputs: ONE launch of two workgroup ranges
+    // (rk_small_gemm_pair: 7.2 us against 6.6 + 8.6 one behind the other at 500 x 200 x 200,
+    // tools/probes/linear_bwd_probe.py 13.1 vs 17.7 us per call with the act' pass; C3 0.251 vs 0.264 ms
+    // per step).  RK_LINEAR_PAIR=0 / rk_linear_pair(0): two launches (same tiles, same sums)
+    if (g_linear_pair < 0) { const char *e = getenv("RK_LINEAR_PAIR"); g_linear_pair = (e && atoi(e) == 0) ? 0 : 1; }
     if (dX && dW && g_linear_pair) return rk_small_gemm_pair(&gx, &gw, stream_);
     if (dX) { rc = rk_small_gemm(&gx, stream_); if (rc) return rc; }
     if (dW) { rc = rk_small_gemm(&gw, stream_); if (rc) return rc; }

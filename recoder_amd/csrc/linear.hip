@@ -183,6 +183,17 @@ __global__ __launch_bounds__(256) void small_gemm_pair_kernel(rk_small_gemm_t g1
                                                               int tiles_n2) {
   constexpr int SM1 = sg_smem_floats<AMODE, BMODE>(), SM2 = sg_smem_floats<1, 1>();
   __shared__ __attribute__((aligned(16))) float smem[SM1 > SM2 ? SM1 : SM2];
+  // (tiles1 < 0: g2's tiles come first in the grid, RK_PAIR_ORDER=1 -- the order makes no difference
+  // (13.09 vs 13.12 us per rk_linear_bwd call), but the FORM does: written as a single if / else over the
+  // two inlined bodies this kernel took the SUM of their times (16.0 us in rocprofv3 against 6.6 + 8.6 for
+  // the two launches) instead of their maximum (7.2 us as compiled from this source); if a toolchain
+  // change brings that back, tools/probes/linear_bwd_probe.py shows it and RK_LINEAR_PAIR=0 avoids it)
+  if (tiles1 < 0) {
+    const int t2 = -tiles1;
+    if ((int)blockIdx.x < t2) small_gemm_tile<1, 1>(g2, (int)blockIdx.x, tiles_n2, 0, 0, smem);
+    else small_gemm_tile<AMODE, BMODE>(g1, (int)blockIdx.x - t2, tiles_n1, vec_a1, vec_b1, smem);
+    return;
+  }
   if ((int)blockIdx.x < tiles1) small_gemm_tile<AMODE, BMODE>(g1, (int)blockIdx.x, tiles_n1, vec_a1, vec_b1, smem);
   else small_gemm_tile<1, 1>(g2, (int)blockIdx.x - tiles1, tiles_n2, 0, 0, smem);
 }
@@ -266,10 +277,12 @@ int rk_small_gemm_pair(const rk_small_gemm_t *g1, const rk_small_gemm_t *g2, voi
   const int t1 = rk_cdiv(g1->M, 32) * tn1, t2 = rk_cdiv(g2->M, 32) * tn2;
   const int va = (al16(g1->A) && g1->lda % 4 == 0 && g1->K % 4 == 0) ? 1 : 0;
   const int vb = (g1->bmode == 0 && al16(g1->B) && g1->ldb % 4 == 0 && g1->K % 4 == 0) ? 1 : 0;
+  static const int swap = [] { const char *e = getenv("RK_PAIR_ORDER"); return (e && atoi(e) == 1) ? 1 : 0; }();
+  const int t1a = swap ? -t2 : t1;
   if (g1->bmode == 0)
-    RK_LAUNCH((small_gemm_pair_kernel<0, 0>), dim3(t1 + t2), dim3(256), 0, stream, *g1, tn1, va, vb, t1, *g2, tn2);
+    RK_LAUNCH((small_gemm_pair_kernel<0, 0>), dim3(t1 + t2), dim3(256), 0, stream, *g1, tn1, va, vb, t1a, *g2, tn2);
   else
-    RK_LAUNCH((small_gemm_pair_kernel<0, 1>), dim3(t1 + t2), dim3(256), 0, stream, *g1, tn1, va, vb, t1, *g2, tn2);
+    RK_LAUNCH((small_gemm_pair_kernel<0, 1>), dim3(t1 + t2), dim3(256), 0, stream, *g1, tn1, va, vb, t1a, *g2, tn2);
   RK_CHECK_LAUNCH("small_gemm_pair");
   return 0;
 }

@@ -1647,7 +1647,7 @@ def test_linear_layer_entry_points_match_torch(B, N, K, wt, act, acc, pair):
                                ptr(db2), ptr(Xact), st), "rk_linear_bwd_dact")
   check(lib.rk_act_grad(ptr(dX), ptr(Xact), B * K, a, st), "rk_act_grad")
   torch.cuda.synchronize()
-  lib.rk_linear_pair(0)
+  lib.rk_linear_pair(1)          # (the default)
   assert torch.equal(dX2, dX) and torch.equal(dW2, dWd) and torch.equal(db2, db) and torch.equal(dY2, dY)
 
 
