@@ -187,7 +187,7 @@ def entry_work(entry, B, h0, n_b, nnz, n_items, cfg):
     return "hbm", (3.0 * n_b + 2.0 * B) * h0 * 4 / 1e9, "GB/s"
   if entry == "rk_mnll_finish":                 # two passes over the B x n_b logits, one write
     return "hbm", 3.0 * B * n_b * 4 / 1e9, "GB/s"
-  if entry in ("rk_linear_fwd", "rk_linear_bwd", "rk_linear_bwd_dact") and cfg["kind"] == "ae" and \
+  if entry in ("rk_linear_fwd", "rk_linear_bwd", "rk_linear_bwd_dact", "rk_linear_bwd_pre") and cfg["kind"] == "ae" and \
       len(cfg["hidden_layers"]) > 1:
     hh = cfg["hidden_layers"]
     fl = 2.0 * B * hh[0] * hh[1] * (1 if entry == "rk_linear_fwd" else 2)

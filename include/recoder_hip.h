@@ -436,6 +436,13 @@ int rk_linear_bwd(float *dY, const float *Y, const float *X, const float *W,
                   int32_t B, int32_t N, int32_t K, int32_t w_transposed,
                   int32_t act, float *dX /* nullable */, float *dW,
                   int32_t dw_accumulate, float *db, void *stream);
+/* rk_linear_bwd for a dY that already IS dYpre = dY * act'(Y) (its producer multiplied act' in: the slab
+ * reduce of the decode's dZ, or the dX epilogue of the layer behind it -- dx_act_y): no pass over it;
+ * dX (* act'(dx_act_y) if given), dW and db = colsum(dYpre) in ONE launch where the small kernel
+ * applies (else rk_colsum + the two products).  `act` is the derivative dx_act_y is taken with. */
+int rk_linear_bwd_pre(const float *dYpre, const float *X, const float *W, int32_t B, int32_t N, int32_t K,
+                      int32_t w_transposed, int32_t act, float *dX /* nullable */, float *dW,
+                      int32_t dw_accumulate, float *db, const float *dx_act_y /* nullable */, void *stream);
 /* tuning switch (default on, RK_LINEAR_PAIR=0 / rk_linear_pair(0): off): rk_linear_bwd's dX and dW
  * products as ONE launch of two workgroup ranges (same tiles, same sums as the two launches) */
 void rk_linear_pair(int32_t on);

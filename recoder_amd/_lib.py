@@ -182,6 +182,8 @@ SIGNATURES = {
   "rk_linear_bwd": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P,
                               c_int32, _P, _P]),
   "rk_linear_pair": (None, [c_int32]),
+  "rk_linear_bwd_pre": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P, c_int32, _P, _P,
+                                  _P]),
   "rk_linear_bwd_dact": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P,
                                    c_int32, _P, _P, _P]),
   "rk_act_grad": (c_int32, [_P, _P, c_int64, c_int32, _P]),

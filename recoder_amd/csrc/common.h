@@ -70,6 +70,8 @@ struct rk_small_gemm_t {
 bool rk_small_gemm_fits(int M, int N, int K);
 int rk_small_gemm(const rk_small_gemm_t *g, void *stream);
 int rk_small_gemm_pair(const rk_small_gemm_t *g1, const rk_small_gemm_t *g2, void *stream);
+int rk_small_gemm_pair_colsum(const rk_small_gemm_t *g1, const rk_small_gemm_t *g2, const float *cs_X,
+                              int cs_rows, int cs_cols, float *cs_out, void *stream);
 // dY <- dY * act'(Y) in place, db[c] = column sums of the result ([rows, cols] row-major)
 int rk_act_grad_colsum(float *dY, const float *Y, int rows, int cols, int act, float *db, void *stream);
 

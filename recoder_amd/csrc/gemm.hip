@@ -1412,7 +1412,8 @@ extern "C" int rk_linear_fwd(const float *X, const float *W, const float *b, int
 
 static int linear_bwd_impl(float *dY, const float *Y, const float *X, const float *W, int32_t B,
                            int32_t N, int32_t K, int32_t w_transposed, int32_t act, float *dX,
-                           float *dW, int32_t dw_accumulate, float *db, const float *dx_act_y, void *stream_);
+                           float *dW, int32_t dw_accumulate, float *db, const float *dx_act_y, void *stream_,
+                           bool pre = false);
 
 static int g_linear_pair = -1;     // -1: RK_LINEAR_PAIR not read yet
 extern "C" void rk_linear_pair(int32_t on) { g_linear_pair = on ? 1 : 0; }
@@ -1431,13 +1432,33 @@ extern "C" int rk_linear_bwd_dact(float *dY, const float *Y, const float *X, con
   return linear_bwd_impl(dY, Y, X, W, B, N, K, w_transposed, act, dX, dW, dw_accumulate, db, dx_act_y, stream_);
 }
 
+extern "C" int rk_linear_bwd_pre(const float *dYpre, const float *X, const float *W, int32_t B, int32_t N,
+                                 int32_t K, int32_t w_transposed, int32_t act, float *dX, float *dW,
+                                 int32_t dw_accumulate, float *db, const float *dx_act_y, void *stream_) {
+  RK_REQUIRE(dX != nullptr || dx_act_y == nullptr, "dx_act_y needs dX");
+  return linear_bwd_impl(const_cast<float *>(dYpre), nullptr, X, W, B, N, K, w_transposed, act, dX, dW,
+                         dw_accumulate, db, dx_act_y, stream_, true);
+}
+
 static int linear_bwd_impl(float *dY, const float *Y, const float *X, const float *W, int32_t B,
                            int32_t N, int32_t K, int32_t w_transposed, int32_t act, float *dX,
-                           float *dW, int32_t dw_accumulate, float *db, const float *dx_act_y, void *stream_) {
+                           float *dW, int32_t dw_accumulate, float *db, const float *dx_act_y, void *stream_,
+                           bool pre) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B == 0) return 0;
-  int rc = db ? rk_act_grad_colsum(dY, Y, B, N, act, db, stream_)
-              : rk_act_grad(dY, Y, (int64_t)B * N, act, stream_);
+  int rc = 0;
+  const int ldw0 = w_transposed ? N : K;
+  if (g_linear_pair < 0) { const char *e = getenv("RK_LINEAR_PAIR"); g_linear_pair = (e && atoi(e) == 0) ? 0 : 1; }
+  // pre: dY already IS dYpre (its producer multiplied act' in) -- no pass over it; the bias gradient's
+  // column sums ride on the dX / dW launch where that is one launch, else they are an rk_colsum
+  const bool small0 = g_gemm_probe == nullptr && rk_small_gemm_fits(B, K, N) &&
+                      rk_small_gemm_fits(w_transposed ? K : N, w_transposed ? N : K, B);
+  const bool cs_in_pair = pre && db && small0 && dX && dW && g_linear_pair;
+  if (!pre)
+    rc = db ? rk_act_grad_colsum(dY, Y, B, N, act, db, stream_)
+            : rk_act_grad(dY, Y, (int64_t)B * N, act, stream_);
+  else if (db && !cs_in_pair)
+    rc = rk_colsum(dY, B, N, N, nullptr, db, stream_);
   if (rc) return rc;
   const int ldw = w_transposed ? N : K;
   const bool small = g_gemm_probe == nullptr && rk_small_gemm_fits(B, K, N) &&
@@ -1460,7 +1481,7 @@ static int linear_bwd_impl(float *dY, const float *Y, const float *X, const floa
     // (rk_small_gemm_pair: 7.2 us against 6.6 + 8.6 one behind the other at 500 x 200 x 200,
     // tools/probes/linear_bwd_probe.py 13.1 vs 17.7 us per call with the act' pass; C3 0.251 vs 0.264 ms
     // per step).  RK_LINEAR_PAIR=0 / rk_linear_pair(0): two launches (same tiles, same sums)
-    if (g_linear_pair < 0) { const char *e = getenv("RK_LINEAR_PAIR"); g_linear_pair = (e && atoi(e) == 0) ? 0 : 1; }
+    if (cs_in_pair) return rk_small_gemm_pair_colsum(&gx, &gw, dY, B, N, db, stream_);
     if (dX && dW && g_linear_pair) return rk_small_gemm_pair(&gx, &gw, stream_);
     if (dX) { rc = rk_small_gemm(&gx, stream_); if (rc) return rc; }
     if (dW) { rc = rk_small_gemm(&gw, stream_); if (rc) return rc; }

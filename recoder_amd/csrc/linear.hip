@@ -175,14 +175,53 @@ __global__ __launch_bounds__(256) void small_gemm_kernel(rk_small_gemm_t g, int 
   small_gemm_tile<AMODE, BMODE>(g, (int)blockIdx.x, tiles_n, vec_a, vec_b, smem);
 }
 
+// out[c] = sum_r X[r * cols + c] for 32 columns per workgroup (256 threads: 32 columns x 8 row
+// slices, 4 accumulators per thread, combined in a fixed order) -- the bias gradient of a Linear
+// layer whose dYpre is already complete, as a third workgroup range of its dX / dW launch
+struct SgColsum {
+  const float *X;
+  int rows, cols;
+  float *out;
+};
+__device__ __forceinline__ void sg_colsum_tile(const SgColsum &c, const int block, float *smem) {
+  const int lc = threadIdx.x & 31, s = threadIdx.x >> 5;
+  const int col = block * 32 + lc;
+  const int per = (c.rows + 7) >> 3;
+  const int r0 = s * per, r1 = min(c.rows, r0 + per);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (col < c.cols) {
+    const float *x = c.X + col;
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {
+      a0 += x[(int64_t)r * c.cols];
+      a1 += x[(int64_t)(r + 1) * c.cols];
+      a2 += x[(int64_t)(r + 2) * c.cols];
+      a3 += x[(int64_t)(r + 3) * c.cols];
+    }
+    for (; r < r1; ++r) a0 += x[(int64_t)r * c.cols];
+  }
+  smem[s * 32 + lc] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (s == 0 && col < c.cols) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += smem[k * 32 + lc];
+    c.out[col] = t;
+  }
+}
+
 // TWO independent contractions in one launch (rk_linear_bwd: dX and dW both need dYpre only):
 // workgroups [0, tiles1) take g1's tiles, the rest g2's (both operands k-major: <1, 1>)
 template <int AMODE, int BMODE>
 __global__ __launch_bounds__(256) void small_gemm_pair_kernel(rk_small_gemm_t g1, int tiles_n1, int vec_a1,
                                                               int vec_b1, int tiles1, rk_small_gemm_t g2,
-                                                              int tiles_n2) {
+                                                              int tiles_n2, SgColsum cs, int n_pair) {
   constexpr int SM1 = sg_smem_floats<AMODE, BMODE>(), SM2 = sg_smem_floats<1, 1>();
   __shared__ __attribute__((aligned(16))) float smem[SM1 > SM2 ? SM1 : SM2];
+  if ((int)blockIdx.x >= n_pair) {       // (behind both products' tiles: the bias gradient's column sums)
+    sg_colsum_tile(cs, (int)blockIdx.x - n_pair, smem);
+    return;
+  }
   // (tiles1 < 0: g2's tiles come first in the grid, RK_PAIR_ORDER=1 -- the order makes no difference
   // (13.09 vs 13.12 us per rk_linear_bwd call), but the FORM does: written as a single if / else over the
   // two inlined bodies this kernel took the SUM of their times (16.0 us in rocprofv3 against 6.6 + 8.6 for
@@ -270,7 +309,15 @@ int rk_small_gemm(const rk_small_gemm_t *g, void *stream_) {
 
 // g1 (amode 0) and g2 (amode 1, bmode 1) as one launch; results identical to two rk_small_gemm calls
 int rk_small_gemm_pair(const rk_small_gemm_t *g1, const rk_small_gemm_t *g2, void *stream_) {
+  return rk_small_gemm_pair_colsum(g1, g2, nullptr, 0, 0, nullptr, stream_);
+}
+
+// ... and db[c] = sum_r dYpre[r * cols + c] (cs_X nullable) as a third workgroup range
+int rk_small_gemm_pair_colsum(const rk_small_gemm_t *g1, const rk_small_gemm_t *g2, const float *cs_X,
+                              int cs_rows, int cs_cols, float *cs_out, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  SgColsum cs = {cs_X, cs_rows, cs_cols, cs_out};
+  const int n_cs = cs_X ? rk_cdiv(cs_cols, 32) : 0;
   RK_REQUIRE(g1->amode == 0 && g2->amode == 1 && g2->bmode == 1, "pair: dX-shaped and dW-shaped operands");
   RK_REQUIRE(g1->M > 0 && g1->N > 0 && g1->K > 0 && g2->M > 0 && g2->N > 0 && g2->K > 0, "pair: empty problem");
   const int tn1 = rk_cdiv(g1->N, 32), tn2 = rk_cdiv(g2->N, 32);
@@ -280,9 +327,11 @@ int rk_small_gemm_pair(const rk_small_gemm_t *g1, const rk_small_gemm_t *g2, voi
   static const int swap = [] { const char *e = getenv("RK_PAIR_ORDER"); return (e && atoi(e) == 1) ? 1 : 0; }();
   const int t1a = swap ? -t2 : t1;
   if (g1->bmode == 0)
-    RK_LAUNCH((small_gemm_pair_kernel<0, 0>), dim3(t1 + t2), dim3(256), 0, stream, *g1, tn1, va, vb, t1a, *g2, tn2);
+    RK_LAUNCH((small_gemm_pair_kernel<0, 0>), dim3(t1 + t2 + n_cs), dim3(256), 0, stream, *g1, tn1, va, vb, t1a, *g2,
+              tn2, cs, t1 + t2);
   else
-    RK_LAUNCH((small_gemm_pair_kernel<0, 1>), dim3(t1 + t2), dim3(256), 0, stream, *g1, tn1, va, vb, t1a, *g2, tn2);
+    RK_LAUNCH((small_gemm_pair_kernel<0, 1>), dim3(t1 + t2 + n_cs), dim3(256), 0, stream, *g1, tn1, va, vb, t1a, *g2,
+              tn2, cs, t1 + t2);
   RK_CHECK_LAUNCH("small_gemm_pair");
   return 0;
 }

@@ -660,20 +660,27 @@ class FusedEngine:
       dz = self.ddec[self.nl - 1]
     # act' folded into the split-K reduce (MF without dropout: the gathered rows ARE the decoder's input)
     fuse_act = (simple or (self.kind != "ae" and not self.drop_active)) and ip is None
+    # hidden stacks without bottleneck dropout: every act' of the backward is multiplied in by the
+    # PRODUCER of the gradient it applies to -- the dZ reduce for the decoder's last hidden output, each
+    # layer's dX epilogue for its input activation -- so a layer's backward is ONE launch (dX, dW and
+    # the bias gradient's column sums: rk_linear_bwd_pre) instead of an act' pass + the products
+    stack_pre = (self.kind == "ae" and self.nl > 0 and not self.drop_active and ip is None and
+                 os.environ.get("RK_ENTRY_STACK_PRE", "1") != "0")
+    zact = self.enc[0] if fuse_act else (self.dec[self.nl - 1] if stack_pre else None)
     if getattr(self, "_dz_done", False):
       self._dz_done = False            # (summed by the dW launch: rk_decode_bwd_dw2_dz_reduce)
     elif getattr(self, "_dz_in_ws", False):
-      check(lib.rk_decode_dz_reduce(ptr(self.ws), B, h0, tb.ref, ptr(self.enc[0]) if fuse_act else None,
+      check(lib.rk_decode_dz_reduce(ptr(self.ws), B, h0, tb.ref, ptr(zact),
                                     self.act, ptr(dz), stream), "rk_decode_dz_reduce")
       self._dz_in_ws = False
     elif getattr(self, "_dz_on_planes", False):
       check(lib.rk_decode_bwd_dz_planes(ptr(self.dO), B, ctypes.byref(self.planes), tb.ref,
-                                        ptr(self.enc[0]) if fuse_act else None, self.act, ptr(dz),
+                                        ptr(zact), self.act, ptr(dz),
                                         ptr(self.ws), stream), "rk_decode_bwd_dz_planes")
       self._dz_on_planes = False
     else:
       check(lib.rk_decode_bwd_dz(ptr(self.dO), B, h0, tb.ref, ptr(W_de),
-                                 ptr(self.enc[0]) if fuse_act else None, self.act, ptr(dz),
+                                 ptr(zact), self.act, ptr(dz),
                                  ptr(self.ws), ptr(self.ranges), stream), "rk_decode_bwd_dz")
     if ip is not None:
       # item parallel: dLoss/d(decoder input) summed over the ranks' item shards; everything
@@ -692,6 +699,12 @@ class FusedEngine:
           w, wt, gw, acc = m.encoding_layers[j].weight, 1, self.g_enc_w[j], 0
         else:
           w, wt, gw, acc = layer.weight, 0, self.g_dec_w[i], 0
+        if stack_pre:
+          # (ddec[i] arrives with act'(dec[i]) in it; dX leaves with act'(x): x is the layer's input)
+          check(lib.rk_linear_bwd_pre(ptr(self.ddec[i]), ptr(x), ptr(w), B, rh[i + 1], rh[i], wt, self.act,
+                                      ptr(dx), ptr(gw), acc, ptr(self.g_dec_b[i]), ptr(x), stream),
+                "rk_linear_bwd_pre")
+          continue
         check(lib.rk_linear_bwd(ptr(self.ddec[i]), ptr(self.dec[i]), ptr(x), ptr(w), B, rh[i + 1],
                                 rh[i], wt, self.act, ptr(dx), ptr(gw), acc, ptr(self.g_dec_b[i]),
                                 stream), "rk_linear_bwd")
@@ -707,6 +720,14 @@ class FusedEngine:
         layer = m.encoding_layers[i]
         # (the stack's first layer: its dX is the embedding layer's gradient -- act'(enc[0]) is
         # folded into that product's epilogue instead of an rk_act_grad launch behind it)
+        if stack_pre:
+          check(lib.rk_linear_bwd_pre(ptr(self.denc[i + 1]), ptr(self.enc[i]), ptr(layer.weight), B,
+                                      self.h[i + 1], self.h[i], 0, self.act, ptr(self.denc[i]),
+                                      ptr(self.g_enc_w[i]), 1 if m.is_constrained else 0,
+                                      ptr(self.g_enc_b[i]), ptr(self.enc[i]), stream), "rk_linear_bwd_pre")
+          if i == 0:
+            fuse_act = True          # (act'(enc[0]) went into that dX)
+          continue
         last = i == 0 and not fuse_act
         check(lib.rk_linear_bwd_dact(ptr(self.denc[i + 1]), ptr(self.enc[i + 1]), ptr(self.enc[i]),
                                      ptr(layer.weight), B, self.h[i + 1], self.h[i], 0, self.act,

@@ -1647,6 +1647,17 @@ def test_linear_layer_entry_points_match_torch(B, N, K, wt, act, acc, pair):
                                ptr(db2), ptr(Xact), st), "rk_linear_bwd_dact")
   check(lib.rk_act_grad(ptr(dX), ptr(Xact), B * K, a, st), "rk_act_grad")
   torch.cuda.synchronize()
+  # rk_linear_bwd_pre: dY already IS dYpre (what the call above left in dY2): dX * act'(Xact), dW and db in
+  # one launch -- the same products bit for bit, db up to the order of its 8 row slices
+  dX3 = torch.empty(B, K, device=dev())
+  dW3 = ((dW0.t().contiguous() if wt else dW0).to(dev()).clone() if acc
+         else torch.empty(K, N, device=dev()) if wt else torch.empty(N, K, device=dev()))
+  db3 = torch.empty(N, device=dev())
+  check(lib.rk_linear_bwd_pre(ptr(dY2), ptr(Xd), ptr(Wd), B, N, K, wt, a, ptr(dX3), ptr(dW3), acc, ptr(db3),
+                              ptr(Xact), st), "rk_linear_bwd_pre")
+  torch.cuda.synchronize()
+  assert torch.equal(dX3, dX2) and torch.equal(dW3, dW2)
+  assert torch.allclose(db3.cpu().double(), gpre.sum(0), **tol)
   lib.rk_linear_pair(1)          # (the default)
   assert torch.equal(dX2, dX) and torch.equal(dW2, dWd) and torch.equal(db2, db) and torch.equal(dY2, dY)
 
