@@ -77,6 +77,8 @@ KERNELS = {"rk_ae_encode_fwd": ["ae_encode_fwd_kernel (+ the W_de[items] split w
            "rk_decode_bwd_dz_planes": ["dz_planes_kernel<TN>", "splitk_reduce_kernel"],
            "rk_decode_dz_reduce": ["splitk_reduce_kernel"], "rk_split_w": ["split_w_kernel"],
            "rk_split_wz": ["split_wz_kernel (W_de[items] and Z plane images, one launch)"],
+           "rk_split_wz_zt": ["split_wz_kernel (W_de[items] unless the encoder forward cut it, Z, Z^T planes)"],
+           "rk_ae_encode_fwd_split_w": ["ae_encode_fwd_kernel (+ the W_de[items] split workgroups)"],
            "rk_decode_bwd_dw2": ["dw3_kernel<BN,false,true>"],
            "rk_decode_bwd_dw2_encode_bwd": ["dw_encbwd_kernel<BN,HV> (dW tiles || encoder-backward columns)"],
            "rk_decode_bwd_dw2_dz_reduce": ["dw_reduce_kernel<BN> (dW tiles || the dZ slab reduce)"],
@@ -183,8 +185,10 @@ def entry_work(entry, B, h0, n_b, nnz, n_items, cfg):
     return "hbm", (-(-int(n_b) // 128) * B * h0 * 4 + 2 * B * h0 * 4) / 1e9, "GB/s"
   if entry == "rk_split_w":                     # gathered decoder rows -> W and W^T plane images
     return "hbm", 3.0 * n_b * h0 * 4 / 1e9, "GB/s"
-  if entry == "rk_split_wz":                    # ... and Z -> its image, in the same launch
+  if entry in ("rk_split_wz", "rk_split_wz_zt"):     # ... and Z -> its image (and Z^T planes), in the same launch
     return "hbm", (3.0 * n_b + 2.0 * B) * h0 * 4 / 1e9, "GB/s"
+  if entry == "rk_ae_encode_fwd_split_w":       # the encoder forward with the W_de[items] split riding on it
+    return "hbm", (nnz * (h0 * 4 + 12) + B * h0 * 4 + 3.0 * n_b * h0 * 4) / 1e9, "GB/s"
   if entry == "rk_mnll_finish":                 # two passes over the B x n_b logits, one write
     return "hbm", 3.0 * B * n_b * 4 / 1e9, "GB/s"
   if entry in ("rk_linear_fwd", "rk_linear_bwd", "rk_linear_bwd_dact", "rk_linear_bwd_pre") and cfg["kind"] == "ae" and \

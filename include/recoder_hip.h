@@ -128,6 +128,15 @@ int rk_ae_encode_fwd(const rk_block_t *blk, int32_t row_off, int32_t B,
                      const uint8_t *keep, float p, uint64_t seed,
                      uint64_t rng_step, const int64_t *users, int32_t act,
                      float *Z0, void *stream);
+/* the same launch with the W_de[tgt = blk items] half of the decode's operand split (rk_split_w: pl->w,
+ * pl->wt, the W scale from ranges[64..127]) as extra workgroups -- for steps sequenced entry by entry
+ * whose split launch then only cuts Z (rk_split_wz_zt with W_de == NULL) */
+struct rk_planes;
+int rk_ae_encode_fwd_split_w(const rk_block_t *blk, int32_t row_off, int32_t B, const float *W_en,
+                             const float *b_en, int32_t h, const uint8_t *keep, float p, uint64_t seed,
+                             uint64_t rng_step, const int64_t *users, int32_t act, float *Z0,
+                             const float *W_de, const int32_t *ranges, const struct rk_planes *pl,
+                             void *stream);
 
 /*
  * rk_ae_encode_fwd_partial -- the raw partial sum of rk_ae_encode_fwd (no bias, no

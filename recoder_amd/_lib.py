@@ -121,6 +121,8 @@ SIGNATURES = {
   "rk_densify": (c_int32, [_BLK, c_int32, c_int32, c_int32, _P, c_int32, _P]),
   "rk_ae_encode_fwd": (c_int32, [_BLK, c_int32, c_int32, _P, _P, c_int32, _P, c_float, c_uint64,
                                  c_uint64, _P, c_int32, _P, _P]),
+  "rk_ae_encode_fwd_split_w": (c_int32, [_BLK, c_int32, c_int32, _P, _P, c_int32, _P, c_float, c_uint64,
+                                         c_uint64, _P, c_int32, _P, _P, _P, POINTER(RkPlanes), _P]),
   "rk_ae_encode_bwd": (c_int32, [_BLK, c_int32, c_int32, _P, c_int32, _P, c_int32, _P, _P]),
   "rk_loss_partials": (c_int32, [c_int32, c_int32]),
   "rk_decode_row_tile": (c_int32, []),

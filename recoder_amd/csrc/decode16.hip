@@ -909,9 +909,10 @@ extern "C" int rk_split_wz_zt(const float *W_de, const float *Z, int32_t B, int3
   RK_REQUIRE(aligned16(W_de) && aligned16(Z), "W_de and Z must be 16-byte aligned");
   RK_REQUIRE(dw_workspace == nullptr || (rk_split_zt_ok() && (((uintptr_t)dw_workspace) & 255) == 0),
              "Z^T pair planes: fp16-pair dW only (rk_split_zt_ok), 256-byte aligned workspace");
-  if (B == 0) return rk_split_w(W_de, h, tgt, ranges, pl, stream_);
+  if (B == 0) return W_de ? rk_split_w(W_de, h, tgt, ranges, pl, stream_) : 0;
   const rkp::SplitW s = split_w_args(W_de, tgt, ranges, pl);
-  const int w_tiles = rk_cdiv(tgt->n_cap, 32);
+  // (W_de == NULL: the W images are already there -- rk_ae_encode_fwd_split_w -- only Z is cut here)
+  const int w_tiles = W_de ? rk_cdiv(tgt->n_cap, 32) : 0;
   const int z_blocks = rk_cdiv((int64_t)B * s.KT * 8, 256);
   SplitZt zt = {};
   int zt_blocks = 0;

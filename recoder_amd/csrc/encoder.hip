@@ -301,6 +301,32 @@ extern "C" int rk_ae_encode_fwd(const rk_block_t *blk, int32_t row_off, int32_t 
                            act, Z0, stream_);
 }
 
+// rk_ae_encode_fwd with the W_de[items] half of the decode's operand split (rk_split_w: pl->w, pl->wt
+// and the W scale) as extra workgroups of the same launch -- what the one-call step does; here for
+// the steps sequenced entry by entry (hidden stacks: the split launch in front of their decode then
+// only cuts Z, rk_split_wz_zt with W_de == NULL)
+extern "C" int rk_ae_encode_fwd_split_w(const rk_block_t *blk, int32_t row_off, int32_t B,
+                                        const float *W_en, const float *b_en, int32_t h,
+                                        const uint8_t *keep, float p, uint64_t seed, uint64_t rng_step,
+                                        const int64_t *users, int32_t act, float *Z0, const float *W_de,
+                                        const int32_t *ranges, const rk_planes_t *pl, void *stream_) {
+  RK_REQUIRE(b_en != nullptr, "b_en is required");
+  RK_REQUIRE(pl && pl->h == h && blk->n_cap <= pl->n_cap, "planes were laid out for another shape");
+  RK_REQUIRE((((uintptr_t)W_de) & 15) == 0, "W_de must be 16-byte aligned");
+  rk_enc_split_t es = {};
+  es.sw = rk_split_w_args(W_de, blk, ranges, pl);
+  es.n_split = rk_cdiv(blk->n_cap, 32);
+  es.zimg = nullptr;
+  es.z_kt = rkp::kp_of(h) / 32;
+  if (const rk_replay_t *rp = rk_replay_get()) {     // replayed per-entry step: cursor-derived
+    const rk_cur_t cur = {rp->cursor, rp->off};
+    return encode_fwd_launch(blk, row_off, B, W_en, b_en, h, keep, p, seed, 0, rp->users_base, nullptr,
+                             act, Z0, stream_, nullptr, cur, &es);
+  }
+  return encode_fwd_launch(blk, row_off, B, W_en, b_en, h, keep, p, seed, rng_step, users, nullptr,
+                           act, Z0, stream_, nullptr, {nullptr, 0}, &es);
+}
+
 extern "C" int rk_ae_encode_fwd_planes(const rk_block_t *blk, int32_t row_off, int32_t B,
                                        const float *W_en, const float *b_en, int32_t h,
                                        const uint8_t *keep, float p, uint64_t seed, uint64_t rng_step,

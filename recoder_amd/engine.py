@@ -327,6 +327,17 @@ class FusedEngine:
                                          stream), "rk_ae_encode_fwd_partial")
       ip.allreduce_sum(self.enc[0][:B * h0])
       check(lib.rk_bias_act(ptr(self.enc[0]), ptr(m.en_bias), B, h0, self.act, stream), "rk_bias_act")
+    elif train and getattr(self, "_split_w_with_fwd", False):
+      # the W_de[items] half of the decode's operand split rides on this launch (as in the one-call
+      # step); _loss then only cuts Z
+      self._check_weight_range()
+      W_de, _ = self._decoder_params()
+      check(lib.rk_ae_encode_fwd_split_w(blk.ref, row_off, B, ptr(m.en_embedding_layer.weight),
+                                         ptr(m.en_bias), self.h[0], ptr(keep_noise), p_noise, self.seed,
+                                         self.rng_step, ptr(blk.users), self.act, ptr(self.enc[0]),
+                                         ptr(W_de), ptr(self.ranges), ctypes.byref(self.planes), stream),
+            "rk_ae_encode_fwd")
+      self._w_split_of = blk
     else:
       check(lib.rk_ae_encode_fwd(blk.ref, row_off, B, ptr(m.en_embedding_layer.weight),
                                  ptr(m.en_bias), self.h[0], ptr(keep_noise), p_noise, self.seed,
@@ -440,6 +451,9 @@ class FusedEngine:
     self._zt_ready = None
     if zt_ws is not None and not self.lib.rk_split_zt_ok():
       zt_ws = None
+    # (the encoder forward of this step already cut W_de[items of this block]: rk_ae_encode_fwd_split_w)
+    w_done = getattr(self, "_w_split_of", None) is tgt and tgt is not None
+    self._w_split_of = None
     if fuse_dz and ip is None and self.planes is not None and self.split16 and self.ws_dw is not None and \
         self.item_parallel is None and lib.rk_decode_dz_fused_ok(B, self.h[0], tgt.n_cap, self.loss_id):
       # training steps sequenced entry by entry (hidden stacks, bottleneck dropout, MatrixFactorization):
@@ -449,8 +463,8 @@ class FusedEngine:
       # in its own workspace in between
       h0 = self.h[0]
       rg = self._ranges(z, B * h0, stream)
-      check(lib.rk_split_wz_zt(ptr(W), ptr(z), B, h0, tgt.ref, rg, ctypes.byref(self.planes), ptr(zt_ws),
-                               stream), "rk_split_wz")
+      check(lib.rk_split_wz_zt(None if w_done else ptr(W), ptr(z), B, h0, tgt.ref, rg, ctypes.byref(self.planes),
+                               ptr(zt_ws), stream), "rk_split_wz")
       self._zt_ready = None if zt_ws is None else zt_ws.data_ptr()
       check(lib.rk_decode_loss_dz_planes(ctypes.byref(self.planes), B, tgt.ref, row_off, ptr(b), self.loss_id,
                                          self.confidence, inv_B, ptr(self.dO), ptr(self.loss_part),
@@ -463,8 +477,8 @@ class FusedEngine:
       # W^T image (rk_decode_bwd_dz_planes) where rk_decode_bwd_dz would split W_de in its k-loop again
       h0 = self.h[0]
       rg = self._ranges(z, B * h0, stream)
-      check(lib.rk_split_wz_zt(ptr(W), ptr(z), B, h0, tgt.ref, rg, ctypes.byref(self.planes), ptr(zt_ws),
-                               stream), "rk_split_wz")
+      check(lib.rk_split_wz_zt(None if w_done else ptr(W), ptr(z), B, h0, tgt.ref, rg, ctypes.byref(self.planes),
+                               ptr(zt_ws), stream), "rk_split_wz")
       self._zt_ready = None if zt_ws is None else zt_ws.data_ptr()
       check(lib.rk_decode_loss_planes(ctypes.byref(self.planes), B, tgt.ref, row_off, ptr(b), self.loss_id,
                                       self.confidence, inv_B, ptr(self.dO), 0, ptr(self.loss_part),
@@ -570,7 +584,15 @@ class FusedEngine:
     h0 = self.h[0]
     rows = B if global_rows is None else global_rows
     if self.kind == "ae":
+      # (the plane kernels will decode this block: its W_de[items] split can ride on the encoder forward)
+      self._w_split_of = None
+      self._split_w_with_fwd = (tgt is None and ip is None and self.planes is not None and self.split16 and
+                                self.item_parallel is None and not bool(m.is_constrained) and
+                                os.environ.get("RK_ENTRY_DZ_FUSED", "1") != "0" and
+                                os.environ.get("RK_ENTRY_PLANES", "1") != "0" and
+                                os.environ.get("RK_ENTRY_W_SPLIT_FWD", "1") != "0")
       z = self._ae_forward(blk, row_off, B, keep_noise, keep_drop, True, stream)
+      self._split_w_with_fwd = False
     else:
       rp = getattr(self, "_replay", None)
       # (replay: the C entry points take the step's users from the cursor; the pointer is a placeholder)
