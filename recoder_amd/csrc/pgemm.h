@@ -1,0 +1,290 @@
+// Pipelined contraction on pre-split operand planes (round 4; csrc/planes.h describes the images).
+//
+//   C[M, N] = sum_k A(m, k) . B(k, n)     every operand a plane image of fp16 pairs  s.x = hi + lo,
+//   a.b = lo.hi + hi.lo + hi.hi accumulated in fp32 on v_mfma_f32_32x32x16_f16 (the arithmetic and the
+//   per-accumulator order of decode16.hip: with equal operands the results agree bit for bit).
+//
+// What is new against decode16.hip's k-loop (write LDS -> barrier -> read LDS -> MFMA, serial):
+//   * the global -> LDS copy is LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write
+//     pass; the copy of k-tile t + 1 is issued BEFORE the MFMAs of k-tile t and lands under them -- two
+//     LDS stages, ONE barrier per k-tile;
+//   * 256 x 256 tiles on 8 waves (wave tile 128 x 64: 48 MFMAs per 24 ds_read_b128 and k-tile) where
+//     the problem is large, 128 x 128 on 4 waves (two workgroups per CU) where it is not;
+//   * an operand whose contraction index runs along the image's ROWS (W in dZ = dO . W, both operands
+//     of dW = dO^T . Z) is read with ds_read_b64_tr_b16, the LDS transpose read of gfx950 -- so the
+//     three contractions of a step need THREE images (Z, W[items], dO) and no transposed copy of any
+//     of them (round 3 wrote W^T and Z^T images as well: 2 x 100 MB per step at C5's sizes).
+//
+// LDS images (lane-linear for the DMA; the bank swizzle is applied to the SOURCE address and to the
+// fragment read, never to the destination):
+//   K along the columns ("KC"): stage = [R rows][128 B line]; 16-byte slot s of row r sits at slot
+//     s ^ ((r >> 1) & 7): the 16 lanes of a ds_read_b128 group hit 16 different slots of the 256-B bank row.
+//   K along the rows ("TR"):    stage = [32 k-rows][C / 32 lines]; byte o of k-row kr sits at
+//     o ^ ((kr & 1) << 6 | (kr & 2) << 6): the 32 lanes of a ds_read_b64_tr_b16 half-wave (4 k-rows x
+//     64 bytes) cover the 256-B bank row exactly once.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+constexpr int LINE = 128;
+
+struct Opnd {
+  const char *img;      // plane image: [rows][lines] x 128 B
+  int64_t pitch;        // bytes per image row
+  int lines;            // lines per image row
+  int rows;             // allocated image rows (KC: clamp of the tile's rows; TR: a multiple of 32)
+};
+
+struct Core {
+  Opnd a, b;
+  int M, N, K;                         // problem size (a capacity where the live size is on the device)
+  const int32_t *Mdev, *Ndev, *Kdev;   // nullable: live sizes on the device
+  int splits;                          // split-K: slabs
+};
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ------------------------------------------------------------------ staging (global -> LDS, LDS-DMA)
+// R = tile extent along the operand's non-K index (rows of a KC operand, columns of a TR operand),
+// NW waves; the stage is R * 128 bytes = R / 8 wave-instructions of 1 KB, Q = R / 8 / NW per wave
+template <int R, bool TR, int NW>
+struct Stager {
+  static constexpr int Q = R / 8 / NW;
+  static_assert(R % (8 * NW) == 0, "tile extent must be a multiple of 8 * waves");
+  const char *src[Q];
+  int64_t step;
+
+  // x0: first row (KC) / first column (TR) of the tile; kt0: first k-tile; lim: live rows (KC clamp)
+  __device__ __forceinline__ void init(const Opnd &o, const int x0, const int kt0, const int lim,
+                                       const int wave, const int lane) {
+    if (!TR) {
+      step = LINE;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int qg = q * NW + wave;
+        const int r = qg * 8 + (lane >> 3);
+        const int s = (lane & 7) ^ ((r >> 1) & 7);
+        const int row = min(x0 + r, lim - 1);
+        src[q] = o.img + (int64_t)row * o.pitch + (int64_t)kt0 * LINE + s * 16;
+      }
+    } else {
+      constexpr int RS = R * 4;            // bytes per k-row of the stage
+      step = 32 * o.pitch;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int qg = q * NW + wave;
+        const int d = qg * 1024 + lane * 16;
+        const int kr = d / RS, off = d % RS;
+        const int o2 = off ^ (((kr & 1) << 6) | ((kr & 2) << 6));
+        const int line = min((x0 >> 5) + (o2 >> 7), o.lines - 1);
+        src[q] = o.img + ((int64_t)kt0 * 32 + kr) * o.pitch + (int64_t)line * LINE + (o2 & 127);
+      }
+    }
+  }
+  __device__ __forceinline__ void issue(char *stage, const int wave) {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int qg = q * NW + wave;
+      __builtin_amdgcn_global_load_lds((gbl_void *)src[q], (lds_void *)(stage + qg * 1024), 16, 0, 0);
+      src[q] += step;
+    }
+  }
+};
+
+// ------------------------------------------------------------------ fragment reads
+// one 32 x 32 x 16 MFMA operand of this lane: 8 consecutive k (8 * lh .. + 7 of k-step ks) of row /
+// column (tile * 32 + l31); plane 0 = hi, 1 = lo
+struct FragKC {
+  int base;                 // l31 * 128
+  int sw;                   // (l31 >> 1) & 7
+  int lh;
+  __device__ __forceinline__ void init(const int lane) {
+    const int l31 = lane & 31;
+    base = l31 * LINE; sw = (l31 >> 1) & 7; lh = lane >> 5;
+  }
+  __device__ __forceinline__ f16x8 load(const char *S, const int tile, const int ks, const int plane) const {
+    const int slot = (ks * 2 + lh + plane * 4) ^ sw;
+    return __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(S + tile * 4096 + base + slot * 16));
+  }
+};
+
+template <int R>
+struct FragTR {
+  static constexpr int RS = R * 4;
+  int row_off;              // ((8 * lh) + (t >> 2)) * RS
+  int col;                  // 32 g + 8 (t & 3)
+  int swz;                  // lane-constant XOR mask (bits 6, 7): k-row & 3 == t >> 2
+  __device__ __forceinline__ void init(const int lane) {
+    const int t = lane & 15, g = (lane >> 4) & 1, lh = lane >> 5;
+    row_off = (8 * lh + (t >> 2)) * RS;
+    col = 32 * g + 8 * (t & 3);
+    swz = (((t >> 2) & 1) << 6) | (((t >> 3) & 1) << 7);
+  }
+  __device__ __forceinline__ f16x8 load(const char *S, const int tile, const int ks, const int plane) const {
+    const int o = ((tile * LINE + plane * 64 + col) ^ swz) + row_off + ks * 16 * RS;
+    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(S + o));
+    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(S + o + 4 * RS));
+    const s16x8 v = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(f16x8, v);
+  }
+};
+
+template <int R, bool TR> struct FragSel { typedef FragKC type; };
+template <int R> struct FragSel<R, true> { typedef FragTR<R> type; };
+
+// ------------------------------------------------------------------ the tile loop
+// Geometry of one workgroup's tile, handed to the epilogue
+struct Tile {
+  int m0, n0;          // origin
+  int M, N;            // live sizes
+  int mt, nt, split;   // tile coordinates, K slab
+  int tm, tn;          // tile counts
+  int t;               // linear live-tile index
+  int wm, wn, lane, wave;
+};
+
+// XCD-aware order (decode16.hip): workgroup L runs on XCD L % 8 and takes a contiguous chunk of the
+// LIVE tile list; consecutive tiles share the B panel (mt fastest)
+__device__ __forceinline__ bool tile_of(const int L, const int total, int &t) {
+  const int chunk = (total + 7) >> 3;
+  t = (L & 7) * chunk + (L >> 3);
+  return (L >> 3) < chunk && t < total;
+}
+
+template <int BM, int BN, int WM, int WN, bool ATR, bool BTR, class Epi>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const Core p, const typename Epi::Args ea) {
+  constexpr int NW = WM * WN, TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_BYTES = BM * LINE, STAGE = (BM + BN) * LINE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int M = p.Mdev ? *p.Mdev : p.M, N = p.Ndev ? *p.Ndev : p.N, K = p.Kdev ? *p.Kdev : p.K;
+  Tile T;
+  T.M = M; T.N = N;
+  T.tm = (M + BM - 1) / BM; T.tn = (N + BN - 1) / BN;
+  const int per_split = T.tm * T.tn;
+  if (!tile_of((int)blockIdx.x, per_split * p.splits, T.t)) return;
+  T.split = T.t / per_split;
+  const int rt = T.t % per_split;
+  T.mt = rt % T.tm; T.nt = rt / T.tm;
+  T.m0 = T.mt * BM; T.n0 = T.nt * BN;
+  const int tid = threadIdx.x;
+  T.lane = tid & 63; T.wave = rfl(tid >> 6);
+  T.wm = T.wave / WN; T.wn = T.wave % WN;
+  // k range of this slab, in k-tiles of 32
+  const int nk_all = (K + 31) >> 5;
+  const int kchunk = (nk_all + p.splits - 1) / p.splits;
+  const int kt0 = T.split * kchunk;
+  const int nk = min(kchunk, nk_all - kt0);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nk > 0) {
+    Stager<BM, ATR, NW> sa;
+    Stager<BN, BTR, NW> sb;
+    sa.init(p.a, T.m0, kt0, ATR ? 0 : min(M, p.a.rows), T.wave, T.lane);
+    sb.init(p.b, T.n0, kt0, BTR ? 0 : min(N, p.b.rows), T.wave, T.lane);
+    typename FragSel<BM, ATR>::type fa;
+    typename FragSel<BN, BTR>::type fb;
+    fa.init(T.lane);
+    fb.init(T.lane);
+    sa.issue(smem, T.wave);
+    sb.issue(smem + A_BYTES, T.wave);
+    for (int kt = 0; kt < nk; ++kt) {
+      // tile kt has landed (every wave waits for its own DMAs, then the barrier) and every wave is
+      // done reading the other stage (its MFMAs of iteration kt - 1 consumed those fragments)
+      __syncthreads();
+      if (kt + 1 < nk) {
+        char *nx = smem + ((kt + 1) & 1) * STAGE;
+        sa.issue(nx, T.wave);
+        sb.issue(nx + A_BYTES, T.wave);
+      }
+      const char *SA = smem + (kt & 1) * STAGE + (T.wm * TM) * 4096 * (ATR ? 0 : 1);
+      const char *SB = smem + (kt & 1) * STAGE + A_BYTES + (T.wn * TN) * 4096 * (BTR ? 0 : 1);
+      const int ta = ATR ? T.wm * TM : 0, tb = BTR ? T.wn * TN : 0;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { ah[i] = fa.load(SA, ta + i, ks, 0); al[i] = fa.load(SA, ta + i, ks, 1); }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { bh[j] = fb.load(SB, tb + j, ks, 0); bl[j] = fb.load(SB, tb + j, ks, 1); }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  Epi::template run<BM, BN, TM, TN>(ea, T, acc, smem);
+}
+
+// ------------------------------------------------------------------ plain store epilogue
+// C[m][n] = acc * scale (+ slab offset per K split): a lane holds 16 rows of ONE column, 32 lanes = 128
+// contiguous bytes per store instruction
+struct EpiStore {
+  struct Args {
+    float *C;
+    int64_t ldc;
+    int64_t slab_stride;     // floats between K slabs
+    const float *scales;     // nullable: [0] * [1] = product of the operand scales
+    float scale;             // used when scales == null
+  };
+  template <int BM, int BN, int TM, int TN>
+  static __device__ __forceinline__ void run(const Args &e, const Tile &T, f32x16 (&acc)[TM][TN], char *) {
+    const float inv = e.scales ? 1.0f / (e.scales[0] * e.scales[1]) : e.scale;
+    float *C = e.C + (int64_t)T.split * e.slab_stride;
+    const int l31 = T.lane & 31, lh = T.lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = T.n0 + (T.wn * TN + j) * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = T.m0 + (T.wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < T.M && n < T.N) C[(int64_t)m * e.ldc + n] = acc[i][j][r] * inv;
+        }
+      }
+  }
+};
+
+template <int BM, int BN, int WM, int WN, bool ATR, bool BTR, class Epi>
+inline hipError_t launch(const Core &p, const typename Epi::Args &ea, int tiles_cap, hipStream_t s) {
+  constexpr int LDS = 2 * (BM + BN) * LINE;
+  auto k = gemm_kernel<BM, BN, WM, WN, ATR, BTR, Epi>;
+  static const hipError_t attr =
+      hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess) return attr;
+  const int grid = ((tiles_cap * p.splits + 7) / 8) * 8;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(WM * WN * 64), LDS, s, p, ea);
+  return hipGetLastError();
+}
+
+}  // namespace pg

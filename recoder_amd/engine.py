@@ -1253,6 +1253,10 @@ class FusedEngine:
     lib, h, cap = self.lib, self.h[0], self.EVAL_CAND_CAP
     if not (self.split16 and k <= cap // 8 and h % 4 == 0):
       return None
+    if lib.rk_gemm_plain_bf16():
+      # RK_GEMM_PREC=bf16: rk_split_image writes PLAIN bf16 images, the fused filter launch multiplies
+      # fp16 pairs (it would read bf16 bits as fp16 and return wrong ids with status 0): strip path
+      return None
     # sample size: the expected number of survivors per row is n_items * k / m -- a quarter of the list
     m_target = max(self.EVAL_SAMPLE_MIN, -(-4 * n_items * k // cap))
     stride = max(1, n_items // m_target)

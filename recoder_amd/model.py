@@ -417,6 +417,7 @@ class Recoder(object):
           if st:
             tensors += [st["exp_avg"], st["exp_avg_sq"]]
       ip.sync_owned(tensors, self.num_items)
+      self._weights_written()
       return
     if getattr(self, "_dp", None) is None or self._fused_kind() != "mf":
       return
@@ -430,6 +431,15 @@ class Recoder(object):
     if self._dp_n_users < w.shape[0]:
       tensors = [t[:self._dp_n_users] for t in tensors]
     sync_owned_rows(tensors, self._dp_n_users, self._dp.group)
+    self._weights_written()
+
+  def _weights_written(self):
+    """Parameters were written through `.data` (no torch version bump: owner-row syncs): the decoder
+    weight bound of the split contractions and the evaluation images must be taken again."""
+    eng = self._engine()
+    if hasattr(eng, "_w_range_stale"):
+      eng._w_range_stale = True
+      eng._eval_img = None
 
   def _setup_data_parallel(self, train_dataset, negative_sampling=True):
     """Under an initialised torch.distributed group (one process per GPU, backend
@@ -440,6 +450,7 @@ class Recoder(object):
     import torch.distributed as dist
     self._dp = None
     self._ip = None
+    self._dp_nnz_cap = {}                  # (keyed on id(matrix): never survives the matrix it was taken for)
     if getattr(self, "_ip_override", None) is not None:
       # tests: several virtual ranks in one process, collectives injected
       return self._enable_item_parallel(self._ip_override, train_dataset)
@@ -455,6 +466,10 @@ class Recoder(object):
       log.warning("multi-GPU training covers the fused DynamicAutoencoder / MatrixFactorization step "
                   "without a separate target matrix: running this configuration replicated on "
                   "every rank")
+      if dp is None:
+        for p_ in self.model.parameters():        # identical replicas whatever each process seeded
+          dist.broadcast(p_.data, src=0)
+        self._weights_written()
       return train_dataset
     if dp is None:
       for p_ in self.model.parameters():          # identical replicas: rank 0's initial weights
@@ -729,8 +744,9 @@ class Recoder(object):
       # (concurrent writers of one path can truncate each other on a shared filesystem), the
       # others wait for the file
       import torch.distributed as dist
-      multi = (getattr(self, "_dp", None) is not None or getattr(self, "_ip", None) is not None) and \
-          getattr(self, "_dp_override", None) is None and getattr(self, "_ip_override", None) is None and \
+      # (also the replicated fallback of _setup_data_parallel -- generic engine, target matrix --
+      # where neither _dp nor _ip is set: every process of an initialised group is here)
+      multi = getattr(self, "_dp_override", None) is None and getattr(self, "_ip_override", None) is None and \
           dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
       if not multi or dist.get_rank() == 0:
         self.save_state(model_checkpoint_prefix)
@@ -754,7 +770,8 @@ class Recoder(object):
       # the step is the one-call autoencoder step; injected collectives (virtual ranks in tests),
       # torch.distributed / gloo and the entry-by-entry engines keep the eager sequencing
       if not (dp.direct and not dp.virtual and eng.c_step_eligible() and
-              os.environ.get("RK_GRAPH_DP", "1") != "0" and self.graph_group <= 8):
+              os.environ.get("RK_GRAPH_DP", "1") != "0" and self.graph_group <= 8 and
+              os.environ.get("RK_COLLATE_MULTI", "1") != "0"):
         return False
     ds = dataloader.dataset
     return (self.mask_hook is None and dataloader.num_sampling_users == dataloader.batch_size and

@@ -131,6 +131,19 @@ def test_fp32_mfma_fallback_keeps_golden_parity():
   assert " passed" in r.stdout and "no tests ran" not in r.stdout, r.stdout[-500:]
 
 
+def test_recommend_under_plain_bf16_never_takes_the_pair_filter():
+  """RK_GEMM_PREC=bf16: rk_split_image writes plain bf16 images; the fused top-k filter multiplies fp16
+  pairs, so recommend() must fall back to the strips there (it returned wrong ids with
+  status 0) -- same ids as the strip path, and the fused launch is never counted."""
+  env = dict(os.environ, RK_GEMM_PREC="bf16")
+  r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
+                      os.path.join(ROOT, "tests", "test_hip_parity.py"), "-k",
+                      "recommend_fused_filter_equals_the_strips"],
+                     cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+  assert " passed" in r.stdout and "no tests ran" not in r.stdout, r.stdout[-500:]
+
+
 @pytest.mark.parametrize("loss_name", ["mse", "bce", "mnll"])
 def test_loss_kernels_publish_max_gradient(loss_name):
   """rk_decode_loss (MSE / BCE epilogue) and rk_mnll_finish publish max |dLoss/dLogit| into

@@ -183,8 +183,20 @@ def make_oracle(c, state):
 # Measured over the eight golden replays (round 3): every bias, hidden layer, MF table and most
 # embedding tables: ALL elements within 1e-5 (worst 3.3e-6 relative where |w| > 1e-3); two embedding
 # tables have 3.5e-4 / 6.9e-4 of their elements beyond it, worst 1.6e-5 / 5.2e-5 relative.
-TIGHT_FRAC = float(os.environ.get("RK_TIGHT_FRAC", "1e-3"))
-TIGHT_REL = float(os.environ.get("RK_TIGHT_REL", "1e-4"))
+# Round 4: the bounds are what was measured plus a small margin, not a round number above it -- the two
+# autoencoder embedding tables get 8e-4 / 6e-5; EVERY other tensor (biases, hidden layers, the
+# MatrixFactorization tables) must meet north_star's 1e-5 on all of its elements, so that a
+# regression of the split arithmetic cannot hide inside the slack.
+TIGHT_FRAC = float(os.environ.get("RK_TIGHT_FRAC", "8e-4"))
+TIGHT_REL = float(os.environ.get("RK_TIGHT_REL", "6e-5"))
+AE_TABLES = ("en_embedding_layer.weight", "de_embedding_layer.weight")
+
+
+def tight_bounds(name, kind):
+  """(max fraction of elements beyond 1e-5 relative, max relative error where |w| > 1e-3) of a tensor."""
+  if kind == "ae" and any(name.endswith(t) for t in AE_TABLES):
+    return TIGHT_FRAC, TIGHT_REL
+  return 0.0, 1e-5
 
 
 def close_stats(a, b, rtol, atol):
@@ -261,8 +273,9 @@ def test_train_replays_reference_golden(name):
     assert frac < 2e-3, (k, frac, mx)
     assert mx < 5e-3 * max(1.0, scale), (k, mx)
     # north_star's tolerance on the parameters themselves (TIGHT_FRAC / TIGHT_REL: see the note there)
-    assert tfrac < TIGHT_FRAC, (k, tfrac)
-    assert trel < TIGHT_REL, (k, trel)
+    bfrac, brel = tight_bounds(k, c["kind"])
+    assert tfrac <= bfrac if bfrac == 0.0 else tfrac < bfrac, (k, tfrac, bfrac)
+    assert trel < brel, (k, trel, brel)
 
 
 def test_model_init_matches_reference_golden():
@@ -1530,7 +1543,10 @@ def test_recommend_fused_filter_equals_the_strips(seed, monkeypatch):
   want = rec.recommend_array(ui, k)
   assert rec.eval_fused_batches == fused
   assert np.array_equal(got, want), dict(n_items=n_items, k=k, B=B, kind=kind, cap=cap, fused=fused)
-  if cap == 4096:
+  from recoder_amd import _lib
+  if _lib.load().rk_gemm_plain_bf16():
+    assert fused == 0                                  # (plain-bf16 images: the fp16-pair filter must not run)
+  elif cap == 4096:
     assert fused == 1                                  # (the filter really ran)
   seen = csr[users].toarray() > 0
   assert not np.take_along_axis(seen, got, axis=1).any()
