@@ -395,8 +395,54 @@ int64_t rk_dz_fused_workspace_bytes(int32_t B, int32_t h, int32_t n_cap);
 int rk_decode_loss_dz_planes(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off,
                              const float *b_de, int32_t loss_kind, float confidence, float inv_B, float *dO,
                              float *loss_part, float *gb_part, float *dz_workspace, void *stream);
+/* the same with dLoss/dLogits leaving as a plane IMAGE (rk_pg_* notes below; granule 64 x 128) instead of
+ * the fp32 matrix: the operand of rk_pg_dw */
+int rk_decode_loss_dz_image(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off,
+                            const float *b_de, int32_t loss_kind, float confidence, float inv_B, void *dO_img,
+                            int32_t rows_img, float *dO_scales, float *loss_part, float *gb_part,
+                            float *dz_workspace, void *stream);
 int rk_decode_dz_reduce(const float *dz_workspace, int32_t B, int32_t h, const rk_block_t *tgt,
                         const float *Zact /* nullable */, int32_t act, float *dZ, void *stream);
+/*
+ * Round 4: the decoder's three contractions as ONE pipelined kernel family (csrc/pgemm.h) on THREE plane
+ * images -- Z, W_de[items] and dLoss/dLogits -- and no transposed copy of any of them: an operand whose
+ * contraction index runs along its image's rows is read from LDS with the transpose read of gfx950
+ * (ds_read_b64_tr_b16); k-tiles travel global -> LDS by LDS-DMA (global_load_lds_dwordx4), the copy of
+ * tile t + 1 in flight under the MFMAs of tile t, one barrier per k-tile.  Replaces, where it applies
+ * (MSE / logistic loss), rk_decode_loss_planes + rk_decode_bwd_dz_planes + rk_decode_bwd_dw2 (reference
+ * nn.py:271-280, losses.py:43-47, and autograd of F.linear).
+ *
+ * rk_pg_decode_loss: decode + loss; dLoss/dLogits leaves as a plane image of fp16 pairs (row m at byte
+ *   m * ld * 4 of dO_img, ld = counts[2] -- the footprint of the fp32 matrix it replaces; rows
+ *   [B, round_up(B, 32)) and columns [n_t, ld) are written as zeros) cut with the TILE's own power-of-two
+ *   scale, published in dO_scales[(row / gr) * ceil(n_cap / gc) + col / gc] with (gr, gc) =
+ *   rk_pg_decode_granule(B, n_cap) (rk_pg_scale_floats floats fit every producer).  dO_f32 (nullable):
+ *   the fp32 matrix as well (tests).  loss_part / gb_part as rk_decode_loss.
+ * rk_pg_dz: dZ[B, h] = dO . W_de[T] (* act'(Zact) if given) from the image and pl->w; workspace:
+ *   rk_pg_dz_workspace_bytes.  rk_pg_dw: the K slabs [rk_pg_dw_splits][n_cap][h] of dW[n_t, h] = dO^T . Z
+ *   from the image and pl->z (rk_adam_multi adds them: g_parts).  (gr, gc): the granule of the producer
+ *   of the image -- rk_pg_decode_granule, or 64 x 128 for rk_decode_loss_dz_planes' image form.
+ */
+int32_t rk_pg_enabled(void);     /* RK_PG=0 switches the family off (the round-3 plane kernels run instead) */
+void rk_pg_decode_granule(int32_t B, int32_t n_cap, int32_t *gr, int32_t *gc);
+int64_t rk_pg_scale_floats(int32_t B_cap, int32_t n_cap);
+int rk_pg_decode_loss(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off,
+                      const float *b_de, int32_t loss_kind, float confidence, float inv_B, void *dO_img,
+                      int32_t rows_img, float *dO_scales, float *dO_f32 /* nullable */, float *loss_part,
+                      float *gb_part, void *stream);
+int64_t rk_pg_dz_workspace_bytes(int32_t B, int32_t h);
+int rk_pg_dz(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
+             const rk_planes_t *pl, const rk_block_t *tgt, const float *Zact /* nullable */, int32_t act,
+             float *dZ, float *workspace, void *stream);
+int32_t rk_pg_dw_splits(int32_t B, int32_t h, int32_t n_cap);
+int64_t rk_pg_dw_workspace_bytes(int32_t B, int32_t h, int32_t n_cap);
+int rk_pg_dw(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
+             const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, void *stream);
+/* rk_pg_dw || rk_ae_encode_bwd (G_en, gb_en as there; nothing accumulated) in ONE launch: the dW tiles
+ * first in the grid, then a wave per item column (domain: rk_dw_encode_bwd_fused_ok) */
+int rk_pg_dw_encode_bwd(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
+                        const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, int32_t row_off,
+                        const float *dZ0pre, float *G_en, float *gb_en, void *stream);
 /* tuning probe (tools/probes/enc_phase_probe.py): device buffer of 8 uint64 per user row of the
  * encoder forward (entry, first entries loaded, gather done, end); NULL (default): off */
 void rk_enc_probe(unsigned long long *buffer);
@@ -634,6 +680,13 @@ typedef struct rk_ae_step {
    * encoder-forward launch, Z in that kernel's epilogue (unbounded activations: rk_amax +
    * rk_split_z), and runs the decode and dZ through the *_planes kernels */
   const rk_planes_t *planes;
+  /* nullable: scale table of the dO IMAGE (rk_pg_scale_floats floats).  Given, whole untied MSE / BCE
+   * steps outside the fused decode's domain (h > 256, >= 1024 rows) run their three contractions on the
+   * pipelined pair-plane kernels (rk_pg_decode_loss / rk_pg_dz / rk_pg_dw): `dO` then holds the image
+   * (do_rows >= round_up(B, 32) rows of ld * 4 bytes -- the fp32 matrix's footprint), the W^T image and
+   * the Z^T planes are not made at all, `ws` holds rk_pg_dz's slabs and ws_dw (or ws) rk_pg_dw's. */
+  float *do_scales;
+  int32_t do_rows;
 } rk_ae_step_t;
 
 void *rk_event_create(void);          /* ordering-only (no timing, device-scope fence) */
@@ -641,6 +694,8 @@ void *rk_timing_event_create(void);   /* for time_ev0 / time_ev1 and rk_event_el
 void rk_event_destroy(void *event);
 float rk_event_elapsed_ms(void *ev0, void *ev1);   /* synchronises on ev1 */
 int rk_ae_train_step(const rk_ae_step_t *step);
+/* != 0: the step as described runs rk_pg_decode_loss / rk_pg_dz / rk_pg_dw (rk_ae_step_t.do_scales) */
+int32_t rk_ae_step_uses_pg(const rk_ae_step_t *step);
 
 /*
  * Graph replay of the hot loop.  rk_collate_at = rk_collate (phase 0) on the users

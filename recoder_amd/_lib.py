@@ -73,6 +73,7 @@ class RkAeStep(Structure):
     ("time_all", POINTER(c_void_p)),
     ("ws_dw", c_void_p), ("dw_stream", c_void_p), ("dw_fork", c_void_p), ("dw_join", c_void_p),
     ("planes", c_void_p),
+    ("do_scales", c_void_p), ("do_rows", c_int32),
   ]
 
 
@@ -168,7 +169,22 @@ SIGNATURES = {
   "rk_dz_fused_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
   "rk_decode_loss_dz_planes": (c_int32, [_P, c_int32, _BLK, c_int32, _P, c_int32, c_float, c_float, _P, _P, _P,
                                          _P, _P]),
+  "rk_decode_loss_dz_image": (c_int32, [_P, c_int32, _BLK, c_int32, _P, c_int32, c_float, c_float, _P, c_int32, _P,
+                                        _P, _P, _P, _P]),
   "rk_decode_dz_reduce": (c_int32, [_P, c_int32, c_int32, _BLK, _P, c_int32, _P, _P]),
+  "rk_pg_enabled": (c_int32, []),
+  "rk_ae_step_uses_pg": (c_int32, [_P]),
+  "rk_pg_decode_granule": (None, [c_int32, c_int32, POINTER(c_int32), POINTER(c_int32)]),
+  "rk_pg_scale_floats": (c_int64, [c_int32, c_int32]),
+  "rk_pg_decode_loss": (c_int32, [POINTER(RkPlanes), c_int32, _BLK, c_int32, _P, c_int32, c_float, c_float, _P,
+                                  c_int32, _P, _P, _P, _P, _P]),
+  "rk_pg_dz_workspace_bytes": (c_int64, [c_int32, c_int32]),
+  "rk_pg_dz": (c_int32, [_P, _P, c_int32, c_int32, c_int32, POINTER(RkPlanes), _BLK, _P, c_int32, _P, _P, _P]),
+  "rk_pg_dw_splits": (c_int32, [c_int32, c_int32, c_int32]),
+  "rk_pg_dw_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
+  "rk_pg_dw": (c_int32, [_P, _P, c_int32, c_int32, c_int32, POINTER(RkPlanes), _BLK, _P, _P]),
+  "rk_pg_dw_encode_bwd": (c_int32, [_P, _P, c_int32, c_int32, c_int32, POINTER(RkPlanes), _BLK, _P, c_int32, _P, _P, _P,
+                                    _P]),
   "rk_dw3_planes_bytes": (c_int64, [c_int32, c_int32]),
   "rk_dw3_rows_pad": (c_int32, [c_int32]),
   "rk_dw3_cols_pad": (c_int32, [c_int32]),

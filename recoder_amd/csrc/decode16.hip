@@ -94,6 +94,11 @@ struct DecP {
   const char *wtp;
   float *dz_ws;
   int h;
+  // ... with dO leaving as a plane IMAGE (csrc/pgemm.h: rk_pg_dw reads it) instead of fp32: C then
+  // holds the image (row m at m * ld * 4 bytes), cut with the tile's scale, published in
+  // dscale[mt * ds_pitch + nt] (granule 64 x 128)
+  float *dscale;
+  int ds_pitch, rows_img;
   // filter epilogue: column n is item col_off + n; blk = the users' INPUT block over the whole
   // catalogue (seen items), has_seen == 0: nothing is masked
   const float *thr;           // [M]
@@ -451,7 +456,7 @@ void decode_planes_kernel(DecP p) {
             else g[e] = 0.f;     // padding columns [N, ld) of the dO row are ZEROS (rk_decode_bwd_dz_planes)
           }
           // (the tiles cover [0, ld): ld = round_up(N, 32) and BN is a multiple of 32)
-          if (m < M && n < ldc)
+          if (m < M && n < ldc && !(DZT > 0 && p.dscale))
             *reinterpret_cast<float4 *>(p.C + (int64_t)m * ldc + n) = make_float4(g[0], g[1], g[2], g[3]);
           if (DZT > 0)      // (rows past M / columns past N hold zeros: g was zeroed above)
             *reinterpret_cast<float4 *>(reinterpret_cast<float *>(smem + DT_OFF) +
@@ -515,6 +520,27 @@ void decode_planes_kernel(DecP p) {
       for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
     __syncthreads();                                     // the epilogue's LDS (transposes, sums) is free
     st_pieces_n<B2_ROWS * 8>(smem, dstB2, rw2, tid);
+    if (p.dscale) {
+      // the dO tile as plane image lines: thread = (row, 32 consecutive columns) = ONE 128-byte line
+      if (tid == 0) p.dscale[mt * p.ds_pitch + nt] = s_do;
+      const int r = tid >> 2, cq = tid & 3;
+      const int m = m0 + r, n = n0 + cq * 32;
+      const int ldi = *p.ld_dev;
+      if (m < p.rows_img && n < ldi) {
+        const float *src = reinterpret_cast<const float *>(smem + DT_OFF) + r * DT_LD + cq * 32;
+        char *d = reinterpret_cast<char *>(p.C) + (int64_t)m * ldi * 4 + (n >> 5) * rkp::LINE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 x0 = *reinterpret_cast<const float4 *>(src + q * 8);
+          const float4 x1 = *reinterpret_cast<const float4 *>(src + q * 8 + 4);
+          uint2 h0, l0, h1, l1;
+          rkp::split4(x0, s_do, h0, l0);
+          rkp::split4(x1, s_do, h1, l1);
+          *reinterpret_cast<uint4 *>(d + q * 16) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+          *reinterpret_cast<uint4 *>(d + 64 + q * 16) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        }
+      }
+    }
     __syncthreads();
     const float *drow = reinterpret_cast<const float *>(smem + DT_OFF) + (wm * 32 + l31) * DT_LD + lh * 8;
     const int b2_off = l31 * ROWB + lh * 16;
@@ -855,8 +881,9 @@ extern "C" void rk_planes_probe(unsigned long long *buffer) { g_probe = buffer; 
 extern "C" void rk_planes_tile(int32_t rows) { g_dec_tm = rows == 64 ? 1 : (rows == 128 ? 2 : 0); }
 
 extern "C" int64_t rk_planes_bytes(int32_t B_cap, int32_t h, int32_t n_cap) {
+  // (image rows in whole groups of 32: csrc/pgemm.h reads an image along its rows in 32-row k-tiles)
   const int64_t KT = rkp::kp_of(h) / 32, n_ld = rkp::kp_of(n_cap);
-  return 256 + align256((int64_t)B_cap * KT * rkp::LINE) + align256((int64_t)n_cap * KT * rkp::LINE) +
+  return 256 + align256((int64_t)rkp::kp_of(B_cap) * KT * rkp::LINE) + align256(n_ld * KT * rkp::LINE) +
          align256((int64_t)rkp::kp_of(h) * (n_ld / 32) * rkp::LINE);
 }
 
@@ -867,8 +894,8 @@ extern "C" int rk_planes_layout(void *buffer, int32_t B_cap, int32_t h, int32_t 
   char *b = (char *)buffer;
   out->scales = (float *)b;
   out->z = b + 256;
-  out->w = (char *)out->z + align256((int64_t)B_cap * KT * rkp::LINE);
-  out->wt = (char *)out->w + align256((int64_t)n_cap * KT * rkp::LINE);
+  out->w = (char *)out->z + align256((int64_t)rkp::kp_of(B_cap) * KT * rkp::LINE);
+  out->wt = (char *)out->w + align256(n_ld * KT * rkp::LINE);
   out->h = h; out->B_cap = B_cap; out->n_cap = n_cap; out->n_ld = (int32_t)n_ld;
   return 0;
 }
@@ -1086,10 +1113,37 @@ extern "C" int32_t rk_decode_dz_fused_ok(int32_t B, int32_t h, int32_t n_cap, in
          dz_fused_slabs_ok(h, n_cap) ? 1 : 0;
 }
 
+static int decode_loss_dz_impl(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off,
+                               const float *b_de, int32_t loss_kind, float confidence, float inv_B, float *dO,
+                               float *loss_part, float *gb_part, float *dz_workspace, float *dO_scales,
+                               int32_t rows_img, void *stream_);
+
 extern "C" int rk_decode_loss_dz_planes(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt,
                                         int32_t row_off, const float *b_de, int32_t loss_kind,
                                         float confidence, float inv_B, float *dO, float *loss_part,
                                         float *gb_part, float *dz_workspace, void *stream_) {
+  return decode_loss_dz_impl(pl, B, tgt, row_off, b_de, loss_kind, confidence, inv_B, dO, loss_part, gb_part,
+                             dz_workspace, nullptr, 0, stream_);
+}
+
+// ... with dLoss/dLogits leaving as a plane IMAGE (row m at byte m * ld * 4 of dO_img, rows
+// [B, round_up(B, 32)) zeros) cut with each 64 x 128 tile's own scale (dO_scales[(m / 64) *
+// ceil(n_cap / 128) + n / 128]): the operand of rk_pg_dw
+extern "C" int rk_decode_loss_dz_image(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt,
+                                       int32_t row_off, const float *b_de, int32_t loss_kind,
+                                       float confidence, float inv_B, void *dO_img, int32_t rows_img,
+                                       float *dO_scales, float *loss_part, float *gb_part,
+                                       float *dz_workspace, void *stream_) {
+  RK_REQUIRE(dO_scales != nullptr && rows_img >= ((B + 31) & ~31) && aligned16(dO_img),
+             "dO image: 16-byte aligned, round_up(B, 32) rows, a scale table");
+  return decode_loss_dz_impl(pl, B, tgt, row_off, b_de, loss_kind, confidence, inv_B, (float *)dO_img, loss_part,
+                             gb_part, dz_workspace, dO_scales, rows_img, stream_);
+}
+
+static int decode_loss_dz_impl(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off,
+                               const float *b_de, int32_t loss_kind, float confidence, float inv_B, float *dO,
+                               float *loss_part, float *gb_part, float *dz_workspace, float *dO_scales,
+                               int32_t rows_img, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(pl && B <= pl->B_cap && tgt->n_cap <= pl->n_cap, "planes were laid out for another shape");
   RK_REQUIRE(row_off >= 0 && row_off + B <= tgt->S_cap, "row slice out of range");
@@ -1107,6 +1161,7 @@ extern "C" int rk_decode_loss_dz_planes(const rk_planes_t *pl, int32_t B, const 
   p.loss_part = loss_part; p.gb_part = gb_part;
   p.ld_dev = tgt->counts + 2;
   p.wtp = (const char *)pl->wt; p.dz_ws = dz_workspace; p.h = pl->h;
+  p.dscale = dO_scales; p.ds_pitch = rk_cdiv(tgt->n_cap, 128); p.rows_img = rows_img;
   const int BM = 64, BN = 128;
   const int grid = rk_cdiv(rk_cdiv(B, BM) * rk_cdiv(tgt->n_cap, BN), 8) * 8;
   const int lds = 256 * ROWB + 64 * 132 * 4;            // W^T stage | dO tile (the k-loop's stages fit below)

@@ -6,15 +6,23 @@
 
 namespace {
 
-template <int HV>
+// DYN: the body's LDS scratch is carved from `sm` (a kernel with dynamic LDS: csrc/pgemm.hip) instead of
+// static arrays
+template <int HV, bool DYN = false>
 __device__ __forceinline__ void ae_encode_bwd_body(
     const rk_block_t &b, int row_off, int B, const float *__restrict__ dZ, int h,
     float *__restrict__ G, int accumulate, float *__restrict__ gb, int n_gb, int bid,
-    int n_seg = 1, int64_t seg_stride = 0) {
+    int n_seg = 1, int64_t seg_stride = 0, char *sm = nullptr) {
   // one workgroup per sampled item column; its 4 waves take the 64-row groups
   // round-robin (popular items hold hundreds of entries -- a single wave per
   // column serialised them into the kernel's tail) and combine in fixed order
-  __shared__ __attribute__((aligned(16))) float part[3][HV * 256];
+  float (*part)[HV * 256];
+  if constexpr (DYN) {
+    part = reinterpret_cast<float (*)[HV * 256]>(sm);
+  } else {
+    __shared__ __attribute__((aligned(16))) float part_s[3][HV * 256];
+    part = part_s;
+  }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (bid < n_gb) {
     // encoder-bias gradient, 64 columns x one of n_seg row segments per workgroup:
@@ -148,18 +156,31 @@ __device__ __forceinline__ void ae_encode_bwd_body(
 // 2048), lists its rows in ascending order, fetches their values in parallel and then streams the
 // dZ rows, 8 loads in flight.  Columns with more than 64 entries are done afterwards by the 4 waves
 // of the workgroup together (64-row groups round-robin, combined in fixed order).
-template <int HV>
+template <int HV, bool DYN = false>
 __device__ __forceinline__ void ae_encode_bwd_cols_body(
     const rk_block_t &b, int row_off, int B, const float *__restrict__ dZ, int h,
-    float *__restrict__ G, int accumulate, float *__restrict__ gb, int n_gb, const int bid) {
+    float *__restrict__ G, int accumulate, float *__restrict__ gb, int n_gb, const int bid,
+    char *sm = nullptr) {
   if (bid < n_gb) {                 // encoder-bias gradient: the shared body's first branch
-    ae_encode_bwd_body<HV>(b, row_off, B, dZ, h, G, accumulate, gb, n_gb, bid);
+    ae_encode_bwd_body<HV, DYN>(b, row_off, B, dZ, h, G, accumulate, gb, n_gb, bid, 1, 0, sm);
     return;
   }
-  __shared__ __attribute__((aligned(16))) float part[3][HV * 256];
-  __shared__ uint16_t rows_l[4][64];
-  __shared__ uint16_t rows_h[2048 + 64];
-  __shared__ int heavy_l[4];          // entries of wave w's column if it is a heavy one, else 0
+  float (*part)[HV * 256];
+  uint16_t (*rows_l)[64];
+  uint16_t *rows_h;
+  int *heavy_l;                       // entries of wave w's column if it is a heavy one, else 0
+  if constexpr (DYN) {
+    part = reinterpret_cast<float (*)[HV * 256]>(sm);
+    rows_l = reinterpret_cast<uint16_t (*)[64]>(sm + 3 * HV * 256 * 4);
+    rows_h = reinterpret_cast<uint16_t *>(sm + 3 * HV * 256 * 4 + 4 * 64 * 2);
+    heavy_l = reinterpret_cast<int *>(sm + 3 * HV * 256 * 4 + 4 * 64 * 2 + (2048 + 64) * 2);
+  } else {
+    __shared__ __attribute__((aligned(16))) float part_s[3][HV * 256];
+    __shared__ uint16_t rows_l_s[4][64];
+    __shared__ uint16_t rows_h_s[2048 + 64];
+    __shared__ int heavy_l_s[4];
+    part = part_s; rows_l = rows_l_s; rows_h = rows_h_s; heavy_l = heavy_l_s;
+  }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int n_b = b.counts[0];
   // wave w of workgroup i takes column i + w * Q, Q = ceil(n_b / 4): columns that are neighbours

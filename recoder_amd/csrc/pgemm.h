@@ -46,11 +46,29 @@ struct Opnd {
   int rows;             // allocated image rows (KC: clamp of the tile's rows; TR: a multiple of 32)
 };
 
+// Per-tile power-of-two scales of the A operand when it is a dO image written by a loss epilogue (the
+// tile's maximum is only known to the workgroup that computed it: every (gr x gc) granule of dO carries
+// its own scale, tab[(row / gr) * pitch + col / gc]).  The consumer keeps its accumulators in the scale
+// of the granule it is in and multiplies them by new / old -- a power of two: exact -- when the k-loop
+// crosses into another one.  mode 1: A(m, k) = dO[m][k] (dZ: rows = m, k = columns); mode 2: A(m, k) =
+// dO[k][m] (dW: rows = k).
+struct Rescale {
+  const float *tab;
+  int gr, gc, pitch;
+  int mode;
+};
+
 struct Core {
   Opnd a, b;
   int M, N, K;                         // problem size (a capacity where the live size is on the device)
   const int32_t *Mdev, *Ndev, *Kdev;   // nullable: live sizes on the device
-  int splits;                          // split-K: slabs
+  const int32_t *a_ld_dev;             // nullable: A is a dO image whose row pitch (4 * ld bytes) and line
+                                       // count (ld / 32) are device-resident (rk_block_t.counts[2])
+  int splits;                          // split-K: slabs (auto_slots > 0: the most there can be)
+  int auto_slots;                      // > 0: the slab count follows the LIVE tile count on the device --
+                                       // min(splits, auto_slots / live tiles, k-tiles / 2), at least 1 --
+  int32_t *splits_out;                 // and is published here (the consumer of the slabs reads it)
+  Rescale rs;
 };
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -60,8 +78,8 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 // NW waves; the stage is R * 128 bytes = R / 8 wave-instructions of 1 KB, Q = R / 8 / NW per wave
 template <int R, bool TR, int NW>
 struct Stager {
-  static constexpr int Q = R / 8 / NW;
-  static_assert(R % (8 * NW) == 0, "tile extent must be a multiple of 8 * waves");
+  static constexpr int Q = R / 8 / NW;       // (NW = number of ISSUING waves)
+  static_assert(R % (8 * NW) == 0, "tile extent must be a multiple of 8 * issuing waves");
   const char *src[Q];
   int64_t step;
 
@@ -162,17 +180,26 @@ __device__ __forceinline__ bool tile_of(const int L, const int total, int &t) {
   return (L >> 3) < chunk && t < total;
 }
 
-template <int BM, int BN, int WM, int WN, bool ATR, bool BTR, class Epi>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const Core p, const typename Epi::Args ea) {
+// VAR (tuning variants, bit mask): 1 = the DMAs of a stage are issued by the first half of the waves only
+// (the other half -- their partners on the SIMDs -- start on the MFMAs at once); 2 = s_setprio(1) around
+// the MFMA clusters
+template <int BM, int BN, int WM, int WN, bool ATR, bool BTR, class Epi, int VAR = 0, bool RS = false>
+__device__ __forceinline__ void gemm_body(const Core &p, const typename Epi::Args &ea, const int L, char *smem) {
   constexpr int NW = WM * WN, TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int NI = (VAR & 1) ? NW / 2 : NW;          // issuing waves
   constexpr int A_BYTES = BM * LINE, STAGE = (BM + BN) * LINE;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int M = p.Mdev ? *p.Mdev : p.M, N = p.Ndev ? *p.Ndev : p.N, K = p.Kdev ? *p.Kdev : p.K;
   Tile T;
   T.M = M; T.N = N;
   T.tm = (M + BM - 1) / BM; T.tn = (N + BN - 1) / BN;
   const int per_split = T.tm * T.tn;
-  if (!tile_of((int)blockIdx.x, per_split * p.splits, T.t)) return;
+  int splits = p.splits;
+  if (p.auto_slots > 0) {
+    splits = min(splits, max(1, p.auto_slots / max(1, per_split)));
+    splits = min(splits, max(1, ((K + 31) >> 5) >> 1));
+    if (L == 0 && threadIdx.x == 0 && p.splits_out) *p.splits_out = splits;
+  }
+  if (!tile_of(L, per_split * splits, T.t)) return;
   T.split = T.t / per_split;
   const int rt = T.t % per_split;
   T.mt = rt % T.tm; T.nt = rt / T.tm;
@@ -182,7 +209,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const Core p, const 
   T.wm = T.wave / WN; T.wn = T.wave % WN;
   // k range of this slab, in k-tiles of 32
   const int nk_all = (K + 31) >> 5;
-  const int kchunk = (nk_all + p.splits - 1) / p.splits;
+  const int kchunk = (nk_all + splits - 1) / splits;
   const int kt0 = T.split * kchunk;
   const int nk = min(kchunk, nk_all - kt0);
 
@@ -194,29 +221,66 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const Core p, const 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // scale of the dO granule each 32-row block of the wave's accumulators is in (Rescale)
+  float cur[TM];
+  int rs_fix[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) { cur[i] = 1.0f; rs_fix[i] = 0; }
+  if (RS && nk > 0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int rb = min(T.m0 + (T.wm * TM + i) * 32, M - 1);
+      rs_fix[i] = p.rs.mode == 1 ? (rb / p.rs.gr) * p.rs.pitch : rb / p.rs.gc;
+      cur[i] = p.rs.tab[rs_fix[i] + (p.rs.mode == 1 ? (kt0 * 32) / p.rs.gc : ((kt0 * 32) / p.rs.gr) * p.rs.pitch)];
+    }
+  }
+
   if (nk > 0) {
-    Stager<BM, ATR, NW> sa;
-    Stager<BN, BTR, NW> sb;
-    sa.init(p.a, T.m0, kt0, ATR ? 0 : min(M, p.a.rows), T.wave, T.lane);
-    sb.init(p.b, T.n0, kt0, BTR ? 0 : min(N, p.b.rows), T.wave, T.lane);
+    Opnd oa = p.a;
+    if (p.a_ld_dev) { oa.lines = *p.a_ld_dev >> 5; oa.pitch = (int64_t)oa.lines * LINE; }
+    Stager<BM, ATR, NI> sa;
+    Stager<BN, BTR, NI> sb;
+    const bool issuer = T.wave < NI;
+    const int iw = issuer ? T.wave : 0;
+    sa.init(oa, T.m0, kt0, ATR ? 0 : min(M, p.a.rows), iw, T.lane);
+    sb.init(p.b, T.n0, kt0, BTR ? 0 : min(N, p.b.rows), iw, T.lane);
     typename FragSel<BM, ATR>::type fa;
     typename FragSel<BN, BTR>::type fb;
     fa.init(T.lane);
     fb.init(T.lane);
-    sa.issue(smem, T.wave);
-    sb.issue(smem + A_BYTES, T.wave);
+    if (issuer) {
+      sa.issue(smem, iw);
+      sb.issue(smem + A_BYTES, iw);
+    }
     for (int kt = 0; kt < nk; ++kt) {
       // tile kt has landed (every wave waits for its own DMAs, then the barrier) and every wave is
       // done reading the other stage (its MFMAs of iteration kt - 1 consumed those fragments)
       __syncthreads();
-      if (kt + 1 < nk) {
+      if (kt + 1 < nk && issuer && !((VAR & 16) && kt >= 1)) {
         char *nx = smem + ((kt + 1) & 1) * STAGE;
-        sa.issue(nx, T.wave);
-        sb.issue(nx + A_BYTES, T.wave);
+        sa.issue(nx, iw);
+        sb.issue(nx + A_BYTES, iw);
       }
       const char *SA = smem + (kt & 1) * STAGE + (T.wm * TM) * 4096 * (ATR ? 0 : 1);
       const char *SB = smem + (kt & 1) * STAGE + A_BYTES + (T.wn * TN) * 4096 * (BTR ? 0 : 1);
       const int ta = ATR ? T.wm * TM : 0, tb = BTR ? T.wn * TN : 0;
+      if (VAR & 4) continue;            // (probe: DMA + barrier only)
+      if (RS) {
+        const int k = (kt0 + kt) * 32;
+        const int kv = p.rs.mode == 1 ? k / p.rs.gc : (k / p.rs.gr) * p.rs.pitch;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float sn = p.rs.tab[rs_fix[i] + kv];
+          if (sn != cur[i]) {                        // (wave-uniform: a granule boundary)
+            const float f = sn / cur[i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
+            cur[i] = sn;
+          }
+        }
+      }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         f16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -224,6 +288,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const Core p, const 
         for (int i = 0; i < TM; ++i) { ah[i] = fa.load(SA, ta + i, ks, 0); al[i] = fa.load(SA, ta + i, ks, 1); }
 #pragma unroll
         for (int j = 0; j < TN; ++j) { bh[j] = fb.load(SB, tb + j, ks, 0); bl[j] = fb.load(SB, tb + j, ks, 1); }
+        if (VAR & 2) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -239,10 +304,28 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const Core p, const 
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        if (VAR & 2) __builtin_amdgcn_s_setprio(0);
       }
     }
   }
-  Epi::template run<BM, BN, TM, TN>(ea, T, acc, smem);
+  if (VAR & 8) {                        // (probe: no epilogue -- keep the accumulators alive)
+    float x = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x += acc[i][j][r];
+    if (x == 1.2345e-30f) *reinterpret_cast<float *>(smem) = x;
+    return;
+  }
+  Epi::template run<BM, BN, TM, TN>(ea, T, acc, smem, cur);
+}
+
+template <int BM, int BN, int WM, int WN, bool ATR, bool BTR, class Epi, int VAR = 0, bool RS = false>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const Core p, const typename Epi::Args ea) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_body<BM, BN, WM, WN, ATR, BTR, Epi, VAR, RS>(p, ea, (int)blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------ plain store epilogue
@@ -257,7 +340,8 @@ struct EpiStore {
     float scale;             // used when scales == null
   };
   template <int BM, int BN, int TM, int TN>
-  static __device__ __forceinline__ void run(const Args &e, const Tile &T, f32x16 (&acc)[TM][TN], char *) {
+  static __device__ __forceinline__ void run(const Args &e, const Tile &T, f32x16 (&acc)[TM][TN], char *,
+                                             const float (&cur)[TM]) {
     const float inv = e.scales ? 1.0f / (e.scales[0] * e.scales[1]) : e.scale;
     float *C = e.C + (int64_t)T.split * e.slab_stride;
     const int l31 = T.lane & 31, lh = T.lane >> 5;
@@ -269,20 +353,28 @@ struct EpiStore {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = T.m0 + (T.wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m < T.M && n < T.N) C[(int64_t)m * e.ldc + n] = acc[i][j][r] * inv;
+          if (m < T.M && n < T.N) C[(int64_t)m * e.ldc + n] = acc[i][j][r] * (inv / cur[i]);
         }
       }
   }
 };
 
-template <int BM, int BN, int WM, int WN, bool ATR, bool BTR, class Epi>
+// workgroups of a launch over tiles_cap tiles: with a device-chosen slab count the live workgroups are
+// the first tiles(live) * splits(live) of the grid, never more than max(tiles_cap, auto_slots)
+inline int grid_of(const Core &p, int tiles_cap) {
+  const int wgs = p.auto_slots > 0 ? (tiles_cap > p.auto_slots ? tiles_cap : (tiles_cap * p.splits < p.auto_slots ? tiles_cap * p.splits : p.auto_slots))
+                                   : tiles_cap * p.splits;
+  return ((wgs + 7) / 8) * 8;
+}
+
+template <int BM, int BN, int WM, int WN, bool ATR, bool BTR, class Epi, int VAR = 0, bool RS = false>
 inline hipError_t launch(const Core &p, const typename Epi::Args &ea, int tiles_cap, hipStream_t s) {
   constexpr int LDS = 2 * (BM + BN) * LINE;
-  auto k = gemm_kernel<BM, BN, WM, WN, ATR, BTR, Epi>;
+  auto k = gemm_kernel<BM, BN, WM, WN, ATR, BTR, Epi, VAR, RS>;
   static const hipError_t attr =
       hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (attr != hipSuccess) return attr;
-  const int grid = ((tiles_cap * p.splits + 7) / 8) * 8;
+  const int grid = grid_of(p, tiles_cap);
   hipLaunchKernelGGL(k, dim3(grid), dim3(WM * WN * 64), LDS, s, p, ea);
   return hipGetLastError();
 }

@@ -1,0 +1,256 @@
+// C ABI of the pipelined pair-plane contractions (csrc/pgemm.h, csrc/pgemm_epi.h): the decoder's three
+// products of a training step on THREE operand images and nothing else,
+//
+//   rk_pg_decode_loss : O = Z . W_de[T]^T + b (reference nn.py:271-280) + MSE / BCE loss epilogue
+//                       (losses.py:43-47, torch BCEWithLogits); dLoss/dLogits leaves as a plane image of
+//                       fp16 pairs with per-tile scales (never as fp32)
+//   rk_pg_dz          : dZ = dO . W_de[T]      (autograd of F.linear w.r.t. its input)   A = dO image,
+//                       B = the W image read along its rows (LDS transpose reads): no W^T image
+//   rk_pg_dw          : dW = dO^T . Z          (autograd of F.linear w.r.t. the weight)  both operands
+//                       read along their rows: no transposed dO, no Z^T planes
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "common.h"
+#include "encoder_bwd.h"
+#include "pgemm_epi.h"
+#include "planes.h"
+
+int rk_splitk_reduce_tiles(const float *ws, int M, int N, const int32_t *Kdev, int max_splits, int tile_k,
+                           const float *Zact, int act, float *out, void *stream);
+
+namespace {
+
+inline bool al16(const void *q) { return ((uintptr_t)q & 15) == 0; }
+
+// tile of the decode by the problem's size (the capacity: the live item count is on the device)
+inline void decode_tile(int B, int n_cap, int &bm, int &bn) {
+  static const int force = [] { const char *e = getenv("RK_PG_TILE"); return e ? atoi(e) : 0; }();   // (tuning)
+  if (force == 256 || (force == 0 && B >= 1024)) { bm = 256; bn = 256; return; }
+  if (force == 1282 || (force == 0 && n_cap >= 16384)) { bm = 128; bn = 256; return; }
+  bm = 128; bn = 128;
+}
+
+inline int dz_splits_for(int B, int h, int bm, int bn) {
+  const int tiles = rk_cdiv(B, bm) * rk_cdiv(h, bn);
+  int s = 512 / std::max(1, tiles);
+  return std::min(64, std::max(1, s));
+}
+inline void dz_tile(int B, int h, int &bm, int &bn) {
+  bn = h <= 128 ? 128 : 256;
+  bm = B >= 1024 ? 256 : 128;
+}
+inline void dw_tile(int h, int n_cap, int &bm, int &bn) {
+  // long item sets: 256 x 256 (or x 128) tiles; else 64 x 128 on 4 waves -- 48 KB of LDS, so that the
+  // encoder backward's workgroups of the same launch (rk_pg_dw_encode_bwd) still run three to a CU
+  if (n_cap >= 32768) { bm = 256; bn = h <= 128 ? 128 : 256; return; }
+  bm = 64; bn = 128;
+}
+
+// dW tiles || encoder-backward columns in ONE launch (as dw3.hip's dw_encbwd_kernel): they need only what
+// the launches in front of them left (the dO image + Z image; dZ0 + the block) and write disjoint outputs
+struct EncBwd {
+  rk_block_t b;
+  int row_off, B;
+  const float *dZ;
+  int h;
+  float *G, *gb;
+  int n_gb;
+};
+template <int BM, int BN, int WM, int WN, int HV>
+__global__ __launch_bounds__(WM * WN * 64) void dw_encbwd_kernel(const pg::Core p, const pg::EpiSlab::Args e,
+                                                                const int n_dw, const EncBwd enc) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x < n_dw) {
+    pg::gemm_body<BM, BN, WM, WN, true, true, pg::EpiSlab, 0, true>(p, e, (int)blockIdx.x, smem);
+    return;
+  }
+  if (threadIdx.x >= 256) return;
+  ae_encode_bwd_cols_body<HV, true>(enc.b, enc.row_off, enc.B, enc.dZ, enc.h, enc.G, 0, enc.gb, enc.n_gb,
+                                    (int)blockIdx.x - n_dw, smem);
+}
+constexpr int DW_MAX_SPLITS = 4, DW_SLOTS = 256;    // (the slab count follows the LIVE item count: pg::Core.auto_slots)
+
+}  // namespace
+
+// RK_PG=0: the round-3 plane kernels everywhere (A/B switch)
+extern "C" int32_t rk_pg_enabled(void) {
+  static const int on = [] { const char *e = getenv("RK_PG"); return (e && atoi(e) == 0) ? 0 : 1; }();
+  return on;
+}
+
+// scale granule of rk_pg_decode_loss's image: 64 rows x 32 columns
+extern "C" void rk_pg_decode_granule(int32_t B, int32_t n_cap, int32_t *gr, int32_t *gc) {
+  (void)B; (void)n_cap;
+  *gr = 64; *gc = 32;
+}
+
+// floats of a scale table that fits every producer (64-row x 32-column granules at the least)
+extern "C" int64_t rk_pg_scale_floats(int32_t B_cap, int32_t n_cap) {
+  return (int64_t)rk_cdiv(B_cap, 64) * rk_cdiv(n_cap, 32) + 64;
+}
+
+extern "C" int rk_pg_decode_loss(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off,
+                                 const float *b_de, int32_t loss_kind, float confidence, float inv_B,
+                                 void *dO_img, int32_t rows_img, float *dO_scales, float *dO_f32,
+                                 float *loss_part, float *gb_part, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(pl && B <= pl->B_cap && tgt->n_cap <= pl->n_cap, "planes were laid out for another shape");
+  RK_REQUIRE(row_off >= 0 && row_off + B <= tgt->S_cap, "row slice out of range");
+  RK_REQUIRE(loss_kind == RK_LOSS_MSE || loss_kind == RK_LOSS_BCE, "mse / logistic epilogues");
+  RK_REQUIRE(tgt->implicit || tgt->pref_rc != nullptr, "explicit values need pref_rc");
+  RK_REQUIRE(dO_img && dO_scales && al16(dO_img) && rows_img >= ((B + 31) & ~31), "dO image: 16-byte aligned, round_up(B, 32) rows");
+  if (B == 0) return 0;
+  int bm, bn;
+  decode_tile(B, tgt->n_cap, bm, bn);
+  // (the logistic epilogue over 8 accumulator tiles per wave is more code than hipcc unrolls: its
+  // accumulators went to scratch memory -- 128 x 256 tiles there)
+  if (bm == 256 && loss_kind == RK_LOSS_BCE) bm = 128;
+  const int KT = rkp::kp_of(pl->h) / 32;
+  pg::Core p = {};
+  p.a.img = (const char *)pl->z; p.a.pitch = (int64_t)KT * pg::LINE; p.a.lines = KT; p.a.rows = pl->B_cap;
+  p.b.img = (const char *)pl->w; p.b.pitch = (int64_t)KT * pg::LINE; p.b.lines = KT; p.b.rows = pl->n_cap;
+  p.M = B; p.N = tgt->n_cap; p.K = pl->h; p.Ndev = tgt->counts; p.splits = 1;
+  pg::LossArgs e = {};
+  e.blk = *tgt; e.row_off = row_off; e.confidence = confidence; e.inv_B = inv_B;
+  e.bias = b_de; e.bidx = tgt->items; e.scales = pl->scales;
+  e.loss_part = loss_part; e.gb_part = gb_part;
+  e.dimg = (char *)dO_img; e.ld_dev = tgt->counts + 2; e.rows_img = rows_img;
+  e.dscale = dO_scales; e.ds_pitch = rk_cdiv(tgt->n_cap, 32);
+  e.C = dO_f32;
+  const int tiles = rk_cdiv(B, bm) * rk_cdiv(tgt->n_cap, bn);
+  hipError_t rc;
+#define GO(BM, BN, WM, WN)                                                                                       \
+  rc = loss_kind == RK_LOSS_MSE                                                                                  \
+           ? pg::launch<BM, BN, WM, WN, false, false, pg::EpiLoss<pg::LOSS_MSE>>(p, e, tiles, stream)            \
+           : pg::launch<BM, BN, WM, WN, false, false, pg::EpiLoss<pg::LOSS_BCE>>(p, e, tiles, stream)
+  if (bm == 256) rc = pg::launch<256, 256, 2, 4, false, false, pg::EpiLoss<pg::LOSS_MSE>>(p, e, tiles, stream);
+  else if (bn == 256) GO(128, 256, 2, 4); else GO(128, 128, 2, 2);
+#undef GO
+  if (rc != hipSuccess) { rk_set_error("pg_decode_loss: %s", hipGetErrorString(rc)); return -1; }
+  return 0;
+}
+
+extern "C" int64_t rk_pg_dz_workspace_bytes(int32_t B, int32_t h) {
+  int bm, bn;
+  dz_tile(B, h, bm, bn);
+  return (int64_t)dz_splits_for(B, h, bm, bn) * B * h * sizeof(float);
+}
+
+extern "C" int rk_pg_dz(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
+                        const rk_planes_t *pl, const rk_block_t *tgt, const float *Zact, int32_t act,
+                        float *dZ, float *workspace, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(pl && tgt->n_cap <= pl->n_cap, "planes were laid out for another shape");
+  RK_REQUIRE(al16(dO_img) && al16(workspace) && al16(dZ) && dO_scales, "operands must be 16-byte aligned");
+  RK_REQUIRE(gr >= 32 && gc >= 32 && gr % 32 == 0 && gc % 32 == 0, "scale granule: multiples of 32");
+  if (B == 0) return 0;
+  const int h = pl->h;
+  int bm, bn;
+  dz_tile(B, h, bm, bn);
+  const int KT = rkp::kp_of(h) / 32;
+  pg::Core p = {};
+  p.a.img = (const char *)dO_img; p.a.rows = B; p.a_ld_dev = tgt->counts + 2;
+  p.a.lines = rk_cdiv(tgt->n_cap, 32); p.a.pitch = (int64_t)p.a.lines * pg::LINE;      // (replaced on the device)
+  p.b.img = (const char *)pl->w; p.b.pitch = (int64_t)KT * pg::LINE; p.b.lines = KT; p.b.rows = pl->n_ld;
+  p.M = B; p.N = h; p.K = tgt->n_cap; p.Kdev = tgt->counts;
+  p.splits = dz_splits_for(B, h, bm, bn);
+  p.rs.tab = dO_scales; p.rs.gr = gr; p.rs.gc = gc; p.rs.pitch = rk_cdiv(tgt->n_cap, gc); p.rs.mode = 1;
+  pg::EpiSlab::Args e = {};
+  e.C = workspace; e.ldc = h; e.slab_stride = (int64_t)B * h; e.bscale = pl->scales + 1;
+  const int tiles = rk_cdiv(B, bm) * rk_cdiv(h, bn);
+  hipError_t rc;
+  if (bm == 256 && bn == 256) rc = pg::launch<256, 256, 2, 4, false, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
+  else if (bm == 256) rc = pg::launch<256, 128, 4, 2, false, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
+  else if (bn == 256) rc = pg::launch<128, 256, 2, 4, false, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
+  else rc = pg::launch<128, 128, 2, 2, false, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
+  if (rc != hipSuccess) { rk_set_error("pg_dz: %s", hipGetErrorString(rc)); return -1; }
+  // every slab is written (an empty K range leaves zeros): summing min(K, splits) of them is the sum
+  return rk_splitk_reduce_tiles(workspace, B, h, tgt->counts, p.splits, 1, Zact, act, dZ, stream_);
+}
+
+// the most K slabs rk_pg_dw writes; the number it did write is published in tgt->counts[4]
+extern "C" int32_t rk_pg_dw_splits(int32_t B, int32_t h, int32_t n_cap) {
+  (void)B; (void)h; (void)n_cap;
+  return DW_MAX_SPLITS;
+}
+extern "C" int64_t rk_pg_dw_workspace_bytes(int32_t B, int32_t h, int32_t n_cap) {
+  return (int64_t)rk_pg_dw_splits(B, h, n_cap) * n_cap * h * sizeof(float);
+}
+
+// slabs [counts[4] <= rk_pg_dw_splits][n_cap][h]: the Adam sweep adds them as it reads the gradient
+// (g_parts / gparts_dev)
+static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
+                      const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, const EncBwd *enc,
+                      void *stream_);
+
+extern "C" int rk_pg_dw(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
+                        const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, void *stream_) {
+  return pg_dw_impl(dO_img, dO_scales, gr, gc, B, pl, tgt, slabs, nullptr, stream_);
+}
+
+// rk_pg_dw and rk_ae_encode_bwd (rows [row_off, row_off + B) of the block `tgt`; G_en / gb_en as there,
+// nothing accumulated) in ONE launch
+extern "C" int rk_pg_dw_encode_bwd(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc,
+                                   int32_t B, const rk_planes_t *pl, const rk_block_t *tgt, float *slabs,
+                                   int32_t row_off, const float *dZ0pre, float *G_en, float *gb_en,
+                                   void *stream_) {
+  RK_REQUIRE(rk_dw_encode_bwd_fused_ok(row_off, B), "outside the fused launch's domain (rk_dw_encode_bwd_fused_ok)");
+  RK_REQUIRE(pl && pl->h % 4 == 0 && pl->h <= 1024, "h must be a multiple of 4, <= 1024");
+  RK_REQUIRE(row_off >= 0 && B >= 0 && row_off + B <= tgt->S_cap, "row slice out of range");
+  RK_REQUIRE(tgt->bits_cr != nullptr && tgt->pref_rc != nullptr,
+             "block was built without the transposed bitmap / prefix index");
+  EncBwd enc = {};
+  enc.b = *tgt; enc.row_off = row_off; enc.B = B; enc.dZ = dZ0pre; enc.h = pl->h; enc.G = G_en; enc.gb = gb_en;
+  enc.n_gb = gb_en ? rk_cdiv(pl->h, 64) : 0;
+  return pg_dw_impl(dO_img, dO_scales, gr, gc, B, pl, tgt, slabs, &enc, stream_);
+}
+
+static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
+                      const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, const EncBwd *enc,
+                      void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(pl && tgt->n_cap <= pl->n_cap && B <= pl->B_cap, "planes were laid out for another shape");
+  RK_REQUIRE(al16(dO_img) && al16(slabs) && dO_scales, "operands must be 16-byte aligned");
+  RK_REQUIRE(gr >= 32 && gc >= 32 && gr % 32 == 0 && gc % 32 == 0, "scale granule: multiples of 32");
+  if (B == 0) return 0;
+  const int h = pl->h;
+  int bm, bn;
+  dw_tile(h, tgt->n_cap, bm, bn);
+  const int KT = rkp::kp_of(h) / 32;
+  pg::Core p = {};
+  p.a.img = (const char *)dO_img; p.a.rows = (B + 31) & ~31; p.a_ld_dev = tgt->counts + 2;
+  p.a.lines = rk_cdiv(tgt->n_cap, 32); p.a.pitch = (int64_t)p.a.lines * pg::LINE;
+  p.b.img = (const char *)pl->z; p.b.pitch = (int64_t)KT * pg::LINE; p.b.lines = KT; p.b.rows = (pl->B_cap + 31) & ~31;
+  p.M = tgt->n_cap; p.Mdev = tgt->counts; p.N = h; p.K = B;
+  p.splits = DW_MAX_SPLITS; p.auto_slots = DW_SLOTS; p.splits_out = tgt->counts + 4;
+  p.rs.tab = dO_scales; p.rs.gr = gr; p.rs.gc = gc; p.rs.pitch = rk_cdiv(tgt->n_cap, gc); p.rs.mode = 2;
+  pg::EpiSlab::Args e = {};
+  e.C = slabs; e.ldc = h; e.slab_stride = (int64_t)tgt->n_cap * h; e.bscale = pl->scales;
+  const int tiles = rk_cdiv(tgt->n_cap, bm) * rk_cdiv(h, bn);
+  hipError_t rc;
+  if (enc) {
+    const int n_dw = pg::grid_of(p, tiles);
+    const int n_enc = rk_cdiv(tgt->n_cap, 4) + enc->n_gb;
+    const int hv = rk_cdiv(h, 256);
+#define GO(BM, BN, WM, WN, HV)                                                                               \
+  do {                                                                                                       \
+    auto k = dw_encbwd_kernel<BM, BN, WM, WN, HV>;                                                           \
+    static const hipError_t attr = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    if (attr != hipSuccess) { rc = attr; break; }                                                            \
+    hipLaunchKernelGGL(k, dim3(n_dw + n_enc), dim3(WM * WN * 64), 2 * (BM + BN) * pg::LINE, stream, p, e, n_dw, *enc); \
+    rc = hipGetLastError();                                                                                  \
+  } while (0)
+#define BY_HV(BM, BN, WM, WN) do { if (hv == 1) GO(BM, BN, WM, WN, 1); else if (hv == 2) GO(BM, BN, WM, WN, 2); else GO(BM, BN, WM, WN, 4); } while (0)
+    if (bm == 256 && bn == 256) BY_HV(256, 256, 2, 4);
+    else if (bm == 256) BY_HV(256, 128, 4, 2);
+    else BY_HV(64, 128, 2, 2);
+#undef BY_HV
+#undef GO
+  } else if (bm == 256 && bn == 256) rc = pg::launch<256, 256, 2, 4, true, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
+  else if (bm == 256) rc = pg::launch<256, 128, 4, 2, true, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
+  else rc = pg::launch<64, 128, 2, 2, true, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
+  if (rc != hipSuccess) { rk_set_error("pg_dw: %s", hipGetErrorString(rc)); return -1; }
+  return 0;
+}

@@ -1,0 +1,243 @@
+// Epilogues of the pipelined pair-plane contraction (csrc/pgemm.h) that need the library's types:
+//   EpiSlab : fp32 slab store of a split-K partial (dZ, dW), the A operand's granule scale divided out
+//   EpiLoss : the decoder's fused loss epilogue (reference losses.py:43-47, torch BCEWithLogits) --
+//             bias gather, target lookup through the block's bitmap, loss partial, column sums (decoder
+//             bias gradient) and dLoss/dLogits written as a PLANE IMAGE of fp16 pairs cut with the
+//             TILE's own power-of-two scale (published in a scale table, pg::Rescale): the dZ and dW
+//             contractions copy that image into LDS like any other operand -- no fp32 dO is written,
+//             no operand is split inside a k-loop any more.
+#pragma once
+#include "common.h"
+#include "pgemm.h"
+#include "planes.h"
+
+namespace pg {
+
+struct EpiSlab {
+  struct Args {
+    float *C;                // [split][M][ldc]
+    int64_t ldc;
+    int64_t slab_stride;     // floats between K slabs
+    const float *bscale;     // device: the B operand's split scale
+  };
+  template <int BM, int BN, int TM, int TN>
+  static __device__ __forceinline__ void run(const Args &e, const Tile &T, f32x16 (&acc)[TM][TN], char *,
+                                             const float (&cur)[TM]) {
+    const float sb = *e.bscale;
+    float *C = e.C + (int64_t)T.split * e.slab_stride;
+    const int l31 = T.lane & 31, lh = T.lane >> 5;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const float inv = 1.0f / (cur[i] * sb);                   // exact: powers of two
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = T.n0 + (T.wn * TN + j) * 32 + l31;
+        if (n < T.N) {
+          float *col = C + n;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = T.m0 + (T.wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m < T.M) col[(int64_t)m * e.ldc] = acc[i][j][r] * inv;
+          }
+        }
+      }
+    }
+  }
+};
+
+enum { LOSS_MSE = 1, LOSS_BCE = 3 };
+
+struct LossArgs {
+    rk_block_t blk;
+    int row_off;
+    float confidence, inv_B;
+    const float *bias;         // decoder bias table
+    const int32_t *bidx;       // compact column -> table row
+    const float *scales;       // [0] Z, [1] W split scales
+    float *loss_part, *gb_part;
+    char *dimg;                // dO image: row m at m * ld * 4 bytes (ld = *ld_dev)
+    const int32_t *ld_dev;
+    int rows_img;              // rows of the image that may be written (>= round_up(M, 32))
+    float *dscale;             // scale table [row / 64][ds_pitch], one entry per 32 columns
+    int ds_pitch;
+    float *C;                  // nullable: dO as fp32 too (tests), leading dimension ld
+};
+
+template <int LOSS>
+struct EpiLoss {
+  typedef LossArgs Args;
+
+  template <int BM, int BN, int TM, int TN>
+  static __device__ __forceinline__ void run(const Args &e, const Tile &T, f32x16 (&acc)[TM][TN], char *smem,
+                                             const float (&)[TM]) {
+    constexpr int TLD = 36;
+    constexpr int NWAVES = (BM / (TM * 32)) * (BN / (TN * 32));
+    const int M = T.M, N = T.N, lane = T.lane;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int rr = lane >> 2, c8 = lane & 3;               // row-major role: rows rr, rr + 16; 8 columns
+    const rk_block_t &b = e.blk;
+    const bool implicit = b.implicit != 0;
+    const int ldc = *e.ld_dev;
+    float *fsm = reinterpret_cast<float *>(smem);
+    float *wlds = fsm + T.wave * (32 * TLD);               // per-wave transposition area
+    float *lred = fsm + NWAVES * (32 * TLD);               // [2 * NWAVES] loss / max partials
+    float *cpart = lred + 2 * NWAVES;                      // [BM / 32][BN] column sums per 32-row block
+    // operands of the loss: gathered bias and bitmap words, all loads in flight before the first use
+    float bv[TN][8];
+    uint32_t bw[TM][TN][2];
+    {
+      int gi[TN][8];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          gi[j][u] = e.bidx[min(T.n0 + (T.wn * TN + j) * 32 + c8 * 8 + u, N - 1)];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int m = T.m0 + (T.wm * TM + i) * 32 + rr + 16 * it;
+            const int row = e.row_off + min(m, M - 1);
+            const int nb = T.n0 + (T.wn * TN + j) * 32;
+            bw[i][j][it] = b.bits_rc[(int64_t)row * b.ldw_rc + min(nb >> 5, b.ldw_rc - 1)];
+          }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bv[j][u] = e.bias[gi[j][u]];
+    }
+    const float inv = 1.0f / (e.scales[0] * e.scales[1]);   // exact: powers of two
+    __syncthreads();                                        // (the k-loop's last stage is free)
+    // Scale granule = 64 rows x 32 columns (two 32 x 32 blocks of one wave): the maximum of a granule is
+    // a WAVE reduction, and only 2 x 16 gradient registers are alive at a time
+    static_assert(TM % 2 == 0, "wave tiles of at least 64 rows");
+    const int64_t pitch = (int64_t)ldc * 4;
+    float lsum = 0.f, gmax_all = 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = T.n0 + (T.wn * TN + j) * 32 + c8 * 8;
+#pragma unroll
+     for (int ih = 0; ih < TM / 2; ++ih) {
+      float G[2][16];
+      float gmax = 0.f;
+#pragma unroll
+      for (int i = 2 * ih; i < 2 * ih + 2; ++i) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) wlds[((r & 3) + 8 * (r >> 2) + 4 * lh) * TLD + l31] = acc[i][j][r] * inv;
+        __builtin_amdgcn_wave_barrier();
+        float cs[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) cs[u] = 0.f;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const float4 v0 = *reinterpret_cast<const float4 *>(wlds + (rr + 16 * it) * TLD + c8 * 8);
+          const float4 v1 = *reinterpret_cast<const float4 *>(wlds + (rr + 16 * it) * TLD + c8 * 8 + 4);
+          const float ov[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          const int m = T.m0 + (T.wm * TM + i) * 32 + rr + 16 * it;
+          const uint32_t w = bw[i][j][it];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const bool ok = (m < M) && (n + u < N);
+            const float o = ov[u] + bv[j][u];
+            float tv = 0.f;
+            if (ok && ((w >> (c8 * 8 + u)) & 1u)) {
+              tv = 1.0f;
+              if (!implicit) tv = b.vals[rk_entry_index(b, e.row_off + m, n + u, w)];
+            }
+            float l, g;
+            if (LOSS == LOSS_MSE) {
+              const float wgt = (tv > 0.f) ? (1.0f + e.confidence) : 1.0f;
+              const float d = o - tv;
+              l = wgt * (d * d);
+              g = (2.0f * d) * (wgt * e.inv_B);
+            } else {  // BCE with logits: (1 - t) * o - logsigmoid(o)
+              const float ls = fminf(o, 0.f) - log1pf(expf(-fabsf(o)));
+              l = (1.0f - tv) * o - ls;
+              const float sg = 1.0f / (1.0f + expf(-o));
+              g = (sg - tv) * e.inv_B;
+            }
+            if (ok) { lsum += l; cs[u] += g; gmax = fmaxf(gmax, fabsf(g)); }
+            else g = 0.f;                 // rows past M / the padding columns [N, ld) are ZEROS in the image
+            G[i & 1][it * 8 + u] = g;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // column sums over the 32 rows of this block: lanes with equal c8 hold different rows
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          cs[u] += __shfl_xor(cs[u], 4, 64);
+          cs[u] += __shfl_xor(cs[u], 8, 64);
+          cs[u] += __shfl_xor(cs[u], 16, 64);
+          cs[u] += __shfl_xor(cs[u], 32, 64);
+        }
+        if (rr == 0) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) cpart[(T.wm * TM + i) * BN + (T.wn * TN + j) * 32 + c8 * 8 + u] = cs[u];
+        }
+      }
+      // the granule's power-of-two scale: max . s in [2^13, 2^14)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
+      gmax_all = fmaxf(gmax_all, gmax);
+      float s_do = 1.0f;
+      if (gmax > 0.f) {
+        const int ex = min(max((int)(__float_as_uint(gmax) >> 23) - 127, -100), 100);
+        s_do = __uint_as_float((uint32_t)(13 - ex + 127) << 23);
+      }
+      // (a tile may overhang the item set / the batch: granule columns past the table's pitch belong to
+      // the NEXT row, granule rows past the batch lie outside the table; neither is ever read)
+      if (lane == 0 && (T.n0 >> 5) + T.wn * TN + j < e.ds_pitch && (T.m0 >> 6) + T.wm * (TM / 2) + ih < ((M + 63) >> 6))
+        e.dscale[(int64_t)((T.m0 >> 6) + T.wm * (TM / 2) + ih) * e.ds_pitch + ((T.n0 >> 5) + T.wn * TN + j)] = s_do;
+      // the image: lane = (2 rows, 8 consecutive columns) of each 32 x 32 block: 16 bytes of hi, 16 of lo
+#pragma unroll
+      for (int i = 2 * ih; i < 2 * ih + 2; ++i)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int m = T.m0 + (T.wm * TM + i) * 32 + rr + 16 * it;
+          if (m < e.rows_img && n < ldc) {
+            uint2 h0, l0, h1, l1;
+            const float *g = &G[i & 1][it * 8];
+            rkp::split4(make_float4(g[0], g[1], g[2], g[3]), s_do, h0, l0);
+            rkp::split4(make_float4(g[4], g[5], g[6], g[7]), s_do, h1, l1);
+            char *d = e.dimg + (int64_t)m * pitch + (n >> 5) * LINE + (n & 31) * 2;
+            *reinterpret_cast<uint4 *>(d) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            *reinterpret_cast<uint4 *>(d + 64) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            if (e.C && m < M) {
+              float *c = e.C + (int64_t)m * ldc + n;
+              *reinterpret_cast<float4 *>(c) = make_float4(g[0], g[1], g[2], g[3]);
+              *reinterpret_cast<float4 *>(c + 4) = make_float4(g[4], g[5], g[6], g[7]);
+            }
+          }
+        }
+     }
+    }
+    lsum = rk_wave_sum(lsum);
+    if (lane == 0) { lred[T.wave] = lsum; lred[NWAVES + T.wave] = gmax_all; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float ls = 0.f, gm = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWAVES; ++w) { ls += lred[w]; gm = fmaxf(gm, lred[NWAVES + w]); }
+      e.loss_part[T.t] = ls;
+      // (the launch-wide maximum, for consumers of an fp32 dO: rk_decode_bwd_dz / dw2)
+      atomicMax(reinterpret_cast<unsigned int *>(b.counts) + 8 + ((int)blockIdx.x & 63), __float_as_uint(gm));
+    }
+    if (e.gb_part) {
+      // one gb_part row per 64 rows of dO (rk_decode_row_tile)
+      for (int c = threadIdx.x; c < BN; c += NWAVES * 64) {
+        const int n = T.n0 + c;
+        if (n < N) {
+#pragma unroll
+          for (int g = 0; g < BM / 64; ++g)
+            if (T.m0 + g * 64 < M)
+              e.gb_part[(int64_t)(T.m0 / 64 + g) * ldc + n] = cpart[(2 * g) * BN + c] + cpart[(2 * g + 1) * BN + c];
+        }
+      }
+    }
+  }
+};
+
+}  // namespace pg

@@ -113,7 +113,8 @@ struct SplitW {
   const int32_t *counts;     // [0] = n_b (device)
   const uint32_t *amax;      // 64 slots: bound of |W| (nullable)
   char *wp;                  // W image   [n rows][KT]
-  char *wtp;                 // W^T image [n_ld / 32 k-tiles][Hp rows]
+  char *wtp;                 // W^T image [n_ld / 32 k-tiles][Hp rows]; NULL: not made (csrc/pgemm.h reads
+                             // the W image along its rows instead)
   float *scales;             // [1] <- the scale used
   int h, KT;                 // KT = kp_of(h) / 32
   int n_ld;                  // items padded (multiple of 32): row pitch of the W^T image = n_ld / 32 lines
@@ -175,12 +176,15 @@ __device__ __forceinline__ void split_w_job(const SplitW &p, const int tile, cha
             *reinterpret_cast<uint2 *>(d) = hi;
             *reinterpret_cast<uint2 *>(d + 64) = lo;
           }
-          uint32_t *dh = reinterpret_cast<uint32_t *>(sh + it * 66 + q * 4);
-          uint32_t *dl = reinterpret_cast<uint32_t *>(sh + 32 * 66 + it * 66 + q * 4);
-          dh[0] = hi.x; dh[1] = hi.y;
-          dl[0] = lo.x; dl[1] = lo.y;
+          if (p.wtp) {
+            uint32_t *dh = reinterpret_cast<uint32_t *>(sh + it * 66 + q * 4);
+            uint32_t *dl = reinterpret_cast<uint32_t *>(sh + 32 * 66 + it * 66 + q * 4);
+            dh[0] = hi.x; dh[1] = hi.y;
+            dl[0] = lo.x; dl[1] = lo.y;
+          }
         }
       }
+      if (p.wtp == nullptr) continue;              // (uniform: no transposed image, no LDS round trip)
       __syncthreads();
       // phase 2: (hidden unit j, 16-byte piece pc): 8 items of one plane -> one piece of the W^T line
       for (int u = tid; u < 64 * 8; u += NT) {

@@ -382,6 +382,26 @@ static int step_item_parallel(const rk_ae_step_t *a, int phase) {
   return 0;
 }
 
+// Does this (whole, single-process) step run its contractions on the pipelined pair-plane kernels
+// (csrc/pgemm.h)?  Untied MSE / BCE steps with operand planes and a scale table, outside the fused
+// decode + dZ launch's domain (h > 256 or >= 1024 rows).
+// Inside the fused decode's domain the decode + dZ launch stays and hands dLoss/dLogits over as an image
+// too (rk_decode_loss_dz_image): dW then runs on rk_pg_dw there as well.
+// Returns 0: neither; 1: all three contractions on csrc/pgemm.h; 2: the fused decode + dZ launch with the
+// image, dW on rk_pg_dw
+static int step_pg_mode(const rk_ae_step_t *a) {
+  const int phase = a->phase == 0 ? RK_STEP_ALL : a->phase;
+  if (phase != RK_STEP_ALL || a->tied || a->loss_kind == RK_LOSS_MNLL) return 0;
+  if (!rk_gemm_split16() || rk_gemm_plain_bf16() || a->ws == nullptr || a->planes == nullptr) return 0;
+  if (a->do_scales == nullptr || !rk_pg_enabled()) return 0;
+  if (rk_decode_dz_fused_ok(a->B, a->h, a->blk->n_cap, a->loss_kind) == 0) return 1;
+  // (opt-in, RK_PG_IMG=1 -- measured at C2: the image pass costs the fused decode launch 6 us (34.0 vs
+  // 28.0) and dW || encoder backward on rk_pg_dw gains 0.8 (23.5 vs 24.3): 0.1222 vs 0.1188 ms per step)
+  static const int img_on = [] { const char *e = getenv("RK_PG_IMG"); return (e && atoi(e) == 1) ? 1 : 0; }();
+  return img_on ? 2 : 0;
+}
+extern "C" int32_t rk_ae_step_uses_pg(const rk_ae_step_t *a) { return (a && a->blk) ? step_pg_mode(a) : 0; }
+
 // The whole step is a serial chain on ONE stream:
 //   encode_fwd ; decode+loss ; dW ; dZ split-K ; reduce ; encode_bwd (+gb_en) ; update
 // (an earlier version ran the dW chain on a second stream: each cross-stream event
@@ -430,6 +450,11 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   // (in the small-shape domain of the fused decode only: at C5's sizes -- dW 100+ us -- the side-stream
   // branch next to dZ -> encoder backward is worth more than its two edges: 0.75 vs 0.83 ms per step)
   const bool dw_enc_fused = dw3 && dz_fused && rk_dw_encode_bwd_fused_ok(a->row_off, B) != 0;
+  // the three contractions on the pipelined pair-plane kernels (csrc/pgemm.h; include/recoder_hip.h
+  // rk_ae_step_t.do_scales): whole untied MSE / BCE steps outside the fused decode's domain
+  const int pg_mode = step_pg_mode(a);
+  const bool pg = pg_mode == 1, img = pg_mode == 2;
+  const float *dw_slabs_pg = dw_branch ? a->ws_dw : a->ws;
   // opt-in (rk_adam_de_side): the decoder table's Adam sweep right behind the dW kernel ON dw_stream,
   // next to the reduce / encoder backward; the update on the chain then covers the rest
   const bool de_side = dw_branch && !dw_enc_fused && phase == RK_STEP_ALL && rk_adam_de_side() != 0;
@@ -439,6 +464,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       if (pl) {
         rk_enc_split_t es = {};
         es.sw = rk_split_w_args(W_de, blk, a->ranges, a->planes);
+        if (pg) es.sw.wtp = nullptr;          // (dZ reads the W image along its rows: no W^T image)
         es.n_split = rk_cdiv(blk->n_cap, 32);
         es.zimg = act_bounded(a->act) ? (char *)a->planes->z : nullptr;
         es.z_kt = rkp::kp_of(h) / 32;
@@ -446,7 +472,8 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
                    "planes were laid out for another shape");
         RK_TRY(rk_ae_encode_fwd_at(blk, a->row_off, B, a->par[RK_PAR_W_EN].p, a->par[RK_PAR_B_EN].p, h,
                                    a->keep, a->noise_p, a->seed, a->cursor, a->cursor_off, a->users,
-                                   a->act, a->Z0, planes ? a->zt_planes : nullptr, sm, &es, a->rng_step));
+                                   a->act, a->Z0, (planes && !pg && !img) ? a->zt_planes : nullptr, sm, &es,
+                                   a->rng_step));
       } else if (a->cursor)
         RK_TRY(rk_ae_encode_fwd_at(blk, a->row_off, B, a->par[RK_PAR_W_EN].p, a->par[RK_PAR_B_EN].p, h,
                                    a->keep, a->noise_p, a->seed, a->cursor, a->cursor_off, a->users,
@@ -465,9 +492,17 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       if (pl) {
         // (unbounded activations: the split scale of Z needs its maximum first)
         if (!act_bounded(a->act)) RK_TRY(rk_split_z(a->Z0, B, h, a->ranges, a->planes, sm));
-        if (dz_fused)
+        if (dz_fused && img)
+          RK_TRY(rk_decode_loss_dz_image(a->planes, B, blk, a->row_off, a->par[RK_PAR_B_DE].p, a->loss_kind,
+                                         a->confidence, a->inv_B, a->dO, a->do_rows, a->do_scales, a->loss_part,
+                                         a->gb_part, a->ws, sm));
+        else if (dz_fused)
           RK_TRY(rk_decode_loss_dz_planes(a->planes, B, blk, a->row_off, a->par[RK_PAR_B_DE].p, a->loss_kind,
                                           a->confidence, a->inv_B, a->dO, a->loss_part, a->gb_part, a->ws, sm));
+        else if (pg)
+          RK_TRY(rk_pg_decode_loss(a->planes, B, blk, a->row_off, a->par[RK_PAR_B_DE].p, a->loss_kind,
+                                   a->confidence, a->inv_B, a->dO, a->do_rows, a->do_scales, nullptr,
+                                   a->loss_part, a->gb_part, sm));
         else
           RK_TRY(rk_decode_loss_planes(a->planes, B, blk, a->row_off, a->par[RK_PAR_B_DE].p, a->loss_kind,
                                        a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, sm));
@@ -500,6 +535,8 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       Timer t(a, RK_ENTRY_DECODE_BWD_DZ, sm);
       if (dz_fused)        // (the decode launch left the column tiles' partials in the workspace)
         RK_TRY(rk_decode_dz_reduce(a->ws, B, h, blk, a->Z0, a->act, a->dZ0, sm));
+      else if (pg)
+        RK_TRY(rk_pg_dz(a->dO, a->do_scales, 64, 32, B, a->planes, blk, a->Z0, a->act, a->dZ0, a->ws, sm));
       else if (pl)
         RK_TRY(rk_decode_bwd_dz_planes(a->dO, B, a->planes, blk, a->Z0, a->act, a->dZ0, a->ws, sm));
       else
@@ -511,6 +548,10 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     } else if (dw_enc_fused) {
       // dW || encoder backward in ONE launch on the chain (dw3.hip dw_encbwd_kernel): no side stream
       Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
+      if (img)
+        RK_TRY(rk_pg_dw_encode_bwd(a->dO, a->do_scales, 64, 128, B, a->planes, blk, dw_branch ? a->ws_dw : a->ws,
+                                   a->row_off, a->dZ0, G_en, a->gb_en, sm));
+      else
       RK_TRY(rk_decode_bwd_dw2_encode_bwd(a->dO, a->Z0, B, h, blk, dw_branch ? a->ws_dw : a->ws,
                                           planes ? a->zt_planes : nullptr, a->ranges, a->row_off, a->dZ0,
                                           G_en, a->gb_en, sm));
@@ -523,7 +564,8 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       RK_TRY(rk_stream_wait_event(a->dw_stream, a->dw_fork));
       {
         Timer t(a, RK_ENTRY_DECODE_BWD_DW, a->dw_stream);
-        RK_TRY(dw_call(a, nullptr, nullptr, planes, a->ws_dw, a->dw_stream));
+        if (pg || img) RK_TRY(rk_pg_dw(a->dO, a->do_scales, 64, pg ? 32 : 128, B, a->planes, blk, a->ws_dw, a->dw_stream));
+        else RK_TRY(dw_call(a, nullptr, nullptr, planes, a->ws_dw, a->dw_stream));
       }
       if (!de_side) {
         RK_TRY(rk_event_record(a->dw_join, a->dw_stream));
@@ -534,7 +576,8 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       // its own K slabs, which rk_adam_multi sums while it reads the gradient)
       {
         Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
-        RK_TRY(dw_call(a, nullptr, nullptr, planes));
+        if (pg || img) RK_TRY(rk_pg_dw(a->dO, a->do_scales, 64, pg ? 32 : 128, B, a->planes, blk, a->ws, sm));
+        else RK_TRY(dw_call(a, nullptr, nullptr, planes));
       }
       Timer t(a, RK_ENTRY_ENCODE_BWD, sm);
       RK_TRY(rk_ae_encode_bwd(blk, a->row_off, B, a->dZ0, h, G_en, 0, a->gb_en, sm));
@@ -557,7 +600,10 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     if (!a->tied) {
       jobs[n] = table_job(a->par[RK_PAR_W_DE], blk, n_items, h, a->G_de, true);
       if (a->ranges) jobs[n].amax_out = a->ranges + 64;
-      if (dw3) {
+      if (pg || img) {
+        jobs[n].g = dw_slabs_pg; jobs[n].g_parts = rk_pg_dw_splits(B, h, blk->n_cap);
+        jobs[n].g_stride = blk->n_cap * h; jobs[n].gparts_dev = blk->counts + 4;
+      } else if (dw3) {
         jobs[n].g = rk_dw3_slabs(dw_branch ? a->ws_dw : a->ws, B, h); jobs[n].g_parts = rk_dw3_max_splits();
         jobs[n].g_stride = blk->n_cap * h; jobs[n].gparts_dev = blk->counts + 4;
       }

@@ -51,6 +51,8 @@ class TimedLib:
                                               "rk_dw3_workspace_bytes", "rk_dw3_max_splits", "rk_dw3_slabs", "rk_gemm_split16", "rk_dw_pairs",
                                               "rk_dw3_planes_bytes", "rk_dw3_rows_pad", "rk_dw3_cols_pad",
                                               "rk_planes_bytes", "rk_planes_layout", "rk_split_zt_ok",
+                                              "rk_pg_enabled", "rk_pg_scale_floats", "rk_pg_decode_granule",
+                                              "rk_pg_dz_workspace_bytes", "rk_pg_dw_workspace_bytes", "rk_pg_dw_splits",
                                               "rk_last_error", "rk_version"):
       return fn
 
@@ -149,7 +151,12 @@ class FusedEngine:
     self.B_cap, self.n_cap, self.ld_cap = B_cap, n_cap, ld_cap
     # (zeroed: the padding columns [n_b, ld) of its rows meet the zeros of the W^T plane image in the
     # dZ contraction and must be finite)
-    self.dO = torch.zeros(B_cap * ld_cap, **f)
+    # (rows in whole groups of 32: as a plane IMAGE -- csrc/pgemm.h, the same footprint -- dW reads it
+    # along its rows in 32-row k-tiles)
+    self.do_rows = cdiv(B_cap, 32) * 32
+    self.dO = torch.zeros(self.do_rows * ld_cap, **f)
+    # per-granule split scales of that image (rk_pg_decode_loss)
+    self.do_scales = torch.ones(self.lib.rk_pg_scale_floats(B_cap, n_cap), **f)
     self.G_de = torch.empty(n_cap * h0, **f)
     # MF: [B | the step's user rows as int32] left by the forward's gather for the SparseAdam job of
     # the user table (rk_gather_rows_amax)
@@ -173,11 +180,14 @@ class FusedEngine:
                               # (any batch below 1024 rows -- a ragged last one too -- may take the fused form)
                               self.lib.rk_dz_fused_workspace_bytes(min(B_cap, 1023), h0, n_cap),
                               self.lib.rk_dw_workspace_bytes(B_cap, h0, n_cap),
-                              self.lib.rk_dw3_workspace_bytes(B_cap, h0, n_cap)) // 4 + 64, **f)
+                              self.lib.rk_dw3_workspace_bytes(B_cap, h0, n_cap),
+                              self.lib.rk_pg_dz_workspace_bytes(B_cap, h0),
+                              self.lib.rk_pg_dw_workspace_bytes(B_cap, h0, n_cap)) // 4 + 64, **f)
     self.split16 = bool(self.lib.rk_gemm_split16())
     self._dw_slabs = None
     # dW as a branch of the one-call step (rk_ae_step_t.dw_stream): a workspace of its own
-    self.ws_dw = (torch.zeros(self.lib.rk_dw3_workspace_bytes(B_cap, h0, n_cap) // 4 + 64, **f)
+    self.ws_dw = (torch.zeros(max(self.lib.rk_dw3_workspace_bytes(B_cap, h0, n_cap),
+                                  self.lib.rk_pg_dw_workspace_bytes(B_cap, h0, n_cap)) // 4 + 64, **f)
                   if self.split16 and self.dw_branch else None)
     # Z^T as bf16 planes for the dW kernel, written by the encoder forward of the one-call step
     # (zeroed once: the padding columns are never written)
@@ -893,6 +903,7 @@ class FusedEngine:
     st.zt_planes = ptr(self.zt_planes)
     st.planes = (ctypes.addressof(self.planes)
                  if self.planes is not None and self.item_parallel is None else None)
+    st.do_scales, st.do_rows = ptr(self.do_scales), self.do_rows
     self._check_weight_range()
     st.ranges = ptr(self.ranges)
     plain = dp is None and not m.is_constrained and self.loss_id != LOSS_MNLL
@@ -926,6 +937,7 @@ class FusedEngine:
         st.cursor_next, st.cursor_advance = replay["next"]
       st.users = replay["users"]             # base of the epoch's user order (offset on the device)
     self._c_calls += 1
+    self._pg_step = False
     name = None
     if self.time_plan is not None and (replay is None or replay.get("timed")):
       name = self.time_plan(replay["index"] if replay is not None else self._c_calls)
@@ -969,6 +981,7 @@ class FusedEngine:
         self._gb_lazy = (cdiv(B, self.row_tile), blk)
     elif dp is None:
       st.phase = STEP_ALL
+      self._pg_step = bool(raw.rk_ae_step_uses_pg(ctypes.byref(st)))
       check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
       if self.loss_id != LOSS_MNLL:
         self._gb_lazy = (cdiv(B, self.row_tile), blk)
@@ -1040,8 +1053,12 @@ class FusedEngine:
     if self._dw_slabs is None:
       return self.G_de[:n_b * h0].view(n_b, h0).clone()
     blk, B = self._dw_slabs
-    ns = int(blk.counts[4].item())
     ws = self.ws_dw if getattr(self, "_ws_dw_live", False) else self.ws
+    if getattr(self, "_pg_step", False):           # rk_pg_dw: the slabs start at the workspace's head
+      ns, off = int(blk.counts[4].item()), 0
+      stride = blk.n_cap * h0
+      return sum(ws[off + k * stride:off + k * stride + n_b * h0].view(n_b, h0) for k in range(ns))
+    ns = int(blk.counts[4].item())
     off = (self.lib.rk_dw3_slabs(ptr(ws), B, h0) - ws.data_ptr()) // 4
     stride = blk.n_cap * h0
     return sum(ws[off + k * stride:off + k * stride + n_b * h0].view(n_b, h0) for k in range(ns))

@@ -62,12 +62,27 @@ static int tr_semantic() {
 
 struct Case { int M, N, K, cfg, atr, btr, splits; };
 
+static int g_var = 0;      // tuning variant (pgemm.h VAR): env VAR
+
+template <int BM, int BN, int WM, int WN, int VAR>
+static hipError_t dispatch_v(const pg::Core &p, const pg::EpiStore::Args &e, int atr, int btr, int tiles, hipStream_t s) {
+  if (!atr && !btr) return pg::launch<BM, BN, WM, WN, false, false, pg::EpiStore, VAR>(p, e, tiles, s);
+  if (!atr && btr) return pg::launch<BM, BN, WM, WN, false, true, pg::EpiStore, VAR>(p, e, tiles, s);
+  if (atr && btr) return pg::launch<BM, BN, WM, WN, true, true, pg::EpiStore, VAR>(p, e, tiles, s);
+  return hipErrorInvalidValue;
+}
 template <int BM, int BN, int WM, int WN>
 static hipError_t dispatch(const pg::Core &p, const pg::EpiStore::Args &e, int atr, int btr, int tiles, hipStream_t s) {
-  if (!atr && !btr) return pg::launch<BM, BN, WM, WN, false, false, pg::EpiStore>(p, e, tiles, s);
-  if (!atr && btr) return pg::launch<BM, BN, WM, WN, false, true, pg::EpiStore>(p, e, tiles, s);
-  if (atr && btr) return pg::launch<BM, BN, WM, WN, true, true, pg::EpiStore>(p, e, tiles, s);
-  return hipErrorInvalidValue;
+  switch (g_var) {
+    case 1: return dispatch_v<BM, BN, WM, WN, 1>(p, e, atr, btr, tiles, s);
+    case 2: return dispatch_v<BM, BN, WM, WN, 2>(p, e, atr, btr, tiles, s);
+    case 3: return dispatch_v<BM, BN, WM, WN, 3>(p, e, atr, btr, tiles, s);
+    case 4: return dispatch_v<BM, BN, WM, WN, 4>(p, e, atr, btr, tiles, s);
+    case 8: return dispatch_v<BM, BN, WM, WN, 8>(p, e, atr, btr, tiles, s);
+    case 12: return dispatch_v<BM, BN, WM, WN, 12>(p, e, atr, btr, tiles, s);
+    case 24: return dispatch_v<BM, BN, WM, WN, 24>(p, e, atr, btr, tiles, s);
+    default: return dispatch_v<BM, BN, WM, WN, 0>(p, e, atr, btr, tiles, s);
+  }
 }
 
 static hipError_t run_cfg(int cfg, const pg::Core &p, const pg::EpiStore::Args &e, int atr, int btr, hipStream_t s) {
@@ -200,6 +215,8 @@ static void bench_case(const char *name, const Case &cs, int reps) {
 
 int main(int argc, char **argv) {
   const char *mode = argc > 1 ? argv[1] : "check";
+  g_var = getenv("VAR") ? atoi(getenv("VAR")) : 0;
+  printf("VAR = %d\n", g_var);
   if (!strcmp(mode, "check")) {
     int bad = tr_semantic();
     const Case cases[] = {
@@ -213,6 +230,22 @@ int main(int argc, char **argv) {
     return bad ? 1 : 0;
   }
   const int reps = argc > 2 ? atoi(argv[2]) : 5;
+  if (!strcmp(mode, "one")) {      // one M N K cfg atr btr splits [reps]: a single case (profiling)
+    Case c = {atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), atoi(argv[8])};
+    bench_case("one", c, argc > 9 ? atoi(argv[9]) : 5);
+    return 0;
+  }
+  if (!strcmp(mode, "quick")) {    // the large shapes on the two main tilings only
+    const int NBq = getenv("NB") ? atoi(getenv("NB")) : 131072;
+    for (int cfg = 0; cfg < 2; ++cfg) bench_case("c5 decode  Z.W^T", {4096, NBq, 512, cfg, 0, 0, 1}, reps);
+    for (int cfg = 0; cfg < 2; ++cfg) bench_case("c5 dZ      dO.W", {4096, 512, NBq, cfg, 0, 1, cfg == 0 ? 16 : 4}, reps);
+    for (int cfg = 0; cfg < 2; ++cfg) bench_case("c5 dW      dO^T.Z", {NBq, 512, 4096, cfg, 1, 1, 1}, reps);
+    for (int cfg = 0; cfg < 2; ++cfg) bench_case("c5b500 decode", {500, 48800, 512, cfg, 0, 0, 1}, reps * 4);
+    for (int cfg = 0; cfg < 2; ++cfg) bench_case("c5b500 dW", {48800, 512, 500, cfg, 1, 1, 1}, reps * 4);
+    for (int cfg = 1; cfg < 3; ++cfg) bench_case("c2 decode", {500, 7900, 200, cfg, 0, 0, 1}, reps * 10);
+    for (int cfg = 1; cfg < 3; ++cfg) bench_case("c2 dW", {7900, 200, 500, cfg, 1, 1, cfg == 1 ? 2 : 4}, reps * 10);
+    return 0;
+  }
   // C5 at B = 4096 (n_b = 336 k in the real step; 131 072 items here: the same tiles, a third of them)
   const int NB = getenv("NB") ? atoi(getenv("NB")) : 131072;
   for (int cfg = 0; cfg < 4; ++cfg) bench_case("c5 decode  Z.W^T", {4096, NB, 512, cfg, 0, 0, 1}, reps);
