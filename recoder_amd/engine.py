@@ -157,12 +157,12 @@ class FusedEngine:
     self.dO = torch.zeros(self.do_rows * ld_cap, **f)
     # per-granule split scales of that image (rk_pg_decode_loss)
     self.do_scales = torch.ones(self.lib.rk_pg_scale_floats(B_cap, n_cap), **f)
-    self.G_de = torch.empty(n_cap * h0, **f)
+    self.G_de = torch.zeros(n_cap * h0, **f)
     # MF: [B | the step's user rows as int32] left by the forward's gather for the SparseAdam job of
     # the user table (rk_gather_rows_amax)
     self._users32_buf = torch.zeros(B_cap + 1, dtype=torch.int32, device=dev) if self.kind == "mf" else None
     # the fused dW + encoder-backward launch writes G_en in row segments (long item columns)
-    self.G_en = torch.empty(n_cap * h0 * self.lib.rk_encode_bwd_segments(B_cap), **f)
+    self.G_en = torch.zeros(n_cap * h0 * self.lib.rk_encode_bwd_segments(B_cap), **f)
     # small gradients in ONE buffer [gb_en (h0) | loss | pad | gb_de (n_cap)] so that a
     # data-parallel step reduces them with a single collective over [0, off + n_b)
     self.small_off = cdiv(h0 + 1, 4) * 4
@@ -802,11 +802,61 @@ class FusedEngine:
     if self.allreduce is not None:
       # data parallel over users: every gradient of the step (live rows of both tables, gathered
       # bias, dense layers, loss) is SUM all-reduced as one in-order RCCL group on this stream
-      self.allreduce.reduce(self.grad_views(n_b_host, "all"))
+      if getattr(self, "owned_rows", False):
+        self._owned_exchange(blk, n_b_host)
+      else:
+        self.allreduce.reduce(self.grad_views(n_b_host, "all"))
     if dw_side is not None:
       main_s.wait_event(self._dw_ev[1])
     self._apply_updates(blk, row_off, B, stream, "all", tgt=tb)
+    if getattr(self, "_own", None) is not None:
+      self._owned_publish(blk)
     return loss
+
+  # ---- owned-row Adam under users-DP (parallel.DataParallel, "owned-row Adam") ----
+  def _sparse_tables(self):
+    """(state name, compact gradient rows) of every SparseAdam embedding table of the step."""
+    S = self.states
+    if self.kind == "ae":
+      if self.model.is_constrained:
+        cand = [("en_embedding_layer.weight", self.G_de)]
+      else:
+        cand = [("en_embedding_layer.weight", self.G_en), ("de_embedding_layer.weight", self.G_de)]
+    else:
+      cand = [("item_embedding_layer.weight", self.G_de)]
+    return [(n, g) for n, g in cand if S[n].sparse]
+
+  def _owned_exchange(self, blk, n_b):
+    """The SparseAdam tables' partial gradient rows go to the ranks that OWN them (variable-count
+    all-to-all); everything else is all-reduced as ever."""
+    dp, h0 = self.allreduce, self.h[0]
+    offs = dp.owned_offsets(blk.items, n_b)
+    tabs = {}
+    own_g = set()
+    for name, G in self._sparse_tables():
+      R, cnt = dp.exchange_rows(G[:n_b * h0], offs, h0)
+      tabs[name] = R
+      own_g.add(G.data_ptr())
+    lo = offs[dp.rank]
+    self._own = dict(offs=offs, tabs=tabs, lo=lo, cnt=offs[dp.rank + 1] - lo, n_b=n_b,
+                     cnt_dev=torch.tensor([offs[dp.rank + 1] - lo], dtype=torch.int32, device=self.device))
+    rest = [v for v in self.grad_views(n_b, "all") if not (v.data_ptr() in own_g and v.numel() == n_b * h0)]
+    dp.reduce(rest)
+
+  def _owned_publish(self, blk):
+    """Every rank's freshly updated rows of the SparseAdam tables -> every replica (the all-gather)."""
+    own, self._own = self._own, None
+    dp, h0 = self.allreduce, self.h[0]
+    n_b, lo, cnt = own["n_b"], own["lo"], own["cnt"]
+    items = blk.items[:n_b].long()
+    for name in own["tabs"]:
+      p = self.states[name].p.data
+      S = p.index_select(0, items[lo:lo + cnt]) if cnt else p.new_zeros((0, h0))
+      T = dp.publish_rows(S, own["offs"], h0)
+      p.index_copy_(0, items, T.view(n_b, h0))
+    # the decoder table's running |W| bound (split scales of the contractions): a rank only sees the
+    # rows it wrote -- MAX over the ranks of the 64 slots (non-negative fp32 bit patterns order as ints)
+    dp.union_marks(self.ranges[64:])
 
   def _dw(self, z, B, blk, gb_de, stream, keep_slabs=False, red=None):
     """G_de = dO^T . z (+ gb_de = colsum(dO) if asked): the bf16-pipe kernel (csrc/dw3.hip) unless
@@ -848,6 +898,8 @@ class FusedEngine:
     """The one-call step (rk_ae_train_step) covers DynamicAutoencoder([h]) without bottleneck
     dropout; everything else runs the per-entry sequencing."""
     m = self.model
+    if getattr(self, "owned_rows", False):
+      return False          # (owned-row Adam under users-DP: sequenced from Python, _owned_exchange)
     return self.use_c_step and self.kind == "ae" and self.nl == 0 and not (m.dropout_prob > 0.0)
 
   def _c_train_step(self, blk, row_off, B, keep_noise, out, global_rows, main_s, replay=None):
@@ -995,22 +1047,25 @@ class FusedEngine:
       # the blocks' whole capacity (rows past n_b are never read by the update) instead of the live
       # rows, and nothing of the step is read on the host
       n_b = dp.n_b(blk) if replay is None else blk.n_cap
+      # (the gradient rows that travel: the live count rounded up to a granule the reduce-scatter can
+      # shard -- rows past n_b are zeros or stale rows nobody reads)
+      n_x = dp.round_rows(n_b, blk.n_cap) if hasattr(dp, "round_rows") else n_b
       G_enc = self.G_de if tied else self.G_en
       if tied:
         # tied weights: the encoder backward accumulates onto dW's rows -- nothing may leave before it
         st.phase = STEP_FWD_DW | STEP_DZ_ENC
         check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
-        dp.reduce([G_enc[:n_b * h0], self.small[:self.small_off + n_b]])
+        dp.reduce([G_enc[:n_x * h0], self.small[:self.small_off + n_b]])
       else:
         # the decoder-side gradients (dW rows, loss, gathered-bias gradient) travel on the
         # communication stream while this stream runs dZ -> encoder backward; the encoder side
         # (gradient rows, encoder bias) follows behind them; the Adam sweep waits for both
         st.phase = STEP_FWD_DW
         check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
-        dp.reduce_async([self.G_de[:n_b * h0], self.small[h0:self.small_off + n_b]], main_s)
+        dp.reduce_async([self.G_de[:n_x * h0], self.small[h0:self.small_off + n_b]], main_s)
         st.phase = STEP_DZ_ENC
         check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
-        dp.reduce_async([G_enc[:n_b * h0], self.small[:h0]], main_s)
+        dp.reduce_async([G_enc[:n_x * h0], self.small[:h0]], main_s)
         dp.join_async(main_s)
       if replay is None:
         out.copy_(self.loss_dp)
@@ -1144,10 +1199,19 @@ class FusedEngine:
     dec = part in ("all", "decoder")
     enc = part in ("all", "encoder")
 
+    own = getattr(self, "_own", None)
+
     def table(name, G, b=None, parts=None):
       b = blk if b is None else b
       s = S[name]
-      if s.sparse:
+      if s.sparse and own is not None and name in own["tabs"]:
+        # this rank's item range only: rows items[lo : lo + cnt], the gradient = the sum, in rank order,
+        # of the world partial arrays the exchange left in R
+        R = own["tabs"][name]
+        cnt = own["cnt"]
+        self._adam_rows(s, b.items[own["lo"]:], None, own["cnt_dev"], max(cnt, 1), R, h0, stream,
+                        parts=(ptr(R), self.allreduce.world, max(cnt, 1) * h0, None, None))
+      elif s.sparse:
         self._adam_rows(s, b.items, None, b.counts, b.n_cap, G, h0, stream, parts=parts)
       else:
         self._adam_table(s, b.pos, G, h0, n_items, stream, parts=parts)

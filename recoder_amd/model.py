@@ -337,7 +337,7 @@ class Recoder(object):
 
     self._pick_engine_for(train_dataset)
     self.__init_training(train_dataset=train_dataset, lr=lr, weight_decay=weight_decay)
-    train_dataset = self._setup_data_parallel(train_dataset, negative_sampling)
+    train_dataset = self._setup_data_parallel(train_dataset, negative_sampling, batch_size)
     if getattr(self, "_ip", None) is not None:
       # item parallel: every rank processes the whole global batch against its items
       batch_size *= self._ip.world
@@ -400,6 +400,7 @@ class Recoder(object):
     checkpoints).  Item parallel: item i's embedding rows / bias live on rank i % N.
     MatrixFactorization under data parallelism: a user's row only receives gradients
     on the rank that holds the user."""
+    self._sync_owned_moments()
     ip = getattr(self, "_ip", None)
     if ip is not None:
       m = self.model
@@ -441,7 +442,7 @@ class Recoder(object):
       eng._w_range_stale = True
       eng._eval_img = None
 
-  def _setup_data_parallel(self, train_dataset, negative_sampling=True):
+  def _setup_data_parallel(self, train_dataset, negative_sampling=True, batch_size=None):
     """Under an initialised torch.distributed group (one process per GPU, backend
     'nccl' = RCCL) the USERS are sharded over the ranks and the gradients are
     all-reduced (recoder_amd/parallel.DataParallel) -- north_star's partitioning and the
@@ -490,6 +491,7 @@ class Recoder(object):
       dp = DataParallel().prepare(self.device)
     dp.attach(self._engine())
     self._dp = dp
+    self._setup_owned_rows(dp, train_dataset, negative_sampling, batch_size)
     n = len(train_dataset)
     lo, hi = shard_range(n, dp.rank, dp.world)
     dp.user_offset = lo
@@ -506,6 +508,42 @@ class Recoder(object):
     # every rank runs the same number of equally sized steps (collectives in lockstep)
     self._dp_users_per_epoch = n // dp.world
     return shard
+
+  def _setup_owned_rows(self, dp, train_dataset, negative_sampling, batch_size):
+    """Owned-row Adam (parallel.DataParallel): with SparseAdam embedding tables every item's rows -- and
+    their moments -- belong to one rank; RK_DP_OWNED=0 keeps the replicated update.  The item-id ranges
+    are balanced by the items' expected presence in a global batch, from the training matrix's column
+    counts (the same on every rank: it is taken before the users are sharded)."""
+    eng = self._engine()
+    eng.owned_rows = False
+    dp.owner_bounds = None
+    sparse = bool(getattr(self.model, "sparse", False)) and self.sparse_optimizer is not None
+    mode = os.environ.get("RK_DP_OWNED", "1")       # 0: replicated update; force: also with one rank (tests)
+    if not (sparse and negative_sampling and batch_size and (dp.world > 1 or mode == "force") and mode != "0"):
+      return
+    if dp.virtual and dp._gather_fn is None:
+      return                                # (injected collectives without a gather: replicated update)
+    dev = getattr(train_dataset, "_dev", None)
+    n_items = int(self.num_items)
+    if dev is not None:
+      freq = torch.bincount(dev.indices[:dev.nnz].long(), minlength=n_items).cpu().numpy()
+    else:
+      freq = np.bincount(train_dataset.interactions_matrix.indices, minlength=n_items)
+    from .parallel import DataParallel
+    dp.set_owner_bounds(DataParallel.balanced_bounds(freq[:n_items], len(train_dataset),
+                                                     dp.world * int(batch_size), dp.world))
+    eng.owned_rows = True
+
+  def _sync_owned_moments(self):
+    """The Adam moments of the owned rows live on their owners: every replica gets them (checkpoints,
+    the end of train(), a later single-process continuation)."""
+    dp = getattr(self, "_dp", None)
+    eng = self._engine()
+    if dp is None or not getattr(eng, "owned_rows", False):
+      return
+    for name, _ in eng._sparse_tables():
+      st = eng.states[name]
+      dp.sync_owned_moments([st.m, st.v])
 
   def _enable_item_parallel(self, ip, train_dataset):
     from .parallel import ItemParallel

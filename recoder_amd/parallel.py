@@ -112,9 +112,10 @@ class DataParallel:
   anything else (gloo in the CPU tests, RK_COMM=torch) through torch.distributed.  rank / world /
   the collectives can be injected (tests: several virtual ranks on one GPU)."""
 
-  def __init__(self, group=None, rank=None, world=None, allreduce_fn=None, allreduce_max_fn=None):
+  def __init__(self, group=None, rank=None, world=None, allreduce_fn=None, allreduce_max_fn=None,
+               allgather_fn=None):
     self.group = group
-    self._sum_fn, self._max_fn = allreduce_fn, allreduce_max_fn
+    self._sum_fn, self._max_fn, self._gather_fn = allreduce_fn, allreduce_max_fn, allgather_fn
     self.virtual = allreduce_fn is not None
     if not self.virtual:
       assert dist.is_initialized()
@@ -122,6 +123,9 @@ class DataParallel:
     self.world = dist.get_world_size(group) if world is None else world
     self.user_offset = 0          # first global user id of this rank's shard
     self._grad_comm = self._mark_comm = None
+    self.exchange_mode = "allreduce"     # how a large gradient bucket is summed: ncclAllReduce | rsag
+    self.calibration = None
+    self.owner_bounds = None             # owned-row Adam: item-id boundaries of the ranks' row ranges
 
   def prepare(self, device):
     """Create the two direct communicators now (a collective: every rank calls it)."""
@@ -129,7 +133,88 @@ class DataParallel:
       self._grad_comm = _make_rccl(self.group, device, self.rank, self.world)
       if self._grad_comm is not None:
         self._mark_comm = _make_rccl(self.group, device, self.rank, self.world)
+        self._pick_exchange(device)
     return self
+
+  # ---- how the large gradient buckets travel --------------------------------------------------
+  # RK_DP_EXCHANGE = allreduce | rsag | auto (default).  A ring all-reduce over point-to-point xGMI is
+  # bound by ONE link direction; reduce-scatter + all-gather of the same bucket (the same bytes) can run
+  # direct, one-shot algorithms over all 7 links of a fully connected node.  Which one this
+  # RCCL build runs faster at the step's bucket size is a property of the machine: `auto` times both
+  # once, at communicator creation, on an 8 MB bucket and keeps the faster (the MAX over the ranks
+  # decides, so every rank takes the same path).
+  def _pick_exchange(self, device):
+    mode = os.environ.get("RK_DP_EXCHANGE", "auto")
+    if mode in ("allreduce", "rsag"):
+      self.exchange_mode = mode
+      return
+    if self.world == 1:
+      return
+    try:
+      self.calibration = self.microbench(8 << 20, device, iters=5)
+      if self.calibration["rsag_us"] < 0.95 * self.calibration["allreduce_us"]:
+        self.exchange_mode = "rsag"
+    except Exception as e:            # noqa: BLE001 -- never fail a training run on the calibration
+      import warnings
+      warnings.warn("exchange calibration failed (%s): ncclAllReduce" % e)
+
+  def microbench(self, nbytes, device, iters=10):
+    """Time ncclAllReduce against reduce-scatter + all-gather on a bucket of `nbytes` (a collective:
+    every rank calls it): {bytes, allreduce_us, rsag_us, *_busbw_GBs} with the slowest rank's times and
+    the bus bandwidth 2 (N - 1) / N . bytes / t as nccl-tests define it."""
+    comm = self._grad_comm
+    n = max(self.world * 64, (nbytes // 4) // (self.world * 64) * (self.world * 64))
+    buf = torch.ones(n, dtype=torch.float32, device=device)
+    scratch = torch.empty(n // self.world, dtype=torch.float32, device=device)
+    st = torch.cuda.current_stream()
+    res = {}
+    for name, fn in (("allreduce", lambda: comm.all_reduce(buf)),
+                     ("rsag", lambda: comm.reduce_scatter_all_gather(buf, scratch))):
+      for _ in range(2):
+        buf.fill_(1.0)
+        fn()
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      st.synchronize()
+      e0.record(st)
+      for _ in range(iters):
+        fn()
+      e1.record(st)
+      e1.synchronize()
+      res[name] = e0.elapsed_time(e1) * 1e3 / iters
+    t = torch.tensor([res["allreduce"], res["rsag"]], dtype=torch.float32, device=device)
+    from .rccl import ncclMax
+    comm.all_reduce(t, op=ncclMax)
+    ar, rs = (float(x) for x in t.cpu())
+    bus = 2.0 * (self.world - 1) / self.world * n * 4
+    return dict(bytes=n * 4, allreduce_us=ar, rsag_us=rs, allreduce_busbw_GBs=bus / ar / 1e3 if ar > 0 else None,
+                rsag_busbw_GBs=bus / rs / 1e3 if rs > 0 else None, world=self.world, picked=self.exchange_mode)
+
+  def _sum_many(self, views, stream=None):
+    """SUM over the ranks of every view, in place, as one in-order RCCL group; large views go as
+    reduce-scatter + all-gather when that is this machine's faster exchange."""
+    comm = self._grad_comm
+    if self.exchange_mode != "rsag":
+      comm.all_reduce_many(views, stream=stream)
+      return
+    small = []
+    for v in views:
+      n = v.numel()
+      if n >= 65536 and n % self.world == 0 and v.dtype == torch.float32:
+        key = (n // self.world, v.device)
+        sc = getattr(self, "_rs_scratch", None)
+        if sc is None or sc.numel() < n // self.world or sc.device != v.device:
+          self._rs_scratch = sc = torch.empty(n // self.world, dtype=torch.float32, device=v.device)
+        comm.reduce_scatter_all_gather(v, sc, stream=stream)
+      else:
+        small.append(v)
+    if small:
+      comm.all_reduce_many(small, stream=stream)
+
+  def round_rows(self, n_rows, cap_rows):
+    """Rows of a gradient bucket that actually travel: the live count rounded up so that rows * h is a
+    multiple of the world size (reduce-scatter shards), never past the buffer's capacity."""
+    g = self.world * 8
+    return min(cap_rows, -(-n_rows // g) * g)
 
   @property
   def direct(self):
@@ -198,7 +283,7 @@ class DataParallel:
       self._ev_go, self._ev_done = torch.cuda.Event(), torch.cuda.Event()
     self._ev_go.record(main_stream)
     self._cstream.wait_event(self._ev_go)
-    self._grad_comm.all_reduce_many(views, stream=self._cstream)
+    self._sum_many(views, stream=self._cstream)
     self._async_pending = True
 
   def join_async(self, main_stream):
@@ -213,9 +298,104 @@ class DataParallel:
       for v in views:
         self._sum_fn(v)
     elif self._grad_comm is not None and all(v.is_cuda for v in views):
-      self._grad_comm.all_reduce_many(views)
+      self._sum_many(views)
     else:
       allreduce_sum(views, self.group)
+
+  # ---- owned-row Adam (SparseAdam tables) -----------------------------------------------------
+  # With replicated weights every rank applies SparseAdam to ALL rows of the union item set: at C5 (8
+  # ranks, ~330 k union rows x 512 x 2 tables x 28 B = 9.5 GB) that is ~1.7 ms of HBM time per rank and
+  # step, eight times over.  Instead every item belongs to ONE rank -- contiguous item-id ranges
+  # [owner_bounds[r], owner_bounds[r + 1]), balanced by the items' expected presence in a batch; the
+  # compact rows of a block are sorted by item id, so a rank's rows are ONE contiguous slice of every
+  # compact gradient array -- and a step exchanges
+  #     partial gradient rows of range r  -> rank r        (variable-count all-to-all: the reduce-scatter)
+  #     SparseAdam on the owned rows only (moments of a row live on its owner)
+  #     updated parameter rows of range r -> every rank    (the all-gather)
+  # the bytes of ONE all-reduce, and 1/N of the Adam sweep.  Exactly the replicated update: the sum of
+  # the N partial rows is taken in rank order inside the Adam job (g_parts = N).
+  def set_owner_bounds(self, bounds):
+    self.owner_bounds = np.asarray(bounds, dtype=np.int64)
+    assert len(self.owner_bounds) == self.world + 1
+
+  @staticmethod
+  def balanced_bounds(item_freq, n_users, rows_per_step, world):
+    """Item-id boundaries that give every rank the same EXPECTED number of union rows per step:
+    item i is in the union of a step's rows with probability 1 - (1 - f_i / n_users) ** rows_per_step."""
+    f = np.asarray(item_freq, dtype=np.float64) / max(1, n_users)
+    p = 1.0 - np.power(np.clip(1.0 - f, 0.0, 1.0), rows_per_step)
+    c = np.concatenate([[0.0], np.cumsum(p)])
+    tot = c[-1] if c[-1] > 0 else 1.0
+    b = [int(np.searchsorted(c, tot * r / world, side="left")) for r in range(world + 1)]
+    b[0], b[-1] = 0, len(f)
+    return np.maximum.accumulate(np.asarray(b, dtype=np.int64))
+
+  def owned_offsets(self, items, n_b):
+    """Compact-row offsets [world + 1] of the ranks' segments in the block's sorted item list (host)."""
+    b = torch.as_tensor(self.owner_bounds[1:-1], dtype=items.dtype, device=items.device)
+    mid = torch.searchsorted(items[:n_b].contiguous(), b).cpu().tolist() if self.world > 1 else []
+    return [0] + [int(x) for x in mid] + [int(n_b)]
+
+  def exchange_rows(self, G, offs, h):
+    """G: this rank's partial compact gradient rows [n_b, h] (flat).  Returns R [world, cnt, h] (flat):
+    R[q] = rank q's partial rows of THIS rank's segment (cnt = its row count)."""
+    lo, hi = offs[self.rank], offs[self.rank + 1]
+    cnt = hi - lo
+    R = torch.empty(self.world * max(cnt, 1) * h, dtype=G.dtype, device=G.device)
+    if self._sum_fn is None and self._grad_comm is not None and G.is_cuda:
+      sends = [G[offs[q] * h:offs[q + 1] * h] for q in range(self.world)]
+      recvs = [R[q * cnt * h:(q + 1) * cnt * h] for q in range(self.world)]
+      self._grad_comm.exchange(sends, recvs)
+      return R, cnt
+    parts = self._gather_all(G[:offs[-1] * h].contiguous())
+    for q in range(self.world):
+      R[q * cnt * h:(q + 1) * cnt * h].copy_(parts[q][lo * h:hi * h])
+    return R, cnt
+
+  def publish_rows(self, S, offs, h):
+    """S: the updated parameter rows of this rank's segment [cnt, h].  Returns T [n_b, h]: every rank's
+    rows in compact order."""
+    n_b = offs[-1]
+    T = torch.empty(n_b * h, dtype=S.dtype, device=S.device)
+    if self._sum_fn is None and self._grad_comm is not None and S.is_cuda:
+      S = S.contiguous().view(-1)
+      sends = [S for _ in range(self.world)]
+      recvs = [T[offs[q] * h:offs[q + 1] * h] for q in range(self.world)]
+      self._grad_comm.exchange(sends, recvs)
+      return T
+    cap = max(offs[q + 1] - offs[q] for q in range(self.world))
+    pad = torch.zeros(max(cap, 1) * h, dtype=S.dtype, device=S.device)
+    pad[:S.numel()].copy_(S.reshape(-1))
+    parts = self._gather_all(pad)
+    for q in range(self.world):
+      n = (offs[q + 1] - offs[q]) * h
+      T[offs[q] * h:offs[q] * h + n].copy_(parts[q][:n])
+    return T
+
+  def _gather_all(self, t):
+    """[t of rank 0, ..., t of rank N - 1] (equal shapes): injected (virtual ranks) or torch.distributed."""
+    if self._gather_fn is not None:
+      return self._gather_fn(t)
+    parts = [torch.empty_like(t) for _ in range(self.world)]
+    dist.all_gather(parts, t, group=self.group)
+    return parts
+
+  def sync_owned_moments(self, tensors):
+    """Every replica gets the rows [owner_bounds[r], owner_bounds[r + 1]) of each tensor (the Adam
+    moments of the owned-row update) from their owner: before a checkpoint / at the end of train()."""
+    if self.owner_bounds is None or self.world == 1:
+      return
+    for r in range(self.world):
+      lo, hi = int(self.owner_bounds[r]), int(self.owner_bounds[r + 1])
+      if hi <= lo:
+        continue
+      for t in tensors:
+        seg = t[lo:hi]
+        if self._gather_fn is not None:
+          seg.copy_(self._gather_fn(seg.contiguous())[r])
+        else:
+          dist.broadcast(seg, src=r if self.group is None else dist.get_global_rank(self.group, r),
+                         group=self.group)
 
 
 class ItemParallel:

@@ -38,6 +38,14 @@ def _load():
                                      ctypes.c_int]
     lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
                                   ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.ncclReduceScatter.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.ncclAllGather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                  ctypes.c_void_p, ctypes.c_void_p]
+    lib.ncclSend.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                             ctypes.c_void_p]
+    lib.ncclRecv.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                             ctypes.c_void_p]
     lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
     lib.ncclGroupStart.argtypes = []
     lib.ncclGroupEnd.argtypes = []
@@ -102,6 +110,63 @@ class RcclComm:
     try:
       for t in tensors:
         self.all_reduce(t, op, stream)
+    finally:
+      _check(lib.ncclGroupEnd(), "ncclGroupEnd")
+
+  @staticmethod
+  def _dt(t):
+    if t.dtype == torch.float32:
+      return ncclFloat32
+    if t.dtype == torch.int32:
+      return ncclInt32
+    raise TypeError("unsupported dtype %s" % t.dtype)
+
+  def reduce_scatter(self, send, recv, op=ncclSum, stream=None):
+    """recv[i] = sum over ranks of send[rank * recv.numel() + i]: send holds world equal shards."""
+    assert send.is_cuda and recv.is_cuda and send.is_contiguous() and recv.is_contiguous()
+    assert send.numel() == recv.numel() * self.world and send.dtype == recv.dtype
+    s = stream if stream is not None else torch.cuda.current_stream()
+    _check(_load().ncclReduceScatter(send.data_ptr(), recv.data_ptr(), recv.numel(), self._dt(send), op,
+                                     self.comm, ctypes.c_void_p(s.cuda_stream)), "ncclReduceScatter")
+    return recv
+
+  def all_gather(self, send, recv, stream=None):
+    """recv[r * send.numel() + i] = rank r's send[i]."""
+    assert send.is_cuda and recv.is_cuda and send.is_contiguous() and recv.is_contiguous()
+    assert recv.numel() == send.numel() * self.world and send.dtype == recv.dtype
+    s = stream if stream is not None else torch.cuda.current_stream()
+    _check(_load().ncclAllGather(send.data_ptr(), recv.data_ptr(), send.numel(), self._dt(send), self.comm,
+                                 ctypes.c_void_p(s.cuda_stream)), "ncclAllGather")
+    return recv
+
+  def reduce_scatter_all_gather(self, t, scratch, stream=None):
+    """SUM all-reduce of t (numel a multiple of world) in place as a reduce-scatter into this rank's shard
+    + an all-gather of the shards: the same bytes as ncclAllReduce, but as two collectives whose direct
+    (one-shot) algorithms drive all xGMI links of a fully connected node at once."""
+    n = t.numel() // self.world
+    mine = scratch[:n]
+    self.reduce_scatter(t, mine, stream=stream)
+    self.all_gather(mine, t, stream=stream)
+    return t
+
+  def exchange(self, sends, recvs, stream=None):
+    """One grouped launch of point-to-point transfers: sends[q] goes to rank q, recvs[q] arrives from
+    rank q (None / empty: nothing to / from that rank -- both sides must agree); the variable-count
+    all-to-all of the owned-row exchange."""
+    lib = _load()
+    s = stream if stream is not None else torch.cuda.current_stream()
+    st = ctypes.c_void_p(s.cuda_stream)
+    _check(lib.ncclGroupStart(), "ncclGroupStart")
+    try:
+      for q in range(self.world):
+        t = sends[q]
+        if t is not None and t.numel() > 0:
+          assert t.is_cuda and t.is_contiguous()
+          _check(lib.ncclSend(t.data_ptr(), t.numel(), self._dt(t), q, self.comm, st), "ncclSend")
+        r = recvs[q]
+        if r is not None and r.numel() > 0:
+          assert r.is_cuda and r.is_contiguous()
+          _check(lib.ncclRecv(r.data_ptr(), r.numel(), self._dt(r), q, self.comm, st), "ncclRecv")
     finally:
       _check(lib.ncclGroupEnd(), "ncclGroupEnd")
 

@@ -23,6 +23,9 @@ def make_case(case):
   if case == "ae_items":          # RK_PARALLEL=items (set by the test)
     mk = lambda: DynamicAutoencoder([64], activation_type="tanh", noise_prob=0.0, sparse=False)
     return csr, mk, "mse", 2e-5, 150, 2
+  if case == "ae_sparse":         # SparseAdam tables: owned-row Adam under users-DP
+    mk = lambda: DynamicAutoencoder([48], activation_type="tanh", noise_prob=0.0, sparse=True)
+    return csr, mk, "mse", 0.0, 150, 2
   if case == "mf_sparse":
     mk = lambda: MatrixFactorization(32, activation_type="none", sparse=True)
     return csr, mk, "logistic", 0.0, 150, 2
@@ -67,7 +70,7 @@ def main():
     bs = B
   rec.train(RecommendationDataset(csr), batch_size=bs, lr=1e-3, weight_decay=wd, num_epochs=epochs,
             negative_sampling=True, model_checkpoint_prefix=prefix + "_ckpt", checkpoint_freq=epochs)
-  out = {"losses": np.concatenate(rec.loss_history)}
+  out = {"losses": np.concatenate(rec.loss_history), "owned": np.asarray(int(bool(getattr(rec._engine(), "owned_rows", False))))}
   for k, v in model.named_parameters():
     out["p/" + k] = v.detach().cpu().numpy()
   np.savez(prefix + "_rank%d.npz" % rank, **out)

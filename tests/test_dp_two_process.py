@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("case", ["ae_dense", "ae_items", "mf_sparse"])
+@pytest.mark.parametrize("case", ["ae_dense", "ae_items", "mf_sparse", "ae_sparse"])
 def test_two_processes_equal_single_process(case, tmp_path):
   from recoder_amd.data import RecommendationDataset
   from recoder_amd.model import Recoder
@@ -49,6 +49,7 @@ def test_two_processes_equal_single_process(case, tmp_path):
   base_l = np.concatenate(rec.loss_history)
   got = [np.load(prefix + "_rank%d.npz" % k) for k in range(world)]
   for g in got:
+    assert int(g["owned"]) == (1 if case in ("mf_sparse", "ae_sparse") else 0)      # (owned-row Adam ran)
     if case == "ae_items":
       pass      # (each rank logs its own shard's share of the loss; the sum is checked below)
     else:

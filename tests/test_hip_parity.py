@@ -716,7 +716,8 @@ def test_dataframe_to_csr_matrix_contract():
   assert m2.shape == m.shape
 
 
-@pytest.mark.parametrize("kind", ["ae", "ae_overlap", "ae_eager", "ae_items", "mf", "mf_sparse"])
+@pytest.mark.parametrize("kind", ["ae", "ae_overlap", "ae_eager", "ae_items", "mf", "mf_sparse", "ae_rsag",
+                                  "ae_eager_rsag", "ae_sparse_owned", "mf_sparse_owned"])
 def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind):
   """Recoder.train under an initialised torch.distributed group (RCCL, 1 rank):
   two-phase collation + all-reduced gradients must reproduce the plain run.  ae_overlap: the
@@ -732,15 +733,32 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
   monkeypatch.setenv("RK_PARALLEL", "items" if kind == "ae_items" else "users")
   items_mode = kind == "ae_items"
   overlap = kind == "ae_overlap"
-  eager_dp = kind == "ae_eager"
+  eager_dp = kind in ("ae_eager", "ae_eager_rsag")
+  # ae_rsag / ae_eager_rsag: the gradient buckets as ncclReduceScatter + ncclAllGather (RK_DP_EXCHANGE);
+  # *_owned: SparseAdam tables under owned-row Adam, forced on with one rank -- the partial rows travel
+  # through the grouped ncclSend / ncclRecv exchange to "their owner", the updated rows back
+  rsag = kind in ("ae_rsag", "ae_eager_rsag")
+  owned = kind.endswith("_owned")
+  if rsag:
+    monkeypatch.setenv("RK_DP_EXCHANGE", "rsag")
+  if owned:
+    monkeypatch.setenv("RK_DP_OWNED", "force")
+  port_off = 40 * rsag + 60 * owned + 7 * (kind == "mf_sparse_owned")
+  ae_sparse = kind == "ae_sparse_owned"
+  if kind == "mf_sparse_owned":
+    kind = "mf_sparse"
+  if rsag or ae_sparse:
+    kind = "ae_eager" if kind == "ae_eager_rsag" else "ae"
   if overlap:
     monkeypatch.setenv("RK_DP_OVERLAP", "1")
   if eager_dp:
     monkeypatch.setenv("RK_GRAPH_DP", "0")
-  graph_dp = kind in ("ae", "ae_overlap")
+  graph_dp = kind in ("ae", "ae_overlap") and not owned
   kind = "ae" if (items_mode or overlap or eager_dp) else kind
   c = STEP_CASES[0][1] if kind == "ae" else dict(kind="mf", embedding_size=32,
                                                  activation_type="tanh", sparse=(kind == "mf_sparse"))
+  if ae_sparse:
+    c = dict(c, sparse=True)
 
   def run(dp):
     torch.manual_seed(11)
@@ -754,13 +772,16 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
     gs = getattr(rec, "_graph_stepper", None)
     if dp:
       assert (gs is not None and gs.dp is rec._dp and gs.warmed) == graph_dp
+      assert bool(getattr(rec._engine(), "owned_rows", False)) == owned
+      if rsag:
+        assert rec._dp.exchange_mode == "rsag"
     return np.concatenate(rec.loss_history), {k: v.detach().cpu().clone() for k, v in model.named_parameters()}
 
   base_l, base_p = run(False)
   monkeypatch.setenv("RK_FORCE_DP", "1")
   monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
   monkeypatch.setenv("MASTER_PORT", str(29577 + ["ae", "mf", "mf_sparse"].index(kind) + 5 * items_mode +
-                                        20 * overlap + 30 * eager_dp))
+                                        20 * overlap + 30 * eager_dp + port_off))
   dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
   try:
     dp_l, dp_p = run(True)
@@ -1026,8 +1047,9 @@ def test_item_parallel_virtual_ranks_random_shapes(seed):
       assert frac < 2e-3, (desc, k, frac, mx, scale)
 
 
-@pytest.mark.parametrize("case", ["mse_dense", "bce_sparse_tied", "ae2_dropout", "ae_logloss"])
-def test_data_parallel_two_virtual_ranks_equal_single_process(case):
+@pytest.mark.parametrize("case", ["mse_dense", "bce_sparse_tied", "ae2_dropout", "ae_logloss", "mse_sparse_owned",
+                                  "mse_sparse_replicated"])
+def test_data_parallel_two_virtual_ranks_equal_single_process(case, monkeypatch):
   """parallel.DataParallel (users sharded -- north_star's partitioning, the multi-GPU default)
   with N = 2 on one GPU: two threads drive the REAL product class -- two-phase collation with the
   MAX-reduced item stamps, the engine's data-parallel phases of rk_ae_train_step, one group of
@@ -1052,6 +1074,13 @@ def test_data_parallel_two_virtual_ranks_equal_single_process(case):
     mk = lambda: DynamicAutoencoder([48, 24], activation_type="tanh", noise_prob=0.0, dropout_prob=0.0,
                                     sparse=False)
     loss, wd = "mse", 1e-5
+  elif case.startswith("mse_sparse"):
+    # SparseAdam tables: every item's rows belong to one rank (owned-row Adam: the partial gradient rows
+    # go to their owner, the updated rows come back) -- or, RK_DP_OWNED=0, the replicated update
+    mk = lambda: DynamicAutoencoder([40], activation_type="tanh", noise_prob=0.0, sparse=True)
+    loss, wd = "mse", 0.0
+    if case.endswith("replicated"):
+      monkeypatch.setenv("RK_DP_OWNED", "0")
   else:
     mk = lambda: DynamicAutoencoder([32], activation_type="tanh", noise_prob=0.0, sparse=False)
     loss, wd = "logloss", 2e-5
@@ -1086,7 +1115,7 @@ def test_data_parallel_two_virtual_ranks_equal_single_process(case):
     model, rec = new()
     rec._Recoder__init_training(RecommendationDataset(csr), kw["lr"], wd)   # same seed, main thread
     rec._dp_override = DataParallel(rank=r, world=world, allreduce_fn=vr.allreduce(r),
-                                    allreduce_max_fn=vr.allreduce_max(r))
+                                    allreduce_max_fn=vr.allreduce_max(r), allgather_fn=vr.allgather(r))
     rec.user_order_hook = (lambda rr: (lambda epoch, n_: shard_orders[rr]))(r)
     reps.append((model, rec))
   errs = []
@@ -1106,12 +1135,23 @@ def test_data_parallel_two_virtual_ranks_equal_single_process(case):
   assert not errs, errs
   for model, rec in reps:
     assert rec._dp is not None and rec._ip is None
+    owned = case in ("bce_sparse_tied", "mse_sparse_owned")
+    assert bool(rec._engine().owned_rows) == owned, (case, rec._engine().owned_rows)
     got_l = np.concatenate(rec.loss_history)
     assert len(got_l) == len(base_l)
     assert np.allclose(got_l, base_l, rtol=2e-5, atol=0), (got_l[:3], base_l[:3])
     for k, v in model.named_parameters():
       frac, mx, scale = close_stats(v.detach().cpu().numpy(), base_p[k].numpy(), 1e-4, 2e-6)
       assert frac < 2e-3, (k, frac, mx, scale)
+  if case == "mse_sparse_owned":
+    # the replicas hold identical parameters AND (after train()'s final sync) identical Adam moments
+    (m0, r0), (m1, r1) = reps
+    for (k, a), (_, b) in zip(m0.named_parameters(), m1.named_parameters()):
+      assert torch.equal(a, b), k
+    for name in ("en_embedding_layer.weight", "de_embedding_layer.weight"):
+      s0, s1 = r0._engine().states[name], r1._engine().states[name]
+      assert torch.equal(s0.m, s1.m) and torch.equal(s0.v, s1.v), name
+      assert float(s0.v.abs().max()) > 0
 
 
 @pytest.mark.parametrize("seed", list(range(24)))
@@ -1171,7 +1211,7 @@ def test_data_parallel_virtual_ranks_random_shapes(seed):
     model, rec = new()
     rec._Recoder__init_training(RecommendationDataset(csr), kw["lr"], wd)
     rec._dp_override = DataParallel(rank=r, world=world, allreduce_fn=vr.allreduce(r),
-                                    allreduce_max_fn=vr.allreduce_max(r))
+                                    allreduce_max_fn=vr.allreduce_max(r), allgather_fn=vr.allgather(r))
     rec.user_order_hook = (lambda rr: (lambda epoch, n_: shard_orders[rr]))(r)
     reps.append((model, rec))
   errs = []

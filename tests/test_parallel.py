@@ -302,3 +302,72 @@ def test_shard_range_partitions():
     assert all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
     sizes = [b - a for a, b in edges]
     assert max(sizes) - min(sizes) <= 1
+
+
+def _owned_worker(rank, world, port, out):
+  """The owned-row exchange primitives of parallel.DataParallel over gloo (CPU tensors): the partial
+  gradient rows of every rank's item range arrive at their owner, the owners' updated rows at everyone."""
+  sys.path.insert(0, ROOT)
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  torch.set_num_threads(1)
+  from recoder_amd.parallel import DataParallel
+  dp = DataParallel().prepare(torch.device("cpu"))
+  n_items, h = 500, 6
+  rng = np.random.RandomState(11)
+  freq = rng.zipf(1.5, n_items).clip(max=300)
+  dp.set_owner_bounds(DataParallel.balanced_bounds(freq, 1000, 64 * world, world))
+  items = torch.from_numpy(np.sort(rng.choice(n_items, 173, replace=False)).astype(np.int32))
+  n_b = len(items)
+  offs = dp.owned_offsets(items, n_b)
+  # segment q holds exactly the items of rank q's id range
+  b = dp.owner_bounds
+  for q in range(world):
+    seg = items[offs[q]:offs[q + 1]].numpy()
+    assert ((seg >= b[q]) & (seg < b[q + 1])).all()
+  G = torch.from_numpy(np.random.RandomState(100 + rank).randn(n_b, h).astype(np.float32)).reshape(-1)
+  R, cnt = dp.exchange_rows(G, offs, h)
+  assert cnt == offs[rank + 1] - offs[rank]
+  want = [torch.from_numpy(np.random.RandomState(100 + q).randn(n_b, h).astype(np.float32))[offs[rank]:offs[rank + 1]]
+          for q in range(world)]
+  for q in range(world):
+    assert torch.equal(R[q * cnt * h:(q + 1) * cnt * h].view(cnt, h), want[q])
+  S = sum(want) * (rank + 2.0)                     # "updated rows" of this rank's segment
+  T = dp.publish_rows(S, offs, h).view(n_b, h)
+  for q in range(world):
+    wq = sum(torch.from_numpy(np.random.RandomState(100 + r).randn(n_b, h).astype(np.float32))[offs[q]:offs[q + 1]]
+             for r in range(world)) * (q + 2.0)
+    assert torch.allclose(T[offs[q]:offs[q + 1]], wq)
+  # moments of the owners' id ranges reach every replica
+  m = torch.full((n_items, 2), float(rank + 1))
+  dp.sync_owned_moments([m])
+  for q in range(world):
+    assert (m[int(b[q]):int(b[q + 1])] == q + 1).all()
+  out[rank] = True
+  dist.destroy_process_group()
+
+
+def test_owned_row_exchange_primitives_two_ranks():
+  world = 2
+  port = _free_port()
+  with mp.Manager() as mgr:
+    out = mgr.dict()
+    mp.spawn(_owned_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out.get(0) and out.get(1)
+
+
+def test_balanced_owner_bounds():
+  """Item-id ranges with equal EXPECTED union rows per step: monotone, covering, balanced on a Zipf
+  catalogue where equal-width ranges are not."""
+  from recoder_amd.parallel import DataParallel
+  rng = np.random.RandomState(0)
+  n_items, n_users, rows = 20000, 100000, 4000
+  freq = np.sort(rng.zipf(1.3, n_items).clip(max=50000))[::-1]          # ids sorted by popularity
+  b = DataParallel.balanced_bounds(freq, n_users, rows, 8)
+  assert b[0] == 0 and b[-1] == n_items and (np.diff(b) >= 0).all()
+  p = 1.0 - np.power(1.0 - np.minimum(freq / n_users, 1.0), rows)
+  mass = np.array([p[b[r]:b[r + 1]].sum() for r in range(8)])
+  assert mass.max() / mass.mean() < 1.1
+  eq = np.array([p[r * n_items // 8:(r + 1) * n_items // 8].sum() for r in range(8)])
+  assert eq.max() / eq.mean() > 2.0
