@@ -524,6 +524,20 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
   eng = rec._engine()
+  # multi-GPU runs: the gradient bucket of this workload through ncclAllReduce and through
+  # reduce-scatter + all-gather, timed in the SAME run (a collective: every rank), so that the first run
+  # on real links validates or refutes DESIGN section 6's pricing in one shot
+  exch = None
+  dp_obj = getattr(rec, "_dp", None)
+  if multi and dp_obj is not None and getattr(dp_obj, "direct", False):
+    try:
+      bucket = 4 * int(getattr(eng, "n_cap_last", 0) or eng.n_cap) * h0
+      exch = dp_obj.microbench(max(bucket, 1 << 20), device, iters=20)
+      exch["mode_used"] = dp_obj.exchange_mode
+      exch["calibration_at_startup"] = dp_obj.calibration
+      exch["owned_row_adam"] = bool(getattr(eng, "owned_rows", False))
+    except Exception as e:          # noqa: BLE001 -- never lose the line
+      exch = {"error": "%s: %s" % (type(e).__name__, e)}
   losses = np.concatenate([np.asarray(x) for x in rec.loss_history]) if rec.loss_history else np.zeros(1)
   assert np.all(np.isfinite(losses)), "non-finite loss"
   global_rows = B * world if multi else B
@@ -702,7 +716,9 @@ def main():
       "data": "synthetic",
       "config": {"workload": cfg["workload"], "api": "Recoder.train", "batch_size_per_gpu": B,
                  "global_batch": global_rows,
-                 "parallelism": "dp%d (users sharded, in-order RCCL gradient all-reduce)" % world
+                 "parallelism": "dp%d (users sharded; gradient buckets: %s; %s)" % (
+                     world, getattr(dp_obj, "exchange_mode", "allreduce"),
+                     "owned-row SparseAdam" if getattr(eng, "owned_rows", False) else "replicated Adam")
                                 if multi else "dp1",
                  "avg_sampled_items": n_b, "avg_nnz_per_batch": nnz,
                  "first_loss": float(losses[0]), "last_loss": float(losses[-1]),
@@ -713,6 +729,7 @@ def main():
                  "first_group_collation": ("in front of the clock; the look-ahead collation behind the last "
                                            "timed group runs inside it (one per group, as in steady state)")
                                           if T.get("precollated") else "inside the timed region, in front of step 0",
+                 "exchange_microbench": exch,
                  "alt_item_parallel": None},
       "roofline": roofline,
     }

@@ -220,20 +220,46 @@ class DataParallel:
   def direct(self):
     return self._grad_comm is not None
 
+  # With more than one rank EVERY collective of this object goes through ONE communicator on ONE
+  # communication stream, tied to the issuing stream by an event on each side: two communicators with
+  # collectives in flight at once and no cross-rank order between them -- the stamp MAX of the look-ahead
+  # collation on the side stream next to a step's gradient exchange, inside one replayed graph -- is the
+  # pattern RCCL documents as deadlock-prone.  One stream + one communicator = one total
+  # order, the same on every rank (the enqueue / capture order is).  With one rank there is nothing to
+  # order and the collectives stay on the issuing stream (no cross-stream edges).
+  def _on_comm_stream(self, device, fn):
+    cur = torch.cuda.current_stream(device)
+    if getattr(self, "_cstream", None) is None:
+      self._cstream = torch.cuda.Stream(device=device)
+      self._ev_go, self._ev_done = torch.cuda.Event(), torch.cuda.Event()
+    ea, eb = torch.cuda.Event(), torch.cuda.Event()
+    ea.record(cur)
+    self._cstream.wait_event(ea)
+    fn(self._cstream)
+    eb.record(self._cstream)
+    cur.wait_event(eb)
+
   def union_marks(self, mark):
-    """MAX all-reduce of the item stamps, in order on the current stream."""
+    """MAX all-reduce of the item stamps, ordered behind the current stream's work."""
     if self._max_fn is not None:
       return self._max_fn(mark)
-    if self._mark_comm is not None and mark.is_cuda:
+    if self._grad_comm is not None and mark.is_cuda:
       from .rccl import ncclMax
+      if self.world > 1:
+        self._on_comm_stream(mark.device, lambda cs: self._grad_comm.all_reduce(mark, op=ncclMax, stream=cs))
+        return mark
       return self._mark_comm.all_reduce(mark, op=ncclMax)
     return union_marks(mark, self.group)
 
   def union_marks_many(self, marks):
-    """The MAX all-reduces of several blocks' stamp arrays, in order on the current stream (one
-    RCCL group on the direct communicator: a replayed group's look-ahead blocks)."""
-    if self._max_fn is None and self._mark_comm is not None and all(m.is_cuda for m in marks):
+    """The MAX all-reduces of several blocks' stamp arrays as one RCCL group (a replayed group's
+    look-ahead blocks), ordered behind the current stream's work."""
+    if self._max_fn is None and self._grad_comm is not None and all(m.is_cuda for m in marks):
       from .rccl import ncclMax
+      if self.world > 1:
+        self._on_comm_stream(marks[0].device,
+                             lambda cs: self._grad_comm.all_reduce_many(marks, op=ncclMax, stream=cs))
+        return
       self._mark_comm.all_reduce_many(marks, op=ncclMax)
       return
     for m in marks:
@@ -298,7 +324,10 @@ class DataParallel:
       for v in views:
         self._sum_fn(v)
     elif self._grad_comm is not None and all(v.is_cuda for v in views):
-      self._sum_many(views)
+      if self.world > 1:
+        self._on_comm_stream(views[0].device, lambda cs: self._sum_many(views, stream=cs))
+      else:
+        self._sum_many(views)
     else:
       allreduce_sum(views, self.group)
 
@@ -345,7 +374,10 @@ class DataParallel:
     if self._sum_fn is None and self._grad_comm is not None and G.is_cuda:
       sends = [G[offs[q] * h:offs[q + 1] * h] for q in range(self.world)]
       recvs = [R[q * cnt * h:(q + 1) * cnt * h] for q in range(self.world)]
-      self._grad_comm.exchange(sends, recvs)
+      if self.world > 1:
+        self._on_comm_stream(G.device, lambda cs: self._grad_comm.exchange(sends, recvs, stream=cs))
+      else:
+        self._grad_comm.exchange(sends, recvs)
       return R, cnt
     parts = self._gather_all(G[:offs[-1] * h].contiguous())
     for q in range(self.world):
@@ -361,7 +393,10 @@ class DataParallel:
       S = S.contiguous().view(-1)
       sends = [S for _ in range(self.world)]
       recvs = [T[offs[q] * h:offs[q + 1] * h] for q in range(self.world)]
-      self._grad_comm.exchange(sends, recvs)
+      if self.world > 1:
+        self._on_comm_stream(S.device, lambda cs: self._grad_comm.exchange(sends, recvs, stream=cs))
+      else:
+        self._grad_comm.exchange(sends, recvs)
       return T
     cap = max(offs[q + 1] - offs[q] for q in range(self.world))
     pad = torch.zeros(max(cap, 1) * h, dtype=S.dtype, device=S.device)
