@@ -83,7 +83,12 @@ KERNELS = {"rk_ae_encode_fwd": ["ae_encode_fwd_kernel (+ the W_de[items] split w
            "rk_decode_bwd_dw2_encode_bwd": ["dw_encbwd_kernel<BN,HV> (dW tiles || encoder-backward columns)"],
            "rk_decode_bwd_dw2_dz_reduce": ["dw_reduce_kernel<BN> (dW tiles || the dZ slab reduce)"],
            "rk_decode_bwd_dw2_encode_bwd_colsum": ["dw_encbwd_kernel<BN,HV> (dW tiles || dO column sums || "
-                                                   "encoder-backward columns)"]}
+                                                   "encoder-backward columns)"],
+           "rk_pg_decode_loss": ["pg::gemm_kernel<BM,BN,..,EpiLoss> (LDS-DMA pipelined decode + loss, dO as a plane image)"],
+           "rk_pg_decode_mnll": ["pg::gemm_kernel<..,EpiStats>", "pg::gemm_kernel<..,EpiLoss<MNLL>>"],
+           "rk_pg_dz": ["pg::gemm_kernel<..,EpiSlab> (dO image x W image read along its rows)", "splitk_reduce_kernel"],
+           "rk_pg_dw": ["pg::gemm_kernel<..,EpiSlab> (both operands read along their rows)"],
+           "rk_pg_dw_encode_bwd": ["dw_encbwd_kernel (pg dW tiles || encoder-backward columns)"]}
 
 CONFIGS = {
   # C2 of BASELINE.json: ML-20M autoencoder, hidden [200], MSE, 1 x MI355X
@@ -112,6 +117,11 @@ CONFIGS = {
                        "MSE, SparseAdam lr 1e-3, negative sampling",
               data="c5u", kind="ae", hidden_layers=[512], activation_type="tanh", noise_prob=0.0,
               sparse=True, loss="mse", batch_size=500, lr=1e-3, weight_decay=0.0),
+  "c5u4k": dict(workload="C5-shaped at B = 4096 (north_star's larger batch): synthetic CSR 100000x1000000 "
+                         "uniform, 100 interactions per user, seed 3; DynamicAutoencoder hidden=[512] tanh, MSE, "
+                         "SparseAdam lr 1e-3, negative sampling (n_b ~ 336 k sampled items per step)",
+                data="c5u", kind="ae", hidden_layers=[512], activation_type="tanh", noise_prob=0.0,
+                sparse=True, loss="mse", batch_size=4096, lr=1e-3, weight_decay=0.0),
   "small": dict(workload="smoke-size synthetic 5000x3000", data="small", kind="ae",
                 hidden_layers=[200], activation_type="tanh", noise_prob=0.5, sparse=False,
                 loss="mse", batch_size=500, lr=1e-3, weight_decay=2e-5),
@@ -179,6 +189,10 @@ def entry_work(entry, B, h0, n_b, nnz, n_items, cfg):
     return "mfma", 2.0 * B * h0 * n_b / 1e12, "TFLOP/s"
   if entry in ("rk_decode_loss_planes", "rk_decode_bwd_dz_planes"):    # the plane kernels outside the fused form
     return "mfma", 2.0 * B * h0 * n_b / 1e12, "TFLOP/s"
+  if entry in ("rk_pg_decode_loss", "rk_pg_dz", "rk_pg_dw", "rk_pg_dw_encode_bwd"):    # csrc/pgemm.h
+    return "mfma", 2.0 * B * h0 * n_b / 1e12, "TFLOP/s"
+  if entry == "rk_pg_decode_mnll":              # the decode twice: statistics pass + decode / loss pass
+    return "mfma", 4.0 * B * h0 * n_b / 1e12, "TFLOP/s"
   if entry == "rk_decode_loss_dz_planes":       # decode + loss + the dZ partials of every column tile
     return "mfma", 4.0 * B * h0 * n_b / 1e12, "TFLOP/s"
   if entry == "rk_decode_dz_reduce":            # the column-tile slabs summed

@@ -430,6 +430,16 @@ int rk_pg_decode_loss(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, i
                       const float *b_de, int32_t loss_kind, float confidence, float inv_B, void *dO_img,
                       int32_t rows_img, float *dO_scales, float *dO_f32 /* nullable */, float *loss_part,
                       float *gb_part, void *stream);
+/* The multinomial NLL (losses.py:68-71) the same way, as two passes over the decode: a statistics pass
+ * that writes 8 bytes per (row, column tile) -- {max, sum exp} of its live columns -- and the decode +
+ * loss pass that merges them into the row's log-sum-exp; no logits matrix is written, re-read and
+ * rewritten (rk_decode_loss_planes + rk_mnll_finish).  mnll_ws: rk_pg_mnll_workspace_floats floats;
+ * loss_part: one partial per tile (rk_loss_partials slots), gb_part as rk_decode_loss. */
+int64_t rk_pg_mnll_workspace_floats(int32_t B, int32_t n_cap);
+int rk_pg_decode_mnll(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off,
+                      const float *b_de, float inv_B, float *mnll_ws, void *dO_img, int32_t rows_img,
+                      float *dO_scales, float *dO_f32 /* nullable */, float *loss_part, float *gb_part,
+                      void *stream);
 int64_t rk_pg_dz_workspace_bytes(int32_t B, int32_t h);
 int rk_pg_dz(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
              const rk_planes_t *pl, const rk_block_t *tgt, const float *Zact /* nullable */, int32_t act,

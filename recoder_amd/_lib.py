@@ -178,6 +178,9 @@ SIGNATURES = {
   "rk_pg_scale_floats": (c_int64, [c_int32, c_int32]),
   "rk_pg_decode_loss": (c_int32, [POINTER(RkPlanes), c_int32, _BLK, c_int32, _P, c_int32, c_float, c_float, _P,
                                   c_int32, _P, _P, _P, _P, _P]),
+  "rk_pg_mnll_workspace_floats": (c_int64, [c_int32, c_int32]),
+  "rk_pg_decode_mnll": (c_int32, [POINTER(RkPlanes), c_int32, _BLK, c_int32, _P, c_float, _P, _P, c_int32, _P, _P, _P,
+                                  _P, _P]),
   "rk_pg_dz_workspace_bytes": (c_int64, [c_int32, c_int32]),
   "rk_pg_dz": (c_int32, [_P, _P, c_int32, c_int32, c_int32, POINTER(RkPlanes), _BLK, _P, c_int32, _P, _P, _P]),
   "rk_pg_dw_splits": (c_int32, [c_int32, c_int32, c_int32]),

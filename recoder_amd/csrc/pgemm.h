@@ -252,11 +252,32 @@ __device__ __forceinline__ void gemm_body(const Core &p, const typename Epi::Arg
       sa.issue(smem, iw);
       sb.issue(smem + A_BYTES, iw);
     }
+#define PG_MFMA3(AH, AL, BH, BL)                                                                   \
+  do {                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)  \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[i], BH[j], acc[i][j], 0, 0, 0);      \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)  \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BL[j], acc[i][j], 0, 0, 0);      \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)  \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[i], BH[j], acc[i][j], 0, 0, 0);      \
+  } while (0)
+    // VAR & 32 ("ping-pong"): the two waves of a SIMD (wave w and w + NW / 2) run half a k-tile apart -- the
+    // late half carries the fragments of its second k-step across the barrier and multiplies them FIRST
+    // behind it, while the early half issues its DMAs and waits for its first fragments; then the roles
+    // swap.  Same MFMAs, same order per accumulator: only their placement around the barrier moves.
+    const bool late = (VAR & 32) && T.wave >= NW / 2;
+    f16x8 pah[TM], pal[TM], pbh[TN], pbl[TN];
     for (int kt = 0; kt < nk; ++kt) {
       // tile kt has landed (every wave waits for its own DMAs, then the barrier) and every wave is
-      // done reading the other stage (its MFMAs of iteration kt - 1 consumed those fragments)
-      __syncthreads();
-      if (kt + 1 < nk && issuer && !((VAR & 16) && kt >= 1)) {
+      // done reading the other stage (its fragment reads of iteration kt - 1 are complete)
+      if (!((VAR & 64) && kt > 0)) __syncthreads();
+      if ((VAR & 64) && kt > 0) {         // (probe: the MFMA sequence alone, on the first tile's fragments)
+        PG_MFMA3(pah, pal, pbh, pbl);
+        PG_MFMA3(pah, pal, pbh, pbl);
+        continue;
+      }
+      if ((VAR & 32) && late && kt > 0) PG_MFMA3(pah, pal, pbh, pbl);
+      if (kt + 1 < nk && issuer && !((VAR & 16) && kt >= 1) && !(VAR & 64)) {
         char *nx = smem + ((kt + 1) & 1) * STAGE;
         sa.issue(nx, iw);
         sb.issue(nx + A_BYTES, iw);
@@ -281,32 +302,36 @@ __device__ __forceinline__ void gemm_body(const Core &p, const typename Epi::Arg
           }
         }
       }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      {
         f16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) { ah[i] = fa.load(SA, ta + i, ks, 0); al[i] = fa.load(SA, ta + i, ks, 1); }
+        for (int i = 0; i < TM; ++i) { ah[i] = fa.load(SA, ta + i, 0, 0); al[i] = fa.load(SA, ta + i, 0, 1); }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) { bh[j] = fb.load(SB, tb + j, ks, 0); bl[j] = fb.load(SB, tb + j, ks, 1); }
+        for (int j = 0; j < TN; ++j) { bh[j] = fb.load(SB, tb + j, 0, 0); bl[j] = fb.load(SB, tb + j, 0, 1); }
         if (VAR & 2) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        PG_MFMA3(ah, al, bh, bl);
         if (VAR & 2) __builtin_amdgcn_s_setprio(0);
       }
+      {
+        f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { ah[i] = fa.load(SA, ta + i, 1, 0); al[i] = fa.load(SA, ta + i, 1, 1); }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { bh[j] = fb.load(SB, tb + j, 1, 0); bl[j] = fb.load(SB, tb + j, 1, 1); }
+        if (((VAR & 32) && late) || (VAR & 64)) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) { pah[i] = ah[i]; pal[i] = al[i]; }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) { pbh[j] = bh[j]; pbl[j] = bl[j]; }
+        } else {
+          if (VAR & 2) __builtin_amdgcn_s_setprio(1);
+          PG_MFMA3(ah, al, bh, bl);
+          if (VAR & 2) __builtin_amdgcn_s_setprio(0);
+        }
+      }
     }
+    if ((VAR & 32) && late && !(VAR & 4)) PG_MFMA3(pah, pal, pbh, pbl);
+#undef PG_MFMA3
   }
   if (VAR & 8) {                        // (probe: no epilogue -- keep the accumulators alive)
     float x = 0.f;

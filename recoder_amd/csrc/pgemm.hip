@@ -24,11 +24,15 @@ namespace {
 
 inline bool al16(const void *q) { return ((uintptr_t)q & 15) == 0; }
 
-// tile of the decode by the problem's size (the capacity: the live item count is on the device)
+// Tile shapes follow the BATCH size alone: the item capacity of a block says nothing about its live item
+// set (C3: 41 k items of capacity, 8.4 k live per batch -- 128 x 256 decode tiles left half the chip
+// idle, a 256-row dW tile's 128 KB of LDS left the encoder backward of the same launch one workgroup
+// per CU: 0.290 vs 0.233 ms per step), and the live count only exists on the device.
 inline void decode_tile(int B, int n_cap, int &bm, int &bn) {
   static const int force = [] { const char *e = getenv("RK_PG_TILE"); return e ? atoi(e) : 0; }();   // (tuning)
+  (void)n_cap;
   if (force == 256 || (force == 0 && B >= 1024)) { bm = 256; bn = 256; return; }
-  if (force == 1282 || (force == 0 && n_cap >= 16384)) { bm = 128; bn = 256; return; }
+  if (force == 1282) { bm = 128; bn = 256; return; }
   bm = 128; bn = 128;
 }
 
@@ -41,10 +45,11 @@ inline void dz_tile(int B, int h, int &bm, int &bn) {
   bn = h <= 128 ? 128 : 256;
   bm = B >= 1024 ? 256 : 128;
 }
-inline void dw_tile(int h, int n_cap, int &bm, int &bn) {
-  // long item sets: 256 x 256 (or x 128) tiles; else 64 x 128 on 4 waves -- 48 KB of LDS, so that the
-  // encoder backward's workgroups of the same launch (rk_pg_dw_encode_bwd) still run three to a CU
-  if (n_cap >= 32768) { bm = 256; bn = h <= 128 ? 128 : 256; return; }
+inline void dw_tile(int B, int h, int n_cap, int &bm, int &bn) {
+  // large batches (K = B): 256 x 256 (or x 128) tiles; else 64 x 128 on 4 waves -- 48 KB of LDS, so that
+  // the encoder backward's workgroups of the same launch (rk_pg_dw_encode_bwd) still run three to a CU
+  (void)n_cap;
+  if (B >= 1024) { bm = 256; bn = h <= 128 ? 128 : 256; return; }
   bm = 64; bn = 128;
 }
 
@@ -58,6 +63,8 @@ struct EncBwd {
   float *G, *gb;
   int n_gb;
 };
+__global__ __launch_bounds__(256) void mnll_merge_kernel(const pg::MnllMerge a) { pg::mnll_merge_body(a, (int)blockIdx.x); }
+
 template <int BM, int BN, int WM, int WN, int HV>
 __global__ __launch_bounds__(WM * WN * 64) void dw_encbwd_kernel(const pg::Core p, const pg::EpiSlab::Args e,
                                                                 const int n_dw, const EncBwd enc) {
@@ -129,6 +136,62 @@ extern "C" int rk_pg_decode_loss(const rk_planes_t *pl, int32_t B, const rk_bloc
   else if (bn == 256) GO(128, 256, 2, 4); else GO(128, 128, 2, 2);
 #undef GO
   if (rc != hipSuccess) { rk_set_error("pg_decode_loss: %s", hipGetErrorString(rc)); return -1; }
+  return 0;
+}
+
+// ---- multinomial NLL: statistics pass + decode / loss pass (pgemm_epi.h EpiStats, EpiLoss<LOSS_MNLL>) ----
+extern "C" int64_t rk_pg_mnll_workspace_floats(int32_t B, int32_t n_cap) {
+  return (int64_t)B * (2 * rk_cdiv(n_cap, 128) + 2) + 64;
+}
+
+extern "C" int rk_pg_decode_mnll(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off,
+                                 const float *b_de, float inv_B, float *mnll_ws, void *dO_img, int32_t rows_img,
+                                 float *dO_scales, float *dO_f32, float *loss_part, float *gb_part,
+                                 void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(pl && B <= pl->B_cap && tgt->n_cap <= pl->n_cap, "planes were laid out for another shape");
+  RK_REQUIRE(row_off >= 0 && row_off + B <= tgt->S_cap, "row slice out of range");
+  RK_REQUIRE(tgt->implicit || tgt->pref_rc != nullptr, "explicit values need pref_rc");
+  RK_REQUIRE(mnll_ws && dO_img && dO_scales && al16(dO_img) && rows_img >= ((B + 31) & ~31),
+             "dO image: 16-byte aligned, round_up(B, 32) rows; a statistics workspace");
+  if (B == 0) return 0;
+  int bm, bn;
+  decode_tile(B, tgt->n_cap, bm, bn);
+  if (bm == 256) bm = 128;               // (the multinomial epilogue: as the logistic one, 4 tiles per wave)
+  const int KT = rkp::kp_of(pl->h) / 32;
+  pg::Core p = {};
+  p.a.img = (const char *)pl->z; p.a.pitch = (int64_t)KT * pg::LINE; p.a.lines = KT; p.a.rows = pl->B_cap;
+  p.b.img = (const char *)pl->w; p.b.pitch = (int64_t)KT * pg::LINE; p.b.lines = KT; p.b.rows = pl->n_cap;
+  p.M = B; p.N = tgt->n_cap; p.K = pl->h; p.Ndev = tgt->counts; p.splits = 1;
+  const int pitch = rk_cdiv(tgt->n_cap, bn);
+  float *stats = mnll_ws, *rowst = mnll_ws + (int64_t)B * pitch * 2;
+  pg::StatsArgs sa = {};
+  sa.blk = *tgt; sa.row_off = row_off; sa.bias = b_de; sa.bidx = tgt->items; sa.scales = pl->scales;
+  sa.stats = stats; sa.pitch = pitch;
+  pg::MnllMerge mm = {};
+  mm.blk = *tgt; mm.row_off = row_off; mm.B = B; mm.Ndev = tgt->counts; mm.bn = bn; mm.stats = stats; mm.pitch = pitch;
+  mm.rowst = rowst;
+  pg::LossArgs e = {};
+  e.blk = *tgt; e.row_off = row_off; e.confidence = 0.f; e.inv_B = inv_B;
+  e.bias = b_de; e.bidx = tgt->items; e.scales = pl->scales;
+  e.loss_part = loss_part; e.gb_part = gb_part;
+  e.dimg = (char *)dO_img; e.ld_dev = tgt->counts + 2; e.rows_img = rows_img;
+  e.dscale = dO_scales; e.ds_pitch = rk_cdiv(tgt->n_cap, 32);
+  e.C = dO_f32;
+  e.rowst_g = rowst;
+  const int tiles = rk_cdiv(B, bm) * rk_cdiv(tgt->n_cap, bn);
+  hipError_t rc;
+  if (bn == 256) rc = pg::launch<128, 256, 2, 4, false, false, pg::EpiStats>(p, sa, tiles, stream);
+  else rc = pg::launch<128, 128, 2, 2, false, false, pg::EpiStats>(p, sa, tiles, stream);
+  if (rc == hipSuccess) {
+    hipLaunchKernelGGL(mnll_merge_kernel, dim3(rk_cdiv(B, 4)), dim3(256), 0, stream, mm);
+    rc = hipGetLastError();
+  }
+  if (rc == hipSuccess) {
+    if (bn == 256) rc = pg::launch<128, 256, 2, 4, false, false, pg::EpiLoss<pg::LOSS_MNLL>>(p, e, tiles, stream);
+    else rc = pg::launch<128, 128, 2, 2, false, false, pg::EpiLoss<pg::LOSS_MNLL>>(p, e, tiles, stream);
+  }
+  if (rc != hipSuccess) { rk_set_error("pg_decode_mnll: %s", hipGetErrorString(rc)); return -1; }
   return 0;
 }
 
@@ -217,7 +280,7 @@ static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, in
   if (B == 0) return 0;
   const int h = pl->h;
   int bm, bn;
-  dw_tile(h, tgt->n_cap, bm, bn);
+  dw_tile(B, h, tgt->n_cap, bm, bn);
   const int KT = rkp::kp_of(h) / 32;
   pg::Core p = {};
   p.a.img = (const char *)dO_img; p.a.rows = (B + 31) & ~31; p.a_ld_dev = tgt->counts + 2;

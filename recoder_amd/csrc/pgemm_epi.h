@@ -45,7 +45,124 @@ struct EpiSlab {
   }
 };
 
-enum { LOSS_MSE = 1, LOSS_BCE = 3 };
+enum { LOSS_MSE = 1, LOSS_MNLL = 2, LOSS_BCE = 3 };
+
+// Multinomial NLL (reference losses.py:68-71: -sum t * log_softmax(o)), two passes over the decode:
+//   pass 1 (EpiStats): nothing of the logits is written -- every (row, column tile) leaves the pair
+//           {max, sum exp(o - max)} of its live columns (8 bytes), tiles of column tile 0 also the row's
+//           target sum;
+//   pass 2 (EpiLoss<LOSS_MNLL>): the decode again, the row's log-sum-exp merged from the pairs (fixed
+//           order), loss + dLoss/dLogits = (softmax * sum_t - t) / B as the plane image like MSE / BCE.
+// 3.2 GF of MFMA work a second time instead of writing, re-reading and rewriting a B x n_b fp32 matrix.
+struct StatsArgs {
+  rk_block_t blk;
+  int row_off;
+  const float *bias;
+  const int32_t *bidx;
+  const float *scales;
+  float *stats;              // [row][pitch][2]
+  int pitch;                 // column tiles of the capacity
+};
+
+struct EpiStats {
+  typedef StatsArgs Args;
+  template <int BM, int BN, int TM, int TN>
+  static __device__ __forceinline__ void run(const Args &e, const Tile &T, f32x16 (&acc)[TM][TN], char *smem,
+                                             const float (&)[TM]) {
+    constexpr int WN = BN / (TN * 32);
+    const int M = T.M, N = T.N, lane = T.lane, l31 = lane & 31, lh = lane >> 5;
+    const float inv = 1.0f / (e.scales[0] * e.scales[1]);
+    float bv[TN];
+    bool live[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = T.n0 + (T.wn * TN + j) * 32 + l31;
+      live[j] = n < N;
+      bv[j] = e.bias[e.bidx[min(n, N - 1)]];
+    }
+    float *pm = reinterpret_cast<float *>(smem);           // [WN][BM] maxima, then [WN][BM] sums
+    float *ps = pm + WN * BM;
+    __syncthreads();                                        // (the k-loop's last stage is free)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float o[TN];
+        float m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          o[j] = live[j] ? acc[i][j][r] * inv + bv[j] : -INFINITY;
+          m = fmaxf(m, o[j]);
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));     // the half-wave's 32 columns
+        float se = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) se += live[j] ? expf(o[j] - m) : 0.f;
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) se += __shfl_xor(se, off, 64);
+        const int lr = (T.wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (l31 == 0) { pm[T.wn * BM + lr] = m; ps[T.wn * BM + lr] = se; }
+      }
+    __syncthreads();
+    // merge the WN column ranges of the tile (fixed order), one thread per row
+    for (int lr = threadIdx.x; lr < BM; lr += (BM / (TM * 32)) * WN * 64) {
+      const int m_ = T.m0 + lr;
+      if (m_ >= M) continue;
+      float mx = pm[lr];
+#pragma unroll
+      for (int w = 1; w < WN; ++w) mx = fmaxf(mx, pm[w * BM + lr]);
+      float se = 0.f;
+#pragma unroll
+      for (int w = 0; w < WN; ++w) se += pm[w * BM + lr] == -INFINITY ? 0.f : ps[w * BM + lr] * expf(pm[w * BM + lr] - mx);
+      float *d = e.stats + ((int64_t)m_ * e.pitch + T.nt) * 2;
+      d[0] = mx; d[1] = se;
+    }
+  }
+};
+
+// between the passes: one WAVE per row merges the row's pairs (lanes over the column tiles, online-softmax
+// merge in a fixed order) into rowst[row] = {log-sum-exp, sum of the row's targets}
+struct MnllMerge {
+  rk_block_t blk;
+  int row_off, B;
+  const int32_t *Ndev;
+  int bn;                    // columns of a statistics tile
+  const float *stats;
+  int pitch;
+  float *rowst;              // [B][2]
+};
+__device__ __forceinline__ void mnll_merge_body(const MnllMerge &a, const int block) {
+  const int lane = threadIdx.x & 63, r = block * 4 + (threadIdx.x >> 6);
+  if (r >= a.B) return;
+  const int ntl = (*a.Ndev + a.bn - 1) / a.bn;
+  const float *st = a.stats + (int64_t)r * a.pitch * 2;
+  const rk_block_t &b = a.blk;
+  const int row = a.row_off + r;
+  const int beg = b.indptr[row], end = b.indptr[row + 1];
+  float mx = -INFINITY, se = 0.f;
+  for (int t = lane; t < ntl; t += 64) {
+    const float2 p = *reinterpret_cast<const float2 *>(st + 2 * t);
+    if (p.x > mx) { se = se * expf(mx - p.x) + p.y; mx = p.x; }        // (expf(-inf) = 0 the first time)
+    else if (p.x > -INFINITY) se += p.y * expf(p.x - mx);
+  }
+  float ts = 0.f;
+  if (!b.implicit)
+    for (int k = beg + lane; k < end; k += 64) ts += b.vals[k];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float om = __shfl_xor(mx, off, 64), os = __shfl_xor(se, off, 64);
+    const float nm = fmaxf(mx, om);
+    se = (mx > -INFINITY ? se * expf(mx - nm) : 0.f) + (om > -INFINITY ? os * expf(om - nm) : 0.f);
+    mx = nm;
+    ts += __shfl_xor(ts, off, 64);
+  }
+  if (lane == 0) {
+    a.rowst[2 * r] = mx + logf(se);
+    a.rowst[2 * r + 1] = b.implicit ? (float)(end - beg) : ts;
+  }
+}
+
 
 struct LossArgs {
     rk_block_t blk;
@@ -61,6 +178,8 @@ struct LossArgs {
     float *dscale;             // scale table [row / 64][ds_pitch], one entry per 32 columns
     int ds_pitch;
     float *C;                  // nullable: dO as fp32 too (tests), leading dimension ld
+    // LOSS_MNLL: [row][2] = {the row's log-sum-exp, the sum of its targets} (mnll_merge_body)
+    const float *rowst_g;
 };
 
 template <int LOSS>
@@ -110,6 +229,14 @@ struct EpiLoss {
     }
     const float inv = 1.0f / (e.scales[0] * e.scales[1]);   // exact: powers of two
     __syncthreads();                                        // (the k-loop's last stage is free)
+    float *rowst = cpart + (BM / 32) * BN;                  // LOSS_MNLL: [BM][2] = {log-sum-exp, target sum}
+    if (LOSS == LOSS_MNLL) {
+      for (int lr = threadIdx.x; lr < BM; lr += NWAVES * 64) {
+        const float2 v = *reinterpret_cast<const float2 *>(e.rowst_g + 2 * (int64_t)min(T.m0 + lr, M - 1));
+        rowst[2 * lr] = v.x; rowst[2 * lr + 1] = v.y;
+      }
+      __syncthreads();
+    }
     // Scale granule = 64 rows x 32 columns (two 32 x 32 blocks of one wave): the maximum of a granule is
     // a WAVE reduction, and only 2 x 16 gradient registers are alive at a time
     static_assert(TM % 2 == 0, "wave tiles of at least 64 rows");
@@ -138,6 +265,11 @@ struct EpiLoss {
           const float ov[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
           const int m = T.m0 + (T.wm * TM + i) * 32 + rr + 16 * it;
           const uint32_t w = bw[i][j][it];
+          float lse = 0.f, tsum = 0.f;
+          if (LOSS == LOSS_MNLL) {
+            lse = rowst[2 * ((T.wm * TM + i) * 32 + rr + 16 * it)];
+            tsum = rowst[2 * ((T.wm * TM + i) * 32 + rr + 16 * it) + 1];
+          }
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
             const bool ok = (m < M) && (n + u < N);
@@ -153,6 +285,10 @@ struct EpiLoss {
               const float d = o - tv;
               l = wgt * (d * d);
               g = (2.0f * d) * (wgt * e.inv_B);
+            } else if (LOSS == LOSS_MNLL) {       // -t * log_softmax(o); d/do = softmax * sum_t - t
+              const float lsm = o - lse;
+              l = -tv * lsm;
+              g = (expf(ok ? lsm : -INFINITY) * tsum - tv) * e.inv_B;
             } else {  // BCE with logits: (1 - t) * o - logsigmoid(o)
               const float ls = fminf(o, 0.f) - log1pf(expf(-fabsf(o)));
               l = (1.0f - tv) * o - ls;

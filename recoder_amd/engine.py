@@ -51,8 +51,8 @@ class TimedLib:
                                               "rk_dw3_workspace_bytes", "rk_dw3_max_splits", "rk_dw3_slabs", "rk_gemm_split16", "rk_dw_pairs",
                                               "rk_dw3_planes_bytes", "rk_dw3_rows_pad", "rk_dw3_cols_pad",
                                               "rk_planes_bytes", "rk_planes_layout", "rk_split_zt_ok",
-                                              "rk_pg_enabled", "rk_pg_scale_floats", "rk_pg_decode_granule",
-                                              "rk_pg_dz_workspace_bytes", "rk_pg_dw_workspace_bytes", "rk_pg_dw_splits",
+                                              "rk_pg_enabled", "rk_pg_scale_floats", "rk_pg_decode_granule", "rk_gemm_plain_bf16",
+                                              "rk_pg_dz_workspace_bytes", "rk_pg_dw_workspace_bytes", "rk_pg_dw_splits", "rk_pg_mnll_workspace_floats",
                                               "rk_last_error", "rk_version"):
       return fn
 
@@ -201,6 +201,16 @@ class FusedEngine:
       self.planes = RkPlanes()
       check(self.lib.rk_planes_layout(ptr(self.planes_buf), B_cap, h0, n_cap, ctypes.byref(self.planes)),
             "rk_planes_layout")
+    # multinomial NLL on the pipelined kernels: the statistics pass's pairs + the rows' target sums
+    self.mnll_ws = (torch.zeros(self.lib.rk_pg_mnll_workspace_floats(B_cap, n_cap), **f)
+                    if self.loss_id == LOSS_MNLL else None)
+    self.planes_nowt = None
+    if self.planes is not None:
+      # the same images without the W^T one (csrc/pgemm.h reads the W image along its rows)
+      from ._lib import RkPlanes
+      self.planes_nowt = RkPlanes()
+      ctypes.memmove(ctypes.byref(self.planes_nowt), ctypes.byref(self.planes), ctypes.sizeof(RkPlanes))
+      self.planes_nowt.wt = None
     self.n_part = self.lib.rk_loss_partials(B_cap, n_cap)
     self.loss_part = torch.zeros(self.n_part, **f)
     self.loss_out = torch.zeros(1, **f)
@@ -345,7 +355,9 @@ class FusedEngine:
       check(lib.rk_ae_encode_fwd_split_w(blk.ref, row_off, B, ptr(m.en_embedding_layer.weight),
                                          ptr(m.en_bias), self.h[0], ptr(keep_noise), p_noise, self.seed,
                                          self.rng_step, ptr(blk.users), self.act, ptr(self.enc[0]),
-                                         ptr(W_de), ptr(self.ranges), ctypes.byref(self.planes), stream),
+                                         ptr(W_de), ptr(self.ranges),
+                                         ctypes.byref(self.planes_nowt if getattr(self, "_split_nowt", False)
+                                                      else self.planes), stream),
             "rk_ae_encode_fwd")
       self._w_split_of = blk
     else:
@@ -445,8 +457,22 @@ class FusedEngine:
     check(self.lib.rk_amax(ptr(z), n, ptr(self.ranges), stream), "rk_amax")
     return ptr(self.ranges)
 
+  def _pg_entry_ok(self, B, n_cap):
+    """Entry-by-entry steps: the three contractions on the pipelined pair-plane kernels (csrc/pgemm.h)
+    -- everything outside the fused decode + dZ launch's domain: the multinomial loss, h > 256,
+    >= 1024 rows."""
+    lib = self.lib
+    # (the multinomial loss as TWO decode passes pays where a pass is flop-bound, not at B = 500: C3,
+    # n_b = 8.4 k -- 25.6 + 5.2 + 27.5 us for statistics / merge / loss passes against 19.7 + 18.9 us for
+    # the decode that writes the logits + rk_mnll_finish; RK_PG_MNLL=1 forces it)
+    if self.loss_id == LOSS_MNLL and B < 1024 and os.environ.get("RK_PG_MNLL") != "1":
+      return False
+    return (self.planes is not None and self.split16 and bool(lib.rk_pg_enabled()) and
+            not lib.rk_gemm_plain_bf16() and self.item_parallel is None and
+            not lib.rk_decode_dz_fused_ok(B, self.h[0], n_cap, self.loss_id))
+
   def _loss(self, z, B, tgt, row_off, denom_rows, stream, out=None, ip=None, defer=False, fuse_dz=False,
-            zt_ws=None):
+            zt_ws=None, pg_ok=False):
     """decode + loss; leaves dLoss/dLogits in self.dO. Returns device scalar.  ip: the
     block holds an item shard (parallel.ItemParallel) -- only the multinomial loss needs to
     know: its softmax statistics are combined over the ranks."""
@@ -456,6 +482,7 @@ class FusedEngine:
     out = self.loss_out if out is None else out
     self._dz_in_ws = False
     self._dz_on_planes = False
+    self._dz_pg = False
     # zt_ws: the workspace the step's dW launch will use -- the split launch then writes Z^T as that
     # kernel's fp16 pair planes at its head (one launch less inside rk_decode_bwd_dw2)
     self._zt_ready = None
@@ -480,6 +507,25 @@ class FusedEngine:
                                          self.confidence, inv_B, ptr(self.dO), ptr(self.loss_part),
                                          ptr(self.gb_part), ptr(self.ws), stream), "rk_decode_loss_dz_planes")
       self._dz_in_ws = True
+    elif fuse_dz and pg_ok and ip is None and self._pg_entry_ok(B, tgt.n_cap) and \
+        os.environ.get("RK_ENTRY_PLANES", "1") != "0":
+      # outside the fused launch's domain: decode + loss, dZ and dW on the pipelined pair-plane kernels --
+      # ONE split launch (W image unless the encoder forward cut it, Z image; no W^T image, no Z^T planes),
+      # dLoss/dLogits as a plane image; the multinomial loss as a statistics pass + the decode / loss pass
+      # (no logits matrix, no rk_mnll_finish)
+      h0 = self.h[0]
+      rg = self._ranges(z, B * h0, stream)
+      check(lib.rk_split_wz_zt(None if w_done else ptr(W), ptr(z), B, h0, tgt.ref, rg,
+                               ctypes.byref(self.planes_nowt), None, stream), "rk_split_wz")
+      if self.loss_id == LOSS_MNLL:
+        check(lib.rk_pg_decode_mnll(ctypes.byref(self.planes), B, tgt.ref, row_off, ptr(b), inv_B,
+                                    ptr(self.mnll_ws), ptr(self.dO), self.do_rows, ptr(self.do_scales), None,
+                                    ptr(self.loss_part), ptr(self.gb_part), stream), "rk_pg_decode_mnll")
+      else:
+        check(lib.rk_pg_decode_loss(ctypes.byref(self.planes), B, tgt.ref, row_off, ptr(b), self.loss_id,
+                                    self.confidence, inv_B, ptr(self.dO), self.do_rows, ptr(self.do_scales),
+                                    None, ptr(self.loss_part), ptr(self.gb_part), stream), "rk_pg_decode_loss")
+      self._dz_pg = True
     elif fuse_dz and ip is None and self.planes is not None and self.split16 and self.item_parallel is None \
         and os.environ.get("RK_ENTRY_PLANES", "1") != "0":
       # outside the fused launch's domain (multinomial loss, h > 256, >= 1024 rows): still the plane
@@ -511,6 +557,8 @@ class FusedEngine:
       check(lib.rk_mnll_finish_ext(ptr(self.dO), B, tgt.ref, row_off, inv_B, ptr(gmax), ptr(glog),
                                    ptr(tsum), ptr(self.loss_part), stream), "rk_mnll_finish_ext")
       n_part = B
+    elif self.loss_id == LOSS_MNLL and self._dz_pg:
+      n_part = self.lib.rk_loss_partials(B, tgt.n_cap)     # (one partial per tile, as mse / logistic)
     elif self.loss_id == LOSS_MNLL:
       check(lib.rk_mnll_finish(ptr(self.dO), B, tgt.ref, row_off, inv_B, ptr(self.loss_part),
                                stream), "rk_mnll_finish")
@@ -588,6 +636,7 @@ class FusedEngine:
     tb = blk if tgt is None else tgt
     self._gb_lazy = None
     self._gb_en_segs = 0
+    self._pg_step = False
     stream = ctypes.c_void_p(main_s.cuda_stream)
     if getattr(self, "_replay", None) is None:
       self.rng_step += 1
@@ -601,6 +650,8 @@ class FusedEngine:
                                 os.environ.get("RK_ENTRY_DZ_FUSED", "1") != "0" and
                                 os.environ.get("RK_ENTRY_PLANES", "1") != "0" and
                                 os.environ.get("RK_ENTRY_W_SPLIT_FWD", "1") != "0")
+      self._split_nowt = bool(self._split_w_with_fwd and self._pg_entry_ok(B, blk.n_cap) and
+                              self.allreduce is None)
       z = self._ae_forward(blk, row_off, B, keep_noise, keep_drop, True, stream)
       self._split_w_with_fwd = False
     else:
@@ -618,7 +669,8 @@ class FusedEngine:
     zt_ws = self.ws_dw if (lazy and not tied and self.split16 and self.ws_dw is not None and
                            os.environ.get("RK_ENTRY_ZT_SPLIT", "1") != "0") else None
     loss = self._loss(z, B, tb, row_off, rows, stream, out, ip=ip, defer=lazy,
-                      fuse_dz=os.environ.get("RK_ENTRY_DZ_FUSED", "1") != "0", zt_ws=zt_ws)
+                      fuse_dz=os.environ.get("RK_ENTRY_DZ_FUSED", "1") != "0", zt_ws=zt_ws,
+                      pg_ok=lazy and not tied and self.ws_dw is not None)
     self._loss_target = loss
 
     # ---- dW = dO^T . z  (+ decoder bias gradient) ----
@@ -647,7 +699,7 @@ class FusedEngine:
     self._dw_deferred = None
     self._dw_colsum = False
     if defer_dw:
-      if self.loss_id == LOSS_MNLL:
+      if self.loss_id == LOSS_MNLL and not self._dz_pg:
         # (dO comes from rk_mnll_finish: its column sums -- the decoder bias gradient -- are taken by
         # extra workgroups of the dW || encoder-backward launch)
         self._dw_colsum = True
@@ -657,7 +709,7 @@ class FusedEngine:
         check(lib.rk_colsum(ptr(self.gb_part), cdiv(B, self.row_tile), tb.n_cap, 0, ptr(tb.counts),
                             ptr(self.gb_de), stream), "rk_colsum")
       self._dw_deferred = z
-    elif self.loss_id == LOSS_MNLL:
+    elif self.loss_id == LOSS_MNLL and not self._dz_pg:
       # dO was produced by rk_mnll_finish: column sums need a pass over dO
       self._dw(z, B, tb, self.gb_de, dw_stream, keep_slabs)
     else:
@@ -705,6 +757,9 @@ class FusedEngine:
       check(lib.rk_decode_dz_reduce(ptr(self.ws), B, h0, tb.ref, ptr(zact),
                                     self.act, ptr(dz), stream), "rk_decode_dz_reduce")
       self._dz_in_ws = False
+    elif getattr(self, "_dz_pg", False):
+      check(lib.rk_pg_dz(ptr(self.dO), ptr(self.do_scales), 64, 32, B, ctypes.byref(self.planes), tb.ref,
+                         ptr(zact), self.act, ptr(dz), ptr(self.ws), stream), "rk_pg_dz")
     elif getattr(self, "_dz_on_planes", False):
       check(lib.rk_decode_bwd_dz_planes(ptr(self.dO), B, ctypes.byref(self.planes), tb.ref,
                                         ptr(zact), self.act, ptr(dz),
@@ -776,7 +831,12 @@ class FusedEngine:
       if getattr(self, "_dw_deferred", None) is not None:
         zz, self._dw_deferred = self._dw_deferred, None
         zt = ptr(self.ws_dw) if getattr(self, "_zt_ready", None) == self.ws_dw.data_ptr() else None
-        if self._dw_colsum:
+        if getattr(self, "_dz_pg", False):
+          check(lib.rk_pg_dw_encode_bwd(ptr(self.dO), ptr(self.do_scales), 64, 32, B, ctypes.byref(self.planes),
+                                        blk.ref, ptr(self.ws_dw), row_off, ptr(self.denc[0]), ptr(G_en),
+                                        ptr(self.gb_en), stream), "rk_pg_dw_encode_bwd")
+          self._pg_step = True
+        elif self._dw_colsum:
           check(lib.rk_decode_bwd_dw2_encode_bwd_colsum(ptr(self.dO), ptr(zz), B, h0, blk.ref, ptr(self.ws_dw),
                                                         zt, ptr(self.ranges), row_off, ptr(self.denc[0]),
                                                         ptr(G_en), ptr(self.gb_en), ptr(self.gb_de), stream),
@@ -872,7 +932,12 @@ class FusedEngine:
       G, ws = (None, self.ws_dw) if keep_slabs else (self.G_de, self.ws)
       if getattr(self, "_dz_in_ws", False):
         ws = self.ws_dw                  # (self.ws holds the decode launch's dZ partials until the reduce)
-      if self.lib.rk_dw_pairs():
+      if getattr(self, "_dz_pg", False):
+        assert keep_slabs and gb_de is None and red is None
+        check(self.lib.rk_pg_dw(ptr(self.dO), ptr(self.do_scales), 64, 32, B, ctypes.byref(self.planes), blk.ref,
+                                ptr(ws), stream), "rk_pg_dw")
+        self._pg_step = True
+      elif self.lib.rk_dw_pairs():
         # (Z^T pair planes already at the head of this workspace: rk_split_wz_zt of this step's decode)
         zt = ptr(ws) if getattr(self, "_zt_ready", None) == ws.data_ptr() else None
         if red is not None:
@@ -1220,8 +1285,12 @@ class FusedEngine:
     dw_parts = gb_parts = None
     if dec and self._dw_slabs is not None and self._dw_slabs[0] is tb:
       ws = self.ws_dw if self._ws_dw_live else self.ws
-      dw_parts = (self.lib.rk_dw3_slabs(ptr(ws), self._dw_slabs[1], h0), self.lib.rk_dw3_max_splits(),
-                  tb.n_cap * h0, None, tb.counts.data_ptr() + 4 * 4)
+      if getattr(self, "_pg_step", False):
+        dw_parts = (ptr(ws), self.lib.rk_pg_dw_splits(self._dw_slabs[1], h0, tb.n_cap), tb.n_cap * h0, None,
+                    tb.counts.data_ptr() + 4 * 4)
+      else:
+        dw_parts = (self.lib.rk_dw3_slabs(ptr(ws), self._dw_slabs[1], h0), self.lib.rk_dw3_max_splits(),
+                    tb.n_cap * h0, None, tb.counts.data_ptr() + 4 * 4)
     if dec and self._gb_lazy is not None and self._gb_lazy[1] is tb:
       gb_parts = (ptr(self.gb_part), self._gb_lazy[0], 0, tb.counts.data_ptr() + 2 * 4, None)
 

@@ -150,3 +150,48 @@ def test_pg_scales_follow_the_data():
   # (rows 1e4 x apart in one fp32 accumulator: the bound of an fp32 matmul of the same operands applies)
   f32 = ((got.float().t() @ Z).double() - got.t() @ Z.double()).abs() / (got.abs().t() @ Z.double().abs() + 1e-300)
   assert e1 < 6e-7 and e2 < max(6e-7, 2 * f32.max().item()), (e1, e2, f32.max().item())
+
+
+@pytest.mark.parametrize("B,h,n_items,ratings", [(500, 200, 3000, False), (37, 20, 400, True), (300, 64, 5000, False),
+                                                 (1, 8, 97, False), (260, 512, 900, True)])
+def test_pg_decode_mnll_matches_the_two_launch_form(B, h, n_items, ratings):
+  """rk_pg_decode_mnll (statistics pass + decode / loss pass, nothing but 8 bytes per row and column tile in
+  between) against rk_decode_loss_planes + rk_mnll_finish (logits matrix written, re-read, rewritten)."""
+  from recoder_amd._lib import LOSS_MNLL
+  lib, blk, W, bias, Z, ranges, pl, buf = _setup(B, h, max(B, 600), n_items, 14, seed=5 * B + h, ratings=ratings)
+  st = current_stream()
+  dev = Z.device
+  f = dict(dtype=torch.float32, device=dev)
+  n_b, nnz, ld, S = blk.counts_host()
+  check(lib.rk_split_w(ptr(W), h, blk.ref, ptr(ranges), ctypes.byref(pl), st))
+  check(lib.rk_split_z(ptr(Z), B, h, ptr(ranges), ctypes.byref(pl), st))
+  dO = torch.zeros(B * blk.ld_cap, **f)
+  part = torch.zeros(max(B, lib.rk_loss_partials(B, blk.n_cap)), **f)
+  check(lib.rk_decode_loss_planes(ctypes.byref(pl), B, blk.ref, 0, ptr(bias), LOSS_MNLL, 0.0, 1.0 / B,
+                                  ptr(dO), 0, ptr(part), None, st))
+  check(lib.rk_mnll_finish(ptr(dO), B, blk.ref, 0, 1.0 / B, ptr(part), st))
+  torch.cuda.synchronize()
+  ref = dO[:B * ld].view(B, ld)[:, :n_b].clone()
+  ref_loss = part[:B].double().sum().item()
+  rows_img = -(-B // 32) * 32
+  img = torch.full(((rows_img + 256) * blk.ld_cap * 2,), 0x7e00, dtype=torch.int16, device=dev)
+  sc = torch.full((lib.rk_pg_scale_floats(B, blk.n_cap),), float("nan"), **f)
+  ws = torch.full((lib.rk_pg_mnll_workspace_floats(B, blk.n_cap),), float("nan"), **f)
+  dO2 = torch.zeros(B * blk.ld_cap, **f)
+  part2 = torch.zeros(lib.rk_loss_partials(B, blk.n_cap), **f)
+  ntile = -(-B // lib.rk_decode_row_tile())
+  gbp2 = torch.zeros(ntile * blk.ld_cap, **f)
+  check(lib.rk_pg_decode_mnll(ctypes.byref(pl), B, blk.ref, 0, ptr(bias), 1.0 / B, ptr(ws), ptr(img), rows_img,
+                              ptr(sc), ptr(dO2), ptr(part2), ptr(gbp2), st))
+  torch.cuda.synchronize()
+  got = dO2[:B * ld].view(B, ld)[:, :n_b]
+  scale = ref.abs().max().item()
+  assert (got - ref).abs().max().item() <= 2e-6 * max(scale, 1e-30), ((got - ref).abs().max().item(), scale)
+  loss = part2.double().sum().item()
+  assert abs(loss - ref_loss) <= 2e-6 * abs(ref_loss), (loss, ref_loss)
+  # decoder bias gradient = column sums of dO (rk_colsum in the two-launch form)
+  gb = gbp2[:ntile * ld].view(ntile, ld)[:, :n_b].sum(0)
+  assert torch.allclose(gb, ref.sum(0), rtol=1e-4, atol=2e-6 * max(scale, 1e-30) * B)
+  rec = _image_to_f32(img[:rows_img * ld * 2].view(rows_img, ld * 2), sc, rows_img, ld, 64, 32, -(-blk.n_cap // 32))
+  assert torch.isfinite(rec).all()
+  assert (rec[:B, :n_b] - got).abs().max().item() <= 2.0 ** -20 * max(got.abs().max().item(), 1e-30)

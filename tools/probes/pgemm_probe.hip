@@ -81,6 +81,10 @@ static hipError_t dispatch(const pg::Core &p, const pg::EpiStore::Args &e, int a
     case 8: return dispatch_v<BM, BN, WM, WN, 8>(p, e, atr, btr, tiles, s);
     case 12: return dispatch_v<BM, BN, WM, WN, 12>(p, e, atr, btr, tiles, s);
     case 24: return dispatch_v<BM, BN, WM, WN, 24>(p, e, atr, btr, tiles, s);
+    case 32: return dispatch_v<BM, BN, WM, WN, 32>(p, e, atr, btr, tiles, s);
+    case 40: return dispatch_v<BM, BN, WM, WN, 40>(p, e, atr, btr, tiles, s);
+    case 56: return dispatch_v<BM, BN, WM, WN, 56>(p, e, atr, btr, tiles, s);
+    case 72: return dispatch_v<BM, BN, WM, WN, 72>(p, e, atr, btr, tiles, s);
     default: return dispatch_v<BM, BN, WM, WN, 0>(p, e, atr, btr, tiles, s);
   }
 }
@@ -193,6 +197,13 @@ static void bench_case(const char *name, const Case &cs, int reps) {
   p.a.img = da; p.a.lines = a_lines; p.a.rows = a_rows; p.a.pitch = (int64_t)a_lines * 128;
   p.b.img = db; p.b.lines = b_lines; p.b.rows = b_rows; p.b.pitch = (int64_t)b_lines * 128;
   p.M = M; p.N = N; p.K = K; p.splits = cs.splits;
+  if (getenv("NLIVE")) {            // the grid covers N (a capacity), the live column count sits on the device
+    int32_t *nd;
+    const int32_t nl = atoi(getenv("NLIVE"));
+    HC(hipMalloc(&nd, 4));
+    HC(hipMemcpy(nd, &nl, 4, hipMemcpyHostToDevice));
+    p.Ndev = nd;
+  }
   pg::EpiStore::Args e = {};
   e.C = dc; e.ldc = N; e.slab_stride = (int64_t)M * N; e.scale = 1.f;
   hipEvent_t e0, e1;

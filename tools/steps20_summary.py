@@ -1,4 +1,5 @@
-rows=[l.split() for l in open("gpurun_out/s20b/dump.txt")]
+import sys
+rows=[l.split() for l in open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/s20b/dump.txt")]
 idx=[i for i,r in enumerate(rows) if len(r)>6 and "cursor_set" in r[6]]
 i0=idx[-2]
 for r in rows[max(0,i0-2):i0+12]: print(" ".join(r)[:110])
