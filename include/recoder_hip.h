@@ -423,6 +423,19 @@ int rk_decode_dz_reduce(const float *dz_workspace, int32_t B, int32_t h, const r
  *   from the image and pl->z (rk_adam_multi adds them: g_parts).  (gr, gc): the granule of the producer
  *   of the image -- rk_pg_decode_granule, or 64 x 128 for rk_decode_loss_dz_planes' image form.
  */
+/* The fused decode + loss + dZ partials of SMALL hidden sizes, register resident (csrc/fdecode.hip): the
+ * 128-item x 128-user tile is computed transposed, so that the loss runs in the accumulator layout and
+ * the gradient tile becomes the MFMA operand of the dZ product through v_permlane32_swap -- no LDS round
+ * trip; the tile's W rows stay resident in LDS and are read a second time along their rows (no W^T image).
+ * dLoss/dLogits leaves as a plane image (scale granule 32 users x 64 items: dO_scales[(m / 32) *
+ * ceil(n_cap / 64) + n / 64]); the slabs as rk_decode_loss_dz_planes leaves them (rk_decode_dz_reduce
+ * sums them).  The decoder bias gradient is NOT produced here: rk_pg_dw_encode_bwd takes it from the image.
+ * Domain: rk_fdec_ok (mse / logistic, h <= 224, < 1024 rows; RK_FDEC=0: off). */
+int32_t rk_fdec_ok(int32_t B, int32_t h, int32_t n_cap, int32_t loss_kind);
+int64_t rk_fdec_workspace_bytes(int32_t B, int32_t h, int32_t n_cap);
+int rk_fdec_loss_dz(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off, const float *b_de,
+                    int32_t loss_kind, float confidence, float inv_B, void *dO_img, int32_t rows_img,
+                    float *dO_scales, float *loss_part, float *dz_workspace, void *stream);
 int32_t rk_pg_enabled(void);     /* RK_PG=0 switches the family off (the round-3 plane kernels run instead) */
 void rk_pg_decode_granule(int32_t B, int32_t n_cap, int32_t *gr, int32_t *gc);
 int64_t rk_pg_scale_floats(int32_t B_cap, int32_t n_cap);
@@ -452,7 +465,9 @@ int rk_pg_dw(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc,
  * first in the grid, then a wave per item column (domain: rk_dw_encode_bwd_fused_ok) */
 int rk_pg_dw_encode_bwd(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
                         const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, int32_t row_off,
-                        const float *dZ0pre, float *G_en, float *gb_en, void *stream);
+                        const float *dZ0pre, float *G_en, float *gb_en,
+                        float *gb_de /* nullable: the decoder bias gradient [n_t] = column sums of dO, from
+                                        the image, by a third workgroup range */, void *stream);
 /* tuning probe (tools/probes/enc_phase_probe.py): device buffer of 8 uint64 per user row of the
  * encoder forward (entry, first entries loaded, gather done, end); NULL (default): off */
 void rk_enc_probe(unsigned long long *buffer);

@@ -172,6 +172,10 @@ SIGNATURES = {
   "rk_decode_loss_dz_image": (c_int32, [_P, c_int32, _BLK, c_int32, _P, c_int32, c_float, c_float, _P, c_int32, _P,
                                         _P, _P, _P, _P]),
   "rk_decode_dz_reduce": (c_int32, [_P, c_int32, c_int32, _BLK, _P, c_int32, _P, _P]),
+  "rk_fdec_ok": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
+  "rk_fdec_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
+  "rk_fdec_loss_dz": (c_int32, [POINTER(RkPlanes), c_int32, _BLK, c_int32, _P, c_int32, c_float, c_float, _P, c_int32,
+                                _P, _P, _P, _P]),
   "rk_pg_enabled": (c_int32, []),
   "rk_ae_step_uses_pg": (c_int32, [_P]),
   "rk_pg_decode_granule": (None, [c_int32, c_int32, POINTER(c_int32), POINTER(c_int32)]),
@@ -187,7 +191,7 @@ SIGNATURES = {
   "rk_pg_dw_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
   "rk_pg_dw": (c_int32, [_P, _P, c_int32, c_int32, c_int32, POINTER(RkPlanes), _BLK, _P, _P]),
   "rk_pg_dw_encode_bwd": (c_int32, [_P, _P, c_int32, c_int32, c_int32, POINTER(RkPlanes), _BLK, _P, c_int32, _P, _P, _P,
-                                    _P]),
+                                    _P, _P]),
   "rk_dw3_planes_bytes": (c_int64, [c_int32, c_int32]),
   "rk_dw3_rows_pad": (c_int32, [c_int32]),
   "rk_dw3_cols_pad": (c_int32, [c_int32]),

@@ -193,6 +193,7 @@ __device__ __forceinline__ void gemm_body(const Core &p, const typename Epi::Arg
   T.M = M; T.N = N;
   T.tm = (M + BM - 1) / BM; T.tn = (N + BN - 1) / BN;
   const int per_split = T.tm * T.tn;
+  const int nk_all = (K + 31) >> 5;
   int splits = p.splits;
   if (p.auto_slots > 0) {
     splits = min(splits, max(1, p.auto_slots / max(1, per_split)));
@@ -208,7 +209,6 @@ __device__ __forceinline__ void gemm_body(const Core &p, const typename Epi::Arg
   T.lane = tid & 63; T.wave = rfl(tid >> 6);
   T.wm = T.wave / WN; T.wn = T.wave % WN;
   // k range of this slab, in k-tiles of 32
-  const int nk_all = (K + 31) >> 5;
   const int kchunk = (nk_all + splits - 1) / splits;
   const int kt0 = T.split * kchunk;
   const int nk = min(kchunk, nk_all - kt0);
@@ -220,6 +220,16 @@ __device__ __forceinline__ void gemm_body(const Core &p, const typename Epi::Arg
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // (probe, VAR & 128 -- a negative result kept for the record: the FIRST workgroup of every CU starts up
+  // to 7/8 of a tile late, by groups of 32 CUs, so that the CUs leave lockstep and one group's epilogue
+  // stores run under the others' MFMAs: 2032 vs 1977 us at C5's B = 4096 -- the epilogue is not HBM
+  // contention between CUs, it is each workgroup's own store / VALU time with nothing beside it on its CU)
+  if ((VAR & 128) && L < 256 && per_split * splits > 512) {
+    const unsigned long long t0 = wall_clock64();
+    const unsigned long long wait = (unsigned long long)(((L >> 3) & 7) * nk_all) * 40;
+    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
 
   // scale of the dO granule each 32-row block of the wave's accumulators is in (Rescale)
   float cur[TM];

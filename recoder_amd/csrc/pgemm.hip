@@ -65,17 +65,65 @@ struct EncBwd {
 };
 __global__ __launch_bounds__(256) void mnll_merge_kernel(const pg::MnllMerge a) { pg::mnll_merge_body(a, (int)blockIdx.x); }
 
+// the decoder bias gradient gb[n] = sum_m dO[m][n] straight from the dO IMAGE (the register-resident fused
+// decode -- csrc/fdecode.hip -- has no column sums to give): a third workgroup range of the launch, 32
+// columns (one image line per row) per workgroup; a thread = (row slot of 64, 8 columns), rows in fixed
+// order, the 64 row slots combined in fixed order through LDS
+struct ColsumImg {
+  const char *img;
+  const int32_t *counts;      // [0] live columns, [2] ld
+  const float *tab;
+  int gr, gc, pitch, rows;    // scale granule, table pitch, rows (users)
+  float *out;                 // [n_cap]
+};
+__device__ __forceinline__ void colsum_img_body(const ColsumImg &c, const int block, char *smem) {
+  const int n_live = c.counts[0], ld = c.counts[2];
+  const int n0 = block * 32;
+  if (n0 >= n_live) return;
+  const int tid = threadIdx.x, rs = tid >> 2, q = tid & 3;       // row slot, 8-column chunk
+  float acc[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+  const int64_t pitch = (int64_t)ld * 4;
+  for (int m = rs; m < c.rows; m += 64) {
+    const char *line = c.img + m * pitch + (int64_t)block * 128 + q * 16;
+    const uint4 hi = *reinterpret_cast<const uint4 *>(line), lo = *reinterpret_cast<const uint4 *>(line + 64);
+    const float is = 1.0f / c.tab[(m / c.gr) * c.pitch + n0 / c.gc];
+    const uint32_t hw[4] = {hi.x, hi.y, hi.z, hi.w}, lw[4] = {lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const rkp::f16x2 h2 = __builtin_bit_cast(rkp::f16x2, hw[u]), l2 = __builtin_bit_cast(rkp::f16x2, lw[u]);
+      acc[2 * u] += ((float)h2[0] + (float)l2[0]) * is;
+      acc[2 * u + 1] += ((float)h2[1] + (float)l2[1]) * is;
+    }
+  }
+  float *part = reinterpret_cast<float *>(smem);            // [64 row slots][32 columns]
+#pragma unroll
+  for (int u = 0; u < 8; ++u) part[rs * 32 + q * 8 + u] = acc[u];
+  __syncthreads();
+  if (tid < 32 && n0 + tid < n_live) {
+    float s = 0.f;
+    for (int k = 0; k < 64; ++k) s += part[k * 32 + tid];
+    c.out[n0 + tid] = s;
+  }
+}
+
 template <int BM, int BN, int WM, int WN, int HV>
 __global__ __launch_bounds__(WM * WN * 64) void dw_encbwd_kernel(const pg::Core p, const pg::EpiSlab::Args e,
-                                                                const int n_dw, const EncBwd enc) {
+                                                                const int n_dw, const EncBwd enc,
+                                                                const ColsumImg cs, const int n_cs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)blockIdx.x < n_dw) {
     pg::gemm_body<BM, BN, WM, WN, true, true, pg::EpiSlab, 0, true>(p, e, (int)blockIdx.x, smem);
     return;
   }
   if (threadIdx.x >= 256) return;
+  if ((int)blockIdx.x < n_dw + n_cs) {
+    colsum_img_body(cs, (int)blockIdx.x - n_dw, smem);
+    return;
+  }
   ae_encode_bwd_cols_body<HV, true>(enc.b, enc.row_off, enc.B, enc.dZ, enc.h, enc.G, 0, enc.gb, enc.n_gb,
-                                    (int)blockIdx.x - n_dw, smem);
+                                    (int)blockIdx.x - n_dw - n_cs, smem);
 }
 constexpr int DW_MAX_SPLITS = 4, DW_SLOTS = 256;    // (the slab count follows the LIVE item count: pg::Core.auto_slots)
 
@@ -246,7 +294,7 @@ extern "C" int64_t rk_pg_dw_workspace_bytes(int32_t B, int32_t h, int32_t n_cap)
 // (g_parts / gparts_dev)
 static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
                       const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, const EncBwd *enc,
-                      void *stream_);
+                      void *stream_, float *gb_de = nullptr);
 
 extern "C" int rk_pg_dw(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
                         const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, void *stream_) {
@@ -258,7 +306,7 @@ extern "C" int rk_pg_dw(const void *dO_img, const float *dO_scales, int32_t gr, 
 extern "C" int rk_pg_dw_encode_bwd(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc,
                                    int32_t B, const rk_planes_t *pl, const rk_block_t *tgt, float *slabs,
                                    int32_t row_off, const float *dZ0pre, float *G_en, float *gb_en,
-                                   void *stream_) {
+                                   float *gb_de, void *stream_) {
   RK_REQUIRE(rk_dw_encode_bwd_fused_ok(row_off, B), "outside the fused launch's domain (rk_dw_encode_bwd_fused_ok)");
   RK_REQUIRE(pl && pl->h % 4 == 0 && pl->h <= 1024, "h must be a multiple of 4, <= 1024");
   RK_REQUIRE(row_off >= 0 && B >= 0 && row_off + B <= tgt->S_cap, "row slice out of range");
@@ -267,12 +315,12 @@ extern "C" int rk_pg_dw_encode_bwd(const void *dO_img, const float *dO_scales, i
   EncBwd enc = {};
   enc.b = *tgt; enc.row_off = row_off; enc.B = B; enc.dZ = dZ0pre; enc.h = pl->h; enc.G = G_en; enc.gb = gb_en;
   enc.n_gb = gb_en ? rk_cdiv(pl->h, 64) : 0;
-  return pg_dw_impl(dO_img, dO_scales, gr, gc, B, pl, tgt, slabs, &enc, stream_);
+  return pg_dw_impl(dO_img, dO_scales, gr, gc, B, pl, tgt, slabs, &enc, stream_, gb_de);
 }
 
 static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
                       const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, const EncBwd *enc,
-                      void *stream_) {
+                      void *stream_, float *gb_de) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(pl && tgt->n_cap <= pl->n_cap && B <= pl->B_cap, "planes were laid out for another shape");
   RK_REQUIRE(al16(dO_img) && al16(slabs) && dO_scales, "operands must be 16-byte aligned");
@@ -297,12 +345,19 @@ static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, in
     const int n_dw = pg::grid_of(p, tiles);
     const int n_enc = rk_cdiv(tgt->n_cap, 4) + enc->n_gb;
     const int hv = rk_cdiv(h, 256);
+    ColsumImg cs = {};
+    int n_cs = 0;
+    if (gb_de) {
+      cs.img = (const char *)dO_img; cs.counts = tgt->counts; cs.tab = dO_scales; cs.gr = gr; cs.gc = gc;
+      cs.pitch = rk_cdiv(tgt->n_cap, gc); cs.rows = B; cs.out = gb_de;
+      n_cs = rk_cdiv(tgt->n_cap, 32);
+    }
 #define GO(BM, BN, WM, WN, HV)                                                                               \
   do {                                                                                                       \
     auto k = dw_encbwd_kernel<BM, BN, WM, WN, HV>;                                                           \
     static const hipError_t attr = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     if (attr != hipSuccess) { rc = attr; break; }                                                            \
-    hipLaunchKernelGGL(k, dim3(n_dw + n_enc), dim3(WM * WN * 64), 2 * (BM + BN) * pg::LINE, stream, p, e, n_dw, *enc); \
+    hipLaunchKernelGGL(k, dim3(n_dw + n_cs + n_enc), dim3(WM * WN * 64), 2 * (BM + BN) * pg::LINE, stream, p, e, n_dw, *enc, cs, n_cs); \
     rc = hipGetLastError();                                                                                  \
   } while (0)
 #define BY_HV(BM, BN, WM, WN) do { if (hv == 1) GO(BM, BN, WM, WN, 1); else if (hv == 2) GO(BM, BN, WM, WN, 2); else GO(BM, BN, WM, WN, 4); } while (0)

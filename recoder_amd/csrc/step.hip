@@ -395,6 +395,10 @@ static int step_pg_mode(const rk_ae_step_t *a) {
   if (!rk_gemm_split16() || rk_gemm_plain_bf16() || a->ws == nullptr || a->planes == nullptr) return 0;
   if (a->do_scales == nullptr || !rk_pg_enabled()) return 0;
   if (rk_decode_dz_fused_ok(a->B, a->h, a->blk->n_cap, a->loss_kind) == 0) return 1;
+  // 3: the register-resident fused decode (csrc/fdecode.hip) + rk_pg_dw || encoder backward || image
+  // column sums -- when the dW / encoder-backward launch can be the fused one (a->ws_dw, the row window)
+  if (a->ws_dw != nullptr && rk_fdec_ok(a->B, a->h, a->blk->n_cap, a->loss_kind) &&
+      rk_dw_encode_bwd_fused_ok(a->row_off, a->B)) return 3;
   // (opt-in, RK_PG_IMG=1 -- measured at C2: the image pass costs the fused decode launch 6 us (34.0 vs
   // 28.0) and dW || encoder backward on rk_pg_dw gains 0.8 (23.5 vs 24.3): 0.1222 vs 0.1188 ms per step)
   static const int img_on = [] { const char *e = getenv("RK_PG_IMG"); return (e && atoi(e) == 1) ? 1 : 0; }();
@@ -453,7 +457,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   // the three contractions on the pipelined pair-plane kernels (csrc/pgemm.h; include/recoder_hip.h
   // rk_ae_step_t.do_scales): whole untied MSE / BCE steps outside the fused decode's domain
   const int pg_mode = step_pg_mode(a);
-  const bool pg = pg_mode == 1, img = pg_mode == 2;
+  const bool pg = pg_mode == 1, img = pg_mode == 2, fdec = pg_mode == 3;
   const float *dw_slabs_pg = dw_branch ? a->ws_dw : a->ws;
   // opt-in (rk_adam_de_side): the decoder table's Adam sweep right behind the dW kernel ON dw_stream,
   // next to the reduce / encoder backward; the update on the chain then covers the rest
@@ -464,7 +468,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       if (pl) {
         rk_enc_split_t es = {};
         es.sw = rk_split_w_args(W_de, blk, a->ranges, a->planes);
-        if (pg) es.sw.wtp = nullptr;          // (dZ reads the W image along its rows: no W^T image)
+        if (pg || fdec) es.sw.wtp = nullptr;  // (dZ reads the W image along its rows: no W^T image)
         es.n_split = rk_cdiv(blk->n_cap, 32);
         es.zimg = act_bounded(a->act) ? (char *)a->planes->z : nullptr;
         es.z_kt = rkp::kp_of(h) / 32;
@@ -472,7 +476,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
                    "planes were laid out for another shape");
         RK_TRY(rk_ae_encode_fwd_at(blk, a->row_off, B, a->par[RK_PAR_W_EN].p, a->par[RK_PAR_B_EN].p, h,
                                    a->keep, a->noise_p, a->seed, a->cursor, a->cursor_off, a->users,
-                                   a->act, a->Z0, (planes && !pg && !img) ? a->zt_planes : nullptr, sm, &es,
+                                   a->act, a->Z0, (planes && !pg && !img && !fdec) ? a->zt_planes : nullptr, sm, &es,
                                    a->rng_step));
       } else if (a->cursor)
         RK_TRY(rk_ae_encode_fwd_at(blk, a->row_off, B, a->par[RK_PAR_W_EN].p, a->par[RK_PAR_B_EN].p, h,
@@ -492,7 +496,10 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       if (pl) {
         // (unbounded activations: the split scale of Z needs its maximum first)
         if (!act_bounded(a->act)) RK_TRY(rk_split_z(a->Z0, B, h, a->ranges, a->planes, sm));
-        if (dz_fused && img)
+        if (dz_fused && fdec)
+          RK_TRY(rk_fdec_loss_dz(a->planes, B, blk, a->row_off, a->par[RK_PAR_B_DE].p, a->loss_kind, a->confidence,
+                                 a->inv_B, a->dO, a->do_rows, a->do_scales, a->loss_part, a->ws, sm));
+        else if (dz_fused && img)
           RK_TRY(rk_decode_loss_dz_image(a->planes, B, blk, a->row_off, a->par[RK_PAR_B_DE].p, a->loss_kind,
                                          a->confidence, a->inv_B, a->dO, a->do_rows, a->do_scales, a->loss_part,
                                          a->gb_part, a->ws, sm));
@@ -548,9 +555,12 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     } else if (dw_enc_fused) {
       // dW || encoder backward in ONE launch on the chain (dw3.hip dw_encbwd_kernel): no side stream
       Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
-      if (img)
+      if (fdec)
+        RK_TRY(rk_pg_dw_encode_bwd(a->dO, a->do_scales, 32, 64, B, a->planes, blk, dw_branch ? a->ws_dw : a->ws,
+                                   a->row_off, a->dZ0, G_en, a->gb_en, a->gb_de, sm));
+      else if (img)
         RK_TRY(rk_pg_dw_encode_bwd(a->dO, a->do_scales, 64, 128, B, a->planes, blk, dw_branch ? a->ws_dw : a->ws,
-                                   a->row_off, a->dZ0, G_en, a->gb_en, sm));
+                                   a->row_off, a->dZ0, G_en, a->gb_en, nullptr, sm));
       else
       RK_TRY(rk_decode_bwd_dw2_encode_bwd(a->dO, a->Z0, B, h, blk, dw_branch ? a->ws_dw : a->ws,
                                           planes ? a->zt_planes : nullptr, a->ranges, a->row_off, a->dZ0,
@@ -600,7 +610,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     if (!a->tied) {
       jobs[n] = table_job(a->par[RK_PAR_W_DE], blk, n_items, h, a->G_de, true);
       if (a->ranges) jobs[n].amax_out = a->ranges + 64;
-      if (pg || img) {
+      if (pg || img || fdec) {
         jobs[n].g = dw_slabs_pg; jobs[n].g_parts = rk_pg_dw_splits(B, h, blk->n_cap);
         jobs[n].g_stride = blk->n_cap * h; jobs[n].gparts_dev = blk->counts + 4;
       } else if (dw3) {
@@ -624,9 +634,9 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     slots[n] = RK_PAR_B_DE;
     jobs[n] = table_job(a->par[RK_PAR_B_DE], blk, n_items, 1, a->gb_de, true);
     jobs[n].par.sparse = 0; jobs[n].rows = nullptr; jobs[n].n_dev = nullptr; jobs[n].pos = blk->pos;
-    if (whole && !mnll) {          // straight from the decode epilogue's row-tile partials
+    if (whole && !mnll && !fdec) { // straight from the decode epilogue's row-tile partials
       jobs[n].g = a->gb_part; jobs[n].g_parts = row_tiles; jobs[n].gstride_dev = blk->counts + 2;
-    }
+    }                              // (fdec: gb_de itself, written by the dW launch's column-sum range)
     ++n;
     slots[n] = RK_PAR_B_EN;
     jobs[n] = table_job(a->par[RK_PAR_B_EN], blk, 1, h, a->gb_en, false);

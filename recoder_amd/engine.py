@@ -834,7 +834,7 @@ class FusedEngine:
         if getattr(self, "_dz_pg", False):
           check(lib.rk_pg_dw_encode_bwd(ptr(self.dO), ptr(self.do_scales), 64, 32, B, ctypes.byref(self.planes),
                                         blk.ref, ptr(self.ws_dw), row_off, ptr(self.denc[0]), ptr(G_en),
-                                        ptr(self.gb_en), stream), "rk_pg_dw_encode_bwd")
+                                        ptr(self.gb_en), None, stream), "rk_pg_dw_encode_bwd")
           self._pg_step = True
         elif self._dw_colsum:
           check(lib.rk_decode_bwd_dw2_encode_bwd_colsum(ptr(self.dO), ptr(zz), B, h0, blk.ref, ptr(self.ws_dw),
@@ -1098,10 +1098,11 @@ class FusedEngine:
         self._gb_lazy = (cdiv(B, self.row_tile), blk)
     elif dp is None:
       st.phase = STEP_ALL
-      self._pg_step = bool(raw.rk_ae_step_uses_pg(ctypes.byref(st)))
+      mode = int(raw.rk_ae_step_uses_pg(ctypes.byref(st)))
+      self._pg_step = bool(mode)
       check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
-      if self.loss_id != LOSS_MNLL:
-        self._gb_lazy = (cdiv(B, self.row_tile), blk)
+      if self.loss_id != LOSS_MNLL and mode != 3:
+        self._gb_lazy = (cdiv(B, self.row_tile), blk)    # (mode 3: gb_de itself, from the dO image)
     else:
       # data parallel over users: forward + whole backward locally, then the live gradient rows
       # of both tables, the gathered-bias gradient, the encoder bias gradient and the loss go out

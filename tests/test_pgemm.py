@@ -195,3 +195,73 @@ def test_pg_decode_mnll_matches_the_two_launch_form(B, h, n_items, ratings):
   rec = _image_to_f32(img[:rows_img * ld * 2].view(rows_img, ld * 2), sc, rows_img, ld, 64, 32, -(-blk.n_cap // 32))
   assert torch.isfinite(rec).all()
   assert (rec[:B, :n_b] - got).abs().max().item() <= 2.0 ** -20 * max(got.abs().max().item(), 1e-30)
+
+
+@pytest.mark.parametrize("B,h,n_items,loss,ratings", [(500, 200, 3000, LOSS_MSE, False), (37, 20, 400, LOSS_BCE, False),
+                                                      (1, 8, 97, LOSS_MSE, False), (130, 128, 2000, LOSS_MSE, True),
+                                                      (300, 64, 5000, LOSS_BCE, True), (513, 224, 700, LOSS_MSE, False),
+                                                      (64, 36, 333, LOSS_BCE, True)])
+def test_fdec_matches_the_lds_fused_decode(B, h, n_items, loss, ratings):
+  """rk_fdec_loss_dz (register-resident fused decode: transposed tile, permlane32 fragments, resident W
+  rows) against rk_decode_loss_dz_planes: the same logits bit for bit (so the same dO up to the image's
+  2^-21), the same loss, dZ against float64."""
+  lib, blk, W, bias, Z, ranges, pl, buf = _setup(B, h, max(B, 600), n_items, 14, seed=7 * B + h, ratings=ratings)
+  if not lib.rk_fdec_ok(B, h, blk.n_cap, loss):
+    pytest.skip("outside the fused decode's domain")
+  st = current_stream()
+  dev = Z.device
+  f = dict(dtype=torch.float32, device=dev)
+  n_b, nnz, ld, S = blk.counts_host()
+  check(lib.rk_split_w(ptr(W), h, blk.ref, ptr(ranges), ctypes.byref(pl), st))
+  check(lib.rk_split_z(ptr(Z), B, h, ptr(ranges), ctypes.byref(pl), st))
+  npart = lib.rk_loss_partials(B, blk.n_cap)
+  ntile = -(-B // lib.rk_decode_row_tile())
+  dO = torch.zeros(B * blk.ld_cap, **f)
+  part = torch.zeros(npart, **f)
+  gbp = torch.zeros(ntile * blk.ld_cap, **f)
+  ws = torch.zeros(lib.rk_dz_fused_workspace_bytes(B, h, blk.n_cap) // 4 + 64, **f)
+  check(lib.rk_decode_loss_dz_planes(ctypes.byref(pl), B, blk.ref, 0, ptr(bias), loss, 0.5, 1.0 / B, ptr(dO),
+                                     ptr(part), ptr(gbp), ptr(ws), st))
+  dZ_ref = torch.zeros(B * h, **f)
+  check(lib.rk_decode_dz_reduce(ptr(ws), B, h, blk.ref, ptr(Z), ACT_TANH, ptr(dZ_ref), st))
+  torch.cuda.synchronize()
+  ref = dO[:B * ld].view(B, ld)[:, :n_b].clone()
+  rows_img = -(-B // 32) * 32
+  img = torch.full(((rows_img + 256) * blk.ld_cap * 2,), 0x7e00, dtype=torch.int16, device=dev)
+  sc = torch.full((lib.rk_pg_scale_floats(B, blk.n_cap),), float("nan"), **f)
+  part2 = torch.zeros(npart, **f)
+  ws2 = torch.full((lib.rk_fdec_workspace_bytes(B, h, blk.n_cap) // 4 + 64,), float("nan"), **f)
+  blk.counts[8:72].zero_()
+  check(lib.rk_fdec_loss_dz(ctypes.byref(pl), B, blk.ref, 0, ptr(bias), loss, 0.5, 1.0 / B, ptr(img), rows_img,
+                            ptr(sc), ptr(part2), ptr(ws2), st))
+  dZ = torch.zeros(B * h, **f)
+  check(lib.rk_decode_dz_reduce(ptr(ws2), B, h, blk.ref, ptr(Z), ACT_TANH, ptr(dZ), st))
+  torch.cuda.synchronize()
+  pitch = -(-blk.n_cap // 64)
+  rec = _image_to_f32(img[:rows_img * ld * 2].view(rows_img, ld * 2), sc, rows_img, ld, 32, 64, pitch)
+  assert torch.isfinite(rec).all()
+  assert float(rec[B:].abs().max()) == 0.0 if rows_img > B else True
+  assert float(rec[:B, n_b:].abs().max()) == 0.0 if ld > n_b else True
+  scale = max(ref.abs().max().item(), 1e-30)
+  err = (rec[:B, :n_b] - ref).abs().max().item()
+  assert err <= 2.0 ** -20 * scale, (err, scale)
+  s1, s2 = part.double().sum().item(), part2.double().sum().item()
+  assert abs(s1 - s2) <= 1e-6 * abs(s1)
+  assert blk.counts[8:72].view(torch.float32).max().item() == ref.abs().max().item()
+  items = blk.items[:n_b].long()
+  exact = (ref.double() @ W[items].double()) * (1.0 - Z.double() ** 2)
+  den = (ref.double().abs() @ W[items].double().abs()) * (1.0 - Z.double() ** 2).abs() + 1e-300
+  e_new = ((dZ.view(B, h).double() - exact).abs() / den).max().item()
+  e_old = ((dZ_ref.view(B, h).double() - exact).abs() / den).max().item()
+  print("B=%d h=%d n_b=%d: image err %.2e of max; dZ err new %.2e old %.2e" % (B, h, n_b, err / scale, e_new, e_old))
+  assert e_new < 6e-7, (e_new, e_old)
+  # ... and rk_pg_dw reads that image (granule 32 x 64)
+  ns = lib.rk_pg_dw_splits(B, h, blk.n_cap)
+  slabs = torch.full((lib.rk_pg_dw_workspace_bytes(B, h, blk.n_cap) // 4,), float("nan"), **f)
+  check(lib.rk_pg_dw(ptr(img), ptr(sc), 32, 64, B, ctypes.byref(pl), blk.ref, ptr(slabs), st))
+  torch.cuda.synchronize()
+  live = int(blk.counts[4].item())
+  G = slabs.view(ns, blk.n_cap, h)[:live, :n_b].double().sum(0)
+  ex = ref.double().t() @ Z.double()
+  e_dw = ((G - ex).abs() / (ref.double().abs().t() @ Z.double().abs() + 1e-300)).max().item()
+  assert e_dw < 6e-7, e_dw

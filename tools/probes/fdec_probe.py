@@ -1,0 +1,76 @@
+#!/usr/bin/env python
+"""The register-resident fused decode (csrc/fdecode.hip) at the C2 shape against the LDS-staged fused
+decode of decode16.hip: HIP-event medians with the caches flushed before every launch (the event pair
+itself costs ~6 us: an empty launch of the same grid).
+    python tools/probes/fdec_probe.py [B h n_items]"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from recoder_amd import _lib                                              # noqa: E402
+from recoder_amd._lib import LOSS_MSE, RkPlanes, check, ptr               # noqa: E402
+from recoder_amd.device import Block, DeviceCSR, current_stream          # noqa: E402
+from recoder_amd import synthetic                                         # noqa: E402
+
+
+def main():
+  B = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+  h = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+  lib = _lib.load()
+  dev = torch.device("cuda")
+  csr = synthetic.ml20m_like(seed=0)
+  n_items = csr.shape[1]
+  dcsr = DeviceCSR(csr)
+  f = dict(dtype=torch.float32, device=dev)
+  g = torch.Generator(device=dev); g.manual_seed(1)
+  W = torch.randn(n_items, h, generator=g, **f) * 0.07
+  bias = torch.randn(n_items, generator=g, **f) * 0.02
+  users = torch.from_numpy(np.random.RandomState(0).permutation(csr.shape[0])[:B]).to(dev)
+  blk = Block(B, int(np.sort(dcsr.degrees)[-B:].sum()), n_items, dev)
+  blk.collate(dcsr, users)
+  Z = torch.tanh(torch.randn(B, h, generator=g, **f))
+  ranges = torch.zeros(128, dtype=torch.int32, device=dev)
+  ranges[64:65].copy_(W.abs().max().reshape(1).view(torch.int32))
+  buf = torch.zeros(lib.rk_planes_bytes(B, h, blk.n_cap) // 4 + 64, **f)
+  pl = RkPlanes()
+  check(lib.rk_planes_layout(ptr(buf), B, h, blk.n_cap, ctypes.byref(pl)))
+  st = current_stream()
+  check(lib.rk_split_w(ptr(W), h, blk.ref, ptr(ranges), ctypes.byref(pl), st))
+  check(lib.rk_split_z(ptr(Z), B, h, ptr(ranges), ctypes.byref(pl), st))
+  n_b = blk.counts_host()[0]
+  rows_img = -(-B // 32) * 32
+  img = torch.zeros((rows_img + 256) * blk.ld_cap * 2, dtype=torch.int16, device=dev)
+  sc = torch.ones(lib.rk_pg_scale_floats(B, blk.n_cap), **f)
+  part = torch.zeros(lib.rk_loss_partials(B, blk.n_cap), **f)
+  ws = torch.zeros(lib.rk_fdec_workspace_bytes(B, h, blk.n_cap) // 4 + 64, **f)
+  dO = torch.zeros(B * blk.ld_cap, **f)
+  gbp = torch.zeros(-(-B // 64) * blk.ld_cap, **f)
+  flush = torch.zeros(64 << 20, **f)
+
+  def timeit(fn, n=30):
+    ts = []
+    for _ in range(n):
+      flush.add_(1.0)                                   # (evict: the step's other launches do that)
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record(); fn(); e1.record(); e1.synchronize()
+      ts.append(e0.elapsed_time(e1) * 1e3)
+    return float(np.median(ts))
+
+  def fdec():
+    check(lib.rk_fdec_loss_dz(ctypes.byref(pl), B, blk.ref, 0, ptr(bias), LOSS_MSE, 0.0, 1.0 / B, ptr(img), rows_img,
+                              ptr(sc), ptr(part), ptr(ws), st))
+
+  def old():
+    check(lib.rk_decode_loss_dz_planes(ctypes.byref(pl), B, blk.ref, 0, ptr(bias), LOSS_MSE, 0.0, 1.0 / B, ptr(dO),
+                                       ptr(part), ptr(gbp), ptr(ws), st))
+  print("C2-shaped block: B = %d, h = %d, n_b = %d" % (B, h, n_b))
+  print("decode16 fused (LDS dO tile, W^T stage): %.1f us" % timeit(old))
+  print("fdec (register resident, W rows resident in LDS): %.1f us" % timeit(fdec))
+
+
+if __name__ == "__main__":
+  main()

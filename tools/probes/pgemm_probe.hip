@@ -85,6 +85,8 @@ static hipError_t dispatch(const pg::Core &p, const pg::EpiStore::Args &e, int a
     case 40: return dispatch_v<BM, BN, WM, WN, 40>(p, e, atr, btr, tiles, s);
     case 56: return dispatch_v<BM, BN, WM, WN, 56>(p, e, atr, btr, tiles, s);
     case 72: return dispatch_v<BM, BN, WM, WN, 72>(p, e, atr, btr, tiles, s);
+    case 128: return dispatch_v<BM, BN, WM, WN, 128>(p, e, atr, btr, tiles, s);
+    case 160: return dispatch_v<BM, BN, WM, WN, 160>(p, e, atr, btr, tiles, s);
     default: return dispatch_v<BM, BN, WM, WN, 0>(p, e, atr, btr, tiles, s);
   }
 }
