@@ -43,6 +43,7 @@ if ROOT not in sys.path:
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_MFMA_F32_TF = 157.3       # v_mfma_f32_32x32x2_f32 dense peak
 PEAK_MFMA_16_TF = 2500.0       # v_mfma_f32_32x32x16_{f16,bf16} dense peak (no sparsity)
+ARGS = None       # the parsed command line (main)
 GEMM_F32 = os.environ.get("RK_GEMM_PREC", "")[:1].lower() == "f"
 # RK_GEMM_PREC=bf16: the decoder contractions of the one-call step on PLAIN bf16 operands (one product,
 # fp32 accumulate) -- BASELINE configs[1] says "bf16"; a separate data point, never the graded line
@@ -50,7 +51,7 @@ GEMM_BF16 = os.environ.get("RK_GEMM_PREC", "")[:1].lower() == "b"
 # MFMA flops the 16-bit pipe spends per algorithmic flop: the three decoder contractions multiply
 # fp16 hi+lo pairs (3 products; dW on bf16 triples -- RK_DW_PREC=bf16x3 -- 6) -- the ceiling on
 # ALGORITHMIC flops is peak / this
-DW_BF16X3 = os.environ.get("RK_DW_PREC", "").lower().startswith("bf16x3")
+DW_BF16X3 = False     # (dW on bf16 triples: an rk_tune knob of the probe header now, not a bench variant)
 PRODUCTS = {"rk_decode_loss": 3, "rk_decode_bwd_dz": 3, "rk_decode_bwd_dw": 6 if DW_BF16X3 else 3,
             "rk_decode_bwd_dw3": 6}
 ENTRIES = ["rk_ae_encode_fwd", "rk_decode_loss", "rk_decode_bwd_dz", "rk_decode_bwd_dw",
@@ -75,9 +76,8 @@ KERNELS = {"rk_ae_encode_fwd": ["ae_encode_fwd_kernel (+ the W_de[items] split w
            "rk_decode_loss_dz_planes": ["decode_planes_kernel<1,2,EPI,3,false,DZT> (decode + loss + dZ partials)"],
            "rk_decode_loss_planes": ["decode_planes_kernel<TM,2,EPI>"],
            "rk_decode_bwd_dz_planes": ["dz_planes_kernel<TN>", "splitk_reduce_kernel"],
-           "rk_decode_dz_reduce": ["splitk_reduce_kernel"], "rk_split_w": ["split_w_kernel"],
-           "rk_split_wz": ["split_wz_kernel (W_de[items] and Z plane images, one launch)"],
-           "rk_split_wz_zt": ["split_wz_kernel (W_de[items] unless the encoder forward cut it, Z, Z^T planes)"],
+           "rk_decode_dz_reduce": ["splitk_reduce_kernel"], 
+           "rk_split_wz": ["split_wz_kernel (W_de[items] unless the encoder forward cut it, Z, Z^T planes: one launch)"],
            "rk_ae_encode_fwd_split_w": ["ae_encode_fwd_kernel (+ the W_de[items] split workgroups)"],
            "rk_decode_bwd_dw2": ["dw3_kernel<BN,false,true>"],
            "rk_decode_bwd_dw2_encode_bwd": ["dw_encbwd_kernel<BN,HV> (dW tiles || encoder-backward columns)"],
@@ -199,7 +199,7 @@ def entry_work(entry, B, h0, n_b, nnz, n_items, cfg):
     return "hbm", (-(-int(n_b) // 128) * B * h0 * 4 + 2 * B * h0 * 4) / 1e9, "GB/s"
   if entry == "rk_split_w":                     # gathered decoder rows -> W and W^T plane images
     return "hbm", 3.0 * n_b * h0 * 4 / 1e9, "GB/s"
-  if entry in ("rk_split_wz", "rk_split_wz_zt"):     # ... and Z -> its image (and Z^T planes), in the same launch
+  if entry == "rk_split_wz":     # ... and Z -> its image (and Z^T planes), in the same launch
     return "hbm", (3.0 * n_b + 2.0 * B) * h0 * 4 / 1e9, "GB/s"
   if entry == "rk_ae_encode_fwd_split_w":       # the encoder forward with the W_de[items] split riding on it
     return "hbm", (nnz * (h0 * 4 + 12) + B * h0 * 4 + 3.0 * n_b * h0 * 4) / 1e9, "GB/s"
@@ -228,8 +228,8 @@ def cpu_baseline(cfg, csr, steps, warmup=4):
   from oracle import recoder_oracle as orc
   # eager PyTorch-CPU on B x n_b matrices stops scaling (and oversubscribes) far
   # below a big host's core count: 256 threads ran 50x slower than 8
-  torch.set_num_threads(min(os.cpu_count(), int(os.environ.get("RK_CPU_THREADS", "16"))))
-  max_seconds = float(os.environ.get("RK_CPU_SECONDS", "20"))
+  torch.set_num_threads(min(os.cpu_count(), ARGS.cpu_threads))
+  max_seconds = ARGS.cpu_seconds
   B = cfg["batch_size"]
   torch.manual_seed(0)
   st = orc.init_ae_state(csr.shape[1], cfg["hidden_layers"])
@@ -264,7 +264,7 @@ def cpu_baseline(cfg, csr, steps, warmup=4):
 
 def recall_check(rec, model, cfg, csr, n_held=1000, k=20):
   """Recall@20 (BASELINE.json's metric names it next to the throughput) of the state the timed run
-  left behind: the product's Recoder.evaluate (strip decode + rk_topk_masked_strip on the GPU)
+  left behind: the product's Recoder.evaluate (strip decode + rk_topk_masked on the GPU)
   against the oracle's evaluate (reference model.py:513-544, metrics.py:23-29 on the CPU) on the SAME
   parameters and the same users -- 80 % of each user's items as input, the other 20 % as the
   relevant set.  Outside the timed region."""
@@ -352,10 +352,23 @@ def main():
   ap.add_argument("--steps", type=int, default=200)
   ap.add_argument("--warmup", type=int, default=24)
   ap.add_argument("--config", default="c2")
-  ap.add_argument("--cpu-steps", type=int, default=1000)   # bounded by RK_CPU_SECONDS (20 s)
+  ap.add_argument("--cpu-steps", type=int, default=1000)   # bounded by --cpu-seconds
+  ap.add_argument("--cpu-seconds", type=float, default=20.0, help="wall-clock bound of the cpu_baseline leg")
+  ap.add_argument("--cpu-threads", type=int, default=16)
+  ap.add_argument("--sample", choices=("post", "timed"), default="post",
+                  help="per-launch brackets: sampled behind the clock (default) or inside the timed region")
+  ap.add_argument("--no-precollate", action="store_true", help="first group's collation inside the timed region")
+  ap.add_argument("--no-pretouch", action="store_true", help="no touch of the optimizer state in front of the clock")
+  ap.add_argument("--prewarm", type=float, default=0.0, help="seconds of untimed extra steps in front of the warmup")
+  ap.add_argument("--alt", choices=("auto", "0", "1"), default="auto",
+                  help="N > 1: also time the item-parallel alternative in a child run (auto: only with > 1 rank)")
+  ap.add_argument("--alt-timeout", type=float, default=300.0)
+  ap.add_argument("--one-gpu-gloo", action="store_true", help="(tests) every rank on GPU 0 over gloo")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-recall", action="store_true")
   args = ap.parse_args()
+  global ARGS
+  ARGS = args
   cfg = CONFIGS[args.config]
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -363,7 +376,7 @@ def main():
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
   # test switch (tools/probes/bench_two_ranks_one_gpu.sh): every rank on GPU 0 with the gloo backend,
   # to run the multi-rank code of this file on a single-GPU box; the line is marked INVALID
-  same_dev = os.environ.get("RK_BENCH_ONE_GPU_GLOO") == "1"
+  same_dev = args.one_gpu_gloo
   if same_dev:
     local_rank = 0
   assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
@@ -431,8 +444,8 @@ def main():
   # Where the launch groups behind `roofline.kernels` are bracketed with HIP events: by default in the
   # G steps right BEHIND the clock (same process, same state, `sampled` says so) -- event records are
   # barrier packets between the launches and cost a bracketed step ~12 us, which the graded interval
-  # must not contain.  RK_BENCH_SAMPLE=timed: inside the timed region as in rounds 1-3.
-  SAMPLE_POST = os.environ.get("RK_BENCH_SAMPLE", "post") == "post"
+  # must not contain.  --sample timed: inside the timed region as in rounds 1-3.
+  SAMPLE_POST = args.sample == "post"
   SAMPLED = ("post-clock group (the %d steps right behind the timed region, same process)" % G) if SAMPLE_POST \
       else "timed region"
 
@@ -478,9 +491,9 @@ def main():
     # front of the clock (as the previous group's look-ahead would have left them), and the look-ahead
     # collation behind the LAST timed group stays inside the region (post-clock sampling: every timed
     # group is a replayed graph with its look-ahead) -- one collation per group either way.
-    T["precollated"] = bool(gs is not None and SAMPLE_POST and os.environ.get("RK_BENCH_PRECOLLATE", "1") != "0"
+    T["precollated"] = bool(gs is not None and SAMPLE_POST and not args.no_precollate
                             and gs.precollate())
-    if os.environ.get("RK_BENCH_PRETOUCH", "1") != "0":
+    if not args.no_pretouch:
       # one read of the parameters and Adam moments: the first timed Adam sweep finds them where every
       # later one does (in the Infinity Cache behind the previous sweep), not cold behind the cut
       for st in eng.states.values():
@@ -520,7 +533,7 @@ def main():
     rec.step_marks[W + K - n_sample] = sample_on
   if SAMPLE_POST:
     rec.step_marks[W + K + G] = lambda: True
-  prewarm = float(os.environ.get("RK_BENCH_PREWARM", "0"))
+  prewarm = args.prewarm
   if prewarm > 0:
     xw = torch.randn(4096, 4096, device=device)
     tw = time.perf_counter()
@@ -557,8 +570,8 @@ def main():
   global_rows = B * world if multi else B
   value = K * global_rows / dt              # users consumed by all ranks per second
 
-  want_alt = multi and (world > 1 or os.environ.get("RK_BENCH_ALT") == "1") and \
-      os.environ.get("RK_BENCH_ALT") != "0" and os.environ.get("RK_PARALLEL", "users") in ("users", "auto")
+  want_alt = multi and (world > 1 or args.alt == "1") and \
+      args.alt != "0" and os.environ.get("RK_PARALLEL", "users") in ("users", "auto")
   out = None
 
   def emit():
@@ -752,7 +765,7 @@ def main():
                         "data point that misses the 1e-5 parity bar (see `recall`: product vs the fp32 oracle); "
                         "the graded line is the default run")
     if same_dev:
-      out["INVALID"] = "RK_BENCH_ONE_GPU_GLOO: all ranks share one GPU, gloo collectives (a code-path test)"
+      out["INVALID"] = "--one-gpu-gloo: all ranks share one GPU, gloo collectives (a code-path test)"
     if world == 1 and not multi and not args.no_recall:
       # Recall@20 of the trained state, product vs oracle (outside the timed region)
       try:
@@ -771,7 +784,7 @@ def main():
     # process (rank 0 printing the line first) if the extra run does not come back -- one rank
     # failing inside it leaves the others waiting in a collective.
     import threading
-    limit = float(os.environ.get("RK_BENCH_ALT_TIMEOUT", "300"))
+    limit = args.alt_timeout
     finished = threading.Event()
 
     def watchdog():

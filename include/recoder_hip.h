@@ -28,6 +28,46 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* (the library is built with -fvisibility=hidden: what this header declares is what it exports) */
+#pragma GCC visibility push(default)
+
+/*
+ * The sizing plan of one step shape: every workspace size, slab count, padding rule and "which fused form
+ * applies" predicate of the entry points below, for (B rows, hidden size h, item capacity n_cap, loss) --
+ * ONE call before the caller allocates (nothing here touches the device).  Fill the four inputs (row_off
+ * only matters for dw_encode_bwd_fused_ok), call rk_plan, read the rest.  The comments of the entry points
+ * name the field that sizes each buffer.
+ */
+typedef struct rk_plan {
+  /* inputs */
+  int32_t B, h, n_cap, loss_kind, row_off;
+  /* process-wide configuration */
+  int32_t gemm_split16;            /* decode / dZ / dW multiply fp16 hi+lo pairs (default) */
+  int32_t gemm_plain_bf16;         /* RK_GEMM_PREC=bf16: plain bf16 operands (a separate data point) */
+  int32_t dw_pairs;                /* dW on fp16 pairs (rk_decode_bwd_dw3) */
+  int32_t split_zt_ok;             /* rk_split_wz's transposed Z planes (dw_workspace) apply */
+  int32_t pg_enabled;              /* the pipelined pair-plane family (rk_pg_*) is on */
+  int32_t graph_timing_supported;  /* time_ev0 / time_ev1 may be recorded inside a captured graph */
+  int32_t decode_row_tile;         /* rows per decode tile: gb_part holds ceil(B / this) rows */
+  int32_t dw3_max_splits, topk_max_k, topk_pairs_max_cap;
+  /* sizes of this shape */
+  int32_t loss_partials;           /* floats of loss_part */
+  int32_t dw_splits;               /* slabs of rk_decode_bwd_dw */
+  int32_t pg_dw_splits;            /* most slabs rk_pg_dw writes */
+  int32_t dw3_rows_pad, dw3_cols_pad;
+  int32_t pg_granule_rows, pg_granule_cols;   /* scale granule of rk_pg_decode_loss's image */
+  int64_t planes_bytes, dz_workspace_bytes, dz_fused_workspace_bytes, dw_workspace_bytes,
+          dw3_workspace_bytes, dw3_planes_bytes, fdec_workspace_bytes, pg_dz_workspace_bytes,
+          pg_dw_workspace_bytes;
+  int64_t pg_scale_floats, pg_mnll_workspace_floats;
+  /* which fused forms cover this shape */
+  int32_t decode_dz_fused_ok;      /* rk_decode_loss_dz_planes */
+  int32_t fdec_ok;                 /* rk_fdec_loss_dz */
+  int32_t dw_encode_bwd_fused_ok;  /* dW || encoder backward in one launch */
+  int32_t adam_de_side;            /* the probe header's RK_TUNE_ADAM_DE_SIDE: the decoder table's Adam sweep is a
+                                      launch of its own behind the dW kernel on dw_stream (off by default) */
+} rk_plan_t;
+int rk_plan(rk_plan_t *plan);
 
 /* activation ids (reference nn.py:6-9 `activation(x, act)`) */
 enum { RK_ACT_NONE = 0, RK_ACT_TANH = 1, RK_ACT_SIGMOID = 2, RK_ACT_RELU = 3,
@@ -84,7 +124,6 @@ typedef struct rk_block {
 int rk_version(void);
 const char *rk_last_error(void);
 /* bytes of split-K workspace rk_decode_bwd_dz needs for (B, h) */
-int64_t rk_dz_workspace_bytes(int32_t B, int32_t h);
 
 /*
  * rk_collate -- replaces RecommendationDataset.__getitem__/_extract
@@ -128,9 +167,9 @@ int rk_ae_encode_fwd(const rk_block_t *blk, int32_t row_off, int32_t B,
                      const uint8_t *keep, float p, uint64_t seed,
                      uint64_t rng_step, const int64_t *users, int32_t act,
                      float *Z0, void *stream);
-/* the same launch with the W_de[tgt = blk items] half of the decode's operand split (rk_split_w: pl->w,
+/* the same launch with the W_de[tgt = blk items] half of the decode's operand split (rk_split_wz: pl->w,
  * pl->wt, the W scale from ranges[64..127]) as extra workgroups -- for steps sequenced entry by entry
- * whose split launch then only cuts Z (rk_split_wz_zt with W_de == NULL) */
+ * whose split launch then only cuts Z (rk_split_wz with W_de == NULL) */
 struct rk_planes;
 int rk_ae_encode_fwd_split_w(const rk_block_t *blk, int32_t row_off, int32_t B, const float *W_en,
                              const float *b_en, int32_t h, const uint8_t *keep, float p, uint64_t seed,
@@ -175,14 +214,12 @@ int rk_ae_encode_bwd(const rk_block_t *blk, int32_t row_off, int32_t B,
  *   MSE/BCE : dO[B,ld] <- dLoss/dLogits, loss partials -> loss_part
  *   MNLL    : dO <- logits (finish with rk_mnll_finish)
  *   NONE    : out[B, ld_out] <- logits (+bias), ld_out host-given
- *   loss_part : [rk_loss_partials(B, n_cap)] floats, all-zero on entry
+ *   loss_part : [rk_plan_t.loss_partials] floats, all-zero on entry
  *   gb_part   : nullable [ceil(B/row_tile)][ld] per-row-tile column sums of dO
  *               (MSE/BCE); colsum over those few rows = gradient of the
  *               gathered decoder bias (saves a second pass over dO)
  */
-int32_t rk_loss_partials(int32_t B, int32_t n_cap);
-/* rows per decode tile: gb_part holds ceil(B / rk_decode_row_tile()) rows */
-int32_t rk_decode_row_tile(void);
+/* rows per decode tile: gb_part holds ceil(B / rk_plan_t.decode_row_tile) rows */
 int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
                    int32_t row_off, const float *W_de, const float *b_de,
                    int32_t loss_kind, float confidence, float inv_B,
@@ -201,17 +238,15 @@ int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
 int rk_amax(const float *x, int64_t n, int32_t *slots, void *stream);
 /* MNLL second pass: row max / logsumexp over the logits in dO, loss, and
  * dO <- (softmax * sum_t - t) * inv_B  (losses.py:68-71 + autograd). */
-int rk_mnll_finish(float *dO, int32_t B, const rk_block_t *tgt, int32_t row_off,
-                   float inv_B, float *loss_part, void *stream);
 /* Item-parallel form of the above (the softmax spans every rank's items):
  * rk_mnll_row_stats writes stats[r] = {max, sum exp(o - max)} over the block's shard of row r;
  * the caller combines them over the ranks and passes, per row, the global max, the log of the
- * global sum (relative to that max) and the target sum of the WHOLE row to rk_mnll_finish_ext. */
+ * global sum (relative to that max) and the target sum of the WHOLE row to rk_mnll_finish. */
 int rk_mnll_row_stats(const float *logits, int32_t B, const rk_block_t *tgt, float *stats,
                       void *stream);
-int rk_mnll_finish_ext(float *dO, int32_t B, const rk_block_t *tgt, int32_t row_off,
-                       float inv_B, const float *row_max, const float *row_logsum,
-                       const float *row_tsum, float *loss_part, void *stream);
+int rk_mnll_finish(float *dO, int32_t B, const rk_block_t *tgt, int32_t row_off,
+                   float inv_B, const float *row_max /* nullable, all three: the block holds whole rows */,
+                   const float *row_logsum, const float *row_tsum, float *loss_part, void *stream);
 /* sum the (unscaled) loss partials in a fixed order (double) and divide by
  * denom = rows of the slice in fp32 (model.py:483-484) -> loss[0]; the consumed
  * partials are reset to 0 (rk_decode_loss requires loss_part zeroed on entry) */
@@ -239,34 +274,22 @@ int rk_decode_bwd_dw_encode_bwd(const float *dO, const float *Z, int32_t B, int3
                                 const rk_block_t *blk, float *G_de, int32_t row_off,
                                 const float *dZ0pre, float *G_en, float *gb_en,
                                 float *workspace, void *stream);
-/* workspace of the call above (0: none needed; NULL is always accepted and disables the
- * split-K of large batches) */
-int64_t rk_dw_workspace_bytes(int32_t B, int32_t h, int32_t n_cap);
-/* number of K slabs the call above cuts dW into for B rows (1 = none).  With more than one,
- * G_de == NULL leaves them unsummed in `workspace` as rk_dw_splits(B) arrays of n_cap*h floats
- * (G_de = their sum in slab order): rk_adam_multi consumes them through g_parts / g_stride and
- * the summing launch disappears. */
-int32_t rk_dw_splits(int32_t B);
-/* tuning probe (tools/gemm_probe.py): device buffer of 8 uint64 per workgroup of the largest
- * GEMM grid, or NULL (default) to switch it off */
-void rk_gemm_probe(unsigned long long *buffer);
+/* (rk_plan_t.dw_splits: the number of K slabs the call above cuts dW into for B rows, 1 = none.  With more
+ * than one, G_de == NULL leaves them unsummed in `workspace` as arrays of n_cap*h floats -- G_de = their sum
+ * in slab order: rk_adam_multi consumes them through g_parts / g_stride and the summing launch disappears.
+ * rk_plan_t.dw_workspace_bytes sizes the workspace; NULL disables the split-K of large batches.) */
 /*
  * rk_decode_bwd_dw3 -- the same contraction G_de[n_t,h] = dO^T . Z (autograd of F.linear,
  * nn.py:280) on the 16-bit matrix pipe at fp32 accuracy and with no operand range: every fp32
  * operand is cut into three bf16 pieces (x = hi + mid + lo exactly), six products per pair are
  * accumulated in fp32 (csrc/dw3.hip).  dO tiles reach LDS by DMA; Z is split once per call into
- * k-contiguous bf16 planes (rk_split_planes_t) at the head of `workspace`.
- *   workspace : rk_dw3_workspace_bytes(B, h, tgt->n_cap) bytes, 256-byte aligned
+ * k-contiguous bf16 planes at the head of `workspace`.
+ *   workspace : rk_plan_t.dw3_workspace_bytes bytes, 256-byte aligned
  *   G_de      : nullable.  The contraction is cut along K into counts[4] slabs (chosen on the
- *               device from the live item count, <= rk_dw3_max_splits()); G_de != NULL receives
+ *               device from the live item count, <= rk_plan_t.dw3_max_splits); G_de != NULL receives
  *               their sum, G_de == NULL leaves them at rk_dw3_slabs(workspace, B, h) as arrays of
  *               n_cap*h floats for rk_adam_multi (rk_adam_job_t.gparts_dev = counts + 4).
  */
-int64_t rk_dw3_workspace_bytes(int32_t B, int32_t h, int32_t n_cap);
-int32_t rk_dw3_max_splits(void);
-/* tuning probe: device buffer of 16 uint64 per workgroup (wall-clock stamps of the k-loop), or
- * NULL (default) to switch it off */
-void rk_dw3_probe(unsigned long long *buffer);
 const float *rk_dw3_slabs(const void *workspace, int32_t B, int32_t h);
 int rk_decode_bwd_dw3(const float *dO, const float *Z, int32_t B, int32_t h,
                       const rk_block_t *tgt, float *G_de, float *gb_de, void *workspace,
@@ -279,22 +302,20 @@ int rk_decode_bwd_dw3(const float *dO, const float *Z, int32_t B, int32_t h,
  * Power-of-two scales from published maxima: dO from tgt->counts[8..71] (the loss kernels), Z from
  * ranges[0..63] (rk_amax notes) when the planes are made here; a caller-provided zt_planes holds
  * pairs written with the static scale (rk_ae_train_step: bounded activations).  Workspace and
- * slab conventions as rk_decode_bwd_dw3.  rk_dw_pairs() != 0: the training step uses this entry
- * (default; RK_DW_PREC=bf16x3 keeps the triples).
+ * slab conventions as rk_decode_bwd_dw3.  rk_plan_t.dw_pairs != 0: the training step uses this entry
+ * (default; the probe header's RK_TUNE_DW_BF16X3 keeps the triples).
  */
 int rk_decode_bwd_dw2(const float *dO, const float *Z, int32_t B, int32_t h,
                       const rk_block_t *tgt, float *G_de, float *gb_de, void *workspace,
                       const void *zt_planes /* nullable */, const int32_t *ranges /* nullable */,
                       void *stream);
-int32_t rk_dw_pairs(void);
 /*
  * rk_decode_bwd_dw2 (the K slabs stay in the workspace, as with G_de == NULL) and rk_ae_encode_bwd in
  * ONE launch: its first workgroups run the dW tiles, the others the encoder backward's columns.  Both
  * depend only on what is in front of them in the step and write disjoint outputs; as two launches
  * they cost the chain 16 + 14 us in line, or a side stream's two cross-queue edges.  Domain:
- * rk_dw_encode_bwd_fused_ok (fp16-pair dW, row window of <= 64 bitmap words; RK_DW_ENC_FUSED=0: off).
+ * rk_plan_t.dw_encode_bwd_fused_ok (fp16-pair dW, row window of <= 64 bitmap words).
  */
-int32_t rk_dw_encode_bwd_fused_ok(int32_t row_off, int32_t B);
 int rk_decode_bwd_dw2_encode_bwd(const float *dO, const float *Z /* nullable with zt_planes */, int32_t B,
                                  int32_t h, const rk_block_t *tgt, void *workspace,
                                  const void *zt_planes /* nullable */, const int32_t *ranges /* nullable */,
@@ -317,38 +338,6 @@ int rk_decode_bwd_dw2_encode_bwd_colsum(const float *dO, const float *Z /* nulla
                                         const void *zt_planes, const int32_t *ranges, int32_t row_off,
                                         const float *dZ0pre, float *G_en, float *gb_en, float *gb_de,
                                         void *stream);
-/* != 0 (RK_ADAM_DE_SIDE=1; off by default): whole steps with a dw_stream run the decoder table's
- * Adam sweep as a launch of its own right behind the dW kernel ON dw_stream -- it needs nothing else
- * of the step -- next to the split-K reduce and the encoder backward of the chain (both
- * latency-bound); the update on the chain covers the encoder table, the biases and the loss.  Same
- * jobs, same arithmetic: bit-identical.  C2: 0.1219 vs 0.1234 ms per step, the two sweeps then read
- * 0.52 of the HBM peak (they share the chip) instead of 0.68 for the one. */
-int32_t rk_adam_de_side(void);
-/* The Z^T planes of rk_decode_bwd_dw3 can be written by the kernel that produces Z:
- * rk_ae_encode_fwd_planes = rk_ae_encode_fwd + the three bf16 planes of its output, into a
- * buffer of rk_dw3_planes_bytes(B, h) bytes that the caller allocated ZEROED (16-byte aligned;
- * rows x columns padded to rk_dw3_rows_pad(B) x rk_dw3_cols_pad(h); the padding rows are
- * rewritten as zeros by every call, the padding columns are never touched). */
-int64_t rk_dw3_planes_bytes(int32_t B, int32_t h);
-int32_t rk_dw3_rows_pad(int32_t B);
-int32_t rk_dw3_cols_pad(int32_t h);
-int rk_ae_encode_fwd_planes(const rk_block_t *blk, int32_t row_off, int32_t B,
-                            const float *W_en, const float *b_en, int32_t h,
-                            const uint8_t *keep, float p, uint64_t seed,
-                            uint64_t rng_step, const int64_t *users, int32_t act,
-                            float *Z0, void *zt_planes, void *stream);
-/* X[rows, cols] fp32 (leading dimension ld) -> three bf16 planes of X^T in the k-contiguous
- * order the kernel above stages: element (k = row, n = col) of plane p at
- * p*rows_pad*cols_pad + ((k/8)*cols_pad + n)*8 + k%8; the padding is written as zeros. */
-int rk_split_planes_t(const float *X, int32_t rows, int32_t cols, int32_t ld,
-                      int32_t rows_pad, int32_t cols_pad, void *planes, void *stream);
-/* != 0: the decoder contractions run on the 16-bit matrix pipe (default); RK_GEMM_PREC=f32 in
- * the environment keeps all of them on the fp32 MFMA */
-int32_t rk_gemm_split16(void);
-/* != 0 (RK_GEMM_PREC=bf16): the *_planes contractions and rk_decode_bwd_dw3 multiply PLAIN bf16
- * operands (one product, fp32 accumulate) -- BASELINE configs[1]'s dtype as a separate data point;
- * it does not meet the 1e-5 parity bar and is never the default */
-int32_t rk_gemm_plain_bf16(void);
 /* The fused call writes G_en as rk_encode_bwd_segments(B) partial arrays of n_cap*h floats
  * each (row segments of long item columns; 1 below 513 rows) and gb_en as as many partial
  * vectors of h floats: the gradients are their sums in segment order -- rk_adam_multi
@@ -363,11 +352,11 @@ int32_t rk_encode_bwd_segments(int32_t B);
  * line = 32 hi + 32 lo values of one row's k-tile) and run the same arithmetic (lo.hi + hi.lo +
  * hi.hi in fp32 on v_mfma_f32_32x32x16_f16, same k order: bit-identical results for equal tile
  * shapes) with a copy -> LDS -> MFMA k-loop:
- *   z  : image of Z [B, h]                (rk_split_z, or the encoder forward of rk_ae_train_step)
- *   w  : image of W_de[items[c]] [n_b, h] (rk_split_w)           -- B operand of the decode
- *   wt : image of its transpose [h, n_b]  (rk_split_w)           -- B operand of dZ
+ *   z  : image of Z [B, h]                (rk_split_wz, or the encoder forward of rk_ae_train_step)
+ *   w  : image of W_de[items[c]] [n_b, h] (rk_split_wz)          -- B operand of the decode
+ *   wt : image of its transpose [h, n_b]  (rk_split_wz)          -- B operand of dZ
  * rk_planes_layout carves the three images + 4 scale slots out of ONE caller-allocated, ZEROED,
- * 256-byte aligned buffer of rk_planes_bytes(B_cap, h, n_cap) bytes (the K padding is never
+ * 256-byte aligned buffer of rk_plan_t.planes_bytes bytes (the K padding is never
  * written and must read as zero).
  */
 typedef struct rk_planes {
@@ -375,10 +364,6 @@ typedef struct rk_planes {
   void *z, *w, *wt;
   int32_t h, B_cap, n_cap, n_ld;   /* n_ld = round_up(n_cap, 32) */
 } rk_planes_t;
-int64_t rk_planes_bytes(int32_t B_cap, int32_t h, int32_t n_cap);
-/* tuning / test hook: rows of a decode tile, 128 or 64 (the tile shape of rk_decode_loss); 0 = by
- * the problem's size (default) */
-void rk_planes_tile(int32_t rows);
 /*
  * The decode + loss of rk_decode_loss_planes (MSE / BCE, 64 x 128 tiles) with dZ FUSED: every workgroup
  * multiplies the dO tile it has just computed (kept in LDS, cut into fp16 pairs with the TILE's own
@@ -387,20 +372,11 @@ void rk_planes_tile(int32_t rows);
  * slabs (* act'(Zact) if given) into dZ.  Replaces rk_decode_loss_planes + rk_decode_bwd_dz_planes
  * (one launch, one pass over dO and one cross-queue edge less); same mathematics, other split scales
  * and summation grouping than the stand-alone kernel (agreement ~1e-7 relative).  Shapes / losses:
- * rk_decode_dz_fused_ok (h <= 256, B < 1024, slab workspace <= 4 GB; always 64-row tiles; RK_DZ_FUSED=0
- * turns it off).
+ * rk_plan_t.decode_dz_fused_ok (h <= 256, B < 1024, slab workspace <= 4 GB; always 64-row tiles).
  */
-int32_t rk_decode_dz_fused_ok(int32_t B, int32_t h, int32_t n_cap, int32_t loss_kind);
-int64_t rk_dz_fused_workspace_bytes(int32_t B, int32_t h, int32_t n_cap);
 int rk_decode_loss_dz_planes(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off,
                              const float *b_de, int32_t loss_kind, float confidence, float inv_B, float *dO,
                              float *loss_part, float *gb_part, float *dz_workspace, void *stream);
-/* the same with dLoss/dLogits leaving as a plane IMAGE (rk_pg_* notes below; granule 64 x 128) instead of
- * the fp32 matrix: the operand of rk_pg_dw */
-int rk_decode_loss_dz_image(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off,
-                            const float *b_de, int32_t loss_kind, float confidence, float inv_B, void *dO_img,
-                            int32_t rows_img, float *dO_scales, float *loss_part, float *gb_part,
-                            float *dz_workspace, void *stream);
 int rk_decode_dz_reduce(const float *dz_workspace, int32_t B, int32_t h, const rk_block_t *tgt,
                         const float *Zact /* nullable */, int32_t act, float *dZ, void *stream);
 /*
@@ -416,12 +392,12 @@ int rk_decode_dz_reduce(const float *dz_workspace, int32_t B, int32_t h, const r
  *   m * ld * 4 of dO_img, ld = counts[2] -- the footprint of the fp32 matrix it replaces; rows
  *   [B, round_up(B, 32)) and columns [n_t, ld) are written as zeros) cut with the TILE's own power-of-two
  *   scale, published in dO_scales[(row / gr) * ceil(n_cap / gc) + col / gc] with (gr, gc) =
- *   rk_pg_decode_granule(B, n_cap) (rk_pg_scale_floats floats fit every producer).  dO_f32 (nullable):
+ *   rk_plan_t.pg_granule_rows / _cols (rk_plan_t.pg_scale_floats floats fit every producer).  dO_f32 (nullable):
  *   the fp32 matrix as well (tests).  loss_part / gb_part as rk_decode_loss.
  * rk_pg_dz: dZ[B, h] = dO . W_de[T] (* act'(Zact) if given) from the image and pl->w; workspace:
- *   rk_pg_dz_workspace_bytes.  rk_pg_dw: the K slabs [rk_pg_dw_splits][n_cap][h] of dW[n_t, h] = dO^T . Z
+ *   rk_plan_t.pg_dz_workspace_bytes.  rk_pg_dw: the K slabs [rk_plan_t.pg_dw_splits][n_cap][h] of dW[n_t, h] = dO^T . Z
  *   from the image and pl->z (rk_adam_multi adds them: g_parts).  (gr, gc): the granule of the producer
- *   of the image -- rk_pg_decode_granule, or 64 x 128 for rk_decode_loss_dz_planes' image form.
+ *   of the image -- rk_plan_t.pg_granule_rows / _cols for rk_pg_decode_loss / rk_pg_decode_mnll, 32 x 64 for rk_fdec_loss_dz.
  */
 /* The fused decode + loss + dZ partials of SMALL hidden sizes, register resident (csrc/fdecode.hip): the
  * 128-item x 128-user tile is computed transposed, so that the loss runs in the accumulator layout and
@@ -430,15 +406,11 @@ int rk_decode_dz_reduce(const float *dz_workspace, int32_t B, int32_t h, const r
  * dLoss/dLogits leaves as a plane image (scale granule 32 users x 64 items: dO_scales[(m / 32) *
  * ceil(n_cap / 64) + n / 64]); the slabs as rk_decode_loss_dz_planes leaves them (rk_decode_dz_reduce
  * sums them).  The decoder bias gradient is NOT produced here: rk_pg_dw_encode_bwd takes it from the image.
- * Domain: rk_fdec_ok (mse / logistic, h <= 224, < 1024 rows; RK_FDEC=0: off). */
-int32_t rk_fdec_ok(int32_t B, int32_t h, int32_t n_cap, int32_t loss_kind);
-int64_t rk_fdec_workspace_bytes(int32_t B, int32_t h, int32_t n_cap);
+ * Domain: rk_plan_t.fdec_ok (mse / logistic, h <= 224, < 1024 rows; RK_FDEC=0: off). */
 int rk_fdec_loss_dz(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off, const float *b_de,
                     int32_t loss_kind, float confidence, float inv_B, void *dO_img, int32_t rows_img,
                     float *dO_scales, float *loss_part, float *dz_workspace, void *stream);
-int32_t rk_pg_enabled(void);     /* RK_PG=0 switches the family off (the round-3 plane kernels run instead) */
-void rk_pg_decode_granule(int32_t B, int32_t n_cap, int32_t *gr, int32_t *gc);
-int64_t rk_pg_scale_floats(int32_t B_cap, int32_t n_cap);
+/* (RK_PG=0 in the environment switches the family off: the round-3 plane kernels run instead) */
 int rk_pg_decode_loss(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off,
                       const float *b_de, int32_t loss_kind, float confidence, float inv_B, void *dO_img,
                       int32_t rows_img, float *dO_scales, float *dO_f32 /* nullable */, float *loss_part,
@@ -446,53 +418,37 @@ int rk_pg_decode_loss(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, i
 /* The multinomial NLL (losses.py:68-71) the same way, as two passes over the decode: a statistics pass
  * that writes 8 bytes per (row, column tile) -- {max, sum exp} of its live columns -- and the decode +
  * loss pass that merges them into the row's log-sum-exp; no logits matrix is written, re-read and
- * rewritten (rk_decode_loss_planes + rk_mnll_finish).  mnll_ws: rk_pg_mnll_workspace_floats floats;
- * loss_part: one partial per tile (rk_loss_partials slots), gb_part as rk_decode_loss. */
-int64_t rk_pg_mnll_workspace_floats(int32_t B, int32_t n_cap);
+ * rewritten (rk_decode_loss_planes + rk_mnll_finish).  mnll_ws: rk_plan_t.pg_mnll_workspace_floats floats;
+ * loss_part: one partial per tile (rk_plan_t.loss_partials slots), gb_part as rk_decode_loss. */
 int rk_pg_decode_mnll(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off,
                       const float *b_de, float inv_B, float *mnll_ws, void *dO_img, int32_t rows_img,
                       float *dO_scales, float *dO_f32 /* nullable */, float *loss_part, float *gb_part,
                       void *stream);
-int64_t rk_pg_dz_workspace_bytes(int32_t B, int32_t h);
 int rk_pg_dz(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
              const rk_planes_t *pl, const rk_block_t *tgt, const float *Zact /* nullable */, int32_t act,
              float *dZ, float *workspace, void *stream);
-int32_t rk_pg_dw_splits(int32_t B, int32_t h, int32_t n_cap);
-int64_t rk_pg_dw_workspace_bytes(int32_t B, int32_t h, int32_t n_cap);
 int rk_pg_dw(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
              const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, void *stream);
 /* rk_pg_dw || rk_ae_encode_bwd (G_en, gb_en as there; nothing accumulated) in ONE launch: the dW tiles
- * first in the grid, then a wave per item column (domain: rk_dw_encode_bwd_fused_ok) */
+ * first in the grid, then a wave per item column (domain: rk_plan_t.dw_encode_bwd_fused_ok) */
 int rk_pg_dw_encode_bwd(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
                         const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, int32_t row_off,
                         const float *dZ0pre, float *G_en, float *gb_en,
                         float *gb_de /* nullable: the decoder bias gradient [n_t] = column sums of dO, from
                                         the image, by a third workgroup range */, void *stream);
-/* tuning probe (tools/probes/enc_phase_probe.py): device buffer of 8 uint64 per user row of the
- * encoder forward (entry, first entries loaded, gather done, end); NULL (default): off */
-void rk_enc_probe(unsigned long long *buffer);
-/* tuning probe (tools/probes/planes_phase_probe.py): device buffer of 8 uint64 per workgroup of the
- * largest grid, or NULL (default) to switch it off */
-void rk_planes_probe(unsigned long long *buffer);
 int rk_planes_layout(void *buffer, int32_t B_cap, int32_t h, int32_t n_cap, rk_planes_t *out);
-/* W_de[tgt->items[0 .. n_b)] -> pl->w and pl->wt; the scale from ranges[64..127] (rk_amax notes) */
-int rk_split_w(const float *W_de, int32_t h, const rk_block_t *tgt, const int32_t *ranges,
-               const rk_planes_t *pl, void *stream);
-/* rk_split_w + rk_split_z as ONE launch (entry-by-entry sequenced steps: MatrixFactorization, hidden
- * stacks -- one launch less in front of every decode; same images, bit for bit) */
-int rk_split_wz(const float *W_de, const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
-                const int32_t *ranges, const rk_planes_t *pl, void *stream);
-/* rk_split_wz that ALSO writes Z^T as the fp16 pair planes (+ their scale) of the dW kernel at the head
- * of dw_workspace -- where rk_decode_bwd_dw2 makes them in a launch of its own when it is called
- * with zt_planes == NULL; call it with zt_planes == workspace == dw_workspace afterwards (the kernel then
- * reads the scale the planes were written with).  dw_workspace NULL: rk_split_wz.  Only where
- * rk_split_zt_ok() (dW on fp16 pairs, not the plain-bf16 data point). */
-int32_t rk_split_zt_ok(void);
-int rk_split_wz_zt(const float *W_de, const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
-                   const int32_t *ranges, const rk_planes_t *pl, void *dw_workspace, void *stream);
-/* Z[B, h] -> pl->z; the scale from ranges[0..63] */
-int rk_split_z(const float *Z, int32_t B, int32_t h, const int32_t *ranges, const rk_planes_t *pl,
-               void *stream);
+/* The operand splits of a decode in ONE launch (same images, bit for bit, as separate launches would make):
+ *   W_de[tgt->items[0 .. n_b)] -> pl->w and pl->wt (pl->wt == NULL: no W^T image); scale from ranges[64..127]
+ *     (rk_amax notes).  W_de NULL: the W images are already there (rk_ae_encode_fwd_split_w).
+ *   Z[B, h] -> pl->z; the scale from ranges[0..63].  Z NULL: only W is cut.
+ *   dw_workspace (nullable): ALSO Z^T as the fp16 pair planes (+ their scale) of the dW kernel at the head of
+ *     dw_workspace -- where rk_decode_bwd_dw2 makes them in a launch of its own when it is called with
+ *     zt_planes == NULL; call it with zt_planes == workspace == dw_workspace afterwards (the kernel then reads
+ *     the scale the planes were written with).  Only where rk_plan_t.split_zt_ok (dW on fp16 pairs, not the
+ *     plain-bf16 data point). */
+int rk_split_wz(const float *W_de /* nullable */, const float *Z /* nullable */, int32_t B, int32_t h,
+                const rk_block_t *tgt, const int32_t *ranges, const rk_planes_t *pl,
+                void *dw_workspace /* nullable */, void *stream);
 /* rk_decode_loss on pl->z x pl->w (arguments as there).  MSE / BCE: the padding columns
  * [n_t, ld) of every dO row are written as zeros. */
 int rk_decode_loss_planes(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off,
@@ -523,9 +479,6 @@ int rk_linear_bwd(float *dY, const float *Y, const float *X, const float *W,
 int rk_linear_bwd_pre(const float *dYpre, const float *X, const float *W, int32_t B, int32_t N, int32_t K,
                       int32_t w_transposed, int32_t act, float *dX /* nullable */, float *dW,
                       int32_t dw_accumulate, float *db, const float *dx_act_y /* nullable */, void *stream);
-/* tuning switch (default on, RK_LINEAR_PAIR=0 / rk_linear_pair(0): off): rk_linear_bwd's dX and dW
- * products as ONE launch of two workgroup ranges (same tiles, same sums as the two launches) */
-void rk_linear_pair(int32_t on);
 /* rk_linear_bwd whose dX leaves multiplied by act'(dx_act_y[B,K]) (nullable): the backward of a
  * stack's FIRST Linear layer hands its gradient to the embedding layer's activation -- the
  * rk_act_grad launch that followed, folded into the dX epilogue (same product, same bits). */
@@ -663,11 +616,11 @@ typedef struct rk_ae_step {
   void *stream;              /* hipStream_t: every kernel of the step goes here, in order */
   int32_t time_entry;        /* RK_ENTRY_*: bracket that entry with the two events below */
   int32_t phase;             /* mask of RK_STEP_* (0 = RK_STEP_ALL) */
-  void *time_ev0, *time_ev1; /* rk_timing_event_create */
+  void *time_ev0, *time_ev1; /* rk_event_create(1) */
   /* item-parallel segments only */
   const float *user_norm;    /* [n_users] L2 norm of every user's whole row (by global user id) */
   int32_t own_rank, own_world;
-  void *zt_planes;           /* nullable: rk_dw3_planes_bytes(B_cap, h) bytes, zeroed once: the
+  void *zt_planes;           /* nullable: rk_plan_t.dw3_planes_bytes bytes, zeroed once: the
                                 encoder forward writes the Z^T planes of the dW kernel there */
   /* HIP-graph replay (whole steps only): a replayed launch cannot take new arguments, so what
    * changes per step is derived ON THE DEVICE from cursor = {global index of the next step,
@@ -698,14 +651,14 @@ typedef struct rk_ae_step {
    * stream behind dw_fork (recorded after the decode) AFTER the chain's launches -- in a stream
    * capture the branch captured first keeps the launching queue, and the chain is the critical
    * one -- and the Adam sweep waits for dw_join.  It then needs a workspace of its own, ws_dw
-   * (rk_dw3_workspace_bytes).  All NULL: dW runs in line on `stream`, in `ws`. */
+   * (rk_plan_t.dw3_workspace_bytes).  All NULL: dW runs in line on `stream`, in `ws`. */
   float *ws_dw;
   void *dw_stream, *dw_fork, *dw_join;
   /* nullable: operand planes (rk_planes_layout) -- the step then splits W_de[items] inside its
    * encoder-forward launch, Z in that kernel's epilogue (unbounded activations: rk_amax +
    * rk_split_z), and runs the decode and dZ through the *_planes kernels */
   const rk_planes_t *planes;
-  /* nullable: scale table of the dO IMAGE (rk_pg_scale_floats floats).  Given, whole untied MSE / BCE
+  /* nullable: scale table of the dO IMAGE (rk_plan_t.pg_scale_floats floats).  Given, whole untied MSE / BCE
    * steps outside the fused decode's domain (h > 256, >= 1024 rows) run their three contractions on the
    * pipelined pair-plane kernels (rk_pg_decode_loss / rk_pg_dz / rk_pg_dw): `dO` then holds the image
    * (do_rows >= round_up(B, 32) rows of ld * 4 bytes -- the fp32 matrix's footprint), the W^T image and
@@ -714,8 +667,8 @@ typedef struct rk_ae_step {
   int32_t do_rows;
 } rk_ae_step_t;
 
-void *rk_event_create(void);          /* ordering-only (no timing, device-scope fence) */
-void *rk_timing_event_create(void);   /* for time_ev0 / time_ev1 and rk_event_elapsed_ms */
+void *rk_event_create(int32_t timing); /* 0: ordering-only (no timing, device-scope fence); 1: for time_ev0 /
+                                          time_ev1 and rk_event_elapsed_ms */
 void rk_event_destroy(void *event);
 float rk_event_elapsed_ms(void *ev0, void *ev1);   /* synchronises on ev1 */
 int rk_ae_train_step(const rk_ae_step_t *step);
@@ -725,7 +678,7 @@ int32_t rk_ae_step_uses_pg(const rk_ae_step_t *step);
 /*
  * Graph replay of the hot loop.  rk_collate_at = rk_collate (phase 0) on the users
  * users_base[(cursor[0] - cursor[1] + off) * S ...] with the stamp of global step cursor[0] + off;
- * rk_cursor_set / rk_cursor_advance maintain the cursor with 1-thread launches (in order on the
+ * rk_cursor_set maintains the cursor with a 1-thread launch (in order on the
  * stream, capturable); rk_adam_consts fills one entry of the per-step constants table on the
  * host.  rk_graph_* wrap hipStreamBeginCapture / EndCapture / hipGraphInstantiate / Launch for a
  * caller that holds raw hipStream_t values: everything enqueued on `stream` (and on streams
@@ -737,18 +690,13 @@ int rk_collate_at(const int64_t *ds_indptr, const int32_t *ds_indices, const flo
 /* the same for n_blk <= RK_COLLATE_MULTI equally shaped blocks in ONE set of launches; block g
  * takes cursor offset off0 + g */
 #define RK_COLLATE_MULTI 8
+/* phase as rk_collate (1: row pointers + item marking; 2: the rest): data-parallel replay puts the
+ * MAX all-reduce of the blocks' mark arrays between the two, inside the capture */
 int rk_collate_at_multi(const int64_t *ds_indptr, const int32_t *ds_indices, const float *ds_data,
                         const int64_t *users_base, int32_t S, int32_t negative_sampling,
                         const int64_t *cursor, int32_t off0, const rk_block_t *const *blks,
-                        int32_t n_blk, void *stream);
-/* phase as rk_collate (1: row pointers + item marking; 2: the rest): data-parallel replay puts the
- * MAX all-reduce of the blocks' mark arrays between the two, inside the capture */
-int rk_collate_at_multi_phase(const int64_t *ds_indptr, const int32_t *ds_indices, const float *ds_data,
-                              const int64_t *users_base, int32_t S, int32_t negative_sampling,
-                              const int64_t *cursor, int32_t off0, const rk_block_t *const *blks,
-                              int32_t n_blk, int32_t phase, void *stream);
+                        int32_t n_blk, int32_t phase /* 0: everything */, void *stream);
 int rk_cursor_set(int64_t *cursor, int64_t step, int64_t epoch_base, void *stream);
-int rk_cursor_advance(int64_t *cursor, int64_t n, void *stream);
 int rk_adam_consts(double lr, double beta1, double beta2, double eps, double weight_decay,
                    int32_t step, int32_t n_steps, int32_t stride_floats, float *out_host);
 /* (entries of steps step .. step + n_steps - 1, 8 floats each, stride_floats apart) */
@@ -788,37 +736,33 @@ int rk_graph_launch(void *graph_exec, void *stream);
 /* != 0: rk_ae_train_step's timing events (time_ev0 / time_all) may be used INSIDE a capture -- they
  * become event-record nodes that every replay re-records.  Depends on the HIP runtime in the process:
  * hipEventRecordWithFlags(hipEventRecordExternal) where it is accepted (ROCm 7.2); with
- * RK_GRAPH_EVENT_NODES=1 also nodes added with hipGraphAddEventRecordNode at the capture's current
+ * the probe header's RK_TUNE_GRAPH_EVENT_NODES: also nodes added with hipGraphAddEventRecordNode at the capture's current
  * dependencies (works on the 7.0 runtime PyTorch bundles; off by default: no faster than the eager
  * brackets there and its intervals read longer); rk_graph_event_node_probe runs that route once on a scratch stream and returns the
  * interval (ms) it read between two such nodes, or a negative code. */
-int32_t rk_graph_timing_supported(void);
-float rk_graph_event_node_probe(void);
 void rk_graph_destroy(void *graph_exec);
 /* cross-stream edges inside a capture (fork / join): event from rk_event_create */
 int rk_event_record(void *event, void *stream);
 int rk_stream_wait_event(void *stream, void *event);
 
 /*
- * rk_topk_masked -- Recoder.recommend (model.py:525-544): scores[B,ld] with the
- * seen items (bits_rc of the non-sampled block) set to -inf, top-k sorted
- * descending (ties: lower index first, as torch.topk on CPU).
+ * rk_topk_masked -- Recoder.recommend (model.py:525-544): scores[B, ld] with the seen items (bits_rc of
+ * the non-sampled block; only positive stored interactions, model.py:537 `output[input > 0]`) set to -inf,
+ * top-k sorted descending (ties: lower index first, as torch.topk on CPU).  Score column c is item
+ * col_off + c * col_stride (mask lookup and returned indices are global); row r's k results go to
+ * out_idx / out_val [r * out_ld ...].
+ *   whole rows          : col_off 0, col_stride 1, out_ld k
+ *   a STRIP of the catalogue (col_stride 1): Recoder.recommend decodes a bounded strip of items at a
+ *     time, keeps each strip's top k and merges them with one more call (seen == NULL) -- the
+ *     [B, n_items] score matrix never exists
+ *   a STRIDED SAMPLE (col_stride > 1): step 1 of the fused form below
  */
-int rk_topk_masked(const float *scores, int32_t B, int32_t n, int32_t ld,
-                   const rk_block_t *seen, int32_t row_off, int32_t k,
-                   int64_t *out_idx, float *out_val, void *stream);
-/* The same on a STRIP of the catalogue: score column c is item col_off + c (mask lookup and
- * returned indices are global), row r's k results go to out_idx / out_val [r * out_ld ...].  Only
- * positive stored interactions are masked (model.py:537 `output[input > 0]`).  Recoder.recommend
- * decodes a bounded strip of items at a time, keeps each strip's top k and merges them with one
- * more call (seen == NULL) -- the [B, n_items] score matrix never exists. */
-int rk_topk_masked_strip(const float *scores, int32_t B, int32_t n, int32_t ld,
-                         const rk_block_t *seen, int32_t row_off, int32_t k, int32_t col_off,
-                         int64_t *out_idx, float *out_val, int32_t out_ld, void *stream);
-int32_t rk_topk_max_k(void);
+int rk_topk_masked(const float *scores, int32_t B, int32_t n, int32_t ld, const rk_block_t *seen,
+                   int32_t row_off, int32_t k, int32_t col_off, int32_t col_stride,
+                   int64_t *out_idx /* nullable */, float *out_val /* nullable */, int32_t out_ld, void *stream);
 /*
  * The fused form (catalogues of more than one strip): no score matrix at all.
- *   1. rk_topk_masked_strided on the scores of a STRIDED SAMPLE of the catalogue (score column c is
+ *   1. rk_topk_masked on the scores of a STRIDED SAMPLE of the catalogue (score column c is
  *      item col_off + c * col_stride): the k-th best sampled score of a row is a lower bound of the
  *      k-th best score of its whole row;
  *   2. rk_decode_filter_planes: the decode over the whole catalogue from plane images (rk_split_image
@@ -831,9 +775,6 @@ int32_t rk_topk_max_k(void);
  */
 int rk_split_image(const float *X, int64_t rows, int32_t K, int64_t ld, const int32_t *amax /* nullable */,
                    float dflt_scale, void *image, float *scales, int32_t slot, void *stream);
-int rk_topk_masked_strided(const float *scores, int32_t B, int32_t n, int32_t ld, const rk_block_t *seen,
-                           int32_t row_off, int32_t k, int32_t col_off, int32_t col_stride,
-                           int64_t *out_idx, float *out_val, int32_t out_ld, void *stream);
 int rk_decode_filter_planes(const void *zimg, const void *wimg, const float *scales, int32_t h, int32_t B,
                             int32_t n, int32_t col_off, const float *b_de /* nullable */,
                             const rk_block_t *seen /* nullable */, int32_t row_off, const float *thr,
@@ -841,8 +782,8 @@ int rk_decode_filter_planes(const void *zimg, const void *wimg, const float *sca
                             const int32_t *n_dev, void *stream);
 int rk_topk_pairs(const float *val, const int32_t *idx, const int32_t *cnt, int32_t B, int32_t cap,
                   int32_t k, int64_t *out_idx, int32_t out_ld, int32_t *status, void *stream);
-int32_t rk_topk_pairs_max_cap(void);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,23 @@ class RkAdamParam(Structure):
               ("weight_decay", c_double), ("step", c_int32), ("sparse", c_int32)]
 
 
+class RkPlan(Structure):
+  """mirror of rk_plan_t"""
+  _fields_ = [
+    ("B", c_int32), ("h", c_int32), ("n_cap", c_int32), ("loss_kind", c_int32), ("row_off", c_int32),
+    ("gemm_split16", c_int32), ("gemm_plain_bf16", c_int32), ("dw_pairs", c_int32), ("split_zt_ok", c_int32),
+    ("pg_enabled", c_int32), ("graph_timing_supported", c_int32), ("decode_row_tile", c_int32),
+    ("dw3_max_splits", c_int32), ("topk_max_k", c_int32), ("topk_pairs_max_cap", c_int32),
+    ("loss_partials", c_int32), ("dw_splits", c_int32), ("pg_dw_splits", c_int32),
+    ("dw3_rows_pad", c_int32), ("dw3_cols_pad", c_int32), ("pg_granule_rows", c_int32), ("pg_granule_cols", c_int32),
+    ("planes_bytes", c_int64), ("dz_workspace_bytes", c_int64), ("dz_fused_workspace_bytes", c_int64),
+    ("dw_workspace_bytes", c_int64), ("dw3_workspace_bytes", c_int64), ("dw3_planes_bytes", c_int64),
+    ("fdec_workspace_bytes", c_int64), ("pg_dz_workspace_bytes", c_int64), ("pg_dw_workspace_bytes", c_int64),
+    ("pg_scale_floats", c_int64), ("pg_mnll_workspace_floats", c_int64),
+    ("decode_dz_fused_ok", c_int32), ("fdec_ok", c_int32), ("dw_encode_bwd_fused_ok", c_int32), ("adam_de_side", c_int32),
+  ]
+
+
 PAR_W_EN, PAR_B_EN, PAR_W_DE, PAR_B_DE = 0, 1, 2, 3
 ENTRY_ALL = -1
 ENTRY = {"rk_ae_encode_fwd": 1, "rk_decode_loss": 2, "rk_decode_bwd_dz": 3, "rk_decode_bwd_dw": 4,
@@ -112,9 +129,11 @@ _BLK = POINTER(RkBlock)
 
 # name -> (restype, argtypes); every symbol include/recoder_hip.h declares
 SIGNATURES = {
+  "rk_plan": (c_int32, [POINTER(RkPlan)]),
+  "rk_probe_buffer": (c_int32, [c_int32, _P]),
+  "rk_tune": (c_int32, [c_int32, c_int32]),
   "rk_version": (c_int32, []),
   "rk_last_error": (c_char_p, []),
-  "rk_dz_workspace_bytes": (c_int64, [c_int32, c_int32]),
   "rk_collate": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _BLK, _P]),
   "rk_ae_encode_fwd_partial": (c_int32, [_BLK, c_int32, c_int32, _P, c_int32, _P, c_float, c_uint64,
                                          c_uint64, _P, _P, _P, _P]),
@@ -125,88 +144,47 @@ SIGNATURES = {
   "rk_ae_encode_fwd_split_w": (c_int32, [_BLK, c_int32, c_int32, _P, _P, c_int32, _P, c_float, c_uint64,
                                          c_uint64, _P, c_int32, _P, _P, _P, POINTER(RkPlanes), _P]),
   "rk_ae_encode_bwd": (c_int32, [_BLK, c_int32, c_int32, _P, c_int32, _P, c_int32, _P, _P]),
-  "rk_loss_partials": (c_int32, [c_int32, c_int32]),
-  "rk_decode_row_tile": (c_int32, []),
   "rk_decode_loss": (c_int32, [_P, c_int32, c_int32, _BLK, c_int32, _P, _P, c_int32, c_float,
                                c_float, _P, c_int32, _P, _P, _P, _P]),
   "rk_amax": (c_int32, [_P, c_int64, _P, _P]),
-  "rk_planes_bytes": (c_int64, [c_int32, c_int32, c_int32]),
-  "rk_planes_tile": (None, [c_int32]),
-  "rk_planes_probe": (None, [_P]),
   "rk_planes_layout": (c_int32, [_P, c_int32, c_int32, c_int32, POINTER(RkPlanes)]),
-  "rk_split_w": (c_int32, [_P, c_int32, _BLK, _P, POINTER(RkPlanes), _P]),
-  "rk_split_z": (c_int32, [_P, c_int32, c_int32, _P, POINTER(RkPlanes), _P]),
-  "rk_split_wz": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, POINTER(RkPlanes), _P]),
-  "rk_split_wz_zt": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, POINTER(RkPlanes), _P, _P]),
-  "rk_split_zt_ok": (c_int32, []),
+  "rk_split_wz": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, POINTER(RkPlanes), _P, _P]),
   "rk_decode_loss_planes": (c_int32, [POINTER(RkPlanes), c_int32, _BLK, c_int32, _P, c_int32, c_float,
                                       c_float, _P, c_int32, _P, _P, _P]),
   "rk_decode_bwd_dz_planes": (c_int32, [_P, c_int32, POINTER(RkPlanes), _BLK, _P, c_int32, _P, _P, _P]),
-  "rk_mnll_finish": (c_int32, [_P, c_int32, _BLK, c_int32, c_float, _P, _P]),
   "rk_mnll_row_stats": (c_int32, [_P, c_int32, _BLK, _P, _P]),
-  "rk_mnll_finish_ext": (c_int32, [_P, c_int32, _BLK, c_int32, c_float, _P, _P, _P, _P, _P]),
+  "rk_mnll_finish": (c_int32, [_P, c_int32, _BLK, c_int32, c_float, _P, _P, _P, _P, _P]),
   "rk_loss_reduce": (c_int32, [_P, c_int32, c_float, _P, _P]),
   "rk_decode_bwd_dz": (c_int32, [_P, c_int32, c_int32, _BLK, _P, _P, c_int32, _P, _P, _P, _P]),
   "rk_decode_bwd_dw": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P]),
   "rk_decode_bwd_dw_encode_bwd": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, c_int32, _P, _P, _P, _P,
                                             _P]),
-  "rk_dw_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
-  "rk_dw3_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
-  "rk_dw3_max_splits": (c_int32, []),
-  "rk_dw3_probe": (None, [_P]),
   "rk_dw3_slabs": (c_void_p, [_P, c_int32, c_int32]),
   "rk_decode_bwd_dw3": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, _P, _P]),
   "rk_decode_bwd_dw2": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, _P, _P, _P]),
-  "rk_dw_pairs": (c_int32, []),
-  "rk_adam_de_side": (c_int32, []),
-  "rk_enc_probe": (None, [_P]),
-  "rk_dw_encode_bwd_fused_ok": (c_int32, [c_int32, c_int32]),
   "rk_decode_bwd_dw2_encode_bwd": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, c_int32, _P, _P, _P, _P]),
   "rk_decode_bwd_dw2_dz_reduce": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, _P, _P, c_int32, _P, _P]),
   "rk_decode_bwd_dw2_encode_bwd_colsum": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, c_int32, _P, _P,
                                                     _P, _P, _P]),
-  "rk_decode_dz_fused_ok": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
-  "rk_dz_fused_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
   "rk_decode_loss_dz_planes": (c_int32, [_P, c_int32, _BLK, c_int32, _P, c_int32, c_float, c_float, _P, _P, _P,
                                          _P, _P]),
-  "rk_decode_loss_dz_image": (c_int32, [_P, c_int32, _BLK, c_int32, _P, c_int32, c_float, c_float, _P, c_int32, _P,
-                                        _P, _P, _P, _P]),
   "rk_decode_dz_reduce": (c_int32, [_P, c_int32, c_int32, _BLK, _P, c_int32, _P, _P]),
-  "rk_fdec_ok": (c_int32, [c_int32, c_int32, c_int32, c_int32]),
-  "rk_fdec_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
   "rk_fdec_loss_dz": (c_int32, [POINTER(RkPlanes), c_int32, _BLK, c_int32, _P, c_int32, c_float, c_float, _P, c_int32,
                                 _P, _P, _P, _P]),
-  "rk_pg_enabled": (c_int32, []),
   "rk_ae_step_uses_pg": (c_int32, [_P]),
-  "rk_pg_decode_granule": (None, [c_int32, c_int32, POINTER(c_int32), POINTER(c_int32)]),
-  "rk_pg_scale_floats": (c_int64, [c_int32, c_int32]),
   "rk_pg_decode_loss": (c_int32, [POINTER(RkPlanes), c_int32, _BLK, c_int32, _P, c_int32, c_float, c_float, _P,
                                   c_int32, _P, _P, _P, _P, _P]),
-  "rk_pg_mnll_workspace_floats": (c_int64, [c_int32, c_int32]),
   "rk_pg_decode_mnll": (c_int32, [POINTER(RkPlanes), c_int32, _BLK, c_int32, _P, c_float, _P, _P, c_int32, _P, _P, _P,
                                   _P, _P]),
-  "rk_pg_dz_workspace_bytes": (c_int64, [c_int32, c_int32]),
   "rk_pg_dz": (c_int32, [_P, _P, c_int32, c_int32, c_int32, POINTER(RkPlanes), _BLK, _P, c_int32, _P, _P, _P]),
-  "rk_pg_dw_splits": (c_int32, [c_int32, c_int32, c_int32]),
-  "rk_pg_dw_workspace_bytes": (c_int64, [c_int32, c_int32, c_int32]),
   "rk_pg_dw": (c_int32, [_P, _P, c_int32, c_int32, c_int32, POINTER(RkPlanes), _BLK, _P, _P]),
   "rk_pg_dw_encode_bwd": (c_int32, [_P, _P, c_int32, c_int32, c_int32, POINTER(RkPlanes), _BLK, _P, c_int32, _P, _P, _P,
                                     _P, _P]),
-  "rk_dw3_planes_bytes": (c_int64, [c_int32, c_int32]),
-  "rk_dw3_rows_pad": (c_int32, [c_int32]),
-  "rk_dw3_cols_pad": (c_int32, [c_int32]),
-  "rk_ae_encode_fwd_planes": (c_int32, [_BLK, c_int32, c_int32, _P, _P, c_int32, _P, c_float, c_uint64,
-                                        c_uint64, _P, c_int32, _P, _P, _P]),
   "rk_split_planes_t": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
-  "rk_gemm_split16": (c_int32, []),
-  "rk_gemm_plain_bf16": (c_int32, []),
-  "rk_gemm_probe": (None, [_P]),
   "rk_encode_bwd_segments": (c_int32, [c_int32]),
-  "rk_dw_splits": (c_int32, [c_int32]),
   "rk_linear_fwd": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
   "rk_linear_bwd": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P,
                               c_int32, _P, _P]),
-  "rk_linear_pair": (None, [c_int32]),
   "rk_linear_bwd_pre": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P, c_int32, _P, _P,
                                   _P]),
   "rk_linear_bwd_dact": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P,
@@ -224,17 +202,14 @@ SIGNATURES = {
                               c_double, c_int32, _P]),
   "rk_adam_multi": (c_int32, [POINTER(RkAdamJob), c_int32, _P, c_int32, c_float, _P, _P]),
   "rk_scatter_pos": (c_int32, [_P, _P, c_int32, c_int32, _P]),
-  "rk_event_create": (c_void_p, []),
-  "rk_timing_event_create": (c_void_p, []),
+  "rk_event_create": (c_void_p, [c_int32]),
   "rk_event_destroy": (None, [c_void_p]),
   "rk_event_elapsed_ms": (c_float, [c_void_p, c_void_p]),
   "rk_ae_train_step": (c_int32, [POINTER(RkAeStep)]),
   "rk_collate_at": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, c_int32, _BLK, _P]),
-  "rk_collate_at_multi": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, c_int32, POINTER(_BLK), c_int32, _P]),
-  "rk_collate_at_multi_phase": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, c_int32, POINTER(_BLK), c_int32,
+  "rk_collate_at_multi": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, c_int32, POINTER(_BLK), c_int32,
                                           c_int32, _P]),
   "rk_cursor_set": (c_int32, [_P, c_int64, c_int64, _P]),
-  "rk_cursor_advance": (c_int32, [_P, c_int64, _P]),
   "rk_adam_consts": (c_int32, [c_double, c_double, c_double, c_double, c_double, c_int32, c_int32,
                                c_int32, _P]),
   "rk_replay_set": (None, [POINTER(RkReplay)]),
@@ -242,22 +217,15 @@ SIGNATURES = {
   "rk_graph_begin": (c_int32, [_P]),
   "rk_graph_end": (c_void_p, [_P]),
   "rk_graph_launch": (c_int32, [_P, _P]),
-  "rk_graph_timing_supported": (c_int32, []),
-  "rk_graph_event_node_probe": (c_float, []),
   "rk_graph_destroy": (None, [_P]),
   "rk_event_record": (c_int32, [_P, _P]),
   "rk_stream_wait_event": (c_int32, [_P, _P]),
-  "rk_topk_masked": (c_int32, [_P, c_int32, c_int32, c_int32, _BLK, c_int32, c_int32, _P, _P, _P]),
-  "rk_topk_masked_strip": (c_int32, [_P, c_int32, c_int32, c_int32, _BLK, c_int32, c_int32, c_int32, _P, _P,
-                                     c_int32, _P]),
-  "rk_topk_max_k": (c_int32, []),
   "rk_split_image": (c_int32, [_P, c_int64, c_int32, c_int64, _P, c_float, _P, _P, c_int32, _P]),
-  "rk_topk_masked_strided": (c_int32, [_P, c_int32, c_int32, c_int32, _BLK, c_int32, c_int32, c_int32, c_int32,
+  "rk_topk_masked": (c_int32, [_P, c_int32, c_int32, c_int32, _BLK, c_int32, c_int32, c_int32, c_int32,
                                        _P, _P, c_int32, _P]),
   "rk_decode_filter_planes": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, _BLK, c_int32, _P,
                                         _P, _P, _P, c_int32, _P, _P]),
   "rk_topk_pairs": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, _P, c_int32, _P, _P]),
-  "rk_topk_pairs_max_cap": (c_int32, []),
 }
 
 _lib = None
@@ -281,8 +249,62 @@ def load():
     fn = getattr(lib, name)          # AttributeError if a declared symbol is missing
     fn.restype = res
     fn.argtypes = args
+  _install_plan_accessors(lib)
+  # the probe header's two entry points under the names tools/ and tests/ were written against
+  lib.rk_gemm_probe = lambda buf: lib.rk_probe_buffer(0, buf)
+  lib.rk_dw3_probe = lambda buf: lib.rk_probe_buffer(1, buf)
+  lib.rk_enc_probe = lambda buf: lib.rk_probe_buffer(2, buf)
+  lib.rk_planes_probe = lambda buf: lib.rk_probe_buffer(3, buf)
+  def tune(knob):
+    def set_(value):
+      _plans.clear()                      # (the plan's predicates follow the knobs)
+      return lib.rk_tune(knob, value)
+    return set_
+  lib.rk_linear_pair, lib.rk_planes_tile = tune(0), tune(1)
   _lib = lib
   return lib
+
+
+_plans = {}
+
+
+def plan(B=0, h=0, n_cap=0, loss_kind=0, row_off=0):
+  """rk_plan of one shape (cached: the plan is a pure function of its inputs and the process environment)."""
+  key = (int(B), int(h), int(n_cap), int(loss_kind), int(row_off))
+  p = _plans.get(key)
+  if p is None:
+    p = RkPlan()
+    p.B, p.h, p.n_cap, p.loss_kind, p.row_off = key
+    check(load().rk_plan(ctypes.byref(p)), "rk_plan")
+    _plans[key] = p
+  return p
+
+
+def _install_plan_accessors(lib):
+  """lib.rk_<field>(...) for the fields of rk_plan_t: the one-value accessors the engine, the tests and the
+  tools were written against (the library itself exports rk_plan only)."""
+  def field(name, args):
+    def get(*a):
+      return getattr(plan(**dict(zip(args, a))), name)
+    return get
+  for name, args in (
+      ("dz_workspace_bytes", ("B", "h")), ("loss_partials", ("B", "n_cap")), ("decode_row_tile", ()),
+      ("planes_bytes", ("B", "h", "n_cap")), ("split_zt_ok", ()), ("dw_workspace_bytes", ("B", "h", "n_cap")),
+      ("dw3_workspace_bytes", ("B", "h", "n_cap")), ("dw3_max_splits", ()), ("dw_pairs", ()),
+      ("dw_encode_bwd_fused_ok", ("row_off", "B")), ("decode_dz_fused_ok", ("B", "h", "n_cap", "loss_kind")),
+      ("dz_fused_workspace_bytes", ("B", "h", "n_cap")), ("fdec_ok", ("B", "h", "n_cap", "loss_kind")),
+      ("fdec_workspace_bytes", ("B", "h", "n_cap")), ("pg_enabled", ()), ("pg_scale_floats", ("B", "n_cap")),
+      ("pg_mnll_workspace_floats", ("B", "n_cap")), ("pg_dz_workspace_bytes", ("B", "h")),
+      ("pg_dw_splits", ("B", "h", "n_cap")), ("pg_dw_workspace_bytes", ("B", "h", "n_cap")),
+      ("dw3_planes_bytes", ("B", "h")), ("dw3_rows_pad", ("B",)), ("dw3_cols_pad", ("h",)), ("gemm_split16", ()),
+      ("gemm_plain_bf16", ()), ("adam_de_side", ()), ("dw_splits", ("B",)), ("graph_timing_supported", ()), ("topk_max_k", ()),
+      ("topk_pairs_max_cap", ())):
+    setattr(lib, "rk_" + name, field(name, args))
+
+  def granule(B, n_cap, gr, gc):
+    p = plan(B=B, n_cap=n_cap)
+    gr._obj.value, gc._obj.value = p.pg_granule_rows, p.pg_granule_cols
+  lib.rk_pg_decode_granule = granule
 
 
 def check(rc, what=""):

@@ -16,7 +16,8 @@ SOURCES = ["capi.hip", "collate.hip", "encoder.hip", "gemm.hip", "decode16.hip",
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified register
 # file); without it hipcc copied all accumulators AGPR<->VGPR around every k-tile
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+         "-Wno-unused-variable", "-Wno-unused-but-set-variable", "-mllvm", "-amdgpu-mfma-vgpr-form",
+         "-fvisibility=hidden"]       # (exports: what include/recoder_hip.h declares, nothing else)
 
 
 def _stale(target, deps):

@@ -500,21 +500,13 @@ extern "C" int rk_collate_at(const int64_t *ds_indptr, const int32_t *ds_indices
 // rk_collate_at for n_blk blocks in ONE set of launches (block g: cursor offset off0 + g): the G
 // look-ahead blocks of a replayed group, or the G blocks behind a cut, cost 3 launches on one queue
 // instead of 3 G on G queues (a 4-branch graph took 140 us to start them under the profiler)
+// phase as rk_collate: 1 = row pointers + item marking, 2 = the rest (data-parallel replay: the
+// MAX all-reduce of the n_blk mark arrays goes between them, captured with the launches)
 extern "C" int rk_collate_at_multi(const int64_t *ds_indptr, const int32_t *ds_indices,
                                    const float *ds_data, const int64_t *users_base, int32_t S,
                                    int32_t negative_sampling, const int64_t *cursor, int32_t off0,
-                                   const rk_block_t *const *blks, int32_t n_blk, void *stream_) {
-  return rk_collate_at_multi_phase(ds_indptr, ds_indices, ds_data, users_base, S, negative_sampling,
-                                   cursor, off0, blks, n_blk, 0, stream_);
-}
-
-// phase as rk_collate: 1 = row pointers + item marking, 2 = the rest (data-parallel replay: the
-// MAX all-reduce of the n_blk mark arrays goes between them, captured with the launches)
-extern "C" int rk_collate_at_multi_phase(const int64_t *ds_indptr, const int32_t *ds_indices,
-                                         const float *ds_data, const int64_t *users_base, int32_t S,
-                                         int32_t negative_sampling, const int64_t *cursor, int32_t off0,
-                                         const rk_block_t *const *blks, int32_t n_blk, int32_t phase,
-                                         void *stream_) {
+                                   const rk_block_t *const *blks, int32_t n_blk, int32_t phase,
+                                   void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(phase >= 0 && phase <= 2, "phase must be 0, 1 or 2");
   RK_REQUIRE(cursor != nullptr && blks != nullptr, "null cursor / blocks");
@@ -575,13 +567,5 @@ extern "C" int rk_cursor_set(int64_t *cursor, int64_t step, int64_t epoch_base, 
   RK_LAUNCH(cursor_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, cursor, step, epoch_base,
             (int64_t)0);
   RK_CHECK_LAUNCH("cursor_set");
-  return 0;
-}
-
-extern "C" int rk_cursor_advance(int64_t *cursor, int64_t n, void *stream_) {
-  RK_REQUIRE(n > 0, "n must be positive");
-  RK_LAUNCH(cursor_set_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream_, cursor, (int64_t)0,
-            (int64_t)0, n);
-  RK_CHECK_LAUNCH("cursor_advance");
   return 0;
 }

@@ -5,6 +5,9 @@
 #include <stdio.h>
 
 #include "../../include/recoder_hip.h"
+#include "../../include/recoder_hip_probe.h"
+#include "internal.h"
+int rk_tune_get(int knob);    // capi.hip: the value of an RK_TUNE_* knob (include/recoder_hip_probe.h)
 
 void rk_set_error(const char *fmt, ...);
 

@@ -94,11 +94,6 @@ struct DecP {
   const char *wtp;
   float *dz_ws;
   int h;
-  // ... with dO leaving as a plane IMAGE (csrc/pgemm.h: rk_pg_dw reads it) instead of fp32: C then
-  // holds the image (row m at m * ld * 4 bytes), cut with the tile's scale, published in
-  // dscale[mt * ds_pitch + nt] (granule 64 x 128)
-  float *dscale;
-  int ds_pitch, rows_img;
   // filter epilogue: column n is item col_off + n; blk = the users' INPUT block over the whole
   // catalogue (seen items), has_seen == 0: nothing is masked
   const float *thr;           // [M]
@@ -456,7 +451,7 @@ void decode_planes_kernel(DecP p) {
             else g[e] = 0.f;     // padding columns [N, ld) of the dO row are ZEROS (rk_decode_bwd_dz_planes)
           }
           // (the tiles cover [0, ld): ld = round_up(N, 32) and BN is a multiple of 32)
-          if (m < M && n < ldc && !(DZT > 0 && p.dscale))
+          if (m < M && n < ldc)
             *reinterpret_cast<float4 *>(p.C + (int64_t)m * ldc + n) = make_float4(g[0], g[1], g[2], g[3]);
           if (DZT > 0)      // (rows past M / columns past N hold zeros: g was zeroed above)
             *reinterpret_cast<float4 *>(reinterpret_cast<float *>(smem + DT_OFF) +
@@ -520,27 +515,6 @@ void decode_planes_kernel(DecP p) {
       for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
     __syncthreads();                                     // the epilogue's LDS (transposes, sums) is free
     st_pieces_n<B2_ROWS * 8>(smem, dstB2, rw2, tid);
-    if (p.dscale) {
-      // the dO tile as plane image lines: thread = (row, 32 consecutive columns) = ONE 128-byte line
-      if (tid == 0) p.dscale[mt * p.ds_pitch + nt] = s_do;
-      const int r = tid >> 2, cq = tid & 3;
-      const int m = m0 + r, n = n0 + cq * 32;
-      const int ldi = *p.ld_dev;
-      if (m < p.rows_img && n < ldi) {
-        const float *src = reinterpret_cast<const float *>(smem + DT_OFF) + r * DT_LD + cq * 32;
-        char *d = reinterpret_cast<char *>(p.C) + (int64_t)m * ldi * 4 + (n >> 5) * rkp::LINE;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 x0 = *reinterpret_cast<const float4 *>(src + q * 8);
-          const float4 x1 = *reinterpret_cast<const float4 *>(src + q * 8 + 4);
-          uint2 h0, l0, h1, l1;
-          rkp::split4(x0, s_do, h0, l0);
-          rkp::split4(x1, s_do, h1, l1);
-          *reinterpret_cast<uint4 *>(d + q * 16) = make_uint4(h0.x, h0.y, h1.x, h1.y);
-          *reinterpret_cast<uint4 *>(d + 64 + q * 16) = make_uint4(l0.x, l0.y, l1.x, l1.y);
-        }
-      }
-    }
     __syncthreads();
     const float *drow = reinterpret_cast<const float *>(smem + DT_OFF) + (wm * 32 + l31) * DT_LD + lh * 8;
     const int b2_off = l31 * ROWB + lh * 16;
@@ -857,13 +831,13 @@ int set_lds(Kern k, int bytes) {
 
 // decode tile shape: by the problem's size unless RK_DEC_TILE / rk_planes_tile force 64 (64 x 128,
 // the tile shape of gemm.hip's decode: bit-identical results) or 128 (128 x 128)
-int g_dec_tm = -1;     // -1: not read yet; 0: by shape; 1 / 2: forced (RK_DEC_TILE, rk_planes_tile)
+// 0: by shape; 1 / 2: forced (rk_tune RK_TUNE_PLANES_TILE = 64 / 128)
+inline int dec_tm_forced() {
+  const int rows = rk_tune_get(RK_TUNE_PLANES_TILE);
+  return rows == 64 ? 1 : (rows == 128 ? 2 : 0);
+}
 inline int dec_tm(int B, int n_cap) {
-  if (g_dec_tm < 0) {
-    const char *e = getenv("RK_DEC_TILE");
-    g_dec_tm = e ? (atoi(e) == 64 ? 1 : (atoi(e) == 128 ? 2 : 0)) : 0;
-  }
-  if (g_dec_tm > 0) return g_dec_tm;
+  if (dec_tm_forced() > 0) return dec_tm_forced();
   // 128 x 128 tiles for large batches; below that 64 x 128 (two workgroups per CU): C2 (B = 500,
   // n_b ~ 7.9 k: one wave of either tiling) 20.4 vs 22.4 us.  (n_b only exists on the device.)
   // (long item sets -- C5: 48.8 k sampled items of 1 M -- take the 128 x 128 tile at any batch size:
@@ -878,7 +852,6 @@ static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
 extern "C" void rk_planes_probe(unsigned long long *buffer) { g_probe = buffer; }
 
-extern "C" void rk_planes_tile(int32_t rows) { g_dec_tm = rows == 64 ? 1 : (rows == 128 ? 2 : 0); }
 
 extern "C" int64_t rk_planes_bytes(int32_t B_cap, int32_t h, int32_t n_cap) {
   // (image rows in whole groups of 32: csrc/pgemm.h reads an image along its rows in 32-row k-tiles)
@@ -928,9 +901,10 @@ extern "C" int rk_split_w(const float *W_de, int32_t h, const rk_block_t *tgt, c
 
 extern "C" int32_t rk_split_zt_ok(void) { return (rk_dw_pairs() && !rk_gemm_plain_bf16()) ? 1 : 0; }
 
-extern "C" int rk_split_wz_zt(const float *W_de, const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
-                              const int32_t *ranges, const rk_planes_t *pl, void *dw_workspace,
-                              void *stream_) {
+extern "C" int rk_split_wz(const float *W_de, const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
+                           const int32_t *ranges, const rk_planes_t *pl, void *dw_workspace,
+                           void *stream_) {
+  if (Z == nullptr) return W_de ? rk_split_w(W_de, h, tgt, ranges, pl, stream_) : 0;
   RK_REQUIRE(pl && pl->h == h && tgt->n_cap <= pl->n_cap && B <= pl->B_cap,
              "planes were laid out for another shape");
   RK_REQUIRE(aligned16(W_de) && aligned16(Z), "W_de and Z must be 16-byte aligned");
@@ -953,11 +927,6 @@ extern "C" int rk_split_wz_zt(const float *W_de, const float *Z, int32_t B, int3
             w_tiles, Z, B, reinterpret_cast<const uint32_t *>(ranges), (char *)pl->z, z_blocks, zt);
   RK_CHECK_LAUNCH("split_wz");
   return 0;
-}
-
-extern "C" int rk_split_wz(const float *W_de, const float *Z, int32_t B, int32_t h, const rk_block_t *tgt,
-                           const int32_t *ranges, const rk_planes_t *pl, void *stream_) {
-  return rk_split_wz_zt(W_de, Z, B, h, tgt, ranges, pl, nullptr, stream_);
 }
 
 extern "C" int rk_split_z(const float *Z, int32_t B, int32_t h, const int32_t *ranges,
@@ -1085,11 +1054,8 @@ extern "C" int rk_decode_filter_planes(const void *zimg, const void *wimg, const
 int rk_splitk_reduce_tiles(const float *ws, int M, int N, const int32_t *Kdev, int max_splits, int tile_k,
                            const float *Zact, int act, float *out, void *stream);
 
-// RK_DZ_FUSED=0: the stand-alone dZ kernel everywhere (A/B switch)
-static int dz_fused_on() {
-  static const int on = [] { const char *e = getenv("RK_DZ_FUSED"); return (e && atoi(e) == 0) ? 0 : 1; }();
-  return on;
-}
+// rk_tune(RK_TUNE_DZ_FUSED, 0): the stand-alone dZ kernel everywhere (A/B switch)
+static int dz_fused_on() { return rk_tune_get(RK_TUNE_DZ_FUSED) != 0; }
 
 // The fused launch always runs 64 x 128 tiles, whatever the block's CAPACITY: the 128-row tile rule of
 // the plain decode (dec_tm: n_cap >= 32768) looks at the capacity because the live item count only
@@ -1107,43 +1073,15 @@ extern "C" int64_t rk_dz_fused_workspace_bytes(int32_t B, int32_t h, int32_t n_c
 }
 
 extern "C" int32_t rk_decode_dz_fused_ok(int32_t B, int32_t h, int32_t n_cap, int32_t loss_kind) {
-  (void)dec_tm(B, n_cap);                                  // (reads RK_DEC_TILE once)
   return dz_fused_on() && !rk_gemm_plain_bf16() && (loss_kind == RK_LOSS_MSE || loss_kind == RK_LOSS_BCE) &&
-         h % 4 == 0 && h <= 256 && B < 1024 && g_dec_tm != 2 &&
+         h % 4 == 0 && h <= 256 && B < 1024 && dec_tm_forced() != 2 &&
          dz_fused_slabs_ok(h, n_cap) ? 1 : 0;
 }
-
-static int decode_loss_dz_impl(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off,
-                               const float *b_de, int32_t loss_kind, float confidence, float inv_B, float *dO,
-                               float *loss_part, float *gb_part, float *dz_workspace, float *dO_scales,
-                               int32_t rows_img, void *stream_);
 
 extern "C" int rk_decode_loss_dz_planes(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt,
                                         int32_t row_off, const float *b_de, int32_t loss_kind,
                                         float confidence, float inv_B, float *dO, float *loss_part,
                                         float *gb_part, float *dz_workspace, void *stream_) {
-  return decode_loss_dz_impl(pl, B, tgt, row_off, b_de, loss_kind, confidence, inv_B, dO, loss_part, gb_part,
-                             dz_workspace, nullptr, 0, stream_);
-}
-
-// ... with dLoss/dLogits leaving as a plane IMAGE (row m at byte m * ld * 4 of dO_img, rows
-// [B, round_up(B, 32)) zeros) cut with each 64 x 128 tile's own scale (dO_scales[(m / 64) *
-// ceil(n_cap / 128) + n / 128]): the operand of rk_pg_dw
-extern "C" int rk_decode_loss_dz_image(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt,
-                                       int32_t row_off, const float *b_de, int32_t loss_kind,
-                                       float confidence, float inv_B, void *dO_img, int32_t rows_img,
-                                       float *dO_scales, float *loss_part, float *gb_part,
-                                       float *dz_workspace, void *stream_) {
-  RK_REQUIRE(dO_scales != nullptr && rows_img >= ((B + 31) & ~31) && aligned16(dO_img),
-             "dO image: 16-byte aligned, round_up(B, 32) rows, a scale table");
-  return decode_loss_dz_impl(pl, B, tgt, row_off, b_de, loss_kind, confidence, inv_B, (float *)dO_img, loss_part,
-                             gb_part, dz_workspace, dO_scales, rows_img, stream_);
-}
-
-static int decode_loss_dz_impl(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off,
-                               const float *b_de, int32_t loss_kind, float confidence, float inv_B, float *dO,
-                               float *loss_part, float *gb_part, float *dz_workspace, float *dO_scales,
-                               int32_t rows_img, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(pl && B <= pl->B_cap && tgt->n_cap <= pl->n_cap, "planes were laid out for another shape");
   RK_REQUIRE(row_off >= 0 && row_off + B <= tgt->S_cap, "row slice out of range");
@@ -1161,7 +1099,6 @@ static int decode_loss_dz_impl(const rk_planes_t *pl, int32_t B, const rk_block_
   p.loss_part = loss_part; p.gb_part = gb_part;
   p.ld_dev = tgt->counts + 2;
   p.wtp = (const char *)pl->wt; p.dz_ws = dz_workspace; p.h = pl->h;
-  p.dscale = dO_scales; p.ds_pitch = rk_cdiv(tgt->n_cap, 128); p.rows_img = rows_img;
   const int BM = 64, BN = 128;
   const int grid = rk_cdiv(rk_cdiv(B, BM) * rk_cdiv(tgt->n_cap, BN), 8) * 8;
   const int lds = 256 * ROWB + 64 * 132 * 4;            // W^T stage | dO tile (the k-loop's stages fit below)
@@ -1216,7 +1153,7 @@ extern "C" int rk_decode_bwd_dz_planes(const float *dO, int32_t B, const rk_plan
   // resident workgroups per CU (C5, h = 512: 190 vs 282 us for 256-column tiles with one)
   int tn = h <= 64 ? 2 : (h <= 128 ? 4 : (h <= 224 ? 7 : 4));
   {
-    static const int tn_env = [] { const char *e = getenv("RK_DZ_TN"); return e ? atoi(e) : 0; }();   // (tuning)
+    const int tn_env = rk_tune_get(RK_TUNE_DZ_TN);   // (tuning)
     if (tn_env == 2 || tn_env == 4 || tn_env == 7 || tn_env == 8) tn = tn_env;
   }
   p.tiles_n = rk_cdiv(h, 32 * tn);

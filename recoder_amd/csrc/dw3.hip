@@ -529,7 +529,7 @@ static int dw_impl(const float *dO, const float *Z, int32_t B, int32_t h, const 
     p.z_scale_dev = sc;
   } else if (zt_planes == workspace && pairs) {
     // the pair planes AND their scale were made in place, at the head of this workspace, by an earlier
-    // launch (rk_split_wz_zt: the operand splits of the step's decode)
+    // launch (rk_split_wz: the operand splits of the step's decode)
     p.z_scale_dev = reinterpret_cast<float *>((char *)workspace + (int64_t)2 * Bp * cols_pad * 2);
   }
   RK_REQUIRE((((uintptr_t)zt_planes) & 15) == 0, "zt_planes must be 16-byte aligned");
@@ -615,8 +615,7 @@ extern "C" int rk_decode_bwd_dw2(const float *dO, const float *Z, int32_t B, int
 // rk_decode_bwd_dw2 (slabs stay in the workspace: G_de == NULL semantics) and rk_ae_encode_bwd (one
 // bitmap word per lane: the row window spans <= 64 words) in ONE launch -- see dw_encbwd_kernel
 extern "C" int32_t rk_dw_encode_bwd_fused_ok(int32_t row_off, int32_t B) {
-  static const int on = [] { const char *e = getenv("RK_DW_ENC_FUSED"); return (e && atoi(e) == 0) ? 0 : 1; }();
-  return on && rk_dw_pairs() && (((row_off + B + 31) >> 5) - (row_off >> 5) <= 64) ? 1 : 0;
+  return rk_tune_get(RK_TUNE_DW_ENC_FUSED) != 0 && rk_dw_pairs() && (((row_off + B + 31) >> 5) - (row_off >> 5) <= 64) ? 1 : 0;
 }
 
 extern "C" int rk_decode_bwd_dw2_encode_bwd(const float *dO, const float *Z, int32_t B, int32_t h,
@@ -661,13 +660,9 @@ extern "C" int rk_decode_bwd_dw2_encode_bwd_colsum(const float *dO, const float 
   return dw_impl(dO, Z, B, h, tgt, nullptr, gb_de, workspace, zt_planes, true, ranges, stream_, &enc);
 }
 
-// RK_DW_PREC=bf16x3 keeps dW on the bf16 triples (no operand range at all) in the training step
+// rk_tune(RK_TUNE_DW_BF16X3, 1) keeps dW on the bf16 triples (no operand range at all) in the training step
 extern "C" int32_t rk_dw_pairs(void) {
-  static const int v = [] {
-    const char *e = getenv("RK_DW_PREC");
-    return (e && e[0] == 'b') ? 0 : 1;
-  }();
-  return (v && !rk_gemm_plain_bf16()) ? 1 : 0;
+  return (rk_tune_get(RK_TUNE_DW_BF16X3) == 0 && !rk_gemm_plain_bf16()) ? 1 : 0;
 }
 
 extern "C" const float *rk_dw3_slabs(const void *workspace, int32_t B, int32_t h) {

@@ -304,7 +304,7 @@ extern "C" int rk_ae_encode_fwd(const rk_block_t *blk, int32_t row_off, int32_t 
 // rk_ae_encode_fwd with the W_de[items] half of the decode's operand split (rk_split_w: pl->w, pl->wt
 // and the W scale) as extra workgroups of the same launch -- what the one-call step does; here for
 // the steps sequenced entry by entry (hidden stacks: the split launch in front of their decode then
-// only cuts Z, rk_split_wz_zt with W_de == NULL)
+// only cuts Z, rk_split_wz with W_de == NULL)
 extern "C" int rk_ae_encode_fwd_split_w(const rk_block_t *blk, int32_t row_off, int32_t B,
                                         const float *W_en, const float *b_en, int32_t h,
                                         const uint8_t *keep, float p, uint64_t seed, uint64_t rng_step,

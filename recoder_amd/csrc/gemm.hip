@@ -984,8 +984,8 @@ inline int dw_splits(int B) {
 
 inline int dz_splits(int B) {
   const int tiles_m = rk_cdiv(B, 128);
-  static const int cap = [] { const char *e = getenv("RK_DZ_SPLITS"); const int v = e ? atoi(e) : 0;
-                              return (v >= 8 && v <= DZ_SPLITS) ? (v & ~7) : DZ_SPLITS; }();
+  const int v = rk_tune_get(RK_TUNE_DZ_SPLITS);
+  const int cap = (v >= 8 && v <= DZ_SPLITS) ? (v & ~7) : DZ_SPLITS;
   int s = (512 / tiles_m) & ~7;
   return s < 8 ? 8 : (s > cap ? cap : s);
 }
@@ -1193,17 +1193,6 @@ extern "C" int rk_decode_loss(const float *Z, int32_t B, int32_t h, const rk_blo
   return 0;
 }
 
-extern "C" int rk_mnll_finish(float *dO, int32_t B, const rk_block_t *tgt, int32_t row_off,
-                              float inv_B, float *loss_part, void *stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  if (B == 0) return 0;
-  RK_REQUIRE(tgt->implicit || tgt->pref_rc != nullptr, "explicit values need pref_rc");
-  RK_LAUNCH(mnll_finish_kernel, dim3(B), dim3(256), 0, stream, dO, *tgt, row_off, inv_B,
-            loss_part, (const float *)nullptr, (const float *)nullptr, (const float *)nullptr);
-  RK_CHECK_LAUNCH("mnll_finish");
-  return 0;
-}
-
 extern "C" int rk_mnll_row_stats(const float *logits, int32_t B, const rk_block_t *tgt, float *stats,
                                  void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -1213,16 +1202,18 @@ extern "C" int rk_mnll_row_stats(const float *logits, int32_t B, const rk_block_
   return 0;
 }
 
-extern "C" int rk_mnll_finish_ext(float *dO, int32_t B, const rk_block_t *tgt, int32_t row_off,
-                                  float inv_B, const float *row_max, const float *row_logsum,
-                                  const float *row_tsum, float *loss_part, void *stream_) {
+// row_max / row_logsum / row_tsum: all NULL (the block holds whole rows) or all given (item parallel)
+extern "C" int rk_mnll_finish(float *dO, int32_t B, const rk_block_t *tgt, int32_t row_off,
+                              float inv_B, const float *row_max, const float *row_logsum,
+                              const float *row_tsum, float *loss_part, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B == 0) return 0;
   RK_REQUIRE(tgt->implicit || tgt->pref_rc != nullptr, "explicit values need pref_rc");
-  RK_REQUIRE(row_max && row_logsum && row_tsum, "row statistics missing");
+  RK_REQUIRE((row_max && row_logsum && row_tsum) || (!row_max && !row_logsum && !row_tsum),
+             "row statistics: all three or none");
   RK_LAUNCH(mnll_finish_kernel, dim3(B), dim3(256), 0, stream, dO, *tgt, row_off, inv_B, loss_part,
             row_max, row_logsum, row_tsum);
-  RK_CHECK_LAUNCH("mnll_finish_ext");
+  RK_CHECK_LAUNCH("mnll_finish");
   return 0;
 }
 
@@ -1415,8 +1406,6 @@ static int linear_bwd_impl(float *dY, const float *Y, const float *X, const floa
                            float *dW, int32_t dw_accumulate, float *db, const float *dx_act_y, void *stream_,
                            bool pre = false);
 
-static int g_linear_pair = -1;     // -1: RK_LINEAR_PAIR not read yet
-extern "C" void rk_linear_pair(int32_t on) { g_linear_pair = on ? 1 : 0; }
 
 extern "C" int rk_linear_bwd(float *dY, const float *Y, const float *X, const float *W, int32_t B,
                              int32_t N, int32_t K, int32_t w_transposed, int32_t act, float *dX,
@@ -1448,7 +1437,7 @@ static int linear_bwd_impl(float *dY, const float *Y, const float *X, const floa
   if (B == 0) return 0;
   int rc = 0;
   const int ldw0 = w_transposed ? N : K;
-  if (g_linear_pair < 0) { const char *e = getenv("RK_LINEAR_PAIR"); g_linear_pair = (e && atoi(e) == 0) ? 0 : 1; }
+  const bool g_linear_pair = rk_tune_get(RK_TUNE_LINEAR_PAIR) != 0;
   // pre: dY already IS dYpre (its producer multiplied act' in) -- no pass over it; the bias gradient's
   // column sums ride on the dX / dW launch where that is one launch, else they are an rk_colsum
   const bool small0 = g_gemm_probe == nullptr && rk_small_gemm_fits(B, K, N) &&
@@ -1480,7 +1469,7 @@ static int linear_bwd_impl(float *dY, const float *Y, const float *X, const floa
     // both read dYpre only and write disjoint outputs: ONE launch of two workgroup ranges
     // (rk_small_gemm_pair: 7.2 us against 6.6 + 8.6 one behind the other at 500 x 200 x 200,
     // tools/probes/linear_bwd_probe.py 13.1 vs 17.7 us per call with the act' pass; C3 0.251 vs 0.264 ms
-    // per step).  RK_LINEAR_PAIR=0 / rk_linear_pair(0): two launches (same tiles, same sums)
+    // per step).  rk_tune(RK_TUNE_LINEAR_PAIR, 0): two launches (same tiles, same sums)
     if (cs_in_pair) return rk_small_gemm_pair_colsum(&gx, &gw, dY, B, N, db, stream_);
     if (dX && dW && g_linear_pair) return rk_small_gemm_pair(&gx, &gw, stream_);
     if (dX) { rc = rk_small_gemm(&gx, stream_); if (rc) return rc; }

@@ -324,7 +324,7 @@ int rk_small_gemm_pair_colsum(const rk_small_gemm_t *g1, const rk_small_gemm_t *
   const int t1 = rk_cdiv(g1->M, 32) * tn1, t2 = rk_cdiv(g2->M, 32) * tn2;
   const int va = (al16(g1->A) && g1->lda % 4 == 0 && g1->K % 4 == 0) ? 1 : 0;
   const int vb = (g1->bmode == 0 && al16(g1->B) && g1->ldb % 4 == 0 && g1->K % 4 == 0) ? 1 : 0;
-  static const int swap = [] { const char *e = getenv("RK_PAIR_ORDER"); return (e && atoi(e) == 1) ? 1 : 0; }();
+  const int swap = rk_tune_get(RK_TUNE_PAIR_ORDER) == 1;
   const int t1a = swap ? -t2 : t1;
   if (g1->bmode == 0)
     RK_LAUNCH((small_gemm_pair_kernel<0, 0>), dim3(t1 + t2 + n_cs), dim3(256), 0, stream, *g1, tn1, va, vb, t1a, *g2,

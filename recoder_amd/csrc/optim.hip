@@ -576,8 +576,7 @@ int rk_adam_multi_at(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part
 // default: +1.2 % throughput at C2, but the sweep then shares the chip with the encoder backward and
 // reads 0.52 of the HBM peak instead of 0.68 -- DESIGN.md section 4)
 extern "C" int32_t rk_adam_de_side(void) {
-  static const int on = [] { const char *e = getenv("RK_ADAM_DE_SIDE"); return (e && atoi(e) == 1) ? 1 : 0; }();
-  return on;
+  return rk_tune_get(RK_TUNE_ADAM_DE_SIDE) == 1;
 }
 
 extern "C" int rk_adam_multi(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part,

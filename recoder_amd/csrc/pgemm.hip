@@ -29,7 +29,7 @@ inline bool al16(const void *q) { return ((uintptr_t)q & 15) == 0; }
 // idle, a 256-row dW tile's 128 KB of LDS left the encoder backward of the same launch one workgroup
 // per CU: 0.290 vs 0.233 ms per step), and the live count only exists on the device.
 inline void decode_tile(int B, int n_cap, int &bm, int &bn) {
-  static const int force = [] { const char *e = getenv("RK_PG_TILE"); return e ? atoi(e) : 0; }();   // (tuning)
+  const int force = rk_tune_get(RK_TUNE_PG_TILE);   // (tuning)
   (void)n_cap;
   if (force == 256 || (force == 0 && B >= 1024)) { bm = 256; bn = 256; return; }
   if (force == 1282) { bm = 128; bn = 256; return; }

@@ -10,20 +10,13 @@
 #include "common.h"
 #include "planes.h"
 
-extern "C" void *rk_event_create(void) {
-  // ordering-only events between streams of ONE device: no timing, and no
+extern "C" void *rk_event_create(int32_t timing) {
+  // timing == 0: ordering-only events between streams of ONE device -- no timing, and no
   // system-scope fence (host / peer visibility is not needed for them)
   hipEvent_t e = nullptr;
-  if (hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
-    rk_set_error("hipEventCreate failed");
-    return nullptr;
-  }
-  return (void *)e;
-}
-
-extern "C" void *rk_timing_event_create(void) {
-  hipEvent_t e = nullptr;
-  if (hipEventCreate(&e) != hipSuccess) {
+  const hipError_t rc = timing ? hipEventCreate(&e)
+                               : hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence);
+  if (rc != hipSuccess) {
     rk_set_error("hipEventCreate failed");
     return nullptr;
   }
@@ -121,14 +114,13 @@ static int external_flag_ok() {
 
 extern "C" float rk_graph_event_node_probe(void);
 static int timing_route() {
+  if (external_flag_ok()) return 1;
+  if (rk_tune_get(RK_TUNE_GRAPH_EVENT_NODES) != 1) return 0;
   static const int route = [] {
-    if (external_flag_ok()) return 1;
-    // (opt-in, RK_GRAPH_EVENT_NODES=1: measured on the 7.0 runtime the bracketed group costs the same
+    // (opt-in, rk_tune(RK_TUNE_GRAPH_EVENT_NODES, 1): measured on the 7.0 runtime the bracketed group costs the same
     // replayed with event nodes as enqueued eagerly -- 0.1385-0.1403 vs 0.1367-0.1385 ms per step of a
     // 20-step run -- and its intervals read 1.5-5 us longer than rocprofv3's kernel durations, where
     // the eager brackets agree with them)
-    const char *e = getenv("RK_GRAPH_EVENT_NODES");
-    if (!(e && atoi(e) == 1)) return 0;
     return rk_graph_event_node_probe() > 0.f ? 2 : 0;
   }();
   return route;
@@ -230,8 +222,7 @@ inline void timer_record(hipEvent_t e, hipStream_t s) {
     rc = timing_route() == 2 ? capture_record_node(e, s) : hipEventRecordWithFlags(e, s, hipEventRecordExternal);
   else
     rc = hipEventRecord(e, s);
-  if (rc != hipSuccess && getenv("RK_DEBUG_TIMER"))
-    fprintf(stderr, "timer_record(%p, %p) capture=%d -> %s\n", (void *)e, (void *)s, (int)st, hipGetErrorString(rc));
+  (void)rc;
 }
 
 struct Timer {
@@ -332,7 +323,7 @@ static int step_item_parallel(const rk_ae_step_t *a, int phase) {
       if (a->ranges && !act_bounded(a->act)) RK_TRY(rk_amax(a->Z0, (int64_t)B * h, a->ranges, sm));
       RK_TRY(rk_decode_loss(a->Z0, B, h, blk, a->row_off, W_de, a->par[RK_PAR_B_DE].p, a->loss_kind,
                             a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, a->ranges, sm));
-      if (mnll) RK_TRY(rk_mnll_finish(a->dO, B, blk, a->row_off, a->inv_B, a->loss_part, sm));
+      if (mnll) RK_TRY(rk_mnll_finish(a->dO, B, blk, a->row_off, a->inv_B, nullptr, nullptr, nullptr, a->loss_part, sm));
     }
     // act'(Z0) is applied to this rank's PARTIAL dZ0 here, inside the split-K reduce: Z0 is the
     // same on every rank, so sum_ranks(dZ0_r) * act'(Z0) = sum_ranks(dZ0_r * act'(Z0)) and the
@@ -385,10 +376,8 @@ static int step_item_parallel(const rk_ae_step_t *a, int phase) {
 // Does this (whole, single-process) step run its contractions on the pipelined pair-plane kernels
 // (csrc/pgemm.h)?  Untied MSE / BCE steps with operand planes and a scale table, outside the fused
 // decode + dZ launch's domain (h > 256 or >= 1024 rows).
-// Inside the fused decode's domain the decode + dZ launch stays and hands dLoss/dLogits over as an image
-// too (rk_decode_loss_dz_image): dW then runs on rk_pg_dw there as well.
-// Returns 0: neither; 1: all three contractions on csrc/pgemm.h; 2: the fused decode + dZ launch with the
-// image, dW on rk_pg_dw
+// Returns 0: neither; 1: all three contractions on csrc/pgemm.h; 3: the register-resident fused decode
+// (csrc/fdecode.hip) with its image, dW on rk_pg_dw
 static int step_pg_mode(const rk_ae_step_t *a) {
   const int phase = a->phase == 0 ? RK_STEP_ALL : a->phase;
   if (phase != RK_STEP_ALL || a->tied || a->loss_kind == RK_LOSS_MNLL) return 0;
@@ -399,10 +388,9 @@ static int step_pg_mode(const rk_ae_step_t *a) {
   // column sums -- when the dW / encoder-backward launch can be the fused one (a->ws_dw, the row window)
   if (a->ws_dw != nullptr && rk_fdec_ok(a->B, a->h, a->blk->n_cap, a->loss_kind) &&
       rk_dw_encode_bwd_fused_ok(a->row_off, a->B)) return 3;
-  // (opt-in, RK_PG_IMG=1 -- measured at C2: the image pass costs the fused decode launch 6 us (34.0 vs
-  // 28.0) and dW || encoder backward on rk_pg_dw gains 0.8 (23.5 vs 24.3): 0.1222 vs 0.1188 ms per step)
-  static const int img_on = [] { const char *e = getenv("RK_PG_IMG"); return (e && atoi(e) == 1) ? 1 : 0; }();
-  return img_on ? 2 : 0;
+  // (a third form -- the LDS-staged fused decode of decode16.hip writing the image as well -- was measured
+  // and dropped: at C2 the image pass cost that launch 6 us and rk_pg_dw gained 0.8: 0.1222 vs 0.1188 ms)
+  return 0;
 }
 extern "C" int32_t rk_ae_step_uses_pg(const rk_ae_step_t *a) { return (a && a->blk) ? step_pg_mode(a) : 0; }
 
@@ -457,7 +445,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   // the three contractions on the pipelined pair-plane kernels (csrc/pgemm.h; include/recoder_hip.h
   // rk_ae_step_t.do_scales): whole untied MSE / BCE steps outside the fused decode's domain
   const int pg_mode = step_pg_mode(a);
-  const bool pg = pg_mode == 1, img = pg_mode == 2, fdec = pg_mode == 3;
+  const bool pg = pg_mode == 1, fdec = pg_mode == 3;
   const float *dw_slabs_pg = dw_branch ? a->ws_dw : a->ws;
   // opt-in (rk_adam_de_side): the decoder table's Adam sweep right behind the dW kernel ON dw_stream,
   // next to the reduce / encoder backward; the update on the chain then covers the rest
@@ -476,7 +464,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
                    "planes were laid out for another shape");
         RK_TRY(rk_ae_encode_fwd_at(blk, a->row_off, B, a->par[RK_PAR_W_EN].p, a->par[RK_PAR_B_EN].p, h,
                                    a->keep, a->noise_p, a->seed, a->cursor, a->cursor_off, a->users,
-                                   a->act, a->Z0, (planes && !pg && !img && !fdec) ? a->zt_planes : nullptr, sm, &es,
+                                   a->act, a->Z0, (planes && !pg && !fdec) ? a->zt_planes : nullptr, sm, &es,
                                    a->rng_step));
       } else if (a->cursor)
         RK_TRY(rk_ae_encode_fwd_at(blk, a->row_off, B, a->par[RK_PAR_W_EN].p, a->par[RK_PAR_B_EN].p, h,
@@ -499,10 +487,6 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
         if (dz_fused && fdec)
           RK_TRY(rk_fdec_loss_dz(a->planes, B, blk, a->row_off, a->par[RK_PAR_B_DE].p, a->loss_kind, a->confidence,
                                  a->inv_B, a->dO, a->do_rows, a->do_scales, a->loss_part, a->ws, sm));
-        else if (dz_fused && img)
-          RK_TRY(rk_decode_loss_dz_image(a->planes, B, blk, a->row_off, a->par[RK_PAR_B_DE].p, a->loss_kind,
-                                         a->confidence, a->inv_B, a->dO, a->do_rows, a->do_scales, a->loss_part,
-                                         a->gb_part, a->ws, sm));
         else if (dz_fused)
           RK_TRY(rk_decode_loss_dz_planes(a->planes, B, blk, a->row_off, a->par[RK_PAR_B_DE].p, a->loss_kind,
                                           a->confidence, a->inv_B, a->dO, a->loss_part, a->gb_part, a->ws, sm));
@@ -517,7 +501,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
         RK_TRY(rk_decode_loss(a->Z0, B, h, blk, a->row_off, W_de, a->par[RK_PAR_B_DE].p, a->loss_kind,
                               a->confidence, a->inv_B, a->dO, 0, a->loss_part, a->gb_part, a->ranges, sm));
       }
-      if (mnll) RK_TRY(rk_mnll_finish(a->dO, B, blk, a->row_off, a->inv_B, a->loss_part, sm));
+      if (mnll) RK_TRY(rk_mnll_finish(a->dO, B, blk, a->row_off, a->inv_B, nullptr, nullptr, nullptr, a->loss_part, sm));
     }
     // dO and the Z^T planes are ready: the dW branch starts here -- and so does whatever else the
     // caller queues behind this event (graph.GraphStepper: the look-ahead collation, which must not
@@ -558,9 +542,6 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       if (fdec)
         RK_TRY(rk_pg_dw_encode_bwd(a->dO, a->do_scales, 32, 64, B, a->planes, blk, dw_branch ? a->ws_dw : a->ws,
                                    a->row_off, a->dZ0, G_en, a->gb_en, a->gb_de, sm));
-      else if (img)
-        RK_TRY(rk_pg_dw_encode_bwd(a->dO, a->do_scales, 64, 128, B, a->planes, blk, dw_branch ? a->ws_dw : a->ws,
-                                   a->row_off, a->dZ0, G_en, a->gb_en, nullptr, sm));
       else
       RK_TRY(rk_decode_bwd_dw2_encode_bwd(a->dO, a->Z0, B, h, blk, dw_branch ? a->ws_dw : a->ws,
                                           planes ? a->zt_planes : nullptr, a->ranges, a->row_off, a->dZ0,
@@ -574,7 +555,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       RK_TRY(rk_stream_wait_event(a->dw_stream, a->dw_fork));
       {
         Timer t(a, RK_ENTRY_DECODE_BWD_DW, a->dw_stream);
-        if (pg || img) RK_TRY(rk_pg_dw(a->dO, a->do_scales, 64, pg ? 32 : 128, B, a->planes, blk, a->ws_dw, a->dw_stream));
+        if (pg) RK_TRY(rk_pg_dw(a->dO, a->do_scales, 64, 32, B, a->planes, blk, a->ws_dw, a->dw_stream));
         else RK_TRY(dw_call(a, nullptr, nullptr, planes, a->ws_dw, a->dw_stream));
       }
       if (!de_side) {
@@ -586,7 +567,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       // its own K slabs, which rk_adam_multi sums while it reads the gradient)
       {
         Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
-        if (pg || img) RK_TRY(rk_pg_dw(a->dO, a->do_scales, 64, pg ? 32 : 128, B, a->planes, blk, a->ws, sm));
+        if (pg) RK_TRY(rk_pg_dw(a->dO, a->do_scales, 64, 32, B, a->planes, blk, a->ws, sm));
         else RK_TRY(dw_call(a, nullptr, nullptr, planes));
       }
       Timer t(a, RK_ENTRY_ENCODE_BWD, sm);
@@ -610,7 +591,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     if (!a->tied) {
       jobs[n] = table_job(a->par[RK_PAR_W_DE], blk, n_items, h, a->G_de, true);
       if (a->ranges) jobs[n].amax_out = a->ranges + 64;
-      if (pg || img || fdec) {
+      if (pg || fdec) {
         jobs[n].g = dw_slabs_pg; jobs[n].g_parts = rk_pg_dw_splits(B, h, blk->n_cap);
         jobs[n].g_stride = blk->n_cap * h; jobs[n].gparts_dev = blk->counts + 4;
       } else if (dw3) {

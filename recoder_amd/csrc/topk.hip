@@ -193,10 +193,10 @@ extern "C" int rk_topk_pairs(const float *val, const int32_t *idx, const int32_t
 
 extern "C" int32_t rk_topk_pairs_max_cap(void) { return PAIRS_CAP; }
 
-extern "C" int rk_topk_masked_strided(const float *scores, int32_t B, int32_t n, int32_t ld,
-                                      const rk_block_t *seen, int32_t row_off, int32_t k,
-                                      int32_t col_off, int32_t col_stride, int64_t *out_idx,
-                                      float *out_val, int32_t out_ld, void *stream_) {
+extern "C" int rk_topk_masked(const float *scores, int32_t B, int32_t n, int32_t ld,
+                              const rk_block_t *seen, int32_t row_off, int32_t k,
+                              int32_t col_off, int32_t col_stride, int64_t *out_idx,
+                              float *out_val, int32_t out_ld, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(k >= 1 && k <= KMAX, "k must be in [1, 1024]");
   RK_REQUIRE(k <= n, "k larger than the number of score columns");
@@ -209,20 +209,6 @@ extern "C" int rk_topk_masked_strided(const float *scores, int32_t B, int32_t n,
                      col_stride);
   RK_CHECK_LAUNCH("topk_masked");
   return 0;
-}
-
-extern "C" int rk_topk_masked_strip(const float *scores, int32_t B, int32_t n, int32_t ld,
-                                    const rk_block_t *seen, int32_t row_off, int32_t k,
-                                    int32_t col_off, int64_t *out_idx, float *out_val,
-                                    int32_t out_ld, void *stream_) {
-  return rk_topk_masked_strided(scores, B, n, ld, seen, row_off, k, col_off, 1, out_idx, out_val, out_ld,
-                                stream_);
-}
-
-extern "C" int rk_topk_masked(const float *scores, int32_t B, int32_t n, int32_t ld,
-                              const rk_block_t *seen, int32_t row_off, int32_t k,
-                              int64_t *out_idx, float *out_val, void *stream_) {
-  return rk_topk_masked_strip(scores, B, n, ld, seen, row_off, k, 0, out_idx, out_val, k, stream_);
 }
 
 extern "C" int32_t rk_topk_max_k(void) { return KMAX; }

@@ -46,14 +46,10 @@ class TimedLib:
 
   def __getattr__(self, name):
     fn = getattr(self._lib, name)
-    if not name.startswith("rk_") or name in ("rk_dz_workspace_bytes", "rk_dz_fused_workspace_bytes", "rk_decode_dz_fused_ok",
-                                              "rk_dw_encode_bwd_fused_ok", "rk_dw_workspace_bytes", "rk_dw_splits", "rk_encode_bwd_segments", "rk_loss_partials", "rk_decode_row_tile",
-                                              "rk_dw3_workspace_bytes", "rk_dw3_max_splits", "rk_dw3_slabs", "rk_gemm_split16", "rk_dw_pairs",
-                                              "rk_dw3_planes_bytes", "rk_dw3_rows_pad", "rk_dw3_cols_pad",
-                                              "rk_planes_bytes", "rk_planes_layout", "rk_split_zt_ok",
-                                              "rk_pg_enabled", "rk_pg_scale_floats", "rk_pg_decode_granule", "rk_gemm_plain_bf16",
-                                              "rk_pg_dz_workspace_bytes", "rk_pg_dw_workspace_bytes", "rk_pg_dw_splits", "rk_pg_mnll_workspace_floats",
-                                              "rk_last_error", "rk_version"):
+    # (sizing accessors -- plain Python over rk_plan -- and host-only calls are not launches)
+    if not name.startswith("rk_") or not hasattr(fn, "argtypes") or name in (
+        "rk_plan", "rk_encode_bwd_segments", "rk_dw3_slabs", "rk_planes_layout", "rk_last_error", "rk_version",
+        "rk_ae_step_uses_pg"):
       return fn
 
     def call(*args):
@@ -116,7 +112,7 @@ class FusedEngine:
     self._cstep = None
     self._c_calls = 0
     # dW on a stream of its own next to the dZ -> encoder-backward chain; RK_DW_BRANCH=0: in line
-    self.dw_branch = os.environ.get("RK_DW_BRANCH", "1") != "0"
+    self.dw_branch = True
     self._dw_objs = None
     # operand ranges of the split-fp16 decoder contractions (include/recoder_hip.h rk_amax):
     # [0..63] max |Z| (filled per call when the activation is unbounded), [64..127] an upper bound
@@ -195,7 +191,7 @@ class FusedEngine:
     # pre-split operand planes of the decoder contractions (csrc/planes.h); RK_PLANES=0: the
     # in-loop split of round 2
     self.planes = None
-    if self.split16 and os.environ.get("RK_PLANES", "1") != "0":
+    if self.split16:
       from ._lib import RkPlanes
       self.planes_buf = torch.zeros(self.lib.rk_planes_bytes(B_cap, h0, n_cap) // 4 + 64, **f)
       self.planes = RkPlanes()
@@ -465,7 +461,7 @@ class FusedEngine:
     # (the multinomial loss as TWO decode passes pays where a pass is flop-bound, not at B = 500: C3,
     # n_b = 8.4 k -- 25.6 + 5.2 + 27.5 us for statistics / merge / loss passes against 19.7 + 18.9 us for
     # the decode that writes the logits + rk_mnll_finish; RK_PG_MNLL=1 forces it)
-    if self.loss_id == LOSS_MNLL and B < 1024 and os.environ.get("RK_PG_MNLL") != "1":
+    if self.loss_id == LOSS_MNLL and B < 1024:
       return False
     return (self.planes is not None and self.split16 and bool(lib.rk_pg_enabled()) and
             not lib.rk_gemm_plain_bf16() and self.item_parallel is None and
@@ -500,7 +496,7 @@ class FusedEngine:
       # in its own workspace in between
       h0 = self.h[0]
       rg = self._ranges(z, B * h0, stream)
-      check(lib.rk_split_wz_zt(None if w_done else ptr(W), ptr(z), B, h0, tgt.ref, rg, ctypes.byref(self.planes),
+      check(lib.rk_split_wz(None if w_done else ptr(W), ptr(z), B, h0, tgt.ref, rg, ctypes.byref(self.planes),
                                ptr(zt_ws), stream), "rk_split_wz")
       self._zt_ready = None if zt_ws is None else zt_ws.data_ptr()
       check(lib.rk_decode_loss_dz_planes(ctypes.byref(self.planes), B, tgt.ref, row_off, ptr(b), self.loss_id,
@@ -508,14 +504,14 @@ class FusedEngine:
                                          ptr(self.gb_part), ptr(self.ws), stream), "rk_decode_loss_dz_planes")
       self._dz_in_ws = True
     elif fuse_dz and pg_ok and ip is None and self._pg_entry_ok(B, tgt.n_cap) and \
-        os.environ.get("RK_ENTRY_PLANES", "1") != "0":
+        True:
       # outside the fused launch's domain: decode + loss, dZ and dW on the pipelined pair-plane kernels --
       # ONE split launch (W image unless the encoder forward cut it, Z image; no W^T image, no Z^T planes),
       # dLoss/dLogits as a plane image; the multinomial loss as a statistics pass + the decode / loss pass
       # (no logits matrix, no rk_mnll_finish)
       h0 = self.h[0]
       rg = self._ranges(z, B * h0, stream)
-      check(lib.rk_split_wz_zt(None if w_done else ptr(W), ptr(z), B, h0, tgt.ref, rg,
+      check(lib.rk_split_wz(None if w_done else ptr(W), ptr(z), B, h0, tgt.ref, rg,
                                ctypes.byref(self.planes_nowt), None, stream), "rk_split_wz")
       if self.loss_id == LOSS_MNLL:
         check(lib.rk_pg_decode_mnll(ctypes.byref(self.planes), B, tgt.ref, row_off, ptr(b), inv_B,
@@ -527,13 +523,13 @@ class FusedEngine:
                                     None, ptr(self.loss_part), ptr(self.gb_part), stream), "rk_pg_decode_loss")
       self._dz_pg = True
     elif fuse_dz and ip is None and self.planes is not None and self.split16 and self.item_parallel is None \
-        and os.environ.get("RK_ENTRY_PLANES", "1") != "0":
+        and True:
       # outside the fused launch's domain (multinomial loss, h > 256, >= 1024 rows): still the plane
       # kernels -- ONE split launch, then the copy -> LDS -> MFMA decode; the dZ product follows on the
       # W^T image (rk_decode_bwd_dz_planes) where rk_decode_bwd_dz would split W_de in its k-loop again
       h0 = self.h[0]
       rg = self._ranges(z, B * h0, stream)
-      check(lib.rk_split_wz_zt(None if w_done else ptr(W), ptr(z), B, h0, tgt.ref, rg, ctypes.byref(self.planes),
+      check(lib.rk_split_wz(None if w_done else ptr(W), ptr(z), B, h0, tgt.ref, rg, ctypes.byref(self.planes),
                                ptr(zt_ws), stream), "rk_split_wz")
       self._zt_ready = None if zt_ws is None else zt_ws.data_ptr()
       check(lib.rk_decode_loss_planes(ctypes.byref(self.planes), B, tgt.ref, row_off, ptr(b), self.loss_id,
@@ -554,13 +550,13 @@ class FusedEngine:
       glog = torch.log((st[..., 1] * torch.exp(st[..., 0] - gmax)).sum(dim=0))
       tsum = ip.user_tsum_dev[tgt.users[row_off:row_off + B]].contiguous()
       gmax, glog = gmax.contiguous(), glog.contiguous()
-      check(lib.rk_mnll_finish_ext(ptr(self.dO), B, tgt.ref, row_off, inv_B, ptr(gmax), ptr(glog),
-                                   ptr(tsum), ptr(self.loss_part), stream), "rk_mnll_finish_ext")
+      check(lib.rk_mnll_finish(ptr(self.dO), B, tgt.ref, row_off, inv_B, ptr(gmax), ptr(glog),
+                               ptr(tsum), ptr(self.loss_part), stream), "rk_mnll_finish")
       n_part = B
     elif self.loss_id == LOSS_MNLL and self._dz_pg:
       n_part = self.lib.rk_loss_partials(B, tgt.n_cap)     # (one partial per tile, as mse / logistic)
     elif self.loss_id == LOSS_MNLL:
-      check(lib.rk_mnll_finish(ptr(self.dO), B, tgt.ref, row_off, inv_B, ptr(self.loss_part),
+      check(lib.rk_mnll_finish(ptr(self.dO), B, tgt.ref, row_off, inv_B, None, None, None, ptr(self.loss_part),
                                stream), "rk_mnll_finish")
       n_part = B
     else:
@@ -647,9 +643,9 @@ class FusedEngine:
       self._w_split_of = None
       self._split_w_with_fwd = (tgt is None and ip is None and self.planes is not None and self.split16 and
                                 self.item_parallel is None and not bool(m.is_constrained) and
-                                os.environ.get("RK_ENTRY_DZ_FUSED", "1") != "0" and
-                                os.environ.get("RK_ENTRY_PLANES", "1") != "0" and
-                                os.environ.get("RK_ENTRY_W_SPLIT_FWD", "1") != "0")
+                                True and
+                                True and
+                                True)
       self._split_nowt = bool(self._split_w_with_fwd and self._pg_entry_ok(B, blk.n_cap) and
                               self.allreduce is None)
       z = self._ae_forward(blk, row_off, B, keep_noise, keep_drop, True, stream)
@@ -667,9 +663,9 @@ class FusedEngine:
     lazy = ip is None and self.allreduce is None
     # (dW will work in ws_dw with its K slabs kept for the Adam sweep: see keep_slabs below)
     zt_ws = self.ws_dw if (lazy and not tied and self.split16 and self.ws_dw is not None and
-                           os.environ.get("RK_ENTRY_ZT_SPLIT", "1") != "0") else None
+                           True) else None
     loss = self._loss(z, B, tb, row_off, rows, stream, out, ip=ip, defer=lazy,
-                      fuse_dz=os.environ.get("RK_ENTRY_DZ_FUSED", "1") != "0", zt_ws=zt_ws,
+                      fuse_dz=True, zt_ws=zt_ws,
                       pg_ok=lazy and not tied and self.ws_dw is not None)
     self._loss_target = loss
 
@@ -682,7 +678,7 @@ class FusedEngine:
     # (off by default: with a dozen more launches on the chain the two cross-queue edges cost more
     # than the overlap buys -- C3 0.307 vs 0.300 ms, C4 0.150 vs 0.147 ms per step; RK_DW_BRANCH_ENTRY=1)
     dw_side = rp.get("dw_stream") if (rp is not None and keep_slabs and self.dw_branch and
-                                      os.environ.get("RK_DW_BRANCH_ENTRY") == "1") else None
+                                      False) else None
     dw_stream = stream
     if dw_side is not None:
       if getattr(self, "_dw_ev", None) is None:
@@ -694,7 +690,7 @@ class FusedEngine:
     # (rk_decode_bwd_dw2_encode_bwd: one launch less on the chain) when both work on ONE block, the K
     # slabs stay in the dW workspace for the Adam sweep and no side stream is in play
     defer_dw = (keep_slabs and dw_side is None and self.kind == "ae" and tb is blk and
-                os.environ.get("RK_ENTRY_DW_ENC_FUSED", "1") != "0" and
+                True and
                 bool(lib.rk_dw_encode_bwd_fused_ok(row_off, B)))
     self._dw_deferred = None
     self._dw_colsum = False
@@ -723,7 +719,7 @@ class FusedEngine:
       # gradient), so the reduce of the decode launch's dZ partials rides on the dW launch
       red = None
       if (self.kind != "ae" and getattr(self, "_dz_in_ws", False) and keep_slabs and dw_side is None and
-          ip is None and self.lib.rk_dw_pairs() and os.environ.get("RK_ENTRY_DW_REDUCE", "1") != "0"):
+          ip is None and self.lib.rk_dw_pairs() and True):
         red = (self.ws, None if self.drop_active else self.enc[0], self.dbott)
       self._dw(z, B, tb, None, dw_stream, keep_slabs, red=red)
       if red is not None:
@@ -749,7 +745,7 @@ class FusedEngine:
     # layer's dX epilogue for its input activation -- so a layer's backward is ONE launch (dX, dW and
     # the bias gradient's column sums: rk_linear_bwd_pre) instead of an act' pass + the products
     stack_pre = (self.kind == "ae" and self.nl > 0 and not self.drop_active and ip is None and
-                 os.environ.get("RK_ENTRY_STACK_PRE", "1") != "0")
+                 True)
     zact = self.enc[0] if fuse_act else (self.dec[self.nl - 1] if stack_pre else None)
     if getattr(self, "_dz_done", False):
       self._dz_done = False            # (summed by the dW launch: rk_decode_bwd_dw2_dz_reduce)
@@ -938,7 +934,7 @@ class FusedEngine:
                                 ptr(ws), stream), "rk_pg_dw")
         self._pg_step = True
       elif self.lib.rk_dw_pairs():
-        # (Z^T pair planes already at the head of this workspace: rk_split_wz_zt of this step's decode)
+        # (Z^T pair planes already at the head of this workspace: rk_split_wz of this step's decode)
         zt = ptr(ws) if getattr(self, "_zt_ready", None) == ws.data_ptr() else None
         if red is not None:
           # red = (the decode launch's dZ partials, Zact or None, dZ): summed by extra workgroups here
@@ -1042,7 +1038,7 @@ class FusedEngine:
     if dw3 and self.ws_dw is not None:
       if self._dw_objs is None:
         raw0 = _lib.load()
-        self._dw_objs = (torch.cuda.Stream(device=self.device), raw0.rk_event_create(), raw0.rk_event_create())
+        self._dw_objs = (torch.cuda.Stream(device=self.device), raw0.rk_event_create(0), raw0.rk_event_create(0))
       # (the graph stepper lends its side stream: dW and its collation share one branch)
       dws = replay.get("dw_stream") if replay is not None else None
       st.ws_dw, st.dw_stream = ptr(self.ws_dw), (dws or self._dw_objs[0]).cuda_stream
@@ -1150,13 +1146,13 @@ class FusedEngine:
     pool = getattr(self, "_event_pool", None)
     if pool:
       return pool.pop()
-    return raw.rk_timing_event_create()
+    return raw.rk_event_create(1)
 
   def reserve_timing_events(self, n):
     raw = _lib.load()
     pool = self.__dict__.setdefault("_event_pool", [])
     while len(pool) < n:
-      pool.append(raw.rk_timing_event_create())
+      pool.append(raw.rk_event_create(1))
 
   def decoder_bias_grad(self, n_b):
     """gb_de[:n_b] of the last training step (tests).  The one-call step consumes the
@@ -1206,7 +1202,7 @@ class FusedEngine:
     raw = _lib.load()
     hip = ctypes.CDLL("libamdhip64.so")
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    pairs = [(raw.rk_timing_event_create(), raw.rk_timing_event_create()) for _ in range(n)]
+    pairs = [(raw.rk_event_create(1), raw.rk_event_create(1)) for _ in range(n)]
     torch.cuda.synchronize()
     for e0, e1 in pairs:
       hip.hipEventRecord(ctypes.c_void_p(e0), st)
@@ -1446,8 +1442,8 @@ class FusedEngine:
     check(lib.rk_decode_loss_planes(ctypes.byref(pl), B, sblk.ref, 0, ptr(b), LOSS_NONE, 0.0, 1.0,
                                     ptr(ws["scores"]), ld, None, None, stream), "rk_decode_loss_planes")
     stride_ = ev["key"][3]
-    check(lib.rk_topk_masked_strided(ptr(ws["scores"]), B, m, ld, blk.ref, 0, k, 0, stride_,
-                                     ptr(ws["s_idx"]), ptr(ws["s_val"]), k, stream), "rk_topk_masked_strided")
+    check(lib.rk_topk_masked(ptr(ws["scores"]), B, m, ld, blk.ref, 0, k, 0, stride_,
+                                     ptr(ws["s_idx"]), ptr(ws["s_val"]), k, stream), "rk_topk_masked")
     ws["thr"][:B].copy_(ws["s_val"][:B, k - 1])
     # 2. the whole catalogue with the filter in the decode's epilogue
     ws["c_cnt"].zero_()

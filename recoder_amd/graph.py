@@ -38,7 +38,7 @@ class GraphStepper:
     self.lib = _lib.load()
     self.eng, self.dcsr, self.B, self.ns, self.G = engine, dcsr, int(B), bool(negative_sampling), int(group)
     self.device = device
-    self.multi = os.environ.get("RK_COLLATE_MULTI", "1") != "0"    # batched collation launches
+    self.multi = True    # batched collation launches
     # data parallel over users (parallel.DataParallel attached to the engine): every block's item
     # set is the union over the ranks -- the MAX all-reduce of the blocks' stamp arrays sits between
     # the two collation phases, captured with them -- and the step's two gradient exchanges are
@@ -68,11 +68,11 @@ class GraphStepper:
     # stream capture needs a stream of its own (not the default stream torch work runs on)
     self.main = torch.cuda.Stream(device=device)
     self.side = torch.cuda.Stream(device=device)
-    self.ev_fork, self.ev_join = self.lib.rk_event_create(), self.lib.rk_event_create()
+    self.ev_fork, self.ev_join = self.lib.rk_event_create(0), self.lib.rk_event_create(0)
     # the group right behind a cut (epoch start, step mark) has no look-ahead blocks: its G
     # collations are independent chains of small launches, run side by side on streams of their own
     self.pre = [torch.cuda.Stream(device=device) for _ in range(self.G - 1)]
-    self.ev_pre = [self.lib.rk_event_create() for _ in range(self.G - 1)]
+    self.ev_pre = [self.lib.rk_event_create(0) for _ in range(self.G - 1)]
     self.st = [[RkAeStep() for _ in range(self.G)] for _ in range(2)]
     self._gen = None                       # engine.alloc_gen the graphs were captured under
     self.recaptures = 0
@@ -136,12 +136,12 @@ class GraphStepper:
     args = (ptr(d.indptr), ptr(d.indices), ptr(d.data), ptr(self.order), self.B, 1 if self.ns else 0,
             self._cur(slot), off0, arr, n)
     if self.dp is None:
-      check(self.lib.rk_collate_at_multi(*args, self._h(stream)), "rk_collate_at_multi")
+      check(self.lib.rk_collate_at_multi(*args, 0, self._h(stream)), "rk_collate_at_multi")
       return
-    check(self.lib.rk_collate_at_multi_phase(*args, 1, self._h(stream)), "rk_collate_at_multi_phase")
+    check(self.lib.rk_collate_at_multi(*args, 1, self._h(stream)), "rk_collate_at_multi")
     with torch.cuda.stream(stream):
       self.dp.union_marks_many([blk.mark for blk in blks])
-    check(self.lib.rk_collate_at_multi_phase(*args, 2, self._h(stream)), "rk_collate_at_multi_phase")
+    check(self.lib.rk_collate_at_multi(*args, 2, self._h(stream)), "rk_collate_at_multi")
 
   def _step(self, slot, g, index=None, advance=None):
     """Enqueue the training step of block [slot][g] (cursor offset g) on the main stream; index
@@ -339,7 +339,7 @@ class GraphStepper:
     with or without the look-ahead collation (without: run() ends with that group).  bench.py calls
     this in front of its timed region; run() then replays it instead of enqueueing the bracketed
     group eagerly."""
-    if not self.warmed or os.environ.get("RK_TIMED_GRAPH", "1") == "0" or \
+    if not self.warmed or False or \
         not self.lib.rk_graph_timing_supported():
       return False
     from ._lib import ENTRY

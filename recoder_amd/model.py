@@ -70,7 +70,7 @@ class Recoder(object):
     self.user_order_hook = None
     self.mask_hook = None
     # steps collated per side-stream hand-over (CollatePrefetcher)
-    self.prefetch_group = int(os.environ.get("RK_PREFETCH_GROUP", "4"))
+    self.prefetch_group = 4
     # steps per replayed HIP graph (graph.py)
     self.graph_group = int(os.environ.get("RK_GRAPH_GROUP", "4"))
     # {global step index: callable}: called right before that step's collation is submitted and
@@ -798,8 +798,6 @@ class Recoder(object):
     eng = self._engine()
     if getattr(eng, "generic", False):
       return False
-    if not eng.c_step_eligible() and os.environ.get("RK_GRAPH_ENTRY", "1") == "0":
-      return False                       # (entry-by-entry sequenced steps: replayed too by default)
     if getattr(self, "_ip", None) is not None:
       return False
     dp = getattr(self, "_dp", None)
@@ -808,8 +806,7 @@ class Recoder(object):
       # the step is the one-call autoencoder step; injected collectives (virtual ranks in tests),
       # torch.distributed / gloo and the entry-by-entry engines keep the eager sequencing
       if not (dp.direct and not dp.virtual and eng.c_step_eligible() and
-              os.environ.get("RK_GRAPH_DP", "1") != "0" and self.graph_group <= 8 and
-              os.environ.get("RK_COLLATE_MULTI", "1") != "0"):
+              self.graph_group <= 8):
         return False
     ds = dataloader.dataset
     return (self.mask_hook is None and dataloader.num_sampling_users == dataloader.batch_size and
@@ -998,7 +995,7 @@ class Recoder(object):
 
   # items decoded at a time by recommend(): [B, strip] fp32 scores stay cache-resident
   # (B = 500: 128 MB) instead of a [B, n_items] matrix in HBM (2 GB at C5's 1 M items)
-  eval_strip_items = int(os.environ.get("RK_EVAL_STRIP", "65536"))
+  eval_strip_items = 65536
 
   def recommend(self, users_interactions, num_recommendations):
     """model.py:525-544: scores with the seen (positive) items at -inf, top-k sorted; a list of
@@ -1011,7 +1008,7 @@ class Recoder(object):
 
     The fused engines never materialise the [B, n_items] score matrix: the catalogue is decoded
     in strips of ``eval_strip_items`` items, each strip's masked top k is kept
-    (``rk_topk_masked_strip``) and the per-strip winners are merged with one more top-k pass --
+    (``rk_topk_masked`` with a column offset) and the per-strip winners are merged with one more top-k pass --
     ties resolve to the lower item id at both levels, as torch.topk on the full row would."""
     self.model.eval()
     self._check_ranges()
@@ -1064,16 +1061,16 @@ class Recoder(object):
           ws["strips"].clear()
         ws["strips"][key] = sblk
       engine.decode_scores(z, B, sblk, scores, ld)
-      _lib.check(lib.rk_topk_masked_strip(scores.data_ptr(), B, hi - lo, ld, blk.ref, 0, k, lo,
+      _lib.check(lib.rk_topk_masked(scores.data_ptr(), B, hi - lo, ld, blk.ref, 0, k, lo, 1,
                                           cand_idx[:, s * k:].data_ptr(), cand_val[:, s * k:].data_ptr(),
-                                          ns * k, current_stream()), "rk_topk_masked_strip")
+                                          ns * k, current_stream()), "rk_topk_masked")
     if ns == 1:
       return cand_idx[:, :k].cpu().numpy().copy()
     # merge: top k of the ns * k candidates (positions), then their item ids.  Candidates are laid
     # out strip by strip, each sorted by (score desc, id asc): equal scores keep ascending ids
     pos = torch.empty(B, k, dtype=torch.int64, device=self.device)
-    _lib.check(lib.rk_topk_masked(cand_val.data_ptr(), B, ns * k, ns * k, None, 0, k, pos.data_ptr(),
-                                  None, current_stream()), "rk_topk_masked")
+    _lib.check(lib.rk_topk_masked(cand_val.data_ptr(), B, ns * k, ns * k, None, 0, k, 0, 1, pos.data_ptr(),
+                                  None, k, current_stream()), "rk_topk_masked")
     return torch.gather(cand_idx, 1, pos).cpu().numpy()
 
   def _recommend_dense(self, users_interactions, k):

@@ -11,6 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "recoder_hip.h")
+PROBE_HEADER = os.path.join(ROOT, "include", "recoder_hip_probe.h")
 
 
 @pytest.fixture(scope="module")
@@ -23,7 +24,7 @@ def lib():
 
 
 def declared_symbols():
-  src = open(HEADER).read()
+  src = open(HEADER).read() + open(PROBE_HEADER).read()
   src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
   return sorted(set(re.findall(r"\b(rk_[a-z0-9_]+)\s*\(", src)))
 
@@ -39,16 +40,26 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert s in syms, "bound but not declared in the header: " + s
 
 
+def test_the_library_exports_exactly_the_declared_symbols(lib):
+  """-fvisibility=hidden + the visibility pragma of the headers: nothing leaks, nothing is missing; the
+  boundary stays small (round-3 review: <= 80 exports)."""
+  from recoder_amd import _lib
+  out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+  exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l)
+  assert exported == declared_symbols()
+  assert len(exported) <= 80
+
+
 def test_struct_layouts_match_the_header(tmp_path, lib):
   from recoder_amd import _lib
   c = tmp_path / "sz.c"
-  c.write_text('#include <stdio.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu\\n", '
-               'sizeof(rk_block_t), sizeof(rk_adam_param_t), sizeof(rk_ae_step_t));return 0;}\n' % HEADER)
+  c.write_text('#include <stdio.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu\\n", '
+               'sizeof(rk_block_t), sizeof(rk_adam_param_t), sizeof(rk_ae_step_t), sizeof(rk_plan_t));return 0;}\n' % HEADER)
   exe = tmp_path / "sz"
   subprocess.check_call(["gcc", str(c), "-o", str(exe)])
   sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
   assert sizes == [ctypes.sizeof(_lib.RkBlock), ctypes.sizeof(_lib.RkAdamParam),
-                   ctypes.sizeof(_lib.RkAeStep)]
+                   ctypes.sizeof(_lib.RkAeStep), ctypes.sizeof(_lib.RkPlan)]
 
 
 def test_version_and_error_string(lib):

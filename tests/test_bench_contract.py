@@ -35,9 +35,8 @@ def check_line(out, n_gpus, steps, warmup):
 
 
 def test_single_gpu_line():
-  r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "8", "--warmup", "4"],
-                     cwd=ROOT, capture_output=True, text=True, timeout=600,
-                     env=dict(os.environ, RK_CPU_SECONDS="2"))
+  r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "8", "--warmup", "4", "--cpu-seconds", "2"],
+                     cwd=ROOT, capture_output=True, text=True, timeout=600)
   assert r.returncode == 0, r.stderr[-2000:]
   d = check_line(r.stdout, 1, 8, 4)
   c = d["cpu_baseline"]
@@ -53,12 +52,12 @@ def test_single_gpu_line():
 def test_two_rank_code_path_on_one_gpu(abandon_alt):
   """abandon_alt: the extra item-parallel run behind the graded one is cut off by its watchdog
   (as if it hung): the graded line must still come out, last on stdout, and every rank exit 0."""
-  env = dict(os.environ, RK_BENCH_ONE_GPU_GLOO="1", MASTER_ADDR="127.0.0.1")
-  if abandon_alt:
-    env["RK_BENCH_ALT_TIMEOUT"] = "0.05"
+  env = dict(os.environ, MASTER_ADDR="127.0.0.1")
   cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
          "--master-addr", "127.0.0.1", "--master-port", "29598" if abandon_alt else "29597", "bench.py",
-         "--gpus", "2", "--steps", "6", "--warmup", "3"]
+         "--gpus", "2", "--steps", "6", "--warmup", "3", "--one-gpu-gloo"]
+  if abandon_alt:
+    cmd += ["--alt-timeout", "0.05"]
   r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
   assert r.returncode == 0, r.stderr[-3000:]
   d = check_line(r.stdout, 2, 6, 3)

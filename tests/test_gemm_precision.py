@@ -168,7 +168,7 @@ def test_loss_kernels_publish_max_gradient(loss_name):
   check(lib.rk_decode_loss(ptr(Z), B, h, blk.ref, 0, ptr(W), ptr(b), kind, 0.5, 1.0 / B, ptr(dO), 0,
                            ptr(part), None, None, st), "rk_decode_loss")
   if loss_name == "mnll":
-    check(lib.rk_mnll_finish(ptr(dO), B, blk.ref, 0, 1.0 / B, ptr(part), st), "rk_mnll_finish")
+    check(lib.rk_mnll_finish(ptr(dO), B, blk.ref, 0, 1.0 / B, None, None, None, ptr(part), st), "rk_mnll_finish")
   torch.cuda.synchronize()
   want = dO[:B * ld].view(B, ld)[:, :n_t].abs().max().cpu().numpy().astype(np.float32)
   slots = blk.counts[8:72].cpu().numpy().astype(np.int32).view(np.float32)

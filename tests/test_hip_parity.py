@@ -724,7 +724,7 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
   two-group exchange of a multi-rank run (decoder-side gradients on the communication stream while
   the step stream runs dZ -> encoder backward), forced on although one rank has nothing to hide.
   ae / ae_overlap replay the phased step, its collectives included, as HIP graphs
-  (graph.GraphStepper with a DataParallel); ae_eager (RK_GRAPH_DP=0) sequences it from the host."""
+  (graph.GraphStepper with a DataParallel); ae_eager (RK_GRAPH=0) sequences it from the host."""
   import torch.distributed as dist
   from recoder_amd.data import RecommendationDataset
   from recoder_amd.model import Recoder
@@ -752,7 +752,7 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
   if overlap:
     monkeypatch.setenv("RK_DP_OVERLAP", "1")
   if eager_dp:
-    monkeypatch.setenv("RK_GRAPH_DP", "0")
+    monkeypatch.setenv("RK_GRAPH", "0")
   graph_dp = kind in ("ae", "ae_overlap") and not owned
   kind = "ae" if (items_mode or overlap or eager_dp) else kind
   c = STEP_CASES[0][1] if kind == "ae" else dict(kind="mf", embedding_size=32,
@@ -813,7 +813,7 @@ def test_data_parallel_graph_replay_is_bitwise_equal_to_host_sequencing(monkeypa
   try:
     out = {}
     for mode in ("1", "0"):
-      monkeypatch.setenv("RK_GRAPH_DP", mode)
+      monkeypatch.setenv("RK_GRAPH", mode)
       torch.manual_seed(13)
       model = make_model(c)
       rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss="mse")
@@ -1623,7 +1623,7 @@ def test_topk_tie_rule_and_strip_merge():
   sd[:, :n] = torch.from_numpy(sc).to(dev)
   idx = torch.empty(B, k, dtype=torch.int64, device=dev)
   val = torch.empty(B, k, dtype=torch.float32, device=dev)
-  check(lib.rk_topk_masked(sd.data_ptr(), B, n, ld, blk.ref, 0, k, idx.data_ptr(), val.data_ptr(),
+  check(lib.rk_topk_masked(sd.data_ptr(), B, n, ld, blk.ref, 0, k, 0, 1, idx.data_ptr(), val.data_ptr(), k,
                            current_stream()), "rk_topk_masked")
   assert np.array_equal(idx.cpu().numpy(), want)
   assert np.array_equal(val.cpu().numpy(), np.take_along_axis(masked, want, 1))
@@ -1634,11 +1634,11 @@ def test_topk_tie_rule_and_strip_merge():
   for s_ in range(ns):
     lo, hi = s_ * strip, min(n, (s_ + 1) * strip)
     part = sd[:, lo:hi].contiguous()
-    check(lib.rk_topk_masked_strip(part.data_ptr(), B, hi - lo, hi - lo, blk.ref, 0, k, lo,
+    check(lib.rk_topk_masked(part.data_ptr(), B, hi - lo, hi - lo, blk.ref, 0, k, lo, 1,
                                    cidx[:, s_ * k:].data_ptr(), cval[:, s_ * k:].data_ptr(), ns * k,
-                                   current_stream()), "rk_topk_masked_strip")
+                                   current_stream()), "rk_topk_masked")
   pos = torch.empty(B, k, dtype=torch.int64, device=dev)
-  check(lib.rk_topk_masked(cval.data_ptr(), B, ns * k, ns * k, None, 0, k, pos.data_ptr(), None,
+  check(lib.rk_topk_masked(cval.data_ptr(), B, ns * k, ns * k, None, 0, k, 0, 1, pos.data_ptr(), None, k,
                            current_stream()), "rk_topk_masked")
   assert np.array_equal(torch.gather(cidx, 1, pos).cpu().numpy(), want)
 
@@ -1745,10 +1745,9 @@ def test_hook_order_that_is_not_one_pass_takes_the_eager_path(monkeypatch):
 
 
 def test_optional_step_layouts_are_bitwise_equal_to_the_default(tmp_path):
-  """The step layouts behind switches that are read once per process -- RK_ADAM_DE_SIDE=1 (the
-  decoder table's Adam sweep as a launch of its own behind dW on the side stream) and
-  (RK_GRAPH_EVENT_NODES=1 only changes how a bench run records its brackets) -- train to the SAME bits as
-  the default: same jobs, same arithmetic, another launch order."""
+  """The step layout behind rk_tune(RK_TUNE_ADAM_DE_SIDE, 1) (the decoder table's Adam sweep as a launch of
+  its own behind dW on the side stream; include/recoder_hip_probe.h) trains to the SAME bits as the
+  default: same jobs, same arithmetic, another launch order."""
   import subprocess
   import sys
   root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1756,6 +1755,8 @@ def test_optional_step_layouts_are_bitwise_equal_to_the_default(tmp_path):
     "import sys, numpy as np, torch\n"
     "sys.path.insert(0, %r)\n"
     "from tests.test_hip_parity import synth_csr\n"
+    "from recoder_amd import _lib\n"
+    "_lib.check(_lib.load().rk_tune(5, int(sys.argv[2])), 'rk_tune')   # RK_TUNE_ADAM_DE_SIDE\n"
     "from recoder_amd.data import RecommendationDataset\n"
     "from recoder_amd.model import Recoder\n"
     "from recoder_amd.nn import DynamicAutoencoder\n"
@@ -1769,9 +1770,9 @@ def test_optional_step_layouts_are_bitwise_equal_to_the_default(tmp_path):
     "out.update({k: v.detach().cpu().numpy() for k, v in m.named_parameters()})\n"
     "np.savez(sys.argv[1], **out)\n" % root)
   res = {}
-  for name, env in (("default", {}), ("de_side", {"RK_ADAM_DE_SIDE": "1"})):
+  for name, knob in (("default", "0"), ("de_side", "1")):
     path = str(tmp_path / (name + ".npz"))
-    r = subprocess.run([sys.executable, "-c", script, path], env=dict(os.environ, PYTHONPATH=root, **env),
+    r = subprocess.run([sys.executable, "-c", script, path, knob], env=dict(os.environ, PYTHONPATH=root),
                        cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     res[name] = np.load(path)

@@ -41,8 +41,7 @@ def test_pg_decode_dz_dw(B, h, n_items, loss, ratings):
   n_b, nnz, ld, S = blk.counts_host()
   npart = lib.rk_loss_partials(B, blk.n_cap)
   ntile = -(-B // lib.rk_decode_row_tile())
-  check(lib.rk_split_w(ptr(W), h, blk.ref, ptr(ranges), ctypes.byref(pl), st))
-  check(lib.rk_split_z(ptr(Z), B, h, ptr(ranges), ctypes.byref(pl), st))
+  check(lib.rk_split_wz(ptr(W), ptr(Z), B, h, blk.ref, ptr(ranges), ctypes.byref(pl), None, st))
   # reference: the round-3 plane decode (fp32 dO)
   dO = torch.zeros(B * blk.ld_cap, **f)
   part = torch.zeros(npart, **f)
@@ -122,8 +121,7 @@ def test_pg_scales_follow_the_data():
   ip = blk.indptr[:B + 1].long()
   blk.vals[int(ip[64]):int(ip[128])] *= 1e4
   n_b, nnz, ld, S = blk.counts_host()
-  check(lib.rk_split_w(ptr(W), h, blk.ref, ptr(ranges), ctypes.byref(pl), st))
-  check(lib.rk_split_z(ptr(Z), B, h, ptr(ranges), ctypes.byref(pl), st))
+  check(lib.rk_split_wz(ptr(W), ptr(Z), B, h, blk.ref, ptr(ranges), ctypes.byref(pl), None, st))
   rows_img = -(-B // 32) * 32
   img = torch.zeros((rows_img + 256) * blk.ld_cap * 2, dtype=torch.int16, device=dev)
   sc = torch.zeros(lib.rk_pg_scale_floats(B, blk.n_cap), **f)
@@ -163,13 +161,12 @@ def test_pg_decode_mnll_matches_the_two_launch_form(B, h, n_items, ratings):
   dev = Z.device
   f = dict(dtype=torch.float32, device=dev)
   n_b, nnz, ld, S = blk.counts_host()
-  check(lib.rk_split_w(ptr(W), h, blk.ref, ptr(ranges), ctypes.byref(pl), st))
-  check(lib.rk_split_z(ptr(Z), B, h, ptr(ranges), ctypes.byref(pl), st))
+  check(lib.rk_split_wz(ptr(W), ptr(Z), B, h, blk.ref, ptr(ranges), ctypes.byref(pl), None, st))
   dO = torch.zeros(B * blk.ld_cap, **f)
   part = torch.zeros(max(B, lib.rk_loss_partials(B, blk.n_cap)), **f)
   check(lib.rk_decode_loss_planes(ctypes.byref(pl), B, blk.ref, 0, ptr(bias), LOSS_MNLL, 0.0, 1.0 / B,
                                   ptr(dO), 0, ptr(part), None, st))
-  check(lib.rk_mnll_finish(ptr(dO), B, blk.ref, 0, 1.0 / B, ptr(part), st))
+  check(lib.rk_mnll_finish(ptr(dO), B, blk.ref, 0, 1.0 / B, None, None, None, ptr(part), st))
   torch.cuda.synchronize()
   ref = dO[:B * ld].view(B, ld)[:, :n_b].clone()
   ref_loss = part[:B].double().sum().item()
@@ -212,8 +209,7 @@ def test_fdec_matches_the_lds_fused_decode(B, h, n_items, loss, ratings):
   dev = Z.device
   f = dict(dtype=torch.float32, device=dev)
   n_b, nnz, ld, S = blk.counts_host()
-  check(lib.rk_split_w(ptr(W), h, blk.ref, ptr(ranges), ctypes.byref(pl), st))
-  check(lib.rk_split_z(ptr(Z), B, h, ptr(ranges), ctypes.byref(pl), st))
+  check(lib.rk_split_wz(ptr(W), ptr(Z), B, h, blk.ref, ptr(ranges), ctypes.byref(pl), None, st))
   npart = lib.rk_loss_partials(B, blk.n_cap)
   ntile = -(-B // lib.rk_decode_row_tile())
   dO = torch.zeros(B * blk.ld_cap, **f)

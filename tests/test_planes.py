@@ -58,8 +58,7 @@ def test_decode_and_dz_on_planes_equal_the_in_loop_split_bit_for_bit(B, h, n_ite
     blk.counts[8:72].zero_()
     if planes:
       lib.rk_planes_tile(tile)
-      check(lib.rk_split_w(ptr(W), h, blk.ref, ptr(ranges), ctypes.byref(pl), st))
-      check(lib.rk_split_z(ptr(Z), B, h, ptr(ranges), ctypes.byref(pl), st))
+      check(lib.rk_split_wz(ptr(W), ptr(Z), B, h, blk.ref, ptr(ranges), ctypes.byref(pl), None, st))
       check(lib.rk_decode_loss_planes(ctypes.byref(pl), B, blk.ref, 0, ptr(bias), loss, 0.5, 1.0 / B,
                                       ptr(dO), blk.ld_cap, ptr(part), ptr(gbp), st))
       lib.rk_planes_tile(0)
@@ -116,14 +115,13 @@ def test_decode_with_fused_dz_equals_the_two_launches(B, h, n_items, loss):
   lib, blk, W, bias, Z, ranges, pl, buf = _setup(B, h, max(B, 600), n_items, 14, seed=B + h,
                                                  ratings=(loss == LOSS_MSE and h == 200))
   if lib.rk_decode_dz_fused_ok(B, h, blk.n_cap, loss) != 1:
-    pytest.skip("the fused decode + dZ launch is switched off (RK_DZ_FUSED=0 / plain bf16 operands)")
+    pytest.skip("the fused decode + dZ launch is switched off (plain bf16 operands)")
   st = current_stream()
   f = dict(dtype=torch.float32, device=Z.device)
   n_b, nnz, ld, S = blk.counts_host()
   npart = lib.rk_loss_partials(B, blk.n_cap)
   ntile = -(-B // lib.rk_decode_row_tile())
-  check(lib.rk_split_w(ptr(W), h, blk.ref, ptr(ranges), ctypes.byref(pl), st))
-  check(lib.rk_split_z(ptr(Z), B, h, ptr(ranges), ctypes.byref(pl), st))
+  check(lib.rk_split_wz(ptr(W), ptr(Z), B, h, blk.ref, ptr(ranges), ctypes.byref(pl), None, st))
   lib.rk_planes_tile(64)
 
   def run(fused):
@@ -161,8 +159,7 @@ def test_plane_images_hold_the_split_operands():
   B, h, n_items = 70, 40, 500
   lib, blk, W, bias, Z, ranges, pl, buf = _setup(B, h, 600, n_items, 12, seed=5)
   st = current_stream()
-  check(lib.rk_split_w(ptr(W), h, blk.ref, ptr(ranges), ctypes.byref(pl), st))
-  check(lib.rk_split_z(ptr(Z), B, h, ptr(ranges), ctypes.byref(pl), st))
+  check(lib.rk_split_wz(ptr(W), ptr(Z), B, h, blk.ref, ptr(ranges), ctypes.byref(pl), None, st))
   torch.cuda.synchronize()
   n_b = blk.counts_host()[0]
   KT = -(-h // 32)
@@ -212,7 +209,7 @@ def test_batched_collation_equals_per_block_collation():
     blk.c.implicit = 0
     arr[g] = ctypes.pointer(blk.c)
   check(lib.rk_collate_at_multi(ptr(dcsr.indptr), ptr(dcsr.indices), ptr(dcsr.data), ptr(order), S, 1,
-                                ptr(cursor), 0, arr, G, st))
+                                ptr(cursor), 0, arr, G, 0, st))
   torch.cuda.synchronize()
   for x, y in zip(a, b):
     n_b, nnz = int(x.counts[0]), int(x.counts[1])
@@ -316,12 +313,11 @@ def test_split_wz_is_the_two_split_launches(B, h, n_items):
   Zu = Z * 37.5                                   # unbounded activation: the range comes from rk_amax
   check(lib.rk_amax(ptr(Zu), B * h, ptr(ranges), st))
   buf.zero_()
-  check(lib.rk_split_w(ptr(W), h, blk.ref, ptr(ranges), ctypes.byref(pl), st))
-  check(lib.rk_split_z(ptr(Zu), B, h, ptr(ranges), ctypes.byref(pl), st))
+  check(lib.rk_split_wz(ptr(W), ptr(Zu), B, h, blk.ref, ptr(ranges), ctypes.byref(pl), None, st))
   torch.cuda.synchronize()
   two = buf.clone()
   buf.zero_()
-  check(lib.rk_split_wz(ptr(W), ptr(Zu), B, h, blk.ref, ptr(ranges), ctypes.byref(pl), st))
+  check(lib.rk_split_wz(ptr(W), ptr(Zu), B, h, blk.ref, ptr(ranges), ctypes.byref(pl), None, st))
   torch.cuda.synchronize()
   assert torch.equal(two.view(torch.int32), buf.view(torch.int32))
 
@@ -358,7 +354,7 @@ def test_gather_rows_amax_is_gather_plus_amax(B, d, act):
 @pytest.mark.parametrize("B,h,n_items,scale", [(500, 128, 3000, 37.5), (130, 64, 900, 1.0), (33, 20, 400, 1e-3),
                                                (300, 260, 2000, 5.0)])
 def test_split_wz_zt_leaves_the_planes_dw2_would_make(B, h, n_items, scale):
-  """rk_split_wz_zt writes Z^T as the dW kernel's fp16 pair planes (+ their scale) at the head of the dW
+  """rk_split_wz (dw_workspace given) writes Z^T as the dW kernel's fp16 pair planes (+ their scale) at the head of the dW
   workspace: rk_decode_bwd_dw2 called with zt_planes == workspace then produces the K slabs it produces
   when it makes the planes itself (zt_planes == NULL), bit for bit -- bounded and unbounded ranges of Z."""
   lib, blk, W, bias, Z, ranges, pl, buf = _setup(B, h, max(B, 600), n_items, 14, seed=3 * B + h)
@@ -383,7 +379,7 @@ def test_split_wz_zt_leaves_the_planes_dw2_would_make(B, h, n_items, scale):
     ws = torch.full((wsz,), 3.0, **f)
     blk.counts[4:5].zero_()
     if pre:
-      check(lib.rk_split_wz_zt(ptr(W), ptr(Zu), B, h, blk.ref, ptr(ranges), ctypes.byref(pl), ptr(ws), st))
+      check(lib.rk_split_wz(ptr(W), ptr(Zu), B, h, blk.ref, ptr(ranges), ctypes.byref(pl), ptr(ws), st))
     check(lib.rk_decode_bwd_dw2(ptr(dO), ptr(Zu), B, h, blk.ref, None, None, ptr(ws), ptr(ws) if pre else None,
                                 ptr(ranges), st))
     torch.cuda.synchronize()

@@ -11,15 +11,16 @@ sys.path.insert(0, ROOT)
 
 def main():
   secs = sys.argv[1] if len(sys.argv) > 1 else "6"
-  os.environ["RK_CPU_SECONDS"] = secs
+  import argparse
   import bench
+  bench.ARGS = argparse.Namespace(cpu_seconds=float(secs), cpu_threads=16)
   cfg = bench.CONFIGS["c2"]
   csr = bench.make_csr(cfg)
   print("host cores: %d; C2 workload, %s s per point" % (os.cpu_count(), secs), flush=True)
   for t in (1, 2, 4, 8, 16, 32, 64, 128, 256):
     if t > os.cpu_count():
       break
-    os.environ["RK_CPU_THREADS"] = str(t)
+    bench.ARGS.cpu_threads = t
     r = bench.cpu_baseline(cfg, csr, 100000, warmup=2)
     print("threads %3d: %8.0f users/s  (%s)" % (r["cores"], r["value"], r["sample"].split(" of ")[0]), flush=True)
 

@@ -1,5 +1,5 @@
 """Times rk_linear_bwd at C3's layer shape (500 x 200 x 200): launch by launch with HIP events.
-RK_LINEAR_PAIR=0: dX and dW as two launches (round 2 / early round 3)."""
+argv[1] = 0: dX and dW as two launches (round 2 / early round 3; rk_tune RK_TUNE_LINEAR_PAIR)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -8,6 +8,8 @@ from recoder_amd._lib import check, ptr
 from recoder_amd.device import current_stream
 
 lib = _lib.load()
+PAIR = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+lib.rk_linear_pair(PAIR)
 dev = torch.device("cuda")
 B, N, K = 500, 200, 200
 f = lambda *s: torch.randn(*s, device=dev)
@@ -27,4 +29,4 @@ for name, fn in [("rk_linear_bwd", lambda: lib.rk_linear_bwd(ptr(dY), ptr(Y), pt
     fn()
   e1.record()
   torch.cuda.synchronize()
-  print("%-20s %.2f us per call (RK_LINEAR_PAIR=%s)" % (name, e0.elapsed_time(e1) * 5.0, os.environ.get("RK_LINEAR_PAIR", "1")))
+  print("%-20s %.2f us per call (pair = %d)" % (name, e0.elapsed_time(e1) * 5.0, PAIR))

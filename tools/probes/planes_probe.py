@@ -82,8 +82,7 @@ def main():
       part = torch.zeros(npart, **f)
       gbp = torch.zeros(ntile * blk.ld_cap, **f)
       blk.counts[8:72].zero_()
-      check(lib.rk_split_w(ptr(W), h, blk.ref, ptr(ranges), ctypes.byref(pl), st))
-      check(lib.rk_split_z(ptr(Z), B, h, ptr(ranges), ctypes.byref(pl), st))
+      check(lib.rk_split_wz(ptr(W), ptr(Z), B, h, blk.ref, ptr(ranges), ctypes.byref(pl), None, st))
       check(lib.rk_decode_loss_planes(ctypes.byref(pl), B, blk.ref, 0, ptr(bias), loss, 0.5, 1.0 / B, ptr(dO),
                                       blk.ld_cap, ptr(part), ptr(gbp), st))
       return dO, part, gbp, blk.counts[8:72].clone()
@@ -109,8 +108,7 @@ def main():
     gbp = torch.zeros(ntile * blk.ld_cap, **f)
     blk.counts[8:72].zero_()
     lib.rk_planes_tile(128)
-    check(lib.rk_split_w(ptr(W), h, blk.ref, ptr(ranges), ctypes.byref(pl), st))
-    check(lib.rk_split_z(ptr(Z), B, h, ptr(ranges), ctypes.byref(pl), st))
+    check(lib.rk_split_wz(ptr(W), ptr(Z), B, h, blk.ref, ptr(ranges), ctypes.byref(pl), None, st))
     check(lib.rk_decode_loss_planes(ctypes.byref(pl), B, blk.ref, 0, ptr(bias), LOSS_MSE, 0.5, 1.0 / B, ptr(dO),
                                     blk.ld_cap, ptr(part), ptr(gbp), st))
     ws = torch.zeros(lib.rk_dz_workspace_bytes(B, h) // 4 + 64, **f)
@@ -126,8 +124,8 @@ def main():
         ref.abs().max().item()), flush=True)
     # timings
     r = {}
-    r["split_w"] = timeit(lambda: check(lib.rk_split_w(ptr(W), h, blk.ref, ptr(ranges), ctypes.byref(pl), st)))
-    r["split_z"] = timeit(lambda: check(lib.rk_split_z(ptr(Z), B, h, ptr(ranges), ctypes.byref(pl), st)))
+    r["split_w"] = timeit(lambda: check(lib.rk_split_wz(ptr(W), None, 0, h, blk.ref, ptr(ranges), ctypes.byref(pl), None, st)))
+    r["split_z"] = timeit(lambda: check(lib.rk_split_wz(None, ptr(Z), B, h, blk.ref, ptr(ranges), ctypes.byref(pl), None, st)))
     r["dec_old"] = timeit(lambda: check(lib.rk_decode_loss(
         ptr(Z), B, h, blk.ref, 0, ptr(W), ptr(bias), LOSS_MSE, 0.5, 1.0 / B, ptr(dO), blk.ld_cap, ptr(part),
         ptr(gbp), ptr(ranges), st)))

@@ -27,7 +27,7 @@ print("k(s1)->ev->k(s2)->ev->s1  : %.1f us" % bench(pingpong))
 def fork_join():
   e1.record(s1); s2.wait_event(e1); k(s1); k(s2); e2.record(s2); s1.wait_event(e2)
 print("fork: k(s1)||k(s2) join   : %.1f us" % bench(fork_join))
-rawe = [lib.rk_event_create() for _ in range(2)]
+rawe = [lib.rk_event_create(0) for _ in range(2)]
 hip = ctypes.CDLL("libamdhip64.so")
 def raw_pingpong():
   k(s1); hip.hipEventRecord(ctypes.c_void_p(rawe[0]), ctypes.c_void_p(s1.cuda_stream)); hip.hipStreamWaitEvent(ctypes.c_void_p(s2.cuda_stream), ctypes.c_void_p(rawe[0]), 0)
