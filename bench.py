@@ -364,11 +364,17 @@ def main():
                   help="N > 1: also time the item-parallel alternative in a child run (auto: only with > 1 rank)")
   ap.add_argument("--alt-timeout", type=float, default=300.0)
   ap.add_argument("--one-gpu-gloo", action="store_true", help="(tests) every rank on GPU 0 over gloo")
+  ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
+                  help="(A/B runs) rk_tune(KNOB, VALUE) of include/recoder_hip_probe.h before anything is launched")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-recall", action="store_true")
   args = ap.parse_args()
   global ARGS
   ARGS = args
+  for kv in args.tune:
+    from recoder_amd import _lib as _rk_lib
+    k, v = kv.split("=")
+    _rk_lib.check(_rk_lib.load().rk_tune(int(k), int(v)), "rk_tune")
   cfg = CONFIGS[args.config]
 
   world = int(os.environ.get("WORLD_SIZE", "1"))
