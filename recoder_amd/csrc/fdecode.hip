@@ -8,7 +8,8 @@
 //     one v_permlane32_swap per register, exactly the B operand of  dZ^T[j, user] += W^T[j, item] .
 //     dO^T[item, user]  -- the gradient tile goes from accumulators to MFMA operand without touching LDS.
 //   * All KT k-tiles of the tile's 128 gathered W rows stay RESIDENT in LDS (KT x 16 KB, copied by LDS-DMA
-//     in one burst at the start; the Z fragments of a wave's own 32 users go straight to registers): the dZ product reads them a second time along their rows with
+//     in one burst at the start; a wave's own 32 users' Z lines are loaded coalesced and turned into
+//     fragments through 4 KB of wave-private LDS): the dZ product reads them a second time along their rows with
 //     ds_read_b64_tr_b16 -- no W^T image is made, written or fetched.
 //   * dLoss/dLogits leaves as a plane image of fp16 pairs (16-byte stores straight from the fragments) cut
 //     with the scale of its 32-user x 128-item granule: rk_pg_dw reads it (csrc/pgemm.hip).
@@ -76,17 +77,18 @@ __device__ __forceinline__ void swap32(uint32_t &a, uint32_t &b) {
 }
 
 constexpr int FD_PITCH(int ktm) { return ktm * 32 + 4; }        // floats per row of the dZ^T exchange
-constexpr int FD_LDS(int ktm) {                                   // W stages | exchange (aliased) + misc
-  return (ktm * WB > 4 * 32 * FD_PITCH(ktm) * 4 ? ktm * WB : 4 * 32 * FD_PITCH(ktm) * 4) + 1024;
+constexpr int FD_LDS(int ktm) {                                   // W stages | exchange (aliased), Z bounce, misc
+  return (ktm * WB > 4 * 32 * FD_PITCH(ktm) * 4 ? ktm * WB : 4 * 32 * FD_PITCH(ktm) * 4) + 8 * 4096 + 1024;
 }
 
 // 512 threads: wave w works on users 32 (w & 3) .. + 31 of the tile and on the item half (w >> 2) -- two
 // waves per SIMD, so that one wave's loss arithmetic, fragment conversions and stores run under the other
 // one's MFMAs (with one wave per SIMD the 336 MFMAs of a tile were 15% of its time).
 template <int KTM, int LOSS>
-__global__ __launch_bounds__(512) void fdec_kernel(const FdecP p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void fdec_kernel(const FdecP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *Wst = smem;                                   // [KTM][128 rows][128 B]
+  char *Zb = smem + FD_LDS(KTM) - 1024 - 8 * 4096;    // [8 waves][32 rows][128 B]
   float *misc = reinterpret_cast<float *>(smem + FD_LDS(KTM) - 1024);   // [128] bias | [16] reductions
   const int M = p.M, N = *p.Ndev;
   const int tm = (M + 127) >> 7, tn = (N + 127) >> 7;
@@ -119,20 +121,23 @@ __global__ __launch_bounds__(512) void fdec_kernel(const FdecP p) {
 #pragma unroll
   for (int kt = 0; kt < KTM; ++kt) sw.issue(Wst + kt * WB, wave);
   asm volatile("" ::: "memory");
-  f16x8 zh[KTM][2], zl[KTM][2];
+  // Z: lane (row slot lane >> 3, 16-byte slot lane & 7) loads one piece of 8 FULL image lines per
+  // instruction (the 28 per-lane fragment loads of the first version touched 32 lines each: the copy phase
+  // took 7.4 instead of 4.4 us); a k-tile's 4 pieces go through 4 KB of wave-private LDS into fragments
+  pg::u32x4 zraw[KTM][4];
   {
-    const char *zsrc = p.zimg + (int64_t)min(m, min(M, p.z_rows) - 1) * (KTM * 128) + 16 * lh;
+    const int zlim = min(M, p.z_rows) - 1;
 #pragma unroll
-    for (int kt = 0; kt < KTM; ++kt)
+    for (int i = 0; i < 4; ++i) {
+      const int zr = min(m0 + 32 * pr + 8 * i + (lane >> 3), zlim);
+      const char *zsrc = p.zimg + (int64_t)zr * (KTM * 128) + 16 * (lane & 7);
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        zh[kt][ks] = *reinterpret_cast<const f16x8 *>(zsrc + kt * 128 + 32 * ks);
-        zl[kt][ks] = *reinterpret_cast<const f16x8 *>(zsrc + kt * 128 + 32 * ks + 64);
-      }
+      for (int kt = 0; kt < KTM; ++kt) zraw[kt][i] = *reinterpret_cast<const pg::u32x4 *>(zsrc + kt * 128);
+    }
   }
-  // the 4 KTM fragment loads above are the only memory operations behind the DMA: it has landed when no
-  // more than those are outstanding (vmcnt counts in issue order)
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * KTM) : "memory");
+  // the 4 KTM loads above are the only memory operations behind the DMA: it has landed when no more than
+  // those are outstanding (vmcnt counts in issue order)
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(4 * KTM) : "memory");     // (lgkmcnt: the bias tile in LDS)
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
@@ -143,9 +148,24 @@ __global__ __launch_bounds__(512) void fdec_kernel(const FdecP p) {
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   pg::FragKC fr;
   fr.init(lane);
+  char *zb = Zb + wave * 4096;                        // this wave's bounce stage: [32 rows][128 B], KC swizzle
 #pragma unroll
   for (int kt = 0; kt < KTM; ++kt) {
     const char *SW = Wst + kt * WB + hf * 8192;
+    // (LDS runs a wave's instructions in order: no wait between the writes and the reads of the stage, nor
+    // before the next k-tile's writes; the wave barriers only pin the compiler's order)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 8 * i + (lane >> 3);
+      *reinterpret_cast<pg::u32x4 *>(zb + r * 128 + (((lane & 7) ^ ((r >> 1) & 7)) << 4)) = zraw[kt][i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f16x8 zh[2], zl[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) { zh[ks] = fr.load(zb, 0, ks, 0); zl[ks] = fr.load(zb, 0, ks, 1); }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       f16x8 wh[2], wl[2];
@@ -153,11 +173,11 @@ __global__ __launch_bounds__(512) void fdec_kernel(const FdecP p) {
       for (int i = 0; i < 2; ++i) { wh[i] = fr.load(SW, i, ks, 0); wl[i] = fr.load(SW, i, ks, 1); }
       // (the order of decode16.hip per accumulator: Z lo . W hi, Z hi . W lo, hi . hi)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], zl[kt][ks], acc[i], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], zl[ks], acc[i], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], zh[kt][ks], acc[i], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], zh[ks], acc[i], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], zh[kt][ks], acc[i], 0, 0, 0);
+      for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], zh[ks], acc[i], 0, 0, 0);
     }
   }
 
@@ -200,7 +220,42 @@ __global__ __launch_bounds__(512) void fdec_kernel(const FdecP p) {
       }
     }
   };
-  if (implicit) loss_pass(std::true_type{}); else loss_pass(std::false_type{});
+  // implicit feedback + squared error (C2): the same arithmetic in 14 instead of 25 VALU instructions per
+  // element -- target and validity bits as shifted masks (one bit-field extract each), the weight as
+  // fma(c, bit, 1) (= 1 or fl(1 + c) exactly), g = d * (w * 2 / B) (= (2 d) * (w / B): scaling by 2 is exact),
+  // masking by AND with 0 / ~0, the tile's bias as 16-byte LDS reads
+  auto loss_pass_mse_implicit = [&]() {
+    const float c = p.confidence, inv_B2 = 2.0f * p.inv_B;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int nrem = N - (nh + 32 * i);
+      uint32_t vmask = nrem >= 32 ? 0xffffffffu : (nrem <= 0 ? 0u : ((1u << nrem) - 1u));
+      if (m >= M) vmask = 0u;
+      const uint32_t vsh = vmask >> (4 * lh), wsh = (words[i] & vmask) >> (4 * lh);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 bq = *reinterpret_cast<const float4 *>(misc + 64 * hf + 32 * i + 8 * q + 4 * lh);
+        const float bias4[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * q + e, bp = e + 8 * q;            // bit of item (r & 3) + 8 (r >> 2) (+ 4 lh: shifted out)
+          const float bitf = (float)((wsh >> bp) & 1u);
+          const uint32_t okm = (uint32_t)(((int32_t)(vsh << (31 - bp))) >> 31);
+          const float o = acc[i][r] * inv + bias4[e];
+          const float d = o - bitf;
+          const float w = fmaf(c, bitf, 1.0f);
+          const float l = w * (d * d);
+          lsum += __uint_as_float(__float_as_uint(l) & okm);
+          const float g = __uint_as_float(__float_as_uint(d * (w * inv_B2)) & okm);
+          gmax = fmaxf(gmax, fabsf(g));
+          acc[i][r] = g;
+        }
+      }
+    }
+  };
+  if (implicit && LOSS == pg::LOSS_MSE) loss_pass_mse_implicit();
+  else if (implicit) loss_pass(std::true_type{});
+  else loss_pass(std::false_type{});
   // the granule's (32 users x 64 items = this wave's) power-of-two scale, the tile's loss partial
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
@@ -213,7 +268,9 @@ __global__ __launch_bounds__(512) void fdec_kernel(const FdecP p) {
   if (lane == 0) {
     misc[128 + wave] = lsum;
     misc[136 + wave] = gmax;
-    if ((m0 >> 5) + pr < ((M + 31) >> 5)) p.dscale[(int64_t)((m0 >> 5) + pr) * p.ds_pitch + 2 * nt + hf] = s_do;
+    // (a half past the capacity -- items [64 ds_pitch, ...) -- has no slot: its column would be the next row's first)
+    if ((m0 >> 5) + pr < ((M + 31) >> 5) && 2 * nt + hf < p.ds_pitch)
+      p.dscale[(int64_t)((m0 >> 5) + pr) * p.ds_pitch + 2 * nt + hf] = s_do;
   }
 
   // ---- dO^T fragments (permlane32 swap), the image, and dZ^T[j, user] += W^T[j, item] . dO^T[item, user]
