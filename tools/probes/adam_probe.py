@@ -76,3 +76,44 @@ for name, jobs, wl in variants():
   tables = sum(1 for j in jobs if j.h == h and j.n_rows == N)
   mb = tables * N * h * 24 / 1e6
   print("%-52s %6.1f us   (%.0f MB of p / m / v traffic: %.2f TB/s on those alone)" % (name, us, mb, mb / us * 1e-6 * 1e6 / 1e6))
+
+
+# ---- the regrouped tail: [decoder-table sweep || encoder backward] | [encoder-table sweep]
+def pair_probe():
+  dZ = torch.randn(B * h, **f) * 1e-3
+  G2 = torch.zeros(blk.n_cap * h, **f)
+  gb2 = torch.zeros(h * 8, **f)
+  s2 = torch.cuda.Stream()
+  full = [job(*tabs[0], N, h, G_en, pos=blk.pos),
+          job(*tabs[1], N, h, slabs, pos=blk.pos, g_parts=4, g_stride=blk.n_cap * h, gparts_dev=nslab),
+          job(*bias[0], N, 1, gb_part, pos=blk.pos, g_parts=8, gstride_dev=blk.counts[2:3]),
+          job(*bias[1], 1, h, gb_en)]
+  de = (RkAdamJob * 2)(full[2], full[1])
+  en = (RkAdamJob * 2)(full[3], full[0])
+  h2 = ctypes.c_void_p(s2.cuda_stream)
+
+  def run(what):
+    ts = []
+    for _ in range(30):
+      other.sum()
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record()
+      if what in ("pair", "enc"):
+        s2.wait_stream(torch.cuda.current_stream())
+        check(lib.rk_ae_encode_bwd(blk.ref, 0, B, ptr(dZ), h, ptr(G2), 0, ptr(gb2), h2))
+      if what in ("pair", "de"):
+        check(lib.rk_adam_multi(de, 2, None, 0, 500.0, None, st))
+      if what == "en":
+        check(lib.rk_adam_multi(en, 2, ptr(loss_part), n_part, 500.0, ptr(loss_out), st))
+      if what in ("pair", "enc"):
+        torch.cuda.current_stream().wait_stream(s2)
+      e1.record()
+      e1.synchronize()
+      ts.append(e0.elapsed_time(e1) * 1e3)
+    return float(np.median(ts[5:]))
+  for what, name in (("enc", "encoder backward alone (second stream, fork + join)"), ("de", "decoder-table + bias sweep alone"),
+                     ("pair", "decoder-table sweep || encoder backward (two streams)"), ("en", "encoder-table + bias sweep + loss")):
+    print("%-60s %6.1f us" % (name, run(what)))
+
+
+pair_probe()

@@ -50,10 +50,11 @@ def main():
   gbp = torch.zeros(-(-B // 64) * blk.ld_cap, **f)
   flush = torch.zeros(64 << 20, **f)
 
-  def timeit(fn, n=30):
+  def timeit(fn, n=30, flush_first=True):
     ts = []
     for _ in range(n):
-      flush.add_(1.0)                                   # (evict: the step's other launches do that)
+      if flush_first:
+        flush.add_(1.0)                                 # (evict: the step's other launches do that)
       e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
       e0.record(); fn(); e1.record(); e1.synchronize()
       ts.append(e0.elapsed_time(e1) * 1e3)
@@ -69,6 +70,25 @@ def main():
   print("C2-shaped block: B = %d, h = %d, n_b = %d" % (B, h, n_b))
   print("decode16 fused (LDS dO tile, W^T stage): %.1f us" % timeit(old))
   print("fdec (register resident, W rows resident in LDS): %.1f us" % timeit(fdec))
+  # the launches behind it in the C2 step, each alone (same flush in front of every launch)
+  dZ = torch.zeros(B * h, **f)
+  slabs = torch.zeros(lib.rk_pg_dw_workspace_bytes(B, h, blk.n_cap) // 4 + 64, **f)
+  G_en = torch.zeros(blk.n_cap * h, **f)
+  gb_en = torch.zeros(h * 8, **f)
+  gb_de = torch.zeros(blk.n_cap, **f)
+  fdec()
+  print("rk_decode_dz_reduce alone: %.1f us" % timeit(lambda: check(lib.rk_decode_dz_reduce(
+      ptr(ws), B, h, blk.ref, ptr(Z), 1, ptr(dZ), st))))
+  print("rk_pg_dw alone (dW tiles from the image): %.1f us, hot %.1f us" % (timeit(lambda: check(lib.rk_pg_dw(
+      ptr(img), ptr(sc), 32, 64, B, ctypes.byref(pl), blk.ref, ptr(slabs), st))), timeit(lambda: check(lib.rk_pg_dw(
+      ptr(img), ptr(sc), 32, 64, B, ctypes.byref(pl), blk.ref, ptr(slabs), st)), flush_first=False)))
+  print("rk_ae_encode_bwd alone: %.1f us" % timeit(lambda: check(lib.rk_ae_encode_bwd(
+      blk.ref, 0, B, ptr(dZ), h, ptr(G_en), 0, ptr(gb_en), st))))
+  print("rk_pg_dw_encode_bwd (dW || encoder backward): %.1f us" % timeit(lambda: check(lib.rk_pg_dw_encode_bwd(
+      ptr(img), ptr(sc), 32, 64, B, ctypes.byref(pl), blk.ref, ptr(slabs), 0, ptr(dZ), ptr(G_en), ptr(gb_en), None, st))))
+  print("rk_pg_dw_encode_bwd (dW || encoder backward || image column sums): %.1f us" % timeit(lambda: check(
+      lib.rk_pg_dw_encode_bwd(ptr(img), ptr(sc), 32, 64, B, ctypes.byref(pl), blk.ref, ptr(slabs), 0, ptr(dZ),
+                              ptr(G_en), ptr(gb_en), ptr(gb_de), st))))
 
 
 if __name__ == "__main__":
