@@ -2,6 +2,9 @@
 // include/recoder_hip.h, which calls every one of them).
 #pragma once
 #include <stdint.h>
+struct rk_planes;
+int rk_pg_dw_dense(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
+                   const struct rk_planes *pl, const rk_block_t *tgt, float *G_de, float *gb_de, void *stream);
 extern "C" {
 int64_t rk_dz_workspace_bytes(int32_t B, int32_t h);
 int32_t rk_loss_partials(int32_t B, int32_t n_cap);

@@ -294,11 +294,19 @@ extern "C" int64_t rk_pg_dw_workspace_bytes(int32_t B, int32_t h, int32_t n_cap)
 // (g_parts / gparts_dev)
 static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
                       const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, const EncBwd *enc,
-                      void *stream_, float *gb_de = nullptr);
+                      void *stream_, float *gb_de = nullptr, bool dense = false);
 
 extern "C" int rk_pg_dw(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
                         const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, void *stream_) {
   return pg_dw_impl(dO_img, dO_scales, gr, gc, B, pl, tgt, slabs, nullptr, stream_);
+}
+
+// rk_pg_dw as ONE dense array G_de[n_cap][h] (no split-K: the data-parallel exchange ships it) + the
+// decoder bias gradient gb_de[n_t] = column sums of dO from the image, one launch (csrc/step.hip: the
+// phased step on the register-resident fused decode); internal
+int rk_pg_dw_dense(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
+                   const rk_planes_t *pl, const rk_block_t *tgt, float *G_de, float *gb_de, void *stream_) {
+  return pg_dw_impl(dO_img, dO_scales, gr, gc, B, pl, tgt, G_de, nullptr, stream_, gb_de, true);
 }
 
 // rk_pg_dw and rk_ae_encode_bwd (rows [row_off, row_off + B) of the block `tgt`; G_en / gb_en as there,
@@ -319,9 +327,13 @@ extern "C" int rk_pg_dw_encode_bwd(const void *dO_img, const float *dO_scales, i
 }
 
 static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
-                      const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, const EncBwd *enc,
-                      void *stream_, float *gb_de) {
+                      const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, const EncBwd *enc_,
+                      void *stream_, float *gb_de, bool dense) {
   hipStream_t stream = (hipStream_t)stream_;
+  // (column sums without an encoder backward: the same launch with an empty encoder range)
+  EncBwd no_enc = {};
+  no_enc.h = pl ? pl->h : 0;
+  const EncBwd *enc = enc_ ? enc_ : (gb_de ? &no_enc : nullptr);
   RK_REQUIRE(pl && tgt->n_cap <= pl->n_cap && B <= pl->B_cap, "planes were laid out for another shape");
   RK_REQUIRE(al16(dO_img) && al16(slabs) && dO_scales, "operands must be 16-byte aligned");
   RK_REQUIRE(gr >= 32 && gc >= 32 && gr % 32 == 0 && gc % 32 == 0, "scale granule: multiples of 32");
@@ -335,7 +347,7 @@ static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, in
   p.a.lines = rk_cdiv(tgt->n_cap, 32); p.a.pitch = (int64_t)p.a.lines * pg::LINE;
   p.b.img = (const char *)pl->z; p.b.pitch = (int64_t)KT * pg::LINE; p.b.lines = KT; p.b.rows = (pl->B_cap + 31) & ~31;
   p.M = tgt->n_cap; p.Mdev = tgt->counts; p.N = h; p.K = B;
-  p.splits = DW_MAX_SPLITS; p.auto_slots = DW_SLOTS; p.splits_out = tgt->counts + 4;
+  p.splits = dense ? 1 : DW_MAX_SPLITS; p.auto_slots = dense ? 0 : DW_SLOTS; p.splits_out = tgt->counts + 4;
   p.rs.tab = dO_scales; p.rs.gr = gr; p.rs.gc = gc; p.rs.pitch = rk_cdiv(tgt->n_cap, gc); p.rs.mode = 2;
   pg::EpiSlab::Args e = {};
   e.C = slabs; e.ldc = h; e.slab_stride = (int64_t)tgt->n_cap * h; e.bscale = pl->scales;
@@ -343,7 +355,7 @@ static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, in
   hipError_t rc;
   if (enc) {
     const int n_dw = pg::grid_of(p, tiles);
-    const int n_enc = rk_cdiv(tgt->n_cap, 4) + enc->n_gb;
+    const int n_enc = enc_ ? rk_cdiv(tgt->n_cap, 4) + enc->n_gb : 0;
     const int hv = rk_cdiv(h, 256);
     ColsumImg cs = {};
     int n_cs = 0;

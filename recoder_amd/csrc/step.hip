@@ -380,9 +380,18 @@ static int step_item_parallel(const rk_ae_step_t *a, int phase) {
 // (csrc/fdecode.hip) with its image, dW on rk_pg_dw
 static int step_pg_mode(const rk_ae_step_t *a) {
   const int phase = a->phase == 0 ? RK_STEP_ALL : a->phase;
-  if (phase != RK_STEP_ALL || a->tied || a->loss_kind == RK_LOSS_MNLL) return 0;
+  if (a->tied || a->loss_kind == RK_LOSS_MNLL) return 0;
   if (!rk_gemm_split16() || rk_gemm_plain_bf16() || a->ws == nullptr || a->planes == nullptr) return 0;
   if (a->do_scales == nullptr || !rk_pg_enabled()) return 0;
+  if (phase != RK_STEP_ALL) {
+    // the PHASED (data-parallel) step: the register-resident fused decode in FWD_DW, dW as one dense array +
+    // the bias gradient from its image (rk_pg_dw_dense), the slab reduce + encoder backward in DZ_ENC.  The
+    // same answer in all three calls of a step (it depends on nothing a phase changes).
+    if ((phase & RK_STEP_IP_ALL) == 0 && a->ws_dw != nullptr && rk_fdec_ok(a->B, a->h, a->blk->n_cap, a->loss_kind) &&
+        rk_decode_dz_fused_ok(a->B, a->h, a->blk->n_cap, a->loss_kind))
+      return 3;
+    return 0;
+  }
   if (rk_decode_dz_fused_ok(a->B, a->h, a->blk->n_cap, a->loss_kind) == 0) return 1;
   // 3: the register-resident fused decode (csrc/fdecode.hip) + rk_pg_dw || encoder backward || image
   // column sums -- when the dW / encoder-backward launch can be the fused one (a->ws_dw, the row window)
@@ -513,11 +522,14 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     if (a->tied || mnll || !whole) {
       Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
       // (the fused decode's dZ slabs sit in a->ws until the DZ_ENC call: dW works in ws_dw then)
-      RK_TRY(dw_call(a, a->G_de, mnll ? a->gb_de : nullptr, planes, dz_fused ? a->ws_dw : nullptr));
+      if (fdec)    // (phased, on the fused decode's image: G_de dense, gb_de from the image's columns)
+        RK_TRY(rk_pg_dw_dense(a->dO, a->do_scales, 32, 64, B, a->planes, blk, a->G_de, a->gb_de, sm));
+      else
+        RK_TRY(dw_call(a, a->G_de, mnll ? a->gb_de : nullptr, planes, dz_fused ? a->ws_dw : nullptr));
     }
     if (!whole) {
       // the data-parallel exchange needs gb_de and the loss scalar as arrays of their own
-      if (!mnll) RK_TRY(rk_colsum(a->gb_part, row_tiles, blk->n_cap, 0, blk->counts, a->gb_de, sm));
+      if (!mnll && !fdec) RK_TRY(rk_colsum(a->gb_part, row_tiles, blk->n_cap, 0, blk->counts, a->gb_de, sm));
       RK_TRY(rk_loss_reduce(a->loss_part, n_part, a->denom, a->loss_out, sm));
     }
   }
@@ -591,7 +603,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     if (!a->tied) {
       jobs[n] = table_job(a->par[RK_PAR_W_DE], blk, n_items, h, a->G_de, true);
       if (a->ranges) jobs[n].amax_out = a->ranges + 64;
-      if (pg || fdec) {
+      if ((pg || fdec) && whole) {
         jobs[n].g = dw_slabs_pg; jobs[n].g_parts = rk_pg_dw_splits(B, h, blk->n_cap);
         jobs[n].g_stride = blk->n_cap * h; jobs[n].gparts_dev = blk->counts + 4;
       } else if (dw3) {
