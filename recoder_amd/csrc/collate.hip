@@ -348,13 +348,29 @@ __device__ __forceinline__ void collate_build_body(
   const int out0 = b.indptr[row];
   const int wr = (b.counts[0] + 31) >> 5;          // bitmap words in use
   n = min(n, b.indptr[row + 1] - out0);            // (the clamped range of a truncated block)
-  for (int k = lane; k < n; k += 64) {
-    const int32_t gi = ds_indices[beg + k];
-    const int32_t c = b.pos[gi];            // (< 0 only in a truncated block, counts[5] != 0)
-    b.cols[out0 + k] = max(c, 0);
-    if (b.gcols) b.gcols[out0 + k] = gi;
-    b.vals[out0 + k] = c < 0 ? 0.0f : (ds_data ? ds_data[beg + k] : 1.0f);
-    if (b.bits_cr && c >= 0) atomicOr(&b.bits_cr[(int64_t)c * b.ldw_cr + (row >> 5)], 1u << (row & 31));
+  // (four entries per lane and round: the item ids, then their positions, are fetched as independent loads --
+  // a 3 000-entry row was 47 rounds of ids -> positions -> stores one after the other, the tail of the launch)
+  for (int k0 = 0; k0 < n; k0 += 256) {
+    int32_t gi[4], c[4];
+    float val[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + u * 64 + lane;
+      gi[u] = k < n ? ds_indices[beg + k] : -1;
+      val[u] = (k < n && ds_data) ? ds_data[beg + k] : 1.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u] = gi[u] >= 0 ? b.pos[gi[u]] : -1;   // (< 0 only in a truncated block, counts[5] != 0)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + u * 64 + lane;
+      if (k < n) {
+        b.cols[out0 + k] = max(c[u], 0);
+        if (b.gcols) b.gcols[out0 + k] = gi[u];
+        b.vals[out0 + k] = c[u] < 0 ? 0.0f : val[u];
+        if (b.bits_cr && c[u] >= 0) atomicOr(&b.bits_cr[(int64_t)c[u] * b.ldw_cr + (row >> 5)], 1u << (row & 31));
+      }
+    }
   }
   uint32_t *wb = wbits + wid * seg;
   uint32_t *bits = b.bits_rc + (int64_t)row * b.ldw_rc;
@@ -364,10 +380,25 @@ __device__ __forceinline__ void collate_build_body(
     const int nw = min(seg, wr - w0);
     for (int w = lane; w < nw; w += 64) wb[w] = 0u;
     __builtin_amdgcn_wave_barrier();
-    for (int k = lane; k < n; k += 64) {
-      const int32_t c = b.pos[ds_indices[beg + k]];
-      const int w = (c >> 5) - w0;
-      if (c >= 0 && w >= 0 && w < nw) atomicOr(&wb[w], 1u << (c & 31));
+    for (int k0 = 0; k0 < n; k0 += 256) {
+      int32_t c[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + u * 64 + lane;
+        c[u] = k < n ? b.cols[out0 + k] : -1;       // (written above by this wave; a truncated entry holds 0 for
+      }                                             //  position < 0: re-read the position for those blocks)
+      if (b.counts[5] != 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k = k0 + u * 64 + lane;
+          c[u] = k < n ? b.pos[ds_indices[beg + k]] : -1;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int w = (c[u] >> 5) - w0;
+        if (c[u] >= 0 && w >= 0 && w < nw) atomicOr(&wb[w], 1u << (c[u] & 31));
+      }
     }
     __builtin_amdgcn_wave_barrier();
     for (int wq = 0; wq < nw; wq += 64) {
