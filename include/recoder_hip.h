@@ -579,7 +579,7 @@ typedef struct rk_adam_param {
  * rk_decode_loss's per-row-tile partials this way.  loss_part != NULL: the last
  * workgroup does what rk_loss_reduce does.
  */
-#define RK_ADAM_MULTI_MAX 6
+#define RK_ADAM_MULTI_MAX 10
 typedef struct rk_adam_job {
   rk_adam_param_t par;
   int32_t n_rows, h;           /* table shape ([1, n] for a flat tensor) */

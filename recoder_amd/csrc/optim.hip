@@ -421,7 +421,11 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(UArgs a) {
     }
   }
   // static indices only (a dynamically indexed by-value struct would go to scratch)
-  if (a.n_jobs > 5 && b >= a.job[5].blk0) run_job(a.job[5], b, a);
+  if (a.n_jobs > 9 && b >= a.job[9].blk0) run_job(a.job[9], b, a);
+  else if (a.n_jobs > 8 && b >= a.job[8].blk0) run_job(a.job[8], b, a);
+  else if (a.n_jobs > 7 && b >= a.job[7].blk0) run_job(a.job[7], b, a);
+  else if (a.n_jobs > 6 && b >= a.job[6].blk0) run_job(a.job[6], b, a);
+  else if (a.n_jobs > 5 && b >= a.job[5].blk0) run_job(a.job[5], b, a);
   else if (a.n_jobs > 4 && b >= a.job[4].blk0) run_job(a.job[4], b, a);
   else if (a.n_jobs > 3 && b >= a.job[3].blk0) run_job(a.job[3], b, a);
   else if (a.n_jobs > 2 && b >= a.job[2].blk0) run_job(a.job[2], b, a);

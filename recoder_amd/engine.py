@@ -17,6 +17,8 @@ from . import _lib
 from ._lib import ACT, LOSS_BCE, LOSS_MNLL, LOSS_MSE, LOSS_NONE, check, ptr
 from .device import Block, cdiv, current_stream, require_gpu
 
+ADAM_MULTI_MAX = 10           # RK_ADAM_MULTI_MAX (include/recoder_hip.h): jobs of one rk_adam_multi launch
+
 LOSS_IDS = {"mse": LOSS_MSE, "logistic": LOSS_BCE, "logloss": LOSS_MNLL}
 
 
@@ -297,10 +299,10 @@ class FusedEngine:
   def _flush_jobs(self, stream):
     from ._lib import RkAdamJob
     jobs, self._jobs = self._jobs, []
-    for i in range(0, len(jobs), 6):
-      chunk = jobs[i:i + 6]
+    for i in range(0, len(jobs), ADAM_MULTI_MAX):
+      chunk = jobs[i:i + ADAM_MULTI_MAX]
       arr = (RkAdamJob * len(chunk))(*chunk)
-      pend = self._pending_loss if i + 6 >= len(jobs) else None
+      pend = self._pending_loss if i + ADAM_MULTI_MAX >= len(jobs) else None
       if pend is not None:
         # the deferred reduction of the step's loss partials rides on the sweep (as in rk_ae_train_step)
         n_part, denom, out = pend
