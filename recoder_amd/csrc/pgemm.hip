@@ -42,7 +42,9 @@ inline int dz_splits_for(int B, int h, int bm, int bn) {
   return std::min(64, std::max(1, s));
 }
 inline void dz_tile(int B, int h, int &bm, int &bn) {
-  bn = h <= 128 ? 128 : 256;
+  // (below 1024 rows 128 x 128 with twice the split-K: C5-shaped at B = 500, h = 512: 83 vs 103 us stand-alone
+  // -- profiles/r04_pgemm_probe.txt c5b500 dZ cfg 1 / cfg 2 -- and 0.736 vs 0.756 ms per step)
+  bn = (h <= 128 || B < 1024) ? 128 : 256;
   bm = B >= 1024 ? 256 : 128;
 }
 inline void dw_tile(int B, int h, int n_cap, int &bm, int &bn) {
