@@ -437,3 +437,36 @@ def test_dw_and_dz_reduce_in_one_launch_equal_the_two_launches(B, h, n_items, ac
     want = dz_ws.view(n_tiles, B * h)[:live].double().sum(0)
     if not zact:
       assert torch.allclose(a[2].double(), want, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,h,n_items,row_off", [(2500, 64, 9000, 0), (2100, 32, 6000, 37), (700, 64, 5000, 0)])
+def test_encoder_backward_over_row_windows(B, h, n_items, row_off):
+  """rk_ae_encode_bwd on a row window of more than 2048 rows over a long item set: the wave-per-column
+  kernel once per window of <= 2016 rows, accumulating (csrc/encoder.hip) -- G_en[c] = sum_r svals[r, c] dZ[r]
+  and gb_en = column sums of dZ against float64."""
+  S = B + row_off
+  lib, blk, W, bias, Z, ranges, pl, buf = _setup(S, h, S, n_items, 6, seed=B + h)
+  st = current_stream()
+  dev = Z.device
+  f = dict(dtype=torch.float32, device=dev)
+  n_b, nnz, ld, _ = blk.counts_host()
+  assert blk.n_cap >= 4096 or B <= 2048
+  g = torch.Generator(device=dev)
+  g.manual_seed(B)
+  dZ0 = torch.randn(B, h, generator=g, **f) * 1e-2
+  blk.svals[:nnz].copy_(torch.rand(nnz, generator=g, **f))
+  G_en = torch.full((blk.n_cap * h,), 3.0, **f)
+  gb = torch.full((h * 8,), 3.0, **f)
+  check(lib.rk_ae_encode_bwd(blk.ref, row_off, B, ptr(dZ0), h, ptr(G_en), 0, ptr(gb), st))
+  torch.cuda.synchronize()
+  indptr = blk.indptr[:S + 1].cpu().numpy()
+  cols = blk.cols[:nnz].cpu().numpy()
+  sv = blk.svals[:nnz].double().cpu().numpy()
+  dz = dZ0.double().cpu().numpy()
+  want = np.zeros((n_b, h))
+  for r in range(B):
+    lo, hi = indptr[row_off + r], indptr[row_off + r + 1]
+    np.add.at(want, cols[lo:hi], sv[lo:hi, None] * dz[r][None, :])
+  got = G_en[:n_b * h].view(n_b, h).double().cpu().numpy()
+  assert np.abs(got - want).max() <= 1e-6 * max(np.abs(want).max(), 1e-30)
+  assert np.abs(gb[:h].double().cpu().numpy() - dz.sum(0)).max() <= 1e-5 * np.abs(dz).sum(0).max()
