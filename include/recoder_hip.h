@@ -111,7 +111,8 @@ typedef struct rk_block {
   uint32_t *bits_rc;  /* [S_cap][ldw_rc] bit (r,c) set iff (r,c) stored */
   uint32_t *bits_cr;  /* [n_cap][ldw_cr] transposed bitmap; NULL = not built
                          (inference-only blocks) */
-  int32_t *scan_tmp;  /* [n_chunks+1] */
+  int32_t *scan_tmp;  /* [2 * (n_chunks + 1)], 8-byte aligned: per-chunk counts (large catalogues) / 64-bit
+                         {stamp, count} slots of the batched collation's look-back scan (<= 64 k items) */
   int32_t *pref_rc;   /* [S_cap][ldw_rc] exclusive prefix popcount of bits_rc per row:
                          entry index of (r,c) = indptr[r] + pref_rc[r][c>>5]
                          + popc(bits_rc[r][c>>5] & ((1<<(c&31))-1)) */

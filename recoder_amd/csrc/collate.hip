@@ -330,6 +330,86 @@ __global__ __launch_bounds__(1024) void collate_scan_small_multi_kernel(int all,
   collate_scan_small_body(b.mark, b.n_items, 1, all, b.pos, b.items, b.counts, b.n_cap, b.nnz_cap, cur);
 }
 
+// ---- scan (small catalogues, batched collation): count + assign of a 2048-item chunk in ONE workgroup, the
+// chunks of a block chained by a decoupled look-back -- every workgroup publishes {stamp, marked items of its
+// chunk} in its 64-bit slot of scan_tmp and adds up the slots in front of it (they belong to workgroups
+// dispatched before it; agent-scope atomics: the slots cross XCDs within the launch).  n_chunks x n_blk light
+// workgroups instead of n_blk workgroups of 1024 threads that hold a CU for 17-30 us each.
+__global__ __launch_bounds__(256) void collate_scan_lb_multi_kernel(int all, MultiBlk mb, rk_cur_t cur) {
+  __shared__ int32_t wsum[4];
+  __shared__ int32_t base_s;
+  cur.off += (int)blockIdx.y;
+  const rk_block_t &b = mb.b[blockIdx.y];
+  const int32_t stamp = rk_cur_stamp(cur);
+  const int c = (int)blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int n_items = b.n_items;
+  unsigned long long *slots = reinterpret_cast<unsigned long long *>(b.scan_tmp);
+  const int it0 = c * RK_SCAN_CHUNK + tid * 8;
+  int32_t mk[8];
+  if (it0 + 7 < n_items) {
+    const int4 m0 = *reinterpret_cast<const int4 *>(b.mark + it0), m1 = *reinterpret_cast<const int4 *>(b.mark + it0 + 4);
+    mk[0] = m0.x; mk[1] = m0.y; mk[2] = m0.z; mk[3] = m0.w; mk[4] = m1.x; mk[5] = m1.y; mk[6] = m1.z; mk[7] = m1.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) mk[k] = it0 + k < n_items ? b.mark[it0 + k] : 0;
+  }
+  uint32_t f = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (it0 + k < n_items && (all || mk[k] == stamp)) f |= 1u << k;
+  const int32_t local = __popc(f);
+  int32_t x = local;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int32_t y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) wsum[wid] = x;
+  __syncthreads();
+  const int32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  if (tid == 0)
+    __hip_atomic_store(slots + c, ((unsigned long long)(uint32_t)stamp << 32) | (uint32_t)total, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  // look-back: the chunks in front of this one (at most 31: one wave)
+  if (wid == 0) {
+    int32_t v = 0;
+    if (lane < c) {
+      unsigned long long s;
+      do {
+        s = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(s >> 32) != (uint32_t)stamp) __builtin_amdgcn_s_sleep(1);
+      } while ((uint32_t)(s >> 32) != (uint32_t)stamp);
+      v = (int32_t)(uint32_t)s;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) base_s = v;
+  }
+  __syncthreads();
+  const int32_t base_cnt = base_s;
+  int32_t woff = 0;
+  for (int w = 0; w < wid; ++w) woff += wsum[w];
+  int32_t p = base_cnt + woff + x - local;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int it = it0 + k;
+    if (it < n_items) {
+      if ((f >> k) & 1u) {
+        if (p < b.n_cap) { b.pos[it] = p; b.items[p] = it; } else { b.pos[it] = -1; }
+        ++p;
+      } else {
+        b.pos[it] = -1;
+      }
+    }
+  }
+  if (c == (int)gridDim.x - 1 && tid == 0) {
+    const int32_t n_all = base_cnt + total, n_b = min(n_all, b.n_cap);      // (see collate_assign_kernel)
+    b.counts[0] = n_b;
+    b.counts[2] = (n_b + 31) & ~31;
+    b.counts[5] = n_all > b.n_cap ? n_all : 0;
+  }
+}
+
 // ---- build: one wave per sampled row -- relabelled columns, values, the row's
 //      bitmap words + their exclusive prefix popcounts (assembled in LDS and
 //      written out whole: bits_rc needs no clearing), transposed-bitmap bits ----
@@ -571,8 +651,9 @@ extern "C" int rk_collate_at_multi(const int64_t *ds_indptr, const int32_t *ds_i
   }
   if (phase == 1) return 0;
   if (b0->n_items <= SMALL_SCAN_MAX) {
-    RK_LAUNCH(collate_scan_small_multi_kernel, dim3(n_blk), dim3(1024), 0, stream, all, mb, cur);
-    RK_CHECK_LAUNCH("collate_scan_small_multi");
+    // (<= 32 chunks: the look-back fits one wave; scan_tmp holds 64-bit slots -- rk_block_t.scan_tmp)
+    RK_LAUNCH(collate_scan_lb_multi_kernel, dim3(b0->n_chunks, n_blk), dim3(256), 0, stream, all, mb, cur);
+    RK_CHECK_LAUNCH("collate_scan_lb_multi");
   } else {
     RK_LAUNCH(collate_count_multi_kernel, dim3(b0->n_chunks, n_blk), dim3(256), 0, stream, all, mb, cur);
     RK_CHECK_LAUNCH("collate_count_multi");

@@ -170,7 +170,7 @@ class Block:
     self.bits_rc = torch.zeros(S_cap * self.ldw_rc, **i32)
     # the transposed bitmap is only needed by the encoder backward (training)
     self.bits_cr = torch.zeros(self.n_cap * self.ldw_cr, **i32) if need_bits_cr else None
-    self.scan_tmp = torch.zeros(self.n_chunks + 1, **i32)
+    self.scan_tmp = torch.zeros(2 * (self.n_chunks + 1), **i32)      # (64-bit slots: rk_block_t.scan_tmp)
     self.pref_rc = torch.zeros(S_cap * self.ldw_rc, **i32)
     self.gcols = torch.zeros(nnz_cap, **i32)
     self.stamp = 0
