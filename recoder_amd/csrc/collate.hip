@@ -413,29 +413,21 @@ __global__ __launch_bounds__(256) void collate_scan_lb_multi_kernel(int all, Mul
 // ---- build: one wave per sampled row -- relabelled columns, values, the row's
 //      bitmap words + their exclusive prefix popcounts (assembled in LDS and
 //      written out whole: bits_rc needs no clearing), transposed-bitmap bits ----
-__device__ __forceinline__ void collate_build_body(
-    const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
-    const float *__restrict__ ds_data, const int64_t *__restrict__ users, int S, const rk_block_t &b,
-    rk_cur_t cur, const int seg) {
-  extern __shared__ uint32_t wbits[];               // [4 waves][seg words]
-  if (cur.cursor) users += rk_cur_local(cur) * S;
-  const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + wid;
-  if (row >= S) return;
-  const int64_t u = users[row];
-  const int64_t beg = ds_indptr[u];
-  int n = (int)(ds_indptr[u + 1] - beg);
-  const int out0 = b.indptr[row];
-  const int wr = (b.counts[0] + 31) >> 5;          // bitmap words in use
-  n = min(n, b.indptr[row + 1] - out0);            // (the clamped range of a truncated block)
-  // (four entries per lane and round: the item ids, then their positions, are fetched as independent loads --
-  // a 3 000-entry row was 47 rounds of ids -> positions -> stores one after the other, the tail of the launch)
-  for (int k0 = 0; k0 < n; k0 += 256) {
+// entries of rows past this go to all four waves of the row's workgroup (below)
+constexpr int BUILD_HEAVY = 512;
+
+// one row's entries k = first, first + stride, ... (four per thread and round: the item ids, then their
+// positions, are fetched as independent loads -- a 3 000-entry row was 47 rounds of ids -> positions -> stores
+// one after the other, the tail of the launch)
+__device__ __forceinline__ void build_entries(const rk_block_t &b, const int32_t *__restrict__ ds_indices,
+                                              const float *__restrict__ ds_data, const int64_t beg, const int n,
+                                              const int out0, const int row, const int first, const int stride) {
+  for (int k0 = first; k0 < n; k0 += 4 * stride) {
     int32_t gi[4], c[4];
     float val[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int k = k0 + u * 64 + lane;
+      const int k = k0 + u * stride;
       gi[u] = k < n ? ds_indices[beg + k] : -1;
       val[u] = (k < n && ds_data) ? ds_data[beg + k] : 1.0f;
     }
@@ -443,7 +435,7 @@ __device__ __forceinline__ void collate_build_body(
     for (int u = 0; u < 4; ++u) c[u] = gi[u] >= 0 ? b.pos[gi[u]] : -1;   // (< 0 only in a truncated block, counts[5] != 0)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int k = k0 + u * 64 + lane;
+      const int k = k0 + u * stride;
       if (k < n) {
         b.cols[out0 + k] = max(c[u], 0);
         if (b.gcols) b.gcols[out0 + k] = gi[u];
@@ -452,52 +444,107 @@ __device__ __forceinline__ void collate_build_body(
       }
     }
   }
-  uint32_t *wb = wbits + wid * seg;
-  uint32_t *bits = b.bits_rc + (int64_t)row * b.ldw_rc;
-  int32_t *pref = b.pref_rc ? b.pref_rc + (int64_t)row * b.ldw_rc : nullptr;
-  int32_t carry = 0;
-  for (int w0 = 0; w0 < wr; w0 += seg) {
-    const int nw = min(seg, wr - w0);
-    for (int w = lane; w < nw; w += 64) wb[w] = 0u;
-    __builtin_amdgcn_wave_barrier();
-    for (int k0 = 0; k0 < n; k0 += 256) {
-      int32_t c[4];
+}
+// the row's bits of bitmap words [w0, w0 + nw) into the LDS segment wb (positions looked up again: the cols this
+// pass could read back were written by other threads of the workgroup when the row is shared)
+__device__ __forceinline__ void build_bits(const rk_block_t &b, const int32_t *__restrict__ ds_indices, const int64_t beg,
+                                           const int n, uint32_t *wb, const int w0, const int nw, const int first,
+                                           const int stride) {
+  for (int k0 = first; k0 < n; k0 += 4 * stride) {
+    int32_t gi[4], c[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int k = k0 + u * 64 + lane;
-        c[u] = k < n ? b.cols[out0 + k] : -1;       // (written above by this wave; a truncated entry holds 0 for
-      }                                             //  position < 0: re-read the position for those blocks)
-      if (b.counts[5] != 0) {
+    for (int u = 0; u < 4; ++u) gi[u] = k0 + u * stride < n ? ds_indices[beg + k0 + u * stride] : -1;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int k = k0 + u * 64 + lane;
-          c[u] = k < n ? b.pos[ds_indices[beg + k]] : -1;
-        }
-      }
+    for (int u = 0; u < 4; ++u) c[u] = gi[u] >= 0 ? b.pos[gi[u]] : -1;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int w = (c[u] >> 5) - w0;
-        if (c[u] >= 0 && w >= 0 && w < nw) atomicOr(&wb[w], 1u << (c[u] & 31));
-      }
+    for (int u = 0; u < 4; ++u) {
+      const int w = (c[u] >> 5) - w0;
+      if (c[u] >= 0 && w >= 0 && w < nw) atomicOr(&wb[w], 1u << (c[u] & 31));
     }
-    __builtin_amdgcn_wave_barrier();
-    for (int wq = 0; wq < nw; wq += 64) {
-      const int w = wq + lane;
-      const uint32_t word = (w < nw) ? wb[w] : 0u;
-      const int32_t c = __popc(word);
-      int32_t x = c;
+  }
+}
+// words [w0, w0 + nw) of the row's bitmap + their exclusive prefix popcounts, by ONE wave
+__device__ __forceinline__ void build_words(const uint32_t *wb, const int w0, const int nw, uint32_t *bits, int32_t *pref,
+                                            int32_t &carry, const int lane) {
+  for (int wq = 0; wq < nw; wq += 64) {
+    const int w = wq + lane;
+    const uint32_t word = (w < nw) ? wb[w] : 0u;
+    const int32_t c = __popc(word);
+    int32_t x = c;
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        int32_t y = __shfl_up(x, off, 64);
-        if (lane >= off) x += y;
-      }
-      if (w < nw) {
-        bits[w0 + w] = word;
-        if (pref) pref[w0 + w] = carry + x - c;
-      }
-      carry += __shfl(x, 63, 64);
+    for (int off = 1; off < 64; off <<= 1) {
+      int32_t y = __shfl_up(x, off, 64);
+      if (lane >= off) x += y;
     }
-    __builtin_amdgcn_wave_barrier();
+    if (w < nw) {
+      bits[w0 + w] = word;
+      if (pref) pref[w0 + w] = carry + x - c;
+    }
+    carry += __shfl(x, 63, 64);
+  }
+}
+
+__device__ __forceinline__ void collate_build_body(
+    const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
+    const float *__restrict__ ds_data, const int64_t *__restrict__ users, int S, const rk_block_t &b,
+    rk_cur_t cur, const int seg) {
+  extern __shared__ uint32_t wbits[];               // [4 waves][seg words]
+  __shared__ int heavy_n[4];
+  if (cur.cursor) users += rk_cur_local(cur) * S;
+  const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
+  const int row = blockIdx.x * 4 + wid;
+  const bool live = row < S;
+  const int wr = (b.counts[0] + 31) >> 5;          // bitmap words in use
+  int64_t beg = 0;
+  int n = 0, out0 = 0;
+  if (live) {
+    const int64_t u = users[row];
+    beg = ds_indptr[u];
+    n = (int)(ds_indptr[u + 1] - beg);
+    out0 = b.indptr[row];
+    n = min(n, b.indptr[row + 1] - out0);          // (the clamped range of a truncated block)
+  }
+  // a wave per row; rows past BUILD_HEAVY entries wait for all four waves (the launch was as long as its
+  // longest row: 12 rounds of dependent loads for 3 000 entries on one wave, 3 on four)
+  const bool heavy = live && n > BUILD_HEAVY;
+  if (lane == 0) heavy_n[wid] = heavy ? 1 : 0;
+  if (live && !heavy) {
+    build_entries(b, ds_indices, ds_data, beg, n, out0, row, lane, 64);
+    uint32_t *wb = wbits + wid * seg;
+    int32_t carry = 0;
+    for (int w0 = 0; w0 < wr; w0 += seg) {
+      const int nw = min(seg, wr - w0);
+      for (int w = lane; w < nw; w += 64) wb[w] = 0u;
+      __builtin_amdgcn_wave_barrier();
+      build_bits(b, ds_indices, beg, n, wb, w0, nw, lane, 64);
+      __builtin_amdgcn_wave_barrier();
+      build_words(wb, w0, nw, b.bits_rc + (int64_t)row * b.ldw_rc,
+                  b.pref_rc ? b.pref_rc + (int64_t)row * b.ldw_rc : nullptr, carry, lane);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  for (int j = 0; j < 4; ++j) {
+    if (heavy_n[j] == 0) continue;                   // (uniform)
+    const int rj = blockIdx.x * 4 + j;
+    const int64_t u = users[rj];
+    const int64_t bj = ds_indptr[u];
+    const int oj = b.indptr[rj];
+    const int nj = min((int)(ds_indptr[u + 1] - bj), b.indptr[rj + 1] - oj);
+    build_entries(b, ds_indices, ds_data, bj, nj, oj, rj, tid, 256);
+    uint32_t *wb = wbits + j * seg;
+    int32_t carry = 0;
+    for (int w0 = 0; w0 < wr; w0 += seg) {
+      const int nw = min(seg, wr - w0);
+      for (int w = tid; w < nw; w += 256) wb[w] = 0u;
+      __syncthreads();
+      build_bits(b, ds_indices, bj, nj, wb, w0, nw, tid, 256);
+      __syncthreads();
+      if (wid == 0)
+        build_words(wb, w0, nw, b.bits_rc + (int64_t)rj * b.ldw_rc,
+                    b.pref_rc ? b.pref_rc + (int64_t)rj * b.ldw_rc : nullptr, carry, lane);
+      __syncthreads();
+    }
   }
 }
 __global__ __launch_bounds__(256) void collate_build_kernel(
