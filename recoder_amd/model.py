@@ -72,7 +72,7 @@ class Recoder(object):
     # steps collated per side-stream hand-over (CollatePrefetcher)
     self.prefetch_group = 4
     # steps per replayed HIP graph (graph.py)
-    self.graph_group = int(os.environ.get("RK_GRAPH_GROUP", "4"))
+    self.graph_group = int(os.environ.get("RK_GRAPH_GROUP", "8"))
     # {global step index: callable}: called right before that step's collation is submitted and
     # its kernels are enqueued (the pipeline is cut there: nothing of the step is in flight yet);
     # returning True ends the training.  bench.py brackets its timed region with two of these.
