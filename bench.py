@@ -88,7 +88,8 @@ KERNELS = {"rk_ae_encode_fwd": ["ae_encode_fwd_kernel (+ the W_de[items] split w
            "rk_pg_decode_mnll": ["pg::gemm_kernel<..,EpiStats>", "pg::gemm_kernel<..,EpiLoss<MNLL>>"],
            "rk_pg_dz": ["pg::gemm_kernel<..,EpiSlab> (dO image x W image read along its rows)", "splitk_reduce_kernel"],
            "rk_pg_dw": ["pg::gemm_kernel<..,EpiSlab> (both operands read along their rows)"],
-           "rk_pg_dw_encode_bwd": ["dw_encbwd_kernel (pg dW tiles || encoder-backward columns)"]}
+           "rk_pg_dw_encode_bwd": ["dw_encbwd_kernel (pg dW tiles || encoder-backward columns)"],
+           "rk_fdec_loss_dz": ["fdec_kernel<KT,LOSS> (decode + loss + dZ partials, register resident)"]}
 
 CONFIGS = {
   # C2 of BASELINE.json: ML-20M autoencoder, hidden [200], MSE, 1 x MI355X
@@ -193,7 +194,7 @@ def entry_work(entry, B, h0, n_b, nnz, n_items, cfg):
     return "mfma", 2.0 * B * h0 * n_b / 1e12, "TFLOP/s"
   if entry == "rk_pg_decode_mnll":              # the decode twice: statistics pass + decode / loss pass
     return "mfma", 4.0 * B * h0 * n_b / 1e12, "TFLOP/s"
-  if entry == "rk_decode_loss_dz_planes":       # decode + loss + the dZ partials of every column tile
+  if entry in ("rk_decode_loss_dz_planes", "rk_fdec_loss_dz"):   # decode + loss + the dZ partials of every column tile
     return "mfma", 4.0 * B * h0 * n_b / 1e12, "TFLOP/s"
   if entry == "rk_decode_dz_reduce":            # the column-tile slabs summed
     return "hbm", (-(-int(n_b) // 128) * B * h0 * 4 + 2 * B * h0 * 4) / 1e9, "GB/s"
@@ -658,7 +659,8 @@ def main():
       # (the steps that really went through the bracketed calls: with graph replay only the eagerly
       # sequenced ones behind the sampling mark do; the decode runs exactly once per step)
       n_sampled = max(1, next((T["entries"][e][0] for e in ("rk_decode_loss", "rk_decode_loss_dz_planes",
-                                                            "rk_decode_loss_planes") if e in T["entries"]),
+                                                            "rk_fdec_loss_dz", "rk_decode_loss_planes",
+                                                            "rk_pg_decode_loss", "rk_pg_decode_mnll") if e in T["entries"]),
                               n_sample))
       for e, (calls, ms) in sorted(T["entries"].items(), key=lambda kv: -kv[1][0] * kv[1][1]):
         per_step = calls / float(n_sampled)

@@ -429,7 +429,9 @@ int rk_pg_dz(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc,
              const rk_planes_t *pl, const rk_block_t *tgt, const float *Zact /* nullable */, int32_t act,
              float *dZ, float *workspace, void *stream);
 int rk_pg_dw(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
-             const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, void *stream);
+             const rk_planes_t *pl, const rk_block_t *tgt, float *slabs,
+             float *gb_de /* nullable: the decoder bias gradient [n_t] = column sums of dO, from the image, by a
+                             second workgroup range of the launch */, void *stream);
 /* rk_pg_dw || rk_ae_encode_bwd (G_en, gb_en as there; nothing accumulated) in ONE launch: the dW tiles
  * first in the grid, then a wave per item column (domain: rk_plan_t.dw_encode_bwd_fused_ok) */
 int rk_pg_dw_encode_bwd(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,

@@ -177,7 +177,7 @@ SIGNATURES = {
   "rk_pg_decode_mnll": (c_int32, [POINTER(RkPlanes), c_int32, _BLK, c_int32, _P, c_float, _P, _P, c_int32, _P, _P, _P,
                                   _P, _P]),
   "rk_pg_dz": (c_int32, [_P, _P, c_int32, c_int32, c_int32, POINTER(RkPlanes), _BLK, _P, c_int32, _P, _P, _P]),
-  "rk_pg_dw": (c_int32, [_P, _P, c_int32, c_int32, c_int32, POINTER(RkPlanes), _BLK, _P, _P]),
+  "rk_pg_dw": (c_int32, [_P, _P, c_int32, c_int32, c_int32, POINTER(RkPlanes), _BLK, _P, _P, _P]),
   "rk_pg_dw_encode_bwd": (c_int32, [_P, _P, c_int32, c_int32, c_int32, POINTER(RkPlanes), _BLK, _P, c_int32, _P, _P, _P,
                                     _P, _P]),
   "rk_split_planes_t": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),

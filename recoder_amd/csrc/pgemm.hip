@@ -299,8 +299,8 @@ static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, in
                       void *stream_, float *gb_de = nullptr, bool dense = false);
 
 extern "C" int rk_pg_dw(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
-                        const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, void *stream_) {
-  return pg_dw_impl(dO_img, dO_scales, gr, gc, B, pl, tgt, slabs, nullptr, stream_);
+                        const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, float *gb_de, void *stream_) {
+  return pg_dw_impl(dO_img, dO_scales, gr, gc, B, pl, tgt, slabs, nullptr, stream_, gb_de);
 }
 
 // rk_pg_dw as ONE dense array G_de[n_cap][h] (no split-K: the data-parallel exchange ships it) + the

@@ -567,7 +567,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       RK_TRY(rk_stream_wait_event(a->dw_stream, a->dw_fork));
       {
         Timer t(a, RK_ENTRY_DECODE_BWD_DW, a->dw_stream);
-        if (pg) RK_TRY(rk_pg_dw(a->dO, a->do_scales, 64, 32, B, a->planes, blk, a->ws_dw, a->dw_stream));
+        if (pg) RK_TRY(rk_pg_dw(a->dO, a->do_scales, 64, 32, B, a->planes, blk, a->ws_dw, nullptr, a->dw_stream));
         else RK_TRY(dw_call(a, nullptr, nullptr, planes, a->ws_dw, a->dw_stream));
       }
       if (!de_side) {
@@ -579,7 +579,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       // its own K slabs, which rk_adam_multi sums while it reads the gradient)
       {
         Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
-        if (pg) RK_TRY(rk_pg_dw(a->dO, a->do_scales, 64, 32, B, a->planes, blk, a->ws, sm));
+        if (pg) RK_TRY(rk_pg_dw(a->dO, a->do_scales, 64, 32, B, a->planes, blk, a->ws, nullptr, sm));
         else RK_TRY(dw_call(a, nullptr, nullptr, planes));
       }
       Timer t(a, RK_ENTRY_ENCODE_BWD, sm);

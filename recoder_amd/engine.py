@@ -933,7 +933,7 @@ class FusedEngine:
       if getattr(self, "_dz_pg", False):
         assert keep_slabs and gb_de is None and red is None
         check(self.lib.rk_pg_dw(ptr(self.dO), ptr(self.do_scales), 64, 32, B, ctypes.byref(self.planes), blk.ref,
-                                ptr(ws), stream), "rk_pg_dw")
+                                ptr(ws), None, stream), "rk_pg_dw")
         self._pg_step = True
       elif self.lib.rk_dw_pairs():
         # (Z^T pair planes already at the head of this workspace: rk_split_wz of this step's decode)

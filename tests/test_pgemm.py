@@ -96,7 +96,7 @@ def test_pg_decode_dz_dw(B, h, n_items, loss, ratings):
   # ---- dW = dO^T . Z as K slabs ----
   ns = lib.rk_pg_dw_splits(B, h, blk.n_cap)
   slabs = torch.full((lib.rk_pg_dw_workspace_bytes(B, h, blk.n_cap) // 4,), float("nan"), **f)
-  check(lib.rk_pg_dw(ptr(img), ptr(sc), gr, gc, B, ctypes.byref(pl), blk.ref, ptr(slabs), st))
+  check(lib.rk_pg_dw(ptr(img), ptr(sc), gr, gc, B, ctypes.byref(pl), blk.ref, ptr(slabs), None, st))
   torch.cuda.synchronize()
   live = int(blk.counts[4].item())
   assert 1 <= live <= ns
@@ -139,7 +139,7 @@ def test_pg_scales_follow_the_data():
   check(lib.rk_pg_dz(ptr(img), ptr(sc), 64, 32, B, ctypes.byref(pl), blk.ref, None, 0, ptr(dZ), ptr(ws), st))
   ns = lib.rk_pg_dw_splits(B, h, blk.n_cap)
   slabs = torch.zeros(lib.rk_pg_dw_workspace_bytes(B, h, blk.n_cap) // 4, **f)
-  check(lib.rk_pg_dw(ptr(img), ptr(sc), 64, 32, B, ctypes.byref(pl), blk.ref, ptr(slabs), st))
+  check(lib.rk_pg_dw(ptr(img), ptr(sc), 64, 32, B, ctypes.byref(pl), blk.ref, ptr(slabs), None, st))
   torch.cuda.synchronize()
   Wt = W[items].double()
   e1 = ((dZ.view(B, h).double() - got @ Wt).abs() / (got.abs() @ Wt.abs() + 1e-300)).max().item()
@@ -254,13 +254,17 @@ def test_fdec_matches_the_lds_fused_decode(B, h, n_items, loss, ratings):
   # ... and rk_pg_dw reads that image (granule 32 x 64)
   ns = lib.rk_pg_dw_splits(B, h, blk.n_cap)
   slabs = torch.full((lib.rk_pg_dw_workspace_bytes(B, h, blk.n_cap) // 4,), float("nan"), **f)
-  check(lib.rk_pg_dw(ptr(img), ptr(sc), 32, 64, B, ctypes.byref(pl), blk.ref, ptr(slabs), st))
+  gbd = torch.full((blk.n_cap,), 7.0, **f)
+  check(lib.rk_pg_dw(ptr(img), ptr(sc), 32, 64, B, ctypes.byref(pl), blk.ref, ptr(slabs), ptr(gbd), st))
   torch.cuda.synchronize()
   live = int(blk.counts[4].item())
   G = slabs.view(ns, blk.n_cap, h)[:live, :n_b].double().sum(0)
   ex = ref.double().t() @ Z.double()
   e_dw = ((G - ex).abs() / (ref.double().abs().t() @ Z.double().abs() + 1e-300)).max().item()
   assert e_dw < 6e-7, e_dw
+  # ... and sums its columns (the decoder bias gradient) in a second workgroup range
+  cs = ref.double().sum(0)
+  assert (gbd[:n_b].double() - cs).abs().max().item() <= 2e-6 * max(ref.double().abs().sum(0).max().item(), 1e-30)
 
 
 def test_fdec_scale_table_has_no_write_past_the_capacity():

@@ -80,8 +80,8 @@ def main():
   print("rk_decode_dz_reduce alone: %.1f us" % timeit(lambda: check(lib.rk_decode_dz_reduce(
       ptr(ws), B, h, blk.ref, ptr(Z), 1, ptr(dZ), st))))
   print("rk_pg_dw alone (dW tiles from the image): %.1f us, hot %.1f us" % (timeit(lambda: check(lib.rk_pg_dw(
-      ptr(img), ptr(sc), 32, 64, B, ctypes.byref(pl), blk.ref, ptr(slabs), st))), timeit(lambda: check(lib.rk_pg_dw(
-      ptr(img), ptr(sc), 32, 64, B, ctypes.byref(pl), blk.ref, ptr(slabs), st)), flush_first=False)))
+      ptr(img), ptr(sc), 32, 64, B, ctypes.byref(pl), blk.ref, ptr(slabs), None, st))), timeit(lambda: check(lib.rk_pg_dw(
+      ptr(img), ptr(sc), 32, 64, B, ctypes.byref(pl), blk.ref, ptr(slabs), None, st)), flush_first=False)))
   print("rk_ae_encode_bwd alone: %.1f us" % timeit(lambda: check(lib.rk_ae_encode_bwd(
       blk.ref, 0, B, ptr(dZ), h, ptr(G_en), 0, ptr(gb_en), st))))
   print("rk_pg_dw_encode_bwd (dW || encoder backward): %.1f us" % timeit(lambda: check(lib.rk_pg_dw_encode_bwd(
