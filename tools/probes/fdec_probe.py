@@ -29,8 +29,11 @@ def main():
   g = torch.Generator(device=dev); g.manual_seed(1)
   W = torch.randn(n_items, h, generator=g, **f) * 0.07
   bias = torch.randn(n_items, generator=g, **f) * 0.02
-  users = torch.from_numpy(np.random.RandomState(0).permutation(csr.shape[0])[:B]).to(dev)
-  blk = Block(B, int(np.sort(dcsr.degrees)[-B:].sum()), n_items, dev)
+  # argv[3]: users collated into the block (default B); more than B = the union item set of a data-parallel
+  # step (B rows of this rank against the items of all ranks' users)
+  S = int(sys.argv[3]) if len(sys.argv) > 3 else B
+  users = torch.from_numpy(np.random.RandomState(0).permutation(csr.shape[0])[:S]).to(dev)
+  blk = Block(S, int(np.sort(dcsr.degrees)[-S:].sum()), n_items, dev)
   blk.collate(dcsr, users)
   Z = torch.tanh(torch.randn(B, h, generator=g, **f))
   ranges = torch.zeros(128, dtype=torch.int32, device=dev)
