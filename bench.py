@@ -360,6 +360,7 @@ def main():
                   help="per-launch brackets: sampled behind the clock (default) or inside the timed region")
   ap.add_argument("--no-precollate", action="store_true", help="first group's collation inside the timed region")
   ap.add_argument("--no-pretouch", action="store_true", help="no touch of the optimizer state in front of the clock")
+  ap.add_argument("--pretouch-reps", type=int, default=8, help="passes of that touch (~0.3 ms each)")
   ap.add_argument("--prewarm", type=float, default=0.0, help="seconds of untimed extra steps in front of the warmup")
   ap.add_argument("--alt", choices=("auto", "0", "1"), default="auto",
                   help="N > 1: also time the item-parallel alternative in a child run (auto: only with > 1 rank)")
@@ -503,10 +504,13 @@ def main():
     if not args.no_pretouch:
       # one read of the parameters and Adam moments: the first timed Adam sweep finds them where every
       # later one does (in the Infinity Cache behind the previous sweep), not cold behind the cut
-      for st in eng.states.values():
-        for t in (st.p, st.m, st.v):
-          if t is not None:
-            t.sum()
+      # -- repeated for ~2 ms, so that the clock starts on a chip at its working frequency (the start mark's
+      # host work leaves it idle for milliseconds: the first timed sweep then read 52 us instead of 39)
+      for _ in range(max(1, args.pretouch_reps)):
+        for st in eng.states.values():
+          for t in (st.p, st.m, st.v):
+            if t is not None:
+              t.sum()
     sync_all()
     T["t0"] = time.perf_counter()
     return False
@@ -621,17 +625,56 @@ def main():
     from recoder_amd import _lib as _rk_lib
     one_call = cfg["kind"] == "ae" and len(cfg["hidden_layers"]) == 1 and cfg["loss"] in ("mse", "logistic") \
         and getattr(eng, "ws_dw", None) is not None and not multi and getattr(eng, "planes", None) is not None
+    step_mode = int(getattr(eng, "_step_mode", 0))
     if one_call:
       lk = 0 if cfg["loss"] == "mse" else 1
       FUSED_DZ = bool(_rk_lib.load().rk_decode_dz_fused_ok(B, h0, eng.n_cap_last, lk))
       FUSED_DW_ENC = bool(_rk_lib.load().rk_dw_encode_bwd_fused_ok(0, B))
-      if FUSED_DZ:
-        KERNELS["rk_decode_loss"] = ["decode_planes_kernel<1,2,EPI,3,false,DZT> (decode + loss + dZ partials per column tile)"]
+      # the kernels the step DISPATCHED (rk_ae_step_uses_pg of the step that ran), named as rocprofv3
+      # --kernel-trace prints them (namespaces stripped)
+      kt, hv, pg_loss = -(-h0 // 32), -(-h0 // 256), 1 if cfg["loss"] == "mse" else 3
+      KERNELS["rk_ae_encode_fwd"] = ["ae_encode_fwd_kernel<1, 8> (user rows || the W_de[items] split workgroups)"]
+      if step_mode == 3:          # csrc/fdecode.hip + csrc/pgemm.hip
+        KERNELS["rk_decode_loss"] = ["fdec_kernel<%d, %d>" % (kt, pg_loss)]
         KERNELS["rk_decode_bwd_dz"] = ["splitk_reduce_kernel"]
-      if FUSED_DW_ENC:
-        KERNELS["rk_decode_bwd_dw"] = ["dw_encbwd_kernel<BN,HV> (dW tiles || encoder-backward columns)"]
+        KERNELS["rk_decode_bwd_dw"] = ["dw_encbwd_kernel<64, 128, 2, 2, %d> (csrc/pgemm.hip: dW tiles from the dO image || "
+                                       "its column sums || encoder-backward columns)" % hv]
+      elif step_mode == 1:        # csrc/pgemm.hip for all three contractions
+        KERNELS["rk_decode_loss"] = ["pg::gemm_kernel<.., pg::EpiLoss<%d>, ..>" % pg_loss]
+        KERNELS["rk_decode_bwd_dz"] = ["pg::gemm_kernel<.., pg::EpiSlab, ..>", "splitk_reduce_kernel"]
+        KERNELS["rk_decode_bwd_dw"] = ["pg::gemm_kernel<.., pg::EpiSlab, ..> (dW, side stream)"]
+      elif FUSED_DZ:              # csrc/decode16.hip + csrc/dw3.hip (rounds 2-3; plain-bf16 variant)
+        KERNELS["rk_decode_loss"] = ["decode_planes_kernel<1, 2, EPI, 3, false, DZT>"]
+        KERNELS["rk_decode_bwd_dz"] = ["splitk_reduce_kernel"]
+        if FUSED_DW_ENC:
+          KERNELS["rk_decode_bwd_dw"] = ["dw_encbwd_kernel<BN, HV> (csrc/dw3.hip)"]
     ADAM_DE_SIDE = bool(_rk_lib.load().rk_adam_de_side()) and getattr(eng, "ws_dw", None) is not None and \
         not multi and bool(timed.get("rk_adam_de") or T["warm"].get("rk_adam_de"))
+
+    pmc_file, pmc_entries = None, {}
+    if args.config == "c2" and not multi:
+      import glob
+      files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+      if files:
+        pmc_file = os.path.relpath(files[-1], ROOT)
+        pmc_entries = json.load(open(files[-1]))["entries"]
+
+    def alg_bytes(entry):
+      # algorithmic HBM bytes of one launch group, the figure PMC traffic is compared
+      # with -- also for the MFMA-bound groups, whose `achieved` is in flops
+      ld = -(-int(n_b) // 32) * 32
+      img = -(-h0 // 32) * 128                   # bytes of one plane-image row (fp16 hi | lo, K padded to 32)
+      slabs = -(-int(n_b) // 128) * B * h0 * 4
+      if entry == "rk_ae_encode_fwd":            # gathered rows + Z + its image (+ W_de[items] read and split)
+        return nnz * (h0 * 4 + 12) + B * h0 * 4 + B * img + (n_b * (h0 * 4 + img) if step_mode else 0)
+      if entry == "rk_decode_loss" and step_mode == 3:
+        return n_b * img + B * img + B * ld * 4 + slabs
+      if entry == "rk_decode_bwd_dz" and (step_mode == 3 or FUSED_DZ):
+        return slabs + 2 * B * h0 * 4
+      if entry == "rk_decode_bwd_dw" and step_mode == 3:
+        return nnz * (h0 * 4 + 8) + n_b * h0 * 4 + B * ld * 4 + B * img + n_b * h0 * 4
+      b, w_, u = algorithmic_work(entry, B, h0, n_b, nnz, n_items, bool(cfg["sparse"]))
+      return w_ * 1e9 if b == "hbm" else None
 
     def line(entry, ms_list, where):
       # median of the bracketed launches (the first bracketed call of a kernel includes its
@@ -642,9 +685,15 @@ def main():
       bound, work, unit = algorithmic_work(entry, B, h0, n_b, nnz, n_items, bool(cfg["sparse"]))
       peak = peak_of(entry, bound)
       ach = work / (ms * 1e-3) if ms > 0 else float("nan")
-      return dict(name=entry, kernels=KERNELS.get(entry, []), avg_us=ms * 1e3, samples=len(ms_list),
-                  sampled=where, bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak,
-                  ideal_us=work / peak * 1e6)
+      d = dict(name=entry, kernels=KERNELS.get(entry, []), avg_us=ms * 1e3, samples=len(ms_list),
+               sampled=where, bound=bound, achieved=ach, peak=peak, unit=unit, frac=ach / peak,
+               ideal_us=work / peak * 1e6)
+      ab = alg_bytes(entry)
+      pm = pmc_entries.get(entry, {}).get("hbm_bytes_per_launch")
+      d["algorithmic_bytes"] = ab
+      d["traffic"] = pm if pm else None          # (committed PMC passes of this command: roofline.traffic_source)
+      d["traffic_over_algorithmic"] = (pm / ab) if (pm and ab) else None
+      return d
     # every launch group of the production step: from the timed region where it was sampled there
     kernels = []
     for e in ENTRIES:
@@ -710,16 +759,12 @@ def main():
     # HBM bytes per launch from the committed rocprofv3 PMC passes of this same workload
     # (profiles/r*_pmc_traffic.json, tools/pmc_traffic.py); null for other configs
     traffic = traffic_source = None
-    if args.config == "c2" and not multi:
-      import glob
-      files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-      if files:
-        ent = json.load(open(files[-1]))["entries"].get(dominant.split("+")[0])
-        if ent:
-          traffic = ent["hbm_bytes_per_launch"]
-          traffic_source = ("%s: committed rocprofv3 PMC passes of this command (FETCH_SIZE / WRITE_SIZE in "
-                            "separate runs, tools/profile_round.sh) -- NOT collected in this run"
-                            % os.path.relpath(files[-1], ROOT))
+    if pmc_file:
+      ent = pmc_entries.get(dominant.split("+")[0])
+      if ent:
+        traffic = ent["hbm_bytes_per_launch"]
+        traffic_source = ("%s: committed rocprofv3 PMC passes of this command (FETCH_SIZE / WRITE_SIZE in "
+                          "separate runs, tools/profile_round.sh) -- NOT collected in this run" % pmc_file)
     # the dW launch group runs on the side stream NEXT to dZ -> encoder backward
     # (rk_ae_step_t.dw_stream): it is not a link of the step's chain then
     side = ["rk_decode_bwd_dw", "rk_adam_de"] if (getattr(eng, "ws_dw", None) is not None and not multi and
@@ -761,6 +806,10 @@ def main():
                  "graph_replay": bool(getattr(rec, "_graph_stepper", None) is not None),
                  "steps_per_graph": G, "bracketed_group_is_graph": bool(T.get("timed_graph")),
                  "kernel_brackets": SAMPLED,
+                 "pretouch": ("parameters + Adam moments read %d x in front of the clock (cache + clock warm)"
+                              % max(1, args.pretouch_reps)) if not args.no_pretouch else "none",
+                 "step_kernels": {0: "csrc/decode16.hip + dw3.hip", 1: "csrc/pgemm.hip",
+                                  3: "csrc/fdecode.hip + pgemm.hip dW"}.get(step_mode) if one_call else "per-entry sequencing",
                  "first_group_collation": ("in front of the clock; the look-ahead collation behind the last "
                                            "timed group runs inside it (one per group, as in steady state)")
                                           if T.get("precollated") else "inside the timed region, in front of step 0",

@@ -114,6 +114,12 @@ __global__ __launch_bounds__(256) void collate_phase1_multi_kernel(
     const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
     const int64_t *__restrict__ users, int S, int all, int nrow_blk, MultiBlk mb, rk_cur_t cur) {
   cur.off += (int)blockIdx.y;
+  // the look-back slots of this collation's scan (collate_scan_lb_multi_kernel) start EMPTY: a slot is
+  // valid once its chunk's workgroup of THIS launch set wrote it -- whatever stamp the previous collation
+  // of the block ran under (the stamp as the ready flag let a block collated twice with one
+  // stamp read the first run's totals)
+  if (blockIdx.x == 0 && (int)threadIdx.x < min(mb.b[blockIdx.y].n_chunks, 32))
+    reinterpret_cast<unsigned long long *>(mb.b[blockIdx.y].scan_tmp)[threadIdx.x] = 0ull;
   collate_phase1_body(ds_indptr, ds_indices, users, S, 1, all, nrow_blk, mb.b[blockIdx.y], cur);
 }
 
@@ -331,8 +337,8 @@ __global__ __launch_bounds__(1024) void collate_scan_small_multi_kernel(int all,
 }
 
 // ---- scan (small catalogues, batched collation): count + assign of a 2048-item chunk in ONE workgroup, the
-// chunks of a block chained by a decoupled look-back -- every workgroup publishes {stamp, marked items of its
-// chunk} in its 64-bit slot of scan_tmp and adds up the slots in front of it (they belong to workgroups
+// chunks of a block chained by a decoupled look-back -- every workgroup publishes {ready, marked items of its
+// chunk} in its 64-bit slot of scan_tmp (zeroed by phase 1 of the same collation) and adds up the slots in front of it (they belong to workgroups
 // dispatched before it; agent-scope atomics: the slots cross XCDs within the launch).  n_chunks x n_blk light
 // workgroups instead of n_blk workgroups of 1024 threads that hold a CU for 17-30 us each.
 __global__ __launch_bounds__(256) void collate_scan_lb_multi_kernel(int all, MultiBlk mb, rk_cur_t cur) {
@@ -367,9 +373,9 @@ __global__ __launch_bounds__(256) void collate_scan_lb_multi_kernel(int all, Mul
   if (lane == 63) wsum[wid] = x;
   __syncthreads();
   const int32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  constexpr unsigned long long READY = 1ull << 63;      // (phase 1 of this collation zeroed the slots)
   if (tid == 0)
-    __hip_atomic_store(slots + c, ((unsigned long long)(uint32_t)stamp << 32) | (uint32_t)total, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(slots + c, READY | (uint32_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // look-back: the chunks in front of this one (at most 31: one wave)
   if (wid == 0) {
     int32_t v = 0;
@@ -377,8 +383,8 @@ __global__ __launch_bounds__(256) void collate_scan_lb_multi_kernel(int all, Mul
       unsigned long long s;
       do {
         s = __hip_atomic_load(slots + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(s >> 32) != (uint32_t)stamp) __builtin_amdgcn_s_sleep(1);
-      } while ((uint32_t)(s >> 32) != (uint32_t)stamp);
+        if (!(s & READY)) __builtin_amdgcn_s_sleep(1);
+      } while (!(s & READY));
       v = (int32_t)(uint32_t)s;
     }
 #pragma unroll

@@ -22,6 +22,8 @@
 // k-major operands sit as [16][tile] and are read with ds_read_b32.
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include <type_traits>
 
 #include "common.h"
@@ -1071,7 +1073,10 @@ extern "C" int32_t rk_gemm_plain_bf16(void) {
 }
 
 extern "C" int64_t rk_dz_workspace_bytes(int32_t B, int32_t h) {
-  return (int64_t)dz_splits(B) * B * h * sizeof(float);
+  // (slabs x rows is not monotone in the batch size: cover every batch size up to the capacity)
+  int64_t rows = 0;
+  for (int b = 1; b <= B; ++b) rows = std::max(rows, (int64_t)dz_splits(b) * b);
+  return rows * h * (int64_t)sizeof(float);
 }
 
 // row segments of the encoder backward inside rk_decode_bwd_dw_encode_bwd (see encoder_bwd.h)

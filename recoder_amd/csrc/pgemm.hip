@@ -246,9 +246,15 @@ extern "C" int rk_pg_decode_mnll(const rk_planes_t *pl, int32_t B, const rk_bloc
 }
 
 extern "C" int64_t rk_pg_dz_workspace_bytes(int32_t B, int32_t h) {
-  int bm, bn;
-  dz_tile(B, h, bm, bn);
-  return (int64_t)dz_splits_for(B, h, bm, bn) * B * h * sizeof(float);
+  // the slab count is not monotone in the batch size (a ragged last batch of 1024 rows takes 64 slabs where
+  // 1100 rows take 51): the workspace of a capacity B covers every batch size up to it
+  int64_t rows = 0;
+  for (int b = 1; b <= B; ++b) {
+    int bm, bn;
+    dz_tile(b, h, bm, bn);
+    rows = std::max(rows, (int64_t)dz_splits_for(b, h, bm, bn) * b);
+  }
+  return rows * h * (int64_t)sizeof(float);
 }
 
 extern "C" int rk_pg_dz(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,

@@ -505,8 +505,7 @@ class FusedEngine:
                                          self.confidence, inv_B, ptr(self.dO), ptr(self.loss_part),
                                          ptr(self.gb_part), ptr(self.ws), stream), "rk_decode_loss_dz_planes")
       self._dz_in_ws = True
-    elif fuse_dz and pg_ok and ip is None and self._pg_entry_ok(B, tgt.n_cap) and \
-        True:
+    elif fuse_dz and pg_ok and ip is None and self._pg_entry_ok(B, tgt.n_cap):
       # outside the fused launch's domain: decode + loss, dZ and dW on the pipelined pair-plane kernels --
       # ONE split launch (W image unless the encoder forward cut it, Z image; no W^T image, no Z^T planes),
       # dLoss/dLogits as a plane image; the multinomial loss as a statistics pass + the decode / loss pass
@@ -524,8 +523,7 @@ class FusedEngine:
                                     self.confidence, inv_B, ptr(self.dO), self.do_rows, ptr(self.do_scales),
                                     None, ptr(self.loss_part), ptr(self.gb_part), stream), "rk_pg_decode_loss")
       self._dz_pg = True
-    elif fuse_dz and ip is None and self.planes is not None and self.split16 and self.item_parallel is None \
-        and True:
+    elif fuse_dz and ip is None and self.planes is not None and self.split16 and self.item_parallel is None:
       # outside the fused launch's domain (multinomial loss, h > 256, >= 1024 rows): still the plane
       # kernels -- ONE split launch, then the copy -> LDS -> MFMA decode; the dZ product follows on the
       # W^T image (rk_decode_bwd_dz_planes) where rk_decode_bwd_dz would split W_de in its k-loop again
@@ -644,10 +642,7 @@ class FusedEngine:
       # (the plane kernels will decode this block: its W_de[items] split can ride on the encoder forward)
       self._w_split_of = None
       self._split_w_with_fwd = (tgt is None and ip is None and self.planes is not None and self.split16 and
-                                self.item_parallel is None and not bool(m.is_constrained) and
-                                True and
-                                True and
-                                True)
+                                self.item_parallel is None and not bool(m.is_constrained))
       self._split_nowt = bool(self._split_w_with_fwd and self._pg_entry_ok(B, blk.n_cap) and
                               self.allreduce is None)
       z = self._ae_forward(blk, row_off, B, keep_noise, keep_drop, True, stream)
@@ -721,7 +716,7 @@ class FusedEngine:
       # gradient), so the reduce of the decode launch's dZ partials rides on the dW launch
       red = None
       if (self.kind != "ae" and getattr(self, "_dz_in_ws", False) and keep_slabs and dw_side is None and
-          ip is None and self.lib.rk_dw_pairs() and True):
+          ip is None and self.lib.rk_dw_pairs()):
         red = (self.ws, None if self.drop_active else self.enc[0], self.dbott)
       self._dw(z, B, tb, None, dw_stream, keep_slabs, red=red)
       if red is not None:
@@ -1098,6 +1093,7 @@ class FusedEngine:
       st.phase = STEP_ALL
       mode = int(raw.rk_ae_step_uses_pg(ctypes.byref(st)))
       self._pg_step = bool(mode)
+      self._step_mode = mode       # (0: decode16 / dw3 kernels, 1: csrc/pgemm.h, 3: csrc/fdecode.hip + pgemm's dW; bench.py names the kernels by it)
       check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
       if self.loss_id != LOSS_MNLL and mode != 3:
         self._gb_lazy = (cdiv(B, self.row_tile), blk)    # (mode 3: gb_de itself, from the dO image)

@@ -339,8 +339,7 @@ class GraphStepper:
     with or without the look-ahead collation (without: run() ends with that group).  bench.py calls
     this in front of its timed region; run() then replays it instead of enqueueing the bracketed
     group eagerly."""
-    if not self.warmed or False or \
-        not self.lib.rk_graph_timing_supported():
+    if not self.warmed or not self.lib.rk_graph_timing_supported():
       return False
     from ._lib import ENTRY
     self.eng.reserve_timing_events(2 * self.G * 2 * (max(ENTRY.values()) + 1))   # (created outside the capture)

@@ -452,6 +452,11 @@ class Recoder(object):
     self._dp = None
     self._ip = None
     self._dp_nnz_cap = {}                  # (keyed on id(matrix): never survives the matrix it was taken for)
+    # (a previous data-parallel train() may have left the engine on owned-row Adam: a run that does not
+    # reach _setup_owned_rows -- no group, the replicated fallback -- must get the one-call step back)
+    eng0 = getattr(self, "_Recoder__engine", None)
+    if eng0 is not None and getattr(eng0, "owned_rows", False):
+      eng0.owned_rows = False
     if getattr(self, "_ip_override", None) is not None:
       # tests: several virtual ranks in one process, collectives injected
       return self._enable_item_parallel(self._ip_override, train_dataset)

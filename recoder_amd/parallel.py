@@ -150,13 +150,31 @@ class DataParallel:
       return
     if self.world == 1:
       return
+    want = "allreduce"
+    ok = 1
     try:
       self.calibration = self.microbench(8 << 20, device, iters=5)
       if self.calibration["rsag_us"] < 0.95 * self.calibration["allreduce_us"]:
-        self.exchange_mode = "rsag"
+        want = "rsag"
     except Exception as e:            # noqa: BLE001 -- never fail a training run on the calibration
       import warnings
       warnings.warn("exchange calibration failed (%s): ncclAllReduce" % e)
+      ok = 0
+    # every rank must issue the SAME collectives: a calibration that failed on one rank only (or left the
+    # ranks with different answers) would pair ncclAllReduce with reduce-scatter / all-gather and hang the
+    # first exchange -- agree over torch.distributed (not the communicator that may just have failed):
+    # rsag only if every rank measured it, succeeded and chose it
+    self.exchange_mode = self._agree_mode(want if ok else "allreduce", device)
+
+  def _agree_mode(self, want, device):
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+      return want
+    backend = str(dist.get_backend(self.group))
+    t = torch.tensor([1 if want == "rsag" else 0], dtype=torch.int32,
+                     device=device if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+    return "rsag" if int(t.item()) == 1 else "allreduce"
 
   def microbench(self, nbytes, device, iters=10):
     """Time ncclAllReduce against reduce-scatter + all-gather on a bucket of `nbytes` (a collective:

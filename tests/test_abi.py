@@ -94,3 +94,19 @@ def test_product_never_imports_the_oracle():
       if f.endswith(".py"):
         src = open(os.path.join(dirpath, f)).read()
         assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# oracle", ""), f
+
+
+def test_dz_workspace_covers_every_batch_size_up_to_the_capacity(lib):
+  """slabs x rows of the stand-alone dZ kernels is not monotone in the batch size; the size
+  returned for a capacity must cover every (ragged) batch below it.  Host-side sizing only."""
+  for h in (64, 200, 512):
+    for fn in (lib.rk_pg_dz_workspace_bytes, lib.rk_dz_workspace_bytes):
+      sizes = [fn(b, h) for b in range(1, 2400, 7)] + [fn(1024, h), fn(1100, h), fn(2048, h), fn(2304, h)]
+      assert all(x > 0 for x in sizes)
+      assert fn(1100, h) >= fn(1024, h) and fn(2304, h) >= fn(2048, h)
+      assert fn(1100, h) >= 64 * 1024 * h * 4 or fn is lib.rk_dz_workspace_bytes
+      prev = 0
+      for b in range(1, 2400, 7):
+        cur = fn(b, h)
+        assert cur >= prev, (h, b)
+        prev = cur

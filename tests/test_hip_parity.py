@@ -412,6 +412,15 @@ STEP_CASES = [
   ("big_then_ragged_mf16", dict(kind="mf", embedding_size=16, activation_type="none", sparse=True,
                                 loss="logistic", loss_params=None, lr=1e-3, weight_decay=0.0),
    (1300, 700, 10), 1030, 1030),
+  # the dZ slab count is not monotone in the batch size -- a ragged last batch of 1024 rows takes
+  # 64 slabs (65 536 slab rows) where the capacity batch of 1100 takes 51 (56 100); few items, so that no other
+  # workspace happens to cover it (h = 512: rk_pg_dz; h = 64: the fused decode's domain ends at 1024 rows)
+  ("ragged_1024_after_1100_ae512", dict(kind="ae", hidden_layers=[512], activation_type="tanh", noise_prob=0.0,
+                                        sparse=False, loss="mse", loss_params=None, lr=1e-3, weight_decay=2e-5),
+   (2124, 300, 8), 1100, 1100),
+  ("ragged_1024_after_1100_ae64", dict(kind="ae", hidden_layers=[64], activation_type="tanh", noise_prob=0.0,
+                                       sparse=True, loss="logistic", loss_params=None, lr=1e-3, weight_decay=0.0),
+   (2124, 300, 8), 1100, 1100),
 ]
 
 

@@ -15,14 +15,19 @@ import sqlite3
 import sys
 from collections import defaultdict
 
+# bracketed entry of the step -> kernel-name prefixes (as rocprofv3 prints them, namespaces stripped) of every
+# generation of kernels an entry can dispatch: round-4 default C2 step = fdec_kernel | splitk_reduce_kernel |
+# pgemm's dw_encbwd_kernel; >= 1024 rows / h > 256 = pg::gemm_kernel<..> (by epilogue); rounds 1-3 behind them
 ENTRY_KERNELS = {
   "rk_adam_multi": ["adam_multi_kernel"],
-  "rk_decode_loss": ["decode_planes_kernel", "gemm_kernel<2, 2, 1, 2, 0, 0, 1"],
-  "rk_decode_bwd_dz": ["dz_planes_kernel", "gemm_kernel<4, 1, 1, 4, 0, 1, 2", "splitk_reduce_kernel"],
-  "rk_decode_bwd_dw": ["dw3_kernel", "dw_encbwd_kernel"],   # dW (csrc/dw3.hip), alone or || encoder backward
+  "rk_decode_loss": ["fdec_kernel", "decode_planes_kernel", "pg::gemm_kernel", "gemm_kernel<2, 2, 1, 2, 0, 0, 1"],
+  "rk_decode_bwd_dz": ["splitk_reduce_kernel", "dz_planes_kernel", "gemm_kernel<4, 1, 1, 4, 0, 1, 2"],
+  "rk_decode_bwd_dw": ["dw_encbwd_kernel", "dw3_kernel", "dw_reduce_kernel"],   # dW alone or || encoder backward
   "rk_ae_encode_bwd": ["ae_encode_bwd_cols_kernel", "ae_encode_bwd_kernel"],
   "rk_ae_encode_fwd": ["ae_encode_fwd_kernel"],
 }
+# (pg::gemm_kernel instantiations are told apart by their epilogue: EpiLoss = the decode)
+PG_ENTRY = {"EpiLoss": "rk_decode_loss", "EpiStats": "rk_decode_loss", "EpiSlab": None}
 
 
 def avg(path, counter):
@@ -37,12 +42,26 @@ def avg(path, counter):
 def main(fetch_db, write_db):
   f, w = avg(fetch_db, "FETCH_SIZE"), avg(write_db, "WRITE_SIZE")
   out = {}
+  seen = set()
   for entry, pats in ENTRY_KERNELS.items():
-    fk = sum(v for k, v in f.items() if any(k.startswith(p) for p in pats))
-    wk = sum(v for k, v in w.items() if any(k.startswith(p) for p in pats))
-    out[entry] = dict(fetch_size_kb=fk, write_size_kb=wk, hbm_bytes_per_launch=(2 * fk + wk) * 1024)
+    def mine(k):
+      if k.startswith("pg::gemm_kernel"):
+        return entry == "rk_decode_loss" and ("EpiLoss" in k or "EpiStats" in k)
+      return any(k.startswith(p) for p in pats)
+    ks = sorted(k for k in set(f) | set(w) if mine(k))
+    seen.update(ks)
+    fk = sum(f.get(k, 0.0) for k in ks)
+    wk = sum(w.get(k, 0.0) for k in ks)
+    out[entry] = dict(kernels=[k[:80] for k in ks], fetch_size_kb=fk, write_size_kb=wk,
+                      hbm_bytes_per_launch=(2 * fk + wk) * 1024)
+  # every other kernel of the run, by name (nothing the step dispatches may go unreported)
+  other = {k[:80]: dict(fetch_size_kb=f.get(k, 0.0), write_size_kb=w.get(k, 0.0),
+                        hbm_bytes_per_launch=(2 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024)
+           for k in sorted(set(f) | set(w)) if k not in seen and not k.startswith("at::") and "rocclr" not in k}
   print(json.dumps({"workload": "bench.py c2 (B=500, h=200, n_b~7.8k)", "formula":
-                    "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes", "entries": out}, indent=1))
+                    "(2*FETCH_SIZE + WRITE_SIZE)*1024, separate --pmc passes (MI355X_MICROARCH.md, HBM: FETCH_SIZE "
+                    "reports half the bytes of a wide coalesced read on gfx950)", "entries": out,
+                    "other_kernels": other}, indent=1))
 
 
 if __name__ == "__main__":
