@@ -605,6 +605,11 @@ typedef struct rk_adam_job {
 
 int rk_adam_multi(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part,
                   int32_t n_part, float denom, float *loss_out, void *stream);
+/* D[row, :] = pos[row] >= 0 ? G[pos[row], :] : 0 for row < n_items, 0 for n_items <= row < rows_pad: the
+ * compact gradient rows of a block laid out by ITEM ID -- the layout a reduce-scatter over equal row
+ * ranges needs (sharded dense Adam, rk_ae_step_t.zero_lo).  h % 4 == 0, 16-byte aligned. */
+int rk_rows_to_dense(const float *G, const int32_t *pos, int32_t n_items, int32_t rows_pad, int32_t h,
+                     float *D, void *stream);
 
 typedef struct rk_ae_step {
   const rk_block_t *blk;
@@ -668,6 +673,14 @@ typedef struct rk_ae_step {
    * the Z^T planes are not made at all, `ws` holds rk_pg_dz's slabs and ws_dw (or ws) rk_pg_dw's. */
   float *do_scales;
   int32_t do_rows;
+  /* Sharded dense Adam under users-DP (ZeRO-1; phased steps, RK_STEP_UPDATE): this rank updates rows
+   * [zero_lo, zero_hi) of the dense-Adam embedding tables only -- their moments live nowhere else -- from
+   * the reduce-scattered DENSE gradient shards zero_g_en / zero_g_de ([zero_hi - zero_lo, h], row zero_lo
+   * first; rk_rows_to_dense laid the compact rows out by item id before the reduce-scatter); the caller
+   * then all-gathers the updated rows.  The update of a row is the replicated one bit for bit (a dense
+   * Adam sweep treats every row independently, reference model.py:135,398-399).  zero_hi == 0: off. */
+  int32_t zero_lo, zero_hi;
+  const float *zero_g_en, *zero_g_de;
 } rk_ae_step_t;
 
 void *rk_event_create(int32_t timing); /* 0: ordering-only (no timing, device-scope fence); 1: for time_ev0 /

@@ -91,6 +91,7 @@ class RkAeStep(Structure):
     ("ws_dw", c_void_p), ("dw_stream", c_void_p), ("dw_fork", c_void_p), ("dw_join", c_void_p),
     ("planes", c_void_p),
     ("do_scales", c_void_p), ("do_rows", c_int32),
+    ("zero_lo", c_int32), ("zero_hi", c_int32), ("zero_g_en", c_void_p), ("zero_g_de", c_void_p),
   ]
 
 
@@ -138,6 +139,7 @@ SIGNATURES = {
   "rk_ae_encode_fwd_partial": (c_int32, [_BLK, c_int32, c_int32, _P, c_int32, _P, c_float, c_uint64,
                                          c_uint64, _P, _P, _P, _P]),
   "rk_bias_act": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P]),
+  "rk_rows_to_dense": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P]),
   "rk_densify": (c_int32, [_BLK, c_int32, c_int32, c_int32, _P, c_int32, _P]),
   "rk_ae_encode_fwd": (c_int32, [_BLK, c_int32, c_int32, _P, _P, c_int32, _P, c_float, c_uint64,
                                  c_uint64, _P, c_int32, _P, _P]),

@@ -625,6 +625,30 @@ extern "C" int rk_scatter_pos(int32_t *pos, const int64_t *rows, int32_t B, int3
   return 0;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void rows_to_dense_kernel(const float4 *__restrict__ G, const int32_t *__restrict__ pos,
+                                                            int n_items, int rows_pad, int hq, float4 *__restrict__ D) {
+  const int64_t tot = (int64_t)rows_pad * hq;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+    const int row = (int)(i / hq), q = (int)(i % hq);
+    const int pr = row < n_items ? pos[row] : -1;
+    D[i] = pr >= 0 ? G[(int64_t)pr * hq + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+}  // namespace
+
+extern "C" int rk_rows_to_dense(const float *G, const int32_t *pos, int32_t n_items, int32_t rows_pad, int32_t h,
+                                float *D, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(h > 0 && h % 4 == 0 && rows_pad >= n_items && n_items >= 0, "h % 4 == 0, rows_pad >= n_items");
+  RK_REQUIRE((((uintptr_t)G | (uintptr_t)D) & 15) == 0, "operands must be 16-byte aligned");
+  if (rows_pad == 0) return 0;
+  RK_LAUNCH(rows_to_dense_kernel, dim3(grid_for((int64_t)rows_pad * (h / 4))), dim3(256), 0, stream,
+            reinterpret_cast<const float4 *>(G), pos, n_items, rows_pad, h / 4, reinterpret_cast<float4 *>(D));
+  RK_CHECK_LAUNCH("rows_to_dense");
+  return 0;
+}
+
 extern "C" int rk_bias_act(float *X, const float *bias, int32_t rows, int32_t cols, int32_t act,
                            void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;

@@ -624,6 +624,20 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
         ++n;
       }
     }
+    // sharded dense Adam (rk_ae_step_t.zero_lo): the table jobs cover this rank's rows only and read the
+    // reduce-scattered dense gradient shard -- row r of the table at zero_g + (r - zero_lo) * h
+    if (a->zero_hi > 0) {
+      RK_REQUIRE(!whole && a->zero_lo >= 0 && a->zero_lo <= a->zero_hi && a->zero_hi <= n_items && a->zero_g_en,
+                 "zero_lo / zero_hi: a row range of the tables, phased steps, with the gradient shards");
+      for (int k = 0; k < n; ++k) {
+        if (jobs[k].par.sparse) continue;
+        const float *shard = slots[k] == RK_PAR_W_DE ? a->zero_g_de : a->zero_g_en;
+        RK_REQUIRE(shard != nullptr, "zero_g_de");
+        jobs[k].pos = nullptr; jobs[k].g_parts = 1; jobs[k].gparts_dev = nullptr;
+        jobs[k].g = shard - (int64_t)a->zero_lo * h;
+        jobs[k].row0 = a->zero_lo; jobs[k].row_step = 1; jobs[k].n_rows = a->zero_hi;
+      }
+    }
     slots[n] = RK_PAR_B_DE;
     jobs[n] = table_job(a->par[RK_PAR_B_DE], blk, n_items, 1, a->gb_de, true);
     jobs[n].par.sparse = 0; jobs[n].rows = nullptr; jobs[n].n_dev = nullptr; jobs[n].pos = blk->pos;

@@ -305,9 +305,10 @@ class FusedEngine:
       pend = self._pending_loss if i + ADAM_MULTI_MAX >= len(jobs) else None
       if pend is not None:
         # the deferred reduction of the step's loss partials rides on the sweep (as in rk_ae_train_step)
-        n_part, denom, out = pend
+        n_part, denom, out = pend[:3]
+        src = pend[3] if len(pend) > 3 else self.loss_part
         self._pending_loss = None
-        check(self.lib.rk_adam_multi(arr, len(chunk), ptr(self.loss_part), n_part, denom, ptr(out), stream),
+        check(self.lib.rk_adam_multi(arr, len(chunk), ptr(src), n_part, denom, ptr(out), stream),
               "rk_adam_multi")
       else:
         check(self.lib.rk_adam_multi(arr, len(chunk), None, 0, 1.0, None, stream), "rk_adam_multi")
@@ -661,7 +662,11 @@ class FusedEngine:
     # (dW will work in ws_dw with its K slabs kept for the Adam sweep: see keep_slabs below)
     zt_ws = self.ws_dw if (lazy and not tied and self.split16 and self.ws_dw is not None and
                            True) else None
-    loss = self._loss(z, B, tb, row_off, rows, stream, out, ip=ip, defer=lazy,
+    # data parallel + graph replay: the rank's share of the loss goes to a scalar of its own, travels with
+    # the gradients, and the step's Adam launch files the sum under the step's slot of `out` (the epoch's
+    # loss buffer) and publishes the next cursor -- as the one-call step does (_c_train_step)
+    dp_replay = self.allreduce is not None and getattr(self, "_replay", None) is not None and ip is None
+    loss = self._loss(z, B, tb, row_off, rows, stream, self.loss_dp if dp_replay else out, ip=ip, defer=lazy,
                       fuse_dz=True, zt_ws=zt_ws,
                       pg_ok=lazy and not tied and self.ws_dw is not None)
     self._loss_target = loss
@@ -724,7 +729,9 @@ class FusedEngine:
         self._dz_done = True
     if dw_side is not None:
       self._dw_ev[1].record(dw_side)
-    n_b_host = self.allreduce.n_b(blk) if self.allreduce is not None else None
+    # (replayed: a captured collective has a fixed size -- the exchange covers the block's capacity, rows past
+    # n_b are never read by the update -- and nothing of the step is read on the host)
+    n_b_host = None if self.allreduce is None else (blk.n_cap if dp_replay else self.allreduce.n_b(blk))
 
     # ---- dZ = dO . W_de[T] and everything upstream of it ----
     W_de, _ = self._decoder_params()
@@ -859,6 +866,9 @@ class FusedEngine:
         self._owned_exchange(blk, n_b_host)
       else:
         self.allreduce.reduce(self.grad_views(n_b_host, "all"))
+      if dp_replay:
+        self._pending_loss = (1, 1.0, out, self.loss_dp)
+        loss = out
     if dw_side is not None:
       main_s.wait_event(self._dw_ev[1])
     self._apply_updates(blk, row_off, B, stream, "all", tgt=tb)
@@ -1029,6 +1039,8 @@ class FusedEngine:
     st.stream = main_s.cuda_stream
     st.cursor, st.cursor_off, st.adam_table, st.cursor_next, st.cursor_advance = None, 0, None, None, 0
     st.ws_dw = st.dw_stream = st.dw_fork = st.dw_join = None
+    st.zero_lo = st.zero_hi = 0
+    st.zero_g_en = st.zero_g_de = None
     if dp is not None and self.ws_dw is not None and not m.is_constrained:
       st.ws_dw = ptr(self.ws_dw)        # (phased steps: dW's own workspace lets the decode launch keep its dZ slabs)
     self._ws_dw_live = False
@@ -1111,7 +1123,33 @@ class FusedEngine:
       # shard -- rows past n_b are zeros or stale rows nobody reads)
       n_x = dp.round_rows(n_b, blk.n_cap) if hasattr(dp, "round_rows") else n_b
       G_enc = self.G_de if tied else self.G_en
-      if tied:
+      zero = getattr(dp, "zero", None) if getattr(self, "zero_adam", False) else None
+      if zero is not None:
+        # sharded dense Adam (parallel.DataParallel "ZeRO-1"): the compact gradient rows go out laid out by
+        # item id and come back reduce-scattered -- this rank's row range of the dense gradient --, the
+        # update covers that range only (rk_ae_step_t.zero_lo), the updated rows are all-gathered
+        lo, hi, sh, rp_ = zero["lo"], zero["hi"], zero["sh"], zero["rows_pad"]
+        D, S_en, S_de = self._zero_buffers(rp_, sh, h0)
+        n_items = blk.n_items
+
+        def stage_of(G):
+          return lambda s_: check(raw.rk_rows_to_dense(ptr(G), ptr(blk.pos), n_items, rp_, h0, ptr(D),
+                                                       ctypes.c_void_p(s_.cuda_stream)), "rk_rows_to_dense")
+        if tied:
+          st.phase = STEP_FWD_DW | STEP_DZ_ENC
+          check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
+          dp.zero_exchange(stage_of(G_enc), D, S_en, [self.small[:self.small_off + n_b]], main_s, overlap=False)
+        else:
+          st.phase = STEP_FWD_DW
+          check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
+          dp.zero_exchange(stage_of(self.G_de), D, S_de, [self.small[h0:self.small_off + n_b]], main_s)
+          st.phase = STEP_DZ_ENC
+          check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
+          dp.zero_exchange(stage_of(G_enc), D, S_en, [self.small[:h0]], main_s)
+          dp.join_async(main_s)
+        st.zero_lo, st.zero_hi = lo, hi
+        st.zero_g_en, st.zero_g_de = ptr(S_en), (None if tied else ptr(S_de))
+      elif tied:
         # tied weights: the encoder backward accumulates onto dW's rows -- nothing may leave before it
         st.phase = STEP_FWD_DW | STEP_DZ_ENC
         check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
@@ -1134,8 +1172,22 @@ class FusedEngine:
         st.loss_part, st.loss_out = ptr(self.loss_dp), ptr(out)
       st.phase = STEP_UPDATE
       check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
+      if zero is not None:
+        names_ = ["en_embedding_layer.weight"] + ([] if tied else ["de_embedding_layer.weight"])
+        dp.zero_publish([S[n_].p.data for n_ in names_], h0, extra_max=self.ranges[64:])
     self._loss_target = out
     return out
+
+  def _zero_buffers(self, rows_pad, sh, h0):
+    """(D [rows_pad, h]: the gradient rows laid out by item id -- one staging buffer, the two halves of a
+    step's exchange use it one after the other on one stream --, the two reduce-scattered shards [sh, h])."""
+    z = getattr(self, "_zero_bufs", None)
+    if z is None or z[0].numel() != rows_pad * h0:
+      f = dict(dtype=torch.float32, device=self.device)
+      z = (torch.zeros(rows_pad * h0, **f), torch.zeros(sh * h0, **f), torch.zeros(sh * h0, **f))
+      self._zero_bufs = z
+      self.alloc_gen = getattr(self, "alloc_gen", 0) + 1
+    return z
 
   def _new_timing_event(self, raw):
     """A timing event -- from the pool graph.GraphStepper.prepare_timed filled BEFORE its capture

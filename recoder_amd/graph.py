@@ -44,7 +44,7 @@ class GraphStepper:
     # the two collation phases, captured with them -- and the step's two gradient exchanges are
     # captured between its phases (engine._c_train_step); all of fixed size
     self.dp = getattr(engine, "allreduce", None)
-    assert self.dp is None or (self.multi and self.G <= self.MULTI_MAX and engine.c_step_eligible())
+    assert self.dp is None or (self.multi and self.G <= self.MULTI_MAX and not getattr(engine, "owned_rows", False))
     self.blocks = [[make_block() for _ in range(self.G)] for _ in range(2)]
     self.tail_blk = make_block()            # ragged last batch: eager, host-provided arguments
     engine.ensure_capacity(self.B, self.blocks[0][0].n_cap)
@@ -157,7 +157,8 @@ class GraphStepper:
       # entry-by-entry sequencing (hidden stacks, dropout, MatrixFactorization) under the replay
       # context: every state's Adam constants have a slot of their own in the table
       replay.update(tab_stride=self.tab_stride, slots=self.slots, users_t=self.order)
-      self.eng.train_step(self.blocks[slot][g], 0, self.B, out=self.loss_buf, replay=replay)
+      self.eng.train_step(self.blocks[slot][g], 0, self.B, out=self.loss_buf, replay=replay,
+                          global_rows=None if self.dp is None else self.B * self.dp.world)
 
   def _group(self, slot, n_steps=None, first_index=None, lookahead=True):
     """One group on slot `slot`: its steps on the main stream, the collation of the NEXT group's

@@ -455,8 +455,9 @@ class Recoder(object):
     # (a previous data-parallel train() may have left the engine on owned-row Adam: a run that does not
     # reach _setup_owned_rows -- no group, the replicated fallback -- must get the one-call step back)
     eng0 = getattr(self, "_Recoder__engine", None)
-    if eng0 is not None and getattr(eng0, "owned_rows", False):
+    if eng0 is not None:
       eng0.owned_rows = False
+      eng0.zero_adam = False
     if getattr(self, "_ip_override", None) is not None:
       # tests: several virtual ranks in one process, collectives injected
       return self._enable_item_parallel(self._ip_override, train_dataset)
@@ -497,6 +498,7 @@ class Recoder(object):
     dp.attach(self._engine())
     self._dp = dp
     self._setup_owned_rows(dp, train_dataset, negative_sampling, batch_size)
+    self._setup_zero_adam(dp)
     n = len(train_dataset)
     lo, hi = shard_range(n, dp.rank, dp.world)
     dp.user_offset = lo
@@ -523,7 +525,14 @@ class Recoder(object):
     eng.owned_rows = False
     dp.owner_bounds = None
     sparse = bool(getattr(self.model, "sparse", False)) and self.sparse_optimizer is not None
-    mode = os.environ.get("RK_DP_OWNED", "1")       # 0: replicated update; force: also with one rank (tests)
+    # RK_DP_OWNED: 0 = replicated update; 1 = owned rows with more than one rank; force = also with one rank
+    # (tests); auto (default) = owned rows only where their price is paid back.  The replicated update
+    # replays as HIP graphs with its collectives captured (every engine, round 5); the owned-row exchange
+    # moves row counts only the host knows -- a device -> host read, ~25 launches enqueued one by one and the
+    # received rows scattered into the tables per step: one forced rank, C4 0.266 vs 0.129 ms per step,
+    # C5-shaped 1.43 vs 0.79 (profiles/r05_bench_c*_dp1_*.json).  What it saves is (1 - 1/N) of the
+    # SparseAdam sweep over the union rows.
+    mode = os.environ.get("RK_DP_OWNED", "auto")
     if not (sparse and negative_sampling and batch_size and (dp.world > 1 or mode == "force") and mode != "0"):
       return
     if dp.virtual and dp._gather_fn is None:
@@ -535,15 +544,50 @@ class Recoder(object):
     else:
       freq = np.bincount(train_dataset.interactions_matrix.indices, minlength=n_items)
     from .parallel import DataParallel
+    if mode == "auto":
+      est = DataParallel.owned_rows_estimate(freq[:n_items], len(train_dataset), dp.world * int(batch_size),
+                                             dp.world, int(eng.h[0]),
+                                             1 if (eng.kind != "ae" or bool(self.model.is_constrained)) else 2)
+      self._dp_owned_estimate = est
+      if est["saved_us"] < 2.0 * est["cost_us"]:
+        return
     dp.set_owner_bounds(DataParallel.balanced_bounds(freq[:n_items], len(train_dataset),
                                                      dp.world * int(batch_size), dp.world))
     eng.owned_rows = True
+
+  def _setup_zero_adam(self, dp):
+    """Sharded dense Adam (parallel.DataParallel, "ZeRO-1"): with optim.Adam on the embedding tables of the
+    one-call autoencoder step every rank owns an equal range of table rows -- gradient rows reduce-scattered,
+    the sweep over 1/N of the rows, the updated rows all-gathered; the moments of a row are kept up to date on
+    its owner only and gathered before checkpoints / validation (_sync_owned_moments).  RK_DP_ZERO = auto
+    (default: with more than one rank) | 0 | force (also with one rank: tests, the one-rank bench line)."""
+    eng = self._engine()
+    eng.zero_adam = False
+    dp.zero = None
+    mode = os.environ.get("RK_DP_ZERO", "auto")
+    if mode == "0" or not (dp.world > 1 or mode == "force"):
+      return
+    if getattr(eng, "generic", False) or getattr(eng, "owned_rows", False) or not eng.c_step_eligible():
+      return
+    if bool(getattr(self.model, "sparse", False)) or self.optimizer is None:
+      return                                # (SparseAdam tables: the replicated or the owned-row update)
+    if dp.virtual and dp._gather_fn is None:
+      return
+    dp.setup_zero(int(self.num_items))
+    eng.zero_adam = True
 
   def _sync_owned_moments(self):
     """The Adam moments of the owned rows live on their owners: every replica gets them (checkpoints,
     the end of train(), a later single-process continuation)."""
     dp = getattr(self, "_dp", None)
     eng = self._engine()
+    if dp is not None and getattr(eng, "zero_adam", False) and dp.zero is not None:
+      # (sharded dense Adam: the moments of rows [lo_r, hi_r) are current on rank r only)
+      names = ["en_embedding_layer.weight"] + ([] if self.model.is_constrained else ["de_embedding_layer.weight"])
+      for name in names:
+        st = eng.states[name]
+        dp.sync_owned_moments([st.m, st.v], bounds=dp.zero_bounds())
+      return
     if dp is None or not getattr(eng, "owned_rows", False):
       return
     for name, _ in eng._sparse_tables():
@@ -810,7 +854,9 @@ class Recoder(object):
       # users-DP replays too when its collectives are our own in-order RCCL calls (capturable) and
       # the step is the one-call autoencoder step; injected collectives (virtual ranks in tests),
       # torch.distributed / gloo and the entry-by-entry engines keep the eager sequencing
-      if not (dp.direct and not dp.virtual and eng.c_step_eligible() and
+      # (round 5: so do the entry-by-entry engines -- MatrixFactorization, hidden stacks -- with the
+      # replicated update; owned-row SparseAdam exchanges row counts only the host knows: eager)
+      if not (dp.direct and not dp.virtual and not getattr(eng, "owned_rows", False) and
               self.graph_group <= 8):
         return False
     ds = dataloader.dataset

@@ -126,6 +126,7 @@ class DataParallel:
     self.exchange_mode = "allreduce"     # how a large gradient bucket is summed: ncclAllReduce | rsag
     self.calibration = None
     self.owner_bounds = None             # owned-row Adam: item-id boundaries of the ranks' row ranges
+    self.zero = None                     # sharded dense Adam: setup_zero
 
   def prepare(self, device):
     """Create the two direct communicators now (a collective: every rank calls it)."""
@@ -377,6 +378,19 @@ class DataParallel:
     b[0], b[-1] = 0, len(f)
     return np.maximum.accumulate(np.asarray(b, dtype=np.int64))
 
+  @staticmethod
+  def owned_rows_estimate(item_freq, n_users, rows_per_step, world, h, tables, hbm_bps=5.0e12, host_us=150.0):
+    """What owned-row SparseAdam would save and cost per step (us), from the expected union item set of a
+    global batch: saved = (1 - 1/N) of the replicated sweep (28 B per element of the union rows); cost = the
+    host-sequenced step (measured at one forced rank: ~150 us of launches enqueued one by one + the read of
+    the row offsets) + gathering the owned rows and scattering every received row into the tables (16 B
+    per element).  RK_DP_OWNED=auto takes the owned rows when saved >= 2 x cost."""
+    f = np.asarray(item_freq, dtype=np.float64) / max(1, n_users)
+    union = float((1.0 - np.power(np.clip(1.0 - f, 0.0, 1.0), rows_per_step)).sum())
+    elems = tables * union * h
+    return dict(union_rows=union, saved_us=elems * 28.0 * (1.0 - 1.0 / world) / hbm_bps * 1e6,
+                cost_us=host_us + elems * 16.0 / hbm_bps * 1e6)
+
   def owned_offsets(self, items, n_b):
     """Compact-row offsets [world + 1] of the ranks' segments in the block's sorted item list (host)."""
     b = torch.as_tensor(self.owner_bounds[1:-1], dtype=items.dtype, device=items.device)
@@ -433,13 +447,119 @@ class DataParallel:
     dist.all_gather(parts, t, group=self.group)
     return parts
 
-  def sync_owned_moments(self, tensors):
+  # ---- sharded dense Adam (ZeRO-1) ------------------------------------------------------------------
+  # optim.Adam with sparse=False sweeps ALL rows of a table every step (weight decay, decaying moments:
+  # reference model.py:135,398-399), 38 us of HBM time at C2, 76 at C3 -- replicated, every rank repeats it.
+  # A dense Adam step treats every row independently, so rank r can own the rows [r sh, (r + 1) sh) of every
+  # dense table, sh = ceil(n_items / N): the compact gradient rows are laid out by item id
+  # (rk_rows_to_dense), REDUCE-SCATTERED over the equal row ranges (fixed counts: capturable), the owner
+  # sweeps its 1/N of the rows -- the only place their moments are kept up to date -- and the updated rows
+  # are ALL-GATHERED.  The bytes of today's reduce-scatter + all-gather of the gradient rows at capacity,
+  # 1/N of the sweep.
+  def setup_zero(self, n_items):
+    sh = -(-int(n_items) // self.world)
+    self.zero = dict(n_items=int(n_items), sh=sh, rows_pad=sh * self.world,
+                     lo=min(int(n_items), self.rank * sh), hi=min(int(n_items), (self.rank + 1) * sh))
+    return self.zero
+
+  def zero_bounds(self):
+    z = self.zero
+    return [min(z["n_items"], r * z["sh"]) for r in range(self.world + 1)]
+
+  def zero_reduce_scatter(self, D, shard, stream=None):
+    """shard <- SUM over the ranks of D[rank's row range] (D: [rows_pad * h] laid out by item id)."""
+    if self._sum_fn is None and self._grad_comm is not None and D.is_cuda:
+      self._grad_comm.reduce_scatter(D, shard, stream=stream)
+      return
+    parts = self._gather_all(D)            # (virtual ranks / gloo: the same sum in rank order)
+    n = shard.numel()
+    acc = parts[0][self.rank * n:(self.rank + 1) * n].clone()
+    for q in range(1, self.world):
+      acc += parts[q][self.rank * n:(self.rank + 1) * n]
+    shard.copy_(acc)
+
+  def zero_all_gather(self, tables, h, stream=None):
+    """Every rank's freshly updated row range of each [n_items, h] table -> every replica, in place."""
+    b = self.zero_bounds()
+    if self._sum_fn is None and self._grad_comm is not None and tables[0].is_cuda:
+      for t in tables:
+        flat = t.view(-1)
+        mine = flat[b[self.rank] * h:b[self.rank + 1] * h]
+        sends = [mine if q != self.rank else None for q in range(self.world)]
+        recvs = [flat[b[q] * h:b[q + 1] * h] if q != self.rank else None for q in range(self.world)]
+        if self.world > 1:
+          self._grad_comm.exchange(sends, recvs, stream=stream)
+      return
+    sh = self.zero["sh"]
+    for t in tables:
+      pad = torch.zeros(sh * h, dtype=t.dtype, device=t.device)
+      mine = t.view(-1)[b[self.rank] * h:b[self.rank + 1] * h]
+      pad[:mine.numel()].copy_(mine)
+      parts = self._gather_all(pad)
+      for q in range(self.world):
+        n = (b[q + 1] - b[q]) * h
+        if q != self.rank and n:
+          t.view(-1)[b[q] * h:b[q] * h + n].copy_(parts[q][:n])
+
+  def zero_exchange(self, stage, D, shard, small, main_stream, overlap=True):
+    """One half of a sharded-Adam step's exchange: stage(stream) lays the compact gradient rows out by item
+    id in D, D is reduce-scattered into `shard`, the small gradients `small` are all-reduced -- on the
+    communication stream behind everything enqueued on main_stream so far when the exchange may overlap the
+    step (join_async makes main_stream wait for it), else in line."""
+    small = [v for v in small if v.numel() > 0]
+    direct = self._sum_fn is None and self._grad_comm is not None and D.is_cuda
+    if direct and overlap and self.overlapped:
+      if getattr(self, "_cstream", None) is None:
+        self._cstream = torch.cuda.Stream(device=D.device)
+        self._ev_go, self._ev_done = torch.cuda.Event(), torch.cuda.Event()
+      self._ev_go.record(main_stream)
+      self._cstream.wait_event(self._ev_go)
+      stage(self._cstream)
+      self.zero_reduce_scatter(D, shard, stream=self._cstream)
+      if small:
+        self._grad_comm.all_reduce_many(small, stream=self._cstream)
+      self._async_pending = True
+      return
+    stage(main_stream)
+    if direct and self.world > 1:
+      def go(cs):
+        self.zero_reduce_scatter(D, shard, stream=cs)
+        if small:
+          self._grad_comm.all_reduce_many(small, stream=cs)
+      self._on_comm_stream(D.device, go)
+    elif direct:
+      self.zero_reduce_scatter(D, shard)
+      if small:
+        self._grad_comm.all_reduce_many(small)
+    else:
+      self.zero_reduce_scatter(D, shard)
+      self.reduce(small)
+
+  def zero_publish(self, tables, h, extra_max=None):
+    """The updated row ranges of `tables` to every replica (+ the MAX over the ranks of `extra_max`, the
+    decoder table's |W| bound: a rank only saw the rows it wrote), ordered behind the current stream's work
+    and in front of whatever it enqueues next."""
+    direct = self._sum_fn is None and self._grad_comm is not None and tables[0].is_cuda
+    if direct and self.world > 1:
+      def go(cs):
+        self.zero_all_gather(tables, h, stream=cs)
+        if extra_max is not None:
+          from .rccl import ncclMax
+          self._grad_comm.all_reduce(extra_max, op=ncclMax, stream=cs)
+      self._on_comm_stream(tables[0].device, go)
+      return
+    self.zero_all_gather(tables, h)
+    if extra_max is not None and self.world > 1:
+      self.union_marks(extra_max)
+
+  def sync_owned_moments(self, tensors, bounds=None):
     """Every replica gets the rows [owner_bounds[r], owner_bounds[r + 1]) of each tensor (the Adam
     moments of the owned-row update) from their owner: before a checkpoint / at the end of train()."""
-    if self.owner_bounds is None or self.world == 1:
+    bounds = self.owner_bounds if bounds is None else bounds
+    if bounds is None or self.world == 1:
       return
     for r in range(self.world):
-      lo, hi = int(self.owner_bounds[r]), int(self.owner_bounds[r + 1])
+      lo, hi = int(bounds[r]), int(bounds[r + 1])
       if hi <= lo:
         continue
       for t in tensors:

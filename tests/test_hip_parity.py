@@ -726,7 +726,8 @@ def test_dataframe_to_csr_matrix_contract():
 
 
 @pytest.mark.parametrize("kind", ["ae", "ae_overlap", "ae_eager", "ae_items", "mf", "mf_sparse", "ae_rsag",
-                                  "ae_eager_rsag", "ae_sparse_owned", "mf_sparse_owned"])
+                                  "ae_eager_rsag", "ae_sparse_owned", "mf_sparse_owned", "ae_stack", "ae_zero",
+                                  "ae_eager_zero"])
 def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind):
   """Recoder.train under an initialised torch.distributed group (RCCL, 1 rank):
   two-phase collation + all-reduced gradients must reproduce the plain run.  ae_overlap: the
@@ -738,6 +739,12 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
   from recoder_amd.data import RecommendationDataset
   from recoder_amd.model import Recoder
   csr = synth_csr(1200, 2500, 25, seed=9)
+  # *_zero: sharded dense Adam forced on with one rank (the "shard" is the whole table): the dense gradient
+  # layout, ncclReduceScatter, the row-range sweep from the shard, the publish -- replayed or host-sequenced
+  zero = kind.endswith("_zero")
+  if zero:
+    monkeypatch.setenv("RK_DP_ZERO", "force")
+    kind = kind[:-5]
   # "ae" = users sharded (gradient all-reduce), "ae_items" = items sharded (parallel.ItemParallel)
   monkeypatch.setenv("RK_PARALLEL", "items" if kind == "ae_items" else "users")
   items_mode = kind == "ae_items"
@@ -752,7 +759,7 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
     monkeypatch.setenv("RK_DP_EXCHANGE", "rsag")
   if owned:
     monkeypatch.setenv("RK_DP_OWNED", "force")
-  port_off = 40 * rsag + 60 * owned + 7 * (kind == "mf_sparse_owned")
+  port_off = 40 * rsag + 60 * owned + 7 * (kind == "mf_sparse_owned") + 110 * zero
   ae_sparse = kind == "ae_sparse_owned"
   if kind == "mf_sparse_owned":
     kind = "mf_sparse"
@@ -762,10 +769,15 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
     monkeypatch.setenv("RK_DP_OVERLAP", "1")
   if eager_dp:
     monkeypatch.setenv("RK_GRAPH", "0")
-  graph_dp = kind in ("ae", "ae_overlap") and not owned
-  kind = "ae" if (items_mode or overlap or eager_dp) else kind
+  # (round 5: the entry-by-entry engines -- MatrixFactorization, hidden stacks -- replay under users-DP too,
+  # their all-reduces captured with the step; owned-row SparseAdam stays host-sequenced)
+  graph_dp = kind in ("ae", "ae_overlap", "mf", "mf_sparse", "ae_stack") and not owned
+  stack = kind == "ae_stack"
+  kind = "ae" if (items_mode or overlap or eager_dp or stack) else kind
   c = STEP_CASES[0][1] if kind == "ae" else dict(kind="mf", embedding_size=32,
                                                  activation_type="tanh", sparse=(kind == "mf_sparse"))
+  if stack:
+    c = dict(c, hidden_layers=[64, 40], loss="logloss")
   if ae_sparse:
     c = dict(c, sparse=True)
 
@@ -773,7 +785,7 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
     torch.manual_seed(11)
     model = make_model(c)
     rec = Recoder(model=model, use_cuda=True, optimizer_type="adam",
-                  loss="mse" if kind == "ae" else "logistic")
+                  loss=("logloss" if stack else "mse") if kind == "ae" else "logistic")
     rec.user_order_hook = lambda epoch, n: np.arange(n, dtype=np.int64)
     rec.train(RecommendationDataset(csr), batch_size=300, lr=1e-3, weight_decay=2e-5, num_epochs=2,
               negative_sampling=True)
@@ -782,6 +794,7 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
     if dp:
       assert (gs is not None and gs.dp is rec._dp and gs.warmed) == graph_dp
       assert bool(getattr(rec._engine(), "owned_rows", False)) == owned
+      assert bool(getattr(rec._engine(), "zero_adam", False)) == zero
       if rsag:
         assert rec._dp.exchange_mode == "rsag"
     return np.concatenate(rec.loss_history), {k: v.detach().cpu().clone() for k, v in model.named_parameters()}
@@ -790,7 +803,7 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
   monkeypatch.setenv("RK_FORCE_DP", "1")
   monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
   monkeypatch.setenv("MASTER_PORT", str(29577 + ["ae", "mf", "mf_sparse"].index(kind) + 5 * items_mode +
-                                        20 * overlap + 30 * eager_dp + port_off))
+                                        20 * overlap + 30 * eager_dp + port_off + 90 * stack))
   dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
   try:
     dp_l, dp_p = run(True)
@@ -1057,7 +1070,7 @@ def test_item_parallel_virtual_ranks_random_shapes(seed):
 
 
 @pytest.mark.parametrize("case", ["mse_dense", "bce_sparse_tied", "ae2_dropout", "ae_logloss", "mse_sparse_owned",
-                                  "mse_sparse_replicated"])
+                                  "mse_sparse_replicated", "mse_dense_replicated", "bce_dense_tied"])
 def test_data_parallel_two_virtual_ranks_equal_single_process(case, monkeypatch):
   """parallel.DataParallel (users sharded -- north_star's partitioning, the multi-GPU default)
   with N = 2 on one GPU: two threads drive the REAL product class -- two-phase collation with the
@@ -1072,10 +1085,20 @@ def test_data_parallel_two_virtual_ranks_equal_single_process(case, monkeypatch)
   from recoder_amd.parallel import DataParallel, shard_range
   csr = synth_csr(1200, 1500, 20, seed=23)
   B, world = 150, 2
-  if case == "mse_dense":
+  if case in ("mse_dense", "mse_dense_replicated"):
+    # dense Adam on the one-call step: SHARDED over the ranks by default (parallel.DataParallel ZeRO-1: dense
+    # gradient layout reduce-scattered, each rank sweeps its row range, updated rows all-gathered);
+    # RK_DP_ZERO=0 keeps the replicated sweep
     mk = lambda: DynamicAutoencoder([64], activation_type="tanh", noise_prob=0.0, sparse=False)
     loss, wd = "mse", 2e-5
+    if case.endswith("replicated"):
+      monkeypatch.setenv("RK_DP_ZERO", "0")
+  elif case == "bce_dense_tied":
+    mk = lambda: DynamicAutoencoder([32], activation_type="sigmoid", noise_prob=0.0, sparse=False,
+                                    is_constrained=True)
+    loss, wd = "logistic", 2e-5
   elif case == "bce_sparse_tied":
+    monkeypatch.setenv("RK_DP_OWNED", "1")     # (owned-row SparseAdam on a tied table)
     mk = lambda: DynamicAutoencoder([32], activation_type="sigmoid", noise_prob=0.0, sparse=True,
                                     is_constrained=True)
     loss, wd = "logistic", 0.0
@@ -1088,8 +1111,8 @@ def test_data_parallel_two_virtual_ranks_equal_single_process(case, monkeypatch)
     # go to their owner, the updated rows come back) -- or, RK_DP_OWNED=0, the replicated update
     mk = lambda: DynamicAutoencoder([40], activation_type="tanh", noise_prob=0.0, sparse=True)
     loss, wd = "mse", 0.0
-    if case.endswith("replicated"):
-      monkeypatch.setenv("RK_DP_OWNED", "0")
+    # (RK_DP_OWNED=auto, the default since round 5, prices the two and would pick the replicated update here)
+    monkeypatch.setenv("RK_DP_OWNED", "0" if case.endswith("replicated") else "1")
   else:
     mk = lambda: DynamicAutoencoder([32], activation_type="tanh", noise_prob=0.0, sparse=False)
     loss, wd = "logloss", 2e-5
@@ -1146,18 +1169,19 @@ def test_data_parallel_two_virtual_ranks_equal_single_process(case, monkeypatch)
     assert rec._dp is not None and rec._ip is None
     owned = case in ("bce_sparse_tied", "mse_sparse_owned")
     assert bool(rec._engine().owned_rows) == owned, (case, rec._engine().owned_rows)
+    assert bool(getattr(rec._engine(), "zero_adam", False)) == (case in ("mse_dense", "bce_dense_tied", "ae_logloss")), case
     got_l = np.concatenate(rec.loss_history)
     assert len(got_l) == len(base_l)
     assert np.allclose(got_l, base_l, rtol=2e-5, atol=0), (got_l[:3], base_l[:3])
     for k, v in model.named_parameters():
       frac, mx, scale = close_stats(v.detach().cpu().numpy(), base_p[k].numpy(), 1e-4, 2e-6)
       assert frac < 2e-3, (k, frac, mx, scale)
-  if case == "mse_sparse_owned":
+  if case in ("mse_sparse_owned", "mse_dense", "bce_dense_tied"):
     # the replicas hold identical parameters AND (after train()'s final sync) identical Adam moments
     (m0, r0), (m1, r1) = reps
     for (k, a), (_, b) in zip(m0.named_parameters(), m1.named_parameters()):
       assert torch.equal(a, b), k
-    for name in ("en_embedding_layer.weight", "de_embedding_layer.weight"):
+    for name in ("en_embedding_layer.weight", "de_embedding_layer.weight")[:1 if case == "bce_dense_tied" else 2]:
       s0, s1 = r0._engine().states[name], r1._engine().states[name]
       assert torch.equal(s0.m, s1.m) and torch.equal(s0.v, s1.v), name
       assert float(s0.v.abs().max()) > 0

@@ -357,6 +357,51 @@ def test_owned_row_exchange_primitives_two_ranks():
     assert out.get(0) and out.get(1)
 
 
+def _zero_worker(rank, world, port, out):
+  """The sharded-dense-Adam (ZeRO-1) primitives of parallel.DataParallel over gloo (CPU tensors): the dense
+  gradient layout reduce-scattered over equal row ranges (n_items not a multiple of the world size), an
+  "update" of the owned rows, the all-gather of the updated rows in place, the moments' final sync."""
+  sys.path.insert(0, ROOT)
+  os.environ["MASTER_ADDR"] = "127.0.0.1"
+  os.environ["MASTER_PORT"] = str(port)
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  torch.set_num_threads(1)
+  from recoder_amd.parallel import DataParallel
+  dp = DataParallel().prepare(torch.device("cpu"))
+  n_items, h = 501, 4                      # (501 = 2 x 251 - 1: the last range is one row short)
+  z = dp.setup_zero(n_items)
+  b = dp.zero_bounds()
+  assert b[0] == 0 and b[-1] == n_items and z["rows_pad"] == z["sh"] * world >= n_items
+  assert (z["lo"], z["hi"]) == (b[rank], b[rank + 1])
+  dense = lambda r: torch.from_numpy(np.random.RandomState(300 + r).randn(z["rows_pad"], h).astype(np.float32))
+  D = dense(rank).reshape(-1).clone()
+  shard = torch.zeros(z["sh"] * h)
+  dp.zero_reduce_scatter(D, shard)
+  want = sum(dense(q) for q in range(world))[rank * z["sh"]:(rank + 1) * z["sh"]]
+  assert torch.allclose(shard.view(-1, h), want)
+  # the owner "updates" its rows of a replicated table from its shard; everyone gets every owner's rows
+  W = torch.arange(n_items * h, dtype=torch.float32).view(n_items, h).clone()
+  W[z["lo"]:z["hi"]] += shard.view(-1, h)[:z["hi"] - z["lo"]]
+  dp.zero_all_gather([W], h)
+  full = torch.arange(n_items * h, dtype=torch.float32).view(n_items, h) + sum(dense(q) for q in range(world))[:n_items]
+  assert torch.allclose(W, full)
+  m = torch.full((n_items, 2), float(rank + 1))
+  dp.sync_owned_moments([m], bounds=b)
+  for q in range(world):
+    assert (m[b[q]:b[q + 1]] == q + 1).all()
+  out[rank] = True
+  dist.destroy_process_group()
+
+
+def test_zero_adam_primitives_two_ranks():
+  world = 2
+  port = _free_port()
+  with mp.Manager() as mgr:
+    out = mgr.dict()
+    mp.spawn(_zero_worker, args=(world, port, out), nprocs=world, join=True)
+    assert out.get(0) and out.get(1)
+
+
 def test_balanced_owner_bounds():
   """Item-id ranges with equal EXPECTED union rows per step: monotone, covering, balanced on a Zipf
   catalogue where equal-width ranges are not."""
