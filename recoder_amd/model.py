@@ -560,12 +560,16 @@ class Recoder(object):
     one-call autoencoder step every rank owns an equal range of table rows -- gradient rows reduce-scattered,
     the sweep over 1/N of the rows, the updated rows all-gathered; the moments of a row are kept up to date on
     its owner only and gathered before checkpoints / validation (_sync_owned_moments).  RK_DP_ZERO = auto
-    (default: with more than one rank) | 0 | force (also with one rank: tests, the one-rank bench line)."""
+    (default: from 8 ranks) | 1 (with more than one rank) | 0 | force (also with one rank: tests, the one-rank
+    bench line).  The exchange then moves the DENSE layout (every row of the tables, = the capacity-sized
+    exchange of a replayed step) where the replicated update's moves the union rows: by tools/dp_model.py the
+    saved 7/8 of the sweep pays for that from 8 ranks at C2 / C3 (282 vs 290, 624 vs 627 us per step at
+    1 TB/s per rank; 2 and 4 ranks lose 5-15 %) -- a model: no run on more than one GPU exists."""
     eng = self._engine()
     eng.zero_adam = False
     dp.zero = None
     mode = os.environ.get("RK_DP_ZERO", "auto")
-    if mode == "0" or not (dp.world > 1 or mode == "force"):
+    if mode == "0" or not (dp.world >= 8 or (mode == "1" and dp.world > 1) or mode == "force"):
       return
     if getattr(eng, "generic", False) or getattr(eng, "owned_rows", False) or not eng.c_step_eligible():
       return

@@ -44,6 +44,7 @@ def main():
   rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
   os.environ["RK_COMM"] = "torch"            # two ranks on one GPU: no RCCL communicator
   os.environ.setdefault("RK_DP_OWNED", "1")  # (auto, the default, would price the two and pick the replicated update)
+  os.environ.setdefault("RK_DP_ZERO", "1")   # (ae_dense: the sharded dense Adam over gloo; auto = from 8 ranks)
   torch.cuda.set_device(0)
   dist.init_process_group("gloo", rank=rank, world_size=world)
   from recoder_amd.data import RecommendationDataset

@@ -1091,9 +1091,9 @@ def test_data_parallel_two_virtual_ranks_equal_single_process(case, monkeypatch)
     # RK_DP_ZERO=0 keeps the replicated sweep
     mk = lambda: DynamicAutoencoder([64], activation_type="tanh", noise_prob=0.0, sparse=False)
     loss, wd = "mse", 2e-5
-    if case.endswith("replicated"):
-      monkeypatch.setenv("RK_DP_ZERO", "0")
+    monkeypatch.setenv("RK_DP_ZERO", "0" if case.endswith("replicated") else "1")
   elif case == "bce_dense_tied":
+    monkeypatch.setenv("RK_DP_ZERO", "1")
     mk = lambda: DynamicAutoencoder([32], activation_type="sigmoid", noise_prob=0.0, sparse=False,
                                     is_constrained=True)
     loss, wd = "logistic", 2e-5
@@ -1114,6 +1114,7 @@ def test_data_parallel_two_virtual_ranks_equal_single_process(case, monkeypatch)
     # (RK_DP_OWNED=auto, the default since round 5, prices the two and would pick the replicated update here)
     monkeypatch.setenv("RK_DP_OWNED", "0" if case.endswith("replicated") else "1")
   else:
+    monkeypatch.setenv("RK_DP_ZERO", "1")
     mk = lambda: DynamicAutoencoder([32], activation_type="tanh", noise_prob=0.0, sparse=False)
     loss, wd = "logloss", 2e-5
   n = csr.shape[0]
@@ -1188,11 +1189,13 @@ def test_data_parallel_two_virtual_ranks_equal_single_process(case, monkeypatch)
 
 
 @pytest.mark.parametrize("seed", list(range(24)))
-def test_data_parallel_virtual_ranks_random_shapes(seed):
+def test_data_parallel_virtual_ranks_random_shapes(seed, monkeypatch):
   """test_data_parallel_two_virtual_ranks_equal_single_process over random shapes: 2 or 3 virtual
   ranks, shard sizes that leave ragged remainders, sampling on / off, dense / sparse / tied, the
-  three losses."""
+  three losses.  Even seeds: dense-Adam tables of the one-call step sharded over the ranks (RK_DP_ZERO=1:
+  item counts that are no multiple of the world size, 3 ranks), odd seeds: the replicated sweep."""
   import threading
+  monkeypatch.setenv("RK_DP_ZERO", "1" if seed % 2 == 0 else "0")
   from recoder_amd.data import RecommendationDataset
   from recoder_amd.model import Recoder
   from recoder_amd.nn import DynamicAutoencoder

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Per-term model of the users-DP step at N = 1 / 2 / 4 / 8 for C2 (dense Adam), C4 and C5 (SparseAdam):
+"""Per-term model of the users-DP step at N = 1 / 2 / 4 / 8 for C2 and C3 (dense Adam: replicated vs sharded, ZeRO-1),
+C4 and C5 (SparseAdam: replicated + graph replay vs owned rows, host-sequenced, with the measured host term):
 union item-set sizes MEASURED on the bench's synthetic matrices, kernel terms scaled from this round's
 single-GPU times, exchange priced at a stated link bandwidth -- a PREDICTION (nothing here has run on more
 than one GPU).  DESIGN.md section 6 quotes this output.
@@ -36,57 +37,76 @@ def main():
   a = ap.parse_args()
   import bench
   HBM = 5.3e6          # bytes / us the Adam sweeps reach (profiles: 5.2-5.5 TB/s)
+  # host terms, MEASURED at one forced RCCL rank (profiles/r05_bench_*_dp1_*.json): a replayed step costs the
+  # host nothing the GPU waits for; the owned-row SparseAdam step is sequenced from the host (a device -> host
+  # read of the row offsets, ~25 launches enqueued one by one): C4 0.266 vs 0.129 ms, C5-shaped 1.43 vs 0.79
+  HOST_OWNED = {"c4": 137.0, "c5u": 150.0}
   rows = []
-  for name, h, kind in (("c2", 200, "dense"), ("c4", 128, "sparse"), ("c5u", 512, "sparse")):
+  for name, h, kind in (("c2", 200, "dense"), ("c3", 200, "dense"), ("c4", 128, "sparse"), ("c5u", 512, "sparse")):
     cfg = bench.CONFIGS[name]
     csr = bench.make_csr(cfg)
     n_items = csr.shape[1]
     B = cfg["batch_size"]
     tables = 1 if cfg["kind"] == "mf" else 2
     nb1 = union_sizes(csr, B, 1, a.steps)
-    # single-GPU kernel terms (us) at n_b = nb1: {fixed, scales with n_b} from this round's profiles
+    # single-GPU kernel terms (us) at n_b = nb1: {fixed, scales with n_b} from the round-4/5 profiles
     if name == "c2":
-      fixed, scaled, adam1 = 14.0, 28.0 + 6.5 + 23.5, 38.0          # enc fwd | decode+dZ, reduce, dW||enc bwd | dense sweep
+      fixed, scaled, adam1 = 13.0, 24.5 + 6.5 + 25.0, 38.5          # enc fwd | fdec, reduce, dW||enc bwd | dense sweep
+    elif name == "c3":
+      fixed, scaled, adam1 = 11.5 + 2 * 6.5 + 2 * 9.4, 19.8 + 19.0 + 25.4 + 7.0 + 30.0 + 10.4, 76.0   # enc fwd, Linears | decode, mnll, dZ, reduce, dW||enc bwd, split | dense sweep
     elif name == "c4":
       fixed, scaled, adam1 = 7.0 + 8.0, 33.0 + 21.0, 18.0            # gather, split | decode+dZ, dW||reduce | SparseAdam
     else:
-      fixed, scaled, adam1 = 90.0, 117.0 + 100.0 + 100.0 + 62.0, 280.0   # enc fwd | decode, dZ, dW, enc bwd | SparseAdam
+      fixed, scaled, adam1 = 79.0, 117.0 + 100.0 + 100.0 + 62.0, 280.0   # enc fwd | decode, dZ, dW, enc bwd | SparseAdam
     for N in (1, 2, 4, 8):
       nb = union_sizes(csr, B, N, a.steps) if N > 1 else nb1
       bytes_g = tables * nb * h * 4 + nb * 4
+      bytes_dense = tables * n_items * h * 4            # the dense layout of the sharded dense Adam (= capacity rows)
       kern = fixed + scaled * nb / nb1
+      adam_zero = host_own = float("nan")
       if kind == "dense":
         adam_rep = adam1                                   # the sweep covers the whole table either way
         adam_own = adam1
+        # ZeRO-1: 1/N of the sweep (p, m, v and the DENSE gradient shard) + laying the compact rows out by item id
+        # (two staging launches: reads n_b rows, writes n_items rows; the decoder half runs beside the chain)
+        adam_zero = (tables * n_items * h * 28 / N) / HBM + (tables * (n_items + nb) * h * 4) / HBM * 0.5
       else:
         adam_rep = adam1 * nb / nb1
         adam_own = adam_rep / N + (tables * nb * h * 4 * 2 * (N - 1) / N) / HBM * 0.5   # + scatter of the others' rows
+        host_own = HOST_OWNED.get(name, 150.0)
       if N == 1:
-        ex_ring = ex_direct = 0.0
+        ex_ring = ex_direct = ex_dense = 0.0
       else:
         ex_ring = 2 * (N - 1) / N * bytes_g / (a.ring * 1e3) + 2 * a.lat
         ex_direct = 2 * (N - 1) / N * bytes_g / (a.bw * 1e3) + 2 * a.lat
+        ex_dense = 2 * (N - 1) / N * bytes_dense / (a.bw * 1e3) + 3 * a.lat
       sync = 0.0 if N == 1 else 25.0
       t_rep_ring = kern + adam_rep + ex_ring + sync
       t_rep_dir = kern + adam_rep + ex_direct + sync
-      t_own_dir = kern + adam_own + ex_direct + sync
-      # NOT the reference's shared-set semantics (each user would only see its own rank's negatives):
-      # every rank decodes its OWN item set, only the gradient rows are unioned -- for comparison
+      t_alt = (kern + adam_zero + ex_dense + sync) if kind == "dense" else (kern + adam_own + ex_direct + sync + host_own)
+      if N == 1:
+        t_alt = t_rep_dir
       t_ownset = (fixed + scaled) + min(adam_rep, adam_own) + ex_direct + sync
-      rows.append((name, N, nb, bytes_g / 1e6, kern, adam_rep, adam_own, ex_ring, ex_direct, t_rep_ring, t_rep_dir,
-                   t_own_dir, t_ownset))
-  print("config N   union n_b  exch MB | kernels  Adam(repl)  Adam(owned) | exch ring@%g  exch direct@%g | step: repl+ring  repl+direct  owned+direct | users/s (best)  x vs N=1 | per-rank item sets (other semantics): step  x" % (a.ring, a.bw))
+      rows.append((name, N, nb, bytes_g / 1e6, bytes_dense / 1e6 if kind == "dense" else float("nan"), kern, adam_rep,
+                   adam_zero if kind == "dense" else adam_own, host_own, ex_ring, ex_direct, ex_dense if kind == "dense" else float("nan"),
+                   t_rep_ring, t_rep_dir, t_alt, t_ownset, kind))
+  print("A PREDICTION: nothing here has run on more than one GPU.  us per step; exchange at %g GB/s per rank (ring: %g)." % (a.bw, a.ring))
+  print("dense-Adam configs (c2, c3): alt = sharded dense Adam (ZeRO-1, graph replay); SparseAdam configs (c4, c5u): alt = owned-row "
+        "Adam, host-sequenced (host = measured at one forced rank)")
+  print("config N   union n_b  exch MB (compact | dense) | kernels  Adam repl  Adam alt  host alt | exch ring  direct  dense | "
+        "step: repl+ring  repl+direct (graph)  alt | best users/s  x vs N=1 | per-rank item sets (other semantics): step  x")
   base = {}
   for r in rows:
     name, N = r[0], r[1]
-    best = min(r[9], r[10], r[11]) if N > 1 else r[9]
+    best = min(r[12], r[13], r[14]) if N > 1 else r[13]
     B = bench.CONFIGS[name]["batch_size"]
     ups = N * B / best * 1e6
     if N == 1:
       base[name] = ups
-    print("%-5s %2d  %9.0f  %7.1f | %7.0f  %9.0f  %10.0f | %12.0f  %13.0f | %14.0f  %11.0f  %12.0f | %10.2f M  %5.2f | %8.0f  %5.2f" % (
-        name, N, r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10], r[11], ups / 1e6, ups / base[name],
-        r[12], (N * B / r[12] * 1e6) / base[name]))
+    f = lambda x, w: ("%" + str(w) + ".0f") % x if x == x else " " * (w - 1) + "-"
+    print("%-5s %2d  %9.0f  %7.1f | %s | %7.0f  %9.0f  %s  %s | %9.0f  %6.0f  %s | %14.0f  %19.0f  %s | %9.2f M  %5.2f | %8.0f  %5.2f" % (
+        name, N, r[2], r[3], f(r[4], 7), r[5], r[6], f(r[7], 8), f(r[8], 8), r[9], r[10], f(r[11], 5), r[12], r[13], f(r[14], 5),
+        ups / 1e6, ups / base[name], r[15], (N * B / r[15] * 1e6) / base[name]))
 
 
 if __name__ == "__main__":
