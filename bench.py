@@ -101,6 +101,10 @@ CONFIGS = {
   "c2s": dict(workload="C2 with sparse=True (SparseAdam on the two tables)",
               data="ml20m", kind="ae", hidden_layers=[200], activation_type="tanh", noise_prob=0.5,
               sparse=True, loss="mse", batch_size=500, lr=1e-3, weight_decay=2e-5),
+  "c2b4k": dict(workload="C2 at B = 4000 users per step (VERDICT r4 #9: the batch at which C2's item set saturates; "
+                         "config.alt_large_batch of a multi-GPU run)",
+                data="ml20m", kind="ae", hidden_layers=[200], activation_type="tanh", noise_prob=0.5,
+                sparse=False, loss="mse", batch_size=4000, lr=1e-3, weight_decay=2e-5),
   # the other BASELINE.json configurations at their 1-GPU shapes (parity-test cases; these lines are
   # extra data points, `python bench.py --config c3|c4|c5u` -- the graded line is c2)
   "c3": dict(workload="C3 MSD-like synthetic CSR 200000x41140 (200k of the 471k users; lognormal degree "
@@ -299,6 +303,50 @@ def recall_check(rec, model, cfg, csr, n_held=1000, k=20):
                        "oracle/recoder_oracle.py evaluate on the same parameters" % (k, csr_in.shape[0]))
 
 
+def alt_large_batch(cfg, csr, B_alt, W, K, world, rank, device, sync_all):
+  """The same workload, users-DP, with B_alt users per rank and step: C2's union item set
+  saturates at ~20 k items, so past B ~ 2 000 per rank the contractions, the exchange and the Adam sweep stop
+  growing with the batch -- the configuration whose weak scaling the first 8-GPU run can judge the exchange
+  on.  Timed like the main run; the graded line stays B = 500."""
+  import torch.distributed as dist
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder
+  n_users, n_items = csr.shape
+  torch.manual_seed(0)
+  model = DynamicAutoencoder(hidden_layers=cfg["hidden_layers"], activation_type=cfg["activation_type"],
+                             noise_prob=cfg["noise_prob"], sparse=cfg["sparse"])
+  rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss=cfg["loss"],
+                num_items=n_items, num_users=n_users)
+  rec.user_order_hook = lambda epoch, n: np.random.RandomState(300 + 1000 * epoch + rank).permutation(n).astype(np.int64)
+  multi = dist.is_available() and dist.is_initialized()
+  per_rank = n_users // world if multi else n_users
+  steps_per_epoch = max(1, per_rank // B_alt)
+  epochs = -(-(W + K) // steps_per_epoch) + 1
+  T = {}
+
+  def start():
+    sync_all()
+    T["t0"] = time.perf_counter()
+    return False
+
+  def stop():
+    sync_all()
+    T["dt"] = time.perf_counter() - T["t0"]
+    return True
+  rec.step_marks = {W: start, W + K: stop}
+  rec.train(RecommendationDataset(csr), batch_size=B_alt, lr=cfg["lr"], weight_decay=cfg["weight_decay"],
+            num_epochs=epochs, negative_sampling=True)
+  dt = T["dt"]
+  if multi:
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+  return {"parallelism": "dp%d (users sharded, B = %d per rank)" % (world, B_alt), "batch_size_per_gpu": B_alt,
+          "value": K * B_alt * world / dt, "unit": "users/s", "ms_per_step": dt / K * 1e3, "steps": K, "warmup": W,
+          "graph_replay": bool(getattr(rec, "_graph_stepper", None) is not None)}
+
+
 def alt_item_parallel(cfg, csr, B, W, K, world, rank, device, sync_all):
   """The same workload with the ITEM dimension sharded (RK_PARALLEL=items): W warm-up + K timed steps
   of B users per rank through Recoder.train, timed like the main run (barrier + synchronize on both
@@ -365,6 +413,9 @@ def main():
   ap.add_argument("--alt", choices=("auto", "0", "1"), default="auto",
                   help="N > 1: also time the item-parallel alternative in a child run (auto: only with > 1 rank)")
   ap.add_argument("--alt-timeout", type=float, default=300.0)
+  ap.add_argument("--alt-large", type=int, default=-1, metavar="B",
+                  help="also time users-DP at B users per rank (config.alt_large_batch); default: 4000 with > 1 rank, "
+                       "off with one; 0 = off")
   ap.add_argument("--one-gpu-gloo", action="store_true", help="(tests) every rank on GPU 0 over gloo")
   ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE",
                   help="(A/B runs) rk_tune(KNOB, VALUE) of include/recoder_hip_probe.h before anything is launched")
@@ -583,6 +634,9 @@ def main():
 
   want_alt = multi and (world > 1 or args.alt == "1") and \
       args.alt != "0" and os.environ.get("RK_PARALLEL", "users") in ("users", "auto")
+  B_large = (4000 if world > 1 else 0) if args.alt_large < 0 else args.alt_large
+  if cfg["kind"] != "ae" or B_large * world > n_users:
+    B_large = 0
   out = None
 
   def emit():
@@ -814,7 +868,7 @@ def main():
                                            "timed group runs inside it (one per group, as in steady state)")
                                           if T.get("precollated") else "inside the timed region, in front of step 0",
                  "exchange_microbench": exch,
-                 "alt_item_parallel": None},
+                 "alt_item_parallel": None, "alt_large_batch": None},
       "roofline": roofline,
     }
     if GEMM_BF16:
@@ -855,9 +909,24 @@ def main():
       alt = alt_item_parallel(cfg, csr, B, W, K, world, rank, device, sync_all)
     except Exception as e:          # noqa: BLE001
       alt = {"error": "%s: %s" % (type(e).__name__, e)}
-    finished.set()
     if rank == 0:
       out["config"]["alt_item_parallel"] = alt
+    if B_large:
+      try:
+        altb = alt_large_batch(cfg, csr, B_large, max(4, W // 2), max(16, K // 5), world, rank, device, sync_all)
+      except Exception as e:          # noqa: BLE001
+        altb = {"error": "%s: %s" % (type(e).__name__, e)}
+      if rank == 0:
+        out["config"]["alt_large_batch"] = altb
+    finished.set()
+  if B_large and not want_alt:
+    # (one rank, or RK_PARALLEL=items: the large-batch line alone)
+    try:
+      altb = alt_large_batch(cfg, csr, B_large, max(4, W // 2), max(16, K // 5), world, rank, device, sync_all)
+    except Exception as e:          # noqa: BLE001
+      altb = {"error": "%s: %s" % (type(e).__name__, e)}
+    if rank == 0:
+      out["config"]["alt_large_batch"] = altb
   if rank == 0:
     emit()
   if multi:

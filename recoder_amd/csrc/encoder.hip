@@ -242,11 +242,19 @@ __global__ __launch_bounds__(256) void ae_encode_bwd_kernel(
 
 // (the workgroup body lives in encoder_bwd.h: the fused dW || encoder-backward launch of dw3.hip
 // runs it next to the dW tiles)
-template <int HV>
+// the light-column variant (two dZ rows in flight) held to six waves per SIMD
+template <int HV, int WW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6))) void ae_encode_bwd_cols_light_kernel(
+    rk_block_t b, int row_off, int B, const float *__restrict__ dZ, int h,
+    float *__restrict__ G, int accumulate, float *__restrict__ gb, int n_gb) {
+  ae_encode_bwd_cols_body<HV, false, WW, 2>(b, row_off, B, dZ, h, G, accumulate, gb, n_gb, (int)blockIdx.x);
+}
+
+template <int HV, int WW = 1, int U = 8>
 __global__ __launch_bounds__(256) void ae_encode_bwd_cols_kernel(
     rk_block_t b, int row_off, int B, const float *__restrict__ dZ, int h,
     float *__restrict__ G, int accumulate, float *__restrict__ gb, int n_gb) {
-  ae_encode_bwd_cols_body<HV>(b, row_off, B, dZ, h, G, accumulate, gb, n_gb, (int)blockIdx.x);
+  ae_encode_bwd_cols_body<HV, false, WW, U>(b, row_off, B, dZ, h, G, accumulate, gb, n_gb, (int)blockIdx.x);
 }
 
 }  // namespace
@@ -369,23 +377,41 @@ extern "C" int rk_ae_encode_bwd(const rk_block_t *blk, int32_t row_off, int32_t 
              "block was built without the transposed bitmap / prefix index");
   const int n_gb = gb_en ? rk_cdiv(h, 64) : 0;
   const int hv = rk_cdiv(h, 256);
-  if (((row_off + B + 31) >> 5) - (row_off >> 5) <= 64) {
-    // the row window fits one bitmap word per lane: a wave per column (4 per workgroup)
-    const int grid = rk_cdiv(blk->n_cap, 4) + n_gb;
-#define LAUNCH(HV)                                                                                 \
-  RK_LAUNCH(ae_encode_bwd_cols_kernel<HV>, dim3(grid), dim3(256), 0, stream, *blk, row_off, B, \
-            dZ0pre, h, G_en, accumulate, gb_en, n_gb)
-    if (hv == 1) LAUNCH(1); else if (hv == 2) LAUNCH(2); else LAUNCH(4);
+  const int words = ((row_off + B + 31) >> 5) - (row_off >> 5);
+  // blocks of LIGHT columns (the item set is as large as the block's entry capacity: about one stored entry
+  // per sampled item -- C5's uniform catalogue): two dZ rows in flight per column instead of eight, half the
+  // registers, twice the columns in flight (the launch is a chain of dependent loads per column)
+  const bool light = blk->n_cap >= 4096 && (int64_t)blk->nnz_cap <= 2 * (int64_t)blk->n_cap;
+  if (words <= 128 && (words <= 64 || blk->n_cap >= 4096)) {
+    // the row window fits one (two: past 2048 rows) bitmap word(s) per lane: a wave per column (4 per workgroup)
+    // (past 2048 rows the bias gradient is one column sum of dZ behind the launch, as for the windows below)
+    const int n_gb_k = words <= 64 ? n_gb : 0;
+    float *gb_k = words <= 64 ? gb_en : nullptr;
+    const int grid = rk_cdiv(blk->n_cap, 4) + n_gb_k;
+#define LAUNCH(HV, WW, U)                                                                                 \
+  RK_LAUNCH((ae_encode_bwd_cols_kernel<HV, WW, U>), dim3(grid), dim3(256), 0, stream, *blk, row_off, B, \
+            dZ0pre, h, G_en, accumulate, gb_k, n_gb_k)
+#define LAUNCH_L(HV, WW)                                                                                 \
+  RK_LAUNCH((ae_encode_bwd_cols_light_kernel<HV, WW>), dim3(grid), dim3(256), 0, stream, *blk, row_off, B, \
+            dZ0pre, h, G_en, accumulate, gb_k, n_gb_k)
+#define BY_HV(WW, U) do { if (hv == 1) LAUNCH(1, WW, U); else if (hv == 2) LAUNCH(2, WW, U); else LAUNCH(4, WW, U); } while (0)
+#define BY_HV_L(WW) do { if (hv == 1) LAUNCH_L(1, WW); else if (hv == 2) LAUNCH_L(2, WW); else LAUNCH(4, WW, 2); } while (0)
+    if (words <= 64) { if (light) BY_HV_L(1); else BY_HV(1, 8); }
+    else { if (light) BY_HV_L(2); else BY_HV(2, 8); }
+#undef BY_HV_L
+#undef BY_HV
+#undef LAUNCH_L
 #undef LAUNCH
     RK_CHECK_LAUNCH("ae_encode_bwd");
+    if (words > 64 && gb_en) return rk_colsum(dZ0pre, B, h, h, nullptr, gb_en, stream_);
     return 0;
   }
   if (blk->n_cap >= 4096) {
-    // a row window of more than 64 bitmap words (more than 2048 rows) over a long item set: the wave-per-column
-    // kernel once per window of <= 2016 rows (the later ones accumulate), the bias gradient as one column sum
-    // of dZ -- the workgroup-per-column kernel below took 2.68 ms for 335 k columns at B = 4096, against
-    // 2 x 0.5 ms (every column holds one or two entries there)
-    const int W = 2016;                            // (63 words: a window that starts mid-word still fits 64)
+    // a row window of more than 128 bitmap words (more than 4096 rows) over a long item set: the wave-per-column
+    // kernel once per window of <= 4064 rows (the later ones accumulate; a column without entries in a later
+    // window is left alone), the bias gradient as one column sum of dZ -- the workgroup-per-column kernel
+    // below took 2.68 ms for 335 k columns at B = 4096
+    const int W = 4064;                            // (127 words: a window that starts mid-word still fits 128)
     for (int r0 = 0; r0 < B; r0 += W) {
       const int nb = B - r0 < W ? B - r0 : W;
       const int rc = rk_ae_encode_bwd(blk, row_off + r0, nb, dZ0pre + (int64_t)r0 * h, h, G_en,

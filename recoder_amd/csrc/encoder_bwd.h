@@ -156,11 +156,15 @@ __device__ __forceinline__ void ae_encode_bwd_body(
 // 2048), lists its rows in ascending order, fetches their values in parallel and then streams the
 // dZ rows, 8 loads in flight.  Columns with more than 64 entries are done afterwards by the 4 waves
 // of the workgroup together (64-row groups round-robin, combined in fixed order).
-template <int HV, bool DYN = false>
+// WW: bitmap words per lane (1: a row window of <= 2048 rows; 2: <= 4096 -- the stand-alone launch only);
+// U: dZ rows of a column in flight (8; 2 = the variant for blocks of LIGHT columns -- one or two stored
+// entries each, C5's uniform catalogue -- whose smaller register footprint doubles the columns in flight).
+template <int HV, bool DYN = false, int WW = 1, int U = 8>
 __device__ __forceinline__ void ae_encode_bwd_cols_body(
     const rk_block_t &b, int row_off, int B, const float *__restrict__ dZ, int h,
     float *__restrict__ G, int accumulate, float *__restrict__ gb, int n_gb, const int bid,
     char *sm = nullptr) {
+  static_assert(WW == 1 || !DYN, "the two-word window exists in the stand-alone kernel only");
   if (bid < n_gb) {                 // encoder-bias gradient: the shared body's first branch
     ae_encode_bwd_body<HV, DYN>(b, row_off, B, dZ, h, G, accumulate, gb, n_gb, bid, 1, 0, sm);
     return;
@@ -177,7 +181,7 @@ __device__ __forceinline__ void ae_encode_bwd_cols_body(
   } else {
     __shared__ __attribute__((aligned(16))) float part_s[3][HV * 256];
     __shared__ uint16_t rows_l_s[4][64];
-    __shared__ uint16_t rows_h_s[2048 + 64];
+    __shared__ uint16_t rows_h_s[WW * 2048 + 64];
     __shared__ int heavy_l_s[4];
     part = part_s; rows_l = rows_l_s; rows_h = rows_h_s; heavy_l = heavy_l_s;
   }
@@ -192,30 +196,46 @@ __device__ __forceinline__ void ae_encode_bwd_cols_body(
   const int c = c0 + wid * Q;
   const bool live = c < n_b;
   const int w0 = row_off >> 5, rend = row_off + B;
-  const int nw = ((rend + 31) >> 5) - w0;              // <= 64 (host-checked)
-  uint32_t m = 0;
-  if (live && lane < nw) {
-    m = b.bits_cr[(int64_t)c * b.ldw_cr + w0 + lane];
-    const int base = (w0 + lane) << 5;
-    if (base < row_off) m &= ~0u << (row_off - base);
-    if (base + 32 > rend) m &= (1u << (rend - base)) - 1u;     // (rend - base is in 1..31 here)
-  }
-  const int cnt = __popc(m);
-  int incl = cnt;
+  const int nw = ((rend + 31) >> 5) - w0;              // <= 64 WW (host-checked)
+  uint32_t mw[WW];
+  int off_w[WW];                                       // where this lane's rows of word set j start in the list
+  int total = 0;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int t = __shfl_up(incl, d, 64);
-    if (lane >= d) incl += t;
+  for (int j = 0; j < WW; ++j) {
+    const int wj = lane + 64 * j;
+    uint32_t m = 0;
+    if (live && wj < nw) {
+      m = b.bits_cr[(int64_t)c * b.ldw_cr + w0 + wj];
+      const int base = (w0 + wj) << 5;
+      if (base < row_off) m &= ~0u << (row_off - base);
+      if (base + 32 > rend) m &= (1u << (rend - base)) - 1u;     // (rend - base is in 1..31 here)
+    }
+    mw[j] = m;
   }
-  const int total = __shfl(incl, 63, 64);
+#pragma unroll
+  for (int j = 0; j < WW; ++j) {
+    const int cnt = __popc(mw[j]);
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += t;
+    }
+    off_w[j] = total + incl - cnt;                     // (ascending rows: word set 0 first)
+    total += __shfl(incl, 63, 64);
+  }
   const bool heavy = total > 64;
   if (lane == 0) heavy_l[wid] = heavy ? total : 0;
   if (!heavy) {
-    int o = incl - cnt;
-    while (m) {
-      const int k = __builtin_ctz(m);
-      m &= m - 1;
-      rows_l[wid][o++] = (uint16_t)(((w0 + lane) << 5) + k - row_off);    // (relative: < 2048 + 32)
+#pragma unroll
+    for (int j = 0; j < WW; ++j) {
+      uint32_t m = mw[j];
+      int o = off_w[j];
+      while (m) {
+        const int k = __builtin_ctz(m);
+        m &= m - 1;
+        rows_l[wid][o++] = (uint16_t)(((w0 + lane + 64 * j) << 5) + k - row_off);    // (relative: < 2048 WW + 32)
+      }
     }
   }
   __syncthreads();
@@ -230,23 +250,23 @@ __device__ __forceinline__ void ae_encode_bwd_cols_body(
       const uint32_t word = b.bits_rc[(int64_t)row * b.ldw_rc + (c >> 5)];
       sv = b.svals[rk_entry_index(b, row, c, word)];
     }
-    for (int k = 0; k < total; k += 8) {
-      int kk[8];
-      float s8[8];
+    for (int k = 0; k < total; k += U) {
+      int kk[U];
+      float s8[U];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {       // (lanes past `total` carry row_off / 0: exact zeros)
+      for (int u = 0; u < U; ++u) {       // (lanes past `total` carry row_off / 0: exact zeros)
         kk[u] = __shfl(row, (k + u) & 63, 64) - row_off;
         s8[u] = (k + u < 64) ? __shfl(sv, (k + u) & 63, 64) : 0.f;
       }
 #pragma unroll
       for (int v = 0; v < HV; ++v) {
         const int hh = min((v * 64 + lane) * 4, h - 4);
-        float4 d4[8];
+        float4 d4[U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < U; ++u)
           d4[u] = *reinterpret_cast<const float4 *>(dZ + (int64_t)kk[u] * h + hh);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < U; ++u) {
           acc[v].x = fmaf(s8[u], d4[u].x, acc[v].x);
           acc[v].y = fmaf(s8[u], d4[u].y, acc[v].y);
           acc[v].z = fmaf(s8[u], d4[u].z, acc[v].z);
@@ -255,7 +275,8 @@ __device__ __forceinline__ void ae_encode_bwd_cols_body(
       }
     }
   }
-  if (live && !heavy) {
+  // (a later row window -- `accumulate` -- of a column without entries in it leaves the row as it is)
+  if (live && !heavy && !(accumulate && total == 0)) {
     float *grow = G + (int64_t)c * h;
 #pragma unroll
     for (int v = 0; v < HV; ++v) {
@@ -278,11 +299,15 @@ __device__ __forceinline__ void ae_encode_bwd_cols_body(
     if (tot_j == 0) continue;
     const int cj = c0 + j * Q;
     if (wid == j) {
-      int o = incl - cnt;
-      while (m) {
-        const int k = __builtin_ctz(m);
-        m &= m - 1;
-        rows_h[o++] = (uint16_t)(((w0 + lane) << 5) + k - row_off);
+#pragma unroll
+      for (int jw = 0; jw < WW; ++jw) {
+        uint32_t m = mw[jw];
+        int o = off_w[jw];
+        while (m) {
+          const int k = __builtin_ctz(m);
+          m &= m - 1;
+          rows_h[o++] = (uint16_t)(((w0 + lane + 64 * jw) << 5) + k - row_off);
+        }
       }
     }
     __syncthreads();
@@ -299,23 +324,24 @@ __device__ __forceinline__ void ae_encode_bwd_cols_body(
         const uint32_t word = b.bits_rc[(int64_t)row * b.ldw_rc + (cj >> 5)];
         sv = b.svals[rk_entry_index(b, row, cj, word)];
       }
-      for (int k = 0; k < ne; k += 16) {
-        int kk[16];
-        float s16[16];
+      constexpr int UH = U >= 8 ? 16 : 2 * U;     // (dZ rows of a heavy column in flight)
+      for (int k = 0; k < ne; k += UH) {
+        int kk[UH];
+        float s16[UH];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {    // (lanes past `ne` carry row_off / 0: exact zeros)
+        for (int u = 0; u < UH; ++u) {    // (lanes past `ne` carry row_off / 0: exact zeros)
           kk[u] = __shfl(row, (k + u) & 63, 64) - row_off;
           s16[u] = (k + u < 64) ? __shfl(sv, (k + u) & 63, 64) : 0.f;
         }
 #pragma unroll
         for (int v = 0; v < HV; ++v) {
           const int hh = min((v * 64 + lane) * 4, h - 4);
-          float4 d4[16];
+          float4 d4[UH];
 #pragma unroll
-          for (int u = 0; u < 16; ++u)
+          for (int u = 0; u < UH; ++u)
             d4[u] = *reinterpret_cast<const float4 *>(dZ + (int64_t)kk[u] * h + hh);
 #pragma unroll
-          for (int u = 0; u < 16; ++u) {
+          for (int u = 0; u < UH; ++u) {
             acc[v].x = fmaf(s16[u], d4[u].x, acc[v].x);
             acc[v].y = fmaf(s16[u], d4[u].y, acc[v].y);
             acc[v].z = fmaf(s16[u], d4[u].z, acc[v].z);
