@@ -405,12 +405,16 @@ int rk_decode_dz_reduce(const float *dz_workspace, int32_t B, int32_t h, const r
  * the gradient tile becomes the MFMA operand of the dZ product through v_permlane32_swap -- no LDS round
  * trip; the tile's W rows stay resident in LDS and are read a second time along their rows (no W^T image).
  * dLoss/dLogits leaves as a plane image (scale granule 32 users x 64 items: dO_scales[(m / 32) *
- * ceil(n_cap / 64) + n / 64]); the slabs as rk_decode_loss_dz_planes leaves them (rk_decode_dz_reduce
- * sums them).  The decoder bias gradient is NOT produced here: rk_pg_dw_encode_bwd takes it from the image.
- * Domain: rk_plan_t.fdec_ok (mse / logistic, h <= 224, < 1024 rows; RK_FDEC=0: off). */
+ * ceil(n_cap / 64) + n / 64]).  Round 5, the STREAMING form: a workgroup walks a GROUP of column tiles of its
+ * 128-user row tile with the dZ accumulators in registers and leaves ONE slab per group (row tiles x groups
+ * ~ one workgroup per CU) -- rk_fdec_dz_reduce sums them (* act'(Zact) if given) into dZ[B, h].  The decoder
+ * bias gradient is NOT produced here: rk_pg_dw_encode_bwd takes it from the image.
+ * Domain: rk_plan_t.fdec_ok (mse / logistic, h <= 224; RK_FDEC=0: off). */
 int rk_fdec_loss_dz(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off, const float *b_de,
                     int32_t loss_kind, float confidence, float inv_B, void *dO_img, int32_t rows_img,
                     float *dO_scales, float *loss_part, float *dz_workspace, void *stream);
+int rk_fdec_dz_reduce(const float *dz_workspace, int32_t B, int32_t h, const rk_block_t *tgt, const float *Zact,
+                      int32_t act, float *dZ, void *stream);
 /* (RK_PG=0 in the environment switches the family off: the round-3 plane kernels run instead) */
 int rk_pg_decode_loss(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off,
                       const float *b_de, int32_t loss_kind, float confidence, float inv_B, void *dO_img,

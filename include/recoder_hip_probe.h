@@ -33,10 +33,16 @@ int rk_probe_buffer(int32_t which, unsigned long long *buffer);
  *   RK_TUNE_DZ_TN         0  column tiles (of 32 hidden units) per workgroup of rk_decode_bwd_dz_planes: 2/4/7/8
  *   RK_TUNE_DZ_SPLITS     0  cap of rk_decode_bwd_dz's split-K (multiple of 8)
  *   RK_TUNE_PAIR_ORDER    0  1: the second GEMM's tiles first in rk_linear_bwd's paired launch
- *   RK_TUNE_GRAPH_EVENT_NODES 0  1: bench brackets inside a captured graph as event-record nodes */
+ *   RK_TUNE_GRAPH_EVENT_NODES 0  1: bench brackets inside a captured graph as event-record nodes
+ *   RK_TUNE_FDEC_STREAM   0  the fused decode (csrc/fdecode.hip) in its STREAMING form -- a workgroup walks a group of
+ *                            column tiles, one dZ slab per group: 1 = from 1024 rows (the fused decode's domain
+ *                            then has no row limit), 2 = always, 0 = never (one workgroup and one slab per 128-item
+ *                            tile, < 1024 rows).  Measured, round 5: C2 at B = 4000 decode + dZ 539 -> 377 us, but the
+ *                            step 0.954 -> 0.996 ms (dW no longer runs beside a stand-alone dZ); B = 500 29.8 vs 23.9 us */
 enum { RK_TUNE_LINEAR_PAIR = 0, RK_TUNE_PLANES_TILE = 1, RK_TUNE_DZ_FUSED = 2, RK_TUNE_DW_ENC_FUSED = 3,
        RK_TUNE_DW_BF16X3 = 4, RK_TUNE_ADAM_DE_SIDE = 5, RK_TUNE_PG_TILE = 6, RK_TUNE_DZ_TN = 7,
-       RK_TUNE_DZ_SPLITS = 8, RK_TUNE_PAIR_ORDER = 9, RK_TUNE_GRAPH_EVENT_NODES = 10, RK_TUNE_COUNT = 11 };
+       RK_TUNE_DZ_SPLITS = 8, RK_TUNE_PAIR_ORDER = 9, RK_TUNE_GRAPH_EVENT_NODES = 10, RK_TUNE_FDEC_STREAM = 11,
+       RK_TUNE_COUNT = 12 };
 int rk_tune(int32_t knob, int32_t value);
 
 /* X[rows, cols] (ld) -> the fragment-ordered transposed fp16 pair planes of rk_decode_bwd_dw3 (test hook of

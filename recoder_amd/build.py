@@ -54,7 +54,8 @@ def build_library(force=False, verbose=True):
   if failed:
     raise RuntimeError("hipcc failed")
   if force or procs or _stale(LIB, objs):
-    cmd = [hipcc, "--offload-arch=gfx950", "--offload-compress", "-shared", "-fPIC", "-o", LIB] + objs
+    # (-z defs: an internal helper that is declared but defined nowhere must fail HERE, not at dlopen on the GPU box)
+    cmd = [hipcc, "--offload-arch=gfx950", "--offload-compress", "-shared", "-fPIC", "-Wl,-z,defs", "-o", LIB] + objs
     if verbose:
       print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

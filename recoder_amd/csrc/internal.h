@@ -5,6 +5,10 @@
 struct rk_planes;
 int rk_pg_dw_dense(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
                    const struct rk_planes *pl, const rk_block_t *tgt, float *G_de, float *gb_de, void *stream);
+int rk_splitk_reduce_tiles(const float *ws, int M, int N, const int32_t *Kdev, int max_splits, int tile_k,
+                           const float *Zact, int act, float *out, void *stream_);
+int rk_fdec_stream(int B);
+int rk_fdec_slabs(int B, int n_cap);
 extern "C" {
 int64_t rk_dz_workspace_bytes(int32_t B, int32_t h);
 int32_t rk_loss_partials(int32_t B, int32_t n_cap);

@@ -392,6 +392,9 @@ static int step_pg_mode(const rk_ae_step_t *a) {
       return 3;
     return 0;
   }
+  // 4: the fused decode in its STREAMING form (>= 1024 rows: one dZ slab per group of column tiles), dW from its
+  // image on rk_pg_dw / rk_pg_dw_encode_bwd, the encoder backward alone past the fused launch's row window
+  if (a->B >= 1024 && a->ws_dw != nullptr && rk_fdec_ok(a->B, a->h, a->blk->n_cap, a->loss_kind)) return 4;
   if (rk_decode_dz_fused_ok(a->B, a->h, a->blk->n_cap, a->loss_kind) == 0) return 1;
   // 3: the register-resident fused decode (csrc/fdecode.hip) + rk_pg_dw || encoder backward || image
   // column sums -- when the dW / encoder-backward launch can be the fused one (a->ws_dw, the row window)
@@ -444,17 +447,17 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   // Phased (data-parallel) steps: the slabs must survive from the FWD_DW call to the DZ_ENC call, so
   // the in-line dW of the first takes the workspace of its own (ws_dw) -- the same predicate in both calls.
   const bool both = (phase & RK_STEP_FWD_DW) && (phase & RK_STEP_DZ_ENC);
+  const int pg_mode = step_pg_mode(a);
   const bool dz_fused = pl && !a->tied && !mnll && a->ws != nullptr && (both ? whole : a->ws_dw != nullptr) &&
                         (phase & (RK_STEP_FWD_DW | RK_STEP_DZ_ENC)) != 0 &&
-                        rk_decode_dz_fused_ok(B, h, blk->n_cap, a->loss_kind) != 0;
+                        (rk_decode_dz_fused_ok(B, h, blk->n_cap, a->loss_kind) != 0 || pg_mode == 4);
   // dW and the encoder backward as ONE launch on the chain instead of a side-stream branch
   // (in the small-shape domain of the fused decode only: at C5's sizes -- dW 100+ us -- the side-stream
   // branch next to dZ -> encoder backward is worth more than its two edges: 0.75 vs 0.83 ms per step)
   const bool dw_enc_fused = dw3 && dz_fused && rk_dw_encode_bwd_fused_ok(a->row_off, B) != 0;
   // the three contractions on the pipelined pair-plane kernels (csrc/pgemm.h; include/recoder_hip.h
   // rk_ae_step_t.do_scales): whole untied MSE / BCE steps outside the fused decode's domain
-  const int pg_mode = step_pg_mode(a);
-  const bool pg = pg_mode == 1, fdec = pg_mode == 3;
+  const bool pg = pg_mode == 1, fdec = pg_mode == 3 || pg_mode == 4;
   const float *dw_slabs_pg = dw_branch ? a->ws_dw : a->ws;
   // opt-in (rk_adam_de_side): the decoder table's Adam sweep right behind the dW kernel ON dw_stream,
   // next to the reduce / encoder backward; the update on the chain then covers the rest
@@ -536,7 +539,9 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   if (phase & RK_STEP_DZ_ENC) {
     {
       Timer t(a, RK_ENTRY_DECODE_BWD_DZ, sm);
-      if (dz_fused)        // (the decode launch left the column tiles' partials in the workspace)
+      if (dz_fused && fdec)   // (the fused decode left one slab per group of column tiles in the workspace)
+        RK_TRY(rk_fdec_dz_reduce(a->ws, B, h, blk, a->Z0, a->act, a->dZ0, sm));
+      else if (dz_fused)   // (the decode launch left the column tiles' partials in the workspace)
         RK_TRY(rk_decode_dz_reduce(a->ws, B, h, blk, a->Z0, a->act, a->dZ0, sm));
       else if (pg)
         RK_TRY(rk_pg_dz(a->dO, a->do_scales, 64, 32, B, a->planes, blk, a->Z0, a->act, a->dZ0, a->ws, sm));
@@ -568,6 +573,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       {
         Timer t(a, RK_ENTRY_DECODE_BWD_DW, a->dw_stream);
         if (pg) RK_TRY(rk_pg_dw(a->dO, a->do_scales, 64, 32, B, a->planes, blk, a->ws_dw, nullptr, a->dw_stream));
+        else if (fdec) RK_TRY(rk_pg_dw(a->dO, a->do_scales, 32, 64, B, a->planes, blk, a->ws_dw, a->gb_de, a->dw_stream));
         else RK_TRY(dw_call(a, nullptr, nullptr, planes, a->ws_dw, a->dw_stream));
       }
       if (!de_side) {
@@ -580,6 +586,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       {
         Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
         if (pg) RK_TRY(rk_pg_dw(a->dO, a->do_scales, 64, 32, B, a->planes, blk, a->ws, nullptr, sm));
+        else if (fdec) RK_TRY(rk_pg_dw(a->dO, a->do_scales, 32, 64, B, a->planes, blk, a->ws, a->gb_de, sm));
         else RK_TRY(dw_call(a, nullptr, nullptr, planes));
       }
       Timer t(a, RK_ENTRY_ENCODE_BWD, sm);

@@ -177,6 +177,7 @@ class FusedEngine:
     self.ws = torch.zeros(max(self.lib.rk_dz_workspace_bytes(B_cap, h0),
                               # (any batch below 1024 rows -- a ragged last one too -- may take the fused form)
                               self.lib.rk_dz_fused_workspace_bytes(min(B_cap, 1023), h0, n_cap),
+                              self.lib.rk_fdec_workspace_bytes(B_cap, h0, n_cap),
                               self.lib.rk_dw_workspace_bytes(B_cap, h0, n_cap),
                               self.lib.rk_dw3_workspace_bytes(B_cap, h0, n_cap),
                               self.lib.rk_pg_dz_workspace_bytes(B_cap, h0),
@@ -1105,10 +1106,10 @@ class FusedEngine:
       st.phase = STEP_ALL
       mode = int(raw.rk_ae_step_uses_pg(ctypes.byref(st)))
       self._pg_step = bool(mode)
-      self._step_mode = mode       # (0: decode16 / dw3 kernels, 1: csrc/pgemm.h, 3: csrc/fdecode.hip + pgemm's dW; bench.py names the kernels by it)
+      self._step_mode = mode       # (0: decode16 / dw3 kernels, 1: csrc/pgemm.h, 3 / 4: csrc/fdecode.hip (4: streaming) + pgemm's dW; bench.py names the kernels by it)
       check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
-      if self.loss_id != LOSS_MNLL and mode != 3:
-        self._gb_lazy = (cdiv(B, self.row_tile), blk)    # (mode 3: gb_de itself, from the dO image)
+      if self.loss_id != LOSS_MNLL and mode not in (3, 4):
+        self._gb_lazy = (cdiv(B, self.row_tile), blk)    # (modes 3 / 4: gb_de itself, from the dO image)
     else:
       # data parallel over users: forward + whole backward locally, then the live gradient rows
       # of both tables, the gathered-bias gradient, the encoder bias gradient and the loss go out
