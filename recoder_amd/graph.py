@@ -80,6 +80,7 @@ class GraphStepper:
     self.exec = [None, None]
     self._la_slot = 1                      # slot holding the newest look-ahead blocks
     self.exec_first = [None, None]         # the group right behind a cut: its collation + its steps, per slot
+    self.exec_tail = [{}, {}]              # per slot: {n: the last n < G steps in front of a cut, no look-ahead}
     self.exec_timed = {}                   # (slot, first global index) -> a group captured WITH timing events
     self.warmed = False
     self.global_step = 0                   # steps this stepper's cursor has seen
@@ -90,10 +91,11 @@ class GraphStepper:
       if e:
         self.lib.rk_graph_destroy(e)
     self.exec = [None, None]
-    for e in self.exec_first:
+    for e in self.exec_first + [x for d in self.exec_tail for x in d.values()]:
       if e:
         self.lib.rk_graph_destroy(e)
     self.exec_first = [None, None]
+    self.exec_tail = [{}, {}]
     for e in self.exec_timed.values():
       self.lib.rk_graph_destroy(e)
     self.exec_timed = {}
@@ -318,11 +320,16 @@ class GraphStepper:
                                       self._h(self.main)), "rk_graph_launch")
         k = G
       else:
-        if need_pre:
-          self._pre_collate(left, slot)
+        eager = eager_plan is not None and any(eager_plan(idx0 + g) for g in range(left))
+        tail = self.exec_tail[slot].get(left) if (self.warmed and not need_pre and not eager) else None
         la = False
-        self._group(slot, left, first_index=idx0, lookahead=False)   # tail: fewer than G steps, eager
-        self._warm_capture()
+        if tail is not None:
+          check(lib.rk_graph_launch(tail, self._h(self.main)), "rk_graph_launch")
+        else:
+          if need_pre:
+            self._pre_collate(left, slot)
+          self._group(slot, left, first_index=idx0, lookahead=False)   # tail: fewer than G steps, eager
+          self._warm_capture()
         k = left
       need_pre = False
       self._advance_host(k)
@@ -364,6 +371,14 @@ class GraphStepper:
     for v in (0, 1):
       if self.exec_first[v] is None:
         self.exec_first[v] = self._capture(lambda v=v: (self._pre_collate(G, v), self._group(v)))
+    # the tails: n < G steps in front of a cut or the epoch's end, without a look-ahead collation.  Enqueued launch
+    # by launch such a step costs the GPU ~17 us more than replayed (the driver's 20-step run = 8 + 8 + 4 steps:
+    # 0.1177 -> see DESIGN.md section 5); one-call step, single process only
+    if self.c_step and self.dp is None and os.environ.get("RK_GRAPH_TAILS", "1") == "1":
+      for v in (0, 1):
+        for n in range(1, G):
+          if n not in self.exec_tail[v]:
+            self.exec_tail[v][n] = self._capture(lambda v=v, n=n: self._group(v, n, lookahead=False))
 
   def cut(self):
     """Forget the look-ahead blocks (a step mark / an eager ragged step follows).  The cursor of the
