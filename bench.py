@@ -66,6 +66,7 @@ ADAM_DE_SIDE = False
 # "rk_decode_bwd_dw", no "rk_ae_encode_bwd" launch)
 FUSED_DZ = False
 FUSED_DW_ENC = False
+STEP_MODE = 0          # rk_ae_step_uses_pg of the step that ran (engine._step_mode): set in main()
 # the kernels each bracketed entry launches (names as rocprofv3 --kernel-trace prints them)
 KERNELS = {"rk_ae_encode_fwd": ["ae_encode_fwd_kernel (+ the W_de[items] split workgroups)"],
            "rk_decode_loss": ["decode_planes_kernel<TM,2,EPI>"],
@@ -168,6 +169,12 @@ def algorithmic_work(entry, B, h0, n_b, nnz, n_items, cfg_sparse=False):
     # (the decoder-side gradient arrives as `slabs` K slabs of the bf16-pipe dW kernel, summed here)
     tiles = -(-int(n_b) // 64) * -(-h0 // (128 if h0 <= 128 else 256))
     slabs = 1 if GEMM_F32 else max(1, min(256 // max(tiles, 1), 4, (-(-B // 64) * 64) // 64))
+    if STEP_MODE in (1, 3, 4):
+      # csrc/pgemm.hip's dW: 64 x 128 tiles below 1024 rows (256-wide from there), split-K chosen on the device as
+      # min(4, 256 / live tiles) -- C2 at B = 500: 123 x 2 tiles, ONE slab (rounds 1-4 priced the dw3.hip rule above:
+      # an extra 6.3 MB slab the PMC passes never saw)
+      bm, bn = (64, 128) if B < 1024 else (256, 128 if h0 <= 128 else 256)
+      slabs = max(1, min(4, 256 // max(1, -(-int(n_b) // bm) * -(-h0 // bn))))
     extra = (slabs - 1) * n_b * h0 * 4
     if cfg_sparse:
       table, rest = n_b * h0 * 28, n_items * 28 + n_b * 32
@@ -679,7 +686,8 @@ def main():
     from recoder_amd import _lib as _rk_lib
     one_call = cfg["kind"] == "ae" and len(cfg["hidden_layers"]) == 1 and cfg["loss"] in ("mse", "logistic") \
         and getattr(eng, "ws_dw", None) is not None and not multi and getattr(eng, "planes", None) is not None
-    step_mode = int(getattr(eng, "_step_mode", 0))
+    global STEP_MODE
+    step_mode = STEP_MODE = int(getattr(eng, "_step_mode", 0))
     if one_call:
       lk = 0 if cfg["loss"] == "mse" else 1
       FUSED_DZ = bool(_rk_lib.load().rk_decode_dz_fused_ok(B, h0, eng.n_cap_last, lk)) or step_mode in (3, 4)

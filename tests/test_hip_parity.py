@@ -418,6 +418,11 @@ STEP_CASES = [
   ("ragged_1024_after_1100_ae512", dict(kind="ae", hidden_layers=[512], activation_type="tanh", noise_prob=0.0,
                                         sparse=False, loss="mse", loss_params=None, lr=1e-3, weight_decay=2e-5),
    (2124, 300, 8), 1100, 1100),
+  # h > 512 at >= 1024 rows: 256 x 256 dW tiles; the merged dW || encoder-backward instantiation spilled there
+  #  -- two launches now
+  ("big_ae640", dict(kind="ae", hidden_layers=[640], activation_type="tanh", noise_prob=0.0,
+                     sparse=True, loss="mse", loss_params=None, lr=1e-3, weight_decay=0.0),
+   (1300, 400, 10), 1100, 1100),
   ("ragged_1024_after_1100_ae64", dict(kind="ae", hidden_layers=[64], activation_type="tanh", noise_prob=0.0,
                                        sparse=True, loss="logistic", loss_params=None, lr=1e-3, weight_decay=0.0),
    (2124, 300, 8), 1100, 1100),
