@@ -615,7 +615,7 @@ extern "C" int rk_decode_bwd_dw2(const float *dO, const float *Z, int32_t B, int
 // rk_decode_bwd_dw2 (slabs stay in the workspace: G_de == NULL semantics) and rk_ae_encode_bwd (one
 // bitmap word per lane: the row window spans <= 64 words) in ONE launch -- see dw_encbwd_kernel
 extern "C" int32_t rk_dw_encode_bwd_fused_ok(int32_t row_off, int32_t B) {
-  return rk_tune_get(RK_TUNE_DW_ENC_FUSED) != 0 && rk_dw_pairs() && (((row_off + B + 31) >> 5) - (row_off >> 5) <= 64) ? 1 : 0;
+  return rk_tune_get(RK_TUNE_DW_ENC_FUSED) == 1 && rk_dw_pairs() && (((row_off + B + 31) >> 5) - (row_off >> 5) <= 64) ? 1 : 0;
 }
 
 extern "C" int rk_decode_bwd_dw2_encode_bwd(const float *dO, const float *Z, int32_t B, int32_t h,

@@ -394,7 +394,10 @@ static int step_pg_mode(const rk_ae_step_t *a) {
   }
   // 4: the fused decode in its STREAMING form (>= 1024 rows: one dZ slab per group of column tiles), dW from its
   // image on rk_pg_dw / rk_pg_dw_encode_bwd, the encoder backward alone past the fused launch's row window
-  if (a->B >= 1024 && a->ws_dw != nullptr && rk_fdec_ok(a->B, a->h, a->blk->n_cap, a->loss_kind)) return 4;
+  // (rk_tune RK_TUNE_DW_ENC_FUSED = 2, an A/B switch: the same below 1024 rows -- the one-tile fused decode, dW on
+  // the side stream beside reduce -> encoder backward instead of sharing the encoder backward's launch)
+  if ((a->B >= 1024 || rk_tune_get(RK_TUNE_DW_ENC_FUSED) == 2) && a->ws_dw != nullptr &&
+      rk_fdec_ok(a->B, a->h, a->blk->n_cap, a->loss_kind)) return 4;
   if (rk_decode_dz_fused_ok(a->B, a->h, a->blk->n_cap, a->loss_kind) == 0) return 1;
   // 3: the register-resident fused decode (csrc/fdecode.hip) + rk_pg_dw || encoder backward || image
   // column sums -- when the dW / encoder-backward launch can be the fused one (a->ws_dw, the row window)

@@ -418,6 +418,14 @@ STEP_CASES = [
   ("ragged_1024_after_1100_ae512", dict(kind="ae", hidden_layers=[512], activation_type="tanh", noise_prob=0.0,
                                         sparse=False, loss="mse", loss_params=None, lr=1e-3, weight_decay=2e-5),
    (2124, 300, 8), 1100, 1100),
+  # HEAVY rows (lognormal degrees around 150: rows of 300 ... 1500 stored interactions, several 64-entry rounds per
+  # wave of the encoder forward; explicit ratings: the norm over the whole row; implicit + noise: the counter RNG)
+  ("heavy_rows_ae200", dict(kind="ae", hidden_layers=[200], activation_type="tanh", noise_prob=0.5,
+                            sparse=False, loss="mse", loss_params=None, lr=1e-3, weight_decay=2e-5),
+   (600, 6000, 150), 200, 200),
+  ("heavy_rows_ae64_bce", dict(kind="ae", hidden_layers=[64], activation_type="relu", noise_prob=0.3,
+                               sparse=True, loss="logistic", loss_params=None, lr=1e-3, weight_decay=0.0),
+   (500, 5000, 200), 128, 128),
   # h > 512 at >= 1024 rows: 256 x 256 dW tiles; the merged dW || encoder-backward instantiation spilled there
   #  -- two launches now
   ("big_ae640", dict(kind="ae", hidden_layers=[640], activation_type="tanh", noise_prob=0.0,
