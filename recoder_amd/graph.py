@@ -81,6 +81,7 @@ class GraphStepper:
     self._la_slot = 1                      # slot holding the newest look-ahead blocks
     self.exec_first = [None, None]         # the group right behind a cut: its collation + its steps, per slot
     self.exec_tail = [{}, {}]              # per slot: {n: the last n < G steps in front of a cut, no look-ahead}
+    self.capture_tails = os.environ.get("RK_BENCH_NO_TAILS") != "1"    # (tools/probes/ab_s20.sh: the A/B of this)
     self.exec_timed = {}                   # (slot, first global index) -> a group captured WITH timing events
     self.warmed = False
     self.global_step = 0                   # steps this stepper's cursor has seen
@@ -374,7 +375,7 @@ class GraphStepper:
     # the tails: n < G steps in front of a cut or the epoch's end, without a look-ahead collation.  Enqueued launch
     # by launch such a step costs the GPU ~17 us more than replayed (the driver's 20-step run = 8 + 8 + 4 steps:
     # 0.1177 -> see DESIGN.md section 5); one-call step, single process only
-    if self.c_step and self.dp is None and os.environ.get("RK_GRAPH_TAILS", "1") == "1":
+    if self.c_step and self.dp is None and self.capture_tails:
       for v in (0, 1):
         for n in range(1, G):
           if n not in self.exec_tail[v]:
