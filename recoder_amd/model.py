@@ -559,17 +559,18 @@ class Recoder(object):
     """Sharded dense Adam (parallel.DataParallel, "ZeRO-1"): with optim.Adam on the embedding tables of the
     one-call autoencoder step every rank owns an equal range of table rows -- gradient rows reduce-scattered,
     the sweep over 1/N of the rows, the updated rows all-gathered; the moments of a row are kept up to date on
-    its owner only and gathered before checkpoints / validation (_sync_owned_moments).  RK_DP_ZERO = auto
-    (default: from 8 ranks) | 1 (with more than one rank) | 0 | force (also with one rank: tests, the one-rank
-    bench line).  The exchange then moves the DENSE layout (every row of the tables, = the capacity-sized
-    exchange of a replayed step) where the replicated update's moves the union rows: by tools/dp_model.py the
-    saved 7/8 of the sweep pays for that from 8 ranks at C2 / C3 (282 vs 290, 624 vs 627 us per step at
-    1 TB/s per rank; 2 and 4 ranks lose 5-15 %) -- a model: no run on more than one GPU exists."""
+    its owner only and gathered before checkpoints / validation (_sync_owned_moments).  RK_DP_ZERO = 0 (default) |
+    1 (with more than one rank) | force (also with one rank: tests, the one-rank bench line).  OPT-IN: the
+    exchange then moves the DENSE layout (every row of the tables, = the capacity-sized exchange of a replayed
+    step) where the replicated update's moves the union rows, and by tools/dp_model.py the saved (1 - 1/N) of
+    the sweep only pays for that at 8 ranks, by 1-3 % (C2 282 vs 290, C3 624 vs 627 us per step at 1 TB/s per
+    rank; 2 and 4 ranks lose 5-15 %) -- a model: no run on more than one GPU exists, and a path that has never
+    met a second RCCL rank is not what the first 8-GPU run should take by default."""
     eng = self._engine()
     eng.zero_adam = False
     dp.zero = None
-    mode = os.environ.get("RK_DP_ZERO", "auto")
-    if mode == "0" or not (dp.world >= 8 or (mode == "1" and dp.world > 1) or mode == "force"):
+    mode = os.environ.get("RK_DP_ZERO", "0")
+    if not ((mode == "1" and dp.world > 1) or mode == "force"):
       return
     if getattr(eng, "generic", False) or getattr(eng, "owned_rows", False) or not eng.c_step_eligible():
       return
