@@ -611,7 +611,8 @@ int rk_adam_multi(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part,
                   int32_t n_part, float denom, float *loss_out, void *stream);
 /* D[row, :] = pos[row] >= 0 ? G[pos[row], :] : 0 for row < n_items, 0 for n_items <= row < rows_pad: the
  * compact gradient rows of a block laid out by ITEM ID -- the layout a reduce-scatter over equal row
- * ranges needs (sharded dense Adam, rk_ae_step_t.zero_lo).  h % 4 == 0, 16-byte aligned. */
+ * ranges needs (sharded dense Adam, rk_ae_step_t.zero_lo).  h % 4 == 0 and 16-byte aligned, or h == 1 (a gathered
+ * bias gradient). */
 int rk_rows_to_dense(const float *G, const int32_t *pos, int32_t n_items, int32_t rows_pad, int32_t h,
                      float *D, void *stream);
 
@@ -685,6 +686,10 @@ typedef struct rk_ae_step {
    * Adam sweep treats every row independently, reference model.py:135,398-399).  zero_hi == 0: off. */
   int32_t zero_lo, zero_hi;
   const float *zero_g_en, *zero_g_de;
+  /* nullable: the decoder bias gradient as a DENSE vector [n_items] (users-DP with per-rank item sets,
+   * RK_DP_ITEMSETS=local: the ranks' compact columns differ, so every gradient travels laid out by item id);
+   * the bias job of RK_STEP_UPDATE then reads it row by row instead of gb_de through the block's pos map */
+  const float *zero_gb_de;
 } rk_ae_step_t;
 
 void *rk_event_create(int32_t timing); /* 0: ordering-only (no timing, device-scope fence); 1: for time_ev0 /

@@ -28,7 +28,7 @@ int rk_probe_buffer(int32_t which, unsigned long long *buffer);
  *   RK_TUNE_DZ_FUSED      1  the fused decode + loss + dZ launch where it applies (rk_plan_t.decode_dz_fused_ok)
  *   RK_TUNE_DW_ENC_FUSED  1  dW || encoder backward in one launch (rk_plan_t.dw_encode_bwd_fused_ok); 0: never (the step then
  *                            leaves the register-resident fused decode too); 2: an A/B form -- the fused decode with dW from its
- *                            image on the side stream beside reduce -> encoder backward (round 5: 0.120 vs 0.1106 ms at C2) */
+ *                            image on the side stream beside reduce -> encoder backward (round 5: 0.120 vs 0.1106 ms at C2)
  *   RK_TUNE_DW_BF16X3     0  dW on bf16 triples (no operand range) instead of fp16 pairs
  *   RK_TUNE_ADAM_DE_SIDE  0  the decoder table's Adam sweep as a launch of its own behind dW on dw_stream
  *   RK_TUNE_PG_TILE       0  decode tile of csrc/pgemm.hip: 256 (256 x 256), 1282 (128 x 256), 0 = by batch size

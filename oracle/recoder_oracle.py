@@ -358,6 +358,30 @@ class OracleRecoder:
       self.sparse_optimizer.step()
     return float(loss.item())
 
+  def train_step_ddp(self, batches, noise_keeps=None):
+    """One iteration of the reference trainer under conventional data parallelism (what wrapping its model in
+    torch DistributedDataParallel does; the reference itself has no multi-device code): every rank runs
+    model.py:454-485 on ITS OWN collated batch -- its own sampled item set --, the losses are averaged over the
+    ranks (DDP averages the gradients), ONE optimizer step follows (model.py:397-402).  batches: one Batch per
+    rank, equally sized.  Returns the averaged loss.  NOT the single-process semantics of a shared item set
+    (data.py:216-223): the oracle of recoder_amd's opt-in RK_DP_ITEMSETS=local mode."""
+    self.training = True
+    if self.optimizer is not None:
+      self.optimizer.zero_grad()
+    if self.sparse_optimizer is not None:
+      self.sparse_optimizer.zero_grad()
+    total = 0.0
+    n = len(batches)
+    for r, b in enumerate(batches):
+      loss = self.compute_loss(b, None, None if noise_keeps is None else noise_keeps[r], None) / n
+      loss.backward()                    # (.grad accumulates over the ranks' batches)
+      total += float(loss.item())
+    if self.optimizer is not None:
+      self.optimizer.step()
+    if self.sparse_optimizer is not None:
+      self.sparse_optimizer.step()
+    return total
+
   def grads(self):
     out = {}
     for k, p in self.params.items():

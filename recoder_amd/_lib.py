@@ -92,6 +92,7 @@ class RkAeStep(Structure):
     ("planes", c_void_p),
     ("do_scales", c_void_p), ("do_rows", c_int32),
     ("zero_lo", c_int32), ("zero_hi", c_int32), ("zero_g_en", c_void_p), ("zero_g_de", c_void_p),
+    ("zero_gb_de", c_void_p),
   ]
 
 

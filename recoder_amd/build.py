@@ -31,7 +31,8 @@ def _stale(target, deps):
 def build_library(force=False, verbose=True):
   hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
   headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
-      [os.path.join(os.path.dirname(CSRC), "..", "include", "recoder_hip.h")]
+      [os.path.join(os.path.dirname(CSRC), "..", "include", "recoder_hip.h"),
+       os.path.join(os.path.dirname(CSRC), "..", "include", "recoder_hip_probe.h")]
   objs = []
   procs = []
   for src in SOURCES:

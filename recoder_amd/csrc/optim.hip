@@ -635,14 +635,27 @@ __global__ __launch_bounds__(256) void rows_to_dense_kernel(const float4 *__rest
     D[i] = pr >= 0 ? G[(int64_t)pr * hq + q] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
+__global__ __launch_bounds__(256) void rows_to_dense1_kernel(const float *__restrict__ G, const int32_t *__restrict__ pos,
+                                                             int n_items, int rows_pad, float *__restrict__ D) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < rows_pad; i += gridDim.x * 256) {
+    const int pr = i < n_items ? pos[i] : -1;
+    D[i] = pr >= 0 ? G[pr] : 0.f;
+  }
+}
 }  // namespace
 
 extern "C" int rk_rows_to_dense(const float *G, const int32_t *pos, int32_t n_items, int32_t rows_pad, int32_t h,
                                 float *D, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  RK_REQUIRE(h > 0 && h % 4 == 0 && rows_pad >= n_items && n_items >= 0, "h % 4 == 0, rows_pad >= n_items");
-  RK_REQUIRE((((uintptr_t)G | (uintptr_t)D) & 15) == 0, "operands must be 16-byte aligned");
+  RK_REQUIRE(rows_pad >= n_items && n_items >= 0, "rows_pad >= n_items");
   if (rows_pad == 0) return 0;
+  if (h == 1) {
+    RK_LAUNCH(rows_to_dense1_kernel, dim3(grid_for(rows_pad)), dim3(256), 0, stream, G, pos, n_items, rows_pad, D);
+    RK_CHECK_LAUNCH("rows_to_dense");
+    return 0;
+  }
+  RK_REQUIRE(h > 0 && h % 4 == 0, "h % 4 == 0 (or 1)");
+  RK_REQUIRE((((uintptr_t)G | (uintptr_t)D) & 15) == 0, "operands must be 16-byte aligned");
   RK_LAUNCH(rows_to_dense_kernel, dim3(grid_for((int64_t)rows_pad * (h / 4))), dim3(256), 0, stream,
             reinterpret_cast<const float4 *>(G), pos, n_items, rows_pad, h / 4, reinterpret_cast<float4 *>(D));
   RK_CHECK_LAUNCH("rows_to_dense");

@@ -651,6 +651,10 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     slots[n] = RK_PAR_B_DE;
     jobs[n] = table_job(a->par[RK_PAR_B_DE], blk, n_items, 1, a->gb_de, true);
     jobs[n].par.sparse = 0; jobs[n].rows = nullptr; jobs[n].n_dev = nullptr; jobs[n].pos = blk->pos;
+    if (a->zero_gb_de) {           // (per-rank item sets: the summed gradient arrives laid out by item id)
+      RK_REQUIRE(!whole, "zero_gb_de: phased steps");
+      jobs[n].g = a->zero_gb_de; jobs[n].pos = nullptr;
+    } else
     if (whole && !mnll && !fdec) { // straight from the decode epilogue's row-tile partials
       jobs[n].g = a->gb_part; jobs[n].g_parts = row_tiles; jobs[n].gstride_dev = blk->counts + 2;
     }                              // (fdec: gb_de itself, written by the dW launch's column-sum range)

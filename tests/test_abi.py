@@ -53,8 +53,11 @@ def test_the_library_exports_exactly_the_declared_symbols(lib):
 def test_struct_layouts_match_the_header(tmp_path, lib):
   from recoder_amd import _lib
   c = tmp_path / "sz.c"
-  c.write_text('#include <stdio.h>\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu\\n", '
-               'sizeof(rk_block_t), sizeof(rk_adam_param_t), sizeof(rk_ae_step_t), sizeof(rk_plan_t));return 0;}\n' % HEADER)
+  # (both headers go through a plain C compiler here: a comment closed too early in the probe header once broke
+  # every .hip file of the library while the prebuilt .so kept the tests green)
+  c.write_text('#include <stdio.h>\n#include "%s"\n#include "%s"\nint main(){printf("%%zu %%zu %%zu %%zu\\n", '
+               'sizeof(rk_block_t), sizeof(rk_adam_param_t), sizeof(rk_ae_step_t), sizeof(rk_plan_t));'
+               'return RK_TUNE_COUNT > 0 ? 0 : 1;}\n' % (HEADER, PROBE_HEADER))
   exe = tmp_path / "sz"
   subprocess.check_call(["gcc", str(c), "-o", str(exe)])
   sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
@@ -110,3 +113,13 @@ def test_dz_workspace_covers_every_batch_size_up_to_the_capacity(lib):
         cur = fn(b, h)
         assert cur >= prev, (h, b)
         prev = cur
+
+
+def test_the_library_is_not_older_than_its_sources():
+  """The in-tree .so travels to the GPU box as built: a source or header edited after the last build would be
+  tested against stale code (and build() would fail later, where nobody looks).  Rebuild, then compare."""
+  from recoder_amd.build import CSRC, LIB, SOURCES, build_library
+  build_library(verbose=False)
+  deps = [os.path.join(CSRC, f) for f in SOURCES] + \
+      [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [HEADER, PROBE_HEADER]
+  assert os.path.getmtime(LIB) >= max(os.path.getmtime(d) for d in deps)
