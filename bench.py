@@ -310,7 +310,7 @@ def recall_check(rec, model, cfg, csr, n_held=1000, k=20):
                        "oracle/recoder_oracle.py evaluate on the same parameters" % (k, csr_in.shape[0]))
 
 
-def alt_large_batch(cfg, csr, B_alt, W, K, world, rank, device, sync_all):
+def alt_large_batch(cfg, csr, B_alt, W, K, world, rank, device, sync_all, env=None, label=None):
   """The same workload, users-DP, with B_alt users per rank and step: C2's union item set
   saturates at ~20 k items, so past B ~ 2 000 per rank the contractions, the exchange and the Adam sweep stop
   growing with the batch -- the configuration whose weak scaling the first 8-GPU run can judge the exchange
@@ -320,6 +320,8 @@ def alt_large_batch(cfg, csr, B_alt, W, K, world, rank, device, sync_all):
   from recoder_amd.model import Recoder
   from recoder_amd.nn import DynamicAutoencoder
   n_users, n_items = csr.shape
+  prev_env = {k: os.environ.get(k) for k in (env or {})}
+  os.environ.update(env or {})
   torch.manual_seed(0)
   model = DynamicAutoencoder(hidden_layers=cfg["hidden_layers"], activation_type=cfg["activation_type"],
                              noise_prob=cfg["noise_prob"], sparse=cfg["sparse"])
@@ -342,14 +344,24 @@ def alt_large_batch(cfg, csr, B_alt, W, K, world, rank, device, sync_all):
     T["dt"] = time.perf_counter() - T["t0"]
     return True
   rec.step_marks = {W: start, W + K: stop}
-  rec.train(RecommendationDataset(csr), batch_size=B_alt, lr=cfg["lr"], weight_decay=cfg["weight_decay"],
-            num_epochs=epochs, negative_sampling=True)
+  try:
+    rec.train(RecommendationDataset(csr), batch_size=B_alt, lr=cfg["lr"], weight_decay=cfg["weight_decay"],
+              num_epochs=epochs, negative_sampling=True)
+  finally:
+    for k, v in prev_env.items():
+      if v is None:
+        os.environ.pop(k, None)
+      else:
+        os.environ[k] = v
   dt = T["dt"]
   if multi:
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-  return {"parallelism": "dp%d (users sharded, B = %d per rank)" % (world, B_alt), "batch_size_per_gpu": B_alt,
+  dp_obj = getattr(rec, "_dp", None)
+  return {"parallelism": label or ("dp%d (users sharded, B = %d per rank)" % (world, B_alt)), "batch_size_per_gpu": B_alt,
+          "local_item_sets": bool(getattr(dp_obj, "local_sets", False)),
+          "sharded_dense_adam": bool(getattr(rec._engine(), "zero_adam", False)),
           "value": K * B_alt * world / dt, "unit": "users/s", "ms_per_step": dt / K * 1e3, "steps": K, "warmup": W,
           "graph_replay": bool(getattr(rec, "_graph_stepper", None) is not None)}
 
@@ -882,7 +894,7 @@ def main():
                                            "timed group runs inside it (one per group, as in steady state)")
                                           if T.get("precollated") else "inside the timed region, in front of step 0",
                  "exchange_microbench": exch,
-                 "alt_item_parallel": None, "alt_large_batch": None},
+                 "alt_item_parallel": None, "alt_large_batch": None, "alt_local_item_sets": None},
       "roofline": roofline,
     }
     if GEMM_BF16:
@@ -932,6 +944,19 @@ def main():
         altb = {"error": "%s: %s" % (type(e).__name__, e)}
       if rank == 0:
         out["config"]["alt_large_batch"] = altb
+    if cfg["kind"] == "ae" and len(cfg["hidden_layers"]) == 1 and not cfg["sparse"]:
+      # the OTHER estimator (opt-in): every rank samples its negatives from its own users'
+      # items (the reference under conventional DDP) -- contractions and item sets stop growing with the ranks;
+      # gradients laid out by item id, reduce-scattered, sharded dense Adam on top
+      try:
+        altl = alt_large_batch(cfg, csr, B, max(4, W // 2), max(16, K // 5), world, rank, device, sync_all,
+                               env={"RK_DP_ITEMSETS": "local", "RK_DP_ZERO": "1"},
+                               label="dp%d (users sharded, PER-RANK item sets: not the reference's shared-set "
+                                     "semantics; dense gradient layout, sharded dense Adam)" % world)
+      except Exception as e:          # noqa: BLE001
+        altl = {"error": "%s: %s" % (type(e).__name__, e)}
+      if rank == 0:
+        out["config"]["alt_local_item_sets"] = altl
     finished.set()
   if B_large and not want_alt:
     # (one rank, or RK_PARALLEL=items: the large-batch line alone)

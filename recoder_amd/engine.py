@@ -1041,7 +1041,7 @@ class FusedEngine:
     st.cursor, st.cursor_off, st.adam_table, st.cursor_next, st.cursor_advance = None, 0, None, None, 0
     st.ws_dw = st.dw_stream = st.dw_fork = st.dw_join = None
     st.zero_lo = st.zero_hi = 0
-    st.zero_g_en = st.zero_g_de = None
+    st.zero_g_en = st.zero_g_de = st.zero_gb_de = None
     if dp is not None and self.ws_dw is not None and not m.is_constrained:
       st.ws_dw = ptr(self.ws_dw)        # (phased steps: dW's own workspace lets the decode launch keep its dZ slabs)
     self._ws_dw_live = False
@@ -1125,31 +1125,53 @@ class FusedEngine:
       n_x = dp.round_rows(n_b, blk.n_cap) if hasattr(dp, "round_rows") else n_b
       G_enc = self.G_de if tied else self.G_en
       zero = getattr(dp, "zero", None) if getattr(self, "zero_adam", False) else None
-      if zero is not None:
-        # sharded dense Adam (parallel.DataParallel "ZeRO-1"): the compact gradient rows go out laid out by
-        # item id and come back reduce-scattered -- this rank's row range of the dense gradient --, the
-        # update covers that range only (rk_ae_step_t.zero_lo), the updated rows are all-gathered
-        lo, hi, sh, rp_ = zero["lo"], zero["hi"], zero["sh"], zero["rows_pad"]
-        D, S_en, S_de = self._zero_buffers(rp_, sh, h0)
+      local = bool(getattr(dp, "local_sets", False))
+      if zero is not None or local:
+        # The gradients travel laid out by ITEM ID (rk_rows_to_dense) and the update reads them row by row:
+        #  * sharded dense Adam (parallel.DataParallel "ZeRO-1"): the dense layout is reduce-scattered -- this
+        #    rank's row range comes back --, the update covers that range only (rk_ae_step_t.zero_lo), the
+        #    updated rows are all-gathered;
+        #  * per-rank item sets (dp.local_sets): the ranks' compact columns differ, so the dense layout is the
+        #    only common one -- all-reduced in place (or reduce-scattered, with the sharded update on top); the
+        #    gathered decoder-bias gradient travels as a dense vector too (rk_ae_step_t.zero_gb_de).
         n_items = blk.n_items
+        if zero is not None:
+          lo, hi, sh, rp_ = zero["lo"], zero["hi"], zero["sh"], zero["rows_pad"]
+          D, S_en, S_de = self._zero_buffers(rp_, sh, h0)
+          D_en = D_de = D
+          sh_en, sh_de = S_en, S_de
+        else:
+          lo, hi, rp_ = 0, n_items, n_items
+          D_en, D_de = self._dense_grad_buffers(n_items, h0)
+          S_en, S_de = D_en, D_de
+          sh_en = sh_de = None               # (all-reduced in place)
+        gb_dense = self._gb_dense_buffer(n_items) if local else None
 
-        def stage_of(G):
-          return lambda s_: check(raw.rk_rows_to_dense(ptr(G), ptr(blk.pos), n_items, rp_, h0, ptr(D),
-                                                       ctypes.c_void_p(s_.cuda_stream)), "rk_rows_to_dense")
+        def stage_of(G, D_, with_gb=False):
+          def go(s_):
+            hs = ctypes.c_void_p(s_.cuda_stream)
+            check(raw.rk_rows_to_dense(ptr(G), ptr(blk.pos), n_items, rp_, h0, ptr(D_), hs), "rk_rows_to_dense")
+            if with_gb and gb_dense is not None:
+              check(raw.rk_rows_to_dense(ptr(self.gb_de), ptr(blk.pos), n_items, n_items, 1, ptr(gb_dense), hs),
+                    "rk_rows_to_dense")
+          return go
+        loss_v, gb_en_v = self.small[h0:h0 + 1], self.small[:h0]
+        dec_small = [loss_v, gb_dense] if local else [self.small[h0:self.small_off + n_b]]
         if tied:
           st.phase = STEP_FWD_DW | STEP_DZ_ENC
           check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
-          dp.zero_exchange(stage_of(G_enc), D, S_en, [self.small[:self.small_off + n_b]], main_s, overlap=False)
+          dp.zero_exchange(stage_of(G_enc, D_en, True), D_en, sh_en, [gb_en_v] + dec_small, main_s, overlap=False)
         else:
           st.phase = STEP_FWD_DW
           check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
-          dp.zero_exchange(stage_of(self.G_de), D, S_de, [self.small[h0:self.small_off + n_b]], main_s)
+          dp.zero_exchange(stage_of(self.G_de, D_de, True), D_de, sh_de, dec_small, main_s)
           st.phase = STEP_DZ_ENC
           check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
-          dp.zero_exchange(stage_of(G_enc), D, S_en, [self.small[:h0]], main_s)
+          dp.zero_exchange(stage_of(G_enc, D_en), D_en, sh_en, [gb_en_v], main_s)
           dp.join_async(main_s)
         st.zero_lo, st.zero_hi = lo, hi
         st.zero_g_en, st.zero_g_de = ptr(S_en), (None if tied else ptr(S_de))
+        st.zero_gb_de = ptr(gb_dense) if local else None
       elif tied:
         # tied weights: the encoder backward accumulates onto dW's rows -- nothing may leave before it
         st.phase = STEP_FWD_DW | STEP_DZ_ENC
@@ -1178,6 +1200,24 @@ class FusedEngine:
         dp.zero_publish([S[n_].p.data for n_ in names_], h0, extra_max=self.ranges[64:])
     self._loss_target = out
     return out
+
+  def _dense_grad_buffers(self, n_items, h0):
+    """(per-rank item sets without sharding) the two tables' gradients laid out by item id, all-reduced in place"""
+    z = getattr(self, "_dense_bufs", None)
+    if z is None or z[0].numel() != n_items * h0:
+      f = dict(dtype=torch.float32, device=self.device)
+      z = (torch.zeros(n_items * h0, **f), torch.zeros(n_items * h0, **f))
+      self._dense_bufs = z
+      self.alloc_gen = getattr(self, "alloc_gen", 0) + 1
+    return z
+
+  def _gb_dense_buffer(self, n_items):
+    z = getattr(self, "_gb_dense", None)
+    if z is None or z.numel() != n_items:
+      z = torch.zeros(n_items, dtype=torch.float32, device=self.device)
+      self._gb_dense = z
+      self.alloc_gen = getattr(self, "alloc_gen", 0) + 1
+    return z
 
   def _zero_buffers(self, rows_pad, sh, h0):
     """(D [rows_pad, h]: the gradient rows laid out by item id -- one staging buffer, the two halves of a

@@ -138,7 +138,7 @@ class GraphStepper:
       cache[key] = arr
     args = (ptr(d.indptr), ptr(d.indices), ptr(d.data), ptr(self.order), self.B, 1 if self.ns else 0,
             self._cur(slot), off0, arr, n)
-    if self.dp is None:
+    if self.dp is None or getattr(self.dp, "local_sets", False):     # (per-rank item sets: no stamp exchange)
       check(self.lib.rk_collate_at_multi(*args, 0, self._h(stream)), "rk_collate_at_multi")
       return
     check(self.lib.rk_collate_at_multi(*args, 1, self._h(stream)), "rk_collate_at_multi")

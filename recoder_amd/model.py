@@ -498,6 +498,7 @@ class Recoder(object):
     dp.attach(self._engine())
     self._dp = dp
     self._setup_owned_rows(dp, train_dataset, negative_sampling, batch_size)
+    self._setup_local_sets(dp, negative_sampling)
     self._setup_zero_adam(dp)
     n = len(train_dataset)
     lo, hi = shard_range(n, dp.rank, dp.world)
@@ -554,6 +555,26 @@ class Recoder(object):
     dp.set_owner_bounds(DataParallel.balanced_bounds(freq[:n_items], len(train_dataset),
                                                      dp.world * int(batch_size), dp.world))
     eng.owned_rows = True
+
+  def _setup_local_sets(self, dp, negative_sampling):
+    """RK_DP_ITEMSETS = union (default) | local.  `local` (opt-in, NOT the reference's single-process semantics):
+    every rank samples its negatives from the items of ITS OWN B users -- what the reference's trainer would do
+    under conventional DDP -- instead of the union over all ranks' users (data.py:216-223 read as one shared item
+    set).  The contractions then stop growing with the number of ranks (C2: 7.8 k items per rank instead of 18.4 k
+    at 8 ranks) and no stamp exchange precedes the collation; the ranks' compact columns differ, so the gradients
+    travel laid out by item id (dense Adam tables of the one-call autoencoder step only).  Its oracle is
+    oracle.recoder_oracle.OracleRecoder.train_step_ddp (gradient accumulation over the ranks' batches)."""
+    eng = self._engine()
+    dp.local_sets = False
+    if os.environ.get("RK_DP_ITEMSETS", "union") != "local":
+      return
+    if getattr(eng, "generic", False) or getattr(eng, "owned_rows", False) or not eng.c_step_eligible():
+      return
+    if bool(getattr(self.model, "sparse", False)) or self.optimizer is None or not negative_sampling:
+      return
+    if dp.virtual and dp._gather_fn is None:
+      return
+    dp.local_sets = True
 
   def _setup_zero_adam(self, dp):
     """Sharded dense Adam (parallel.DataParallel, "ZeRO-1"): with optim.Adam on the embedding tables of the
@@ -625,7 +646,7 @@ class Recoder(object):
     collated from unsharded matrices and get the plain capacity."""
     nnz_cap = max(1, _top_sum(dcsr.degrees, S))
     n_cap = nnz_cap
-    if train and getattr(self, "_dp", None) is not None:
+    if train and getattr(self, "_dp", None) is not None and not getattr(self._dp, "local_sets", False):
       # the union item set can exceed one rank's nnz bound; the SAME capacity on every rank (a
       # rank with lighter users would otherwise clamp n_b on its own and the gradient exchange
       # would disagree on its sizes): MAX over the ranks, once per (matrix, group size)

@@ -127,6 +127,10 @@ class DataParallel:
     self.calibration = None
     self.owner_bounds = None             # owned-row Adam: item-id boundaries of the ranks' row ranges
     self.zero = None                     # sharded dense Adam: setup_zero
+    # per-rank item sets (RK_DP_ITEMSETS=local, opt-in): every rank samples its negatives from ITS OWN users'
+    # items -- the semantics of the reference under conventional DDP, not of its shared item set -- and the
+    # gradients travel laid out by item id (model.Recoder._setup_local_sets)
+    self.local_sets = False
 
   def prepare(self, device):
     """Create the two direct communicators now (a collective: every rank calls it)."""
@@ -288,9 +292,12 @@ class DataParallel:
     """Two-phase collation with the union item set.  ``users_dev`` are rows of this
     rank's shard; the block carries their GLOBAL ids (MatrixFactorization looks its
     user rows up by them, the dropout RNG is keyed on them)."""
-    blk.collate(dcsr, users_dev, phase=1)
-    self.union_marks(blk.mark)
-    blk.collate(dcsr, users_dev, phase=2)
+    if self.local_sets:
+      blk.collate(dcsr, users_dev)         # (this rank's own item set: no exchange of the stamps)
+    else:
+      blk.collate(dcsr, users_dev, phase=1)
+      self.union_marks(blk.mark)
+      blk.collate(dcsr, users_dev, phase=2)
     if self.user_offset:
       blk.users = users_dev + self.user_offset
 
@@ -505,8 +512,24 @@ class DataParallel:
     """One half of a sharded-Adam step's exchange: stage(stream) lays the compact gradient rows out by item
     id in D, D is reduce-scattered into `shard`, the small gradients `small` are all-reduced -- on the
     communication stream behind everything enqueued on main_stream so far when the exchange may overlap the
-    step (join_async makes main_stream wait for it), else in line."""
+    step (join_async makes main_stream wait for it), else in line.  shard None (per-rank item sets without
+    sharding): D itself is all-reduced in place, with the small ones."""
     small = [v for v in small if v.numel() > 0]
+    if shard is None:
+      direct = self._sum_fn is None and self._grad_comm is not None and D.is_cuda
+      if direct and overlap and self.overlapped:
+        if getattr(self, "_cstream", None) is None:
+          self._cstream = torch.cuda.Stream(device=D.device)
+          self._ev_go, self._ev_done = torch.cuda.Event(), torch.cuda.Event()
+        self._ev_go.record(main_stream)
+        self._cstream.wait_event(self._ev_go)
+        stage(self._cstream)
+        self._sum_many([D] + small, stream=self._cstream)
+        self._async_pending = True
+        return
+      stage(main_stream)
+      self.reduce([D] + small)
+      return
     direct = self._sum_fn is None and self._grad_comm is not None and D.is_cuda
     if direct and overlap and self.overlapped:
       if getattr(self, "_cstream", None) is None:

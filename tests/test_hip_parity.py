@@ -755,7 +755,7 @@ def test_dataframe_to_csr_matrix_contract():
 
 @pytest.mark.parametrize("kind", ["ae", "ae_overlap", "ae_eager", "ae_items", "mf", "mf_sparse", "ae_rsag",
                                   "ae_eager_rsag", "ae_sparse_owned", "mf_sparse_owned", "ae_stack", "ae_zero",
-                                  "ae_eager_zero"])
+                                  "ae_eager_zero", "ae_local", "ae_eager_local"])
 def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind):
   """Recoder.train under an initialised torch.distributed group (RCCL, 1 rank):
   two-phase collation + all-reduced gradients must reproduce the plain run.  ae_overlap: the
@@ -773,6 +773,12 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
   if zero:
     monkeypatch.setenv("RK_DP_ZERO", "force")
     kind = kind[:-5]
+  # *_local: per-rank item sets (RK_DP_ITEMSETS=local; with one rank the rank's set IS the union): the gradients
+  # laid out by item id, all-reduced in place, the update reading them row by row
+  local = kind.endswith("_local")
+  if local:
+    monkeypatch.setenv("RK_DP_ITEMSETS", "local")
+    kind = kind[:-6]
   # "ae" = users sharded (gradient all-reduce), "ae_items" = items sharded (parallel.ItemParallel)
   monkeypatch.setenv("RK_PARALLEL", "items" if kind == "ae_items" else "users")
   items_mode = kind == "ae_items"
@@ -787,7 +793,7 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
     monkeypatch.setenv("RK_DP_EXCHANGE", "rsag")
   if owned:
     monkeypatch.setenv("RK_DP_OWNED", "force")
-  port_off = 40 * rsag + 60 * owned + 7 * (kind == "mf_sparse_owned") + 110 * zero
+  port_off = 40 * rsag + 60 * owned + 7 * (kind == "mf_sparse_owned") + 110 * zero + 130 * local
   ae_sparse = kind == "ae_sparse_owned"
   if kind == "mf_sparse_owned":
     kind = "mf_sparse"
@@ -823,6 +829,7 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
       assert (gs is not None and gs.dp is rec._dp and gs.warmed) == graph_dp
       assert bool(getattr(rec._engine(), "owned_rows", False)) == owned
       assert bool(getattr(rec._engine(), "zero_adam", False)) == zero
+      assert bool(getattr(rec._dp, "local_sets", False)) == local
       if rsag:
         assert rec._dp.exchange_mode == "rsag"
     return np.concatenate(rec.loss_history), {k: v.detach().cpu().clone() for k, v in model.named_parameters()}
@@ -1214,6 +1221,90 @@ def test_data_parallel_two_virtual_ranks_equal_single_process(case, monkeypatch)
       s0, s1 = r0._engine().states[name], r1._engine().states[name]
       assert torch.equal(s0.m, s1.m) and torch.equal(s0.v, s1.v), name
       assert float(s0.v.abs().max()) > 0
+
+
+@pytest.mark.parametrize("variant", ["allreduce", "sharded", "tied", "three_ranks"])
+def test_data_parallel_local_item_sets_equal_the_ddp_oracle(variant, monkeypatch):
+  """RK_DP_ITEMSETS=local (opt-in): every rank samples its negatives from ITS OWN users' item set -- the reference's
+  trainer under conventional DDP, not its shared item set -- and the gradients travel laid out by item id (all-reduced
+  in place, or reduce-scattered with the sharded dense update on top).  Virtual ranks on one GPU against
+  oracle.train_step_ddp: gradient accumulation over the ranks' batches, one optimizer step."""
+  import threading
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder
+  from recoder_amd.parallel import DataParallel, shard_range
+  monkeypatch.setenv("RK_DP_ITEMSETS", "local")
+  monkeypatch.setenv("RK_DP_ZERO", "1" if variant in ("sharded", "three_ranks") else "0")
+  world = 3 if variant == "three_ranks" else 2
+  tied = variant == "tied"
+  csr = synth_csr(606, 1501, 20, seed=41)
+  B, epochs = 100, 2
+  n = csr.shape[0]
+  per = n // world
+  mk = lambda: DynamicAutoencoder([64], activation_type="tanh", noise_prob=0.0, sparse=False, is_constrained=tied)
+  loss, wd, lr = ("logistic" if tied else "mse"), 2e-5, 1e-3
+  orders = {e: [np.random.RandomState(50 + 10 * e + r).permutation(shard_range(n, r, world)[1] - shard_range(n, r, world)[0])[:per]
+                .astype(np.int64) for r in range(world)] for e in range(1, epochs + 1)}
+  vr = _VirtualRanks(world)
+  reps = []
+  for r in range(world):
+    torch.manual_seed(23)
+    model = mk()
+    rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss=loss)
+    rec._Recoder__init_training(RecommendationDataset(csr), lr, wd)
+    rec._dp_override = DataParallel(rank=r, world=world, allreduce_fn=vr.allreduce(r),
+                                    allreduce_max_fn=vr.allreduce_max(r), allgather_fn=vr.allgather(r))
+    rec.user_order_hook = (lambda rr: (lambda epoch, n_: orders[epoch][rr]))(r)
+    reps.append((model, rec))
+  init = {k: v.detach().cpu().clone() for k, v in reps[0][0].named_parameters()}
+  errs = []
+
+  def run(r):
+    try:
+      torch.cuda.set_device(0)
+      reps[r][1].train(RecommendationDataset(csr), batch_size=B, lr=lr, weight_decay=wd, num_epochs=epochs,
+                       negative_sampling=True)
+    except BaseException as e:       # noqa: B036 -- release the other threads
+      errs.append(e)
+      vr.barrier.abort()
+  threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+  for t in threads:
+    t.start()
+  for t in threads:
+    t.join(timeout=300)
+  assert not errs, errs
+  # the oracle: one model, per step one Batch PER RANK (collated on its own: its own item set), averaged loss
+  o = orc.OracleRecoder("ae", init, hidden_layers=[64], activation_type="tanh", is_constrained=tied, loss=loss,
+                        loss_params=None, lr=lr, weight_decay=wd)
+  want = []
+  for e in range(1, epochs + 1):
+    for off in range(0, (per // B) * B, B):
+      batches = []
+      for r in range(world):
+        users = shard_range(n, r, world)[0] + orders[e][r][off:off + B]
+        batches.append(orc.collate(orc.extract_rows(csr, users), users, B, True)[0])
+      want.append(o.train_step_ddp(batches))
+    tail = per % B
+    if tail:
+      batches = []
+      for r in range(world):
+        users = shard_range(n, r, world)[0] + orders[e][r][(per // B) * B:per]
+        batches.append(orc.collate(orc.extract_rows(csr, users), users, tail, True)[0])
+      want.append(o.train_step_ddp(batches))
+  want = np.asarray(want)
+  ref_p = o.state()
+  for model, rec in reps:
+    assert rec._dp is not None and rec._dp.local_sets
+    assert bool(getattr(rec._engine(), "zero_adam", False)) == (variant in ("sharded", "three_ranks"))
+    got = np.concatenate(rec.loss_history)
+    assert len(got) == len(want)
+    assert np.allclose(got, want, rtol=2e-5, atol=0), (got[:3], want[:3])
+    for k, v in model.named_parameters():
+      frac, mx, scale = close_stats(v.detach().cpu().numpy(), ref_p[k].numpy(), 1e-4, 2e-6)
+      assert frac < 2e-3, (k, frac, mx, scale)
+  for (k, a), (_, b) in zip(reps[0][0].named_parameters(), reps[1][0].named_parameters()):
+    assert torch.equal(a, b), k
 
 
 @pytest.mark.parametrize("seed", list(range(24)))

@@ -86,7 +86,13 @@ def main():
       t_alt = (kern + adam_zero + ex_dense + sync) if kind == "dense" else (kern + adam_own + ex_direct + sync + host_own)
       if N == 1:
         t_alt = t_rep_dir
-      t_ownset = (fixed + scaled) + min(adam_rep, adam_own) + ex_direct + sync
+      if kind == "dense":
+        # BUILT (round 5, RK_DP_ITEMSETS=local + RK_DP_ZERO=1): kernels at the rank's own item set, the gradients laid
+        # out by item id (staging), reduce-scatter + all-gather of the dense layout, 1/N of the sweep
+        adam_loc = (tables * n_items * h * 28 / N) / HBM + (tables * (n_items + nb1) * h * 4) / HBM * 0.5
+        t_ownset = (fixed + scaled) + (adam_loc if N > 1 else adam_rep) + ex_dense + sync
+      else:
+        t_ownset = (fixed + scaled) + min(adam_rep, adam_own) + ex_direct + sync      # (SparseAdam tables: not built)
       rows.append((name, N, nb, bytes_g / 1e6, bytes_dense / 1e6 if kind == "dense" else float("nan"), kern, adam_rep,
                    adam_zero if kind == "dense" else adam_own, host_own, ex_ring, ex_direct, ex_dense if kind == "dense" else float("nan"),
                    t_rep_ring, t_rep_dir, t_alt, t_ownset, kind))
@@ -94,7 +100,7 @@ def main():
   print("dense-Adam configs (c2, c3): alt = sharded dense Adam (ZeRO-1, graph replay); SparseAdam configs (c4, c5u): alt = owned-row "
         "Adam, host-sequenced (host = measured at one forced rank)")
   print("config N   union n_b  exch MB (compact | dense) | kernels  Adam repl  Adam alt  host alt | exch ring  direct  dense | "
-        "step: repl+ring  repl+direct (graph)  alt | best users/s  x vs N=1 | per-rank item sets (other semantics): step  x")
+        "step: repl+ring  repl+direct (graph)  alt | best users/s  x vs N=1 | per-rank item sets (RK_DP_ITEMSETS=local, the reference under DDP -- another estimator; dense-Adam configs: built): step  x")
   base = {}
   for r in rows:
     name, N = r[0], r[1]
