@@ -66,6 +66,8 @@ typedef struct rk_plan {
   int32_t dw_encode_bwd_fused_ok;  /* dW || encoder backward in one launch */
   int32_t adam_de_side;            /* the probe header's RK_TUNE_ADAM_DE_SIDE: the decoder table's Adam sweep is a
                                       launch of its own behind the dW kernel on dw_stream (off by default) */
+  int32_t mf_fdec_ok;              /* entry-by-entry sequenced steps without a reader of dZ in front of the update
+                                      (MatrixFactorization): rk_fdec_loss_dz + rk_pg_dw_dz_reduce cover this shape */
 } rk_plan_t;
 int rk_plan(rk_plan_t *plan);
 
@@ -415,6 +417,12 @@ int rk_fdec_loss_dz(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int
                     float *dO_scales, float *loss_part, float *dz_workspace, void *stream);
 int rk_fdec_dz_reduce(const float *dz_workspace, int32_t B, int32_t h, const rk_block_t *tgt, const float *Zact,
                       int32_t act, float *dZ, void *stream);
+/* rk_pg_dw (dW slabs from the dO image, + the decoder bias gradient from its columns) with rk_fdec_dz_reduce riding on
+ * the SAME launch as a workgroup range -- steps in which nothing between the decode and the optimizer reads dZ
+ * (MatrixFactorization: the user rows' gradient); < 1024 rows. */
+int rk_pg_dw_dz_reduce(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
+                       const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, float *gb_de /* nullable */,
+                       const float *dz_workspace, const float *Zact /* nullable */, int32_t act, float *dZ, void *stream);
 /* (RK_PG=0 in the environment switches the family off: the round-3 plane kernels run instead) */
 int rk_pg_decode_loss(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off,
                       const float *b_de, int32_t loss_kind, float confidence, float inv_B, void *dO_img,

@@ -57,6 +57,7 @@ class RkPlan(Structure):
     ("fdec_workspace_bytes", c_int64), ("pg_dz_workspace_bytes", c_int64), ("pg_dw_workspace_bytes", c_int64),
     ("pg_scale_floats", c_int64), ("pg_mnll_workspace_floats", c_int64),
     ("decode_dz_fused_ok", c_int32), ("fdec_ok", c_int32), ("dw_encode_bwd_fused_ok", c_int32), ("adam_de_side", c_int32),
+    ("mf_fdec_ok", c_int32),
   ]
 
 
@@ -175,6 +176,8 @@ SIGNATURES = {
   "rk_fdec_loss_dz": (c_int32, [POINTER(RkPlanes), c_int32, _BLK, c_int32, _P, c_int32, c_float, c_float, _P, c_int32,
                                 _P, _P, _P, _P]),
   "rk_fdec_dz_reduce": (c_int32, [_P, c_int32, c_int32, _BLK, _P, c_int32, _P, _P]),
+  "rk_pg_dw_dz_reduce": (c_int32, [_P, _P, c_int32, c_int32, c_int32, POINTER(RkPlanes), _BLK, _P, _P, _P, _P, c_int32,
+                                   _P, _P]),
   "rk_ae_step_uses_pg": (c_int32, [_P]),
   "rk_pg_decode_loss": (c_int32, [POINTER(RkPlanes), c_int32, _BLK, c_int32, _P, c_int32, c_float, c_float, _P,
                                   c_int32, _P, _P, _P, _P, _P]),
@@ -297,6 +300,7 @@ def _install_plan_accessors(lib):
       ("dw3_workspace_bytes", ("B", "h", "n_cap")), ("dw3_max_splits", ()), ("dw_pairs", ()),
       ("dw_encode_bwd_fused_ok", ("row_off", "B")), ("decode_dz_fused_ok", ("B", "h", "n_cap", "loss_kind")),
       ("dz_fused_workspace_bytes", ("B", "h", "n_cap")), ("fdec_ok", ("B", "h", "n_cap", "loss_kind")),
+      ("mf_fdec_ok", ("B", "h", "n_cap", "loss_kind")),
       ("fdec_workspace_bytes", ("B", "h", "n_cap")), ("pg_enabled", ()), ("pg_scale_floats", ("B", "n_cap")),
       ("pg_mnll_workspace_floats", ("B", "n_cap")), ("pg_dz_workspace_bytes", ("B", "h")),
       ("pg_dw_splits", ("B", "h", "n_cap")), ("pg_dw_workspace_bytes", ("B", "h", "n_cap")),

@@ -51,6 +51,7 @@ extern "C" int rk_plan(rk_plan_t *p) {
   p->fdec_ok = rk_fdec_ok(B, h, n, loss);
   p->dw_encode_bwd_fused_ok = rk_dw_encode_bwd_fused_ok(p->row_off, B);
   p->adam_de_side = rk_adam_de_side();
+  p->mf_fdec_ok = (rk_tune_get(RK_TUNE_MF_FDEC) != 0 && B < 1024 && rk_fdec_ok(B, h, n, loss)) ? 1 : 0;
   return 0;
 }
 
@@ -76,7 +77,7 @@ extern "C" int rk_probe_buffer(int32_t which, unsigned long long *buffer) {
   return -1;
 }
 // defaults of the knobs (include/recoder_hip_probe.h RK_TUNE_*)
-static int g_tune[RK_TUNE_COUNT] = {1, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0};
+static int g_tune[RK_TUNE_COUNT] = {1, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1};
 int rk_tune_get(int knob) { return g_tune[knob]; }
 extern "C" int rk_tune(int32_t knob, int32_t value) {
   if (knob < 0 || knob >= RK_TUNE_COUNT) {

@@ -16,6 +16,7 @@
 #include "encoder_bwd.h"
 #include "pgemm_epi.h"
 #include "planes.h"
+#include "splitk_reduce.h"
 
 int rk_splitk_reduce_tiles(const float *ws, int M, int N, const int32_t *Kdev, int max_splits, int tile_k,
                            const float *Zact, int act, float *out, void *stream);
@@ -126,6 +127,25 @@ __global__ __launch_bounds__(WM * WN * 64) void dw_encbwd_kernel(const pg::Core 
   }
   ae_encode_bwd_cols_body<HV, true>(enc.b, enc.row_off, enc.B, enc.dZ, enc.h, enc.G, 0, enc.gb, enc.n_gb,
                                     (int)blockIdx.x - n_dw - n_cs, smem);
+}
+// dW tiles || the image's column sums || the dZ SLAB REDUCE of the fused decode in ONE launch (MatrixFactorization
+// steps: nothing between the decode and the Adam sweep reads dZ -- the user rows' gradient --, so its reduce need
+// not be a link of the chain; csrc/dw3.hip's dw_reduce_kernel did the same for the round-3 decode): 256-thread
+// workgroups throughout, the reduce body with 4 waves per 64 outputs
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void dw_red_kernel(const pg::Core p, const pg::EpiSlab::Args e, const int n_dw,
+                                                             const ColsumImg cs, const int n_cs, const rkred::Args red) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(WM * WN * 64 == 256, "the reduce range runs rkred::body<4>");
+  if ((int)blockIdx.x < n_dw) {
+    pg::gemm_body<BM, BN, WM, WN, true, true, pg::EpiSlab, 0, true>(p, e, (int)blockIdx.x, smem);
+    return;
+  }
+  if ((int)blockIdx.x < n_dw + n_cs) {
+    colsum_img_body(cs, (int)blockIdx.x - n_dw, smem);
+    return;
+  }
+  rkred::body<4>(red, (int)blockIdx.x - n_dw - n_cs, reinterpret_cast<float4 (*)[64]>(smem));
 }
 constexpr int DW_MAX_SPLITS = 4, DW_SLOTS = 256;    // (the slab count follows the LIVE item count: pg::Core.auto_slots)
 
@@ -302,7 +322,7 @@ extern "C" int64_t rk_pg_dw_workspace_bytes(int32_t B, int32_t h, int32_t n_cap)
 // (g_parts / gparts_dev)
 static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
                       const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, const EncBwd *enc,
-                      void *stream_, float *gb_de = nullptr, bool dense = false);
+                      void *stream_, float *gb_de = nullptr, bool dense = false, const rkred::Args *red = nullptr);
 
 extern "C" int rk_pg_dw(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
                         const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, float *gb_de, void *stream_) {
@@ -346,9 +366,20 @@ extern "C" int rk_pg_dw_encode_bwd(const void *dO_img, const float *dO_scales, i
   return pg_dw_impl(dO_img, dO_scales, gr, gc, B, pl, tgt, slabs, &enc, stream_, gb_de);
 }
 
+// rk_pg_dw (+ gb_de) with the slab reduce of rk_fdec_loss_dz riding on the launch (< 1024 rows: 64 x 128 tiles)
+extern "C" int rk_pg_dw_dz_reduce(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
+                                  const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, float *gb_de,
+                                  const float *dz_workspace, const float *Zact, int32_t act, float *dZ,
+                                  void *stream_) {
+  RK_REQUIRE(B < 1024, "rk_pg_dw_dz_reduce: batches below 1024 rows (the 256-thread dW tiles)");
+  RK_REQUIRE(al16(dz_workspace) && al16(dZ), "operands must be 16-byte aligned");
+  const rkred::Args red = {dz_workspace, B, pl ? pl->h : 0, tgt->counts, 128, rk_fdec_slabs(B, tgt->n_cap), Zact, act, dZ};
+  return pg_dw_impl(dO_img, dO_scales, gr, gc, B, pl, tgt, slabs, nullptr, stream_, gb_de, false, &red);
+}
+
 static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
                       const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, const EncBwd *enc_,
-                      void *stream_, float *gb_de, bool dense) {
+                      void *stream_, float *gb_de, bool dense, const rkred::Args *red) {
   hipStream_t stream = (hipStream_t)stream_;
   // (column sums without an encoder backward: the same launch with an empty encoder range)
   EncBwd no_enc = {};
@@ -373,7 +404,22 @@ static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, in
   e.C = slabs; e.ldc = h; e.slab_stride = (int64_t)tgt->n_cap * h; e.bscale = pl->scales;
   const int tiles = rk_cdiv(tgt->n_cap, bm) * rk_cdiv(h, bn);
   hipError_t rc;
-  if (enc) {
+  if (red) {
+    const int n_dw = pg::grid_of(p, tiles);
+    ColsumImg cs = {};
+    int n_cs = 0;
+    if (gb_de) {
+      cs.img = (const char *)dO_img; cs.counts = tgt->counts; cs.tab = dO_scales; cs.gr = gr; cs.gc = gc;
+      cs.pitch = rk_cdiv(tgt->n_cap, gc); cs.rows = B; cs.out = gb_de;
+      n_cs = rk_cdiv(tgt->n_cap, 32);
+    }
+    const int n_red = rkred::blocks(red->M, red->N);
+    auto k = dw_red_kernel<64, 128, 2, 2>;
+    static const hipError_t attr = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) { rk_set_error("LDS attribute"); return -1; }
+    hipLaunchKernelGGL(k, dim3(n_dw + n_cs + n_red), dim3(256), 2 * (64 + 128) * pg::LINE, stream, p, e, n_dw, cs, n_cs, *red);
+    rc = hipGetLastError();
+  } else if (enc) {
     const int n_dw = pg::grid_of(p, tiles);
     const int n_enc = enc_ ? rk_cdiv(tgt->n_cap, 4) + enc->n_gb : 0;
     const int hv = rk_cdiv(h, 256);

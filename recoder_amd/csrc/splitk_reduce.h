@@ -19,7 +19,11 @@ struct Args {
 inline int blocks(int M, int N) { return (int)(((int64_t)M * N / 4 + 63) / 64); }
 
 // ws[split][M][N] -> out[M][N] (fixed split order), optional * act'(Zact); workgroup `block` of
-// RED_W * 64 threads, `part`: (RED_W - 1) * 64 float4 of LDS
+// RW * 64 threads (RW = RED_W = 8 in the stand-alone launch; 4 where it rides on a launch of 256-thread
+// workgroups: csrc/pgemm.hip), `part`: (RW - 1) * 64 float4 of LDS.  The sum is taken in ascending slab order
+// within a wave's share and the shares are combined in wave order: a different RW groups the same additions
+// differently (agreement to rounding, each form deterministic).
+template <int RW = RED_W>
 __device__ __forceinline__ void body(const Args &a, const int block, float4 (*part)[64]) {
   // 64 float4 outputs per workgroup; the waves each sum a contiguous share of the splits (all of
   // its loads in flight at once: the slabs come from the Infinity Cache / HBM, and the launch is as
@@ -33,7 +37,7 @@ __device__ __forceinline__ void body(const Args &a, const int block, float4 (*pa
   const float4 *ws4 = reinterpret_cast<const float4 *>(a.ws);
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int64_t i = (int64_t)block * 64 + lane;
-  const int per = (ns + RED_W - 1) / RED_W;
+  const int per = (ns + RW - 1) / RW;
   const int z1 = min(ns, (q + 1) * per);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   // (the activation values of the fused act' are fetched with the slabs, not behind the barrier)
@@ -57,7 +61,7 @@ __device__ __forceinline__ void body(const Args &a, const int block, float4 (*pa
   __syncthreads();
   if (q == 0 && i < tot4) {
 #pragma unroll
-    for (int w = 0; w < RED_W - 1; ++w) {
+    for (int w = 0; w < RW - 1; ++w) {
       const float4 b = part[w][lane];
       s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
     }

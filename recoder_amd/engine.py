@@ -457,6 +457,15 @@ class FusedEngine:
     check(self.lib.rk_amax(ptr(z), n, ptr(self.ranges), stream), "rk_amax")
     return ptr(self.ranges)
 
+  def _fdec_entry_ok(self, B, n_cap):
+    """MatrixFactorization steps (sequenced entry by entry) on the register-resident fused decode
+    (rk_fdec_loss_dz: decode + loss + dZ partials, dLoss/dLogits as a plane image) with dW from the image, its
+    column sums and the slab reduce in ONE launch behind it (rk_pg_dw_dz_reduce) -- round 5."""
+    lib = self.lib
+    return (self.kind == "mf" and self.planes is not None and self.split16 and self.ws_dw is not None and
+            self.item_parallel is None and self.allreduce is None and not lib.rk_gemm_plain_bf16() and
+            bool(lib.rk_mf_fdec_ok(B, self.h[0], n_cap, self.loss_id)))
+
   def _pg_entry_ok(self, B, n_cap):
     """Entry-by-entry steps: the three contractions on the pipelined pair-plane kernels (csrc/pgemm.h)
     -- everything outside the fused decode + dZ launch's domain: the multinomial loss, h > 256,
@@ -483,6 +492,7 @@ class FusedEngine:
     self._dz_in_ws = False
     self._dz_on_planes = False
     self._dz_pg = False
+    self._dz_fdec = False
     # zt_ws: the workspace the step's dW launch will use -- the split launch then writes Z^T as that
     # kernel's fp16 pair planes at its head (one launch less inside rk_decode_bwd_dw2)
     self._zt_ready = None
@@ -491,7 +501,17 @@ class FusedEngine:
     # (the encoder forward of this step already cut W_de[items of this block]: rk_ae_encode_fwd_split_w)
     w_done = getattr(self, "_w_split_of", None) is tgt and tgt is not None
     self._w_split_of = None
-    if fuse_dz and ip is None and self.planes is not None and self.split16 and self.ws_dw is not None and \
+    if fuse_dz and pg_ok and ip is None and self._fdec_entry_ok(B, tgt.n_cap):
+      h0 = self.h[0]
+      rg = self._ranges(z, B * h0, stream)
+      check(lib.rk_split_wz(None if w_done else ptr(W), ptr(z), B, h0, tgt.ref, rg,
+                               ctypes.byref(self.planes_nowt), None, stream), "rk_split_wz")
+      check(lib.rk_fdec_loss_dz(ctypes.byref(self.planes), B, tgt.ref, row_off, ptr(b), self.loss_id,
+                                self.confidence, inv_B, ptr(self.dO), self.do_rows, ptr(self.do_scales),
+                                ptr(self.loss_part), ptr(self.ws), stream), "rk_fdec_loss_dz")
+      self._dz_pg = True          # (dO is a plane image: dW reads it -- granule 32 x 64, self._dz_fdec)
+      self._dz_fdec = True
+    elif fuse_dz and ip is None and self.planes is not None and self.split16 and self.ws_dw is not None and \
         self.item_parallel is None and lib.rk_decode_dz_fused_ok(B, self.h[0], tgt.n_cap, self.loss_id):
       # training steps sequenced entry by entry (hidden stacks, bottleneck dropout, MatrixFactorization):
       # the operands are split once (two launches) and the decode launch leaves the dZ partials of its
@@ -711,6 +731,17 @@ class FusedEngine:
     elif self.loss_id == LOSS_MNLL and not self._dz_pg:
       # dO was produced by rk_mnll_finish: column sums need a pass over dO
       self._dw(z, B, tb, self.gb_de, dw_stream, keep_slabs)
+    elif getattr(self, "_dz_fdec", False):
+      # the fused decode leaves no column sums: the dW launch takes the bias gradient from the image's columns
+      # -- and, MatrixFactorization (nothing before the Adam sweep reads dZ), the slab reduce as a third range
+      zact = None if self.drop_active else self.enc[0]
+      check(lib.rk_pg_dw_dz_reduce(ptr(self.dO), ptr(self.do_scales), 32, 64, B, ctypes.byref(self.planes), tb.ref,
+                                   ptr(self.ws_dw), ptr(self.gb_de), ptr(self.ws), ptr(zact), self.act,
+                                   ptr(self.dbott), stream), "rk_pg_dw_dz_reduce")
+      self._dw_slabs = (tb, B)
+      self._ws_dw_live = True
+      self._pg_step = True
+      self._dz_done = True
     else:
       # the loss epilogue already reduced dO per row tile: sum those few rows
       if lazy:
