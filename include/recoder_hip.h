@@ -705,7 +705,10 @@ void *rk_event_create(int32_t timing); /* 0: ordering-only (no timing, device-sc
 void rk_event_destroy(void *event);
 float rk_event_elapsed_ms(void *ev0, void *ev1);   /* synchronises on ev1 */
 int rk_ae_train_step(const rk_ae_step_t *step);
-/* != 0: the step as described runs rk_pg_decode_loss / rk_pg_dz / rk_pg_dw (rk_ae_step_t.do_scales) */
+/* != 0: the step as described runs rk_pg_decode_loss / rk_pg_dz / rk_pg_dw (rk_ae_step_t.do_scales).  Bits 0-3: 1 = the
+ * pipelined pair-plane kernels, 3 / 4 = the register-resident fused decode (4: streaming form) + rk_pg_dw; bit 4 (16):
+ * the decoder bias gradient of the step is left as K slabs in gb_part -- gb_part[s * n_cap + c], s < counts[4] -- (the
+ * dW tiles' output column h against a ones column of the Z image), not in gb_de */
 int32_t rk_ae_step_uses_pg(const rk_ae_step_t *step);
 
 /*

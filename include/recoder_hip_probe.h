@@ -38,6 +38,10 @@ int rk_probe_buffer(int32_t which, unsigned long long *buffer);
  *   RK_TUNE_GRAPH_EVENT_NODES 0  1: bench brackets inside a captured graph as event-record nodes
  *   RK_TUNE_MF_FDEC       1  MatrixFactorization steps on rk_fdec_loss_dz + rk_pg_dw_dz_reduce (rk_plan_t.mf_fdec_ok); 0: the
  *                            round-3 pair rk_decode_loss_dz_planes + rk_decode_bwd_dw2_dz_reduce
+ *   RK_TUNE_DW_RING       0  LDS stages of the 64 x 128 dW tiles' DMA ring (csrc/pgemm.h): 3 / 4 / 6 = the deep ring (counted
+ *                            vmcnt waits, raw s_barrier, asm transpose reads), anything else = the two-stage loop
+ *   RK_TUNE_DW_ONES       1  whole steps on the fused decode, h % 32 != 0: the decoder bias gradient as output column h of the dW
+ *                            tiles (a ones column in the Z image's padding) instead of a column-sum range over the dO image
  *   RK_TUNE_FDEC_STREAM   0  the fused decode (csrc/fdecode.hip) in its STREAMING form -- a workgroup walks a group of
  *                            column tiles, one dZ slab per group: 1 = from 1024 rows (the fused decode's domain
  *                            then has no row limit), 2 = always, 0 = never (one workgroup and one slab per 128-item
@@ -46,7 +50,7 @@ int rk_probe_buffer(int32_t which, unsigned long long *buffer);
 enum { RK_TUNE_LINEAR_PAIR = 0, RK_TUNE_PLANES_TILE = 1, RK_TUNE_DZ_FUSED = 2, RK_TUNE_DW_ENC_FUSED = 3,
        RK_TUNE_DW_BF16X3 = 4, RK_TUNE_ADAM_DE_SIDE = 5, RK_TUNE_PG_TILE = 6, RK_TUNE_DZ_TN = 7,
        RK_TUNE_DZ_SPLITS = 8, RK_TUNE_PAIR_ORDER = 9, RK_TUNE_GRAPH_EVENT_NODES = 10, RK_TUNE_FDEC_STREAM = 11,
-       RK_TUNE_MF_FDEC = 12, RK_TUNE_COUNT = 13 };
+       RK_TUNE_MF_FDEC = 12, RK_TUNE_DW_RING = 13, RK_TUNE_DW_ONES = 14, RK_TUNE_COUNT = 15 };
 int rk_tune(int32_t knob, int32_t value);
 
 /* X[rows, cols] (ld) -> the fragment-ordered transposed fp16 pair planes of rk_decode_bwd_dw3 (test hook of

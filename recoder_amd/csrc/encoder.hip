@@ -32,7 +32,7 @@ __global__ __launch_bounds__(FW * 64) void ae_encode_fwd_kernel(
     uint64_t rng_step, const int64_t *__restrict__ users, const float *__restrict__ user_norm,
     int act, float *__restrict__ Z0, uint16_t *__restrict__ planes, int64_t plane_stride,
     int cols_pad, rk_cur_t cur, rkp::SplitW sw, int n_split, char *__restrict__ zimg, int z_kt,
-    int zt_pairs, unsigned long long *probe) {
+    int zt_pairs, unsigned long long *probe, int z_ones) {
   __shared__ float red[FW];
   constexpr int PART_B = (FW - 1) * HV * 256 * 4;
   __shared__ __attribute__((aligned(16))) char sm_raw[PART_B > rkp::SPLIT_W_LDS ? PART_B : rkp::SPLIT_W_LDS];
@@ -203,6 +203,11 @@ __global__ __launch_bounds__(FW * 64) void ae_encode_fwd_kernel(
           const float sz = sw.plain ? 1.0f : rkp::SCALE_Z;
           rkp::store_split4(zimg + (int64_t)r * z_kt * rkp::LINE, hh, y, sz, sw.plain != 0);
           if (r == 0 && tid == 0) sw.scales[0] = sz;     // (consumers read the scale from there)
+          // z_ones (h % 32 != 0): the first padding column of the image row holds the constant 1 -- dW = dO^T . Z
+          // then leaves the column sums of dO (the decoder bias gradient) in its output column h for free; the
+          // decode multiplies the column with the W image's zero padding
+          if (z_ones && hh == h - 4)
+            rkp::store_split4(zimg + (int64_t)r * z_kt * rkp::LINE, h, make_float4(1.f, 0.f, 0.f, 0.f), sz, false);
         }
         if (planes) {
           // Z^T as three bf16 planes in the fragment order of the dW kernel (csrc/dw3.hip):
@@ -278,15 +283,16 @@ static int encode_fwd_launch(const rk_block_t *blk, int32_t row_off, int32_t B, 
   const int cols_pad = rk_dw3_cols_pad(h);
   const int64_t plane_stride = (int64_t)rk_dw3_rows_pad(B) * cols_pad;
   rkp::SplitW sw = {};
-  int n_split = 0, z_kt = 0;
+  int n_split = 0, z_kt = 0, z_ones = 0;
   char *zimg = nullptr;
   if (es) {
     sw = es->sw; n_split = es->n_split; zimg = es->zimg; z_kt = es->z_kt;
+    z_ones = (es->z_ones && zimg && !sw.plain && h % 32 != 0) ? 1 : 0;
   }
 #define LAUNCH(HV)                                                                         \
   RK_LAUNCH((ae_encode_fwd_kernel<HV, 8>), dim3(n_split + rows), dim3(FW * 64), 0, stream, *blk, row_off, \
                      B, W_en, b_en, h, keep, p, scale, seed, rng_step, users, user_norm, act, Z0, \
-                     (uint16_t *)zt_planes, plane_stride, cols_pad, cur, sw, n_split, zimg, z_kt, zt_pairs, g_enc_probe)
+                     (uint16_t *)zt_planes, plane_stride, cols_pad, cur, sw, n_split, zimg, z_kt, zt_pairs, g_enc_probe, z_ones)
   if (hv == 1) LAUNCH(1); else if (hv == 2) LAUNCH(2); else LAUNCH(4);
 #undef LAUNCH
   RK_CHECK_LAUNCH("ae_encode_fwd");

@@ -5,6 +5,13 @@
 struct rk_planes;
 int rk_pg_dw_dense(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
                    const struct rk_planes *pl, const rk_block_t *tgt, float *G_de, float *gb_de, void *stream);
+// rk_pg_dw_encode_bwd for a Z image whose padding column h holds the constant 1 (h % 32 != 0; the encoder forward of
+// the same rk_ae_train_step call wrote it: rk_enc_split_t.z_ones): no column-sum range -- the dW tiles' output
+// column h IS the decoder bias gradient, one slab of it per K slab: gb_slabs[s * tgt->n_cap + c], s < counts[4]
+int rk_pg_dw_encode_bwd_ones(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
+                             const struct rk_planes *pl, const rk_block_t *tgt, float *slabs, int32_t row_off,
+                             const float *dZ0pre, float *G_en, float *gb_en, float *gb_slabs, void *stream);
+int rk_pg_dw_ones_ok(int32_t B, int32_t h, int32_t n_cap);
 int rk_splitk_reduce_tiles(const float *ws, int M, int N, const int32_t *Kdev, int max_splits, int tile_k,
                            const float *Zact, int act, float *out, void *stream_);
 int rk_fdec_stream(int B);

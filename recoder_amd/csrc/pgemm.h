@@ -73,6 +73,16 @@ struct Core {
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// A wave-uniform word of a table an EARLIER launch wrote, through the scalar cache (s_load: lgkmcnt).  As a
+// vector load it sits on the VM counter behind the LDS-DMAs of the next k-tile, and the wait for its value
+// drains them: the k-loops that rescale (dW, dZ on a dO image) ran their MFMAs only AFTER the next tile had
+// landed -- no overlap at all (round 5: found in the ISA, `global_load_dword; s_waitcnt vmcnt(0)` right
+// behind the six global_load_lds of the next tile).
+typedef const __attribute__((address_space(4))) float kconst_float;
+__device__ __forceinline__ float sload(const float *tab, const int idx) {
+  return *(kconst_float *)(tab + rfl(idx));
+}
+
 // ------------------------------------------------------------------ staging (global -> LDS, LDS-DMA)
 // R = tile extent along the operand's non-K index (rows of a KC operand, columns of a TR operand),
 // NW waves; the stage is R * 128 bytes = R / 8 wave-instructions of 1 KB, Q = R / 8 / NW per wave
@@ -120,6 +130,34 @@ struct Stager {
   }
 };
 
+// ---- pieces of the deep-ring k-loop (gemm_body, NS > 2) ----------------------------------------------------
+// The compiler drains the VM counter (s_waitcnt vmcnt(0)) in front of the first ds_read_b64_tr_b16 INTRINSIC
+// behind an LDS-DMA (it cannot tell the stage being read from the stage being filled; the plain ds_read_b128 of
+// the KC operands it does tell apart) and in front of every __syncthreads(): with TR operands the "copy lands
+// under the MFMAs" pipeline above never overlapped anything, and a ring deeper than two stages is impossible.
+// The deep ring therefore reads its fragments with the instruction as inline asm (no memory operand for the
+// pass that inserts waits to reason about), counts its own waits and crosses a raw s_barrier.
+template <int OFF>
+__device__ __forceinline__ s16x4 ds_tr_asm(const uint32_t addr) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// wait until at most `ahead` (0 .. MAXA) later tiles' DMAs of this wave (QPW instructions each) are outstanding
+template <int MAXA, int QPW>
+__device__ __forceinline__ void wait_tiles(const int ahead) {
+  if constexpr (MAXA == 0) wait_vm<0>();
+  else {
+    if (ahead >= MAXA) wait_vm<MAXA * QPW>();
+    else wait_tiles<MAXA - 1, QPW>(ahead);
+  }
+}
+__device__ __forceinline__ uint32_t lds_addr(const char *p) {
+  return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char *)p;
+}
+
 // ------------------------------------------------------------------ fragment reads
 // one 32 x 32 x 16 MFMA operand of this lane: 8 consecutive k (8 * lh .. + 7 of k-step ks) of row /
 // column (tile * 32 + l31); plane 0 = hi, 1 = lo
@@ -148,6 +186,17 @@ struct FragTR {
     row_off = (8 * lh + (t >> 2)) * RS;
     col = 32 * g + 8 * (t & 3);
     swz = (((t >> 2) & 1) << 6) | (((t >> 3) & 1) << 7);
+  }
+  // deep ring: lane offset of (tile, plane) inside a stage; the two halves of k-step KS by immediate offsets
+  __device__ __forceinline__ int off(const int tile, const int plane) const {
+    return ((tile * LINE + plane * 64 + col) ^ swz) + row_off;
+  }
+  // (the two halves stay apart until the wait for them has been passed: a register copy in between would read
+  // them before they are written -- nothing interlocks a VALU read of a register an LDS read is still to fill)
+  template <int KS>
+  static __device__ __forceinline__ void load_asm(const uint32_t a, s16x4 &v0, s16x4 &v1) {
+    v0 = ds_tr_asm<KS * 16 * RS>(a);
+    v1 = ds_tr_asm<KS * 16 * RS + 4 * RS>(a);
   }
   __device__ __forceinline__ f16x8 load(const char *S, const int tile, const int ks, const int plane) const {
     const int o = ((tile * LINE + plane * 64 + col) ^ swz) + row_off + ks * 16 * RS;
@@ -183,7 +232,8 @@ __device__ __forceinline__ bool tile_of(const int L, const int total, int &t) {
 // VAR (tuning variants, bit mask): 1 = the DMAs of a stage are issued by the first half of the waves only
 // (the other half -- their partners on the SIMDs -- start on the MFMAs at once); 2 = s_setprio(1) around
 // the MFMA clusters
-template <int BM, int BN, int WM, int WN, bool ATR, bool BTR, class Epi, int VAR = 0, bool RS = false>
+// NS: LDS stages (2: the loop above; > 2: the deep ring -- both operands TR, NS - 1 k-tiles in flight)
+template <int BM, int BN, int WM, int WN, bool ATR, bool BTR, class Epi, int VAR = 0, bool RS = false, int NS = 2>
 __device__ __forceinline__ void gemm_body(const Core &p, const typename Epi::Args &ea, const int L, char *smem) {
   constexpr int NW = WM * WN, TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int NI = (VAR & 1) ? NW / 2 : NW;          // issuing waves
@@ -241,7 +291,7 @@ __device__ __forceinline__ void gemm_body(const Core &p, const typename Epi::Arg
     for (int i = 0; i < TM; ++i) {
       const int rb = min(T.m0 + (T.wm * TM + i) * 32, M - 1);
       rs_fix[i] = p.rs.mode == 1 ? (rb / p.rs.gr) * p.rs.pitch : rb / p.rs.gc;
-      cur[i] = p.rs.tab[rs_fix[i] + (p.rs.mode == 1 ? (kt0 * 32) / p.rs.gc : ((kt0 * 32) / p.rs.gr) * p.rs.pitch)];
+      cur[i] = sload(p.rs.tab, rs_fix[i] + (p.rs.mode == 1 ? (kt0 * 32) / p.rs.gc : ((kt0 * 32) / p.rs.gr) * p.rs.pitch));
     }
   }
 
@@ -258,6 +308,123 @@ __device__ __forceinline__ void gemm_body(const Core &p, const typename Epi::Arg
     typename FragSel<BN, BTR>::type fb;
     fa.init(T.lane);
     fb.init(T.lane);
+    if constexpr (NS > 2 || (VAR & 256)) {           // (VAR & 256: this loop at TWO stages -- one tile in flight)
+      static_assert(ATR && BTR && (VAR & ~256) == 0, "the deep ring: both operands read along their rows, no probe variants");
+      constexpr int QPW = Stager<BM, ATR, NI>::Q + Stager<BN, BTR, NI>::Q;
+      static_assert((NS - 2) * QPW <= 63, "vmcnt is a 6-bit counter");
+      constexpr int RA = BM * 4, RB = BN * 4;                // bytes per k-row of the A / B stage
+#pragma unroll
+      for (int st = 0; st < NS - 1; ++st)
+        if (st < nk) {
+          sa.issue(smem + st * STAGE, iw);
+          sb.issue(smem + st * STAGE + A_BYTES, iw);
+        }
+      // lane offsets of the wave's fragments inside a stage
+      int oa_[TM][2], ob_[TN][2];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) { oa_[i][0] = fa.off(T.wm * TM + i, 0); oa_[i][1] = fa.off(T.wm * TM + i, 1); }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) { ob_[j][0] = fb.off(T.wn * TN + j, 0) + A_BYTES; ob_[j][1] = fb.off(T.wn * TN + j, 1) + A_BYTES; }
+      const uint32_t base = lds_addr(smem);
+      int stage = 0;
+      for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed: this wave's DMAs of it (at most NS - 2 later tiles may still fly), then the barrier;
+        // behind the barrier every wave is also done with the stage of tile kt - 1 -- the next DMA's target
+        wait_tiles<NS - 2, QPW>(nk - 1 - kt);
+        asm volatile("s_barrier" ::: "memory");
+        if (kt + NS - 1 < nk) {
+          const int st = stage == 0 ? NS - 1 : stage - 1;
+          sa.issue(smem + st * STAGE, iw);
+          sb.issue(smem + st * STAGE + A_BYTES, iw);
+        }
+        if (RS) {
+          const int k = (kt0 + kt) * 32;
+          const int kv = p.rs.mode == 1 ? k / p.rs.gc : (k / p.rs.gr) * p.rs.pitch;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const float sn = sload(p.rs.tab, rs_fix[i] + kv);
+            if (sn != cur[i]) {
+              const float f = sn / cur[i];
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= f;
+              cur[i] = sn;
+            }
+          }
+        }
+        const uint32_t sbase = base + (uint32_t)(stage * STAGE);
+        // fragment halves: [k-step][plane][tile][half]
+        s16x4 ra[2][2][TM][2], rb[2][2][TN][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+              if (ks == 0) FragTR<BM>::template load_asm<0>(sbase + oa_[i][pl], ra[ks][pl][i][0], ra[ks][pl][i][1]);
+              else FragTR<BM>::template load_asm<1>(sbase + oa_[i][pl], ra[ks][pl][i][0], ra[ks][pl][i][1]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              if (ks == 0) FragTR<BN>::template load_asm<0>(sbase + ob_[j][pl], rb[ks][pl][j][0], rb[ks][pl][j][1]);
+              else FragTR<BN>::template load_asm<1>(sbase + ob_[j][pl], rb[ks][pl][j][0], rb[ks][pl][j][1]);
+            }
+          }
+        }
+        // (the asm reads are invisible to the compiler's LGKM bookkeeping: the wait for them is ours.  Nothing
+        // else is on the counter here -- the scale's s_load above was waited for by its compare)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(ra[ks][pl][i][0]), "+v"(ra[ks][pl][i][1]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rb[ks][pl][j][0]), "+v"(rb[ks][pl][j][1]));
+          }
+        f16x8 ah0[TM], al0[TM], bh0[TN], bl0[TN], ah1[TM], al1[TM], bh1[TN], bl1[TN];
+#define PG_CAT(X) __builtin_bit_cast(f16x8, __builtin_shufflevector(X[0], X[1], 0, 1, 2, 3, 4, 5, 6, 7))
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          ah0[i] = PG_CAT(ra[0][0][i]); al0[i] = PG_CAT(ra[0][1][i]);
+          ah1[i] = PG_CAT(ra[1][0][i]); al1[i] = PG_CAT(ra[1][1][i]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          bh0[j] = PG_CAT(rb[0][0][j]); bl0[j] = PG_CAT(rb[0][1][j]);
+          bh1[j] = PG_CAT(rb[1][0][j]); bl1[j] = PG_CAT(rb[1][1][j]);
+        }
+#undef PG_CAT
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0[i], bh0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[i], bl0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[i], bh0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1[i], bh1[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[i], bl1[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[i], bh1[j], acc[i][j], 0, 0, 0);
+        stage = stage + 1 == NS ? 0 : stage + 1;
+      }
+      __syncthreads();
+    } else {
     if (issuer) {
       sa.issue(smem, iw);
       sb.issue(smem + A_BYTES, iw);
@@ -301,7 +468,7 @@ __device__ __forceinline__ void gemm_body(const Core &p, const typename Epi::Arg
         const int kv = p.rs.mode == 1 ? k / p.rs.gc : (k / p.rs.gr) * p.rs.pitch;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          const float sn = p.rs.tab[rs_fix[i] + kv];
+          const float sn = sload(p.rs.tab, rs_fix[i] + kv);
           if (sn != cur[i]) {                        // (wave-uniform: a granule boundary)
             const float f = sn / cur[i];
 #pragma unroll
@@ -342,6 +509,7 @@ __device__ __forceinline__ void gemm_body(const Core &p, const typename Epi::Arg
     }
     if ((VAR & 32) && late && !(VAR & 4)) PG_MFMA3(pah, pal, pbh, pbl);
 #undef PG_MFMA3
+    }
   }
   if (VAR & 8) {                        // (probe: no epilogue -- keep the accumulators alive)
     float x = 0.f;
@@ -357,10 +525,10 @@ __device__ __forceinline__ void gemm_body(const Core &p, const typename Epi::Arg
   Epi::template run<BM, BN, TM, TN>(ea, T, acc, smem, cur);
 }
 
-template <int BM, int BN, int WM, int WN, bool ATR, bool BTR, class Epi, int VAR = 0, bool RS = false>
+template <int BM, int BN, int WM, int WN, bool ATR, bool BTR, class Epi, int VAR = 0, bool RS = false, int NS = 2>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(const Core p, const typename Epi::Args ea) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm_body<BM, BN, WM, WN, ATR, BTR, Epi, VAR, RS>(p, ea, (int)blockIdx.x, smem);
+  gemm_body<BM, BN, WM, WN, ATR, BTR, Epi, VAR, RS, NS>(p, ea, (int)blockIdx.x, smem);
 }
 
 // ------------------------------------------------------------------ plain store epilogue
@@ -402,10 +570,10 @@ inline int grid_of(const Core &p, int tiles_cap) {
   return ((wgs + 7) / 8) * 8;
 }
 
-template <int BM, int BN, int WM, int WN, bool ATR, bool BTR, class Epi, int VAR = 0, bool RS = false>
+template <int BM, int BN, int WM, int WN, bool ATR, bool BTR, class Epi, int VAR = 0, bool RS = false, int NS = 2>
 inline hipError_t launch(const Core &p, const typename Epi::Args &ea, int tiles_cap, hipStream_t s) {
-  constexpr int LDS = 2 * (BM + BN) * LINE;
-  auto k = gemm_kernel<BM, BN, WM, WN, ATR, BTR, Epi, VAR, RS>;
+  constexpr int LDS = NS * (BM + BN) * LINE;
+  auto k = gemm_kernel<BM, BN, WM, WN, ATR, BTR, Epi, VAR, RS, NS>;
   static const hipError_t attr =
       hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (attr != hipSuccess) return attr;

@@ -111,13 +111,14 @@ __device__ __forceinline__ void colsum_img_body(const ColsumImg &c, const int bl
   }
 }
 
-template <int BM, int BN, int WM, int WN, int HV>
+// RING: 0 = the two-stage loop as the compiler schedules it; 2 / 3 / 4 / 6 = LDS stages of the ring loop (csrc/pgemm.h)
+template <int BM, int BN, int WM, int WN, int HV, int RING = 0>
 __global__ __launch_bounds__(WM * WN * 64) void dw_encbwd_kernel(const pg::Core p, const pg::EpiSlab::Args e,
                                                                 const int n_dw, const EncBwd enc,
                                                                 const ColsumImg cs, const int n_cs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)blockIdx.x < n_dw) {
-    pg::gemm_body<BM, BN, WM, WN, true, true, pg::EpiSlab, 0, true>(p, e, (int)blockIdx.x, smem);
+    pg::gemm_body<BM, BN, WM, WN, true, true, pg::EpiSlab, RING == 2 ? 256 : 0, true, RING < 3 ? 2 : RING>(p, e, (int)blockIdx.x, smem);
     return;
   }
   if (threadIdx.x >= 256) return;
@@ -132,13 +133,13 @@ __global__ __launch_bounds__(WM * WN * 64) void dw_encbwd_kernel(const pg::Core 
 // steps: nothing between the decode and the Adam sweep reads dZ -- the user rows' gradient --, so its reduce need
 // not be a link of the chain; csrc/dw3.hip's dw_reduce_kernel did the same for the round-3 decode): 256-thread
 // workgroups throughout, the reduce body with 4 waves per 64 outputs
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int RING = 0>
 __global__ __launch_bounds__(WM * WN * 64) void dw_red_kernel(const pg::Core p, const pg::EpiSlab::Args e, const int n_dw,
                                                              const ColsumImg cs, const int n_cs, const rkred::Args red) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   static_assert(WM * WN * 64 == 256, "the reduce range runs rkred::body<4>");
   if ((int)blockIdx.x < n_dw) {
-    pg::gemm_body<BM, BN, WM, WN, true, true, pg::EpiSlab, 0, true>(p, e, (int)blockIdx.x, smem);
+    pg::gemm_body<BM, BN, WM, WN, true, true, pg::EpiSlab, RING == 2 ? 256 : 0, true, RING < 3 ? 2 : RING>(p, e, (int)blockIdx.x, smem);
     return;
   }
   if ((int)blockIdx.x < n_dw + n_cs) {
@@ -147,7 +148,8 @@ __global__ __launch_bounds__(WM * WN * 64) void dw_red_kernel(const pg::Core p, 
   }
   rkred::body<4>(red, (int)blockIdx.x - n_dw - n_cs, reinterpret_cast<float4 (*)[64]>(smem));
 }
-constexpr int DW_MAX_SPLITS = 4, DW_SLOTS = 256;    // (the slab count follows the LIVE item count: pg::Core.auto_slots)
+constexpr int DW_MAX_SPLITS = 4, DW_SLOTS = 256;    // (the slab count follows the LIVE item count: pg::Core.auto_slots;
+                                                    // 512 / 768 slots, round 5: C2's merged launch 24.7 -> 54-57 us, C4's 20.9 -> 23.5-25.7)
 
 }  // namespace
 
@@ -322,7 +324,8 @@ extern "C" int64_t rk_pg_dw_workspace_bytes(int32_t B, int32_t h, int32_t n_cap)
 // (g_parts / gparts_dev)
 static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
                       const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, const EncBwd *enc,
-                      void *stream_, float *gb_de = nullptr, bool dense = false, const rkred::Args *red = nullptr);
+                      void *stream_, float *gb_de = nullptr, bool dense = false, const rkred::Args *red = nullptr,
+                      bool ones = false);
 
 extern "C" int rk_pg_dw(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
                         const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, float *gb_de, void *stream_) {
@@ -366,6 +369,28 @@ extern "C" int rk_pg_dw_encode_bwd(const void *dO_img, const float *dO_scales, i
   return pg_dw_impl(dO_img, dO_scales, gr, gc, B, pl, tgt, slabs, &enc, stream_, gb_de);
 }
 
+// the Z image carries a ones column (csrc/internal.h): the output column h of the dW tiles is the bias gradient
+int rk_pg_dw_ones_ok(int32_t B, int32_t h, int32_t n_cap) {
+  int bm, bn;
+  dw_tile(B, h, n_cap, bm, bn);
+  // (a free padding column inside the image's last line; the merged launch -- not the two-launch form of the
+  // 256 x 256 tiles with h > 512; fp16-pair operands)
+  return (h % 32 != 0 && !(bm == 256 && bn == 256 && rk_cdiv(h, 256) > 2) && !rk_gemm_plain_bf16()) ? 1 : 0;
+}
+int rk_pg_dw_encode_bwd_ones(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
+                             const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, int32_t row_off,
+                             const float *dZ0pre, float *G_en, float *gb_en, float *gb_slabs, void *stream_) {
+  RK_REQUIRE(rk_dw_encode_bwd_fused_ok(row_off, B), "outside the fused launch's domain (rk_dw_encode_bwd_fused_ok)");
+  RK_REQUIRE(pl && rk_pg_dw_ones_ok(B, pl->h, tgt->n_cap) && gb_slabs, "rk_pg_dw_ones_ok");
+  RK_REQUIRE(row_off >= 0 && B >= 0 && row_off + B <= tgt->S_cap, "row slice out of range");
+  RK_REQUIRE(tgt->bits_cr != nullptr && tgt->pref_rc != nullptr,
+             "block was built without the transposed bitmap / prefix index");
+  EncBwd enc = {};
+  enc.b = *tgt; enc.row_off = row_off; enc.B = B; enc.dZ = dZ0pre; enc.h = pl->h; enc.G = G_en; enc.gb = gb_en;
+  enc.n_gb = gb_en ? rk_cdiv(pl->h, 64) : 0;
+  return pg_dw_impl(dO_img, dO_scales, gr, gc, B, pl, tgt, slabs, &enc, stream_, gb_slabs, false, nullptr, true);
+}
+
 // rk_pg_dw (+ gb_de) with the slab reduce of rk_fdec_loss_dz riding on the launch (< 1024 rows: 64 x 128 tiles)
 extern "C" int rk_pg_dw_dz_reduce(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
                                   const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, float *gb_de,
@@ -379,7 +404,7 @@ extern "C" int rk_pg_dw_dz_reduce(const void *dO_img, const float *dO_scales, in
 
 static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
                       const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, const EncBwd *enc_,
-                      void *stream_, float *gb_de, bool dense, const rkred::Args *red) {
+                      void *stream_, float *gb_de, bool dense, const rkred::Args *red, bool ones) {
   hipStream_t stream = (hipStream_t)stream_;
   // (column sums without an encoder backward: the same launch with an empty encoder range)
   EncBwd no_enc = {};
@@ -402,6 +427,7 @@ static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, in
   p.rs.tab = dO_scales; p.rs.gr = gr; p.rs.gc = gc; p.rs.pitch = rk_cdiv(tgt->n_cap, gc); p.rs.mode = 2;
   pg::EpiSlab::Args e = {};
   e.C = slabs; e.ldc = h; e.slab_stride = (int64_t)tgt->n_cap * h; e.bscale = pl->scales;
+  if (ones) { e.gb = gb_de; e.gb_stride = tgt->n_cap; e.gb_col = h; }     // (gb_de: one slab per K slab here)
   const int tiles = rk_cdiv(tgt->n_cap, bm) * rk_cdiv(h, bn);
   hipError_t rc;
   if (red) {
@@ -414,18 +440,25 @@ static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, in
       n_cs = rk_cdiv(tgt->n_cap, 32);
     }
     const int n_red = rkred::blocks(red->M, red->N);
-    auto k = dw_red_kernel<64, 128, 2, 2>;
-    static const hipError_t attr = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (attr != hipSuccess) { rk_set_error("LDS attribute"); return -1; }
-    hipLaunchKernelGGL(k, dim3(n_dw + n_cs + n_red), dim3(256), 2 * (64 + 128) * pg::LINE, stream, p, e, n_dw, cs, n_cs, *red);
-    rc = hipGetLastError();
+    const int ring = rk_tune_get(RK_TUNE_DW_RING);
+#define GO_RED(NS)                                                                                            \
+  do {                                                                                                        \
+    auto k = dw_red_kernel<64, 128, 2, 2, NS>;                                                                \
+    constexpr int ST = NS < 3 ? 2 : NS;                                                                       \
+    static const hipError_t attr = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    if (attr != hipSuccess) { rk_set_error("LDS attribute"); return -1; }                                     \
+    hipLaunchKernelGGL(k, dim3(n_dw + n_cs + n_red), dim3(256), ST * (64 + 128) * pg::LINE, stream, p, e, n_dw, cs, n_cs, *red); \
+    rc = hipGetLastError();                                                                                   \
+  } while (0)
+    if (ring == 2) GO_RED(2); else if (ring == 3) GO_RED(3); else if (ring == 4) GO_RED(4); else if (ring == 6) GO_RED(6); else GO_RED(0);
+#undef GO_RED
   } else if (enc) {
     const int n_dw = pg::grid_of(p, tiles);
     const int n_enc = enc_ ? rk_cdiv(tgt->n_cap, 4) + enc->n_gb : 0;
     const int hv = rk_cdiv(h, 256);
     ColsumImg cs = {};
     int n_cs = 0;
-    if (gb_de) {
+    if (gb_de && !ones) {
       cs.img = (const char *)dO_img; cs.counts = tgt->counts; cs.tab = dO_scales; cs.gr = gr; cs.gc = gc;
       cs.pitch = rk_cdiv(tgt->n_cap, gc); cs.rows = B; cs.out = gb_de;
       n_cs = rk_cdiv(tgt->n_cap, 32);
@@ -439,15 +472,34 @@ static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, in
     rc = hipGetLastError();                                                                                  \
   } while (0)
 #define BY_HV(BM, BN, WM, WN) do { if (hv == 1) GO(BM, BN, WM, WN, 1); else if (hv == 2) GO(BM, BN, WM, WN, 2); else GO(BM, BN, WM, WN, 4); } while (0)
+#define GO_NS(BM, BN, WM, WN, HV, NS)                                                                        \
+  do {                                                                                                       \
+    auto k = dw_encbwd_kernel<BM, BN, WM, WN, HV, NS>;                                                       \
+    constexpr int ST = NS < 3 ? 2 : NS;                                                                      \
+    static const hipError_t attr = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    if (attr != hipSuccess) { rc = attr; break; }                                                            \
+    hipLaunchKernelGGL(k, dim3(n_dw + n_cs + n_enc), dim3(WM * WN * 64), ST * (BM + BN) * pg::LINE, stream, p, e, n_dw, *enc, cs, n_cs); \
+    rc = hipGetLastError();                                                                                  \
+  } while (0)
+    const int ring = rk_tune_get(RK_TUNE_DW_RING);
     if (bm == 256 && bn == 256) {            // (hv == 4 never gets here: rk_pg_dw_encode_bwd)
       if (hv == 1) GO(256, 256, 2, 4, 1); else GO(256, 256, 2, 4, 2);
     }
     else if (bm == 256) BY_HV(256, 128, 4, 2);
+    else if (ring >= 2 && ring <= 6 && hv <= 2) {          // (the ring loop: csrc/pgemm.h)
+      if (hv == 1) { if (ring == 2) GO_NS(64, 128, 2, 2, 1, 2); else if (ring == 3) GO_NS(64, 128, 2, 2, 1, 3); else if (ring == 4) GO_NS(64, 128, 2, 2, 1, 4); else GO_NS(64, 128, 2, 2, 1, 6); }
+      else { if (ring == 2) GO_NS(64, 128, 2, 2, 2, 2); else if (ring == 3) GO_NS(64, 128, 2, 2, 2, 3); else if (ring == 4) GO_NS(64, 128, 2, 2, 2, 4); else GO_NS(64, 128, 2, 2, 2, 6); }
+    }
     else BY_HV(64, 128, 2, 2);
+#undef GO_NS
 #undef BY_HV
 #undef GO
   } else if (bm == 256 && bn == 256) rc = pg::launch<256, 256, 2, 4, true, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
   else if (bm == 256) rc = pg::launch<256, 128, 4, 2, true, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
+  else if (rk_tune_get(RK_TUNE_DW_RING) == 2) rc = pg::launch<64, 128, 2, 2, true, true, pg::EpiSlab, 256, true, 2>(p, e, tiles, stream);
+  else if (rk_tune_get(RK_TUNE_DW_RING) == 3) rc = pg::launch<64, 128, 2, 2, true, true, pg::EpiSlab, 0, true, 3>(p, e, tiles, stream);
+  else if (rk_tune_get(RK_TUNE_DW_RING) == 4) rc = pg::launch<64, 128, 2, 2, true, true, pg::EpiSlab, 0, true, 4>(p, e, tiles, stream);
+  else if (rk_tune_get(RK_TUNE_DW_RING) == 6) rc = pg::launch<64, 128, 2, 2, true, true, pg::EpiSlab, 0, true, 6>(p, e, tiles, stream);
   else rc = pg::launch<64, 128, 2, 2, true, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
   if (rc != hipSuccess) { rk_set_error("pg_dw: %s", hipGetErrorString(rc)); return -1; }
   return 0;

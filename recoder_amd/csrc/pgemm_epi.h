@@ -19,6 +19,9 @@ struct EpiSlab {
     int64_t ldc;
     int64_t slab_stride;     // floats between K slabs
     const float *bscale;     // device: the B operand's split scale
+    float *gb;               // nullable: output column gb_col (a padding column: n == N) goes here instead --
+    int64_t gb_stride;       // gb[split * gb_stride + m]: with a ones column in the B image the column sums of A
+    int gb_col;
   };
   template <int BM, int BN, int TM, int TN>
   static __device__ __forceinline__ void run(const Args &e, const Tile &T, f32x16 (&acc)[TM][TN], char *,
@@ -38,6 +41,13 @@ struct EpiSlab {
           for (int r = 0; r < 16; ++r) {
             const int m = T.m0 + (T.wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (m < T.M) col[(int64_t)m * e.ldc] = acc[i][j][r] * inv;
+          }
+        } else if (e.gb && n == e.gb_col) {
+          float *g = e.gb + (int64_t)T.split * e.gb_stride;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = T.m0 + (T.wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m < T.M) g[m] = acc[i][j][r] * inv;
           }
         }
       }

@@ -213,6 +213,7 @@ struct rk_enc_split_t {
   int n_split;          // where the Z image's scale goes
   char *zimg;           // nullable: Z image written by the kernel's epilogue (static scale)
   int z_kt;
+  int z_ones;           // != 0 (and h % 32 != 0): image column h of every row <- 1 (rk_pg_dw_encode_bwd_ones)
 };
 rkp::SplitW rk_split_w_args(const float *W_de, const rk_block_t *tgt, const int32_t *ranges,
                             const rk_planes_t *pl);

@@ -407,7 +407,25 @@ static int step_pg_mode(const rk_ae_step_t *a) {
   // and dropped: at C2 the image pass cost that launch 6 us and rk_pg_dw gained 0.8: 0.1222 vs 0.1188 ms)
   return 0;
 }
-extern "C" int32_t rk_ae_step_uses_pg(const rk_ae_step_t *a) { return (a && a->blk) ? step_pg_mode(a) : 0; }
+// the decoder bias gradient as output column h of the dW tiles (a ones column in the Z image's padding, written
+// by this call's encoder forward; csrc/internal.h): whole steps on the fused decode with the merged dW || encoder
+// backward launch, h % 32 != 0, and room for one bias slab per K slab in gb_part (the fused decode leaves it unused)
+static bool step_dw_ones(const rk_ae_step_t *a, const int pg_mode) {
+  const int phase = a->phase == 0 ? RK_STEP_ALL : a->phase;
+  if (phase != RK_STEP_ALL || !(pg_mode == 3 || pg_mode == 4) || !act_bounded(a->act) || a->gb_part == nullptr) return false;
+  const rk_block_t *blk = a->blk;
+  const int B = a->B, h = a->h;
+  const bool dz_fused = rk_decode_dz_fused_ok(B, h, blk->n_cap, a->loss_kind) != 0 || pg_mode == 4;
+  if (!dz_fused || !rk_dw_encode_bwd_fused_ok(a->row_off, B)) return false;      // (the merged dW || encoder backward launch)
+  const int row_tiles = rk_cdiv(B, rk_decode_row_tile());
+  return rk_tune_get(RK_TUNE_DW_ONES) != 0 && rk_pg_dw_ones_ok(B, h, blk->n_cap) != 0 &&
+         (int64_t)row_tiles * (rk_cdiv(blk->n_cap, 32) * 32) >= (int64_t)rk_pg_dw_splits(B, h, blk->n_cap) * blk->n_cap;
+}
+extern "C" int32_t rk_ae_step_uses_pg(const rk_ae_step_t *a) {
+  if (!(a && a->blk)) return 0;
+  const int mode = step_pg_mode(a);
+  return mode | (step_dw_ones(a, mode) ? 16 : 0);
+}
 
 // The whole step is a serial chain on ONE stream:
 //   encode_fwd ; decode+loss ; dW ; dZ split-K ; reduce ; encode_bwd (+gb_en) ; update
@@ -462,6 +480,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   // rk_ae_step_t.do_scales): whole untied MSE / BCE steps outside the fused decode's domain
   const bool pg = pg_mode == 1, fdec = pg_mode == 3 || pg_mode == 4;
   const float *dw_slabs_pg = dw_branch ? a->ws_dw : a->ws;
+  const bool dw_ones = dw_enc_fused && step_dw_ones(a, pg_mode);
   // opt-in (rk_adam_de_side): the decoder table's Adam sweep right behind the dW kernel ON dw_stream,
   // next to the reduce / encoder backward; the update on the chain then covers the rest
   const bool de_side = dw_branch && !dw_enc_fused && phase == RK_STEP_ALL && rk_adam_de_side() != 0;
@@ -475,6 +494,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
         es.n_split = rk_cdiv(blk->n_cap, 32);
         es.zimg = act_bounded(a->act) ? (char *)a->planes->z : nullptr;
         es.z_kt = rkp::kp_of(h) / 32;
+        es.z_ones = dw_ones ? 1 : 0;
         RK_REQUIRE(a->planes->h == h && B <= a->planes->B_cap && blk->n_cap <= a->planes->n_cap,
                    "planes were laid out for another shape");
         RK_TRY(rk_ae_encode_fwd_at(blk, a->row_off, B, a->par[RK_PAR_W_EN].p, a->par[RK_PAR_B_EN].p, h,
@@ -559,7 +579,10 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     } else if (dw_enc_fused) {
       // dW || encoder backward in ONE launch on the chain (dw3.hip dw_encbwd_kernel): no side stream
       Timer t(a, RK_ENTRY_DECODE_BWD_DW, sm);
-      if (fdec)
+      if (fdec && dw_ones)     // (the bias gradient as the dW tiles' output column h: no column-sum range)
+        RK_TRY(rk_pg_dw_encode_bwd_ones(a->dO, a->do_scales, 32, 64, B, a->planes, blk, dw_branch ? a->ws_dw : a->ws,
+                                        a->row_off, a->dZ0, G_en, a->gb_en, a->gb_part, sm));
+      else if (fdec)
         RK_TRY(rk_pg_dw_encode_bwd(a->dO, a->do_scales, 32, 64, B, a->planes, blk, dw_branch ? a->ws_dw : a->ws,
                                    a->row_off, a->dZ0, G_en, a->gb_en, a->gb_de, sm));
       else
@@ -657,7 +680,10 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     } else
     if (whole && !mnll && !fdec) { // straight from the decode epilogue's row-tile partials
       jobs[n].g = a->gb_part; jobs[n].g_parts = row_tiles; jobs[n].gstride_dev = blk->counts + 2;
-    }                              // (fdec: gb_de itself, written by the dW launch's column-sum range)
+    } else if (dw_ones) {          // one slab per K slab of the dW launch (its output column h: rk_pg_dw_encode_bwd_ones)
+      jobs[n].g = a->gb_part; jobs[n].g_parts = rk_pg_dw_splits(B, h, blk->n_cap); jobs[n].g_stride = blk->n_cap;
+      jobs[n].gparts_dev = blk->counts + 4;
+    }                              // (fdec otherwise: gb_de itself, written by the dW launch's column-sum range)
     ++n;
     slots[n] = RK_PAR_B_EN;
     jobs[n] = table_job(a->par[RK_PAR_B_EN], blk, 1, h, a->gb_en, false);

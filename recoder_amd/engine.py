@@ -1135,12 +1135,15 @@ class FusedEngine:
         self._gb_lazy = (cdiv(B, self.row_tile), blk)
     elif dp is None:
       st.phase = STEP_ALL
-      mode = int(raw.rk_ae_step_uses_pg(ctypes.byref(st)))
+      flags = int(raw.rk_ae_step_uses_pg(ctypes.byref(st)))
+      mode = flags & 15
       self._pg_step = bool(mode)
       self._step_mode = mode       # (0: decode16 / dw3 kernels, 1: csrc/pgemm.h, 3 / 4: csrc/fdecode.hip (4: streaming) + pgemm's dW; bench.py names the kernels by it)
       check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
       if self.loss_id != LOSS_MNLL and mode not in (3, 4):
         self._gb_lazy = (cdiv(B, self.row_tile), blk)    # (modes 3 / 4: gb_de itself, from the dO image)
+      elif flags & 16:
+        self._gb_lazy = ("slabs", blk)                   # (... or one slab per K slab of dW in gb_part)
     else:
       # data parallel over users: forward + whole backward locally, then the live gradient rows
       # of both tables, the gathered-bias gradient, the encoder bias gradient and the loss go out
@@ -1282,6 +1285,9 @@ class FusedEngine:
     if self._gb_lazy is None:
       return self.gb_de[:n_b].clone()
     tiles, blk = self._gb_lazy
+    if tiles == "slabs":
+      ns = int(blk.counts[4].item())
+      return sum(self.gb_part[k * blk.n_cap:k * blk.n_cap + n_b] for k in range(ns))
     ld = blk.counts_host()[2]
     return self.gb_part[:tiles * ld].view(tiles, ld)[:, :n_b].sum(0)
 

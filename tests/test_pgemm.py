@@ -105,6 +105,20 @@ def test_pg_decode_dz_dw(B, h, n_items, loss, ratings):
   scale = g64.abs().t() @ Z.double().abs() + 1e-300
   e_dw = ((G - exact).abs() / scale).max().item()
   assert e_dw < 6e-7, e_dw
+  # the deep DMA ring of the 64 x 128 dW tiles (RK_TUNE_DW_RING = 13: 3 / 4 / 6 LDS stages, counted waits, raw
+  # barriers, asm transpose reads): the same MFMAs in the same order per accumulator -- bit for bit
+  if B < 1024:
+    for ring in (2, 3, 4, 6):
+      slabs2 = torch.full_like(slabs, float("nan"))
+      lib.rk_tune(13, ring)
+      try:
+        for _ in range(3):          # (a race in the ring would come and go: three runs)
+          check(lib.rk_pg_dw(ptr(img), ptr(sc), gr, gc, B, ctypes.byref(pl), blk.ref, ptr(slabs2), None, st))
+          torch.cuda.synchronize()
+          assert int(blk.counts[4].item()) == live
+          assert torch.equal(slabs2.view(ns, blk.n_cap, h)[:live, :n_b], slabs.view(ns, blk.n_cap, h)[:live, :n_b]), ring
+      finally:
+        lib.rk_tune(13, 0)
   print("B=%d h=%d n_b=%d: image err %.2e of max, dZ %.2e, dW %.2e (of sum |products|), %d dW slabs" % (
       B, h, n_b, err / max(got.abs().max().item(), 1e-30), e_dz, e_dw, ns))
 

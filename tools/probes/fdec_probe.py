@@ -97,6 +97,13 @@ def main():
   print("rk_pg_dw alone (dW tiles from the image): %.1f us, hot %.1f us" % (timeit(lambda: check(lib.rk_pg_dw(
       ptr(img), ptr(sc), 32, 64, B, ctypes.byref(pl), blk.ref, ptr(slabs), None, st))), timeit(lambda: check(lib.rk_pg_dw(
       ptr(img), ptr(sc), 32, 64, B, ctypes.byref(pl), blk.ref, ptr(slabs), None, st)), flush_first=False)))
+  # RK_TUNE_DW_RING (13): LDS stages of the dW tiles' ring loop (2 / 3 / 4 / 6)
+  for v in (2, 3, 4, 6):
+    lib.rk_tune(13, v)
+    print("rk_pg_dw alone, RK_TUNE_DW_RING = %d: %.1f us, hot %.1f us" % (v, timeit(lambda: check(lib.rk_pg_dw(
+        ptr(img), ptr(sc), 32, 64, B, ctypes.byref(pl), blk.ref, ptr(slabs), None, st))), timeit(lambda: check(lib.rk_pg_dw(
+        ptr(img), ptr(sc), 32, 64, B, ctypes.byref(pl), blk.ref, ptr(slabs), None, st)), flush_first=False)))
+  lib.rk_tune(13, 0)
   print("rk_ae_encode_bwd alone: %.1f us" % timeit(lambda: check(lib.rk_ae_encode_bwd(
       blk.ref, 0, B, ptr(dZ), h, ptr(G_en), 0, ptr(gb_en), st))))
   print("rk_pg_dw_encode_bwd (dW || encoder backward): %.1f us" % timeit(lambda: check(lib.rk_pg_dw_encode_bwd(

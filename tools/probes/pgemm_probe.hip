@@ -96,6 +96,15 @@ static hipError_t run_cfg(int cfg, const pg::Core &p, const pg::EpiStore::Args &
   if (cfg == 1) return dispatch<128, 128, 2, 2>(p, e, atr, btr, ((p.M + 127) / 128) * ((p.N + 127) / 128), s);
   if (cfg == 2) return dispatch<128, 256, 2, 4>(p, e, atr, btr, ((p.M + 127) / 128) * ((p.N + 255) / 256), s);
   if (cfg == 3) return dispatch<256, 128, 4, 2>(p, e, atr, btr, ((p.M + 255) / 256) * ((p.N + 127) / 128), s);
+  if (cfg == 4) {                // the 64 x 128 dW tile of < 1024-row batches; env RING = LDS stages of the deep ring
+    const int tiles = ((p.M + 63) / 64) * ((p.N + 127) / 128);
+    static const int ring = getenv("RING") ? atoi(getenv("RING")) : 0;
+    if (atr && btr && ring == 2) return pg::launch<64, 128, 2, 2, true, true, pg::EpiStore, 256, false, 2>(p, e, tiles, s);
+    if (atr && btr && ring == 3) return pg::launch<64, 128, 2, 2, true, true, pg::EpiStore, 0, false, 3>(p, e, tiles, s);
+    if (atr && btr && ring == 4) return pg::launch<64, 128, 2, 2, true, true, pg::EpiStore, 0, false, 4>(p, e, tiles, s);
+    if (atr && btr && ring == 6) return pg::launch<64, 128, 2, 2, true, true, pg::EpiStore, 0, false, 6>(p, e, tiles, s);
+    return dispatch<64, 128, 2, 2>(p, e, atr, btr, tiles, s);
+  }
   return hipErrorInvalidValue;
 }
 
