@@ -38,8 +38,11 @@ int rk_probe_buffer(int32_t which, unsigned long long *buffer);
  *   RK_TUNE_GRAPH_EVENT_NODES 0  1: bench brackets inside a captured graph as event-record nodes
  *   RK_TUNE_MF_FDEC       1  MatrixFactorization steps on rk_fdec_loss_dz + rk_pg_dw_dz_reduce (rk_plan_t.mf_fdec_ok); 0: the
  *                            round-3 pair rk_decode_loss_dz_planes + rk_decode_bwd_dw2_dz_reduce
- *   RK_TUNE_DW_RING       0  LDS stages of the 64 x 128 dW tiles' DMA ring (csrc/pgemm.h): 3 / 4 / 6 = the deep ring (counted
- *                            vmcnt waits, raw s_barrier, asm transpose reads), anything else = the two-stage loop
+ *   RK_TUNE_DW_RING       2  LDS stages of the 64 x 128 dW tiles' ring k-loop (csrc/pgemm.h: counted vmcnt waits, raw
+ *                            s_barrier, asm transpose reads): 2 (default: the LDS footprint of the two-stage loop, the next
+ *                            tile's DMA now really under the MFMAs), 3 / 4 / 6 = deeper rings (faster alone -- 18.0 -> 13.2 us
+ *                            at C2's shape --, slower in the merged launches: every workgroup range pays the LDS); 0 = the
+ *                            two-stage loop as the compiler schedules it (vmcnt(0) before the first transpose read)
  *   RK_TUNE_DW_ONES       1  whole steps on the fused decode, h % 32 != 0: the decoder bias gradient as output column h of the dW
  *                            tiles (a ones column in the Z image's padding) instead of a column-sum range over the dO image
  *   RK_TUNE_FDEC_STREAM   0  the fused decode (csrc/fdecode.hip) in its STREAMING form -- a workgroup walks a group of

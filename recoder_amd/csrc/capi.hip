@@ -77,7 +77,7 @@ extern "C" int rk_probe_buffer(int32_t which, unsigned long long *buffer) {
   return -1;
 }
 // defaults of the knobs (include/recoder_hip_probe.h RK_TUNE_*)
-static int g_tune[RK_TUNE_COUNT] = {1, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 1};
+static int g_tune[RK_TUNE_COUNT] = {1, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 2, 1};
 int rk_tune_get(int knob) { return g_tune[knob]; }
 extern "C" int rk_tune(int32_t knob, int32_t value) {
   if (knob < 0 || knob >= RK_TUNE_COUNT) {

@@ -309,22 +309,28 @@ __device__ __forceinline__ void gemm_body(const Core &p, const typename Epi::Arg
     fa.init(T.lane);
     fb.init(T.lane);
     if constexpr (NS > 2 || (VAR & 256)) {           // (VAR & 256: this loop at TWO stages -- one tile in flight)
-      static_assert(ATR && BTR && (VAR & ~256) == 0, "the deep ring: both operands read along their rows, no probe variants");
+      static_assert((ATR || BTR) && (VAR & ~256) == 0, "the ring loop: an operand read along its rows, no probe variants");
       constexpr int QPW = Stager<BM, ATR, NI>::Q + Stager<BN, BTR, NI>::Q;
       static_assert((NS - 2) * QPW <= 63, "vmcnt is a 6-bit counter");
-      constexpr int RA = BM * 4, RB = BN * 4;                // bytes per k-row of the A / B stage
+      // small wave tiles hold the fragments of BOTH k-steps of a k-tile (one wait per k-tile); large ones (the
+      // 128 x 64 wave tile of the 256 x 256 workgroup: 48 VGPRs per k-step) one k-step at a time
+      constexpr bool BOTH = (TM + TN) * 16 <= 48;
 #pragma unroll
       for (int st = 0; st < NS - 1; ++st)
         if (st < nk) {
           sa.issue(smem + st * STAGE, iw);
           sb.issue(smem + st * STAGE + A_BYTES, iw);
         }
-      // lane offsets of the wave's fragments inside a stage
+      // lane offsets of the wave's TR fragments inside a stage (KC operands: FragKC::load on the stage pointer)
       int oa_[TM][2], ob_[TN][2];
+      if constexpr (ATR) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) { oa_[i][0] = fa.off(T.wm * TM + i, 0); oa_[i][1] = fa.off(T.wm * TM + i, 1); }
+        for (int i = 0; i < TM; ++i) { oa_[i][0] = fa.off(T.wm * TM + i, 0); oa_[i][1] = fa.off(T.wm * TM + i, 1); }
+      }
+      if constexpr (BTR) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) { ob_[j][0] = fb.off(T.wn * TN + j, 0) + A_BYTES; ob_[j][1] = fb.off(T.wn * TN + j, 1) + A_BYTES; }
+        for (int j = 0; j < TN; ++j) { ob_[j][0] = fb.off(T.wn * TN + j, 0) + A_BYTES; ob_[j][1] = fb.off(T.wn * TN + j, 1) + A_BYTES; }
+      }
       const uint32_t base = lds_addr(smem);
       int stage = 0;
       for (int kt = 0; kt < nk; ++kt) {
@@ -354,73 +360,78 @@ __device__ __forceinline__ void gemm_body(const Core &p, const typename Epi::Arg
           }
         }
         const uint32_t sbase = base + (uint32_t)(stage * STAGE);
-        // fragment halves: [k-step][plane][tile][half]
-        s16x4 ra[2][2][TM][2], rb[2][2][TN][2];
+        const char *SA = smem + stage * STAGE + (T.wm * TM) * 4096;          // (KC operands)
+        const char *SB = smem + stage * STAGE + A_BYTES + (T.wn * TN) * 4096;
+        constexpr int NKS = BOTH ? 2 : 1;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int k0 = 0; k0 < 2; k0 += NKS) {
+          // fragment halves of the TR operands: [k-step][plane][tile][half]; whole fragments of the KC operands
+          s16x4 ra[NKS][2][TM][2], rb[NKS][2][TN][2];
+          f16x8 ah[NKS][TM], al[NKS][TM], bh[NKS][TN], bl[NKS][TN];
 #pragma unroll
-          for (int pl = 0; pl < 2; ++pl) {
+          for (int q = 0; q < NKS; ++q) {
+            const int ks = k0 + q;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-              if (ks == 0) FragTR<BM>::template load_asm<0>(sbase + oa_[i][pl], ra[ks][pl][i][0], ra[ks][pl][i][1]);
-              else FragTR<BM>::template load_asm<1>(sbase + oa_[i][pl], ra[ks][pl][i][0], ra[ks][pl][i][1]);
-            }
+            for (int pl = 0; pl < 2; ++pl) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              if (ks == 0) FragTR<BN>::template load_asm<0>(sbase + ob_[j][pl], rb[ks][pl][j][0], rb[ks][pl][j][1]);
-              else FragTR<BN>::template load_asm<1>(sbase + ob_[j][pl], rb[ks][pl][j][0], rb[ks][pl][j][1]);
+              for (int i = 0; i < TM; ++i) {
+                if constexpr (ATR) {
+                  if (ks == 0) FragTR<BM>::template load_asm<0>(sbase + oa_[i][pl], ra[q][pl][i][0], ra[q][pl][i][1]);
+                  else FragTR<BM>::template load_asm<1>(sbase + oa_[i][pl], ra[q][pl][i][0], ra[q][pl][i][1]);
+                } else {
+                  if (pl == 0) ah[q][i] = fa.load(SA, i, ks, 0); else al[q][i] = fa.load(SA, i, ks, 1);
+                }
+              }
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                if constexpr (BTR) {
+                  if (ks == 0) FragTR<BN>::template load_asm<0>(sbase + ob_[j][pl], rb[q][pl][j][0], rb[q][pl][j][1]);
+                  else FragTR<BN>::template load_asm<1>(sbase + ob_[j][pl], rb[q][pl][j][0], rb[q][pl][j][1]);
+                } else {
+                  if (pl == 0) bh[q][j] = fb.load(SB, j, ks, 0); else bl[q][j] = fb.load(SB, j, ks, 1);
+                }
+              }
             }
           }
-        }
-        // (the asm reads are invisible to the compiler's LGKM bookkeeping: the wait for them is ours.  Nothing
-        // else is on the counter here -- the scale's s_load above was waited for by its compare)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int pl = 0; pl < 2; ++pl) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(ra[ks][pl][i][0]), "+v"(ra[ks][pl][i][1]));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rb[ks][pl][j][0]), "+v"(rb[ks][pl][j][1]));
-          }
-        f16x8 ah0[TM], al0[TM], bh0[TN], bl0[TN], ah1[TM], al1[TM], bh1[TN], bl1[TN];
+          // (the asm reads are invisible to the compiler's LGKM bookkeeping: the wait for them is ours; its own
+          // waits for the KC operands' ds_read_b128 can only come out stronger than needed.  The scale's s_load
+          // above was waited for by its compare.)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #define PG_CAT(X) __builtin_bit_cast(f16x8, __builtin_shufflevector(X[0], X[1], 0, 1, 2, 3, 4, 5, 6, 7))
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          ah0[i] = PG_CAT(ra[0][0][i]); al0[i] = PG_CAT(ra[0][1][i]);
-          ah1[i] = PG_CAT(ra[1][0][i]); al1[i] = PG_CAT(ra[1][1][i]);
-        }
+          for (int q = 0; q < NKS; ++q) {
+            if constexpr (ATR) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          bh0[j] = PG_CAT(rb[0][0][j]); bl0[j] = PG_CAT(rb[0][1][j]);
-          bh1[j] = PG_CAT(rb[1][0][j]); bl1[j] = PG_CAT(rb[1][1][j]);
-        }
+              for (int i = 0; i < TM; ++i) {
+                asm volatile("" : "+v"(ra[q][0][i][0]), "+v"(ra[q][0][i][1]), "+v"(ra[q][1][i][0]), "+v"(ra[q][1][i][1]));
+                ah[q][i] = PG_CAT(ra[q][0][i]); al[q][i] = PG_CAT(ra[q][1][i]);
+              }
+            }
+            if constexpr (BTR) {
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                asm volatile("" : "+v"(rb[q][0][j][0]), "+v"(rb[q][0][j][1]), "+v"(rb[q][1][j][0]), "+v"(rb[q][1][j][1]));
+                bh[q][j] = PG_CAT(rb[q][0][j]); bl[q][j] = PG_CAT(rb[q][1][j]);
+              }
+            }
+          }
 #undef PG_CAT
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int q = 0; q < NKS; ++q) {
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0[i], bh0[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+              for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[q][i], bh[q][j], acc[i][j], 0, 0, 0);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[i], bl0[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+              for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q][i], bl[q][j], acc[i][j], 0, 0, 0);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0[i], bh0[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1[i], bh1[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[i], bl1[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1[i], bh1[j], acc[i][j], 0, 0, 0);
+              for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[q][i], bh[q][j], acc[i][j], 0, 0, 0);
+          }
+        }
         stage = stage + 1 == NS ? 0 : stage + 1;
       }
       __syncthreads();

@@ -302,10 +302,17 @@ extern "C" int rk_pg_dz(const void *dO_img, const float *dO_scales, int32_t gr, 
   e.C = workspace; e.ldc = h; e.slab_stride = (int64_t)B * h; e.bscale = pl->scales + 1;
   const int tiles = rk_cdiv(B, bm) * rk_cdiv(h, bn);
   hipError_t rc;
-  if (bm == 256 && bn == 256) rc = pg::launch<256, 256, 2, 4, false, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
-  else if (bm == 256) rc = pg::launch<256, 128, 4, 2, false, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
-  else if (bn == 256) rc = pg::launch<128, 256, 2, 4, false, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
-  else rc = pg::launch<128, 128, 2, 2, false, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
+  // (RK_TUNE_DW_RING != 0: the ring k-loop of csrc/pgemm.h -- the W image's transpose reads as asm, so that the next
+  // tile's DMA lands under the MFMAs instead of being drained in front of the first read)
+  const bool ring = rk_tune_get(RK_TUNE_DW_RING) != 0;
+  if (bm == 256 && bn == 256) rc = ring ? pg::launch<256, 256, 2, 4, false, true, pg::EpiSlab, 256, true>(p, e, tiles, stream)
+                                        : pg::launch<256, 256, 2, 4, false, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
+  else if (bm == 256) rc = ring ? pg::launch<256, 128, 4, 2, false, true, pg::EpiSlab, 256, true>(p, e, tiles, stream)
+                                : pg::launch<256, 128, 4, 2, false, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
+  else if (bn == 256) rc = ring ? pg::launch<128, 256, 2, 4, false, true, pg::EpiSlab, 256, true>(p, e, tiles, stream)
+                                : pg::launch<128, 256, 2, 4, false, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
+  else rc = ring ? pg::launch<128, 128, 2, 2, false, true, pg::EpiSlab, 256, true>(p, e, tiles, stream)
+                 : pg::launch<128, 128, 2, 2, false, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
   if (rc != hipSuccess) { rk_set_error("pg_dz: %s", hipGetErrorString(rc)); return -1; }
   // every slab is written (an empty K range leaves zeros): summing min(K, splits) of them is the sum
   return rk_splitk_reduce_tiles(workspace, B, h, tgt->counts, p.splits, 1, Zact, act, dZ, stream_);
@@ -483,8 +490,10 @@ static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, in
   } while (0)
     const int ring = rk_tune_get(RK_TUNE_DW_RING);
     if (bm == 256 && bn == 256) {            // (hv == 4 never gets here: rk_pg_dw_encode_bwd)
-      if (hv == 1) GO(256, 256, 2, 4, 1); else GO(256, 256, 2, 4, 2);
+      if (ring != 0) { if (hv == 1) GO_NS(256, 256, 2, 4, 1, 2); else GO_NS(256, 256, 2, 4, 2, 2); }
+      else { if (hv == 1) GO(256, 256, 2, 4, 1); else GO(256, 256, 2, 4, 2); }
     }
+    else if (bm == 256 && ring != 0) { if (hv == 1) GO_NS(256, 128, 4, 2, 1, 2); else if (hv == 2) GO_NS(256, 128, 4, 2, 2, 2); else GO_NS(256, 128, 4, 2, 4, 2); }
     else if (bm == 256) BY_HV(256, 128, 4, 2);
     else if (ring >= 2 && ring <= 6 && hv <= 2) {          // (the ring loop: csrc/pgemm.h)
       if (hv == 1) { if (ring == 2) GO_NS(64, 128, 2, 2, 1, 2); else if (ring == 3) GO_NS(64, 128, 2, 2, 1, 3); else if (ring == 4) GO_NS(64, 128, 2, 2, 1, 4); else GO_NS(64, 128, 2, 2, 1, 6); }
@@ -494,8 +503,10 @@ static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, in
 #undef GO_NS
 #undef BY_HV
 #undef GO
-  } else if (bm == 256 && bn == 256) rc = pg::launch<256, 256, 2, 4, true, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
-  else if (bm == 256) rc = pg::launch<256, 128, 4, 2, true, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
+  } else if (bm == 256 && bn == 256) rc = rk_tune_get(RK_TUNE_DW_RING) != 0 ? pg::launch<256, 256, 2, 4, true, true, pg::EpiSlab, 256, true>(p, e, tiles, stream)
+                                                                             : pg::launch<256, 256, 2, 4, true, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
+  else if (bm == 256) rc = rk_tune_get(RK_TUNE_DW_RING) != 0 ? pg::launch<256, 128, 4, 2, true, true, pg::EpiSlab, 256, true>(p, e, tiles, stream)
+                                                              : pg::launch<256, 128, 4, 2, true, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
   else if (rk_tune_get(RK_TUNE_DW_RING) == 2) rc = pg::launch<64, 128, 2, 2, true, true, pg::EpiSlab, 256, true, 2>(p, e, tiles, stream);
   else if (rk_tune_get(RK_TUNE_DW_RING) == 3) rc = pg::launch<64, 128, 2, 2, true, true, pg::EpiSlab, 0, true, 3>(p, e, tiles, stream);
   else if (rk_tune_get(RK_TUNE_DW_RING) == 4) rc = pg::launch<64, 128, 2, 2, true, true, pg::EpiSlab, 0, true, 4>(p, e, tiles, stream);
