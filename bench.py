@@ -711,8 +711,10 @@ def main():
       if step_mode == 3:          # csrc/fdecode.hip + csrc/pgemm.hip
         KERNELS["rk_decode_loss"] = ["fdec_kernel<%d, %d>" % (kt, pg_loss)]
         KERNELS["rk_decode_bwd_dz"] = ["splitk_reduce_kernel"]
-        KERNELS["rk_decode_bwd_dw"] = ["dw_encbwd_kernel<64, 128, 2, 2, %d> (csrc/pgemm.hip: dW tiles from the dO image || "
-                                       "its column sums || encoder-backward columns)" % hv]
+        ones = bool(int(getattr(eng, "_step_flags", 0)) & 16)
+        KERNELS["rk_decode_bwd_dw"] = ["dw_encbwd_kernel<64, 128, 2, 2, %d, 2> (csrc/pgemm.hip: dW tiles from the dO image%s || "
+                                       "encoder-backward columns)" % (hv, ", their output column h = the decoder bias gradient "
+                                                                      "(ones column of the Z image)" if ones else " || its column sums")]
       elif step_mode == 4:        # csrc/fdecode.hip streaming + csrc/pgemm.hip dW (>= 1024 rows)
         KERNELS["rk_decode_loss"] = ["fdec_stream_kernel<%d, %d, %s>" % (kt, pg_loss, "true" if cfg["loss"] == "mse" else "false")]
         KERNELS["rk_decode_bwd_dz"] = ["splitk_reduce_kernel"]

@@ -809,6 +809,7 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(const float *__restrict__
   reinterpret_cast<float4 *>(out)[i] = s;
 }
 
+constexpr int MNLL_CACHE = 12;      // quads of a row per thread kept in registers by mnll_finish_kernel
 // MNLL second pass, one block per row (see rk_mnll_finish in the header)
 // ext_* (nullable, per row): the softmax statistics and the target sum of the WHOLE row when
 // the block only holds a shard of its items (item-parallel training)
@@ -836,6 +837,18 @@ __global__ __launch_bounds__(256) void mnll_finish_kernel(float *dO, rk_block_t 
     t0 = implicit ? 1.0f : b.vals[beg + tid];
     x0 = orow[b.cols[beg + tid]];
   }
+  // The row's first MNLL_CACHE * 1024 logits are fetched ONCE, all loads in flight together, and stay in registers
+  // for both passes (C3: 8.4 k columns = 9 quads per thread; the statistics pass and the gradient pass each walked
+  // them as a chain of dependent round trips: 19-21 us for 51 MB); longer rows continue from memory as before
+  float4 xc[MNLL_CACHE];
+  uint32_t wc[MNLL_CACHE];
+  const uint32_t *brow = b.bits_rc + (int64_t)row * b.ldw_rc;
+#pragma unroll
+  for (int u = 0; u < MNLL_CACHE; ++u) {
+    const int i = tid + u * 256;
+    xc[u] = i < n4 ? orow4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    wc[u] = i < n4 ? brow[i >> 3] : 0u;
+  }
   float mx = -INFINITY, lsum;
   if (ext_max) {
     mx = ext_max[r];
@@ -845,7 +858,21 @@ __global__ __launch_bounds__(256) void mnll_finish_kernel(float *dO, rk_block_t 
     // rescaled when it moves (online softmax); the (max, sum) pairs of the threads are merged the
     // same way in fixed order
     float m = -INFINITY, se = 0.f;
-    for (int i = tid; i < n4; i += 256) {
+#pragma unroll
+    for (int u = 0; u < MNLL_CACHE; ++u) {
+      const int i = tid + u * 256;
+      if (i < n4) {
+        float4 x = xc[u];
+        const int c = i << 2;
+        if (c + 1 >= n) x.y = -INFINITY;
+        if (c + 2 >= n) x.z = -INFINITY;
+        if (c + 3 >= n) x.w = -INFINITY;
+        const float m4 = fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w));
+        if (m4 > m) { se *= expf(m - m4); m = m4; }      // (expf(-inf) = 0 on the first quad)
+        se += (expf(x.x - m) + expf(x.y - m)) + (expf(x.z - m) + expf(x.w - m));
+      }
+    }
+    for (int i = tid + MNLL_CACHE * 256; i < n4; i += 256) {
       float4 x = orow4[i];
       const int c = i << 2;
       if (c + 1 >= n) x.y = -INFINITY;
@@ -888,11 +915,8 @@ __global__ __launch_bounds__(256) void mnll_finish_kernel(float *dO, rk_block_t 
   const float sum_g = ext_tsum ? -ext_tsum[r] * inv_B : (red2[4] + red2[5]) + (red2[6] + red2[7]);
   float gmax = 0.f;
   // dense part: dO = g - softmax * sum_g,  g = -t*inv_B at stored positions
-  const uint32_t *brow = b.bits_rc + (int64_t)row * b.ldw_rc;
-  for (int i = tid; i < n4; i += 256) {
-    const float4 x = orow4[i];
+  auto grad_quad = [&](const int i, const float4 x, const uint32_t word) {
     const int c = i << 2;
-    const uint32_t word = brow[c >> 5];
     const uint32_t nib = (word >> (c & 31)) & 15u;
     float xs[4] = {x.x, x.y, x.z, x.w}, go[4];
 #pragma unroll
@@ -907,7 +931,13 @@ __global__ __launch_bounds__(256) void mnll_finish_kernel(float *dO, rk_block_t 
       gmax = fmaxf(gmax, fabsf(go[e4]));
     }
     reinterpret_cast<float4 *>(orow)[i] = make_float4(go[0], go[1], go[2], go[3]);
+  };
+#pragma unroll
+  for (int u = 0; u < MNLL_CACHE; ++u) {
+    const int i = tid + u * 256;
+    if (i < n4) grad_quad(i, xc[u], wc[u]);
   }
+  for (int i = tid + MNLL_CACHE * 256; i < n4; i += 256) grad_quad(i, orow4[i], brow[i >> 3]);
   // running max |dLoss/dLogit| of the block, as the MSE / BCE epilogue publishes it
   gmax = rk_wave_max(gmax);
   __syncthreads();

@@ -1137,6 +1137,7 @@ class FusedEngine:
       st.phase = STEP_ALL
       flags = int(raw.rk_ae_step_uses_pg(ctypes.byref(st)))
       mode = flags & 15
+      self._step_flags = flags     # (bit 4: the bias gradient as output column h of the dW tiles -- recoder_hip.h)
       self._pg_step = bool(mode)
       self._step_mode = mode       # (0: decode16 / dw3 kernels, 1: csrc/pgemm.h, 3 / 4: csrc/fdecode.hip (4: streaming) + pgemm's dW; bench.py names the kernels by it)
       check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
