@@ -55,7 +55,7 @@ struct FdecP {
 constexpr int WB = 128 * 128;    // bytes of one 128-row k-tile stage
 
 // MFMA A operand of dZ^T = W^T . dO^T from a RESIDENT W stage [128 item rows][128 B] (csrc/pgemm.h "KC"
-// layout, 16-byte slots swizzled by (row >> 1) & 7): this lane's hidden unit = 16 g + (l & 15) of the stage's
+// layout, 16-byte slots swizzled by pg::kc_sw(row)): this lane's hidden unit = 16 g + (l & 15) of the stage's
 // 32, 8 consecutive items starting at row0 (a multiple of 8) -- two transpose reads of 4 rows each
 __device__ __forceinline__ f16x8 w_tr_frag(const char *S, const int row0, const int lane, const int plane) {
   const int t = lane & 15, g = (lane >> 4) & 1;
@@ -66,7 +66,7 @@ __device__ __forceinline__ f16x8 w_tr_frag(const char *S, const int row0, const 
   for (int u = 0; u < 2; ++u) {
     const int row = row0 + 4 * u + (t >> 2);
     v[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (pg::lds_s16x4 *)(S + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4) + within));
+        (pg::lds_s16x4 *)(S + row * 128 + ((slot ^ pg::kc_sw(row)) << 4) + within));
   }
   const pg::s16x8 x = __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(f16x8, x);
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = 8 * i + (lane >> 3);
-      *reinterpret_cast<pg::u32x4 *>(zb + r * 128 + (((lane & 7) ^ ((r >> 1) & 7)) << 4)) = zraw[kt][i];
+      *reinterpret_cast<pg::u32x4 *>(zb + r * 128 + (((lane & 7) ^ pg::kc_sw(r)) << 4)) = zraw[kt][i];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = 8 * i + (ln >> 3);
-        *reinterpret_cast<pg::u32x4 *>(zb + r * 128 + (((ln & 7) ^ ((r >> 1) & 7)) << 4)) = zraw[i];
+        *reinterpret_cast<pg::u32x4 *>(zb + r * 128 + (((ln & 7) ^ pg::kc_sw(r)) << 4)) = zraw[i];
       }
       if (kt + 1 < KTM) {      // (the next k-tile's pieces, in flight under this one's MFMAs)
 #pragma unroll

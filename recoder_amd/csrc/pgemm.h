@@ -18,7 +18,10 @@
 // LDS images (lane-linear for the DMA; the bank swizzle is applied to the SOURCE address and to the
 // fragment read, never to the destination):
 //   K along the columns ("KC"): stage = [R rows][128 B line]; 16-byte slot s of row r sits at slot
-//     s ^ ((r >> 1) & 7): the 16 lanes of a ds_read_b128 group hit 16 different slots of the 256-B bank row.
+//     s ^ kc_sw(r), a permutation of the row pair's index (r >> 1) & 7: the 16 lanes of a ds_read_b128 group hit 16
+//     different slots of the 256-B bank row.  (Round 5: bit 0 of the pair index goes to bit 2 of the mask, so that the
+//     rows r and r + 2 of a TRANSPOSE read of this layout -- csrc/fdecode.hip reads its resident W stage that way for
+//     dZ: 4 rows x 64 bytes per half-wave -- sit in different 64-byte halves; with the plain index they shared 16 banks.)
 //   K along the rows ("TR"):    stage = [32 k-rows][C / 32 lines]; byte o of k-row kr sits at
 //     o ^ ((kr & 1) << 6 | (kr & 2) << 6): the 32 lanes of a ds_read_b64_tr_b16 half-wave (4 k-rows x
 //     64 bytes) cover the 256-B bank row exactly once.
@@ -72,6 +75,11 @@ struct Core {
 };
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// slot mask of row r in a KC stage (see the header comment)
+__device__ __forceinline__ int kc_sw(const int r) {
+  const int x = (r >> 1) & 7;
+  return ((x & 1) << 2) | (x & 2) | (x >> 2);
+}
 
 // A wave-uniform word of a table an EARLIER launch wrote, through the scalar cache (s_load: lgkmcnt).  As a
 // vector load it sits on the VM counter behind the LDS-DMAs of the next k-tile, and the wait for its value
@@ -102,7 +110,7 @@ struct Stager {
       for (int q = 0; q < Q; ++q) {
         const int qg = q * NW + wave;
         const int r = qg * 8 + (lane >> 3);
-        const int s = (lane & 7) ^ ((r >> 1) & 7);
+        const int s = (lane & 7) ^ kc_sw(r);
         const int row = min(x0 + r, lim - 1);
         src[q] = o.img + (int64_t)row * o.pitch + (int64_t)kt0 * LINE + s * 16;
       }
@@ -163,11 +171,11 @@ __device__ __forceinline__ uint32_t lds_addr(const char *p) {
 // column (tile * 32 + l31); plane 0 = hi, 1 = lo
 struct FragKC {
   int base;                 // l31 * 128
-  int sw;                   // (l31 >> 1) & 7
+  int sw;                   // kc_sw(l31)
   int lh;
   __device__ __forceinline__ void init(const int lane) {
     const int l31 = lane & 31;
-    base = l31 * LINE; sw = (l31 >> 1) & 7; lh = lane >> 5;
+    base = l31 * LINE; sw = kc_sw(l31); lh = lane >> 5;
   }
   __device__ __forceinline__ f16x8 load(const char *S, const int tile, const int ks, const int plane) const {
     const int slot = (ks * 2 + lh + plane * 4) ^ sw;
