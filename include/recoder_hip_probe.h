@@ -40,8 +40,9 @@ int rk_probe_buffer(int32_t which, unsigned long long *buffer);
  *                            round-3 pair rk_decode_loss_dz_planes + rk_decode_bwd_dw2_dz_reduce
  *   RK_TUNE_DW_RING       2  LDS stages of the 64 x 128 dW tiles' ring k-loop (csrc/pgemm.h: counted vmcnt waits, raw
  *                            s_barrier, asm transpose reads): 2 (default: the LDS footprint of the two-stage loop, the next
- *                            tile's DMA now really under the MFMAs), 3 / 4 / 6 = deeper rings (faster alone -- 18.0 -> 13.2 us
- *                            at C2's shape --, slower in the merged launches: every workgroup range pays the LDS); 0 = the
+ *                            tile's DMA now really under the MFMAs), 4 = a deeper ring (3 / 4 / 6 stages measured: faster
+ *                            alone -- 18.0 -> 13.2 us at C2's shape --, slower in the merged launches: every workgroup range
+ *                            pays the LDS; only 4 is still instantiated); 0 = the
  *                            two-stage loop as the compiler schedules it (vmcnt(0) before the first transpose read)
  *   RK_TUNE_DW_ONES       1  whole steps on the fused decode, h % 32 != 0: the decoder bias gradient as output column h of the dW
  *                            tiles (a ones column in the Z image's padding) instead of a column-sum range over the dO image

@@ -111,7 +111,7 @@ __device__ __forceinline__ void colsum_img_body(const ColsumImg &c, const int bl
   }
 }
 
-// RING: 0 = the two-stage loop as the compiler schedules it; 2 / 3 / 4 / 6 = LDS stages of the ring loop (csrc/pgemm.h)
+// RING: 0 = the two-stage loop as the compiler schedules it; 2 / 4 = LDS stages of the ring loop (csrc/pgemm.h)
 template <int BM, int BN, int WM, int WN, int HV, int RING = 0>
 __global__ __launch_bounds__(WM * WN * 64) void dw_encbwd_kernel(const pg::Core p, const pg::EpiSlab::Args e,
                                                                 const int n_dw, const EncBwd enc,
@@ -457,7 +457,7 @@ static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, in
     hipLaunchKernelGGL(k, dim3(n_dw + n_cs + n_red), dim3(256), ST * (64 + 128) * pg::LINE, stream, p, e, n_dw, cs, n_cs, *red); \
     rc = hipGetLastError();                                                                                   \
   } while (0)
-    if (ring == 2) GO_RED(2); else if (ring == 3) GO_RED(3); else if (ring == 4) GO_RED(4); else if (ring == 6) GO_RED(6); else GO_RED(0);
+    if (ring == 2) GO_RED(2); else if (ring == 4) GO_RED(4); else GO_RED(0);
 #undef GO_RED
   } else if (enc) {
     const int n_dw = pg::grid_of(p, tiles);
@@ -495,9 +495,9 @@ static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, in
     }
     else if (bm == 256 && ring != 0) { if (hv == 1) GO_NS(256, 128, 4, 2, 1, 2); else if (hv == 2) GO_NS(256, 128, 4, 2, 2, 2); else GO_NS(256, 128, 4, 2, 4, 2); }
     else if (bm == 256) BY_HV(256, 128, 4, 2);
-    else if (ring >= 2 && ring <= 6 && hv <= 2) {          // (the ring loop: csrc/pgemm.h)
-      if (hv == 1) { if (ring == 2) GO_NS(64, 128, 2, 2, 1, 2); else if (ring == 3) GO_NS(64, 128, 2, 2, 1, 3); else if (ring == 4) GO_NS(64, 128, 2, 2, 1, 4); else GO_NS(64, 128, 2, 2, 1, 6); }
-      else { if (ring == 2) GO_NS(64, 128, 2, 2, 2, 2); else if (ring == 3) GO_NS(64, 128, 2, 2, 2, 3); else if (ring == 4) GO_NS(64, 128, 2, 2, 2, 4); else GO_NS(64, 128, 2, 2, 2, 6); }
+    else if ((ring == 2 || ring == 4) && hv <= 2) {          // (the ring loop: csrc/pgemm.h)
+      if (hv == 1) { if (ring == 2) GO_NS(64, 128, 2, 2, 1, 2); else GO_NS(64, 128, 2, 2, 1, 4); }
+      else { if (ring == 2) GO_NS(64, 128, 2, 2, 2, 2); else GO_NS(64, 128, 2, 2, 2, 4); }
     }
     else BY_HV(64, 128, 2, 2);
 #undef GO_NS
@@ -508,9 +508,7 @@ static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, in
   else if (bm == 256) rc = rk_tune_get(RK_TUNE_DW_RING) != 0 ? pg::launch<256, 128, 4, 2, true, true, pg::EpiSlab, 256, true>(p, e, tiles, stream)
                                                               : pg::launch<256, 128, 4, 2, true, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
   else if (rk_tune_get(RK_TUNE_DW_RING) == 2) rc = pg::launch<64, 128, 2, 2, true, true, pg::EpiSlab, 256, true, 2>(p, e, tiles, stream);
-  else if (rk_tune_get(RK_TUNE_DW_RING) == 3) rc = pg::launch<64, 128, 2, 2, true, true, pg::EpiSlab, 0, true, 3>(p, e, tiles, stream);
   else if (rk_tune_get(RK_TUNE_DW_RING) == 4) rc = pg::launch<64, 128, 2, 2, true, true, pg::EpiSlab, 0, true, 4>(p, e, tiles, stream);
-  else if (rk_tune_get(RK_TUNE_DW_RING) == 6) rc = pg::launch<64, 128, 2, 2, true, true, pg::EpiSlab, 0, true, 6>(p, e, tiles, stream);
   else rc = pg::launch<64, 128, 2, 2, true, true, pg::EpiSlab, 0, true>(p, e, tiles, stream);
   if (rc != hipSuccess) { rk_set_error("pg_dw: %s", hipGetErrorString(rc)); return -1; }
   return 0;

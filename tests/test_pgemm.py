@@ -108,7 +108,7 @@ def test_pg_decode_dz_dw(B, h, n_items, loss, ratings):
   # the deep DMA ring of the 64 x 128 dW tiles (RK_TUNE_DW_RING = 13: 3 / 4 / 6 LDS stages, counted waits, raw
   # barriers, asm transpose reads): the same MFMAs in the same order per accumulator -- bit for bit
   if B < 1024:
-    for ring in (2, 3, 4, 6):
+    for ring in (2, 4):
       slabs2 = torch.full_like(slabs, float("nan"))
       lib.rk_tune(13, ring)
       try:

@@ -65,7 +65,7 @@ def main():
     live = int(blk.counts[4].item())
     side = torch.cuda.Stream()
     noise = torch.zeros(48 << 20, **f)
-    for ring in ((2, 3, 4, 6) if B < 1024 else (2,)):
+    for ring in ((2, 4) if B < 1024 else (2,)):
       lib.rk_tune(13, ring)
       for load in (False, True):
         wrong = wrongz = 0

@@ -98,7 +98,7 @@ def main():
       ptr(img), ptr(sc), 32, 64, B, ctypes.byref(pl), blk.ref, ptr(slabs), None, st))), timeit(lambda: check(lib.rk_pg_dw(
       ptr(img), ptr(sc), 32, 64, B, ctypes.byref(pl), blk.ref, ptr(slabs), None, st)), flush_first=False)))
   # RK_TUNE_DW_RING (13): LDS stages of the dW tiles' ring loop (2 / 3 / 4 / 6)
-  for v in (2, 3, 4, 6):
+  for v in (2, 4):
     lib.rk_tune(13, v)
     print("rk_pg_dw alone, RK_TUNE_DW_RING = %d: %.1f us, hot %.1f us" % (v, timeit(lambda: check(lib.rk_pg_dw(
         ptr(img), ptr(sc), 32, 64, B, ctypes.byref(pl), blk.ref, ptr(slabs), None, st))), timeit(lambda: check(lib.rk_pg_dw(
