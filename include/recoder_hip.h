@@ -419,10 +419,12 @@ int rk_fdec_dz_reduce(const float *dz_workspace, int32_t B, int32_t h, const rk_
                       int32_t act, float *dZ, void *stream);
 /* rk_pg_dw (dW slabs from the dO image, + the decoder bias gradient from its columns) with rk_fdec_dz_reduce riding on
  * the SAME launch as a workgroup range -- steps in which nothing between the decode and the optimizer reads dZ
- * (MatrixFactorization: the user rows' gradient); < 1024 rows. */
+ * (MatrixFactorization: the user rows' gradient); < 1024 rows.  dense != 0: no split-K -- `slabs` is the ONE dense
+ * gradient array [n_cap][h] (the data-parallel exchange ships it). */
 int rk_pg_dw_dz_reduce(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
                        const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, float *gb_de /* nullable */,
-                       const float *dz_workspace, const float *Zact /* nullable */, int32_t act, float *dZ, void *stream);
+                       const float *dz_workspace, const float *Zact /* nullable */, int32_t act, float *dZ,
+                       int32_t dense, void *stream);
 /* (RK_PG=0 in the environment switches the family off: the round-3 plane kernels run instead) */
 int rk_pg_decode_loss(const rk_planes_t *pl, int32_t B, const rk_block_t *tgt, int32_t row_off,
                       const float *b_de, int32_t loss_kind, float confidence, float inv_B, void *dO_img,

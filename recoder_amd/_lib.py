@@ -177,7 +177,7 @@ SIGNATURES = {
                                 _P, _P, _P, _P]),
   "rk_fdec_dz_reduce": (c_int32, [_P, c_int32, c_int32, _BLK, _P, c_int32, _P, _P]),
   "rk_pg_dw_dz_reduce": (c_int32, [_P, _P, c_int32, c_int32, c_int32, POINTER(RkPlanes), _BLK, _P, _P, _P, _P, c_int32,
-                                   _P, _P]),
+                                   _P, c_int32, _P]),
   "rk_ae_step_uses_pg": (c_int32, [_P]),
   "rk_pg_decode_loss": (c_int32, [POINTER(RkPlanes), c_int32, _BLK, c_int32, _P, c_int32, c_float, c_float, _P,
                                   c_int32, _P, _P, _P, _P, _P]),

@@ -402,11 +402,11 @@ int rk_pg_dw_encode_bwd_ones(const void *dO_img, const float *dO_scales, int32_t
 extern "C" int rk_pg_dw_dz_reduce(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
                                   const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, float *gb_de,
                                   const float *dz_workspace, const float *Zact, int32_t act, float *dZ,
-                                  void *stream_) {
+                                  int32_t dense, void *stream_) {
   RK_REQUIRE(B < 1024, "rk_pg_dw_dz_reduce: batches below 1024 rows (the 256-thread dW tiles)");
   RK_REQUIRE(al16(dz_workspace) && al16(dZ), "operands must be 16-byte aligned");
   const rkred::Args red = {dz_workspace, B, pl ? pl->h : 0, tgt->counts, 128, rk_fdec_slabs(B, tgt->n_cap), Zact, act, dZ};
-  return pg_dw_impl(dO_img, dO_scales, gr, gc, B, pl, tgt, slabs, nullptr, stream_, gb_de, false, &red);
+  return pg_dw_impl(dO_img, dO_scales, gr, gc, B, pl, tgt, slabs, nullptr, stream_, gb_de, dense != 0, &red);
 }
 
 static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,

@@ -463,7 +463,7 @@ class FusedEngine:
     column sums and the slab reduce in ONE launch behind it (rk_pg_dw_dz_reduce) -- round 5."""
     lib = self.lib
     return (self.kind == "mf" and self.planes is not None and self.split16 and self.ws_dw is not None and
-            self.item_parallel is None and self.allreduce is None and not lib.rk_gemm_plain_bf16() and
+            self.item_parallel is None and not lib.rk_gemm_plain_bf16() and
             bool(lib.rk_mf_fdec_ok(B, self.h[0], n_cap, self.loss_id)))
 
   def _pg_entry_ok(self, B, n_cap):
@@ -481,7 +481,7 @@ class FusedEngine:
             not lib.rk_decode_dz_fused_ok(B, self.h[0], n_cap, self.loss_id))
 
   def _loss(self, z, B, tgt, row_off, denom_rows, stream, out=None, ip=None, defer=False, fuse_dz=False,
-            zt_ws=None, pg_ok=False):
+            zt_ws=None, pg_ok=False, fdec_ok=False):
     """decode + loss; leaves dLoss/dLogits in self.dO. Returns device scalar.  ip: the
     block holds an item shard (parallel.ItemParallel) -- only the multinomial loss needs to
     know: its softmax statistics are combined over the ranks."""
@@ -501,7 +501,7 @@ class FusedEngine:
     # (the encoder forward of this step already cut W_de[items of this block]: rk_ae_encode_fwd_split_w)
     w_done = getattr(self, "_w_split_of", None) is tgt and tgt is not None
     self._w_split_of = None
-    if fuse_dz and pg_ok and ip is None and self._fdec_entry_ok(B, tgt.n_cap):
+    if fuse_dz and fdec_ok and ip is None and self._fdec_entry_ok(B, tgt.n_cap):
       h0 = self.h[0]
       rg = self._ranges(z, B * h0, stream)
       check(lib.rk_split_wz(None if w_done else ptr(W), ptr(z), B, h0, tgt.ref, rg,
@@ -689,7 +689,9 @@ class FusedEngine:
     dp_replay = self.allreduce is not None and getattr(self, "_replay", None) is not None and ip is None
     loss = self._loss(z, B, tb, row_off, rows, stream, self.loss_dp if dp_replay else out, ip=ip, defer=lazy,
                       fuse_dz=True, zt_ws=zt_ws,
-                      pg_ok=lazy and not tied and self.ws_dw is not None)
+                      pg_ok=lazy and not tied and self.ws_dw is not None,
+                      # (users-DP too: dW then leaves ONE dense array for the exchange -- rk_pg_dw_dz_reduce dense)
+                      fdec_ok=ip is None and not tied and self.ws_dw is not None)
     self._loss_target = loss
 
     # ---- dW = dO^T . z  (+ decoder bias gradient) ----
@@ -736,11 +738,13 @@ class FusedEngine:
       # -- and, MatrixFactorization (nothing before the Adam sweep reads dZ), the slab reduce as a third range
       zact = None if self.drop_active else self.enc[0]
       check(lib.rk_pg_dw_dz_reduce(ptr(self.dO), ptr(self.do_scales), 32, 64, B, ctypes.byref(self.planes), tb.ref,
-                                   ptr(self.ws_dw), ptr(self.gb_de), ptr(self.ws), ptr(zact), self.act,
-                                   ptr(self.dbott), stream), "rk_pg_dw_dz_reduce")
-      self._dw_slabs = (tb, B)
-      self._ws_dw_live = True
-      self._pg_step = True
+                                   ptr(self.ws_dw if keep_slabs else self.G_de), ptr(self.gb_de), ptr(self.ws),
+                                   ptr(zact), self.act, ptr(self.dbott), 0 if keep_slabs else 1, stream),
+            "rk_pg_dw_dz_reduce")
+      # (single process: the K slabs stay in ws_dw for the Adam sweep to add up; users-DP: one dense G_de)
+      self._dw_slabs = (tb, B) if keep_slabs else None
+      self._ws_dw_live = bool(keep_slabs)
+      self._pg_step = bool(keep_slabs)
       self._dz_done = True
     else:
       # the loss epilogue already reduced dO per row tile: sum those few rows
