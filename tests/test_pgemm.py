@@ -299,6 +299,27 @@ def _fdec_case(B, h, n_items, loss, ratings):
   # ... and sums its columns (the decoder bias gradient) in a second workgroup range
   cs = ref.double().sum(0)
   assert (gbd[:n_b].double() - cs).abs().max().item() <= 2e-6 * max(ref.double().abs().sum(0).max().item(), 1e-30)
+  # ... and rk_pg_dw_dz_reduce does all of it -- dW, the column sums, the dZ slab reduce -- in ONE launch: the same
+  # numbers bit for bit, as K slabs (single process) and as one dense array (dense = 1: the users-DP exchange)
+  if B < 1024:
+    for dense in (0, 1):
+      out = torch.full_like(slabs, float("nan"))
+      gb2 = torch.full((blk.n_cap,), 7.0, **f)
+      dZ2 = torch.full((B * h,), float("nan"), **f)
+      check(lib.rk_pg_dw_dz_reduce(ptr(img), ptr(sc), 32, 64, B, ctypes.byref(pl), blk.ref, ptr(out), ptr(gb2), ptr(ws2),
+                                   ptr(Z), ACT_TANH, ptr(dZ2), dense, st))
+      torch.cuda.synchronize()
+      # (the slabs are added up by 4 waves per output group here, by 16 in rk_fdec_dz_reduce: another order)
+      assert ((dZ2.view(B, h).double() - exact).abs() / den).max().item() < 6e-7
+      assert torch.equal(gb2[:n_b], gbd[:n_b])
+      if dense:
+        G2 = out[:blk.n_cap * h].view(blk.n_cap, h)[:n_b].double()
+        assert ((G2 - ex).abs() / (ref.double().abs().t() @ Z.double().abs() + 1e-300)).max().item() < 6e-7
+        if live == 1:
+          assert torch.equal(out[:blk.n_cap * h].view(blk.n_cap, h)[:n_b], slabs.view(ns, blk.n_cap, h)[0, :n_b])
+      else:
+        assert int(blk.counts[4].item()) == live
+        assert torch.equal(out.view(ns, blk.n_cap, h)[:live, :n_b], slabs.view(ns, blk.n_cap, h)[:live, :n_b])
 
 
 def test_fdec_scale_table_has_no_write_past_the_capacity():
