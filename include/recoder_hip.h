@@ -636,6 +636,9 @@ typedef struct rk_ae_step {
   rk_adam_param_t par[RK_PAR_COUNT];
   /* workspaces (sizes as FusedEngine.ensure_capacity allocates them) */
   float *Z0, *dZ0, *dO, *G_de, *G_en, *gb_de, *gb_part, *gb_en, *ws, *loss_part, *loss_out;
+  /* (gb_part: ceil(B / rk_plan_t.decode_row_tile) rows of round_up(n_cap, 32) floats.  Whole steps on the fused decode
+   * with h % 32 != 0 leave the decoder bias gradient THERE as one slab of n_cap floats per K slab of dW -- see
+   * rk_ae_step_uses_pg bit 4 -- when that fits, i.e. rk_plan_t.pg_dw_splits * n_cap floats) */
   void *stream;              /* hipStream_t: every kernel of the step goes here, in order */
   int32_t time_entry;        /* RK_ENTRY_*: bracket that entry with the two events below */
   int32_t phase;             /* mask of RK_STEP_* (0 = RK_STEP_ALL) */
