@@ -106,6 +106,10 @@ CONFIGS = {
                          "config.alt_large_batch of a multi-GPU run)",
                 data="ml20m", kind="ae", hidden_layers=[200], activation_type="tanh", noise_prob=0.5,
                 sparse=False, loss="mse", batch_size=4000, lr=1e-3, weight_decay=2e-5),
+  "c3mse": dict(workload="C3's model with the squared error (hidden=[200,200] tanh noise 0.5, MSE, dense Adam) on the C3 matrix: "
+                         "the entry-by-entry sequenced autoencoder step on the fused decode (round 5; not a BASELINE config)",
+                data="msd200k", kind="ae", hidden_layers=[200, 200], activation_type="tanh", noise_prob=0.5,
+                sparse=False, loss="mse", batch_size=500, lr=1e-3, weight_decay=2e-5),
   # the other BASELINE.json configurations at their 1-GPU shapes (parity-test cases; these lines are
   # extra data points, `python bench.py --config c3|c4|c5u` -- the graded line is c2)
   "c3": dict(workload="C3 MSD-like synthetic CSR 200000x41140 (200k of the 471k users; lognormal degree "

@@ -457,14 +457,20 @@ class FusedEngine:
     check(self.lib.rk_amax(ptr(z), n, ptr(self.ranges), stream), "rk_amax")
     return ptr(self.ranges)
 
-  def _fdec_entry_ok(self, B, n_cap):
-    """MatrixFactorization steps (sequenced entry by entry) on the register-resident fused decode
-    (rk_fdec_loss_dz: decode + loss + dZ partials, dLoss/dLogits as a plane image) with dW from the image, its
-    column sums and the slab reduce in ONE launch behind it (rk_pg_dw_dz_reduce) -- round 5."""
+  def _fdec_entry_ok(self, B, n_cap, row_off=0, own_block=True):
+    """Steps sequenced entry by entry on the register-resident fused decode (rk_fdec_loss_dz: decode + loss + dZ
+    partials, dLoss/dLogits as a plane image) -- round 5.  MatrixFactorization: dW from the image, its column sums
+    and the slab reduce in ONE launch behind it (rk_pg_dw_dz_reduce; users-DP: its dense form).  Autoencoders with
+    hidden stacks / bottleneck dropout (single process, untied, MSE / BCE, the block is its own target):
+    rk_fdec_dz_reduce, the stack's backward, then dW || column sums || encoder backward (rk_pg_dw_encode_bwd)."""
     lib = self.lib
-    return (self.kind == "mf" and self.planes is not None and self.split16 and self.ws_dw is not None and
-            self.item_parallel is None and not lib.rk_gemm_plain_bf16() and
-            bool(lib.rk_mf_fdec_ok(B, self.h[0], n_cap, self.loss_id)))
+    if not (self.planes is not None and self.split16 and self.ws_dw is not None and self.item_parallel is None and
+            not lib.rk_gemm_plain_bf16() and bool(lib.rk_mf_fdec_ok(B, self.h[0], n_cap, self.loss_id))):
+      return False
+    if self.kind == "mf":
+      return True
+    return (self.allreduce is None and not bool(self.model.is_constrained) and own_block and
+            bool(lib.rk_dw_encode_bwd_fused_ok(row_off, B)))
 
   def _pg_entry_ok(self, B, n_cap):
     """Entry-by-entry steps: the three contractions on the pipelined pair-plane kernels (csrc/pgemm.h)
@@ -481,7 +487,7 @@ class FusedEngine:
             not lib.rk_decode_dz_fused_ok(B, self.h[0], n_cap, self.loss_id))
 
   def _loss(self, z, B, tgt, row_off, denom_rows, stream, out=None, ip=None, defer=False, fuse_dz=False,
-            zt_ws=None, pg_ok=False, fdec_ok=False):
+            zt_ws=None, pg_ok=False, fdec_ok=False, own_block=True):
     """decode + loss; leaves dLoss/dLogits in self.dO. Returns device scalar.  ip: the
     block holds an item shard (parallel.ItemParallel) -- only the multinomial loss needs to
     know: its softmax statistics are combined over the ranks."""
@@ -501,7 +507,7 @@ class FusedEngine:
     # (the encoder forward of this step already cut W_de[items of this block]: rk_ae_encode_fwd_split_w)
     w_done = getattr(self, "_w_split_of", None) is tgt and tgt is not None
     self._w_split_of = None
-    if fuse_dz and fdec_ok and ip is None and self._fdec_entry_ok(B, tgt.n_cap):
+    if fuse_dz and fdec_ok and ip is None and self._fdec_entry_ok(B, tgt.n_cap, row_off, own_block):
       h0 = self.h[0]
       rg = self._ranges(z, B * h0, stream)
       check(lib.rk_split_wz(None if w_done else ptr(W), ptr(z), B, h0, tgt.ref, rg,
@@ -665,8 +671,9 @@ class FusedEngine:
       self._w_split_of = None
       self._split_w_with_fwd = (tgt is None and ip is None and self.planes is not None and self.split16 and
                                 self.item_parallel is None and not bool(m.is_constrained))
-      self._split_nowt = bool(self._split_w_with_fwd and self._pg_entry_ok(B, blk.n_cap) and
-                              self.allreduce is None)
+      self._split_nowt = bool(self._split_w_with_fwd and self.allreduce is None and
+                              (self._pg_entry_ok(B, blk.n_cap) or
+                               self._fdec_entry_ok(B, blk.n_cap, row_off, tgt is None)))
       z = self._ae_forward(blk, row_off, B, keep_noise, keep_drop, True, stream)
       self._split_w_with_fwd = False
     else:
@@ -691,7 +698,7 @@ class FusedEngine:
                       fuse_dz=True, zt_ws=zt_ws,
                       pg_ok=lazy and not tied and self.ws_dw is not None,
                       # (users-DP too: dW then leaves ONE dense array for the exchange -- rk_pg_dw_dz_reduce dense)
-                      fdec_ok=ip is None and not tied and self.ws_dw is not None)
+                      fdec_ok=ip is None and not tied and self.ws_dw is not None, own_block=tb is blk)
     self._loss_target = loss
 
     # ---- dW = dO^T . z  (+ decoder bias gradient) ----
@@ -724,6 +731,8 @@ class FusedEngine:
         # (dO comes from rk_mnll_finish: its column sums -- the decoder bias gradient -- are taken by
         # extra workgroups of the dW || encoder-backward launch)
         self._dw_colsum = True
+      elif getattr(self, "_dz_fdec", False):
+        pass                     # (the fused decode has no column sums to give: the deferred launch takes them from the image)
       elif lazy:
         self._gb_lazy = (cdiv(B, self.row_tile), tb)
       else:
@@ -793,6 +802,9 @@ class FusedEngine:
       check(lib.rk_decode_dz_reduce(ptr(self.ws), B, h0, tb.ref, ptr(zact),
                                     self.act, ptr(dz), stream), "rk_decode_dz_reduce")
       self._dz_in_ws = False
+    elif getattr(self, "_dz_fdec", False):
+      check(lib.rk_fdec_dz_reduce(ptr(self.ws), B, h0, tb.ref, ptr(zact), self.act, ptr(dz), stream),
+            "rk_fdec_dz_reduce")
     elif getattr(self, "_dz_pg", False):
       check(lib.rk_pg_dz(ptr(self.dO), ptr(self.do_scales), 64, 32, B, ctypes.byref(self.planes), tb.ref,
                          ptr(zact), self.act, ptr(dz), ptr(self.ws), stream), "rk_pg_dz")
@@ -867,7 +879,13 @@ class FusedEngine:
       if getattr(self, "_dw_deferred", None) is not None:
         zz, self._dw_deferred = self._dw_deferred, None
         zt = ptr(self.ws_dw) if getattr(self, "_zt_ready", None) == self.ws_dw.data_ptr() else None
-        if getattr(self, "_dz_pg", False):
+        if getattr(self, "_dz_fdec", False):
+          # (the fused decode's image: granule 32 x 64; its columns' sums = the decoder bias gradient ride along)
+          check(lib.rk_pg_dw_encode_bwd(ptr(self.dO), ptr(self.do_scales), 32, 64, B, ctypes.byref(self.planes),
+                                        blk.ref, ptr(self.ws_dw), row_off, ptr(self.denc[0]), ptr(G_en),
+                                        ptr(self.gb_en), ptr(self.gb_de), stream), "rk_pg_dw_encode_bwd")
+          self._pg_step = True
+        elif getattr(self, "_dz_pg", False):
           check(lib.rk_pg_dw_encode_bwd(ptr(self.dO), ptr(self.do_scales), 64, 32, B, ctypes.byref(self.planes),
                                         blk.ref, ptr(self.ws_dw), row_off, ptr(self.denc[0]), ptr(G_en),
                                         ptr(self.gb_en), None, stream), "rk_pg_dw_encode_bwd")
