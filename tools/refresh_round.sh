@@ -8,7 +8,7 @@ export MASTER_ADDR=127.0.0.1 MASTER_PORT=29655 TMPDIR=/tmp
 timeout 900 bash tools/profile_round.sh $tag > gpurun_out/${tag}_console.txt 2>&1
 o=gpurun_out/$tag
 timeout 300 python bench.py > $o/bench_default.json 2> $o/bench_default.err
-for c in c3 c4 c5u c5u4k; do timeout 300 python bench.py --config $c --no-cpu-baseline > $o/bench_$c.json 2>> $o/bench.err; done
+for c in c3 c3mse c4 c5u c5u4k; do timeout 300 python bench.py --config $c --no-cpu-baseline > $o/bench_$c.json 2>> $o/bench.err; done
 for c in c3 c4 c5u4k; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format rocpd -d $o -o st_$c -- python bench.py --config $c --no-cpu-baseline --no-recall > $o/st_$c.log 2>&1
   python tools/rocpd_stats.py $(find $o -name "st_${c}_results.db") > $o/kernel_stats_$c.md 2>> $o/bench.err
@@ -32,7 +32,7 @@ cp gpurun_out/${tag}_s20/dump.txt $o/steps20_timeline.txt
 timeout 120 python tools/probes/fdec_probe.py > $o/fdec_probe.txt 2>&1
 rm -f $(find $o -name '*.db')
 tail -3 gpurun_out/${tag}_console.txt
-for f in $o/bench_default.json $o/bench.json $o/bench_steps20.json $o/bench_steps20_r3method.json $o/bench_c3.json $o/bench_c4.json $o/bench_c5u.json $o/bench_c5u4k.json $o/bench_c2b4k.json $o/bench_c2b4k_stream.json $o/bench_c2_bf16.json $o/bench_c2_dp1.json $o/bench_c2_dp1_zero.json $o/bench_c4_dp1_owned0.json $o/bench_c4_dp1_ownedforce.json $o/bench_c5u_dp1_owned0.json $o/bench_c5u_dp1_ownedforce.json; do python - "$f" <<'P'
+for f in $o/bench_default.json $o/bench.json $o/bench_steps20.json $o/bench_steps20_r3method.json $o/bench_c3.json $o/bench_c3mse.json $o/bench_c4.json $o/bench_c5u.json $o/bench_c5u4k.json $o/bench_c2b4k.json $o/bench_c2b4k_stream.json $o/bench_c2_bf16.json $o/bench_c2_dp1.json $o/bench_c2_dp1_zero.json $o/bench_c4_dp1_owned0.json $o/bench_c4_dp1_ownedforce.json $o/bench_c5u_dp1_owned0.json $o/bench_c5u_dp1_ownedforce.json; do python - "$f" <<'P'
 import sys, json
 try:
   d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
