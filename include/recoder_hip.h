@@ -66,8 +66,10 @@ typedef struct rk_plan {
   int32_t dw_encode_bwd_fused_ok;  /* dW || encoder backward in one launch */
   int32_t adam_de_side;            /* the probe header's RK_TUNE_ADAM_DE_SIDE: the decoder table's Adam sweep is a
                                       launch of its own behind the dW kernel on dw_stream (off by default) */
-  int32_t mf_fdec_ok;              /* entry-by-entry sequenced steps without a reader of dZ in front of the update
-                                      (MatrixFactorization): rk_fdec_loss_dz + rk_pg_dw_dz_reduce cover this shape */
+  int32_t mf_fdec_ok;              /* entry-by-entry sequenced steps (MatrixFactorization: rk_fdec_loss_dz +
+                                      rk_pg_dw_dz_reduce; hidden stacks / dropout with MSE / BCE: rk_fdec_loss_dz +
+                                      rk_fdec_dz_reduce + rk_pg_dw_encode_bwd): the fused decode covers this shape
+                                      (the probe header's RK_TUNE_MF_FDEC value, 0 = off) */
 } rk_plan_t;
 int rk_plan(rk_plan_t *plan);
 
