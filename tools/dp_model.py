@@ -51,11 +51,11 @@ def main():
     nb1 = union_sizes(csr, B, 1, a.steps)
     # single-GPU kernel terms (us) at n_b = nb1: {fixed, scales with n_b} from the round-4/5 profiles
     if name == "c2":
-      fixed, scaled, adam1 = 13.0, 24.5 + 6.5 + 25.0, 38.5          # enc fwd | fdec, reduce, dW||enc bwd | dense sweep
+      fixed, scaled, adam1 = 12.5, 24.0 + 9.0 + 18.0 + 15.0, 38.5   # enc fwd | fdec, reduce, dW (dense) + encoder backward of the PHASED step (r05_bench_c2_dp1_rccl.json) | dense sweep
     elif name == "c3":
       fixed, scaled, adam1 = 11.5 + 2 * 6.5 + 2 * 9.4, 19.8 + 19.0 + 25.4 + 7.0 + 30.0 + 10.4, 76.0   # enc fwd, Linears | decode, mnll, dZ, reduce, dW||enc bwd, split | dense sweep
     elif name == "c4":
-      fixed, scaled, adam1 = 7.0 + 8.0, 33.0 + 21.0, 18.0            # gather, split | decode+dZ, dW||reduce | SparseAdam
+      fixed, scaled, adam1 = 6.5 + 7.6 + 8.4 + 6.5, 28.0 + 20.0, 19.0   # gather, split, loss reduce, user rows | fused decode, dW || colsum || reduce (r05_bench_c4_dp1_replicated.json) | SparseAdam
     else:
       fixed, scaled, adam1 = 79.0, 117.0 + 100.0 + 100.0 + 62.0, 280.0   # enc fwd | decode, dZ, dW, enc bwd | SparseAdam
     for N in (1, 2, 4, 8):
