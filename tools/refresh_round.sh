@@ -9,7 +9,7 @@ timeout 900 bash tools/profile_round.sh $tag > gpurun_out/${tag}_console.txt 2>&
 o=gpurun_out/$tag
 timeout 300 python bench.py > $o/bench_default.json 2> $o/bench_default.err
 for c in c3 c3mse c4 c5u c5u4k; do timeout 300 python bench.py --config $c --no-cpu-baseline > $o/bench_$c.json 2>> $o/bench.err; done
-for c in c3 c4 c5u4k; do
+for c in c3 c4 c5u c5u4k; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format rocpd -d $o -o st_$c -- python bench.py --config $c --no-cpu-baseline --no-recall > $o/st_$c.log 2>&1
   python tools/rocpd_stats.py $(find $o -name "st_${c}_results.db") > $o/kernel_stats_$c.md 2>> $o/bench.err
 done
