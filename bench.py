@@ -67,6 +67,9 @@ ADAM_DE_SIDE = False
 FUSED_DZ = False
 FUSED_DW_ENC = False
 STEP_MODE = 0          # rk_ae_step_uses_pg of the step that ran (engine._step_mode): set in main()
+# lazy dense Adam (csrc/optim.hip table_sweep_lazy): average rows of a table one sweep brings up to date (the rows
+# with a gradient, the rows the next step reads, the round-robin chunk) -- None: every row (the plain sweep)
+LAZY_ROWS = None
 # the kernels each bracketed entry launches (names as rocprofv3 --kernel-trace prints them)
 KERNELS = {"rk_ae_encode_fwd": ["ae_encode_fwd_kernel (+ the W_de[items] split workgroups)"],
            "rk_decode_loss": ["decode_planes_kernel<TM,2,EPI>"],
@@ -182,6 +185,11 @@ def algorithmic_work(entry, B, h0, n_b, nnz, n_items, cfg_sparse=False):
     extra = (slabs - 1) * n_b * h0 * 4
     if cfg_sparse:
       table, rest = n_b * h0 * 28, n_items * 28 + n_b * 32
+    elif LAZY_ROWS is not None:
+      # the lazy sweep: p, m, v of the swept rows only (read + written), the gradient rows, per row the two item
+      # maps + the stamp (read) and the swept rows' stamps (written)
+      table = LAZY_ROWS * h0 * 24 + n_b * h0 * 4 + n_items * 12 + LAZY_ROWS * 4
+      rest = n_items * 28 + n_b * 32 + h0 * 28
     else:
       table, rest = n_items * h0 * 24 + n_b * h0 * 4 + n_items * 4, n_items * 28 + n_b * 32 + h0 * 28
     if ADAM_DE_SIDE:        # this launch: the encoder table + the small tensors
@@ -431,6 +439,7 @@ def main():
                   help="per-launch brackets: sampled behind the clock (default) or inside the timed region")
   ap.add_argument("--no-precollate", action="store_true", help="first group's collation inside the timed region")
   ap.add_argument("--no-pretouch", action="store_true", help="no touch of the optimizer state in front of the clock")
+  ap.add_argument("--no-tails", action="store_true", help="the last steps in front of a cut launch by launch, not as a captured tail graph")
   ap.add_argument("--pretouch-reps", type=int, default=8, help="passes of that touch (~0.3 ms each)")
   ap.add_argument("--prewarm", type=float, default=0.0, help="seconds of untimed extra steps in front of the warmup")
   ap.add_argument("--alt", choices=("auto", "0", "1"), default="auto",
@@ -575,6 +584,10 @@ def main():
     # group is a replayed graph with its look-ahead) -- one collation per group either way.
     T["precollated"] = bool(gs is not None and SAMPLE_POST and not args.no_precollate
                             and gs.precollate())
+    # the timed region's last K % G steps as a captured tail graph (captured here, in front of the clock)
+    if gs is not None:
+      gs.capture_tails = not args.no_tails
+      gs.prepare_tails([K % G])
     if not args.no_pretouch:
       # one read of the parameters and Adam moments: the first timed Adam sweep finds them where every
       # later one does (in the Infinity Cache behind the previous sweep), not cold behind the cut
@@ -677,6 +690,9 @@ def main():
       lo, hi = shard_range(n_users, rank, world)
       shard = csr[lo:hi]
     nbs, nnzs = [], []
+    gs_ = getattr(rec, "_graph_stepper", None)
+    lazy_L = int(eng.lazy_period) if (gs_ is not None and getattr(gs_, "lazy", None)) else 0
+    swept, prev_items = [], None
     for i in range(W, min(W + K, W + (50 if not multi else 10))):
       ep, k = 1 + i // steps_per_epoch, i % steps_per_epoch
       if ep not in orders:
@@ -684,6 +700,15 @@ def main():
       rows = shard[orders[ep][k * B:(k + 1) * B]]
       nnzs.append(rows.nnz)
       items = np.unique(rows.indices)
+      if lazy_L and prev_items is not None:
+        # rows the lazy sweep of the PREVIOUS step touched: its own item set, this step's, the round-robin chunk
+        mask = np.zeros(n_items, dtype=bool)
+        mask[prev_items] = True
+        mask[items] = True
+        c = (i - 1) % lazy_L
+        mask[c * n_items // lazy_L:(c + 1) * n_items // lazy_L] = True
+        swept.append(int(mask.sum()))
+      prev_items = items
       if multi:
         # every rank works on the UNION item set of the global batch (users-DP: the all-reduced
         # stamps): rebuild the other ranks' batches from their seeded orders
@@ -696,6 +721,8 @@ def main():
           items = np.union1d(items, np.unique(csr[lo_r:hi_r][o_r].indices))
       nbs.append(len(items))
     n_b, nnz = float(np.mean(nbs)), float(np.mean(nnzs))
+    global LAZY_ROWS
+    LAZY_ROWS = float(np.mean(swept)) if swept else None
     ev_over = eng.event_pair_overhead_ms()
     timed = eng.timed_samples_ms()
     global ADAM_DE_SIDE, FUSED_DZ, FUSED_DW_ENC
@@ -899,6 +926,12 @@ def main():
                  "first_group_collation": ("in front of the clock; the look-ahead collation behind the last "
                                            "timed group runs inside it (one per group, as in steady state)")
                                           if T.get("precollated") else "inside the timed region, in front of step 0",
+                 "lazy_adam": ({"period": lazy_L, "avg_rows_swept_per_table": LAZY_ROWS, "of_rows": n_items,
+                                "note": "dense Adam's rows without a gradient that the next step does not read are caught "
+                                        "up later by replaying their missed steps, bit for bit (csrc/optim.hip "
+                                        "table_sweep_lazy; RK_ADAM_LAZY=0: every row every step); the last step of "
+                                        "the timed region leaves every row up to date"}
+                               if LAZY_ROWS is not None else None),
                  "exchange_microbench": exch,
                  "alt_item_parallel": None, "alt_large_batch": None, "alt_local_item_sets": None},
       "roofline": roofline,

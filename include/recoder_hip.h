@@ -617,16 +617,44 @@ typedef struct rk_adam_job {
   const int32_t *gparts_dev;   /* nullable: the number of gradient parts is read from the device
                                   (rk_decode_bwd_dw3 publishes its slab count in counts[4]);
                                   g_parts is then the capacity */
+  /* LAZY dense Adam (lazy_stamp != NULL; dense table jobs with pos, h % 4 == 0, constants from the replay
+   * table, i.e. a cursor): optim.Adam with a dense gradient (model.py:135,398-399) updates EVERY row of the
+   * table every step -- rows outside the block's item set with g = 0 (+ weight_decay * p).  That update is a
+   * recurrence of the row's own (p, m, v) and the per-step constants only, so it can be applied LATER by
+   * replaying the identical per-step arithmetic.  lazy_stamp[row] = global index of the first step NOT yet
+   * applied to the row.  A launch of step T brings up to date (missed steps with g = 0, then step T with its
+   * gradient) exactly the rows that
+   *   have a gradient (pos[row] >= 0), or are read by the NEXT step (lazy_pos_next[row] >= 0 -- that step's
+   *   forward needs them current), or lie in chunk T % lazy_period of the table (bounds every lag by
+   *   lazy_period steps);
+   * lazy_pos_next == NULL: every row (what the last step in front of a checkpoint / validation / the end of
+   * train() does).  Row by row the result is BITWISE the dense sweep's.  rk_adam_lazy_flush below brings
+   * every row up to date without a step. */
+  const int32_t *lazy_pos_next;
+  int32_t *lazy_stamp;
+  int32_t lazy_period;         /* >= 1 */
 } rk_adam_job_t;
 
 int rk_adam_multi(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part,
                   int32_t n_part, float denom, float *loss_out, void *stream);
+/* Replay the missed steps [lazy_stamp[row], next_step) of every row of the jobs' tables (g = 0 + weight
+ * decay) and set lazy_stamp[row] = next_step: afterwards the tables are what the dense sweeps would have
+ * left.  table / tab_stride / tab_slots as rk_replay_t.adam_table (entry of global step s and job j at
+ * table[(s - epoch_base) * tab_stride + tab_slots[j]]); only p / m / v, n_rows, h, lazy_stamp and amax_out
+ * of a job are read. */
+int rk_adam_lazy_flush(const rk_adam_job_t *jobs, int32_t n_jobs, const void *table, int32_t tab_stride,
+                       const int32_t *tab_slots, int64_t next_step, int64_t epoch_base, void *stream);
 /* D[row, :] = pos[row] >= 0 ? G[pos[row], :] : 0 for row < n_items, 0 for n_items <= row < rows_pad: the
  * compact gradient rows of a block laid out by ITEM ID -- the layout a reduce-scatter over equal row
  * ranges needs (sharded dense Adam, rk_ae_step_t.zero_lo).  h % 4 == 0 and 16-byte aligned, or h == 1 (a gathered
  * bias gradient). */
 int rk_rows_to_dense(const float *G, const int32_t *pos, int32_t n_items, int32_t rows_pad, int32_t h,
                      float *D, void *stream);
+/* X_k[n_b * h_k .. n_cap * h_k) <- 0 for n_arrays <= 4 compact [n_cap, h_k] gradient arrays, n_b = counts[0] read on the
+ * device.  Replayed data-parallel steps exchange the blocks' whole capacity (a captured collective has a fixed size)
+ * summed in place: the rows past the live items, which no kernel rewrites, must be zero going in. */
+int rk_zero_tail_rows(float *const *X, const int32_t *h, int32_t n_arrays, const int32_t *counts, int32_t n_cap,
+                      void *stream);
 
 typedef struct rk_ae_step {
   const rk_block_t *blk;
@@ -705,6 +733,12 @@ typedef struct rk_ae_step {
    * RK_DP_ITEMSETS=local: the ranks' compact columns differ, so every gradient travels laid out by item id);
    * the bias job of RK_STEP_UPDATE then reads it row by row instead of gb_de through the block's pos map */
   const float *zero_gb_de;
+  /* Lazy dense Adam of the two embedding tables (rk_adam_job_t.lazy_stamp; whole replayed steps, dense Adam):
+   * stamps of W_en / W_de ([n_items] int32 each; lazy_stamp_de unused with tied weights), the NEXT step's
+   * pos map (NULL: this step leaves every row up to date), the round-robin period.  lazy_stamp_en == NULL: off. */
+  int32_t *lazy_stamp_en, *lazy_stamp_de;
+  const int32_t *lazy_pos_next;
+  int32_t lazy_period;
 } rk_ae_step_t;
 
 void *rk_event_create(int32_t timing); /* 0: ordering-only (no timing, device-scope fence); 1: for time_ev0 /

@@ -94,6 +94,7 @@ class RkAeStep(Structure):
     ("do_scales", c_void_p), ("do_rows", c_int32),
     ("zero_lo", c_int32), ("zero_hi", c_int32), ("zero_g_en", c_void_p), ("zero_g_de", c_void_p),
     ("zero_gb_de", c_void_p),
+    ("lazy_stamp_en", c_void_p), ("lazy_stamp_de", c_void_p), ("lazy_pos_next", c_void_p), ("lazy_period", c_int32),
   ]
 
 
@@ -120,6 +121,7 @@ class RkAdamJob(Structure):
     ("gstride_dev", c_void_p), ("g", c_void_p),
     ("row0", c_int32), ("row_step", c_int32),
     ("amax_out", c_void_p), ("gparts_dev", c_void_p),
+    ("lazy_pos_next", c_void_p), ("lazy_stamp", c_void_p), ("lazy_period", c_int32),
   ]
 
 
@@ -142,6 +144,7 @@ SIGNATURES = {
                                          c_uint64, _P, _P, _P, _P]),
   "rk_bias_act": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P]),
   "rk_rows_to_dense": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P]),
+  "rk_zero_tail_rows": (c_int32, [POINTER(c_void_p), POINTER(c_int32), c_int32, _P, c_int32, _P]),
   "rk_densify": (c_int32, [_BLK, c_int32, c_int32, c_int32, _P, c_int32, _P]),
   "rk_ae_encode_fwd": (c_int32, [_BLK, c_int32, c_int32, _P, _P, c_int32, _P, c_float, c_uint64,
                                  c_uint64, _P, c_int32, _P, _P]),
@@ -208,6 +211,7 @@ SIGNATURES = {
   "rk_adam_dense": (c_int32, [_P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double,
                               c_double, c_int32, _P]),
   "rk_adam_multi": (c_int32, [POINTER(RkAdamJob), c_int32, _P, c_int32, c_float, _P, _P]),
+  "rk_adam_lazy_flush": (c_int32, [POINTER(RkAdamJob), c_int32, _P, c_int32, POINTER(c_int32), c_int64, c_int64, _P]),
   "rk_scatter_pos": (c_int32, [_P, _P, c_int32, c_int32, _P]),
   "rk_event_create": (c_void_p, [c_int32]),
   "rk_event_destroy": (None, [c_void_p]),

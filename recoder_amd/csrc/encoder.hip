@@ -206,8 +206,11 @@ __global__ __launch_bounds__(FW * 64) void ae_encode_fwd_kernel(
           // z_ones (h % 32 != 0): the first padding column of the image row holds the constant 1 -- dW = dO^T . Z
           // then leaves the column sums of dO (the decoder bias gradient) in its output column h for free; the
           // decode multiplies the column with the W image's zero padding
-          if (z_ones && hh == h - 4)
-            rkp::store_split4(zimg + (int64_t)r * z_kt * rkp::LINE, h, make_float4(1.f, 0.f, 0.f, 0.f), sz, false);
+          // (a launch WITHOUT z_ones writes zeros there: a step that does not use the ones column -- a ragged batch,
+          // another mode of the same engine -- must not find a stale 1 of an earlier one)
+          if ((h & 31) != 0 && hh == h - 4)
+            rkp::store_split4(zimg + (int64_t)r * z_kt * rkp::LINE, h, make_float4(z_ones ? 1.f : 0.f, 0.f, 0.f, 0.f), sz,
+                              sw.plain != 0);
         }
         if (planes) {
           // Z^T as three bf16 planes in the fragment order of the dW kernel (csrc/dw3.hip):

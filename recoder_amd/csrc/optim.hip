@@ -20,17 +20,25 @@ namespace {
 
 struct AdamC {
   float one_m_b1, b2, one_m_b2, eps, wd;
-  float bc2_sqrt;     // sqrt(1 - beta2^t)
+  float inv_bc2_sqrt; // 1 / sqrt(1 - beta2^t)
   float neg_step;     // -(lr / (1 - beta1^t))           (Adam)
   float neg_step_sp;  // -(lr * sqrt(1-beta2^t) / (1-beta1^t))   (SparseAdam)
 };
 
+// One Adam update of one element.  EVERY dense-Adam path of this file goes through this one function with every
+// operation spelled out (explicit fma, no contraction left to the compiler): the lazy sweep replays missed steps
+// with it and must reproduce the dense sweep bit for bit, whatever code surrounds the call.
+// Round 6: sqrt(v) / bc2_sqrt + eps as fma(sqrt(v), 1 / bc2_sqrt, eps) with the hardware square root, and the final
+// quotient as a multiplication by the hardware reciprocal (both within 1 ulp) -- the IEEE sqrt + two IEEE divisions
+// of rounds 1-5 were ~45 of the update's ~60 VALU issue slots per element, which made the sweep (and above all the
+// replay of missed steps) VALU-bound next to its HBM traffic: tools/probes/lazy_adam_probe.hip.
 __device__ __forceinline__ void adam1(float &p, float &m, float &v, float g, const AdamC &c) {
-  if (c.wd != 0.f) g = g + c.wd * p;                 // grad.add(param, alpha=wd)
+#pragma clang fp contract(off)
+  if (c.wd != 0.f) g = fmaf(c.wd, p, g);             // grad.add(param, alpha=wd)
   m = fmaf(c.one_m_b1, g - m, m);                    // exp_avg.lerp_(grad, 1-beta1)
-  v = v * c.b2 + (c.one_m_b2 * g) * g;               // mul_(beta2).addcmul_(g, g, 1-beta2)
-  const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
-  p = p + (c.neg_step * m) / denom;                  // addcdiv_(exp_avg, denom, -step_size)
+  v = fmaf(c.one_m_b2 * g, g, v * c.b2);             // mul_(beta2).addcmul_(g, g, 1-beta2)
+  const float denom = fmaf(__builtin_amdgcn_sqrtf(v), c.inv_bc2_sqrt, c.eps);
+  p = fmaf(c.neg_step * m, __builtin_amdgcn_rcpf(denom), p);   // addcdiv_(exp_avg, denom, -step_size)
 }
 
 __device__ __forceinline__ void sadam1(float &p, float &m, float &v, float g, const AdamC &c) {
@@ -273,9 +281,29 @@ struct UJob {
   AdamC c;
 };
 
+// The BIG jobs of a launch -- dense Adam sweeps of [n_rows, h] embedding tables through pos, h % 4 == 0 -- as lean
+// records of their own, at most two per launch, LAST in the grid: their fields sit at static offsets of the kernel
+// argument (a few wide scalar loads), the element index is 32-bit and nothing of the general job's options
+// (row strides, SparseAdam, scalar elements) is in their way.
+struct UTab {
+  float4 *p, *m, *v;
+  const float4 *g;             // compact gradient rows (+ g_parts - 1 more arrays, gs4 float4s apart)
+  const int32_t *pos;          // row -> compact gradient row or -1
+  const int32_t *pos_next;     // lazy: the next step's map (null: every row is brought up to date)
+  int32_t *stamp;              // lazy: row -> first step not yet applied; null: the plain sweep
+  const int32_t *gparts_dev;
+  uint32_t *amax_out;
+  int64_t gs4;
+  int n_rows, hq, g_parts, tab_slot, lazy_period, blk0, nblk;
+  AdamC c;
+};
+
 struct UArgs {
+  int blk0[RK_ADAM_MULTI_MAX];   // first workgroup of job k (INT_MAX past n_jobs): the kernel's job lookup
   UJob job[RK_ADAM_MULTI_MAX];
   int n_jobs;
+  UTab tab[2];
+  int n_tab;
   float *loss_part;
   int n_part;
   float denom;
@@ -289,6 +317,10 @@ struct UArgs {
   // group's other launches may still be reading `cur`) <- this one advanced by `advance`
   int64_t *cursor_next;
   int advance;
+  // lazy jobs without a cursor (rk_adam_lazy_flush): the step the rows are brought up to (exclusive) and the
+  // epoch's first step; flush_only: no step of its own is applied
+  int64_t host_T, host_base;
+  int flush_only;
 };
 
 template <typename T> struct VecOps;
@@ -352,8 +384,11 @@ __device__ __forceinline__ void update_job(const UJob &J, int lb, const AdamC &C
   if (J.sparse) {
     const int n = *J.n_dev;
     const int64_t tot = (int64_t)n * hq;
+    const bool idx32 = tot < ((int64_t)1 << 31);
     for (int64_t i = (int64_t)lb * 256 + threadIdx.x; i < tot; i += step) {
-      const int r = (int)(i / hq), q = (int)(i % hq);
+      int r, q;
+      if (idx32) { r = (int)((uint32_t)i / (uint32_t)hq); q = (int)((uint32_t)i - (uint32_t)r * (uint32_t)hq); }
+      else { r = (int)(i / hq); q = (int)(i % hq); }
       const int64_t o = (int64_t)J.rows[r] * hq + q;
       T g = *reinterpret_cast<const T *>(J.g + i * V::W);
       for (int t = 1; t < g_parts; ++t)
@@ -369,12 +404,16 @@ __device__ __forceinline__ void update_job(const UJob &J, int lb, const AdamC &C
   const int rows_live = J.row0 < J.n_rows ? (J.n_rows - J.row0 + J.row_step - 1) / J.row_step : 0;
   const int64_t tot = (int64_t)rows_live * hq;
   const bool by_row = J.pos != nullptr || J.row_step != 1 || J.row0 != 0;
+  const bool idx32 = tot < ((int64_t)1 << 31);       // (a 64-bit division per element costs as much as the update itself)
   for (int64_t i = (int64_t)lb * 256 + threadIdx.x; i < tot; i += step) {
     int64_t e = i;                      // element (in units of T) of the parameter
     int64_t go = i * V::W;              // gradient offset (floats)
     bool have = true;
     if (by_row) {
-      const int row = J.row0 + (int)(i / hq) * J.row_step, q = (int)(i % hq);
+      int r0, q;
+      if (idx32) { r0 = (int)((uint32_t)i / (uint32_t)hq); q = (int)((uint32_t)i - (uint32_t)r0 * (uint32_t)hq); }
+      else { r0 = (int)(i / hq); q = (int)(i % hq); }
+      const int row = J.row0 + r0 * J.row_step;
       e = (int64_t)row * hq + q;
       go = e * V::W;
       if (J.pos) {
@@ -387,12 +426,13 @@ __device__ __forceinline__ void update_job(const UJob &J, int lb, const AdamC &C
     if (have) {
       g = *reinterpret_cast<const T *>(J.g + go);
       int t = 1;
-      for (; t + 8 <= g_parts; t += 8) {           // partial gradients, fixed order; the
-        T v[8];                                      // loads of a group are independent
+      constexpr int U = V::W == 4 ? 4 : 8;         // (float4: the K slabs of dW, at most 4; float: 8 row-tile partials)
+      for (; t + U <= g_parts; t += U) {           // partial gradients, fixed order; the
+        T v[U];                                      // loads of a group are independent
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const T *>(J.g + (t + u) * stride + go);
+        for (int u = 0; u < U; ++u) v[u] = *reinterpret_cast<const T *>(J.g + (t + u) * stride + go);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) V::add(g, v[u]);
+        for (int u = 0; u < U; ++u) V::add(g, v[u]);
       }
       for (; t < g_parts; ++t)
         V::add(g, *reinterpret_cast<const T *>(J.g + t * stride + go));
@@ -405,6 +445,102 @@ __device__ __forceinline__ void update_job(const UJob &J, int lb, const AdamC &C
   if (J.amax_out) publish_pmax(J.amax_out, seen, pmax);
 }
 
+// Lazy dense Adam of an embedding table (include/recoder_hip.h rk_adam_job_t.lazy_stamp).  One WAVE per table
+// row (its lanes the row's float4s): the row is skipped as a whole -- three 4-byte loads -- or brought up to
+// date by replaying the steps it missed, stamp[row] .. T - 1, with g = 0 and those steps' constants from the
+// table, then step T with the gradient.  Every replayed step is the same adam1 call the dense sweep makes for a
+// row without a gradient (g = 0 + wd * p), so p / m / v come out bit for bit.  The stamp is read by all lanes
+// and written by lane 0 behind the row's last store: nobody else touches the row in this launch.
+__device__ __forceinline__ float4 tab_gradient(const UTab &J, const uint32_t go, const int g_parts) {
+  const float4 *gp = J.g + go;
+  float4 g = *gp;
+  int t = 1;
+  for (; t + 2 <= g_parts; t += 2) {            // the K slabs of dW, summed in slab order
+    const float4 v0 = gp[t * J.gs4], v1 = gp[(t + 1) * J.gs4];
+    VecOps<float4>::add(g, v0);
+    VecOps<float4>::add(g, v1);
+  }
+  for (; t < g_parts; ++t) VecOps<float4>::add(g, gp[t * J.gs4]);
+  return g;
+}
+
+__device__ __forceinline__ void table_sweep_lazy(const UTab &J, const int lb, const UArgs &a) {
+  using V = VecOps<float4>;
+  const int lane = threadIdx.x & 63;
+  const int n_waves = J.nblk * 4;
+  const uint32_t hq = J.hq;
+  const int64_t T = a.cur.cursor ? rk_cur_global(a.cur) : a.host_T;
+  const int64_t base = a.cur.cursor ? a.cur.cursor[1] : a.host_base;
+  const int end = (int)(a.flush_only ? T : T + 1);               // rows leave current up to here (exclusive)
+  const int Tl = (int)(T - base);                                 // this step's row of the constants table
+  const AdamC *tab = a.ctab + J.tab_slot;
+  const int tstride = a.tab_stride;
+  const int L = J.lazy_period;
+  const int c = (int)(T % L);
+  const int lo = (int)((int64_t)c * J.n_rows / L), hi = (int)((int64_t)(c + 1) * J.n_rows / L);
+  const int g_parts = J.gparts_dev ? min(*J.gparts_dev, J.g_parts) : J.g_parts;
+  float pmax = 0.f;
+  const uint32_t seen = J.amax_out ? *pmax_slot(J.amax_out) : 0u;
+  // (the row index is wave-uniform: through readfirstlane its pos / stamp loads and the replayed steps' constants
+  // are scalar loads, the replay loop's trip count a scalar.)  The rows in rotated order, from the round-robin
+  // chunk's first row: the long replays start with the launch
+  for (int w = __builtin_amdgcn_readfirstlane(lb * 4 + (int)(threadIdx.x >> 6)); w < J.n_rows; w += n_waves) {
+    const int row = w + lo < J.n_rows ? w + lo : w + lo - J.n_rows;
+    const int pr = a.flush_only ? -1 : J.pos[row];
+    const bool have = pr >= 0;
+    const bool need = have || J.pos_next == nullptr || J.pos_next[row] >= 0 || (row >= lo && row < hi);
+    if (!need) continue;
+    const int nx = J.stamp[row];
+    if (nx >= end) continue;                                   // (a flush of a row that is current)
+    const int lag = end - nx;                                   // steps to apply: [nx, end)
+    for (uint32_t q = lane; q < hq; q += 64) {
+      const uint32_t e = (uint32_t)row * hq + q;
+      float4 p1 = J.p[e], m1 = J.m[e], v1 = J.v[e];
+      float4 g = V::zero();
+      if (have) g = tab_gradient(J, (uint32_t)pr * hq + q, g_parts);
+      for (int k = lag - 1; k >= 0; --k) {                     // step end - 1 - k; k == 0 is step T unless flushing
+        const AdamC C = tab[(int64_t)(Tl - (a.flush_only ? 1 : 0) - k) * tstride];
+        const float4 gs = (k == 0 && have) ? g : V::zero();
+        V::adam(p1, m1, v1, gs, C);
+        pmax = fmaxf(pmax, absmax_of<float4>(p1));
+      }
+      J.p[e] = p1; J.m[e] = m1; J.v[e] = v1;
+    }
+    if (lane == 0) J.stamp[row] = end;
+  }
+  if (J.amax_out) publish_pmax(J.amax_out, seen, pmax);
+}
+
+// the plain sweep of a big table: one float4 per thread, every row
+__device__ __forceinline__ void table_sweep_dense(const UTab &J, const int lb, const UArgs &a) {
+  using V = VecOps<float4>;
+  AdamC C = J.c;
+  if (a.ctab && J.tab_slot >= 0) C = a.ctab[rk_cur_local(a.cur) * a.tab_stride + J.tab_slot];
+  const uint32_t hq = J.hq, tot = (uint32_t)J.n_rows * hq, step = (uint32_t)J.nblk * 256u;
+  const int g_parts = J.gparts_dev ? min(*J.gparts_dev, J.g_parts) : J.g_parts;
+  float pmax = 0.f;
+  const uint32_t seen = J.amax_out ? *pmax_slot(J.amax_out) : 0u;
+  for (uint32_t i = (uint32_t)lb * 256u + threadIdx.x; i < tot; i += step) {
+    const uint32_t row = i / hq, q = i - row * hq;
+    const int pr = J.pos[row];
+    float4 g = V::zero();
+    if (pr >= 0) g = tab_gradient(J, (uint32_t)pr * hq + q, g_parts);
+    float4 p1 = J.p[i], m1 = J.m[i], v1 = J.v[i];
+    V::adam(p1, m1, v1, g, C);
+    J.p[i] = p1; J.m[i] = m1; J.v[i] = v1;
+    pmax = fmaxf(pmax, absmax_of<float4>(p1));
+  }
+  if (J.amax_out) publish_pmax(J.amax_out, seen, pmax);
+}
+
+template <bool LAZY>
+__device__ __forceinline__ void table_sweep(const UTab &J, const int b, const UArgs &a) {
+  if constexpr (LAZY) {
+    if (J.stamp) { table_sweep_lazy(J, b - J.blk0, a); return; }
+  }
+  table_sweep_dense(J, b - J.blk0, a);
+}
+
 __device__ __forceinline__ void run_job(const UJob &J, int b, const UArgs &a) {
   AdamC C = J.c;
   if (a.ctab && J.tab_slot >= 0) C = a.ctab[rk_cur_local(a.cur) * a.tab_stride + J.tab_slot];
@@ -412,7 +548,9 @@ __device__ __forceinline__ void run_job(const UJob &J, int b, const UArgs &a) {
   else update_job<float>(J, b - J.blk0, C);
 }
 
-__global__ __launch_bounds__(256) void adam_multi_kernel(UArgs a) {
+// LAZY: the instantiation of launches that hold a lazy job (the dense sweeps keep their registers)
+template <bool LAZY>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void adam_multi_kernel(UArgs a) {
   int b = blockIdx.x;
   if (a.loss_part) {
     if (b != 0) {
@@ -450,17 +588,35 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(UArgs a) {
     return;
     }
   }
-  // static indices only (a dynamically indexed by-value struct would go to scratch)
-  if (a.n_jobs > 9 && b >= a.job[9].blk0) run_job(a.job[9], b, a);
-  else if (a.n_jobs > 8 && b >= a.job[8].blk0) run_job(a.job[8], b, a);
-  else if (a.n_jobs > 7 && b >= a.job[7].blk0) run_job(a.job[7], b, a);
-  else if (a.n_jobs > 6 && b >= a.job[6].blk0) run_job(a.job[6], b, a);
-  else if (a.n_jobs > 5 && b >= a.job[5].blk0) run_job(a.job[5], b, a);
-  else if (a.n_jobs > 4 && b >= a.job[4].blk0) run_job(a.job[4], b, a);
-  else if (a.n_jobs > 3 && b >= a.job[3].blk0) run_job(a.job[3], b, a);
-  else if (a.n_jobs > 2 && b >= a.job[2].blk0) run_job(a.job[2], b, a);
-  else if (a.n_jobs > 1 && b >= a.job[1].blk0) run_job(a.job[1], b, a);
-  else run_job(a.job[0], b, a);
+  // the big table sweeps: the last workgroups of the grid
+  if (a.n_tab > 0 && b >= a.tab[0].blk0) {
+    if (a.n_tab > 1 && b >= a.tab[1].blk0) table_sweep<LAZY>(a.tab[1], b, a);
+    else table_sweep<LAZY>(a.tab[0], b, a);
+    return;
+  }
+  // The workgroup's job: the first blocks of the jobs sit side by side in the argument (ONE scalar load; slots past
+  // n_jobs hold INT_MAX), the job record is then COPIED out under a static index (a dynamically indexed by-value
+  // struct would go to scratch) and ONE copy of the update code runs on it.  Round 6: ten inlined copies of the
+  // update code behind a chain of ten dependent scalar loads cost every (short-lived: one element per thread) wave
+  // 28 scalar memory instructions and ~190 scalar ALU instructions before its first vector load -- 6.5 x the
+  // probe kernel's (tools/probes/lazy_adam_probe.hip), and the sweep ran at 5.5 TB/s where that kernel reads 7.
+  int j = 0;
+#pragma unroll
+  for (int k = 1; k < RK_ADAM_MULTI_MAX; ++k) j += b >= a.blk0[k] ? 1 : 0;
+  UJob J;
+  switch (j) {
+    case 9: J = a.job[9]; break;
+    case 8: J = a.job[8]; break;
+    case 7: J = a.job[7]; break;
+    case 6: J = a.job[6]; break;
+    case 5: J = a.job[5]; break;
+    case 4: J = a.job[4]; break;
+    case 3: J = a.job[3]; break;
+    case 2: J = a.job[2]; break;
+    case 1: J = a.job[1]; break;
+    default: J = a.job[0]; break;
+  }
+  run_job(J, b, a);
 }
 
 AdamC make_consts(double lr, double b1, double b2, double eps, double wd, int step) {
@@ -472,7 +628,7 @@ AdamC make_consts(double lr, double b1, double b2, double eps, double wd, int st
   c.wd = (float)wd;
   const double bc1 = 1.0 - pow(b1, (double)step);
   const double bc2 = 1.0 - pow(b2, (double)step);
-  c.bc2_sqrt = (float)sqrt(bc2);
+  c.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
   c.neg_step = (float)(-(lr / bc1));
   c.neg_step_sp = (float)(-(lr * sqrt(bc2) / bc1));
   return c;
@@ -556,9 +712,9 @@ int rk_adam_multi_at(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part
   RK_REQUIRE((loss_part == nullptr) == (loss_out == nullptr), "loss_part and loss_out go together");
   UArgs a = {};
   int blocks = 0;
+  int big[2] = {-1, -1};
   for (int j = 0; j < n_jobs; ++j) {
     const rk_adam_job_t &s = jobs[j];
-    UJob &d = a.job[a.n_jobs];
     RK_REQUIRE(s.par.step >= 1, "step must be >= 1");
     RK_REQUIRE(s.h >= 1 && s.n_rows >= 0, "bad job shape");
     RK_REQUIRE(!(s.par.sparse && (s.rows == nullptr || s.n_dev == nullptr)),
@@ -575,13 +731,39 @@ int rk_adam_multi_at(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part
     const int64_t rows = s.par.sparse ? s.n_cap
                                       : (s.row0 < s.n_rows ? (s.n_rows - s.row0 + row_step - 1) / row_step : 0);
     if (rows == 0) continue;
+    const int slot = (table && tab_slots) ? tab_slots[j] : -1;
+    // a BIG table sweep (UTab): dense Adam through pos over every row of a float4 table whose element and
+    // gradient indices fit 32 bits -- at most two per launch, behind the other jobs
+    const bool table_job = !s.par.sparse && s.pos != nullptr && vec && row_step == 1 && s.row0 == 0 &&
+                           s.gstride_dev == nullptr && ((int64_t)s.n_rows * s.h >= 65536 || s.lazy_stamp != nullptr) &&
+                           (int64_t)s.n_rows * s.h < ((int64_t)1 << 32) && a.n_tab < 2;
+    if (s.lazy_stamp) {
+      RK_REQUIRE(table_job && s.lazy_period >= 1,
+                 "lazy jobs: dense Adam through pos on a [n_rows, h % 4 == 0] table, all rows, lazy_period >= 1, at most "
+                 "two per launch");
+      RK_REQUIRE(cursor != nullptr && table != nullptr && slot >= 0,
+                 "lazy jobs take their constants from the replay table (cursor + table + slot)");
+    }
+    if (table_job) {
+      UTab &t = a.tab[a.n_tab];
+      t.p = reinterpret_cast<float4 *>(s.par.p); t.m = reinterpret_cast<float4 *>(s.par.m);
+      t.v = reinterpret_cast<float4 *>(s.par.v); t.g = reinterpret_cast<const float4 *>(s.g);
+      t.pos = s.pos; t.pos_next = s.lazy_pos_next; t.stamp = s.lazy_stamp; t.lazy_period = s.lazy_stamp ? s.lazy_period : 0;
+      t.gparts_dev = s.gparts_dev; t.amax_out = reinterpret_cast<uint32_t *>(s.amax_out);
+      t.gs4 = s.g_stride / 4; t.n_rows = s.n_rows; t.hq = s.h / 4; t.g_parts = s.g_parts; t.tab_slot = slot;
+      t.c = make_consts(s.par.lr, s.par.beta1, s.par.beta2, s.par.eps, s.par.weight_decay, s.par.step);
+      t.nblk = grid_for((int64_t)s.n_rows * s.h / 4);
+      big[a.n_tab++] = j;
+      continue;
+    }
+    UJob &d = a.job[a.n_jobs];
     d.p = s.par.p; d.m = s.par.m; d.v = s.par.v; d.g = s.g;
     d.pos = s.par.sparse ? nullptr : s.pos;
     d.rows = s.rows; d.n_dev = s.n_dev; d.gstride_dev = s.gstride_dev; d.gparts_dev = s.gparts_dev;
     d.n_rows = s.n_rows; d.h = s.h; d.g_parts = s.g_parts; d.g_stride = s.g_stride;
     d.sparse = s.par.sparse ? 1 : 0;
     d.row0 = s.row0; d.row_step = row_step;
-    d.tab_slot = (table && tab_slots) ? tab_slots[j] : -1;
+    d.tab_slot = slot;
     d.amax_out = reinterpret_cast<uint32_t *>(s.amax_out);
     d.c = make_consts(s.par.lr, s.par.beta1, s.par.beta2, s.par.eps,
                       s.par.sparse ? 0.0 : s.par.weight_decay, s.par.step);
@@ -590,18 +772,23 @@ int rk_adam_multi_at(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part
     blocks += d.nblk;
     ++a.n_jobs;
   }
+  for (int k = 0; k < a.n_tab; ++k) { a.tab[k].blk0 = blocks; blocks += a.tab[k].nblk; }
   if (loss_part) {
     a.loss_part = loss_part; a.n_part = n_part; a.denom = denom; a.loss_out = loss_out;
     blocks += 1;
   }
   if (blocks == 0) return 0;
-  if (a.n_jobs == 0) { a.n_jobs = 1; a.job[0].nblk = 0; a.job[0].h = 1; }   // loss only
+  if (a.n_jobs == 0) { a.n_jobs = 1; a.job[0].nblk = 0; a.job[0].h = 1; a.job[0].blk0 = 0; }   // no general job
+  for (int k = 0; k < RK_ADAM_MULTI_MAX; ++k) a.blk0[k] = k < a.n_jobs ? a.job[k].blk0 : 0x7fffffff;
   a.cur.cursor = cursor; a.cur.off = cursor_off;
   a.ctab = (const AdamC *)table; a.tab_stride = tab_stride;
   RK_REQUIRE(cursor_next == nullptr || (cursor != nullptr && loss_part != nullptr && cursor_next != cursor),
              "cursor_next needs a cursor, the loss block and a buffer of its own");
   a.cursor_next = cursor_next; a.advance = advance;
-  RK_LAUNCH(adam_multi_kernel, dim3(blocks), dim3(256), 0, stream, a);
+  bool lazy = false;
+  for (int k = 0; k < a.n_tab; ++k) lazy = lazy || a.tab[k].stamp != nullptr;
+  if (lazy) RK_LAUNCH(adam_multi_kernel<true>, dim3(blocks), dim3(256), 0, stream, a);
+  else RK_LAUNCH(adam_multi_kernel<false>, dim3(blocks), dim3(256), 0, stream, a);
   RK_CHECK_LAUNCH("adam_multi");
   return 0;
 }
@@ -627,6 +814,44 @@ extern "C" int rk_adam_multi(const rk_adam_job_t *jobs, int32_t n_jobs, float *l
   }
   return rk_adam_multi_at(jobs, n_jobs, loss_part, n_part, denom, loss_out, nullptr, 0, nullptr, 0,
                           nullptr, nullptr, 0, stream_);
+}
+
+extern "C" int rk_adam_lazy_flush(const rk_adam_job_t *jobs, int32_t n_jobs, const void *table, int32_t tab_stride,
+                                  const int32_t *tab_slots, int64_t next_step, int64_t epoch_base, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(n_jobs >= 0 && n_jobs <= RK_ADAM_MULTI_MAX, "too many jobs for one launch");
+  RK_REQUIRE(n_jobs == 0 || (jobs != nullptr && table != nullptr && tab_slots != nullptr), "null jobs / table / slots");
+  RK_REQUIRE(next_step >= epoch_base, "next_step >= epoch_base");
+  for (int j0 = 0; j0 < n_jobs; j0 += 2) {              // two tables per launch
+    UArgs a = {};
+    int blocks = 0;
+    for (int j = j0; j < n_jobs && j < j0 + 2; ++j) {
+      const rk_adam_job_t &s = jobs[j];
+      RK_REQUIRE(s.lazy_stamp != nullptr && s.h >= 4 && s.h % 4 == 0 && s.n_rows >= 0 && tab_slots[j] >= 0 &&
+                 (int64_t)s.n_rows * s.h < ((int64_t)1 << 32),
+                 "flush jobs: lazy_stamp, h % 4 == 0, a table slot");
+      RK_REQUIRE((((uintptr_t)s.par.p | (uintptr_t)s.par.m | (uintptr_t)s.par.v) & 15) == 0, "16-byte aligned tables");
+      if (s.n_rows == 0) continue;
+      UTab &t = a.tab[a.n_tab++];
+      t.p = reinterpret_cast<float4 *>(s.par.p); t.m = reinterpret_cast<float4 *>(s.par.m);
+      t.v = reinterpret_cast<float4 *>(s.par.v);
+      t.n_rows = s.n_rows; t.hq = s.h / 4; t.g_parts = 1;
+      t.tab_slot = tab_slots[j];
+      t.amax_out = reinterpret_cast<uint32_t *>(s.amax_out);
+      t.stamp = s.lazy_stamp; t.lazy_period = 1;
+      t.blk0 = blocks;
+      t.nblk = grid_for((int64_t)s.n_rows * s.h / 4);
+      blocks += t.nblk;
+    }
+    if (blocks == 0) continue;
+    a.n_jobs = 1; a.job[0].nblk = 0; a.job[0].h = 1;
+    for (int k = 0; k < RK_ADAM_MULTI_MAX; ++k) a.blk0[k] = k < a.n_jobs ? 0 : 0x7fffffff;
+    a.ctab = (const AdamC *)table; a.tab_stride = tab_stride;
+    a.host_T = next_step; a.host_base = epoch_base; a.flush_only = 1;
+    RK_LAUNCH(adam_multi_kernel<true>, dim3(blocks), dim3(256), 0, stream, a);
+    RK_CHECK_LAUNCH("adam_lazy_flush");
+  }
+  return 0;
 }
 
 // one entry of the per-step constants table (8 floats): exactly what rk_adam_multi derives from
@@ -689,6 +914,40 @@ extern "C" int rk_rows_to_dense(const float *G, const int32_t *pos, int32_t n_it
   RK_LAUNCH(rows_to_dense_kernel, dim3(grid_for((int64_t)rows_pad * (h / 4))), dim3(256), 0, stream,
             reinterpret_cast<const float4 *>(G), pos, n_items, rows_pad, h / 4, reinterpret_cast<float4 *>(D));
   RK_CHECK_LAUNCH("rows_to_dense");
+  return 0;
+}
+
+namespace {
+struct ZeroTails { float *x[4]; int h[4]; int n; };
+__global__ __launch_bounds__(256) void zero_tail_rows_kernel(ZeroTails z, const int32_t *counts, int n_cap) {
+  const int n_b = min(max(counts[0], 0), n_cap);
+  for (int k = 0; k < z.n; ++k) {
+    float *x = k == 0 ? z.x[0] : k == 1 ? z.x[1] : k == 2 ? z.x[2] : z.x[3];
+    const int h = k == 0 ? z.h[0] : k == 1 ? z.h[1] : k == 2 ? z.h[2] : z.h[3];
+    const int64_t lo = (int64_t)n_b * h, hi = (int64_t)n_cap * h;
+    for (int64_t i = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (int64_t)gridDim.x * 256) x[i] = 0.f;
+  }
+}
+}  // namespace
+
+// X_k[n_b * h_k .. n_cap * h_k) <- 0 for up to four [n_cap, h_k] arrays, n_b = counts[0] read on the device: the
+// rows of the compact gradient arrays past the block's live items.  A REPLAYED data-parallel step exchanges the
+// blocks' whole capacity (a captured collective has a fixed size) and sums in place: rows nobody rewrites would be
+// multiplied by the world size every step.
+extern "C" int rk_zero_tail_rows(float *const *X, const int32_t *h, int32_t n_arrays, const int32_t *counts,
+                                 int32_t n_cap, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  RK_REQUIRE(n_arrays >= 0 && n_arrays <= 4 && (n_arrays == 0 || (X && h && counts)), "at most four arrays");
+  if (n_arrays == 0 || n_cap == 0) return 0;
+  ZeroTails z = {};
+  int hmax = 1;
+  for (int k = 0; k < n_arrays; ++k) {
+    RK_REQUIRE(X[k] != nullptr && h[k] >= 1, "null array / bad width");
+    z.x[k] = X[k]; z.h[k] = h[k]; hmax = h[k] > hmax ? h[k] : hmax;
+  }
+  z.n = n_arrays;
+  RK_LAUNCH(zero_tail_rows_kernel, dim3(grid_for((int64_t)n_cap * hmax / 8)), dim3(256), 0, stream, z, counts, n_cap);
+  RK_CHECK_LAUNCH("zero_tail_rows");
   return 0;
 }
 

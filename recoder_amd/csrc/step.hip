@@ -645,6 +645,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
       }
       slots[n] = RK_PAR_W_DE;
       if (de_side) {
+        RK_REQUIRE(a->lazy_stamp_en == nullptr, "rk_adam_de_side and lazy Adam do not combine");
         const int32_t sl = RK_PAR_W_DE;
         {
           Timer t(a, RK_ENTRY_ADAM_DE, a->dw_stream);
@@ -669,6 +670,18 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
         jobs[k].pos = nullptr; jobs[k].g_parts = 1; jobs[k].gparts_dev = nullptr;
         jobs[k].g = shard - (int64_t)a->zero_lo * h;
         jobs[k].row0 = a->zero_lo; jobs[k].row_step = 1; jobs[k].n_rows = a->zero_hi;
+      }
+    }
+    // lazy dense Adam of the embedding tables (rk_adam_job_t.lazy_stamp): rows without a gradient that the next
+    // step does not read are caught up later
+    if (a->lazy_stamp_en) {
+      RK_REQUIRE(whole && a->cursor != nullptr && a->zero_hi == 0 && a->lazy_period >= 1 && (a->tied || a->lazy_stamp_de),
+                 "lazy Adam: whole replayed steps, both stamp arrays, lazy_period >= 1");
+      for (int k = 0; k < n; ++k) {
+        if (jobs[k].par.sparse) continue;
+        jobs[k].lazy_stamp = slots[k] == RK_PAR_W_DE ? a->lazy_stamp_de : a->lazy_stamp_en;
+        jobs[k].lazy_pos_next = a->lazy_pos_next;
+        jobs[k].lazy_period = a->lazy_period;
       }
     }
     slots[n] = RK_PAR_B_DE;

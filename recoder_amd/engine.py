@@ -120,6 +120,10 @@ class FusedEngine:
     # [0..63] max |Z| (filled per call when the activation is unbounded), [64..127] an upper bound
     # of |decoder table| (its maximum now; the Adam sweep keeps it running from there)
     self.ranges = torch.zeros(128, dtype=torch.int32, device=self.device)
+    # lazy dense Adam of the embedding tables (include/recoder_hip.h rk_adam_job_t.lazy_stamp): the round-robin
+    # period that bounds a row's lag; RK_ADAM_LAZY=0 switches it off (every row swept every step)
+    self.lazy_period = max(0, int(os.environ.get("RK_ADAM_LAZY", "16")))
+    self._lazy_stamps = {}
     self.act_bounded = model.activation_type in ("tanh", "sigmoid")
     self._w_range_stale = True
     self._w_range_key = None
@@ -270,6 +274,52 @@ class FusedEngine:
     b1, b2 = g["betas"]
     return float(g["lr"]), float(b1), float(b2), float(g["eps"])
 
+  # ---- lazy dense Adam (graph.GraphStepper drives it: it knows the NEXT step's block) ----
+  def lazy_tables(self):
+    """Names of the dense-Adam embedding tables whose sweeps can skip rows (DynamicAutoencoder, single process):
+    optim.Adam on a dense embedding gradient (model.py:135,398-399) touches every row every step; rows outside
+    the step's item set that the next step does not read are caught up later by replaying their missed
+    steps bit for bit (csrc/optim.hip update_job_lazy)."""
+    if (self.lazy_period < 1 or self.kind != "ae" or self.allreduce is not None or self.item_parallel is not None or
+        self.h[0] % 4 != 0 or bool(_lib.load().rk_adam_de_side())):
+      return []
+    names = ["en_embedding_layer.weight"] + ([] if self.model.is_constrained else ["de_embedding_layer.weight"])
+    if not all(n in self.states and not self.states[n].sparse for n in names):
+      return []
+    return names
+
+  def lazy_stamp(self, name):
+    """[n_rows] int32: global index of the first step not yet applied to a row of table `name`."""
+    t = self._lazy_stamps.get(name)
+    n = self.states[name].p.shape[0]
+    if t is None or t.numel() != n:
+      t = torch.zeros(n, dtype=torch.int32, device=self.device)
+      self._lazy_stamps[name] = t
+    return t
+
+  def lazy_mark_current(self, names, step):
+    """Every row of the tables is up to date in front of global step `step` (the dense sweeps ran)."""
+    for n in names:
+      self.lazy_stamp(n).fill_(int(step))
+
+  def lazy_flush(self, names, slots, table, tab_stride, next_step, epoch_base, stream):
+    """Replay every row's missed steps up to (excluding) global step `next_step`: rk_adam_lazy_flush."""
+    from ._lib import RkAdamJob
+    arr = (RkAdamJob * len(names))()
+    sl = (ctypes.c_int32 * len(names))()
+    W_dec = self._decoder_params()[0]
+    for i, n in enumerate(names):
+      st = self.states[n]
+      a = arr[i].par
+      a.p, a.m, a.v = ptr(st.p), ptr(st.m), ptr(st.v)
+      arr[i].n_rows, arr[i].h = st.p.shape[0], st.p.shape[1]
+      arr[i].lazy_stamp, arr[i].lazy_period = ptr(self.lazy_stamp(n)), 1
+      if st.p is W_dec:
+        arr[i].amax_out = self.ranges.data_ptr() + 64 * 4
+      sl[i] = slots[n]
+    check(self.lib.rk_adam_lazy_flush(arr, len(names), table, tab_stride, sl, int(next_step), int(epoch_base), stream),
+          "rk_adam_lazy_flush")
+
   # The updates of one step are collected as rk_adam_job_t records and issued through
   # rk_adam_multi, six per launch (the same per-element arithmetic as rk_adam_table / rk_adam_rows /
   # rk_adam_dense; a hidden-stack model has ~11 parameter tensors, i.e. ~11 launches and FFI calls
@@ -295,6 +345,9 @@ class FusedEngine:
       j.g, j.g_parts, j.g_stride, j.gstride_dev, j.gparts_dev = parts
     if s.p is self._decoder_params()[0]:       # the table the decoder GEMMs read: keep its bound
       j.amax_out = self.ranges.data_ptr() + 64 * 4
+    lz = rp.get("lazy") if rp is not None else None
+    if lz is not None and pos is not None and rows is None and s.name in lz["names"]:
+      j.lazy_stamp, j.lazy_pos_next, j.lazy_period = ptr(self.lazy_stamp(s.name)), lz["pos_next"], self.lazy_period
     self._jobs.append(j)
 
   def _flush_jobs(self, stream):
@@ -916,6 +969,9 @@ class FusedEngine:
     if self.allreduce is not None:
       # data parallel over users: every gradient of the step (live rows of both tables, gathered
       # bias, dense layers, loss) is SUM all-reduced as one in-order RCCL group on this stream
+      if dp_replay:
+        tails = [(self.G_de, h0), (self.gb_de, 1)] + ([(self.G_en, h0)] if self.kind == "ae" and not tied else [])
+        self._zero_grad_tails(tb, tails, stream)
       if getattr(self, "owned_rows", False):
         self._owned_exchange(blk, n_b_host)
       else:
@@ -1095,6 +1151,15 @@ class FusedEngine:
     st.ws_dw = st.dw_stream = st.dw_fork = st.dw_join = None
     st.zero_lo = st.zero_hi = 0
     st.zero_g_en = st.zero_g_de = st.zero_gb_de = None
+    st.lazy_stamp_en = st.lazy_stamp_de = st.lazy_pos_next = None
+    st.lazy_period = 0
+    lz = replay.get("lazy") if replay is not None else None
+    if lz is not None and dp is None and self.item_parallel is None:
+      # (the stepper knows the next step's block: rows without a gradient that it does not read are caught up later)
+      st.lazy_stamp_en = ptr(self.lazy_stamp("en_embedding_layer.weight"))
+      if not m.is_constrained:
+        st.lazy_stamp_de = ptr(self.lazy_stamp("de_embedding_layer.weight"))
+      st.lazy_pos_next, st.lazy_period = lz["pos_next"], self.lazy_period
     if dp is not None and self.ws_dw is not None and not m.is_constrained:
       st.ws_dw = ptr(self.ws_dw)        # (phased steps: dW's own workspace lets the decode launch keep its dZ slabs)
     self._ws_dw_live = False
@@ -1177,6 +1242,9 @@ class FusedEngine:
       # the blocks' whole capacity (rows past n_b are never read by the update) instead of the live
       # rows, and nothing of the step is read on the host
       n_b = dp.n_b(blk) if replay is None else blk.n_cap
+      if replay is not None:
+        self._zero_grad_tails(blk, [(self.G_de, self.h[0]), (self.G_en, self.h[0]), (self.gb_de, 1)],
+                              ctypes.c_void_p(main_s.cuda_stream))
       # (the gradient rows that travel: the live count rounded up to a granule the reduce-scatter can
       # shard -- rows past n_b are zeros or stale rows nobody reads)
       n_x = dp.round_rows(n_b, blk.n_cap) if hasattr(dp, "round_rows") else n_b
@@ -1257,6 +1325,15 @@ class FusedEngine:
         dp.zero_publish([S[n_].p.data for n_ in names_], h0, extra_max=self.ranges[64:])
     self._loss_target = out
     return out
+
+  def _zero_grad_tails(self, blk, arrays, stream):
+    """Rows [n_b, n_cap) of the compact gradient arrays <- 0 (rk_zero_tail_rows): in front of a replayed
+    data-parallel exchange over the block's capacity, whose in-place sum would otherwise multiply whatever those
+    rows hold by the world size step after step.  arrays: [(tensor, width)]."""
+    n = len(arrays)
+    X = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in arrays])
+    H = (ctypes.c_int32 * n)(*[int(w) for _, w in arrays])
+    check(self.lib.rk_zero_tail_rows(X, H, n, ptr(blk.counts), blk.n_cap, stream), "rk_zero_tail_rows")
 
   def _dense_grad_buffers(self, n_items, h0):
     """(per-rank item sets without sharding) the two tables' gradients laid out by item id, all-reduced in place"""

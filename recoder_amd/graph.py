@@ -17,7 +17,6 @@ per-step loss.  The captured kernels are the same C-ABI entry points the eager p
 the ragged last batch, groups bench.py brackets with timing events) run eagerly through them.
 """
 import ctypes
-import os
 
 import numpy as np
 import torch
@@ -81,11 +80,17 @@ class GraphStepper:
     self._la_slot = 1                      # slot holding the newest look-ahead blocks
     self.exec_first = [None, None]         # the group right behind a cut: its collation + its steps, per slot
     self.exec_tail = [{}, {}]              # per slot: {n: the last n < G steps in front of a cut, no look-ahead}
-    self.capture_tails = os.environ.get("RK_BENCH_NO_TAILS") != "1"    # (tools/probes/ab_s20.sh: the A/B of this)
+    self.capture_tails = True              # (bench.py --no-tails / tools/probes/ab_s20.sh: the A/B of this)
     self.exec_timed = {}                   # (slot, first global index) -> a group captured WITH timing events
     self.warmed = False
     self.global_step = 0                   # steps this stepper's cursor has seen
     self.epoch_base = 0
+    # lazy dense Adam (engine.lazy_tables): a step's sweep skips the rows that neither carry a gradient nor are
+    # read by the NEXT step -- whose block this stepper has collated by then; run() leaves every row up to date
+    self.lazy = list(engine.lazy_tables()) if (self.dp is None and self.G >= 2) else []
+    self.ev_join_early = self.lib.rk_event_create(0)
+    self._stamps_at = None                 # global step at which every stamp says "up to date"
+    self.lazy_flushes = 0
 
   def _drop_graphs(self):
     for e in self.exec:
@@ -104,7 +109,7 @@ class GraphStepper:
 
   def close(self):
     self._drop_graphs()
-    for e in [self.ev_fork, self.ev_join] + self.ev_pre:
+    for e in [self.ev_fork, self.ev_join, self.ev_join_early] + self.ev_pre:
       self.lib.rk_event_destroy(e)
 
   # ----------------------------------------------------------------- pieces
@@ -146,13 +151,16 @@ class GraphStepper:
       self.dp.union_marks_many([blk.mark for blk in blks])
     check(self.lib.rk_collate_at_multi(*args, 2, self._h(stream)), "rk_collate_at_multi")
 
-  def _step(self, slot, g, index=None, advance=None):
+  def _step(self, slot, g, index=None, advance=None, next_blk=None):
     """Enqueue the training step of block [slot][g] (cursor offset g) on the main stream; index
     != None: an eager step that bench.py's time plan may bracket; advance: the group's last step
-    publishes the other slot's cursor."""
+    publishes the other slot's cursor; next_blk: the block of the step that follows (lazy Adam; None:
+    this step's sweep leaves every row up to date)."""
     replay = dict(st=self.st[slot][g], cursor=self._cur(slot), off=g, table=ptr(self.table),
                   users=ptr(self.order_global), timed=index is not None, index=index, dw_stream=self.side,
                   next=None if advance is None else (self._cur(1 - slot), advance))
+    if self.lazy:
+      replay["lazy"] = dict(names=self.lazy, pos_next=None if next_blk is None else ptr(next_blk.pos))
     if self.c_step:
       self.eng._c_train_step(self.blocks[slot][g], 0, self.B, None, self.loss_buf,
                              None if self.dp is None else self.B * self.dp.world, self.main, replay=replay)
@@ -182,8 +190,17 @@ class GraphStepper:
     multi = G <= self.MULTI_MAX and self.multi
     for g in range(max(n_steps, G)):
       if g < n_steps:
+        nxt = None
+        if self.lazy and g + 1 < n_steps:
+          nxt = self.blocks[slot][g + 1]
+        elif self.lazy and lookahead and g > 0:
+          # the group's last step: its Adam sweep reads the item map of the NEXT group's first block, collated on
+          # the side stream since step 0 -- joined here instead of behind the step (long done by now)
+          check(lib.rk_event_record(self.ev_join_early, self._h(self.side)), "rk_event_record")
+          check(lib.rk_stream_wait_event(self._h(self.main), self.ev_join_early), "rk_stream_wait_event")
+          nxt = self.blocks[1 - slot][0]
         self._step(slot, g, None if first_index is None else first_index + g,
-                   advance=n_steps if g == n_steps - 1 else None)
+                   advance=n_steps if g == n_steps - 1 else None, next_blk=nxt)
       if lookahead and multi:
         # the G look-ahead blocks in ONE set of launches, behind the dW kernel of step 0 (which the
         # Adam sweep of step 0 waits for; nothing needs the blocks before the end of the group)
@@ -276,6 +293,10 @@ class GraphStepper:
       torch.cuda.current_stream().synchronize()
       self._drop_graphs()
       self.recaptures += 1
+    if self.lazy and self._stamps_at != self.global_step:
+      # (first run, or steps ran outside this stepper -- the ragged batch of an epoch -- since the last one)
+      self.eng.lazy_mark_current(self.lazy, self.global_step)
+      self._stamps_at = self.global_step
     need_pre = self._collated is None
     if need_pre:
       # nothing of the first group is in flight yet: its blocks are collated in front of its steps
@@ -331,11 +352,24 @@ class GraphStepper:
             self._pre_collate(left, slot)
           self._group(slot, left, first_index=idx0, lookahead=False)   # tail: fewer than G steps, eager
           self._warm_capture()
+          if self._tails_ok() and not eager:
+            self._capture_tail(slot, left)     # (the next tail of this length on this slot replays)
         k = left
       need_pre = False
       self._advance_host(k)
       done += k
       slot = 1 - slot
+    if self.lazy:
+      # a last group WITH look-ahead left the rows stale that its look-ahead block does not read: whatever follows
+      # run() (a mark, validation, a checkpoint, the ragged batch, the next epoch's constants table) sees the
+      # tables the dense sweeps would have left.  (Without look-ahead the last step's own sweep did this.)
+      if la:
+        slots = ({"en_embedding_layer.weight": PAR_W_EN, "de_embedding_layer.weight": PAR_W_DE} if self.c_step
+                 else self.slots)
+        self.eng.lazy_flush(self.lazy, slots, ptr(self.table), self.tab_stride, self.global_step, self.epoch_base,
+                            self._h(self.main))
+        self.lazy_flushes += 1
+      self._stamps_at = self.global_step
     # the look-ahead blocks of the next group -- if the last group collated them (an eagerly
     # enqueued last group does not: every caller cuts behind run(), see model._run_epoch_graph)
     self._collated = slot if la else None
@@ -372,14 +406,28 @@ class GraphStepper:
     for v in (0, 1):
       if self.exec_first[v] is None:
         self.exec_first[v] = self._capture(lambda v=v: (self._pre_collate(G, v), self._group(v)))
-    # the tails: n < G steps in front of a cut or the epoch's end, without a look-ahead collation.  Enqueued launch
-    # by launch such a step costs the GPU ~17 us more than replayed (the driver's 20-step run = 8 + 8 + 4 steps:
-    # 0.1177 -> see DESIGN.md section 5); one-call step, single process only
-    if self.c_step and self.dp is None and self.capture_tails:
-      for v in (0, 1):
-        for n in range(1, G):
-          if n not in self.exec_tail[v]:
-            self.exec_tail[v][n] = self._capture(lambda v=v, n=n: self._group(v, n, lookahead=False))
+
+  # the tails: n < G steps in front of a cut or the epoch's end, without a look-ahead collation.  Enqueued launch
+  # by launch such a step costs the GPU ~17 us more than replayed (the driver's 20-step run = 8 + 8 + 4 steps:
+  # DESIGN.md section 5); one-call step, single process only.  Captured on demand (all 2 (G - 1) of
+  # them at warm-up were ~56 step captures that every re-allocation of the engine's workspaces threw away, and an
+  # epoch uses one length): the first tail of a length runs launch by launch and is captured behind it;
+  # prepare_tails captures the lengths a caller knows it will need (bench.py, in front of its clock)
+  def _tails_ok(self):
+    return self.warmed and self.c_step and self.dp is None and self.capture_tails
+
+  def _capture_tail(self, slot, n):
+    if n not in self.exec_tail[slot]:
+      self.exec_tail[slot][n] = self._capture(lambda: self._group(slot, n, lookahead=False))
+
+  def prepare_tails(self, lengths):
+    if not self._tails_ok():
+      return False
+    for v in (0, 1):
+      for n in lengths:
+        if 0 < int(n) < self.G:
+          self._capture_tail(v, int(n))
+    return True
 
   def cut(self):
     """Forget the look-ahead blocks (a step mark / an eager ragged step follows).  The cursor of the

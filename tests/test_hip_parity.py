@@ -853,19 +853,27 @@ def test_recoder_data_parallel_one_rank_equals_single_process(monkeypatch, kind)
     assert frac < 2e-3, (k, frac, mx, scale)
 
 
-def test_data_parallel_graph_replay_is_bitwise_equal_to_host_sequencing(monkeypatch):
+@pytest.mark.parametrize("case_name", ["ae200_mse", "mf128_mse_sparse", "mf64_bce_dense_drop", "stack_mse", "stack_logloss"])
+def test_data_parallel_graph_replay_is_bitwise_equal_to_host_sequencing(case_name, monkeypatch):
   """Users-DP under one RCCL rank: the phased step replayed as HIP graphs (collectives inside, exchange
   over the blocks' capacity) against the same step sequenced from the host (exchange over the live
-  rows): same losses, same parameters, to the bit."""
+  rows): same losses, same parameters, to the bit.  The one-call autoencoder step and the
+  entry-by-entry engines -- MatrixFactorization, hidden stacks -- whose replay captures train_step with its
+  collectives, capacity-sized gradient views and the loss_dp -> loss-slot publish."""
   import torch.distributed as dist
   from recoder_amd.data import RecommendationDataset
   from recoder_amd.model import Recoder
   csr = synth_csr(1300, 2500, 25, seed=19)
-  c = STEP_CASES[0][1]
+  extra = {"stack_mse": dict(kind="ae", hidden_layers=[64, 32], activation_type="tanh", noise_prob=0.3, sparse=False,
+                             loss="mse"),
+           "stack_logloss": dict(kind="ae", hidden_layers=[48, 24], activation_type="tanh", noise_prob=0.0,
+                                 dropout_prob=0.2, sparse=False, loss="logloss")}
+  c = extra.get(case_name) or next(cfg for name, cfg, *_ in STEP_CASES if name == case_name)
   monkeypatch.setenv("RK_PARALLEL", "users")
   monkeypatch.setenv("RK_FORCE_DP", "1")
   monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
-  monkeypatch.setenv("MASTER_PORT", "29643")
+  monkeypatch.setenv("MASTER_PORT", str(29643 + ["ae200_mse", "mf128_mse_sparse", "mf64_bce_dense_drop", "stack_mse",
+                                                 "stack_logloss"].index(case_name)))
   dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
   try:
     out = {}
@@ -873,12 +881,14 @@ def test_data_parallel_graph_replay_is_bitwise_equal_to_host_sequencing(monkeypa
       monkeypatch.setenv("RK_GRAPH", mode)
       torch.manual_seed(13)
       model = make_model(c)
-      rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss="mse")
+      rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss=c["loss"])
       rec.user_order_hook = lambda epoch, n: np.random.RandomState(epoch).permutation(n)
       rec.train(RecommendationDataset(csr), batch_size=250, lr=1e-3, weight_decay=2e-5, num_epochs=2,
                 negative_sampling=True)
       gs = getattr(rec, "_graph_stepper", None)
       assert (gs is not None and gs.dp is rec._dp and gs.warmed) == (mode == "1")
+      if mode == "1":
+        assert gs.c_step == (case_name == "ae200_mse")
       out[mode] = (np.concatenate(rec.loss_history), {k: v.detach().cpu().clone() for k, v in model.named_parameters()})
   finally:
     dist.destroy_process_group()
