@@ -256,11 +256,16 @@ def cpu_baseline(cfg, csr, steps, warmup=4):
   max_seconds = ARGS.cpu_seconds
   B = cfg["batch_size"]
   torch.manual_seed(0)
-  st = orc.init_ae_state(csr.shape[1], cfg["hidden_layers"])
-  o = orc.OracleRecoder("ae", st, hidden_layers=cfg["hidden_layers"],
-                        activation_type=cfg["activation_type"], noise_prob=cfg["noise_prob"],
-                        sparse=cfg["sparse"], loss=cfg["loss"], lr=cfg["lr"],
-                        weight_decay=cfg["weight_decay"])
+  if cfg["kind"] == "mf":
+    st = orc.init_mf_state(csr.shape[1], csr.shape[0], cfg["embedding_size"])
+    o = orc.OracleRecoder("mf", st, activation_type=cfg["activation_type"], sparse=cfg["sparse"], loss=cfg["loss"],
+                          lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+  else:
+    st = orc.init_ae_state(csr.shape[1], cfg["hidden_layers"])
+    o = orc.OracleRecoder("ae", st, hidden_layers=cfg["hidden_layers"],
+                          activation_type=cfg["activation_type"], noise_prob=cfg["noise_prob"],
+                          sparse=cfg["sparse"], loss=cfg["loss"], lr=cfg["lr"],
+                          weight_decay=cfg["weight_decay"])
   rng = np.random.RandomState(1)
   order = rng.permutation(csr.shape[0])
   t0 = None
@@ -270,7 +275,7 @@ def cpu_baseline(cfg, csr, steps, warmup=4):
       t0 = time.perf_counter()
     users = order[(i * B) % (len(order) - B):][:B]
     b = orc.collate(orc.extract_rows(csr, users), users, B, True)[0]   # collation included
-    keep = (rng.random_sample(b.indices.shape[1]) >= cfg["noise_prob"]).astype(np.uint8)
+    keep = (rng.random_sample(b.indices.shape[1]) >= cfg.get("noise_prob", 0.0)).astype(np.uint8)
     o.train_step(b, None, keep, None)
     if i >= warmup:
       done += B
