@@ -176,7 +176,7 @@ def algorithmic_work(entry, B, h0, n_b, nnz, n_items, cfg_sparse=False):
     # (the decoder-side gradient arrives as `slabs` K slabs of the bf16-pipe dW kernel, summed here)
     tiles = -(-int(n_b) // 64) * -(-h0 // (128 if h0 <= 128 else 256))
     slabs = 1 if GEMM_F32 else max(1, min(256 // max(tiles, 1), 4, (-(-B // 64) * 64) // 64))
-    if STEP_MODE in (1, 3, 4):
+    if STEP_MODE in (1, 3):
       # csrc/pgemm.hip's dW: 64 x 128 tiles below 1024 rows (256-wide from there), split-K chosen on the device as
       # min(4, 256 / live tiles) -- C2 at B = 500: 123 x 2 tiles, ONE slab (rounds 1-4 priced the dw3.hip rule above:
       # an extra 6.3 MB slab the PMC passes never saw)
@@ -738,7 +738,7 @@ def main():
     step_mode = STEP_MODE = int(getattr(eng, "_step_mode", 0))
     if one_call:
       lk = 0 if cfg["loss"] == "mse" else 1
-      FUSED_DZ = bool(_rk_lib.load().rk_decode_dz_fused_ok(B, h0, eng.n_cap_last, lk)) or step_mode in (3, 4)
+      FUSED_DZ = bool(_rk_lib.load().rk_decode_dz_fused_ok(B, h0, eng.n_cap_last, lk)) or step_mode == 3
       FUSED_DW_ENC = bool(_rk_lib.load().rk_dw_encode_bwd_fused_ok(0, B))
       # the kernels the step DISPATCHED (rk_ae_step_uses_pg of the step that ran), named as rocprofv3
       # --kernel-trace prints them (namespaces stripped)
@@ -751,11 +751,6 @@ def main():
         KERNELS["rk_decode_bwd_dw"] = ["dw_encbwd_kernel<64, 128, 2, 2, %d, 2> (csrc/pgemm.hip: dW tiles from the dO image%s || "
                                        "encoder-backward columns)" % (hv, ", their output column h = the decoder bias gradient "
                                                                       "(ones column of the Z image)" if ones else " || its column sums")]
-      elif step_mode == 4:        # csrc/fdecode.hip streaming + csrc/pgemm.hip dW (>= 1024 rows)
-        KERNELS["rk_decode_loss"] = ["fdec_stream_kernel<%d, %d, %s>" % (kt, pg_loss, "true" if cfg["loss"] == "mse" else "false")]
-        KERNELS["rk_decode_bwd_dz"] = ["splitk_reduce_kernel"]
-        KERNELS["rk_decode_bwd_dw"] = ["pg::gemm_kernel<.., pg::EpiSlab, ..> (dW from the dO image, side stream)" if B > 2048 else
-                                       "dw_encbwd_kernel<256, ..> (csrc/pgemm.hip)"]
       elif step_mode == 1:        # csrc/pgemm.hip for all three contractions
         KERNELS["rk_decode_loss"] = ["pg::gemm_kernel<.., pg::EpiLoss<%d>, ..>" % pg_loss]
         KERNELS["rk_decode_bwd_dz"] = ["pg::gemm_kernel<.., pg::EpiSlab, ..>", "splitk_reduce_kernel"]
@@ -784,9 +779,9 @@ def main():
       slabs = -(-int(n_b) // 128) * B * h0 * 4
       if entry == "rk_ae_encode_fwd":            # gathered rows + Z + its image (+ W_de[items] read and split)
         return nnz * (h0 * 4 + 12) + B * h0 * 4 + B * img + (n_b * (h0 * 4 + img) if step_mode else 0)
-      if entry == "rk_decode_loss" and step_mode in (3, 4):
+      if entry == "rk_decode_loss" and step_mode == 3:
         return n_b * img + B * img + B * ld * 4 + slabs
-      if entry == "rk_decode_bwd_dz" and (step_mode in (3, 4) or FUSED_DZ):
+      if entry == "rk_decode_bwd_dz" and (step_mode == 3 or FUSED_DZ):
         return slabs + 2 * B * h0 * 4
       if entry == "rk_decode_bwd_dw" and step_mode == 3:
         return nnz * (h0 * 4 + 8) + n_b * h0 * 4 + B * ld * 4 + B * img + n_b * h0 * 4
@@ -926,8 +921,7 @@ def main():
                  "pretouch": ("parameters + Adam moments read %d x in front of the clock (cache + clock warm)"
                               % max(1, args.pretouch_reps)) if not args.no_pretouch else "none",
                  "step_kernels": {0: "csrc/decode16.hip + dw3.hip", 1: "csrc/pgemm.hip",
-                                  3: "csrc/fdecode.hip + pgemm.hip dW",
-                                  4: "csrc/fdecode.hip (streaming) + pgemm.hip dW"}.get(step_mode) if one_call else "per-entry sequencing",
+                                  3: "csrc/fdecode.hip + pgemm.hip dW"}.get(step_mode) if one_call else "per-entry sequencing",
                  "first_group_collation": ("in front of the clock; the look-ahead collation behind the last "
                                            "timed group runs inside it (one per group, as in steady state)")
                                           if T.get("precollated") else "inside the timed region, in front of step 0",

@@ -66,6 +66,11 @@ typedef struct rk_plan {
   int32_t dw_encode_bwd_fused_ok;  /* dW || encoder backward in one launch */
   int32_t adam_de_side;            /* the probe header's RK_TUNE_ADAM_DE_SIDE: the decoder table's Adam sweep is a
                                       launch of its own behind the dW kernel on dw_stream (off by default) */
+  int32_t encode_bwd_segments;     /* the fused fp32 dW || encoder-backward call writes G_en as this many partial
+                                      arrays of n_cap * h floats (gb_en: of h floats), summed by rk_adam_multi */
+  int32_t _pad0;
+  int64_t dw3_slabs_offset_bytes;  /* rk_decode_bwd_dw3 / dw2 with G_de == NULL leave their K slabs this far into the
+                                      workspace (behind the Z^T planes) */
   int32_t mf_fdec_ok;              /* entry-by-entry sequenced steps (MatrixFactorization: rk_fdec_loss_dz +
                                       rk_pg_dw_dz_reduce; hidden stacks / dropout with MSE / BCE: rk_fdec_loss_dz +
                                       rk_fdec_dz_reduce + rk_pg_dw_encode_bwd): the fused decode covers this shape
@@ -271,15 +276,11 @@ int rk_decode_bwd_dz(const float *dO, int32_t B, int32_t h,
 int rk_decode_bwd_dw(const float *dO, const float *Z, int32_t B, int32_t h,
                      const rk_block_t *tgt, float *G_de, float *gb_de,
                      void *stream);
-/* rk_decode_bwd_dw + rk_ae_encode_bwd(accumulate = 0) on the same block in ONE
- * launch: the MFMA-bound dW tiles and the latency-bound encoder-backward gathers
- * are independent and share the GPU (untied weights only).  For large B the dW
- * contraction is split along K into `workspace` slabs, summed in fixed order. */
-int rk_decode_bwd_dw_encode_bwd(const float *dO, const float *Z, int32_t B, int32_t h,
-                                const rk_block_t *blk, float *G_de, int32_t row_off,
-                                const float *dZ0pre, float *G_en, float *gb_en,
-                                float *workspace, void *stream);
-/* (rk_plan_t.dw_splits: the number of K slabs the call above cuts dW into for B rows, 1 = none.  With more
+/* (The fp32 tiles' dW + rk_ae_encode_bwd(accumulate = 0) on one block also exist as ONE launch -- the MFMA-bound dW
+ * tiles and the latency-bound encoder-backward gathers share the GPU -- inside rk_ae_train_step (RK_GEMM_PREC=f32,
+ * item-parallel steps); rounds 1-5 exported it as rk_decode_bwd_dw_encode_bwd.  For large B that call cuts the
+ * contraction along K into `workspace` slabs, summed in fixed order.) */
+/* (rk_plan_t.dw_splits: the number of K slabs that call cuts dW into for B rows, 1 = none.  With more
  * than one, G_de == NULL leaves them unsummed in `workspace` as arrays of n_cap*h floats -- G_de = their sum
  * in slab order: rk_adam_multi consumes them through g_parts / g_stride and the summing launch disappears.
  * rk_plan_t.dw_workspace_bytes sizes the workspace; NULL disables the split-K of large batches.) */
@@ -292,10 +293,9 @@ int rk_decode_bwd_dw_encode_bwd(const float *dO, const float *Z, int32_t B, int3
  *   workspace : rk_plan_t.dw3_workspace_bytes bytes, 256-byte aligned
  *   G_de      : nullable.  The contraction is cut along K into counts[4] slabs (chosen on the
  *               device from the live item count, <= rk_plan_t.dw3_max_splits); G_de != NULL receives
- *               their sum, G_de == NULL leaves them at rk_dw3_slabs(workspace, B, h) as arrays of
+ *               their sum, G_de == NULL leaves them at workspace + rk_plan_t.dw3_slabs_offset_bytes as arrays of
  *               n_cap*h floats for rk_adam_multi (rk_adam_job_t.gparts_dev = counts + 4).
  */
-const float *rk_dw3_slabs(const void *workspace, int32_t B, int32_t h);
 int rk_decode_bwd_dw3(const float *dO, const float *Z, int32_t B, int32_t h,
                       const rk_block_t *tgt, float *G_de, float *gb_de, void *workspace,
                       const void *zt_planes /* nullable: made from Z into workspace */,
@@ -343,11 +343,10 @@ int rk_decode_bwd_dw2_encode_bwd_colsum(const float *dO, const float *Z /* nulla
                                         const void *zt_planes, const int32_t *ranges, int32_t row_off,
                                         const float *dZ0pre, float *G_en, float *gb_en, float *gb_de,
                                         void *stream);
-/* The fused call writes G_en as rk_encode_bwd_segments(B) partial arrays of n_cap*h floats
+/* The fused call writes G_en as rk_plan_t.encode_bwd_segments partial arrays of n_cap*h floats
  * each (row segments of long item columns; 1 below 513 rows) and gb_en as as many partial
  * vectors of h floats: the gradients are their sums in segment order -- rk_adam_multi
  * consumes them through g_parts / g_stride. */
-int32_t rk_encode_bwd_segments(int32_t B);
 
 /*
  * Pre-split operand planes of the decoder contractions (csrc/planes.h, csrc/decode16.hip).
@@ -515,9 +514,7 @@ int rk_dropout(float *X, const uint8_t *keep, int64_t n, int32_t ncols, float p,
 int rk_colsum(const float *X, int32_t rows, int32_t cols, int32_t ld,
               const int32_t *counts_dev /* nullable */, float *out,
               void *stream);
-int rk_gather_rows(const float *E, const int64_t *rows, int32_t B, int32_t d,
-                   int32_t act, float *out, void *stream);
-/* the same gather (nn.py:344-362: MatrixFactorization's user rows) that also
+/* out[r, :] = act(E[rows[r], :]) (nn.py:344-362: MatrixFactorization's user rows), which also
  *   slots  (nullable): publishes max |out| in slots[0..63] the way rk_amax does (64 workgroups, one
  *                      slot each): gather + rk_amax in one launch for unbounded activations;
  *   rows32 (nullable, B + 1 ints): rows32[0] <- B, rows32[1 + r] <- rows[r] -- the index array and
@@ -533,22 +530,15 @@ int rk_gather_rows_amax(const float *E, const int64_t *rows, int32_t B, int32_t 
  * step count after increment.  Hyper-parameters are doubles because torch
  * evaluates `1 - beta`, the bias corrections and the step size in Python
  * doubles before the one conversion to fp32.
- *   rk_adam_table : full sweep of a [n_rows,h] table; row i gets gradient
- *                   G[pos[i]] if pos[i] >= 0 else 0; L2 weight decay (K14a).
  *   rk_adam_rows  : SparseAdam on the rows idx[0..n_dev) (K14b); no decay.
- *   rk_adam_dense : plain dense tensor (biases, hidden layers).
+ * (Dense Adam -- a full sweep of a [n_rows, h] table whose row i gets gradient G[pos[i]] if pos[i] >= 0 else 0 with L2
+ * weight decay, K14a, or a plain dense tensor -- is a job of rk_adam_multi below; rounds 1-5 also exported it
+ * as rk_adam_table / rk_adam_dense.)
  */
-int rk_adam_table(float *W, float *m, float *v, int32_t n_rows, int32_t h,
-                  const int32_t *pos, const float *G, double lr, double beta1,
-                  double beta2, double eps, double weight_decay, int32_t step,
-                  void *stream);
 int rk_adam_rows(float *W, float *m, float *v, int32_t h, const int32_t *idx32,
                  const int64_t *idx64, const int32_t *n_dev, int32_t n_cap,
                  const float *G, double lr, double beta1, double beta2,
                  double eps, int32_t step, void *stream);
-int rk_adam_dense(float *p, float *m, float *v, const float *g, int64_t n,
-                  double lr, double beta1, double beta2, double eps,
-                  double weight_decay, int32_t step, void *stream);
 /* user-row position map for MF dense Adam: pos[users[r]] = r (or -1 to clear) */
 int rk_scatter_pos(int32_t *pos, const int64_t *rows, int32_t B, int32_t clear,
                    void *stream);
@@ -591,7 +581,7 @@ typedef struct rk_adam_param {
  * rk_adam_multi -- all parameter updates of one step (optimizer.step +
  * sparse_optimizer.step, model.py:398-402) and, optionally, the loss scalar in
  * ONE launch: up to RK_ADAM_MULTI_MAX jobs, each the exact arithmetic of
- * rk_adam_table (pos != NULL), rk_adam_dense (pos == NULL) or rk_adam_rows
+ * a dense-Adam table sweep (pos != NULL), a plain dense tensor (pos == NULL) or rk_adam_rows
  * (par.sparse: rows / n_dev / n_cap).  The gradient of a dense job may be the
  * sum of g_parts arrays g + t * stride (t ascending; stride = *gstride_dev when
  * given, else g_stride) -- the decoder-bias gradient is consumed straight from
@@ -741,13 +731,38 @@ typedef struct rk_ae_step {
   int32_t lazy_period;
 } rk_ae_step_t;
 
+/*
+ * The collectives of the data-parallel step (users sharded over the GPUs of a node; one process per GPU): thin RCCL
+ * wrappers, enqueued IN ORDER on the caller's stream -- inside a stream capture too (they are kernels) -- so that a
+ * phased step is gradient launches and exchanges on one stream with nothing in between.  The reference has no
+ * multi-device code (its backward + update: model.py:397-402).  RCCL is bound at run time (dlopen): `librccl` names
+ * the librccl.so to use (a PyTorch process: the one torch loaded), NULL: the loaded / default one.
+ *   rk_comm_unique_id  rank 0 draws the 128-byte id; the caller hands it to the other ranks (any side channel)
+ *   rk_comm_init       every rank, with the same id -> communicator handle (NULL: rk_last_error)
+ *   rk_allreduce_bucket  n buckets in place; several buckets = ONE RCCL group (one fused launch)
+ *   rk_reduce_scatter  recv[i] = sum over ranks of send[rank * recv_count + i]
+ *   rk_all_gather      recv[r * send_count + i] = rank r's send[i]
+ *   rk_exchange        grouped point-to-point: sends[q] (send_counts[q] elements) to rank q, recvs[q] from rank q
+ */
+enum { RK_COMM_F32 = 0, RK_COMM_I32 = 1 };
+enum { RK_COMM_SUM = 0, RK_COMM_MAX = 1 };
+int rk_comm_unique_id(void *id128, const char *librccl);
+void *rk_comm_init(const void *id128, int32_t world, int32_t rank, const char *librccl);
+void rk_comm_destroy(void *comm);
+int rk_allreduce_bucket(void *comm, void *const *bufs, const int64_t *counts, int32_t n, int32_t dtype, int32_t op,
+                        void *stream);
+int rk_reduce_scatter(void *comm, const void *send, void *recv, int64_t recv_count, int32_t dtype, void *stream);
+int rk_all_gather(void *comm, const void *send, void *recv, int64_t send_count, int32_t dtype, void *stream);
+int rk_exchange(void *comm, int32_t world, void *const *sends, const int64_t *send_counts, void *const *recvs,
+                const int64_t *recv_counts, int32_t dtype, void *stream);
+
 void *rk_event_create(int32_t timing); /* 0: ordering-only (no timing, device-scope fence); 1: for time_ev0 /
                                           time_ev1 and rk_event_elapsed_ms */
 void rk_event_destroy(void *event);
 float rk_event_elapsed_ms(void *ev0, void *ev1);   /* synchronises on ev1 */
 int rk_ae_train_step(const rk_ae_step_t *step);
 /* != 0: the step as described runs rk_pg_decode_loss / rk_pg_dz / rk_pg_dw (rk_ae_step_t.do_scales).  Bits 0-3: 1 = the
- * pipelined pair-plane kernels, 3 / 4 = the register-resident fused decode (4: streaming form) + rk_pg_dw; bit 4 (16):
+ * pipelined pair-plane kernels, 3 = the register-resident fused decode + rk_pg_dw; bit 4 (16):
  * the decoder bias gradient of the step is left as K slabs in gb_part -- gb_part[s * n_cap + c], s < counts[4] -- (the
  * dW tiles' output column h against a ones column of the Z image), not in gb_de */
 int32_t rk_ae_step_uses_pg(const rk_ae_step_t *step);
@@ -780,12 +795,12 @@ int rk_adam_consts(double lr, double beta1, double beta2, double eps, double wei
 /*
  * Graph replay of steps that are sequenced ENTRY BY ENTRY from the host (hidden stacks, bottleneck
  * dropout, MatrixFactorization: everything outside rk_ae_train_step).  Between rk_replay_set and
- * rk_replay_clear (thread-local) the entry points below take what changes from step to step from
+ * rk_replay_set(NULL) (thread-local) the entry points below take what changes from step to step from
  * the device-resident cursor instead of their host arguments, so that a captured sequence of them
  * can be replayed:
  *   rk_ae_encode_fwd                       rng_step = cursor[0] + off + 1; users = users_base + local * B
  *   rk_dropout                             rng_step = cursor[0] + off + 1
- *   rk_gather_rows / rk_scatter_pos /      rows / idx64 = users_base + local * B  (the pointer argument
+ *   rk_gather_rows_amax / rk_scatter_pos / rows / idx64 = users_base + local * B  (the pointer argument
  *   rk_adam_rows (idx64)                   is ignored)
  *   rk_adam_rows / rk_adam_multi           Adam constants = adam_table[local * tab_stride + slot]
  *                                          (slot: the call's `step` argument / rk_adam_job_t.par.step
@@ -805,8 +820,7 @@ typedef struct rk_replay {
   int32_t advance;           /* with cursor_next */
   int64_t *cursor_next;      /* nullable */
 } rk_replay_t;
-void rk_replay_set(const rk_replay_t *ctx);
-void rk_replay_clear(void);
+void rk_replay_set(const rk_replay_t *ctx);   /* NULL: leave the replay context */
 int rk_graph_begin(void *stream);
 void *rk_graph_end(void *stream);              /* -> executable graph handle, NULL on error */
 int rk_graph_launch(void *graph_exec, void *stream);

@@ -27,8 +27,7 @@ int rk_probe_buffer(int32_t which, unsigned long long *buffer);
  *   RK_TUNE_PLANES_TILE   0  rows of the decode tile of csrc/decode16.hip: 64 / 128, 0 = by shape
  *   RK_TUNE_DZ_FUSED      1  the fused decode + loss + dZ launch where it applies (rk_plan_t.decode_dz_fused_ok)
  *   RK_TUNE_DW_ENC_FUSED  1  dW || encoder backward in one launch (rk_plan_t.dw_encode_bwd_fused_ok); 0: never (the step then
- *                            leaves the register-resident fused decode too); 2: an A/B form -- the fused decode with dW from its
- *                            image on the side stream beside reduce -> encoder backward (round 5: 0.120 vs 0.1106 ms at C2)
+ *                            leaves the register-resident fused decode too)
  *   RK_TUNE_DW_BF16X3     0  dW on bf16 triples (no operand range) instead of fp16 pairs
  *   RK_TUNE_ADAM_DE_SIDE  0  the decoder table's Adam sweep as a launch of its own behind dW on dw_stream
  *   RK_TUNE_PG_TILE       0  decode tile of csrc/pgemm.hip: 256 (256 x 256), 1282 (128 x 256), 0 = by batch size
@@ -46,21 +45,13 @@ int rk_probe_buffer(int32_t which, unsigned long long *buffer);
  *                            two-stage loop as the compiler schedules it (vmcnt(0) before the first transpose read)
  *   RK_TUNE_DW_ONES       1  whole steps on the fused decode, h % 32 != 0: the decoder bias gradient as output column h of the dW
  *                            tiles (a ones column in the Z image's padding) instead of a column-sum range over the dO image
- *   RK_TUNE_FDEC_STREAM   0  the fused decode (csrc/fdecode.hip) in its STREAMING form -- a workgroup walks a group of
- *                            column tiles, one dZ slab per group: 1 = from 1024 rows (the fused decode's domain
- *                            then has no row limit), 2 = always, 0 = never (one workgroup and one slab per 128-item
- *                            tile, < 1024 rows).  Measured, round 5: C2 at B = 4000 decode + dZ 539 -> 377 us, but the
- *                            step 0.954 -> 0.996 ms (dW no longer runs beside a stand-alone dZ); B = 500 29.8 vs 23.9 us */
+ *   RK_TUNE_FDEC_STREAM   -  (round 5's streaming form of the fused decode: removed in round 6, the index stays reserved --
+ *                            tools/probes/patches/r06_fdec_streaming_form.patch) */
 enum { RK_TUNE_LINEAR_PAIR = 0, RK_TUNE_PLANES_TILE = 1, RK_TUNE_DZ_FUSED = 2, RK_TUNE_DW_ENC_FUSED = 3,
        RK_TUNE_DW_BF16X3 = 4, RK_TUNE_ADAM_DE_SIDE = 5, RK_TUNE_PG_TILE = 6, RK_TUNE_DZ_TN = 7,
        RK_TUNE_DZ_SPLITS = 8, RK_TUNE_PAIR_ORDER = 9, RK_TUNE_GRAPH_EVENT_NODES = 10, RK_TUNE_FDEC_STREAM = 11,
        RK_TUNE_MF_FDEC = 12, RK_TUNE_DW_RING = 13, RK_TUNE_DW_ONES = 14, RK_TUNE_COUNT = 15 };
 int rk_tune(int32_t knob, int32_t value);
-
-/* X[rows, cols] (ld) -> the fragment-ordered transposed fp16 pair planes of rk_decode_bwd_dw3 (test hook of
- * the layout; the training step makes them in the encoder forward or in rk_split_wz) */
-int rk_split_planes_t(const float *X, int32_t rows, int32_t cols, int32_t ld, int32_t rows_pad, int32_t cols_pad,
-                      void *planes, void *stream);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -57,6 +57,7 @@ class RkPlan(Structure):
     ("fdec_workspace_bytes", c_int64), ("pg_dz_workspace_bytes", c_int64), ("pg_dw_workspace_bytes", c_int64),
     ("pg_scale_floats", c_int64), ("pg_mnll_workspace_floats", c_int64),
     ("decode_dz_fused_ok", c_int32), ("fdec_ok", c_int32), ("dw_encode_bwd_fused_ok", c_int32), ("adam_de_side", c_int32),
+    ("encode_bwd_segments", c_int32), ("_pad0", c_int32), ("dw3_slabs_offset_bytes", c_int64),
     ("mf_fdec_ok", c_int32),
   ]
 
@@ -164,9 +165,6 @@ SIGNATURES = {
   "rk_loss_reduce": (c_int32, [_P, c_int32, c_float, _P, _P]),
   "rk_decode_bwd_dz": (c_int32, [_P, c_int32, c_int32, _BLK, _P, _P, c_int32, _P, _P, _P, _P]),
   "rk_decode_bwd_dw": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P]),
-  "rk_decode_bwd_dw_encode_bwd": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, c_int32, _P, _P, _P, _P,
-                                            _P]),
-  "rk_dw3_slabs": (c_void_p, [_P, c_int32, c_int32]),
   "rk_decode_bwd_dw3": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, _P, _P]),
   "rk_decode_bwd_dw2": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, _P, _P, _P]),
   "rk_decode_bwd_dw2_encode_bwd": (c_int32, [_P, _P, c_int32, c_int32, _BLK, _P, _P, _P, c_int32, _P, _P, _P, _P]),
@@ -190,8 +188,6 @@ SIGNATURES = {
   "rk_pg_dw": (c_int32, [_P, _P, c_int32, c_int32, c_int32, POINTER(RkPlanes), _BLK, _P, _P, _P]),
   "rk_pg_dw_encode_bwd": (c_int32, [_P, _P, c_int32, c_int32, c_int32, POINTER(RkPlanes), _BLK, _P, c_int32, _P, _P, _P,
                                     _P, _P]),
-  "rk_split_planes_t": (c_int32, [_P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
-  "rk_encode_bwd_segments": (c_int32, [c_int32]),
   "rk_linear_fwd": (c_int32, [_P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P]),
   "rk_linear_bwd": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P, _P,
                               c_int32, _P, _P]),
@@ -202,17 +198,20 @@ SIGNATURES = {
   "rk_act_grad": (c_int32, [_P, _P, c_int64, c_int32, _P]),
   "rk_dropout": (c_int32, [_P, _P, c_int64, c_int32, c_float, c_uint64, c_uint64, _P]),
   "rk_colsum": (c_int32, [_P, c_int32, c_int32, c_int32, _P, _P, _P]),
-  "rk_gather_rows": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P]),
   "rk_gather_rows_amax": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P, _P, _P]),
-  "rk_adam_table": (c_int32, [_P, _P, _P, c_int32, c_int32, _P, _P, c_double, c_double, c_double,
-                              c_double, c_double, c_int32, _P]),
   "rk_adam_rows": (c_int32, [_P, _P, _P, c_int32, _P, _P, _P, c_int32, _P, c_double, c_double,
                              c_double, c_double, c_int32, _P]),
-  "rk_adam_dense": (c_int32, [_P, _P, _P, _P, c_int64, c_double, c_double, c_double, c_double,
-                              c_double, c_int32, _P]),
   "rk_adam_multi": (c_int32, [POINTER(RkAdamJob), c_int32, _P, c_int32, c_float, _P, _P]),
   "rk_adam_lazy_flush": (c_int32, [POINTER(RkAdamJob), c_int32, _P, c_int32, POINTER(c_int32), c_int64, c_int64, _P]),
   "rk_scatter_pos": (c_int32, [_P, _P, c_int32, c_int32, _P]),
+  "rk_comm_unique_id": (c_int32, [_P, c_char_p]),
+  "rk_comm_init": (c_void_p, [_P, c_int32, c_int32, c_char_p]),
+  "rk_comm_destroy": (None, [_P]),
+  "rk_allreduce_bucket": (c_int32, [_P, POINTER(c_void_p), POINTER(c_int64), c_int32, c_int32, c_int32, _P]),
+  "rk_reduce_scatter": (c_int32, [_P, _P, _P, c_int64, c_int32, _P]),
+  "rk_all_gather": (c_int32, [_P, _P, _P, c_int64, c_int32, _P]),
+  "rk_exchange": (c_int32, [_P, c_int32, POINTER(c_void_p), POINTER(c_int64), POINTER(c_void_p), POINTER(c_int64),
+                            c_int32, _P]),
   "rk_event_create": (c_void_p, [c_int32]),
   "rk_event_destroy": (None, [c_void_p]),
   "rk_event_elapsed_ms": (c_float, [c_void_p, c_void_p]),
@@ -224,7 +223,6 @@ SIGNATURES = {
   "rk_adam_consts": (c_int32, [c_double, c_double, c_double, c_double, c_double, c_int32, c_int32,
                                c_int32, _P]),
   "rk_replay_set": (None, [POINTER(RkReplay)]),
-  "rk_replay_clear": (None, []),
   "rk_graph_begin": (c_int32, [_P]),
   "rk_graph_end": (c_void_p, [_P]),
   "rk_graph_launch": (c_int32, [_P, _P]),
@@ -310,8 +308,10 @@ def _install_plan_accessors(lib):
       ("pg_dw_splits", ("B", "h", "n_cap")), ("pg_dw_workspace_bytes", ("B", "h", "n_cap")),
       ("dw3_planes_bytes", ("B", "h")), ("dw3_rows_pad", ("B",)), ("dw3_cols_pad", ("h",)), ("gemm_split16", ()),
       ("gemm_plain_bf16", ()), ("adam_de_side", ()), ("dw_splits", ("B",)), ("graph_timing_supported", ()), ("topk_max_k", ()),
-      ("topk_pairs_max_cap", ())):
+      ("topk_pairs_max_cap", ()), ("encode_bwd_segments", ("B",))):
     setattr(lib, "rk_" + name, field(name, args))
+  # (the K slabs of rk_decode_bwd_dw3 / dw2 inside their workspace: a pointer, as the export of rounds 2-5 returned it)
+  lib.rk_dw3_slabs = lambda ws, B, h: (ws or 0) + plan(B=B, h=h).dw3_slabs_offset_bytes
 
   def granule(B, n_cap, gr, gc):
     p = plan(B=B, n_cap=n_cap)

@@ -12,7 +12,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "librecoder_hip.so")
-SOURCES = ["capi.hip", "collate.hip", "encoder.hip", "gemm.hip", "decode16.hip", "linear.hip", "dw3.hip", "pgemm.hip", "fdecode.hip", "optim.hip", "topk.hip", "step.hip"]
+SOURCES = ["capi.hip", "collate.hip", "encoder.hip", "gemm.hip", "decode16.hip", "linear.hip", "dw3.hip", "pgemm.hip", "fdecode.hip", "optim.hip", "topk.hip", "step.hip", "comm.hip"]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (gfx950 has a unified register
 # file); without it hipcc copied all accumulators AGPR<->VGPR around every k-tile
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
@@ -56,7 +56,7 @@ def build_library(force=False, verbose=True):
     raise RuntimeError("hipcc failed")
   if force or procs or _stale(LIB, objs):
     # (-z defs: an internal helper that is declared but defined nowhere must fail HERE, not at dlopen on the GPU box)
-    cmd = [hipcc, "--offload-arch=gfx950", "--offload-compress", "-shared", "-fPIC", "-Wl,-z,defs", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "--offload-compress", "-shared", "-fPIC", "-Wl,-z,defs", "-o", LIB] + objs + ["-ldl"]
     if verbose:
       print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

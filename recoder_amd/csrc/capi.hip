@@ -51,6 +51,8 @@ extern "C" int rk_plan(rk_plan_t *p) {
   p->fdec_ok = rk_fdec_ok(B, h, n, loss);
   p->dw_encode_bwd_fused_ok = rk_dw_encode_bwd_fused_ok(p->row_off, B);
   p->adam_de_side = rk_adam_de_side();
+  p->encode_bwd_segments = rk_encode_bwd_segments(B);
+  p->dw3_slabs_offset_bytes = (const char *)rk_dw3_slabs(nullptr, B, h) - (const char *)nullptr;
   p->mf_fdec_ok = (rk_tune_get(RK_TUNE_MF_FDEC) != 0 && B < 1024 && rk_fdec_ok(B, h, n, loss)) ? 1 : 0;
   return 0;
 }
@@ -62,7 +64,6 @@ extern "C" void rk_replay_set(const rk_replay_t *ctx) {
   g_replay_on = ctx != nullptr && ctx->cursor != nullptr;
   if (g_replay_on) g_replay = *ctx;
 }
-extern "C" void rk_replay_clear(void) { g_replay_on = false; }
 const rk_replay_t *rk_replay_get(void) { return g_replay_on ? &g_replay : nullptr; }
 
 // include/recoder_hip_probe.h: the tuning probes and switches of tools/ and tests/ behind two entry points

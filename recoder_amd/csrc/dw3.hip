@@ -471,11 +471,6 @@ static int split_planes_t_launch(const float *X, int32_t rows, int32_t cols, int
                                  int32_t cols_pad, void *planes, int pairs, const uint32_t *amax,
                                  float *scale_out, void *stream_);
 
-extern "C" int rk_split_planes_t(const float *X, int32_t rows, int32_t cols, int32_t ld,
-                                 int32_t rows_pad, int32_t cols_pad, void *planes, void *stream_) {
-  return split_planes_t_launch(X, rows, cols, ld, rows_pad, cols_pad, planes, 0, nullptr, nullptr, stream_);
-}
-
 static int split_planes_t_launch(const float *X, int32_t rows, int32_t cols, int32_t ld, int32_t rows_pad,
                                  int32_t cols_pad, void *planes, int pairs, const uint32_t *amax,
                                  float *scale_out, void *stream_) {
@@ -665,7 +660,7 @@ extern "C" int32_t rk_dw_pairs(void) {
   return (rk_tune_get(RK_TUNE_DW_BF16X3) == 0 && !rk_gemm_plain_bf16()) ? 1 : 0;
 }
 
-extern "C" const float *rk_dw3_slabs(const void *workspace, int32_t B, int32_t h) {
+const float *rk_dw3_slabs(const void *workspace, int32_t B, int32_t h) {
   const int64_t planes_b = (dw3_plane_bytes(B, h) + 255) & ~(int64_t)255;
   return (const float *)((const char *)workspace + planes_b);
 }

@@ -363,320 +363,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// The STREAMING form (round 5): a workgroup owns a 128-user row tile and a GROUP of column tiles
-// (nt = g, g + NG, ...: NG groups per row tile, tm * NG ~ one workgroup per CU) and walks them with the dZ^T
-// accumulators of its users staying in registers -- ONE slab per group instead of one per 128-item tile:
-// B = 4000 at C2 (32 row tiles x 133 column tiles) leaves 8 slabs instead of 133 (425 MB of slab traffic
-// -> 26), a union item set of 18 k items at B = 500 runs as 256 workgroups of 2-3 tiles instead of 2.25
-// waves of workgroups paid as 3, and a block whose capacity is far above its live item set (C3: 41 k items
-// of capacity, 8.4 k live) launches 256 workgroups instead of 1 284.  With one tile per workgroup (C2 at
-// B = 500: 4 x 62 tiles, NG = 64) it does exactly what fdec_kernel does.
-//   * the accumulators carry the scale of the LAST tile's dO granule: moving to a tile with another
-//     power-of-two scale multiplies them by the ratio (exact), as pg::Rescale does in the pipelined family;
-//   * the Z fragments of the wave's 32 users are not held across the tile (the accumulators need the
-//     registers): every k-tile's four 16-byte pieces are fetched one k-tile ahead, from L2.
-// FAST: implicit feedback + squared error (C2) -- the straight-line loss pass only (a kernel that also holds the
-// general pass, with its value look-ups under branches, keeps ~100 more registers live across the tile loop)
-template <int KTM, int LOSS, bool FAST>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void fdec_stream_kernel(const FdecP p, const int NG) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char *Wst = smem;                                   // [KTM][128 rows][128 B]
-  char *Zb = smem + FD_LDS(KTM) - 1024 - 8 * 4096;    // [8 waves][32 rows][128 B]
-  float *misc = reinterpret_cast<float *>(smem + FD_LDS(KTM) - 1024);   // [128] bias | [16] reductions
-  const int M = p.M, N = *p.Ndev;
-  const int tm = (M + 127) >> 7, tn = (N + 127) >> 7;
-  int t;
-  if (!pg::tile_of((int)blockIdx.x, tm * NG, t)) return;
-  const int mt = t % tm, g = t / tm;
-  if (g >= tn) return;                                // (no column tile for this group: its slab is not live)
-  const int m0 = mt * 128;
-  const int tid = threadIdx.x, lane = tid & 63, wave = pg::rfl(tid >> 6);
-  const int pr = wave & 3, hf = wave >> 2;
-  const int l31 = lane & 31, lh = lane >> 5;
-  const int m = m0 + 32 * pr + l31;
-  const int mrow = p.row_off + min(m, M - 1);
-  const rk_block_t &b = p.blk;
-  const float sz_sw = p.scales[0] * p.scales[1];
-  const float inv = 1.0f / sz_sw;
-  const bool implicit = b.implicit != 0;
-  const int ldi = b.counts[2];
-  const bool st_ok = m < p.rows_img;
-  pg::Opnd ow = {p.wimg, (int64_t)KTM * 128, KTM, p.w_rows};
-  char *zb = Zb + wave * 4096;                        // this wave's bounce stage: [32 rows][128 B], KC swizzle
-  // this lane's pieces of the wave's Z lines: row slot lane >> 3 of four 8-row groups, 16-byte slot lane & 7
-  const char *zsrc[4];
-  {
-    const int zlim = min(M, p.z_rows) - 1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      zsrc[i] = p.zimg + (int64_t)min(m0 + 32 * pr + 8 * i + (lane >> 3), zlim) * (KTM * 128) + 16 * (lane & 7);
-  }
-  f32x16 acc2[KTM];
-#pragma unroll
-  for (int j = 0; j < KTM; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
-  float s_prev = 0.f;                                 // scale the accumulators carry (0: nothing accumulated yet)
-  float lsum_all = 0.f, gmax_all = 0.f;
-
-#pragma clang loop unroll(disable)
-  for (int nt = g; nt < tn; nt += NG) {
-    const int n0 = nt * 128;
-    // (the lane id is laundered once per tile: the dozens of LDS fragment addresses derived from it are then
-    // recomputed per tile instead of being hoisted out of the loop and held in registers across it -- the
-    // accumulators need them: 256 VGPRs + 344 bytes of scratch otherwise)
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    pg::FragKC fr;
-    fr.init(ln);
-    if (nt != g) {
-      // (the previous tile's image stores are out, every wave is done with its W stages and bias)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-    uint32_t words[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      words[i] = b.bits_rc[(int64_t)mrow * b.ldw_rc + min((n0 >> 5) + 2 * hf + i, b.ldw_rc - 1)];
-    if (tid < 128) misc[tid] = p.bias[p.bidx[min(n0 + tid, N - 1)]];
-    pg::Stager<128, false, 8> sw;
-    sw.init(ow, n0, 0, min(N, p.w_rows), wave, lane);
-#pragma unroll
-    for (int kt = 0; kt < KTM; ++kt) sw.issue(Wst + kt * WB, wave);
-    asm volatile("" ::: "memory");
-    pg::u32x4 zraw[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) zraw[i] = *reinterpret_cast<const pg::u32x4 *>(zsrc[i]);
-    // (the 4 loads above are the only memory operations behind the DMA: it has landed when no more than
-    // those are outstanding -- vmcnt counts in issue order)
-    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < KTM; ++kt) {
-      const char *SW = Wst + kt * WB + hf * 8192;
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int r = 8 * i + (ln >> 3);
-        *reinterpret_cast<pg::u32x4 *>(zb + r * 128 + (((ln & 7) ^ pg::kc_sw(r)) << 4)) = zraw[i];
-      }
-      if (kt + 1 < KTM) {      // (the next k-tile's pieces, in flight under this one's MFMAs)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) zraw[i] = *reinterpret_cast<const pg::u32x4 *>(zsrc[i] + (kt + 1) * 128);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      f16x8 zh[2], zl[2];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) { zh[ks] = fr.load(zb, 0, ks, 0); zl[ks] = fr.load(zb, 0, ks, 1); }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        f16x8 wh[2], wl[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { wh[i] = fr.load(SW, i, ks, 0); wl[i] = fr.load(SW, i, ks, 1); }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], zl[ks], acc[i], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], zh[ks], acc[i], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], zh[ks], acc[i], 0, 0, 0);
-      }
-    }
-
-    // ---- loss (as fdec_kernel): lane = user m, acc[i][r] = item n0 + 64 hf + 32 i + (r & 3) + 8 (r >> 2) + 4 lh
-    const int nh = n0 + 64 * hf;
-    float lsum = 0.f, gmax = 0.f;
-    if (FAST) {
-      const float c = p.confidence, inv_B2 = 2.0f * p.inv_B;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int nrem = N - (nh + 32 * i);
-        uint32_t vmask = nrem >= 32 ? 0xffffffffu : (nrem <= 0 ? 0u : ((1u << nrem) - 1u));
-        if (m >= M) vmask = 0u;
-        const uint32_t vsh = vmask >> (4 * lh), wsh = (words[i] & vmask) >> (4 * lh);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 bq = *reinterpret_cast<const float4 *>(misc + 64 * hf + 32 * i + 8 * q + 4 * lh);
-          const float bias4[4] = {bq.x, bq.y, bq.z, bq.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * q + e, bp = e + 8 * q;
-            const float bitf = (float)((wsh >> bp) & 1u);
-            const uint32_t okm = (uint32_t)(((int32_t)(vsh << (31 - bp))) >> 31);
-            const float o = acc[i][r] * inv + bias4[e];
-            const float d = o - bitf;
-            const float w = fmaf(c, bitf, 1.0f);
-            const float l = w * (d * d);
-            lsum += __uint_as_float(__float_as_uint(l) & okm);
-            const float gg = __uint_as_float(__float_as_uint(d * (w * inv_B2)) & okm);
-            gmax = fmaxf(gmax, fabsf(gg));
-            acc[i][r] = gg;
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const uint32_t w = words[i];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int nl = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const int n = nh + 32 * i + nl;
-          const bool ok = (m < M) && (n < N);
-          const float o = acc[i][r] * inv + misc[64 * hf + 32 * i + nl];
-          float tv = 0.f;
-          if (ok && ((w >> nl) & 1u)) {
-            tv = 1.0f;
-            if (!implicit) tv = b.vals[rk_entry_index(b, mrow, n, w)];
-          }
-          float l, gg;
-          if (LOSS == pg::LOSS_MSE) {
-            const float wgt = (tv > 0.f) ? (1.0f + p.confidence) : 1.0f;
-            const float d = o - tv;
-            l = wgt * (d * d);
-            gg = (2.0f * d) * (wgt * p.inv_B);
-          } else {  // BCE with logits
-            const float ls = fminf(o, 0.f) - log1pf(expf(-fabsf(o)));
-            l = (1.0f - tv) * o - ls;
-            const float sg = 1.0f / (1.0f + expf(-o));
-            gg = (sg - tv) * p.inv_B;
-          }
-          if (ok) { lsum += l; gmax = fmaxf(gmax, fabsf(gg)); } else gg = 0.f;
-          acc[i][r] = gg;
-        }
-      }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
-    lsum_all += lsum;
-    gmax_all = fmaxf(gmax_all, gmax);
-    float s_do = 1.0f;
-    if (gmax > 0.f) {
-      const int ex = min(max((int)(__float_as_uint(gmax) >> 23) - 127, -100), 100);
-      s_do = __uint_as_float((uint32_t)(13 - ex + 127) << 23);
-    }
-    if (lane == 0 && (m0 >> 5) + pr < ((M + 31) >> 5) && 2 * nt + hf < p.ds_pitch)
-      p.dscale[(int64_t)((m0 >> 5) + pr) * p.ds_pitch + 2 * nt + hf] = s_do;
-    // the accumulators move to this tile's scale (a ratio of powers of two: exact)
-    if (s_prev != 0.f && s_prev != s_do) {
-      const float ratio = s_do / s_prev;
-#pragma unroll
-      for (int j = 0; j < KTM; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[j][r] *= ratio;
-    }
-    s_prev = s_do;
-
-    // ---- dO^T fragments (permlane32 swap), the image, and dZ^T[j, user] += W^T[j, item] . dO^T[item, user]
-    char *drow = p.dimg + (int64_t)m * ldi * 4 + (int64_t)(nh >> 5) * 128;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        // (one 16-item group at a time: the scheduler otherwise converts every group's fragments and fetches
-        // their W^T operands ahead, ~50 registers the accumulators of the tile loop do not leave)
-        __builtin_amdgcn_sched_barrier(0);
-        uint2 fh, fl, sh, sl;
-        rkp::split4(make_float4(acc[i][8 * s + 0], acc[i][8 * s + 1], acc[i][8 * s + 2], acc[i][8 * s + 3]), s_do, fh, fl);
-        rkp::split4(make_float4(acc[i][8 * s + 4], acc[i][8 * s + 5], acc[i][8 * s + 6], acc[i][8 * s + 7]), s_do, sh, sl);
-        swap32(fh.x, sh.x); swap32(fh.y, sh.y); swap32(fl.x, sl.x); swap32(fl.y, sl.y);
-        const uint4 hi4 = make_uint4(fh.x, fh.y, sh.x, sh.y), lo4 = make_uint4(fl.x, fl.y, sl.x, sl.y);
-        if (st_ok && nh + 32 * i < ldi) {
-          char *d = drow + i * 128 + (16 * s + 8 * lh) * 2;
-          *reinterpret_cast<uint4 *>(d) = hi4;
-          *reinterpret_cast<uint4 *>(d + 64) = lo4;
-        }
-        const f16x8 dh = __builtin_bit_cast(f16x8, hi4), dl = __builtin_bit_cast(f16x8, lo4);
-        const int row0 = 64 * hf + 32 * i + 16 * s + 8 * lh;
-#pragma unroll
-        for (int j = 0; j < KTM; ++j) {
-          const f16x8 ah = w_tr_frag(Wst + j * WB, row0, ln, 0), al = w_tr_frag(Wst + j * WB, row0, ln, 1);
-          acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, dh, acc2[j], 0, 0, 0);
-          acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, dl, acc2[j], 0, 0, 0);
-          acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, dh, acc2[j], 0, 0, 0);
-        }
-      }
-    }
-  }
-
-  // ---- the group's slab: the two item halves of a user group meet in LDS (over the W stages), as fdec_kernel
-  lsum_all = rk_wave_sum(lsum_all);
-  if (lane == 0) { misc[128 + wave] = lsum_all; misc[136 + wave] = gmax_all; }
-  constexpr int PITCH = FD_PITCH(KTM);
-  float *X = reinterpret_cast<float *>(smem) + pr * 32 * PITCH;
-  const float inv2 = 1.0f / (s_prev * p.scales[1]);
-  __syncthreads();
-  if (hf == 1) {
-#pragma unroll
-    for (int j = 0; j < KTM; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<float4 *>(X + l31 * PITCH + 32 * j + 8 * q + 4 * lh) =
-            make_float4(acc2[j][4 * q] * inv2, acc2[j][4 * q + 1] * inv2, acc2[j][4 * q + 2] * inv2, acc2[j][4 * q + 3] * inv2);
-  }
-  __syncthreads();
-  if (hf == 0) {
-#pragma unroll
-    for (int j = 0; j < KTM; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float4 *x = reinterpret_cast<float4 *>(X + l31 * PITCH + 32 * j + 8 * q + 4 * lh);
-        const float4 u = *x;
-        *x = make_float4(acc2[j][4 * q] * inv2 + u.x, acc2[j][4 * q + 1] * inv2 + u.y, acc2[j][4 * q + 2] * inv2 + u.z,
-                         acc2[j][4 * q + 3] * inv2 + u.w);
-      }
-  }
-  __syncthreads();
-  {
-    const int h4 = p.h >> 2;
-    const int rows = min(32, M - (m0 + 32 * pr));
-    float4 *ws = reinterpret_cast<float4 *>(p.dz_ws + ((int64_t)g * M + m0 + 32 * pr) * p.h);
-    for (int idx = hf * 64 + lane; idx < rows * h4; idx += 128) {
-      const int row = idx / h4, c = idx - row * h4;
-      ws[idx] = *reinterpret_cast<const float4 *>(X + row * PITCH + 4 * c);
-    }
-  }
-  if (tid == 0) {
-    float ls = 0.f, gm = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) { ls += misc[128 + w]; gm = fmaxf(gm, misc[136 + w]); }
-    p.loss_part[t] = ls;
-    atomicMax(reinterpret_cast<unsigned int *>(b.counts) + 8 + ((int)blockIdx.x & 63), __float_as_uint(gm));
-  }
-}
-
 inline bool al16(const void *q) { return ((uintptr_t)q & 15) == 0; }
 
 }  // namespace
 
 // the shapes the register-resident fused decode covers: MSE / logistic, 2, 4 or 7 k-tiles of 32 hidden
 // units (h <= 224: 7 resident k-tiles of the W tile = 112 KB of LDS), below 1024 rows, slab workspace below 4 GB; RK_FDEC=0: off
-// Which form runs a batch of B rows (rk_tune RK_TUNE_FDEC_STREAM: 0 = the default, never; 1: from 1024 rows; 2: always).
-// Measured (round 5, one MI355X): with one tile per group (C2 at B = 500) the streaming kernel takes 29.8 us against
-// 23.9 (it cannot keep all of a tile's Z lines in flight and spills 200 bytes per lane); at B = 4000 it replaces the
-// pipelined family's decode 218 + dZ 321 us by 364 + 13 (reduce) -- but the step goes from 0.954 to 0.996 ms: the
-// stand-alone dZ used to run BESIDE dW (336-366 us at 80 TF/s, the long pole of that step), the fused form leaves dW
-// only the reduce + encoder backward to hide behind.  Kept behind the knob until dW at h = 200 is faster.
-int rk_fdec_stream(int B) {
-  const int v = rk_tune_get(RK_TUNE_FDEC_STREAM);
-  return v == 2 || (v == 1 && B >= 1024);
-}
-// dZ slabs the fused decode leaves for rk_fdec_dz_reduce: one per GROUP of column tiles in the streaming form
-// (row tiles x groups ~ one workgroup per CU of the MI355X), one per 128-item column tile otherwise
+// dZ slabs the fused decode leaves for rk_fdec_dz_reduce: one per 128-item column tile.  (A STREAMING form -- a workgroup
+// walking a group of column tiles with the dZ accumulators in registers, one slab per group -- was built in round 5,
+// measured slower wherever it applied and is kept as tools/probes/patches/r06_fdec_streaming_form.patch.)
 int rk_fdec_slabs(int B, int n_cap) {
-  const int tn = rk_cdiv(n_cap, 128);
-  if (!rk_fdec_stream(B)) return tn;
-  const int tm = std::max(1, rk_cdiv(B, 128));
-  return std::max(1, std::min(tn, 256 / tm));
+  (void)B;
+  return rk_cdiv(n_cap, 128);
 }
 
 extern "C" int rk_fdec_dz_reduce(const float *dz_workspace, int32_t B, int32_t h, const rk_block_t *tgt,
@@ -692,7 +390,7 @@ extern "C" int32_t rk_fdec_ok(int32_t B, int32_t h, int32_t n_cap, int32_t loss_
   const int kt = rkp::kp_of(h) / 32;
   return on && rk_pg_enabled() && rk_gemm_split16() && !rk_gemm_plain_bf16() &&
          (loss_kind == RK_LOSS_MSE || loss_kind == RK_LOSS_BCE) && h % 4 == 0 && h <= 224 &&
-         (B < 1024 || rk_fdec_stream(B)) && B <= 32768 &&
+         B < 1024 &&
          (kt == 2 || kt == 4 || kt == 7) &&
          (int64_t)rk_fdec_slabs(B, n_cap) * B * h * (int64_t)sizeof(float) <= ((int64_t)4 << 30) ? 1 : 0;
 }
@@ -723,30 +421,13 @@ extern "C" int rk_fdec_loss_dz(const rk_planes_t *pl, int32_t B, const rk_block_
   p.bias = b_de; p.bidx = tgt->items; p.loss_part = loss_part;
   p.dimg = (char *)dO_img; p.rows_img = rows_img; p.dscale = dO_scales; p.ds_pitch = rk_cdiv(tgt->n_cap, 64);
   p.dz_ws = dz_workspace; p.h = pl->h;
-  const int stream_form = rk_fdec_stream(B);
-  const int NG = rk_fdec_slabs(B, tgt->n_cap);
-  const int grid = stream_form ? rk_cdiv(rk_cdiv(B, 128) * NG, 8) * 8
-                               : rk_cdiv(rk_cdiv(B, 128) * rk_cdiv(tgt->n_cap, 128), 8) * 8;
+  const int grid = rk_cdiv(rk_cdiv(B, 128) * rk_cdiv(tgt->n_cap, 128), 8) * 8;
 #define GO(KTM, LOSS)                                                                                          \
   do {                                                                                                         \
-    if (stream_form) {                                                                                         \
-      if (LOSS == pg::LOSS_MSE && tgt->implicit) {                                                             \
-        auto k = fdec_stream_kernel<KTM, pg::LOSS_MSE, true>;                                                  \
-        static const hipError_t attr = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        if (attr != hipSuccess) { rk_set_error("LDS attribute"); return -1; }                                  \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(512), FD_LDS(KTM), stream, p, NG);                              \
-      } else {                                                                                                 \
-        auto k = fdec_stream_kernel<KTM, LOSS, false>;                                                         \
-        static const hipError_t attr = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        if (attr != hipSuccess) { rk_set_error("LDS attribute"); return -1; }                                  \
-        hipLaunchKernelGGL(k, dim3(grid), dim3(512), FD_LDS(KTM), stream, p, NG);                              \
-      }                                                                                                        \
-    } else {                                                                                                   \
-      auto k = fdec_kernel<KTM, LOSS>;                                                                         \
-      static const hipError_t attr = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      if (attr != hipSuccess) { rk_set_error("LDS attribute"); return -1; }                                    \
-      hipLaunchKernelGGL(k, dim3(grid), dim3(512), FD_LDS(KTM), stream, p);                                    \
-    }                                                                                                          \
+    auto k = fdec_kernel<KTM, LOSS>;                                                                           \
+    static const hipError_t attr = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    if (attr != hipSuccess) { rk_set_error("LDS attribute"); return -1; }                                      \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), FD_LDS(KTM), stream, p);                                      \
   } while (0)
 #define BY_KT(LOSS)                                                                                            \
   do { if (p.KT == 2) GO(2, LOSS); else if (p.KT == 4) GO(4, LOSS); else GO(7, LOSS); } while (0)

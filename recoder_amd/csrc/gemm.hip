@@ -1110,7 +1110,7 @@ extern "C" int64_t rk_dz_workspace_bytes(int32_t B, int32_t h) {
 }
 
 // row segments of the encoder backward inside rk_decode_bwd_dw_encode_bwd (see encoder_bwd.h)
-extern "C" int32_t rk_encode_bwd_segments(int32_t B) {
+int32_t rk_encode_bwd_segments(int32_t B) {
   const int s = rk_cdiv(B, 512);
   return s < 1 ? 1 : (s > 8 ? 8 : s);
 }
@@ -1345,7 +1345,7 @@ extern "C" int rk_decode_bwd_dw(const float *dO, const float *Z, int32_t B, int3
 }
 
 // rk_decode_bwd_dw + rk_ae_encode_bwd (untied weights, same block) in one launch
-extern "C" int rk_decode_bwd_dw_encode_bwd(const float *dO, const float *Z, int32_t B, int32_t h,
+int rk_decode_bwd_dw_encode_bwd(const float *dO, const float *Z, int32_t B, int32_t h,
                                            const rk_block_t *blk, float *G_de, int32_t row_off,
                                            const float *dZ0pre, float *G_en, float *gb_en,
                                            float *workspace, void *stream_) {

@@ -14,8 +14,13 @@ int rk_pg_dw_encode_bwd_ones(const void *dO_img, const float *dO_scales, int32_t
 int rk_pg_dw_ones_ok(int32_t B, int32_t h, int32_t n_cap);
 int rk_splitk_reduce_tiles(const float *ws, int M, int N, const int32_t *Kdev, int max_splits, int tile_k,
                            const float *Zact, int act, float *out, void *stream_);
-int rk_fdec_stream(int B);
 int rk_fdec_slabs(int B, int n_cap);
+const float *rk_dw3_slabs(const void *workspace, int32_t B, int32_t h);   // K slabs of dw3 / dw2 inside their workspace
+int32_t rk_encode_bwd_segments(int32_t B);                                // row segments of the fused fp32 dW || encoder backward
+// gemm.hip: the fp32 tiles' dW + rk_ae_encode_bwd(accumulate = 0) in ONE launch (RK_GEMM_PREC=f32, item-parallel steps)
+int rk_decode_bwd_dw_encode_bwd(const float *dO, const float *Z, int32_t B, int32_t h, const rk_block_t *blk, float *G_de,
+                                int32_t row_off, const float *dZ0pre, float *G_en, float *gb_en, float *workspace,
+                                void *stream);
 extern "C" {
 int64_t rk_dz_workspace_bytes(int32_t B, int32_t h);
 int32_t rk_loss_partials(int32_t B, int32_t n_cap);

@@ -3,7 +3,7 @@
 // Adam     : torch.optim.Adam `_single_tensor_adam` as driven by the reference
 //            (model.py:135,398-399): L2 weight decay folded into the gradient,
 //            lerp first moment, bias-corrected step, eps added after the
-//            bias-corrected sqrt.  rk_adam_table is the "dense gradient"
+//            bias-corrected sqrt.  A table job with pos is the "dense gradient"
 //            (sparse=False) form for an embedding table: the reference
 //            materialises a full [n_items,h] gradient that is zero outside the
 //            sampled rows (K13/K14a of SURVEY 2.3); here the sweep reads the
@@ -50,54 +50,6 @@ __device__ __forceinline__ void sadam1(float &p, float &m, float &v, float g, co
   v = v + uv;
   const float denom = sqrtf(dsq) + c.eps;
   p = p + (numer / denom) * c.neg_step_sp;
-}
-
-__global__ __launch_bounds__(256) void adam_table_kernel(float *W, float *m, float *v, int n_rows,
-                                                         int h, const int32_t *pos,
-                                                         const float *G, AdamC c) {
-  const int hq = h >> 2;
-  const int64_t tot = (int64_t)n_rows * hq;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
-    const int row = (int)(i / hq), q = (int)(i % hq);
-    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (pos) {
-      const int pr = pos[row];
-      if (pr >= 0) g = *reinterpret_cast<const float4 *>(G + (int64_t)pr * h + q * 4);
-    } else {
-      g = *reinterpret_cast<const float4 *>(G + (int64_t)row * h + q * 4);
-    }
-    float4 p4 = reinterpret_cast<float4 *>(W)[i];
-    float4 m4 = reinterpret_cast<float4 *>(m)[i];
-    float4 v4 = reinterpret_cast<float4 *>(v)[i];
-    adam1(p4.x, m4.x, v4.x, g.x, c);
-    adam1(p4.y, m4.y, v4.y, g.y, c);
-    adam1(p4.z, m4.z, v4.z, g.z, c);
-    adam1(p4.w, m4.w, v4.w, g.w, c);
-    reinterpret_cast<float4 *>(W)[i] = p4;
-    reinterpret_cast<float4 *>(m)[i] = m4;
-    reinterpret_cast<float4 *>(v)[i] = v4;
-  }
-}
-
-// scalar variant (h == 1 tables such as the decoder bias, or h % 4 != 0)
-__global__ __launch_bounds__(256) void adam_table_scalar_kernel(float *W, float *m, float *v,
-                                                                int n_rows, int h,
-                                                                const int32_t *pos,
-                                                                const float *G, AdamC c) {
-  const int64_t tot = (int64_t)n_rows * h;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
-    const int row = (int)(i / h), q = (int)(i % h);
-    float g = 0.f;
-    if (pos) {
-      const int pr = pos[row];
-      if (pr >= 0) g = G[(int64_t)pr * h + q];
-    } else {
-      g = G[i];
-    }
-    float p1 = W[i], m1 = m[i], v1 = v[i];
-    adam1(p1, m1, v1, g, c);
-    W[i] = p1; m[i] = m1; v[i] = v1;
-  }
 }
 
 __global__ __launch_bounds__(256) void adam_rows_kernel(float *W, float *m, float *v, int h,
@@ -181,17 +133,7 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float *X, int rows, 
   }
 }
 
-__global__ __launch_bounds__(256) void gather_rows_kernel(const float *E, const int64_t *rows, int B,
-                                                          int d, int act, float *out, rk_cur_t cur) {
-  if (cur.cursor) rows += rk_cur_local(cur) * B;
-  const int64_t tot = (int64_t)B * d;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
-    const int r = (int)(i / d), q = (int)(i % d);
-    out[i] = rk_act(E[rows[r] * d + q], act);
-  }
-}
-
-// the same gather with max |out| published for the split contractions (rk_amax's contract: the
+// out[r, :] = act(E[rows[r], :]) with max |out| published for the split contractions (rk_amax's contract: the
 // maximum over the 64 slots is what the kernels use): 64 workgroups, workgroup b files ITS maximum
 // under slots[b] -- no atomics, no zeroing pass, one launch instead of two in front of an MF decode
 // rows32 (nullable): rows32[0] <- B, rows32[1 + r] <- rows[r] -- the step's user rows as the int32
@@ -484,29 +426,35 @@ __device__ __forceinline__ void table_sweep_lazy(const UTab &J, const int lb, co
   // (the row index is wave-uniform: through readfirstlane its pos / stamp loads and the replayed steps' constants
   // are scalar loads, the replay loop's trip count a scalar.)  The rows in rotated order, from the round-robin
   // chunk's first row: the long replays start with the launch
+  // the constants of the LAST step a row is brought through (this step's; a flush: the one before): every row needs them
+  const AdamC C_last = tab[(int64_t)(Tl - (a.flush_only ? 1 : 0)) * tstride];
   for (int w = __builtin_amdgcn_readfirstlane(lb * 4 + (int)(threadIdx.x >> 6)); w < J.n_rows; w += n_waves) {
     const int row = w + lo < J.n_rows ? w + lo : w + lo - J.n_rows;
-    const int pr = a.flush_only ? -1 : J.pos[row];
-    const bool have = pr >= 0;
-    const bool need = have || J.pos_next == nullptr || J.pos_next[row] >= 0 || (row >= lo && row < hi);
-    if (!need) continue;
+    // the row's three words in ONE round trip (a short-circuited chain of them was three): its gradient row, the next
+    // step's, its stamp; the row's vectors are then fetched before the stamp is looked at
+    const int pr = (a.flush_only || J.pos == nullptr) ? -1 : J.pos[row];
+    const int pn = J.pos_next ? J.pos_next[row] : 0;
     const int nx = J.stamp[row];
-    if (nx >= end) continue;                                   // (a flush of a row that is current)
-    const int lag = end - nx;                                   // steps to apply: [nx, end)
+    const bool have = pr >= 0;
+    const bool need = have || pn >= 0 || (row >= lo && row < hi);
+    if (!need) continue;
+    const int lag = end - nx;                                   // steps to apply: [nx, end); <= 0: a flush of a current row
     for (uint32_t q = lane; q < hq; q += 64) {
       const uint32_t e = (uint32_t)row * hq + q;
       float4 p1 = J.p[e], m1 = J.m[e], v1 = J.v[e];
       float4 g = V::zero();
       if (have) g = tab_gradient(J, (uint32_t)pr * hq + q, g_parts);
-      for (int k = lag - 1; k >= 0; --k) {                     // step end - 1 - k; k == 0 is step T unless flushing
+      if (lag <= 0) continue;
+      for (int k = lag - 1; k > 0; --k) {                      // the missed steps end - 1 - k, oldest first: g = 0
         const AdamC C = tab[(int64_t)(Tl - (a.flush_only ? 1 : 0) - k) * tstride];
-        const float4 gs = (k == 0 && have) ? g : V::zero();
-        V::adam(p1, m1, v1, gs, C);
+        V::adam(p1, m1, v1, V::zero(), C);
         pmax = fmaxf(pmax, absmax_of<float4>(p1));
       }
+      V::adam(p1, m1, v1, g, C_last);                          // step T with its gradient (a flush: the last missed step)
+      pmax = fmaxf(pmax, absmax_of<float4>(p1));
       J.p[e] = p1; J.m[e] = m1; J.v[e] = v1;
     }
-    if (lane == 0) J.stamp[row] = end;
+    if (lane == 0 && lag > 0) J.stamp[row] = end;
   }
   if (J.amax_out) publish_pmax(J.amax_out, seen, pmax);
 }
@@ -643,25 +591,6 @@ inline int grid_for(int64_t n) {
 
 }  // namespace
 
-extern "C" int rk_adam_table(float *W, float *m, float *v, int32_t n_rows, int32_t h,
-                             const int32_t *pos, const float *G, double lr, double beta1,
-                             double beta2, double eps, double weight_decay, int32_t step,
-                             void *stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  RK_REQUIRE(step >= 1, "step must be >= 1");
-  if (n_rows == 0) return 0;
-  const AdamC c = make_consts(lr, beta1, beta2, eps, weight_decay, step);
-  if (h % 4 == 0 && (((uintptr_t)W | (uintptr_t)m | (uintptr_t)v | (uintptr_t)G) & 15) == 0) {
-    RK_LAUNCH(adam_table_kernel, dim3(grid_for((int64_t)n_rows * h / 4)), dim3(256), 0,
-                       stream, W, m, v, n_rows, h, pos, G, c);
-  } else {
-    RK_LAUNCH(adam_table_scalar_kernel, dim3(grid_for((int64_t)n_rows * h)), dim3(256), 0,
-                       stream, W, m, v, n_rows, h, pos, G, c);
-  }
-  RK_CHECK_LAUNCH("adam_table");
-  return 0;
-}
-
 extern "C" int rk_adam_rows(float *W, float *m, float *v, int32_t h, const int32_t *idx32,
                             const int64_t *idx64, const int32_t *n_dev, int32_t n_cap,
                             const float *G, double lr, double beta1, double beta2, double eps,
@@ -682,20 +611,6 @@ extern "C" int rk_adam_rows(float *W, float *m, float *v, int32_t h, const int32
   RK_LAUNCH(adam_rows_kernel, dim3(grid_for((int64_t)n_cap * h)), dim3(256), 0, stream, W,
                      m, v, h, idx32, idx64, n_dev, n_cap, G, c, cur, ctab, tab_stride, tab_slot);
   RK_CHECK_LAUNCH("adam_rows");
-  return 0;
-}
-
-extern "C" int rk_adam_dense(float *p, float *m, float *v, const float *g, int64_t n, double lr,
-                             double beta1, double beta2, double eps, double weight_decay,
-                             int32_t step, void *stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  RK_REQUIRE(step >= 1, "step must be >= 1");
-  RK_REQUIRE(n < (int64_t)1 << 31, "tensor too large for one call");
-  if (n == 0) return 0;
-  const AdamC c = make_consts(lr, beta1, beta2, eps, weight_decay, step);
-  RK_LAUNCH(adam_table_scalar_kernel, dim3(grid_for(n)), dim3(256), 0, stream, p, m, v,
-                     (int)n, 1, (const int32_t *)nullptr, g, c);
-  RK_CHECK_LAUNCH("adam_dense");
   return 0;
 }
 
@@ -1007,17 +922,5 @@ extern "C" int rk_gather_rows_amax(const float *E, const int64_t *rows, int32_t 
     RK_LAUNCH(gather_rows_amax_kernel<false>, dim3(64), dim3(256), 0, stream, E, rows, B, d, act, out,
               reinterpret_cast<uint32_t *>(slots), rows32, cur);
   RK_CHECK_LAUNCH("gather_rows_amax");
-  return 0;
-}
-
-extern "C" int rk_gather_rows(const float *E, const int64_t *rows, int32_t B, int32_t d,
-                              int32_t act, float *out, void *stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  if (B == 0) return 0;
-  rk_cur_t cur = {nullptr, 0};
-  if (const rk_replay_t *rp = rk_replay_get()) { cur = {rp->cursor, rp->off}; rows = rp->users_base; }
-  RK_LAUNCH(gather_rows_kernel, dim3(grid_for((int64_t)B * d)), dim3(256), 0, stream, E,
-                     rows, B, d, act, out, cur);
-  RK_CHECK_LAUNCH("gather_rows");
   return 0;
 }

@@ -377,7 +377,7 @@ static int step_item_parallel(const rk_ae_step_t *a, int phase) {
 // (csrc/pgemm.h)?  Untied MSE / BCE steps with operand planes and a scale table, outside the fused
 // decode + dZ launch's domain (h > 256 or >= 1024 rows).
 // Returns 0: neither; 1: all three contractions on csrc/pgemm.h; 3: the register-resident fused decode
-// (csrc/fdecode.hip) with its image, dW on rk_pg_dw
+// (csrc/fdecode.hip) with its image, dW on rk_pg_dw  (4, round 5's streaming form of that decode, is gone)
 static int step_pg_mode(const rk_ae_step_t *a) {
   const int phase = a->phase == 0 ? RK_STEP_ALL : a->phase;
   if (a->tied || a->loss_kind == RK_LOSS_MNLL) return 0;
@@ -392,12 +392,6 @@ static int step_pg_mode(const rk_ae_step_t *a) {
       return 3;
     return 0;
   }
-  // 4: the fused decode in its STREAMING form (>= 1024 rows: one dZ slab per group of column tiles), dW from its
-  // image on rk_pg_dw / rk_pg_dw_encode_bwd, the encoder backward alone past the fused launch's row window
-  // (rk_tune RK_TUNE_DW_ENC_FUSED = 2, an A/B switch: the same below 1024 rows -- the one-tile fused decode, dW on
-  // the side stream beside reduce -> encoder backward instead of sharing the encoder backward's launch)
-  if ((a->B >= 1024 || rk_tune_get(RK_TUNE_DW_ENC_FUSED) == 2) && a->ws_dw != nullptr &&
-      rk_fdec_ok(a->B, a->h, a->blk->n_cap, a->loss_kind)) return 4;
   if (rk_decode_dz_fused_ok(a->B, a->h, a->blk->n_cap, a->loss_kind) == 0) return 1;
   // 3: the register-resident fused decode (csrc/fdecode.hip) + rk_pg_dw || encoder backward || image
   // column sums -- when the dW / encoder-backward launch can be the fused one (a->ws_dw, the row window)
@@ -412,10 +406,10 @@ static int step_pg_mode(const rk_ae_step_t *a) {
 // backward launch, h % 32 != 0, and room for one bias slab per K slab in gb_part (the fused decode leaves it unused)
 static bool step_dw_ones(const rk_ae_step_t *a, const int pg_mode) {
   const int phase = a->phase == 0 ? RK_STEP_ALL : a->phase;
-  if (phase != RK_STEP_ALL || !(pg_mode == 3 || pg_mode == 4) || !act_bounded(a->act) || a->gb_part == nullptr) return false;
+  if (phase != RK_STEP_ALL || pg_mode != 3 || !act_bounded(a->act) || a->gb_part == nullptr) return false;
   const rk_block_t *blk = a->blk;
   const int B = a->B, h = a->h;
-  const bool dz_fused = rk_decode_dz_fused_ok(B, h, blk->n_cap, a->loss_kind) != 0 || pg_mode == 4;
+  const bool dz_fused = rk_decode_dz_fused_ok(B, h, blk->n_cap, a->loss_kind) != 0;
   if (!dz_fused || !rk_dw_encode_bwd_fused_ok(a->row_off, B)) return false;      // (the merged dW || encoder backward launch)
   const int row_tiles = rk_cdiv(B, rk_decode_row_tile());
   return rk_tune_get(RK_TUNE_DW_ONES) != 0 && rk_pg_dw_ones_ok(B, h, blk->n_cap) != 0 &&
@@ -471,14 +465,14 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   const int pg_mode = step_pg_mode(a);
   const bool dz_fused = pl && !a->tied && !mnll && a->ws != nullptr && (both ? whole : a->ws_dw != nullptr) &&
                         (phase & (RK_STEP_FWD_DW | RK_STEP_DZ_ENC)) != 0 &&
-                        (rk_decode_dz_fused_ok(B, h, blk->n_cap, a->loss_kind) != 0 || pg_mode == 4);
+                        rk_decode_dz_fused_ok(B, h, blk->n_cap, a->loss_kind) != 0;
   // dW and the encoder backward as ONE launch on the chain instead of a side-stream branch
   // (in the small-shape domain of the fused decode only: at C5's sizes -- dW 100+ us -- the side-stream
   // branch next to dZ -> encoder backward is worth more than its two edges: 0.75 vs 0.83 ms per step)
   const bool dw_enc_fused = dw3 && dz_fused && rk_dw_encode_bwd_fused_ok(a->row_off, B) != 0;
   // the three contractions on the pipelined pair-plane kernels (csrc/pgemm.h; include/recoder_hip.h
   // rk_ae_step_t.do_scales): whole untied MSE / BCE steps outside the fused decode's domain
-  const bool pg = pg_mode == 1, fdec = pg_mode == 3 || pg_mode == 4;
+  const bool pg = pg_mode == 1, fdec = pg_mode == 3;
   const float *dw_slabs_pg = dw_branch ? a->ws_dw : a->ws;
   const bool dw_ones = dw_enc_fused && step_dw_ones(a, pg_mode);
   // opt-in (rk_adam_de_side): the decoder table's Adam sweep right behind the dW kernel ON dw_stream,

@@ -50,7 +50,7 @@ class TimedLib:
     fn = getattr(self._lib, name)
     # (sizing accessors -- plain Python over rk_plan -- and host-only calls are not launches)
     if not name.startswith("rk_") or not hasattr(fn, "argtypes") or name in (
-        "rk_plan", "rk_encode_bwd_segments", "rk_dw3_slabs", "rk_planes_layout", "rk_last_error", "rk_version",
+        "rk_plan", "rk_planes_layout", "rk_last_error", "rk_version",
         "rk_ae_step_uses_pg"):
       return fn
 
@@ -466,8 +466,9 @@ class FusedEngine:
       if want_rows:
         self._users32 = self._users32_buf
     else:
-      check(lib.rk_gather_rows(ptr(m.user_embedding_layer.weight), ptr(users), B, d, self.act,
-                               ptr(self.enc[0]), stream), "rk_gather_rows")
+      if B > 0:
+        check(lib.rk_gather_rows_amax(ptr(m.user_embedding_layer.weight), ptr(users), B, d, self.act,
+                                      ptr(self.enc[0]), None, None, stream), "rk_gather_rows_amax")
     z = self.enc[0]
     if self.drop_active:
       n = B * d
@@ -702,7 +703,7 @@ class FusedEngine:
         return self._entry_train_step(blk, row_off, B, keep_noise, keep_drop, out, global_rows, tgt, main_s)
       finally:
         self._replay = None
-        raw_lib.rk_replay_clear()
+        raw_lib.rk_replay_set(None)
     return self._entry_train_step(blk, row_off, B, keep_noise, keep_drop, out, global_rows, tgt, main_s)
 
   def _entry_train_step(self, blk, row_off, B, keep_noise, keep_drop, out, global_rows, tgt, main_s):
@@ -1226,10 +1227,10 @@ class FusedEngine:
       mode = flags & 15
       self._step_flags = flags     # (bit 4: the bias gradient as output column h of the dW tiles -- recoder_hip.h)
       self._pg_step = bool(mode)
-      self._step_mode = mode       # (0: decode16 / dw3 kernels, 1: csrc/pgemm.h, 3 / 4: csrc/fdecode.hip (4: streaming) + pgemm's dW; bench.py names the kernels by it)
+      self._step_mode = mode       # (0: decode16 / dw3 kernels, 1: csrc/pgemm.h, 3: csrc/fdecode.hip + pgemm's dW; bench.py names the kernels by it)
       check(raw.rk_ae_train_step(ctypes.byref(st)), "rk_ae_train_step")
-      if self.loss_id != LOSS_MNLL and mode not in (3, 4):
-        self._gb_lazy = (cdiv(B, self.row_tile), blk)    # (modes 3 / 4: gb_de itself, from the dO image)
+      if self.loss_id != LOSS_MNLL and mode != 3:
+        self._gb_lazy = (cdiv(B, self.row_tile), blk)    # (mode 3: gb_de itself, from the dO image)
       elif flags & 16:
         self._gb_lazy = ("slabs", blk)                   # (... or one slab per K slab of dW in gb_part)
     else:

@@ -176,29 +176,6 @@ def test_loss_kernels_publish_max_gradient(loss_name):
   assert want > 0
 
 
-def test_dw_slabs_contract():
-  """rk_dw_splits / G_de == NULL: leaving the dW split-K slabs unsummed is only valid when the call
-  cuts K at all; otherwise the entry point refuses (error code + message, nothing launched)."""
-  from recoder_amd import _lib
-  from recoder_amd._lib import ptr
-  from recoder_amd.device import current_stream
-  lib = _lib.load()
-  dev = torch.device("cuda")
-  assert lib.rk_dw_splits(500) == 1 and lib.rk_dw_splits(4000) > 1
-  B, h, n_t, n_items = 200, 64, 300, 2000
-  blk, _ = _block(B, n_items, n_t, dev, seed=4)
-  f = dict(dtype=torch.float32, device=dev)
-  dO = torch.zeros(B * blk.ld_cap, **f)
-  Z = torch.zeros(B * h, **f)
-  dZ = torch.zeros(B * h, **f)
-  G_en = torch.zeros(blk.n_cap * h, **f)
-  ws = torch.zeros(max(4, lib.rk_dw_workspace_bytes(B, h, blk.n_cap) // 4), **f)
-  rc = lib.rk_decode_bwd_dw_encode_bwd(ptr(dO), ptr(Z), B, h, blk.ref, None, 0, ptr(dZ), ptr(G_en), None,
-                                       ptr(ws), current_stream())
-  assert rc < 0
-  assert b"rk_dw_splits" in lib.rk_last_error()
-
-
 # ---------------------------------------------------------------------------------------------
 # bf16-pipe dW (csrc/dw3.hip): three bf16 pieces per fp32 operand, six products, no operand range
 # ---------------------------------------------------------------------------------------------
@@ -298,27 +275,3 @@ def test_dw3_has_no_operand_range(gtop, ztop):
   assert err < max(5e-7, 1.05 * err32), (err, err32)
 
 
-def test_split_planes_t_is_exact():
-  """x = hi + mid + lo exactly (the three bf16 planes) for every fp32 whose pieces stay above the
-  subnormal range (|x| >= 2^-100 or so), zero padding."""
-  from recoder_amd import _lib
-  from recoder_amd._lib import check, ptr
-  from recoder_amd.device import current_stream
-  lib = _lib.load()
-  dev = torch.device("cuda")
-  rows, cols, rp, cp = 37, 21, 64, 128
-  g = torch.Generator(device="cpu").manual_seed(1)
-  X = (torch.randn(rows, cols, generator=g) * 10.0 ** (torch.rand(rows, cols, generator=g) * 12 - 6)).float()
-  X[0, 0] = 0.0
-  X[1, 1] = 3.0e38
-  X[2, 2] = 1.0e-30
-  planes = torch.zeros(3 * rp * cp, dtype=torch.int16, device=dev)
-  planes.fill_(0x7fc0)                     # NaN pattern: the padding must be overwritten
-  check(lib.rk_split_planes_t(ptr(X.to(dev)), rows, cols, cols, rp, cp, ptr(planes), current_stream()),
-        "rk_split_planes_t")
-  p = planes.view(3, rp // 8, cp, 8).cpu()
-  as_f32 = (p.to(torch.int32) << 16).view(torch.float32).double()          # bf16 -> fp32 bits
-  tot = as_f32.sum(0)                                                      # [k/8][n][8]
-  back = tot.permute(0, 2, 1).reshape(rp, cp)                               # [k][n]
-  assert torch.equal(back[:rows, :cols], X.double())
-  assert (back[rows:] == 0).all() and (back[:, cols:] == 0).all()

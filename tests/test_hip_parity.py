@@ -470,21 +470,6 @@ def _fuzz_cases(n=20, seed=2024):
 STEP_CASES += _fuzz_cases(40)
 
 
-@pytest.mark.parametrize("name", ["big_then_ragged_ae64", "ragged_1024_after_1100_ae64", "mse_dense_h200"])
-def test_steps_match_oracle_with_the_streaming_fused_decode(name):
-  """Whole steps on the STREAMING fused decode (rk_tune RK_TUNE_FDEC_STREAM: 1 = batches of >= 1024 rows --
-  rk_ae_train_step's mode 4: one dZ slab per group of column tiles, dW from the image on rk_pg_dw /
-  rk_pg_dw_encode_bwd --, 2 = every batch) against the oracle: the step cases with large batches."""
-  from recoder_amd import _lib
-  lib = _lib.load()
-  case = next(x for x in STEP_CASES if x[0] == name) if name != "mse_dense_h200" else STEP_CASES[0]
-  lib.rk_tune(11, 2 if name == "mse_dense_h200" else 1)
-  try:
-    test_steps_match_oracle(*case)
-  finally:
-    lib.rk_tune(11, 0)
-
-
 @pytest.mark.parametrize("name,c,shape,B,S", STEP_CASES, ids=[x[0] for x in STEP_CASES])
 def test_steps_match_oracle(name, c, shape, B, S):
   from recoder_amd.data import RecommendationDataset

@@ -80,7 +80,7 @@ def test_lazy_sweeps_equal_dense_sweeps_bit_for_bit(wd, period, h):
       try:
         check(lib.rk_adam_multi(ctypes.byref(j), 1, None, 0, 1.0, None, stream), "rk_adam_multi")
       finally:
-        lib.rk_replay_clear()
+        lib.rk_replay_set(None)
       if lazy:
         st = stamp.cpu().numpy()
         assert st.max() == base + t + 1 and st.min() >= base + t + 1 - period

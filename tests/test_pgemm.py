@@ -216,22 +216,6 @@ def test_fdec_matches_the_lds_fused_decode(B, h, n_items, loss, ratings):
   _fdec_case(B, h, n_items, loss, ratings)
 
 
-@pytest.mark.parametrize("B,h,n_items,loss,ratings", [(500, 200, 3000, LOSS_MSE, False), (37, 20, 400, LOSS_BCE, False),
-                                                      (700, 200, 20000, LOSS_MSE, False), (900, 128, 9000, LOSS_BCE, True),
-                                                      (513, 64, 12000, LOSS_MSE, True), (130, 128, 2000, LOSS_MSE, True)])
-def test_fdec_streaming_form(B, h, n_items, loss, ratings):
-  """The same checks on the STREAMING form (rk_tune RK_TUNE_FDEC_STREAM = 2: a workgroup walks a group of column
-  tiles with the dZ accumulators in registers, one slab per group, rescaled between tiles) -- shapes with one
-  and with several tiles per group."""
-  from recoder_amd import _lib
-  lib = _lib.load()
-  lib.rk_tune(11, 2)
-  try:
-    _fdec_case(B, h, n_items, loss, ratings)
-  finally:
-    lib.rk_tune(11, 0)
-
-
 def _fdec_case(B, h, n_items, loss, ratings):
   """rk_fdec_loss_dz (register-resident fused decode: transposed tile, permlane32 fragments, resident W
   rows) against rk_decode_loss_dz_planes: the same logits bit for bit (so the same dO up to the image's

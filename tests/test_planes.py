@@ -324,7 +324,7 @@ def test_split_wz_is_the_two_split_launches(B, h, n_items):
 
 @pytest.mark.parametrize("B,d,act", [(500, 128, 0), (37, 20, 3), (1, 8, 4), (1000, 64, 1)])
 def test_gather_rows_amax_is_gather_plus_amax(B, d, act):
-  """rk_gather_rows_amax == rk_gather_rows followed by rk_amax: the same rows, and the maximum over the
+  """rk_gather_rows_amax == a gather (torch) followed by rk_amax: the same rows, and the maximum over the
   64 published slots (what the split kernels use) is max |out| exactly."""
   lib = _lib.load()
   dev = torch.device("cuda")
@@ -337,17 +337,21 @@ def test_gather_rows_amax_is_gather_plus_amax(B, d, act):
   out1 = torch.empty(B * d, device=dev)
   r0 = torch.full((128,), 7, dtype=torch.int32, device=dev)
   r1 = torch.full((128,), 7, dtype=torch.int32, device=dev)
-  check(lib.rk_gather_rows(ptr(E), ptr(rows), B, d, act, ptr(out0), st))
+  out0 = E[rows].contiguous()
+  out0 = {0: out0, 1: torch.tanh(out0), 3: torch.relu(out0),
+          4: torch.nn.functional.selu(out0)}[act].reshape(-1).contiguous()
   check(lib.rk_amax(ptr(out0), B * d, ptr(r0), st))
   r32 = torch.full((B + 3,), -5, dtype=torch.int32, device=dev)
   check(lib.rk_gather_rows_amax(ptr(E), ptr(rows), B, d, act, ptr(out1), ptr(r1), ptr(r32), st))
   out2 = torch.empty(B * d, device=dev)
   check(lib.rk_gather_rows_amax(ptr(E), ptr(rows), B, d, act, ptr(out2), None, None, st))   # plain gather
   torch.cuda.synchronize()
-  assert torch.equal(out0, out1) and torch.equal(out0, out2)
+  assert torch.equal(out1, out2)
+  assert torch.allclose(out0, out1, rtol=2e-6, atol=1e-7)            # (tanh / selu: torch's vs the library's)
   # the rows as an int32 index array behind their count (a SparseAdam job's rows / n_dev)
   assert int(r32[0]) == B and torch.equal(r32[1:B + 1].long(), rows) and bool((r32[B + 1:] == -5).all())
-  assert int(r0[:64].max()) == int(r1[:64].max()) == int(out0.abs().max().view(torch.int32))
+  assert int(r1[:64].max()) == int(out1.abs().max().view(torch.int32))
+  assert abs(int(r0[:64].max()) - int(r1[:64].max())) <= 4           # (bit patterns: a few ulp between the two tanh)
   assert torch.equal(r0[64:], r1[64:])            # the W half is not touched
 
 

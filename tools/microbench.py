@@ -4,13 +4,15 @@
     python tools/microbench.py [B ...]
 
 Times rk_decode_loss (MSE epilogue vs plain store), rk_decode_bwd_dz,
-rk_decode_bwd_dw, rk_ae_encode_fwd/bwd and rk_adam_table with HIP events, for the
+rk_decode_bwd_dw, rk_ae_encode_fwd/bwd and a dense-Adam table job of rk_adam_multi with HIP events, for the
 C2 shape (ML-20M-like items, h = 200) at several batch sizes.
 """
 import os
 import sys
 
 import numpy as np
+import ctypes
+
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -94,15 +96,12 @@ def main():
     r["enc_fwd"] = timeit(lambda: check(lib.rk_ae_encode_fwd(
         blk.ref, 0, B, ptr(W), ptr(bias), h, None, 0.5, 1, 1, ptr(users), 1, ptr(Z0), st)))
     r["enc_bwd"] = timeit(lambda: check(lib.rk_ae_encode_bwd(blk.ref, 0, B, ptr(dZ), h, ptr(G), 0, None, st)))
-    nseg = lib.rk_encode_bwd_segments(B)
-    Gs = torch.empty(blk.n_cap * h * nseg, **f)
-    wsd = torch.empty(max(4, lib.rk_dw_workspace_bytes(B, h, blk.n_cap) // 4), **f)
-    r["dw+enc_bwd"] = timeit(lambda: check(lib.rk_decode_bwd_dw_encode_bwd(
-        ptr(dO), ptr(Z), B, h, blk.ref, ptr(G), 0, ptr(dZ), ptr(Gs), None, ptr(wsd), st)))
-    r["dw+enc_nosplit"] = timeit(lambda: check(lib.rk_decode_bwd_dw_encode_bwd(
-        ptr(dO), ptr(Z), B, h, blk.ref, ptr(G), 0, ptr(dZ), ptr(Gs), None, None, st)))
-    r["adam_tab"] = timeit(lambda: check(lib.rk_adam_table(
-        ptr(W), ptr(m), ptr(v), n_items, h, ptr(blk.pos), ptr(G), 1e-3, 0.9, 0.999, 1e-8, 2e-5, 1, st)))
+    from recoder_amd._lib import RkAdamJob
+    job = RkAdamJob()
+    job.par.p, job.par.m, job.par.v = ptr(W), ptr(m), ptr(v)
+    job.par.lr, job.par.beta1, job.par.beta2, job.par.eps, job.par.weight_decay, job.par.step = 1e-3, 0.9, 0.999, 1e-8, 2e-5, 1
+    job.n_rows, job.h, job.pos, job.g, job.g_parts = n_items, h, ptr(blk.pos), ptr(G), 1
+    r["adam_tab"] = timeit(lambda: check(lib.rk_adam_multi(ctypes.byref(job), 1, None, 0, 1.0, None, st)))
     gf = 2.0 * B * h * n_b / 1e9
     print("B=%5d n_b=%6d nnz=%7d | " % (B, n_b, nnz) +
           " ".join("%s %.1fus" % (k, t) for k, t in r.items()) +

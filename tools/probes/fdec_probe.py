@@ -73,18 +73,6 @@ def main():
   print("C2-shaped block: B = %d, h = %d, n_b = %d" % (B, h, n_b))
   print("decode16 fused (LDS dO tile, W^T stage): %.1f us" % timeit(old))
   print("fdec (register resident, W rows resident in LDS): %.1f us" % timeit(fdec))
-  lib.rk_tune(11, 2)            # RK_TUNE_FDEC_STREAM: the streaming form (one slab per group of column tiles)
-  ws_s = torch.zeros(lib.rk_fdec_workspace_bytes(B, h, blk.n_cap) // 4 + 64, **f)
-  def fdec_s():
-    check(lib.rk_fdec_loss_dz(ctypes.byref(pl), B, blk.ref, 0, ptr(bias), LOSS_MSE, 0.0, 1.0 / B, ptr(img), rows_img,
-                              ptr(sc), ptr(part), ptr(ws_s), st))
-  print("fdec, streaming form (%d row tiles x groups of column tiles, %d tiles live): %.1f us" % (
-      -(-B // 128), -(-B // 128) * -(-n_b // 128), timeit(fdec_s)))
-  dZs = torch.zeros(B * h, **f)
-  fdec_s()
-  print("rk_fdec_dz_reduce of its slabs: %.1f us" % timeit(lambda: check(lib.rk_fdec_dz_reduce(
-      ptr(ws_s), B, h, blk.ref, ptr(Z), 1, ptr(dZs), st))))
-  lib.rk_tune(11, 0)
   # the launches behind it in the C2 step, each alone (same flush in front of every launch)
   dZ = torch.zeros(B * h, **f)
   slabs = torch.zeros(lib.rk_pg_dw_workspace_bytes(B, h, blk.n_cap) // 4 + 64, **f)

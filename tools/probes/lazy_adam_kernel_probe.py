@@ -60,7 +60,7 @@ def run(lazy, cold):
     e0.record()
     check(lib.rk_adam_multi(jobs, 2, None, 0, 1.0, None, stream), "rk_adam_multi")
     e1.record()
-    lib.rk_replay_clear()
+    lib.rk_replay_set(None)
     torch.cuda.synchronize()
     times.append(e0.elapsed_time(e1) * 1000)
     if lazy:
