@@ -669,8 +669,11 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
     // lazy dense Adam of the embedding tables (rk_adam_job_t.lazy_stamp): rows without a gradient that the next
     // step does not read are caught up later
     if (a->lazy_stamp_en) {
-      RK_REQUIRE(whole && a->cursor != nullptr && a->zero_hi == 0 && a->lazy_period >= 1 && (a->tied || a->lazy_stamp_de),
-                 "lazy Adam: whole replayed steps, both stamp arrays, lazy_period >= 1");
+      // (whole steps, or the UPDATE call of a phased data-parallel step with the replicated update: every rank sweeps
+      // the same rows of identical tables)
+      RK_REQUIRE((whole || phase == RK_STEP_UPDATE) && a->cursor != nullptr && a->zero_hi == 0 && a->zero_gb_de == nullptr &&
+                 a->lazy_period >= 1 && (a->tied || a->lazy_stamp_de),
+                 "lazy Adam: replayed steps with the replicated update, both stamp arrays, lazy_period >= 1");
       for (int k = 0; k < n; ++k) {
         if (jobs[k].par.sparse) continue;
         jobs[k].lazy_stamp = slots[k] == RK_PAR_W_DE ? a->lazy_stamp_de : a->lazy_stamp_en;

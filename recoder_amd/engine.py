@@ -280,9 +280,15 @@ class FusedEngine:
     optim.Adam on a dense embedding gradient (model.py:135,398-399) touches every row every step; rows outside
     the step's item set that the next step does not read are caught up later by replaying their missed
     steps bit for bit (csrc/optim.hip update_job_lazy)."""
-    if (self.lazy_period < 1 or self.kind != "ae" or self.allreduce is not None or self.item_parallel is not None or
+    if (self.lazy_period < 1 or self.kind != "ae" or self.item_parallel is not None or
         self.h[0] % 4 != 0 or bool(_lib.load().rk_adam_de_side())):
       return []
+    if self.allreduce is not None:
+      # users-DP: the replicated update only (every rank sweeps the same rows of identical tables; the blocks' item
+      # maps are the union sets, equal on all ranks) -- not the sharded / per-rank-item-set / owned-row variants
+      dp = self.allreduce
+      if (getattr(self, "zero_adam", False) or getattr(dp, "local_sets", False) or getattr(self, "owned_rows", False)):
+        return []
     names = ["en_embedding_layer.weight"] + ([] if self.model.is_constrained else ["de_embedding_layer.weight"])
     if not all(n in self.states and not self.states[n].sparse for n in names):
       return []
@@ -1155,7 +1161,7 @@ class FusedEngine:
     st.lazy_stamp_en = st.lazy_stamp_de = st.lazy_pos_next = None
     st.lazy_period = 0
     lz = replay.get("lazy") if replay is not None else None
-    if lz is not None and dp is None and self.item_parallel is None:
+    if lz is not None and self.item_parallel is None:
       # (the stepper knows the next step's block: rows without a gradient that it does not read are caught up later)
       st.lazy_stamp_en = ptr(self.lazy_stamp("en_embedding_layer.weight"))
       if not m.is_constrained:

@@ -87,7 +87,7 @@ class GraphStepper:
     self.epoch_base = 0
     # lazy dense Adam (engine.lazy_tables): a step's sweep skips the rows that neither carry a gradient nor are
     # read by the NEXT step -- whose block this stepper has collated by then; run() leaves every row up to date
-    self.lazy = list(engine.lazy_tables()) if (self.dp is None and self.G >= 2) else []
+    self.lazy = list(engine.lazy_tables()) if self.G >= 2 else []
     self.ev_join_early = self.lib.rk_event_create(0)
     self._stamps_at = None                 # global step at which every stamp says "up to date"
     self.lazy_flushes = 0
