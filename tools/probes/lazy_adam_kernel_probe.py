@@ -1,6 +1,6 @@
 """rk_adam_multi's lazy sweep against its dense sweep IN ISOLATION at the C2 shape (two 20108 x 200 tables, item sets
-drawn like the synthetic ML-20M matrix), hot (back to back) and cold (1 GB streamed in between):
-    python tools/probes/lazy_adam_kernel_probe.py [period]"""
+drawn like the synthetic ML-20M matrix) or C3's (41140 items), hot (back to back) and cold (1 GB streamed in between):
+    python tools/probes/lazy_adam_kernel_probe.py [period] [hot|cold|both] [c2|c3]"""
 import ctypes
 import sys
 
@@ -14,7 +14,8 @@ from recoder_amd._lib import RkAdamJob, RkReplay, check, ptr
 period = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 lib = _lib.load()
 dev = torch.device("cuda")
-m = synthetic.ml20m_like()
+cfg = sys.argv[3] if len(sys.argv) > 3 else "c2"
+m = synthetic.ml20m_like() if cfg == "c2" else synthetic.msd_like(n_users=200000)
 N, h, B = m.shape[1], 200, 500
 rng = np.random.RandomState(0)
 order = rng.permutation(m.shape[0])
@@ -68,7 +69,7 @@ def run(lazy, cold):
   return np.median(times[20:]), (np.mean(rows[20:]) / N if rows else 1.0)
 
 
-modes = {'hot': (False,), 'cold': (True,)}.get(sys.argv[2] if len(sys.argv) > 2 else '', (False, True))
+modes = {'hot': (False,), 'cold': (True,)}.get(sys.argv[2] if len(sys.argv) > 2 else 'both', (False, True))
 for cold in modes:
   d, _ = run(False, cold)
   z, frac = run(True, cold)
