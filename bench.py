@@ -445,6 +445,9 @@ def main():
   ap.add_argument("--no-precollate", action="store_true", help="first group's collation inside the timed region")
   ap.add_argument("--no-pretouch", action="store_true", help="no touch of the optimizer state in front of the clock")
   ap.add_argument("--no-tails", action="store_true", help="the last steps in front of a cut launch by launch, not as a captured tail graph")
+  ap.add_argument("--eager-groups", action="store_true",
+                  help="(PMC passes) every group of steps enqueued launch by launch through the graph stepper -- the "
+                       "replayed steps' kernels and arguments (lazy Adam included), without hipGraphLaunch")
   ap.add_argument("--pretouch-reps", type=int, default=8, help="passes of that touch (~0.3 ms each)")
   ap.add_argument("--prewarm", type=float, default=0.0, help="seconds of untimed extra steps in front of the warmup")
   ap.add_argument("--alt", choices=("auto", "0", "1"), default="auto",
@@ -535,7 +538,7 @@ def main():
     # warm-up: the first group of steps runs eagerly with every launch group bracketed, the rest
     # replays the captured graphs (so that the timed region starts with warm graphs)
     # (i counts from 0 on the graph path and from 1 on the eagerly sequenced ones: <= covers both)
-    return "all" if i <= min(G, max(1, W // 2)) else None
+    return "all" if i <= min(G, max(1, W // 2)) else ("eager" if args.eager_groups else None)
 
   # Where the launch groups behind `roofline.kernels` are bracketed with HIP events: by default in the
   # G steps right BEHIND the clock (same process, same state, `sampled` says so) -- event records are
@@ -562,7 +565,7 @@ def main():
     # timed region: ONE whole group is enqueued eagerly with every launch group bracketed;
     # everything else is graph replay
     if SAMPLE_POST:
-      return "all" if W + K <= i < W + K + G else None
+      return "all" if W + K <= i < W + K + G else ("eager" if args.eager_groups else None)
     # -- and of that group only as many steps as a 5 % sample of K (every bracket costs two event
     # records = two barrier packets in the queue)
     last = bracket_first(K)
