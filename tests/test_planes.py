@@ -474,3 +474,24 @@ def test_encoder_backward_over_row_windows(B, h, n_items, row_off):
   got = G_en[:n_b * h].view(n_b, h).double().cpu().numpy()
   assert np.abs(got - want).max() <= 1e-6 * max(np.abs(want).max(), 1e-30)
   assert np.abs(gb[:h].double().cpu().numpy() - dz.sum(0)).max() <= 1e-5 * np.abs(dz).sum(0).max()
+
+
+def test_zero_tail_rows_clears_exactly_the_rows_past_the_live_count():
+  """rk_zero_tail_rows: rows [n_b, n_cap) of up to four compact [n_cap, h] arrays <- 0 with n_b read on the
+  device -- what a replayed data-parallel step does in front of its capacity-sized, in-place summed exchange."""
+  lib = _lib.load()
+  dev = torch.device("cuda")
+  st = current_stream()
+  n_cap = 777
+  for n_b in (0, 1, 300, 776, 777, 900):
+    counts = torch.tensor([n_b, 0, 0, 0], dtype=torch.int32, device=dev)
+    widths = [200, 1, 64, 8]
+    arrs = [torch.full((n_cap * w + 5,), 3.0, device=dev) for w in widths]       # (+5: nothing past the array is touched)
+    X = (ctypes.c_void_p * 4)(*[a.data_ptr() for a in arrs])
+    H = (ctypes.c_int32 * 4)(*widths)
+    check(lib.rk_zero_tail_rows(X, H, 4, ptr(counts), n_cap, st))
+    torch.cuda.synchronize()
+    live = min(max(n_b, 0), n_cap)
+    for a, w in zip(arrs, widths):
+      assert bool((a[:live * w] == 3.0).all()) and bool((a[live * w:n_cap * w] == 0.0).all())
+      assert bool((a[n_cap * w:] == 3.0).all())
