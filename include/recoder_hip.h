@@ -640,11 +640,13 @@ int rk_adam_lazy_flush(const rk_adam_job_t *jobs, int32_t n_jobs, const void *ta
  * bias gradient). */
 int rk_rows_to_dense(const float *G, const int32_t *pos, int32_t n_items, int32_t rows_pad, int32_t h,
                      float *D, void *stream);
-/* X_k[n_b * h_k .. n_cap * h_k) <- 0 for n_arrays <= 4 compact [n_cap, h_k] gradient arrays, n_b = counts[0] read on the
+/* X_k[n_b * h_k .. top * h_k) <- 0 for n_arrays <= 4 compact [n_cap, h_k] gradient arrays, n_b = counts[0] read on the
  * device.  Replayed data-parallel steps exchange the blocks' whole capacity (a captured collective has a fixed size)
- * summed in place: the rows past the live items, which no kernel rewrites, must be zero going in. */
+ * summed in place: the rows past the live items, which no kernel rewrites, must be zero going in.  high_water
+ * (nullable device int32; 0 for freshly zeroed arrays): rows at or past it are known to be zero; top = max(*high_water,
+ * n_b) is stored back -- a step clears what a larger earlier item set left behind, not the whole tail.  NULL: top = n_cap. */
 int rk_zero_tail_rows(float *const *X, const int32_t *h, int32_t n_arrays, const int32_t *counts, int32_t n_cap,
-                      void *stream);
+                      int32_t *high_water, void *stream);
 
 typedef struct rk_ae_step {
   const rk_block_t *blk;

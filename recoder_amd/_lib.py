@@ -145,7 +145,7 @@ SIGNATURES = {
                                          c_uint64, _P, _P, _P, _P]),
   "rk_bias_act": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P]),
   "rk_rows_to_dense": (c_int32, [_P, _P, c_int32, c_int32, c_int32, _P, _P]),
-  "rk_zero_tail_rows": (c_int32, [POINTER(c_void_p), POINTER(c_int32), c_int32, _P, c_int32, _P]),
+  "rk_zero_tail_rows": (c_int32, [POINTER(c_void_p), POINTER(c_int32), c_int32, _P, c_int32, _P, _P]),
   "rk_densify": (c_int32, [_BLK, c_int32, c_int32, c_int32, _P, c_int32, _P]),
   "rk_ae_encode_fwd": (c_int32, [_BLK, c_int32, c_int32, _P, _P, c_int32, _P, c_float, c_uint64,
                                  c_uint64, _P, c_int32, _P, _P]),

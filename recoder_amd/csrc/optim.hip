@@ -12,6 +12,8 @@
 //            rows only (model.py:138,401-402): no weight decay, eps added to
 //            the raw sqrt, bias correction folded into the step size.
 #include <stdlib.h>
+
+#include <algorithm>
 #include <string.h>
 
 #include "common.h"
@@ -834,23 +836,29 @@ extern "C" int rk_rows_to_dense(const float *G, const int32_t *pos, int32_t n_it
 
 namespace {
 struct ZeroTails { float *x[4]; int h[4]; int n; };
-__global__ __launch_bounds__(256) void zero_tail_rows_kernel(ZeroTails z, const int32_t *counts, int n_cap) {
+__global__ __launch_bounds__(256) void zero_tail_rows_kernel(ZeroTails z, const int32_t *counts, int n_cap, int32_t *hwm) {
   const int n_b = min(max(counts[0], 0), n_cap);
+  // (hwm: rows at or past it are known to be zero; whichever value a workgroup reads -- the old one or the one
+  // workgroup 0 is about to write -- max(hwm, n_b) is the same bound)
+  const int top = hwm ? min(max(*hwm, n_b), n_cap) : n_cap;
   for (int k = 0; k < z.n; ++k) {
     float *x = k == 0 ? z.x[0] : k == 1 ? z.x[1] : k == 2 ? z.x[2] : z.x[3];
     const int h = k == 0 ? z.h[0] : k == 1 ? z.h[1] : k == 2 ? z.h[2] : z.h[3];
-    const int64_t lo = (int64_t)n_b * h, hi = (int64_t)n_cap * h;
+    const int64_t lo = (int64_t)n_b * h, hi = (int64_t)top * h;
     for (int64_t i = lo + (int64_t)blockIdx.x * 256 + threadIdx.x; i < hi; i += (int64_t)gridDim.x * 256) x[i] = 0.f;
   }
+  if (hwm && blockIdx.x == 0 && threadIdx.x == 0) *hwm = top;
 }
 }  // namespace
 
-// X_k[n_b * h_k .. n_cap * h_k) <- 0 for up to four [n_cap, h_k] arrays, n_b = counts[0] read on the device: the
+// X_k[n_b * h_k .. top * h_k) <- 0 for up to four [n_cap, h_k] arrays, n_b = counts[0] read on the device: the
 // rows of the compact gradient arrays past the block's live items.  A REPLAYED data-parallel step exchanges the
 // blocks' whole capacity (a captured collective has a fixed size) and sums in place: rows nobody rewrites would be
-// multiplied by the world size every step.
+// multiplied by the world size every step.  high_water (nullable, device int32, 0 for freshly zeroed
+// arrays): the rows at or past it are known to be zero -- top = max(*high_water, n_b), which the call stores back;
+// a step then clears the few rows a LARGER earlier item set left behind, not the whole tail (NULL: top = n_cap).
 extern "C" int rk_zero_tail_rows(float *const *X, const int32_t *h, int32_t n_arrays, const int32_t *counts,
-                                 int32_t n_cap, void *stream_) {
+                                 int32_t n_cap, int32_t *high_water, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RK_REQUIRE(n_arrays >= 0 && n_arrays <= 4 && (n_arrays == 0 || (X && h && counts)), "at most four arrays");
   if (n_arrays == 0 || n_cap == 0) return 0;
@@ -861,7 +869,9 @@ extern "C" int rk_zero_tail_rows(float *const *X, const int32_t *h, int32_t n_ar
     z.x[k] = X[k]; z.h[k] = h[k]; hmax = h[k] > hmax ? h[k] : hmax;
   }
   z.n = n_arrays;
-  RK_LAUNCH(zero_tail_rows_kernel, dim3(grid_for((int64_t)n_cap * hmax / 8)), dim3(256), 0, stream, z, counts, n_cap);
+  // (with a high-water mark the range is a few hundred rows: a small grid)
+  const int grid = high_water ? std::min(grid_for((int64_t)n_cap * hmax / 8), 128) : grid_for((int64_t)n_cap * hmax / 8);
+  RK_LAUNCH(zero_tail_rows_kernel, dim3(grid), dim3(256), 0, stream, z, counts, n_cap, high_water);
   RK_CHECK_LAUNCH("zero_tail_rows");
   return 0;
 }

@@ -160,6 +160,8 @@ class FusedEngine:
     # per-granule split scales of that image (rk_pg_decode_loss)
     self.do_scales = torch.ones(self.lib.rk_pg_scale_floats(B_cap, n_cap), **f)
     self.G_de = torch.zeros(n_cap * h0, **f)
+    # rows of the compact gradient arrays at or past this mark are zero (rk_zero_tail_rows, data-parallel replay)
+    self._grad_hwm = torch.zeros(1, dtype=torch.int32, device=dev)
     # MF: [B | the step's user rows as int32] left by the forward's gather for the SparseAdam job of
     # the user table (rk_gather_rows_amax)
     self._users32_buf = torch.zeros(B_cap + 1, dtype=torch.int32, device=dev) if self.kind == "mf" else None
@@ -1340,7 +1342,9 @@ class FusedEngine:
     n = len(arrays)
     X = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in arrays])
     H = (ctypes.c_int32 * n)(*[int(w) for _, w in arrays])
-    check(self.lib.rk_zero_tail_rows(X, H, n, ptr(blk.counts), blk.n_cap, stream), "rk_zero_tail_rows")
+    # (the arrays are allocated zeroed: ensure_capacity resets the high-water mark with them)
+    check(self.lib.rk_zero_tail_rows(X, H, n, ptr(blk.counts), min(blk.n_cap, self.n_cap), ptr(self._grad_hwm), stream),
+          "rk_zero_tail_rows")
 
   def _dense_grad_buffers(self, n_items, h0):
     """(per-rank item sets without sharding) the two tables' gradients laid out by item id, all-reduced in place"""

@@ -477,21 +477,38 @@ def test_encoder_backward_over_row_windows(B, h, n_items, row_off):
 
 
 def test_zero_tail_rows_clears_exactly_the_rows_past_the_live_count():
-  """rk_zero_tail_rows: rows [n_b, n_cap) of up to four compact [n_cap, h] arrays <- 0 with n_b read on the
-  device -- what a replayed data-parallel step does in front of its capacity-sized, in-place summed exchange."""
+  """rk_zero_tail_rows: rows [n_b, top) of up to four compact [n_cap, h] arrays <- 0 with n_b read on the
+  device -- what a replayed data-parallel step does in front of its capacity-sized, in-place summed exchange.  Without a
+  high-water mark top = n_cap; with one, top = max(mark, n_b) and the mark moves up."""
   lib = _lib.load()
   dev = torch.device("cuda")
   st = current_stream()
   n_cap = 777
+  widths = [200, 1, 64, 8]
   for n_b in (0, 1, 300, 776, 777, 900):
     counts = torch.tensor([n_b, 0, 0, 0], dtype=torch.int32, device=dev)
-    widths = [200, 1, 64, 8]
     arrs = [torch.full((n_cap * w + 5,), 3.0, device=dev) for w in widths]       # (+5: nothing past the array is touched)
     X = (ctypes.c_void_p * 4)(*[a.data_ptr() for a in arrs])
     H = (ctypes.c_int32 * 4)(*widths)
-    check(lib.rk_zero_tail_rows(X, H, 4, ptr(counts), n_cap, st))
+    check(lib.rk_zero_tail_rows(X, H, 4, ptr(counts), n_cap, None, st))
     torch.cuda.synchronize()
     live = min(max(n_b, 0), n_cap)
     for a, w in zip(arrs, widths):
       assert bool((a[:live * w] == 3.0).all()) and bool((a[live * w:n_cap * w] == 0.0).all())
       assert bool((a[n_cap * w:] == 3.0).all())
+  # with the mark: a sequence of steps whose live rows are rewritten with "gradients" and whose tails must read zero
+  hwm = torch.zeros(1, dtype=torch.int32, device=dev)
+  arrs = [torch.zeros(n_cap * w, device=dev) for w in widths]
+  X = (ctypes.c_void_p * 4)(*[a.data_ptr() for a in arrs])
+  H = (ctypes.c_int32 * 4)(*widths)
+  top = 0
+  for step, n_b in enumerate((400, 380, 500, 120, 777, 300, 301)):
+    for a, w in zip(arrs, widths):
+      a[:n_b * w] = float(step + 1)                       # the step's kernels rewrite the live rows only
+    counts = torch.tensor([n_b, 0, 0, 0], dtype=torch.int32, device=dev)
+    check(lib.rk_zero_tail_rows(X, H, 4, ptr(counts), n_cap, ptr(hwm), st))
+    torch.cuda.synchronize()
+    top = max(top, n_b)
+    assert int(hwm[0]) == top
+    for a, w in zip(arrs, widths):
+      assert bool((a[:n_b * w] == float(step + 1)).all()) and bool((a[n_b * w:] == 0.0).all())
