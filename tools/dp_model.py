@@ -28,6 +28,26 @@ def union_sizes(csr, B, world, steps, seed=0):
   return float(np.mean(out))
 
 
+def swept_frac(csr, B, world, steps, period=16, seed=0):
+  """Fraction of a table's rows a LAZY dense-Adam sweep brings up to date (round 6): the union item sets of two
+  consecutive global batches + the round-robin chunk."""
+  n, n_items = csr.shape
+  per = n // world
+  sets = []
+  for k in range(steps + 1):
+    rows = [np.random.RandomState(seed + 1000 * r).permutation(per)[k * B:(k + 1) * B] + r * per for r in range(world)]
+    sets.append(np.unique(csr[np.concatenate(rows)].indices))
+  out = []
+  for k in range(steps):
+    m = np.zeros(n_items, dtype=bool)
+    m[sets[k]] = True
+    m[sets[k + 1]] = True
+    c = k % period
+    m[c * n_items // period:(c + 1) * n_items // period] = True
+    out.append(m.mean())
+  return float(np.mean(out))
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--bw", type=float, default=300.0, help="GB/s a rank moves over its 7 xGMI links in a direct RS / AG")
@@ -37,7 +57,7 @@ def main():
   a = ap.parse_args()
   import bench
   HBM = 5.3e6          # bytes / us the Adam sweeps reach (profiles: 5.2-5.5 TB/s)
-  # host terms, MEASURED at one forced RCCL rank (profiles/r05_bench_*_dp1_*.json): a replayed step costs the
+  # host terms, MEASURED at one forced RCCL rank (profiles/r0[56]_bench_*_dp1_*.json): a replayed step costs the
   # host nothing the GPU waits for; the owned-row SparseAdam step is sequenced from the host (a device -> host
   # read of the row offsets, ~25 launches enqueued one by one): C4 0.266 vs 0.129 ms, C5-shaped 1.43 vs 0.79
   HOST_OWNED = {"c4": 137.0, "c5u": 150.0}
@@ -50,14 +70,21 @@ def main():
     tables = 1 if cfg["kind"] == "mf" else 2
     nb1 = union_sizes(csr, B, 1, a.steps)
     # single-GPU kernel terms (us) at n_b = nb1: {fixed, scales with n_b} from the round-4/5 profiles
+    # round 6: adam1 = the dense sweep with the explicit-fma update (every row), lazy1 = (fraction of rows swept, us) of
+    # the LAZY sweep at one rank -- between the two the model interpolates by the fraction of rows the ranks' union item
+    # sets of two consecutive steps + the chunk cover (it reaches the dense sweep where the union is the catalogue)
+    lazy1 = None
     if name == "c2":
-      fixed, scaled, adam1 = 12.5, 24.0 + 9.0 + 18.0 + 15.0, 38.5   # enc fwd | fdec, reduce, dW (dense) + encoder backward of the PHASED step (r05_bench_c2_dp1_rccl.json) | dense sweep
+      fixed, scaled, adam1 = 13.5, 24.0 + 9.1 + 17.8 + 15.3, 35.0   # enc fwd | fdec, reduce, dW (dense) + encoder backward of the PHASED step (r06 one-rank line) | dense sweep
+      lazy1 = 29.0
     elif name == "c3":
-      fixed, scaled, adam1 = 11.5 + 2 * 6.5 + 2 * 9.4, 19.8 + 19.0 + 25.4 + 7.0 + 30.0 + 10.4, 76.0   # enc fwd, Linears | decode, mnll, dZ, reduce, dW||enc bwd, split | dense sweep
+      fixed, scaled, adam1 = 11.5 + 2 * 6.5 + 2 * 9.4, 19.8 + 17.3 + 25.4 + 7.0 + 30.0 + 6.3, 68.0   # enc fwd, Linears | decode, mnll, dZ, reduce, dW||enc bwd, split | dense sweep
+      lazy1 = 50.0
     elif name == "c4":
-      fixed, scaled, adam1 = 6.5 + 7.6 + 8.4 + 6.5, 28.0 + 20.0, 19.0   # gather, split, loss reduce, user rows | fused decode, dW || colsum || reduce (r05_bench_c4_dp1_replicated.json) | SparseAdam
+      fixed, scaled, adam1 = 6.5 + 7.6 + 8.4 + 6.5, 28.0 + 20.0, 17.0   # gather, split, loss reduce, user rows | fused decode, dW || colsum || reduce | SparseAdam
     else:
-      fixed, scaled, adam1 = 79.0, 117.0 + 100.0 + 100.0 + 62.0, 280.0   # enc fwd | decode, dZ, dW, enc bwd | SparseAdam
+      fixed, scaled, adam1 = 88.0, 118.0 + 115.0 + 100.0 + 62.0, 276.0   # enc fwd | decode, dZ, dW, enc bwd | SparseAdam
+    f1 = swept_frac(csr, B, 1, a.steps) if lazy1 is not None else None
     for N in (1, 2, 4, 8):
       nb = union_sizes(csr, B, N, a.steps) if N > 1 else nb1
       bytes_g = tables * nb * h * 4 + nb * 4
@@ -65,8 +92,10 @@ def main():
       kern = fixed + scaled * nb / nb1
       adam_zero = host_own = float("nan")
       if kind == "dense":
-        adam_rep = adam1                                   # the sweep covers the whole table either way
-        adam_own = adam1
+        # the replicated sweep is LAZY (round 6): its rows grow with the ranks' union item sets
+        fN = swept_frac(csr, B, N, a.steps) if N > 1 else f1
+        adam_rep = lazy1 + (adam1 - lazy1) * max(0.0, fN - f1) / max(1e-9, 1.0 - f1)
+        adam_own = adam_rep
         # ZeRO-1: 1/N of the sweep (p, m, v and the DENSE gradient shard) + laying the compact rows out by item id
         # (two staging launches: reads n_b rows, writes n_items rows; the decoder half runs beside the chain)
         adam_zero = (tables * n_items * h * 28 / N) / HBM + (tables * (n_items + nb) * h * 4) / HBM * 0.5
