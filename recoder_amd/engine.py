@@ -294,6 +294,8 @@ class FusedEngine:
     names = ["en_embedding_layer.weight"] + ([] if self.model.is_constrained else ["de_embedding_layer.weight"])
     if not all(n in self.states and not self.states[n].sparse for n in names):
       return []
+    if any(self.states[n].p.numel() >= (1 << 32) for n in names):     # (the lean table sweeps index with 32 bits)
+      return []
     return names
 
   def lazy_stamp(self, name):
