@@ -731,6 +731,7 @@ def main():
     n_b, nnz = float(np.mean(nbs)), float(np.mean(nnzs))
     global LAZY_ROWS
     LAZY_ROWS = float(np.mean(swept)) if swept else None
+    KERNELS["rk_adam_multi"] = KERNELS["rk_adam_de"] = ["adam_multi_kernel<true>" if LAZY_ROWS is not None else "adam_multi_kernel<false>"]
     ev_over = eng.event_pair_overhead_ms()
     timed = eng.timed_samples_ms()
     global ADAM_DE_SIDE, FUSED_DZ, FUSED_DW_ENC
@@ -748,11 +749,12 @@ def main():
       kt, hv, pg_loss = -(-h0 // 32), -(-h0 // 256), 1 if cfg["loss"] == "mse" else 3
       KERNELS["rk_ae_encode_fwd"] = ["ae_encode_fwd_kernel<1, 8> (user rows || the W_de[items] split workgroups)"]
       if step_mode == 3:          # csrc/fdecode.hip + csrc/pgemm.hip
-        KERNELS["rk_decode_loss"] = ["fdec_kernel<%d, %d>" % (kt, pg_loss)]
+        KERNELS["rk_decode_loss"] = ["fdec_kernel<%d, %d%s>" % (kt, pg_loss, ", true" if GEMM_BF16 else "")]
         KERNELS["rk_decode_bwd_dz"] = ["splitk_reduce_kernel"]
         ones = bool(int(getattr(eng, "_step_flags", 0)) & 16)
-        KERNELS["rk_decode_bwd_dw"] = ["dw_encbwd_kernel<64, 128, 2, 2, %d, 2> (csrc/pgemm.hip: dW tiles from the dO image%s || "
-                                       "encoder-backward columns)" % (hv, ", their output column h = the decoder bias gradient "
+        KERNELS["rk_decode_bwd_dw"] = ["dw_encbwd_kernel<64, 128, 2, 2, %d, 2%s> (csrc/pgemm.hip: dW tiles from the dO image%s || "
+                                       "encoder-backward columns)" % (hv, ", true" if GEMM_BF16 else "",
+                                                                      ", their output column h = the decoder bias gradient "
                                                                       "(ones column of the Z image)" if ones else " || its column sums")]
       elif step_mode == 1:        # csrc/pgemm.hip for all three contractions
         KERNELS["rk_decode_loss"] = ["pg::gemm_kernel<.., pg::EpiLoss<%d>, ..>" % pg_loss]
@@ -959,7 +961,7 @@ def main():
       "roofline": roofline,
     }
     if GEMM_BF16:
-      out["variant"] = ("RK_GEMM_PREC=bf16: plain bf16 operands -- the dtype BASELINE configs[1] names; a SEPARATE "
+      out["variant"] = ("RK_GEMM_PREC=bf16: plain bf16 operands, ONE product per contraction on the current kernel family (round 6) -- the dtype BASELINE configs[1] names; a SEPARATE "
                         "data point that misses the 1e-5 parity bar (see `recall`: product vs the fp32 oracle); "
                         "the graded line is the default run")
     if same_dev:

@@ -290,7 +290,7 @@ static int encode_fwd_launch(const rk_block_t *blk, int32_t row_off, int32_t B, 
   char *zimg = nullptr;
   if (es) {
     sw = es->sw; n_split = es->n_split; zimg = es->zimg; z_kt = es->z_kt;
-    z_ones = (es->z_ones && zimg && !sw.plain && h % 32 != 0) ? 1 : 0;
+    z_ones = (es->z_ones && zimg && h % 32 != 0) ? 1 : 0;     // (plain bf16 images too: 1.0 is exact)
   }
 #define LAUNCH(HV)                                                                         \
   RK_LAUNCH((ae_encode_fwd_kernel<HV, 8>), dim3(n_split + rows), dim3(FW * 64), 0, stream, *blk, row_off, \

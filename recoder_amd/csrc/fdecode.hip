@@ -86,7 +86,9 @@ constexpr int FD_LDS(int ktm) {                                   // W stages | 
 // 512 threads: wave w works on users 32 (w & 3) .. + 31 of the tile and on the item half (w >> 2) -- two
 // waves per SIMD, so that one wave's loss arithmetic, fragment conversions and stores run under the other
 // one's MFMAs (with one wave per SIMD the 336 MFMAs of a tile were 15% of its time).
-template <int KTM, int LOSS>
+// PLAIN (RK_GEMM_PREC=bf16): the W / Z images hold one bf16 value per element (hi halves, scale 1) -- one product on
+// v_mfma_f32_32x32x16_bf16 for the decode and for dZ, the lo halves are never read; dO leaves as plain bf16 too
+template <int KTM, int LOSS, bool PLAIN = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void fdec_kernel(const FdecP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char *Wst = smem;                                   // [KTM][128 rows][128 B]
@@ -167,12 +169,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     f16x8 zh[2], zl[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) { zh[ks] = fr.load(zb, 0, ks, 0); zl[ks] = fr.load(zb, 0, ks, 1); }
+    for (int ks = 0; ks < 2; ++ks) { zh[ks] = fr.load(zb, 0, ks, 0); if (!PLAIN) zl[ks] = fr.load(zb, 0, ks, 1); }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       f16x8 wh[2], wl[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) { wh[i] = fr.load(SW, i, ks, 0); wl[i] = fr.load(SW, i, ks, 1); }
+      for (int i = 0; i < 2; ++i) { wh[i] = fr.load(SW, i, ks, 0); if (!PLAIN) wl[i] = fr.load(SW, i, ks, 1); }
+      if constexpr (PLAIN) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pg::bf16x8, wh[i]),
+                                                           __builtin_bit_cast(pg::bf16x8, zh[ks]), acc[i], 0, 0, 0);
+        continue;
+      }
       // (the order of decode16.hip per accumulator: Z lo . W hi, Z hi . W lo, hi . hi)
 #pragma unroll
       for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], zl[ks], acc[i], 0, 0, 0);
@@ -263,7 +272,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
   lsum = rk_wave_sum(lsum);
   float s_do = 1.0f;
-  if (gmax > 0.f) {
+  if (!PLAIN && gmax > 0.f) {
     const int ex = min(max((int)(__float_as_uint(gmax) >> 23) - 127, -100), 100);
     s_do = __uint_as_float((uint32_t)(13 - ex + 127) << 23);
   }
@@ -290,8 +299,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int s = 0; s < 2; ++s) {
       // this lane's items 16 s + 4 lh + {0..3} ("first") and 16 s + 8 + 4 lh + {0..3} ("second") of block i
       uint2 fh, fl, sh, sl;
+      if constexpr (PLAIN) {
+        rkp::plain4(make_float4(acc[i][8 * s + 0], acc[i][8 * s + 1], acc[i][8 * s + 2], acc[i][8 * s + 3]), fh, fl);
+        rkp::plain4(make_float4(acc[i][8 * s + 4], acc[i][8 * s + 5], acc[i][8 * s + 6], acc[i][8 * s + 7]), sh, sl);
+      } else {
       rkp::split4(make_float4(acc[i][8 * s + 0], acc[i][8 * s + 1], acc[i][8 * s + 2], acc[i][8 * s + 3]), s_do, fh, fl);
       rkp::split4(make_float4(acc[i][8 * s + 4], acc[i][8 * s + 5], acc[i][8 * s + 6], acc[i][8 * s + 7]), s_do, sh, sl);
+      }
       // lanes < 32 keep `first` and take the partner's `first` (items + 4 .. + 7); lanes >= 32 take the
       // partner's `second` (items + 8 .. + 11) and keep theirs: first.upper <-> second.lower
       swap32(fh.x, sh.x); swap32(fh.y, sh.y); swap32(fl.x, sl.x); swap32(fl.y, sl.y);
@@ -306,7 +320,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int row0 = 64 * hf + 32 * i + 16 * s + 8 * lh;
 #pragma unroll
       for (int j = 0; j < KTM; ++j) {
-        {
+        if constexpr (PLAIN) {
+          const f16x8 ah = w_tr_frag(Wst + j * WB, row0, lane, 0);
+          acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(pg::bf16x8, ah), __builtin_bit_cast(pg::bf16x8, dh),
+                                                            acc2[j], 0, 0, 0);
+        } else {
           const f16x8 ah = w_tr_frag(Wst + j * WB, row0, lane, 0), al = w_tr_frag(Wst + j * WB, row0, lane, 1);
           acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, dh, acc2[j], 0, 0, 0);
           acc2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, dl, acc2[j], 0, 0, 0);
@@ -388,7 +406,9 @@ extern "C" int rk_fdec_dz_reduce(const float *dz_workspace, int32_t B, int32_t h
 extern "C" int32_t rk_fdec_ok(int32_t B, int32_t h, int32_t n_cap, int32_t loss_kind) {
   static const int on = [] { const char *e = getenv("RK_FDEC"); return (e && atoi(e) == 0) ? 0 : 1; }();
   const int kt = rkp::kp_of(h) / 32;
-  return on && rk_pg_enabled() && rk_gemm_split16() && !rk_gemm_plain_bf16() &&
+  // (plain bf16 operands, RK_GEMM_PREC=bf16: the same kernel with one product -- whole single-process steps only,
+  // rk_ae_train_step decides)
+  return on && rk_pg_enabled() && rk_gemm_split16() &&
          (loss_kind == RK_LOSS_MSE || loss_kind == RK_LOSS_BCE) && h % 4 == 0 && h <= 224 &&
          B < 1024 &&
          (kt == 2 || kt == 4 || kt == 7) &&
@@ -422,12 +442,20 @@ extern "C" int rk_fdec_loss_dz(const rk_planes_t *pl, int32_t B, const rk_block_
   p.dimg = (char *)dO_img; p.rows_img = rows_img; p.dscale = dO_scales; p.ds_pitch = rk_cdiv(tgt->n_cap, 64);
   p.dz_ws = dz_workspace; p.h = pl->h;
   const int grid = rk_cdiv(rk_cdiv(B, 128) * rk_cdiv(tgt->n_cap, 128), 8) * 8;
+  const bool plain = rk_gemm_plain_bf16() != 0;
 #define GO(KTM, LOSS)                                                                                          \
   do {                                                                                                         \
-    auto k = fdec_kernel<KTM, LOSS>;                                                                           \
-    static const hipError_t attr = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    if (attr != hipSuccess) { rk_set_error("LDS attribute"); return -1; }                                      \
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), FD_LDS(KTM), stream, p);                                      \
+    if (plain) {                                                                                               \
+      auto k = fdec_kernel<KTM, LOSS, true>;                                                                   \
+      static const hipError_t attr = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      if (attr != hipSuccess) { rk_set_error("LDS attribute"); return -1; }                                    \
+      hipLaunchKernelGGL(k, dim3(grid), dim3(512), FD_LDS(KTM), stream, p);                                    \
+    } else {                                                                                                   \
+      auto k = fdec_kernel<KTM, LOSS>;                                                                         \
+      static const hipError_t attr = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      if (attr != hipSuccess) { rk_set_error("LDS attribute"); return -1; }                                    \
+      hipLaunchKernelGGL(k, dim3(grid), dim3(512), FD_LDS(KTM), stream, p);                                    \
+    }                                                                                                          \
   } while (0)
 #define BY_KT(LOSS)                                                                                            \
   do { if (p.KT == 2) GO(2, LOSS); else if (p.KT == 4) GO(4, LOSS); else GO(7, LOSS); } while (0)

@@ -33,6 +33,7 @@ namespace pg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -241,8 +242,12 @@ __device__ __forceinline__ bool tile_of(const int L, const int total, int &t) {
 // (the other half -- their partners on the SIMDs -- start on the MFMAs at once); 2 = s_setprio(1) around
 // the MFMA clusters
 // NS: LDS stages (2: the loop above; > 2: the deep ring -- both operands TR, NS - 1 k-tiles in flight)
-template <int BM, int BN, int WM, int WN, bool ATR, bool BTR, class Epi, int VAR = 0, bool RS = false, int NS = 2>
+// PLAIN (RK_GEMM_PREC=bf16, the ring loop only): the images hold ONE bf16 value per element in their hi halves (scale 1,
+// lo halves zero) -- one product on v_mfma_f32_32x32x16_bf16 instead of three on the f16 instruction, the lo planes
+// are neither read from LDS nor multiplied
+template <int BM, int BN, int WM, int WN, bool ATR, bool BTR, class Epi, int VAR = 0, bool RS = false, int NS = 2, bool PLAIN = false>
 __device__ __forceinline__ void gemm_body(const Core &p, const typename Epi::Args &ea, const int L, char *smem) {
+  static_assert(!PLAIN || (VAR & 256) != 0, "plain bf16 operands: the ring k-loop only");
   constexpr int NW = WM * WN, TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int NI = (VAR & 1) ? NW / 2 : NW;          // issuing waves
   constexpr int A_BYTES = BM * LINE, STAGE = (BM + BN) * LINE;
@@ -380,7 +385,7 @@ __device__ __forceinline__ void gemm_body(const Core &p, const typename Epi::Arg
           for (int q = 0; q < NKS; ++q) {
             const int ks = k0 + q;
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
+            for (int pl = 0; pl < (PLAIN ? 1 : 2); ++pl) {
 #pragma unroll
               for (int i = 0; i < TM; ++i) {
                 if constexpr (ATR) {
@@ -411,21 +416,40 @@ __device__ __forceinline__ void gemm_body(const Core &p, const typename Epi::Arg
             if constexpr (ATR) {
 #pragma unroll
               for (int i = 0; i < TM; ++i) {
+                if constexpr (PLAIN) {
+                  asm volatile("" : "+v"(ra[q][0][i][0]), "+v"(ra[q][0][i][1]));
+                  ah[q][i] = PG_CAT(ra[q][0][i]);
+                } else {
                 asm volatile("" : "+v"(ra[q][0][i][0]), "+v"(ra[q][0][i][1]), "+v"(ra[q][1][i][0]), "+v"(ra[q][1][i][1]));
                 ah[q][i] = PG_CAT(ra[q][0][i]); al[q][i] = PG_CAT(ra[q][1][i]);
+                }
               }
             }
             if constexpr (BTR) {
 #pragma unroll
               for (int j = 0; j < TN; ++j) {
+                if constexpr (PLAIN) {
+                  asm volatile("" : "+v"(rb[q][0][j][0]), "+v"(rb[q][0][j][1]));
+                  bh[q][j] = PG_CAT(rb[q][0][j]);
+                } else {
                 asm volatile("" : "+v"(rb[q][0][j][0]), "+v"(rb[q][0][j][1]), "+v"(rb[q][1][j][0]), "+v"(rb[q][1][j][1]));
                 bh[q][j] = PG_CAT(rb[q][0][j]); bl[q][j] = PG_CAT(rb[q][1][j]);
+                }
               }
             }
           }
 #undef PG_CAT
 #pragma unroll
           for (int q = 0; q < NKS; ++q) {
+            if constexpr (PLAIN) {
+#pragma unroll
+              for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[q][i]),
+                                                                      __builtin_bit_cast(bf16x8, bh[q][j]), acc[i][j], 0, 0, 0);
+              continue;
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll

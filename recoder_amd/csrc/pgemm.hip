@@ -112,13 +112,14 @@ __device__ __forceinline__ void colsum_img_body(const ColsumImg &c, const int bl
 }
 
 // RING: 0 = the two-stage loop as the compiler schedules it; 2 / 4 = LDS stages of the ring loop (csrc/pgemm.h)
-template <int BM, int BN, int WM, int WN, int HV, int RING = 0>
+// PLAIN: RK_GEMM_PREC=bf16 -- both images hold one bf16 value per element (csrc/pgemm.h)
+template <int BM, int BN, int WM, int WN, int HV, int RING = 0, bool PLAIN = false>
 __global__ __launch_bounds__(WM * WN * 64) void dw_encbwd_kernel(const pg::Core p, const pg::EpiSlab::Args e,
                                                                 const int n_dw, const EncBwd enc,
                                                                 const ColsumImg cs, const int n_cs) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)blockIdx.x < n_dw) {
-    pg::gemm_body<BM, BN, WM, WN, true, true, pg::EpiSlab, RING == 2 ? 256 : 0, true, RING < 3 ? 2 : RING>(p, e, (int)blockIdx.x, smem);
+    pg::gemm_body<BM, BN, WM, WN, true, true, pg::EpiSlab, RING == 2 ? 256 : 0, true, RING < 3 ? 2 : RING, PLAIN>(p, e, (int)blockIdx.x, smem);
     return;
   }
   if (threadIdx.x >= 256) return;
@@ -353,7 +354,8 @@ extern "C" int rk_pg_dw_encode_bwd(const void *dO_img, const float *dO_scales, i
                                    int32_t B, const rk_planes_t *pl, const rk_block_t *tgt, float *slabs,
                                    int32_t row_off, const float *dZ0pre, float *G_en, float *gb_en,
                                    float *gb_de, void *stream_) {
-  RK_REQUIRE(rk_dw_encode_bwd_fused_ok(row_off, B), "outside the fused launch's domain (rk_dw_encode_bwd_fused_ok)");
+  RK_REQUIRE(rk_dw_encode_bwd_fused_ok(row_off, B) || (rk_gemm_plain_bf16() && (((row_off + B + 31) >> 5) - (row_off >> 5) <= 64)),
+             "outside the fused launch's domain (rk_dw_encode_bwd_fused_ok)");
   RK_REQUIRE(pl && pl->h % 4 == 0 && pl->h <= 1024, "h must be a multiple of 4, <= 1024");
   RK_REQUIRE(row_off >= 0 && B >= 0 && row_off + B <= tgt->S_cap, "row slice out of range");
   RK_REQUIRE(tgt->bits_cr != nullptr && tgt->pref_rc != nullptr,
@@ -382,12 +384,13 @@ int rk_pg_dw_ones_ok(int32_t B, int32_t h, int32_t n_cap) {
   dw_tile(B, h, n_cap, bm, bn);
   // (a free padding column inside the image's last line; the merged launch -- not the two-launch form of the
   // 256 x 256 tiles with h > 512; fp16-pair operands)
-  return (h % 32 != 0 && !(bm == 256 && bn == 256 && rk_cdiv(h, 256) > 2) && !rk_gemm_plain_bf16()) ? 1 : 0;
+  return (h % 32 != 0 && !(bm == 256 && bn == 256 && rk_cdiv(h, 256) > 2)) ? 1 : 0;
 }
 int rk_pg_dw_encode_bwd_ones(const void *dO_img, const float *dO_scales, int32_t gr, int32_t gc, int32_t B,
                              const rk_planes_t *pl, const rk_block_t *tgt, float *slabs, int32_t row_off,
                              const float *dZ0pre, float *G_en, float *gb_en, float *gb_slabs, void *stream_) {
-  RK_REQUIRE(rk_dw_encode_bwd_fused_ok(row_off, B), "outside the fused launch's domain (rk_dw_encode_bwd_fused_ok)");
+  RK_REQUIRE(rk_dw_encode_bwd_fused_ok(row_off, B) || (rk_gemm_plain_bf16() && (((row_off + B + 31) >> 5) - (row_off >> 5) <= 64)),
+             "outside the fused launch's domain (rk_dw_encode_bwd_fused_ok)");
   RK_REQUIRE(pl && rk_pg_dw_ones_ok(B, pl->h, tgt->n_cap) && gb_slabs, "rk_pg_dw_ones_ok");
   RK_REQUIRE(row_off >= 0 && B >= 0 && row_off + B <= tgt->S_cap, "row slice out of range");
   RK_REQUIRE(tgt->bits_cr != nullptr && tgt->pref_rc != nullptr,
@@ -489,6 +492,17 @@ static int pg_dw_impl(const void *dO_img, const float *dO_scales, int32_t gr, in
     rc = hipGetLastError();                                                                                  \
   } while (0)
     const int ring = rk_tune_get(RK_TUNE_DW_RING);
+    if (rk_gemm_plain_bf16()) {
+      // plain bf16 images (RK_GEMM_PREC=bf16; the fused decode's domain: < 1024 rows, h <= 224): the two-stage ring loop of
+      // the 64 x 128 tiles, one product; the bias gradient as the tiles' output column h (no column-sum range: that
+      // range reads fp16 pairs)
+      if (!(bm == 64 && hv == 1 && n_cs == 0)) { rk_set_error("pg_dw: plain bf16 operands cover the 64 x 128 tiles, h <= 256, bias gradient as column h"); return -1; }
+      auto k = dw_encbwd_kernel<64, 128, 2, 2, 1, 2, true>;
+      static const hipError_t attr = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (attr != hipSuccess) { rk_set_error("LDS attribute"); return -1; }
+      hipLaunchKernelGGL(k, dim3(n_dw + n_cs + n_enc), dim3(256), 2 * (64 + 128) * pg::LINE, stream, p, e, n_dw, *enc, cs, n_cs);
+      rc = hipGetLastError();
+    } else
     if (bm == 256 && bn == 256) {            // (hv == 4 never gets here: rk_pg_dw_encode_bwd)
       if (ring != 0) { if (hv == 1) GO_NS(256, 256, 2, 4, 1, 2); else GO_NS(256, 256, 2, 4, 2, 2); }
       else { if (hv == 1) GO(256, 256, 2, 4, 1); else GO(256, 256, 2, 4, 2); }

@@ -378,11 +378,26 @@ static int step_item_parallel(const rk_ae_step_t *a, int phase) {
 // decode + dZ launch's domain (h > 256 or >= 1024 rows).
 // Returns 0: neither; 1: all three contractions on csrc/pgemm.h; 3: the register-resident fused decode
 // (csrc/fdecode.hip) with its image, dW on rk_pg_dw  (4, round 5's streaming form of that decode, is gone)
+static bool step_dw_ones(const rk_ae_step_t *a, const int pg_mode);
+// the merged dW || encoder-backward launch of csrc/pgemm.hip covers this row window (rk_dw_encode_bwd_fused_ok also asks for
+// the fp16-pair dW of dw3.hip, which plain bf16 operands -- RK_GEMM_PREC=bf16 -- do not have: the pgemm tiles do not care)
+static bool pg_merged_ok(int row_off, int B) {
+  if (rk_dw_encode_bwd_fused_ok(row_off, B)) return true;
+  return rk_gemm_plain_bf16() && rk_tune_get(RK_TUNE_DW_ENC_FUSED) == 1 && (((row_off + B + 31) >> 5) - (row_off >> 5) <= 64);
+}
 static int step_pg_mode(const rk_ae_step_t *a) {
   const int phase = a->phase == 0 ? RK_STEP_ALL : a->phase;
   if (a->tied || a->loss_kind == RK_LOSS_MNLL) return 0;
-  if (!rk_gemm_split16() || rk_gemm_plain_bf16() || a->ws == nullptr || a->planes == nullptr) return 0;
+  if (!rk_gemm_split16() || a->ws == nullptr || a->planes == nullptr) return 0;
   if (a->do_scales == nullptr || !rk_pg_enabled()) return 0;
+  if (rk_gemm_plain_bf16()) {
+    // RK_GEMM_PREC=bf16 on the current family (round 6): whole single-process steps in the fused decode's domain whose
+    // decoder bias gradient comes out of the dW tiles (step_dw_ones: the image's column-sum range reads fp16 pairs) --
+    // fdec_kernel<.., PLAIN> + dw_encbwd_kernel<64, 128, .., PLAIN>; everything else keeps the round-2/3 plain kernels
+    if (phase == RK_STEP_ALL && a->B < 1024 && a->ws_dw != nullptr && rk_fdec_ok(a->B, a->h, a->blk->n_cap, a->loss_kind) &&
+        pg_merged_ok(a->row_off, a->B) && rkp::kp_of(a->h) <= 256 && step_dw_ones(a, 3)) return 3;
+    return 0;
+  }
   if (phase != RK_STEP_ALL) {
     // the PHASED (data-parallel) step: the register-resident fused decode in FWD_DW, dW as one dense array +
     // the bias gradient from its image (rk_pg_dw_dense), the slab reduce + encoder backward in DZ_ENC.  The
@@ -409,8 +424,8 @@ static bool step_dw_ones(const rk_ae_step_t *a, const int pg_mode) {
   if (phase != RK_STEP_ALL || pg_mode != 3 || !act_bounded(a->act) || a->gb_part == nullptr) return false;
   const rk_block_t *blk = a->blk;
   const int B = a->B, h = a->h;
-  const bool dz_fused = rk_decode_dz_fused_ok(B, h, blk->n_cap, a->loss_kind) != 0;
-  if (!dz_fused || !rk_dw_encode_bwd_fused_ok(a->row_off, B)) return false;      // (the merged dW || encoder backward launch)
+  const bool dz_fused = rk_decode_dz_fused_ok(B, h, blk->n_cap, a->loss_kind) != 0 || pg_mode == 3;
+  if (!dz_fused || !pg_merged_ok(a->row_off, B)) return false;      // (the merged dW || encoder backward launch)
   const int row_tiles = rk_cdiv(B, rk_decode_row_tile());
   return rk_tune_get(RK_TUNE_DW_ONES) != 0 && rk_pg_dw_ones_ok(B, h, blk->n_cap) != 0 &&
          (int64_t)row_tiles * (rk_cdiv(blk->n_cap, 32) * 32) >= (int64_t)rk_pg_dw_splits(B, h, blk->n_cap) * blk->n_cap;
@@ -465,11 +480,11 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   const int pg_mode = step_pg_mode(a);
   const bool dz_fused = pl && !a->tied && !mnll && a->ws != nullptr && (both ? whole : a->ws_dw != nullptr) &&
                         (phase & (RK_STEP_FWD_DW | RK_STEP_DZ_ENC)) != 0 &&
-                        rk_decode_dz_fused_ok(B, h, blk->n_cap, a->loss_kind) != 0;
+                        (rk_decode_dz_fused_ok(B, h, blk->n_cap, a->loss_kind) != 0 || pg_mode == 3);
   // dW and the encoder backward as ONE launch on the chain instead of a side-stream branch
   // (in the small-shape domain of the fused decode only: at C5's sizes -- dW 100+ us -- the side-stream
   // branch next to dZ -> encoder backward is worth more than its two edges: 0.75 vs 0.83 ms per step)
-  const bool dw_enc_fused = dw3 && dz_fused && rk_dw_encode_bwd_fused_ok(a->row_off, B) != 0;
+  const bool dw_enc_fused = dw3 && dz_fused && (rk_dw_encode_bwd_fused_ok(a->row_off, B) != 0 || (pg_mode == 3 && pg_merged_ok(a->row_off, B)));
   // the three contractions on the pipelined pair-plane kernels (csrc/pgemm.h; include/recoder_hip.h
   // rk_ae_step_t.do_scales): whole untied MSE / BCE steps outside the fused decode's domain
   const bool pg = pg_mode == 1, fdec = pg_mode == 3;

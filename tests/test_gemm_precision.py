@@ -275,3 +275,66 @@ def test_dw3_has_no_operand_range(gtop, ztop):
   assert err < max(5e-7, 1.05 * err32), (err, err32)
 
 
+
+
+# ---------------------------------------------------------------------------------------------
+# RK_GEMM_PREC=bf16 on the CURRENT kernel family (round 6): fdec_kernel<.., PLAIN> + dw_encbwd_kernel<.., PLAIN>
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.skipif(os.environ.get("RK_GEMM_PREC", "")[:1].lower() != "b", reason="runs in the RK_GEMM_PREC=bf16 sub-process")
+@pytest.mark.parametrize("h,loss,conf", [(200, "mse", 0.0), (40, "mse", 2.5), (200, "logistic", 0.0)])
+def test_plain_bf16_steps_on_the_fused_decode(h, loss, conf):
+  """Whole single-process steps with plain bf16 operands run the register-resident fused decode and the dW tiles of
+  csrc/pgemm.h with ONE product each (rk_ae_step_uses_pg == 3, bias gradient as the tiles' output column h) and stay
+  within bf16's error of the fp32 oracle: losses to 2e-3 relative (8 mantissa bits on every operand of three chained
+  contractions), the run bitwise reproducible."""
+  from oracle import recoder_oracle as orc
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder
+  from tests.test_hip_parity import synth_csr
+  csr = synth_csr(1500, 3000, 30, seed=5, ratings=False)
+  B = 500
+  order = np.random.RandomState(3).permutation(csr.shape[0]).astype(np.int64)
+  lp = {"confidence": conf} if conf else None
+
+  def run():
+    torch.manual_seed(11)
+    model = DynamicAutoencoder([h], activation_type="tanh", noise_prob=0.0, sparse=False)
+    rec = Recoder(model=model, use_cuda=True, optimizer_type="adam", loss=loss, loss_params=lp)
+    rec.user_order_hook = lambda epoch, n: order
+    ds = RecommendationDataset(csr)
+    rec._Recoder__init_training(ds, 1e-3, 2e-5)
+    init = {k: v.detach().cpu().clone() for k, v in model.named_parameters()}
+    rec.train(ds, batch_size=B, lr=1e-3, weight_decay=2e-5, num_epochs=2, negative_sampling=True)
+    eng = rec._engine()
+    assert int(getattr(eng, "_step_mode", 0)) == 3 and int(getattr(eng, "_step_flags", 0)) & 16
+    return init, np.concatenate(rec.loss_history), {k: v.detach().cpu().clone() for k, v in model.named_parameters()}
+
+  init, got, pars = run()
+  _, got2, pars2 = run()
+  assert np.array_equal(got, got2)
+  for k in pars:
+    assert torch.equal(pars[k], pars2[k]), k
+  o = orc.OracleRecoder("ae", init, hidden_layers=[h], activation_type="tanh", loss=loss, loss_params=lp,
+                        lr=1e-3, weight_decay=2e-5)
+  want = []
+  for ep in range(2):
+    for off in range(0, csr.shape[0], B):
+      users = order[off:off + B]
+      b = orc.collate(orc.extract_rows(csr, users), users, B, True)[0]
+      want.append(o.train_step(b))
+  want = np.asarray(want, dtype=np.float64)
+  rel = np.abs(got - want) / np.abs(want)
+  print("plain bf16, h = %d %s: max relative loss error %.2e over %d steps" % (h, loss, rel.max(), len(want)))
+  assert rel.max() < 2e-3, rel
+  assert rel.max() > 1e-7          # (it IS the one-product path, not the split one)
+
+
+def test_plain_bf16_runs_the_current_kernel_family():
+  """RK_GEMM_PREC=bf16 (read once per process): the cases above in a sub-process."""
+  env = dict(os.environ, RK_GEMM_PREC="bf16")
+  r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-s",
+                      os.path.join(ROOT, "tests", "test_gemm_precision.py"), "-k", "plain_bf16_steps_on_the_fused_decode"],
+                     cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+  assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+  assert "3 passed" in r.stdout, r.stdout[-800:]
