@@ -13,7 +13,7 @@
 //     are; the transposition dO^T needs happens for free in the fragment read (a lane reads 8
 //     k-rows of ONE item column) and the bf16 split is done in registers by the consuming wave.
 //   * Z [B, h] is small and re-read by every workgroup: it is split ONCE per step into bf16 planes
-//     stored in fragment order -- [plane][k/8][n][8] -- (rk_split_planes_t below) and goes from
+//     stored in fragment order -- [plane][k/8][n][8] -- (split_planes_t_launch below) and goes from
 //     L2 straight into the registers of the one wave that owns those columns.
 //   * What bounds the kernel is what a CU can FETCH: ~290 cache lines (128 B) per us and CU from
 //     L2, whatever the path -- an LDS-DMA ring of any depth, register prefetch, a rotated K order

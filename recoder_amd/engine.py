@@ -281,7 +281,7 @@ class FusedEngine:
     """Names of the dense-Adam embedding tables whose sweeps can skip rows (DynamicAutoencoder, single process):
     optim.Adam on a dense embedding gradient (model.py:135,398-399) touches every row every step; rows outside
     the step's item set that the next step does not read are caught up later by replaying their missed
-    steps bit for bit (csrc/optim.hip update_job_lazy)."""
+    steps bit for bit (csrc/optim.hip table_sweep_lazy)."""
     if (self.lazy_period < 1 or self.kind != "ae" or self.item_parallel is not None or
         self.h[0] % 4 != 0 or bool(_lib.load().rk_adam_de_side())):
       return []
@@ -331,8 +331,7 @@ class FusedEngine:
           "rk_adam_lazy_flush")
 
   # The updates of one step are collected as rk_adam_job_t records and issued through
-  # rk_adam_multi, six per launch (the same per-element arithmetic as rk_adam_table / rk_adam_rows /
-  # rk_adam_dense; a hidden-stack model has ~11 parameter tensors, i.e. ~11 launches and FFI calls
+  # rk_adam_multi, ten per launch (a hidden-stack model has ~11 parameter tensors, i.e. ~11 launches and FFI calls
   # otherwise).  Index arrays that are int64 (MF user rows) go through rk_adam_rows directly.
   def _job(self, s, n_rows, h, g, pos=None, rows=None, n_dev=None, n_cap=0, parts=None):
     """parts = (pointer, g_parts, g_stride, gstride_dev, gparts_dev): the gradient is the sum, in

@@ -9,7 +9,7 @@ collective be enqueued in order on the step's stream -- and captured with the st
 
 The communicator is bootstrapped through the already initialised torch.distributed
 group (rank 0's 128-byte id is broadcast with it); the C side binds the librccl.so that torch
-itself loaded (rk_comm_library).  If anything fails, callers fall back to torch.distributed.
+itself loaded (the `librccl` argument of rk_comm_unique_id / rk_comm_init).  If anything fails, callers fall back to torch.distributed.
 """
 import ctypes
 import os

@@ -1,4 +1,4 @@
-"""Lazy dense Adam (include/recoder_hip.h rk_adam_job_t.lazy_stamp, csrc/optim.hip update_job_lazy).
+"""Lazy dense Adam (include/recoder_hip.h rk_adam_job_t.lazy_stamp, csrc/optim.hip table_sweep_lazy).
 
 optim.Adam with a dense embedding gradient (reference model.py:135,398-399) updates EVERY row of a table every
 step; the lazy sweep skips the rows that neither carry a gradient nor are read by the next step and catches them up
