@@ -138,23 +138,27 @@ __global__ __launch_bounds__(FW * 64) void ae_encode_fwd_kernel(
     } else {
       item = 0;
     }
-    const int cnt = min(64, wend - base);
-    // no branch on dropped entries (s == 0 contributes exactly +0): the row
-    // loads of consecutive entries are independent and stay in flight together
-    // (lanes past the wave's range carry item 0 / s 0, so rounding cnt up to a
-    // multiple of 8 only adds exact zeros)
+    // dropped entries (s == 0: half of them at the reference's noise_prob 0.5) are not gathered at all: the
+    // wave walks the set bits of the ballot of its live entries, UB at a time.  Exact: a skipped entry would
+    // have added fmaf(0, w, acc) == acc (acc is never -0: it starts at +0 and x + (-x) rounds to +0).
+    // The row loads of consecutive live entries are independent and stay in flight together; a pass
+    // short of UB live entries pads with item 0 / s 0 (exact zeros).
     // UB row loads in flight per lane.  (16 instead of 8 does not shorten a heavy row -- 7.4 vs 7.7 us for
     // 599 entries: the row is bound by what ONE CU fetches, ~560 cache lines per us -- and costs the
     // light rows occupancy: 17.3-18.3 vs 15.8 us for the launch inside the step)
-    for (int k = 0; k < cnt; k += UB) {
+    unsigned long long live = __ballot(s != 0.f);
+    while (live) {
       int it[UB];
       float sv[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         // (the lane index is wave-uniform: v_readlane into a scalar register instead of a ds_bpermute
         // through the LDS crossbar; 16 VGPRs less, same speed)
-        it[u] = __builtin_amdgcn_readlane(item, (k + u) & 63);
-        sv[u] = (k + u < 64) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), (k + u) & 63)) : 0.f;
+        const bool has = live != 0ull;
+        const int kk = has ? __builtin_ctzll(live) : 0;
+        live &= live - 1ull;                          // (0 & ~0 stays 0)
+        it[u] = has ? __builtin_amdgcn_readlane(item, kk) : 0;
+        sv[u] = has ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), kk)) : 0.f;
       }
 #pragma unroll
       for (int v = 0; v < HV; ++v) {

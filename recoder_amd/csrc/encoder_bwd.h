@@ -92,7 +92,8 @@ __device__ __forceinline__ void ae_encode_bwd_body(
         s = b.svals[rk_entry_index(b, row, c, word)];
       }
     }
-    unsigned long long mask = __ballot(on);
+    // (entries the input noise dropped -- s == 0 -- are skipped: exact zeros either way)
+    unsigned long long mask = __ballot(on && s != 0.f);
     // ascending-row order, 8 row loads in flight per pass
     while (mask) {
       int kk[8];
@@ -250,13 +251,19 @@ __device__ __forceinline__ void ae_encode_bwd_cols_body(
       const uint32_t word = b.bits_rc[(int64_t)row * b.ldw_rc + (c >> 5)];
       sv = b.svals[rk_entry_index(b, row, c, word)];
     }
-    for (int k = 0; k < total; k += U) {
+    // entries the input noise dropped (sv == 0: half of them at noise_prob 0.5) are skipped: the wave walks
+    // the set bits of the ballot of its live entries (exact: fmaf(0, d, acc) == acc, acc never -0)
+    unsigned long long lv = __ballot(sv != 0.f);
+    while (lv) {
       int kk[U];
       float s8[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {       // (lanes past `total` carry row_off / 0: exact zeros)
-        kk[u] = __shfl(row, (k + u) & 63, 64) - row_off;
-        s8[u] = (k + u < 64) ? __shfl(sv, (k + u) & 63, 64) : 0.f;
+      for (int u = 0; u < U; ++u) {       // (a pass short of U live entries pads with row 0 / 0: exact zeros)
+        const bool has = lv != 0ull;
+        const int k = has ? __builtin_ctzll(lv) : 0;
+        lv &= lv - 1ull;
+        kk[u] = has ? __builtin_amdgcn_readlane(row, k) - row_off : 0;
+        s8[u] = has ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), k)) : 0.f;
       }
 #pragma unroll
       for (int v = 0; v < HV; ++v) {
@@ -325,13 +332,17 @@ __device__ __forceinline__ void ae_encode_bwd_cols_body(
         sv = b.svals[rk_entry_index(b, row, cj, word)];
       }
       constexpr int UH = U >= 8 ? 16 : 2 * U;     // (dZ rows of a heavy column in flight)
-      for (int k = 0; k < ne; k += UH) {
+      unsigned long long lv = __ballot(sv != 0.f);      // (dropped entries skipped, as above)
+      while (lv) {
         int kk[UH];
         float s16[UH];
 #pragma unroll
-        for (int u = 0; u < UH; ++u) {    // (lanes past `ne` carry row_off / 0: exact zeros)
-          kk[u] = __shfl(row, (k + u) & 63, 64) - row_off;
-          s16[u] = (k + u < 64) ? __shfl(sv, (k + u) & 63, 64) : 0.f;
+        for (int u = 0; u < UH; ++u) {    // (a short pass pads with row 0 / 0: exact zeros)
+          const bool has = lv != 0ull;
+          const int k = has ? __builtin_ctzll(lv) : 0;
+          lv &= lv - 1ull;
+          kk[u] = has ? __builtin_amdgcn_readlane(row, k) - row_off : 0;
+          s16[u] = has ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), k)) : 0.f;
         }
 #pragma unroll
         for (int v = 0; v < HV; ++v) {
