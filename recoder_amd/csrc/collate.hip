@@ -42,19 +42,20 @@ struct MultiBlk {
 __device__ __forceinline__ void collate_phase1_body(
     const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
     const int64_t *__restrict__ users, int S, int32_t stamp, int all, int nrow_blk, const rk_block_t &b,
-    rk_cur_t cur) {
+    rk_cur_t cur, const int bx, const int nbx) {
+  // (bx of nbx: the role index -- blockIdx.x of a launch with one workgroup per role, or a workgroup's turn)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   if (cur.cursor) { users += rk_cur_local(cur) * S; stamp = rk_cur_stamp(cur); }
-  if ((int)blockIdx.x < nrow_blk) {
+  if (bx < nrow_blk) {
     if (all) return;
-    const int row = blockIdx.x * 4 + wid;
+    const int row = bx * 4 + wid;
     if (row >= S) return;
     const int64_t u = users[row];
     const int64_t beg = ds_indptr[u], end = ds_indptr[u + 1];
     for (int64_t e = beg + lane; e < end; e += 64) b.mark[ds_indices[e]] = stamp;
     return;
   }
-  if ((int)blockIdx.x == nrow_blk) {
+  if (bx == nrow_blk) {
     __shared__ int32_t wsum[4];
     __shared__ int32_t carry_s;
     if (tid == 0) carry_s = 0;
@@ -94,7 +95,7 @@ __device__ __forceinline__ void collate_phase1_body(
     return;
   }
   if (b.bits_cr) {
-    const int zb = blockIdx.x - nrow_blk - 1, nz = gridDim.x - nrow_blk - 1;
+    const int zb = bx - nrow_blk - 1, nz = nbx - nrow_blk - 1;
     const int64_t tot4 = ((int64_t)b.n_cap * b.ldw_cr) >> 2;     // uint4 granules
     uint4 *p4 = reinterpret_cast<uint4 *>(b.bits_cr);
     for (int64_t i = (int64_t)zb * 256 + tid; i < tot4; i += (int64_t)nz * 256)
@@ -108,11 +109,11 @@ __global__ __launch_bounds__(256) void collate_phase1_kernel(
     const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
     const int64_t *__restrict__ users, int S, int32_t stamp, int all, int nrow_blk, rk_block_t b,
     rk_cur_t cur) {
-  collate_phase1_body(ds_indptr, ds_indices, users, S, stamp, all, nrow_blk, b, cur);
+  collate_phase1_body(ds_indptr, ds_indices, users, S, stamp, all, nrow_blk, b, cur, (int)blockIdx.x, (int)gridDim.x);
 }
 __global__ __launch_bounds__(256) void collate_phase1_multi_kernel(
     const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
-    const int64_t *__restrict__ users, int S, int all, int nrow_blk, MultiBlk mb, rk_cur_t cur) {
+    const int64_t *__restrict__ users, int S, int all, int nrow_blk, MultiBlk mb, rk_cur_t cur, int nbx) {
   cur.off += (int)blockIdx.y;
   // the look-back slots of this collation's scan (collate_scan_lb_multi_kernel) start EMPTY: a slot is
   // valid once its chunk's workgroup of THIS launch set wrote it -- whatever stamp the previous collation
@@ -120,7 +121,12 @@ __global__ __launch_bounds__(256) void collate_phase1_multi_kernel(
   // stamp read the first run's totals)
   if (blockIdx.x == 0 && (int)threadIdx.x < min(mb.b[blockIdx.y].n_chunks, 32))
     reinterpret_cast<unsigned long long *>(mb.b[blockIdx.y].scan_tmp)[threadIdx.x] = 0ull;
-  collate_phase1_body(ds_indptr, ds_indices, users, S, 1, all, nrow_blk, mb.b[blockIdx.y], cur);
+  // (the grid may hold fewer workgroups than roles: the look-ahead collation of a replayed group runs BESIDE the
+  // training chain and has eight steps to finish -- a small grid takes few of the chain's wave slots; rk_collate_at_multi)
+  for (int bx = blockIdx.x; bx < nbx; bx += gridDim.x) {
+    collate_phase1_body(ds_indptr, ds_indices, users, S, 1, all, nrow_blk, mb.b[blockIdx.y], cur, bx, nbx);
+    __syncthreads();
+  }
 }
 
 // ---- count: marked items per chunk (large catalogues) ----
@@ -493,12 +499,12 @@ __device__ __forceinline__ void build_words(const uint32_t *wb, const int w0, co
 __device__ __forceinline__ void collate_build_body(
     const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
     const float *__restrict__ ds_data, const int64_t *__restrict__ users, int S, const rk_block_t &b,
-    rk_cur_t cur, const int seg) {
+    rk_cur_t cur, const int seg, const int bx) {
   extern __shared__ uint32_t wbits[];               // [4 waves][seg words]
   __shared__ int heavy_n[4];
   if (cur.cursor) users += rk_cur_local(cur) * S;
   const int tid = threadIdx.x, wid = tid >> 6, lane = tid & 63;
-  const int row = blockIdx.x * 4 + wid;
+  const int row = bx * 4 + wid;
   const bool live = row < S;
   const int wr = (b.counts[0] + 31) >> 5;          // bitmap words in use
   int64_t beg = 0;
@@ -532,7 +538,7 @@ __device__ __forceinline__ void collate_build_body(
   __syncthreads();
   for (int j = 0; j < 4; ++j) {
     if (heavy_n[j] == 0) continue;                   // (uniform)
-    const int rj = blockIdx.x * 4 + j;
+    const int rj = bx * 4 + j;
     const int64_t u = users[rj];
     const int64_t bj = ds_indptr[u];
     const int oj = b.indptr[rj];
@@ -557,14 +563,17 @@ __global__ __launch_bounds__(256) void collate_build_kernel(
     const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
     const float *__restrict__ ds_data, const int64_t *__restrict__ users, int S, rk_block_t b,
     rk_cur_t cur, int seg) {
-  collate_build_body(ds_indptr, ds_indices, ds_data, users, S, b, cur, seg);
+  collate_build_body(ds_indptr, ds_indices, ds_data, users, S, b, cur, seg, (int)blockIdx.x);
 }
 __global__ __launch_bounds__(256) void collate_build_multi_kernel(
     const int64_t *__restrict__ ds_indptr, const int32_t *__restrict__ ds_indices,
     const float *__restrict__ ds_data, const int64_t *__restrict__ users, int S, MultiBlk mb,
-    rk_cur_t cur, int seg) {
+    rk_cur_t cur, int seg, int nbx) {
   cur.off += (int)blockIdx.y;
-  collate_build_body(ds_indptr, ds_indices, ds_data, users, S, mb.b[blockIdx.y], cur, seg);
+  for (int bx = blockIdx.x; bx < nbx; bx += gridDim.x) {        // (see collate_phase1_multi_kernel)
+    collate_build_body(ds_indptr, ds_indices, ds_data, users, S, mb.b[blockIdx.y], cur, seg, bx);
+    __syncthreads();
+  }
 }
 
 }  // namespace
@@ -697,9 +706,15 @@ extern "C" int rk_collate_at_multi(const int64_t *ds_indptr, const int32_t *ds_i
     if (nzero < 1) nzero = 1;
     if (nzero > 512) nzero = 512;
   }
+  // workgroups per block of the two row-parallel launches: 32 (RK_COLLATE_GRID; 0 = one per role).  These launches run
+  // BESIDE the training chain of a replayed group (graph.GraphStepper's look-ahead collation), which pays for every wave
+  // slot they hold: 8 x 32 looping workgroups instead of 8 x 125-150 short ones -- the collation takes 81 instead of 60 us
+  // of its stream, the chain loses 0.7-3.3 us per step less (tools/probes/ab_collate_grid.sh)
+  static const int cap = [] { const char *e = getenv("RK_COLLATE_GRID"); return e ? atoi(e) : 32; }();
   if (phase != 2) {
-    RK_LAUNCH(collate_phase1_multi_kernel, dim3(nrow_blk + 1 + nzero, n_blk), dim3(256), 0, stream, ds_indptr,
-              ds_indices, users_base, S, all, nrow_blk, mb, cur);
+    const int nbx = nrow_blk + 1 + nzero;
+    RK_LAUNCH(collate_phase1_multi_kernel, dim3(cap > 0 ? std::min(cap, nbx) : nbx, n_blk), dim3(256), 0, stream, ds_indptr,
+              ds_indices, users_base, S, all, nrow_blk, mb, cur, nbx);
     RK_CHECK_LAUNCH("collate_phase1_multi");
   }
   if (phase == 1) return 0;
@@ -714,8 +729,8 @@ extern "C" int rk_collate_at_multi(const int64_t *ds_indptr, const int32_t *ds_i
     RK_CHECK_LAUNCH("collate_assign_multi");
   }
   const int seg = seg_words_for(b0->n_cap);
-  RK_LAUNCH(collate_build_multi_kernel, dim3(rk_cdiv(S, 4), n_blk), dim3(256), 4 * seg * sizeof(uint32_t), stream,
-            ds_indptr, ds_indices, ds_data, users_base, S, mb, cur, seg);
+  RK_LAUNCH(collate_build_multi_kernel, dim3(cap > 0 ? std::min(cap, rk_cdiv(S, 4)) : rk_cdiv(S, 4), n_blk), dim3(256),
+            4 * seg * sizeof(uint32_t), stream, ds_indptr, ds_indices, ds_data, users_base, S, mb, cur, seg, rk_cdiv(S, 4));
   RK_CHECK_LAUNCH("collate_build_multi");
   return 0;
 }
