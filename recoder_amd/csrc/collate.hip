@@ -706,14 +706,15 @@ extern "C" int rk_collate_at_multi(const int64_t *ds_indptr, const int32_t *ds_i
     if (nzero < 1) nzero = 1;
     if (nzero > 512) nzero = 512;
   }
-  // workgroups per block of the two row-parallel launches: 32 (RK_COLLATE_GRID; 0 = one per role).  These launches run
-  // BESIDE the training chain of a replayed group (graph.GraphStepper's look-ahead collation), which pays for every wave
-  // slot they hold: 8 x 32 looping workgroups instead of 8 x 125-150 short ones -- the collation takes 81 instead of 60 us
-  // of its stream, the chain loses 0.7-3.3 us per step less (tools/probes/ab_collate_grid.sh)
-  static const int cap = [] { const char *e = getenv("RK_COLLATE_GRID"); return e ? atoi(e) : 32; }();
+  // workgroups per block of the two row-parallel launches.  These launches run BESIDE the training chain of a replayed
+  // group (graph.GraphStepper's look-ahead collation), which pays for every wave slot they hold: 8 x 32 looping workgroups
+  // instead of 8 x 125-150 short ones -- the collation takes 81 instead of 60 us of its stream, the chain loses less to it
+  // (C2, alternating on one box, four boxes: 0.0933-0.0948 vs 0.0954-0.0970 ms per step; caps of 16 .. 64 within 0.5 us
+  // of each other, 4 no better than none)
+  constexpr int cap = 32;
   if (phase != 2) {
     const int nbx = nrow_blk + 1 + nzero;
-    RK_LAUNCH(collate_phase1_multi_kernel, dim3(cap > 0 ? std::min(cap, nbx) : nbx, n_blk), dim3(256), 0, stream, ds_indptr,
+    RK_LAUNCH(collate_phase1_multi_kernel, dim3(std::min(cap, nbx), n_blk), dim3(256), 0, stream, ds_indptr,
               ds_indices, users_base, S, all, nrow_blk, mb, cur, nbx);
     RK_CHECK_LAUNCH("collate_phase1_multi");
   }
@@ -729,7 +730,7 @@ extern "C" int rk_collate_at_multi(const int64_t *ds_indptr, const int32_t *ds_i
     RK_CHECK_LAUNCH("collate_assign_multi");
   }
   const int seg = seg_words_for(b0->n_cap);
-  RK_LAUNCH(collate_build_multi_kernel, dim3(cap > 0 ? std::min(cap, rk_cdiv(S, 4)) : rk_cdiv(S, 4), n_blk), dim3(256),
+  RK_LAUNCH(collate_build_multi_kernel, dim3(std::min(cap, rk_cdiv(S, 4)), n_blk), dim3(256),
             4 * seg * sizeof(uint32_t), stream, ds_indptr, ds_indices, ds_data, users_base, S, mb, cur, seg, rk_cdiv(S, 4));
   RK_CHECK_LAUNCH("collate_build_multi");
   return 0;
