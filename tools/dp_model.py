@@ -75,11 +75,11 @@ def main():
     # sets of two consecutive steps + the chunk cover (it reaches the dense sweep where the union is the catalogue)
     lazy1 = None
     if name == "c2":
-      fixed, scaled, adam1 = 13.5, 24.0 + 9.1 + 17.8 + 15.3, 35.0   # enc fwd | fdec, reduce, dW (dense) + encoder backward of the PHASED step (r06 one-rank line) | dense sweep
+      fixed, scaled, adam1 = 12.5, 23.6 + 9.2 + 17.9 + 14.3, 35.0   # enc fwd | fdec, reduce, dW (dense) + encoder backward of the PHASED step (r06 one-rank line) | dense sweep
       lazy1 = 29.0
     elif name == "c3":
-      fixed, scaled, adam1 = 11.5 + 2 * 6.5 + 2 * 9.4, 19.8 + 17.3 + 25.4 + 7.0 + 30.0 + 6.3, 68.0   # enc fwd, Linears | decode, mnll, dZ, reduce, dW||enc bwd, split | dense sweep
-      lazy1 = 50.0
+      fixed, scaled, adam1 = 10.5 + 2 * 6.6 + 2 * 8.9, 18.7 + 15.2 + 16.8 + 6.3 + 28.9 + 5.0, 68.0   # enc fwd, Linears | decode, mnll, dZ, reduce, dW||enc bwd, split | dense sweep
+      lazy1 = 48.0
     elif name == "c4":
       fixed, scaled, adam1 = 6.5 + 7.6 + 8.4 + 6.5, 28.0 + 20.0, 17.0   # gather, split, loss reduce, user rows | fused decode, dW || colsum || reduce | SparseAdam
     else:
