@@ -55,11 +55,7 @@ DW_BF16X3 = False     # (dW on bf16 triples: an rk_tune knob of the probe header
 PRODUCTS = {"rk_decode_loss": 3, "rk_decode_bwd_dz": 3, "rk_decode_bwd_dw": 6 if DW_BF16X3 else 3,
             "rk_decode_bwd_dw3": 6}
 ENTRIES = ["rk_ae_encode_fwd", "rk_decode_loss", "rk_decode_bwd_dz", "rk_decode_bwd_dw",
-           "rk_ae_encode_bwd", "rk_adam_multi", "rk_adam_de"]
-# rk_adam_de_side() (csrc/step.hip): the decoder table's Adam sweep is a launch of its own on the dW
-# stream ("rk_adam_de"), the step's update launch ("rk_adam_multi") covers the rest -- the SAME kernel
-# twice per step; set in main() from the library
-ADAM_DE_SIDE = False
+           "rk_ae_encode_bwd", "rk_adam_multi"]
 # the one-call step's launch structure (set in main() from the library): dZ fused into the decode
 # launch (decode16.hip DZT: "rk_decode_loss" then carries both contractions, "rk_decode_bwd_dz" is the
 # slab reduce alone) and dW || encoder backward as one launch (dw3.hip dw_encbwd_kernel: bracketed as
@@ -76,7 +72,7 @@ KERNELS = {"rk_ae_encode_fwd": ["ae_encode_fwd_kernel (+ the W_de[items] split w
            "rk_decode_bwd_dz": ["dz_planes_kernel<TN>", "splitk_reduce_kernel"],
            "rk_decode_bwd_dw": ["dw3_kernel<BN,PLAIN,PAIRS> (+ split_planes_t_kernel when the encoder did not write Z^T)"],
            "rk_ae_encode_bwd": ["ae_encode_bwd_cols_kernel", "ae_encode_bwd_kernel"],
-           "rk_adam_multi": ["adam_multi_kernel"], "rk_adam_de": ["adam_multi_kernel"],
+           "rk_adam_multi": ["adam_multi_kernel"],
            "rk_decode_loss_dz_planes": ["decode_planes_kernel<1,2,EPI,3,false,DZT> (decode + loss + dZ partials)"],
            "rk_decode_loss_planes": ["decode_planes_kernel<TM,2,EPI>"],
            "rk_decode_bwd_dz_planes": ["dz_planes_kernel<TN>", "splitk_reduce_kernel"],
@@ -192,14 +188,7 @@ def algorithmic_work(entry, B, h0, n_b, nnz, n_items, cfg_sparse=False):
       rest = n_items * 28 + n_b * 32 + h0 * 28
     else:
       table, rest = n_items * h0 * 24 + n_b * h0 * 4 + n_items * 4, n_items * 28 + n_b * 32 + h0 * 28
-    if ADAM_DE_SIDE:        # this launch: the encoder table + the small tensors
-      return "hbm", (table + rest) / 1e9, "GB/s"
     return "hbm", (2 * table + extra + rest) / 1e9, "GB/s"
-  if entry == "rk_adam_de":  # the decoder table behind dW (its gradient arrives as K slabs, summed here)
-    tiles = -(-int(n_b) // 64) * -(-h0 // (128 if h0 <= 128 else 256))
-    slabs = 1 if GEMM_F32 else max(1, min(256 // max(tiles, 1), 4, (-(-B // 64) * 64) // 64))
-    table = n_b * h0 * 28 if cfg_sparse else n_items * h0 * 24 + n_b * h0 * 4 + n_items * 4
-    return "hbm", (table + (slabs - 1) * n_b * h0 * 4) / 1e9, "GB/s"
   return "hbm", 0.0, "GB/s"
 
 
@@ -731,10 +720,10 @@ def main():
     n_b, nnz = float(np.mean(nbs)), float(np.mean(nnzs))
     global LAZY_ROWS
     LAZY_ROWS = float(np.mean(swept)) if swept else None
-    KERNELS["rk_adam_multi"] = KERNELS["rk_adam_de"] = ["adam_multi_kernel<true>" if LAZY_ROWS is not None else "adam_multi_kernel<false>"]
+    KERNELS["rk_adam_multi"] = ["adam_multi_kernel<true>" if LAZY_ROWS is not None else "adam_multi_kernel<false>"]
     ev_over = eng.event_pair_overhead_ms()
     timed = eng.timed_samples_ms()
-    global ADAM_DE_SIDE, FUSED_DZ, FUSED_DW_ENC
+    global FUSED_DZ, FUSED_DW_ENC
     from recoder_amd import _lib as _rk_lib
     one_call = cfg["kind"] == "ae" and len(cfg["hidden_layers"]) == 1 and cfg["loss"] in ("mse", "logistic") \
         and getattr(eng, "ws_dw", None) is not None and not multi and getattr(eng, "planes", None) is not None
@@ -765,8 +754,6 @@ def main():
         KERNELS["rk_decode_bwd_dz"] = ["splitk_reduce_kernel"]
         if FUSED_DW_ENC:
           KERNELS["rk_decode_bwd_dw"] = ["dw_encbwd_kernel<BN, HV> (csrc/dw3.hip)"]
-    ADAM_DE_SIDE = bool(_rk_lib.load().rk_adam_de_side()) and getattr(eng, "ws_dw", None) is not None and \
-        not multi and bool(timed.get("rk_adam_de") or T["warm"].get("rk_adam_de"))
 
     pmc_file, pmc_entries = None, {}
     if args.config == "c2" and not multi:
@@ -854,12 +841,11 @@ def main():
       kernels = [dict(name="rk_adam_multi", kernels=KERNELS.get("rk_adam_multi", []), avg_us=float("nan"),
                       samples=0, sampled="none", bound="hbm", achieved=float("nan"), peak=PEAK_HBM_GBS,
                       unit="GB/s", frac=float("nan"), ideal_us=float("nan"))]
-    # the dominant KERNEL: the one the step spends most time in, over all its launches (the Adam sweep
-    # runs as two launches of adam_multi_kernel when the decoder table's half sits on the dW stream)
+    # the dominant KERNEL: the one the step spends most time in, over all its launches
     by_kernel = {}
     for k in kernels:
       if k["avg_us"] == k["avg_us"]:
-        key = tuple(k["kernels"]) if k["name"] in ("rk_adam_multi", "rk_adam_de") else (k["name"],)
+        key = tuple(k["kernels"]) if k["name"] == "rk_adam_multi" else (k["name"],)
         by_kernel.setdefault(key, []).append(k)
     group = max(by_kernel.values(), key=lambda ks: sum(k["avg_us"] * k.get("launches_per_step", 1) for k in ks)) \
         if by_kernel else [kernels[0]]
@@ -884,8 +870,7 @@ def main():
                           "separate runs, tools/profile_round.sh) -- NOT collected in this run" % pmc_file)
     # the dW launch group runs on the side stream NEXT to dZ -> encoder backward
     # (rk_ae_step_t.dw_stream): it is not a link of the step's chain then
-    side = ["rk_decode_bwd_dw", "rk_adam_de"] if (getattr(eng, "ws_dw", None) is not None and not multi and
-                                                  not FUSED_DW_ENC) else []
+    side = ["rk_decode_bwd_dw"] if (getattr(eng, "ws_dw", None) is not None and not multi and not FUSED_DW_ENC) else []
     for k in kernels:
       if k["name"] in side:
         k["concurrent_with"] = ["rk_decode_bwd_dz", "rk_ae_encode_bwd"]

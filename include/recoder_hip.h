@@ -64,11 +64,8 @@ typedef struct rk_plan {
   int32_t decode_dz_fused_ok;      /* rk_decode_loss_dz_planes */
   int32_t fdec_ok;                 /* rk_fdec_loss_dz */
   int32_t dw_encode_bwd_fused_ok;  /* dW || encoder backward in one launch */
-  int32_t adam_de_side;            /* the probe header's RK_TUNE_ADAM_DE_SIDE: the decoder table's Adam sweep is a
-                                      launch of its own behind the dW kernel on dw_stream (off by default) */
   int32_t encode_bwd_segments;     /* the fused fp32 dW || encoder-backward call writes G_en as this many partial
                                       arrays of n_cap * h floats (gb_en: of h floats), summed by rk_adam_multi */
-  int32_t _pad0;
   int64_t dw3_slabs_offset_bytes;  /* rk_decode_bwd_dw3 / dw2 with G_de == NULL leave their K slabs this far into the
                                       workspace (behind the Z^T planes) */
   int32_t mf_fdec_ok;              /* entry-by-entry sequenced steps (MatrixFactorization: rk_fdec_loss_dz +
@@ -557,9 +554,7 @@ enum { RK_PAR_W_EN = 0, RK_PAR_B_EN = 1, RK_PAR_W_DE = 2, RK_PAR_B_DE = 3, RK_PA
 enum { RK_ENTRY_NONE = 0, RK_ENTRY_ENCODE_FWD = 1, RK_ENTRY_DECODE_LOSS = 2,
        RK_ENTRY_DECODE_BWD_DZ = 3, RK_ENTRY_DECODE_BWD_DW = 4, RK_ENTRY_ENCODE_BWD = 5,
        RK_ENTRY_ADAM_MULTI = 6,
-       RK_ENTRY_ADAM_DE = 7 /* the decoder table's Adam sweep when it runs behind dW on dw_stream
-                               (rk_adam_de_side): the same kernel as ADAM_MULTI, a launch of its own */,
-       RK_ENTRY_COUNT = 8,
+       RK_ENTRY_COUNT = 7,
        RK_ENTRY_ALL = -1 /* bracket every entry: rk_ae_step_t.time_all */ };
 /* rk_ae_step_t.phase: which part of the step to enqueue (0 = all).  Data parallel
  * callers run FWD_DW, all-reduce the decoder-side gradients, DZ_ENC, all-reduce the

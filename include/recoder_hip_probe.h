@@ -29,7 +29,8 @@ int rk_probe_buffer(int32_t which, unsigned long long *buffer);
  *   RK_TUNE_DW_ENC_FUSED  1  dW || encoder backward in one launch (rk_plan_t.dw_encode_bwd_fused_ok); 0: never (the step then
  *                            leaves the register-resident fused decode too)
  *   RK_TUNE_DW_BF16X3     0  dW on bf16 triples (no operand range) instead of fp16 pairs
- *   RK_TUNE_ADAM_DE_SIDE  0  the decoder table's Adam sweep as a launch of its own behind dW on dw_stream
+ *   RK_TUNE_ADAM_DE_SIDE  -  (the decoder table's Adam sweep as a launch of its own behind dW on dw_stream: removed in
+ *                            round 6 -- +1.2 % at C2 in round 3, excluded by the lazy sweeps since; the index stays reserved)
  *   RK_TUNE_PG_TILE       0  decode tile of csrc/pgemm.hip: 256 (256 x 256), 1282 (128 x 256), 0 = by batch size
  *   RK_TUNE_DZ_TN         0  column tiles (of 32 hidden units) per workgroup of rk_decode_bwd_dz_planes: 2/4/7/8
  *   RK_TUNE_DZ_SPLITS     0  cap of rk_decode_bwd_dz's split-K (multiple of 8)

@@ -56,8 +56,8 @@ class RkPlan(Structure):
     ("dw_workspace_bytes", c_int64), ("dw3_workspace_bytes", c_int64), ("dw3_planes_bytes", c_int64),
     ("fdec_workspace_bytes", c_int64), ("pg_dz_workspace_bytes", c_int64), ("pg_dw_workspace_bytes", c_int64),
     ("pg_scale_floats", c_int64), ("pg_mnll_workspace_floats", c_int64),
-    ("decode_dz_fused_ok", c_int32), ("fdec_ok", c_int32), ("dw_encode_bwd_fused_ok", c_int32), ("adam_de_side", c_int32),
-    ("encode_bwd_segments", c_int32), ("_pad0", c_int32), ("dw3_slabs_offset_bytes", c_int64),
+    ("decode_dz_fused_ok", c_int32), ("fdec_ok", c_int32), ("dw_encode_bwd_fused_ok", c_int32),
+    ("encode_bwd_segments", c_int32), ("dw3_slabs_offset_bytes", c_int64),
     ("mf_fdec_ok", c_int32),
   ]
 
@@ -65,7 +65,7 @@ class RkPlan(Structure):
 PAR_W_EN, PAR_B_EN, PAR_W_DE, PAR_B_DE = 0, 1, 2, 3
 ENTRY_ALL = -1
 ENTRY = {"rk_ae_encode_fwd": 1, "rk_decode_loss": 2, "rk_decode_bwd_dz": 3, "rk_decode_bwd_dw": 4,
-         "rk_ae_encode_bwd": 5, "rk_adam_multi": 6, "rk_adam_de": 7}
+         "rk_ae_encode_bwd": 5, "rk_adam_multi": 6}
 
 
 class RkAeStep(Structure):
@@ -307,7 +307,7 @@ def _install_plan_accessors(lib):
       ("pg_mnll_workspace_floats", ("B", "n_cap")), ("pg_dz_workspace_bytes", ("B", "h")),
       ("pg_dw_splits", ("B", "h", "n_cap")), ("pg_dw_workspace_bytes", ("B", "h", "n_cap")),
       ("dw3_planes_bytes", ("B", "h")), ("dw3_rows_pad", ("B",)), ("dw3_cols_pad", ("h",)), ("gemm_split16", ()),
-      ("gemm_plain_bf16", ()), ("adam_de_side", ()), ("dw_splits", ("B",)), ("graph_timing_supported", ()), ("topk_max_k", ()),
+      ("gemm_plain_bf16", ()), ("dw_splits", ("B",)), ("graph_timing_supported", ()), ("topk_max_k", ()),
       ("topk_pairs_max_cap", ()), ("encode_bwd_segments", ("B",))):
     setattr(lib, "rk_" + name, field(name, args))
   # (the K slabs of rk_decode_bwd_dw3 / dw2 inside their workspace: a pointer, as the export of rounds 2-5 returned it)

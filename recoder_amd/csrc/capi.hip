@@ -50,7 +50,6 @@ extern "C" int rk_plan(rk_plan_t *p) {
   p->decode_dz_fused_ok = rk_decode_dz_fused_ok(B, h, n, loss);
   p->fdec_ok = rk_fdec_ok(B, h, n, loss);
   p->dw_encode_bwd_fused_ok = rk_dw_encode_bwd_fused_ok(p->row_off, B);
-  p->adam_de_side = rk_adam_de_side();
   p->encode_bwd_segments = rk_encode_bwd_segments(B);
   p->dw3_slabs_offset_bytes = (const char *)rk_dw3_slabs(nullptr, B, h) - (const char *)nullptr;
   p->mf_fdec_ok = (rk_tune_get(RK_TUNE_MF_FDEC) != 0 && B < 1024 && rk_fdec_ok(B, h, n, loss)) ? 1 : 0;

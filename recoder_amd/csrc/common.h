@@ -50,7 +50,6 @@ int rk_splitk_reduce(const float *ws, int M, int N, const int32_t *Kdev, int spl
 int rk_dz_splits(int B);
 extern "C" int32_t rk_gemm_plain_bf16(void);
 extern "C" int32_t rk_dw_pairs(void);
-extern "C" int32_t rk_adam_de_side(void);
 extern "C" int32_t rk_dw_encode_bwd_fused_ok(int32_t row_off, int32_t B);
 int rk_adam_multi_at(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part, int32_t n_part,
                      float denom, float *loss_out, const int64_t *cursor, int32_t cursor_off,

@@ -62,7 +62,6 @@ void rk_gemm_probe(unsigned long long *buffer);
 void rk_dw3_probe(unsigned long long *buffer);
 void rk_enc_probe(unsigned long long *buffer);
 void rk_planes_probe(unsigned long long *buffer);
-int32_t rk_adam_de_side(void);
 int rk_split_w(const float *W_de, int32_t h, const rk_block_t *tgt, const int32_t *ranges,
                const rk_planes_t *pl, void *stream);
 int rk_split_z(const float *Z, int32_t B, int32_t h, const int32_t *ranges, const rk_planes_t *pl,

@@ -710,13 +710,6 @@ int rk_adam_multi_at(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part
   return 0;
 }
 
-// RK_ADAM_DE_SIDE=1: the decoder table's sweep as a launch of its own behind dW on dw_stream (off by
-// default: +1.2 % throughput at C2, but the sweep then shares the chip with the encoder backward and
-// reads 0.52 of the HBM peak instead of 0.68 -- DESIGN.md section 4)
-extern "C" int32_t rk_adam_de_side(void) {
-  return rk_tune_get(RK_TUNE_ADAM_DE_SIDE) == 1;
-}
-
 extern "C" int rk_adam_multi(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part,
                              int32_t n_part, float denom, float *loss_out, void *stream_) {
   if (const rk_replay_t *rp = rk_replay_get()) {

@@ -490,9 +490,6 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
   const bool pg = pg_mode == 1, fdec = pg_mode == 3;
   const float *dw_slabs_pg = dw_branch ? a->ws_dw : a->ws;
   const bool dw_ones = dw_enc_fused && step_dw_ones(a, pg_mode);
-  // opt-in (rk_adam_de_side): the decoder table's Adam sweep right behind the dW kernel ON dw_stream,
-  // next to the reduce / encoder backward; the update on the chain then covers the rest
-  const bool de_side = dw_branch && !dw_enc_fused && phase == RK_STEP_ALL && rk_adam_de_side() != 0;
   if (phase & RK_STEP_FWD_DW) {
     {
       Timer t(a, RK_ENTRY_ENCODE_FWD, sm);
@@ -611,10 +608,8 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
         else if (fdec) RK_TRY(rk_pg_dw(a->dO, a->do_scales, 32, 64, B, a->planes, blk, a->ws_dw, a->gb_de, a->dw_stream));
         else RK_TRY(dw_call(a, nullptr, nullptr, planes, a->ws_dw, a->dw_stream));
       }
-      if (!de_side) {
-        RK_TRY(rk_event_record(a->dw_join, a->dw_stream));
-        RK_TRY(rk_stream_wait_event(sm, a->dw_join));
-      }
+      RK_TRY(rk_event_record(a->dw_join, a->dw_stream));
+      RK_TRY(rk_stream_wait_event(sm, a->dw_join));
     } else if (dw3) {
       // the dZ slabs in the workspace are consumed: the bf16-pipe dW takes it over (Z^T planes +
       // its own K slabs, which rk_adam_multi sums while it reads the gradient)
@@ -653,19 +648,7 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
         jobs[n].g_stride = blk->n_cap * h; jobs[n].gparts_dev = blk->counts + 4;
       }
       slots[n] = RK_PAR_W_DE;
-      if (de_side) {
-        RK_REQUIRE(a->lazy_stamp_en == nullptr, "rk_adam_de_side and lazy Adam do not combine");
-        const int32_t sl = RK_PAR_W_DE;
-        {
-          Timer t(a, RK_ENTRY_ADAM_DE, a->dw_stream);
-          RK_TRY(rk_adam_multi_at(&jobs[n], 1, nullptr, 0, a->denom, nullptr, a->cursor, a->cursor_off,
-                                  a->adam_table, RK_PAR_COUNT, &sl, nullptr, 0, a->dw_stream));
-        }
-        RK_TRY(rk_event_record(a->dw_join, a->dw_stream));
-        RK_TRY(rk_stream_wait_event(sm, a->dw_join));
-      } else {
-        ++n;
-      }
+      ++n;
     }
     // sharded dense Adam (rk_ae_step_t.zero_lo): the table jobs cover this rank's rows only and read the
     // reduce-scattered dense gradient shard -- row r of the table at zero_g + (r - zero_lo) * h

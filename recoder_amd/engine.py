@@ -283,7 +283,7 @@ class FusedEngine:
     the step's item set that the next step does not read are caught up later by replaying their missed
     steps bit for bit (csrc/optim.hip table_sweep_lazy)."""
     if (self.lazy_period < 1 or self.kind != "ae" or self.item_parallel is not None or
-        self.h[0] % 4 != 0 or bool(_lib.load().rk_adam_de_side())):
+        self.h[0] % 4 != 0):
       return []
     if self.allreduce is not None:
       # users-DP: the replicated update only (every rank sweeps the same rows of identical tables; the blocks' item

@@ -1892,39 +1892,3 @@ def test_hook_order_that_is_not_one_pass_takes_the_eager_path(monkeypatch):
     return np.concatenate(rec.loss_history)
   a, b = run(False), run(True)
   assert len(a) == 2 * 3 and np.array_equal(a, b)
-
-
-def test_optional_step_layouts_are_bitwise_equal_to_the_default(tmp_path):
-  """The step layout behind rk_tune(RK_TUNE_ADAM_DE_SIDE, 1) (the decoder table's Adam sweep as a launch of
-  its own behind dW on the side stream; include/recoder_hip_probe.h) trains to the SAME bits as the
-  default: same jobs, same arithmetic, another launch order."""
-  import subprocess
-  import sys
-  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  script = (
-    "import sys, numpy as np, torch\n"
-    "sys.path.insert(0, %r)\n"
-    "from tests.test_hip_parity import synth_csr\n"
-    "from recoder_amd import _lib\n"
-    "_lib.check(_lib.load().rk_tune(5, int(sys.argv[2])), 'rk_tune')   # RK_TUNE_ADAM_DE_SIDE\n"
-    "from recoder_amd.data import RecommendationDataset\n"
-    "from recoder_amd.model import Recoder\n"
-    "from recoder_amd.nn import DynamicAutoencoder\n"
-    "csr = synth_csr(900, 1500, 20, seed=41)\n"
-    "torch.manual_seed(5)\n"
-    "m = DynamicAutoencoder([64], activation_type='tanh', noise_prob=0.3, sparse=False)\n"
-    "rec = Recoder(model=m, use_cuda=True, optimizer_type='adam', loss='mse')\n"
-    "rec.user_order_hook = lambda e, n: np.random.RandomState(e).permutation(n)\n"
-    "rec.train(RecommendationDataset(csr), batch_size=100, lr=1e-3, weight_decay=2e-5, num_epochs=3, negative_sampling=True)\n"
-    "out = {'losses': np.concatenate(rec.loss_history)}\n"
-    "out.update({k: v.detach().cpu().numpy() for k, v in m.named_parameters()})\n"
-    "np.savez(sys.argv[1], **out)\n" % root)
-  res = {}
-  for name, knob in (("default", "0"), ("de_side", "1")):
-    path = str(tmp_path / (name + ".npz"))
-    r = subprocess.run([sys.executable, "-c", script, path, knob], env=dict(os.environ, PYTHONPATH=root),
-                       cwd=root, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    res[name] = np.load(path)
-  for k in res["default"].files:
-    assert np.array_equal(res["default"][k], res["de_side"][k]), k
