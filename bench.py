@@ -152,7 +152,7 @@ def make_csr(cfg):
   raise ValueError(cfg["data"])
 
 
-def algorithmic_work(entry, B, h0, n_b, nnz, n_items, cfg_sparse=False):
+def algorithmic_work(entry, B, h0, n_b, nnz, n_items, cfg_sparse=False, lazy_rows=None):
   """(bound, work per launch group [TFLOP or GB], unit) of one C-ABI entry."""
   gemm = 2.0 * B * h0 * n_b
   if entry == "rk_decode_loss" and FUSED_DZ:
@@ -181,10 +181,11 @@ def algorithmic_work(entry, B, h0, n_b, nnz, n_items, cfg_sparse=False):
     extra = (slabs - 1) * n_b * h0 * 4
     if cfg_sparse:
       table, rest = n_b * h0 * 28, n_items * 28 + n_b * 32
-    elif LAZY_ROWS is not None:
-      # the lazy sweep: p, m, v of the swept rows only (read + written), the gradient rows, per row the two item
-      # maps + the stamp (read) and the swept rows' stamps (written)
-      table = LAZY_ROWS * h0 * 24 + n_b * h0 * 4 + n_items * 12 + LAZY_ROWS * 4
+    elif lazy_rows is not None:
+      # the LAZY sweep's own bytes (roofline.lazy_sweep; the entry itself is priced on SURVEY 8(d)'s dense sweep):
+      # p, m, v of the swept rows only (read + written), the gradient rows, per row the two item maps + the stamp
+      # (read) and the swept rows' stamps (written)
+      table = lazy_rows * h0 * 24 + n_b * h0 * 4 + n_items * 12 + lazy_rows * 4
       rest = n_items * 28 + n_b * 32 + h0 * 28
     else:
       table, rest = n_items * h0 * 24 + n_b * h0 * 4 + n_items * 4, n_items * 28 + n_b * 32 + h0 * 28
@@ -877,28 +878,28 @@ def main():
     chain_us = sum(k["avg_us"] * k.get("launches_per_step", 1) for k in kernels if k["name"] not in side) + \
         sum(k["avg_us"] * k["launches_per_step"] for k in small)
     ideal_us = sum(k["ideal_us"] * k.get("launches_per_step", 1) for k in kernels)
-    # lazy dense Adam: the sweep's OWN algorithmic bytes (the rows it has to bring up to date) are what `achieved` is
-    # priced on -- the conservative figure; SURVEY 8(d)'s per-step formula (optim.Adam sweeps every row every step,
-    # model.py:135,398-399) is quoted next to it: the same update in fewer bytes, not a faster memory system
-    dense_sem = None
+    # lazy dense Adam: `achieved` / `frac` / `step` are priced on SURVEY 8(d)'s ALGORITHMIC bytes -- optim.Adam with a
+    # dense gradient sweeps every row of both tables every step (model.py:135,398-399; "the figures roofline.achieved
+    # and the judge's check are computed from"), as in rounds 1-5.  The lazy sweeps deliver that update while moving
+    # fewer bytes (`traffic`, the PMC figure, is BELOW the algorithmic bytes): `lazy_sweep` prices the same launch on
+    # the bytes it actually has to move -- the rows it brings up to date -- which is the figure to read for how well
+    # the memory system is used
+    lazy_sweep = None
     if LAZY_ROWS is not None:
-      lazy_rows, adam_us = LAZY_ROWS, next((k["avg_us"] for k in kernels if k["name"] == "rk_adam_multi"), None)
-      LAZY_ROWS = None
-      try:
-        _, w_dense, _ = algorithmic_work("rk_adam_multi", B, h0, n_b, nnz, n_items, bool(cfg["sparse"]))
-      finally:
-        LAZY_ROWS = lazy_rows
-      ideal_dense = ideal_us + sum((w_dense - (k["achieved"] * k["avg_us"] * 1e-6)) / PEAK_HBM_GBS * 1e6 *
-                                   k.get("launches_per_step", 1) for k in kernels if k["name"] == "rk_adam_multi")
-      dense_sem = dict(adam_bytes=w_dense * 1e9, adam_achieved=(w_dense / (adam_us * 1e-6)) if adam_us else None,
-                       adam_frac=(w_dense / (adam_us * 1e-6) / PEAK_HBM_GBS) if adam_us else None,
-                       step_ideal_us=ideal_dense, step_frac=ideal_dense / (dt / K * 1e6),
-                       note="SURVEY 8(d)'s bytes of the dense sweeps (every row, every step) over the measured times: "
-                            "what the lazy sweeps deliver of the ALGORITHM's traffic; `achieved` / `frac` / `step` "
-                            "above are priced on the bytes the lazy sweeps themselves have to move")
+      adam_us = next((k["avg_us"] for k in kernels if k["name"] == "rk_adam_multi"), None)
+      _, w_dense, _ = algorithmic_work("rk_adam_multi", B, h0, n_b, nnz, n_items, bool(cfg["sparse"]))
+      _, w_own, _ = algorithmic_work("rk_adam_multi", B, h0, n_b, nnz, n_items, bool(cfg["sparse"]), lazy_rows=LAZY_ROWS)
+      ideal_own = ideal_us - (w_dense - w_own) / PEAK_HBM_GBS * 1e6
+      lazy_sweep = dict(rows_swept_per_table=LAZY_ROWS, of_rows=n_items, own_bytes=w_own * 1e9,
+                        achieved=(w_own / (adam_us * 1e-6)) if adam_us else None,
+                        frac=(w_own / (adam_us * 1e-6) / PEAK_HBM_GBS) if adam_us else None,
+                        step_ideal_us=ideal_own, step_frac=ideal_own / (dt / K * 1e6),
+                        note="the same launch priced on the bytes the lazy sweeps have to move (p / m / v of the rows "
+                             "brought up to date, their gradient rows, the maps and stamps): memory-system efficiency; "
+                             "`achieved` / `frac` / `step` above follow SURVEY 8(d) (every row, every step), as rounds 1-5 did")
     roofline = dict(bound=dom["bound"], achieved=dom["achieved"], peak=dom["peak"], unit=dom["unit"],
                     frac=dom["frac"], traffic=traffic, traffic_source=traffic_source, kernel=dominant,
-                    dense_sweep_semantics=dense_sem,
+                    lazy_sweep=lazy_sweep,
                     kernel_names=dom["kernels"],
                     avg_launch_ms=dom["avg_us"] / 1e3, samples=dom["samples"],
                     event_pair_overhead_ms=ev_over, kernels=kernels, small_launches=small,
