@@ -618,6 +618,12 @@ typedef struct rk_adam_job {
   const int32_t *lazy_pos_next;
   int32_t *lazy_stamp;
   int32_t lazy_period;         /* >= 1 */
+  /* nullable (lazy_pos_next != NULL): the rows that have a gradient or are read by the next step (pos >= 0 or
+   * lazy_pos_next >= 0), ascending, and their number -- built ahead of the step by rk_lazy_need_lists; the sweep then
+   * takes one wave per listed row + one per row of the round-robin chunk instead of one per table row (a third of
+   * C2's waves, two thirds of C3's, found nothing to do) */
+  const int32_t *lazy_need_list;
+  const int32_t *lazy_need_count;
 } rk_adam_job_t;
 
 int rk_adam_multi(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part,
@@ -726,6 +732,9 @@ typedef struct rk_ae_step {
   int32_t *lazy_stamp_en, *lazy_stamp_de;
   const int32_t *lazy_pos_next;
   int32_t lazy_period;
+  /* nullable, with lazy_pos_next: the need list of this block and the next one (rk_lazy_need_lists; both tables share
+   * it: they are swept through the same two maps) */
+  const int32_t *lazy_need_list, *lazy_need_count;
 } rk_ae_step_t;
 
 /*
@@ -785,6 +794,13 @@ int rk_collate_at_multi(const int64_t *ds_indptr, const int32_t *ds_indices, con
                         const int64_t *users_base, int32_t S, int32_t negative_sampling,
                         const int64_t *cursor, int32_t off0, const rk_block_t *const *blks,
                         int32_t n_blk, int32_t phase /* 0: everything */, void *stream);
+/* The need lists of the lazy dense Adam (rk_adam_job_t.lazy_need_list) for the steps of n_blk consecutive collated
+ * blocks: lists[i] (capacity n_items) = the item ids that block i OR block i + 1 holds (pos >= 0), ascending, and
+ * counts[i][0] their number, i = 0 .. n_blk - 2 -- the rows step i's sweep has to touch besides its round-robin chunk.
+ * One launch, no temporaries; catalogues of at most RK_NEED_LIST_MAX_ITEMS items (beyond: no lists, the sweep scans). */
+#define RK_NEED_LIST_MAX_ITEMS (64 * RK_SCAN_CHUNK)
+int rk_lazy_need_lists(const rk_block_t *const *blks, int32_t n_blk, int32_t *const *lists, int32_t *const *counts,
+                       void *stream);
 int rk_cursor_set(int64_t *cursor, int64_t step, int64_t epoch_base, void *stream);
 int rk_adam_consts(double lr, double beta1, double beta2, double eps, double weight_decay,
                    int32_t step, int32_t n_steps, int32_t stride_floats, float *out_host);

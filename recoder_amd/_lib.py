@@ -96,6 +96,7 @@ class RkAeStep(Structure):
     ("zero_lo", c_int32), ("zero_hi", c_int32), ("zero_g_en", c_void_p), ("zero_g_de", c_void_p),
     ("zero_gb_de", c_void_p),
     ("lazy_stamp_en", c_void_p), ("lazy_stamp_de", c_void_p), ("lazy_pos_next", c_void_p), ("lazy_period", c_int32),
+    ("lazy_need_list", c_void_p), ("lazy_need_count", c_void_p),
   ]
 
 
@@ -123,6 +124,7 @@ class RkAdamJob(Structure):
     ("row0", c_int32), ("row_step", c_int32),
     ("amax_out", c_void_p), ("gparts_dev", c_void_p),
     ("lazy_pos_next", c_void_p), ("lazy_stamp", c_void_p), ("lazy_period", c_int32),
+    ("lazy_need_list", c_void_p), ("lazy_need_count", c_void_p),
   ]
 
 
@@ -217,6 +219,7 @@ SIGNATURES = {
   "rk_event_elapsed_ms": (c_float, [c_void_p, c_void_p]),
   "rk_ae_train_step": (c_int32, [POINTER(RkAeStep)]),
   "rk_collate_at": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, c_int32, _BLK, _P]),
+  "rk_lazy_need_lists": (c_int32, [POINTER(_BLK), c_int32, POINTER(c_void_p), POINTER(c_void_p), _P]),
   "rk_collate_at_multi": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, c_int32, POINTER(_BLK), c_int32,
                                           c_int32, _P]),
   "rk_cursor_set": (c_int32, [_P, c_int64, c_int64, _P]),

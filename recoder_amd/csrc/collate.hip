@@ -736,6 +736,93 @@ extern "C" int rk_collate_at_multi(const int64_t *ds_indptr, const int32_t *ds_i
   return 0;
 }
 
+// ---- need lists of the lazy dense Adam (include/recoder_hip.h rk_lazy_need_lists): pair y = (block y, block y + 1),
+//      workgroup x = chunk x of RK_SCAN_CHUNK item ids.  The chunk's offset in the list is counted by the workgroup
+//      itself over the ids in front of it (at most 63 chunks of two L2-resident maps: no temporaries, no second launch) ----
+namespace {
+struct NeedLists {
+  const int32_t *pos_a[RK_COLLATE_MULTI], *pos_b[RK_COLLATE_MULTI];
+  int32_t *list[RK_COLLATE_MULTI], *count[RK_COLLATE_MULTI];
+  int n_items, n_chunks;
+};
+__global__ __launch_bounds__(256) void need_lists_kernel(NeedLists p) {
+  __shared__ int32_t red[4], wsum[4];
+  const int y = blockIdx.y, c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int32_t *pa = p.pos_a[y], *pb = p.pos_b[y];
+  // (16-byte loads, four per map in flight: one id per thread and trip was a chain of dependent round trips --
+  // 47-61 us per launch at C2's ten chunks)
+  int32_t part = 0;
+  const int4 *pa4 = reinterpret_cast<const int4 *>(pa), *pb4 = reinterpret_cast<const int4 *>(pb);
+  const int n4 = c * (RK_SCAN_CHUNK / 4);
+  for (int i0 = tid; i0 < n4; i0 += 4 * 256) {
+    int4 va[4], vb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256;
+      va[u] = i < n4 ? pa4[i] : make_int4(-1, -1, -1, -1);
+      vb[u] = i < n4 ? pb4[i] : make_int4(-1, -1, -1, -1);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      part += ((va[u].x >= 0 || vb[u].x >= 0) ? 1 : 0) + ((va[u].y >= 0 || vb[u].y >= 0) ? 1 : 0) +
+              ((va[u].z >= 0 || vb[u].z >= 0) ? 1 : 0) + ((va[u].w >= 0 || vb[u].w >= 0) ? 1 : 0);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+  if (lane == 0) red[wid] = part;
+  __syncthreads();
+  const int32_t base = red[0] + red[1] + red[2] + red[3];
+  const int it0 = c * RK_SCAN_CHUNK + tid * 8;
+  int32_t f[8], local = 0;
+  int32_t va8[8], vb8[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {               // (loads first: independent)
+    const int it = it0 + k;
+    va8[k] = it < p.n_items ? pa[it] : -1;
+    vb8[k] = it < p.n_items ? pb[it] : -1;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    f[k] = (va8[k] >= 0 || vb8[k] >= 0) ? 1 : 0;
+    local += f[k];
+  }
+  int32_t x = local;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int32_t v = __shfl_up(x, off, 64);
+    if (lane >= off) x += v;
+  }
+  if (lane == 63) wsum[wid] = x;
+  __syncthreads();
+  int32_t woff = 0;
+  for (int w = 0; w < wid; ++w) woff += wsum[w];
+  int32_t o = base + woff + x - local;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (f[k]) p.list[y][o++] = it0 + k;
+  if (c == p.n_chunks - 1 && tid == 255) p.count[y][0] = o;      // (the last thread of the last chunk: the total)
+}
+}  // namespace
+
+extern "C" int rk_lazy_need_lists(const rk_block_t *const *blks, int32_t n_blk, int32_t *const *lists,
+                                  int32_t *const *counts, void *stream_) {
+  RK_REQUIRE(blks != nullptr && n_blk >= 1 && n_blk <= RK_COLLATE_MULTI, "1 .. RK_COLLATE_MULTI blocks");
+  if (n_blk < 2) return 0;
+  RK_REQUIRE(lists != nullptr && counts != nullptr, "null lists / counts");
+  NeedLists p = {};
+  p.n_items = blks[0]->n_items; p.n_chunks = blks[0]->n_chunks;
+  RK_REQUIRE(p.n_items >= 1 && p.n_items <= RK_NEED_LIST_MAX_ITEMS && p.n_chunks == rk_cdiv(p.n_items, RK_SCAN_CHUNK),
+             "catalogue too large for need lists (RK_NEED_LIST_MAX_ITEMS)");
+  for (int i = 0; i + 1 < n_blk; ++i) {
+    RK_REQUIRE(blks[i] && blks[i + 1] && blks[i + 1]->n_items == p.n_items && lists[i] && counts[i], "null block / list");
+    RK_REQUIRE((((uintptr_t)blks[i]->pos | (uintptr_t)blks[i + 1]->pos) & 15) == 0, "pos maps must be 16-byte aligned");
+    p.pos_a[i] = blks[i]->pos; p.pos_b[i] = blks[i + 1]->pos; p.list[i] = lists[i]; p.count[i] = counts[i];
+  }
+  RK_LAUNCH(need_lists_kernel, dim3(p.n_chunks, n_blk - 1), dim3(256), 0, (hipStream_t)stream_, p);
+  RK_CHECK_LAUNCH("lazy_need_lists");
+  return 0;
+}
+
 namespace {
 __global__ void cursor_set_kernel(int64_t *cursor, int64_t step, int64_t epoch_base, int64_t add) {
   if (add) { cursor[0] += add; return; }

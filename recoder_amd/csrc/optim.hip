@@ -239,6 +239,7 @@ struct UTab {
   uint32_t *amax_out;
   int64_t gs4;
   int n_rows, hq, g_parts, tab_slot, lazy_period, blk0, nblk;
+  const int32_t *need_list, *need_count;   // lazy: the need-set outside the chunk as a list (nullable)
   AdamC c;
 };
 
@@ -430,15 +431,24 @@ __device__ __forceinline__ void table_sweep_lazy(const UTab &J, const int lb, co
   // chunk's first row: the long replays start with the launch
   // the constants of the LAST step a row is brought through (this step's; a flush: the one before): every row needs them
   const AdamC C_last = tab[(int64_t)(Tl - (a.flush_only ? 1 : 0)) * tstride];
-  for (int w = __builtin_amdgcn_readfirstlane(lb * 4 + (int)(threadIdx.x >> 6)); w < J.n_rows; w += n_waves) {
-    const int row = w + lo < J.n_rows ? w + lo : w + lo - J.n_rows;
+  // with a need list (rk_lazy_need_lists: the rows with a gradient or read by the next step, whatever the step): work
+  // items 0 .. hi - lo - 1 are the chunk's rows -- those of them the list does not hold -- the others the listed rows;
+  // no wave for a row outside both
+  const bool listed = J.need_list != nullptr;
+  const int n_chunk = hi - lo;
+  const int n_work = listed ? n_chunk + *J.need_count : J.n_rows;
+  for (int w = __builtin_amdgcn_readfirstlane(lb * 4 + (int)(threadIdx.x >> 6)); w < n_work; w += n_waves) {
+    int row;
+    if (listed) row = w < n_chunk ? lo + w : J.need_list[w - n_chunk];
+    else row = w + lo < J.n_rows ? w + lo : w + lo - J.n_rows;
     // the row's three words in ONE round trip (a short-circuited chain of them was three): its gradient row, the next
     // step's, its stamp; the row's vectors are then fetched before the stamp is looked at
     const int pr = (a.flush_only || J.pos == nullptr) ? -1 : J.pos[row];
     const int pn = J.pos_next ? J.pos_next[row] : 0;
     const int nx = J.stamp[row];
     const bool have = pr >= 0;
-    const bool need = have || pn >= 0 || (row >= lo && row < hi);
+    const bool in_list = have || pn >= 0;
+    const bool need = listed ? (w < n_chunk ? !in_list : true) : (in_list || (row >= lo && row < hi));
     if (!need) continue;
     const int lag = end - nx;                                   // steps to apply: [nx, end); <= 0: a flush of a current row
     for (uint32_t q = lane; q < hq; q += 64) {
@@ -670,6 +680,10 @@ int rk_adam_multi_at(const rk_adam_job_t *jobs, int32_t n_jobs, float *loss_part
       t.gs4 = s.g_stride / 4; t.n_rows = s.n_rows; t.hq = s.h / 4; t.g_parts = s.g_parts; t.tab_slot = slot;
       t.c = make_consts(s.par.lr, s.par.beta1, s.par.beta2, s.par.eps, s.par.weight_decay, s.par.step);
       t.nblk = grid_for((int64_t)s.n_rows * s.h / 4);
+      t.need_list = s.lazy_stamp ? s.lazy_need_list : nullptr;
+      t.need_count = s.lazy_stamp ? s.lazy_need_count : nullptr;
+      RK_REQUIRE((t.need_list == nullptr) == (t.need_count == nullptr) && (t.need_list == nullptr || s.lazy_pos_next != nullptr),
+                 "lazy_need_list and lazy_need_count go together, with lazy_pos_next");
       big[a.n_tab++] = j;
       continue;
     }

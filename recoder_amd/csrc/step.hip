@@ -677,6 +677,8 @@ extern "C" int rk_ae_train_step(const rk_ae_step_t *a) {
         jobs[k].lazy_stamp = slots[k] == RK_PAR_W_DE ? a->lazy_stamp_de : a->lazy_stamp_en;
         jobs[k].lazy_pos_next = a->lazy_pos_next;
         jobs[k].lazy_period = a->lazy_period;
+        jobs[k].lazy_need_list = a->lazy_pos_next ? a->lazy_need_list : nullptr;
+        jobs[k].lazy_need_count = a->lazy_pos_next ? a->lazy_need_count : nullptr;
       }
     }
     slots[n] = RK_PAR_B_DE;

@@ -122,7 +122,10 @@ class FusedEngine:
     self.ranges = torch.zeros(128, dtype=torch.int32, device=self.device)
     # lazy dense Adam of the embedding tables (include/recoder_hip.h rk_adam_job_t.lazy_stamp): the round-robin
     # period that bounds a row's lag; RK_ADAM_LAZY=0 switches it off (every row swept every step)
-    self.lazy_period = max(0, int(os.environ.get("RK_ADAM_LAZY", "16")))
+    # ("<period>,list" / "<period>,scan": force the sweeps' need lists on / off -- graph.GraphStepper decides by shape)
+    _lz = os.environ.get("RK_ADAM_LAZY", "16").split(",")
+    self.lazy_period = max(0, int(_lz[0]))
+    self.lazy_lists = _lz[1] if len(_lz) > 1 and _lz[1] in ("list", "scan") else "auto"
     self._lazy_stamps = {}
     self.act_bounded = model.activation_type in ("tanh", "sigmoid")
     self._w_range_stale = True
@@ -357,6 +360,8 @@ class FusedEngine:
     lz = rp.get("lazy") if rp is not None else None
     if lz is not None and pos is not None and rows is None and s.name in lz["names"]:
       j.lazy_stamp, j.lazy_pos_next, j.lazy_period = ptr(self.lazy_stamp(s.name)), lz["pos_next"], self.lazy_period
+      if lz["pos_next"] is not None and lz.get("need"):
+        j.lazy_need_list, j.lazy_need_count = lz["need"]
     self._jobs.append(j)
 
   def _flush_jobs(self, stream):
@@ -1161,7 +1166,7 @@ class FusedEngine:
     st.ws_dw = st.dw_stream = st.dw_fork = st.dw_join = None
     st.zero_lo = st.zero_hi = 0
     st.zero_g_en = st.zero_g_de = st.zero_gb_de = None
-    st.lazy_stamp_en = st.lazy_stamp_de = st.lazy_pos_next = None
+    st.lazy_stamp_en = st.lazy_stamp_de = st.lazy_pos_next = st.lazy_need_list = st.lazy_need_count = None
     st.lazy_period = 0
     lz = replay.get("lazy") if replay is not None else None
     if lz is not None and self.item_parallel is None:
@@ -1170,6 +1175,7 @@ class FusedEngine:
       if not m.is_constrained:
         st.lazy_stamp_de = ptr(self.lazy_stamp("de_embedding_layer.weight"))
       st.lazy_pos_next, st.lazy_period = lz["pos_next"], self.lazy_period
+      st.lazy_need_list, st.lazy_need_count = lz.get("need") or (None, None)
     if dp is not None and self.ws_dw is not None and not m.is_constrained:
       st.ws_dw = ptr(self.ws_dw)        # (phased steps: dW's own workspace lets the decode launch keep its dZ slabs)
     self._ws_dw_live = False

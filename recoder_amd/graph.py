@@ -17,6 +17,7 @@ per-step loss.  The captured kernels are the same C-ABI entry points the eager p
 the ragged last batch, groups bench.py brackets with timing events) run eagerly through them.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -89,6 +90,28 @@ class GraphStepper:
     # read by the NEXT step -- whose block this stepper has collated by then; run() leaves every row up to date
     self.lazy = list(engine.lazy_tables()) if self.G >= 2 else []
     self.ev_join_early = self.lib.rk_event_create(0)
+    # need lists of the lazy sweeps (rk_lazy_need_lists): per block the rows that it or the block behind it holds, built
+    # right behind their collation; a step whose two blocks were collated by one such call hands its sweep the list
+    # Where most rows are skipped: a list saves the waves of the skipped rows (C3, 41 140 items of which a step's two
+    # blocks hold 13 k: the sweep 47.9 -> 44 us, the step 0.191 -> 0.188 ms), and costs two small launches per group on
+    # the side stream -- at C2 (20 108 items, 60 % of them swept) the sweep gains nothing inside the step and the step
+    # loses 1.2 us.  Rule: a block's expected item set (from the matrix's item frequencies) covers less than 30 % of
+    # the catalogue (C2: 39 %, C3: 20 %); RK_ADAM_LAZY=16,list / 16,scan force it
+    mode = getattr(engine, "lazy_lists", "auto")
+    self.need_lists = bool(self.lazy) and self.multi and self.G <= self.MULTI_MAX and mode != "scan"
+    if self.need_lists and mode == "auto":
+      n_items = int(self.blocks[0][0].c.n_items)
+      freq = torch.bincount(dcsr.indices.long(), minlength=n_items).double() / max(1, int(n_users))
+      rows = self.B * (1 if self.dp is None else self.dp.world)
+      self.need_cover = float((1.0 - (1.0 - freq).clamp(0.0, 1.0).pow(rows)).sum()) / max(1, n_items)
+      self.need_lists = self.need_cover < 0.3             # (+ RK_NEED_LIST_MAX_ITEMS, below)
+    # id(block) -> (list [n_items] int32, count [1] int32), allocated HERE: an allocation inside a stream capture
+    # would put its zero fill into the graph, i.e. clear the list again at every replay
+    self._need = {}
+    if self.need_lists and int(self.blocks[0][0].c.n_items) <= 64 * 2048:
+      for blk in self.blocks[0] + self.blocks[1]:
+        self._need[id(blk)] = (torch.zeros(int(blk.c.n_items), dtype=torch.int32, device=device),
+                               torch.zeros(1, dtype=torch.int32, device=device))
     self._stamps_at = None                 # global step at which every stamp says "up to date"
     self.lazy_flushes = 0
 
@@ -119,8 +142,41 @@ class GraphStepper:
   def _cur(self, slot):
     return self.cursors.data_ptr() + 16 * slot
 
+  @staticmethod
+  def _mark_collated(blk):
+    """`blk` is (about to be) collated again: its need list and the one of the block in front of it are stale."""
+    blk._gen = getattr(blk, "_gen", 0) + 1
+    blk._need_for = None
+
+  def _need_build(self, blks, stream):
+    """The need lists of consecutive collated blocks (blks[i] followed by blks[i + 1]) on `stream`, behind their
+    collation; blks[i]._need_for names the successor (and its collation count) the list was built for."""
+    n = len(blks)
+    n_items = int(blks[0].c.n_items)
+    if not self.need_lists or n < 2 or n_items > 64 * 2048:       # (RK_NEED_LIST_MAX_ITEMS: larger catalogues scan)
+      return
+    arr = (ctypes.POINTER(_lib.RkBlock) * n)(*[ctypes.pointer(blk.c) for blk in blks])
+    lists, counts = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+    for i, blk in enumerate(blks[:-1]):
+      buf = self._need.get(id(blk))
+      if buf is None:                       # (a block that is not one of the stepper's: no list)
+        return
+      lists[i], counts[i] = buf[0].data_ptr(), buf[1].data_ptr()
+    check(self.lib.rk_lazy_need_lists(arr, n, lists, counts, self._h(stream)), "rk_lazy_need_lists")
+    for i, blk in enumerate(blks[:-1]):
+      blk._need_for = (blks[i + 1], getattr(blks[i + 1], "_gen", 0))
+
+  def _need_of(self, blk, nxt):
+    """(list, count) pointers for the step of `blk` followed by `nxt`, or None (no list for this pair: the sweep scans)."""
+    tag = getattr(blk, "_need_for", None) if self.need_lists and nxt is not None else None
+    if tag is None or tag[0] is not nxt or tag[1] != getattr(nxt, "_gen", 0):
+      return None
+    buf = self._need[id(blk)]
+    return ptr(buf[0]), ptr(buf[1])
+
   def _collate(self, blk, off, stream, slot):
     d = self.dcsr
+    self._mark_collated(blk)
     blk.c.implicit = 1 if d.data is None else 0
     blk.S = self.B
     check(self.lib.rk_collate_at(ptr(d.indptr), ptr(d.indices), ptr(d.data), ptr(self.order), self.B,
@@ -141,15 +197,18 @@ class GraphStepper:
         blk.S = self.B
         arr[g] = ctypes.pointer(blk.c)
       cache[key] = arr
+    for blk in blks:
+      self._mark_collated(blk)
     args = (ptr(d.indptr), ptr(d.indices), ptr(d.data), ptr(self.order), self.B, 1 if self.ns else 0,
             self._cur(slot), off0, arr, n)
     if self.dp is None or getattr(self.dp, "local_sets", False):     # (per-rank item sets: no stamp exchange)
       check(self.lib.rk_collate_at_multi(*args, 0, self._h(stream)), "rk_collate_at_multi")
-      return
-    check(self.lib.rk_collate_at_multi(*args, 1, self._h(stream)), "rk_collate_at_multi")
-    with torch.cuda.stream(stream):
-      self.dp.union_marks_many([blk.mark for blk in blks])
-    check(self.lib.rk_collate_at_multi(*args, 2, self._h(stream)), "rk_collate_at_multi")
+    else:
+      check(self.lib.rk_collate_at_multi(*args, 1, self._h(stream)), "rk_collate_at_multi")
+      with torch.cuda.stream(stream):
+        self.dp.union_marks_many([blk.mark for blk in blks])
+      check(self.lib.rk_collate_at_multi(*args, 2, self._h(stream)), "rk_collate_at_multi")
+    self._need_build(blks, stream)
 
   def _step(self, slot, g, index=None, advance=None, next_blk=None):
     """Enqueue the training step of block [slot][g] (cursor offset g) on the main stream; index
@@ -160,7 +219,8 @@ class GraphStepper:
                   users=ptr(self.order_global), timed=index is not None, index=index, dw_stream=self.side,
                   next=None if advance is None else (self._cur(1 - slot), advance))
     if self.lazy:
-      replay["lazy"] = dict(names=self.lazy, pos_next=None if next_blk is None else ptr(next_blk.pos))
+      replay["lazy"] = dict(names=self.lazy, pos_next=None if next_blk is None else ptr(next_blk.pos),
+                            need=self._need_of(self.blocks[slot][g], next_blk))
     if self.c_step:
       self.eng._c_train_step(self.blocks[slot][g], 0, self.B, None, self.loss_buf,
                              None if self.dp is None else self.B * self.dp.world, self.main, replay=replay)
@@ -211,6 +271,10 @@ class GraphStepper:
           if self.c_step and ev is not None and self.eng._ws_dw_live:
             check(lib.rk_stream_wait_event(self._h(self.side), ev[1]), "rk_stream_wait_event")
           self._collate_many(self.blocks[1 - slot], n_steps, self.side, slot)
+          if self.need_lists and n_steps >= 2:
+            # (... and the list of this group's LAST step, which is followed by the first of those blocks: the early
+            # join in front of that step covers it)
+            self._need_build([self.blocks[slot][n_steps - 1], self.blocks[1 - slot][0]], self.side)
       elif g < G and lookahead:
         self._collate(self.blocks[1 - slot][g], n_steps + g, self.side, slot)
     check(lib.rk_event_record(self.ev_join, self._h(self.side)), "rk_event_record")

@@ -26,8 +26,36 @@ def _consts_table(lib, steps, lrs, wd, first_step, stride=1):
   return th.cuda()
 
 
+def _need_lists(lib, poss, N):
+  """rk_lazy_need_lists over consecutive pos maps (as the graph stepper calls it behind a collation): per step the
+  (list, count) device tensors, checked against numpy."""
+  from recoder_amd._lib import RkBlock, check, ptr
+  out = []
+  for t0 in range(0, len(poss) - 1, 7):                     # (at most RK_COLLATE_MULTI = 8 blocks per call)
+    chunk = poss[t0:t0 + 8]
+    n = len(chunk)
+    blks = [RkBlock() for _ in range(n)]
+    for b, pos in zip(blks, chunk):
+      b.n_items, b.n_chunks, b.pos = N, -(-N // 2048), ptr(pos)
+    arr = (ctypes.POINTER(RkBlock) * n)(*[ctypes.pointer(b) for b in blks])
+    lists = [torch.full((N,), -7, dtype=torch.int32, device="cuda") for _ in range(n - 1)]
+    counts = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(n - 1)]
+    lp = (ctypes.c_void_p * n)(*[x.data_ptr() for x in lists], None)
+    cp = (ctypes.c_void_p * n)(*[x.data_ptr() for x in counts], None)
+    check(lib.rk_lazy_need_lists(arr, n, lp, cp, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+          "rk_lazy_need_lists")
+    for i in range(n - 1):
+      want = np.nonzero((chunk[i].cpu().numpy() >= 0) | (chunk[i + 1].cpu().numpy() >= 0))[0]
+      c = int(counts[i].item())
+      assert c == len(want) and np.array_equal(lists[i][:c].cpu().numpy(), want)
+      assert bool((lists[i][c:] == -7).all())               # (nothing written past the count)
+      out.append((lists[i], counts[i]))
+  return out
+
+
+@pytest.mark.parametrize("use_list", [False, True])
 @pytest.mark.parametrize("wd,period,h", [(2e-5, 16, 200), (0.0, 4, 64), (1e-3, 7, 512), (2e-5, 1, 32)])
-def test_lazy_sweeps_equal_dense_sweeps_bit_for_bit(wd, period, h):
+def test_lazy_sweeps_equal_dense_sweeps_bit_for_bit(wd, period, h, use_list):
   from recoder_amd import _lib
   from recoder_amd._lib import RkAdamJob, RkReplay, check, ptr
   lib = _lib.load()
@@ -47,6 +75,7 @@ def test_lazy_sweeps_equal_dense_sweeps_bit_for_bit(wd, period, h):
     sets.append(items)
     poss.append(torch.from_numpy(pos).to(dev))
     grads.append(torch.randn(len(items), h, device=dev) * 0.1)
+  need = _need_lists(lib, poss, N) if use_list else None    # (need[t]: the rows of steps t and t + 1)
   p0 = torch.randn(N, h, device=dev) * 0.3
   m0 = torch.randn(N, h, device=dev) * 0.01
   v0 = torch.rand(N, h, device=dev) * 1e-4
@@ -76,6 +105,8 @@ def test_lazy_sweeps_equal_dense_sweeps_bit_for_bit(wd, period, h):
       if lazy:
         nxt = poss[t + 1] if t + 1 < n_steps and (t + 1) not in flush_at else None
         j.lazy_stamp, j.lazy_pos_next, j.lazy_period = ptr(stamp), ptr(nxt), period
+        if need is not None and nxt is not None:           # (the sweep takes its rows from the list + the chunk)
+          j.lazy_need_list, j.lazy_need_count = ptr(need[t][0]), ptr(need[t][1])
       lib.rk_replay_set(ctypes.byref(ctx))
       try:
         check(lib.rk_adam_multi(ctypes.byref(j), 1, None, 0, 1.0, None, stream), "rk_adam_multi")
@@ -162,12 +193,15 @@ def test_training_with_lazy_adam_is_bitwise_the_dense_sweep(case, monkeypatch, t
     # (22 whole batches + a ragged one per epoch, groups of 8: the mark at 16 ends a run() on a whole replayed group
     # WITH look-ahead -- rows stay behind, rk_adam_lazy_flush brings them up; the one at 30 cuts a group)
     rec.step_marks = {16: lambda: seen.append(16) or False, 30: lambda: seen.append(30) or False}
-    prefix = str(tmp_path / ("lazy%d" % period))
+    prefix = str(tmp_path / ("lazy%s" % str(period).replace(",", "_")))
     rec.train(RecommendationDataset(csr), val_dataset=RecommendationDataset(val, val), num_epochs=3, eval_freq=1,
               model_checkpoint_prefix=prefix, checkpoint_freq=3, **kw)
     assert seen == [16, 30]
     gs = rec._graph_stepper
+    lists = str(period).endswith(",list")
+    period = int(str(period).split(",")[0])
     assert bool(gs.lazy) == (period > 0)
+    assert not lists or (gs.need_lists and any(getattr(b, "_need_for", None) for b in gs.blocks[0] + gs.blocks[1]))
     if period > 0:
       assert gs.lazy_flushes >= 1                    # (a run() that ended on a whole group with look-ahead)
       for n in gs.lazy:                              # nothing is left behind
@@ -189,7 +223,8 @@ def test_training_with_lazy_adam_is_bitwise_the_dense_sweep(case, monkeypatch, t
   d = run(0)
   z = run(16)
   s = run(3)                                         # (a short period: the round-robin chunk wraps many times)
-  for o in (z, s):
+  l = run("16,list")                                 # (the sweeps take their rows from rk_lazy_need_lists' lists)
+  for o in (z, s, l):
     assert np.array_equal(d[0], o[0]), np.abs(d[0] - o[0]).max()
     assert d[1] == o[1]
     for k in d[2]:

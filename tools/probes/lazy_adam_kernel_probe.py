@@ -36,6 +36,19 @@ stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 junk = torch.empty(1 << 28, dtype=torch.float32, device=dev)
 
 
+import os
+use_list = os.environ.get("PROBE_LIST") == "1"
+lists = []
+for t in range(n_steps):
+  c = t % period
+  lo, hi = c * N // period, (c + 1) * N // period
+  need = (poss[t] >= 0) | (poss[t + 1] >= 0)
+  need[lo:hi] = False
+  idx = torch.nonzero(need).flatten().to(torch.int32)
+  idx = idx[torch.randperm(idx.numel(), device=dev)] if os.environ.get("PROBE_LIST_SHUFFLE") == "1" else idx
+  lists.append((idx.contiguous(), torch.tensor([idx.numel()], dtype=torch.int32, device=dev)))
+
+
 def run(lazy, cold):
   tabs = [[torch.randn(N, h, device=dev) * 0.1, torch.zeros(N, h, device=dev), torch.full((N, h), 1e-4, device=dev),
            torch.zeros(N, dtype=torch.int32, device=dev)] for _ in range(2)]
@@ -54,6 +67,8 @@ def run(lazy, cold):
       j.n_rows, j.h, j.g, j.g_parts, j.pos = N, h, ptr(grads[t]), 1, ptr(poss[t])
       if lazy:
         j.lazy_stamp, j.lazy_pos_next, j.lazy_period = ptr(st), ptr(poss[t + 1]), period
+        if use_list:            # (PROBE_LIST=1: the need-set outside the chunk as a list, built here with torch)
+          j.lazy_need_list, j.lazy_need_count = ptr(lists[t][0]), ptr(lists[t][1])
     if cold:
       junk.fill_(float(t))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
