@@ -937,6 +937,8 @@ def main():
                                            "timed group runs inside it (one per group, as in steady state)")
                                           if T.get("precollated") else "inside the timed region, in front of step 0",
                  "lazy_adam": ({"period": lazy_L, "avg_rows_swept_per_table": LAZY_ROWS, "of_rows": n_items,
+                                "need_lists": bool(getattr(getattr(rec, "_graph_stepper", None), "need_lists", False)),
+                                "block_item_cover": getattr(getattr(rec, "_graph_stepper", None), "need_cover", None),
                                 "note": "dense Adam's rows without a gradient that the next step does not read are caught "
                                         "up later by replaying their missed steps, bit for bit (csrc/optim.hip "
                                         "table_sweep_lazy; RK_ADAM_LAZY=0: every row every step); the last step of "
