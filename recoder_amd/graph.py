@@ -101,7 +101,10 @@ class GraphStepper:
     self.need_lists = bool(self.lazy) and self.multi and self.G <= self.MULTI_MAX and mode != "scan"
     if self.need_lists and mode == "auto":
       n_items = int(self.blocks[0][0].c.n_items)
-      freq = torch.bincount(dcsr.indices.long(), minlength=n_items).double() / max(1, int(n_users))
+      freq = torch.zeros(n_items, dtype=torch.float64, device=device)
+      for lo in range(0, int(dcsr.indices.numel()), 1 << 26):          # (in pieces: bincount wants int64 ids)
+        freq += torch.bincount(dcsr.indices[lo:lo + (1 << 26)].long(), minlength=n_items)[:n_items]
+      freq /= max(1, int(n_users))
       rows = self.B * (1 if self.dp is None else self.dp.world)
       self.need_cover = float((1.0 - (1.0 - freq).clamp(0.0, 1.0).pow(rows)).sum()) / max(1, n_items)
       self.need_lists = self.need_cover < 0.3             # (+ RK_NEED_LIST_MAX_ITEMS, below)

@@ -3,7 +3,7 @@
 # every committed number of a round in one call: tools/profile_round.sh (C2 kernel stats, PMC traffic,
 # SQ counters, bench lines), the other configurations' bench lines and kernel stats, the bf16 and
 # one-rank RCCL data points, the 20-step timeline -> gpurun_out/<tag>/
-tag=${1:-r06f}
+tag=${1:-r06g}
 export MASTER_ADDR=127.0.0.1 MASTER_PORT=29655 TMPDIR=/tmp
 timeout 900 bash tools/profile_round.sh $tag > gpurun_out/${tag}_console.txt 2>&1
 o=gpurun_out/$tag
