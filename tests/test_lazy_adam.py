@@ -249,3 +249,33 @@ def test_lazy_adam_is_off_where_it_does_not_apply(monkeypatch):
     rec = Recoder(model=mk(), use_cuda=True, optimizer_type="adam", loss="mse")
     rec.train(RecommendationDataset(csr), batch_size=64, lr=1e-3, weight_decay=0.0, num_epochs=1, negative_sampling=True)
     assert rec._graph_stepper.lazy == []
+
+
+def test_need_lists_follow_the_matrix(monkeypatch):
+  """The sweeps' need lists (rk_lazy_need_lists) are built where a block's expected item set covers less than 30 %
+  of the catalogue (graph.GraphStepper: most rows would be skipped), not where most rows are swept anyway;
+  RK_ADAM_LAZY=<period>,list / ,scan force either."""
+  from recoder_amd.data import RecommendationDataset
+  from recoder_amd.model import Recoder
+  from recoder_amd.nn import DynamicAutoencoder
+
+  def stepper(csr, batch, env=None):
+    if env is None:
+      monkeypatch.delenv("RK_ADAM_LAZY", raising=False)
+    else:
+      monkeypatch.setenv("RK_ADAM_LAZY", env)
+    torch.manual_seed(3)
+    rec = Recoder(model=DynamicAutoencoder([32], activation_type="tanh", sparse=False), use_cuda=True,
+                  optimizer_type="adam", loss="mse")
+    rec.train(RecommendationDataset(csr), batch_size=batch, lr=1e-3, weight_decay=0.0, num_epochs=1, negative_sampling=True)
+    return rec._graph_stepper
+
+  wide = synth_csr(1200, 6000, 8, seed=75)       # 16 users x 8 items of 6 000: a block holds ~2 % of the catalogue
+  gs = stepper(wide, 16)
+  assert gs.lazy and gs.need_lists and gs.need_cover < 0.1
+  assert any(getattr(b, "_need_for", None) for b in gs.blocks[0] + gs.blocks[1])
+  narrow = synth_csr(1200, 300, 12, seed=76)     # 64 users x 12 items of 300: most of the catalogue in every block
+  gs = stepper(narrow, 64)
+  assert gs.lazy and not gs.need_lists and gs.need_cover > 0.5
+  assert not stepper(wide, 16, "16,scan").need_lists
+  assert stepper(narrow, 64, "16,list").need_lists
